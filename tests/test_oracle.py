@@ -1,0 +1,139 @@
+"""CPU tests of the oracle itself: the TF-path restatement against the golden
+fixtures produced from the MATLAB-path transliteration (the ground truth the
+reference's tests use), and both against an independent quadrature.
+
+Mirrors tests/test_predictions.py, test_sparse_predictions.py, test_cascade.py,
+test_controllers.py, test_rewards.py of the reference (rtol 1e-4 there; the
+oracle must agree far tighter than the 1e-5 the product is held to)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import matlab_path as mp
+from oracle import quadrature as qd
+from oracle import tf_path as tp
+
+RTOL = 1e-8
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("name,rtol", [("predictions.npz", 1e-8), ("predictions_lownoise.npz", 1e-6)])
+def test_predictions_vs_gp0(golden_dir, name, rtol):
+    g = _load(golden_dir, name)
+    iK, beta = tp.calculate_factorizations(g["X"], g["Y"], g["lengthscales"], g["variance"], g["noise"])
+    for fn in (tp.predict_given_factorizations, tp.predict_given_factorizations_pairs):
+        M, S, V = fn(g["X"], g["lengthscales"], g["variance"], g["m"], g["s"], iK, beta)
+        assert M.shape == g["M"].shape and S.shape == g["S"].shape and V.shape == g["V"].shape
+        np.testing.assert_allclose(M, g["M"], rtol=rtol)
+        np.testing.assert_allclose(S, g["S"], rtol=rtol)
+        np.testing.assert_allclose(V, g["V"], rtol=rtol)
+
+
+def test_golden_is_reproducible(golden_dir):
+    g = _load(golden_dir, "predictions.npz")
+    M, S, V = mp.gp0(g["X"], g["Y"], g["hyp"], g["m"].T, g["s"])
+    np.testing.assert_allclose(M.T, g["M"], rtol=1e-12)
+    np.testing.assert_allclose(S, g["S"], rtol=1e-10)
+
+
+def test_sparse_vs_gp1(golden_dir):
+    g = _load(golden_dir, "sparse_predictions.npz")
+    iK, beta = tp.fitc_factorizations(g["X"], g["Y"], g["Z"], g["lengthscales"], g["variance"], g["noise"])
+    M, S, V = tp.predict_given_factorizations(g["Z"], g["lengthscales"], g["variance"], g["m"], g["s"], iK, beta)
+    np.testing.assert_allclose(M, g["M"], rtol=1e-7)
+    np.testing.assert_allclose(S, g["S"], rtol=1e-7)
+    np.testing.assert_allclose(V, g["V"], rtol=1e-7)
+
+
+def test_cascade_vs_pred(golden_dir):
+    g = _load(golden_dir, "cascade.npz")
+    model = tp.Model(g["X"], g["Y"], g["lengthscales"], g["variance"], g["noise"])
+    ctrl = lambda m, s: tp.linear_controller(m, s, g["W"], g["b"], g["max_action"])
+    rew = lambda m, s: tp.exponential_reward(m, s)
+    H = int(g["horizon"])
+    for cache in (False, True):
+        M, S, R = tp.predict(model, ctrl, rew, g["m"], g["s"], H, cache=cache)
+        np.testing.assert_allclose(M[0], g["M_traj"][:, -1], rtol=1e-8)
+        np.testing.assert_allclose(S, g["S_traj"][:, :, -1], rtol=1e-7)
+    assert R.shape == (1, 1) and 0 < R[0, 0] < H
+    # n = 0 returns the inputs and zero reward (Appendix A.10)
+    M0, S0, R0 = tp.predict(model, ctrl, rew, g["m"], g["s"], 0)
+    assert np.array_equal(M0, g["m"]) and np.array_equal(S0, g["s"]) and R0[0, 0] == 0
+
+
+def test_rbf_vs_gp2(golden_dir):
+    g = _load(golden_dir, "rbf_controller.npz")
+    M, S, V = tp.rbf_controller(g["m"], g["s"], g["X"], g["Y"], g["lengthscales"], squash=False)
+    np.testing.assert_allclose(M, g["M"], rtol=1e-8)
+    np.testing.assert_allclose(S, g["S"], rtol=1e-7)
+    np.testing.assert_allclose(V, g["V"], rtol=1e-8)
+
+
+def test_linear_and_squash(golden_dir):
+    g = _load(golden_dir, "linear_controller.npz")
+    M, S, V = tp.linear_controller(g["m"], g["s"], g["W"], g["b"], squash=False)
+    np.testing.assert_allclose(M, g["M"], rtol=1e-12)
+    np.testing.assert_allclose(S, g["S"], rtol=1e-12)
+    np.testing.assert_allclose(V, g["V"], rtol=1e-12)
+    g = _load(golden_dir, "squash.npz")
+    M, S, V = tp.squash_sin(g["m"], g["s"], float(g["e"]))
+    np.testing.assert_allclose(M, g["M"], rtol=1e-12)
+    np.testing.assert_allclose(S, g["S"], rtol=1e-12)
+    np.testing.assert_allclose(V, g["V"], rtol=1e-12)
+
+
+def test_reward(golden_dir):
+    g = _load(golden_dir, "reward.npz")
+    mu, sr = tp.exponential_reward(g["m"], g["s"])
+    np.testing.assert_allclose(mu[0, 0], g["muR"], rtol=1e-12)
+    np.testing.assert_allclose(sr[0, 0], g["sR"], rtol=1e-10)
+    mu, sr = tp.exponential_reward(g["m"], g["s"], g["W2"], g["t2"])
+    np.testing.assert_allclose(mu[0, 0], g["muR2"], rtol=1e-12)
+    np.testing.assert_allclose(sr[0, 0], g["sR2"], rtol=1e-10)
+    # linear / combined rewards (pilco/rewards.py:53-81; untested in the reference)
+    W = np.array([0.5, -1.0])
+    mu_l, s_l = tp.linear_reward(g["m"], g["s"], W)
+    np.testing.assert_allclose(mu_l, g["m"] @ W[:, None])
+    mu_c, s_c = tp.combined_rewards(g["m"], g["s"], [lambda m, s: tp.linear_reward(m, s, W),
+                                                     lambda m, s: tp.exponential_reward(m, s)], [2.0, 0.5])
+    np.testing.assert_allclose(mu_c, 2.0 * mu_l + 0.5 * tp.exponential_reward(g["m"], g["s"])[0])
+
+
+def test_quadrature_pins_the_integrals():
+    rs = np.random.RandomState(5)
+    d = 2
+    X = rs.rand(30, d) * 2
+    Y = np.sin(X) @ rs.rand(d, 2)
+    ls = np.array([[1.0, 0.8], [0.6, 1.2]])
+    var = np.array([1.1, 0.7])
+    nz = np.array([1e-2, 2e-2])
+    iK, beta = tp.calculate_factorizations(X, Y, ls, var, nz)
+    m = np.array([[0.8, 1.1]])
+    s = np.array([[0.3, 0.1], [0.1, 0.2]])
+    Mq, Sq, Vq = qd.gp_moments_quadrature(X, ls, var, m, s, iK, beta, order=60)
+    M, S, V = tp.predict_given_factorizations(X, ls, var, m, s, iK, beta)
+    np.testing.assert_allclose(M, Mq, rtol=1e-10)
+    np.testing.assert_allclose(S, Sq, rtol=1e-9)
+    np.testing.assert_allclose(V, Vq, rtol=1e-10)
+    Mm, Sm, Vm = mp.gp0(X, Y, mp.hyp_from(ls, var, nz), m.T, s)
+    np.testing.assert_allclose(Mm.T, Mq, rtol=1e-10)
+    np.testing.assert_allclose(Sm, Sq, rtol=1e-9)
+    np.testing.assert_allclose(Vm, Vq, rtol=1e-10)
+
+
+def test_zero_covariance_is_safe():
+    """PILCO.compute_action evaluates at s = 0 (pilco.py:115-116, Appendix A.8)."""
+    rs = np.random.RandomState(2)
+    X = rs.rand(20, 2)
+    Y = np.sin(X) @ rs.rand(2, 1)
+    ls = np.array([[1.0, 0.7]])
+    iK, beta = tp.calculate_factorizations(X, Y, ls, np.array([1.0]), np.array([1e-3]))
+    m = np.array([[0.3, 0.4]])
+    M, S, V = tp.predict_given_factorizations(X, ls, np.array([1.0]), m, np.zeros((2, 2)), iK, beta)
+    kx = tp.se_ard_K(m, X, ls, np.array([1.0]))[0, 0]
+    np.testing.assert_allclose(M[0, 0], kx @ beta[0], rtol=1e-12)
+    np.testing.assert_allclose(S[0, 0], 1.0 - kx @ iK[0] @ kx, rtol=1e-7)
