@@ -1,0 +1,159 @@
+/*
+ * pilco_hip.h -- C ABI of libpilco_hip.so, the MI355X (gfx950) implementation of
+ * the PILCO moment-matching rollout and GP-factorisation hot path.
+ *
+ * The reference (nrontsis/PILCO) has no FFI layer: its boundary is the Python
+ * method surface of pilco.models.MGPR / SMGPR / PILCO.  Each entry point below
+ * names the reference method (file:line under /root/reference) whose arithmetic
+ * it replaces; pilco_amd/ (Python, ctypes) re-creates that method surface on top
+ * of this header, and INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions: every matrix is row-major float64 in caller-owned HOST memory
+ * unless a parameter is documented as a device pointer; the library owns all
+ * device memory.  A context is bound to one GPU and must be used from one host
+ * thread at a time.  Every function returns a pilco_status (0 = OK) and never
+ * aborts; pilco_last_error() gives the message for the last failure.
+ */
+#ifndef PILCO_HIP_H
+#define PILCO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PILCO_HIP_ABI_VERSION 1
+
+typedef struct pilco_ctx pilco_ctx;
+
+typedef enum pilco_status {
+    PILCO_OK = 0,
+    PILCO_E_SHAPE = 1,   /* inconsistent sizes / null pointer */
+    PILCO_E_NOT_PD = 2,  /* Cholesky failed: the reference raises InvalidArgumentError (tests/test_cascade.py:22) */
+    PILCO_E_HIP = 3,     /* HIP runtime error */
+    PILCO_E_RCCL = 4,    /* RCCL error */
+    PILCO_E_STATE = 5,   /* call order violated (e.g. predict before set_data) */
+    PILCO_E_ALLOC = 6
+} pilco_status;
+
+/* ------------------------------------------------------------------ context */
+int pilco_abi_version(void);
+/* device: HIP device ordinal.  One context per process per GPU. */
+int pilco_ctx_create(int device, pilco_ctx** out);
+int pilco_ctx_destroy(pilco_ctx* ctx);
+const char* pilco_last_error(const pilco_ctx* ctx);
+/* index of the output whose Gram matrix was not positive definite (-1 if none) */
+int pilco_last_not_pd_output(const pilco_ctx* ctx);
+/* 0 = MFMA pair kernel (default), 1 = plain-VALU pair kernel (same results to rounding) */
+int pilco_set_pair_kernel(pilco_ctx* ctx, int variant);
+/* checks the f64 MFMA fragment layout assumptions on the device; 0 = OK */
+int pilco_selftest(pilco_ctx* ctx);
+
+/* ------------------------------------------------------------------ GP model
+ * Slot 0 is the dynamics model (MGPR / SMGPR); slot 1 is the RBF policy
+ * (RbfController is an MGPR subclass, pilco/controllers.py:80-129).            */
+#define PILCO_SLOT_DYNAMICS 0
+#define PILCO_SLOT_POLICY 1
+
+/* MGPR.__init__/set_data (pilco/models/mgpr.py:18-45): X (N,D), Y (N,E).
+ * N may change between calls; any cached factorisation is invalidated. */
+int pilco_gp_set_data(pilco_ctx* ctx, int slot, const double* X, const double* Y, int N, int D, int E);
+/* kernel.lengthscales (E,D), kernel.variance (E), likelihood.variance (E)
+ * (properties at pilco/models/mgpr.py:170-186). Invalidates the factorisation. */
+int pilco_gp_set_hyp(pilco_ctx* ctx, int slot, const double* lengthscales, const double* variance, const double* noise);
+/* SMGPR inducing inputs Z (M,D) of model 0, used for every output
+ * (pilco/models/smgpr.py:20-22,47-52).  M = 0 switches back to the exact GP. */
+int pilco_gp_set_inducing(pilco_ctx* ctx, int slot, const double* Z, int M);
+/* MGPR.K(X1, X2) (pilco/models/mgpr.py:154-157): out (E,N1,N2). X2 may be NULL (= X1). */
+int pilco_gp_gram(pilco_ctx* ctx, int slot, const double* X1, int N1, const double* X2, int N2, double* out);
+/* MGPR.calculate_factorizations (pilco/models/mgpr.py:81-89) or, when inducing
+ * inputs are set, SMGPR.calculate_factorizations (pilco/models/smgpr.py:24-45).
+ * Result stays on the device and is cached until data / hyper-parameters change. */
+int pilco_gp_factorize(pilco_ctx* ctx, int slot);
+/* number of points the moment-matching runs over: N (exact) or M (sparse) */
+int pilco_gp_num_points(const pilco_ctx* ctx, int slot);
+/* download iK (E,n,n) and beta (E,n); either may be NULL */
+int pilco_gp_get_factors(pilco_ctx* ctx, int slot, double* iK, double* beta);
+/* upload caller-supplied factors for predict_given_factorizations(m,s,iK,beta)
+ * (pilco/models/mgpr.py:91); iK may be NULL meaning all-zero (RbfController,
+ * pilco/controllers.py:116). */
+int pilco_gp_set_factors(pilco_ctx* ctx, int slot, const double* iK, const double* beta);
+/* MGPR.predict_given_factorizations with the factors held on the device
+ * (pilco/models/mgpr.py:91-149): m (1,D), s (D,D) -> M (1,E), S (E,E), V (D,E).
+ * pilco_gp_predict = predict_on_noisy_inputs (mgpr.py:77-79) with the
+ * factorisation cached instead of recomputed. */
+int pilco_gp_predict(pilco_ctx* ctx, int slot, const double* m, const double* s, double* M, double* S, double* V);
+
+/* ------------------------------------------------------------------ rollout */
+typedef enum pilco_policy_kind {
+    PILCO_POLICY_NONE = 0,   /* control_dim == 0 */
+    PILCO_POLICY_LINEAR = 1, /* LinearController (pilco/controllers.py:39-63) */
+    PILCO_POLICY_RBF = 2     /* RbfController (pilco/controllers.py:80-129); GP in PILCO_SLOT_POLICY */
+} pilco_policy_kind;
+
+typedef struct pilco_policy {
+    int kind;
+    int state_dim;            /* E of the dynamics model */
+    int control_dim;          /* D - E */
+    const double* W;          /* linear: (control_dim, state_dim) */
+    const double* b;          /* linear: (1, control_dim) */
+    const double* max_action; /* (control_dim) scale of squash_sin (controllers.py:13-36); NULL = ones */
+    int squash;               /* 1 = apply squash_sin (the reference always does inside propagate) */
+} pilco_policy;
+
+typedef enum pilco_reward_kind {
+    PILCO_REWARD_EXPONENTIAL = 1, /* ExponentialReward (pilco/rewards.py:7-51) */
+    PILCO_REWARD_LINEAR = 2       /* LinearReward (pilco/rewards.py:53-61) */
+} pilco_reward_kind;
+
+typedef struct pilco_reward_term {
+    int kind;
+    double coef;     /* CombinedRewards coefficient (pilco/rewards.py:64-81); 1 for a single reward */
+    const double* W; /* exponential: (E,E); linear: (E) */
+    const double* t; /* exponential: (1,E) target; NULL = zeros */
+} pilco_reward_term;
+
+/* PILCO.predict (pilco/models/pilco.py:118-136) = H x [reward(m,s); propagate
+ * (pilco.py:138-153)].  m0 (1,E), S0 (E,E) -> mH (1,E), SH (E,E), reward (sum of
+ * the mean rewards of the PRE-propagation states).  traj (optional, may be
+ * NULL): (H+1) x (E + E*E) doubles, the state after every step.
+ * The factorisation of slot 0 (and slot 1 for an RBF policy) must be current. */
+int pilco_rollout(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                  const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj);
+/* PILCO.propagate (pilco/models/pilco.py:138-153): one step, no reward. */
+int pilco_propagate(pilco_ctx* ctx, const pilco_policy* policy, const double* m_x, const double* s_x, double* M_x, double* S_x);
+/* controller.compute_action(m, s, squash) -> M (1,U), S (U,U), V (E,U)
+ * (pilco/controllers.py:46-58,108-121) and reward.compute_reward(m,s) ->
+ * muR, sR (pilco/rewards.py:19-51,58-61,73-81), evaluated on the device. */
+int pilco_policy_action(pilco_ctx* ctx, const pilco_policy* policy, const double* m, const double* s, double* M, double* S, double* V);
+int pilco_reward_eval(pilco_ctx* ctx, const pilco_reward_term* rewards, int n_rewards, int state_dim, const double* m, const double* s, double* muR, double* sR);
+
+/* ------------------------------------------------------------------ timing / introspection */
+/* Time `reps` back-to-back rollouts with HIP events on the library's stream.
+ * ms_total: wall time of the timed region; ms_pair: summed duration of the
+ * pair kernel launches inside it (its own event pairs); n_pair_launches: count. */
+int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                        const double* m0, const double* S0, int H, int reps, double* mH, double* SH, double* reward,
+                        float* ms_total, float* ms_pair, int* n_pair_launches);
+/* Time `reps` factorisations (invalidating the cache each time): ms per factorisation. */
+int pilco_factorize_timed(pilco_ctx* ctx, int slot, int reps, float* ms_each);
+
+/* ------------------------------------------------------------------ multi-GPU
+ * One process per GPU.  The P = E(E+1)/2 output pairs (and with them the
+ * outputs' factorisations) are dealt round-robin over the ranks; one
+ * ncclAllGather (RCCL over xGMI) per horizon step reassembles (M, S, V).
+ * id: 128 opaque bytes produced on rank 0 and broadcast by the host launcher. */
+#define PILCO_COMM_ID_BYTES 128
+int pilco_comm_unique_id(void* id128);
+int pilco_comm_init(pilco_ctx* ctx, const void* id128, int rank, int nranks);
+/* sharding without a communicator: the caller moves the bytes (host fake
+ * all-gather for tests; gloo fallback).  Ownership map: pair p -> rank. */
+int pilco_shard_set(pilco_ctx* ctx, int rank, int nranks);
+int pilco_shard_owner_of_pair(const pilco_ctx* ctx, int pair_index);
+int pilco_comm_rank(const pilco_ctx* ctx);
+int pilco_comm_size(const pilco_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PILCO_HIP_H */

@@ -1,0 +1,349 @@
+"""ctypes binding of libpilco_hip.so (include/pilco_hip.h).
+
+No PyTorch, no TensorFlow: plain ctypes + NumPy.  The library is built in-tree by
+``__graft_entry__.build()`` / ``make -C pilco_amd/csrc``.  There is NO CPU
+fallback: if the library or a GPU is missing every compute call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpilco_hip.so")
+
+PILCO_OK = 0
+STATUS_NAMES = {1: "PILCO_E_SHAPE", 2: "PILCO_E_NOT_PD", 3: "PILCO_E_HIP", 4: "PILCO_E_RCCL",
+                5: "PILCO_E_STATE", 6: "PILCO_E_ALLOC"}
+SLOT_DYNAMICS, SLOT_POLICY = 0, 1
+POLICY_NONE, POLICY_LINEAR, POLICY_RBF = 0, 1, 2
+REWARD_EXPONENTIAL, REWARD_LINEAR = 1, 2
+COMM_ID_BYTES = 128
+
+_dp = C.POINTER(C.c_double)
+
+
+class PilcoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{STATUS_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class NotPositiveDefiniteError(PilcoError):
+    """The reference raises tf.errors.InvalidArgumentError here (tests/test_cascade.py:22)."""
+
+
+class PolicyStruct(C.Structure):
+    _fields_ = [("kind", C.c_int), ("state_dim", C.c_int), ("control_dim", C.c_int),
+                ("W", _dp), ("b", _dp), ("max_action", _dp), ("squash", C.c_int)]
+
+
+class RewardTerm(C.Structure):
+    _fields_ = [("kind", C.c_int), ("coef", C.c_double), ("W", _dp), ("t", _dp)]
+
+
+# every symbol include/pilco_hip.h declares: name -> (restype, argtypes)
+_vp = C.c_void_p
+SIGNATURES = {
+    "pilco_abi_version": (C.c_int, []),
+    "pilco_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "pilco_ctx_destroy": (C.c_int, [_vp]),
+    "pilco_last_error": (C.c_char_p, [_vp]),
+    "pilco_last_not_pd_output": (C.c_int, [_vp]),
+    "pilco_set_pair_kernel": (C.c_int, [_vp, C.c_int]),
+    "pilco_selftest": (C.c_int, [_vp]),
+    "pilco_gp_set_data": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int]),
+    "pilco_gp_set_hyp": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
+    "pilco_gp_set_inducing": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
+    "pilco_gp_gram": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp]),
+    "pilco_gp_factorize": (C.c_int, [_vp, C.c_int]),
+    "pilco_gp_num_points": (C.c_int, [_vp, C.c_int]),
+    "pilco_gp_get_factors": (C.c_int, [_vp, C.c_int, _dp, _dp]),
+    "pilco_gp_set_factors": (C.c_int, [_vp, C.c_int, _dp, _dp]),
+    "pilco_gp_predict": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "pilco_rollout": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
+                                _dp, _dp, _dp, _dp]),
+    "pilco_propagate": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp]),
+    "pilco_policy_action": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp, _dp]),
+    "pilco_reward_eval": (C.c_int, [_vp, C.POINTER(RewardTerm), C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
+    "pilco_rollout_timed": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp,
+                                      C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "pilco_factorize_timed": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "pilco_comm_unique_id": (C.c_int, [_vp]),
+    "pilco_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "pilco_shard_set": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "pilco_shard_owner_of_pair": (C.c_int, [_vp, C.c_int]),
+    "pilco_comm_rank": (C.c_int, [_vp]),
+    "pilco_comm_size": (C.c_int, [_vp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load libpilco_hip.so and bind every declared symbol.  Raises if the HIP
+    extension has not been built -- there is deliberately no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C pilco_amd/csrc). "
+            "pilco_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+class Context:
+    """One GPU context (pilco_ctx).  All arrays in/out are host NumPy float64."""
+
+    def __init__(self, device=None):
+        self.lib = load_library()
+        if device is None:
+            device = int(os.environ.get("PILCO_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        h = _vp()
+        rc = self.lib.pilco_ctx_create(int(device), C.byref(h))
+        if rc != PILCO_OK or not h:
+            raise PilcoError(rc, f"cannot create a HIP context on device {device} "
+                                 "(no MI355X visible?). pilco_amd has no CPU fallback.")
+        self.h = h
+        self.device = int(device)
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pilco_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != PILCO_OK:
+            msg = self.lib.pilco_last_error(self.h).decode("utf-8", "replace")
+            if rc == 2:
+                raise NotPositiveDefiniteError(rc, msg)
+            raise PilcoError(rc, msg)
+
+    # ---- GP model
+    def selftest(self):
+        self._chk(self.lib.pilco_selftest(self.h))
+
+    def set_pair_kernel(self, variant):
+        self._chk(self.lib.pilco_set_pair_kernel(self.h, int(variant)))
+
+    def gp_set_data(self, slot, X, Y):
+        X = _f64(X)
+        Y = _f64(Y)
+        if X.ndim != 2 or Y.ndim != 2 or X.shape[0] != Y.shape[0]:
+            raise ValueError("data must be (X (N,D), Y (N,E))")
+        self._chk(self.lib.pilco_gp_set_data(self.h, slot, _ptr(X), _ptr(Y), X.shape[0], X.shape[1], Y.shape[1]))
+
+    def gp_set_hyp(self, slot, lengthscales, variance, noise):
+        ls, var, nz = _f64(lengthscales), _f64(variance).reshape(-1), _f64(noise).reshape(-1)
+        self._chk(self.lib.pilco_gp_set_hyp(self.h, slot, _ptr(ls), _ptr(var), _ptr(nz)))
+
+    def gp_set_inducing(self, slot, Z):
+        if Z is None:
+            self._chk(self.lib.pilco_gp_set_inducing(self.h, slot, None, 0))
+        else:
+            Z = _f64(Z)
+            self._chk(self.lib.pilco_gp_set_inducing(self.h, slot, _ptr(Z), Z.shape[0]))
+
+    def gp_gram(self, slot, X1, X2, E):
+        X1 = _f64(X1)
+        X2a = None if X2 is None else _f64(X2)
+        n2 = X1.shape[0] if X2a is None else X2a.shape[0]
+        out = np.empty((E, X1.shape[0], n2))
+        self._chk(self.lib.pilco_gp_gram(self.h, slot, _ptr(X1), X1.shape[0], _ptr(X2a), n2, _ptr(out)))
+        return out
+
+    def gp_factorize(self, slot):
+        self._chk(self.lib.pilco_gp_factorize(self.h, slot))
+
+    def gp_num_points(self, slot):
+        return self.lib.pilco_gp_num_points(self.h, slot)
+
+    def gp_get_factors(self, slot, E, want_iK=True):
+        n = self.gp_num_points(slot)
+        iK = np.empty((E, n, n)) if want_iK else None
+        beta = np.empty((E, n))
+        self._chk(self.lib.pilco_gp_get_factors(self.h, slot, _ptr(iK), _ptr(beta)))
+        return iK, beta
+
+    def gp_set_factors(self, slot, iK, beta):
+        iKa = None if iK is None else _f64(iK)
+        beta = _f64(beta)
+        self._chk(self.lib.pilco_gp_set_factors(self.h, slot, _ptr(iKa), _ptr(beta)))
+
+    def gp_predict(self, slot, m, s, D, E):
+        m = _f64(m, (D,))
+        s = _f64(s, (D, D))
+        M = np.empty((1, E))
+        S = np.empty((E, E))
+        V = np.empty((D, E))
+        self._chk(self.lib.pilco_gp_predict(self.h, slot, _ptr(m), _ptr(s), _ptr(M), _ptr(S), _ptr(V)))
+        return M, S, V
+
+    # ---- policy / reward marshalling
+    def _policy(self, spec):
+        """spec: dict(kind, state_dim, control_dim, W, b, max_action, squash)."""
+        keep = []
+        p = PolicyStruct()
+        p.kind = spec["kind"]
+        p.state_dim = spec["state_dim"]
+        p.control_dim = spec["control_dim"]
+        p.squash = 1 if spec.get("squash", True) else 0
+        U, E = p.control_dim, p.state_dim
+        if spec["kind"] == POLICY_LINEAR:
+            W = _f64(spec["W"], (U, E))
+            b = _f64(spec["b"], (U,))
+            keep += [W, b]
+            p.W, p.b = _ptr(W), _ptr(b)
+        ma = spec.get("max_action", None)
+        if ma is not None and U > 0:
+            ma = _f64(np.broadcast_to(np.asarray(ma, np.float64).reshape(-1) if np.ndim(ma) else np.float64(ma), (U,)))
+            keep.append(ma)
+            p.max_action = _ptr(ma)
+        return p, keep
+
+    def _rewards(self, terms, E):
+        """terms: list of dict(kind, coef, W, t)."""
+        arr = (RewardTerm * max(len(terms), 1))()
+        keep = []
+        for i, t in enumerate(terms):
+            arr[i].kind = t["kind"]
+            arr[i].coef = float(t.get("coef", 1.0))
+            if t["kind"] == REWARD_EXPONENTIAL:
+                W = _f64(t["W"], (E, E))
+                tg = _f64(t["t"], (E,)) if t.get("t") is not None else None
+                keep += [W, tg]
+                arr[i].W, arr[i].t = _ptr(W), _ptr(tg)
+            else:
+                W = _f64(t["W"], (E,))
+                keep.append(W)
+                arr[i].W = _ptr(W)
+        return arr, keep
+
+    def rollout(self, policy, rewards, m0, S0, H, want_traj=False):
+        E = policy["state_dim"]
+        p, k1 = self._policy(policy)
+        r, k2 = self._rewards(rewards, E)
+        m0 = _f64(m0, (E,))
+        S0 = _f64(S0, (E, E))
+        mH = np.empty((1, E))
+        SH = np.empty((E, E))
+        rew = np.zeros((1, 1))
+        traj = np.empty((H + 1, E + E * E)) if want_traj else None
+        self._chk(self.lib.pilco_rollout(self.h, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H),
+                                         _ptr(mH), _ptr(SH), _ptr(rew), _ptr(traj)))
+        if want_traj:
+            return mH, SH, rew, traj
+        return mH, SH, rew
+
+    def propagate(self, policy, m_x, s_x):
+        E = policy["state_dim"]
+        p, k1 = self._policy(policy)
+        m_x = _f64(m_x, (E,))
+        s_x = _f64(s_x, (E, E))
+        M = np.empty((1, E))
+        S = np.empty((E, E))
+        self._chk(self.lib.pilco_propagate(self.h, C.byref(p), _ptr(m_x), _ptr(s_x), _ptr(M), _ptr(S)))
+        return M, S
+
+    def policy_action(self, policy, m, s):
+        E, U = policy["state_dim"], policy["control_dim"]
+        p, k1 = self._policy(policy)
+        m = _f64(m, (E,))
+        s = _f64(s, (E, E))
+        M = np.empty((1, U))
+        S = np.empty((U, U))
+        V = np.empty((E, U))
+        self._chk(self.lib.pilco_policy_action(self.h, C.byref(p), _ptr(m), _ptr(s), _ptr(M), _ptr(S), _ptr(V)))
+        return M, S, V
+
+    def reward_eval(self, rewards, E, m, s):
+        r, k2 = self._rewards(rewards, E)
+        m = _f64(m, (E,))
+        s = _f64(s, (E, E))
+        mu = C.c_double()
+        var = C.c_double()
+        self._chk(self.lib.pilco_reward_eval(self.h, r, len(rewards), E, _ptr(m), _ptr(s), C.byref(mu), C.byref(var)))
+        return np.array([[mu.value]]), np.array([[var.value]])
+
+    def rollout_timed(self, policy, rewards, m0, S0, H, reps, time_pair=True):
+        E = policy["state_dim"]
+        p, k1 = self._policy(policy)
+        r, k2 = self._rewards(rewards, E)
+        m0 = _f64(m0, (E,))
+        S0 = _f64(S0, (E, E))
+        mH = np.empty((1, E))
+        SH = np.empty((E, E))
+        rew = np.zeros((1, 1))
+        ms_total = C.c_float()
+        ms_pair = C.c_float()
+        npair = C.c_int()
+        self._chk(self.lib.pilco_rollout_timed(self.h, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H),
+                                               int(reps), _ptr(mH), _ptr(SH), _ptr(rew), C.byref(ms_total),
+                                               C.byref(ms_pair) if time_pair else None, C.byref(npair)))
+        return dict(mH=mH, SH=SH, reward=rew, ms_total=ms_total.value, ms_pair=ms_pair.value,
+                    n_pair_launches=npair.value)
+
+    def factorize_timed(self, slot, reps):
+        ms = C.c_float()
+        self._chk(self.lib.pilco_factorize_timed(self.h, slot, int(reps), C.byref(ms)))
+        return ms.value
+
+    # ---- sharding
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        rc = self.lib.pilco_comm_unique_id(buf)
+        if rc != PILCO_OK:
+            raise PilcoError(rc, "ncclGetUniqueId failed")
+        return bytes(buf.raw)
+
+    def comm_init(self, id_bytes, rank, nranks):
+        buf = C.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
+        self._chk(self.lib.pilco_comm_init(self.h, buf, int(rank), int(nranks)))
+
+    def shard_set(self, rank, nranks):
+        self._chk(self.lib.pilco_shard_set(self.h, int(rank), int(nranks)))
+
+
+_default_ctx = None
+
+
+def get_context():
+    """Process-wide default context (device = $PILCO_DEVICE or $LOCAL_RANK or 0)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def set_context(ctx):
+    global _default_ctx
+    _default_ctx = ctx

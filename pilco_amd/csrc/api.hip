@@ -1,0 +1,868 @@
+// C ABI of libpilco_hip.so (see include/pilco_hip.h): context, GP slots,
+// factorisation drivers, single moment-matching step, rollout, sharding.
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "moment.h"
+
+using namespace pilco;
+
+namespace {
+
+struct Slot {
+    int N = 0, D = 0, E = 0, M = 0;  // data size, input dim, outputs, inducing points (0 = exact)
+    int Npad = 0;                    // padded N
+    int n = 0, npad = 0;             // points the moment matching runs over (N or M) and padding
+    bool has_data = false, has_hyp = false, factor_valid = false, user_factors = false, iK_null = false;
+    std::vector<double> hZ;
+    DevBuf Xt, Yt, Zt, ls, var, noise;         // Yt: [E][Npad]
+    DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
+    DevBuf Kmn, Am, AmInv, AmD, iAt, G;        // FITC extras
+    // moment-matching workspace
+    DevBuf w_in, w_At, w_Bt, w_small, w_part, w_gath, w_out;
+    int* d_lists = nullptr;
+    size_t lists_cap = 0;
+    MMWork wk{};
+    bool wk_valid = false;
+    int wk_variant = -1;
+    std::vector<int> pair_owner;  // [P]
+};
+
+}  // namespace
+
+struct pilco_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::string err;
+    int not_pd = -1;
+    int variant = 0;
+    int rank = 0, nranks = 1;
+    ncclComm_t comm = nullptr;
+    Slot slot[2];
+    int* d_info = nullptr;
+    DevBuf state;   // m_x, s_x, s1, reward, act_out, rew_out
+    DevBuf params;  // policy + reward parameters
+    DevBuf traj;
+    DevBuf selftest;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> pair_events;
+};
+
+namespace {
+
+int fail(pilco_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(call)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(ctx, PILCO_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+#define ENSURE(buf, count)                                                                                 \
+    do {                                                                                                   \
+        if ((buf).ensure(count) != hipSuccess) return fail(ctx, PILCO_E_ALLOC, "hipMalloc failed: " #buf); \
+    } while (0)
+
+int check_slot(pilco_ctx* ctx, int slot) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (slot < 0 || slot > 1) return fail(ctx, PILCO_E_SHAPE, "slot must be 0 (dynamics) or 1 (policy)");
+    return PILCO_OK;
+}
+
+// pair p = a(a+1)/2 + b; dealing order: diagonal pairs first, then the rest
+std::vector<int> deal_pairs(int E, int nranks) {
+    const int P = E * (E + 1) / 2;
+    std::vector<int> owner(P, 0);
+    int k = 0;
+    for (int a = 0; a < E; ++a) owner[a * (a + 1) / 2 + a] = (k++) % nranks;
+    for (int a = 0; a < E; ++a)
+        for (int b = 0; b < a; ++b) owner[a * (a + 1) / 2 + b] = (k++) % nranks;
+    return owner;
+}
+
+int build_work(pilco_ctx* ctx, Slot& s) {
+    if (s.wk_valid && s.wk_variant == ctx->variant) return PILCO_OK;
+    const int E = s.E, D = s.D, npad = s.npad;
+    const int P = E * (E + 1) / 2;
+    const int W = ctx->nranks, rank = ctx->rank;
+    s.pair_owner = deal_pairs(E, W);
+    std::vector<int> pair_list, own_outputs;
+    std::vector<std::vector<int>> lists(W), outs(W);
+    for (int a = 0; a < E; ++a) {  // same order as deal_pairs so list order is deterministic
+        const int p = a * (a + 1) / 2 + a;
+        lists[s.pair_owner[p]].push_back(p);
+        outs[s.pair_owner[p]].push_back(a);
+    }
+    for (int a = 0; a < E; ++a)
+        for (int b = 0; b < a; ++b) {
+            const int p = a * (a + 1) / 2 + b;
+            lists[s.pair_owner[p]].push_back(p);
+        }
+    pair_list = lists[rank];
+    own_outputs = outs[rank];
+    const int PLcap = (P + W - 1) / W, ELcap = (E + W - 1) / W;
+    MMWork& wk = s.wk;
+    wk.PL = (int)pair_list.size();
+    wk.EL = (int)own_outputs.size();
+    wk.P = P;
+    wk.KP = mm_kp(D);
+    wk.NCH = mm_prep_nch(npad, std::max(wk.PL, 1));
+    wk.NT = mm_pair_nt(npad, ctx->variant, std::max(wk.PL, 1));
+    wk.OUTOFF = PLcap;
+    wk.SEG = PLcap + ELcap * (1 + D);
+    wk.rank = rank;
+    wk.nranks = W;
+    std::vector<int> asm_pair(P), asm_out(E);
+    for (int r = 0; r < W; ++r) {
+        for (size_t k = 0; k < lists[r].size(); ++k) asm_pair[lists[r][k]] = r * wk.SEG + (int)k;
+        for (size_t o = 0; o < outs[r].size(); ++o) asm_out[outs[r][o]] = r * wk.SEG + wk.OUTOFF + (int)o * (1 + D);
+    }
+    // int lists on the device: pair_list | own_outputs | asm_pair | asm_out
+    std::vector<int> all;
+    all.insert(all.end(), pair_list.begin(), pair_list.end());
+    all.insert(all.end(), own_outputs.begin(), own_outputs.end());
+    all.insert(all.end(), asm_pair.begin(), asm_pair.end());
+    all.insert(all.end(), asm_out.begin(), asm_out.end());
+    if (all.size() > s.lists_cap) {
+        if (s.d_lists) (void)hipFree(s.d_lists);
+        s.d_lists = nullptr;
+        HIPCHK(hipMalloc(&s.d_lists, all.size() * sizeof(int)));
+        s.lists_cap = all.size();
+    }
+    HIPCHK(hipMemcpyAsync(s.d_lists, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));  // `all` is a stack vector
+    wk.pair_list = s.d_lists;
+    wk.own_outputs = s.d_lists + pair_list.size();
+    wk.asm_pair_src = wk.own_outputs + own_outputs.size();
+    wk.asm_out_src = wk.asm_pair_src + P;
+    const int PLa = std::max(wk.PL, 1);
+    ENSURE(s.w_in, (size_t)D + D * D);
+    ENSURE(s.w_At, (size_t)PLa * wk.KP * npad);
+    ENSURE(s.w_Bt, (size_t)PLa * wk.KP * npad);
+    ENSURE(s.w_small, (size_t)PLa + (size_t)E * D * D + E + (size_t)E * wk.NCH * (1 + D));
+    ENSURE(s.w_part, (size_t)PLa * wk.NT * 2);
+    ENSURE(s.w_gath, (size_t)W * wk.SEG);
+    ENSURE(s.w_out, (size_t)E + E * E + D * E);
+    wk.in_m = s.w_in.p;
+    wk.in_s = s.w_in.p + D;
+    wk.At = s.w_At.p;
+    wk.Bt = s.w_Bt.p;
+    wk.pair_isdet = s.w_small.p;
+    wk.T = wk.pair_isdet + PLa;
+    wk.c = wk.T + (size_t)E * D * D;
+    wk.mean_part = wk.c + E;
+    wk.pair_part = s.w_part.p;
+    wk.gath = s.w_gath.p;
+    wk.out_M = s.w_out.p;
+    wk.out_S = wk.out_M + E;
+    wk.out_V = wk.out_S + E * E;
+    HIPCHK(hipMemsetAsync(s.w_gath.p, 0, sizeof(double) * W * wk.SEG, ctx->st));
+    s.wk_valid = true;
+    s.wk_variant = ctx->variant;
+    return PILCO_OK;
+}
+
+MMModel model_of(const Slot& s) {
+    MMModel md{};
+    md.Pt = s.M > 0 ? s.Zt.p : s.Xt.p;
+    md.ls = s.ls.p;
+    md.var = s.var.p;
+    md.beta = s.beta.p;
+    md.iK = s.iK_null ? nullptr : s.iK.p;
+    md.n = s.n;
+    md.npad = s.npad;
+    md.D = s.D;
+    md.E = s.E;
+    return md;
+}
+
+int all_gather_segments(pilco_ctx* ctx, Slot& s) {
+    if (ctx->nranks == 1) return PILCO_OK;
+    if (!ctx->comm) return fail(ctx, PILCO_E_STATE, "sharded context without communicator: use the host exchange path");
+    double* base = s.wk.gath;
+    ncclResult_t r = ncclAllGather(base + (size_t)ctx->rank * s.wk.SEG, base, s.wk.SEG, ncclDouble, ctx->comm, ctx->st);
+    if (r != ncclSuccess) return fail(ctx, PILCO_E_RCCL, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+    return PILCO_OK;
+}
+
+// ---- exact GP: Gram -> Cholesky -> L^{-1} -> iK = L^{-T} L^{-1}, beta = L^{-T} (L^{-1} y)
+int factorize_exact(pilco_ctx* ctx, Slot& s) {
+    const int E = s.E, npad = s.Npad, nblk = npad / NB;
+    const size_t mat = (size_t)npad * npad;
+    ENSURE(s.K, E * mat);
+    ENSURE(s.Linv, E * mat);
+    ENSURE(s.iK, E * mat);
+    ENSURE(s.invD, (size_t)E * nblk * NB * NB);
+    ENSURE(s.beta, (size_t)E * npad);
+    ENSURE(s.Tscr, (size_t)E * NB * npad);
+    ENSURE(s.vec, (size_t)E * npad);
+    hipStream_t st = ctx->st;
+    HIPCHK(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * 64, st));
+    launch_gram(st, s.Xt.p, npad, s.N, s.Xt.p, npad, s.N, s.D, s.ls.p, s.var.p, E, s.K.p, npad, npad, 1, s.noise.p, 0.0);
+    launch_potrf(st, s.K.p, npad, E, s.invD.p, ctx->d_info);
+    launch_trtri(st, s.K.p, npad, E, s.invD.p, s.Linv.p, s.Tscr.p);
+    GemmDesc g{};
+    g.A = s.Linv.p; g.lda = npad; g.sA = (long)mat;
+    g.B = s.Linv.p; g.ldb = npad; g.sB = (long)mat;
+    g.C = s.iK.p; g.ldc = npad; g.sC = (long)mat;
+    g.M = npad; g.N = npad; g.K = npad; g.alpha = 1.0; g.beta = 0.0; g.tile_mode = 0; g.k_mode = 1;
+    launch_gemm(st, g, true, false, E);
+    launch_clear_padding(st, s.iK.p, npad, s.N, E);
+    launch_matvec(st, s.Linv.p, npad, E, s.Yt.p, s.vec.p, false);
+    launch_matvec(st, s.Linv.p, npad, E, s.vec.p, s.beta.p, true);
+    int info[64];
+    HIPCHK(hipMemcpyAsync(info, ctx->d_info, sizeof(int) * std::min(E, 64), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int a = 0; a < std::min(E, 64); ++a)
+        if (info[a] != 0) {
+            ctx->not_pd = a;
+            return fail(ctx, PILCO_E_NOT_PD, "Cholesky failed: K + noise*I of output " + std::to_string(a) +
+                                                 " is not positive definite (pivot " + std::to_string(info[a]) + ")");
+        }
+    s.n = s.N;
+    s.npad = npad;
+    s.iK_null = false;
+    return PILCO_OK;
+}
+
+}  // namespace
+
+// sparse FITC factorisation lives in fitc.hip
+int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr);
+
+extern "C" {
+
+int pilco_abi_version(void) { return PILCO_HIP_ABI_VERSION; }
+
+int pilco_ctx_create(int device, pilco_ctx** out) {
+    if (!out) return PILCO_E_SHAPE;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PILCO_E_HIP;
+    if (device < 0 || device >= count) return PILCO_E_SHAPE;
+    if (hipSetDevice(device) != hipSuccess) return PILCO_E_HIP;
+    pilco_ctx* ctx = new pilco_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&ctx->d_info, 64 * sizeof(int)) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
+        hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return PILCO_E_HIP;
+    }
+    const char* env = getenv("PILCO_PAIR_KERNEL");
+    if (env) ctx->variant = (atoi(env) == 1) ? 1 : 0;
+    *out = ctx;
+    return PILCO_OK;
+}
+
+int pilco_ctx_destroy(pilco_ctx* ctx) {
+    if (!ctx) return PILCO_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->st);
+    if (ctx->comm) ncclCommDestroy(ctx->comm);
+    for (Slot& s : ctx->slot) {
+        for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr,
+                          &s.vec, &s.Kmn, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
+                          &s.w_part, &s.w_gath, &s.w_out})
+            b->release();
+        if (s.d_lists) (void)hipFree(s.d_lists);
+    }
+    ctx->state.release();
+    ctx->params.release();
+    ctx->traj.release();
+    ctx->selftest.release();
+    for (hipEvent_t e : ctx->pair_events) (void)hipEventDestroy(e);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->d_info) (void)hipFree(ctx->d_info);
+    if (ctx->st) (void)hipStreamDestroy(ctx->st);
+    delete ctx;
+    return PILCO_OK;
+}
+
+const char* pilco_last_error(const pilco_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int pilco_last_not_pd_output(const pilco_ctx* ctx) { return ctx ? ctx->not_pd : -1; }
+
+int pilco_set_pair_kernel(pilco_ctx* ctx, int variant) {
+    if (!ctx || variant < 0 || variant > 1) return PILCO_E_SHAPE;
+    ctx->variant = variant;
+    return PILCO_OK;
+}
+
+int pilco_selftest(pilco_ctx* ctx) {
+    if (!ctx) return PILCO_E_SHAPE;
+    HIPCHK(hipSetDevice(ctx->device));
+    ENSURE(ctx->selftest, 256);
+    double h[256];
+    const int r = launch_selftest_mfma(ctx->st, ctx->selftest.p, h);
+    if (r < 0) return fail(ctx, PILCO_E_HIP, "selftest launch failed");
+    if (r > 0) return fail(ctx, PILCO_E_STATE, "f64 MFMA fragment layout differs from the assumed map at element " + std::to_string(r - 1));
+    return PILCO_OK;
+}
+
+int pilco_gp_set_data(pilco_ctx* ctx, int slot, const double* X, const double* Y, int N, int D, int E) {
+    if (int r = check_slot(ctx, slot)) return r;
+    if (!X || !Y || N <= 0 || D <= 0 || E <= 0) return fail(ctx, PILCO_E_SHAPE, "set_data: bad sizes");
+    if (D > MAX_D) return fail(ctx, PILCO_E_SHAPE, "set_data: GP input dimension > 32 not supported by this build");
+    if (E > 64) return fail(ctx, PILCO_E_SHAPE, "set_data: more than 64 outputs not supported by this build");
+    HIPCHK(hipSetDevice(ctx->device));
+    Slot& s = ctx->slot[slot];
+    const bool reshape = (D != s.D || E != s.E);
+    s.N = N; s.D = D; s.E = E;
+    s.Npad = round_up(N, NB);
+    if (reshape) { s.has_hyp = false; s.M = 0; }
+    ENSURE(s.Xt, (size_t)D * s.Npad);
+    ENSURE(s.Yt, (size_t)E * s.Npad);
+    // stage through a scratch device buffer: X (N,D) -> Xt [D][Npad]; Y (N,E) -> Yt [E][Npad]
+    const size_t need = (size_t)N * std::max(D, E);
+    ENSURE(s.vec, std::max(need, (size_t)E * s.Npad));
+    HIPCHK(hipMemcpyAsync(s.vec.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice, ctx->st));
+    launch_transpose_points(ctx->st, s.vec.p, N, D, s.Xt.p, s.Npad);
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipMemcpyAsync(s.vec.p, Y, sizeof(double) * N * E, hipMemcpyHostToDevice, ctx->st));
+    launch_transpose_points(ctx->st, s.vec.p, N, E, s.Yt.p, s.Npad);
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    s.has_data = true;
+    s.factor_valid = false;
+    s.user_factors = false;
+    if (s.M == 0) { s.n = N; s.npad = s.Npad; }
+    s.wk_valid = false;
+    return PILCO_OK;
+}
+
+int pilco_gp_set_hyp(pilco_ctx* ctx, int slot, const double* lengthscales, const double* variance, const double* noise) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.has_data) return fail(ctx, PILCO_E_STATE, "set_hyp before set_data");
+    if (!lengthscales || !variance || !noise) return fail(ctx, PILCO_E_SHAPE, "set_hyp: null pointer");
+    for (int i = 0; i < s.E * s.D; ++i)
+        if (!(lengthscales[i] > 0.0)) return fail(ctx, PILCO_E_SHAPE, "set_hyp: lengthscales must be positive");
+    for (int i = 0; i < s.E; ++i)
+        if (!(variance[i] > 0.0) || !(noise[i] >= 0.0)) return fail(ctx, PILCO_E_SHAPE, "set_hyp: variance must be positive, noise non-negative");
+    HIPCHK(hipSetDevice(ctx->device));
+    ENSURE(s.ls, (size_t)s.E * s.D);
+    ENSURE(s.var, (size_t)s.E);
+    ENSURE(s.noise, (size_t)s.E);
+    HIPCHK(hipMemcpyAsync(s.ls.p, lengthscales, sizeof(double) * s.E * s.D, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(s.var.p, variance, sizeof(double) * s.E, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(s.noise.p, noise, sizeof(double) * s.E, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    s.has_hyp = true;
+    s.factor_valid = false;
+    s.user_factors = false;
+    return PILCO_OK;
+}
+
+int pilco_gp_set_inducing(pilco_ctx* ctx, int slot, const double* Z, int M) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.has_data) return fail(ctx, PILCO_E_STATE, "set_inducing before set_data");
+    if (M < 0 || (M > 0 && !Z)) return fail(ctx, PILCO_E_SHAPE, "set_inducing: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    s.M = M;
+    s.factor_valid = false;
+    s.user_factors = false;
+    s.wk_valid = false;
+    if (M == 0) {
+        s.n = s.N;
+        s.npad = s.Npad;
+        return PILCO_OK;
+    }
+    s.n = M;
+    s.npad = round_up(M, NB);
+    ENSURE(s.Zt, (size_t)s.D * s.npad);
+    ENSURE(s.vec, std::max((size_t)M * s.D, (size_t)s.E * std::max(s.Npad, s.npad)));
+    HIPCHK(hipMemcpyAsync(s.vec.p, Z, sizeof(double) * M * s.D, hipMemcpyHostToDevice, ctx->st));
+    launch_transpose_points(ctx->st, s.vec.p, M, s.D, s.Zt.p, s.npad);
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    return PILCO_OK;
+}
+
+int pilco_gp_gram(pilco_ctx* ctx, int slot, const double* X1, int N1, const double* X2, int N2, double* out) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.has_hyp) return fail(ctx, PILCO_E_STATE, "gram before set_hyp");
+    if (!X1 || N1 <= 0 || !out) return fail(ctx, PILCO_E_SHAPE, "gram: bad arguments");
+    if (!X2) { X2 = X1; N2 = N1; }
+    if (N2 <= 0) return fail(ctx, PILCO_E_SHAPE, "gram: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int p1 = round_up(N1, NB), p2 = round_up(N2, NB), D = s.D, E = s.E;
+    DevBuf raw, t1, t2, K;
+    auto cleanup = [&]() { raw.release(); t1.release(); t2.release(); K.release(); };
+    if (raw.ensure((size_t)std::max(N1, N2) * D) != hipSuccess || t1.ensure((size_t)D * p1) != hipSuccess ||
+        t2.ensure((size_t)D * p2) != hipSuccess || K.ensure((size_t)E * p1 * p2) != hipSuccess) {
+        cleanup();
+        return fail(ctx, PILCO_E_ALLOC, "gram: hipMalloc failed");
+    }
+    hipError_t e = hipMemcpyAsync(raw.p, X1, sizeof(double) * N1 * D, hipMemcpyHostToDevice, ctx->st);
+    launch_transpose_points(ctx->st, raw.p, N1, D, t1.p, p1);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(raw.p, X2, sizeof(double) * N2 * D, hipMemcpyHostToDevice, ctx->st);
+    launch_transpose_points(ctx->st, raw.p, N2, D, t2.p, p2);
+    launch_gram(ctx->st, t1.p, p1, N1, t2.p, p2, N2, D, s.ls.p, s.var.p, E, K.p, p1, p2, 0, nullptr, 0.0);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(out, sizeof(double) * N2, K.p, sizeof(double) * p2, sizeof(double) * N2, (size_t)N1, hipMemcpyDeviceToHost, ctx->st);
+    // the E matrices are strided by p1*p2 on the device and N1*N2 on the host
+    for (int a = 1; a < E && e == hipSuccess; ++a)
+        e = hipMemcpy2DAsync(out + (size_t)a * N1 * N2, sizeof(double) * N2, K.p + (size_t)a * p1 * p2, sizeof(double) * p2,
+                             sizeof(double) * N2, (size_t)N1, hipMemcpyDeviceToHost, ctx->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->st);
+    cleanup();
+    if (e != hipSuccess) return fail(ctx, PILCO_E_HIP, std::string("gram: ") + hipGetErrorString(e));
+    return PILCO_OK;
+}
+
+int pilco_gp_factorize(pilco_ctx* ctx, int slot) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.has_data || !s.has_hyp) return fail(ctx, PILCO_E_STATE, "factorize needs set_data and set_hyp first");
+    if (s.factor_valid && !s.user_factors) return PILCO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->not_pd = -1;
+    int r = (s.M > 0) ? pilco_factorize_fitc(ctx, &s) : factorize_exact(ctx, s);
+    if (r != PILCO_OK) return r;
+    s.factor_valid = true;
+    s.user_factors = false;
+    s.wk_valid = false;
+    return PILCO_OK;
+}
+
+int pilco_gp_num_points(const pilco_ctx* ctx, int slot) {
+    if (!ctx || slot < 0 || slot > 1) return -1;
+    return ctx->slot[slot].n;
+}
+
+int pilco_gp_get_factors(pilco_ctx* ctx, int slot, double* iK, double* beta) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "get_factors: no current factorisation");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = s.n, npad = s.npad, E = s.E;
+    if (iK) {
+        if (s.iK_null) {
+            memset(iK, 0, sizeof(double) * (size_t)E * n * n);
+        } else {
+            for (int a = 0; a < E; ++a)
+                HIPCHK(hipMemcpy2DAsync(iK + (size_t)a * n * n, sizeof(double) * n, s.iK.p + (size_t)a * npad * npad,
+                                        sizeof(double) * npad, sizeof(double) * n, (size_t)n, hipMemcpyDeviceToHost, ctx->st));
+        }
+    }
+    if (beta)
+        HIPCHK(hipMemcpy2DAsync(beta, sizeof(double) * n, s.beta.p, sizeof(double) * npad, sizeof(double) * n, (size_t)E,
+                                hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    return PILCO_OK;
+}
+
+int pilco_gp_set_factors(pilco_ctx* ctx, int slot, const double* iK, const double* beta) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.has_data || !s.has_hyp) return fail(ctx, PILCO_E_STATE, "set_factors needs set_data and set_hyp first");
+    if (!beta) return fail(ctx, PILCO_E_SHAPE, "set_factors: beta is required");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = s.n, npad = s.npad, E = s.E;
+    ENSURE(s.beta, (size_t)E * npad);
+    HIPCHK(hipMemsetAsync(s.beta.p, 0, sizeof(double) * E * npad, ctx->st));
+    HIPCHK(hipMemcpy2DAsync(s.beta.p, sizeof(double) * npad, beta, sizeof(double) * n, sizeof(double) * n, (size_t)E,
+                            hipMemcpyHostToDevice, ctx->st));
+    if (iK) {
+        ENSURE(s.iK, (size_t)E * npad * npad);
+        HIPCHK(hipMemsetAsync(s.iK.p, 0, sizeof(double) * E * npad * npad, ctx->st));
+        for (int a = 0; a < E; ++a)
+            HIPCHK(hipMemcpy2DAsync(s.iK.p + (size_t)a * npad * npad, sizeof(double) * npad, iK + (size_t)a * n * n,
+                                    sizeof(double) * n, sizeof(double) * n, (size_t)n, hipMemcpyHostToDevice, ctx->st));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    s.iK_null = (iK == nullptr);
+    s.factor_valid = true;
+    s.user_factors = true;
+    return PILCO_OK;
+}
+
+int pilco_gp_predict(pilco_ctx* ctx, int slot, const double* m, const double* s_in, double* M, double* S, double* V) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "predict: no current factorisation (call pilco_gp_factorize)");
+    if (!m || !s_in || !M || !S || !V) return fail(ctx, PILCO_E_SHAPE, "predict: null pointer");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (int r = build_work(ctx, s)) return r;
+    const int D = s.D, E = s.E;
+    HIPCHK(hipMemcpyAsync(s.wk.in_m, m, sizeof(double) * D, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(s.wk.in_s, s_in, sizeof(double) * D * D, hipMemcpyHostToDevice, ctx->st));
+    const MMModel md = model_of(s);
+    if (s.wk.PL > 0) {
+        launch_mm_prep(ctx->st, md, s.wk);
+        launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
+    }
+    GlueArgs g{};
+    g.E = E; g.D = D; g.U = 0;
+    g.wk = s.wk;
+    g.var = s.var.p;
+    g.flags = GF_PACK;
+    launch_glue(ctx->st, g);
+    if (int r = all_gather_segments(ctx, s)) return r;
+    g.flags = GF_ASSEMBLE;
+    launch_glue(ctx->st, g);
+    HIPCHK(hipMemcpyAsync(M, s.wk.out_M, sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(S, s.wk.out_S, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(V, s.wk.out_V, sizeof(double) * D * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    return PILCO_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ rollout
+namespace {
+
+struct RolloutPlan {
+    GlueArgs g{};
+    int E = 0, D = 0, U = 0;
+};
+
+int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_term* rw, int n_rw, int H, bool want_traj,
+                  RolloutPlan& plan) {
+    Slot& s = ctx->slot[0];
+    if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "rollout: dynamics model has no current factorisation");
+    if (!pol) return fail(ctx, PILCO_E_SHAPE, "rollout: null policy");
+    const int E = s.E, D = s.D, U = D - E;
+    if (pol->state_dim != E || pol->control_dim != U || U < 0)
+        return fail(ctx, PILCO_E_SHAPE, "rollout: policy dims do not match the model (state_dim must be E, control_dim D-E)");
+    if (pol->kind == PILCO_POLICY_NONE && U != 0) return fail(ctx, PILCO_E_SHAPE, "rollout: policy NONE needs D == E");
+    if (pol->kind == PILCO_POLICY_LINEAR && (U == 0 || !pol->W || !pol->b)) return fail(ctx, PILCO_E_SHAPE, "rollout: linear policy needs W, b and control_dim > 0");
+    if (pol->kind == PILCO_POLICY_RBF) return fail(ctx, PILCO_E_STATE, "rollout: RBF policy not available in this build");
+    if (pol->kind < 0 || pol->kind > 2) return fail(ctx, PILCO_E_SHAPE, "rollout: unknown policy kind");
+    if (n_rw < 0 || n_rw > MAX_REWARD_TERMS || (n_rw > 0 && !rw)) return fail(ctx, PILCO_E_SHAPE, "rollout: 0..4 reward terms supported");
+    if (int r = build_work(ctx, s)) return r;
+    // state: m_x[E] s_x[E*E] s1[E*D] reward[1] act_out[U+U*U+E*U] rew_out[2]
+    const size_t n_state = (size_t)E + E * E + (size_t)E * D + 1 + (U + U * U + (size_t)E * U) + 2;
+    ENSURE(ctx->state, n_state);
+    // params: W[U*E] b[U] maxact[U] then per reward W[E*E] t[E]
+    const size_t n_par = (size_t)U * E + 2 * U + (size_t)MAX_REWARD_TERMS * (E * E + E) + 8;
+    ENSURE(ctx->params, n_par);
+    if (want_traj) ENSURE(ctx->traj, (size_t)(H + 1) * (E + E * E));
+    std::vector<double> hp(n_par, 0.0);
+    size_t off = 0;
+    GlueArgs& g = plan.g;
+    g = GlueArgs{};
+    g.E = E; g.D = D; g.U = U;
+    g.wk = s.wk;
+    g.var = s.var.p;
+    g.m_x = ctx->state.p;
+    g.s_x = g.m_x + E;
+    g.s1 = g.s_x + E * E;
+    g.reward = g.s1 + (size_t)E * D;
+    g.traj = want_traj ? ctx->traj.p : nullptr;
+    g.pol_kind = pol->kind;
+    g.squash = pol->squash;
+    if (pol->kind == PILCO_POLICY_LINEAR) {
+        memcpy(&hp[off], pol->W, sizeof(double) * U * E);
+        g.W = ctx->params.p + off; off += (size_t)U * E;
+        memcpy(&hp[off], pol->b, sizeof(double) * U);
+        g.b = ctx->params.p + off; off += U;
+        for (int u = 0; u < U; ++u) hp[off + u] = pol->max_action ? pol->max_action[u] : 1.0;
+        g.maxact = ctx->params.p + off; off += U;
+    }
+    g.n_rewards = n_rw;
+    for (int i = 0; i < n_rw; ++i) {
+        g.rw[i].kind = rw[i].kind;
+        g.rw[i].coef = rw[i].coef;
+        if (rw[i].kind == PILCO_REWARD_EXPONENTIAL) {
+            if (!rw[i].W) return fail(ctx, PILCO_E_SHAPE, "rollout: exponential reward needs W");
+            memcpy(&hp[off], rw[i].W, sizeof(double) * E * E);
+            g.rw[i].W = ctx->params.p + off; off += (size_t)E * E;
+            if (rw[i].t) memcpy(&hp[off], rw[i].t, sizeof(double) * E);
+            g.rw[i].t = ctx->params.p + off; off += E;
+        } else if (rw[i].kind == PILCO_REWARD_LINEAR) {
+            if (!rw[i].W) return fail(ctx, PILCO_E_SHAPE, "rollout: linear reward needs W");
+            memcpy(&hp[off], rw[i].W, sizeof(double) * E);
+            g.rw[i].W = ctx->params.p + off; off += E;
+            g.rw[i].t = ctx->params.p + off;
+        } else {
+            return fail(ctx, PILCO_E_SHAPE, "rollout: unknown reward kind");
+        }
+    }
+    HIPCHK(hipMemcpyAsync(ctx->params.p, hp.data(), sizeof(double) * n_par, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));  // hp is a local vector
+    plan.E = E; plan.D = D; plan.U = U;
+    return PILCO_OK;
+}
+
+// enqueue one full rollout on the stream (state already uploaded)
+int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev) {
+    Slot& s = ctx->slot[0];
+    const MMModel md = model_of(s);
+    GlueArgs g = plan.g;
+    HIPCHK(hipMemsetAsync(g.reward, 0, sizeof(double), ctx->st));
+    g.step = 0;
+    g.flags = GF_TRAJ | (H > 0 ? (GF_REWARD | GF_POLICY) : 0);
+    launch_glue(ctx->st, g);
+    size_t evi = 0;
+    for (int t = 0; t < H; ++t) {
+        if (s.wk.PL > 0) {
+            launch_mm_prep(ctx->st, md, s.wk);
+            if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
+            launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
+            if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
+        }
+        g.step = t + 1;
+        const int tail = GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ | (t + 1 < H ? (GF_REWARD | GF_POLICY) : 0);
+        if (ctx->nranks == 1) {
+            g.flags = GF_PACK | tail;
+            launch_glue(ctx->st, g);
+        } else {
+            g.flags = GF_PACK;
+            launch_glue(ctx->st, g);
+            if (int r = all_gather_segments(ctx, s)) return r;
+            g.flags = tail;
+            launch_glue(ctx->st, g);
+        }
+    }
+    return PILCO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pilco_rollout(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                  const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!m0 || !S0 || !mH || !SH || !reward || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    RolloutPlan plan;
+    if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, traj != nullptr, plan)) return r;
+    const int E = plan.E;
+    HIPCHK(hipMemcpyAsync(plan.g.m_x, m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(plan.g.s_x, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
+    if (int r = enqueue_rollout(ctx, plan, H, nullptr)) return r;
+    HIPCHK(hipMemcpyAsync(mH, plan.g.m_x, sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(SH, plan.g.s_x, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(reward, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
+    if (traj)
+        HIPCHK(hipMemcpyAsync(traj, ctx->traj.p, sizeof(double) * (size_t)(H + 1) * (E + E * E), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    return PILCO_OK;
+}
+
+int pilco_propagate(pilco_ctx* ctx, const pilco_policy* policy, const double* m_x, const double* s_x, double* M_x, double* S_x) {
+    double r = 0.0;
+    return pilco_rollout(ctx, policy, nullptr, 0, m_x, s_x, 1, M_x, S_x, &r, nullptr);
+}
+
+int pilco_policy_action(pilco_ctx* ctx, const pilco_policy* policy, const double* m, const double* s_in, double* M, double* S, double* V) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!policy || !m || !s_in || !M || !S || !V) return fail(ctx, PILCO_E_SHAPE, "policy_action: null pointer");
+    if (policy->kind != PILCO_POLICY_LINEAR) return fail(ctx, PILCO_E_STATE, "policy_action: only the linear policy is evaluated through this entry point in this build");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int E = policy->state_dim, U = policy->control_dim;
+    if (E <= 0 || U <= 0 || E > MAX_D || U > MAX_D || !policy->W || !policy->b) return fail(ctx, PILCO_E_SHAPE, "policy_action: bad dims");
+    const size_t n_state = (size_t)E + E * E + (size_t)U * E + 2 * U + (U + U * U + (size_t)E * U);
+    ENSURE(ctx->state, n_state + 8);
+    std::vector<double> h(n_state, 0.0);
+    memcpy(&h[0], m, sizeof(double) * E);
+    memcpy(&h[E], s_in, sizeof(double) * E * E);
+    size_t off = (size_t)E + E * E;
+    GlueArgs g{};
+    g.E = E; g.D = E + U; g.U = U;
+    g.m_x = ctx->state.p;
+    g.s_x = g.m_x + E;
+    memcpy(&h[off], policy->W, sizeof(double) * U * E);
+    g.W = ctx->state.p + off; off += (size_t)U * E;
+    memcpy(&h[off], policy->b, sizeof(double) * U);
+    g.b = ctx->state.p + off; off += U;
+    for (int u = 0; u < U; ++u) h[off + u] = policy->max_action ? policy->max_action[u] : 1.0;
+    g.maxact = ctx->state.p + off; off += U;
+    g.act_out = ctx->state.p + off;
+    g.pol_kind = PILCO_POLICY_LINEAR;
+    g.squash = policy->squash;
+    g.flags = GF_POLICY;
+    HIPCHK(hipMemcpyAsync(ctx->state.p, h.data(), sizeof(double) * n_state, hipMemcpyHostToDevice, ctx->st));
+    launch_glue(ctx->st, g);
+    std::vector<double> o((size_t)U + U * U + (size_t)E * U);
+    HIPCHK(hipMemcpyAsync(o.data(), g.act_out, sizeof(double) * o.size(), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    memcpy(M, &o[0], sizeof(double) * U);
+    memcpy(S, &o[U], sizeof(double) * U * U);
+    memcpy(V, &o[(size_t)U + U * U], sizeof(double) * E * U);
+    return PILCO_OK;
+}
+
+int pilco_reward_eval(pilco_ctx* ctx, const pilco_reward_term* rewards, int n_rewards, int state_dim, const double* m,
+                      const double* s_in, double* muR, double* sR) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!rewards || n_rewards <= 0 || n_rewards > MAX_REWARD_TERMS || !m || !s_in || !muR || !sR || state_dim <= 0 || state_dim > MAX_D)
+        return fail(ctx, PILCO_E_SHAPE, "reward_eval: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int E = state_dim;
+    const size_t n = (size_t)E + E * E + (size_t)n_rewards * (E * E + E) + 2;
+    ENSURE(ctx->state, n + 8);
+    std::vector<double> h(n, 0.0);
+    memcpy(&h[0], m, sizeof(double) * E);
+    memcpy(&h[E], s_in, sizeof(double) * E * E);
+    size_t off = (size_t)E + E * E;
+    GlueArgs g{};
+    g.E = E; g.D = E; g.U = 0;
+    g.m_x = ctx->state.p;
+    g.s_x = g.m_x + E;
+    g.n_rewards = n_rewards;
+    for (int i = 0; i < n_rewards; ++i) {
+        g.rw[i].kind = rewards[i].kind;
+        g.rw[i].coef = rewards[i].coef;
+        if (!rewards[i].W) return fail(ctx, PILCO_E_SHAPE, "reward_eval: W is required");
+        if (rewards[i].kind == PILCO_REWARD_EXPONENTIAL) {
+            memcpy(&h[off], rewards[i].W, sizeof(double) * E * E);
+            g.rw[i].W = ctx->state.p + off; off += (size_t)E * E;
+            if (rewards[i].t) memcpy(&h[off], rewards[i].t, sizeof(double) * E);
+            g.rw[i].t = ctx->state.p + off; off += E;
+        } else if (rewards[i].kind == PILCO_REWARD_LINEAR) {
+            memcpy(&h[off], rewards[i].W, sizeof(double) * E);
+            g.rw[i].W = ctx->state.p + off; off += E;
+            g.rw[i].t = g.rw[i].W;
+        } else {
+            return fail(ctx, PILCO_E_SHAPE, "reward_eval: unknown reward kind");
+        }
+    }
+    g.rew_out = ctx->state.p + off;
+    g.flags = GF_REWARD;
+    HIPCHK(hipMemcpyAsync(ctx->state.p, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->st));
+    launch_glue(ctx->st, g);
+    double o[2];
+    HIPCHK(hipMemcpyAsync(o, g.rew_out, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    *muR = o[0];
+    *sR = o[1];
+    return PILCO_OK;
+}
+
+int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                        const double* m0, const double* S0, int H, int reps, double* mH, double* SH, double* reward,
+                        float* ms_total, float* ms_pair, int* n_pair_launches) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!m0 || !S0 || !mH || !SH || !reward || H < 0 || reps <= 0 || !ms_total) return fail(ctx, PILCO_E_SHAPE, "rollout_timed: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    RolloutPlan plan;
+    if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, false, plan)) return r;
+    const int E = plan.E;
+    ENSURE(ctx->selftest, (size_t)E + E * E + 256);
+    double* init = ctx->selftest.p + 256;  // device copy of (m0, S0) so that the timed region has no host traffic
+    HIPCHK(hipMemcpyAsync(init, m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(init + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->st));
+    for (int rep = 0; rep < reps; ++rep) {
+        HIPCHK(hipMemcpyAsync(plan.g.m_x, init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
+        if (int r = enqueue_rollout(ctx, plan, H, nullptr)) return r;
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->st));
+    HIPCHK(hipEventSynchronize(ctx->ev1));
+    HIPCHK(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    if (ms_pair) {
+        // second pass with an event pair around every pair-kernel launch (perturbs the total, so timed separately)
+        const size_t need = (size_t)2 * H;
+        while (ctx->pair_events.size() < need) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            ctx->pair_events.push_back(e);
+        }
+        HIPCHK(hipMemcpyAsync(plan.g.m_x, init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
+        if (int r = enqueue_rollout(ctx, plan, H, &ctx->pair_events)) return r;
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        float tot = 0.f;
+        int cnt = 0;
+        if (ctx->slot[0].wk.PL > 0)
+            for (int t = 0; t < H; ++t) {
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, ctx->pair_events[2 * t], ctx->pair_events[2 * t + 1]));
+                tot += ms;
+                ++cnt;
+            }
+        *ms_pair = tot;
+        if (n_pair_launches) *n_pair_launches = cnt;
+    }
+    HIPCHK(hipMemcpyAsync(mH, plan.g.m_x, sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(SH, plan.g.s_x, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(reward, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    return PILCO_OK;
+}
+
+int pilco_factorize_timed(pilco_ctx* ctx, int slot, int reps, float* ms_each) {
+    if (int r = check_slot(ctx, slot)) return r;
+    if (reps <= 0 || !ms_each) return fail(ctx, PILCO_E_SHAPE, "factorize_timed: bad arguments");
+    Slot& s = ctx->slot[slot];
+    s.factor_valid = false;
+    if (int r = pilco_gp_factorize(ctx, slot)) return r;  // warm-up, allocations
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->st));
+    for (int i = 0; i < reps; ++i) {
+        s.factor_valid = false;
+        if (int r = pilco_gp_factorize(ctx, slot)) return r;
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->st));
+    HIPCHK(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *ms_each = ms / reps;
+    return PILCO_OK;
+}
+
+// ------------------------------------------------------------------ multi-GPU
+int pilco_comm_unique_id(void* id128) {
+    if (!id128) return PILCO_E_SHAPE;
+    static_assert(sizeof(ncclUniqueId) <= PILCO_COMM_ID_BYTES, "ncclUniqueId larger than the ABI slot");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return PILCO_E_RCCL;
+    memset(id128, 0, PILCO_COMM_ID_BYTES);
+    memcpy(id128, &id, sizeof(id));
+    return PILCO_OK;
+}
+
+int pilco_shard_set(pilco_ctx* ctx, int rank, int nranks) {
+    if (!ctx || nranks <= 0 || rank < 0 || rank >= nranks) return fail(ctx, PILCO_E_SHAPE, "shard_set: bad rank / nranks");
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    for (Slot& s : ctx->slot) s.wk_valid = false;
+    return PILCO_OK;
+}
+
+int pilco_comm_init(pilco_ctx* ctx, const void* id128, int rank, int nranks) {
+    if (!ctx || !id128) return PILCO_E_SHAPE;
+    if (int r = pilco_shard_set(ctx, rank, nranks)) return r;
+    HIPCHK(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&ctx->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        ctx->comm = nullptr;
+        return fail(ctx, PILCO_E_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    }
+    return PILCO_OK;
+}
+
+int pilco_shard_owner_of_pair(const pilco_ctx* ctx, int pair_index) {
+    if (!ctx) return -1;
+    const Slot& s = ctx->slot[0];
+    if (pair_index < 0 || pair_index >= (int)s.pair_owner.size()) return -1;
+    return s.pair_owner[pair_index];
+}
+
+int pilco_comm_rank(const pilco_ctx* ctx) { return ctx ? ctx->rank : -1; }
+int pilco_comm_size(const pilco_ctx* ctx) { return ctx ? ctx->nranks : -1; }
+
+}  // extern "C"
+
+// FITC factorisation is added in a later milestone; until then fail loudly.
+int pilco_factorize_fitc(pilco_ctx* ctx, void*) {
+    return fail(ctx, PILCO_E_STATE, "sparse (FITC) factorisation not available in this build");
+}

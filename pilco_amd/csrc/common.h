@@ -1,0 +1,75 @@
+// Internal declarations shared by the translation units of libpilco_hip.so.
+// gfx950 only; no portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pilco_hip.h"
+
+namespace pilco {
+
+constexpr int NB = 64;  // factorisation block size == padding unit of every device matrix
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct DevBuf {
+    double* p = nullptr;
+    size_t cap = 0;  // in doubles
+    hipError_t ensure(size_t count) {
+        if (count <= cap && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, count * sizeof(double));
+        if (e == hipSuccess) cap = count;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// ---------------------------------------------------------------- linalg.hip
+struct GemmDesc {
+    const double* A;
+    const double* B;
+    double* C;
+    int M, N, K;        // all multiples of 64 / 64 / 16
+    int lda, ldb, ldc;
+    long sA, sB, sC;    // batch strides (doubles)
+    double alpha, beta;
+    int tile_mode;      // 0 all tiles, 1 only tiles with row-block >= col-block
+    int k_mode;         // 0 full K, 1 k >= max(i0,j0), 2 k >= j0, 3 k < i0+64 (A lower-triangular rows), 4: k>=j0 && k<i0+64
+};
+// C = alpha * op(A) op(B) + beta * C, batched; op selected by ta/tb (0 = as stored, 1 = transposed)
+void launch_gemm(hipStream_t st, const GemmDesc& g, bool ta, bool tb, int batch);
+
+// Gram matrices: out[a][i][j] = var[a] exp(-0.5 sum_d ((P1[d][i]-P2[d][j])/ls[a][d])^2)
+// P1t: [D][ld1], P2t: [D][ld2] (transposed points); out: [E][rows_pad][cols_pad].
+// diag_mode 0: none; 1: += diag_add[a] on i==j<n1, padding diag = 1; 2: += jitter on diag, padding diag = 1
+void launch_gram(hipStream_t st, const double* P1t, int ld1, int n1, const double* P2t, int ld2, int n2, int D,
+                 const double* ls, const double* var, int E, double* out, int rows_pad, int cols_pad, int diag_mode,
+                 const double* diag_add, double jitter);
+
+// Blocked Cholesky (lower) of batch matrices A[b] (npad x npad, ld = npad), in place; strictly-upper part zeroed.
+// invD receives the inverses of the diagonal 64x64 blocks of L: [batch][npad/64][64][64].
+// info[b] = 0 or 1-based index of the first non-positive pivot.
+void launch_potrf(hipStream_t st, double* A, int npad, int batch, double* invD, int* info);
+// Linv = L^{-1} (lower), using invD from launch_potrf; T is scratch [batch][64][npad].
+void launch_trtri(hipStream_t st, const double* L, int npad, int batch, const double* invD, double* Linv, double* T);
+// y = op(A) x, A [batch][npad][npad], x,y [batch][npad]
+void launch_matvec(hipStream_t st, const double* A, int npad, int batch, const double* x, double* y, bool trans);
+// zero rows/cols >= n of batch square matrices
+void launch_clear_padding(hipStream_t st, double* A, int npad, int n, int batch);
+void launch_transpose_points(hipStream_t st, const double* X, int n, int D, double* Xt, int ld);
+
+// ---------------------------------------------------------------- moment.hip
+struct MMWork;  // defined in moment.h
+
+}  // namespace pilco

@@ -1,0 +1,324 @@
+// Dense float64 building blocks of the GP factorisation (T1-T4, T20 of SURVEY.md
+// section 2.2), hand-written for gfx950:
+//   * SE-ARD Gram build (coalesced reads of the transposed point set),
+//   * 64x64x16 LDS-tiled batched GEMM on v_mfma_f64_16x16x4_f64,
+//   * right-looking blocked Cholesky (diag block factor + inverse in LDS,
+//     panel and trailing update on the MFMA GEMM),
+//   * blocked triangular inverse, mat-vec, padding helpers.
+// Every device matrix is padded to a multiple of 64 with an identity / zero
+// padding so that no kernel needs edge handling.
+#include "common.h"
+
+namespace pilco {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ Gram
+// replaces gpflow SquaredExponential.K as called from pilco/models/mgpr.py:154-157
+__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ P1t, int ld1, int n1,
+                                              const double* __restrict__ P2t, int ld2, int n2, int D,
+                                              const double* __restrict__ ls, const double* __restrict__ var,
+                                              double* __restrict__ out, int rows_pad, int cols_pad, int diag_mode,
+                                              const double* __restrict__ diag_add, double jitter) {
+    const int a = blockIdx.z;
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols_pad) return;
+    double v;
+    if (i < n1 && j < n2) {
+        double r2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double il = 1.0 / ls[a * D + d];
+            const double diff = (P1t[(long)d * ld1 + i] - P2t[(long)d * ld2 + j]) * il;
+            r2 = fma(diff, diff, r2);
+        }
+        v = var[a] * exp(-0.5 * r2);
+        if (i == j) {
+            if (diag_mode == 1) v += diag_add[a];
+            if (diag_mode == 2) v += jitter;
+        }
+    } else {
+        v = (diag_mode != 0 && i == j) ? 1.0 : 0.0;
+    }
+    out[((long)a * rows_pad + i) * cols_pad + j] = v;
+}
+
+void launch_gram(hipStream_t st, const double* P1t, int ld1, int n1, const double* P2t, int ld2, int n2, int D,
+                 const double* ls, const double* var, int E, double* out, int rows_pad, int cols_pad, int diag_mode,
+                 const double* diag_add, double jitter) {
+    dim3 grid((cols_pad + 255) / 256, rows_pad, E);
+    hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, st, P1t, ld1, n1, P2t, ld2, n2, D, ls, var, out, rows_pad, cols_pad,
+                       diag_mode, diag_add, jitter);
+}
+
+__global__ void k_transpose_points(const double* __restrict__ X, int n, int D, double* __restrict__ Xt, int ld) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ld) return;
+    for (int d = 0; d < D; ++d) Xt[(long)d * ld + i] = (i < n) ? X[(long)i * D + d] : 0.0;
+}
+
+void launch_transpose_points(hipStream_t st, const double* X, int n, int D, double* Xt, int ld) {
+    hipLaunchKernelGGL(k_transpose_points, dim3((ld + 255) / 256), dim3(256), 0, st, X, n, D, Xt, ld);
+}
+
+// ------------------------------------------------------------------ GEMM (f64 MFMA)
+// Block tile 64x64, K step 16, 4 waves in a 2x2 arrangement, each wave a 32x32
+// sub-tile = 2x2 v_mfma_f64_16x16x4_f64 accumulators.  LDS tiles are stored
+// k-major ([k][i] / [k][j]) so that an MFMA operand read is 16 consecutive
+// doubles per k row; the row stride of 80 doubles puts the two k rows of a
+// 32-lane ds_read_b64 group on disjoint bank halves.
+constexpr int LDS_LD = 80;
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
+    const int bj = blockIdx.x, bi = blockIdx.y, bz = blockIdx.z;
+    if (g.tile_mode == 1 && bi < bj) return;
+    const int i0 = bi * 64, j0 = bj * 64;
+    int kbeg = 0, kend = g.K;
+    if (g.k_mode == 1) kbeg = (i0 > j0 ? i0 : j0);
+    if (g.k_mode == 2) kbeg = j0;
+    kbeg &= ~15;
+    __shared__ double As[16][LDS_LD];
+    __shared__ double Bs[16][LDS_LD];
+    const double* A = g.A + (long)bz * g.sA;
+    const double* B = g.B + (long)bz * g.sB;
+    double* C = g.C + (long)bz * g.sC;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wi = (w >> 1) * 32, wj = (w & 1) * 32;
+    const int lr = lane >> 4, lc = lane & 15;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        if (!TA) {  // A stored (M,K): rows contiguous along k -> transposing write
+            const int i = t >> 2, kq = (t & 3) * 4;
+            const double* src = A + (long)(i0 + i) * g.lda + k0 + kq;
+            const double2 v0 = *reinterpret_cast<const double2*>(src);
+            const double2 v1 = *reinterpret_cast<const double2*>(src + 2);
+            As[kq + 0][i] = v0.x;
+            As[kq + 1][i] = v0.y;
+            As[kq + 2][i] = v1.x;
+            As[kq + 3][i] = v1.y;
+        } else {  // A stored (K,M): rows contiguous along i
+            const int k = t >> 4, iq = (t & 15) * 4;
+            const double* src = A + (long)(k0 + k) * g.lda + i0 + iq;
+            const double2 v0 = *reinterpret_cast<const double2*>(src);
+            const double2 v1 = *reinterpret_cast<const double2*>(src + 2);
+            *reinterpret_cast<double2*>(&As[k][iq]) = v0;
+            *reinterpret_cast<double2*>(&As[k][iq + 2]) = v1;
+        }
+        if (!TB) {  // B stored (K,N)
+            const int k = t >> 4, jq = (t & 15) * 4;
+            const double* src = B + (long)(k0 + k) * g.ldb + j0 + jq;
+            const double2 v0 = *reinterpret_cast<const double2*>(src);
+            const double2 v1 = *reinterpret_cast<const double2*>(src + 2);
+            *reinterpret_cast<double2*>(&Bs[k][jq]) = v0;
+            *reinterpret_cast<double2*>(&Bs[k][jq + 2]) = v1;
+        } else {  // B stored (N,K)
+            const int j = t >> 2, kq = (t & 3) * 4;
+            const double* src = B + (long)(j0 + j) * g.ldb + k0 + kq;
+            const double2 v0 = *reinterpret_cast<const double2*>(src);
+            const double2 v1 = *reinterpret_cast<const double2*>(src + 2);
+            Bs[kq + 0][j] = v0.x;
+            Bs[kq + 1][j] = v0.y;
+            Bs[kq + 2][j] = v1.x;
+            Bs[kq + 3][j] = v1.y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4) {
+            const double a0 = As[kk + lr][wi + lc];
+            const double a1 = As[kk + lr][wi + 16 + lc];
+            const double b0 = Bs[kk + lr][wj + lc];
+            const double b1 = Bs[kk + lr][wj + 16 + lc];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wi + 16 * ti + lr + 4 * r;
+                const int col = j0 + wj + 16 * tj + lc;
+                double* c = C + (long)row * g.ldc + col;
+                double v = g.alpha * acc[ti][tj][r];
+                if (g.beta != 0.0) v = fma(g.beta, *c, v);
+                *c = v;
+            }
+}
+
+void launch_gemm(hipStream_t st, const GemmDesc& g, bool ta, bool tb, int batch) {
+    if (g.M <= 0 || g.N <= 0) return;
+    dim3 grid(g.N / 64, g.M / 64, batch);
+    if (!ta && !tb) hipLaunchKernelGGL((k_gemm64<false, false>), grid, dim3(256), 0, st, g);
+    if (!ta && tb) hipLaunchKernelGGL((k_gemm64<false, true>), grid, dim3(256), 0, st, g);
+    if (ta && !tb) hipLaunchKernelGGL((k_gemm64<true, false>), grid, dim3(256), 0, st, g);
+    if (ta && tb) hipLaunchKernelGGL((k_gemm64<true, true>), grid, dim3(256), 0, st, g);
+}
+
+// ------------------------------------------------------------------ Cholesky
+// Factor the kb-th 64x64 diagonal block in LDS (unblocked, 2 barriers per
+// column), write L_kk back, and invert it (one wave, one column per lane).
+// replaces tf.linalg.cholesky at pilco/models/mgpr.py:84 / smgpr.py:29,35
+__global__ __launch_bounds__(256) void k_potf2_inv(double* __restrict__ Aall, int npad, int kb,
+                                                   double* __restrict__ invD, int* __restrict__ info) {
+    __shared__ double Ls[64][65];
+    __shared__ double Xs[64][65];
+    const int b = blockIdx.x;
+    const int nblk = npad / 64;
+    double* A = Aall + (long)b * npad * npad + (long)kb * 64 * npad + kb * 64;
+    const int t = threadIdx.x;
+    for (int e = t; e < 4096; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        Ls[i][j] = A[(long)i * npad + j];
+    }
+    const int ri = t >> 2, cq = t & 3;
+    for (int j = 0; j < 64; ++j) {
+        __syncthreads();
+        double d = Ls[j][j];
+        if (!(d > 0.0)) {  // also catches NaN
+            if (t == 0) atomicCAS(&info[b], 0, kb * 64 + j + 1);
+            d = 1.0;
+        }
+        const double rinv = 1.0 / sqrt(d);
+        // trailing update of row ri: columns c in (j, ri]
+        if (ri > j) {
+            const double lij = Ls[ri][j] * rinv;
+            for (int c = j + 1 + cq; c <= ri; c += 4) Ls[ri][c] = fma(-lij, Ls[c][j] * rinv, Ls[ri][c]);
+        }
+        __syncthreads();
+        if (t < 64 && t >= j) Ls[t][j] = (t == j) ? d * rinv : Ls[t][j] * rinv;
+    }
+    __syncthreads();
+    for (int e = t; e < 4096; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        A[(long)i * npad + j] = (j <= i) ? Ls[i][j] : 0.0;
+    }
+    // inverse of the lower-triangular block: lane j solves column j by forward substitution
+    if (t < 64) {
+        const int j = t;
+        for (int i = 0; i < 64; ++i) {
+            double x;
+            if (i < j) {
+                x = 0.0;
+            } else if (i == j) {
+                x = 1.0 / Ls[j][j];
+            } else {
+                double sum = 0.0;
+                for (int k = j; k < i; ++k) sum = fma(Ls[i][k], Xs[k][j], sum);
+                x = -sum / Ls[i][i];
+            }
+            Xs[i][j] = x;
+        }
+    }
+    __syncthreads();
+    double* out = invD + ((long)b * nblk + kb) * 4096;
+    for (int e = t; e < 4096; e += 256) out[e] = Xs[e >> 6][e & 63];
+}
+
+void launch_potrf(hipStream_t st, double* A, int npad, int batch, double* invD, int* info) {
+    const int nblk = npad / 64;
+    const long sA = (long)npad * npad;
+    for (int kb = 0; kb < nblk; ++kb) {
+        hipLaunchKernelGGL(k_potf2_inv, dim3(batch), dim3(256), 0, st, A, npad, kb, invD, info);
+        const int rem = nblk - kb - 1;
+        if (rem <= 0) break;
+        double* panel = A + (long)(kb + 1) * 64 * npad + kb * 64;
+        GemmDesc p{};  // panel <- panel * inv(L_kk)^T
+        p.A = panel; p.lda = npad; p.sA = sA;
+        p.B = invD + (long)kb * 4096; p.ldb = 64; p.sB = (long)nblk * 4096;
+        p.C = panel; p.ldc = npad; p.sC = sA;
+        p.M = rem * 64; p.N = 64; p.K = 64; p.alpha = 1.0; p.beta = 0.0; p.tile_mode = 0; p.k_mode = 0;
+        launch_gemm(st, p, false, true, batch);
+        GemmDesc u{};  // trailing (lower tiles) -= panel * panel^T
+        u.A = panel; u.lda = npad; u.sA = sA;
+        u.B = panel; u.ldb = npad; u.sB = sA;
+        u.C = A + (long)(kb + 1) * 64 * npad + (kb + 1) * 64; u.ldc = npad; u.sC = sA;
+        u.M = rem * 64; u.N = rem * 64; u.K = 64; u.alpha = -1.0; u.beta = 1.0; u.tile_mode = 1; u.k_mode = 0;
+        launch_gemm(st, u, false, true, batch);
+    }
+}
+
+// ------------------------------------------------------------------ triangular inverse
+__global__ void k_copy_block(const double* __restrict__ src, long s_src, double* __restrict__ dst, int ldd, long s_dst) {
+    const int b = blockIdx.x;
+    const double* s = src + (long)b * s_src;
+    double* d = dst + (long)b * s_dst;
+    for (int e = threadIdx.x; e < 4096; e += blockDim.x) d[(long)(e >> 6) * ldd + (e & 63)] = s[e];
+}
+
+void launch_trtri(hipStream_t st, const double* L, int npad, int batch, const double* invD, double* Linv, double* T) {
+    const int nblk = npad / 64;
+    const long sA = (long)npad * npad;
+    (void)hipMemsetAsync(Linv, 0, sizeof(double) * sA * batch, st);
+    for (int I = 0; I < nblk; ++I) {
+        hipLaunchKernelGGL(k_copy_block, dim3(batch), dim3(256), 0, st, invD + (long)I * 4096, (long)nblk * 4096,
+                           Linv + (long)I * 64 * npad + I * 64, npad, sA);
+        if (I == 0) continue;
+        GemmDesc a{};  // T = L[I, 0:I] * Linv[0:I, 0:I]
+        a.A = L + (long)I * 64 * npad; a.lda = npad; a.sA = sA;
+        a.B = Linv; a.ldb = npad; a.sB = sA;
+        a.C = T; a.ldc = npad; a.sC = (long)64 * npad;
+        a.M = 64; a.N = I * 64; a.K = I * 64; a.alpha = 1.0; a.beta = 0.0; a.tile_mode = 0; a.k_mode = 2;
+        launch_gemm(st, a, false, false, batch);
+        GemmDesc c{};  // Linv[I, 0:I] = -inv(L_II) * T
+        c.A = invD + (long)I * 4096; c.lda = 64; c.sA = (long)nblk * 4096;
+        c.B = T; c.ldb = npad; c.sB = (long)64 * npad;
+        c.C = Linv + (long)I * 64 * npad; c.ldc = npad; c.sC = sA;
+        c.M = 64; c.N = I * 64; c.K = 64; c.alpha = -1.0; c.beta = 0.0; c.tile_mode = 0; c.k_mode = 0;
+        launch_gemm(st, c, false, false, batch);
+    }
+}
+
+// ------------------------------------------------------------------ mat-vec, padding
+__global__ __launch_bounds__(256) void k_matvec(const double* __restrict__ A, int npad, const double* __restrict__ x,
+                                                double* __restrict__ y, int trans) {
+    const int b = blockIdx.y;
+    const double* Ab = A + (long)b * npad * npad;
+    const double* xb = x + (long)b * npad;
+    if (trans) {  // y[j] = sum_i A[i][j] x[i]; one thread per column, coalesced across lanes
+        const int j = blockIdx.x * 256 + threadIdx.x;
+        if (j >= npad) return;
+        double s = 0.0;
+        for (int i = 0; i < npad; ++i) s = fma(Ab[(long)i * npad + j], xb[i], s);
+        y[(long)b * npad + j] = s;
+    } else {  // y[i] = sum_j A[i][j] x[j]; one wave per row
+        const int lane = threadIdx.x & 63;
+        const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (i >= npad) return;
+        double s = 0.0;
+        for (int j = lane; j < npad; j += 64) s = fma(Ab[(long)i * npad + j], xb[j], s);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if (lane == 0) y[(long)b * npad + i] = s;
+    }
+}
+
+void launch_matvec(hipStream_t st, const double* A, int npad, int batch, const double* x, double* y, bool trans) {
+    dim3 grid(trans ? (npad + 255) / 256 : (npad + 3) / 4, batch);
+    hipLaunchKernelGGL(k_matvec, grid, dim3(256), 0, st, A, npad, x, y, trans ? 1 : 0);
+}
+
+__global__ void k_clear_padding(double* __restrict__ A, int npad, int n) {
+    const int b = blockIdx.z;
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= npad) return;
+    if (i >= n || j >= n) A[((long)b * npad + i) * npad + j] = 0.0;
+}
+
+void launch_clear_padding(hipStream_t st, double* A, int npad, int n, int batch) {
+    if (n == npad) return;
+    hipLaunchKernelGGL(k_clear_padding, dim3((npad + 255) / 256, npad, batch), dim3(256), 0, st, A, npad, n);
+}
+
+}  // namespace pilco

@@ -1,0 +1,100 @@
+// Device-side descriptors of the moment-matching step (internal).
+#pragma once
+#include "common.h"
+
+namespace pilco {
+
+constexpr int MAX_REWARD_TERMS = 4;
+constexpr int MAX_D = 32;  // GP input dimension supported by the register-tiled kernels
+
+// One GP as the moment-matching kernels see it (all device pointers).
+struct MMModel {
+    const double* Pt;    // [D][npad]  points, transposed (training inputs X, inducing Z, or RBF centres)
+    const double* ls;    // [E][D]
+    const double* var;   // [E]
+    const double* beta;  // [E][npad]  zero padded
+    const double* iK;    // [E][npad][npad] zero padded, or nullptr (== 0: RbfController, controllers.py:116)
+    int n, npad, D, E;
+};
+
+// Per-slot workspace of one step.
+struct MMWork {
+    double* in_m;        // [D]      input mean  (joint state-action mean)
+    double* in_s;        // [D][D]   input covariance
+    double* At;          // [PL][KP][npad]  row-side operand   (2 Q z_i | u_i | 1 | 0..)
+    double* Bt;          // [PL][KP][npad]  column-side operand (w_j   | 1 | v_j | 0..)
+    double* pair_isdet;  // [PL]     1/sqrt(det R_ab)
+    double* T;           // [E][D][D] (s + Lambda_a^2)^{-1}
+    double* c;           // [E]      sigma_f,a^2 / sqrt(det B_a)
+    double* mean_part;   // [E][NCH][1+D]
+    double* pair_part;   // [PL][NT][2]
+    double* gath;        // [nranks][SEG]  packed per-rank results (all-gather buffer)
+    double* out_M;       // [E]
+    double* out_S;       // [E][E]
+    double* out_V;       // [D][E]
+    const int* pair_list;     // [PL] global pair index p = a(a+1)/2 + b of every local pair
+    const int* own_outputs;   // [EL] outputs whose diagonal pair is local
+    const int* asm_pair_src;  // [P]  index into gath of the pair's value
+    const int* asm_out_src;   // [E]  index into gath of M_a (V_a follows)
+    int PL, EL, P, KP, NCH, NT, SEG, OUTOFF, rank, nranks;  // OUTOFF: offset of the output records inside a segment
+};
+
+struct RewardDev {
+    int kind;
+    double coef;
+    const double* W;  // device
+    const double* t;  // device (never null: zeros if the caller passed NULL)
+};
+
+enum GlueFlags {
+    GF_PACK = 1,       // reduce tile partials of the local pairs/outputs into gath[rank]
+    GF_ASSEMBLE = 2,   // gath -> out_M, out_S, out_V
+    GF_PROPAGATE = 4,  // state <- state + GP increment (pilco.py:147-149)
+    GF_TRAJ = 8,       // store state into traj[step]
+    GF_REWARD = 16,    // reward accumulator += mean reward of the current state
+    GF_POLICY = 32,    // controller + joint Gaussian -> in_m, in_s, s1 (pilco.py:139-144)
+    GF_RBF_POST = 64,  // RBF policy: S -= diag(var - 1e-6), squash, joint (controllers.py:116-121)
+    GF_RBF_PRE = 128   // RBF policy: copy the state into the policy slot's input
+};
+
+struct GlueArgs {
+    int flags;
+    int E;  // state dim
+    int D;  // GP input dim = E + U
+    int U;
+    MMWork wk;          // dynamics slot workspace
+    const double* var;  // dynamics kernel variances [E]
+    MMWork pwk;         // policy slot workspace (RBF policy only)
+    const double* pvar; // policy kernel variances [U]
+    // rollout state
+    double* m_x;     // [E]
+    double* s_x;     // [E][E]
+    double* s1;      // [E][D]  = [s_x, s_x c_xu], kept for propagate
+    double* reward;  // [1]
+    double* traj;    // [(H+1)][E + E*E] or nullptr
+    int step;
+    // policy
+    int pol_kind;
+    const double* W;       // [U][E]
+    const double* b;       // [U]
+    const double* maxact;  // [U]
+    int squash;
+    int n_rewards;
+    RewardDev rw[MAX_REWARD_TERMS];
+    // direct outputs of pilco_policy_action / pilco_reward_eval (optional)
+    double* act_out;  // [U + U*U + E*U]
+    double* rew_out;  // [2]
+};
+
+void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk);
+// variant 0 = MFMA, 1 = VALU
+void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int variant);
+void launch_glue(hipStream_t st, const GlueArgs& g);
+size_t glue_lds_bytes(int E, int D);
+// tile-partial counts per pair for a variant (NT) and the number of row chunks of the prep kernel
+int mm_pair_nt(int npad, int variant, int PL);
+int mm_prep_nch(int npad, int PL);
+int mm_kp(int D);
+int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf);
+
+}  // namespace pilco

@@ -1,0 +1,249 @@
+"""GPU parity tests (run through gpurun: pytest -m gpu).  Every test calls the
+HIP path through the C ABI (ctypes) and compares with the CPU oracle / golden
+fixtures.  Tolerance: 1e-5 relative (north_star); the reference's own tests use
+1e-4 (tests/test_predictions.py:61-63) and 2e-4 (tests/test_cascade.py:77-78)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import tf_path as tp
+from pilco_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pilco_amd import _lib
+    c = _lib.get_context()
+    return c
+
+
+def _mgpr(cfg, cls=None, **kw):
+    from pilco_amd.models import MGPR
+    cls = cls or MGPR
+    m = cls((cfg["X"], cfg["Y"]), **kw)
+    for i, mdl in enumerate(m.models):
+        mdl.kernel.lengthscales.assign(cfg["lengthscales"][i])
+        mdl.kernel.variance.assign(cfg["variance"][i])
+        mdl.likelihood.variance.assign(cfg["noise"][i])
+    return m
+
+
+def test_selftest_mfma_layout(ctx):
+    ctx.selftest()
+
+
+def test_gram_matches_oracle(ctx):
+    c = synthetic.config_c1()
+    m = _mgpr(c)
+    K = m.K(c["X"])
+    Ko = tp.se_ard_K(c["X"], None, c["lengthscales"], c["variance"])
+    np.testing.assert_allclose(K, Ko, rtol=1e-12, atol=1e-15)
+    X2 = np.random.RandomState(1).rand(37, 3)
+    np.testing.assert_allclose(m.K(c["X"], X2), tp.se_ard_K(c["X"], X2, c["lengthscales"], c["variance"]),
+                               rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("N", [100, 257])
+def test_factorization_matches_oracle(ctx, N):
+    rs = np.random.RandomState(N)
+    X = rs.randn(N, 4)
+    Y = np.sin(X) @ rs.randn(4, 3) + 1e-2 * rs.randn(N, 3)
+    cfg = dict(X=X, Y=Y, lengthscales=1.0 + rs.rand(3, 4), variance=0.5 + rs.rand(3), noise=np.array([1e-2, 3e-3, 1e-3]))
+    m = _mgpr(cfg)
+    iK, beta = m.calculate_factorizations()
+    iKo, betao = tp.calculate_factorizations(X, Y, cfg["lengthscales"], cfg["variance"], cfg["noise"])
+    assert iK.shape == iKo.shape and beta.shape == betao.shape
+    for a in range(3):
+        assert np.linalg.norm(iK[a] - iKo[a]) / np.linalg.norm(iKo[a]) < 1e-9
+        assert np.linalg.norm(beta[a] - betao[a]) / np.linalg.norm(betao[a]) < 1e-9
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("name", ["predictions.npz", "predictions_lownoise.npz"])
+def test_predictions_golden(ctx, golden_dir, name, variant):
+    """BASELINE config 1 = tests/test_predictions.py (set_data between two predicts included)."""
+    g = np.load(os.path.join(golden_dir, name))
+    ctx.set_pair_kernel(variant)
+    try:
+        cfg = dict(X=g["X_first"], Y=g["Y"], lengthscales=g["lengthscales"], variance=g["variance"], noise=g["noise"])
+        m = _mgpr(cfg)
+        M0, S0, V0 = m.predict_on_noisy_inputs(g["m"], g["s"])
+        m.set_data((g["X"], g["Y"]))  # no stale cache (test_predictions.py:33-37)
+        M, S, V = m.predict_on_noisy_inputs(g["m"], g["s"])
+        assert M.shape == g["M"].shape and S.shape == g["S"].shape and V.shape == g["V"].shape
+        assert not np.allclose(M0, M)
+        rtol = RTOL if "lownoise" not in name else 1e-4
+        np.testing.assert_allclose(M, g["M"], rtol=rtol)
+        np.testing.assert_allclose(S, g["S"], rtol=rtol)
+        np.testing.assert_allclose(V, g["V"], rtol=rtol)
+    finally:
+        ctx.set_pair_kernel(0)
+
+
+def test_predict_given_factorizations_roundtrip(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "predictions.npz"))
+    cfg = dict(X=g["X"], Y=g["Y"], lengthscales=g["lengthscales"], variance=g["variance"], noise=g["noise"])
+    m = _mgpr(cfg)
+    iK, beta = tp.calculate_factorizations(g["X"], g["Y"], g["lengthscales"], g["variance"], g["noise"])
+    M, S, V = m.predict_given_factorizations(g["m"], g["s"], iK, beta)
+    np.testing.assert_allclose(M, g["M"], rtol=RTOL)
+    np.testing.assert_allclose(S, g["S"], rtol=RTOL)
+    np.testing.assert_allclose(V, g["V"], rtol=RTOL)
+    # zeroed iK (RbfController.compute_action, controllers.py:116)
+    Mz, Sz, Vz = m.predict_given_factorizations(g["m"], g["s"], 0.0 * iK, beta)
+    Mo, So, Vo = tp.predict_given_factorizations(g["X"], g["lengthscales"], g["variance"], g["m"], g["s"], 0.0 * iK, beta)
+    np.testing.assert_allclose(Sz, So, rtol=RTOL)
+    # and the cached factorisation is restored afterwards
+    M2, S2, V2 = m.predict_on_noisy_inputs(g["m"], g["s"])
+    np.testing.assert_allclose(S2, g["S"], rtol=RTOL)
+
+
+def test_zero_covariance_input(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "predictions.npz"))
+    cfg = dict(X=g["X"], Y=g["Y"], lengthscales=g["lengthscales"], variance=g["variance"], noise=g["noise"])
+    m = _mgpr(cfg)
+    s0 = np.zeros((3, 3))
+    M, S, V = m.predict_on_noisy_inputs(g["m"], s0)
+    iK, beta = tp.calculate_factorizations(g["X"], g["Y"], g["lengthscales"], g["variance"], g["noise"])
+    Mo, So, Vo = tp.predict_given_factorizations(g["X"], g["lengthscales"], g["variance"], g["m"], s0, iK, beta)
+    np.testing.assert_allclose(M, Mo, rtol=RTOL)
+    np.testing.assert_allclose(S, So, rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(V, Vo, rtol=RTOL)
+
+
+def _pilco_from(cfg, horizon):
+    from pilco_amd.models import PILCO
+    p = PILCO((cfg["X"], cfg["Y"]), horizon=horizon)
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(cfg["lengthscales"][i])
+        mdl.kernel.variance.assign(cfg["variance"][i])
+        mdl.likelihood.variance.assign(cfg["noise"][i])
+    return p
+
+
+def test_cascade_golden(ctx, golden_dir):
+    """tests/test_cascade.py: H=10 rollout, LinearController, max_action=[[10]] vs pred.m."""
+    g = np.load(os.path.join(golden_dir, "cascade.npz"))
+    H = int(g["horizon"])
+    cfg = {k: g[k] for k in ("X", "Y", "lengthscales", "variance", "noise")}
+    p = _pilco_from(cfg, H)
+    p.controller.W.assign(g["W"])
+    p.controller.b.assign(g["b"])
+    p.controller.max_action = g["max_action"]
+    M, S, R, traj = p.predict_trajectory(g["m"], g["s"], H)
+    np.testing.assert_allclose(M[0], g["M_traj"][:, -1], rtol=RTOL)
+    np.testing.assert_allclose(S, g["S_traj"][:, :, -1], rtol=RTOL)
+    for t in range(H + 1):
+        np.testing.assert_allclose(traj[t, :2], g["M_traj"][:, t], rtol=RTOL)
+        np.testing.assert_allclose(traj[t, 2:].reshape(2, 2), g["S_traj"][:, :, t], rtol=RTOL)
+    model = tp.Model(g["X"], g["Y"], g["lengthscales"], g["variance"], g["noise"])
+    ctrl = lambda m, s: tp.linear_controller(m, s, g["W"], g["b"], g["max_action"])
+    Mo, So, Ro = tp.predict(model, ctrl, tp.exponential_reward, g["m"], g["s"], H, cache=True)
+    np.testing.assert_allclose(R, Ro, rtol=RTOL)
+    # predict == repeated propagate; n = 0 returns the inputs with zero reward
+    m1, s1 = p.propagate(g["m"], g["s"])
+    np.testing.assert_allclose(m1[0], g["M_traj"][:, 1], rtol=RTOL)
+    np.testing.assert_allclose(s1, g["S_traj"][:, :, 1], rtol=RTOL)
+    M0, S0, R0 = p.predict(g["m"], g["s"], 0)
+    assert np.array_equal(M0, g["m"]) and np.array_equal(S0, g["s"]) and R0[0, 0] == 0.0
+    np.testing.assert_allclose(p.compute_reward(), -p.training_loss())
+
+
+def test_controllers_and_reward_golden(ctx, golden_dir):
+    from pilco_amd.controllers import LinearController, squash_sin
+    from pilco_amd.rewards import CombinedRewards, ExponentialReward, LinearReward
+    g = np.load(os.path.join(golden_dir, "linear_controller.npz"))
+    lin = LinearController(3, 2)
+    lin.W.assign(g["W"])
+    lin.b.assign(g["b"])
+    M, S, V = lin.compute_action(g["m"], g["s"], squash=False)
+    assert M.shape == g["M"].shape and S.shape == g["S"].shape and V.shape == g["V"].shape
+    np.testing.assert_allclose(M, g["M"], rtol=1e-12)
+    np.testing.assert_allclose(S, g["S"], rtol=1e-12)
+    np.testing.assert_allclose(V, g["V"], rtol=1e-12)
+    g = np.load(os.path.join(golden_dir, "squash.npz"))
+    M, S, V = squash_sin(g["m"], g["s"], float(g["e"]))
+    np.testing.assert_allclose(M, g["M"], rtol=1e-10)
+    np.testing.assert_allclose(S, g["S"], rtol=1e-10)
+    np.testing.assert_allclose(V, g["V"], rtol=1e-10)
+    g = np.load(os.path.join(golden_dir, "reward.npz"))
+    mu, sr = ExponentialReward(2).compute_reward(g["m"], g["s"])
+    np.testing.assert_allclose(mu[0, 0], g["muR"], rtol=1e-10)
+    np.testing.assert_allclose(sr[0, 0], g["sR"], rtol=1e-8)
+    mu, sr = ExponentialReward(2, W=g["W2"], t=g["t2"]).compute_reward(g["m"], g["s"])
+    np.testing.assert_allclose(mu[0, 0], g["muR2"], rtol=1e-10)
+    np.testing.assert_allclose(sr[0, 0], g["sR2"], rtol=1e-8)
+    W = np.array([0.5, -1.0])
+    comb = CombinedRewards(2, [LinearReward(2, W), ExponentialReward(2)], coefs=[2.0, 0.5])
+    mu_c, s_c = comb.compute_reward(g["m"], g["s"])
+    mu_o, s_o = tp.combined_rewards(g["m"], g["s"], [lambda m, s: tp.linear_reward(m, s, W),
+                                                     lambda m, s: tp.exponential_reward(m, s)], [2.0, 0.5])
+    np.testing.assert_allclose(mu_c, mu_o, rtol=1e-10)
+    np.testing.assert_allclose(s_c, s_o, rtol=1e-8)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_midsize_random_vs_oracle(ctx, variant):
+    c = synthetic.config_c2(N=300, D=5, E=4, noise=1e-2, seed=11, control_dim=1)
+    ctx.set_pair_kernel(variant)
+    try:
+        m = _mgpr(c)
+        rs = np.random.RandomState(3)
+        mm = 0.3 * rs.randn(1, 5)
+        A = 0.3 * rs.randn(5, 5)
+        ss = A @ A.T + 0.05 * np.eye(5)
+        M, S, V = m.predict_on_noisy_inputs(mm, ss)
+        iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+        Mo, So, Vo = tp.predict_given_factorizations(c["X"], c["lengthscales"], c["variance"], mm, ss, iK, beta)
+        np.testing.assert_allclose(M, Mo, rtol=RTOL)
+        np.testing.assert_allclose(S, So, rtol=RTOL, atol=1e-12)
+        np.testing.assert_allclose(V, Vo, rtol=RTOL)
+    finally:
+        ctx.set_pair_kernel(0)
+
+
+def test_full_size_c2_step_and_rollout(ctx):
+    """BASELINE config 2 (N=1000, D=10, E=10): one step and a 3-step rollout vs the oracle."""
+    c = synthetic.config_c2()
+    p = _pilco_from(c, 3)
+    iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+    M, S, V = p.mgpr.predict_on_noisy_inputs(c["m0"], c["S0"])
+    Mo, So, Vo = tp.predict_given_factorizations_pairs(c["X"], c["lengthscales"], c["variance"], c["m0"], c["S0"], iK, beta)
+    np.testing.assert_allclose(M, Mo, rtol=RTOL)
+    np.testing.assert_allclose(S, So, rtol=RTOL, atol=1e-10)
+    np.testing.assert_allclose(V, Vo, rtol=RTOL, atol=1e-12)
+    model = tp.Model(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"], pairs=True)
+    model._cache = (iK, beta)
+    Mo, So, Ro = tp.predict(model, tp.no_controller, tp.exponential_reward, c["m0"], c["S0"], 3, cache=True)
+    Mg, Sg, Rg = p.predict(c["m0"], c["S0"], 3)
+    np.testing.assert_allclose(Mg, Mo, rtol=RTOL)
+    np.testing.assert_allclose(Sg, So, rtol=RTOL, atol=1e-10)
+    np.testing.assert_allclose(Rg, Ro, rtol=RTOL)
+    # bitwise reproducibility of repeated rollouts (fixed-order reductions, no atomics)
+    Mg2, Sg2, Rg2 = p.predict(c["m0"], c["S0"], 3)
+    assert np.array_equal(Mg, Mg2) and np.array_equal(Sg, Sg2) and np.array_equal(Rg, Rg2)
+
+
+def test_set_data_changes_n_and_not_pd_error(ctx):
+    from pilco_amd import NotPositiveDefiniteError
+    c = synthetic.config_c2(N=130, D=4, E=2, seed=5, control_dim=2)
+    m = _mgpr(c)
+    m.predict_on_noisy_inputs(np.zeros((1, 4)), 0.1 * np.eye(4))
+    c2 = synthetic.config_c2(N=70, D=4, E=2, seed=6, control_dim=2)
+    m.set_data((c2["X"], c2["Y"]))
+    M, S, V = m.predict_on_noisy_inputs(np.zeros((1, 4)), 0.1 * np.eye(4))
+    iK, beta = tp.calculate_factorizations(c2["X"], c2["Y"], c["lengthscales"], c["variance"], c["noise"])
+    Mo, So, Vo = tp.predict_given_factorizations(c2["X"], c["lengthscales"], c["variance"], np.zeros((1, 4)), 0.1 * np.eye(4), iK, beta)
+    np.testing.assert_allclose(S, So, rtol=RTOL, atol=1e-12)
+    # duplicated inputs with zero noise: K is singular -> the reference raises from tf.linalg.cholesky
+    Xd = np.vstack([c2["X"][:10], c2["X"][:10]])
+    Yd = np.vstack([c2["Y"][:10], c2["Y"][:10]])
+    m.set_data((Xd, Yd))
+    for mdl in m.models:
+        mdl.likelihood.variance.assign(0.0)
+    with pytest.raises(NotPositiveDefiniteError):
+        m.predict_on_noisy_inputs(np.zeros((1, 4)), 0.1 * np.eye(4))
