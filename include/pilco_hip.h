@@ -44,7 +44,9 @@ int pilco_ctx_destroy(pilco_ctx* ctx);
 const char* pilco_last_error(const pilco_ctx* ctx);
 /* index of the output whose Gram matrix was not positive definite (-1 if none) */
 int pilco_last_not_pd_output(const pilco_ctx* ctx);
-/* 0 = MFMA pair kernel (default), 1 = plain-VALU pair kernel (same results to rounding) */
+/* pair-kernel variant: 0 = MFMA, stream-K work split (default, fastest; run-to-run bitwise stable);
+ * 1 = plain-VALU tiled reference; 2 = MFMA tiled (bits also independent of the number of ranks).
+ * All three agree to rounding. */
 int pilco_set_pair_kernel(pilco_ctx* ctx, int variant);
 /* checks the f64 MFMA fragment layout assumptions on the device; 0 = OK */
 int pilco_selftest(pilco_ctx* ctx);

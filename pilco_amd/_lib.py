@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpilco_hip.so")
+LIB_PATH = os.environ.get("PILCO_LIB", os.path.join(_HERE, "libpilco_hip.so"))
 
 PILCO_OK = 0
 STATUS_NAMES = {1: "PILCO_E_SHAPE", 2: "PILCO_E_NOT_PD", 3: "PILCO_E_HIP", 4: "PILCO_E_RCCL",

@@ -46,6 +46,7 @@ struct pilco_ctx {
     DevBuf params;  // policy + reward parameters
     DevBuf traj;
     DevBuf selftest;
+    DevBuf exp_tab;  // 2^(j/64), j = 0..63
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> pair_events;
 };
@@ -92,24 +93,10 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     const int P = E * (E + 1) / 2;
     const int W = ctx->nranks, rank = ctx->rank;
     s.pair_owner = deal_pairs(E, W);
-    std::vector<int> pair_list, own_outputs;
-    std::vector<std::vector<int>> lists(W), outs(W);
-    for (int a = 0; a < E; ++a) {  // same order as deal_pairs so list order is deterministic
-        const int p = a * (a + 1) / 2 + a;
-        lists[s.pair_owner[p]].push_back(p);
-        outs[s.pair_owner[p]].push_back(a);
-    }
-    for (int a = 0; a < E; ++a)
-        for (int b = 0; b < a; ++b) {
-            const int p = a * (a + 1) / 2 + b;
-            lists[s.pair_owner[p]].push_back(p);
-        }
-    pair_list = lists[rank];
-    own_outputs = outs[rank];
     const int PLcap = (P + W - 1) / W, ELcap = (E + W - 1) / W;
     MMWork& wk = s.wk;
-    wk.PL = (int)pair_list.size();
-    wk.EL = (int)own_outputs.size();
+    wk.PL = (rank < P) ? (P - rank + W - 1) / W : 0;
+    wk.EL = (rank < E) ? (E - rank + W - 1) / W : 0;
     wk.P = P;
     wk.KP = mm_kp(D);
     wk.NCH = mm_prep_nch(npad, std::max(wk.PL, 1));
@@ -118,35 +105,71 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.SEG = PLcap + ELcap * (1 + D);
     wk.rank = rank;
     wk.nranks = W;
-    std::vector<int> asm_pair(P), asm_out(E);
-    for (int r = 0; r < W; ++r) {
-        for (size_t k = 0; k < lists[r].size(); ++k) asm_pair[lists[r][k]] = r * wk.SEG + (int)k;
-        for (size_t o = 0; o < outs[r].size(); ++o) asm_out[outs[r][o]] = r * wk.SEG + wk.OUTOFF + (int)o * (1 + D);
+    const int PLa = std::max(wk.PL, 1);
+    // stream-K geometry (variant 0)
+    wk.sk_waves = 0;
+    std::vector<int> wl(PLa, 0), wh(PLa, -1);
+    if (ctx->variant == 0 && wk.PL > 0) {
+        int tdiag, toff;
+        mm_pair_sk_steps(npad, &tdiag, &toff);
+        // local pairs kk = pl*W + rank are diagonal (kk < E) first; they stream iK unless it is absent
+        int nd = 0;
+        if (!s.iK_null)
+            for (int pl = 0; pl < wk.PL; ++pl)
+                if (pl * W + rank < E) ++nd;
+        if (s.iK_null) tdiag = toff;
+        const long T = (long)nd * tdiag + (long)(wk.PL - nd) * toff;
+        int waves = mm_pair_sk_capacity(wk.KP);
+        if ((long)waves > T) waves = (int)std::max<long>(4, (T + 3) / 4 * 4);
+        wk.sk_waves = waves;
+        wk.sk_total = (int)T;
+        wk.sk_nd = nd;
+        wk.sk_tdiag = tdiag;
+        wk.sk_toff = toff;
+        wk.sk_ud = 3;
+        wk.sk_uo = 2;
+        if (const char* env = getenv("PILCO_SK_UNITS")) {
+            int a = 0, b = 0;
+            if (sscanf(env, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { wk.sk_ud = a; wk.sk_uo = b; }
+        }
+        const int nd_steps = nd * tdiag;
+        std::vector<int> bnd(waves + 1);
+        for (int w = 0; w <= waves; ++w) bnd[w] = mm_sk_boundary(w, waves, nd_steps, (int)T, wk.sk_ud, wk.sk_uo);
+        auto wave_of = [&](long x) {  // the last wave whose first step is <= x and which is not empty before x
+            int lo = 0, hi = waves - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) / 2;
+                if (bnd[mid] <= x) lo = mid; else hi = mid - 1;
+            }
+            return lo;
+        };
+        for (int k = 0; k < wk.PL; ++k) {
+            const long S0 = (k < nd) ? (long)k * tdiag : (long)nd * tdiag + (long)(k - nd) * toff;
+            const long S1 = S0 + ((k < nd) ? tdiag : toff);
+            wl[k] = wave_of(S0);
+            wh[k] = wave_of(S1 - 1);
+        }
     }
-    // int lists on the device: pair_list | own_outputs | asm_pair | asm_out
     std::vector<int> all;
-    all.insert(all.end(), pair_list.begin(), pair_list.end());
-    all.insert(all.end(), own_outputs.begin(), own_outputs.end());
-    all.insert(all.end(), asm_pair.begin(), asm_pair.end());
-    all.insert(all.end(), asm_out.begin(), asm_out.end());
-    if (all.size() > s.lists_cap) {
+    all.insert(all.end(), wl.begin(), wl.end());
+    all.insert(all.end(), wh.begin(), wh.end());
+    const size_t n_int = all.size() + (size_t)2 * std::max(wk.sk_waves, 4);
+    if (n_int > s.lists_cap) {
         if (s.d_lists) (void)hipFree(s.d_lists);
         s.d_lists = nullptr;
-        HIPCHK(hipMalloc(&s.d_lists, all.size() * sizeof(int)));
-        s.lists_cap = all.size();
+        HIPCHK(hipMalloc(&s.d_lists, n_int * sizeof(int)));
+        s.lists_cap = n_int;
     }
     HIPCHK(hipMemcpyAsync(s.d_lists, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));  // `all` is a stack vector
-    wk.pair_list = s.d_lists;
-    wk.own_outputs = s.d_lists + pair_list.size();
-    wk.asm_pair_src = wk.own_outputs + own_outputs.size();
-    wk.asm_out_src = wk.asm_pair_src + P;
-    const int PLa = std::max(wk.PL, 1);
+    wk.sk_wlo = s.d_lists;
+    wk.sk_whi = s.d_lists + PLa;
+    wk.sk_pidx = s.d_lists + 2 * PLa;
     ENSURE(s.w_in, (size_t)D + D * D);
     ENSURE(s.w_At, (size_t)PLa * wk.KP * npad);
     ENSURE(s.w_Bt, (size_t)PLa * wk.KP * npad);
     ENSURE(s.w_small, (size_t)PLa + (size_t)E * D * D + E + (size_t)E * wk.NCH * (1 + D));
-    ENSURE(s.w_part, (size_t)PLa * wk.NT * 2);
+    ENSURE(s.w_part, std::max((size_t)PLa * wk.NT * 2, (size_t)2 * std::max(wk.sk_waves, 4)));
     ENSURE(s.w_gath, (size_t)W * wk.SEG);
     ENSURE(s.w_out, (size_t)E + E * E + D * E);
     wk.in_m = s.w_in.p;
@@ -158,13 +181,109 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.c = wk.T + (size_t)E * D * D;
     wk.mean_part = wk.c + E;
     wk.pair_part = s.w_part.p;
+    wk.sk_part = s.w_part.p;
     wk.gath = s.w_gath.p;
     wk.out_M = s.w_out.p;
     wk.out_S = wk.out_M + E;
     wk.out_V = wk.out_S + E * E;
+    wk.exp_tab = ctx->exp_tab.p;
     HIPCHK(hipMemsetAsync(s.w_gath.p, 0, sizeof(double) * W * wk.SEG, ctx->st));
     s.wk_valid = true;
     s.wk_variant = ctx->variant;
+    return PILCO_OK;
+}
+
+// W (E x E, symmetric PSD) = F F^T with F (E x rank) from a cyclic Jacobi eigen-decomposition.
+// Returns rank, or -1 when W is not symmetric PSD (the general pivoted device path is used then).
+int psd_factor(const double* W, int E, std::vector<double>& F) {
+    double scale = 0.0;
+    for (int i = 0; i < E * E; ++i) scale = std::max(scale, std::fabs(W[i]));
+    if (scale == 0.0) { F.clear(); return 0; }
+    for (int i = 0; i < E; ++i)
+        for (int j = 0; j < i; ++j)
+            if (std::fabs(W[i * E + j] - W[j * E + i]) > 1e-13 * scale) return -1;
+    std::vector<double> A(W, W + E * E), V(E * E, 0.0);
+    for (int i = 0; i < E; ++i) V[i * E + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int i = 0; i < E; ++i)
+            for (int j = 0; j < i; ++j) off += A[i * E + j] * A[i * E + j];
+        if (off <= 1e-32 * scale * scale) break;
+        for (int p = 0; p < E; ++p)
+            for (int q = p + 1; q < E; ++q) {
+                const double apq = A[p * E + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * E + q] - A[p * E + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < E; ++k) {
+                    const double akp = A[k * E + p], akq = A[k * E + q];
+                    A[k * E + p] = c * akp - sn * akq;
+                    A[k * E + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < E; ++k) {
+                    const double apk = A[p * E + k], aqk = A[q * E + k];
+                    A[p * E + k] = c * apk - sn * aqk;
+                    A[q * E + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < E; ++k) {
+                    const double vkp = V[k * E + p], vkq = V[k * E + q];
+                    V[k * E + p] = c * vkp - sn * vkq;
+                    V[k * E + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    double lmax = 0.0;
+    for (int i = 0; i < E; ++i) lmax = std::max(lmax, A[i * E + i]);
+    for (int i = 0; i < E; ++i)
+        if (A[i * E + i] < -1e-12 * std::max(lmax, scale)) return -1;
+    std::vector<int> keep;
+    for (int i = 0; i < E; ++i)
+        if (A[i * E + i] > 1e-15 * lmax) keep.push_back(i);
+    const int r = (int)keep.size();
+    F.assign((size_t)E * std::max(r, 1), 0.0);
+    for (int k = 0; k < r; ++k) {
+        const double sq = std::sqrt(A[keep[k] * E + keep[k]]);
+        for (int e = 0; e < E; ++e) F[(size_t)e * r + k] = V[e * E + keep[k]] * sq;
+    }
+    return r;
+}
+
+// marshal reward terms into a host staging vector; pointers are patched relative to dev_base
+int stage_rewards(pilco_ctx* ctx, const pilco_reward_term* rw, int n_rw, int E, std::vector<double>& hp, size_t& off,
+                  const double* dev_base, RewardDev* out) {
+    for (int i = 0; i < n_rw; ++i) {
+        out[i].kind = rw[i].kind;
+        out[i].coef = rw[i].coef;
+        out[i].F = nullptr;
+        out[i].rank = -1;
+        if (!rw[i].W) return fail(ctx, PILCO_E_SHAPE, "reward: W is required");
+        if (rw[i].kind == PILCO_REWARD_EXPONENTIAL) {
+            hp.resize(std::max(hp.size(), off + (size_t)2 * E * E + E));
+            memcpy(&hp[off], rw[i].W, sizeof(double) * E * E);
+            out[i].W = dev_base + off; off += (size_t)E * E;
+            if (rw[i].t) memcpy(&hp[off], rw[i].t, sizeof(double) * E);
+            else std::fill(hp.begin() + off, hp.begin() + off + E, 0.0);
+            out[i].t = dev_base + off; off += E;
+            std::vector<double> F;
+            const int r = psd_factor(rw[i].W, E, F);
+            out[i].rank = r;
+            if (r > 0) {
+                memcpy(&hp[off], F.data(), sizeof(double) * E * r);
+                out[i].F = dev_base + off;
+            } else if (r == 0) {
+                out[i].F = dev_base + off;
+            }
+            off += (size_t)E * E;
+        } else if (rw[i].kind == PILCO_REWARD_LINEAR) {
+            hp.resize(std::max(hp.size(), off + (size_t)E));
+            memcpy(&hp[off], rw[i].W, sizeof(double) * E);
+            out[i].W = dev_base + off; off += E;
+            out[i].t = out[i].W;
+        } else {
+            return fail(ctx, PILCO_E_SHAPE, "reward: unknown kind");
+        }
+    }
     return PILCO_OK;
 }
 
@@ -255,8 +374,17 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
         delete ctx;
         return PILCO_E_HIP;
     }
+    {
+        double tab[64];
+        for (int j = 0; j < 64; ++j) tab[j] = std::exp2((double)j / 64.0);
+        if (ctx->exp_tab.ensure(64) != hipSuccess ||
+            hipMemcpy(ctx->exp_tab.p, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) {
+            delete ctx;
+            return PILCO_E_HIP;
+        }
+    }
     const char* env = getenv("PILCO_PAIR_KERNEL");
-    if (env) ctx->variant = (atoi(env) == 1) ? 1 : 0;
+    if (env) ctx->variant = (atoi(env) >= 0 && atoi(env) <= 2) ? atoi(env) : 0;
     *out = ctx;
     return PILCO_OK;
 }
@@ -277,6 +405,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     ctx->params.release();
     ctx->traj.release();
     ctx->selftest.release();
+    ctx->exp_tab.release();
     for (hipEvent_t e : ctx->pair_events) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -290,7 +419,7 @@ const char* pilco_last_error(const pilco_ctx* ctx) { return ctx ? ctx->err.c_str
 int pilco_last_not_pd_output(const pilco_ctx* ctx) { return ctx ? ctx->not_pd : -1; }
 
 int pilco_set_pair_kernel(pilco_ctx* ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 1) return PILCO_E_SHAPE;
+    if (!ctx || variant < 0 || variant > 2) return PILCO_E_SHAPE;
     ctx->variant = variant;
     return PILCO_OK;
 }
@@ -300,8 +429,9 @@ int pilco_selftest(pilco_ctx* ctx) {
     HIPCHK(hipSetDevice(ctx->device));
     ENSURE(ctx->selftest, 256);
     double h[256];
-    const int r = launch_selftest_mfma(ctx->st, ctx->selftest.p, h);
+    const int r = launch_selftest_mfma(ctx->st, ctx->selftest.p, h, ctx->exp_tab.p);
     if (r < 0) return fail(ctx, PILCO_E_HIP, "selftest launch failed");
+    if (r == 100000) return fail(ctx, PILCO_E_STATE, "table-driven exp deviates from the library exp by more than 2 ulp");
     if (r > 0) return fail(ctx, PILCO_E_STATE, "f64 MFMA fragment layout differs from the assumed map at element " + std::to_string(r - 1));
     return PILCO_OK;
 }
@@ -310,7 +440,7 @@ int pilco_gp_set_data(pilco_ctx* ctx, int slot, const double* X, const double* Y
     if (int r = check_slot(ctx, slot)) return r;
     if (!X || !Y || N <= 0 || D <= 0 || E <= 0) return fail(ctx, PILCO_E_SHAPE, "set_data: bad sizes");
     if (D > MAX_D) return fail(ctx, PILCO_E_SHAPE, "set_data: GP input dimension > 32 not supported by this build");
-    if (E > 64) return fail(ctx, PILCO_E_SHAPE, "set_data: more than 64 outputs not supported by this build");
+    if (E > MAX_D) return fail(ctx, PILCO_E_SHAPE, "set_data: more than 32 outputs not supported by this build");
     HIPCHK(hipSetDevice(ctx->device));
     Slot& s = ctx->slot[slot];
     const bool reshape = (D != s.D || E != s.E);
@@ -482,6 +612,7 @@ int pilco_gp_set_factors(pilco_ctx* ctx, int slot, const double* iK, const doubl
     s.iK_null = (iK == nullptr);
     s.factor_valid = true;
     s.user_factors = true;
+    s.wk_valid = false;  // the stream-K geometry depends on whether an iK stream exists
     return PILCO_OK;
 }
 
@@ -497,7 +628,8 @@ int pilco_gp_predict(pilco_ctx* ctx, int slot, const double* m, const double* s_
     HIPCHK(hipMemcpyAsync(s.wk.in_s, s_in, sizeof(double) * D * D, hipMemcpyHostToDevice, ctx->st));
     const MMModel md = model_of(s);
     if (s.wk.PL > 0) {
-        launch_mm_prep(ctx->st, md, s.wk);
+        RewardArgs none{};
+        launch_mm_prep(ctx->st, md, s.wk, none);
         launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
     }
     GlueArgs g{};
@@ -524,6 +656,7 @@ namespace {
 
 struct RolloutPlan {
     GlueArgs g{};
+    RewardArgs ra{};
     int E = 0, D = 0, U = 0;
 };
 
@@ -544,8 +677,8 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
     // state: m_x[E] s_x[E*E] s1[E*D] reward[1] act_out[U+U*U+E*U] rew_out[2]
     const size_t n_state = (size_t)E + E * E + (size_t)E * D + 1 + (U + U * U + (size_t)E * U) + 2;
     ENSURE(ctx->state, n_state);
-    // params: W[U*E] b[U] maxact[U] then per reward W[E*E] t[E]
-    const size_t n_par = (size_t)U * E + 2 * U + (size_t)MAX_REWARD_TERMS * (E * E + E) + 8;
+    // params: W[U*E] b[U] maxact[U] then per reward W[E*E] t[E] F[E*E]
+    const size_t n_par = (size_t)U * E + 2 * U + (size_t)MAX_REWARD_TERMS * (2 * E * E + E) + 8;
     ENSURE(ctx->params, n_par);
     if (want_traj) ENSURE(ctx->traj, (size_t)(H + 1) * (E + E * E));
     std::vector<double> hp(n_par, 0.0);
@@ -570,25 +703,15 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
         for (int u = 0; u < U; ++u) hp[off + u] = pol->max_action ? pol->max_action[u] : 1.0;
         g.maxact = ctx->params.p + off; off += U;
     }
-    g.n_rewards = n_rw;
-    for (int i = 0; i < n_rw; ++i) {
-        g.rw[i].kind = rw[i].kind;
-        g.rw[i].coef = rw[i].coef;
-        if (rw[i].kind == PILCO_REWARD_EXPONENTIAL) {
-            if (!rw[i].W) return fail(ctx, PILCO_E_SHAPE, "rollout: exponential reward needs W");
-            memcpy(&hp[off], rw[i].W, sizeof(double) * E * E);
-            g.rw[i].W = ctx->params.p + off; off += (size_t)E * E;
-            if (rw[i].t) memcpy(&hp[off], rw[i].t, sizeof(double) * E);
-            g.rw[i].t = ctx->params.p + off; off += E;
-        } else if (rw[i].kind == PILCO_REWARD_LINEAR) {
-            if (!rw[i].W) return fail(ctx, PILCO_E_SHAPE, "rollout: linear reward needs W");
-            memcpy(&hp[off], rw[i].W, sizeof(double) * E);
-            g.rw[i].W = ctx->params.p + off; off += E;
-            g.rw[i].t = ctx->params.p + off;
-        } else {
-            return fail(ctx, PILCO_E_SHAPE, "rollout: unknown reward kind");
-        }
-    }
+    RewardArgs& ra = plan.ra;
+    ra = RewardArgs{};
+    ra.n = n_rw;
+    ra.E = E;
+    ra.m_x = g.m_x;
+    ra.s_x = g.s_x;
+    ra.reward_acc = g.reward;
+    if (int r = stage_rewards(ctx, rw, n_rw, E, hp, off, ctx->params.p, ra.rw)) return r;
+    if (hp.size() > n_par) return fail(ctx, PILCO_E_ALLOC, "rollout: parameter staging overflow");
     HIPCHK(hipMemcpyAsync(ctx->params.p, hp.data(), sizeof(double) * n_par, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));  // hp is a local vector
     plan.E = E; plan.D = D; plan.U = U;
@@ -602,18 +725,18 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
     GlueArgs g = plan.g;
     HIPCHK(hipMemsetAsync(g.reward, 0, sizeof(double), ctx->st));
     g.step = 0;
-    g.flags = GF_TRAJ | (H > 0 ? (GF_REWARD | GF_POLICY) : 0);
+    g.flags = GF_TRAJ | (H > 0 ? GF_POLICY : 0);
     launch_glue(ctx->st, g);
     size_t evi = 0;
     for (int t = 0; t < H; ++t) {
         if (s.wk.PL > 0) {
-            launch_mm_prep(ctx->st, md, s.wk);
+            launch_mm_prep(ctx->st, md, s.wk, plan.ra);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
             launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
         }
         g.step = t + 1;
-        const int tail = GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ | (t + 1 < H ? (GF_REWARD | GF_POLICY) : 0);
+        const int tail = GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ | (t + 1 < H ? GF_POLICY : 0);
         if (ctx->nranks == 1) {
             g.flags = GF_PACK | tail;
             launch_glue(ctx->st, g);
@@ -704,7 +827,7 @@ int pilco_reward_eval(pilco_ctx* ctx, const pilco_reward_term* rewards, int n_re
         return fail(ctx, PILCO_E_SHAPE, "reward_eval: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
     const int E = state_dim;
-    const size_t n = (size_t)E + E * E + (size_t)n_rewards * (E * E + E) + 2;
+    const size_t n = (size_t)E + E * E + (size_t)n_rewards * (2 * E * E + E) + 2;
     ENSURE(ctx->state, n + 8);
     std::vector<double> h(n, 0.0);
     memcpy(&h[0], m, sizeof(double) * E);
@@ -715,26 +838,13 @@ int pilco_reward_eval(pilco_ctx* ctx, const pilco_reward_term* rewards, int n_re
     g.m_x = ctx->state.p;
     g.s_x = g.m_x + E;
     g.n_rewards = n_rewards;
-    for (int i = 0; i < n_rewards; ++i) {
-        g.rw[i].kind = rewards[i].kind;
-        g.rw[i].coef = rewards[i].coef;
-        if (!rewards[i].W) return fail(ctx, PILCO_E_SHAPE, "reward_eval: W is required");
-        if (rewards[i].kind == PILCO_REWARD_EXPONENTIAL) {
-            memcpy(&h[off], rewards[i].W, sizeof(double) * E * E);
-            g.rw[i].W = ctx->state.p + off; off += (size_t)E * E;
-            if (rewards[i].t) memcpy(&h[off], rewards[i].t, sizeof(double) * E);
-            g.rw[i].t = ctx->state.p + off; off += E;
-        } else if (rewards[i].kind == PILCO_REWARD_LINEAR) {
-            memcpy(&h[off], rewards[i].W, sizeof(double) * E);
-            g.rw[i].W = ctx->state.p + off; off += E;
-            g.rw[i].t = g.rw[i].W;
-        } else {
-            return fail(ctx, PILCO_E_SHAPE, "reward_eval: unknown reward kind");
-        }
-    }
+    if (int r = stage_rewards(ctx, rewards, n_rewards, E, h, off, ctx->state.p, g.rw)) return r;
+    if (h.size() < off + 2) h.resize(off + 2, 0.0);
+    ENSURE(ctx->state, h.size() + 8);
+    if (g.m_x != ctx->state.p) return fail(ctx, PILCO_E_ALLOC, "reward_eval: staging buffer moved");
     g.rew_out = ctx->state.p + off;
     g.flags = GF_REWARD;
-    HIPCHK(hipMemcpyAsync(ctx->state.p, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(ctx->state.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->st));
     launch_glue(ctx->st, g);
     double o[2];
     HIPCHK(hipMemcpyAsync(o, g.rew_out, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->st));

@@ -32,10 +32,17 @@ struct MMWork {
     double* out_M;       // [E]
     double* out_S;       // [E][E]
     double* out_V;       // [D][E]
-    const int* pair_list;     // [PL] global pair index p = a(a+1)/2 + b of every local pair
-    const int* own_outputs;   // [EL] outputs whose diagonal pair is local
-    const int* asm_pair_src;  // [P]  index into gath of the pair's value
-    const int* asm_out_src;   // [E]  index into gath of M_a (V_a follows)
+    // Ownership is closed-form: pairs are dealt round-robin in the order
+    // (0,0),(1,1),..,(E-1,E-1),(1,0),(2,0),(2,1),(3,0).. : order index kk -> rank kk % nranks,
+    // local index kk / nranks; output a belongs to the owner of (a,a).
+    // stream-K decomposition of the MFMA pair kernel (variant 0)
+    double* sk_part;     // [sk_waves][2] per-wave partial of the (at most two) pairs a wave touches
+    int* sk_pidx;        // [sk_waves][2] local pair index of each partial (-1 = none)
+    const int* sk_wlo;   // [PL] first wave touching the local pair
+    const int* sk_whi;   // [PL] last wave touching the local pair
+    int sk_waves, sk_total, sk_nd, sk_tdiag, sk_toff;
+    int sk_ud, sk_uo;    // cost units of a diagonal / off-diagonal column step (diagonal steps also stream iK)
+    const double* exp_tab;    // [64] 2^(j/64), for the table-driven fp64 exp of the pair kernel
     int PL, EL, P, KP, NCH, NT, SEG, OUTOFF, rank, nranks;  // OUTOFF: offset of the output records inside a segment
 };
 
@@ -44,6 +51,19 @@ struct RewardDev {
     double coef;
     const double* W;  // device
     const double* t;  // device (never null: zeros if the caller passed NULL)
+    const double* F;  // device [E][rank]: W = F F^T (symmetric PSD W), or nullptr
+    int rank;         // >= 0: factored fast path; -1: general pivoted path
+};
+
+// Reward of the current state, evaluated by one extra workgroup of the prep launch
+// (off the critical path of the step) and accumulated into reward_acc.
+struct RewardArgs {
+    int n;            // number of terms (0 = no reward workgroup)
+    int E;
+    RewardDev rw[MAX_REWARD_TERMS];
+    const double* m_x;
+    const double* s_x;
+    double* reward_acc;
 };
 
 enum GlueFlags {
@@ -86,15 +106,19 @@ struct GlueArgs {
     double* rew_out;  // [2]
 };
 
-void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk);
-// variant 0 = MFMA, 1 = VALU
+void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const RewardArgs& ra);
+// variant 0 = MFMA stream-K, 1 = VALU (tiled), 2 = MFMA tiled (bits independent of the rank count)
 void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int variant);
+// stream-K geometry: resident waves of the MFMA pair kernel for this KP, and the per-pair step counts
+int mm_pair_sk_capacity(int KP);
+void mm_pair_sk_steps(int npad, int* tdiag, int* toff);
+int mm_sk_boundary(int w, int waves, int nd_steps, int total, int ud, int uo);
 void launch_glue(hipStream_t st, const GlueArgs& g);
 size_t glue_lds_bytes(int E, int D);
 // tile-partial counts per pair for a variant (NT) and the number of row chunks of the prep kernel
 int mm_pair_nt(int npad, int variant, int PL);
 int mm_prep_nch(int npad, int PL);
 int mm_kp(int D);
-int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf);
+int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf, const double* exp_tab);
 
 }  // namespace pilco

@@ -2,36 +2,98 @@
 // gfx950 kernels per horizon step:
 //
 //   k_mm_prep  : per output pair (a,b): R_ab, det R_ab, Q_ab = R^{-1} s / 2 by a
-//                pivoted Gauss-Jordan in LDS; then the O(N D^2) per-row vectors
-//                of Appendix B (u_i, p_i = 2 Q z_i | w_j, v_j) written k-major so
-//                the pair kernel reads MFMA fragments with 128-byte segments;
-//                diagonal pairs also do the mean / input-output covariance sums
-//                (mgpr.py:102-118).
+//                register-resident Gauss-Jordan in one wave (column per lane,
+//                v_readlane broadcasts, no LDS, no barriers); then the O(N D^2)
+//                per-row vectors of Appendix B (u_i, p_i = 2 Q z_i | w_j, v_j)
+//                written k-major so the pair kernel reads MFMA fragments with
+//                128-byte segments; diagonal pairs also do the mean / input-output
+//                covariance sums (mgpr.py:102-118).  One extra workgroup of the
+//                same launch evaluates the reward of the current state
+//                (rewards.py:32-39), off the step's critical path.
 //   k_mm_pair  : the O(N^2) part (mgpr.py:120-144): exponent tile = A^T B on
 //                v_mfma_f64_16x16x4_f64 with K = D+2 (u and v folded into the
-//                contraction), fp64 exp, beta-weighted reduction and, for a == b,
-//                the streamed iK tile.  No atomics: one partial per tile, summed
-//                in a fixed order => bitwise reproducible.
+//                contraction), table-driven fp64 exp, beta-weighted reduction and,
+//                for a == b, the streamed iK tile.  No atomics: one partial per
+//                tile, summed in a fixed order => bitwise reproducible.
 //   k_glue     : one workgroup: tile-partial reduction, S assembly
-//                (mgpr.py:145-147), propagate (pilco.py:147-149), reward
-//                (rewards.py:32-39), controller + joint Gaussian for the next step
-//                (controllers.py:13-58, pilco.py:139-144).
+//                (mgpr.py:145-147), propagate (pilco.py:147-149), controller +
+//                joint Gaussian for the next step (controllers.py:13-58,
+//                pilco.py:139-144).
 #include "moment.h"
 
 namespace pilco {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void decode_pair(int p, int& a, int& b) {
-    a = 0;
-    while ((a + 1) * (a + 2) / 2 <= p) ++a;
-    b = p - a * (a + 1) / 2;
+// local pair index -> outputs (a >= b); see the dealing order in moment.h
+__device__ __forceinline__ void local_pair_ab(const MMWork& wk, int E, int pl, int& a, int& b) {
+    const int kk = pl * wk.nranks + wk.rank;
+    if (kk < E) {
+        a = b = kk;
+        return;
+    }
+    const int q = kk - E;
+    a = 1;
+    while (a * (a + 1) / 2 <= q) ++a;
+    b = q - a * (a - 1) / 2;
+}
+__device__ __forceinline__ int pair_order_index(int E, int a, int b) {  // a >= b
+    return (a == b) ? a : E + a * (a - 1) / 2 + b;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Table-driven fp64 exp for the pair kernel: x = (64 m + j) ln2/64 + r,
+// exp(x) = 2^m * T[j] * (1 + r + r^2/2 + ... + r^5/120), |r| <= ln2/128 so the
+// degree-5 tail is < 4e-17.  n = rint(64 x / ln2) comes out of the low mantissa
+// bits of x*C + 1.5*2^52 (no cvt), 2^m is an integer add into the exponent field.
+// Inputs below -700 are clamped (result ~1e-304 instead of 0); the exponents of
+// this path are bounded above by log(var_a var_b).  The reduction uses a single
+// ln2/64 constant: its rounding contributes |x| * 1.1e-16 relative error, the same
+// size as the rounding of the exponent x itself.  Split into three phases so that a
+// wave keeps all its table reads in flight while it evaluates the polynomials.
+#define FEXP_C 92.332482616893656758       /* 64 / ln2 */
+#define FEXP_MAGIC 6755399441055744.0      /* 1.5 * 2^52 */
+#define FEXP_LN2_64 0.010830424696249145   /* ln2 / 64 */
+
+__device__ __forceinline__ double fexp_clamp(double x) {
+    double y;
+    const double lo = -700.0;
+    asm("v_max_f64 %0, %1, %2" : "=v"(y) : "v"(x), "s"(lo));  // one instruction: no canonicalising pre-max
+    return y;
+}
+__device__ __forceinline__ double fexp_t(double x) { return fma(x, FEXP_C, FEXP_MAGIC); }
+__device__ __forceinline__ double fexp_poly(double x, double t) {
+    const double nf = t - FEXP_MAGIC;
+    const double r = fma(nf, -FEXP_LN2_64, x);
+    double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    q = fma(r, q, 1.0 / 6.0);
+    q = fma(r, q, 0.5);
+    q = fma(r, q, 1.0);
+    return r * q;
+}
+__device__ __forceinline__ double fexp_finish(double tv, double pm1, double t) {
+    const double res = fma(tv, pm1, tv);
+    const int lo = __double2loint(t) & ~63;
+    int hi;
+    asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(hi) : "v"(lo), "v"(__double2hiint(res)));  // exponent += n >> 6
+    return __hiloint2double(hi, __double2loint(res));
+}
+__device__ __forceinline__ double fexp(double x, const double* __restrict__ tab) {
+    x = fexp_clamp(x);
+    const double t = fexp_t(x);
+    const double tv = tab[__double2loint(t) & 63];
+    return fexp_finish(tv, fexp_poly(x, t), t);
 }
 
 // Pivoted Gauss-Jordan on an n x nc augmented matrix held in LDS (row-major,
 // ld = nc), ping-ponging between two buffers: one barrier per pivot step.
 // Called by the whole workgroup.  Returns the buffer holding [I | A^{-1} B];
-// det = det(A) (valid in every thread).
+// det = det(A) (valid in every thread).  General (slow) path.
 __device__ double* gauss_jordan(double* G0, double* G1, int n, int nc, double& det) {
     double* cur = G0;
     double* nxt = G1;
@@ -69,25 +131,199 @@ __device__ double* gauss_jordan(double* G0, double* G1, int n, int nc, double& d
     return cur;
 }
 
+// Unpivoted Gauss-Jordan by the FIRST WAVE on an n x nc (nc <= 64) matrix in
+// LDS, lane = column; for symmetric positive definite (or diagonally similar to
+// SPD) systems.  LDS operations of one wave execute in order, so no barriers are
+// needed inside.  det is returned through LDS slot *det_slot after the barrier.
+__device__ void gj_lds_wave(double* A, int n, int nc, double* det_slot) {
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        const bool on = c < nc;
+        double det = 1.0;
+        for (int k = 0; k < n; ++k) {
+            const double piv = A[k * nc + k];
+            det *= piv;
+            const double pk = on ? A[k * nc + c] / piv : 0.0;
+            for (int r = 0; r < n; ++r) {
+                if (r == k) continue;
+                const double f = A[r * nc + k];
+                const double v = on ? A[r * nc + c] : 0.0;
+                if (on) A[r * nc + c] = fma(-f, pk, v);
+            }
+            if (on) A[k * nc + c] = pk;
+            asm volatile("" ::: "memory");
+        }
+        if (c == 0) *det_slot = det;
+    }
+    __syncthreads();
+}
+
+// Unpivoted Gauss-Jordan entirely in registers: lane c of one wave holds column c
+// of the DT x 2DT augmented matrix [A | B]; the pivot column is broadcast with
+// v_readlane.  On return lanes DT..2DT-1 hold the columns of A^{-1} B.
+template <int DT>
+__device__ __forceinline__ double gj_wave(double (&a)[DT]) {
+    double det = 1.0;
+#pragma unroll
+    for (int k = 0; k < DT; ++k) {
+        const double piv = readlane_f64(a[k], k);
+        det *= piv;
+        const double pk = a[k] / piv;
+#pragma unroll
+        for (int r = 0; r < DT; ++r) {
+            if (r == k) continue;
+            const double f = readlane_f64(a[r], k);
+            a[r] = fma(-f, pk, a[r]);
+        }
+        a[k] = pk;
+    }
+    return det;
+}
+
+// ------------------------------------------------------------------ rewards
+// exp(-scale q / 2) / sqrt(det(I + scale S W)),  q = d^T W (I + scale S W)^{-1} d,  d = m - t
+// (rewards.py:32-48; scale 1 -> mean, scale 2 -> second moment).  ws: LDS scratch.
+__device__ double exp_reward_moment(const RewardDev& rw, int E, double scale, const double* mx, const double* sx,
+                                    double* ws) {
+    const int t = threadIdx.x;
+    double result;
+    if (rw.rank >= 0) {
+        // W = F F^T: q = y^T (I + scale F^T S F)^{-1} y, y = F^T d; det(I + scale S W) = det(I_r + scale F^T S F)
+        const int r = rw.rank, nc = r + 1;
+        double* y = ws;              // [E]
+        double* SF = y + E;          // [E*E]
+        double* A = SF + E * E;      // [E*(E+1)]
+        double* slot = A + E * (E + 1);
+        for (int k = t; k < r; k += blockDim.x) {
+            double acc = 0.0;
+            for (int e = 0; e < E; ++e) acc = fma(rw.F[e * r + k], mx[e] - rw.t[e], acc);
+            y[k] = acc;
+        }
+        for (int e2 = t; e2 < E * r; e2 += blockDim.x) {
+            const int e = e2 / r, k = e2 - e * r;
+            double acc = 0.0;
+            for (int f = 0; f < E; ++f) acc = fma(sx[e * E + f], rw.F[f * r + k], acc);
+            SF[e2] = acc;
+        }
+        __syncthreads();
+        for (int e2 = t; e2 < r * nc; e2 += blockDim.x) {
+            const int k = e2 / nc, l = e2 - k * nc;
+            double v;
+            if (l < r) {
+                double acc = 0.0;
+                for (int e = 0; e < E; ++e) acc = fma(rw.F[e * r + k], SF[e * r + l], acc);
+                v = fma(scale, acc, (k == l) ? 1.0 : 0.0);
+            } else {
+                v = y[k];
+            }
+            A[e2] = v;
+        }
+        __syncthreads();
+        gj_lds_wave(A, r, nc, slot);
+        if (t == 0) {
+            double q = 0.0;
+            for (int k = 0; k < r; ++k) q = fma(y[k], A[k * nc + r], q);
+            slot[1] = exp(-0.5 * scale * q) / sqrt(slot[0]);
+        }
+        __syncthreads();
+        result = slot[1];
+        __syncthreads();
+    } else {
+        // general W: aug = [(I + scale S W)^T | W^T] -> X^T, X = W (I + scale S W)^{-1}
+        const int nc = 2 * E;
+        double* G0 = ws;
+        double* G1 = G0 + 2 * E * E;
+        double* slot = G1 + 2 * E * E;
+        for (int e = t; e < E * nc; e += blockDim.x) {
+            const int r = e / nc, c = e - r * nc;
+            double v;
+            if (c < E) {
+                double sw = 0.0;  // (S W)[c][r]
+                for (int k = 0; k < E; ++k) sw = fma(sx[c * E + k], rw.W[k * E + r], sw);
+                v = fma(scale, sw, (r == c) ? 1.0 : 0.0);
+            } else {
+                v = rw.W[(c - E) * E + r];
+            }
+            G0[e] = v;
+        }
+        double det;
+        double* res = gauss_jordan(G0, G1, E, nc, det);
+        if (t == 0) {
+            double q = 0.0;
+            for (int r = 0; r < E; ++r) {
+                double acc = 0.0;
+                for (int c = 0; c < E; ++c) acc = fma(res[c * nc + E + r], mx[c] - rw.t[c], acc);
+                q = fma(mx[r] - rw.t[r], acc, q);
+            }
+            slot[0] = exp(-0.5 * scale * q) / sqrt(det);
+        }
+        __syncthreads();
+        result = slot[0];
+        __syncthreads();
+    }
+    return result;
+}
+
+size_t reward_lds_doubles(int E) { return (size_t)E + (size_t)E * E + 4 * (size_t)E * E + (size_t)E * (E + 1) + 16; }
+
+// mean (and variance) of the combined reward at (mx, sx) held in LDS (rewards.py:19-81)
+__device__ void reward_eval(int n, const RewardDev* rws, int E, const double* mx, const double* sx, double* ws,
+                            bool want_var, double& mu_out, double& var_out) {
+    double mu = 0.0, var = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const RewardDev& rw = rws[i];
+        double m_i = 0.0, v_i = 0.0;
+        if (rw.kind == PILCO_REWARD_EXPONENTIAL) {
+            m_i = exp_reward_moment(rw, E, 1.0, mx, sx, ws);
+            if (want_var) v_i = exp_reward_moment(rw, E, 2.0, mx, sx, ws) - m_i * m_i;
+        } else {  // linear: rewards.py:58-61
+            for (int k = 0; k < E; ++k) m_i = fma(mx[k], rw.W[k], m_i);
+            if (want_var)
+                for (int r = 0; r < E; ++r)
+                    for (int c = 0; c < E; ++c) v_i = fma(rw.W[r] * sx[r * E + c], rw.W[c], v_i);
+        }
+        mu = fma(rw.coef, m_i, mu);
+        var = fma(rw.coef * rw.coef, v_i, var);
+    }
+    mu_out = mu;
+    var_out = var;
+}
+
+__device__ void reward_block(const RewardArgs& ra, double* sm) {
+    const int E = ra.E, t = threadIdx.x;
+    double* mx = sm;
+    double* sx = mx + E;
+    double* ws = sx + E * E;
+    if (t < E) mx[t] = ra.m_x[t];
+    for (int e = t; e < E * E; e += blockDim.x) sx[e] = ra.s_x[e];
+    __syncthreads();
+    double mu, var;
+    reward_eval(ra.n, ra.rw, E, mx, sx, ws, false, mu, var);
+    if (t == 0) ra.reward_acc[0] += mu;  // pilco.py:133 (single writer, stream-ordered)
+}
+
 // ------------------------------------------------------------------ prep
 template <int DT>
-__global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk) {
+__global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk, RewardArgs ra) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    if ((int)blockIdx.x == wk.PL) {  // the reward workgroup
+        if (blockIdx.y == 0 && ra.n > 0) reward_block(ra, sm);
+        return;
+    }
     const int D = md.D, npad = md.npad;
     double* s_m = sm;
     double* s_ia2 = s_m + DT;
     double* s_ib2 = s_ia2 + DT;
     double* s_ia = s_ib2 + DT;
-    double* s_s = s_ia + DT;
-    double* s_Q = s_s + DT * DT;
-    double* s_T = s_Q + DT * DT;
-    double* G0 = s_T + DT * DT;
-    double* G1 = G0 + 2 * DT * DT;
-    double* red = G1 + 2 * DT * DT;  // 4 * (DT + 1)
-    const int t = threadIdx.x;
+    double* s_s = s_ia + DT;           // [DT*DT] input covariance (D x D, ld D)
+    double* s_Q = s_s + DT * DT;       // [DT*DT] ld DT
+    double* s_T = s_Q + DT * DT;       // [DT*DT] ld DT
+    double* s_sc = s_T + DT * DT;      // [4] isdet, cfac
+    double* red = s_sc + 4;            // 4 * (DT + 1)
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int pl = blockIdx.x, ch = blockIdx.y;
     int a, b;
-    decode_pair(wk.pair_list[pl], a, b);
+    local_pair_ab(wk, md.E, pl, a, b);
     const bool diag = (a == b);
     if (t < D) {
         s_m[t] = wk.in_m[t];
@@ -98,39 +334,64 @@ __global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk) {
     }
     for (int e = t; e < D * D; e += 256) s_s[e] = wk.in_s[e];
     __syncthreads();
-    const int nc = 2 * D;
-    // [R | s],  R = s diag(la^-2 + lb^-2) + I        (mgpr.py:121-124,129)
-    for (int e = t; e < D * nc; e += 256) {
-        const int r = e / nc, c = e - r * nc;
-        G0[e] = (c < D) ? fma(s_s[r * D + c], s_ia2[c] + s_ib2[c], (r == c) ? 1.0 : 0.0) : s_s[r * D + c - D];
-    }
-    double det;
-    double* res = gauss_jordan(G0, G1, D, nc, det);
-    for (int e = t; e < D * D; e += 256) {
-        const int r = e / D, c = e - r * D;
-        s_Q[r * DT + c] = 0.5 * res[r * nc + D + c];
-    }
-    if (ch == 0 && t == 0) wk.pair_isdet[pl] = 1.0 / sqrt(det);
-    __syncthreads();
-    double cfac = 0.0;
-    if (diag) {
+    if (w == 0) {
+        // [R | s],  R = s diag(la^-2 + lb^-2) + I        (mgpr.py:121-124,129); padded with identity
+        double col[DT];
+        const int c = lane;
+#pragma unroll
+        for (int r = 0; r < DT; ++r) {
+            double v = 0.0;
+            if (c < DT) {
+                v = (r == c) ? 1.0 : 0.0;
+                if (r < D && c < D) v = fma(s_s[r * D + c], s_ia2[c] + s_ib2[c], v);
+            } else if (c < 2 * DT) {
+                const int cc = c - DT;
+                if (r < D && cc < D) v = s_s[r * D + cc];
+            }
+            col[r] = v;
+        }
+        const double det = gj_wave<DT>(col);
+        if (c >= DT && c < DT + D) {
+#pragma unroll
+            for (int r = 0; r < DT; ++r)
+                if (r < D) s_Q[r * DT + (c - DT)] = 0.5 * col[r];
+        }
+        if (lane == 0) {
+            s_sc[0] = 1.0 / sqrt(det);
+            if (ch == 0) wk.pair_isdet[pl] = s_sc[0];
+        }
+    } else if (w == 1 && diag) {
         // [B | I],  B = Lambda^-1 s Lambda^-1 + I; T = Lambda^-1 B^-1 Lambda^-1   (mgpr.py:103-111)
-        for (int e = t; e < D * nc; e += 256) {
-            const int r = e / nc, c = e - r * nc;
-            G0[e] = (c < D) ? fma(s_s[r * D + c], s_ia[r] * s_ia[c], (r == c) ? 1.0 : 0.0) : ((c - D == r) ? 1.0 : 0.0);
+        double col[DT];
+        const int c = lane;
+#pragma unroll
+        for (int r = 0; r < DT; ++r) {
+            double v = 0.0;
+            if (c < DT) {
+                v = (r == c) ? 1.0 : 0.0;
+                if (r < D && c < D) v = fma(s_s[r * D + c], s_ia[r] * s_ia[c], v);
+            } else if (c < 2 * DT) {
+                v = (c - DT == r) ? 1.0 : 0.0;
+            }
+            col[r] = v;
         }
-        double detB;
-        res = gauss_jordan(G0, G1, D, nc, detB);
-        for (int e = t; e < D * D; e += 256) {
-            const int r = e / D, c = e - r * D;
-            const double v = res[r * nc + D + c] * s_ia[r] * s_ia[c];
-            s_T[r * DT + c] = v;
-            if (ch == 0) wk.T[((long)a * D + r) * D + c] = v;
+        const double detB = gj_wave<DT>(col);
+        if (c >= DT && c < DT + D) {
+            const int cc = c - DT;
+#pragma unroll
+            for (int r = 0; r < DT; ++r)
+                if (r < D) {
+                    const double v = col[r] * s_ia[r] * s_ia[cc];
+                    s_T[r * DT + cc] = v;
+                    if (ch == 0) wk.T[((long)a * D + r) * D + cc] = v;
+                }
         }
-        cfac = md.var[a] / sqrt(detB);
-        if (ch == 0 && t == 0) wk.c[a] = cfac;
-        __syncthreads();
+        if (lane == 0) {
+            s_sc[1] = md.var[a] / sqrt(detB);
+            if (ch == 0) wk.c[a] = s_sc[1];
+        }
     }
+    __syncthreads();
     const double logva = log(md.var[a]), logvb = log(md.var[b]);
     const int KP = wk.KP;
     const int rpc = npad / wk.NCH;
@@ -208,7 +469,6 @@ __global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk) {
         }
     }
     if (diag) {
-        const int lane = t & 63, w = t >> 6;
         for (int off = 32; off > 0; off >>= 1) g += __shfl_down(g, off);
         if (lane == 0) red[w * (DT + 1)] = g;
 #pragma unroll
@@ -225,7 +485,11 @@ __global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk) {
     }
 }
 
-size_t prep_lds_bytes(int DT) { return sizeof(double) * (4 * DT + 3 * DT * DT + 4 * DT * DT + 4 * (DT + 1)); }
+size_t prep_lds_bytes(int DT, int E_reward) {
+    const size_t own = (size_t)4 * DT + 3 * (size_t)DT * DT + 4 + 4 * (size_t)(DT + 1);
+    const size_t rew = E_reward > 0 ? reward_lds_doubles(E_reward) : 0;
+    return sizeof(double) * (own > rew ? own : rew);
+}
 
 int mm_kp(int D) { return round_up(D + 2, 4); }
 
@@ -237,11 +501,12 @@ int mm_prep_nch(int npad, int PL) {
     return nch;
 }
 
-void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk) {
-    dim3 grid(wk.PL, wk.NCH);
+void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const RewardArgs& ra) {
+    dim3 grid(wk.PL + (ra.n > 0 ? 1 : 0), wk.NCH);
     const int D = md.D;
+    const int Er = ra.n > 0 ? ra.E : 0;
 #define PREP(DT_)                                                                                          \
-    hipLaunchKernelGGL((k_mm_prep<DT_>), grid, dim3(256), prep_lds_bytes(DT_), st, md, wk)
+    hipLaunchKernelGGL((k_mm_prep<DT_>), grid, dim3(256), prep_lds_bytes(DT_, Er), st, md, wk, ra)
     if (D <= 4) PREP(4);
     else if (D <= 8) PREP(8);
     else if (D <= 12) PREP(12);
@@ -255,86 +520,272 @@ void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk) {
 // Work item of a workgroup: (local pair, 64-row tile, column block); the four
 // waves take consecutive column sub-ranges of JW columns.  Per 16-column step a
 // wave issues 4*KC MFMAs (four 16-row tiles) and 16 exps per lane.
+//
+// a != b : S_num += beta_a,i beta_b,j L_ij; 16 per-row accumulators, beta_a applied at the end.
+// a == b : L_aa and (beta beta^T - iK_a) are symmetric, so only column steps at or right of the
+//          64x64 diagonal block are evaluated (weight 2 right of it): half the exps and half the
+//          iK stream.  S_num += (beta_i beta_j - iK_ij) L_ij, one accumulator per result register.
+#ifndef PAIR_RT
+#define PAIR_RT 4      // 16-row MFMA tiles per wave (rows per work item = 16 * PAIR_RT)
+#endif
+// ablation switches for kernel experiments (tools/): never defined in product builds
+#ifndef PAIR_ABL
+#define PAIR_ABL 0
+#endif
+#if PAIR_ABL == 2
+#define PAIR_ABL_TAB(v) (1.0 + 1e-9 * (double)(__double2loint(tt[i]) & 63))
+#else
+#define PAIR_ABL_TAB(v) (v)
+#endif
+#if PAIR_ABL == 3
+#define PAIR_ABL_MFMA(a_, b_, e_) (d4{e_[0] + a_ * b_, e_[1] - a_, e_[2] + b_, e_[3] * 0.5})
+#else
+#define PAIR_ABL_MFMA(a_, b_, e_) __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, e_, 0, 0, 0)
+#endif
+#ifndef PAIR_MINW
+#define PAIR_MINW 1    // __launch_bounds__ min waves per SIMD for the pair kernel
+#endif
+template <int KC, bool DIAG>
+__device__ __forceinline__ double pair_wave(const double* __restrict__ At, const double* __restrict__ Bt,
+                                            const double* __restrict__ beta_a, const double* __restrict__ beta_b,
+                                            const double* __restrict__ iKa, const double* __restrict__ tab, int npad, int i0,
+                                            int jbeg, int jend, int lane) {
+    constexpr int NE = 4 * PAIR_RT;  // exponent values per lane per 16-column step
+    const int lr = lane >> 4, lc = lane & 15;
+    double af[PAIR_RT][KC];
+#pragma unroll
+    for (int rt = 0; rt < PAIR_RT; ++rt)
+#pragma unroll
+        for (int c = 0; c < KC; ++c) af[rt][c] = At[(long)(4 * c + lr) * npad + i0 + 16 * rt + lc];
+    double acc[NE];
+    double bi[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        acc[i] = 0.0;
+        bi[i] = beta_a[i0 + 16 * (i >> 2) + lr + 4 * (i & 3)];
+    }
+    if (DIAG && jbeg < i0) jbeg = i0;  // columns left of the diagonal block are mirrored by the transposed tile
+    double total = 0.0;
+    // software pipeline: operands of the next column step are loaded while this one is evaluated
+    double bfn[KC], bbn = 0.0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) bfn[c] = 0.0;
+    if (jbeg < jend) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) bfn[c] = Bt[(long)(4 * c + lr) * npad + jbeg + lc];
+        bbn = beta_b[jbeg + lc];
+    }
+    for (int j0 = jbeg; j0 < jend; j0 += 16) {
+        double bf[KC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) bf[c] = bfn[c];
+        const double bb = bbn;
+        double ik[NE];
+        if (DIAG) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i)
+                ik[i] = iKa[(long)(i0 + 16 * (i >> 2) + lr + 4 * (i & 3)) * npad + j0 + lc];
+        }
+        if (PAIR_ABL != 4 && j0 + 16 < jend) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) bfn[c] = Bt[(long)(4 * c + lr) * npad + j0 + 16 + lc];
+            bbn = beta_b[j0 + 16 + lc];
+        }
+        // exponent tiles: C/D layout of the f64 MFMA is col = lane & 15, row = (lane >> 4) + 4 * reg
+        double x[NE], tt[NE], tv[NE], pm[NE];
+#pragma unroll
+        for (int rt = 0; rt < PAIR_RT; ++rt) {
+            d4 e = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < KC; ++c) e = PAIR_ABL_MFMA(af[rt][c], bf[c], e);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[4 * rt + r] = e[r];
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            x[i] = fexp_clamp(x[i]);
+            tt[i] = fexp_t(x[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) tv[i] = PAIR_ABL_TAB(tab[__double2loint(tt[i]) & 63]);
+        __builtin_amdgcn_sched_barrier(0);
+        // Horner stages across all NE elements at once: NE independent fp64 chains per wave
+        double rr[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) rr[i] = fma(tt[i] - FEXP_MAGIC, -FEXP_LN2_64, x[i]);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], 1.0 / 120.0, 1.0 / 24.0);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], pm[i], 1.0 / 6.0);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], pm[i], 0.5);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], pm[i], 1.0);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) pm[i] = rr[i] * pm[i];
+        __builtin_amdgcn_sched_barrier(0);
+#if PAIR_ABL == 1
+#pragma unroll
+        for (int i = 0; i < NE; ++i) { tv[i] = x[i]; pm[i] = 0.0; tt[i] = 0.0; }
+#define FEXP_FINISH(a_, b_, c_) (a_)
+#else
+#define FEXP_FINISH(a_, b_, c_) fexp_finish(a_, b_, c_)
+#endif
+        if (DIAG) {
+            double st[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < NE; ++i)
+                st[i & 3] = fma(fma(bi[i], bb, -ik[i]), FEXP_FINISH(tv[i], pm[i], tt[i]), st[i & 3]);
+            const double wgt = (j0 >= i0 + 16 * PAIR_RT) ? 2.0 : 1.0;
+            total = fma(wgt, (st[0] + st[1]) + (st[2] + st[3]), total);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) acc[i] = fma(bb, FEXP_FINISH(tv[i], pm[i], tt[i]), acc[i]);
+        }
+    }
+    if (!DIAG) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) total = fma(bi[i], acc[i], total);
+    }
+    return total;
+}
+
 template <int KC>
-__global__ __launch_bounds__(256) void k_mm_pair_mfma(MMModel md, MMWork wk, int NJB) {
-    __shared__ double red[8];
+__global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_tiled(MMModel md, MMWork wk, int NJB) {
+    __shared__ double red[4];
+    __shared__ double tab[64];
+    if (threadIdx.x < 64) tab[threadIdx.x] = wk.exp_tab[threadIdx.x];
+    __syncthreads();
     const int npad = md.npad;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int lr = lane >> 4, lc = lane & 15;
     const int jb = blockIdx.x % NJB, ti = blockIdx.x / NJB, pl = blockIdx.y;
     int a, b;
-    decode_pair(wk.pair_list[pl], a, b);
+    local_pair_ab(wk, md.E, pl, a, b);
     const bool diag = (a == b) && (md.iK != nullptr);
     const int KP = wk.KP;
     const double* At = wk.At + (long)pl * KP * npad;
     const double* Bt = wk.Bt + (long)pl * KP * npad;
     const double* beta_a = md.beta + (long)a * npad;
     const double* beta_b = md.beta + (long)b * npad;
-    const int i0 = ti * 64;
+    const int i0 = ti * 16 * PAIR_RT;
     const int JB = npad / NJB, JW = JB / 4;
     const int jbeg = jb * JB + w * JW;
-
-    double af[4][KC];
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int c = 0; c < KC; ++c) af[rt][c] = At[(long)(4 * c + lr) * npad + i0 + 16 * rt + lc];
-    double s1[4][4], s2[4][4];
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s1[rt][r] = 0.0;
-            s2[rt][r] = 0.0;
-        }
-    const double* iKa = diag ? md.iK + (long)a * npad * npad : nullptr;
-
-    for (int j0 = jbeg; j0 < jbeg + JW; j0 += 16) {
-        double bf[KC];
-#pragma unroll
-        for (int c = 0; c < KC; ++c) bf[c] = Bt[(long)(4 * c + lr) * npad + j0 + lc];
-        const double bb = beta_b[j0 + lc];
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            d4 e = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int c = 0; c < KC; ++c) e = __builtin_amdgcn_mfma_f64_16x16x4f64(af[rt][c], bf[c], e, 0, 0, 0);
-            // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double L = exp(e[r]);
-                s1[rt][r] = fma(bb, L, s1[rt][r]);
-                if (diag) {
-                    const int row = i0 + 16 * rt + lr + 4 * r;
-                    s2[rt][r] = fma(iKa[(long)row * npad + j0 + lc], L, s2[rt][r]);
-                }
-            }
-        }
-    }
-    double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = i0 + 16 * rt + lr + 4 * r;
-            t1 = fma(beta_a[row], s1[rt][r], t1);
-            t2 += s2[rt][r];
-        }
-    for (int off = 32; off > 0; off >>= 1) {
-        t1 += __shfl_down(t1, off);
-        t2 += __shfl_down(t2, off);
-    }
-    if (lane == 0) {
-        red[2 * w] = t1;
-        red[2 * w + 1] = t2;
-    }
+    double t1;
+    if (diag)
+        t1 = pair_wave<KC, true>(At, Bt, beta_a, beta_b, md.iK + (long)a * npad * npad, tab, npad, i0, jbeg, jbeg + JW, lane);
+    else
+        t1 = pair_wave<KC, false>(At, Bt, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jbeg + JW, lane);
+    for (int off = 32; off > 0; off >>= 1) t1 += __shfl_down(t1, off);
+    if (lane == 0) red[w] = t1;
     __syncthreads();
     if (threadIdx.x == 0) {
         double* out = wk.pair_part + ((long)pl * wk.NT + ti * NJB + jb) * 2;
-        out[0] = ((red[0] + red[2]) + red[4]) + red[6];
-        out[1] = ((red[1] + red[3]) + red[5]) + red[7];
+        out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+        out[1] = 0.0;  // the trace term is already folded into out[0]
     }
 }
+
+// Stream-K form of the same computation: the column steps of all local (pair, row tile)
+// rows are laid out on one line and cut into sk_waves equal ranges, so that every resident
+// wave does the same number of 16-column steps (no tail, no per-tile launch overhead).
+// A range touches at most two pairs; each wave writes one partial per touched pair.
+// first column step of wave w: the cost line (diagonal steps weigh sk_ud units, the others sk_uo)
+// is cut into sk_waves equal parts; a step belongs to the wave in whose part it starts.
+__host__ __device__ inline int sk_boundary_of(int w, int waves, int nd_steps, int total, int ud, int uo) {
+    const long Ud = (long)nd_steps * ud;
+    const long C = Ud + (long)(total - nd_steps) * uo;
+    const long x = (long)w * C / waves;
+    if (w >= waves) return total;
+    if (x <= Ud) return (int)((x + ud - 1) / ud);
+    return nd_steps + (int)((x - Ud + uo - 1) / uo);
+}
+__device__ __forceinline__ int sk_boundary(const MMWork& wk, int w) {
+    return sk_boundary_of(w, wk.sk_waves, wk.sk_nd * wk.sk_tdiag, wk.sk_total, wk.sk_ud, wk.sk_uo);
+}
+int mm_sk_boundary(int w, int waves, int nd_steps, int total, int ud, int uo) {
+    return sk_boundary_of(w, waves, nd_steps, total, ud, uo);
+}
+
+template <int KC>
+__global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWork wk) {
+    __shared__ double tab[64];
+    if (threadIdx.x < 64) tab[threadIdx.x] = wk.exp_tab[threadIdx.x];
+    __syncthreads();
+    const int npad = md.npad, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int NS = npad / 16;
+    const int KP = wk.KP;
+    const int nd_steps = wk.sk_nd * wk.sk_tdiag;
+    int step = sk_boundary(wk, w);
+    const int end = sk_boundary(wk, w + 1);
+    double out0 = 0.0, out1 = 0.0, cur = 0.0;
+    int p0 = -1, p1 = -1, cur_pl = -1;
+    while (step < end) {
+        int pl, q, ti, sidx, cnt;
+        const bool dg = step < nd_steps;
+        if (dg) {
+            pl = step / wk.sk_tdiag;
+            q = step - pl * wk.sk_tdiag;
+            ti = 0;
+            int c = NS;
+            while (q >= c) {
+                q -= c;
+                ++ti;
+                c -= PAIR_RT;
+            }
+            sidx = ti * PAIR_RT + q;
+            cnt = c - q;
+        } else {
+            const int r = step - nd_steps;
+            pl = wk.sk_nd + r / wk.sk_toff;
+            q = r - (pl - wk.sk_nd) * wk.sk_toff;
+            ti = q / NS;
+            sidx = q - ti * NS;
+            cnt = NS - sidx;
+        }
+        const int seg = (cnt < end - step) ? cnt : (end - step);
+        if (pl != cur_pl) {
+            if (cur_pl >= 0) {  // a range touches at most two pairs
+                out0 = cur;
+                p0 = cur_pl;
+            }
+            cur_pl = pl;
+            cur = 0.0;
+        }
+        int a, b;
+        local_pair_ab(wk, md.E, pl, a, b);
+        const double* At = wk.At + (long)pl * KP * npad;
+        const double* Bt = wk.Bt + (long)pl * KP * npad;
+        const double* beta_a = md.beta + (long)a * npad;
+        const double* beta_b = md.beta + (long)b * npad;
+        const int i0 = ti * 16 * PAIR_RT, jbeg = sidx * 16, jend = jbeg + seg * 16;
+        if (dg)
+            cur += pair_wave<KC, true>(At, Bt, beta_a, beta_b, md.iK + (long)a * npad * npad, tab, npad, i0, jbeg, jend, lane);
+        else
+            cur += pair_wave<KC, false>(At, Bt, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jend, lane);
+        step += seg;
+    }
+    if (cur_pl >= 0) {
+        if (p0 < 0) {
+            out0 = cur;
+            p0 = cur_pl;
+        } else {
+            out1 = cur;
+            p1 = cur_pl;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        out0 += __shfl_down(out0, off);
+        out1 += __shfl_down(out1, off);
+    }
+    if (lane == 0) {
+        wk.sk_part[2 * w] = out0;
+        wk.sk_part[2 * w + 1] = out1;
+        wk.sk_pidx[2 * w] = p0;
+        wk.sk_pidx[2 * w + 1] = p1;
+    }
+}
+
 
 // ------------------------------------------------------------------ pair kernel, plain VALU
 // Reference implementation of the same tile sums without matrix cores: one row
@@ -349,7 +800,7 @@ __global__ __launch_bounds__(256) void k_mm_pair_valu(MMModel md, MMWork wk) {
     const int ncb = npad / 64;
     const int tj = blockIdx.x % ncb, ti = blockIdx.x / ncb, pl = blockIdx.y;
     int a, b;
-    decode_pair(wk.pair_list[pl], a, b);
+    local_pair_ab(wk, md.E, pl, a, b);
     const bool diag = (a == b) && (md.iK != nullptr);
     const int KP = wk.KP;
     const double* At = wk.At + (long)pl * KP * npad;
@@ -398,7 +849,7 @@ __global__ __launch_bounds__(256) void k_mm_pair_valu(MMModel md, MMWork wk) {
 static int pair_njb(int npad, int PL) {
     const int nb = npad / 64;
     int njb = 1;
-    while (njb * 2 <= nb && nb % (njb * 2) == 0 && (long)PL * nb * njb < 1536) njb *= 2;
+    while (njb * 2 <= nb && nb % (njb * 2) == 0 && (long)PL * (npad / (16 * PAIR_RT)) * njb < 1536) njb *= 2;
     const char* env = getenv("PILCO_PAIR_NJB");
     if (env) {
         const int v = atoi(env);
@@ -409,7 +860,45 @@ static int pair_njb(int npad, int PL) {
 
 int mm_pair_nt(int npad, int variant, int PL) {
     if (variant == 1) return ((npad + 255) / 256) * (npad / 64);
-    return (npad / 64) * pair_njb(npad, PL);
+    if (variant == 2) {  // depends on npad only, so the summation order is the same for every rank count
+        const int nb = npad / 64;
+        int njb = 1;
+        while (njb * 2 <= nb && nb % (njb * 2) == 0 && njb < 4) njb *= 2;
+        return (npad / (16 * PAIR_RT)) * njb;
+    }
+    return (npad / (16 * PAIR_RT)) * pair_njb(npad, PL);
+}
+
+void mm_pair_sk_steps(int npad, int* tdiag, int* toff) {
+    const int NS = npad / 16, NTI = npad / (16 * PAIR_RT);
+    *toff = NTI * NS;
+    *tdiag = NTI * NS - PAIR_RT * NTI * (NTI - 1) / 2;
+}
+
+template <int KC>
+static int sk_capacity_of() {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mm_pair_sk<KC>, 256, 0) != hipSuccess || nb <= 0) nb = 2;
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    return nb * cus * 4;
+}
+
+int mm_pair_sk_capacity(int KP) {
+    const char* env = getenv("PILCO_SK_WAVES");
+    if (env && atoi(env) >= 4) return atoi(env) / 4 * 4;
+    switch (KP / 4) {
+        case 1: return sk_capacity_of<1>();
+        case 2: return sk_capacity_of<2>();
+        case 3: return sk_capacity_of<3>();
+        case 4: return sk_capacity_of<4>();
+        case 5: return sk_capacity_of<5>();
+        case 6: return sk_capacity_of<6>();
+        case 7: return sk_capacity_of<7>();
+        case 8: return sk_capacity_of<8>();
+        default: return sk_capacity_of<9>();
+    }
 }
 
 void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int variant) {
@@ -426,21 +915,38 @@ void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int var
 #undef PV
         return;
     }
-    const int NJB = wk.NT / (md.npad / 64);
-    dim3 grid((md.npad / 64) * NJB, wk.PL);
-#define PM(K_) hipLaunchKernelGGL((k_mm_pair_mfma<K_>), grid, dim3(256), 0, st, md, wk, NJB)
-    switch (KP / 4) {
-        case 1: PM(1); break;
-        case 2: PM(2); break;
-        case 3: PM(3); break;
-        case 4: PM(4); break;
-        case 5: PM(5); break;
-        case 6: PM(6); break;
-        case 7: PM(7); break;
-        case 8: PM(8); break;
-        default: PM(9); break;
-    }
+    if (variant == 2) {
+        const int NJB = wk.NT / (md.npad / (16 * PAIR_RT));
+        dim3 grid((md.npad / (16 * PAIR_RT)) * NJB, wk.PL);
+#define PM(K_) hipLaunchKernelGGL((k_mm_pair_tiled<K_>), grid, dim3(256), 0, st, md, wk, NJB)
+        switch (KP / 4) {
+            case 1: PM(1); break;
+            case 2: PM(2); break;
+            case 3: PM(3); break;
+            case 4: PM(4); break;
+            case 5: PM(5); break;
+            case 6: PM(6); break;
+            case 7: PM(7); break;
+            case 8: PM(8); break;
+            default: PM(9); break;
+        }
 #undef PM
+        return;
+    }
+    dim3 grid(wk.sk_waves / 4);
+#define PS(K_) hipLaunchKernelGGL((k_mm_pair_sk<K_>), grid, dim3(256), 0, st, md, wk)
+    switch (KP / 4) {
+        case 1: PS(1); break;
+        case 2: PS(2); break;
+        case 3: PS(3); break;
+        case 4: PS(4); break;
+        case 5: PS(5); break;
+        case 6: PS(6); break;
+        case 7: PS(7); break;
+        case 8: PS(8); break;
+        default: PS(9); break;
+    }
+#undef PS
 }
 
 // ------------------------------------------------------------------ glue (one workgroup)
@@ -452,74 +958,16 @@ struct GlueLds {
     double* cxu;  // [nm*nm]
     double* t1;   // [nm*nm]
     double* t2;   // [nm*nm]
-    double* G0;   // [2*nm*nm]
-    double* G1;   // [2*nm*nm]
-    double* misc; // [64 + 34*34]
+    double* ws;   // reward scratch (standalone reward_eval only) / pack scratch
+    double* misc; // [128]
 };
 
 size_t glue_lds_bytes(int E, int D) {
     const int nm = E > D ? E : D;
-    return sizeof(double) * (size_t)(2 * nm + 9 * nm * nm + 64 + 34 * 34);
-}
-
-// mean (and optionally variance) of exp(-(x-t)^T W (x-t)/2), x ~ N(m, s): rewards.py:32-48
-__device__ double exp_reward_mean(const GlueLds& L, int E, const double* W, const double* tg, double scale) {
-    // aug = [(I + scale*SW)^T | W^T]  ->  X^T with X = W (I + scale*SW)^{-1}
-    const int nc = 2 * E;
-    for (int e = threadIdx.x; e < E * nc; e += blockDim.x) {
-        const int r = e / nc, c = e - r * nc;
-        double v;
-        if (c < E) {
-            double sw = 0.0;  // (S W)[c][r]
-            for (int k = 0; k < E; ++k) sw = fma(L.sx[c * E + k], W[k * E + r], sw);
-            v = fma(scale, sw, (r == c) ? 1.0 : 0.0);
-        } else {
-            v = W[(c - E) * E + r];
-        }
-        L.G0[e] = v;
-    }
-    double det;
-    double* res = gauss_jordan(L.G0, L.G1, E, nc, det);
-    // quad = d X d^T with X^T in res[:, E:]
-    double q = 0.0;
-    if (threadIdx.x == 0) {
-        for (int r = 0; r < E; ++r) {
-            const double dr = L.mx[r] - tg[r];
-            double acc = 0.0;
-            for (int c = 0; c < E; ++c) acc = fma(res[c * nc + E + r], L.mx[c] - tg[c], acc);
-            q = fma(dr, acc, q);
-        }
-        L.misc[0] = exp(-0.5 * scale * q) / sqrt(det);
-    }
-    __syncthreads();
-    const double out = L.misc[0];
-    __syncthreads();
-    return out;
-}
-
-__device__ void reward_eval(const GlueArgs& g, const GlueLds& L, double& mu_out, double& var_out, bool want_var) {
-    const int E = g.E;
-    double mu = 0.0, var = 0.0;
-    for (int i = 0; i < g.n_rewards; ++i) {
-        const RewardDev& rw = g.rw[i];
-        double m_i = 0.0, v_i = 0.0;
-        if (rw.kind == PILCO_REWARD_EXPONENTIAL) {
-            m_i = exp_reward_mean(L, E, rw.W, rw.t, 1.0);
-            if (want_var) {
-                const double r2 = exp_reward_mean(L, E, rw.W, rw.t, 2.0);
-                v_i = r2 - m_i * m_i;
-            }
-        } else {  // linear: rewards.py:58-61
-            for (int k = 0; k < E; ++k) m_i = fma(L.mx[k], rw.W[k], m_i);
-            if (want_var)
-                for (int r = 0; r < E; ++r)
-                    for (int c = 0; c < E; ++c) v_i = fma(rw.W[r] * L.sx[r * E + c], rw.W[c], v_i);
-        }
-        mu = fma(rw.coef, m_i, mu);
-        var = fma(rw.coef * rw.coef, v_i, var);
-    }
-    mu_out = mu;
-    var_out = var;
+    size_t ws = reward_lds_doubles(E);
+    const size_t pack = (size_t)nm * (nm + 2) + 64;
+    if (pack > ws) ws = pack;
+    return sizeof(double) * ((size_t)2 * nm + 5 * (size_t)nm * nm + ws + 128);
 }
 
 // squash_sin on (mu[U], su[U][U]) in place; cdiag[u] = e_u exp(-s_uu/2) cos(m_u)   (controllers.py:13-36)
@@ -539,19 +987,18 @@ __device__ void squash_inplace(const GlueLds& L, int U, const double* maxact, do
         const double eu = maxact ? maxact[t] : 1.0;
         const double ex = exp(-L.su[t * U + t] / 2.0);
         cdiag[t] = eu * ex * cos(L.mu[t]);
-        L.misc[32 + t] = eu * ex * sin(L.mu[t]);
+        L.misc[64 + t] = eu * ex * sin(L.mu[t]);
     }
     __syncthreads();
     for (int e = t; e < U * U; e += blockDim.x) L.su[e] = L.t2[e];
-    if (t < U) L.mu[t] = L.misc[32 + t];
+    if (t < U) L.mu[t] = L.misc[64 + t];
     __syncthreads();
 }
 
 // joint Gaussian of (x,u) from mx,sx,mu,su,cxu in LDS -> in_m, in_s, s1 (pilco.py:141-144)
 __device__ void write_joint(const GlueArgs& g, const GlueLds& L) {
     const int E = g.E, U = g.U, D = g.D, t = threadIdx.x;
-    // sc = s_x c_xu  (E,U)
-    for (int e = t; e < E * U; e += blockDim.x) {
+    for (int e = t; e < E * U; e += blockDim.x) {  // sc = s_x c_xu  (E,U)
         const int r = e / U, u = e - r * U;
         double acc = 0.0;
         for (int k = 0; k < E; ++k) acc = fma(L.sx[r * E + k], L.cxu[k * U + u], acc);
@@ -572,28 +1019,51 @@ __device__ void write_joint(const GlueArgs& g, const GlueLds& L) {
     __syncthreads();
 }
 
-
 // Reduce the tile partials of the local pairs / owned outputs into this rank's
-// segment of the gather buffer.  Fixed summation order (tile index, then chunk
-// index): results do not depend on the number of ranks.
-__device__ void mm_pack(const MMWork& wk, int D, double* scratch) {
+// segment of the gather buffer.  Four lanes per pair sum fixed quarters of the
+// tile list and are combined in a fixed tree: the result does not depend on the
+// number of ranks or on timing.  seg_lds (optional) receives a copy.
+__device__ void mm_pack(const MMWork& wk, int D, int E, double* scratch, double* seg_lds) {
     const int t = threadIdx.x;
     double* seg = wk.gath + (long)wk.rank * wk.SEG;
-    for (int k = t; k < wk.PL; k += blockDim.x) {
-        int a, b;
-        decode_pair(wk.pair_list[k], a, b);
-        const double* part = wk.pair_part + (long)k * wk.NT * 2;
+    for (int base = 0; base < wk.PL; base += 64) {
+        const int k = base + (t >> 2), gq = t & 3;
         double s0 = 0.0, s1 = 0.0;
-        for (int q = 0; q < wk.NT; ++q) {
-            s0 += part[2 * q];
-            s1 += part[2 * q + 1];
+        if (k < wk.PL) {
+            if (wk.sk_waves > 0) {  // stream-K partials: waves wlo..whi, the slot whose pair index matches
+                const int wlo = wk.sk_wlo[k], n = wk.sk_whi[k] - wlo + 1;
+                const int q0 = wlo + (int)((long)n * gq / 4), q1 = wlo + (int)((long)n * (gq + 1) / 4);
+                for (int q = q0; q < q1; ++q) {
+                    const int p0 = wk.sk_pidx[2 * q], p1 = wk.sk_pidx[2 * q + 1];
+                    const double v0 = wk.sk_part[2 * q], v1 = wk.sk_part[2 * q + 1];
+                    if (p0 == k) s0 += v0;
+                    if (p1 == k) s0 += v1;
+                }
+            } else {
+                const double* part = wk.pair_part + (long)k * wk.NT * 2;
+                const int q0 = (int)((long)wk.NT * gq / 4), q1 = (int)((long)wk.NT * (gq + 1) / 4);
+                for (int q = q0; q < q1; ++q) {
+                    s0 += part[2 * q];
+                    s1 += part[2 * q + 1];
+                }
+            }
         }
-        seg[k] = ((a == b) ? (s0 - s1) : s0) * wk.pair_isdet[k];   // mgpr.py:144-145
+        s0 += __shfl_xor(s0, 1);
+        s1 += __shfl_xor(s1, 1);
+        s0 += __shfl_xor(s0, 2);
+        s1 += __shfl_xor(s1, 2);
+        if (k < wk.PL && gq == 0) {
+            int a, b;
+            local_pair_ab(wk, E, k, a, b);
+            const double v = ((a == b) ? (s0 - s1) : s0) * wk.pair_isdet[k];   // mgpr.py:144-145
+            seg[k] = v;
+            if (seg_lds) seg_lds[k] = v;
+        }
     }
     const int W1 = 1 + D;
     for (int e = t; e < wk.EL * W1; e += blockDim.x) {
         const int o = e / W1, idx = e - o * W1;
-        const int a = wk.own_outputs[o];
+        const int a = o * wk.nranks + wk.rank;
         double s = 0.0;
         for (int ch = 0; ch < wk.NCH; ++ch) s += wk.mean_part[((long)a * wk.NCH + ch) * W1 + idx];
         scratch[e] = s;
@@ -601,7 +1071,7 @@ __device__ void mm_pack(const MMWork& wk, int D, double* scratch) {
     __syncthreads();
     for (int e = t; e < wk.EL * W1; e += blockDim.x) {
         const int o = e / W1, idx = e - o * W1;
-        const int a = wk.own_outputs[o];
+        const int a = o * wk.nranks + wk.rank;
         const double ca = wk.c[a];
         double v;
         if (idx == 0) {
@@ -613,21 +1083,23 @@ __device__ void mm_pack(const MMWork& wk, int D, double* scratch) {
             v = ca * acc;                                          // V_a[d]       (mgpr.py:118)
         }
         seg[wk.OUTOFF + e] = v;
+        if (seg_lds) seg_lds[wk.OUTOFF + e] = v;
     }
     __syncthreads();
 }
 
-// gath -> out_M [E], out_S [E][E], out_V [D][E]; also left in LDS (oM, oS, oV)
-__device__ void mm_assemble(const MMWork& wk, const double* var, int D, int E, double* oM, double* oS, double* oV) {
+// gath (global, or its LDS copy when single-rank) -> out_M [E], out_S [E][E], out_V [D][E]; also left in LDS
+__device__ void mm_assemble(const MMWork& wk, const double* src, const double* var, int D, int E, double* oM,
+                            double* oS, double* oV) {
     const int t = threadIdx.x;
     for (int a = t; a < E; a += blockDim.x) {
-        const double v = wk.gath[wk.asm_out_src[a]];
+        const double v = src[(a % wk.nranks) * wk.SEG + wk.OUTOFF + (a / wk.nranks) * (1 + D)];
         oM[a] = v;
         wk.out_M[a] = v;
     }
     for (int e = t; e < D * E; e += blockDim.x) {
         const int d = e / E, a = e - d * E;
-        const double v = wk.gath[wk.asm_out_src[a] + 1 + d];
+        const double v = src[(a % wk.nranks) * wk.SEG + wk.OUTOFF + (a / wk.nranks) * (1 + D) + 1 + d];
         oV[e] = v;
         wk.out_V[e] = v;
     }
@@ -635,7 +1107,8 @@ __device__ void mm_assemble(const MMWork& wk, const double* var, int D, int E, d
     for (int e = t; e < E * E; e += blockDim.x) {
         const int a = e / E, b = e - a * E;
         const int hi = a > b ? a : b, lo = a > b ? b : a;
-        double v = wk.gath[wk.asm_pair_src[hi * (hi + 1) / 2 + lo]];
+        const int kk = pair_order_index(E, hi, lo);
+        double v = src[(kk % wk.nranks) * wk.SEG + kk / wk.nranks];
         if (a == b) v += var[a];                                   // mgpr.py:146
         v = fma(-oM[a], oM[b], v);                                 // mgpr.py:147
         oS[e] = v;
@@ -656,14 +1129,14 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
     L.cxu = L.su + nm * nm;
     L.t1 = L.cxu + nm * nm;
     L.t2 = L.t1 + nm * nm;
-    L.G0 = L.t2 + nm * nm;
-    L.G1 = L.G0 + 2 * nm * nm;
-    L.misc = L.G1 + 2 * nm * nm;
+    L.misc = L.t2 + nm * nm;
+    L.ws = L.misc + 128;
 
-    if (g.flags & GF_PACK) mm_pack(g.wk, D, L.misc + 64);
+    const bool local_asm = (g.flags & GF_PACK) && (g.flags & GF_ASSEMBLE) && g.wk.nranks == 1 && g.wk.SEG <= nm * nm;
+    if (g.flags & GF_PACK) mm_pack(g.wk, D, E, L.ws, local_asm ? L.t2 : nullptr);
     if (g.flags & GF_ASSEMBLE) {
         // oM -> mu, oS -> su, oV -> cxu (LDS scratch reused)
-        mm_assemble(g.wk, g.var, D, E, L.mu, L.su, L.cxu);
+        mm_assemble(g.wk, local_asm ? L.t2 : g.wk.gath, g.var, D, E, L.mu, L.su, L.cxu);
     }
     if (g.flags & GF_PROPAGATE) {
         // t1 = s1 V (E,E); state += increment                      (pilco.py:147-149)
@@ -673,15 +1146,17 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
             for (int k = 0; k < D; ++k) acc = fma(g.s1[r * D + k], L.cxu[k * E + c], acc);
             L.t1[e] = acc;
         }
+        if (t < E) L.mx[t] = L.mu[t] + g.m_x[t];
         __syncthreads();
         for (int e = t; e < E * E; e += blockDim.x) {
             const int r = e / E, c = e - r * E;
-            g.s_x[e] = ((L.su[e] + g.s_x[e]) + L.t1[e]) + L.t1[c * E + r];
+            const double v = ((L.su[e] + g.s_x[e]) + L.t1[e]) + L.t1[c * E + r];
+            L.sx[e] = v;
+            g.s_x[e] = v;
         }
-        if (t < E) g.m_x[t] = L.mu[t] + g.m_x[t];
+        if (t < E) g.m_x[t] = L.mx[t];
         __syncthreads();
-    }
-    if (g.flags & (GF_TRAJ | GF_REWARD | GF_POLICY | GF_RBF_PRE)) {
+    } else if (g.flags & (GF_TRAJ | GF_REWARD | GF_POLICY)) {
         if (t < E) L.mx[t] = g.m_x[t];
         for (int e = t; e < E * E; e += blockDim.x) L.sx[e] = g.s_x[e];
         __syncthreads();
@@ -691,15 +1166,15 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
         if (t < E) dst[t] = L.mx[t];
         for (int e = t; e < E * E; e += blockDim.x) dst[E + e] = L.sx[e];
     }
-    if (g.flags & GF_REWARD) {
+    if (g.flags & GF_REWARD) {  // standalone evaluation (pilco_reward_eval); the rollout uses the prep workgroup
         double mu, var;
-        reward_eval(g, L, mu, var, g.rew_out != nullptr);
+        reward_eval(g.n_rewards, g.rw, E, L.mx, L.sx, L.ws, g.rew_out != nullptr, mu, var);
         if (t == 0) {
             if (g.rew_out) {
                 g.rew_out[0] = mu;
                 g.rew_out[1] = var;
             } else {
-                g.reward[0] += mu;                                  // pilco.py:133
+                g.reward[0] += mu;
             }
         }
         __syncthreads();
@@ -768,7 +1243,30 @@ __global__ void k_selftest_mfma(double* out) {
     for (int r = 0; r < 4; ++r) out[lane * 4 + r] = acc[r];
 }
 
-int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf) {
+// max relative deviation of the table-driven exp from the library exp over [-720, 8]
+__global__ void k_selftest_fexp(const double* tab_g, double* out) {
+    __shared__ double tab[64];
+    if (threadIdx.x < 64) tab[threadIdx.x] = tab_g[threadIdx.x];
+    __syncthreads();
+    double worst = 0.0;
+    for (int i = threadIdx.x; i < 200000; i += blockDim.x) {
+        const double x = -720.0 + 728.0 * ((double)i + 0.37) / 200000.0;
+        const double ref = exp(fmax(x, -700.0));
+        const double got = fexp(x, tab);
+        // allowed: 1 ulp of the result + the |x| eps conditioning of the single-constant reduction
+        const double rel = fabs(got - ref) / ref / (2.3e-16 + 1.2e-16 * fabs(x));
+        worst = fmax(worst, rel);
+    }
+    for (int off = 32; off > 0; off >>= 1) worst = fmax(worst, __shfl_down(worst, off));
+    if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = worst;
+}
+
+int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf, const double* exp_tab) {
+    hipLaunchKernelGGL(k_selftest_fexp, dim3(1), dim3(256), 0, st, exp_tab, dbuf);
+    if (hipMemcpyAsync(hbuf, dbuf, 4 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    for (int w = 0; w < 4; ++w)
+        if (!(hbuf[w] < 1.0)) return 100000;
     hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, st, dbuf);
     if (hipMemcpyAsync(hbuf, dbuf, 256 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;

@@ -62,7 +62,7 @@ def test_factorization_matches_oracle(ctx, N):
         assert np.linalg.norm(beta[a] - betao[a]) / np.linalg.norm(betao[a]) < 1e-9
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("name", ["predictions.npz", "predictions_lownoise.npz"])
 def test_predictions_golden(ctx, golden_dir, name, variant):
     """BASELINE config 1 = tests/test_predictions.py (set_data between two predicts included)."""
@@ -186,7 +186,7 @@ def test_controllers_and_reward_golden(ctx, golden_dir):
     np.testing.assert_allclose(s_c, s_o, rtol=1e-8)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_midsize_random_vs_oracle(ctx, variant):
     c = synthetic.config_c2(N=300, D=5, E=4, noise=1e-2, seed=11, control_dim=1)
     ctx.set_pair_kernel(variant)

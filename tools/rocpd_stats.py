@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd (.db) kernel trace: per-kernel count / total / avg / min / max (us).
+usage: python tools/rocpd_stats.py results.db [out.csv]"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                       f"from kernels group by {name_col} order by sum(end-start) desc").fetchall()
+    total = sum(r[2] for r in rows) or 1
+    lines = ["kernel,calls,total_us,avg_us,min_us,max_us,percent"]
+    for n, c, s, a, mn, mx in rows:
+        short = n.split("(")[0][:90]
+        lines.append(f"\"{short}\",{c},{s/1e3:.1f},{a/1e3:.2f},{mn/1e3:.2f},{mx/1e3:.2f},{100*s/total:.1f}")
+    text = "\n".join(lines)
+    print(text)
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "w").write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()
