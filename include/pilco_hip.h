@@ -137,6 +137,9 @@ int pilco_reward_eval(pilco_ctx* ctx, const pilco_reward_term* rewards, int n_re
 int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
                         const double* m0, const double* S0, int H, int reps, double* mH, double* SH, double* reward,
                         float* ms_total, float* ms_pair, int* n_pair_launches);
+/* Developer aid: the first call (out32 may be NULL) switches on phase timestamps inside the
+ * prep / glue kernels (100 MHz wall clock); later calls copy the 32 slots of the last launch. */
+int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32);
 /* Time `reps` factorisations (invalidating the cache each time): ms per factorisation. */
 int pilco_factorize_timed(pilco_ctx* ctx, int slot, int reps, float* ms_each);
 

@@ -72,6 +72,7 @@ SIGNATURES = {
                                       C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "pilco_factorize_timed": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "pilco_debug_timestamps": (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
     "pilco_comm_unique_id": (C.c_int, [_vp]),
     "pilco_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "pilco_shard_set": (C.c_int, [_vp, C.c_int, C.c_int]),
@@ -316,6 +317,11 @@ class Context:
         ms = C.c_float()
         self._chk(self.lib.pilco_factorize_timed(self.h, slot, int(reps), C.byref(ms)))
         return ms.value
+
+    def debug_timestamps(self, read=True):
+        buf = (C.c_ulonglong * 32)()
+        self._chk(self.lib.pilco_debug_timestamps(self.h, buf if read else None))
+        return list(buf)
 
     # ---- sharding
     def comm_unique_id(self):

@@ -47,6 +47,7 @@ struct pilco_ctx {
     DevBuf traj;
     DevBuf selftest;
     DevBuf exp_tab;  // 2^(j/64), j = 0..63
+    unsigned long long* dbg = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> pair_events;
 };
@@ -105,6 +106,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.SEG = PLcap + ELcap * (1 + D);
     wk.rank = rank;
     wk.nranks = W;
+    wk.abl = getenv("PILCO_ABL") ? atoi(getenv("PILCO_ABL")) : 0;
     const int PLa = std::max(wk.PL, 1);
     // stream-K geometry (variant 0)
     wk.sk_waves = 0;
@@ -168,7 +170,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     ENSURE(s.w_in, (size_t)D + D * D);
     ENSURE(s.w_At, (size_t)PLa * wk.KP * npad);
     ENSURE(s.w_Bt, (size_t)PLa * wk.KP * npad);
-    ENSURE(s.w_small, (size_t)PLa + (size_t)E * D * D + E + (size_t)E * wk.NCH * (1 + D));
+    ENSURE(s.w_small, (size_t)PLa + (size_t)E * wk.NCH * (1 + D));
     ENSURE(s.w_part, std::max((size_t)PLa * wk.NT * 2, (size_t)2 * std::max(wk.sk_waves, 4)));
     ENSURE(s.w_gath, (size_t)W * wk.SEG);
     ENSURE(s.w_out, (size_t)E + E * E + D * E);
@@ -177,9 +179,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.At = s.w_At.p;
     wk.Bt = s.w_Bt.p;
     wk.pair_isdet = s.w_small.p;
-    wk.T = wk.pair_isdet + PLa;
-    wk.c = wk.T + (size_t)E * D * D;
-    wk.mean_part = wk.c + E;
+    wk.mean_part = wk.pair_isdet + PLa;
     wk.pair_part = s.w_part.p;
     wk.sk_part = s.w_part.p;
     wk.gath = s.w_gath.p;
@@ -187,6 +187,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.out_S = wk.out_M + E;
     wk.out_V = wk.out_S + E * E;
     wk.exp_tab = ctx->exp_tab.p;
+    wk.dbg = ctx->dbg;
     HIPCHK(hipMemsetAsync(s.w_gath.p, 0, sizeof(double) * W * wk.SEG, ctx->st));
     s.wk_valid = true;
     s.wk_variant = ctx->variant;
@@ -628,19 +629,23 @@ int pilco_gp_predict(pilco_ctx* ctx, int slot, const double* m, const double* s_
     HIPCHK(hipMemcpyAsync(s.wk.in_s, s_in, sizeof(double) * D * D, hipMemcpyHostToDevice, ctx->st));
     const MMModel md = model_of(s);
     if (s.wk.PL > 0) {
-        RewardArgs none{};
-        launch_mm_prep(ctx->st, md, s.wk, none);
+        launch_mm_prep(ctx->st, md, s.wk);
         launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
     }
     GlueArgs g{};
     g.E = E; g.D = D; g.U = 0;
     g.wk = s.wk;
     g.var = s.var.p;
-    g.flags = GF_PACK;
-    launch_glue(ctx->st, g);
-    if (int r = all_gather_segments(ctx, s)) return r;
-    g.flags = GF_ASSEMBLE;
-    launch_glue(ctx->st, g);
+    if (ctx->nranks == 1) {
+        g.flags = GF_PACK | GF_ASSEMBLE;
+        launch_glue(ctx->st, g);
+    } else {
+        g.flags = GF_PACK;
+        launch_glue(ctx->st, g);
+        if (int r = all_gather_segments(ctx, s)) return r;
+        g.flags = GF_ASSEMBLE;
+        launch_glue(ctx->st, g);
+    }
     HIPCHK(hipMemcpyAsync(M, s.wk.out_M, sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(S, s.wk.out_S, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(V, s.wk.out_V, sizeof(double) * D * E, hipMemcpyDeviceToHost, ctx->st));
@@ -656,7 +661,7 @@ namespace {
 
 struct RolloutPlan {
     GlueArgs g{};
-    RewardArgs ra{};
+    double* st[2] = {nullptr, nullptr};  // double-buffered state: m_x[E] | s_x[E*E]
     int E = 0, D = 0, U = 0;
 };
 
@@ -674,8 +679,8 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
     if (pol->kind < 0 || pol->kind > 2) return fail(ctx, PILCO_E_SHAPE, "rollout: unknown policy kind");
     if (n_rw < 0 || n_rw > MAX_REWARD_TERMS || (n_rw > 0 && !rw)) return fail(ctx, PILCO_E_SHAPE, "rollout: 0..4 reward terms supported");
     if (int r = build_work(ctx, s)) return r;
-    // state: m_x[E] s_x[E*E] s1[E*D] reward[1] act_out[U+U*U+E*U] rew_out[2]
-    const size_t n_state = (size_t)E + E * E + (size_t)E * D + 1 + (U + U * U + (size_t)E * U) + 2;
+    // state: 2 x (m_x[E] s_x[E*E]) | s1[E*D] | reward[1]
+    const size_t n_state = 2 * ((size_t)E + E * E) + (size_t)E * D + 1 + 8;
     ENSURE(ctx->state, n_state);
     // params: W[U*E] b[U] maxact[U] then per reward W[E*E] t[E] F[E*E]
     const size_t n_par = (size_t)U * E + 2 * U + (size_t)MAX_REWARD_TERMS * (2 * E * E + E) + 8;
@@ -688,9 +693,9 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
     g.E = E; g.D = D; g.U = U;
     g.wk = s.wk;
     g.var = s.var.p;
-    g.m_x = ctx->state.p;
-    g.s_x = g.m_x + E;
-    g.s1 = g.s_x + E * E;
+    plan.st[0] = ctx->state.p;
+    plan.st[1] = ctx->state.p + (E + E * E);
+    g.s1 = ctx->state.p + 2 * (E + E * E);
     g.reward = g.s1 + (size_t)E * D;
     g.traj = want_traj ? ctx->traj.p : nullptr;
     g.pol_kind = pol->kind;
@@ -703,14 +708,8 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
         for (int u = 0; u < U; ++u) hp[off + u] = pol->max_action ? pol->max_action[u] : 1.0;
         g.maxact = ctx->params.p + off; off += U;
     }
-    RewardArgs& ra = plan.ra;
-    ra = RewardArgs{};
-    ra.n = n_rw;
-    ra.E = E;
-    ra.m_x = g.m_x;
-    ra.s_x = g.s_x;
-    ra.reward_acc = g.reward;
-    if (int r = stage_rewards(ctx, rw, n_rw, E, hp, off, ctx->params.p, ra.rw)) return r;
+    g.n_rewards = n_rw;
+    if (int r = stage_rewards(ctx, rw, n_rw, E, hp, off, ctx->params.p, g.rw)) return r;
     if (hp.size() > n_par) return fail(ctx, PILCO_E_ALLOC, "rollout: parameter staging overflow");
     HIPCHK(hipMemcpyAsync(ctx->params.p, hp.data(), sizeof(double) * n_par, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));  // hp is a local vector
@@ -718,34 +717,45 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
     return PILCO_OK;
 }
 
-// enqueue one full rollout on the stream (state already uploaded)
+// enqueue one full rollout on the stream (initial state already in plan.st[0]); the final
+// state ends up in plan.st[H & 1]
 int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev) {
     Slot& s = ctx->slot[0];
     const MMModel md = model_of(s);
+    const int E = plan.E;
     GlueArgs g = plan.g;
+    const bool rew = g.n_rewards > 0;
     HIPCHK(hipMemsetAsync(g.reward, 0, sizeof(double), ctx->st));
     g.step = 0;
+    g.m_x = plan.st[0];
+    g.s_x = plan.st[0] + E;
+    g.m_out = nullptr;
+    g.s_out = nullptr;
     g.flags = GF_TRAJ | (H > 0 ? GF_POLICY : 0);
     launch_glue(ctx->st, g);
     size_t evi = 0;
     for (int t = 0; t < H; ++t) {
         if (s.wk.PL > 0) {
-            launch_mm_prep(ctx->st, md, s.wk, plan.ra);
+            launch_mm_prep(ctx->st, md, s.wk);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
             launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
         }
         g.step = t + 1;
+        g.m_x = plan.st[t & 1];
+        g.s_x = plan.st[t & 1] + E;
+        g.m_out = plan.st[(t + 1) & 1];
+        g.s_out = plan.st[(t + 1) & 1] + E;
         const int tail = GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ | (t + 1 < H ? GF_POLICY : 0);
         if (ctx->nranks == 1) {
             g.flags = GF_PACK | tail;
-            launch_glue(ctx->st, g);
+            launch_glue(ctx->st, g, rew && !(s.wk.abl & 8));   // workgroup 1: reward of state t (pilco.py:133)
         } else {
             g.flags = GF_PACK;
             launch_glue(ctx->st, g);
             if (int r = all_gather_segments(ctx, s)) return r;
             g.flags = tail;
-            launch_glue(ctx->st, g);
+            launch_glue(ctx->st, g, rew);
         }
     }
     return PILCO_OK;
@@ -763,11 +773,11 @@ int pilco_rollout(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     RolloutPlan plan;
     if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, traj != nullptr, plan)) return r;
     const int E = plan.E;
-    HIPCHK(hipMemcpyAsync(plan.g.m_x, m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipMemcpyAsync(plan.g.s_x, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(plan.st[0], m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(plan.st[0] + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
     if (int r = enqueue_rollout(ctx, plan, H, nullptr)) return r;
-    HIPCHK(hipMemcpyAsync(mH, plan.g.m_x, sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(SH, plan.g.s_x, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(mH, plan.st[H & 1], sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(SH, plan.st[H & 1] + E, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(reward, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
     if (traj)
         HIPCHK(hipMemcpyAsync(traj, ctx->traj.p, sizeof(double) * (size_t)(H + 1) * (E + E * E), hipMemcpyDeviceToHost, ctx->st));
@@ -841,7 +851,6 @@ int pilco_reward_eval(pilco_ctx* ctx, const pilco_reward_term* rewards, int n_re
     if (int r = stage_rewards(ctx, rewards, n_rewards, E, h, off, ctx->state.p, g.rw)) return r;
     if (h.size() < off + 2) h.resize(off + 2, 0.0);
     ENSURE(ctx->state, h.size() + 8);
-    if (g.m_x != ctx->state.p) return fail(ctx, PILCO_E_ALLOC, "reward_eval: staging buffer moved");
     g.rew_out = ctx->state.p + off;
     g.flags = GF_REWARD;
     HIPCHK(hipMemcpyAsync(ctx->state.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->st));
@@ -871,7 +880,7 @@ int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipEventRecord(ctx->ev0, ctx->st));
     for (int rep = 0; rep < reps; ++rep) {
-        HIPCHK(hipMemcpyAsync(plan.g.m_x, init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
+        HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
         if (int r = enqueue_rollout(ctx, plan, H, nullptr)) return r;
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->st));
@@ -885,7 +894,7 @@ int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_
             HIPCHK(hipEventCreate(&e));
             ctx->pair_events.push_back(e);
         }
-        HIPCHK(hipMemcpyAsync(plan.g.m_x, init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
+        HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
         if (int r = enqueue_rollout(ctx, plan, H, &ctx->pair_events)) return r;
         HIPCHK(hipStreamSynchronize(ctx->st));
         float tot = 0.f;
@@ -900,8 +909,8 @@ int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_
         *ms_pair = tot;
         if (n_pair_launches) *n_pair_launches = cnt;
     }
-    HIPCHK(hipMemcpyAsync(mH, plan.g.m_x, sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(SH, plan.g.s_x, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(mH, plan.st[H & 1], sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(SH, plan.st[H & 1] + E, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(reward, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());
@@ -965,6 +974,21 @@ int pilco_shard_owner_of_pair(const pilco_ctx* ctx, int pair_index) {
     const Slot& s = ctx->slot[0];
     if (pair_index < 0 || pair_index >= (int)s.pair_owner.size()) return -1;
     return s.pair_owner[pair_index];
+}
+
+int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32) {
+    if (!ctx) return PILCO_E_SHAPE;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->dbg) {
+        HIPCHK(hipMalloc(&ctx->dbg, 32 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(ctx->dbg, 0, 32 * sizeof(unsigned long long)));
+        for (Slot& s : ctx->slot) s.wk_valid = false;
+    }
+    if (out32) {
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        HIPCHK(hipMemcpy(out32, ctx->dbg, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    return PILCO_OK;
 }
 
 int pilco_comm_rank(const pilco_ctx* ctx) { return ctx ? ctx->rank : -1; }

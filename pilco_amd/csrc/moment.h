@@ -24,9 +24,7 @@ struct MMWork {
     double* At;          // [PL][KP][npad]  row-side operand   (2 Q z_i | u_i | 1 | 0..)
     double* Bt;          // [PL][KP][npad]  column-side operand (w_j   | 1 | v_j | 0..)
     double* pair_isdet;  // [PL]     1/sqrt(det R_ab)
-    double* T;           // [E][D][D] (s + Lambda_a^2)^{-1}
-    double* c;           // [E]      sigma_f,a^2 / sqrt(det B_a)
-    double* mean_part;   // [E][NCH][1+D]
+    double* mean_part;   // [E][NCH][1+D]  per row chunk: c_a g and c_a T_a h (contributions to M_a, V_a)
     double* pair_part;   // [PL][NT][2]
     double* gath;        // [nranks][SEG]  packed per-rank results (all-gather buffer)
     double* out_M;       // [E]
@@ -41,6 +39,8 @@ struct MMWork {
     const int* sk_wlo;   // [PL] first wave touching the local pair
     const int* sk_whi;   // [PL] last wave touching the local pair
     int sk_waves, sk_total, sk_nd, sk_tdiag, sk_toff;
+    unsigned long long* dbg;  // optional [32] phase timestamps (100 MHz wall clock) of the last prep / glue launch
+    int abl;             // experiment switches (PILCO_ABL, tools only; 0 in product use)
     int sk_ud, sk_uo;    // cost units of a diagonal / off-diagonal column step (diagonal steps also stream iK)
     const double* exp_tab;    // [64] 2^(j/64), for the table-driven fp64 exp of the pair kernel
     int PL, EL, P, KP, NCH, NT, SEG, OUTOFF, rank, nranks;  // OUTOFF: offset of the output records inside a segment
@@ -53,17 +53,6 @@ struct RewardDev {
     const double* t;  // device (never null: zeros if the caller passed NULL)
     const double* F;  // device [E][rank]: W = F F^T (symmetric PSD W), or nullptr
     int rank;         // >= 0: factored fast path; -1: general pivoted path
-};
-
-// Reward of the current state, evaluated by one extra workgroup of the prep launch
-// (off the critical path of the step) and accumulated into reward_acc.
-struct RewardArgs {
-    int n;            // number of terms (0 = no reward workgroup)
-    int E;
-    RewardDev rw[MAX_REWARD_TERMS];
-    const double* m_x;
-    const double* s_x;
-    double* reward_acc;
 };
 
 enum GlueFlags {
@@ -87,8 +76,10 @@ struct GlueArgs {
     MMWork pwk;         // policy slot workspace (RBF policy only)
     const double* pvar; // policy kernel variances [U]
     // rollout state
-    double* m_x;     // [E]
-    double* s_x;     // [E][E]
+    const double* m_x;  // [E]     current state (read)
+    const double* s_x;  // [E][E]
+    double* m_out;      // [E]     next state (written by GF_PROPAGATE; the other half of the double buffer)
+    double* s_out;      // [E][E]
     double* s1;      // [E][D]  = [s_x, s_x c_xu], kept for propagate
     double* reward;  // [1]
     double* traj;    // [(H+1)][E + E*E] or nullptr
@@ -106,14 +97,14 @@ struct GlueArgs {
     double* rew_out;  // [2]
 };
 
-void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const RewardArgs& ra);
+void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk);
 // variant 0 = MFMA stream-K, 1 = VALU (tiled), 2 = MFMA tiled (bits independent of the rank count)
 void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int variant);
 // stream-K geometry: resident waves of the MFMA pair kernel for this KP, and the per-pair step counts
 int mm_pair_sk_capacity(int KP);
 void mm_pair_sk_steps(int npad, int* tdiag, int* toff);
 int mm_sk_boundary(int w, int waves, int nd_steps, int total, int ud, int uo);
-void launch_glue(hipStream_t st, const GlueArgs& g);
+void launch_glue(hipStream_t st, const GlueArgs& g, bool with_reward_block = false);
 size_t glue_lds_bytes(int E, int D);
 // tile-partial counts per pair for a variant (NT) and the number of row chunks of the prep kernel
 int mm_pair_nt(int npad, int variant, int PL);

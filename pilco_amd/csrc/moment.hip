@@ -41,6 +41,28 @@ __device__ __forceinline__ int pair_order_index(int E, int a, int b) {  // a >= 
     return (a == b) ? a : E + a * (a - 1) / 2 + b;
 }
 
+#define DBG_STAMP(wk_, slot_, cond_)                                           \
+    do {                                                                       \
+        if ((wk_).dbg && (cond_)) (wk_).dbg[slot_] = wall_clock64();          \
+    } while (0)
+
+// Wave-wide sum in lane 63 with DPP row shifts / broadcasts (no LDS traffic, fixed order).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row sum
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return v;
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -131,33 +153,6 @@ __device__ double* gauss_jordan(double* G0, double* G1, int n, int nc, double& d
     return cur;
 }
 
-// Unpivoted Gauss-Jordan by the FIRST WAVE on an n x nc (nc <= 64) matrix in
-// LDS, lane = column; for symmetric positive definite (or diagonally similar to
-// SPD) systems.  LDS operations of one wave execute in order, so no barriers are
-// needed inside.  det is returned through LDS slot *det_slot after the barrier.
-__device__ void gj_lds_wave(double* A, int n, int nc, double* det_slot) {
-    if (threadIdx.x < 64) {
-        const int c = threadIdx.x;
-        const bool on = c < nc;
-        double det = 1.0;
-        for (int k = 0; k < n; ++k) {
-            const double piv = A[k * nc + k];
-            det *= piv;
-            const double pk = on ? A[k * nc + c] / piv : 0.0;
-            for (int r = 0; r < n; ++r) {
-                if (r == k) continue;
-                const double f = A[r * nc + k];
-                const double v = on ? A[r * nc + c] : 0.0;
-                if (on) A[r * nc + c] = fma(-f, pk, v);
-            }
-            if (on) A[k * nc + c] = pk;
-            asm volatile("" ::: "memory");
-        }
-        if (c == 0) *det_slot = det;
-    }
-    __syncthreads();
-}
-
 // Unpivoted Gauss-Jordan entirely in registers: lane c of one wave holds column c
 // of the DT x 2DT augmented matrix [A | B]; the pivot column is broadcast with
 // v_readlane.  On return lanes DT..2DT-1 hold the columns of A^{-1} B.
@@ -181,6 +176,36 @@ __device__ __forceinline__ double gj_wave(double (&a)[DT]) {
 }
 
 // ------------------------------------------------------------------ rewards
+// Solve (I_r + scale F^T S F) x = y in registers (one wave, column per lane) and return
+// exp(-scale y^T x / 2) / sqrt(det) through *slot.  A: [r][r] in LDS, y: [r] in LDS.
+template <int ET>
+__device__ void reward_solve(const double* A, const double* y, int r, double scale, double* slot) {
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        double col[ET];
+#pragma unroll
+        for (int k = 0; k < ET; ++k) {
+            double v = 0.0;
+            if (c < ET) {
+                v = (k == c) ? 1.0 : 0.0;
+                if (k < r && c < r) v = A[k * r + c];
+            } else if (c == ET) {
+                v = (k < r) ? y[k] : 0.0;
+            }
+            col[k] = v;
+        }
+        const double det = gj_wave<ET>(col);
+        if (c == ET) {
+            double q = 0.0;
+#pragma unroll
+            for (int k = 0; k < ET; ++k)
+                if (k < r) q = fma(y[k], col[k], q);
+            *slot = exp(-0.5 * scale * q) / sqrt(det);
+        }
+    }
+    __syncthreads();
+}
+
 // exp(-scale q / 2) / sqrt(det(I + scale S W)),  q = d^T W (I + scale S W)^{-1} d,  d = m - t
 // (rewards.py:32-48; scale 1 -> mean, scale 2 -> second moment).  ws: LDS scratch.
 __device__ double exp_reward_moment(const RewardDev& rw, int E, double scale, const double* mx, const double* sx,
@@ -188,45 +213,44 @@ __device__ double exp_reward_moment(const RewardDev& rw, int E, double scale, co
     const int t = threadIdx.x;
     double result;
     if (rw.rank >= 0) {
-        // W = F F^T: q = y^T (I + scale F^T S F)^{-1} y, y = F^T d; det(I + scale S W) = det(I_r + scale F^T S F)
-        const int r = rw.rank, nc = r + 1;
+        // W = F F^T (symmetric PSD): q = y^T (I + scale F^T S F)^{-1} y with y = F^T d, and
+        // det(I + scale S W) = det(I_r + scale F^T S F): an SPD r x r system, no pivoting needed.
+        const int r = rw.rank;
         double* y = ws;              // [E]
-        double* SF = y + E;          // [E*E]
-        double* A = SF + E * E;      // [E*(E+1)]
-        double* slot = A + E * (E + 1);
+        double* Fl = y + E;          // [E*E]  F staged in LDS
+        double* SF = Fl + E * E;     // [E*E]
+        double* A = SF + E * E;      // [E*E]
+        double* slot = A + E * E;
+        for (int e2 = t; e2 < E * r; e2 += blockDim.x) Fl[e2] = rw.F[e2];
+        if (t < E) slot[2 + t] = mx[t] - rw.t[t];
+        __syncthreads();
+        const double* d = slot + 2;
         for (int k = t; k < r; k += blockDim.x) {
             double acc = 0.0;
-            for (int e = 0; e < E; ++e) acc = fma(rw.F[e * r + k], mx[e] - rw.t[e], acc);
+            _Pragma("unroll 8") for (int e = 0; e < E; ++e) acc = fma(Fl[e * r + k], d[e], acc);
             y[k] = acc;
         }
         for (int e2 = t; e2 < E * r; e2 += blockDim.x) {
             const int e = e2 / r, k = e2 - e * r;
             double acc = 0.0;
-            for (int f = 0; f < E; ++f) acc = fma(sx[e * E + f], rw.F[f * r + k], acc);
+            _Pragma("unroll 8") for (int f = 0; f < E; ++f) acc = fma(sx[e * E + f], Fl[f * r + k], acc);
             SF[e2] = acc;
         }
         __syncthreads();
-        for (int e2 = t; e2 < r * nc; e2 += blockDim.x) {
-            const int k = e2 / nc, l = e2 - k * nc;
-            double v;
-            if (l < r) {
-                double acc = 0.0;
-                for (int e = 0; e < E; ++e) acc = fma(rw.F[e * r + k], SF[e * r + l], acc);
-                v = fma(scale, acc, (k == l) ? 1.0 : 0.0);
-            } else {
-                v = y[k];
-            }
-            A[e2] = v;
+        for (int e2 = t; e2 < r * r; e2 += blockDim.x) {
+            const int k = e2 / r, l = e2 - k * r;
+            double acc = 0.0;
+            _Pragma("unroll 8") for (int e = 0; e < E; ++e) acc = fma(Fl[e * r + k], SF[e * r + l], acc);
+            A[e2] = fma(scale, acc, (k == l) ? 1.0 : 0.0);
         }
         __syncthreads();
-        gj_lds_wave(A, r, nc, slot);
-        if (t == 0) {
-            double q = 0.0;
-            for (int k = 0; k < r; ++k) q = fma(y[k], A[k * nc + r], q);
-            slot[1] = exp(-0.5 * scale * q) / sqrt(slot[0]);
-        }
-        __syncthreads();
-        result = slot[1];
+        if (E <= 4) reward_solve<4>(A, y, r, scale, slot);
+        else if (E <= 8) reward_solve<8>(A, y, r, scale, slot);
+        else if (E <= 12) reward_solve<12>(A, y, r, scale, slot);
+        else if (E <= 16) reward_solve<16>(A, y, r, scale, slot);
+        else if (E <= 24) reward_solve<24>(A, y, r, scale, slot);
+        else reward_solve<32>(A, y, r, scale, slot);
+        result = slot[0];
         __syncthreads();
     } else {
         // general W: aug = [(I + scale S W)^T | W^T] -> X^T, X = W (I + scale S W)^{-1}
@@ -239,7 +263,7 @@ __device__ double exp_reward_moment(const RewardDev& rw, int E, double scale, co
             double v;
             if (c < E) {
                 double sw = 0.0;  // (S W)[c][r]
-                for (int k = 0; k < E; ++k) sw = fma(sx[c * E + k], rw.W[k * E + r], sw);
+                _Pragma("unroll 8") for (int k = 0; k < E; ++k) sw = fma(sx[c * E + k], rw.W[k * E + r], sw);
                 v = fma(scale, sw, (r == c) ? 1.0 : 0.0);
             } else {
                 v = rw.W[(c - E) * E + r];
@@ -252,7 +276,7 @@ __device__ double exp_reward_moment(const RewardDev& rw, int E, double scale, co
             double q = 0.0;
             for (int r = 0; r < E; ++r) {
                 double acc = 0.0;
-                for (int c = 0; c < E; ++c) acc = fma(res[c * nc + E + r], mx[c] - rw.t[c], acc);
+                _Pragma("unroll 8") for (int c = 0; c < E; ++c) acc = fma(res[c * nc + E + r], mx[c] - rw.t[c], acc);
                 q = fma(mx[r] - rw.t[r], acc, q);
             }
             slot[0] = exp(-0.5 * scale * q) / sqrt(det);
@@ -264,7 +288,7 @@ __device__ double exp_reward_moment(const RewardDev& rw, int E, double scale, co
     return result;
 }
 
-size_t reward_lds_doubles(int E) { return (size_t)E + (size_t)E * E + 4 * (size_t)E * E + (size_t)E * (E + 1) + 16; }
+__host__ __device__ inline size_t reward_lds_doubles(int E) { return (size_t)E + 4 * (size_t)E * E + (size_t)E + 16; }
 
 // mean (and variance) of the combined reward at (mx, sx) held in LDS (rewards.py:19-81)
 __device__ void reward_eval(int n, const RewardDev* rws, int E, const double* mx, const double* sx, double* ws,
@@ -277,10 +301,10 @@ __device__ void reward_eval(int n, const RewardDev* rws, int E, const double* mx
             m_i = exp_reward_moment(rw, E, 1.0, mx, sx, ws);
             if (want_var) v_i = exp_reward_moment(rw, E, 2.0, mx, sx, ws) - m_i * m_i;
         } else {  // linear: rewards.py:58-61
-            for (int k = 0; k < E; ++k) m_i = fma(mx[k], rw.W[k], m_i);
+            _Pragma("unroll 8") for (int k = 0; k < E; ++k) m_i = fma(mx[k], rw.W[k], m_i);
             if (want_var)
                 for (int r = 0; r < E; ++r)
-                    for (int c = 0; c < E; ++c) v_i = fma(rw.W[r] * sx[r * E + c], rw.W[c], v_i);
+                    _Pragma("unroll 8") for (int c = 0; c < E; ++c) v_i = fma(rw.W[r] * sx[r * E + c], rw.W[c], v_i);
         }
         mu = fma(rw.coef, m_i, mu);
         var = fma(rw.coef * rw.coef, v_i, var);
@@ -289,27 +313,10 @@ __device__ void reward_eval(int n, const RewardDev* rws, int E, const double* mx
     var_out = var;
 }
 
-__device__ void reward_block(const RewardArgs& ra, double* sm) {
-    const int E = ra.E, t = threadIdx.x;
-    double* mx = sm;
-    double* sx = mx + E;
-    double* ws = sx + E * E;
-    if (t < E) mx[t] = ra.m_x[t];
-    for (int e = t; e < E * E; e += blockDim.x) sx[e] = ra.s_x[e];
-    __syncthreads();
-    double mu, var;
-    reward_eval(ra.n, ra.rw, E, mx, sx, ws, false, mu, var);
-    if (t == 0) ra.reward_acc[0] += mu;  // pilco.py:133 (single writer, stream-ordered)
-}
-
 // ------------------------------------------------------------------ prep
 template <int DT>
-__global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk, RewardArgs ra) {
+__global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    if ((int)blockIdx.x == wk.PL) {  // the reward workgroup
-        if (blockIdx.y == 0 && ra.n > 0) reward_block(ra, sm);
-        return;
-    }
     const int D = md.D, npad = md.npad;
     double* s_m = sm;
     double* s_ia2 = s_m + DT;
@@ -322,19 +329,42 @@ __global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk, RewardAr
     double* red = s_sc + 4;            // 4 * (DT + 1)
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int pl = blockIdx.x, ch = blockIdx.y;
+    const bool dbg0 = (t == 0 && pl == 0 && ch == 0);
+    DBG_STAMP(wk, 0, dbg0);
     int a, b;
     local_pair_ab(wk, md.E, pl, a, b);
     const bool diag = (a == b);
-    if (t < D) {
-        s_m[t] = wk.in_m[t];
-        const double la = md.ls[a * D + t], lb = md.ls[b * D + t];
-        s_ia2[t] = 1.0 / (la * la);
-        s_ib2[t] = 1.0 / (lb * lb);
-        s_ia[t] = 1.0 / la;
+    if (t < DT) {
+        double la = 1.0, lb = 1.0, mm = 0.0;
+        if (t < D) {
+            mm = wk.in_m[t];
+            la = md.ls[a * D + t];
+            lb = md.ls[b * D + t];
+        }
+        s_m[t] = mm;
+        s_ia2[t] = (t < D) ? 1.0 / (la * la) : 0.0;
+        s_ib2[t] = (t < D) ? 1.0 / (lb * lb) : 0.0;
+        s_ia[t] = (t < D) ? 1.0 / la : 0.0;
     }
     for (int e = t; e < D * D; e += 256) s_s[e] = wk.in_s[e];
+    for (int e = t; e < DT * DT; e += 256) {  // padded rows / columns of Q and T stay zero
+        s_Q[e] = 0.0;
+        s_T[e] = 0.0;
+    }
     __syncthreads();
-    if (w == 0) {
+    DBG_STAMP(wk, 1, dbg0);
+    // the first rows' coordinates are fetched now so that their latency overlaps the Gauss-Jordan waves
+    const int rpc = npad / wk.NCH;
+    const int i_begin = ch * rpc, i_end = i_begin + rpc;
+    double xpre[DT];
+    {
+        const int ip = (i_begin + t < i_end) ? i_begin + t : i_begin;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) xpre[d] = (d < D) ? md.Pt[(long)d * npad + ip] : 0.0;
+    }
+    if (wk.abl & 2) {
+        if (t == 0) { s_sc[0] = 1.0; s_sc[1] = 1.0; }
+    } else if (w == 0) {
         // [R | s],  R = s diag(la^-2 + lb^-2) + I        (mgpr.py:121-124,129); padded with identity
         double col[DT];
         const int c = lane;
@@ -383,112 +413,127 @@ __global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk, RewardAr
                 if (r < D) {
                     const double v = col[r] * s_ia[r] * s_ia[cc];
                     s_T[r * DT + cc] = v;
-                    if (ch == 0) wk.T[((long)a * D + r) * D + cc] = v;
                 }
         }
         if (lane == 0) {
             s_sc[1] = md.var[a] / sqrt(detB);
-            if (ch == 0) wk.c[a] = s_sc[1];
         }
     }
     __syncthreads();
+    DBG_STAMP(wk, 2, dbg0);
     const double logva = log(md.var[a]), logvb = log(md.var[b]);
     const int KP = wk.KP;
-    const int rpc = npad / wk.NCH;
-    const int i_begin = ch * rpc, i_end = i_begin + rpc;
-    double* At = wk.At + (long)pl * KP * npad;
-    double* Bt = wk.Bt + (long)pl * KP * npad;
+    double* At = wk.At + (long)pl * KP * npad + ((wk.abl & 1) ? (long)(-i_begin - (t & ~63)) : 0);
+    double* Bt = wk.Bt + (long)pl * KP * npad + ((wk.abl & 1) ? (long)(-i_begin - (t & ~63)) : 0);
     const double* beta_a = md.beta + (long)a * npad;
     double g = 0.0;
     double h[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) h[d] = 0.0;
-    for (int i = i_begin + t; i < i_end; i += 256) {
+    for (int i = i_begin + t; i < ((wk.abl & 4) ? i_begin : i_end); i += 256) {
         const bool valid = i < md.n;
-        double zeta[DT];
+        double zeta[DT], z[DT], wv[DT], qz[DT], qw[DT];
 #pragma unroll
-        for (int d = 0; d < DT; ++d) zeta[d] = (d < D && valid) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
-        // row side: z = zeta / la^2
-        {
-            double kk = logva, u = 0.0;
-#pragma unroll
-            for (int d = 0; d < DT; ++d)
-                if (d < D) kk = fma(-0.5 * zeta[d] * zeta[d], s_ia2[d], kk);
-#pragma unroll
-            for (int r = 0; r < DT; ++r) {
-                if (r < D) {
-                    double qz = 0.0;
-#pragma unroll
-                    for (int c = 0; c < DT; ++c)
-                        if (c < D) qz = fma(s_Q[r * DT + c], zeta[c] * s_ia2[c], qz);
-                    u = fma(zeta[r] * s_ia2[r], qz, u);
-                    At[(long)r * npad + i] = valid ? 2.0 * qz : 0.0;
-                }
-            }
-            At[(long)D * npad + i] = valid ? (kk + u) : 0.0;
-            At[(long)(D + 1) * npad + i] = valid ? 1.0 : 0.0;
-            for (int k = D + 2; k < KP; ++k) At[(long)k * npad + i] = 0.0;
+        for (int d = 0; d < DT; ++d) {
+            const double xv = (i == i_begin + t) ? xpre[d] : ((d < D) ? md.Pt[(long)d * npad + i] : 0.0);
+            zeta[d] = (d < D && valid) ? xv - s_m[d] : 0.0;
         }
-        // column side: w = zeta / lb^2
-        {
-            double kk = logvb, v = 0.0;
+        double ka = logva, kb = logvb;
 #pragma unroll
-            for (int d = 0; d < DT; ++d)
-                if (d < D) kk = fma(-0.5 * zeta[d] * zeta[d], s_ib2[d], kk);
+        for (int d = 0; d < DT; ++d) {
+            z[d] = zeta[d] * s_ia2[d];     // z = zeta / la^2   (padding: ia2 = ib2 = 0)
+            wv[d] = zeta[d] * s_ib2[d];    // w = zeta / lb^2
+            ka = fma(-0.5 * zeta[d], z[d], ka);
+            kb = fma(-0.5 * zeta[d], wv[d], kb);
+            qz[d] = 0.0;
+            qw[d] = 0.0;
+        }
+        // Q z and Q w by columns of the symmetric Q: DT independent accumulators per product,
+        // one LDS row (wide reads) per column step -- no LDS latency on the dependency chain
+#pragma unroll
+        for (int c = 0; c < DT; ++c) {
+            double qrow[DT];
+#pragma unroll
+            for (int r = 0; r < DT; ++r) qrow[r] = s_Q[c * DT + r];
 #pragma unroll
             for (int r = 0; r < DT; ++r) {
-                if (r < D) {
-                    double qw = 0.0;
-#pragma unroll
-                    for (int c = 0; c < DT; ++c)
-                        if (c < D) qw = fma(s_Q[r * DT + c], zeta[c] * s_ib2[c], qw);
-                    v = fma(zeta[r] * s_ib2[r], qw, v);
-                    Bt[(long)r * npad + i] = valid ? zeta[r] * s_ib2[r] : 0.0;
-                }
+                qz[r] = fma(qrow[r], z[c], qz[r]);
+                qw[r] = fma(qrow[r], wv[c], qw[r]);
             }
-            Bt[(long)D * npad + i] = valid ? 1.0 : 0.0;
-            Bt[(long)(D + 1) * npad + i] = valid ? (kk + v) : 0.0;
-            for (int k = D + 2; k < KP; ++k) Bt[(long)k * npad + i] = 0.0;
+        }
+        double u = 0.0, v = 0.0;
+#pragma unroll
+        for (int r = 0; r < DT; ++r) {
+            u = fma(z[r], qz[r], u);
+            v = fma(wv[r], qw[r], v);
+        }
+#pragma unroll
+        for (int r = 0; r < DT; ++r)
+            if (r < D) {
+                At[(long)r * npad + i] = 2.0 * qz[r];   // zero for padded rows (zeta = 0)
+                Bt[(long)r * npad + i] = wv[r];
+            }
+        At[(long)D * npad + i] = valid ? (ka + u) : 0.0;
+        At[(long)(D + 1) * npad + i] = valid ? 1.0 : 0.0;
+        Bt[(long)D * npad + i] = valid ? 1.0 : 0.0;
+        Bt[(long)(D + 1) * npad + i] = valid ? (kb + v) : 0.0;
+        for (int k = D + 2; k < KP; ++k) {
+            At[(long)k * npad + i] = 0.0;
+            Bt[(long)k * npad + i] = 0.0;
         }
         if (diag) {  // mean part: lb_i = exp(-zeta^T T zeta / 2) beta_i      (mgpr.py:113)
+            double tz[DT];
+#pragma unroll
+            for (int r = 0; r < DT; ++r) tz[r] = 0.0;
+#pragma unroll
+            for (int c = 0; c < DT; ++c) {
+                double trow[DT];
+#pragma unroll
+                for (int r = 0; r < DT; ++r) trow[r] = s_T[c * DT + r];
+#pragma unroll
+                for (int r = 0; r < DT; ++r) tz[r] = fma(trow[r], zeta[c], tz[r]);
+            }
             double q = 0.0;
 #pragma unroll
-            for (int r = 0; r < DT; ++r) {
-                if (r < D) {
-                    double tz = 0.0;
-#pragma unroll
-                    for (int c = 0; c < DT; ++c)
-                        if (c < D) tz = fma(s_T[r * DT + c], zeta[c], tz);
-                    q = fma(zeta[r], tz, q);
-                }
-            }
+            for (int r = 0; r < DT; ++r) q = fma(zeta[r], tz[r], q);
             const double lb = exp(-0.5 * q) * beta_a[i];
             g += lb;
 #pragma unroll
             for (int d = 0; d < DT; ++d) h[d] = fma(zeta[d], lb, h[d]);
         }
     }
+    DBG_STAMP(wk, 3, dbg0);
     if (diag) {
-        for (int off = 32; off > 0; off >>= 1) g += __shfl_down(g, off);
-        if (lane == 0) red[w * (DT + 1)] = g;
+        g = wave_sum_lane63(g);
+        if (lane == 63) red[w * (DT + 1)] = g;
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
-            double v = h[d];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-            if (lane == 0) red[w * (DT + 1) + 1 + d] = v;
+            const double v = wave_sum_lane63(h[d]);
+            if (lane == 63) red[w * (DT + 1) + 1 + d] = v;
         }
         __syncthreads();
+        // block sums of g and h, then M and V contributions of this row chunk:
+        // c g (mgpr.py:117) and c T h (mgpr.py:118, V = c tiL^T lb = c T sum_i zeta_i lb_i)
+        double* hs = red + 4 * (DT + 1);  // [DT + 1]
+        if (t < 1 + D) hs[t] = ((red[t] + red[(DT + 1) + t]) + red[2 * (DT + 1) + t]) + red[3 * (DT + 1) + t];
+        __syncthreads();
         if (t < 1 + D) {
-            const double v = ((red[t] + red[(DT + 1) + t]) + red[2 * (DT + 1) + t]) + red[3 * (DT + 1) + t];
+            double v;
+            if (t == 0) {
+                v = s_sc[1] * hs[0];
+            } else {
+                double acc = 0.0;
+                _Pragma("unroll 8") for (int k = 0; k < D; ++k) acc = fma(s_T[(t - 1) * DT + k], hs[1 + k], acc);
+                v = s_sc[1] * acc;
+            }
             wk.mean_part[((long)a * wk.NCH + ch) * (1 + D) + t] = v;
         }
     }
+    DBG_STAMP(wk, 4, dbg0);
 }
 
-size_t prep_lds_bytes(int DT, int E_reward) {
-    const size_t own = (size_t)4 * DT + 3 * (size_t)DT * DT + 4 + 4 * (size_t)(DT + 1);
-    const size_t rew = E_reward > 0 ? reward_lds_doubles(E_reward) : 0;
-    return sizeof(double) * (own > rew ? own : rew);
+size_t prep_lds_bytes(int DT) {
+    return sizeof(double) * ((size_t)4 * DT + 3 * (size_t)DT * DT + 4 + 5 * (size_t)(DT + 1));
 }
 
 int mm_kp(int D) { return round_up(D + 2, 4); }
@@ -501,12 +546,11 @@ int mm_prep_nch(int npad, int PL) {
     return nch;
 }
 
-void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const RewardArgs& ra) {
-    dim3 grid(wk.PL + (ra.n > 0 ? 1 : 0), wk.NCH);
+void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk) {
+    dim3 grid(wk.PL, wk.NCH);
     const int D = md.D;
-    const int Er = ra.n > 0 ? ra.E : 0;
 #define PREP(DT_)                                                                                          \
-    hipLaunchKernelGGL((k_mm_prep<DT_>), grid, dim3(256), prep_lds_bytes(DT_, Er), st, md, wk, ra)
+    hipLaunchKernelGGL((k_mm_prep<DT_>), grid, dim3(256), prep_lds_bytes(DT_), st, md, wk)
     if (D <= 4) PREP(4);
     else if (D <= 8) PREP(8);
     else if (D <= 12) PREP(12);
@@ -949,25 +993,48 @@ void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int var
 #undef PS
 }
 
-// ------------------------------------------------------------------ glue (one workgroup)
+// ------------------------------------------------------------------ glue
+// Workgroup 0 is the serial link of the step: everything it needs is pulled into LDS
+// with one batch of loads, then (pack ->) assemble -> propagate -> controller -> joint.
+// Workgroup 1 (rollouts with a reward) evaluates the reward of the PRE-propagation
+// state concurrently (pilco.py:133); the state is double-buffered so it never races
+// with workgroup 0's update.
 struct GlueLds {
-    double* mx;   // [nm]
-    double* sx;   // [nm*nm]
+    double* mx;   // [nm]     current state mean
+    double* sx;   // [nm*nm]  current state covariance
     double* mu;   // [nm]
     double* su;   // [nm*nm]
     double* cxu;  // [nm*nm]
     double* t1;   // [nm*nm]
     double* t2;   // [nm*nm]
-    double* ws;   // reward scratch (standalone reward_eval only) / pack scratch
+    double* s1;   // [nm*nm]  s1 = [s_x, s_x c_xu] of the previous joint
+    double* seg;  // [SEG]    this rank's packed results
+    double* mp;   // [EL*NCH*(1+D)] mean partials
     double* misc; // [128]
+    double* ws;   // reward scratch (standalone reward_eval / workgroup 1)
 };
 
-size_t glue_lds_bytes(int E, int D) {
+static size_t glue_lds_doubles(int E, int D, int SEG, int mp) {
     const int nm = E > D ? E : D;
-    size_t ws = reward_lds_doubles(E);
-    const size_t pack = (size_t)nm * (nm + 2) + 64;
-    if (pack > ws) ws = pack;
-    return sizeof(double) * ((size_t)2 * nm + 5 * (size_t)nm * nm + ws + 128);
+    return (size_t)2 * nm + 6 * (size_t)nm * nm + (size_t)SEG + (size_t)mp + 128 + reward_lds_doubles(E);
+}
+size_t glue_lds_bytes(int E, int D) { return sizeof(double) * glue_lds_doubles(E, D, 0, 0); }
+
+// global -> LDS copy with all loads of a 1024-element chunk in flight before the first wait
+__device__ __forceinline__ void bulk_load(double* dst, const double* __restrict__ src, int n) {
+    for (int base = 0; base < n; base += 1024) {
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = base + k * 256 + (int)threadIdx.x;
+            v[k] = (e < n) ? src[e] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = base + k * 256 + (int)threadIdx.x;
+            if (e < n) dst[e] = v[k];
+        }
+    }
 }
 
 // squash_sin on (mu[U], su[U][U]) in place; cdiag[u] = e_u exp(-s_uu/2) cos(m_u)   (controllers.py:13-36)
@@ -1001,7 +1068,7 @@ __device__ void write_joint(const GlueArgs& g, const GlueLds& L) {
     for (int e = t; e < E * U; e += blockDim.x) {  // sc = s_x c_xu  (E,U)
         const int r = e / U, u = e - r * U;
         double acc = 0.0;
-        for (int k = 0; k < E; ++k) acc = fma(L.sx[r * E + k], L.cxu[k * U + u], acc);
+        _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.sx[r * E + k], L.cxu[k * U + u], acc);
         L.t1[e] = acc;
     }
     __syncthreads();
@@ -1016,14 +1083,12 @@ __device__ void write_joint(const GlueArgs& g, const GlueLds& L) {
         g.wk.in_s[e] = v;
         if (r < E) g.s1[r * D + c] = v;
     }
-    __syncthreads();
 }
 
-// Reduce the tile partials of the local pairs / owned outputs into this rank's
-// segment of the gather buffer.  Four lanes per pair sum fixed quarters of the
-// tile list and are combined in a fixed tree: the result does not depend on the
-// number of ranks or on timing.  seg_lds (optional) receives a copy.
-__device__ void mm_pack(const MMWork& wk, int D, int E, double* scratch, double* seg_lds) {
+// Reduce the tile / stream-K partials of the local pairs and the row-chunk partials of the
+// owned outputs into this rank's segment (LDS copy + global gather buffer).  Four lanes per
+// pair sum fixed quarters of the partial list and are combined in a fixed tree.
+__device__ void mm_pack(const MMWork& wk, int D, int E, const GlueLds& L, int pre_wlo, int pre_whi) {
     const int t = threadIdx.x;
     double* seg = wk.gath + (long)wk.rank * wk.SEG;
     for (int base = 0; base < wk.PL; base += 64) {
@@ -1031,7 +1096,8 @@ __device__ void mm_pack(const MMWork& wk, int D, int E, double* scratch, double*
         double s0 = 0.0, s1 = 0.0;
         if (k < wk.PL) {
             if (wk.sk_waves > 0) {  // stream-K partials: waves wlo..whi, the slot whose pair index matches
-                const int wlo = wk.sk_wlo[k], n = wk.sk_whi[k] - wlo + 1;
+                const int wlo = (base == 0) ? pre_wlo : wk.sk_wlo[k];
+                const int n = ((base == 0) ? pre_whi : wk.sk_whi[k]) - wlo + 1;
                 const int q0 = wlo + (int)((long)n * gq / 4), q1 = wlo + (int)((long)n * (gq + 1) / 4);
                 for (int q = q0; q < q1; ++q) {
                     const int p0 = wk.sk_pidx[2 * q], p1 = wk.sk_pidx[2 * q + 1];
@@ -1057,38 +1123,21 @@ __device__ void mm_pack(const MMWork& wk, int D, int E, double* scratch, double*
             local_pair_ab(wk, E, k, a, b);
             const double v = ((a == b) ? (s0 - s1) : s0) * wk.pair_isdet[k];   // mgpr.py:144-145
             seg[k] = v;
-            if (seg_lds) seg_lds[k] = v;
+            L.seg[k] = v;
         }
     }
     const int W1 = 1 + D;
-    for (int e = t; e < wk.EL * W1; e += blockDim.x) {
+    for (int e = t; e < wk.EL * W1; e += blockDim.x) {   // M_a and V_a: sums of the chunk contributions
         const int o = e / W1, idx = e - o * W1;
-        const int a = o * wk.nranks + wk.rank;
-        double s = 0.0;
-        for (int ch = 0; ch < wk.NCH; ++ch) s += wk.mean_part[((long)a * wk.NCH + ch) * W1 + idx];
-        scratch[e] = s;
-    }
-    __syncthreads();
-    for (int e = t; e < wk.EL * W1; e += blockDim.x) {
-        const int o = e / W1, idx = e - o * W1;
-        const int a = o * wk.nranks + wk.rank;
-        const double ca = wk.c[a];
-        double v;
-        if (idx == 0) {
-            v = ca * scratch[o * W1];                              // M_a          (mgpr.py:117)
-        } else {
-            const int d = idx - 1;
-            double acc = 0.0;
-            for (int k = 0; k < D; ++k) acc = fma(wk.T[((long)a * D + d) * D + k], scratch[o * W1 + 1 + k], acc);
-            v = ca * acc;                                          // V_a[d]       (mgpr.py:118)
-        }
-        seg[wk.OUTOFF + e] = v;
-        if (seg_lds) seg_lds[wk.OUTOFF + e] = v;
+        double sum = 0.0;
+        _Pragma("unroll 8") for (int ch = 0; ch < wk.NCH; ++ch) sum += L.mp[(o * wk.NCH + ch) * W1 + idx];
+        seg[wk.OUTOFF + e] = sum;
+        L.seg[wk.OUTOFF + e] = sum;
     }
     __syncthreads();
 }
 
-// gath (global, or its LDS copy when single-rank) -> out_M [E], out_S [E][E], out_V [D][E]; also left in LDS
+// packed results -> out_M [E], out_S [E][E], out_V [D][E]; also left in LDS (oM, oS, oV)
 __device__ void mm_assemble(const MMWork& wk, const double* src, const double* var, int D, int E, double* oM,
                             double* oS, double* oV) {
     const int t = threadIdx.x;
@@ -1121,6 +1170,8 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int E = g.E, D = g.D, U = g.U, t = threadIdx.x;
     const int nm = E > D ? E : D;
+    const int mp_n = (g.flags & GF_PACK) ? g.wk.EL * g.wk.NCH * (1 + D) : 0;
+    const int seg_n = (g.flags & (GF_PACK | GF_ASSEMBLE)) ? g.wk.SEG * ((g.flags & GF_PACK) ? 1 : g.wk.nranks) : 0;
     GlueLds L;
     L.mx = sm;
     L.sx = L.mx + nm;
@@ -1129,76 +1180,111 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
     L.cxu = L.su + nm * nm;
     L.t1 = L.cxu + nm * nm;
     L.t2 = L.t1 + nm * nm;
-    L.misc = L.t2 + nm * nm;
+    L.s1 = L.t2 + nm * nm;
+    L.misc = L.s1 + nm * nm;
     L.ws = L.misc + 128;
+    L.seg = L.ws + reward_lds_doubles(E);
+    L.mp = L.seg + seg_n;
 
-    const bool local_asm = (g.flags & GF_PACK) && (g.flags & GF_ASSEMBLE) && g.wk.nranks == 1 && g.wk.SEG <= nm * nm;
-    if (g.flags & GF_PACK) mm_pack(g.wk, D, E, L.ws, local_asm ? L.t2 : nullptr);
-    if (g.flags & GF_ASSEMBLE) {
-        // oM -> mu, oS -> su, oV -> cxu (LDS scratch reused)
-        mm_assemble(g.wk, local_asm ? L.t2 : g.wk.gath, g.var, D, E, L.mu, L.su, L.cxu);
+    const bool dbg0 = (t == 0);
+    if (blockIdx.x == 1) {  // reward of the current (pre-propagation) state
+        DBG_STAMP(g.wk, 20, dbg0);
+        if (t < E) L.mx[t] = g.m_x[t];
+        bulk_load(L.sx, g.s_x, E * E);
+        __syncthreads();
+        double mu, var;
+        reward_eval(g.n_rewards, g.rw, E, L.mx, L.sx, L.ws, false, mu, var);
+        if (t == 0) g.reward[0] += mu;  // single writer, stream ordered          (pilco.py:133)
+        DBG_STAMP(g.wk, 21, dbg0);
+        return;
     }
+
+    DBG_STAMP(g.wk, 8, dbg0);
+    int pre_wlo = 0, pre_whi = -1;
+    if ((g.flags & GF_PACK) && g.wk.sk_waves > 0 && (t >> 2) < g.wk.PL) {
+        pre_wlo = g.wk.sk_wlo[t >> 2];
+        pre_whi = g.wk.sk_whi[t >> 2];
+    }
+    // one batch of loads for everything the serial part reads
+    if (g.flags & (GF_PROPAGATE | GF_TRAJ | GF_REWARD | GF_POLICY)) {
+        if (t < E) L.mx[t] = g.m_x[t];
+        bulk_load(L.sx, g.s_x, E * E);
+    }
+    if (g.flags & GF_PROPAGATE) bulk_load(L.s1, g.s1, E * D);
+    if (g.flags & GF_PACK) bulk_load(L.mp, g.wk.mean_part, mp_n);
+    if ((g.flags & GF_ASSEMBLE) && !(g.flags & GF_PACK)) bulk_load(L.seg, g.wk.gath, seg_n);
+    __syncthreads();
+
+    DBG_STAMP(g.wk, 9, dbg0);
+    if ((g.flags & GF_PACK) && !(g.wk.abl & 16)) mm_pack(g.wk, D, E, L, pre_wlo, pre_whi);
+    DBG_STAMP(g.wk, 10, dbg0);
+    if (g.flags & GF_ASSEMBLE) {
+        // single rank: the LDS copy of the segment is the whole gather buffer
+        mm_assemble(g.wk, L.seg, g.var, D, E, L.mu, L.su, L.cxu);  // oM -> mu, oS -> su, oV -> cxu
+    }
+    DBG_STAMP(g.wk, 11, dbg0);
     if (g.flags & GF_PROPAGATE) {
         // t1 = s1 V (E,E); state += increment                      (pilco.py:147-149)
         for (int e = t; e < E * E; e += blockDim.x) {
             const int r = e / E, c = e - r * E;
             double acc = 0.0;
-            for (int k = 0; k < D; ++k) acc = fma(g.s1[r * D + k], L.cxu[k * E + c], acc);
+            _Pragma("unroll 8") for (int k = 0; k < D; ++k) acc = fma(L.s1[r * D + k], L.cxu[k * E + c], acc);
             L.t1[e] = acc;
         }
-        if (t < E) L.mx[t] = L.mu[t] + g.m_x[t];
         __syncthreads();
         for (int e = t; e < E * E; e += blockDim.x) {
             const int r = e / E, c = e - r * E;
-            const double v = ((L.su[e] + g.s_x[e]) + L.t1[e]) + L.t1[c * E + r];
-            L.sx[e] = v;
-            g.s_x[e] = v;
+            const double v = ((L.su[e] + L.sx[e]) + L.t1[e]) + L.t1[c * E + r];
+            L.t2[e] = v;
+            g.s_out[e] = v;
         }
-        if (t < E) g.m_x[t] = L.mx[t];
+        if (t < E) {
+            const double v = L.mu[t] + L.mx[t];
+            L.misc[96 + t] = v;
+            g.m_out[t] = v;
+        }
         __syncthreads();
-    } else if (g.flags & (GF_TRAJ | GF_REWARD | GF_POLICY)) {
-        if (t < E) L.mx[t] = g.m_x[t];
-        for (int e = t; e < E * E; e += blockDim.x) L.sx[e] = g.s_x[e];
+        for (int e = t; e < E * E; e += blockDim.x) L.sx[e] = L.t2[e];
+        if (t < E) L.mx[t] = L.misc[96 + t];
         __syncthreads();
     }
+    DBG_STAMP(g.wk, 12, dbg0);
     if ((g.flags & GF_TRAJ) && g.traj) {
         double* dst = g.traj + (long)g.step * (E + E * E);
         if (t < E) dst[t] = L.mx[t];
         for (int e = t; e < E * E; e += blockDim.x) dst[E + e] = L.sx[e];
     }
-    if (g.flags & GF_REWARD) {  // standalone evaluation (pilco_reward_eval); the rollout uses the prep workgroup
+    if (g.flags & GF_REWARD) {  // standalone evaluation (pilco_reward_eval)
         double mu, var;
-        reward_eval(g.n_rewards, g.rw, E, L.mx, L.sx, L.ws, g.rew_out != nullptr, mu, var);
+        reward_eval(g.n_rewards, g.rw, E, L.mx, L.sx, L.ws, true, mu, var);
         if (t == 0) {
-            if (g.rew_out) {
-                g.rew_out[0] = mu;
-                g.rew_out[1] = var;
-            } else {
-                g.reward[0] += mu;
-            }
+            g.rew_out[0] = mu;
+            g.rew_out[1] = var;
         }
         __syncthreads();
     }
     if (g.flags & GF_POLICY) {
         if (g.pol_kind == PILCO_POLICY_LINEAR) {
             // M = m W^T + b, S = W s W^T, V = W^T                  (controllers.py:52-54)
+            bulk_load(L.t2, g.W, U * E);
+            __syncthreads();
             if (t < U) {
                 double acc = g.b[t];
-                for (int k = 0; k < E; ++k) acc = fma(g.W[t * E + k], L.mx[k], acc);
+                _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.t2[t * E + k], L.mx[k], acc);
                 L.mu[t] = acc;
             }
             for (int e = t; e < U * E; e += blockDim.x) {
                 const int u = e / E, c = e - u * E;
                 double acc = 0.0;
-                for (int k = 0; k < E; ++k) acc = fma(g.W[u * E + k], L.sx[k * E + c], acc);
+                _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.t2[u * E + k], L.sx[k * E + c], acc);
                 L.t1[e] = acc;  // W s
-                L.cxu[c * U + u] = g.W[e];
+                L.cxu[c * U + u] = L.t2[e];
             }
             __syncthreads();
             for (int e = t; e < U * U; e += blockDim.x) {
                 const int u = e / U, v = e - u * U;
                 double acc = 0.0;
-                for (int k = 0; k < E; ++k) acc = fma(L.t1[u * E + k], g.W[v * E + k], acc);
+                _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.t1[u * E + k], L.t2[v * E + k], acc);
                 L.su[e] = acc;
             }
             __syncthreads();
@@ -1217,17 +1303,20 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
             write_joint(g, L);
         }
     }
+    DBG_STAMP(g.wk, 13, dbg0);
 }
 
-void launch_glue(hipStream_t st, const GlueArgs& g) {
-    const size_t lds = glue_lds_bytes(g.E, g.D);
+void launch_glue(hipStream_t st, const GlueArgs& g, bool with_reward_block) {
+    const int mp_n = (g.flags & GF_PACK) ? g.wk.EL * g.wk.NCH * (1 + g.D) : 0;
+    const int seg_n = (g.flags & (GF_PACK | GF_ASSEMBLE)) ? g.wk.SEG * ((g.flags & GF_PACK) ? 1 : g.wk.nranks) : 0;
+    const size_t lds = sizeof(double) * glue_lds_doubles(g.E, g.D, seg_n, mp_n);
     static size_t configured = 0;
     if (lds > configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_glue), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         configured = lds;
     }
-    hipLaunchKernelGGL(k_glue, dim3(1), dim3(256), lds, st, g);
+    hipLaunchKernelGGL(k_glue, dim3(with_reward_block ? 2 : 1), dim3(256), lds, st, g);
 }
 
 // ------------------------------------------------------------------ self test
