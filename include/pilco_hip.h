@@ -140,6 +140,8 @@ int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_
 /* Developer aid: the first call (out32 may be NULL) switches on phase timestamps inside the
  * prep / glue kernels (100 MHz wall clock); later calls copy the 32 slots of the last launch. */
 int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32);
+/* per-workgroup (start, end) stamps of the last prep launch, n values (developer aid) */
+int pilco_debug_blocks(pilco_ctx* ctx, unsigned long long* out, int n);
 /* Time `reps` factorisations (invalidating the cache each time): ms per factorisation. */
 int pilco_factorize_timed(pilco_ctx* ctx, int slot, int reps, float* ms_each);
 

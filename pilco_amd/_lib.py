@@ -73,6 +73,7 @@ SIGNATURES = {
                                       C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "pilco_factorize_timed": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "pilco_debug_timestamps": (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
+    "pilco_debug_blocks": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.c_int]),
     "pilco_comm_unique_id": (C.c_int, [_vp]),
     "pilco_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "pilco_shard_set": (C.c_int, [_vp, C.c_int, C.c_int]),
@@ -319,8 +320,13 @@ class Context:
         return ms.value
 
     def debug_timestamps(self, read=True):
-        buf = (C.c_ulonglong * 32)()
+        buf = (C.c_ulonglong * 64)()
         self._chk(self.lib.pilco_debug_timestamps(self.h, buf if read else None))
+        return list(buf)
+
+    def debug_blocks(self, n):
+        buf = (C.c_ulonglong * n)()
+        self._chk(self.lib.pilco_debug_blocks(self.h, buf, n))
         return list(buf)
 
     # ---- sharding

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 
 #include "moment.h"
 
@@ -48,7 +49,13 @@ struct pilco_ctx {
     DevBuf selftest;
     DevBuf exp_tab;  // 2^(j/64), j = 0..63
     unsigned long long* dbg = nullptr;
+    // cached hipGraph of one rollout (single-rank): replayed while the plan key is unchanged
+    hipGraphExec_t graph = nullptr;
+    std::vector<unsigned long long> graph_key;
+    bool use_graph = true;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t st2 = nullptr;                        // side stream of the reward kernel
+    hipEvent_t ev_state = nullptr, ev_rew = nullptr;  // fork / join of the side stream
     std::vector<hipEvent_t> pair_events;
 };
 
@@ -370,8 +377,11 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
     pilco_ctx* ctx = new pilco_ctx();
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&ctx->d_info, 64 * sizeof(int)) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
-        hipEventCreate(&ctx->ev1) != hipSuccess) {
+        hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_state, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_rew, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return PILCO_E_HIP;
     }
@@ -384,6 +394,7 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
             return PILCO_E_HIP;
         }
     }
+    if (const char* eg = getenv("PILCO_NO_GRAPH")) ctx->use_graph = (atoi(eg) == 0);
     const char* env = getenv("PILCO_PAIR_KERNEL");
     if (env) ctx->variant = (atoi(env) >= 0 && atoi(env) <= 2) ? atoi(env) : 0;
     *out = ctx;
@@ -394,6 +405,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (!ctx) return PILCO_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->st);
+    if (ctx->graph) (void)hipGraphExecDestroy(ctx->graph);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
         for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr,
@@ -410,6 +422,9 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     for (hipEvent_t e : ctx->pair_events) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_state) (void)hipEventDestroy(ctx->ev_state);
+    if (ctx->ev_rew) (void)hipEventDestroy(ctx->ev_rew);
+    if (ctx->st2) (void)hipStreamDestroy(ctx->st2);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->st) (void)hipStreamDestroy(ctx->st);
     delete ctx;
@@ -709,6 +724,7 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
         g.maxact = ctx->params.p + off; off += U;
     }
     g.n_rewards = n_rw;
+    g.rew_out = nullptr;
     if (int r = stage_rewards(ctx, rw, n_rw, E, hp, off, ctx->params.p, g.rw)) return r;
     if (hp.size() > n_par) return fail(ctx, PILCO_E_ALLOC, "rollout: parameter staging overflow");
     HIPCHK(hipMemcpyAsync(ctx->params.p, hp.data(), sizeof(double) * n_par, hipMemcpyHostToDevice, ctx->st));
@@ -718,13 +734,14 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
 }
 
 // enqueue one full rollout on the stream (initial state already in plan.st[0]); the final
-// state ends up in plan.st[H & 1]
+// state ends up in plan.st[H & 1].  The reward of state t (pilco.py:133) is evaluated by the
+// second workgroup of the glue launch that turns state t into state t+1.
 int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev) {
     Slot& s = ctx->slot[0];
     const MMModel md = model_of(s);
     const int E = plan.E;
     GlueArgs g = plan.g;
-    const bool rew = g.n_rewards > 0;
+    const bool rew = g.n_rewards > 0 && !(s.wk.abl & 8);
     HIPCHK(hipMemsetAsync(g.reward, 0, sizeof(double), ctx->st));
     g.step = 0;
     g.m_x = plan.st[0];
@@ -737,6 +754,7 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
     for (int t = 0; t < H; ++t) {
         if (s.wk.PL > 0) {
             launch_mm_prep(ctx->st, md, s.wk);
+            if (ctx->dbg && (s.wk.abl & 64)) launch_stamp(ctx->st, ctx->dbg, 30);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
             launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
@@ -749,15 +767,69 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
         const int tail = GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ | (t + 1 < H ? GF_POLICY : 0);
         if (ctx->nranks == 1) {
             g.flags = GF_PACK | tail;
-            launch_glue(ctx->st, g, rew && !(s.wk.abl & 8));   // workgroup 1: reward of state t (pilco.py:133)
         } else {
             g.flags = GF_PACK;
             launch_glue(ctx->st, g);
             if (int r = all_gather_segments(ctx, s)) return r;
             g.flags = tail;
-            launch_glue(ctx->st, g, rew);
         }
+        launch_glue(ctx->st, g, rew);
     }
+    return PILCO_OK;
+}
+
+// Run one rollout: replay the cached hipGraph when the launch sequence is unchanged
+// (same buffers, sizes, horizon, policy / reward structure), otherwise (re)capture it.
+int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
+    Slot& s = ctx->slot[0];
+    if (!ctx->use_graph || ctx->nranks != 1 || (ctx->dbg && !getenv("PILCO_DBG_GRAPH"))) return enqueue_rollout(ctx, plan, H, nullptr);
+    const GlueArgs& g = plan.g;
+    std::vector<unsigned long long> key = {
+        (unsigned long long)H, (unsigned long long)g.pol_kind, (unsigned long long)g.n_rewards, (unsigned long long)g.squash,
+        (unsigned long long)ctx->variant, (unsigned long long)(uintptr_t)plan.st[0], (unsigned long long)(uintptr_t)g.s1,
+        (unsigned long long)(uintptr_t)g.traj, (unsigned long long)(uintptr_t)g.W, (unsigned long long)(uintptr_t)g.maxact,
+        (unsigned long long)(uintptr_t)s.w_part.p, (unsigned long long)(uintptr_t)s.w_At.p, (unsigned long long)(uintptr_t)s.w_Bt.p,
+        (unsigned long long)(uintptr_t)s.w_small.p, (unsigned long long)(uintptr_t)s.w_gath.p, (unsigned long long)(uintptr_t)s.w_out.p,
+        (unsigned long long)(uintptr_t)s.w_in.p, (unsigned long long)(uintptr_t)s.d_lists, (unsigned long long)(uintptr_t)s.beta.p,
+        (unsigned long long)(uintptr_t)s.iK.p, (unsigned long long)s.iK_null, (unsigned long long)(uintptr_t)s.Xt.p,
+        (unsigned long long)(uintptr_t)s.Zt.p, (unsigned long long)(uintptr_t)s.ls.p, (unsigned long long)s.n,
+        (unsigned long long)s.wk.sk_waves, (unsigned long long)s.wk.NT, (unsigned long long)s.wk.NCH, (unsigned long long)s.wk.abl};
+    for (int i = 0; i < g.n_rewards; ++i) {
+        key.push_back((unsigned long long)g.rw[i].kind);
+        key.push_back((unsigned long long)(long long)g.rw[i].rank);
+        key.push_back((unsigned long long)(uintptr_t)g.rw[i].W);
+        unsigned long long cbits;
+        memcpy(&cbits, &g.rw[i].coef, sizeof(cbits));
+        key.push_back(cbits);
+    }
+    if (!ctx->graph || key != ctx->graph_key) {
+        if (ctx->graph) {
+            (void)hipGraphExecDestroy(ctx->graph);
+            ctx->graph = nullptr;
+        }
+        // warm the per-kernel one-time host configuration outside the capture
+        if (int r = enqueue_rollout(ctx, plan, H > 0 ? 1 : 0, nullptr)) return r;
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(ctx->st, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_rollout(ctx, plan, H, nullptr);
+        hipError_t e = hipStreamEndCapture(ctx->st, &graph);
+        if (rc != PILCO_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e != hipSuccess) return fail(ctx, PILCO_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        e = hipGraphInstantiate(&ctx->graph, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+            ctx->graph = nullptr;
+            return fail(ctx, PILCO_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        }
+        ctx->graph_key = key;
+        // the warm-up rollout above overwrote the initial state: the caller re-uploads it (see callers)
+        return -1;
+    }
+    HIPCHK(hipGraphLaunch(ctx->graph, ctx->st));
     return PILCO_OK;
 }
 
@@ -773,9 +845,14 @@ int pilco_rollout(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     RolloutPlan plan;
     if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, traj != nullptr, plan)) return r;
     const int E = plan.E;
-    HIPCHK(hipMemcpyAsync(plan.st[0], m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipMemcpyAsync(plan.st[0] + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
-    if (int r = enqueue_rollout(ctx, plan, H, nullptr)) return r;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIPCHK(hipMemcpyAsync(plan.st[0], m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
+        HIPCHK(hipMemcpyAsync(plan.st[0] + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
+        const int r = run_rollout(ctx, plan, H);
+        if (r == -1) continue;  // graph was just (re)captured: upload the state again and replay it
+        if (r != PILCO_OK) return r;
+        break;
+    }
     HIPCHK(hipMemcpyAsync(mH, plan.st[H & 1], sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(SH, plan.st[H & 1] + E, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(reward, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
@@ -846,15 +923,15 @@ int pilco_reward_eval(pilco_ctx* ctx, const pilco_reward_term* rewards, int n_re
     GlueArgs g{};
     g.E = E; g.D = E; g.U = 0;
     g.m_x = ctx->state.p;
-    g.s_x = g.m_x + E;
+    g.s_x = ctx->state.p + E;
     g.n_rewards = n_rewards;
     if (int r = stage_rewards(ctx, rewards, n_rewards, E, h, off, ctx->state.p, g.rw)) return r;
     if (h.size() < off + 2) h.resize(off + 2, 0.0);
-    ENSURE(ctx->state, h.size() + 8);
+    if (h.size() + 8 > ctx->state.cap) return fail(ctx, PILCO_E_ALLOC, "reward_eval: staging overflow");
     g.rew_out = ctx->state.p + off;
-    g.flags = GF_REWARD;
+    g.flags = 0;  // workgroup 0 idles; workgroup 1 evaluates mean and variance
     HIPCHK(hipMemcpyAsync(ctx->state.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->st));
-    launch_glue(ctx->st, g);
+    launch_glue(ctx->st, g, true);
     double o[2];
     HIPCHK(hipMemcpyAsync(o, g.rew_out, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
@@ -878,10 +955,18 @@ int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_
     HIPCHK(hipMemcpyAsync(init, m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipMemcpyAsync(init + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
+    {   // make sure the graph exists before the timed region
+        HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
+        const int r = run_rollout(ctx, plan, H);
+        if (r != PILCO_OK && r != -1) return r;
+        HIPCHK(hipStreamSynchronize(ctx->st));
+    }
     HIPCHK(hipEventRecord(ctx->ev0, ctx->st));
     for (int rep = 0; rep < reps; ++rep) {
         HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
-        if (int r = enqueue_rollout(ctx, plan, H, nullptr)) return r;
+        const int r = run_rollout(ctx, plan, H);
+        if (r == -1) return fail(ctx, PILCO_E_STATE, "rollout_timed: graph re-captured inside the timed region");
+        if (r != PILCO_OK) return r;
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->st));
     HIPCHK(hipEventSynchronize(ctx->ev1));
@@ -976,17 +1061,29 @@ int pilco_shard_owner_of_pair(const pilco_ctx* ctx, int pair_index) {
     return s.pair_owner[pair_index];
 }
 
-int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32) {
+int pilco_debug_blocks(pilco_ctx* ctx, unsigned long long* out, int n) {
+    if (!ctx || !ctx->dbg || !out || n <= 0 || n > 4032) return PILCO_E_SHAPE;
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipMemcpy(out, ctx->dbg + 64, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PILCO_OK;
+}
+
+int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32) {  // 64 slots
     if (!ctx) return PILCO_E_SHAPE;
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->dbg) {
-        HIPCHK(hipMalloc(&ctx->dbg, 32 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&ctx->dbg, 4096 * sizeof(unsigned long long)));
         HIPCHK(hipMemset(ctx->dbg, 0, 32 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(ctx->dbg + 5, 0xff, sizeof(unsigned long long)));
+        HIPCHK(hipMemset(ctx->dbg + 22, 0xff, sizeof(unsigned long long)));
         for (Slot& s : ctx->slot) s.wk_valid = false;
     }
     if (out32) {
         HIPCHK(hipStreamSynchronize(ctx->st));
-        HIPCHK(hipMemcpy(out32, ctx->dbg, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out32, ctx->dbg, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemset(ctx->dbg, 0, 32 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(ctx->dbg + 5, 0xff, sizeof(unsigned long long)));
+        HIPCHK(hipMemset(ctx->dbg + 22, 0xff, sizeof(unsigned long long)));
     }
     return PILCO_OK;
 }

@@ -60,7 +60,6 @@ enum GlueFlags {
     GF_ASSEMBLE = 2,   // gath -> out_M, out_S, out_V
     GF_PROPAGATE = 4,  // state <- state + GP increment (pilco.py:147-149)
     GF_TRAJ = 8,       // store state into traj[step]
-    GF_REWARD = 16,    // reward accumulator += mean reward of the current state
     GF_POLICY = 32,    // controller + joint Gaussian -> in_m, in_s, s1 (pilco.py:139-144)
     GF_RBF_POST = 64,  // RBF policy: S -= diag(var - 1e-6), squash, joint (controllers.py:116-121)
     GF_RBF_PRE = 128   // RBF policy: copy the state into the policy slot's input
@@ -73,8 +72,6 @@ struct GlueArgs {
     int U;
     MMWork wk;          // dynamics slot workspace
     const double* var;  // dynamics kernel variances [E]
-    MMWork pwk;         // policy slot workspace (RBF policy only)
-    const double* pvar; // policy kernel variances [U]
     // rollout state
     const double* m_x;  // [E]     current state (read)
     const double* s_x;  // [E][E]
@@ -94,7 +91,7 @@ struct GlueArgs {
     RewardDev rw[MAX_REWARD_TERMS];
     // direct outputs of pilco_policy_action / pilco_reward_eval (optional)
     double* act_out;  // [U + U*U + E*U]
-    double* rew_out;  // [2]
+    double* rew_out;  // [2] mean, variance: set only by pilco_reward_eval
 };
 
 void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk);
@@ -110,6 +107,7 @@ size_t glue_lds_bytes(int E, int D);
 int mm_pair_nt(int npad, int variant, int PL);
 int mm_prep_nch(int npad, int PL);
 int mm_kp(int D);
+void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot);
 int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf, const double* exp_tab);
 
 }  // namespace pilco

@@ -41,6 +41,12 @@ __device__ __forceinline__ int pair_order_index(int E, int a, int b) {  // a >= 
     return (a == b) ? a : E + a * (a - 1) / 2 + b;
 }
 
+// Write-through (sc1) store: the 10 MB of per-step operands leave the XCD's L2 as they are
+// produced instead of in the end-of-kernel write-back, which is what the next kernel waits on.
+__device__ __forceinline__ void store_wt(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #define DBG_STAMP(wk_, slot_, cond_)                                           \
     do {                                                                       \
         if ((wk_).dbg && (cond_)) (wk_).dbg[slot_] = wall_clock64();          \
@@ -176,34 +182,28 @@ __device__ __forceinline__ double gj_wave(double (&a)[DT]) {
 }
 
 // ------------------------------------------------------------------ rewards
-// Solve (I_r + scale F^T S F) x = y in registers (one wave, column per lane) and return
-// exp(-scale y^T x / 2) / sqrt(det) through *slot.  A: [r][r] in LDS, y: [r] in LDS.
-template <int ET>
-__device__ void reward_solve(const double* A, const double* y, int r, double scale, double* slot) {
-    if (threadIdx.x < 64) {
-        const int c = threadIdx.x;
-        double col[ET];
-#pragma unroll
-        for (int k = 0; k < ET; ++k) {
-            double v = 0.0;
-            if (c < ET) {
-                v = (k == c) ? 1.0 : 0.0;
-                if (k < r && c < r) v = A[k * r + c];
-            } else if (c == ET) {
-                v = (k < r) ? y[k] : 0.0;
-            }
-            col[k] = v;
+// Unpivoted Gauss-Jordan for symmetric positive definite systems on an n x nc augmented
+// matrix in LDS (ping-pong buffers, one barrier per pivot, one element per thread when
+// n*nc <= blockDim).  Returns the buffer holding [I | A^{-1} B]; det in every thread.
+__device__ double* gauss_jordan_spd(double* G0, double* G1, int n, int nc, double& det) {
+    double* cur = G0;
+    double* nxt = G1;
+    det = 1.0;
+    for (int k = 0; k < n; ++k) {
+        __syncthreads();
+        const double piv = cur[k * nc + k];
+        det *= piv;
+        for (int e = threadIdx.x; e < n * nc; e += blockDim.x) {
+            const int r = e / nc, c = e - r * nc;
+            const double pk = cur[k * nc + c] / piv;
+            nxt[e] = (r == k) ? pk : fma(-cur[r * nc + k], pk, cur[r * nc + c]);
         }
-        const double det = gj_wave<ET>(col);
-        if (c == ET) {
-            double q = 0.0;
-#pragma unroll
-            for (int k = 0; k < ET; ++k)
-                if (k < r) q = fma(y[k], col[k], q);
-            *slot = exp(-0.5 * scale * q) / sqrt(det);
-        }
+        double* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
     }
     __syncthreads();
+    return cur;
 }
 
 // exp(-scale q / 2) / sqrt(det(I + scale S W)),  q = d^T W (I + scale S W)^{-1} d,  d = m - t
@@ -220,7 +220,7 @@ __device__ double exp_reward_moment(const RewardDev& rw, int E, double scale, co
         double* Fl = y + E;          // [E*E]  F staged in LDS
         double* SF = Fl + E * E;     // [E*E]
         double* A = SF + E * E;      // [E*E]
-        double* slot = A + E * E;
+        double* slot = A + E * E + E * (E + 1);
         for (int e2 = t; e2 < E * r; e2 += blockDim.x) Fl[e2] = rw.F[e2];
         if (t < E) slot[2 + t] = mx[t] - rw.t[t];
         __syncthreads();
@@ -244,12 +244,24 @@ __device__ double exp_reward_moment(const RewardDev& rw, int E, double scale, co
             A[e2] = fma(scale, acc, (k == l) ? 1.0 : 0.0);
         }
         __syncthreads();
-        if (E <= 4) reward_solve<4>(A, y, r, scale, slot);
-        else if (E <= 8) reward_solve<8>(A, y, r, scale, slot);
-        else if (E <= 12) reward_solve<12>(A, y, r, scale, slot);
-        else if (E <= 16) reward_solve<16>(A, y, r, scale, slot);
-        else if (E <= 24) reward_solve<24>(A, y, r, scale, slot);
-        else reward_solve<32>(A, y, r, scale, slot);
+        // [A | y] -> A^{-1} y; A is SPD so no pivoting is needed
+        double* G0 = SF;             // SF is dead from here on: reuse as the augmented matrix
+        double* G1 = A + E * E;      // [E*(E+1)]
+        const int nc = r + 1;
+        for (int e2 = t; e2 < r * nc; e2 += blockDim.x) {
+            const int k = e2 / nc, l = e2 - k * nc;
+            G1[e2] = (l < r) ? A[k * r + l] : y[k];
+        }
+        __syncthreads();
+        for (int e2 = t; e2 < r * nc; e2 += blockDim.x) G0[e2] = G1[e2];
+        double det;
+        const double* res = gauss_jordan_spd(G0, G1, r, nc, det);
+        if (t == 0) {
+            double q = 0.0;
+            for (int k = 0; k < r; ++k) q = fma(y[k], res[k * nc + r], q);
+            slot[0] = exp(-0.5 * scale * q) / sqrt(det);
+        }
+        __syncthreads();
         result = slot[0];
         __syncthreads();
     } else {
@@ -288,7 +300,7 @@ __device__ double exp_reward_moment(const RewardDev& rw, int E, double scale, co
     return result;
 }
 
-__host__ __device__ inline size_t reward_lds_doubles(int E) { return (size_t)E + 4 * (size_t)E * E + (size_t)E + 16; }
+__host__ __device__ inline size_t reward_lds_doubles(int E) { return (size_t)E + 4 * (size_t)E * E + (size_t)E * (E + 1) + (size_t)E + 16; }
 
 // mean (and variance) of the combined reward at (mx, sx) held in LDS (rewards.py:19-81)
 __device__ void reward_eval(int n, const RewardDev* rws, int E, const double* mx, const double* sx, double* ws,
@@ -314,8 +326,11 @@ __device__ void reward_eval(int n, const RewardDev* rws, int E, const double* mx
 }
 
 // ------------------------------------------------------------------ prep
+#ifndef PREP_MINW
+#define PREP_MINW 1
+#endif
 template <int DT>
-__global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk) {
+__global__ __launch_bounds__(256, PREP_MINW) void k_mm_prep(MMModel md, MMWork wk) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = md.D, npad = md.npad;
     double* s_m = sm;
@@ -331,6 +346,9 @@ __global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk) {
     const int pl = blockIdx.x, ch = blockIdx.y;
     const bool dbg0 = (t == 0 && pl == 0 && ch == 0);
     DBG_STAMP(wk, 0, dbg0);
+    if (wk.dbg && t == 0) {
+        wk.dbg[64 + 2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
+    }
     int a, b;
     local_pair_ab(wk, md.E, pl, a, b);
     const bool diag = (a == b);
@@ -353,15 +371,8 @@ __global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk) {
     }
     __syncthreads();
     DBG_STAMP(wk, 1, dbg0);
-    // the first rows' coordinates are fetched now so that their latency overlaps the Gauss-Jordan waves
     const int rpc = npad / wk.NCH;
     const int i_begin = ch * rpc, i_end = i_begin + rpc;
-    double xpre[DT];
-    {
-        const int ip = (i_begin + t < i_end) ? i_begin + t : i_begin;
-#pragma unroll
-        for (int d = 0; d < DT; ++d) xpre[d] = (d < D) ? md.Pt[(long)d * npad + ip] : 0.0;
-    }
     if (wk.abl & 2) {
         if (t == 0) { s_sc[0] = 1.0; s_sc[1] = 1.0; }
     } else if (w == 0) {
@@ -421,6 +432,7 @@ __global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk) {
     }
     __syncthreads();
     DBG_STAMP(wk, 2, dbg0);
+    DBG_STAMP(wk, 48 + w, lane == 0 && pl == 30 && ch == 1);
     const double logva = log(md.var[a]), logvb = log(md.var[b]);
     const int KP = wk.KP;
     double* At = wk.At + (long)pl * KP * npad + ((wk.abl & 1) ? (long)(-i_begin - (t & ~63)) : 0);
@@ -432,54 +444,41 @@ __global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk) {
     for (int d = 0; d < DT; ++d) h[d] = 0.0;
     for (int i = i_begin + t; i < ((wk.abl & 4) ? i_begin : i_end); i += 256) {
         const bool valid = i < md.n;
-        double zeta[DT], z[DT], wv[DT], qz[DT], qw[DT];
+        double zeta[DT];
 #pragma unroll
-        for (int d = 0; d < DT; ++d) {
-            const double xv = (i == i_begin + t) ? xpre[d] : ((d < D) ? md.Pt[(long)d * npad + i] : 0.0);
-            zeta[d] = (d < D && valid) ? xv - s_m[d] : 0.0;
-        }
-        double ka = logva, kb = logvb;
+        for (int d = 0; d < DT; ++d) zeta[d] = (d < D && valid) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
+        // Row side, then column side: y = Q x by columns of the symmetric Q (DT independent
+        // accumulators, one wide LDS row read per column step: no LDS latency on the FMA chains).
 #pragma unroll
-        for (int d = 0; d < DT; ++d) {
-            z[d] = zeta[d] * s_ia2[d];     // z = zeta / la^2   (padding: ia2 = ib2 = 0)
-            wv[d] = zeta[d] * s_ib2[d];    // w = zeta / lb^2
-            ka = fma(-0.5 * zeta[d], z[d], ka);
-            kb = fma(-0.5 * zeta[d], wv[d], kb);
-            qz[d] = 0.0;
-            qw[d] = 0.0;
-        }
-        // Q z and Q w by columns of the symmetric Q: DT independent accumulators per product,
-        // one LDS row (wide reads) per column step -- no LDS latency on the dependency chain
+        for (int side = 0; side < 2; ++side) {
+            const double* il2 = side ? s_ib2 : s_ia2;   // padding entries are zero
+            double x[DT], y[DT];
+            double kk = side ? logvb : logva;
 #pragma unroll
-        for (int c = 0; c < DT; ++c) {
-            double qrow[DT];
-#pragma unroll
-            for (int r = 0; r < DT; ++r) qrow[r] = s_Q[c * DT + r];
-#pragma unroll
-            for (int r = 0; r < DT; ++r) {
-                qz[r] = fma(qrow[r], z[c], qz[r]);
-                qw[r] = fma(qrow[r], wv[c], qw[r]);
+            for (int d = 0; d < DT; ++d) {
+                x[d] = zeta[d] * il2[d];
+                kk = fma(-0.5 * zeta[d], x[d], kk);
+                y[d] = 0.0;
             }
-        }
-        double u = 0.0, v = 0.0;
 #pragma unroll
-        for (int r = 0; r < DT; ++r) {
-            u = fma(z[r], qz[r], u);
-            v = fma(wv[r], qw[r], v);
-        }
+            for (int c = 0; c < DT; ++c) {
+                double qrow[DT];
 #pragma unroll
-        for (int r = 0; r < DT; ++r)
-            if (r < D) {
-                At[(long)r * npad + i] = 2.0 * qz[r];   // zero for padded rows (zeta = 0)
-                Bt[(long)r * npad + i] = wv[r];
+                for (int r = 0; r < DT; ++r) qrow[r] = s_Q[c * DT + r];
+#pragma unroll
+                for (int r = 0; r < DT; ++r) y[r] = fma(qrow[r], x[c], y[r]);
+                if ((c & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // keep at most two rows of Q in flight
             }
-        At[(long)D * npad + i] = valid ? (ka + u) : 0.0;
-        At[(long)(D + 1) * npad + i] = valid ? 1.0 : 0.0;
-        Bt[(long)D * npad + i] = valid ? 1.0 : 0.0;
-        Bt[(long)(D + 1) * npad + i] = valid ? (kb + v) : 0.0;
-        for (int k = D + 2; k < KP; ++k) {
-            At[(long)k * npad + i] = 0.0;
-            Bt[(long)k * npad + i] = 0.0;
+            double quad = 0.0;
+#pragma unroll
+            for (int r = 0; r < DT; ++r) quad = fma(x[r], y[r], quad);
+            double* dst = side ? Bt : At;
+#pragma unroll
+            for (int r = 0; r < DT; ++r)
+                if (r < D) store_wt(&dst[(long)r * npad + i], side ? x[r] : 2.0 * y[r]);   // w_j | 2 Q z_i (0 for padded rows)
+            store_wt(&dst[(long)(D + side) * npad + i], valid ? (kk + quad) : 0.0);        // u_i at k = D | v_j at k = D+1
+            store_wt(&dst[(long)(D + 1 - side) * npad + i], valid ? 1.0 : 0.0);
+            for (int k = D + 2; k < KP; ++k) store_wt(&dst[(long)k * npad + i], 0.0);
         }
         if (diag) {  // mean part: lb_i = exp(-zeta^T T zeta / 2) beta_i      (mgpr.py:113)
             double tz[DT];
@@ -492,6 +491,7 @@ __global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk) {
                 for (int r = 0; r < DT; ++r) trow[r] = s_T[c * DT + r];
 #pragma unroll
                 for (int r = 0; r < DT; ++r) tz[r] = fma(trow[r], zeta[c], tz[r]);
+                if ((c & 1) == 1) __builtin_amdgcn_sched_barrier(0);
             }
             double q = 0.0;
 #pragma unroll
@@ -503,6 +503,8 @@ __global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk) {
         }
     }
     DBG_STAMP(wk, 3, dbg0);
+    DBG_STAMP(wk, 40 + w, lane == 0 && pl == 0 && ch == 0);
+    DBG_STAMP(wk, 44 + w, lane == 0 && pl == 30 && ch == 1);
     if (diag) {
         g = wave_sum_lane63(g);
         if (lane == 63) red[w * (DT + 1)] = g;
@@ -530,6 +532,9 @@ __global__ __launch_bounds__(256) void k_mm_prep(MMModel md, MMWork wk) {
         }
     }
     DBG_STAMP(wk, 4, dbg0);
+    if (wk.dbg && t == 0) {
+        wk.dbg[65 + 2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
+    }
 }
 
 size_t prep_lds_bytes(int DT) {
@@ -539,10 +544,15 @@ size_t prep_lds_bytes(int DT) {
 int mm_kp(int D) { return round_up(D + 2, 4); }
 
 int mm_prep_nch(int npad, int PL) {
-    // enough row chunks to occupy the chip, each chunk a multiple of 64 rows
+    // Row chunks per pair: as many as keep the whole grid resident in ONE round (the kernel
+    // needs the full register file: one workgroup per CU), each chunk a multiple of 64 rows.
+    int cus = 256;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     const int nb = npad / 64;
     int nch = 1;
-    while (nch * 2 <= nb && nb % (nch * 2) == 0 && PL * nch < 256) nch *= 2;
+    while (nch * 2 <= nb && nb % (nch * 2) == 0 && PL * nch * 2 <= cus) nch *= 2;
     return nch;
 }
 
@@ -759,6 +769,7 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int NS = npad / 16;
     const int KP = wk.KP;
+    DBG_STAMP(wk, 16, w == 0 && lane == 0);
     const int nd_steps = wk.sk_nd * wk.sk_tdiag;
     int step = sk_boundary(wk, w);
     const int end = sk_boundary(wk, w + 1);
@@ -828,6 +839,9 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
         wk.sk_pidx[2 * w] = p0;
         wk.sk_pidx[2 * w + 1] = p1;
     }
+    DBG_STAMP(wk, 17, w == 0 && lane == 0);
+    DBG_STAMP(wk, 18, w == wk.sk_waves - 1 && lane == 0);
+    if (wk.dbg && lane == 0 && (w & 7) == 0) wk.dbg[1024 + (w >> 3)] = wall_clock64();  // end stamp of every 8th wave
 }
 
 
@@ -1011,12 +1025,13 @@ struct GlueLds {
     double* seg;  // [SEG]    this rank's packed results
     double* mp;   // [EL*NCH*(1+D)] mean partials
     double* misc; // [128]
-    double* ws;   // reward scratch (standalone reward_eval / workgroup 1)
 };
 
 static size_t glue_lds_doubles(int E, int D, int SEG, int mp) {
     const int nm = E > D ? E : D;
-    return (size_t)2 * nm + 6 * (size_t)nm * nm + (size_t)SEG + (size_t)mp + 128 + reward_lds_doubles(E);
+    const size_t tail = (size_t)SEG + (size_t)mp;
+    const size_t rew = reward_lds_doubles(E);
+    return (size_t)2 * nm + 6 * (size_t)nm * nm + 128 + (tail > rew ? tail : rew);
 }
 size_t glue_lds_bytes(int E, int D) { return sizeof(double) * glue_lds_doubles(E, D, 0, 0); }
 
@@ -1182,31 +1197,41 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
     L.t2 = L.t1 + nm * nm;
     L.s1 = L.t2 + nm * nm;
     L.misc = L.s1 + nm * nm;
-    L.ws = L.misc + 128;
-    L.seg = L.ws + reward_lds_doubles(E);
+    L.seg = L.misc + 128;
     L.mp = L.seg + seg_n;
 
     const bool dbg0 = (t == 0);
-    if (blockIdx.x == 1) {  // reward of the current (pre-propagation) state
+    const int dbo = (g.step == 0) ? 16 : 0;  // the initial glue of a rollout stamps slots 24..29
+    if (blockIdx.x == 1) {
+        // Workgroup 1: reward of the current (pre-propagation) state (rewards.py:19-81), evaluated
+        // concurrently with workgroup 0; the state is double-buffered so there is no race.
         DBG_STAMP(g.wk, 20, dbg0);
+        double* ws = L.seg;  // scratch: this workgroup uses none of the pack / assemble storage
         if (t < E) L.mx[t] = g.m_x[t];
         bulk_load(L.sx, g.s_x, E * E);
         __syncthreads();
         double mu, var;
-        reward_eval(g.n_rewards, g.rw, E, L.mx, L.sx, L.ws, false, mu, var);
-        if (t == 0) g.reward[0] += mu;  // single writer, stream ordered          (pilco.py:133)
+        reward_eval(g.n_rewards, g.rw, E, L.mx, L.sx, ws, g.rew_out != nullptr, mu, var);
+        if (t == 0) {
+            if (g.rew_out) {
+                g.rew_out[0] = mu;   // pilco_reward_eval: mean and variance
+                g.rew_out[1] = var;
+            } else {
+                g.reward[0] += mu;   // rollout (pilco.py:133): single writer, stream ordered
+            }
+        }
         DBG_STAMP(g.wk, 21, dbg0);
         return;
     }
 
-    DBG_STAMP(g.wk, 8, dbg0);
+    DBG_STAMP(g.wk, 8 + dbo, dbg0);
     int pre_wlo = 0, pre_whi = -1;
     if ((g.flags & GF_PACK) && g.wk.sk_waves > 0 && (t >> 2) < g.wk.PL) {
         pre_wlo = g.wk.sk_wlo[t >> 2];
         pre_whi = g.wk.sk_whi[t >> 2];
     }
     // one batch of loads for everything the serial part reads
-    if (g.flags & (GF_PROPAGATE | GF_TRAJ | GF_REWARD | GF_POLICY)) {
+    if (g.flags & (GF_PROPAGATE | GF_TRAJ | GF_POLICY)) {
         if (t < E) L.mx[t] = g.m_x[t];
         bulk_load(L.sx, g.s_x, E * E);
     }
@@ -1215,14 +1240,14 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
     if ((g.flags & GF_ASSEMBLE) && !(g.flags & GF_PACK)) bulk_load(L.seg, g.wk.gath, seg_n);
     __syncthreads();
 
-    DBG_STAMP(g.wk, 9, dbg0);
+    DBG_STAMP(g.wk, 9 + dbo, dbg0);
     if ((g.flags & GF_PACK) && !(g.wk.abl & 16)) mm_pack(g.wk, D, E, L, pre_wlo, pre_whi);
-    DBG_STAMP(g.wk, 10, dbg0);
+    DBG_STAMP(g.wk, 10 + dbo, dbg0);
     if (g.flags & GF_ASSEMBLE) {
         // single rank: the LDS copy of the segment is the whole gather buffer
         mm_assemble(g.wk, L.seg, g.var, D, E, L.mu, L.su, L.cxu);  // oM -> mu, oS -> su, oV -> cxu
     }
-    DBG_STAMP(g.wk, 11, dbg0);
+    DBG_STAMP(g.wk, 11 + dbo, dbg0);
     if (g.flags & GF_PROPAGATE) {
         // t1 = s1 V (E,E); state += increment                      (pilco.py:147-149)
         for (int e = t; e < E * E; e += blockDim.x) {
@@ -1248,20 +1273,11 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
         if (t < E) L.mx[t] = L.misc[96 + t];
         __syncthreads();
     }
-    DBG_STAMP(g.wk, 12, dbg0);
+    DBG_STAMP(g.wk, 12 + dbo, dbg0);
     if ((g.flags & GF_TRAJ) && g.traj) {
         double* dst = g.traj + (long)g.step * (E + E * E);
         if (t < E) dst[t] = L.mx[t];
         for (int e = t; e < E * E; e += blockDim.x) dst[E + e] = L.sx[e];
-    }
-    if (g.flags & GF_REWARD) {  // standalone evaluation (pilco_reward_eval)
-        double mu, var;
-        reward_eval(g.n_rewards, g.rw, E, L.mx, L.sx, L.ws, true, mu, var);
-        if (t == 0) {
-            g.rew_out[0] = mu;
-            g.rew_out[1] = var;
-        }
-        __syncthreads();
     }
     if (g.flags & GF_POLICY) {
         if (g.pol_kind == PILCO_POLICY_LINEAR) {
@@ -1303,7 +1319,14 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
             write_joint(g, L);
         }
     }
-    DBG_STAMP(g.wk, 13, dbg0);
+    DBG_STAMP(g.wk, 13 + dbo, dbg0);
+}
+
+__global__ void k_stamp(unsigned long long* dbg, int slot) {
+    if (threadIdx.x == 0) dbg[slot] = wall_clock64();
+}
+void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot) {
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, st, dbg, slot);
 }
 
 void launch_glue(hipStream_t st, const GlueArgs& g, bool with_reward_block) {
