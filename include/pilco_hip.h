@@ -157,6 +157,19 @@ int pilco_comm_init(pilco_ctx* ctx, const void* id128, int rank, int nranks);
  * all-gather for tests; gloo fallback).  Ownership map: pair p -> rank. */
 int pilco_shard_set(pilco_ctx* ctx, int rank, int nranks);
 int pilco_shard_owner_of_pair(const pilco_ctx* ctx, int pair_index);
+/* Layout of the per-step exchange (pure host functions, usable without a GPU).
+ * out5 = {local pairs, owned outputs, SEG (doubles per rank), OUTOFF, P}; pairs are dealt
+ * round-robin in the order (0,0),(1,1),..,(E-1,E-1),(1,0),(2,0),(2,1),.. and output a belongs
+ * to the owner of (a,a).  *_slot return indices into the gathered buffer [nranks][SEG]. */
+int pilco_shard_plan(int E, int D, int nranks, int rank, int* out5);
+int pilco_shard_pair_slot(int E, int D, int nranks, int a, int b);
+int pilco_shard_output_slot(int E, int D, int nranks, int a);
+/* One sharded moment-matching step with the exchange done by the caller: shard_pack runs this
+ * rank's pairs and returns its SEG doubles; after an all-gather by any transport, shard_finish
+ * assembles (M, S, V) from the [nranks][SEG] buffer.  pilco_gp_predict / pilco_rollout do the
+ * same with ncclAllGather when a communicator is attached. */
+int pilco_gp_shard_pack(pilco_ctx* ctx, int slot, const double* m, const double* s, double* segment);
+int pilco_gp_shard_finish(pilco_ctx* ctx, int slot, const double* gathered, double* M, double* S, double* V);
 int pilco_comm_rank(const pilco_ctx* ctx);
 int pilco_comm_size(const pilco_ctx* ctx);
 

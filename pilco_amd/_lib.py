@@ -78,6 +78,11 @@ SIGNATURES = {
     "pilco_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "pilco_shard_set": (C.c_int, [_vp, C.c_int, C.c_int]),
     "pilco_shard_owner_of_pair": (C.c_int, [_vp, C.c_int]),
+    "pilco_shard_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "pilco_shard_pair_slot": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pilco_shard_output_slot": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pilco_gp_shard_pack": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
+    "pilco_gp_shard_finish": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
     "pilco_comm_rank": (C.c_int, [_vp]),
     "pilco_comm_size": (C.c_int, [_vp]),
 }
@@ -341,8 +346,42 @@ class Context:
         buf = C.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
         self._chk(self.lib.pilco_comm_init(self.h, buf, int(rank), int(nranks)))
 
+    def shard_pack(self, slot, m, s, D, E, nranks, rank):
+        plan = shard_plan(E, D, nranks, rank)
+        m = _f64(m, (D,))
+        s = _f64(s, (D, D))
+        seg = np.zeros(plan["SEG"])
+        self._chk(self.lib.pilco_gp_shard_pack(self.h, slot, _ptr(m), _ptr(s), _ptr(seg)))
+        return seg
+
+    def shard_finish(self, slot, gathered, D, E):
+        g = _f64(gathered).reshape(-1)
+        M = np.empty((1, E))
+        S = np.empty((E, E))
+        V = np.empty((D, E))
+        self._chk(self.lib.pilco_gp_shard_finish(self.h, slot, _ptr(g), _ptr(M), _ptr(S), _ptr(V)))
+        return M, S, V
+
     def shard_set(self, rank, nranks):
         self._chk(self.lib.pilco_shard_set(self.h, int(rank), int(nranks)))
+
+
+def shard_plan(E, D, nranks, rank):
+    """Ownership / gather-buffer layout of the sharded step (pure host function)."""
+    lib = load_library()
+    out = (C.c_int * 5)()
+    rc = lib.pilco_shard_plan(int(E), int(D), int(nranks), int(rank), out)
+    if rc != PILCO_OK:
+        raise PilcoError(rc, "bad shard plan arguments")
+    return dict(PL=out[0], EL=out[1], SEG=out[2], OUTOFF=out[3], P=out[4])
+
+
+def shard_pair_slot(E, D, nranks, a, b):
+    return load_library().pilco_shard_pair_slot(int(E), int(D), int(nranks), int(a), int(b))
+
+
+def shard_output_slot(E, D, nranks, a):
+    return load_library().pilco_shard_output_slot(int(E), int(D), int(nranks), int(a))
 
 
 _default_ctx = None

@@ -310,8 +310,8 @@ MMModel model_of(const Slot& s) {
 }
 
 int all_gather_segments(pilco_ctx* ctx, Slot& s) {
-    if (ctx->nranks == 1) return PILCO_OK;
-    if (!ctx->comm) return fail(ctx, PILCO_E_STATE, "sharded context without communicator: use the host exchange path");
+    if (ctx->nranks == 1 && !ctx->comm) return PILCO_OK;
+    if (!ctx->comm) return fail(ctx, PILCO_E_STATE, "sharded context without communicator: use pilco_gp_shard_pack / pilco_gp_shard_finish");
     double* base = s.wk.gath;
     ncclResult_t r = ncclAllGather(base + (size_t)ctx->rank * s.wk.SEG, base, s.wk.SEG, ncclDouble, ctx->comm, ctx->st);
     if (r != ncclSuccess) return fail(ctx, PILCO_E_RCCL, std::string("ncclAllGather: ") + ncclGetErrorString(r));
@@ -651,7 +651,7 @@ int pilco_gp_predict(pilco_ctx* ctx, int slot, const double* m, const double* s_
     g.E = E; g.D = D; g.U = 0;
     g.wk = s.wk;
     g.var = s.var.p;
-    if (ctx->nranks == 1) {
+    if (ctx->nranks == 1 && !ctx->comm) {
         g.flags = GF_PACK | GF_ASSEMBLE;
         launch_glue(ctx->st, g);
     } else {
@@ -765,7 +765,7 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
         g.m_out = plan.st[(t + 1) & 1];
         g.s_out = plan.st[(t + 1) & 1] + E;
         const int tail = GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ | (t + 1 < H ? GF_POLICY : 0);
-        if (ctx->nranks == 1) {
+        if (ctx->nranks == 1 && !ctx->comm) {
             g.flags = GF_PACK | tail;
         } else {
             g.flags = GF_PACK;
@@ -782,7 +782,7 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
 // (same buffers, sizes, horizon, policy / reward structure), otherwise (re)capture it.
 int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
     Slot& s = ctx->slot[0];
-    if (!ctx->use_graph || ctx->nranks != 1 || (ctx->dbg && !getenv("PILCO_DBG_GRAPH"))) return enqueue_rollout(ctx, plan, H, nullptr);
+    if (!ctx->use_graph || ctx->nranks != 1 || ctx->comm || (ctx->dbg && !getenv("PILCO_DBG_GRAPH"))) return enqueue_rollout(ctx, plan, H, nullptr);
     const GlueArgs& g = plan.g;
     std::vector<unsigned long long> key = {
         (unsigned long long)H, (unsigned long long)g.pol_kind, (unsigned long long)g.n_rewards, (unsigned long long)g.squash,
@@ -1085,6 +1085,85 @@ int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32) {  // 64 s
         HIPCHK(hipMemset(ctx->dbg + 5, 0xff, sizeof(unsigned long long)));
         HIPCHK(hipMemset(ctx->dbg + 22, 0xff, sizeof(unsigned long long)));
     }
+    return PILCO_OK;
+}
+
+// ---- pure host functions of the ownership / gather-buffer layout (no GPU needed)
+int pilco_shard_plan(int E, int D, int nranks, int rank, int* out5) {
+    if (E <= 0 || D <= 0 || nranks <= 0 || rank < 0 || rank >= nranks || !out5) return PILCO_E_SHAPE;
+    const int P = E * (E + 1) / 2;
+    const int PLcap = (P + nranks - 1) / nranks, ELcap = (E + nranks - 1) / nranks;
+    out5[0] = (rank < P) ? (P - rank + nranks - 1) / nranks : 0;  // local pairs
+    out5[1] = (rank < E) ? (E - rank + nranks - 1) / nranks : 0;  // owned outputs
+    out5[2] = PLcap + ELcap * (1 + D);                            // SEG: doubles per rank in the gather buffer
+    out5[3] = PLcap;                                              // OUTOFF: offset of the output records
+    out5[4] = P;
+    return PILCO_OK;
+}
+// index into the gathered buffer [nranks][SEG] of the value of pair (a,b), a >= b
+int pilco_shard_pair_slot(int E, int D, int nranks, int a, int b) {
+    if (a < b) { const int t = a; a = b; b = t; }
+    if (b < 0 || a >= E) return -1;
+    int plan[5];
+    if (pilco_shard_plan(E, D, nranks, 0, plan) != PILCO_OK) return -1;
+    const int kk = (a == b) ? a : E + a * (a - 1) / 2 + b;
+    return (kk % nranks) * plan[2] + kk / nranks;
+}
+// index of M_a in the gathered buffer (V_a[0..D) follows)
+int pilco_shard_output_slot(int E, int D, int nranks, int a) {
+    if (a < 0 || a >= E) return -1;
+    int plan[5];
+    if (pilco_shard_plan(E, D, nranks, 0, plan) != PILCO_OK) return -1;
+    return (a % nranks) * plan[2] + plan[3] + (a / nranks) * (1 + D);
+}
+
+// ---- host-mediated exchange: the caller moves the segments between the ranks
+int pilco_gp_shard_pack(pilco_ctx* ctx, int slot, const double* m, const double* s_in, double* segment) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "shard_pack: no current factorisation");
+    if (!m || !s_in || !segment) return fail(ctx, PILCO_E_SHAPE, "shard_pack: null pointer");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (int r = build_work(ctx, s)) return r;
+    const int D = s.D, E = s.E;
+    HIPCHK(hipMemcpyAsync(s.wk.in_m, m, sizeof(double) * D, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(s.wk.in_s, s_in, sizeof(double) * D * D, hipMemcpyHostToDevice, ctx->st));
+    const MMModel md = model_of(s);
+    if (s.wk.PL > 0) {
+        launch_mm_prep(ctx->st, md, s.wk);
+        launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
+    }
+    GlueArgs g{};
+    g.E = E; g.D = D; g.U = 0;
+    g.wk = s.wk;
+    g.var = s.var.p;
+    g.flags = GF_PACK;
+    launch_glue(ctx->st, g);
+    HIPCHK(hipMemcpyAsync(segment, s.wk.gath + (size_t)ctx->rank * s.wk.SEG, sizeof(double) * s.wk.SEG, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    return PILCO_OK;
+}
+
+int pilco_gp_shard_finish(pilco_ctx* ctx, int slot, const double* gathered, double* M, double* S, double* V) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.wk_valid) return fail(ctx, PILCO_E_STATE, "shard_finish before shard_pack");
+    if (!gathered || !M || !S || !V) return fail(ctx, PILCO_E_SHAPE, "shard_finish: null pointer");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int D = s.D, E = s.E;
+    HIPCHK(hipMemcpyAsync(s.wk.gath, gathered, sizeof(double) * (size_t)ctx->nranks * s.wk.SEG, hipMemcpyHostToDevice, ctx->st));
+    GlueArgs g{};
+    g.E = E; g.D = D; g.U = 0;
+    g.wk = s.wk;
+    g.var = s.var.p;
+    g.flags = GF_ASSEMBLE;
+    launch_glue(ctx->st, g);
+    HIPCHK(hipMemcpyAsync(M, s.wk.out_M, sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(S, s.wk.out_S, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(V, s.wk.out_V, sizeof(double) * D * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
     return PILCO_OK;
 }
 

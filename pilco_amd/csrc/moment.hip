@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256, PREP_MINW) void k_mm_prep(MMModel md, MMWork w
                 _Pragma("unroll 8") for (int k = 0; k < D; ++k) acc = fma(s_T[(t - 1) * DT + k], hs[1 + k], acc);
                 v = s_sc[1] * acc;
             }
-            wk.mean_part[((long)a * wk.NCH + ch) * (1 + D) + t] = v;
+            wk.mean_part[((long)(a / wk.nranks) * wk.NCH + ch) * (1 + D) + t] = v;  // indexed by the LOCAL output number
         }
     }
     DBG_STAMP(wk, 4, dbg0);

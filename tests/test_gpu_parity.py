@@ -247,3 +247,75 @@ def test_set_data_changes_n_and_not_pd_error(ctx):
         mdl.likelihood.variance.assign(0.0)
     with pytest.raises(NotPositiveDefiniteError):
         m.predict_on_noisy_inputs(np.zeros((1, 4)), 0.1 * np.eye(4))
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_step_two_contexts_host_allgather(variant, nranks):
+    """BASELINE config 3 data path on one GPU: `nranks` contexts each run their share of the pairs,
+    the test plays the all-gather, every rank assembles the same (M, S, V).  With the tiled kernel
+    (variant 2) the result is bit-identical to the single-rank run."""
+    from pilco_amd import _lib
+    c = synthetic.config_c2(N=200, D=6, E=5, noise=1e-2, seed=21, control_dim=1)
+    rs = np.random.RandomState(8)
+    m = 0.2 * rs.randn(1, 6)
+    A = 0.3 * rs.randn(6, 6)
+    s = A @ A.T + 0.05 * np.eye(6)
+    ctxs = []
+    try:
+        ref = _lib.Context(device=0)
+        ref.set_pair_kernel(variant)
+        ref.gp_set_data(0, c["X"], c["Y"])
+        ref.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"])
+        ref.gp_factorize(0)
+        M1, S1, V1 = ref.gp_predict(0, m, s, 6, 5)
+        segs = []
+        for r in range(nranks):
+            cx = _lib.Context(device=0)
+            cx.set_pair_kernel(variant)
+            cx.shard_set(r, nranks)
+            cx.gp_set_data(0, c["X"], c["Y"])
+            cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"])
+            cx.gp_factorize(0)
+            ctxs.append(cx)
+            segs.append(cx.shard_pack(0, m, s, 6, 5, nranks, r))
+        gathered = np.concatenate(segs)
+        for cx in ctxs:
+            M, S, V = cx.shard_finish(0, gathered, 6, 5)
+            if variant == 2:
+                assert np.array_equal(M, M1) and np.array_equal(S, S1) and np.array_equal(V, V1)
+            else:
+                np.testing.assert_allclose(M, M1, rtol=1e-13)
+                np.testing.assert_allclose(S, S1, rtol=1e-10, atol=1e-14)
+                np.testing.assert_allclose(V, V1, rtol=1e-13)
+        iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+        Mo, So, Vo = tp.predict_given_factorizations(c["X"], c["lengthscales"], c["variance"], m, s, iK, beta)
+        np.testing.assert_allclose(S, So, rtol=RTOL, atol=1e-12)
+        ref.close()
+    finally:
+        for cx in ctxs:
+            cx.close()
+
+
+def test_rccl_path_world_size_one():
+    """The RCCL branch (pack -> ncclAllGather -> assemble) with a one-rank communicator."""
+    from pilco_amd import _lib
+    c = synthetic.config_cascade()
+    cx = _lib.Context(device=0)
+    try:
+        cx.comm_init(cx.comm_unique_id(), 0, 1)
+        cx.gp_set_data(0, c["X"], c["Y"])
+        cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"])
+        cx.gp_factorize(0)
+        pol = dict(kind=_lib.POLICY_LINEAR, state_dim=2, control_dim=1, W=c["W"], b=c["b"].reshape(-1),
+                   max_action=c["max_action"], squash=True)
+        rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(2), t=np.zeros(2))]
+        M, S, R = cx.rollout(pol, rw, c["m"], c["s"], 4)
+        model = tp.Model(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+        ctrl = lambda mm, ss: tp.linear_controller(mm, ss, c["W"], c["b"], c["max_action"])
+        Mo, So, Ro = tp.predict(model, ctrl, tp.exponential_reward, c["m"], c["s"], 4, cache=True)
+        np.testing.assert_allclose(M, Mo, rtol=RTOL)
+        np.testing.assert_allclose(S, So, rtol=RTOL)
+        np.testing.assert_allclose(R, Ro, rtol=RTOL)
+    finally:
+        cx.close()

@@ -1,0 +1,145 @@
+"""CPU tests of the multi-GPU exchange contract (no GPU needed).
+
+The per-step exchange of the sharded rollout is one all-gather of fixed-size
+segments; which pair / output lands where is defined by pure host functions of
+libpilco_hip.so (pilco_shard_plan / _pair_slot / _output_slot).  Here two gloo
+ranks each evaluate their share of one moment-matching step with the CPU oracle,
+pack it with those functions, all-gather over torch.distributed (gloo) and
+assemble -- the result must equal the single-process oracle.  This is the N>1
+path of bench.py minus the device kernels (which test_gpu_parity.py covers with
+two contexts on one GPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported():
+    """The C-ABI library loads and exports every symbol include/pilco_hip.h declares."""
+    import re
+    from pilco_amd import _lib
+    lib = _lib.load_library()
+    hdr = open(os.path.join(ROOT, "include", "pilco_hip.h")).read()
+    declared = set(re.findall(r"\b(pilco_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"pilco_ctx", "pilco_status"}
+    assert declared, "no declarations parsed"
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, f"symbols declared in the header but not exported: {missing}"
+    unbound = [n for n in sorted(declared) if n not in _lib.SIGNATURES]
+    assert not unbound, f"symbols without a ctypes signature: {unbound}"
+    assert lib.pilco_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Compute calls fail loudly when no MI355X is visible (there is no CPU path)."""
+    from pilco_amd import _lib
+    import ctypes as C
+    h = C.c_void_p()
+    rc = _lib.load_library().pilco_ctx_create(0, C.byref(h))
+    if rc == 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(_lib.PilcoError):
+        _lib.Context(device=0)
+
+
+@pytest.mark.parametrize("E,D,W", [(10, 10, 8), (10, 11, 4), (2, 3, 2), (3, 5, 5), (4, 4, 1)])
+def test_shard_plan_is_a_partition(E, D, W):
+    from pilco_amd import _lib
+    P = E * (E + 1) // 2
+    plans = [_lib.shard_plan(E, D, W, r) for r in range(W)]
+    assert sum(p["PL"] for p in plans) == P and sum(p["EL"] for p in plans) == E
+    assert len({p["SEG"] for p in plans}) == 1
+    SEG = plans[0]["SEG"]
+    slots = set()
+    for a in range(E):
+        for b in range(a + 1):
+            s = _lib.shard_pair_slot(E, D, W, a, b)
+            assert s == _lib.shard_pair_slot(E, D, W, b, a)
+            r, k = divmod(s, SEG)
+            assert 0 <= r < W and k < plans[r]["PL"]
+            slots.add(s)
+    assert len(slots) == P
+    for a in range(E):
+        s = _lib.shard_output_slot(E, D, W, a)
+        r, k = divmod(s, SEG)
+        # the owner of output a is the owner of pair (a,a)
+        assert r == _lib.shard_pair_slot(E, D, W, a, a) // SEG
+        assert plans[r]["OUTOFF"] <= k and k + 1 + D <= SEG
+    assert max(p["PL"] for p in plans) - min(p["PL"] for p in plans) <= 1
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import tf_path as tp
+    from pilco_amd import _lib, synthetic
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        # the RCCL unique id travels as 128 opaque bytes: same broadcast as bench.py
+        id_t = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            id_t = torch.arange(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+        dist.broadcast(id_t, src=0)
+        assert bytes(id_t.numpy().tobytes()) == bytes(range(_lib.COMM_ID_BYTES))
+        c = synthetic.config_c2(N=60, D=5, E=4, noise=1e-2, seed=3, control_dim=1)
+        E, D = 4, 5
+        rs = np.random.RandomState(0)
+        m = 0.2 * rs.randn(1, D)
+        A = 0.3 * rs.randn(D, D)
+        s = A @ A.T + 0.05 * np.eye(D)
+        iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+        Mo, So, Vo = tp.predict_given_factorizations(c["X"], c["lengthscales"], c["variance"], m, s, iK, beta)
+        plan = _lib.shard_plan(E, D, world, rank)
+        seg = np.zeros(plan["SEG"])
+        # a rank fills only what it owns; values before "+ var - M M^T": S_ab + M_a M_b - delta var_a
+        for a in range(E):
+            for b in range(a + 1):
+                slot = _lib.shard_pair_slot(E, D, world, a, b)
+                if slot // plan["SEG"] == rank:
+                    seg[slot % plan["SEG"]] = So[a, b] + Mo[0, a] * Mo[0, b] - (c["variance"][a] if a == b else 0.0)
+            slot = _lib.shard_output_slot(E, D, world, a)
+            if slot // plan["SEG"] == rank:
+                k = slot % plan["SEG"]
+                seg[k] = Mo[0, a]
+                seg[k + 1:k + 1 + D] = Vo[:, a]
+        gathered = [torch.zeros(plan["SEG"], dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.from_numpy(seg))
+        g = torch.cat(gathered).numpy()
+        M = np.array([[g[_lib.shard_output_slot(E, D, world, a)] for a in range(E)]])
+        V = np.stack([g[_lib.shard_output_slot(E, D, world, a) + 1:_lib.shard_output_slot(E, D, world, a) + 1 + D] for a in range(E)], axis=1)
+        S = np.empty((E, E))
+        for a in range(E):
+            for b in range(E):
+                S[a, b] = g[_lib.shard_pair_slot(E, D, world, a, b)] + (c["variance"][a] if a == b else 0.0) - M[0, a] * M[0, b]
+        ok = np.allclose(M, Mo, rtol=1e-13) and np.allclose(S, So, rtol=1e-11, atol=1e-14) and np.allclose(V, Vo, rtol=1e-13)
+        # max-over-ranks timing reduction used by bench.py
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok = ok and t.item() == float(world)
+        dist.barrier()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world_size_2_exchange():
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
