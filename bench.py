@@ -120,6 +120,15 @@ def main():
     flop_local = flop / world  # pairs are dealt over the ranks
     achieved = flop_local / (pair_ms * 1e-3) / 1e12 if pair_ms > 0 else 0.0
 
+    # HBM bytes per pair-kernel launch: PMC counters of the committed rocprofv3 profile of this same
+    # command (profiles/r01_pmc_summary.json: 2*FETCH_SIZE + WRITE_SIZE, see the calibration note there)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            traffic = json.load(f)["pair_kernel_hbm_bytes_per_launch"] / world
+    except Exception:
+        traffic = None
+
     if rank == 0:
         out = {
             "metric": "moment-matching rollouts/sec (N=1000,D=10,E=10,H=40)",
@@ -139,8 +148,9 @@ def main():
                                    "factorisation cached (R-fwd)",
                        "parallelism": "pairs%d" % world, "event_ms_per_rollout": res["ms_total"] / args.steps},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "k_mm_pair_mfma", "avg_launch_ms": pair_ms,
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "k_mm_pair_sk (f64 MFMA exponent tiles + fp64 exp; MFMA and fp64 VALU share one pipe)",
+                         "avg_launch_ms": pair_ms,
                          "algorithmic_flop_per_launch": flop_local, "exp_per_launch": exps / world,
                          "gexp_per_s": exps / world / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0,
                          "algorithmic_bytes_per_launch": byts / world,
