@@ -20,7 +20,7 @@ struct Slot {
     std::vector<double> hZ;
     DevBuf Xt, Yt, Zt, ls, var, noise;         // Yt: [E][Npad]
     DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
-    DevBuf Kmn, Am, AmInv, AmD, iAt, G;        // FITC extras
+    DevBuf Kmn, V2, Am, AmInv, AmD, iAt, G;    // FITC extras
     // moment-matching workspace
     DevBuf w_in, w_At, w_Bt, w_small, w_part, w_gath, w_out;
     int* d_lists = nullptr;
@@ -409,7 +409,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
         for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr,
-                          &s.vec, &s.Kmn, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
+                          &s.vec, &s.Kmn, &s.V2, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
                           &s.w_part, &s.w_gath, &s.w_out})
             b->release();
         if (s.d_lists) (void)hipFree(s.d_lists);
@@ -1172,7 +1172,91 @@ int pilco_comm_size(const pilco_ctx* ctx) { return ctx ? ctx->nranks : -1; }
 
 }  // extern "C"
 
-// FITC factorisation is added in a later milestone; until then fail loudly.
-int pilco_factorize_fitc(pilco_ctx* ctx, void*) {
-    return fail(ctx, PILCO_E_STATE, "sparse (FITC) factorisation not available in this build");
+// ---- sparse GP: FITC factorisation of pilco/models/smgpr.py:24-45 on the device.
+// With L = chol(Kmm + 1e-6 I), V = L^{-1} Kmn / G, Am = chol(V V^T + sn2 I), At = L Am:
+//   beta = L^{-T} (Am Am^T)^{-1} (V/G) y,   iK = Kmm^{-1} - sn2 At^{-T} At^{-1}.
+// Explicit triangular inverses turn every solve into an MFMA GEMM / mat-vec.
+int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
+    Slot& s = *static_cast<Slot*>(slot_ptr);
+    const int E = s.E, Mp = s.npad, Np = s.Npad, nblk = Mp / NB;
+    const size_t mm = (size_t)Mp * Mp, mn = (size_t)Mp * Np;
+    ENSURE(s.K, E * mm);        // Kmm -> L
+    ENSURE(s.Linv, E * mm);
+    ENSURE(s.iK, E * mm);
+    ENSURE(s.invD, (size_t)E * nblk * NB * NB);
+    ENSURE(s.Kmn, E * mn);      // Kmn -> V
+    ENSURE(s.Am, E * mm);
+    ENSURE(s.AmInv, E * mm);
+    ENSURE(s.AmD, (size_t)E * nblk * NB * NB);
+    ENSURE(s.iAt, E * mm);
+    ENSURE(s.G, (size_t)E * Np);
+    ENSURE(s.beta, (size_t)E * Mp);
+    ENSURE(s.Tscr, (size_t)E * NB * Mp);
+    ENSURE(s.vec, (size_t)E * std::max(Mp, Np) * 2);
+    hipStream_t st = ctx->st;
+    HIPCHK(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * 64, st));
+    // smgpr.py:27-28: Kmm = K(Z) + 1e-6 I, Kmn = K(Z, X)
+    launch_gram(st, s.Zt.p, Mp, s.M, s.Zt.p, Mp, s.M, s.D, s.ls.p, s.var.p, E, s.K.p, Mp, Mp, 2, nullptr, 1e-6);
+    launch_gram(st, s.Zt.p, Mp, s.M, s.Xt.p, Np, s.N, s.D, s.ls.p, s.var.p, E, s.Kmn.p, Mp, Np, 0, nullptr, 0.0);
+    launch_potrf(st, s.K.p, Mp, E, s.invD.p, ctx->d_info);                      // smgpr.py:29
+    launch_trtri(st, s.K.p, Mp, E, s.invD.p, s.Linv.p, s.Tscr.p);
+    GemmDesc g{};
+    // V = L^{-1} Kmn  (smgpr.py:30) -- out of place into vec? Kmn is (Mp, Np): use iAt-sized scratch is too small, so
+    // write V into a second Kmn-sized buffer: reuse s.Am? no (Mp x Mp).  V goes to s.Kmn2 = s.vec is too small -> allocate.
+    DevBuf& Vb = s.V2;
+    ENSURE(Vb, E * mn);
+    g = GemmDesc{};
+    g.A = s.Linv.p; g.lda = Mp; g.sA = (long)mm;
+    g.B = s.Kmn.p; g.ldb = Np; g.sB = (long)mn;
+    g.C = Vb.p; g.ldc = Np; g.sC = (long)mn;
+    g.M = Mp; g.N = Np; g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.k_mode = 3;
+    launch_gemm(st, g, false, false, E);
+    launch_fitc_scale(st, Vb.p, Mp, Np, E, s.var.p, s.noise.p, s.G.p);          // smgpr.py:31-33
+    // Am = chol(V V^T + sn2 I)  (smgpr.py:34-35)
+    g = GemmDesc{};
+    g.A = Vb.p; g.lda = Np; g.sA = (long)mn;
+    g.B = Vb.p; g.ldb = Np; g.sB = (long)mn;
+    g.C = s.Am.p; g.ldc = Mp; g.sC = (long)mm;
+    g.M = Mp; g.N = Mp; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
+    launch_gemm(st, g, false, true, E);
+    launch_add_diag(st, s.Am.p, Mp, E, s.noise.p);
+    launch_potrf(st, s.Am.p, Mp, E, s.AmD.p, ctx->d_info + 32);
+    launch_trtri(st, s.Am.p, Mp, E, s.AmD.p, s.AmInv.p, s.Tscr.p);
+    // iAt = (L Am)^{-1} = Am^{-1} L^{-1}  (smgpr.py:36-37)
+    g = GemmDesc{};
+    g.A = s.AmInv.p; g.lda = Mp; g.sA = (long)mm;
+    g.B = s.Linv.p; g.ldb = Mp; g.sB = (long)mm;
+    g.C = s.iAt.p; g.ldc = Mp; g.sC = (long)mm;
+    g.M = Mp; g.N = Mp; g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.k_mode = 4;
+    launch_gemm(st, g, false, false, E);
+    // beta = L^{-T} Am^{-T} Am^{-1} (V/G) y  (smgpr.py:38-42)
+    double* r0 = s.vec.p;
+    double* r1 = s.vec.p + (size_t)E * Mp;
+    launch_fitc_rhs(st, Vb.p, s.G.p, s.Yt.p, Mp, Np, E, r0);
+    launch_matvec(st, s.AmInv.p, Mp, E, r0, r1, false);
+    launch_matvec(st, s.AmInv.p, Mp, E, r1, r0, true);
+    launch_matvec(st, s.Linv.p, Mp, E, r0, s.beta.p, true);
+    // iK = Kmm^{-1} - sn2 iAt^T iAt  (smgpr.py:43-44)
+    g = GemmDesc{};
+    g.A = s.Linv.p; g.lda = Mp; g.sA = (long)mm;
+    g.B = s.Linv.p; g.ldb = Mp; g.sB = (long)mm;
+    g.C = s.iK.p; g.ldc = Mp; g.sC = (long)mm;
+    g.M = Mp; g.N = Mp; g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.k_mode = 1;
+    launch_gemm(st, g, true, false, E);
+    g.A = s.iAt.p;
+    g.B = s.iAt.p;
+    g.alpha = -1.0; g.alpha_vec = s.noise.p; g.beta = 1.0; g.k_mode = 1;
+    launch_gemm(st, g, true, false, E);
+    launch_clear_padding(st, s.iK.p, Mp, s.M, E);
+    int info[64];
+    HIPCHK(hipMemcpyAsync(info, ctx->d_info, sizeof(int) * 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int a = 0; a < std::min(E, 32); ++a)
+        if (info[a] != 0 || info[32 + a] != 0) {
+            ctx->not_pd = a;
+            return fail(ctx, PILCO_E_NOT_PD, "FITC Cholesky failed for output " + std::to_string(a));
+        }
+    s.n = s.M;
+    s.iK_null = false;
+    return PILCO_OK;
 }

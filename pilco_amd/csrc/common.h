@@ -44,8 +44,9 @@ struct GemmDesc {
     int lda, ldb, ldc;
     long sA, sB, sC;    // batch strides (doubles)
     double alpha, beta;
+    const double* alpha_vec;  // optional per-batch multiplier of alpha (device), or nullptr
     int tile_mode;      // 0 all tiles, 1 only tiles with row-block >= col-block
-    int k_mode;         // 0 full K, 1 k >= max(i0,j0), 2 k >= j0, 3 k < i0+64 (A lower-triangular rows), 4: k>=j0 && k<i0+64
+    int k_mode;         // 0 full K; 1: k >= max(i0,j0); 2: k >= j0; 3: k < i0+64 (A lower triangular); 4: j0 <= k < i0+64
 };
 // C = alpha * op(A) op(B) + beta * C, batched; op selected by ta/tb (0 = as stored, 1 = transposed)
 void launch_gemm(hipStream_t st, const GemmDesc& g, bool ta, bool tb, int batch);
@@ -68,6 +69,13 @@ void launch_matvec(hipStream_t st, const double* A, int npad, int batch, const d
 // zero rows/cols >= n of batch square matrices
 void launch_clear_padding(hipStream_t st, double* A, int npad, int n, int batch);
 void launch_transpose_points(hipStream_t st, const double* X, int n, int D, double* Xt, int ld);
+// FITC helpers (smgpr.py:30-43)
+// G[b][n] = sqrt(1 + (var[b] - sum_m V[b][m][n]^2) / noise[b]);  V[b][m][n] /= G[b][n]
+void launch_fitc_scale(hipStream_t st, double* V, int mpad, int npad, int batch, const double* var, const double* noise, double* G);
+// A[b][i][i] += d[b]
+void launch_add_diag(hipStream_t st, double* A, int npad, int batch, const double* d);
+// r[b][m] = sum_n V[b][m][n] / G[b][n] * y[b][n]
+void launch_fitc_rhs(hipStream_t st, const double* V, const double* G, const double* y, int mpad, int npad, int batch, double* r);
 
 // ---------------------------------------------------------------- moment.hip
 struct MMWork;  // defined in moment.h

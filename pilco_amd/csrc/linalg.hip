@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
     const int i0 = bi * 64, j0 = bj * 64;
     int kbeg = 0, kend = g.K;
     if (g.k_mode == 1) kbeg = (i0 > j0 ? i0 : j0);
-    if (g.k_mode == 2) kbeg = j0;
+    if (g.k_mode == 2 || g.k_mode == 4) kbeg = j0;
+    if (g.k_mode == 3 || g.k_mode == 4) kend = (i0 + 64 < g.K) ? i0 + 64 : g.K;
     kbeg &= ~15;
     __shared__ double As[16][LDS_LD];
     __shared__ double Bs[16][LDS_LD];
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
                 const int row = i0 + wi + 16 * ti + lr + 4 * r;
                 const int col = j0 + wj + 16 * tj + lc;
                 double* c = C + (long)row * g.ldc + col;
-                double v = g.alpha * acc[ti][tj][r];
+                double v = g.alpha * (g.alpha_vec ? g.alpha_vec[bz] : 1.0) * acc[ti][tj][r];
                 if (g.beta != 0.0) v = fma(g.beta, *c, v);
                 *c = v;
             }
@@ -278,6 +279,52 @@ void launch_trtri(hipStream_t st, const double* L, int npad, int batch, const do
         c.M = 64; c.N = I * 64; c.K = 64; c.alpha = -1.0; c.beta = 0.0; c.tile_mode = 0; c.k_mode = 0;
         launch_gemm(st, c, false, false, batch);
     }
+}
+
+// ------------------------------------------------------------------ FITC helpers
+__global__ __launch_bounds__(256) void k_fitc_scale(double* __restrict__ V, int mpad, int npad, const double* __restrict__ var,
+                                                    const double* __restrict__ noise, double* __restrict__ G) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= npad) return;
+    double* Vb = V + (long)b * mpad * npad;
+    double ss = 0.0;
+    for (int m = 0; m < mpad; ++m) {
+        const double v = Vb[(long)m * npad + n];
+        ss = fma(v, v, ss);
+    }
+    const double g = sqrt(1.0 + (var[b] - ss) / noise[b]);   // smgpr.py:31-32
+    G[(long)b * npad + n] = g;
+    const double ig = 1.0 / g;
+    for (int m = 0; m < mpad; ++m) Vb[(long)m * npad + n] *= ig;  // smgpr.py:33
+}
+void launch_fitc_scale(hipStream_t st, double* V, int mpad, int npad, int batch, const double* var, const double* noise, double* G) {
+    hipLaunchKernelGGL(k_fitc_scale, dim3((npad + 255) / 256, batch), dim3(256), 0, st, V, mpad, npad, var, noise, G);
+}
+
+__global__ void k_add_diag(double* __restrict__ A, int npad, const double* __restrict__ d) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < npad) A[((long)b * npad + i) * npad + i] += d[b];
+}
+void launch_add_diag(hipStream_t st, double* A, int npad, int batch, const double* d) {
+    hipLaunchKernelGGL(k_add_diag, dim3((npad + 255) / 256, batch), dim3(256), 0, st, A, npad, d);
+}
+
+__global__ __launch_bounds__(256) void k_fitc_rhs(const double* __restrict__ V, const double* __restrict__ G,
+                                                  const double* __restrict__ y, int mpad, int npad, double* __restrict__ r) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= mpad) return;
+    const double* Vr = V + ((long)b * mpad + m) * npad;
+    double s = 0.0;
+    for (int n = lane; n < npad; n += 64) s = fma(Vr[n] / G[(long)b * npad + n], y[(long)b * npad + n], s);   // smgpr.py:40
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) r[(long)b * mpad + m] = s;
+}
+void launch_fitc_rhs(hipStream_t st, const double* V, const double* G, const double* y, int mpad, int npad, int batch, double* r) {
+    hipLaunchKernelGGL(k_fitc_rhs, dim3((mpad + 3) / 4, batch), dim3(256), 0, st, V, G, y, mpad, npad, r);
 }
 
 // ------------------------------------------------------------------ mat-vec, padding

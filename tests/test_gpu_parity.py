@@ -319,3 +319,50 @@ def test_rccl_path_world_size_one():
         np.testing.assert_allclose(R, Ro, rtol=RTOL)
     finally:
         cx.close()
+
+
+def test_sparse_predictions_golden(ctx, golden_dir):
+    """tests/test_sparse_predictions.py: SMGPR (FITC, M=30) vs gp1.m."""
+    from pilco_amd.models import SMGPR
+    g = np.load(os.path.join(golden_dir, "sparse_predictions.npz"))
+    cfg = dict(X=g["X"], Y=g["Y"], lengthscales=g["lengthscales"], variance=g["variance"], noise=g["noise"])
+    m = _mgpr(cfg, cls=SMGPR, num_induced_points=30)
+    for mdl in m.models:
+        mdl.inducing_variable.Z.assign(g["Z"])
+    M, S, V = m.predict_on_noisy_inputs(g["m"], g["s"])
+    assert M.shape == g["M"].shape and S.shape == g["S"].shape and V.shape == g["V"].shape
+    np.testing.assert_allclose(M, g["M"], rtol=RTOL)
+    np.testing.assert_allclose(S, g["S"], rtol=RTOL)
+    np.testing.assert_allclose(V, g["V"], rtol=RTOL)
+    iK, beta = m.calculate_factorizations()
+    iKo, betao = tp.fitc_factorizations(g["X"], g["Y"], g["Z"], g["lengthscales"], g["variance"], g["noise"])
+    assert iK.shape == iKo.shape == (2, 30, 30) and beta.shape == (2, 30)
+    for a in range(2):
+        assert np.linalg.norm(iK[a] - iKo[a]) / np.linalg.norm(iKo[a]) < 1e-7
+        assert np.linalg.norm(beta[a] - betao[a]) / np.linalg.norm(betao[a]) < 1e-7
+    np.testing.assert_allclose(m.centralized_input(g["m"]), g["Z"] - g["m"])
+
+
+def test_sparse_config4_scale(ctx):
+    """BASELINE config 4 shape (M=200, N=5000, D=10, E=10): FITC factorisation + one step + 2-step rollout."""
+    from pilco_amd.models import PILCO
+    c = synthetic.config_c4()
+    p = PILCO((c["X"], c["Y"]), num_induced_points=200, horizon=2)
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(c["lengthscales"][i])
+        mdl.kernel.variance.assign(c["variance"][i])
+        mdl.likelihood.variance.assign(c["noise"][i])
+        mdl.inducing_variable.Z.assign(c["Z"])
+    M, S, V = p.mgpr.predict_on_noisy_inputs(c["m0"], c["S0"])
+    iK, beta = tp.fitc_factorizations(c["X"], c["Y"], c["Z"], c["lengthscales"], c["variance"], c["noise"])
+    Mo, So, Vo = tp.predict_given_factorizations_pairs(c["Z"], c["lengthscales"], c["variance"], c["m0"], c["S0"], iK, beta)
+    np.testing.assert_allclose(M, Mo, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(S, So, rtol=RTOL, atol=1e-10)
+    np.testing.assert_allclose(V, Vo, rtol=RTOL, atol=1e-12)
+    model = tp.Model(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"], Z=c["Z"], pairs=True)
+    model._cache = (iK, beta)
+    Mo, So, Ro = tp.predict(model, tp.no_controller, tp.exponential_reward, c["m0"], c["S0"], 2, cache=True)
+    Mg, Sg, Rg = p.predict(c["m0"], c["S0"], 2)
+    np.testing.assert_allclose(Mg, Mo, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(Sg, So, rtol=RTOL, atol=1e-10)
+    np.testing.assert_allclose(Rg, Ro, rtol=RTOL)
