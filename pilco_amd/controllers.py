@@ -54,3 +54,92 @@ class LinearController:
     @property
     def trainable_parameters(self):
         return [p for p in (self.W, self.b) if p.trainable]
+
+
+class RbfController:
+    """RBF network controller = deterministic GP (controllers.py:80-129; Deisenroth et al. 2015, sec. 5.3.2).
+
+    In the reference this is an MGPR subclass whose ``compute_action`` calls
+    ``predict_given_factorizations(m, s, 0.0 * iK, beta)`` and subtracts ``diag(variance - 1e-6)``.
+    Here the policy GP lives in device slot 1 (PILCO_SLOT_POLICY) and is evaluated by the same
+    moment-matching kernels with the iK stream switched off."""
+
+    def __init__(self, state_dim, control_dim, num_basis_functions, max_action=1.0, ctx=None):
+        from .models.mgpr import MGPR
+
+        class _PolicyGP(MGPR):
+            _slot = _lib.SLOT_POLICY
+
+        self.state_dim = state_dim
+        self.control_dim = control_dim
+        self.num_basis_functions = num_basis_functions
+        self.max_action = max_action
+        self._gp = _PolicyGP((np.random.randn(num_basis_functions, state_dim),
+                              0.1 * np.random.randn(num_basis_functions, control_dim)), ctx=ctx)
+        for model in self._gp.models:
+            model.kernel.variance.assign(1.0)               # controllers.py:92-93
+            model.kernel.variance.trainable = False
+            model.likelihood.variance.assign(1e-4)          # FakeGPR, controllers.py:67,76-77
+            model.likelihood.variance.trainable = False
+            model.kernel.lengthscales.lower = 1e-3          # positive(lower=1e-3), controllers.py:100
+
+    # -- the MGPR surface the reference's callers use on an RbfController
+    @property
+    def models(self):
+        return self._gp.models
+
+    @property
+    def ctx(self):
+        return self._gp.ctx
+
+    def set_data(self, data):
+        self._gp.set_data(data)
+        self.num_basis_functions = self._gp.num_datapoints
+
+    @property
+    def X(self):
+        return self._gp.X
+
+    @property
+    def Y(self):
+        return self._gp.Y
+
+    @property
+    def lengthscales(self):
+        return self._gp.lengthscales
+
+    @property
+    def variance(self):
+        return self._gp.variance
+
+    @property
+    def noise(self):
+        return self._gp.noise
+
+    def calculate_factorizations(self):
+        return self._gp.calculate_factorizations()
+
+    def sync(self):
+        """Push centres / targets / lengthscales to the device and refresh beta."""
+        self._gp._user_factors = None
+        self._gp._ensure_factorized()
+
+    def policy_spec(self, squash=True):
+        self.sync()
+        return dict(kind=_lib.POLICY_RBF, state_dim=self.state_dim, control_dim=self.control_dim,
+                    max_action=self.max_action, squash=squash)
+
+    def compute_action(self, m, s, squash=True):
+        return self.ctx.policy_action(self.policy_spec(squash), m, s)
+
+    def randomize(self):
+        """controllers.py:123-129."""
+        X = np.random.normal(size=self._gp.X.shape)
+        Y = self.max_action / 10 * np.random.normal(size=self._gp.Y.shape)
+        self._gp.set_data((X, Y))
+        for m in self.models:
+            m.kernel.lengthscales.assign(1 + 0.1 * np.random.normal(size=m.kernel.lengthscales.shape))
+
+    @property
+    def trainable_parameters(self):
+        return [m.kernel.lengthscales for m in self.models]

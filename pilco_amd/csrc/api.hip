@@ -17,6 +17,7 @@ struct Slot {
     int Npad = 0;                    // padded N
     int n = 0, npad = 0;             // points the moment matching runs over (N or M) and padding
     bool has_data = false, has_hyp = false, factor_valid = false, user_factors = false, iK_null = false;
+    bool ignore_iK = false;  // policy slot: RbfController evaluates with iK zeroed (controllers.py:116)
     std::vector<double> hZ;
     DevBuf Xt, Yt, Zt, ls, var, noise;         // Yt: [E][Npad]
     DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
@@ -123,10 +124,11 @@ int build_work(pilco_ctx* ctx, Slot& s) {
         mm_pair_sk_steps(npad, &tdiag, &toff);
         // local pairs kk = pl*W + rank are diagonal (kk < E) first; they stream iK unless it is absent
         int nd = 0;
-        if (!s.iK_null)
+        const bool no_iK = s.iK_null || s.ignore_iK;
+        if (!no_iK)
             for (int pl = 0; pl < wk.PL; ++pl)
                 if (pl * W + rank < E) ++nd;
-        if (s.iK_null) tdiag = toff;
+        if (no_iK) tdiag = toff;
         const long T = (long)nd * tdiag + (long)(wk.PL - nd) * toff;
         int waves = mm_pair_sk_capacity(wk.KP);
         if ((long)waves > T) waves = (int)std::max<long>(4, (T + 3) / 4 * 4);
@@ -301,7 +303,7 @@ MMModel model_of(const Slot& s) {
     md.ls = s.ls.p;
     md.var = s.var.p;
     md.beta = s.beta.p;
-    md.iK = s.iK_null ? nullptr : s.iK.p;
+    md.iK = (s.iK_null || s.ignore_iK) ? nullptr : s.iK.p;
     md.n = s.n;
     md.npad = s.npad;
     md.D = s.D;
@@ -376,6 +378,7 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return PILCO_E_HIP;
     pilco_ctx* ctx = new pilco_ctx();
     ctx->device = device;
+    ctx->slot[PILCO_SLOT_POLICY].ignore_iK = true;
     if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&ctx->d_info, 64 * sizeof(int)) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
@@ -690,7 +693,13 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
         return fail(ctx, PILCO_E_SHAPE, "rollout: policy dims do not match the model (state_dim must be E, control_dim D-E)");
     if (pol->kind == PILCO_POLICY_NONE && U != 0) return fail(ctx, PILCO_E_SHAPE, "rollout: policy NONE needs D == E");
     if (pol->kind == PILCO_POLICY_LINEAR && (U == 0 || !pol->W || !pol->b)) return fail(ctx, PILCO_E_SHAPE, "rollout: linear policy needs W, b and control_dim > 0");
-    if (pol->kind == PILCO_POLICY_RBF) return fail(ctx, PILCO_E_STATE, "rollout: RBF policy not available in this build");
+    if (pol->kind == PILCO_POLICY_RBF) {
+        Slot& ps = ctx->slot[PILCO_SLOT_POLICY];
+        if (!ps.factor_valid) return fail(ctx, PILCO_E_STATE, "rollout: RBF policy slot has no current factorisation");
+        if (ps.D != E || ps.E != U || U == 0) return fail(ctx, PILCO_E_SHAPE, "rollout: RBF policy GP must map state_dim -> control_dim");
+        if (ctx->nranks != 1) return fail(ctx, PILCO_E_STATE, "rollout: the RBF policy is evaluated unsharded; use one rank");
+        if (int r = build_work(ctx, ps)) return r;
+    }
     if (pol->kind < 0 || pol->kind > 2) return fail(ctx, PILCO_E_SHAPE, "rollout: unknown policy kind");
     if (n_rw < 0 || n_rw > MAX_REWARD_TERMS || (n_rw > 0 && !rw)) return fail(ctx, PILCO_E_SHAPE, "rollout: 0..4 reward terms supported");
     if (int r = build_work(ctx, s)) return r;
@@ -715,6 +724,12 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
     g.traj = want_traj ? ctx->traj.p : nullptr;
     g.pol_kind = pol->kind;
     g.squash = pol->squash;
+    if (pol->kind == PILCO_POLICY_RBF) {
+        g.pwk = ctx->slot[PILCO_SLOT_POLICY].wk;
+        g.pvar = ctx->slot[PILCO_SLOT_POLICY].var.p;
+        for (int u = 0; u < U; ++u) hp[off + u] = pol->max_action ? pol->max_action[u] : 1.0;
+        g.maxact = ctx->params.p + off; off += U;
+    }
     if (pol->kind == PILCO_POLICY_LINEAR) {
         memcpy(&hp[off], pol->W, sizeof(double) * U * E);
         g.W = ctx->params.p + off; off += (size_t)U * E;
@@ -748,8 +763,23 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
     g.s_x = plan.st[0] + E;
     g.m_out = nullptr;
     g.s_out = nullptr;
-    g.flags = GF_TRAJ | (H > 0 ? GF_POLICY : 0);
+    const bool rbf = (g.pol_kind == PILCO_POLICY_RBF);
+    Slot& ps = ctx->slot[PILCO_SLOT_POLICY];
+    const MMModel pmd = rbf ? model_of(ps) : MMModel{};
+    // RBF policy (controllers.py:108-121): the glue that produced the state hands it to the policy GP
+    // (GF_RBF_PRE), the policy's moment matching runs as its own prep/pair, a second glue squashes and
+    // builds the joint Gaussian (GF_RBF_POST | GF_POLICY).
+    auto policy_stage = [&](GlueArgs& ga) {
+        launch_mm_prep(ctx->st, pmd, ps.wk);
+        launch_mm_pair(ctx->st, pmd, ps.wk, ctx->variant);
+        const int keep = ga.flags;
+        ga.flags = GF_RBF_POST | GF_POLICY;
+        launch_glue(ctx->st, ga);
+        ga.flags = keep;
+    };
+    g.flags = GF_TRAJ | (H > 0 ? (rbf ? GF_RBF_PRE : GF_POLICY) : 0);
     launch_glue(ctx->st, g);
+    if (rbf && H > 0) policy_stage(g);
     size_t evi = 0;
     for (int t = 0; t < H; ++t) {
         if (s.wk.PL > 0) {
@@ -764,7 +794,8 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
         g.s_x = plan.st[t & 1] + E;
         g.m_out = plan.st[(t + 1) & 1];
         g.s_out = plan.st[(t + 1) & 1] + E;
-        const int tail = GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ | (t + 1 < H ? GF_POLICY : 0);
+        const bool more = t + 1 < H;
+        const int tail = GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ | (more ? (rbf ? GF_RBF_PRE : GF_POLICY) : 0);
         if (ctx->nranks == 1 && !ctx->comm) {
             g.flags = GF_PACK | tail;
         } else {
@@ -774,6 +805,11 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
             g.flags = tail;
         }
         launch_glue(ctx->st, g, rew);
+        if (rbf && more) {  // the policy stage reads the NEW state
+            g.m_x = g.m_out;
+            g.s_x = g.s_out;
+            policy_stage(g);
+        }
     }
     return PILCO_OK;
 }
@@ -793,7 +829,12 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
         (unsigned long long)(uintptr_t)s.w_in.p, (unsigned long long)(uintptr_t)s.d_lists, (unsigned long long)(uintptr_t)s.beta.p,
         (unsigned long long)(uintptr_t)s.iK.p, (unsigned long long)s.iK_null, (unsigned long long)(uintptr_t)s.Xt.p,
         (unsigned long long)(uintptr_t)s.Zt.p, (unsigned long long)(uintptr_t)s.ls.p, (unsigned long long)s.n,
-        (unsigned long long)s.wk.sk_waves, (unsigned long long)s.wk.NT, (unsigned long long)s.wk.NCH, (unsigned long long)s.wk.abl};
+        (unsigned long long)s.wk.sk_waves, (unsigned long long)s.wk.NT, (unsigned long long)s.wk.NCH, (unsigned long long)s.wk.abl,
+        (unsigned long long)(uintptr_t)ctx->slot[1].w_part.p, (unsigned long long)(uintptr_t)ctx->slot[1].w_At.p,
+        (unsigned long long)(uintptr_t)ctx->slot[1].beta.p, (unsigned long long)(uintptr_t)ctx->slot[1].Xt.p,
+        (unsigned long long)(uintptr_t)ctx->slot[1].d_lists, (unsigned long long)ctx->slot[1].n,
+        (unsigned long long)ctx->slot[1].wk.sk_waves, (unsigned long long)(uintptr_t)ctx->slot[1].w_small.p,
+        (unsigned long long)(uintptr_t)ctx->slot[1].w_in.p, (unsigned long long)(uintptr_t)ctx->slot[1].ls.p};
     for (int i = 0; i < g.n_rewards; ++i) {
         key.push_back((unsigned long long)g.rw[i].kind);
         key.push_back((unsigned long long)(long long)g.rw[i].rank);
@@ -871,10 +912,50 @@ int pilco_propagate(pilco_ctx* ctx, const pilco_policy* policy, const double* m_
 int pilco_policy_action(pilco_ctx* ctx, const pilco_policy* policy, const double* m, const double* s_in, double* M, double* S, double* V) {
     if (!ctx) return PILCO_E_SHAPE;
     if (!policy || !m || !s_in || !M || !S || !V) return fail(ctx, PILCO_E_SHAPE, "policy_action: null pointer");
-    if (policy->kind != PILCO_POLICY_LINEAR) return fail(ctx, PILCO_E_STATE, "policy_action: only the linear policy is evaluated through this entry point in this build");
+    if (policy->kind != PILCO_POLICY_LINEAR && policy->kind != PILCO_POLICY_RBF) return fail(ctx, PILCO_E_SHAPE, "policy_action: policy kind must be LINEAR or RBF");
     HIPCHK(hipSetDevice(ctx->device));
     const int E = policy->state_dim, U = policy->control_dim;
-    if (E <= 0 || U <= 0 || E > MAX_D || U > MAX_D || !policy->W || !policy->b) return fail(ctx, PILCO_E_SHAPE, "policy_action: bad dims");
+    if (E <= 0 || U <= 0 || E > MAX_D || U > MAX_D) return fail(ctx, PILCO_E_SHAPE, "policy_action: bad dims");
+    if (policy->kind == PILCO_POLICY_RBF) {
+        Slot& ps = ctx->slot[PILCO_SLOT_POLICY];
+        if (!ps.factor_valid) return fail(ctx, PILCO_E_STATE, "policy_action: RBF policy slot has no current factorisation");
+        if (ps.D != E || ps.E != U) return fail(ctx, PILCO_E_SHAPE, "policy_action: RBF policy GP must map state_dim -> control_dim");
+        if (int r = build_work(ctx, ps)) return r;
+        const size_t n_st = (size_t)E + E * E + U + (U + U * U + (size_t)E * U);
+        ENSURE(ctx->state, n_st + 8);
+        std::vector<double> h(n_st, 0.0);
+        memcpy(&h[0], m, sizeof(double) * E);
+        memcpy(&h[E], s_in, sizeof(double) * E * E);
+        size_t off = (size_t)E + E * E;
+        GlueArgs g{};
+        g.E = E; g.D = E + U; g.U = U;
+        g.m_x = ctx->state.p;
+        g.s_x = ctx->state.p + E;
+        for (int u = 0; u < U; ++u) h[off + u] = policy->max_action ? policy->max_action[u] : 1.0;
+        g.maxact = ctx->state.p + off; off += U;
+        g.act_out = ctx->state.p + off;
+        g.pol_kind = PILCO_POLICY_RBF;
+        g.squash = policy->squash;
+        g.pwk = ps.wk;
+        g.pvar = ps.var.p;
+        HIPCHK(hipMemcpyAsync(ctx->state.p, h.data(), sizeof(double) * n_st, hipMemcpyHostToDevice, ctx->st));
+        HIPCHK(hipMemcpyAsync(ps.wk.in_m, m, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
+        HIPCHK(hipMemcpyAsync(ps.wk.in_s, s_in, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
+        const MMModel pmd = model_of(ps);
+        launch_mm_prep(ctx->st, pmd, ps.wk);
+        launch_mm_pair(ctx->st, pmd, ps.wk, ctx->variant);
+        g.flags = GF_RBF_POST | GF_POLICY;
+        launch_glue(ctx->st, g);
+        std::vector<double> o((size_t)U + U * U + (size_t)E * U);
+        HIPCHK(hipMemcpyAsync(o.data(), g.act_out, sizeof(double) * o.size(), hipMemcpyDeviceToHost, ctx->st));
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        HIPCHK(hipGetLastError());
+        memcpy(M, &o[0], sizeof(double) * U);
+        memcpy(S, &o[U], sizeof(double) * U * U);
+        memcpy(V, &o[(size_t)U + U * U], sizeof(double) * E * U);
+        return PILCO_OK;
+    }
+    if (!policy->W || !policy->b) return fail(ctx, PILCO_E_SHAPE, "policy_action: linear policy needs W and b");
     const size_t n_state = (size_t)E + E * E + (size_t)U * E + 2 * U + (U + U * U + (size_t)E * U);
     ENSURE(ctx->state, n_state + 8);
     std::vector<double> h(n_state, 0.0);

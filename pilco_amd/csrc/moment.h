@@ -72,6 +72,8 @@ struct GlueArgs {
     int U;
     MMWork wk;          // dynamics slot workspace
     const double* var;  // dynamics kernel variances [E]
+    MMWork pwk;         // policy slot workspace (RBF policy only)
+    const double* pvar; // policy kernel variances [U]
     // rollout state
     const double* m_x;  // [E]     current state (read)
     const double* s_x;  // [E][E]

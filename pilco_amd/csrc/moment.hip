@@ -1111,8 +1111,9 @@ __device__ void mm_pack(const MMWork& wk, int D, int E, const GlueLds& L, int pr
         double s0 = 0.0, s1 = 0.0;
         if (k < wk.PL) {
             if (wk.sk_waves > 0) {  // stream-K partials: waves wlo..whi, the slot whose pair index matches
-                const int wlo = (base == 0) ? pre_wlo : wk.sk_wlo[k];
-                const int n = ((base == 0) ? pre_whi : wk.sk_whi[k]) - wlo + 1;
+                const bool pre = (base == 0 && pre_whi >= pre_wlo);
+                const int wlo = pre ? pre_wlo : wk.sk_wlo[k];
+                const int n = (pre ? pre_whi : wk.sk_whi[k]) - wlo + 1;
                 const int q0 = wlo + (int)((long)n * gq / 4), q1 = wlo + (int)((long)n * (gq + 1) / 4);
                 for (int q = q0; q < q1; ++q) {
                     const int p0 = wk.sk_pidx[2 * q], p1 = wk.sk_pidx[2 * q + 1];
@@ -1185,8 +1186,12 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int E = g.E, D = g.D, U = g.U, t = threadIdx.x;
     const int nm = E > D ? E : D;
-    const int mp_n = (g.flags & GF_PACK) ? g.wk.EL * g.wk.NCH * (1 + D) : 0;
-    const int seg_n = (g.flags & (GF_PACK | GF_ASSEMBLE)) ? g.wk.SEG * ((g.flags & GF_PACK) ? 1 : g.wk.nranks) : 0;
+    int mp_n = (g.flags & GF_PACK) ? g.wk.EL * g.wk.NCH * (1 + D) : 0;
+    int seg_n = (g.flags & (GF_PACK | GF_ASSEMBLE)) ? g.wk.SEG * ((g.flags & GF_PACK) ? 1 : g.wk.nranks) : 0;
+    if (g.flags & GF_RBF_POST) {  // this launch reduces the POLICY GP (inputs = state, outputs = controls)
+        mp_n = g.pwk.EL * g.pwk.NCH * (1 + E);
+        seg_n = g.pwk.SEG;
+    }
     GlueLds L;
     L.mx = sm;
     L.sx = L.mx + nm;
@@ -1231,12 +1236,13 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
         pre_whi = g.wk.sk_whi[t >> 2];
     }
     // one batch of loads for everything the serial part reads
-    if (g.flags & (GF_PROPAGATE | GF_TRAJ | GF_POLICY)) {
+    if (g.flags & (GF_PROPAGATE | GF_TRAJ | GF_POLICY | GF_RBF_PRE)) {
         if (t < E) L.mx[t] = g.m_x[t];
         bulk_load(L.sx, g.s_x, E * E);
     }
     if (g.flags & GF_PROPAGATE) bulk_load(L.s1, g.s1, E * D);
     if (g.flags & GF_PACK) bulk_load(L.mp, g.wk.mean_part, mp_n);
+    if (g.flags & GF_RBF_POST) bulk_load(L.mp, g.pwk.mean_part, mp_n);
     if ((g.flags & GF_ASSEMBLE) && !(g.flags & GF_PACK)) bulk_load(L.seg, g.wk.gath, seg_n);
     __syncthreads();
 
@@ -1279,7 +1285,24 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
         if (t < E) dst[t] = L.mx[t];
         for (int e = t; e < E * E; e += blockDim.x) dst[E + e] = L.sx[e];
     }
+    if (g.flags & GF_RBF_PRE) {  // RbfController: the state is the input of the policy GP (controllers.py:115-116)
+        if (t < E) g.pwk.in_m[t] = L.mx[t];
+        for (int e = t; e < E * E; e += blockDim.x) g.pwk.in_s[e] = L.sx[e];
+    }
     if (g.flags & GF_POLICY) {
+        if (g.pol_kind == PILCO_POLICY_RBF) {
+            // mean-function-only GP: iK = 0, then S -= diag(var - 1e-6)      (controllers.py:116-117)
+            mm_pack(g.pwk, E, U, L, 0, -1);
+            mm_assemble(g.pwk, L.seg, g.pvar, E, U, L.mu, L.su, L.cxu);   // M (U), S (U,U), V (E,U)
+            if (t < U) L.su[t * U + t] -= g.pvar[t] - 1e-6;
+            __syncthreads();
+            if (g.squash) {
+                double* cdiag = L.misc + 1;
+                squash_inplace(L, U, g.maxact, cdiag);
+                for (int e = t; e < E * U; e += blockDim.x) L.cxu[e] *= cdiag[e % U];
+                __syncthreads();
+            }
+        }
         if (g.pol_kind == PILCO_POLICY_LINEAR) {
             // M = m W^T + b, S = W s W^T, V = W^T                  (controllers.py:52-54)
             bulk_load(L.t2, g.W, U * E);
@@ -1330,8 +1353,12 @@ void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot) {
 }
 
 void launch_glue(hipStream_t st, const GlueArgs& g, bool with_reward_block) {
-    const int mp_n = (g.flags & GF_PACK) ? g.wk.EL * g.wk.NCH * (1 + g.D) : 0;
-    const int seg_n = (g.flags & (GF_PACK | GF_ASSEMBLE)) ? g.wk.SEG * ((g.flags & GF_PACK) ? 1 : g.wk.nranks) : 0;
+    int mp_n = (g.flags & GF_PACK) ? g.wk.EL * g.wk.NCH * (1 + g.D) : 0;
+    int seg_n = (g.flags & (GF_PACK | GF_ASSEMBLE)) ? g.wk.SEG * ((g.flags & GF_PACK) ? 1 : g.wk.nranks) : 0;
+    if (g.flags & GF_RBF_POST) {
+        mp_n = g.pwk.EL * g.pwk.NCH * (1 + g.E);
+        seg_n = g.pwk.SEG;
+    }
     const size_t lds = sizeof(double) * glue_lds_doubles(g.E, g.D, seg_n, mp_n);
     static size_t configured = 0;
     if (lds > configured) {

@@ -366,3 +366,53 @@ def test_sparse_config4_scale(ctx):
     np.testing.assert_allclose(Mg, Mo, rtol=RTOL, atol=1e-12)
     np.testing.assert_allclose(Sg, So, rtol=RTOL, atol=1e-10)
     np.testing.assert_allclose(Rg, Ro, rtol=RTOL)
+
+
+def test_rbf_controller_golden(ctx, golden_dir):
+    """tests/test_controllers.py:test_rbf: RbfController.compute_action(squash=False) vs gp2.m, then squashed
+    and inside a rollout against the oracle."""
+    from pilco_amd.controllers import RbfController
+    from pilco_amd.models import PILCO
+    g = np.load(os.path.join(golden_dir, "rbf_controller.npz"))
+    rbf = RbfController(3, 2, 100)
+    rbf.set_data((g["X"], g["Y"]))
+    for i, mdl in enumerate(rbf.models):
+        mdl.kernel.lengthscales.assign(g["lengthscales"][i])
+    M, S, V = rbf.compute_action(g["m"], g["s"], squash=False)
+    assert M.shape == g["M"].shape and S.shape == g["S"].shape and V.shape == g["V"].shape
+    np.testing.assert_allclose(M, g["M"], rtol=RTOL)
+    np.testing.assert_allclose(S, g["S"], rtol=RTOL)
+    np.testing.assert_allclose(V, g["V"], rtol=RTOL)
+    Ms, Ss, Vs = rbf.compute_action(g["m"], g["s"], squash=True)
+    Mo, So, Vo = tp.rbf_controller(g["m"], g["s"], g["X"], g["Y"], g["lengthscales"], max_action=1.0, squash=True)
+    np.testing.assert_allclose(Ms, Mo, rtol=RTOL)
+    np.testing.assert_allclose(Ss, So, rtol=RTOL)
+    np.testing.assert_allclose(Vs, Vo, rtol=RTOL)
+    # rollout with an RBF policy: dynamics on (state 3 + control 2) -> 3
+    rs = np.random.RandomState(4)
+    X = rs.randn(80, 5)
+    Y = 0.3 * np.sin(X) @ rs.randn(5, 3) + 1e-2 * rs.randn(80, 3)
+    ls = 1.0 + rs.rand(3, 5)
+    var = 0.5 + rs.rand(3)
+    nz = 1e-2 * np.ones(3)
+    ctl = RbfController(3, 2, 20, max_action=2.0)
+    cX, cY = rs.randn(20, 3), 0.3 * rs.randn(20, 2)
+    ctl.set_data((cX, cY))
+    cl = 1.0 + 0.3 * rs.rand(2, 3)
+    for i, mdl in enumerate(ctl.models):
+        mdl.kernel.lengthscales.assign(cl[i])
+    p = PILCO((X, Y), horizon=4, controller=ctl)
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(ls[i])
+        mdl.kernel.variance.assign(var[i])
+        mdl.likelihood.variance.assign(nz[i])
+    m0 = 0.1 * rs.randn(1, 3)
+    S0 = 0.05 * np.eye(3)
+    Mg, Sg, Rg = p.predict(m0, S0, 4)
+    model = tp.Model(X, Y, ls, var, nz)
+    octl = lambda mm, ss: tp.rbf_controller(mm, ss, cX, cY, cl, max_action=2.0, squash=True)
+    Mo, So, Ro = tp.predict(model, octl, tp.exponential_reward, m0, S0, 4, cache=True)
+    np.testing.assert_allclose(Mg, Mo, rtol=RTOL)
+    np.testing.assert_allclose(Sg, So, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(Rg, Ro, rtol=RTOL)
+    np.testing.assert_allclose(p.compute_action(m0), tp.rbf_controller(m0, np.zeros((3, 3)), cX, cY, cl, max_action=2.0)[0], rtol=RTOL)
