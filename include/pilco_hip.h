@@ -72,6 +72,11 @@ int pilco_gp_gram(pilco_ctx* ctx, int slot, const double* X1, int N1, const doub
  * inputs are set, SMGPR.calculate_factorizations (pilco/models/smgpr.py:24-45).
  * Result stays on the device and is cached until data / hyper-parameters change. */
 int pilco_gp_factorize(pilco_ctx* ctx, int slot);
+/* Negative log marginal likelihood of every output at the current hyper-parameters and its gradient
+ * w.r.t. (lengthscales[D], kernel variance, noise variance): what gpflow's GPR.training_loss and its
+ * autodiff provide to MGPR.optimize (pilco/models/mgpr.py:47-75), without the prior terms (added on
+ * the host).  nlml (E), grad (E, D+2) may be NULL.  Exact GP only. */
+int pilco_gp_nlml(pilco_ctx* ctx, int slot, double* nlml, double* grad);
 /* number of points the moment-matching runs over: N (exact) or M (sparse) */
 int pilco_gp_num_points(const pilco_ctx* ctx, int slot);
 /* download iK (E,n,n) and beta (E,n); either may be NULL */

@@ -59,6 +59,7 @@ SIGNATURES = {
     "pilco_gp_set_inducing": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
     "pilco_gp_gram": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp]),
     "pilco_gp_factorize": (C.c_int, [_vp, C.c_int]),
+    "pilco_gp_nlml": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "pilco_gp_num_points": (C.c_int, [_vp, C.c_int]),
     "pilco_gp_get_factors": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "pilco_gp_set_factors": (C.c_int, [_vp, C.c_int, _dp, _dp]),
@@ -190,6 +191,12 @@ class Context:
 
     def gp_factorize(self, slot):
         self._chk(self.lib.pilco_gp_factorize(self.h, slot))
+
+    def gp_nlml(self, slot, D, E, want_grad=True):
+        nlml = np.empty(E)
+        grad = np.empty((E, D + 2)) if want_grad else None
+        self._chk(self.lib.pilco_gp_nlml(self.h, slot, _ptr(nlml), _ptr(grad)))
+        return nlml, grad
 
     def gp_num_points(self, slot):
         return self.lib.pilco_gp_num_points(self.h, slot)

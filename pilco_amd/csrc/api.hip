@@ -582,6 +582,41 @@ int pilco_gp_factorize(pilco_ctx* ctx, int slot) {
     return PILCO_OK;
 }
 
+int pilco_gp_nlml(pilco_ctx* ctx, int slot, double* nlml, double* grad) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.has_data || !s.has_hyp) return fail(ctx, PILCO_E_STATE, "nlml needs set_data and set_hyp first");
+    if (s.M > 0) return fail(ctx, PILCO_E_STATE, "nlml: the FITC training objective is not built; exact GP only");
+    if (!nlml) return fail(ctx, PILCO_E_SHAPE, "nlml: null pointer");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!s.factor_valid || s.user_factors) {
+        s.factor_valid = false;
+        if (int r = pilco_gp_factorize(ctx, slot)) return r;
+    }
+    const int E = s.E, D = s.D, npad = s.Npad, N = s.N;
+    // after factorize_exact: s.K holds L, s.iK the inverse, s.beta = alpha, s.Yt the targets
+    const size_t npart = (size_t)E * (npad / NB) * 34;
+    ENSURE(s.vec, std::max((size_t)E * npad * 2, npart + (size_t)E * (D + 2) + 2 * (size_t)E));
+    double* d_part = s.vec.p;
+    double* d_grad = d_part + npart;
+    double* d_logdet = d_grad + (size_t)E * (D + 2);
+    launch_logdet(ctx->st, s.K.p, npad, N, E, d_logdet);
+    if (grad) launch_nlml_grad(ctx->st, s.Xt.p, npad, N, D, s.ls.p, s.var.p, s.iK.p, s.beta.p, E, d_part, d_grad);
+    std::vector<double> hl(E), hb((size_t)E * npad), hy((size_t)E * npad);
+    HIPCHK(hipMemcpyAsync(hl.data(), d_logdet, sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(hb.data(), s.beta.p, sizeof(double) * E * npad, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(hy.data(), s.Yt.p, sizeof(double) * E * npad, hipMemcpyDeviceToHost, ctx->st));
+    if (grad) HIPCHK(hipMemcpyAsync(grad, d_grad, sizeof(double) * E * (D + 2), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    for (int a = 0; a < E; ++a) {
+        double ya = 0.0;
+        for (int i = 0; i < N; ++i) ya += hy[(size_t)a * npad + i] * hb[(size_t)a * npad + i];
+        nlml[a] = 0.5 * ya + hl[a] + 0.5 * N * std::log(2.0 * M_PI);
+    }
+    return PILCO_OK;
+}
+
 int pilco_gp_num_points(const pilco_ctx* ctx, int slot) {
     if (!ctx || slot < 0 || slot > 1) return -1;
     return ctx->slot[slot].n;

@@ -327,6 +327,88 @@ void launch_fitc_rhs(hipStream_t st, const double* V, const double* G, const dou
     hipLaunchKernelGGL(k_fitc_rhs, dim3((mpad + 3) / 4, batch), dim3(256), 0, st, V, G, y, mpad, npad, r);
 }
 
+// ------------------------------------------------------------------ GP training sums
+__global__ __launch_bounds__(256) void k_logdet(const double* __restrict__ L, int npad, int n, double* __restrict__ out) {
+    __shared__ double red[4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    double s = 0.0;
+    for (int i = t; i < n; i += 256) s += log(L[((long)b * npad + i) * npad + i]);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((t & 63) == 0) red[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) out[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+void launch_logdet(hipStream_t st, const double* L, int npad, int n, int batch, double* out) {
+    hipLaunchKernelGGL(k_logdet, dim3(batch), dim3(256), 0, st, L, npad, n, out);
+}
+
+// one workgroup per (output, 64-row tile): thread t handles column j = t, t+256, ... of its rows;
+// partial[b][tile][D+2]; a second launch reduces the tiles in fixed order.
+constexpr int NLML_MAXD = 32;
+__global__ __launch_bounds__(256) void k_nlml_grad_partial(const double* __restrict__ Pt, int npad, int n, int D,
+                                                           const double* __restrict__ ls, const double* __restrict__ var,
+                                                           const double* __restrict__ iK, const double* __restrict__ beta,
+                                                           double* __restrict__ partial) {
+    __shared__ double xi[NLML_MAXD][64];
+    __shared__ double bi[64];
+    __shared__ double red[4][NLML_MAXD + 2];
+    const int b = blockIdx.y, tile = blockIdx.x, t = threadIdx.x;
+    const int i0 = tile * 64;
+    for (int e = t; e < D * 64; e += 256) xi[e >> 6][e & 63] = Pt[(long)(e >> 6) * npad + i0 + (e & 63)];
+    if (t < 64) bi[t] = beta[(long)b * npad + i0 + t];
+    __syncthreads();
+    const double v = var[b];
+    double il[NLML_MAXD];
+    double acc[NLML_MAXD + 2];
+    for (int d = 0; d < NLML_MAXD; ++d) il[d] = (d < D) ? 1.0 / ls[b * D + d] : 0.0;
+    for (int d = 0; d < NLML_MAXD + 2; ++d) acc[d] = 0.0;
+    const double* iKb = iK + (long)b * npad * npad;
+    for (int j = t; j < n; j += 256) {
+        double xj[NLML_MAXD];
+        for (int d = 0; d < D; ++d) xj[d] = Pt[(long)d * npad + j];
+        const double bj = beta[(long)b * npad + j];
+        for (int ii = 0; ii < 64; ++ii) {
+            const int i = i0 + ii;
+            if (i >= n) break;
+            double r2 = 0.0;
+            double sq[NLML_MAXD];
+            for (int d = 0; d < D; ++d) {
+                const double df = (xi[d][ii] - xj[d]) * il[d];
+                sq[d] = df * df;
+                r2 += sq[d];
+            }
+            const double k = v * exp(-0.5 * r2);
+            const double w = iKb[(long)i * npad + j] - bi[ii] * bj;
+            const double wk = w * k;
+            for (int d = 0; d < D; ++d) acc[d] = fma(wk, sq[d] * il[d], acc[d]);   // (x_i-x_j)^2 / l^3
+            acc[D] += wk;
+            if (i == j) acc[D + 1] += w;
+        }
+    }
+    for (int d = 0; d < D + 2; ++d) {
+        double s = acc[d];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if ((t & 63) == 0) red[t >> 6][d] = s;
+    }
+    __syncthreads();
+    if (t < D + 2) partial[((long)b * gridDim.x + tile) * (NLML_MAXD + 2) + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+__global__ void k_nlml_grad_reduce(const double* __restrict__ partial, int ntiles, int D, const double* __restrict__ var,
+                                   double* __restrict__ grad) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t >= D + 2) return;
+    double s = 0.0;
+    for (int q = 0; q < ntiles; ++q) s += partial[((long)b * ntiles + q) * (NLML_MAXD + 2) + t];
+    if (t == D) s /= var[b];
+    grad[b * (D + 2) + t] = 0.5 * s;
+}
+void launch_nlml_grad(hipStream_t st, const double* Pt, int npad, int n, int D, const double* ls, const double* var,
+                      const double* iK, const double* beta, int batch, double* partial, double* grad) {
+    const int ntiles = npad / 64;
+    hipLaunchKernelGGL(k_nlml_grad_partial, dim3(ntiles, batch), dim3(256), 0, st, Pt, npad, n, D, ls, var, iK, beta, partial);
+    hipLaunchKernelGGL(k_nlml_grad_reduce, dim3(batch), dim3(64), 0, st, partial, ntiles, D, var, grad);
+}
+
 // ------------------------------------------------------------------ mat-vec, padding
 __global__ __launch_bounds__(256) void k_matvec(const double* __restrict__ A, int npad, const double* __restrict__ x,
                                                 double* __restrict__ y, int trans) {

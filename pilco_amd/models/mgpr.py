@@ -81,7 +81,7 @@ class MGPR:
     # -- reference: mgpr.py:47-75
     def optimize(self, restarts=1):
         from ..training import optimize_mgpr
-        optimize_mgpr(self, restarts=restarts)
+        return optimize_mgpr(self, restarts=restarts)
 
     # -- reference: mgpr.py:77-79
     def predict_on_noisy_inputs(self, m, s):

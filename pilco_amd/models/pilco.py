@@ -66,7 +66,7 @@ class PILCO:
     # pilco.py:75-113
     def optimize_policy(self, maxiter=50, restarts=1, verbose=True):
         from ..training import optimize_policy
-        optimize_policy(self, maxiter=maxiter, restarts=restarts, verbose=verbose)
+        return optimize_policy(self, maxiter=maxiter, restarts=restarts, verbose=verbose)
 
     # pilco.py:115-116
     def compute_action(self, x_m):

@@ -1,10 +1,200 @@
-"""Optimiser glue.  Built in a later milestone."""
+"""Optimiser glue around the device kernels.
+
+``optimize_mgpr``   -- MGPR.optimize (pilco/models/mgpr.py:47-75): MAP fit of the per-output GP
+hyper-parameters.  The objective follows GPflow's GPR.training_loss as recalled in SURVEY.md
+Appendix C: negative log marginal likelihood minus the Gamma log-priors on the lengthscales
+(shape 1.1, rate 0.1) and the kernel variance (shape 1.5, rate 0.5), optimised in softplus space
+(noise variance >= 1e-6) with SciPy L-BFGS-B.  NLML and its gradient come from the device
+(pilco_gp_nlml); the E outputs are independent, so they are optimised jointly as one separable
+problem (one batched factorisation per evaluation).  Parity with GPflow's optimiser trajectory is
+unpinned in the reference itself (no test inspects trained values).
+
+``optimize_policy`` -- PILCO.optimize_policy (pilco/models/pilco.py:75-113): L-BFGS-B over the
+controller parameters with the GP frozen, restarts via controller.randomize().  The gradient of the
+rollout reward is taken by central finite differences of device rollouts (deterministic, bitwise
+repeatable); the analytic adjoint is the next step.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+from scipy.optimize import minimize
+from scipy.special import gammaln
+
+NOISE_LOWER = 1e-6
 
 
-def optimize_mgpr(mgpr, restarts=1):
-    raise NotImplementedError("GP hyper-parameter training on the device is not built yet; "
-                              "set hyper-parameters through model.kernel.*.assign()")
+def _softplus(u):
+    return np.logaddexp(0.0, u)
+
+
+def _softplus_inv(x):
+    x = np.maximum(x, 1e-300)
+    return np.where(x > 30.0, x, np.log(np.expm1(np.minimum(x, 30.0))))
+
+
+def _dsoftplus(u):
+    return 1.0 / (1.0 + np.exp(-u))
+
+
+def _gamma_logpdf_and_grad(x, shape, rate):
+    lp = shape * np.log(rate) - gammaln(shape) + (shape - 1.0) * np.log(x) - rate * x
+    return lp, (shape - 1.0) / x - rate
+
+
+def _mgpr_pack(mgpr):
+    ls, var, nz = mgpr.lengthscales, mgpr.variance, mgpr.noise
+    return np.concatenate([_softplus_inv(ls).ravel(), _softplus_inv(var), _softplus_inv(np.maximum(nz - NOISE_LOWER, 1e-12))])
+
+
+def _mgpr_unpack(mgpr, u):
+    E, D = mgpr.num_outputs, mgpr.num_dims
+    ls = _softplus(u[:E * D]).reshape(E, D)
+    var = _softplus(u[E * D:E * D + E])
+    nz = NOISE_LOWER + _softplus(u[E * D + E:])
+    return ls, var, nz
+
+
+def mgpr_objective(mgpr, u, noise_trainable=True):
+    """Sum over outputs of GPflow's training loss and its gradient in the unconstrained space."""
+    E, D = mgpr.num_outputs, mgpr.num_dims
+    ls, var, nz = _mgpr_unpack(mgpr, u)
+    for i, m in enumerate(mgpr.models):
+        m.kernel.lengthscales.assign(ls[i])
+        m.kernel.variance.assign(var[i])
+        m.likelihood.variance.assign(nz[i])
+    mgpr._sync()
+    nlml, g = mgpr.ctx.gp_nlml(mgpr._slot, D, E)
+    lp_l, dlp_l = _gamma_logpdf_and_grad(ls, 1.1, 0.1)          # mgpr.py:33
+    lp_v, dlp_v = _gamma_logpdf_and_grad(var, 1.5, 0.5)         # mgpr.py:34
+    per_output = nlml - lp_l.sum(1) - lp_v
+    g_ls = (g[:, :D] - dlp_l) * _dsoftplus(u[:E * D]).reshape(E, D)
+    g_var = (g[:, D] - dlp_v) * _dsoftplus(u[E * D:E * D + E])
+    g_nz = g[:, D + 1] * _dsoftplus(u[E * D + E:]) * (1.0 if noise_trainable else 0.0)
+    return per_output, np.concatenate([g_ls.ravel(), g_var, g_nz])
+
+
+def optimize_mgpr(mgpr, restarts=1, maxiter=1000, verbose=False):
+    from .models.smgpr import SMGPR
+    from . import _lib
+    if isinstance(mgpr, SMGPR):
+        raise NotImplementedError("FITC hyper-parameter / inducing-point training is not built; "
+                                  "set hyper-parameters and Z explicitly")
+    noise_trainable = all(m.likelihood.variance.trainable for m in mgpr.models)
+
+    def run(u0):
+        best = {"per": None}
+
+        def fun(u):
+            try:
+                per, grad = mgpr_objective(mgpr, u, noise_trainable)
+            except _lib.NotPositiveDefiniteError:
+                return 1e25, np.zeros_like(u)
+            best["per"] = per
+            return float(per.sum()), grad
+
+        res = minimize(fun, u0, jac=True, method="L-BFGS-B", options=dict(maxiter=maxiter))
+        per, _ = mgpr_objective(mgpr, res.x, noise_trainable)
+        return res.x, per
+
+    E, D = mgpr.num_outputs, mgpr.num_dims
+    u_best, per_best = run(_mgpr_pack(mgpr))
+    for _ in range(restarts):
+        # randomize(model), mgpr.py:8-15
+        ls0 = 1 + 0.01 * np.random.normal(size=(E, D))
+        var0 = 1 + 0.01 * np.random.normal(size=E)
+        nz0 = 1 + 0.01 * np.random.normal(size=E) if noise_trainable else mgpr.noise
+        u0 = np.concatenate([_softplus_inv(ls0).ravel(), _softplus_inv(var0), _softplus_inv(np.maximum(nz0 - NOISE_LOWER, 1e-12))])
+        u, per = run(u0)
+        better = per < per_best
+        if verbose:
+            print("restart: per-output losses", per, "improved", better)
+        # keep, per output, the better of the two fits (the outputs are independent problems)
+        ub = u_best.copy()
+        for a in np.nonzero(better)[0]:
+            ub[a * D:(a + 1) * D] = u[a * D:(a + 1) * D]
+            ub[E * D + a] = u[E * D + a]
+            ub[E * D + E + a] = u[E * D + E + a]
+        u_best, per_best = ub, np.minimum(per, per_best)
+    mgpr_objective(mgpr, u_best, noise_trainable)   # leaves the best parameters assigned
+    mgpr._sync()
+    return per_best
+
+
+# --------------------------------------------------------------------------- policy
+def _policy_params(controller):
+    """(get, set) over a flat unconstrained vector for LinearController / RbfController."""
+    from .controllers import LinearController, RbfController
+    if isinstance(controller, LinearController):
+        shapes = [controller.W.shape, controller.b.shape]
+
+        def get():
+            return np.concatenate([controller.W.numpy().ravel(), controller.b.numpy().ravel()])
+
+        def put(u):
+            n0 = int(np.prod(shapes[0]))
+            controller.W.assign(u[:n0].reshape(shapes[0]))
+            controller.b.assign(u[n0:].reshape(shapes[1]))
+        return get, put
+    if isinstance(controller, RbfController):
+        gp = controller._gp
+        bf, d, k = gp.num_datapoints, gp.num_dims, gp.num_outputs
+        lower = 1e-3                                              # positive(lower=1e-3), controllers.py:100
+
+        def get():
+            return np.concatenate([gp.X.ravel(), gp.Y.ravel(), _softplus_inv(gp.lengthscales - lower).ravel()])
+
+        def put(u):
+            X = u[:bf * d].reshape(bf, d)
+            Y = u[bf * d:bf * d + bf * k].reshape(bf, k)
+            ls = lower + _softplus(u[bf * d + bf * k:]).reshape(k, d)
+            gp.set_data((X, Y))
+            for i, m in enumerate(gp.models):
+                m.kernel.lengthscales.assign(ls[i])
+        return get, put
+    raise TypeError("optimize_policy supports LinearController and RbfController")
+
+
+def policy_loss_and_grad(pilco, u, put, eps=1e-6):
+    """-reward and its central-difference gradient (2n+1 device rollouts)."""
+    put(u)
+    f0 = float(pilco.training_loss()[0, 0])
+    g = np.empty_like(u)
+    for i in range(u.size):
+        h = eps * max(1.0, abs(u[i]))
+        up = u.copy()
+        up[i] += h
+        put(up)
+        fp = float(pilco.training_loss()[0, 0])
+        up[i] -= 2 * h
+        put(up)
+        fm = float(pilco.training_loss()[0, 0])
+        g[i] = (fp - fm) / (2 * h)
+    put(u)
+    return f0, g
 
 
 def optimize_policy(pilco, maxiter=50, restarts=1, verbose=True):
-    raise NotImplementedError("policy optimisation is not built yet")
+    if pilco.controller is None:
+        raise ValueError("optimize_policy: the model has no controller (control_dim == 0)")
+    get, put = _policy_params(pilco.controller)
+
+    def run():
+        start = time.time()
+        res = minimize(lambda u: policy_loss_and_grad(pilco, u, put), get(), jac=True, method="L-BFGS-B",
+                       options=dict(maxiter=maxiter))
+        put(res.x)
+        r = float(pilco.compute_reward()[0, 0])
+        if verbose:
+            print("Controller's optimization: done in %.1f seconds with reward=%.3f." % (time.time() - start, r))
+        return res.x, r
+
+    best_u, best_r = run()
+    for _ in range(restarts - 1):                                  # pilco.py:94-107
+        pilco.controller.randomize()
+        u, r = run()
+        if r > best_r:
+            best_u, best_r = u, r
+    put(best_u)
+    return best_r

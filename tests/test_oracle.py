@@ -137,3 +137,20 @@ def test_zero_covariance_is_safe():
     kx = tp.se_ard_K(m, X, ls, np.array([1.0]))[0, 0]
     np.testing.assert_allclose(M[0, 0], kx @ beta[0], rtol=1e-12)
     np.testing.assert_allclose(S[0, 0], 1.0 - kx @ iK[0] @ kx, rtol=1e-7)
+
+
+def test_nlml_gradient_oracle_is_consistent():
+    """The training-objective restatement: analytic gradient vs central differences."""
+    from oracle.gp_train import nlml_and_grad
+    rs = np.random.RandomState(9)
+    X = rs.randn(40, 3)
+    y = np.sin(X) @ rs.randn(3) + 0.05 * rs.randn(40)
+    th = np.array([1.1, 0.8, 1.5, 0.9, 0.02])
+    f0, g = nlml_and_grad(X, y, th[:3], th[3], th[4])
+    for i in range(5):
+        h = 1e-6 * th[i]
+        tp_, tm_ = th.copy(), th.copy()
+        tp_[i] += h
+        tm_[i] -= h
+        fd = (nlml_and_grad(X, y, tp_[:3], tp_[3], tp_[4])[0] - nlml_and_grad(X, y, tm_[:3], tm_[3], tm_[4])[0]) / (2 * h)
+        np.testing.assert_allclose(g[i], fd, rtol=1e-5)
