@@ -88,11 +88,20 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 #define FEXP_MAGIC 6755399441055744.0      /* 1.5 * 2^52 */
 #define FEXP_LN2_64 0.010830424696249145   /* ln2 / 64 */
 
+#ifndef PAIR_OPT
+#define PAIR_OPT 0   // experiment bits (tools): 1 no inline asm, 2 no clamp, 4 no sched barriers
+#endif
 __device__ __forceinline__ double fexp_clamp(double x) {
+#if PAIR_OPT & 2
+    return x;
+#elif PAIR_OPT & 1
+    return fmax(x, -700.0);
+#else
     double y;
     const double lo = -700.0;
     asm("v_max_f64 %0, %1, %2" : "=v"(y) : "v"(x), "s"(lo));  // one instruction: no canonicalising pre-max
     return y;
+#endif
 }
 __device__ __forceinline__ double fexp_t(double x) { return fma(x, FEXP_C, FEXP_MAGIC); }
 __device__ __forceinline__ double fexp_poly(double x, double t) {
@@ -108,7 +117,11 @@ __device__ __forceinline__ double fexp_finish(double tv, double pm1, double t) {
     const double res = fma(tv, pm1, tv);
     const int lo = __double2loint(t) & ~63;
     int hi;
+#if PAIR_OPT & 1
+    hi = __double2hiint(res) + (lo << 14);
+#else
     asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(hi) : "v"(lo), "v"(__double2hiint(res)));  // exponent += n >> 6
+#endif
     return __hiloint2double(hi, __double2loint(res));
 }
 __device__ __forceinline__ double fexp(double x, const double* __restrict__ tab) {
@@ -159,23 +172,51 @@ __device__ double* gauss_jordan(double* G0, double* G1, int n, int nc, double& d
     return cur;
 }
 
-// Unpivoted Gauss-Jordan entirely in registers: lane c of one wave holds column c
-// of the DT x 2DT augmented matrix [A | B]; the pivot column is broadcast with
-// v_readlane.  On return lanes DT..2DT-1 hold the columns of A^{-1} B.
+#ifndef GJ_VIA_LDS
+#define GJ_VIA_LDS 0
+#endif
+// 1/x to fp64 accuracy: hardware reciprocal estimate + two Newton steps (short dependency chain;
+// the IEEE division sequence is ~3x longer and sits on the critical path of every pivot).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// Unpivoted Gauss-Jordan with the matrix in registers: lane c of ONE wave holds column c of the
+// DT x 2DT augmented matrix [A | B].  Per pivot the owning lane publishes its column (the
+// multipliers) through a DT-double LDS buffer that every lane reads back as a broadcast; LDS
+// operations of one wave execute in order, so no barrier is needed.  On return lanes DT..2DT-1 hold
+// the columns of A^{-1} B.  For SPD / diagonally-similar-to-SPD systems (no pivoting).
 template <int DT>
-__device__ __forceinline__ double gj_wave(double (&a)[DT]) {
+__device__ __forceinline__ double gj_wave(double (&a)[DT], double* colbuf, int lane) {
     double det = 1.0;
 #pragma unroll
     for (int k = 0; k < DT; ++k) {
-        const double piv = readlane_f64(a[k], k);
-        det *= piv;
-        const double pk = a[k] / piv;
+#if GJ_VIA_LDS
+        if (lane == k) {
 #pragma unroll
-        for (int r = 0; r < DT; ++r) {
-            if (r == k) continue;
-            const double f = readlane_f64(a[r], k);
-            a[r] = fma(-f, pk, a[r]);
+            for (int r = 0; r < DT; ++r) colbuf[r] = a[r];
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double f[DT];
+#pragma unroll
+        for (int r = 0; r < DT; ++r) f[r] = colbuf[r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+        double f[DT];
+#pragma unroll
+        for (int r = 0; r < DT; ++r) f[r] = readlane_f64(a[r], k);
+        (void)colbuf;
+        (void)lane;
+#endif
+        const double piv = f[k];
+        det *= piv;
+        const double pk = a[k] * fast_rcp(piv);
+#pragma unroll
+        for (int r = 0; r < DT; ++r)
+            if (r != k) a[r] = fma(-f[r], pk, a[r]);
         a[k] = pk;
     }
     return det;
@@ -326,11 +367,12 @@ __device__ void reward_eval(int n, const RewardDev* rws, int E, const double* mx
 }
 
 // ------------------------------------------------------------------ prep
-#ifndef PREP_MINW
-#define PREP_MINW 1
-#endif
+// 512 threads per workgroup = the whole register file of one CU.  The 256 rows of the chunk are
+// handled twice in parallel: threads 0..255 ("group 0") build the row-side operand, threads
+// 256..511 ("group 1") the column-side operand; on a diagonal pair both operands are the same
+// vectors, so group 0 writes both and group 1 does the mean / input-output covariance sums.
 template <int DT>
-__global__ __launch_bounds__(256, PREP_MINW) void k_mm_prep(MMModel md, MMWork wk) {
+__global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = md.D, npad = md.npad;
     double* s_m = sm;
@@ -341,14 +383,14 @@ __global__ __launch_bounds__(256, PREP_MINW) void k_mm_prep(MMModel md, MMWork w
     double* s_Q = s_s + DT * DT;       // [DT*DT] ld DT
     double* s_T = s_Q + DT * DT;       // [DT*DT] ld DT
     double* s_sc = s_T + DT * DT;      // [4] isdet, cfac
-    double* red = s_sc + 4;            // 4 * (DT + 1)
+    double* red = s_sc + 4;            // 5 * (DT + 1)
+    double* colbuf = red + 5 * (DT + 1);  // 2 * DT: pivot columns of the two Gauss-Jordan waves
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int grp = t >> 8, tl = t & 255;
     const int pl = blockIdx.x, ch = blockIdx.y;
     const bool dbg0 = (t == 0 && pl == 0 && ch == 0);
     DBG_STAMP(wk, 0, dbg0);
-    if (wk.dbg && t == 0) {
-        wk.dbg[64 + 2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
-    }
+    if (wk.dbg && t == 0) wk.dbg[64 + 2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
     int a, b;
     local_pair_ab(wk, md.E, pl, a, b);
     const bool diag = (a == b);
@@ -364,8 +406,8 @@ __global__ __launch_bounds__(256, PREP_MINW) void k_mm_prep(MMModel md, MMWork w
         s_ib2[t] = (t < D) ? 1.0 / (lb * lb) : 0.0;
         s_ia[t] = (t < D) ? 1.0 / la : 0.0;
     }
-    for (int e = t; e < D * D; e += 256) s_s[e] = wk.in_s[e];
-    for (int e = t; e < DT * DT; e += 256) {  // padded rows / columns of Q and T stay zero
+    for (int e = t; e < D * D; e += 512) s_s[e] = wk.in_s[e];
+    for (int e = t; e < DT * DT; e += 512) {  // padded rows / columns of Q and T stay zero
         s_Q[e] = 0.0;
         s_T[e] = 0.0;
     }
@@ -391,7 +433,7 @@ __global__ __launch_bounds__(256, PREP_MINW) void k_mm_prep(MMModel md, MMWork w
             }
             col[r] = v;
         }
-        const double det = gj_wave<DT>(col);
+        const double det = gj_wave<DT>(col, colbuf, lane);
         if (c >= DT && c < DT + D) {
 #pragma unroll
             for (int r = 0; r < DT; ++r)
@@ -401,7 +443,7 @@ __global__ __launch_bounds__(256, PREP_MINW) void k_mm_prep(MMModel md, MMWork w
             s_sc[0] = 1.0 / sqrt(det);
             if (ch == 0) wk.pair_isdet[pl] = s_sc[0];
         }
-    } else if (w == 1 && diag) {
+    } else if (w == 4 && diag) {
         // [B | I],  B = Lambda^-1 s Lambda^-1 + I; T = Lambda^-1 B^-1 Lambda^-1   (mgpr.py:103-111)
         double col[DT];
         const int c = lane;
@@ -416,44 +458,38 @@ __global__ __launch_bounds__(256, PREP_MINW) void k_mm_prep(MMModel md, MMWork w
             }
             col[r] = v;
         }
-        const double detB = gj_wave<DT>(col);
+        const double detB = gj_wave<DT>(col, colbuf + DT, lane);
         if (c >= DT && c < DT + D) {
             const int cc = c - DT;
 #pragma unroll
             for (int r = 0; r < DT; ++r)
-                if (r < D) {
-                    const double v = col[r] * s_ia[r] * s_ia[cc];
-                    s_T[r * DT + cc] = v;
-                }
+                if (r < D) s_T[r * DT + cc] = col[r] * s_ia[r] * s_ia[cc];
         }
-        if (lane == 0) {
-            s_sc[1] = md.var[a] / sqrt(detB);
-        }
+        if (lane == 0) s_sc[1] = md.var[a] / sqrt(detB);
     }
     __syncthreads();
     DBG_STAMP(wk, 2, dbg0);
-    DBG_STAMP(wk, 48 + w, lane == 0 && pl == 30 && ch == 1);
-    const double logva = log(md.var[a]), logvb = log(md.var[b]);
     const int KP = wk.KP;
-    double* At = wk.At + (long)pl * KP * npad + ((wk.abl & 1) ? (long)(-i_begin - (t & ~63)) : 0);
-    double* Bt = wk.Bt + (long)pl * KP * npad + ((wk.abl & 1) ? (long)(-i_begin - (t & ~63)) : 0);
-    const double* beta_a = md.beta + (long)a * npad;
+    double* At = wk.At + (long)pl * KP * npad;
+    double* Bt = wk.Bt + (long)pl * KP * npad;
     double g = 0.0;
     double h[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) h[d] = 0.0;
-    for (int i = i_begin + t; i < ((wk.abl & 4) ? i_begin : i_end); i += 256) {
+    const bool mean_role = diag && grp == 1;
+    for (int i = i_begin + tl; i < ((wk.abl & 4) ? i_begin : i_end); i += 256) {
         const bool valid = i < md.n;
         double zeta[DT];
 #pragma unroll
         for (int d = 0; d < DT; ++d) zeta[d] = (d < D && valid) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
-        // Row side, then column side: y = Q x by columns of the symmetric Q (DT independent
-        // accumulators, one wide LDS row read per column step: no LDS latency on the FMA chains).
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
+        if (!mean_role) {
+            // y = Q x by columns of the symmetric Q: DT independent accumulators, one wide LDS row
+            // read per column step (no LDS latency on the FMA chains).  side 0: x = zeta / la^2 -> row
+            // operand (2 Q z | u | 1); side 1: x = zeta / lb^2 -> column operand (w | 1 | v).
+            const int side = diag ? 0 : grp;
             const double* il2 = side ? s_ib2 : s_ia2;   // padding entries are zero
             double x[DT], y[DT];
-            double kk = side ? logvb : logva;
+            double kk = log(md.var[side ? b : a]);
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
                 x[d] = zeta[d] * il2[d];
@@ -472,15 +508,25 @@ __global__ __launch_bounds__(256, PREP_MINW) void k_mm_prep(MMModel md, MMWork w
             double quad = 0.0;
 #pragma unroll
             for (int r = 0; r < DT; ++r) quad = fma(x[r], y[r], quad);
-            double* dst = side ? Bt : At;
+            const double uv = valid ? (kk + quad) : 0.0;
+            const double one = valid ? 1.0 : 0.0;
+            if (side == 0) {
 #pragma unroll
-            for (int r = 0; r < DT; ++r)
-                if (r < D) store_wt(&dst[(long)r * npad + i], side ? x[r] : 2.0 * y[r]);   // w_j | 2 Q z_i (0 for padded rows)
-            store_wt(&dst[(long)(D + side) * npad + i], valid ? (kk + quad) : 0.0);        // u_i at k = D | v_j at k = D+1
-            store_wt(&dst[(long)(D + 1 - side) * npad + i], valid ? 1.0 : 0.0);
-            for (int k = D + 2; k < KP; ++k) store_wt(&dst[(long)k * npad + i], 0.0);
-        }
-        if (diag) {  // mean part: lb_i = exp(-zeta^T T zeta / 2) beta_i      (mgpr.py:113)
+                for (int r = 0; r < DT; ++r)
+                    if (r < D) store_wt(&At[(long)r * npad + i], 2.0 * y[r]);   // 2 Q z_i (0 on padded rows)
+                store_wt(&At[(long)D * npad + i], uv);                           // u_i
+                store_wt(&At[(long)(D + 1) * npad + i], one);
+                for (int k = D + 2; k < KP; ++k) store_wt(&At[(long)k * npad + i], 0.0);
+            }
+            if (side == 1 || diag) {
+#pragma unroll
+                for (int r = 0; r < DT; ++r)
+                    if (r < D) store_wt(&Bt[(long)r * npad + i], x[r]);         // w_j
+                store_wt(&Bt[(long)D * npad + i], one);
+                store_wt(&Bt[(long)(D + 1) * npad + i], uv);                     // v_j
+                for (int k = D + 2; k < KP; ++k) store_wt(&Bt[(long)k * npad + i], 0.0);
+            }
+        } else {  // mean part: lb_i = exp(-zeta^T T zeta / 2) beta_i      (mgpr.py:113)
             double tz[DT];
 #pragma unroll
             for (int r = 0; r < DT; ++r) tz[r] = 0.0;
@@ -496,22 +542,23 @@ __global__ __launch_bounds__(256, PREP_MINW) void k_mm_prep(MMModel md, MMWork w
             double q = 0.0;
 #pragma unroll
             for (int r = 0; r < DT; ++r) q = fma(zeta[r], tz[r], q);
-            const double lb = exp(-0.5 * q) * beta_a[i];
+            const double lb = exp(-0.5 * q) * md.beta[(long)a * npad + i];
             g += lb;
 #pragma unroll
             for (int d = 0; d < DT; ++d) h[d] = fma(zeta[d], lb, h[d]);
         }
     }
     DBG_STAMP(wk, 3, dbg0);
-    DBG_STAMP(wk, 40 + w, lane == 0 && pl == 0 && ch == 0);
-    DBG_STAMP(wk, 44 + w, lane == 0 && pl == 30 && ch == 1);
     if (diag) {
-        g = wave_sum_lane63(g);
-        if (lane == 63) red[w * (DT + 1)] = g;
+        if (grp == 1) {
+            const int wq = w - 4;
+            g = wave_sum_lane63(g);
+            if (lane == 63) red[wq * (DT + 1)] = g;
 #pragma unroll
-        for (int d = 0; d < DT; ++d) {
-            const double v = wave_sum_lane63(h[d]);
-            if (lane == 63) red[w * (DT + 1) + 1 + d] = v;
+            for (int d = 0; d < DT; ++d) {
+                const double v = wave_sum_lane63(h[d]);
+                if (lane == 63) red[wq * (DT + 1) + 1 + d] = v;
+            }
         }
         __syncthreads();
         // block sums of g and h, then M and V contributions of this row chunk:
@@ -532,13 +579,11 @@ __global__ __launch_bounds__(256, PREP_MINW) void k_mm_prep(MMModel md, MMWork w
         }
     }
     DBG_STAMP(wk, 4, dbg0);
-    if (wk.dbg && t == 0) {
-        wk.dbg[65 + 2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
-    }
+    if (wk.dbg && t == 0) wk.dbg[65 + 2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
 }
 
 size_t prep_lds_bytes(int DT) {
-    return sizeof(double) * ((size_t)4 * DT + 3 * (size_t)DT * DT + 4 + 5 * (size_t)(DT + 1));
+    return sizeof(double) * ((size_t)4 * DT + 3 * (size_t)DT * DT + 4 + 5 * (size_t)(DT + 1) + 2 * (size_t)DT);
 }
 
 int mm_kp(int D) { return round_up(D + 2, 4); }
@@ -560,7 +605,7 @@ void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk) {
     dim3 grid(wk.PL, wk.NCH);
     const int D = md.D;
 #define PREP(DT_)                                                                                          \
-    hipLaunchKernelGGL((k_mm_prep<DT_>), grid, dim3(256), prep_lds_bytes(DT_), st, md, wk)
+    hipLaunchKernelGGL((k_mm_prep<DT_>), grid, dim3(512), prep_lds_bytes(DT_), st, md, wk)
     if (D <= 4) PREP(4);
     else if (D <= 8) PREP(8);
     else if (D <= 12) PREP(12);
@@ -580,7 +625,7 @@ void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk) {
 //          64x64 diagonal block are evaluated (weight 2 right of it): half the exps and half the
 //          iK stream.  S_num += (beta_i beta_j - iK_ij) L_ij, one accumulator per result register.
 #ifndef PAIR_RT
-#define PAIR_RT 4      // 16-row MFMA tiles per wave (rows per work item = 16 * PAIR_RT)
+#define PAIR_RT 2      // 16-row MFMA tiles per wave (rows per work item = 16 * PAIR_RT); 2 measured best
 #endif
 // ablation switches for kernel experiments (tools/): never defined in product builds
 #ifndef PAIR_ABL
@@ -595,6 +640,9 @@ void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk) {
 #define PAIR_ABL_MFMA(a_, b_, e_) (d4{e_[0] + a_ * b_, e_[1] - a_, e_[2] + b_, e_[3] * 0.5})
 #else
 #define PAIR_ABL_MFMA(a_, b_, e_) __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, e_, 0, 0, 0)
+#endif
+#ifndef PAIR_PF
+#define PAIR_PF 2      // operand prefetch distance in 16-column steps
 #endif
 #ifndef PAIR_MINW
 #define PAIR_MINW 1    // __launch_bounds__ min waves per SIMD for the pair kernel
@@ -620,30 +668,38 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
     }
     if (DIAG && jbeg < i0) jbeg = i0;  // columns left of the diagonal block are mirrored by the transposed tile
     double total = 0.0;
-    // software pipeline: operands of the next column step are loaded while this one is evaluated
-    double bfn[KC], bbn = 0.0;
+    // software pipeline: the operands of the column step PAIR_PF ahead are requested while this one is
+    // evaluated (a first touch of Bt / beta misses the XCD's L2: ~2 us, more than one step)
+    double ring[PAIR_PF][KC + 1];
 #pragma unroll
-    for (int c = 0; c < KC; ++c) bfn[c] = 0.0;
-    if (jbeg < jend) {
+    for (int p = 0; p < PAIR_PF; ++p) {
 #pragma unroll
-        for (int c = 0; c < KC; ++c) bfn[c] = Bt[(long)(4 * c + lr) * npad + jbeg + lc];
-        bbn = beta_b[jbeg + lc];
+        for (int c = 0; c <= KC; ++c) ring[p][c] = 0.0;
+        if (jbeg + 16 * p < jend) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) ring[p][c] = Bt[(long)(4 * c + lr) * npad + jbeg + 16 * p + lc];
+            ring[p][KC] = beta_b[jbeg + 16 * p + lc];
+        }
     }
     for (int j0 = jbeg; j0 < jend; j0 += 16) {
         double bf[KC];
 #pragma unroll
-        for (int c = 0; c < KC; ++c) bf[c] = bfn[c];
-        const double bb = bbn;
+        for (int c = 0; c < KC; ++c) bf[c] = ring[0][c];
+        const double bb = ring[0][KC];
+#pragma unroll
+        for (int p = 0; p + 1 < PAIR_PF; ++p)
+#pragma unroll
+            for (int c = 0; c <= KC; ++c) ring[p][c] = ring[p + 1][c];
         double ik[NE];
         if (DIAG) {
 #pragma unroll
             for (int i = 0; i < NE; ++i)
                 ik[i] = iKa[(long)(i0 + 16 * (i >> 2) + lr + 4 * (i & 3)) * npad + j0 + lc];
         }
-        if (PAIR_ABL != 4 && j0 + 16 < jend) {
+        if (PAIR_ABL != 4 && j0 + 16 * PAIR_PF < jend) {
 #pragma unroll
-            for (int c = 0; c < KC; ++c) bfn[c] = Bt[(long)(4 * c + lr) * npad + j0 + 16 + lc];
-            bbn = beta_b[j0 + 16 + lc];
+            for (int c = 0; c < KC; ++c) ring[PAIR_PF - 1][c] = Bt[(long)(4 * c + lr) * npad + j0 + 16 * PAIR_PF + lc];
+            ring[PAIR_PF - 1][KC] = beta_b[j0 + 16 * PAIR_PF + lc];
         }
         // exponent tiles: C/D layout of the f64 MFMA is col = lane & 15, row = (lane >> 4) + 4 * reg
         double x[NE], tt[NE], tv[NE], pm[NE];
@@ -662,7 +718,9 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
         }
 #pragma unroll
         for (int i = 0; i < NE; ++i) tv[i] = PAIR_ABL_TAB(tab[__double2loint(tt[i]) & 63]);
+#if !(PAIR_OPT & 4)
         __builtin_amdgcn_sched_barrier(0);
+#endif
         // Horner stages across all NE elements at once: NE independent fp64 chains per wave
         double rr[NE];
 #pragma unroll
