@@ -135,6 +135,19 @@ int pilco_propagate(pilco_ctx* ctx, const pilco_policy* policy, const double* m_
 int pilco_policy_action(pilco_ctx* ctx, const pilco_policy* policy, const double* m, const double* s, double* M, double* S, double* V);
 int pilco_reward_eval(pilco_ctx* ctx, const pilco_reward_term* rewards, int n_rewards, int state_dim, const double* m, const double* s, double* muR, double* sR);
 
+/* ------------------------------------------------------------------ reverse mode
+ * The reference differentiates training_loss with TensorFlow's autodiff (pilco/models/pilco.py:85-90);
+ * here the adjoint of the moment-matching step is hand-derived.
+ * pilco_gp_predict_vjp: cotangents Mbar (1,E), Sbar (E,E), Vbar (D,E) of pilco_gp_predict's outputs ->
+ * mbar (1,D), sbar (D,D, symmetric) at the input (m, s).  Single rank, D <= 14.
+ * pilco_rollout_tape: pilco_rollout that also returns, per step, the joint Gaussian handed to the
+ * dynamics GP (m (D), s (D,D), s1 (E,D)) and its outputs (M (E), S (E,E), V (D,E)). */
+int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double* s, const double* Mbar,
+                         const double* Sbar, const double* Vbar, double* mbar, double* sbar);
+int pilco_rollout_tape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                       const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj,
+                       double* tape);
+
 /* ------------------------------------------------------------------ timing / introspection */
 /* Time `reps` back-to-back rollouts with HIP events on the library's stream.
  * ms_total: wall time of the timed region; ms_pair: summed duration of the

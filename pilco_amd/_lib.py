@@ -66,6 +66,9 @@ SIGNATURES = {
     "pilco_gp_predict": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "pilco_rollout": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
                                 _dp, _dp, _dp, _dp]),
+    "pilco_gp_predict_vjp": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "pilco_rollout_tape": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
+                                     _dp, _dp, _dp, _dp, _dp]),
     "pilco_propagate": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp]),
     "pilco_policy_action": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp, _dp]),
     "pilco_reward_eval": (C.c_int, [_vp, C.POINTER(RewardTerm), C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
@@ -277,6 +280,26 @@ class Context:
         if want_traj:
             return mH, SH, rew, traj
         return mH, SH, rew
+
+    def gp_predict_vjp(self, slot, m, s, Mbar, Sbar, Vbar, D, E):
+        m = _f64(m, (D,)); s = _f64(s, (D, D))
+        Mb = _f64(Mbar, (E,)); Sb = _f64(Sbar, (E, E)); Vb = _f64(Vbar, (D, E))
+        mbar = np.empty((1, D)); sbar = np.empty((D, D))
+        self._chk(self.lib.pilco_gp_predict_vjp(self.h, slot, _ptr(m), _ptr(s), _ptr(Mb), _ptr(Sb), _ptr(Vb), _ptr(mbar), _ptr(sbar)))
+        return mbar, sbar
+
+    def rollout_tape(self, policy, rewards, m0, S0, H):
+        E = policy["state_dim"]; D = E + policy["control_dim"]
+        p, k1 = self._policy(policy)
+        r, k2 = self._rewards(rewards, E)
+        m0 = _f64(m0, (E,)); S0 = _f64(S0, (E, E))
+        mH = np.empty((1, E)); SH = np.empty((E, E)); rew = np.zeros((1, 1))
+        traj = np.empty((H + 1, E + E * E))
+        TS = D + D * D + E * D + E + E * E + D * E
+        tape = np.zeros((max(H, 1), TS))
+        self._chk(self.lib.pilco_rollout_tape(self.h, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H),
+                                              _ptr(mH), _ptr(SH), _ptr(rew), _ptr(traj), _ptr(tape)))
+        return mH, SH, rew, traj, tape[:H]
 
     def propagate(self, policy, m_x, s_x):
         E = policy["state_dim"]

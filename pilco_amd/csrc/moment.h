@@ -82,6 +82,7 @@ struct GlueArgs {
     double* s1;      // [E][D]  = [s_x, s_x c_xu], kept for propagate
     double* reward;  // [1]
     double* traj;    // [(H+1)][E + E*E] or nullptr
+    double* tape;    // [H][D + D*D + E*D + E + E*E + D*E] joint (m, s, s1) and GP outputs (M, S, V) of every step, or nullptr
     int step;
     // policy
     int pol_kind;
@@ -110,6 +111,9 @@ int mm_pair_nt(int npad, int variant, int PL);
 int mm_prep_nch(int npad, int PL);
 int mm_kp(int D);
 void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot);
+// reverse pass of the pair sums (single rank, D + 2 <= 16): rowmom [(2P-E)][16][npad] scratch,
+// out [P][1 + D + D*D] = (N_ab | A | I) per pair, see k_mm_bwd_post
+void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* out);
 int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf, const double* exp_tab);
 
 }  // namespace pilco

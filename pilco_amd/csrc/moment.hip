@@ -903,6 +903,148 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
 }
 
 
+// ------------------------------------------------------------------ adjoint of the pair sums
+// d e_ij/d m = P (z_i + w_j) and d e_ij/d s = (P y)(P y)^T / 2, so the reverse
+// pass needs, per pair, only   r_i = sum_j W_ij L_ij,   c_j = sum_i W_ij L_ij,   m_i = sum_j W_ij L_ij w_j
+// with W = beta_a beta_b^T (- iK_a on the diagonal pair).  One wave owns 16 rows and sweeps all
+// columns; the exponent tile is computed TRANSPOSED (column operand as MFMA A, row operand as B) so
+// that the weighted tile W.L lands in the B-operand layout of a second MFMA that contracts it with
+// [w_j | 1]: moments and row sums cost 4 MFMAs per 16x16 tile and no VALU reductions.  Column sums
+// come from the same kernel run on the reversed orientation (rows from the b side).
+// rowmom[op][d][i]: orientation 0: d < D -> m_i[d], d = D -> r_i; orientation 1: d = D+1 -> c_j.
+template <int KC>
+__global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ rowmom) {
+    __shared__ double tab[64];
+    if (threadIdx.x < 64) tab[threadIdx.x] = wk.exp_tab[threadIdx.x];
+    __syncthreads();
+    const int npad = md.npad, D = md.D, E = md.E;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lr = lane >> 4, lc = lane & 15;
+    const int op = blockIdx.y;
+    const int P = wk.PL;
+    const int orient = (op >= P) ? 1 : 0;
+    const int pl = orient ? (op - P + E) : op;
+    int a, b;
+    local_pair_ab(wk, E, pl, a, b);
+    const int KP = wk.KP;
+    const double* At = wk.At + (long)pl * KP * npad;
+    const double* Bt = wk.Bt + (long)pl * KP * npad;
+    const double* RowArr = orient ? Bt : At;   // operand of the rows this wave owns
+    const double* ColArr = orient ? At : Bt;   // operand of the swept columns
+    const double* beta_row = md.beta + (long)(orient ? b : a) * npad;
+    const double* beta_col = md.beta + (long)(orient ? a : b) * npad;
+    const bool diag = (a == b) && (md.iK != nullptr);
+    const double* iKa = diag ? md.iK + (long)a * npad * npad : nullptr;
+    const int i0 = blockIdx.x * 64 + w * 16;
+    double rf[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) rf[c] = RowArr[(long)(4 * c + lr) * npad + i0 + lc];
+    const double brow = beta_row[i0 + lc];
+    // second-product operand mask: which rows d = lc of the column operand are contracted
+    const bool dsel = orient ? (lc == D + 1) : (lc <= D);
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int j0 = 0; j0 < npad; j0 += 16) {
+        d4 e = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const double cf = ColArr[(long)(4 * c + lr) * npad + j0 + lc];
+            e = __builtin_amdgcn_mfma_f64_16x16x4f64(cf, rf[c], e, 0, 0, 0);   // e[r]: i = i0+lc, j = j0+lr+4r
+        }
+        double wl[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + lr + 4 * r;
+            double wgt = brow * beta_col[j];
+            if (diag) wgt -= iKa[(long)j * npad + i0 + lc];   // iK is symmetric: coalesced along the rows
+            wl[r] = wgt * fexp(e[r], tab);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double a2 = dsel ? ColArr[(long)lc * npad + j0 + 4 * r + lr] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, wl[r], acc, 0, 0, 0);
+        }
+    }
+    double* out = rowmom + (long)op * 16 * npad;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(long)(lr + 4 * r) * npad + i0 + lc] = acc[r];
+}
+
+// Per unordered pair: N_ab = sum_i r_i,  A = sum_i (r_i z_i + c_i w_i)  (D),
+// I = sum_i (r_i z_i z_i^T + c_i w_i w_i^T + z_i m_i^T + m_i z_i^T)  (D x D).   out[pl][1 + D + D*D]
+__global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, const double* __restrict__ rowmom,
+                                                    double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int npad = md.npad, D = md.D, E = md.E, t = threadIdx.x;
+    const int pl = blockIdx.x, P = wk.PL;
+    int a, b;
+    local_pair_ab(wk, E, pl, a, b);
+    const double* mom0 = rowmom + (long)pl * 16 * npad;
+    const double* mom1 = (a != b) ? rowmom + (long)(P + pl - E) * 16 * npad : nullptr;
+    double* zs = sm;              // [64][D]
+    double* ws = zs + 64 * D;     // [64][D]
+    double* ms = ws + 64 * D;     // [64][D]
+    double* rs = ms + 64 * D;     // [64]
+    double* cs = rs + 64;         // [64]
+    const int nI = D * D;
+    double acc = 0.0;
+    for (int i0 = 0; i0 < npad; i0 += 64) {
+        __syncthreads();
+        for (int e = t; e < 64 * D; e += 256) {
+            const int ii = e / D, d = e - ii * D;
+            const int i = i0 + ii;
+            const bool valid = i < md.n;
+            const double zeta = valid ? md.Pt[(long)d * npad + i] - wk.in_m[d] : 0.0;
+            const double la = md.ls[a * D + d], lb = md.ls[b * D + d];
+            zs[e] = zeta / (la * la);
+            ws[e] = zeta / (lb * lb);
+            ms[e] = valid ? mom0[(long)d * npad + i] : 0.0;
+        }
+        if (t < 64) {
+            const int i = i0 + t;
+            const bool valid = i < md.n;
+            const double r = valid ? mom0[(long)D * npad + i] : 0.0;
+            rs[t] = r;
+            cs[t] = valid ? (mom1 ? mom1[(long)(D + 1) * npad + i] : r) : 0.0;
+        }
+        __syncthreads();
+        if (t < nI) {
+            const int d = t / D, e2 = t - d * D;
+            for (int ii = 0; ii < 64; ++ii) {
+                const double zd = zs[ii * D + d], ze = zs[ii * D + e2];
+                acc = fma(rs[ii] * zd, ze, acc);
+                acc = fma(cs[ii] * ws[ii * D + d], ws[ii * D + e2], acc);
+                acc = fma(zd, ms[ii * D + e2], acc);
+                acc = fma(ms[ii * D + d], ze, acc);
+            }
+        } else if (t < nI + D) {
+            const int d = t - nI;
+            for (int ii = 0; ii < 64; ++ii) acc = fma(rs[ii], zs[ii * D + d], fma(cs[ii], ws[ii * D + d], acc));
+        } else if (t == nI + D) {
+            for (int ii = 0; ii < 64; ++ii) acc += rs[ii];
+        }
+    }
+    double* o = out + (long)pl * (1 + D + nI);
+    if (t < nI) o[1 + D + t] = acc;
+    else if (t < nI + D) o[1 + (t - nI)] = acc;
+    else if (t == nI + D) o[0] = acc;
+}
+
+void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* out) {
+    const int P = wk.PL, E = md.E, D = md.D;
+    const int nOP = P + (P - E);
+    dim3 grid(md.npad / 64, nOP);
+#define PB(K_) hipLaunchKernelGGL((k_mm_bwd_pair<K_>), grid, dim3(256), 0, st, md, wk, rowmom)
+    switch (wk.KP / 4) {
+        case 1: PB(1); break;
+        case 2: PB(2); break;
+        case 3: PB(3); break;
+        default: PB(4); break;
+    }
+#undef PB
+    const size_t lds = sizeof(double) * ((size_t)3 * 64 * D + 128);
+    hipLaunchKernelGGL(k_mm_bwd_post, dim3(P), dim3(256), lds, st, md, wk, rowmom, out);
+}
+
 // ------------------------------------------------------------------ pair kernel, plain VALU
 // Reference implementation of the same tile sums without matrix cores: one row
 // per thread (256-row tile), 64 columns staged in LDS and read by broadcast.
@@ -1155,7 +1297,13 @@ __device__ void write_joint(const GlueArgs& g, const GlueLds& L) {
         else v = L.su[(r - E) * U + (c - E)];
         g.wk.in_s[e] = v;
         if (r < E) g.s1[r * D + c] = v;
+        if (g.tape) {
+            double* rec = g.tape + (long)g.step * (D + D * D + E * D + E + E * E + D * E);
+            rec[D + e] = v;
+            if (r < E) rec[D + D * D + r * D + c] = v;
+        }
     }
+    if (g.tape && t < D) g.tape[(long)g.step * (D + D * D + E * D + E + E * E + D * E) + t] = (t < E) ? L.mx[t] : L.mu[t - E];
 }
 
 // Reduce the tile / stream-K partials of the local pairs and the row-chunk partials of the
@@ -1310,6 +1458,12 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
     if (g.flags & GF_ASSEMBLE) {
         // single rank: the LDS copy of the segment is the whole gather buffer
         mm_assemble(g.wk, L.seg, g.var, D, E, L.mu, L.su, L.cxu);  // oM -> mu, oS -> su, oV -> cxu
+        if (g.tape && g.step >= 1) {
+            double* rec = g.tape + (long)(g.step - 1) * (D + D * D + E * D + E + E * E + D * E) + D + D * D + E * D;
+            if (t < E) rec[t] = L.mu[t];
+            for (int e = t; e < E * E; e += blockDim.x) rec[E + e] = L.su[e];
+            for (int e = t; e < D * E; e += blockDim.x) rec[E + E * E + e] = L.cxu[e];
+        }
     }
     DBG_STAMP(g.wk, 11 + dbo, dbg0);
     if (g.flags & GF_PROPAGATE) {

@@ -465,3 +465,44 @@ def test_optimize_policy_increases_reward(ctx):
     r1 = p.optimize_policy(maxiter=15, restarts=1, verbose=False)
     assert r1 > r0 + 1e-3
     np.testing.assert_allclose(float(p.compute_reward()[0, 0]), r1)
+
+
+@pytest.mark.parametrize("shape", [(60, 3, 2), (300, 5, 4), (1000, 10, 10)])
+def test_moment_matching_vjp_vs_autograd(ctx, shape):
+    """pilco_gp_predict_vjp (hand-derived adjoint, device pair sums) against torch autograd of the restated
+    forward pass (what TensorFlow's reverse mode gives the reference, pilco.py:85-90)."""
+    import torch
+    from oracle import torch_path as tq
+    N, D, E = shape
+    c = synthetic.config_c2(N=N, D=D, E=E, noise=1e-2, seed=N, control_dim=max(D - E, 0))
+    mg = _mgpr(c)
+    rs = np.random.RandomState(1)
+    m = 0.2 * rs.randn(1, D)
+    A = 0.3 * rs.randn(D, D)
+    s = A @ A.T + 0.05 * np.eye(D)
+    Mbar, Sbar, Vbar = rs.randn(1, E), rs.randn(E, E), rs.randn(D, E)
+    mg._ensure_factorized()
+    mbar, sbar = ctx.gp_predict_vjp(0, m, s, Mbar, Sbar, Vbar, D, E)
+    iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+    if N <= 300:
+        mt = torch.tensor(m, dtype=torch.float64, requires_grad=True)
+        st = torch.tensor(s, dtype=torch.float64, requires_grad=True)
+        M, S, V = tq.predict_given_factorizations(c["X"], c["lengthscales"], c["variance"], mt, st, iK, beta)
+        ((torch.tensor(Mbar) * M).sum() + (torch.tensor(Sbar) * S).sum() + (torch.tensor(Vbar) * V).sum()).backward()
+        gm, gs = mt.grad.numpy(), st.grad.numpy()
+        gs = 0.5 * (gs + gs.T)
+    else:  # full size: directional finite differences of the device forward pass
+        gm = gs = None
+    if gm is not None:
+        np.testing.assert_allclose(mbar, gm, rtol=1e-6, atol=1e-9 * np.abs(gm).max())
+        np.testing.assert_allclose(sbar, gs, rtol=1e-6, atol=1e-9 * np.abs(gs).max())
+    dm = rs.randn(1, D)
+    dS = rs.randn(D, D)
+    dS = dS + dS.T
+    h = 1e-6
+    def phi(mm, ss):
+        M, S, V = ctx.gp_predict(0, mm, ss, D, E)
+        return (Mbar * M).sum() + (Sbar * S).sum() + (Vbar * V).sum()
+    fd = (phi(m + h * dm, s + h * dS) - phi(m - h * dm, s - h * dS)) / (2 * h)
+    an = (mbar * dm).sum() + (sbar * dS).sum()
+    np.testing.assert_allclose(an, fd, rtol=2e-5)
