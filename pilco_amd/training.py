@@ -157,8 +157,15 @@ def _policy_params(controller):
 
 
 def policy_loss_and_grad(pilco, u, put, eps=1e-6):
-    """-reward and its central-difference gradient (2n+1 device rollouts)."""
+    """-reward and its gradient: the hand-derived adjoint (pilco_amd/adjoint.py) for a linear controller
+    with an exponential reward, central differences of device rollouts (2n+1 of them) otherwise."""
+    from .controllers import LinearController
+    from .rewards import ExponentialReward
     put(u)
+    if isinstance(pilco.controller, LinearController) and isinstance(pilco.reward, ExponentialReward) and pilco.control_dim > 0:
+        from .adjoint import rollout_value_and_grad
+        r, Wb, bb = rollout_value_and_grad(pilco)
+        return -r, -np.concatenate([Wb.ravel(), bb.ravel()])
     f0 = float(pilco.training_loss()[0, 0])
     g = np.empty_like(u)
     for i in range(u.size):

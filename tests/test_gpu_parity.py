@@ -506,3 +506,52 @@ def test_moment_matching_vjp_vs_autograd(ctx, shape):
     fd = (phi(m + h * dm, s + h * dS) - phi(m - h * dm, s - h * dS)) / (2 * h)
     an = (mbar * dm).sum() + (sbar * dS).sum()
     np.testing.assert_allclose(an, fd, rtol=2e-5)
+
+
+def test_policy_gradient_adjoint_vs_autograd_and_fd(ctx):
+    """d reward / d (W, b) of an H-step rollout: device adjoint vs torch autograd of the restated rollout
+    (the reference's TF reverse mode through the while_loop, pilco.py:85-90,126-135) and vs central differences."""
+    import torch
+    from oracle import torch_path as tq
+    from pilco_amd.adjoint import rollout_value_and_grad
+    from pilco_amd.rewards import ExponentialReward
+    c = synthetic.config_cascade()
+    cfg = {k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise")}
+    H = 5
+    p = _pilco_from(cfg, H)
+    Wr = np.array([[1.5, 0.2], [0.2, 0.7]])
+    tr = np.array([[1.0, 0.3]])
+    p.reward = ExponentialReward(2, W=Wr, t=tr)
+    p.m_init, p.S_init = c["m"], c["s"]
+    p.controller.W.assign(c["W"])
+    p.controller.b.assign(c["b"])
+    p.controller.max_action = 2.0
+    r, Wb, bb = rollout_value_and_grad(p)
+    np.testing.assert_allclose(r, float(p.compute_reward()[0, 0]), rtol=1e-12)
+    # autograd oracle
+    iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+    Wt = torch.tensor(c["W"], dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(c["b"], dtype=torch.float64, requires_grad=True)
+    gp = lambda m, s: tq.predict_given_factorizations(c["X"], c["lengthscales"], c["variance"], m, s, iK, beta)
+    ctl = lambda m, s: tq.linear_controller(m, s, Wt, bt, 2.0)
+    rw = lambda m, s: tq.exponential_reward(m, s, Wr, tr)
+    _, _, R = tq.predict(gp, ctl, rw, tq.t(c["m"]), tq.t(c["s"]), H)
+    R.sum().backward()
+    np.testing.assert_allclose(r, R.item(), rtol=1e-8)
+    np.testing.assert_allclose(Wb, Wt.grad.numpy(), rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(bb, bt.grad.numpy(), rtol=1e-6, atol=1e-10)
+    # central differences of device rollouts, and bitwise repeatability of the gradient
+    h = 1e-6
+    W0 = c["W"].copy()
+    for idx in [(0, 0), (0, 1)]:
+        Wp, Wm = W0.copy(), W0.copy()
+        Wp[idx] += h
+        Wm[idx] -= h
+        p.controller.W.assign(Wp)
+        fp = float(p.compute_reward()[0, 0])
+        p.controller.W.assign(Wm)
+        fm = float(p.compute_reward()[0, 0])
+        np.testing.assert_allclose(Wb[idx], (fp - fm) / (2 * h), rtol=1e-4)
+    p.controller.W.assign(W0)
+    r2, Wb2, bb2 = rollout_value_and_grad(p)
+    assert r2 == r and np.array_equal(Wb2, Wb) and np.array_equal(bb2, bb)
