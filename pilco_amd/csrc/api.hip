@@ -58,6 +58,7 @@ struct pilco_ctx {
     hipGraphExec_t graph = nullptr;
     std::vector<unsigned long long> graph_key;
     bool use_graph = true;
+    bool graph_rccl_failed = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t st2 = nullptr;                        // side stream of the reward kernel
     hipEvent_t ev_state = nullptr, ev_rew = nullptr;  // fork / join of the side stream
@@ -867,7 +868,11 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
 // (same buffers, sizes, horizon, policy / reward structure), otherwise (re)capture it.
 int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
     Slot& s = ctx->slot[0];
-    if (!ctx->use_graph || ctx->nranks != 1 || ctx->comm || (ctx->dbg && !getenv("PILCO_DBG_GRAPH"))) return enqueue_rollout(ctx, plan, H, nullptr);
+    // With a communicator the captured graph contains the ncclAllGather nodes (RCCL supports stream
+    // capture); if capture or instantiation fails the rollout falls back to eager launches for good.
+    const bool sharded = (ctx->nranks != 1 || ctx->comm);
+    if (!ctx->use_graph || (sharded && (!ctx->comm || ctx->graph_rccl_failed)) || (ctx->dbg && !getenv("PILCO_DBG_GRAPH")))
+        return enqueue_rollout(ctx, plan, H, nullptr);
     const GlueArgs& g = plan.g;
     std::vector<unsigned long long> key = {
         (unsigned long long)H, (unsigned long long)g.pol_kind, (unsigned long long)g.n_rewards, (unsigned long long)g.squash,
@@ -906,13 +911,30 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
         hipError_t e = hipStreamEndCapture(ctx->st, &graph);
         if (rc != PILCO_OK) {
             if (graph) (void)hipGraphDestroy(graph);
+            if (sharded) {
+                ctx->graph_rccl_failed = true;
+                (void)hipGetLastError();
+                return -1;
+            }
             return rc;
         }
-        if (e != hipSuccess) return fail(ctx, PILCO_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        if (e != hipSuccess) {
+            if (sharded) {  // not fatal: run this and all later sharded rollouts eagerly
+                ctx->graph_rccl_failed = true;
+                (void)hipGetLastError();
+                return -1;
+            }
+            return fail(ctx, PILCO_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        }
         e = hipGraphInstantiate(&ctx->graph, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) {
             ctx->graph = nullptr;
+            if (sharded) {
+                ctx->graph_rccl_failed = true;
+                (void)hipGetLastError();
+                return -1;
+            }
             return fail(ctx, PILCO_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
         }
         ctx->graph_key = key;
@@ -1094,8 +1116,11 @@ int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_
     HIPCHK(hipEventRecord(ctx->ev0, ctx->st));
     for (int rep = 0; rep < reps; ++rep) {
         HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
-        const int r = run_rollout(ctx, plan, H);
-        if (r == -1) return fail(ctx, PILCO_E_STATE, "rollout_timed: graph re-captured inside the timed region");
+        int r = run_rollout(ctx, plan, H);
+        if (r == -1) {  // only possible when the sharded capture fell back to eager mode: redo this rollout
+            HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
+            r = run_rollout(ctx, plan, H);
+        }
         if (r != PILCO_OK) return r;
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->st));

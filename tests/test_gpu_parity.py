@@ -555,3 +555,51 @@ def test_policy_gradient_adjoint_vs_autograd_and_fd(ctx):
     p.controller.W.assign(W0)
     r2, Wb2, bb2 = rollout_value_and_grad(p)
     assert r2 == r and np.array_equal(Wb2, Wb) and np.array_equal(bb2, bb)
+
+
+def test_degenerate_dims_and_two_controls(ctx):
+    """Smallest shapes (N=17, D=1, E=1: one point dimension, one output, no control) and a rollout with two
+    control dimensions, each against the oracle; plus the policy gradient with U=2 against autograd."""
+    import torch
+    from oracle import torch_path as tq
+    from pilco_amd.adjoint import rollout_value_and_grad
+    from pilco_amd.models import PILCO
+    rs = np.random.RandomState(3)
+    X = rs.randn(17, 1)
+    Y = np.sin(X) + 0.01 * rs.randn(17, 1)
+    cfg = dict(X=X, Y=Y, lengthscales=np.array([[0.9]]), variance=np.array([1.3]), noise=np.array([1e-2]))
+    m = _mgpr(cfg)
+    M, S, V = m.predict_on_noisy_inputs(np.array([[0.2]]), np.array([[0.3]]))
+    iK, beta = tp.calculate_factorizations(X, Y, cfg["lengthscales"], cfg["variance"], cfg["noise"])
+    Mo, So, Vo = tp.predict_given_factorizations(X, cfg["lengthscales"], cfg["variance"], np.array([[0.2]]), np.array([[0.3]]), iK, beta)
+    np.testing.assert_allclose(M, Mo, rtol=RTOL)
+    np.testing.assert_allclose(S, So, rtol=RTOL)
+    np.testing.assert_allclose(V, Vo, rtol=RTOL)
+    # state 2, controls 2
+    X = rs.randn(90, 4)
+    Y = 0.3 * np.sin(X) @ rs.randn(4, 2) + 1e-2 * rs.randn(90, 2)
+    ls, var, nz = 1.0 + rs.rand(2, 4), 0.5 + rs.rand(2), 1e-2 * np.ones(2)
+    W, b = 0.5 * rs.randn(2, 2), 0.2 * rs.randn(1, 2)
+    p = PILCO((X, Y), horizon=4)
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(ls[i]); mdl.kernel.variance.assign(var[i]); mdl.likelihood.variance.assign(nz[i])
+    p.controller.W.assign(W); p.controller.b.assign(b); p.controller.max_action = np.array([1.5, 0.7])
+    m0, S0 = 0.1 * rs.randn(1, 2), 0.05 * np.eye(2)
+    p.m_init, p.S_init = m0, S0
+    Mg, Sg, Rg = p.predict(m0, S0, 4)
+    model = tp.Model(X, Y, ls, var, nz)
+    ctl = lambda mm, ss: tp.linear_controller(mm, ss, W, b, np.array([1.5, 0.7]))
+    Mo, So, Ro = tp.predict(model, ctl, tp.exponential_reward, m0, S0, 4, cache=True)
+    np.testing.assert_allclose(Mg, Mo, rtol=RTOL)
+    np.testing.assert_allclose(Sg, So, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(Rg, Ro, rtol=RTOL)
+    r, Wb, bb = rollout_value_and_grad(p)
+    iK, beta = tp.calculate_factorizations(X, Y, ls, var, nz)
+    Wt = torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    gp = lambda mm, ss: tq.predict_given_factorizations(X, ls, var, mm, ss, iK, beta)
+    _, _, R = tq.predict(gp, lambda mm, ss: tq.linear_controller(mm, ss, Wt, bt, np.array([1.5, 0.7])),
+                         lambda mm, ss: tq.exponential_reward(mm, ss), tq.t(m0), tq.t(S0), 4)
+    R.sum().backward()
+    np.testing.assert_allclose(Wb, Wt.grad.numpy(), rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(bb, bt.grad.numpy(), rtol=1e-6, atol=1e-10)
