@@ -603,3 +603,25 @@ def test_degenerate_dims_and_two_controls(ctx):
     R.sum().backward()
     np.testing.assert_allclose(Wb, Wt.grad.numpy(), rtol=1e-6, atol=1e-10)
     np.testing.assert_allclose(bb, bt.grad.numpy(), rtol=1e-6, atol=1e-10)
+
+
+def test_safe_pilco_accumulator(ctx):
+    """SafePILCO.predict (safe_pilco_extension/safe_pilco.py:29-50) against a host loop over the oracle rollout."""
+    from pilco_amd.safe import SafePILCO, SingleConstraint
+    from pilco_amd.rewards import ExponentialReward
+    c = synthetic.config_cascade()
+    risk = SingleConstraint(0, high=1.2, inside=False)
+    p = SafePILCO((c["X"], c["Y"]), horizon=4, reward_add=ExponentialReward(2), reward_mult=risk, mu=3.0)
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(c["lengthscales"][i]); mdl.kernel.variance.assign(c["variance"][i]); mdl.likelihood.variance.assign(c["noise"][i])
+    p.controller.W.assign(c["W"]); p.controller.b.assign(c["b"]); p.controller.max_action = c["max_action"]
+    M, S, R = p.predict(c["m"], c["s"], 4)
+    model = tp.Model(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+    ctl = lambda mm, ss: tp.linear_controller(mm, ss, c["W"], c["b"], c["max_action"])
+    m_x, s_x, add, mult = c["m"], c["s"], 0.0, 1.0
+    for _ in range(4):
+        add += tp.exponential_reward(m_x, s_x)[0][0, 0]
+        mult *= 1.0 - float(risk.compute_reward(m_x, s_x)[0])
+        m_x, s_x = tp.propagate(model, ctl, m_x, s_x, cache=True)
+    np.testing.assert_allclose(M, m_x, rtol=RTOL)
+    np.testing.assert_allclose(R[0, 0], add + 3.0 * (1.0 - mult), rtol=RTOL)
