@@ -108,3 +108,21 @@ def predict(gp, controller, reward, m_x, s_x, n):
         total = total + reward(m_x, s_x)
         m_x, s_x = propagate(gp, controller, m_x, s_x)
     return m_x, s_x, total
+
+
+def rbf_controller(m, s, X, Y, ls, noise, max_action=1.0, squash=True):
+    """controllers.py:108-121: deterministic GP with unit signal variance, iK := 0, S -= diag(var - 1e-6)."""
+    n, d = X.shape
+    U = Y.shape[1]
+    var = torch.ones(U, dtype=DT)
+    beta = []
+    for a in range(U):
+        K = torch.exp(-0.5 * torch.sum(((X[:, None, :] - X[None, :, :]) / ls[a]) ** 2, -1))
+        beta.append(torch.linalg.solve(K + noise[a] * torch.eye(n, dtype=DT), Y[:, a]))
+    beta = torch.stack(beta)
+    M, S, V = predict_given_factorizations(X, ls, var, m, s, torch.zeros((U, n, n), dtype=DT), beta)
+    S = S - torch.diag(var - 1e-6)
+    if squash:
+        M, S, V2 = squash_sin(M, S, max_action)
+        V = V @ V2
+    return M, S, V

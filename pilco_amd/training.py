@@ -157,15 +157,22 @@ def _policy_params(controller):
 
 
 def policy_loss_and_grad(pilco, u, put, eps=1e-6):
-    """-reward and its gradient: the hand-derived adjoint (pilco_amd/adjoint.py) for a linear controller
-    with an exponential reward, central differences of device rollouts (2n+1 of them) otherwise."""
-    from .controllers import LinearController
-    from .rewards import ExponentialReward
+    """-reward and its gradient: the hand-derived adjoint (pilco_amd/adjoint.py) for linear and RBF controllers
+    with exponential / linear / combined rewards, central differences of device rollouts (2n+1 of them) otherwise."""
+    from . import _lib
+    from .controllers import LinearController, RbfController
     put(u)
-    if isinstance(pilco.controller, LinearController) and isinstance(pilco.reward, ExponentialReward) and pilco.control_dim > 0:
+    ctl = pilco.controller
+    analytic = pilco.control_dim > 0 and all(t["kind"] in (_lib.REWARD_EXPONENTIAL, _lib.REWARD_LINEAR) for t in pilco.reward.terms())
+    if analytic and isinstance(ctl, LinearController):
         from .adjoint import rollout_value_and_grad
-        r, Wb, bb = rollout_value_and_grad(pilco)
+        r, (Wb, bb) = rollout_value_and_grad(pilco)
         return -r, -np.concatenate([Wb.ravel(), bb.ravel()])
+    if analytic and isinstance(ctl, RbfController):
+        from .adjoint import rollout_value_and_grad
+        r, (Xb, Yb, lb) = rollout_value_and_grad(pilco)
+        nu = lb.size                                         # ls = lower + softplus(u): d ls / du = sigmoid(u)
+        return -r, -np.concatenate([Xb.ravel(), Yb.ravel(), (lb * _dsoftplus(u[-nu:]).reshape(lb.shape)).ravel()])
     f0 = float(pilco.training_loss()[0, 0])
     g = np.empty_like(u)
     for i in range(u.size):

@@ -526,7 +526,7 @@ def test_policy_gradient_adjoint_vs_autograd_and_fd(ctx):
     p.controller.W.assign(c["W"])
     p.controller.b.assign(c["b"])
     p.controller.max_action = 2.0
-    r, Wb, bb = rollout_value_and_grad(p)
+    r, (Wb, bb) = rollout_value_and_grad(p)
     np.testing.assert_allclose(r, float(p.compute_reward()[0, 0]), rtol=1e-12)
     # autograd oracle
     iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
@@ -553,7 +553,7 @@ def test_policy_gradient_adjoint_vs_autograd_and_fd(ctx):
         fm = float(p.compute_reward()[0, 0])
         np.testing.assert_allclose(Wb[idx], (fp - fm) / (2 * h), rtol=1e-4)
     p.controller.W.assign(W0)
-    r2, Wb2, bb2 = rollout_value_and_grad(p)
+    r2, (Wb2, bb2) = rollout_value_and_grad(p)
     assert r2 == r and np.array_equal(Wb2, Wb) and np.array_equal(bb2, bb)
 
 
@@ -593,7 +593,7 @@ def test_degenerate_dims_and_two_controls(ctx):
     np.testing.assert_allclose(Mg, Mo, rtol=RTOL)
     np.testing.assert_allclose(Sg, So, rtol=RTOL, atol=1e-12)
     np.testing.assert_allclose(Rg, Ro, rtol=RTOL)
-    r, Wb, bb = rollout_value_and_grad(p)
+    r, (Wb, bb) = rollout_value_and_grad(p)
     iK, beta = tp.calculate_factorizations(X, Y, ls, var, nz)
     Wt = torch.tensor(W, dtype=torch.float64, requires_grad=True)
     bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
@@ -625,3 +625,44 @@ def test_safe_pilco_accumulator(ctx):
         m_x, s_x = tp.propagate(model, ctl, m_x, s_x, cache=True)
     np.testing.assert_allclose(M, m_x, rtol=RTOL)
     np.testing.assert_allclose(R[0, 0], add + 3.0 * (1.0 - mult), rtol=RTOL)
+
+
+def test_rbf_policy_gradient_adjoint_vs_autograd(ctx):
+    """d reward / d (centres, targets, lengthscales) of a rollout driven by an RbfController with a combined
+    (exponential + linear) reward: adjoint (device GP VJP + host policy VJP) vs torch autograd of the restated
+    rollout (what TF's reverse mode gives the reference, pilco.py:85-90; controllers.py:108-121), then one
+    optimize_policy run that must not lower the reward."""
+    import torch
+    from oracle import torch_path as tq
+    from pilco_amd.adjoint import rollout_value_and_grad
+    from pilco_amd.controllers import RbfController
+    from pilco_amd.models import PILCO
+    from pilco_amd.rewards import CombinedRewards, ExponentialReward, LinearReward
+    c = synthetic.config_cascade()
+    rs = np.random.RandomState(11)
+    H, bf = 4, 6
+    ctl = RbfController(2, 1, bf, max_action=1.5)
+    Xp, Yp = rs.randn(bf, 2), 0.4 * rs.randn(bf, 1)
+    lsp = 1 + 0.2 * rs.rand(1, 2)
+    ctl.set_data((Xp, Yp))
+    ctl.models[0].kernel.lengthscales.assign(lsp[0])
+    Wl = np.array([[0.3], [-0.2]])
+    rew = CombinedRewards(2, [ExponentialReward(2), LinearReward(2, Wl)], coefs=[1.0, 0.5])
+    p = PILCO((c["X"], c["Y"]), horizon=H, controller=ctl, reward=rew, m_init=c["m"], S_init=c["s"])
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(c["lengthscales"][i]); mdl.kernel.variance.assign(c["variance"][i]); mdl.likelihood.variance.assign(c["noise"][i])
+    r, (Xb, Yb, lb) = rollout_value_and_grad(p)
+    np.testing.assert_allclose(r, float(p.compute_reward()[0, 0]), rtol=1e-12)
+    iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+    tX, tY, tl = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (Xp, Yp, lsp)]
+    gp = lambda m, s: tq.predict_given_factorizations(c["X"], c["lengthscales"], c["variance"], m, s, iK, beta)
+    pol = lambda m, s: tq.rbf_controller(m, s, tX, tY, tl, torch.full((1,), 1e-4, dtype=torch.float64), 1.5)
+    rw = lambda m, s: tq.exponential_reward(m, s) + 0.5 * m @ tq.t(Wl)
+    _, _, R = tq.predict(gp, pol, rw, tq.t(c["m"]), tq.t(c["s"]), H)
+    R.sum().backward()
+    np.testing.assert_allclose(r, R.item(), rtol=1e-8)
+    np.testing.assert_allclose(Xb, tX.grad.numpy(), rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(Yb, tY.grad.numpy(), rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(lb, tl.grad.numpy(), rtol=1e-6, atol=1e-10)
+    r_opt = p.optimize_policy(maxiter=5, verbose=False)
+    assert r_opt >= r - 1e-12

@@ -154,3 +154,33 @@ def test_nlml_gradient_oracle_is_consistent():
         tm_[i] -= h
         fd = (nlml_and_grad(X, y, tp_[:3], tp_[3], tp_[4])[0] - nlml_and_grad(X, y, tm_[:3], tm_[3], tm_[4])[0]) / (2 * h)
         np.testing.assert_allclose(g[i], fd, rtol=1e-5)
+
+
+def test_rbf_policy_vjp_host_math_vs_autograd():
+    """The hand-reversed RBF policy layer of pilco_amd/adjoint.py (host NumPy, O(bf^2)) against torch autograd of the
+    restated controllers.py:108-121 -- values and cotangents of (m, s, centres, targets, lengthscales)."""
+    import torch
+    from oracle import torch_path as tq
+    from pilco_amd.adjoint import rbf_policy_fwd, rbf_policy_vjp
+    rng = np.random.RandomState(3)
+    n, d, U = 9, 3, 2
+    X, Y = rng.randn(n, d), 0.3 * rng.randn(n, U)
+    ls, nz = 1 + 0.3 * rng.rand(U, d), np.full(U, 1e-4)
+    m = 0.2 * rng.randn(1, d)
+    A = rng.randn(d, d)
+    s = 0.1 * A @ A.T
+    M, S, V, cache = rbf_policy_fwd(m, s, X, Y, ls, nz)
+    tm, ts, tX, tY, tl = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (m, s, X, Y, ls)]
+    Mo, So, Vo = tq.rbf_controller(tm, ts, tX, tY, tl, torch.tensor(nz), squash=False)
+    np.testing.assert_allclose(M, Mo.detach().numpy().ravel(), rtol=1e-10)
+    np.testing.assert_allclose(S, So.detach().numpy(), rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(V, Vo.detach().numpy(), rtol=1e-10)
+    Mb, Sb, Vb = rng.randn(U), rng.randn(U, U), rng.randn(d, U)
+    loss = (Mo.reshape(-1) * torch.tensor(Mb)).sum() + (So * torch.tensor(Sb)).sum() + (Vo * torch.tensor(Vb)).sum()
+    g = [x.numpy() for x in torch.autograd.grad(loss, [tm, ts, tX, tY, tl])]
+    mb, sb, Xb, Yb, lb = rbf_policy_vjp(cache, Mb, Sb, Vb)
+    np.testing.assert_allclose(mb, g[0], rtol=1e-9)
+    np.testing.assert_allclose(sb + sb.T, g[1] + g[1].T, rtol=1e-9, atol=1e-12)   # s is symmetric: only that part is defined
+    np.testing.assert_allclose(Xb, g[2], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(Yb, g[3], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(lb, g[4], rtol=1e-9, atol=1e-12)

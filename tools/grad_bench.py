@@ -15,8 +15,8 @@ p.m_init, p.S_init = c["m0"], c["S0"]
 t0 = time.time(); r = p.compute_reward(); t1 = time.time()
 for _ in range(2): r = p.compute_reward()
 t2 = time.time()
-v, Wb, bb = rollout_value_and_grad(p)
+v, (Wb, bb) = rollout_value_and_grad(p)
 t3 = time.time()
-v, Wb, bb = rollout_value_and_grad(p)
+v, (Wb, bb) = rollout_value_and_grad(p)
 t4 = time.time()
 print("C2u forward rollout %.2f ms; value+gradient %.1f ms (first %.1f ms); reward %.6f |dW| %.3e" % ((t2 - t1) / 2 * 1e3, (t4 - t3) * 1e3, (t3 - t2) * 1e3, v, np.abs(Wb).max()))
