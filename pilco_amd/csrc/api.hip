@@ -3,6 +3,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 
@@ -18,10 +19,7 @@ struct Slot {
     int n = 0, npad = 0;             // points the moment matching runs over (N or M) and padding
     bool has_data = false, has_hyp = false, factor_valid = false, user_factors = false, iK_null = false;
     bool ignore_iK = false;  // policy slot: RbfController evaluates with iK zeroed (controllers.py:116)
-    std::vector<double> hZ;
-    std::vector<double> hX, hls, hvar, hbeta;  // host copies for the adjoint's O(N D^2) algebra (points [n][D], beta [E][n])
-    bool hbeta_valid = false;
-    DevBuf bwd_mom, bwd_out;                   // reverse-pass scratch
+    DevBuf bwd_mom, bwd_part, bwd_out;         // reverse-pass scratch
     DevBuf Xt, Yt, Zt, ls, var, noise;         // Yt: [E][Npad]
     DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
     DevBuf Kmn, V2, Am, AmInv, AmD, iAt, G;    // FITC extras
@@ -417,7 +415,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
         for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr,
-                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_out, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
+                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_part, &s.bwd_out, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
                           &s.w_part, &s.w_gath, &s.w_out})
             b->release();
         if (s.d_lists) (void)hipFree(s.d_lists);
@@ -483,8 +481,6 @@ int pilco_gp_set_data(pilco_ctx* ctx, int slot, const double* X, const double* Y
     HIPCHK(hipMemcpyAsync(s.vec.p, Y, sizeof(double) * N * E, hipMemcpyHostToDevice, ctx->st));
     launch_transpose_points(ctx->st, s.vec.p, N, E, s.Yt.p, s.Npad);
     HIPCHK(hipStreamSynchronize(ctx->st));
-    s.hX.assign(X, X + (size_t)N * D);
-    s.hbeta_valid = false;
     s.has_data = true;
     s.factor_valid = false;
     s.user_factors = false;
@@ -510,9 +506,6 @@ int pilco_gp_set_hyp(pilco_ctx* ctx, int slot, const double* lengthscales, const
     HIPCHK(hipMemcpyAsync(s.var.p, variance, sizeof(double) * s.E, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipMemcpyAsync(s.noise.p, noise, sizeof(double) * s.E, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
-    s.hls.assign(lengthscales, lengthscales + (size_t)s.E * s.D);
-    s.hvar.assign(variance, variance + s.E);
-    s.hbeta_valid = false;
     s.has_hyp = true;
     s.factor_valid = false;
     s.user_factors = false;
@@ -536,8 +529,6 @@ int pilco_gp_set_inducing(pilco_ctx* ctx, int slot, const double* Z, int M) {
     }
     s.n = M;
     s.npad = round_up(M, NB);
-    s.hZ.assign(Z, Z + (size_t)M * s.D);
-    s.hbeta_valid = false;
     ENSURE(s.Zt, (size_t)s.D * s.npad);
     ENSURE(s.vec, std::max((size_t)M * s.D, (size_t)s.E * std::max(s.Npad, s.npad)));
     HIPCHK(hipMemcpyAsync(s.vec.p, Z, sizeof(double) * M * s.D, hipMemcpyHostToDevice, ctx->st));
@@ -592,7 +583,6 @@ int pilco_gp_factorize(pilco_ctx* ctx, int slot) {
     s.factor_valid = true;
     s.user_factors = false;
     s.wk_valid = false;
-    s.hbeta_valid = false;
     return PILCO_OK;
 }
 
@@ -678,7 +668,6 @@ int pilco_gp_set_factors(pilco_ctx* ctx, int slot, const double* iK, const doubl
     }
     HIPCHK(hipStreamSynchronize(ctx->st));
     s.iK_null = (iK == nullptr);
-    s.hbeta_valid = false;
     s.factor_valid = true;
     s.user_factors = true;
     s.wk_valid = false;  // the stream-K geometry depends on whether an iK stream exists
@@ -1325,55 +1314,10 @@ int pilco_gp_shard_finish(pilco_ctx* ctx, int slot, const double* gathered, doub
 int pilco_comm_rank(const pilco_ctx* ctx) { return ctx ? ctx->rank : -1; }
 int pilco_comm_size(const pilco_ctx* ctx) { return ctx ? ctx->nranks : -1; }
 
-}  // extern "C"
-
-namespace {
-
-// small dense helpers for the host side of the adjoint (D <= 32)
-bool invert_small(const std::vector<double>& A, int n, std::vector<double>& inv, double& det) {
-    std::vector<double> a(A);
-    inv.assign((size_t)n * n, 0.0);
-    for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
-    det = 1.0;
-    for (int k = 0; k < n; ++k) {
-        int p = k;
-        for (int r = k + 1; r < n; ++r)
-            if (std::fabs(a[(size_t)r * n + k]) > std::fabs(a[(size_t)p * n + k])) p = r;
-        if (a[(size_t)p * n + k] == 0.0) return false;
-        if (p != k) {
-            for (int c = 0; c < n; ++c) {
-                std::swap(a[(size_t)p * n + c], a[(size_t)k * n + c]);
-                std::swap(inv[(size_t)p * n + c], inv[(size_t)k * n + c]);
-            }
-            det = -det;
-        }
-        const double piv = a[(size_t)k * n + k];
-        det *= piv;
-        for (int c = 0; c < n; ++c) {
-            a[(size_t)k * n + c] /= piv;
-            inv[(size_t)k * n + c] /= piv;
-        }
-        for (int r = 0; r < n; ++r) {
-            if (r == k) continue;
-            const double f = a[(size_t)r * n + k];
-            if (f == 0.0) continue;
-            for (int c = 0; c < n; ++c) {
-                a[(size_t)r * n + c] -= f * a[(size_t)k * n + c];
-                inv[(size_t)r * n + c] -= f * inv[(size_t)k * n + c];
-            }
-        }
-    }
-    return true;
-}
-
-}  // namespace
-
-extern "C" {
-
 // Vector-Jacobian product of one moment-matching step (the reverse of pilco_gp_predict):
 // given cotangents Mbar (1,E), Sbar (E,E), Vbar (D,E) returns mbar (1,D) and the symmetric sbar (D,D).
-// O(N^2) part on the device (k_mm_bwd_pair / k_mm_bwd_post), O(N D^2) mean part and the per-pair
-// D x D algebra on the host.  Single rank, exact or sparse model, D + 2 <= 16.
+// Entirely on the device (k_mm_bwd_pair / _post / _fin for the pair sums, k_mm_bwd_mean for the mean part); the
+// host only sums the E + P contribution records.  Single rank, exact or sparse model, D <= 14.
 int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double* s_in, const double* Mbar,
                          const double* Sbar, const double* Vbar, double* mbar, double* sbar) {
     if (int r = check_slot(ctx, slot)) return r;
@@ -1381,148 +1325,40 @@ int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double
     if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "predict_vjp: no current factorisation");
     if (!m || !s_in || !Mbar || !Sbar || !Vbar || !mbar || !sbar) return fail(ctx, PILCO_E_SHAPE, "predict_vjp: null pointer");
     if (ctx->nranks != 1) return fail(ctx, PILCO_E_STATE, "predict_vjp: single rank only");
-    const int D = s.D, E = s.E, n = s.n, npad = s.npad;
+    const int D = s.D, E = s.E, npad = s.npad;
     if (D + 2 > 16) return fail(ctx, PILCO_E_SHAPE, "predict_vjp: D <= 14 in this build");
     HIPCHK(hipSetDevice(ctx->device));
     if (int r = build_work(ctx, s)) return r;
     const int P = s.wk.PL;
-    if (!s.hbeta_valid) {
-        std::vector<double> tmp((size_t)E * npad);
-        HIPCHK(hipMemcpy(tmp.data(), s.beta.p, sizeof(double) * E * npad, hipMemcpyDeviceToHost));
-        s.hbeta.assign((size_t)E * n, 0.0);
-        for (int a = 0; a < E; ++a) memcpy(&s.hbeta[(size_t)a * n], &tmp[(size_t)a * npad], sizeof(double) * n);
-        s.hbeta_valid = true;
-    }
-    // ---- device: operands, reverse pair sweep, per-pair sums
-    const int nOP = 2 * P - E, rec = 1 + D + D * D;
+    // ---- device: operands (prep), reverse pair sweep, mean part, per-pair / per-output contributions
+    const int nOP = 2 * P - E, rec = D + D * D, nb = E + E * E + D * E;
     ENSURE(s.bwd_mom, (size_t)nOP * 16 * npad);
-    ENSURE(s.bwd_out, (size_t)P * rec);
+    ENSURE(s.bwd_part, (size_t)P * mm_bwd_rc(npad) * (1 + rec));
+    ENSURE(s.bwd_out, (size_t)(E + P) * rec + nb);
+    double* bars = s.bwd_out.p + (size_t)(E + P) * rec;
+    std::vector<double> hb(nb);
+    memcpy(hb.data(), Mbar, sizeof(double) * E);
+    memcpy(hb.data() + E, Sbar, sizeof(double) * E * E);
+    memcpy(hb.data() + E + E * E, Vbar, sizeof(double) * D * E);
     HIPCHK(hipMemcpyAsync(s.wk.in_m, m, sizeof(double) * D, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipMemcpyAsync(s.wk.in_s, s_in, sizeof(double) * D * D, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(bars, hb.data(), sizeof(double) * nb, hipMemcpyHostToDevice, ctx->st));
     const MMModel md = model_of(s);
     launch_mm_prep(ctx->st, md, s.wk);
-    launch_mm_bwd(ctx->st, md, s.wk, s.bwd_mom.p, s.bwd_out.p);
-    std::vector<double> po((size_t)P * rec);
+    launch_mm_bwd(ctx->st, md, s.wk, s.bwd_mom.p, s.bwd_part.p, bars, s.bwd_out.p);
+    std::vector<double> po((size_t)(E + P) * rec);
     HIPCHK(hipMemcpyAsync(po.data(), s.bwd_out.p, sizeof(double) * po.size(), hipMemcpyDeviceToHost, ctx->st));
-    // ---- host: mean part while the device works
-    std::vector<double> mb(D, 0.0), sb((size_t)D * D, 0.0), Mf(E), A((size_t)D * D), T, zeta((size_t)n * D);
-    for (int i = 0; i < n; ++i)
-        for (int d = 0; d < D; ++d) zeta[(size_t)i * D + d] = (s.M > 0 ? s.hZ : s.hX)[(size_t)i * D + d] - m[d];
-    struct Mean { std::vector<double> T, l, h; double c, g; };
-    std::vector<Mean> mean(E);
-    for (int a = 0; a < E; ++a) {
-        double ldet_l = 0.0;
-        for (int r = 0; r < D; ++r)
-            for (int c = 0; c < D; ++c) A[(size_t)r * D + c] = s_in[(size_t)r * D + c] + (r == c ? s.hls[(size_t)a * D + r] * s.hls[(size_t)a * D + r] : 0.0);
-        for (int d = 0; d < D; ++d) ldet_l += 2.0 * std::log(s.hls[(size_t)a * D + d]);
-        double det;
-        Mean& me = mean[a];
-        if (!invert_small(A, D, me.T, det)) return fail(ctx, PILCO_E_NOT_PD, "predict_vjp: s + Lambda^2 is singular");
-        me.c = s.hvar[a] * std::exp(0.5 * ldet_l) / std::sqrt(det);
-        me.l.assign(n, 0.0);
-        me.h.assign(D, 0.0);
-        me.g = 0.0;
-        for (int i = 0; i < n; ++i) {
-            const double* z = &zeta[(size_t)i * D];
-            double q = 0.0;
-            for (int r = 0; r < D; ++r) {
-                double tz = 0.0;
-                for (int c = 0; c < D; ++c) tz += me.T[(size_t)r * D + c] * z[c];
-                q += z[r] * tz;
-            }
-            const double li = std::exp(-0.5 * q) * s.hbeta[(size_t)a * n + i];
-            me.l[i] = li;
-            me.g += li;
-            for (int d = 0; d < D; ++d) me.h[d] += li * z[d];
-        }
-        Mf[a] = me.c * me.g;
-    }
-    for (int a = 0; a < E; ++a) {
-        const Mean& me = mean[a];
-        double mu = Mbar[a];
-        for (int b = 0; b < E; ++b) mu -= (Sbar[(size_t)a * E + b] + Sbar[(size_t)b * E + a]) * Mf[b];   // S = ... - M M^T
-        std::vector<double> u(D, 0.0), Th(D, 0.0), wq(D, 0.0), H2q((size_t)D * D, 0.0);
-        for (int r = 0; r < D; ++r)
-            for (int c = 0; c < D; ++c) {
-                u[r] += me.T[(size_t)r * D + c] * Vbar[(size_t)c * E + a];
-                Th[r] += me.T[(size_t)r * D + c] * me.h[c];
-            }
-        double vTh = 0.0;
-        for (int d = 0; d < D; ++d) vTh += Vbar[(size_t)d * E + a] * Th[d];
-        const double phi = me.c * (mu * me.g + vTh);
-        for (int i = 0; i < n; ++i) {
-            const double* z = &zeta[(size_t)i * D];
-            double q = mu;
-            for (int d = 0; d < D; ++d) q += z[d] * u[d];
-            const double lq = me.l[i] * q;
-            for (int d = 0; d < D; ++d) {
-                wq[d] += lq * z[d];
-                for (int e2 = 0; e2 < D; ++e2) H2q[(size_t)d * D + e2] += lq * z[d] * z[e2];
-            }
-        }
-        for (int r = 0; r < D; ++r) {
-            double tw = 0.0;
-            for (int c = 0; c < D; ++c) tw += me.T[(size_t)r * D + c] * wq[c];
-            mb[r] += me.c * (tw - me.g * u[r]);
-        }
-        // sbar += -phi T / 2 + c T H2q T / 2 - c (u Th^T + Th u^T) / 2
-        std::vector<double> TH((size_t)D * D, 0.0);
-        for (int r = 0; r < D; ++r)
-            for (int c = 0; c < D; ++c) {
-                double acc = 0.0;
-                for (int k = 0; k < D; ++k) acc += me.T[(size_t)r * D + k] * H2q[(size_t)k * D + c];
-                TH[(size_t)r * D + c] = acc;
-            }
-        for (int r = 0; r < D; ++r)
-            for (int c = 0; c < D; ++c) {
-                double acc = 0.0;
-                for (int k = 0; k < D; ++k) acc += TH[(size_t)r * D + k] * me.T[(size_t)k * D + c];
-                sb[(size_t)r * D + c] += -0.5 * phi * me.T[(size_t)r * D + c] + 0.5 * me.c * acc - 0.5 * me.c * (u[r] * Th[c] + Th[r] * u[c]);
-            }
-    }
-    // ---- host: covariance part from the per-pair device sums
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());
-    std::vector<double> Pm, lam(D), PI((size_t)D * D), PL2((size_t)D * D);
-    for (int pl = 0; pl < P; ++pl) {
-        int a, b;
-        if (pl < E) { a = b = pl; } else { const int q = pl - E; a = 1; while (a * (a + 1) / 2 <= q) ++a; b = q - a * (a - 1) / 2; }
-        for (int d = 0; d < D; ++d) {
-            const double la = s.hls[(size_t)a * D + d], lb = s.hls[(size_t)b * D + d];
-            lam[d] = 1.0 / (la * la) + 1.0 / (lb * lb);
-        }
-        for (int r = 0; r < D; ++r)   // I + Lambda s
-            for (int c = 0; c < D; ++c) A[(size_t)r * D + c] = lam[r] * s_in[(size_t)r * D + c] + (r == c ? 1.0 : 0.0);
-        double det;
-        if (!invert_small(A, D, Pm, det)) return fail(ctx, PILCO_E_NOT_PD, "predict_vjp: I + Lambda s is singular");
-        const double shat = (a == b) ? Sbar[(size_t)a * E + a] : Sbar[(size_t)a * E + b] + Sbar[(size_t)b * E + a];
-        const double kappa = shat / std::sqrt(det);   // det(I + Lambda s) = det(s Lambda + I) = det R_ab
-        const double* o = &po[(size_t)pl * rec];
-        const double Nab = o[0];
-        const double* Av = o + 1;
-        const double* Im = o + 1 + D;
-        for (int r = 0; r < D; ++r) {
-            double acc = 0.0;
-            for (int c = 0; c < D; ++c) acc += Pm[(size_t)r * D + c] * Av[c];
-            mb[r] += kappa * acc;
-        }
-        for (int r = 0; r < D; ++r)
-            for (int c = 0; c < D; ++c) {
-                double acc = 0.0;
-                for (int k = 0; k < D; ++k) acc += Pm[(size_t)r * D + k] * Im[(size_t)k * D + c];
-                PI[(size_t)r * D + c] = acc;
-                PL2[(size_t)r * D + c] = Pm[(size_t)r * D + c] * lam[c];   // P Lambda
-            }
-        for (int r = 0; r < D; ++r)
-            for (int c = 0; c < D; ++c) {
-                double acc = 0.0;
-                for (int k = 0; k < D; ++k) acc += PI[(size_t)r * D + k] * Pm[(size_t)c * D + k];   // (P I P^T)[r][c]
-                sb[(size_t)r * D + c] += kappa * (0.5 * acc - 0.25 * Nab * (PL2[(size_t)r * D + c] + PL2[(size_t)c * D + r]));
-            }
-    }
-    for (int d = 0; d < D; ++d) mbar[d] = mb[d];
+    // ---- host: sum the E + P records in a fixed order, symmetrise
+    std::vector<double> acc(rec, 0.0);
+    for (int k = 0; k < E + P; ++k)
+        for (int e = 0; e < rec; ++e) acc[e] += po[(size_t)k * rec + e];
+    for (int e = 0; e < rec; ++e)
+        if (!std::isfinite(acc[e])) return fail(ctx, PILCO_E_NOT_PD, "predict_vjp: singular s + Lambda^2 or I + Lambda s");
+    for (int d = 0; d < D; ++d) mbar[d] = acc[d];
     for (int r = 0; r < D; ++r)
-        for (int c = 0; c < D; ++c) sbar[(size_t)r * D + c] = 0.5 * (sb[(size_t)r * D + c] + sb[(size_t)c * D + r]);
+        for (int c = 0; c < D; ++c) sbar[(size_t)r * D + c] = 0.5 * (acc[D + (size_t)r * D + c] + acc[D + (size_t)c * D + r]);
     return PILCO_OK;
 }
 

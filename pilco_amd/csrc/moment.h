@@ -111,9 +111,12 @@ int mm_pair_nt(int npad, int variant, int PL);
 int mm_prep_nch(int npad, int PL);
 int mm_kp(int D);
 void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot);
-// reverse pass of the pair sums (single rank, D + 2 <= 16): rowmom [(2P-E)][16][npad] scratch,
-// out [P][1 + D + D*D] = (N_ab | A | I) per pair, see k_mm_bwd_post
-void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* out);
+// reverse pass of one moment-matching step (single rank, D <= 14; the step's prep kernel must precede it on st):
+// rowmom [(2P-E)][16][npad] and part [P][mm_bwd_rc][1 + D + D*D] are scratch, bars = (Mbar | Sbar | Vbar) on the
+// device, out [E + P][D + D*D] = per output / per pair contributions (mbar | sbar), summed by the caller
+void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* part, const double* bars,
+                   double* out);
+int mm_bwd_rc(int npad);
 int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf, const double* exp_tab);
 
 }  // namespace pilco

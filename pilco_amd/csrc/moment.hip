@@ -969,35 +969,39 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
     for (int r = 0; r < 4; ++r) out[(long)(lr + 4 * r) * npad + i0 + lc] = acc[r];
 }
 
-// Per unordered pair: N_ab = sum_i r_i,  A = sum_i (r_i z_i + c_i w_i)  (D),
-// I = sum_i (r_i z_i z_i^T + c_i w_i w_i^T + z_i m_i^T + m_i z_i^T)  (D x D).   out[pl][1 + D + D*D]
+// Per unordered pair and row chunk: partial sums of  N_ab = sum_i r_i,  A = sum_i (r_i z_i + c_i w_i)  (D),
+// I = sum_i (r_i z_i z_i^T + c_i w_i w_i^T + z_i m_i^T + m_i z_i^T)  (D x D).   part[pl][chunk][1 + D + D*D]
+constexpr int BWD_RC = 8;  // row chunks per pair (npad / 64 is a multiple of it or smaller)
 __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, const double* __restrict__ rowmom,
-                                                    double* __restrict__ out) {
+                                                    double* __restrict__ part, int nrc) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int npad = md.npad, D = md.D, E = md.E, t = threadIdx.x;
-    const int pl = blockIdx.x, P = wk.PL;
+    const int pl = blockIdx.x, P = wk.PL, rc = blockIdx.y;
     int a, b;
     local_pair_ab(wk, E, pl, a, b);
     const double* mom0 = rowmom + (long)pl * 16 * npad;
     const double* mom1 = (a != b) ? rowmom + (long)(P + pl - E) * 16 * npad : nullptr;
-    double* zs = sm;              // [64][D]
-    double* ws = zs + 64 * D;     // [64][D]
-    double* ms = ws + 64 * D;     // [64][D]
-    double* rs = ms + 64 * D;     // [64]
+    const int LD = D | 1;         // odd row stride: the (d, e) readers of one point spread over the banks
+    double* zs = sm;              // [64][LD]
+    double* ws = zs + 64 * LD;    // [64][LD]
+    double* ms = ws + 64 * LD;    // [64][LD]
+    double* rs = ms + 64 * LD;    // [64]
     double* cs = rs + 64;         // [64]
     const int nI = D * D;
+    const int nblk = npad / 64;
     double acc = 0.0;
-    for (int i0 = 0; i0 < npad; i0 += 64) {
+    for (int blk = rc; blk < nblk; blk += nrc) {
+        const int i0 = blk * 64;
         __syncthreads();
         for (int e = t; e < 64 * D; e += 256) {
-            const int ii = e / D, d = e - ii * D;
+            const int d = e >> 6, ii = e & 63;   // consecutive threads -> consecutive points: coalesced
             const int i = i0 + ii;
             const bool valid = i < md.n;
             const double zeta = valid ? md.Pt[(long)d * npad + i] - wk.in_m[d] : 0.0;
             const double la = md.ls[a * D + d], lb = md.ls[b * D + d];
-            zs[e] = zeta / (la * la);
-            ws[e] = zeta / (lb * lb);
-            ms[e] = valid ? mom0[(long)d * npad + i] : 0.0;
+            zs[ii * LD + d] = zeta / (la * la);
+            ws[ii * LD + d] = zeta / (lb * lb);
+            ms[ii * LD + d] = valid ? mom0[(long)d * npad + i] : 0.0;
         }
         if (t < 64) {
             const int i = i0 + t;
@@ -1010,26 +1014,210 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
         if (t < nI) {
             const int d = t / D, e2 = t - d * D;
             for (int ii = 0; ii < 64; ++ii) {
-                const double zd = zs[ii * D + d], ze = zs[ii * D + e2];
+                const double zd = zs[ii * LD + d], ze = zs[ii * LD + e2];
                 acc = fma(rs[ii] * zd, ze, acc);
-                acc = fma(cs[ii] * ws[ii * D + d], ws[ii * D + e2], acc);
-                acc = fma(zd, ms[ii * D + e2], acc);
-                acc = fma(ms[ii * D + d], ze, acc);
+                acc = fma(cs[ii] * ws[ii * LD + d], ws[ii * LD + e2], acc);
+                acc = fma(zd, ms[ii * LD + e2], acc);
+                acc = fma(ms[ii * LD + d], ze, acc);
             }
         } else if (t < nI + D) {
             const int d = t - nI;
-            for (int ii = 0; ii < 64; ++ii) acc = fma(rs[ii], zs[ii * D + d], fma(cs[ii], ws[ii * D + d], acc));
+            for (int ii = 0; ii < 64; ++ii) acc = fma(rs[ii], zs[ii * LD + d], fma(cs[ii], ws[ii * LD + d], acc));
         } else if (t == nI + D) {
             for (int ii = 0; ii < 64; ++ii) acc += rs[ii];
         }
     }
-    double* o = out + (long)pl * (1 + D + nI);
+    double* o = part + ((long)pl * nrc + rc) * (1 + D + nI);
     if (t < nI) o[1 + D + t] = acc;
     else if (t < nI + D) o[1 + (t - nI)] = acc;
     else if (t == nI + D) o[0] = acc;
 }
 
-void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* out) {
+// Per pair: P = (I + Lambda s)^-1, kappa = Shat_ab / sqrt(det R_ab), and the pair's contribution
+//   mbar += kappa P A,   sbar += kappa (P I P^T / 2 - N (P Lambda + Lambda P^T) / 4)      
+// out[E + pl][D + D*D].  bars = (Mbar [E] | Sbar [E][E] | Vbar [D][E]) on the device.
+__global__ __launch_bounds__(256) void k_mm_bwd_fin(MMModel md, MMWork wk, const double* __restrict__ part, int nrc,
+                                                   const double* __restrict__ bars, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x;
+    int a, b;
+    local_pair_ab(wk, E, pl, a, b);
+    const int nI = D * D, rec = 1 + D + nI, nc = 2 * D;
+    double* G0 = sm;               // [D][2D]
+    double* G1 = G0 + D * nc;      // [D][2D]
+    double* Iv = G1 + D * nc;      // [rec]  summed partials (N | A | I)
+    double* PI = Iv + rec;         // [D][D]
+    double* lam = PI + nI;         // [D]
+    for (int e = t; e < rec; e += 256) {
+        double acc = 0.0;
+        for (int c = 0; c < nrc; ++c) acc += part[((long)pl * nrc + c) * rec + e];   // fixed order
+        Iv[e] = acc;
+    }
+    if (t < D) {
+        const double la = md.ls[a * D + t], lb = md.ls[b * D + t];
+        lam[t] = 1.0 / (la * la) + 1.0 / (lb * lb);
+    }
+    __syncthreads();
+    for (int e = t; e < D * nc; e += 256) {
+        const int r = e / nc, c = e - r * nc;
+        G0[e] = (c < D) ? lam[r] * wk.in_s[r * D + c] + (r == c ? 1.0 : 0.0) : (c - D == r ? 1.0 : 0.0);
+    }
+    double det;
+    const double* G = gauss_jordan(G0, G1, D, nc, det);   // P = G[:, D:]
+    const double* Sbar = bars + E;
+    const double shat = (a == b) ? Sbar[a * E + a] : Sbar[a * E + b] + Sbar[b * E + a];
+    const double kappa = shat / sqrt(det);   // det(I + Lambda s) = det(s Lambda + I) = det R_ab
+    const double Nab = Iv[0];
+    const double* Av = Iv + 1;
+    const double* Im = Iv + 1 + D;
+    if (t < nI) {
+        const int r = t / D, c = t - r * D;
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k) acc = fma(G[r * nc + D + k], Im[k * D + c], acc);
+        PI[t] = acc;
+    }
+    __syncthreads();
+    double* o = out + (long)(E + pl) * (D + nI);
+    if (t < nI) {
+        const int r = t / D, c = t - r * D;
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k) acc = fma(PI[r * D + k], G[c * nc + D + k], acc);   // (P I P^T)[r][c]
+        const double pl2 = G[r * nc + D + c] * lam[c] + G[c * nc + D + r] * lam[r];     // P Lambda + Lambda P^T
+        o[D + t] = kappa * (0.5 * acc - 0.25 * Nab * pl2);
+    } else if (t < nI + D) {
+        const int r = t - nI;
+        double acc = 0.0;
+        for (int c = 0; c < D; ++c) acc = fma(G[r * nc + D + c], Av[c], acc);
+        o[r] = kappa * acc;
+    }
+}
+
+// Reverse of the mean part (mgpr.py:99-118) for output a = blockIdx.x, including the -M M^T term of S:
+// with T = (s + Lambda_a^2)^-1, l_i = beta_i exp(-zeta_i^T T zeta_i / 2), g = sum l_i, h = sum l_i zeta_i,
+// u = T Vbar_a, mu = Mbar_a - sum_b (Sbar_ab + Sbar_ba) M_b, q_i = mu + zeta_i . u:
+//   mbar_a = c (T sum l_i q_i zeta_i - g u),
+//   sbar_a = -phi T / 2 + c T (sum l_i q_i zeta_i zeta_i^T) T / 2 - c (u (T h)^T + (T h) u^T) / 2,  phi = c (mu g + Vbar_a . T h).
+// M_b is read from the mean partials the prep kernel of the same step left in wk.mean_part.  out[a][D + D*D].
+__global__ __launch_bounds__(256) void k_mm_bwd_mean(MMModel md, MMWork wk, const double* __restrict__ bars,
+                                                    double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int D = md.D, E = md.E, npad = md.npad, t = threadIdx.x, a = blockIdx.x;
+    const int nI = D * D, nc = 2 * D, LD = D | 1;
+    double* G0 = sm;                // [D][2D]
+    double* G1 = G0 + D * nc;       // [D][2D]
+    double* zs = G1 + D * nc;       // [256][LD]
+    double* lv = zs + 256 * LD;     // [256]
+    double* lq = lv + 256;          // [256]
+    double* u = lq + 256;           // [D]
+    double* Th = u + D;             // [D]
+    double* red = Th + D;           // [nI + 2 D + 1]   H2q | wq | h | g
+    double* TH = red + nI + 2 * D + 1;  // [D][D]
+    double* sc = TH + nI;           // [4] mu, c, vTh
+    const double* Mbar = bars;
+    const double* Sbar = bars + E;
+    const double* Vbar = bars + E + E * E;
+    for (int e = t; e < D * nc; e += 256) {
+        const int r = e / nc, c = e - r * nc;
+        const double l = md.ls[a * D + r];
+        G0[e] = (c < D) ? wk.in_s[r * D + c] + (r == c ? l * l : 0.0) : (c - D == r ? 1.0 : 0.0);
+    }
+    double det;
+    const double* G = gauss_jordan(G0, G1, D, nc, det);   // T = G[:, D:]
+    if (t < D) {
+        double acc = 0.0;
+        for (int c = 0; c < D; ++c) acc = fma(G[t * nc + D + c], Vbar[c * E + a], acc);
+        u[t] = acc;
+    }
+    if (t == 64) {
+        double mu = Mbar[a];
+        for (int b = 0; b < E; ++b) {
+            double Mb = 0.0;
+            for (int ch = 0; ch < wk.NCH; ++ch) Mb += wk.mean_part[((long)b * wk.NCH + ch) * (1 + D)];
+            mu -= (Sbar[a * E + b] + Sbar[b * E + a]) * Mb;
+        }
+        double lp = 1.0;
+        for (int d = 0; d < D; ++d) lp *= md.ls[a * D + d];
+        sc[0] = mu;
+        sc[1] = md.var[a] * lp / sqrt(det);
+    }
+    __syncthreads();
+    const double mu = sc[0], c_a = sc[1];
+    double acc = 0.0;
+    for (int i0 = 0; i0 < npad; i0 += 256) {
+        const int i = i0 + t;
+        double l = 0.0, q = 0.0;
+        if (i < md.n) {
+            double quad = 0.0;
+            q = mu;
+            for (int d = 0; d < D; ++d) zs[t * LD + d] = md.Pt[(long)d * npad + i] - wk.in_m[d];
+            for (int r = 0; r < D; ++r) {
+                double tz = 0.0;
+                for (int c = 0; c < D; ++c) tz = fma(G[r * nc + D + c], zs[t * LD + c], tz);
+                quad = fma(zs[t * LD + r], tz, quad);
+                q = fma(zs[t * LD + r], u[r], q);
+            }
+            l = exp(-0.5 * quad) * md.beta[(long)a * npad + i];
+        } else {
+            for (int d = 0; d < D; ++d) zs[t * LD + d] = 0.0;
+        }
+        lv[t] = l;
+        lq[t] = l * q;
+        __syncthreads();
+        if (t < nI) {
+            const int d = t / D, e2 = t - d * D;
+            for (int ii = 0; ii < 256; ++ii) acc = fma(lq[ii] * zs[ii * LD + d], zs[ii * LD + e2], acc);
+        } else if (t < nI + D) {
+            const int d = t - nI;
+            for (int ii = 0; ii < 256; ++ii) acc = fma(lq[ii], zs[ii * LD + d], acc);
+        } else if (t < nI + 2 * D) {
+            const int d = t - nI - D;
+            for (int ii = 0; ii < 256; ++ii) acc = fma(lv[ii], zs[ii * LD + d], acc);
+        } else if (t == nI + 2 * D) {
+            for (int ii = 0; ii < 256; ++ii) acc += lv[ii];
+        }
+        __syncthreads();
+    }
+    if (t <= nI + 2 * D) red[t] = acc;
+    __syncthreads();
+    const double* H2q = red;
+    const double* wq = red + nI;
+    const double* h = red + nI + D;
+    const double g = red[nI + 2 * D];
+    if (t < D) {
+        double acc2 = 0.0;
+        for (int c = 0; c < D; ++c) acc2 = fma(G[t * nc + D + c], h[c], acc2);
+        Th[t] = acc2;
+    }
+    if (t < nI) {
+        const int r = t / D, c = t - r * D;
+        double acc2 = 0.0;
+        for (int k = 0; k < D; ++k) acc2 = fma(G[r * nc + D + k], H2q[k * D + c], acc2);
+        TH[t] = acc2;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double vTh = 0.0;
+        for (int d = 0; d < D; ++d) vTh = fma(Vbar[d * E + a], Th[d], vTh);
+        sc[2] = c_a * (mu * g + vTh);
+    }
+    __syncthreads();
+    const double phi = sc[2];
+    double* o = out + (long)a * (D + nI);
+    if (t < nI) {
+        const int r = t / D, c = t - r * D;
+        double acc2 = 0.0;
+        for (int k = 0; k < D; ++k) acc2 = fma(TH[r * D + k], G[k * nc + D + c], acc2);
+        o[D + t] = -0.5 * phi * G[r * nc + D + c] + 0.5 * c_a * acc2 - 0.5 * c_a * (u[r] * Th[c] + Th[r] * u[c]);
+    } else if (t < nI + D) {
+        const int r = t - nI;
+        double tw = 0.0;
+        for (int c = 0; c < D; ++c) tw = fma(G[r * nc + D + c], wq[c], tw);
+        o[r] = c_a * (tw - g * u[r]);
+    }
+}
+
+void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* part, const double* bars,
+                   double* out) {
     const int P = wk.PL, E = md.E, D = md.D;
     const int nOP = P + (P - E);
     dim3 grid(md.npad / 64, nOP);
@@ -1041,9 +1229,16 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
         default: PB(4); break;
     }
 #undef PB
-    const size_t lds = sizeof(double) * ((size_t)3 * 64 * D + 128);
-    hipLaunchKernelGGL(k_mm_bwd_post, dim3(P), dim3(256), lds, st, md, wk, rowmom, out);
+    const int LD = D | 1, nI = D * D;
+    const size_t lds_mean = sizeof(double) * ((size_t)4 * D * D + 256 * LD + 512 + 2 * D + nI + 2 * D + 1 + nI + 4);
+    hipLaunchKernelGGL(k_mm_bwd_mean, dim3(E), dim3(256), lds_mean, st, md, wk, bars, out);
+    const int nrc = std::min(BWD_RC, md.npad / 64);
+    const size_t lds = sizeof(double) * ((size_t)3 * 64 * LD + 128);
+    hipLaunchKernelGGL(k_mm_bwd_post, dim3(P, nrc), dim3(256), lds, st, md, wk, rowmom, part, nrc);
+    const size_t lds_fin = sizeof(double) * ((size_t)4 * D * D + 1 + D + nI + nI + D);
+    hipLaunchKernelGGL(k_mm_bwd_fin, dim3(P), dim3(256), lds_fin, st, md, wk, part, nrc, bars, out);
 }
+int mm_bwd_rc(int npad) { return std::min(BWD_RC, npad / 64); }
 
 // ------------------------------------------------------------------ pair kernel, plain VALU
 // Reference implementation of the same tile sums without matrix cores: one row
