@@ -19,7 +19,7 @@ struct Slot {
     int n = 0, npad = 0;             // points the moment matching runs over (N or M) and padding
     bool has_data = false, has_hyp = false, factor_valid = false, user_factors = false, iK_null = false;
     bool ignore_iK = false;  // policy slot: RbfController evaluates with iK zeroed (controllers.py:116)
-    DevBuf bwd_mom, bwd_part, bwd_out;         // reverse-pass scratch
+    DevBuf bwd_mom, bwd_cp, bwd_part, bwd_out; // reverse-pass scratch
     DevBuf Xt, Yt, Zt, ls, var, noise;         // Yt: [E][Npad]
     DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
     DevBuf Kmn, V2, Am, AmInv, AmD, iAt, G;    // FITC extras
@@ -61,6 +61,8 @@ struct pilco_ctx {
     hipStream_t st2 = nullptr;                        // side stream of the reward kernel
     hipEvent_t ev_state = nullptr, ev_rew = nullptr;  // fork / join of the side stream
     std::vector<hipEvent_t> pair_events;
+    double* pin = nullptr;   // pinned host staging buffer of the reverse pass (truly asynchronous small copies)
+    size_t pin_cap = 0;
 };
 
 namespace {
@@ -179,7 +181,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.sk_wlo = s.d_lists;
     wk.sk_whi = s.d_lists + PLa;
     wk.sk_pidx = s.d_lists + 2 * PLa;
-    ENSURE(s.w_in, (size_t)D + D * D);
+    ENSURE(s.w_in, (size_t)D + D * D + E + E * E + D * E);   // m | s | cotangents (Mbar | Sbar | Vbar) of the reverse pass
     ENSURE(s.w_At, (size_t)PLa * wk.KP * npad);
     ENSURE(s.w_Bt, (size_t)PLa * wk.KP * npad);
     ENSURE(s.w_small, (size_t)PLa + (size_t)E * wk.NCH * (1 + D));
@@ -415,7 +417,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
         for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr,
-                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_part, &s.bwd_out, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
+                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
                           &s.w_part, &s.w_gath, &s.w_out})
             b->release();
         if (s.d_lists) (void)hipFree(s.d_lists);
@@ -433,6 +435,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (ctx->ev_rew) (void)hipEventDestroy(ctx->ev_rew);
     if (ctx->st2) (void)hipStreamDestroy(ctx->st2);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->st) (void)hipStreamDestroy(ctx->st);
     delete ctx;
     return PILCO_OK;
@@ -1316,7 +1319,7 @@ int pilco_comm_size(const pilco_ctx* ctx) { return ctx ? ctx->nranks : -1; }
 
 // Vector-Jacobian product of one moment-matching step (the reverse of pilco_gp_predict):
 // given cotangents Mbar (1,E), Sbar (E,E), Vbar (D,E) returns mbar (1,D) and the symmetric sbar (D,D).
-// Entirely on the device (k_mm_bwd_pair / _post / _fin for the pair sums, k_mm_bwd_mean for the mean part); the
+// Entirely on the device (k_mm_bwd_pair / _post / _fin; the mean part rides in extra workgroups of _post / _fin); the
 // host only sums the E + P contribution records.  Single rank, exact or sparse model, D <= 14.
 int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double* s_in, const double* Mbar,
                          const double* Sbar, const double* Vbar, double* mbar, double* sbar) {
@@ -1331,23 +1334,34 @@ int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double
     if (int r = build_work(ctx, s)) return r;
     const int P = s.wk.PL;
     // ---- device: operands (prep), reverse pair sweep, mean part, per-pair / per-output contributions
-    const int nOP = 2 * P - E, rec = D + D * D, nb = E + E * E + D * E;
-    ENSURE(s.bwd_mom, (size_t)nOP * 16 * npad);
-    ENSURE(s.bwd_part, (size_t)P * mm_bwd_rc(npad) * (1 + rec));
-    ENSURE(s.bwd_out, (size_t)(E + P) * rec + nb);
-    double* bars = s.bwd_out.p + (size_t)(E + P) * rec;
-    std::vector<double> hb(nb);
-    memcpy(hb.data(), Mbar, sizeof(double) * E);
-    memcpy(hb.data() + E, Sbar, sizeof(double) * E * E);
-    memcpy(hb.data() + E + E * E, Vbar, sizeof(double) * D * E);
-    HIPCHK(hipMemcpyAsync(s.wk.in_m, m, sizeof(double) * D, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipMemcpyAsync(s.wk.in_s, s_in, sizeof(double) * D * D, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipMemcpyAsync(bars, hb.data(), sizeof(double) * nb, hipMemcpyHostToDevice, ctx->st));
+    const int rec = D + D * D, nb = E + E * E + D * E;
+    int njs, nrb;
+    mm_bwd_geometry(npad, P, &njs, &nrb);
+    ENSURE(s.bwd_mom, (size_t)P * njs * 16 * npad);
+    ENSURE(s.bwd_cp, (size_t)std::max(1, P - E) * nrb * npad);
+    ENSURE(s.bwd_part, (size_t)(P + E) * mm_bwd_rc(npad) * (1 + rec + D));   // pair partials, then mean partials
+    ENSURE(s.bwd_out, (size_t)(E + P) * rec);
+    const size_t n_in = (size_t)D + D * D + nb, n_out = (size_t)(E + P) * rec;
+    if (ctx->pin_cap < n_in + n_out) {
+        if (ctx->pin) (void)hipHostFree(ctx->pin);
+        ctx->pin = nullptr;
+        ctx->pin_cap = 0;
+        HIPCHK(hipHostMalloc((void**)&ctx->pin, sizeof(double) * (n_in + n_out), hipHostMallocDefault));
+        ctx->pin_cap = n_in + n_out;
+    }
+    double* hin = ctx->pin;
+    const double* po = ctx->pin + n_in;
+    memcpy(hin, m, sizeof(double) * D);
+    memcpy(hin + D, s_in, sizeof(double) * D * D);
+    memcpy(hin + D + D * D, Mbar, sizeof(double) * E);
+    memcpy(hin + D + D * D + E, Sbar, sizeof(double) * E * E);
+    memcpy(hin + D + D * D + E + E * E, Vbar, sizeof(double) * D * E);
+    HIPCHK(hipMemcpyAsync(s.wk.in_m, hin, sizeof(double) * n_in, hipMemcpyHostToDevice, ctx->st));   // in_m | in_s | bars are contiguous
+    const double* bars = s.wk.in_s + D * D;
     const MMModel md = model_of(s);
     launch_mm_prep(ctx->st, md, s.wk);
-    launch_mm_bwd(ctx->st, md, s.wk, s.bwd_mom.p, s.bwd_part.p, bars, s.bwd_out.p);
-    std::vector<double> po((size_t)(E + P) * rec);
-    HIPCHK(hipMemcpyAsync(po.data(), s.bwd_out.p, sizeof(double) * po.size(), hipMemcpyDeviceToHost, ctx->st));
+    launch_mm_bwd(ctx->st, md, s.wk, s.bwd_mom.p, s.bwd_cp.p, s.bwd_part.p, bars, s.bwd_out.p);
+    HIPCHK(hipMemcpyAsync(ctx->pin + n_in, s.bwd_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());
     // ---- host: sum the E + P records in a fixed order, symmetrise

@@ -112,10 +112,12 @@ int mm_prep_nch(int npad, int PL);
 int mm_kp(int D);
 void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot);
 // reverse pass of one moment-matching step (single rank, D <= 14; the step's prep kernel must precede it on st):
-// rowmom [(2P-E)][16][npad] and part [P][mm_bwd_rc][1 + D + D*D] are scratch, bars = (Mbar | Sbar | Vbar) on the
-// device, out [E + P][D + D*D] = per output / per pair contributions (mbar | sbar), summed by the caller
-void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* part, const double* bars,
-                   double* out);
+// scratch: rowmom [P][njs][16][npad], cpart [P - E][nrb][npad] (njs, nrb from mm_bwd_geometry) and
+// part [P][mm_bwd_rc][1 + D + D*D] + [E][mm_bwd_rc][D*D + 2D + 1]; bars = (Mbar | Sbar | Vbar) on the device,
+// out [E + P][D + D*D] = per output / per pair contributions (mbar | sbar), summed by the caller
+void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* part,
+                   const double* bars, double* out);
+void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb);
 int mm_bwd_rc(int npad);
 int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf, const double* exp_tab);
 

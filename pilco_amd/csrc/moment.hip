@@ -906,81 +906,280 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
 // ------------------------------------------------------------------ adjoint of the pair sums
 // d e_ij/d m = P (z_i + w_j) and d e_ij/d s = (P y)(P y)^T / 2, so the reverse
 // pass needs, per pair, only   r_i = sum_j W_ij L_ij,   c_j = sum_i W_ij L_ij,   m_i = sum_j W_ij L_ij w_j
-// with W = beta_a beta_b^T (- iK_a on the diagonal pair).  One wave owns 16 rows and sweeps all
-// columns; the exponent tile is computed TRANSPOSED (column operand as MFMA A, row operand as B) so
+// with W = beta_a beta_b^T (- iK_a on the diagonal pair).  A wave owns 16*BWD_RT rows and sweeps a range
+// of columns; the exponent tile is computed TRANSPOSED (column operand as MFMA A, row operand as B) so
 // that the weighted tile W.L lands in the B-operand layout of a second MFMA that contracts it with
-// [w_j | 1]: moments and row sums cost 4 MFMAs per 16x16 tile and no VALU reductions.  Column sums
-// come from the same kernel run on the reversed orientation (rows from the b side).
-// rowmom[op][d][i]: orientation 0: d < D -> m_i[d], d = D -> r_i; orientation 1: d = D+1 -> c_j.
+// [w_j | 1]: moments and row sums cost 4 MFMAs per 16x16 tile and no VALU reductions.  The column sums of
+// an off-diagonal pair run along the lanes of a DPP row: four row_shr adds per result register, the four
+// waves of a workgroup keep their partial columns in separate LDS slices that are summed in a fixed order
+// (diagonal pairs: c = r by symmetry).
+// rowmom[pl][js][16][npad]: d < D -> m_i[d], d = D -> r_i, per column split js;
+// cpart[pl - E][row block][npad]: column sums over the rows of one workgroup.
+#ifndef BWD_RT
+#define BWD_RT 2
+#endif
 template <int KC>
-__global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ rowmom) {
+__global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ rowmom,
+                                                    double* __restrict__ cpart, int njs) {
     __shared__ double tab[64];
+    extern __shared__ __attribute__((aligned(16))) double csl[];   // [4][jw]
     if (threadIdx.x < 64) tab[threadIdx.x] = wk.exp_tab[threadIdx.x];
     __syncthreads();
     const int npad = md.npad, D = md.D, E = md.E;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lr = lane >> 4, lc = lane & 15;
-    const int op = blockIdx.y;
-    const int P = wk.PL;
-    const int orient = (op >= P) ? 1 : 0;
-    const int pl = orient ? (op - P + E) : op;
+    const int pl = blockIdx.y, js = blockIdx.z, rb = blockIdx.x;
     int a, b;
     local_pair_ab(wk, E, pl, a, b);
     const int KP = wk.KP;
     const double* At = wk.At + (long)pl * KP * npad;
     const double* Bt = wk.Bt + (long)pl * KP * npad;
-    const double* RowArr = orient ? Bt : At;   // operand of the rows this wave owns
-    const double* ColArr = orient ? At : Bt;   // operand of the swept columns
-    const double* beta_row = md.beta + (long)(orient ? b : a) * npad;
-    const double* beta_col = md.beta + (long)(orient ? a : b) * npad;
-    const bool diag = (a == b) && (md.iK != nullptr);
-    const double* iKa = diag ? md.iK + (long)a * npad * npad : nullptr;
-    const int i0 = blockIdx.x * 64 + w * 16;
-    double rf[KC];
+    const double* beta_a = md.beta + (long)a * npad;
+    const double* beta_b = md.beta + (long)b * npad;
+    const bool diag = (a == b);
+    const double* iKa = (diag && md.iK) ? md.iK + (long)a * npad * npad : nullptr;
+    const int jw = npad / njs, jbeg = js * jw, jend = jbeg + jw;
+    const int ibase = rb * 64 * BWD_RT + w * 16 * BWD_RT;
+    double rf[BWD_RT][KC], brow[BWD_RT];
+    int irow[BWD_RT];
 #pragma unroll
-    for (int c = 0; c < KC; ++c) rf[c] = RowArr[(long)(4 * c + lr) * npad + i0 + lc];
-    const double brow = beta_row[i0 + lc];
-    // second-product operand mask: which rows d = lc of the column operand are contracted
-    const bool dsel = orient ? (lc == D + 1) : (lc <= D);
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
-    for (int j0 = 0; j0 < npad; j0 += 16) {
-        d4 e = {0.0, 0.0, 0.0, 0.0};
+    for (int rt = 0; rt < BWD_RT; ++rt) {
+        const bool ok = ibase + 16 * rt < npad;                  // wave-uniform; rows past the padding weigh zero
+        irow[rt] = ok ? ibase + 16 * rt + lc : lc;
+        brow[rt] = ok ? beta_a[irow[rt]] : 0.0;
 #pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            const double cf = ColArr[(long)(4 * c + lr) * npad + j0 + lc];
-            e = __builtin_amdgcn_mfma_f64_16x16x4f64(cf, rf[c], e, 0, 0, 0);   // e[r]: i = i0+lc, j = j0+lr+4r
-        }
-        double wl[4];
+        for (int c = 0; c < KC; ++c) rf[rt][c] = At[(long)(4 * c + lr) * npad + irow[rt]];
+    }
+    const bool dsel = lc <= D;   // rows of the column operand contracted by the second product: w_j (d < D) and the ones
+    d4 acc[BWD_RT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = j0 + lr + 4 * r;
-            double wgt = brow * beta_col[j];
-            if (diag) wgt -= iKa[(long)j * npad + i0 + lc];   // iK is symmetric: coalesced along the rows
-            wl[r] = wgt * fexp(e[r], tab);
-        }
+    for (int rt = 0; rt < BWD_RT; ++rt) acc[rt] = d4{0.0, 0.0, 0.0, 0.0};
+    double* myslice = csl + w * jw;
+    for (int j0 = jbeg; j0 < jend; j0 += 16) {
+        double cf[KC], a2[4], bcol[4];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) cf[c] = Bt[(long)(4 * c + lr) * npad + j0 + lc];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const double a2 = dsel ? ColArr[(long)lc * npad + j0 + 4 * r + lr] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, wl[r], acc, 0, 0, 0);
+            bcol[r] = beta_b[j0 + lr + 4 * r];
+            a2[r] = dsel ? Bt[(long)lc * npad + j0 + 4 * r + lr] : 0.0;
+        }
+        double csum[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int rt = 0; rt < BWD_RT; ++rt) {
+            d4 e = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+                e = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[c], rf[rt][c], e, 0, 0, 0);   // e[r]: i = irow, j = j0+lr+4r
+            double wl[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double wgt = brow[rt] * bcol[r];
+                if (iKa) wgt -= iKa[(long)(j0 + lr + 4 * r) * npad + irow[rt]];   // iK is symmetric: coalesced along the rows
+                wl[r] = wgt * fexp(e[r], tab);
+                csum[r] += wl[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[r], wl[r], acc[rt], 0, 0, 0);
+        }
+        if (!diag) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = csum[r];
+                v = dpp_add<0x111, 0xf>(v);
+                v = dpp_add<0x112, 0xf>(v);
+                v = dpp_add<0x114, 0xf>(v);
+                v = dpp_add<0x118, 0xf>(v);   // lane 15 of every DPP row: sum over the 16 rows i
+                if (lc == 15) myslice[j0 - jbeg + lr + 4 * r] = v;
+            }
         }
     }
-    double* out = rowmom + (long)op * 16 * npad;
+    double* out = rowmom + ((long)pl * njs + js) * 16 * npad;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[(long)(lr + 4 * r) * npad + i0 + lc] = acc[r];
+    for (int rt = 0; rt < BWD_RT; ++rt)
+        if (ibase + 16 * rt < npad) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(long)(lr + 4 * r) * npad + irow[rt]] = acc[rt][r];
+        }
+    if (!diag) {
+        __syncthreads();
+        double* cp = cpart + ((long)(pl - wk.EL) * gridDim.x + rb) * npad + jbeg;
+        for (int jj = threadIdx.x; jj < jw; jj += 256)
+            cp[jj] = (csl[jj] + csl[jw + jj]) + (csl[2 * jw + jj] + csl[3 * jw + jj]);
+    }
+}
+
+// Reverse of the mean part (mgpr.py:99-118) for output a, including the -M M^T term of S:
+// with T = (s + Lambda_a^2)^-1, l_i = beta_i exp(-zeta_i^T T zeta_i / 2), g = sum l_i, h = sum l_i zeta_i,
+// u = T Vbar_a, mu = Mbar_a - sum_b (Sbar_ab + Sbar_ba) M_b, q_i = mu + zeta_i . u:
+//   mbar_a = c (T sum l_i q_i zeta_i - g u),
+//   sbar_a = -phi T / 2 + c T (sum l_i q_i zeta_i zeta_i^T) T / 2 - c (u (T h)^T + (T h) u^T) / 2,  phi = c (mu g + Vbar_a . T h).
+// M_b is read from the mean partials the prep kernel of the same step left in wk.mean_part.
+// Common head of the two stages: T (returned, [D][2D] with T in the right half), u, mu, c_a in LDS.
+__device__ const double* bwd_mean_head(const MMModel& md, const MMWork& wk, const double* __restrict__ bars, int a,
+                                       double* G0, double* G1, double* u, double* sc) {
+    const int D = md.D, E = md.E, t = threadIdx.x, nc = 2 * D;
+    const double* Mbar = bars;
+    const double* Sbar = bars + E;
+    const double* Vbar = bars + E + E * E;
+    for (int e = t; e < D * nc; e += 256) {
+        const int r = e / nc, c = e - r * nc;
+        const double l = md.ls[a * D + r];
+        G0[e] = (c < D) ? wk.in_s[r * D + c] + (r == c ? l * l : 0.0) : (c - D == r ? 1.0 : 0.0);
+    }
+    double det;
+    const double* G = gauss_jordan(G0, G1, D, nc, det);   // T = G[:, D:]
+    if (t < D) {
+        double acc = 0.0;
+        for (int c = 0; c < D; ++c) acc = fma(G[t * nc + D + c], Vbar[c * E + a], acc);
+        u[t] = acc;
+    }
+    if (t == 64) {
+        double mu = Mbar[a];
+        for (int b = 0; b < E; ++b) {
+            double Mb = 0.0;
+            for (int ch = 0; ch < wk.NCH; ++ch) Mb += wk.mean_part[((long)b * wk.NCH + ch) * (1 + D)];
+            mu -= (Sbar[a * E + b] + Sbar[b * E + a]) * Mb;
+        }
+        double lp = 1.0;
+        for (int d = 0; d < D; ++d) lp *= md.ls[a * D + d];
+        sc[0] = mu;
+        sc[1] = md.var[a] * lp / sqrt(det);
+    }
+    __syncthreads();
+    return G;
+}
+
+// stage 1 (a workgroup of k_mm_bwd_post): sums over the 64-point blocks rc, rc + nrc, ..:  mpart[a][rc][D*D + 2D + 1]
+__device__ void bwd_mean_partial(const MMModel& md, const MMWork& wk, const double* __restrict__ bars, int a, int rc,
+                                 int nrc, double* __restrict__ mpart, double* sm) {
+    const int D = md.D, npad = md.npad, t = threadIdx.x;
+    const int nI = D * D, nc = 2 * D, LD = D | 1;
+    double* G0 = sm;                // [D][2D]
+    double* G1 = G0 + D * nc;       // [D][2D]
+    double* zs = G1 + D * nc;       // [64][LD]
+    double* lv = zs + 64 * LD;      // [64]
+    double* lq = lv + 64;           // [64]
+    double* u = lq + 64;            // [D]
+    double* sc = u + D;             // [2]
+    const double* G = bwd_mean_head(md, wk, bars, a, G0, G1, u, sc);
+    const double mu = sc[0];
+    double acc = 0.0;
+    for (int blk = rc; blk < npad / 64; blk += nrc) {
+        if (t < 64) {
+            const int i = blk * 64 + t;
+            double l = 0.0, q = 0.0;
+            if (i < md.n) {
+                double quad = 0.0;
+                q = mu;
+                for (int d = 0; d < D; ++d) zs[t * LD + d] = md.Pt[(long)d * npad + i] - wk.in_m[d];
+                for (int r = 0; r < D; ++r) {
+                    double tz = 0.0;
+                    for (int c = 0; c < D; ++c) tz = fma(G[r * nc + D + c], zs[t * LD + c], tz);
+                    quad = fma(zs[t * LD + r], tz, quad);
+                    q = fma(zs[t * LD + r], u[r], q);
+                }
+                l = exp(-0.5 * quad) * md.beta[(long)a * npad + i];
+            } else {
+                for (int d = 0; d < D; ++d) zs[t * LD + d] = 0.0;
+            }
+            lv[t] = l;
+            lq[t] = l * q;
+        }
+        __syncthreads();
+        if (t < nI) {
+            const int d = t / D, e2 = t - d * D;
+            for (int ii = 0; ii < 64; ++ii) acc = fma(lq[ii] * zs[ii * LD + d], zs[ii * LD + e2], acc);
+        } else if (t < nI + D) {
+            const int d = t - nI;
+            for (int ii = 0; ii < 64; ++ii) acc = fma(lq[ii], zs[ii * LD + d], acc);
+        } else if (t < nI + 2 * D) {
+            const int d = t - nI - D;
+            for (int ii = 0; ii < 64; ++ii) acc = fma(lv[ii], zs[ii * LD + d], acc);
+        } else if (t == nI + 2 * D) {
+            for (int ii = 0; ii < 64; ++ii) acc += lv[ii];
+        }
+        __syncthreads();
+    }
+    if (t <= nI + 2 * D) mpart[((long)a * nrc + rc) * (nI + 2 * D + 1) + t] = acc;
+}
+
+// stage 2 (a workgroup of k_mm_bwd_fin): out[a][D + D*D]
+__device__ void bwd_mean_final(const MMModel& md, const MMWork& wk, const double* __restrict__ bars, int a, int nrc,
+                               const double* __restrict__ mpart, double* __restrict__ out, double* sm) {
+    const int D = md.D, E = md.E, t = threadIdx.x;
+    const int nI = D * D, nc = 2 * D;
+    double* G0 = sm;                // [D][2D]
+    double* G1 = G0 + D * nc;       // [D][2D]
+    double* u = G1 + D * nc;        // [D]
+    double* sc = u + D;             // [4]  mu, c_a, phi
+    double* Th = sc + 4;            // [D]
+    double* red = Th + D;           // [nI + 2 D + 1]   H2q | wq | h | g
+    double* TH = red + nI + 2 * D + 1;  // [D][D]
+    const double* Vbar = bars + E + E * E;
+    const double* G = bwd_mean_head(md, wk, bars, a, G0, G1, u, sc);
+    const double mu = sc[0], c_a = sc[1];
+    if (t <= nI + 2 * D) {
+        double acc = 0.0;
+        for (int c = 0; c < nrc; ++c) acc += mpart[((long)a * nrc + c) * (nI + 2 * D + 1) + t];   // fixed order
+        red[t] = acc;
+    }
+    __syncthreads();
+    const double* H2q = red;
+    const double* wq = red + nI;
+    const double* h = red + nI + D;
+    const double g = red[nI + 2 * D];
+    if (t < D) {
+        double acc2 = 0.0;
+        for (int c = 0; c < D; ++c) acc2 = fma(G[t * nc + D + c], h[c], acc2);
+        Th[t] = acc2;
+    }
+    if (t < nI) {
+        const int r = t / D, c = t - r * D;
+        double acc2 = 0.0;
+        for (int k = 0; k < D; ++k) acc2 = fma(G[r * nc + D + k], H2q[k * D + c], acc2);
+        TH[t] = acc2;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double vTh = 0.0;
+        for (int d = 0; d < D; ++d) vTh = fma(Vbar[d * E + a], Th[d], vTh);
+        sc[2] = c_a * (mu * g + vTh);
+    }
+    __syncthreads();
+    const double phi = sc[2];
+    double* o = out + (long)a * (D + nI);
+    if (t < nI) {
+        const int r = t / D, c = t - r * D;
+        double acc2 = 0.0;
+        for (int k = 0; k < D; ++k) acc2 = fma(TH[r * D + k], G[k * nc + D + c], acc2);
+        o[D + t] = -0.5 * phi * G[r * nc + D + c] + 0.5 * c_a * acc2 - 0.5 * c_a * (u[r] * Th[c] + Th[r] * u[c]);
+    } else if (t < nI + D) {
+        const int r = t - nI;
+        double tw = 0.0;
+        for (int c = 0; c < D; ++c) tw = fma(G[r * nc + D + c], wq[c], tw);
+        o[r] = c_a * (tw - g * u[r]);
+    }
 }
 
 // Per unordered pair and row chunk: partial sums of  N_ab = sum_i r_i,  A = sum_i (r_i z_i + c_i w_i)  (D),
 // I = sum_i (r_i z_i z_i^T + c_i w_i w_i^T + z_i m_i^T + m_i z_i^T)  (D x D).   part[pl][chunk][1 + D + D*D]
-constexpr int BWD_RC = 8;  // row chunks per pair (npad / 64 is a multiple of it or smaller)
+constexpr int BWD_RC = 16;  // row chunks per pair / output
 __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, const double* __restrict__ rowmom,
-                                                    double* __restrict__ part, int nrc) {
+                                                    const double* __restrict__ cpart, int njs, int nrb,
+                                                    double* __restrict__ part, int nrc,
+                                                    const double* __restrict__ bars, double* __restrict__ mpart) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int npad = md.npad, D = md.D, E = md.E, t = threadIdx.x;
-    const int pl = blockIdx.x, P = wk.PL, rc = blockIdx.y;
+    const int pl = blockIdx.x, rc = blockIdx.y;
+    if (pl >= wk.PL) {   // the last E workgroup columns: mean part of output pl - PL
+        bwd_mean_partial(md, wk, bars, pl - wk.PL, rc, nrc, mpart, sm);
+        return;
+    }
     int a, b;
     local_pair_ab(wk, E, pl, a, b);
-    const double* mom0 = rowmom + (long)pl * 16 * npad;
-    const double* mom1 = (a != b) ? rowmom + (long)(P + pl - E) * 16 * npad : nullptr;
+    const double* mom0 = rowmom + (long)pl * njs * 16 * npad;
+    const double* cp = (a != b) ? cpart + (long)(pl - wk.EL) * nrb * npad : nullptr;
     const int LD = D | 1;         // odd row stride: the (d, e) readers of one point spread over the banks
     double* zs = sm;              // [64][LD]
     double* ws = zs + 64 * LD;    // [64][LD]
@@ -1001,14 +1200,24 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
             const double la = md.ls[a * D + d], lb = md.ls[b * D + d];
             zs[ii * LD + d] = zeta / (la * la);
             ws[ii * LD + d] = zeta / (lb * lb);
-            ms[ii * LD + d] = valid ? mom0[(long)d * npad + i] : 0.0;
+            double mv = 0.0;
+            if (valid)
+                for (int q = 0; q < njs; ++q) mv += mom0[((long)q * 16 + d) * npad + i];
+            ms[ii * LD + d] = mv;
         }
         if (t < 64) {
             const int i = i0 + t;
             const bool valid = i < md.n;
-            const double r = valid ? mom0[(long)D * npad + i] : 0.0;
+            double r = 0.0, c = 0.0;
+            if (valid) {
+                for (int q = 0; q < njs; ++q) r += mom0[((long)q * 16 + D) * npad + i];
+                if (cp)
+                    for (int q = 0; q < nrb; ++q) c += cp[(long)q * npad + i];
+                else
+                    c = r;
+            }
             rs[t] = r;
-            cs[t] = valid ? (mom1 ? mom1[(long)(D + 1) * npad + i] : r) : 0.0;
+            cs[t] = c;
         }
         __syncthreads();
         if (t < nI) {
@@ -1037,9 +1246,14 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
 //   mbar += kappa P A,   sbar += kappa (P I P^T / 2 - N (P Lambda + Lambda P^T) / 4)      
 // out[E + pl][D + D*D].  bars = (Mbar [E] | Sbar [E][E] | Vbar [D][E]) on the device.
 __global__ __launch_bounds__(256) void k_mm_bwd_fin(MMModel md, MMWork wk, const double* __restrict__ part, int nrc,
-                                                   const double* __restrict__ bars, double* __restrict__ out) {
+                                                   const double* __restrict__ bars, const double* __restrict__ mpart,
+                                                   double* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x;
+    if (pl >= wk.PL) {
+        bwd_mean_final(md, wk, bars, pl - wk.PL, nrc, mpart, out, sm);
+        return;
+    }
     int a, b;
     local_pair_ab(wk, E, pl, a, b);
     const int nI = D * D, rec = 1 + D + nI, nc = 2 * D;
@@ -1092,136 +1306,21 @@ __global__ __launch_bounds__(256) void k_mm_bwd_fin(MMModel md, MMWork wk, const
     }
 }
 
-// Reverse of the mean part (mgpr.py:99-118) for output a = blockIdx.x, including the -M M^T term of S:
-// with T = (s + Lambda_a^2)^-1, l_i = beta_i exp(-zeta_i^T T zeta_i / 2), g = sum l_i, h = sum l_i zeta_i,
-// u = T Vbar_a, mu = Mbar_a - sum_b (Sbar_ab + Sbar_ba) M_b, q_i = mu + zeta_i . u:
-//   mbar_a = c (T sum l_i q_i zeta_i - g u),
-//   sbar_a = -phi T / 2 + c T (sum l_i q_i zeta_i zeta_i^T) T / 2 - c (u (T h)^T + (T h) u^T) / 2,  phi = c (mu g + Vbar_a . T h).
-// M_b is read from the mean partials the prep kernel of the same step left in wk.mean_part.  out[a][D + D*D].
-__global__ __launch_bounds__(256) void k_mm_bwd_mean(MMModel md, MMWork wk, const double* __restrict__ bars,
-                                                    double* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int D = md.D, E = md.E, npad = md.npad, t = threadIdx.x, a = blockIdx.x;
-    const int nI = D * D, nc = 2 * D, LD = D | 1;
-    double* G0 = sm;                // [D][2D]
-    double* G1 = G0 + D * nc;       // [D][2D]
-    double* zs = G1 + D * nc;       // [256][LD]
-    double* lv = zs + 256 * LD;     // [256]
-    double* lq = lv + 256;          // [256]
-    double* u = lq + 256;           // [D]
-    double* Th = u + D;             // [D]
-    double* red = Th + D;           // [nI + 2 D + 1]   H2q | wq | h | g
-    double* TH = red + nI + 2 * D + 1;  // [D][D]
-    double* sc = TH + nI;           // [4] mu, c, vTh
-    const double* Mbar = bars;
-    const double* Sbar = bars + E;
-    const double* Vbar = bars + E + E * E;
-    for (int e = t; e < D * nc; e += 256) {
-        const int r = e / nc, c = e - r * nc;
-        const double l = md.ls[a * D + r];
-        G0[e] = (c < D) ? wk.in_s[r * D + c] + (r == c ? l * l : 0.0) : (c - D == r ? 1.0 : 0.0);
-    }
-    double det;
-    const double* G = gauss_jordan(G0, G1, D, nc, det);   // T = G[:, D:]
-    if (t < D) {
-        double acc = 0.0;
-        for (int c = 0; c < D; ++c) acc = fma(G[t * nc + D + c], Vbar[c * E + a], acc);
-        u[t] = acc;
-    }
-    if (t == 64) {
-        double mu = Mbar[a];
-        for (int b = 0; b < E; ++b) {
-            double Mb = 0.0;
-            for (int ch = 0; ch < wk.NCH; ++ch) Mb += wk.mean_part[((long)b * wk.NCH + ch) * (1 + D)];
-            mu -= (Sbar[a * E + b] + Sbar[b * E + a]) * Mb;
-        }
-        double lp = 1.0;
-        for (int d = 0; d < D; ++d) lp *= md.ls[a * D + d];
-        sc[0] = mu;
-        sc[1] = md.var[a] * lp / sqrt(det);
-    }
-    __syncthreads();
-    const double mu = sc[0], c_a = sc[1];
-    double acc = 0.0;
-    for (int i0 = 0; i0 < npad; i0 += 256) {
-        const int i = i0 + t;
-        double l = 0.0, q = 0.0;
-        if (i < md.n) {
-            double quad = 0.0;
-            q = mu;
-            for (int d = 0; d < D; ++d) zs[t * LD + d] = md.Pt[(long)d * npad + i] - wk.in_m[d];
-            for (int r = 0; r < D; ++r) {
-                double tz = 0.0;
-                for (int c = 0; c < D; ++c) tz = fma(G[r * nc + D + c], zs[t * LD + c], tz);
-                quad = fma(zs[t * LD + r], tz, quad);
-                q = fma(zs[t * LD + r], u[r], q);
-            }
-            l = exp(-0.5 * quad) * md.beta[(long)a * npad + i];
-        } else {
-            for (int d = 0; d < D; ++d) zs[t * LD + d] = 0.0;
-        }
-        lv[t] = l;
-        lq[t] = l * q;
-        __syncthreads();
-        if (t < nI) {
-            const int d = t / D, e2 = t - d * D;
-            for (int ii = 0; ii < 256; ++ii) acc = fma(lq[ii] * zs[ii * LD + d], zs[ii * LD + e2], acc);
-        } else if (t < nI + D) {
-            const int d = t - nI;
-            for (int ii = 0; ii < 256; ++ii) acc = fma(lq[ii], zs[ii * LD + d], acc);
-        } else if (t < nI + 2 * D) {
-            const int d = t - nI - D;
-            for (int ii = 0; ii < 256; ++ii) acc = fma(lv[ii], zs[ii * LD + d], acc);
-        } else if (t == nI + 2 * D) {
-            for (int ii = 0; ii < 256; ++ii) acc += lv[ii];
-        }
-        __syncthreads();
-    }
-    if (t <= nI + 2 * D) red[t] = acc;
-    __syncthreads();
-    const double* H2q = red;
-    const double* wq = red + nI;
-    const double* h = red + nI + D;
-    const double g = red[nI + 2 * D];
-    if (t < D) {
-        double acc2 = 0.0;
-        for (int c = 0; c < D; ++c) acc2 = fma(G[t * nc + D + c], h[c], acc2);
-        Th[t] = acc2;
-    }
-    if (t < nI) {
-        const int r = t / D, c = t - r * D;
-        double acc2 = 0.0;
-        for (int k = 0; k < D; ++k) acc2 = fma(G[r * nc + D + k], H2q[k * D + c], acc2);
-        TH[t] = acc2;
-    }
-    __syncthreads();
-    if (t == 0) {
-        double vTh = 0.0;
-        for (int d = 0; d < D; ++d) vTh = fma(Vbar[d * E + a], Th[d], vTh);
-        sc[2] = c_a * (mu * g + vTh);
-    }
-    __syncthreads();
-    const double phi = sc[2];
-    double* o = out + (long)a * (D + nI);
-    if (t < nI) {
-        const int r = t / D, c = t - r * D;
-        double acc2 = 0.0;
-        for (int k = 0; k < D; ++k) acc2 = fma(TH[r * D + k], G[k * nc + D + c], acc2);
-        o[D + t] = -0.5 * phi * G[r * nc + D + c] + 0.5 * c_a * acc2 - 0.5 * c_a * (u[r] * Th[c] + Th[r] * u[c]);
-    } else if (t < nI + D) {
-        const int r = t - nI;
-        double tw = 0.0;
-        for (int c = 0; c < D; ++c) tw = fma(G[r * nc + D + c], wq[c], tw);
-        o[r] = c_a * (tw - g * u[r]);
-    }
+void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb) {
+    *nrb = (npad + 64 * BWD_RT - 1) / (64 * BWD_RT);
+    int q = 1;   // column splits: enough workgroups for a few balanced rounds of the chip
+    while (q < 4 && (npad / 16) % (2 * q) == 0 && (long)*nrb * PL * q < 1536) q *= 2;
+    *njs = q;
 }
 
-void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* part, const double* bars,
-                   double* out) {
+void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* part,
+                   const double* bars, double* out) {
     const int P = wk.PL, E = md.E, D = md.D;
-    const int nOP = P + (P - E);
-    dim3 grid(md.npad / 64, nOP);
-#define PB(K_) hipLaunchKernelGGL((k_mm_bwd_pair<K_>), grid, dim3(256), 0, st, md, wk, rowmom)
+    int njs, nrb;
+    mm_bwd_geometry(md.npad, P, &njs, &nrb);
+    dim3 grid(nrb, P, njs);
+    const size_t lds_pair = sizeof(double) * 4 * (md.npad / njs);
+#define PB(K_) hipLaunchKernelGGL((k_mm_bwd_pair<K_>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs)
     switch (wk.KP / 4) {
         case 1: PB(1); break;
         case 2: PB(2); break;
@@ -1230,13 +1329,14 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
     }
 #undef PB
     const int LD = D | 1, nI = D * D;
-    const size_t lds_mean = sizeof(double) * ((size_t)4 * D * D + 256 * LD + 512 + 2 * D + nI + 2 * D + 1 + nI + 4);
-    hipLaunchKernelGGL(k_mm_bwd_mean, dim3(E), dim3(256), lds_mean, st, md, wk, bars, out);
-    const int nrc = std::min(BWD_RC, md.npad / 64);
-    const size_t lds = sizeof(double) * ((size_t)3 * 64 * LD + 128);
-    hipLaunchKernelGGL(k_mm_bwd_post, dim3(P, nrc), dim3(256), lds, st, md, wk, rowmom, part, nrc);
-    const size_t lds_fin = sizeof(double) * ((size_t)4 * D * D + 1 + D + nI + nI + D);
-    hipLaunchKernelGGL(k_mm_bwd_fin, dim3(P), dim3(256), lds_fin, st, md, wk, part, nrc, bars, out);
+    const int nrc = mm_bwd_rc(md.npad);
+    double* mpart = part + (size_t)P * nrc * (1 + D + nI);
+    const size_t lds_post = sizeof(double) * std::max((size_t)3 * 64 * LD + 128, (size_t)4 * D * D + 64 * LD + 128 + D + 2);
+    hipLaunchKernelGGL(k_mm_bwd_post, dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
+                       bars, mpart);
+    const size_t lds_fin = sizeof(double) * std::max((size_t)4 * D * D + 1 + D + nI + nI + D,
+                                                     (size_t)4 * D * D + D + 4 + D + nI + 2 * D + 1 + nI);
+    hipLaunchKernelGGL(k_mm_bwd_fin, dim3(P + E), dim3(256), lds_fin, st, md, wk, part, nrc, bars, mpart, out);
 }
 int mm_bwd_rc(int npad) { return std::min(BWD_RC, npad / 64); }
 
