@@ -168,70 +168,87 @@ void launch_gemm(hipStream_t st, const GemmDesc& g, bool ta, bool tb, int batch)
 }
 
 // ------------------------------------------------------------------ Cholesky
-// Factor the kb-th 64x64 diagonal block in LDS (unblocked, 2 barriers per
-// column), write L_kk back, and invert it (one wave, one column per lane).
+// Factor the kb-th 64x64 diagonal block and invert the factor, ONE wave per matrix with the block in
+// registers: lane i holds row i.  Column j: the pivot comes from lane j by v_readlane, the scaled column is
+// published through a 64-double LDS line that every lane reads back as broadcasts, and the trailing update
+// is 63-j independent FMAs per lane -- no workgroup barriers, no LDS-resident matrix on the critical path.
+// L^-1: lane j solves column j by forward substitution against broadcast rows of L (four partial sums).
 // replaces tf.linalg.cholesky at pilco/models/mgpr.py:84 / smgpr.py:29,35
-__global__ __launch_bounds__(256) void k_potf2_inv(double* __restrict__ Aall, int npad, int kb,
-                                                   double* __restrict__ invD, int* __restrict__ info) {
-    __shared__ double Ls[64][65];
-    __shared__ double Xs[64][65];
+__device__ __forceinline__ double rsqrt_f64(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    y = fma(y, fma(-0.5 * d * y, y, 0.5), y);
+    y = fma(y, fma(-0.5 * d * y, y, 0.5), y);
+    return y;
+}
+__global__ __launch_bounds__(64) void k_potf2_inv(double* __restrict__ Aall, int npad, int kb,
+                                                  double* __restrict__ invD, int* __restrict__ info) {
+    constexpr int LD = 66;   // 16-byte aligned rows, lanes of a column spread over the banks
+    __shared__ __attribute__((aligned(16))) double Ls[64 * LD];
+    __shared__ __attribute__((aligned(16))) double col[64];
+    __shared__ double rd[64];
     const int b = blockIdx.x;
     const int nblk = npad / 64;
     double* A = Aall + (long)b * npad * npad + (long)kb * 64 * npad + kb * 64;
-    const int t = threadIdx.x;
-    for (int e = t; e < 4096; e += 256) {
-        const int i = e >> 6, j = e & 63;
-        Ls[i][j] = A[(long)i * npad + j];
-    }
-    const int ri = t >> 2, cq = t & 3;
+    const int lane = threadIdx.x;
+    for (int r = 0; r < 64; ++r) Ls[r * LD + lane] = A[(long)r * npad + lane];
+    __syncthreads();
+    double a[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) a[c] = Ls[lane * LD + c];
+    int bad = 0;
+#pragma unroll
     for (int j = 0; j < 64; ++j) {
-        __syncthreads();
-        double d = Ls[j][j];
+        double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[j]), j),
+                                    __builtin_amdgcn_readlane(__double2loint(a[j]), j));
         if (!(d > 0.0)) {  // also catches NaN
-            if (t == 0) atomicCAS(&info[b], 0, kb * 64 + j + 1);
+            if (bad == 0) bad = kb * 64 + j + 1;
             d = 1.0;
         }
-        const double rinv = 1.0 / sqrt(d);
-        // trailing update of row ri: columns c in (j, ri]
-        if (ri > j) {
-            const double lij = Ls[ri][j] * rinv;
-            for (int c = j + 1 + cq; c <= ri; c += 4) Ls[ri][c] = fma(-lij, Ls[c][j] * rinv, Ls[ri][c]);
-        }
-        __syncthreads();
-        if (t < 64 && t >= j) Ls[t][j] = (t == j) ? d * rinv : Ls[t][j] * rinv;
-    }
-    __syncthreads();
-    for (int e = t; e < 4096; e += 256) {
-        const int i = e >> 6, j = e & 63;
-        A[(long)i * npad + j] = (j <= i) ? Ls[i][j] : 0.0;
-    }
-    // inverse of the lower-triangular block: lane j solves column j by forward substitution
-    if (t < 64) {
-        const int j = t;
-        for (int i = 0; i < 64; ++i) {
-            double x;
-            if (i < j) {
-                x = 0.0;
-            } else if (i == j) {
-                x = 1.0 / Ls[j][j];
-            } else {
-                double sum = 0.0;
-                for (int k = j; k < i; ++k) sum = fma(Ls[i][k], Xs[k][j], sum);
-                x = -sum / Ls[i][i];
-            }
-            Xs[i][j] = x;
+        const double rinv = rsqrt_f64(d);
+        const double l = a[j] * rinv;   // lane i >= j: L[i][j]; lane j: sqrt(d)
+        a[j] = l;
+        if (j < 63) {
+            col[lane] = l;
+            __syncthreads();
+#pragma unroll
+            for (int c = j + 1; c < 64; ++c) a[c] = fma(-l, col[c], a[c]);
         }
     }
+    if (bad && lane == 0) atomicCAS(&info[b], 0, bad);
     __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 64; ++c) Ls[lane * LD + c] = (c <= lane) ? a[c] : 0.0;
+    __syncthreads();
+    rd[lane] = 1.0 / Ls[lane * LD + lane];
+    __syncthreads();
+    for (int r = 0; r < 64; ++r) A[(long)r * npad + lane] = Ls[r * LD + lane];
+    // inverse of the lower-triangular block: lane j owns column j
+    double x[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int k = 0; k + 3 < i; k += 4) {
+            s0 = fma(Ls[i * LD + k], x[k], s0);
+            s1 = fma(Ls[i * LD + k + 1], x[k + 1], s1);
+            s2 = fma(Ls[i * LD + k + 2], x[k + 2], s2);
+            s3 = fma(Ls[i * LD + k + 3], x[k + 3], s3);
+        }
+#pragma unroll
+        for (int k = i & ~3; k < i; ++k) s0 = fma(Ls[i * LD + k], x[k], s0);
+        const double rhs = (i == lane ? 1.0 : 0.0) - ((s0 + s1) + (s2 + s3));
+        x[i] = rhs * rd[i];
+    }
     double* out = invD + ((long)b * nblk + kb) * 4096;
-    for (int e = t; e < 4096; e += 256) out[e] = Xs[e >> 6][e & 63];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) out[i * 64 + lane] = x[i];
 }
 
 void launch_potrf(hipStream_t st, double* A, int npad, int batch, double* invD, int* info) {
     const int nblk = npad / 64;
     const long sA = (long)npad * npad;
     for (int kb = 0; kb < nblk; ++kb) {
-        hipLaunchKernelGGL(k_potf2_inv, dim3(batch), dim3(256), 0, st, A, npad, kb, invD, info);
+        hipLaunchKernelGGL(k_potf2_inv, dim3(batch), dim3(64), 0, st, A, npad, kb, invD, info);
         const int rem = nblk - kb - 1;
         if (rem <= 0) break;
         double* panel = A + (long)(kb + 1) * 64 * npad + kb * 64;
