@@ -334,13 +334,12 @@ int factorize_exact(pilco_ctx* ctx, Slot& s) {
     ENSURE(s.iK, E * mat);
     ENSURE(s.invD, (size_t)E * nblk * NB * NB);
     ENSURE(s.beta, (size_t)E * npad);
-    ENSURE(s.Tscr, (size_t)E * NB * npad);
     ENSURE(s.vec, (size_t)E * npad);
     hipStream_t st = ctx->st;
     HIPCHK(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * 64, st));
     launch_gram(st, s.Xt.p, npad, s.N, s.Xt.p, npad, s.N, s.D, s.ls.p, s.var.p, E, s.K.p, npad, npad, 1, s.noise.p, 0.0);
     launch_potrf(st, s.K.p, npad, E, s.invD.p, ctx->d_info);
-    launch_trtri(st, s.K.p, npad, E, s.invD.p, s.Linv.p, s.Tscr.p);
+    launch_trtri(st, s.K.p, npad, E, s.invD.p, s.Linv.p, s.iK.p, (long)mat);   // iK is free until the next GEMM
     GemmDesc g{};
     g.A = s.Linv.p; g.lda = npad; g.sA = (long)mat;
     g.B = s.Linv.p; g.ldb = npad; g.sB = (long)mat;
@@ -1425,7 +1424,7 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     ENSURE(s.iAt, E * mm);
     ENSURE(s.G, (size_t)E * Np);
     ENSURE(s.beta, (size_t)E * Mp);
-    ENSURE(s.Tscr, (size_t)E * NB * Mp);
+    ENSURE(s.Tscr, (size_t)E * Mp * Mp);
     ENSURE(s.vec, (size_t)E * std::max(Mp, Np) * 2);
     hipStream_t st = ctx->st;
     HIPCHK(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * 64, st));
@@ -1433,7 +1432,7 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     launch_gram(st, s.Zt.p, Mp, s.M, s.Zt.p, Mp, s.M, s.D, s.ls.p, s.var.p, E, s.K.p, Mp, Mp, 2, nullptr, 1e-6);
     launch_gram(st, s.Zt.p, Mp, s.M, s.Xt.p, Np, s.N, s.D, s.ls.p, s.var.p, E, s.Kmn.p, Mp, Np, 0, nullptr, 0.0);
     launch_potrf(st, s.K.p, Mp, E, s.invD.p, ctx->d_info);                      // smgpr.py:29
-    launch_trtri(st, s.K.p, Mp, E, s.invD.p, s.Linv.p, s.Tscr.p);
+    launch_trtri(st, s.K.p, Mp, E, s.invD.p, s.Linv.p, s.Tscr.p, (long)Mp * Mp);
     GemmDesc g{};
     // V = L^{-1} Kmn  (smgpr.py:30) -- out of place into vec? Kmn is (Mp, Np): use iAt-sized scratch is too small, so
     // write V into a second Kmn-sized buffer: reuse s.Am? no (Mp x Mp).  V goes to s.Kmn2 = s.vec is too small -> allocate.
@@ -1455,7 +1454,7 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     launch_gemm(st, g, false, true, E);
     launch_add_diag(st, s.Am.p, Mp, E, s.noise.p);
     launch_potrf(st, s.Am.p, Mp, E, s.AmD.p, ctx->d_info + 32);
-    launch_trtri(st, s.Am.p, Mp, E, s.AmD.p, s.AmInv.p, s.Tscr.p);
+    launch_trtri(st, s.Am.p, Mp, E, s.AmD.p, s.AmInv.p, s.Tscr.p, (long)Mp * Mp);
     // iAt = (L Am)^{-1} = Am^{-1} L^{-1}  (smgpr.py:36-37)
     g = GemmDesc{};
     g.A = s.AmInv.p; g.lda = Mp; g.sA = (long)mm;

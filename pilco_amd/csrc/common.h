@@ -47,6 +47,10 @@ struct GemmDesc {
     const double* alpha_vec;  // optional per-batch multiplier of alpha (device), or nullptr
     int tile_mode;      // 0 all tiles, 1 only tiles with row-block >= col-block
     int k_mode;         // 0 full K; 1: k >= max(i0,j0); 2: k >= j0; 3: k < i0+64 (A lower triangular); 4: j0 <= k < i0+64
+    // optional second batch level: batch index z -> matrix z / nsub, sub-problem z % nsub (nsub = 0: off)
+    int nsub;
+    long ssA, ssB, ssC; // sub-problem strides (doubles)
+    int sub_rows0, sub_rows_step;  // sub-problem q only has rows < sub_rows0 - q * sub_rows_step (row tiles past that are skipped)
 };
 // C = alpha * op(A) op(B) + beta * C, batched; op selected by ta/tb (0 = as stored, 1 = transposed)
 void launch_gemm(hipStream_t st, const GemmDesc& g, bool ta, bool tb, int batch);
@@ -62,8 +66,9 @@ void launch_gram(hipStream_t st, const double* P1t, int ld1, int n1, const doubl
 // invD receives the inverses of the diagonal 64x64 blocks of L: [batch][npad/64][64][64].
 // info[b] = 0 or 1-based index of the first non-positive pivot.
 void launch_potrf(hipStream_t st, double* A, int npad, int batch, double* invD, int* info);
-// Linv = L^{-1} (lower), using invD from launch_potrf; T is scratch [batch][64][npad].
-void launch_trtri(hipStream_t st, const double* L, int npad, int batch, const double* invD, double* Linv, double* T);
+// Linv = L^{-1} (lower), using invD from launch_potrf; T is scratch, batch matrices of tstride >= npad*npad/2 doubles.
+void launch_trtri(hipStream_t st, const double* L, int npad, int batch, const double* invD, double* Linv, double* T,
+                  long tstride);
 // y = op(A) x, A [batch][npad][npad], x,y [batch][npad]
 void launch_matvec(hipStream_t st, const double* A, int npad, int batch, const double* x, double* y, bool trans);
 // zero rows/cols >= n of batch square matrices

@@ -81,9 +81,15 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
     kbeg &= ~15;
     __shared__ double As[16][LDS_LD];
     __shared__ double Bs[16][LDS_LD];
-    const double* A = g.A + (long)bz * g.sA;
-    const double* B = g.B + (long)bz * g.sB;
-    double* C = g.C + (long)bz * g.sC;
+    int mat = bz, sub = 0;
+    if (g.nsub > 0) {
+        mat = bz / g.nsub;
+        sub = bz - mat * g.nsub;
+        if (i0 >= g.sub_rows0 - sub * g.sub_rows_step) return;
+    }
+    const double* A = g.A + (long)mat * g.sA + (long)sub * g.ssA;
+    const double* B = g.B + (long)mat * g.sB + (long)sub * g.ssB;
+    double* C = g.C + (long)mat * g.sC + (long)sub * g.ssC;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wi = (w >> 1) * 32, wj = (w & 1) * 32;
     const int lr = lane >> 4, lc = lane & 15;
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
                 const int row = i0 + wi + 16 * ti + lr + 4 * r;
                 const int col = j0 + wj + 16 * tj + lc;
                 double* c = C + (long)row * g.ldc + col;
-                double v = g.alpha * (g.alpha_vec ? g.alpha_vec[bz] : 1.0) * acc[ti][tj][r];
+                double v = g.alpha * (g.alpha_vec ? g.alpha_vec[mat] : 1.0) * acc[ti][tj][r];
                 if (g.beta != 0.0) v = fma(g.beta, *c, v);
                 *c = v;
             }
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
 
 void launch_gemm(hipStream_t st, const GemmDesc& g, bool ta, bool tb, int batch) {
     if (g.M <= 0 || g.N <= 0) return;
-    dim3 grid(g.N / 64, g.M / 64, batch);
+    dim3 grid(g.N / 64, g.M / 64, batch * (g.nsub > 0 ? g.nsub : 1));
     if (!ta && !tb) hipLaunchKernelGGL((k_gemm64<false, false>), grid, dim3(256), 0, st, g);
     if (!ta && tb) hipLaunchKernelGGL((k_gemm64<false, true>), grid, dim3(256), 0, st, g);
     if (ta && !tb) hipLaunchKernelGGL((k_gemm64<true, false>), grid, dim3(256), 0, st, g);
@@ -268,32 +274,37 @@ void launch_potrf(hipStream_t st, double* A, int npad, int batch, double* invD, 
 }
 
 // ------------------------------------------------------------------ triangular inverse
-__global__ void k_copy_block(const double* __restrict__ src, long s_src, double* __restrict__ dst, int ldd, long s_dst) {
-    const int b = blockIdx.x;
-    const double* s = src + (long)b * s_src;
-    double* d = dst + (long)b * s_dst;
-    for (int e = threadIdx.x; e < 4096; e += blockDim.x) d[(long)(e >> 6) * ldd + (e & 63)] = s[e];
+// Recursive doubling: with the inverses of the 64x64 diagonal blocks in place (from k_potf2_inv), level h merges
+// pairs of inverted h x h diagonal blocks A, B of a 2h block [[A^-1, 0], [X, B^-1]] with X = -B^-1 (C A^-1),
+// C = L[lower-left].  Two batched GEMMs per level over all (matrix, block) pairs: log2(npad/64) levels instead of
+// one GEMM pair per block row.  Trailing partial blocks (npad/64 not a power of two) are clipped per sub-problem.
+__global__ void k_copy_diag_blocks(const double* __restrict__ invD, double* __restrict__ Linv, int npad) {
+    const int I = blockIdx.x, b = blockIdx.y, nblk = npad / 64;
+    const double* s = invD + ((long)b * nblk + I) * 4096;
+    double* d = Linv + (long)b * npad * npad + (long)I * 64 * npad + I * 64;
+    for (int e = threadIdx.x; e < 4096; e += blockDim.x) d[(long)(e >> 6) * npad + (e & 63)] = s[e];
 }
 
-void launch_trtri(hipStream_t st, const double* L, int npad, int batch, const double* invD, double* Linv, double* T) {
-    const int nblk = npad / 64;
+void launch_trtri(hipStream_t st, const double* L, int npad, int batch, const double* invD, double* Linv, double* T,
+                  long tstride) {
     const long sA = (long)npad * npad;
     (void)hipMemsetAsync(Linv, 0, sizeof(double) * sA * batch, st);
-    for (int I = 0; I < nblk; ++I) {
-        hipLaunchKernelGGL(k_copy_block, dim3(batch), dim3(256), 0, st, invD + (long)I * 4096, (long)nblk * 4096,
-                           Linv + (long)I * 64 * npad + I * 64, npad, sA);
-        if (I == 0) continue;
-        GemmDesc a{};  // T = L[I, 0:I] * Linv[0:I, 0:I]
-        a.A = L + (long)I * 64 * npad; a.lda = npad; a.sA = sA;
-        a.B = Linv; a.ldb = npad; a.sB = sA;
-        a.C = T; a.ldc = npad; a.sC = (long)64 * npad;
-        a.M = 64; a.N = I * 64; a.K = I * 64; a.alpha = 1.0; a.beta = 0.0; a.tile_mode = 0; a.k_mode = 2;
+    hipLaunchKernelGGL(k_copy_diag_blocks, dim3(npad / 64, batch), dim3(256), 0, st, invD, Linv, npad);
+    for (int h = 64; h < npad; h *= 2) {
+        const int nsub = (npad - h + 2 * h - 1) / (2 * h);   // 2h blocks whose lower half is not empty
+        GemmDesc a{};  // T_q = C_q * A_q^-1      (A_q^-1 lower triangular: k >= j0)
+        a.A = L + (long)h * npad; a.lda = npad; a.sA = sA; a.ssA = (long)2 * h * (npad + 1);
+        a.B = Linv; a.ldb = npad; a.sB = sA; a.ssB = (long)2 * h * (npad + 1);
+        a.C = T; a.ldc = h; a.sC = tstride; a.ssC = (long)h * h;
+        a.M = h; a.N = h; a.K = h; a.alpha = 1.0; a.beta = 0.0; a.tile_mode = 0; a.k_mode = 2;
+        a.nsub = nsub; a.sub_rows0 = npad - h; a.sub_rows_step = 2 * h;
         launch_gemm(st, a, false, false, batch);
-        GemmDesc c{};  // Linv[I, 0:I] = -inv(L_II) * T
-        c.A = invD + (long)I * 4096; c.lda = 64; c.sA = (long)nblk * 4096;
-        c.B = T; c.ldb = npad; c.sB = (long)64 * npad;
-        c.C = Linv + (long)I * 64 * npad; c.ldc = npad; c.sC = sA;
-        c.M = 64; c.N = I * 64; c.K = 64; c.alpha = -1.0; c.beta = 0.0; c.tile_mode = 0; c.k_mode = 0;
+        GemmDesc c{};  // X_q = -B_q^-1 * T_q     (B_q^-1 lower triangular: k < i0 + 64)
+        c.A = Linv + (long)h * (npad + 1); c.lda = npad; c.sA = sA; c.ssA = (long)2 * h * (npad + 1);
+        c.B = T; c.ldb = h; c.sB = tstride; c.ssB = (long)h * h;
+        c.C = Linv + (long)h * npad; c.ldc = npad; c.sC = sA; c.ssC = (long)2 * h * (npad + 1);
+        c.M = h; c.N = h; c.K = h; c.alpha = -1.0; c.beta = 0.0; c.tile_mode = 0; c.k_mode = 3;
+        c.nsub = nsub; c.sub_rows0 = npad - h; c.sub_rows_step = 2 * h;
         launch_gemm(st, c, false, false, batch);
     }
 }
@@ -432,12 +443,20 @@ __global__ __launch_bounds__(256) void k_matvec(const double* __restrict__ A, in
     const int b = blockIdx.y;
     const double* Ab = A + (long)b * npad * npad;
     const double* xb = x + (long)b * npad;
-    if (trans) {  // y[j] = sum_i A[i][j] x[i]; one thread per column, coalesced across lanes
-        const int j = blockIdx.x * 256 + threadIdx.x;
-        if (j >= npad) return;
-        double s = 0.0;
-        for (int i = 0; i < npad; ++i) s = fma(Ab[(long)i * npad + j], xb[i], s);
-        y[(long)b * npad + j] = s;
+    if (trans) {  // y[j] = sum_i A[i][j] x[i]; 64 columns per workgroup, the four waves split the rows
+        __shared__ double red[4][64];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int j = blockIdx.x * 64 + lane;
+        double s0 = 0.0, s1 = 0.0;
+        int i = w;
+        for (; i + 4 < npad; i += 8) {
+            s0 = fma(Ab[(long)i * npad + j], xb[i], s0);
+            s1 = fma(Ab[(long)(i + 4) * npad + j], xb[i + 4], s1);
+        }
+        for (; i < npad; i += 4) s0 = fma(Ab[(long)i * npad + j], xb[i], s0);
+        red[w][lane] = s0 + s1;
+        __syncthreads();
+        if (w == 0) y[(long)b * npad + j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     } else {  // y[i] = sum_j A[i][j] x[j]; one wave per row
         const int lane = threadIdx.x & 63;
         const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -450,7 +469,7 @@ __global__ __launch_bounds__(256) void k_matvec(const double* __restrict__ A, in
 }
 
 void launch_matvec(hipStream_t st, const double* A, int npad, int batch, const double* x, double* y, bool trans) {
-    dim3 grid(trans ? (npad + 255) / 256 : (npad + 3) / 4, batch);
+    dim3 grid(trans ? npad / 64 : (npad + 3) / 4, batch);
     hipLaunchKernelGGL(k_matvec, grid, dim3(256), 0, st, A, npad, x, y, trans ? 1 : 0);
 }
 
