@@ -61,12 +61,53 @@ def cpu_baseline(cfg):
                         "(mgpr.py:77-79) would give %.4f rollouts/s" % (t_fact, t_step, 1.0 / (H * (t_step + t_fact)))))
 
 
+def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout):
+    """The other two variants SURVEY.md 8(d) asks for, measured after the timed region (1 GPU):
+    R-fwd+fact (factorise once, then roll out: what a fresh model pays) and R-grad (value + gradient of the
+    rollout reward w.r.t. a linear controller at C2u: state 10 + 1 control, D=11)."""
+    from pilco_amd import synthetic
+    from pilco_amd.adjoint import rollout_value_and_grad
+    from pilco_amd.models import PILCO
+    out = {}
+    fact_ms = ctx.factorize_timed(0, 5)
+    out["factorisation_ms"] = fact_ms
+    out["R_fwd_fact_rollouts_per_s"] = 1e3 / (fact_ms + ms_rollout)
+    cu = synthetic.config_c2(N=N, D=D + 1, E=E)
+    p = PILCO((cu["X"], cu["Y"]), horizon=H, ctx=ctx)
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(cu["lengthscales"][i])
+        mdl.kernel.variance.assign(cu["variance"][i])
+        mdl.likelihood.variance.assign(cu["noise"][i])
+    p.controller.W.assign(cu["W"])
+    p.controller.b.assign(cu["b"])
+    p.controller.max_action = 1.0
+    p.m_init, p.S_init = cu["m0"], cu["S0"]
+    rollout_value_and_grad(p)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        rollout_value_and_grad(p)
+    g_ms = (time.perf_counter() - t0) / 3 * 1e3
+    p.compute_reward()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        p.compute_reward()
+    f_ms = (time.perf_counter() - t0) / 3 * 1e3
+    out["R_grad_C2u_ms"] = g_ms
+    out["R_grad_C2u_per_s"] = 1e3 / g_ms
+    out["R_fwd_C2u_ms"] = f_ms
+    # restore the benchmark model in slot 0
+    ctx.gp_set_data(0, cfg["X"], cfg["Y"])
+    ctx.gp_set_hyp(0, cfg["lengthscales"], cfg["variance"], cfg["noise"])
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,6 +197,8 @@ def main():
                          "algorithmic_bytes_per_launch": byts / world,
                          "hbm_GBps_algorithmic": byts / world / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0},
         }
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_metrics(ctx, cfg, policy, rewards, ms_per_rollout)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))

@@ -123,7 +123,6 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     const int PLa = std::max(wk.PL, 1);
     // stream-K geometry (variant 0)
     wk.sk_waves = 0;
-    std::vector<int> wl(PLa, 0), wh(PLa, -1);
     if (ctx->variant == 0 && wk.PL > 0) {
         int tdiag, toff;
         mm_pair_sk_steps(npad, &tdiag, &toff);
@@ -142,45 +141,21 @@ int build_work(pilco_ctx* ctx, Slot& s) {
         wk.sk_nd = nd;
         wk.sk_tdiag = tdiag;
         wk.sk_toff = toff;
-        wk.sk_ud = 3;
-        wk.sk_uo = 2;
+        wk.sk_ud = 5;   // measured: a diagonal step (iK stream + one more FMA per element) costs ~5/4 of an off-diagonal one
+        wk.sk_uo = 4;
         if (const char* env = getenv("PILCO_SK_UNITS")) {
             int a = 0, b = 0;
             if (sscanf(env, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { wk.sk_ud = a; wk.sk_uo = b; }
         }
-        const int nd_steps = nd * tdiag;
-        std::vector<int> bnd(waves + 1);
-        for (int w = 0; w <= waves; ++w) bnd[w] = mm_sk_boundary(w, waves, nd_steps, (int)T, wk.sk_ud, wk.sk_uo);
-        auto wave_of = [&](long x) {  // the last wave whose first step is <= x and which is not empty before x
-            int lo = 0, hi = waves - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) / 2;
-                if (bnd[mid] <= x) lo = mid; else hi = mid - 1;
-            }
-            return lo;
-        };
-        for (int k = 0; k < wk.PL; ++k) {
-            const long S0 = (k < nd) ? (long)k * tdiag : (long)nd * tdiag + (long)(k - nd) * toff;
-            const long S1 = S0 + ((k < nd) ? tdiag : toff);
-            wl[k] = wave_of(S0);
-            wh[k] = wave_of(S1 - 1);
-        }
     }
-    std::vector<int> all;
-    all.insert(all.end(), wl.begin(), wl.end());
-    all.insert(all.end(), wh.begin(), wh.end());
-    const size_t n_int = all.size() + (size_t)2 * std::max(wk.sk_waves, 4);
+    const size_t n_int = (size_t)2 * std::max(wk.sk_waves, 4);
     if (n_int > s.lists_cap) {
         if (s.d_lists) (void)hipFree(s.d_lists);
         s.d_lists = nullptr;
         HIPCHK(hipMalloc(&s.d_lists, n_int * sizeof(int)));
         s.lists_cap = n_int;
     }
-    HIPCHK(hipMemcpyAsync(s.d_lists, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));  // `all` is a stack vector
-    wk.sk_wlo = s.d_lists;
-    wk.sk_whi = s.d_lists + PLa;
-    wk.sk_pidx = s.d_lists + 2 * PLa;
+    wk.sk_pidx = s.d_lists;
     ENSURE(s.w_in, (size_t)D + D * D + E + E * E + D * E);   // m | s | cotangents (Mbar | Sbar | Vbar) of the reverse pass
     ENSURE(s.w_At, (size_t)PLa * wk.KP * npad);
     ENSURE(s.w_Bt, (size_t)PLa * wk.KP * npad);

@@ -36,8 +36,6 @@ struct MMWork {
     // stream-K decomposition of the MFMA pair kernel (variant 0)
     double* sk_part;     // [sk_waves][2] per-wave partial of the (at most two) pairs a wave touches
     int* sk_pidx;        // [sk_waves][2] local pair index of each partial (-1 = none)
-    const int* sk_wlo;   // [PL] first wave touching the local pair
-    const int* sk_whi;   // [PL] last wave touching the local pair
     int sk_waves, sk_total, sk_nd, sk_tdiag, sk_toff;
     unsigned long long* dbg;  // optional [32] phase timestamps (100 MHz wall clock) of the last prep / glue launch
     int abl;             // experiment switches (PILCO_ABL, tools only; 0 in product use)

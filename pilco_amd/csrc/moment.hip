@@ -647,12 +647,24 @@ void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk) {
 #ifndef PAIR_MINW
 #define PAIR_MINW 1    // __launch_bounds__ min waves per SIMD for the pair kernel
 #endif
+// Buffer loads for the hot loop: wave-uniform resource (base pointer) + 32-bit per-lane byte offset + scalar byte
+// offset, i.e. no 64-bit address arithmetic in the VALU stream (the fp64 pipe is the bottleneck of this kernel).
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const double* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, 0x7fffffff, 0x00020000);   // raw, untyped
+}
+__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+
 template <int KC, bool DIAG>
 __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const double* __restrict__ Bt,
                                             const double* __restrict__ beta_a, const double* __restrict__ beta_b,
                                             const double* __restrict__ iKa, const double* __restrict__ tab, int npad, int i0,
                                             int jbeg, int jend, int lane) {
     constexpr int NE = 4 * PAIR_RT;  // exponent values per lane per 16-column step
+    static_assert(PAIR_PF == 2, "the column loop is unrolled over a two-slot operand ring");
     const int lr = lane >> 4, lc = lane & 15;
     double af[PAIR_RT][KC];
 #pragma unroll
@@ -661,45 +673,45 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
         for (int c = 0; c < KC; ++c) af[rt][c] = At[(long)(4 * c + lr) * npad + i0 + 16 * rt + lc];
     double acc[NE];
     double bi[NE];
+    unsigned ik_off[NE];
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         acc[i] = 0.0;
-        bi[i] = beta_a[i0 + 16 * (i >> 2) + lr + 4 * (i & 3)];
+        const int row = i0 + 16 * (i >> 2) + lr + 4 * (i & 3);
+        bi[i] = beta_a[row];
+        ik_off[i] = ((unsigned)(row - i0) * (unsigned)npad + (unsigned)lc) * 8u;   // relative to row i0: < 32 rows
     }
+    unsigned b_off[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) b_off[c] = ((unsigned)(4 * c + lr) * (unsigned)npad + (unsigned)lc) * 8u;
+    const unsigned bb_off = (unsigned)lc * 8u;
+    const __amdgpu_buffer_rsrc_t rB = buf_rsrc(Bt), rbeta = buf_rsrc(beta_b);
+    const __amdgpu_buffer_rsrc_t rIK = buf_rsrc(DIAG ? iKa + (long)i0 * npad : Bt);
     if (DIAG && jbeg < i0) jbeg = i0;  // columns left of the diagonal block are mirrored by the transposed tile
     double total = 0.0;
-    // software pipeline: the operands of the column step PAIR_PF ahead are requested while this one is
+    // software pipeline: the operands of the column step two ahead are requested while this one is
     // evaluated (a first touch of Bt / beta misses the XCD's L2: ~2 us, more than one step)
-    double ring[PAIR_PF][KC + 1];
+    double ring[2][KC + 1];
 #pragma unroll
-    for (int p = 0; p < PAIR_PF; ++p) {
+    for (int p = 0; p < 2; ++p) {
 #pragma unroll
         for (int c = 0; c <= KC; ++c) ring[p][c] = 0.0;
         if (jbeg + 16 * p < jend) {
 #pragma unroll
-            for (int c = 0; c < KC; ++c) ring[p][c] = Bt[(long)(4 * c + lr) * npad + jbeg + 16 * p + lc];
-            ring[p][KC] = beta_b[jbeg + 16 * p + lc];
+            for (int c = 0; c < KC; ++c) ring[p][c] = buf_ld(rB, b_off[c], (unsigned)(jbeg + 16 * p) * 8u);
+            ring[p][KC] = buf_ld(rbeta, bb_off, (unsigned)(jbeg + 16 * p) * 8u);
         }
     }
-    for (int j0 = jbeg; j0 < jend; j0 += 16) {
+    // one 16-column step on ring slot rg; the slot is refilled with the operands of column step j0 + 32
+    auto step = [&](double (&rg)[KC + 1], const int j0) {
         double bf[KC];
 #pragma unroll
-        for (int c = 0; c < KC; ++c) bf[c] = ring[0][c];
-        const double bb = ring[0][KC];
-#pragma unroll
-        for (int p = 0; p + 1 < PAIR_PF; ++p)
-#pragma unroll
-            for (int c = 0; c <= KC; ++c) ring[p][c] = ring[p + 1][c];
+        for (int c = 0; c < KC; ++c) bf[c] = rg[c];
+        const double bb = rg[KC];
         double ik[NE];
         if (DIAG) {
 #pragma unroll
-            for (int i = 0; i < NE; ++i)
-                ik[i] = iKa[(long)(i0 + 16 * (i >> 2) + lr + 4 * (i & 3)) * npad + j0 + lc];
-        }
-        if (PAIR_ABL != 4 && j0 + 16 * PAIR_PF < jend) {
-#pragma unroll
-            for (int c = 0; c < KC; ++c) ring[PAIR_PF - 1][c] = Bt[(long)(4 * c + lr) * npad + j0 + 16 * PAIR_PF + lc];
-            ring[PAIR_PF - 1][KC] = beta_b[j0 + 16 * PAIR_PF + lc];
+            for (int i = 0; i < NE; ++i) ik[i] = buf_ld(rIK, ik_off[i], (unsigned)j0 * 8u);
         }
         // exponent tiles: C/D layout of the f64 MFMA is col = lane & 15, row = (lane >> 4) + 4 * reg
         double x[NE], tt[NE], tv[NE], pm[NE];
@@ -710,6 +722,11 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
             for (int c = 0; c < KC; ++c) e = PAIR_ABL_MFMA(af[rt][c], bf[c], e);
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[4 * rt + r] = e[r];
+        }
+        if (PAIR_ABL != 4 && j0 + 32 < jend) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) rg[c] = buf_ld(rB, b_off[c], (unsigned)(j0 + 32) * 8u);
+            rg[KC] = buf_ld(rbeta, bb_off, (unsigned)(j0 + 32) * 8u);
         }
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
@@ -754,6 +771,10 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
 #pragma unroll
             for (int i = 0; i < NE; ++i) acc[i] = fma(bb, FEXP_FINISH(tv[i], pm[i], tt[i]), acc[i]);
         }
+    };
+    for (int j0 = jbeg; j0 < jend; j0 += 32) {
+        step(ring[0], j0);
+        if (j0 + 16 < jend) step(ring[1], j0 + 16);
     }
     if (!DIAG) {
 #pragma unroll
@@ -803,13 +824,40 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_tiled(MMModel md, MM
 // A range touches at most two pairs; each wave writes one partial per touched pair.
 // first column step of wave w: the cost line (diagonal steps weigh sk_ud units, the others sk_uo)
 // is cut into sk_waves equal parts; a step belongs to the wave in whose part it starts.
+// floor(a / b) for 0 <= a < 2^52, 0 < b: one fp64 division and an exact integer fix-up (the emulated 64-bit integer
+// division is ~10x slower, and these quotients sit at the head of the glue kernel's critical path)
+__host__ __device__ inline long div_floor(long a, long b) {
+    long q = (long)((double)a / (double)b);
+    while (q * b > a) --q;
+    while ((q + 1) * b <= a) ++q;
+    return q;
+}
 __host__ __device__ inline int sk_boundary_of(int w, int waves, int nd_steps, int total, int ud, int uo) {
     const long Ud = (long)nd_steps * ud;
     const long C = Ud + (long)(total - nd_steps) * uo;
-    const long x = (long)w * C / waves;
     if (w >= waves) return total;
-    if (x <= Ud) return (int)((x + ud - 1) / ud);
-    return nd_steps + (int)((x - Ud + uo - 1) / uo);
+    const long x = div_floor((long)w * C, waves);
+    if (x <= Ud) return (int)div_floor(x + ud - 1, ud);
+    return nd_steps + (int)div_floor(x - Ud + uo - 1, uo);
+}
+// inverse: the last wave whose first step is <= x  (boundary(w) <= x  <=>  floor(w C / waves) <= cost(x))
+__host__ __device__ inline int sk_wave_of(long x, int waves, int nd_steps, int total, int ud, int uo) {
+    const long Ud = (long)nd_steps * ud;
+    const long C = Ud + (long)(total - nd_steps) * uo;
+    const long cx = (x <= nd_steps) ? x * ud : Ud + (x - nd_steps) * uo;
+    long w = div_floor((cx + 1) * waves + C - 1, C) - 1;
+    if (w > waves - 1) w = waves - 1;
+    return (int)w;
+}
+// waves holding partials of local pair k: first wave, its slot for this pair, last wave
+__host__ __device__ inline void sk_pair_waves(int k, int waves, int nd, int tdiag, int toff, int total, int ud, int uo,
+                                              int& wlo, int& fslot, int& whi) {
+    const long S0 = (k < nd) ? (long)k * tdiag : (long)nd * tdiag + (long)(k - nd) * toff;
+    const long S1 = S0 + ((k < nd) ? tdiag : toff);
+    const int nd_steps = nd * tdiag;
+    wlo = sk_wave_of(S0, waves, nd_steps, total, ud, uo);
+    fslot = sk_boundary_of(wlo, waves, nd_steps, total, ud, uo) < S0 ? 1 : 0;   // a wave that starts before the pair holds it second
+    whi = sk_wave_of(S1 - 1, waves, nd_steps, total, ud, uo);
 }
 __device__ __forceinline__ int sk_boundary(const MMWork& wk, int w) {
     return sk_boundary_of(w, wk.sk_waves, wk.sk_nd * wk.sk_tdiag, wk.sk_total, wk.sk_ud, wk.sk_uo);
@@ -1604,33 +1652,74 @@ __device__ void write_joint(const GlueArgs& g, const GlueLds& L) {
 // Reduce the tile / stream-K partials of the local pairs and the row-chunk partials of the
 // owned outputs into this rank's segment (LDS copy + global gather buffer).  Four lanes per
 // pair sum fixed quarters of the partial list and are combined in a fixed tree.
-__device__ void mm_pack(const MMWork& wk, int D, int E, const GlueLds& L, int pre_wlo, int pre_whi) {
+// Round `base` of mm_pack (4 threads per pair), split in two so that the loads of the first round are ISSUED at the very
+// start of the glue kernel, together with its other loads, and consumed after them (vmcnt is in order: one round trip).
+// Only kernel arguments go into the addresses (closed-form wave ranges).
+struct PackPre {
+    double v[16];
+    double isdet;
+    int qn, q1, wlo, fs;   // next unread wave, end of this thread's range, first wave of the pair and its slot
+};
+__device__ __forceinline__ void mm_pack_issue(const MMWork& wk, int base, PackPre& pp) {
+    const int t = threadIdx.x;
+    const int k = base + (t >> 2), gq = t & 3;
+    pp.isdet = 0.0;
+    pp.qn = pp.q1 = pp.wlo = pp.fs = 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) pp.v[u] = 0.0;
+    if (k >= wk.PL) return;
+    pp.isdet = wk.pair_isdet[k];
+    if (wk.sk_waves > 0) {  // stream-K partials of waves wlo..whi; every wave after the first holds this pair in slot 0
+        int whi;
+        sk_pair_waves(k, wk.sk_waves, wk.sk_nd, wk.sk_tdiag, wk.sk_toff, wk.sk_total, wk.sk_ud, wk.sk_uo, pp.wlo, pp.fs, whi);
+        const int n = whi - pp.wlo + 1;
+        const int q0 = pp.wlo + ((n * gq) >> 2);
+        pp.q1 = pp.wlo + ((n * (gq + 1)) >> 2);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int q = q0 + u;
+            if (q < pp.q1) pp.v[u] = wk.sk_part[2 * q + ((q == pp.wlo) ? pp.fs : 0)];
+        }
+        pp.qn = q0 + 16;
+    }
+}
+__device__ __forceinline__ void mm_pack_sum(const MMWork& wk, int base, const PackPre& pp, double& s0, double& s1) {
+    const int t = threadIdx.x;
+    const int k = base + (t >> 2), gq = t & 3;
+    s0 = 0.0;
+    s1 = 0.0;
+    if (k >= wk.PL) return;
+    if (wk.sk_waves > 0) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s0 += pp.v[u];
+        for (int qb = pp.qn; qb < pp.q1; qb += 16) {   // long ranges (few pairs): 16 independent loads at a time
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int q = qb + u;
+                v[u] = (q < pp.q1) ? wk.sk_part[2 * q] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s0 += v[u];
+        }
+    } else {
+        const double* part = wk.pair_part + (long)k * wk.NT * 2;
+        const int q0 = (int)((long)wk.NT * gq / 4), q1 = (int)((long)wk.NT * (gq + 1) / 4);
+        for (int q = q0; q < q1; ++q) {
+            s0 += part[2 * q];
+            s1 += part[2 * q + 1];
+        }
+    }
+}
+
+__device__ void mm_pack(const MMWork& wk, int D, int E, const GlueLds& L, PackPre& pp) {
     const int t = threadIdx.x;
     double* seg = wk.gath + (long)wk.rank * wk.SEG;
     for (int base = 0; base < wk.PL; base += 64) {
         const int k = base + (t >> 2), gq = t & 3;
-        double s0 = 0.0, s1 = 0.0;
-        if (k < wk.PL) {
-            if (wk.sk_waves > 0) {  // stream-K partials: waves wlo..whi, the slot whose pair index matches
-                const bool pre = (base == 0 && pre_whi >= pre_wlo);
-                const int wlo = pre ? pre_wlo : wk.sk_wlo[k];
-                const int n = (pre ? pre_whi : wk.sk_whi[k]) - wlo + 1;
-                const int q0 = wlo + (int)((long)n * gq / 4), q1 = wlo + (int)((long)n * (gq + 1) / 4);
-                for (int q = q0; q < q1; ++q) {
-                    const int p0 = wk.sk_pidx[2 * q], p1 = wk.sk_pidx[2 * q + 1];
-                    const double v0 = wk.sk_part[2 * q], v1 = wk.sk_part[2 * q + 1];
-                    if (p0 == k) s0 += v0;
-                    if (p1 == k) s0 += v1;
-                }
-            } else {
-                const double* part = wk.pair_part + (long)k * wk.NT * 2;
-                const int q0 = (int)((long)wk.NT * gq / 4), q1 = (int)((long)wk.NT * (gq + 1) / 4);
-                for (int q = q0; q < q1; ++q) {
-                    s0 += part[2 * q];
-                    s1 += part[2 * q + 1];
-                }
-            }
-        }
+        if (base > 0) mm_pack_issue(wk, base, pp);
+        double s0, s1;
+        mm_pack_sum(wk, base, pp, s0, s1);
         s0 += __shfl_xor(s0, 1);
         s1 += __shfl_xor(s1, 1);
         s0 += __shfl_xor(s0, 2);
@@ -1638,7 +1727,7 @@ __device__ void mm_pack(const MMWork& wk, int D, int E, const GlueLds& L, int pr
         if (k < wk.PL && gq == 0) {
             int a, b;
             local_pair_ab(wk, E, k, a, b);
-            const double v = ((a == b) ? (s0 - s1) : s0) * wk.pair_isdet[k];   // mgpr.py:144-145
+            const double v = ((a == b) ? (s0 - s1) : s0) * pp.isdet;   // mgpr.py:144-145
             seg[k] = v;
             L.seg[k] = v;
         }
@@ -1731,11 +1820,8 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
     }
 
     DBG_STAMP(g.wk, 8 + dbo, dbg0);
-    int pre_wlo = 0, pre_whi = -1;
-    if ((g.flags & GF_PACK) && g.wk.sk_waves > 0 && (t >> 2) < g.wk.PL) {
-        pre_wlo = g.wk.sk_wlo[t >> 2];
-        pre_whi = g.wk.sk_whi[t >> 2];
-    }
+    PackPre pp;   // first round of the pack: its loads are in flight together with the batch below
+    if ((g.flags & GF_PACK) && !(g.wk.abl & 16)) mm_pack_issue(g.wk, 0, pp);
     // one batch of loads for everything the serial part reads
     if (g.flags & (GF_PROPAGATE | GF_TRAJ | GF_POLICY | GF_RBF_PRE)) {
         if (t < E) L.mx[t] = g.m_x[t];
@@ -1748,7 +1834,7 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
     __syncthreads();
 
     DBG_STAMP(g.wk, 9 + dbo, dbg0);
-    if ((g.flags & GF_PACK) && !(g.wk.abl & 16)) mm_pack(g.wk, D, E, L, pre_wlo, pre_whi);
+    if ((g.flags & GF_PACK) && !(g.wk.abl & 16)) mm_pack(g.wk, D, E, L, pp);
     DBG_STAMP(g.wk, 10 + dbo, dbg0);
     if (g.flags & GF_ASSEMBLE) {
         // single rank: the LDS copy of the segment is the whole gather buffer
@@ -1799,7 +1885,9 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
     if (g.flags & GF_POLICY) {
         if (g.pol_kind == PILCO_POLICY_RBF) {
             // mean-function-only GP: iK = 0, then S -= diag(var - 1e-6)      (controllers.py:116-117)
-            mm_pack(g.pwk, E, U, L, 0, -1);
+            PackPre pq;
+            mm_pack_issue(g.pwk, 0, pq);
+            mm_pack(g.pwk, E, U, L, pq);
             mm_assemble(g.pwk, L.seg, g.pvar, E, U, L.mu, L.su, L.cxu);   // M (U), S (U,U), V (E,U)
             if (t < U) L.su[t * U + t] -= g.pvar[t] - 1e-6;
             __syncthreads();
