@@ -50,7 +50,7 @@ struct pilco_ctx {
     DevBuf traj;
     DevBuf tape;
     DevBuf selftest;
-    DevBuf exp_tab;  // 2^(j/64), j = 0..63
+    DevBuf exp_tab;  // 2^(j/n), j = 0..n-1, n = mm_exp_table_size()
     unsigned long long* dbg = nullptr;
     // cached hipGraph of one rollout (single-rank): replayed while the plan key is unchanged
     hipGraphExec_t graph = nullptr;
@@ -368,9 +368,10 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
         return PILCO_E_HIP;
     }
     {
-        double tab[64];
-        for (int j = 0; j < 64; ++j) tab[j] = std::exp2((double)j / 64.0);
-        if (ctx->exp_tab.ensure(64) != hipSuccess ||
+        double tab[256];
+        const int tn = mm_exp_table_size();
+        for (int j = 0; j < tn; ++j) tab[j] = std::exp2((double)j / (double)tn);
+        if (ctx->exp_tab.ensure(256) != hipSuccess ||
             hipMemcpy(ctx->exp_tab.p, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) {
             delete ctx;
             return PILCO_E_HIP;

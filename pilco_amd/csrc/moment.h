@@ -40,7 +40,7 @@ struct MMWork {
     unsigned long long* dbg;  // optional [32] phase timestamps (100 MHz wall clock) of the last prep / glue launch
     int abl;             // experiment switches (PILCO_ABL, tools only; 0 in product use)
     int sk_ud, sk_uo;    // cost units of a diagonal / off-diagonal column step (diagonal steps also stream iK)
-    const double* exp_tab;    // [64] 2^(j/64), for the table-driven fp64 exp of the pair kernel
+    const double* exp_tab;    // [n] 2^(j/n), n = mm_exp_table_size(), for the table-driven fp64 exp of the pair kernel
     int PL, EL, P, KP, NCH, NT, SEG, OUTOFF, rank, nranks;  // OUTOFF: offset of the output records inside a segment
 };
 
@@ -117,6 +117,7 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
                    const double* bars, double* out);
 void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb);
 int mm_bwd_rc(int npad);
+int mm_exp_table_size();   // entries of the 2^(j/n) table the pair kernels were built for
 int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf, const double* exp_tab);
 
 }  // namespace pilco

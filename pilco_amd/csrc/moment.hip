@@ -75,18 +75,27 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// Table-driven fp64 exp for the pair kernel: x = (64 m + j) ln2/64 + r,
-// exp(x) = 2^m * T[j] * (1 + r + r^2/2 + ... + r^5/120), |r| <= ln2/128 so the
-// degree-5 tail is < 4e-17.  n = rint(64 x / ln2) comes out of the low mantissa
+// Table-driven fp64 exp for the pair kernel: with T = 2^FEXP_TB table entries, x = (T m + j) ln2/T + r,
+// exp(x) = 2^m * tab[j] * (1 + r + r^2/2 + r^3/6 + r^4/24), |r| <= ln2/(2T): for T = 256 the dropped
+// r^5/120 term is < 4e-17 (T = 64 keeps it).  n = rint(T x / ln2) comes out of the low mantissa
 // bits of x*C + 1.5*2^52 (no cvt), 2^m is an integer add into the exponent field.
 // Inputs below -700 are clamped (result ~1e-304 instead of 0); the exponents of
 // this path are bounded above by log(var_a var_b).  The reduction uses a single
-// ln2/64 constant: its rounding contributes |x| * 1.1e-16 relative error, the same
+// ln2/T constant: its rounding contributes |x| * 1.1e-16 relative error, the same
 // size as the rounding of the exponent x itself.  Split into three phases so that a
 // wave keeps all its table reads in flight while it evaluates the polynomials.
+#ifndef FEXP_TB
+#define FEXP_TB 8    // log2 of the table size: 256 entries let the polynomial stop at degree 4 (|r| <= ln2/512)
+#endif
+#define FEXP_TN (1 << FEXP_TB)
+#if FEXP_TB == 6
 #define FEXP_C 92.332482616893656758       /* 64 / ln2 */
-#define FEXP_MAGIC 6755399441055744.0      /* 1.5 * 2^52 */
 #define FEXP_LN2_64 0.010830424696249145   /* ln2 / 64 */
+#else
+#define FEXP_C 369.3299304675746       /* 256 / ln2 */
+#define FEXP_LN2_64 0.0027076061740622863   /* ln2 / 256 */
+#endif
+#define FEXP_MAGIC 6755399441055744.0      /* 1.5 * 2^52 */
 
 #ifndef PAIR_OPT
 #define PAIR_OPT 0   // experiment bits (tools): 1 no inline asm, 2 no clamp, 4 no sched barriers
@@ -107,27 +116,31 @@ __device__ __forceinline__ double fexp_t(double x) { return fma(x, FEXP_C, FEXP_
 __device__ __forceinline__ double fexp_poly(double x, double t) {
     const double nf = t - FEXP_MAGIC;
     const double r = fma(nf, -FEXP_LN2_64, x);
+#if FEXP_TB == 6
     double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
     q = fma(r, q, 1.0 / 6.0);
+#else
+    double q = fma(r, 1.0 / 24.0, 1.0 / 6.0);
+#endif
     q = fma(r, q, 0.5);
     q = fma(r, q, 1.0);
     return r * q;
 }
 __device__ __forceinline__ double fexp_finish(double tv, double pm1, double t) {
     const double res = fma(tv, pm1, tv);
-    const int lo = __double2loint(t) & ~63;
+    const int lo = __double2loint(t) & ~(FEXP_TN - 1);
     int hi;
 #if PAIR_OPT & 1
-    hi = __double2hiint(res) + (lo << 14);
+    hi = __double2hiint(res) + (lo << (20 - FEXP_TB));
 #else
-    asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(hi) : "v"(lo), "v"(__double2hiint(res)));  // exponent += n >> 6
+    asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(hi) : "v"(lo), "v"(__double2hiint(res)), "n"(20 - FEXP_TB));  // exponent += n >> FEXP_TB
 #endif
     return __hiloint2double(hi, __double2loint(res));
 }
 __device__ __forceinline__ double fexp(double x, const double* __restrict__ tab) {
     x = fexp_clamp(x);
     const double t = fexp_t(x);
-    const double tv = tab[__double2loint(t) & 63];
+    const double tv = tab[__double2loint(t) & (FEXP_TN - 1)];
     return fexp_finish(tv, fexp_poly(x, t), t);
 }
 
@@ -632,7 +645,7 @@ void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk) {
 #define PAIR_ABL 0
 #endif
 #if PAIR_ABL == 2
-#define PAIR_ABL_TAB(v) (1.0 + 1e-9 * (double)(__double2loint(tt[i]) & 63))
+#define PAIR_ABL_TAB(v) (1.0 + 1e-9 * (double)(__double2loint(tt[i]) & (FEXP_TN - 1)))
 #else
 #define PAIR_ABL_TAB(v) (v)
 #endif
@@ -734,7 +747,7 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
             tt[i] = fexp_t(x[i]);
         }
 #pragma unroll
-        for (int i = 0; i < NE; ++i) tv[i] = PAIR_ABL_TAB(tab[__double2loint(tt[i]) & 63]);
+        for (int i = 0; i < NE; ++i) tv[i] = PAIR_ABL_TAB(tab[__double2loint(tt[i]) & (FEXP_TN - 1)]);
 #if !(PAIR_OPT & 4)
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -742,10 +755,15 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
         double rr[NE];
 #pragma unroll
         for (int i = 0; i < NE; ++i) rr[i] = fma(tt[i] - FEXP_MAGIC, -FEXP_LN2_64, x[i]);
+#if FEXP_TB == 6
 #pragma unroll
         for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], 1.0 / 120.0, 1.0 / 24.0);
 #pragma unroll
         for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], pm[i], 1.0 / 6.0);
+#else
+#pragma unroll
+        for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], 1.0 / 24.0, 1.0 / 6.0);
+#endif
 #pragma unroll
         for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], pm[i], 0.5);
 #pragma unroll
@@ -786,8 +804,8 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
 template <int KC>
 __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_tiled(MMModel md, MMWork wk, int NJB) {
     __shared__ double red[4];
-    __shared__ double tab[64];
-    if (threadIdx.x < 64) tab[threadIdx.x] = wk.exp_tab[threadIdx.x];
+    __shared__ double tab[FEXP_TN];
+    for (int e = threadIdx.x; e < FEXP_TN; e += blockDim.x) tab[e] = wk.exp_tab[e];
     __syncthreads();
     const int npad = md.npad;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -868,8 +886,8 @@ int mm_sk_boundary(int w, int waves, int nd_steps, int total, int ud, int uo) {
 
 template <int KC>
 __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWork wk) {
-    __shared__ double tab[64];
-    if (threadIdx.x < 64) tab[threadIdx.x] = wk.exp_tab[threadIdx.x];
+    __shared__ double tab[FEXP_TN];
+    for (int e = threadIdx.x; e < FEXP_TN; e += blockDim.x) tab[e] = wk.exp_tab[e];
     __syncthreads();
     const int npad = md.npad, lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -969,9 +987,9 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
 template <int KC>
 __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ rowmom,
                                                     double* __restrict__ cpart, int njs) {
-    __shared__ double tab[64];
+    __shared__ double tab[FEXP_TN];
     extern __shared__ __attribute__((aligned(16))) double csl[];   // [4][jw]
-    if (threadIdx.x < 64) tab[threadIdx.x] = wk.exp_tab[threadIdx.x];
+    for (int e = threadIdx.x; e < FEXP_TN; e += blockDim.x) tab[e] = wk.exp_tab[e];
     __syncthreads();
     const int npad = md.npad, D = md.D, E = md.E;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1979,8 +1997,8 @@ __global__ void k_selftest_mfma(double* out) {
 
 // max relative deviation of the table-driven exp from the library exp over [-720, 8]
 __global__ void k_selftest_fexp(const double* tab_g, double* out) {
-    __shared__ double tab[64];
-    if (threadIdx.x < 64) tab[threadIdx.x] = tab_g[threadIdx.x];
+    __shared__ double tab[FEXP_TN];
+    for (int e = threadIdx.x; e < FEXP_TN; e += blockDim.x) tab[e] = tab_g[e];
     __syncthreads();
     double worst = 0.0;
     for (int i = threadIdx.x; i < 200000; i += blockDim.x) {
@@ -1994,6 +2012,8 @@ __global__ void k_selftest_fexp(const double* tab_g, double* out) {
     for (int off = 32; off > 0; off >>= 1) worst = fmax(worst, __shfl_down(worst, off));
     if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = worst;
 }
+
+int mm_exp_table_size() { return FEXP_TN; }
 
 int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf, const double* exp_tab) {
     hipLaunchKernelGGL(k_selftest_fexp, dim3(1), dim3(256), 0, st, exp_tab, dbuf);
