@@ -1016,19 +1016,34 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
 #pragma unroll
         for (int c = 0; c < KC; ++c) rf[rt][c] = At[(long)(4 * c + lr) * npad + irow[rt]];
     }
-    const bool dsel = lc <= D;   // rows of the column operand contracted by the second product: w_j (d < D) and the ones
+    // buffer loads: uniform resource + per-lane byte offset + scalar column offset (no 64-bit VALU address math)
+    const __amdgpu_buffer_rsrc_t rB = buf_rsrc(Bt), rbeta = buf_rsrc(beta_b);
+    const __amdgpu_buffer_rsrc_t rIK = buf_rsrc(iKa ? iKa + (long)jbeg * npad : Bt);
+    unsigned cf_off[KC], a2_off[4], bc_off[4], ik_off[BWD_RT][4];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) cf_off[c] = ((unsigned)(4 * c + lr) * (unsigned)npad + (unsigned)lc) * 8u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        bc_off[r] = (unsigned)(lr + 4 * r) * 8u;
+        // rows of the column operand contracted by the second product: w_j (d < D) and the ones (d = D); lanes past
+        // that repeat row D: their result rows (d > D of rowmom) are never read
+        a2_off[r] = ((unsigned)(lc <= D ? lc : D) * (unsigned)npad + (unsigned)(4 * r + lr)) * 8u;
+#pragma unroll
+        for (int rt = 0; rt < BWD_RT; ++rt) ik_off[rt][r] = ((unsigned)(lr + 4 * r) * (unsigned)npad + (unsigned)irow[rt]) * 8u;
+    }
     d4 acc[BWD_RT];
 #pragma unroll
     for (int rt = 0; rt < BWD_RT; ++rt) acc[rt] = d4{0.0, 0.0, 0.0, 0.0};
     double* myslice = csl + w * jw;
     for (int j0 = jbeg; j0 < jend; j0 += 16) {
         double cf[KC], a2[4], bcol[4];
+        const unsigned so = (unsigned)j0 * 8u;
 #pragma unroll
-        for (int c = 0; c < KC; ++c) cf[c] = Bt[(long)(4 * c + lr) * npad + j0 + lc];
+        for (int c = 0; c < KC; ++c) cf[c] = buf_ld(rB, cf_off[c], so);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            bcol[r] = beta_b[j0 + lr + 4 * r];
-            a2[r] = dsel ? Bt[(long)lc * npad + j0 + 4 * r + lr] : 0.0;
+            bcol[r] = buf_ld(rbeta, bc_off[r], so);
+            a2[r] = buf_ld(rB, a2_off[r], so);
         }
         double csum[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1041,7 +1056,7 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double wgt = brow[rt] * bcol[r];
-                if (iKa) wgt -= iKa[(long)(j0 + lr + 4 * r) * npad + irow[rt]];   // iK is symmetric: coalesced along the rows
+                if (iKa) wgt -= buf_ld(rIK, ik_off[rt][r], (unsigned)(j0 - jbeg) * (unsigned)npad * 8u);   // iK symmetric: coalesced along the rows
                 wl[r] = wgt * fexp(e[r], tab);
                 csum[r] += wl[r];
             }
