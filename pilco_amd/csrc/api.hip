@@ -1315,7 +1315,7 @@ int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double
     ENSURE(s.bwd_mom, (size_t)P * njs * 16 * npad);
     ENSURE(s.bwd_cp, (size_t)std::max(1, P - E) * nrb * npad);
     ENSURE(s.bwd_part, (size_t)(P + E) * mm_bwd_rc(npad) * (1 + rec + D));   // pair partials, then mean partials
-    ENSURE(s.bwd_out, (size_t)(E + P) * rec);
+    ENSURE(s.bwd_out, (size_t)(E + P) * rec + (size_t)(E + P) * (D * D + D + 2));   // contributions | head records
     const size_t n_in = (size_t)D + D * D + nb, n_out = (size_t)(E + P) * rec;
     if (ctx->pin_cap < n_in + n_out) {
         if (ctx->pin) (void)hipHostFree(ctx->pin);
@@ -1335,7 +1335,7 @@ int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double
     const double* bars = s.wk.in_s + D * D;
     const MMModel md = model_of(s);
     launch_mm_prep(ctx->st, md, s.wk);
-    launch_mm_bwd(ctx->st, md, s.wk, s.bwd_mom.p, s.bwd_cp.p, s.bwd_part.p, bars, s.bwd_out.p);
+    launch_mm_bwd(ctx->st, md, s.wk, s.bwd_mom.p, s.bwd_cp.p, s.bwd_part.p, bars, s.bwd_out.p + (size_t)(E + P) * rec, s.bwd_out.p);
     HIPCHK(hipMemcpyAsync(ctx->pin + n_in, s.bwd_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());

@@ -984,11 +984,78 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
 #ifndef BWD_RT
 #define BWD_RT 2
 #endif
+// Per-step constants of the reverse pass, computed once by spare workgroups of the k_mm_bwd_pair launch and read by
+// k_mm_bwd_post / k_mm_bwd_fin:   head[h][D*D + D + 2]
+//   output a (h = a):      T = (s + Lambda_a^2)^-1 | u = T Vbar_a | mu = Mbar_a - sum_b (Sbar_ab + Sbar_ba) M_b | c_a
+//   pair pl (h = E + pl):  P = (I + Lambda_ab s)^-1 | lambda_ab | kappa = Shat_ab / sqrt(det R_ab) | 0
+// M_b comes from the mean partials the prep kernel of the same step left in wk.mean_part.
+__device__ void bwd_head(const MMModel& md, const MMWork& wk, const double* __restrict__ bars, int h,
+                         double* __restrict__ head, double* sm) {
+    const int D = md.D, E = md.E, t = threadIdx.x, nc = 2 * D, nI = D * D;
+    double* G0 = sm;               // [D][2D]
+    double* G1 = G0 + D * nc;      // [D][2D]
+    double* lam = G1 + D * nc;     // [D]
+    const double* Mbar = bars;
+    const double* Sbar = bars + E;
+    const double* Vbar = bars + E + E * E;
+    double* o = head + (long)h * (nI + D + 2);
+    int a = h, b = h;
+    if (h >= E) local_pair_ab(wk, E, h - E, a, b);
+    if (t < D) {
+        const double la = md.ls[a * D + t], lb = md.ls[b * D + t];
+        lam[t] = (h < E) ? la * la : 1.0 / (la * la) + 1.0 / (lb * lb);
+    }
+    __syncthreads();
+    for (int e = t; e < D * nc; e += 256) {
+        const int r = e / nc, c = e - r * nc;
+        double v;
+        if (c >= D) v = (c - D == r) ? 1.0 : 0.0;
+        else if (h < E) v = wk.in_s[r * D + c] + (r == c ? lam[r] : 0.0);        // s + Lambda_a^2
+        else v = lam[r] * wk.in_s[r * D + c] + (r == c ? 1.0 : 0.0);             // I + Lambda_ab s
+        G0[e] = v;
+    }
+    double det;
+    const double* G = gauss_jordan(G0, G1, D, nc, det);   // inverse in G[:, D:]
+    if (t < nI) o[t] = G[(t / D) * nc + D + (t % D)];
+    if (h < E) {
+        if (t < D) {
+            double acc = 0.0;
+            for (int c = 0; c < D; ++c) acc = fma(G[t * nc + D + c], Vbar[c * E + a], acc);
+            o[nI + t] = acc;
+        }
+        if (t == 64) {
+            double mu = Mbar[a];
+            for (int bb = 0; bb < E; ++bb) {
+                double Mb = 0.0;
+                for (int ch = 0; ch < wk.NCH; ++ch) Mb += wk.mean_part[((long)bb * wk.NCH + ch) * (1 + D)];
+                mu -= (Sbar[a * E + bb] + Sbar[bb * E + a]) * Mb;
+            }
+            double lp = 1.0;
+            for (int d = 0; d < D; ++d) lp *= md.ls[a * D + d];
+            o[nI + D] = mu;
+            o[nI + D + 1] = md.var[a] * lp / sqrt(det);
+        }
+    } else {
+        if (t < D) o[nI + t] = lam[t];
+        if (t == 64) {
+            const double shat = (a == b) ? Sbar[a * E + a] : Sbar[a * E + b] + Sbar[b * E + a];
+            o[nI + D] = shat / sqrt(det);   // det(I + Lambda s) = det(s Lambda + I) = det R_ab
+            o[nI + D + 1] = 0.0;
+        }
+    }
+}
+
 template <int KC>
 __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ rowmom,
-                                                    double* __restrict__ cpart, int njs) {
+                                                    double* __restrict__ cpart, int njs, const double* __restrict__ bars,
+                                                    double* __restrict__ head) {
     __shared__ double tab[FEXP_TN];
-    extern __shared__ __attribute__((aligned(16))) double csl[];   // [4][jw]
+    extern __shared__ __attribute__((aligned(16))) double csl[];   // [4][jw]  (head workgroups: Gauss-Jordan scratch)
+    if ((int)blockIdx.y >= wk.PL) {   // spare workgroups: the step's D x D inverses, one per output / pair
+        const int h = ((int)blockIdx.y - wk.PL) * (int)(gridDim.x * gridDim.z) + (int)(blockIdx.z * gridDim.x + blockIdx.x);
+        if (h < md.E + wk.PL) bwd_head(md, wk, bars, h, head, csl);
+        return;
+    }
     for (int e = threadIdx.x; e < FEXP_TN; e += blockDim.x) tab[e] = wk.exp_tab[e];
     __syncthreads();
     const int npad = md.npad, D = md.D, E = md.E;
@@ -1096,55 +1163,20 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
 //   mbar_a = c (T sum l_i q_i zeta_i - g u),
 //   sbar_a = -phi T / 2 + c T (sum l_i q_i zeta_i zeta_i^T) T / 2 - c (u (T h)^T + (T h) u^T) / 2,  phi = c (mu g + Vbar_a . T h).
 // M_b is read from the mean partials the prep kernel of the same step left in wk.mean_part.
-// Common head of the two stages: T (returned, [D][2D] with T in the right half), u, mu, c_a in LDS.
-__device__ const double* bwd_mean_head(const MMModel& md, const MMWork& wk, const double* __restrict__ bars, int a,
-                                       double* G0, double* G1, double* u, double* sc) {
-    const int D = md.D, E = md.E, t = threadIdx.x, nc = 2 * D;
-    const double* Mbar = bars;
-    const double* Sbar = bars + E;
-    const double* Vbar = bars + E + E * E;
-    for (int e = t; e < D * nc; e += 256) {
-        const int r = e / nc, c = e - r * nc;
-        const double l = md.ls[a * D + r];
-        G0[e] = (c < D) ? wk.in_s[r * D + c] + (r == c ? l * l : 0.0) : (c - D == r ? 1.0 : 0.0);
-    }
-    double det;
-    const double* G = gauss_jordan(G0, G1, D, nc, det);   // T = G[:, D:]
-    if (t < D) {
-        double acc = 0.0;
-        for (int c = 0; c < D; ++c) acc = fma(G[t * nc + D + c], Vbar[c * E + a], acc);
-        u[t] = acc;
-    }
-    if (t == 64) {
-        double mu = Mbar[a];
-        for (int b = 0; b < E; ++b) {
-            double Mb = 0.0;
-            for (int ch = 0; ch < wk.NCH; ++ch) Mb += wk.mean_part[((long)b * wk.NCH + ch) * (1 + D)];
-            mu -= (Sbar[a * E + b] + Sbar[b * E + a]) * Mb;
-        }
-        double lp = 1.0;
-        for (int d = 0; d < D; ++d) lp *= md.ls[a * D + d];
-        sc[0] = mu;
-        sc[1] = md.var[a] * lp / sqrt(det);
-    }
-    __syncthreads();
-    return G;
-}
-
 // stage 1 (a workgroup of k_mm_bwd_post): sums over the 64-point blocks rc, rc + nrc, ..:  mpart[a][rc][D*D + 2D + 1]
-__device__ void bwd_mean_partial(const MMModel& md, const MMWork& wk, const double* __restrict__ bars, int a, int rc,
+__device__ void bwd_mean_partial(const MMModel& md, const MMWork& wk, const double* __restrict__ head, int a, int rc,
                                  int nrc, double* __restrict__ mpart, double* sm) {
     const int D = md.D, npad = md.npad, t = threadIdx.x;
-    const int nI = D * D, nc = 2 * D, LD = D | 1;
-    double* G0 = sm;                // [D][2D]
-    double* G1 = G0 + D * nc;       // [D][2D]
-    double* zs = G1 + D * nc;       // [64][LD]
+    const int nI = D * D, LD = D | 1;
+    double* T = sm;                 // [D][D]
+    double* zs = T + nI;            // [64][LD]
     double* lv = zs + 64 * LD;      // [64]
     double* lq = lv + 64;           // [64]
-    double* u = lq + 64;            // [D]
-    double* sc = u + D;             // [2]
-    const double* G = bwd_mean_head(md, wk, bars, a, G0, G1, u, sc);
-    const double mu = sc[0];
+    double* u = lq + 64;            // [D + 2]: u | mu | c_a
+    const double* hd = head + (long)a * (nI + D + 2);
+    for (int e = t; e < nI + D + 2; e += 256) (e < nI ? T[e] : u[e - nI]) = hd[e];
+    __syncthreads();
+    const double mu = u[D];
     double acc = 0.0;
     for (int blk = rc; blk < npad / 64; blk += nrc) {
         if (t < 64) {
@@ -1156,7 +1188,7 @@ __device__ void bwd_mean_partial(const MMModel& md, const MMWork& wk, const doub
                 for (int d = 0; d < D; ++d) zs[t * LD + d] = md.Pt[(long)d * npad + i] - wk.in_m[d];
                 for (int r = 0; r < D; ++r) {
                     double tz = 0.0;
-                    for (int c = 0; c < D; ++c) tz = fma(G[r * nc + D + c], zs[t * LD + c], tz);
+                    for (int c = 0; c < D; ++c) tz = fma(T[r * D + c], zs[t * LD + c], tz);
                     quad = fma(zs[t * LD + r], tz, quad);
                     q = fma(zs[t * LD + r], u[r], q);
                 }
@@ -1170,15 +1202,15 @@ __device__ void bwd_mean_partial(const MMModel& md, const MMWork& wk, const doub
         __syncthreads();
         if (t < nI) {
             const int d = t / D, e2 = t - d * D;
-            for (int ii = 0; ii < 64; ++ii) acc = fma(lq[ii] * zs[ii * LD + d], zs[ii * LD + e2], acc);
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc = fma(lq[ii] * zs[ii * LD + d], zs[ii * LD + e2], acc);
         } else if (t < nI + D) {
             const int d = t - nI;
-            for (int ii = 0; ii < 64; ++ii) acc = fma(lq[ii], zs[ii * LD + d], acc);
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc = fma(lq[ii], zs[ii * LD + d], acc);
         } else if (t < nI + 2 * D) {
             const int d = t - nI - D;
-            for (int ii = 0; ii < 64; ++ii) acc = fma(lv[ii], zs[ii * LD + d], acc);
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc = fma(lv[ii], zs[ii * LD + d], acc);
         } else if (t == nI + 2 * D) {
-            for (int ii = 0; ii < 64; ++ii) acc += lv[ii];
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc += lv[ii];
         }
         __syncthreads();
     }
@@ -1186,59 +1218,59 @@ __device__ void bwd_mean_partial(const MMModel& md, const MMWork& wk, const doub
 }
 
 // stage 2 (a workgroup of k_mm_bwd_fin): out[a][D + D*D]
-__device__ void bwd_mean_final(const MMModel& md, const MMWork& wk, const double* __restrict__ bars, int a, int nrc,
-                               const double* __restrict__ mpart, double* __restrict__ out, double* sm) {
+__device__ void bwd_mean_final(const MMModel& md, const double* __restrict__ bars, const double* __restrict__ head, int a,
+                               int nrc, const double* __restrict__ mpart, double* __restrict__ out, double* sm) {
     const int D = md.D, E = md.E, t = threadIdx.x;
-    const int nI = D * D, nc = 2 * D;
-    double* G0 = sm;                // [D][2D]
-    double* G1 = G0 + D * nc;       // [D][2D]
-    double* u = G1 + D * nc;        // [D]
-    double* sc = u + D;             // [4]  mu, c_a, phi
-    double* Th = sc + 4;            // [D]
+    const int nI = D * D;
+    double* T = sm;                 // [D][D]
+    double* u = T + nI;             // [D + 2]: u | mu | c_a
+    double* sc = u + D + 2;         // [2]  phi
+    double* Th = sc + 2;            // [D]
     double* red = Th + D;           // [nI + 2 D + 1]   H2q | wq | h | g
     double* TH = red + nI + 2 * D + 1;  // [D][D]
     const double* Vbar = bars + E + E * E;
-    const double* G = bwd_mean_head(md, wk, bars, a, G0, G1, u, sc);
-    const double mu = sc[0], c_a = sc[1];
+    const double* hd = head + (long)a * (nI + D + 2);
+    for (int e = t; e < nI + D + 2; e += 256) (e < nI ? T[e] : u[e - nI]) = hd[e];
     if (t <= nI + 2 * D) {
         double acc = 0.0;
         for (int c = 0; c < nrc; ++c) acc += mpart[((long)a * nrc + c) * (nI + 2 * D + 1) + t];   // fixed order
         red[t] = acc;
     }
     __syncthreads();
+    const double mu = u[D], c_a = u[D + 1];
     const double* H2q = red;
     const double* wq = red + nI;
     const double* h = red + nI + D;
     const double g = red[nI + 2 * D];
     if (t < D) {
         double acc2 = 0.0;
-        for (int c = 0; c < D; ++c) acc2 = fma(G[t * nc + D + c], h[c], acc2);
+        for (int c = 0; c < D; ++c) acc2 = fma(T[t * D + c], h[c], acc2);
         Th[t] = acc2;
     }
     if (t < nI) {
         const int r = t / D, c = t - r * D;
         double acc2 = 0.0;
-        for (int k = 0; k < D; ++k) acc2 = fma(G[r * nc + D + k], H2q[k * D + c], acc2);
+        for (int k = 0; k < D; ++k) acc2 = fma(T[r * D + k], H2q[k * D + c], acc2);
         TH[t] = acc2;
     }
     __syncthreads();
     if (t == 0) {
         double vTh = 0.0;
         for (int d = 0; d < D; ++d) vTh = fma(Vbar[d * E + a], Th[d], vTh);
-        sc[2] = c_a * (mu * g + vTh);
+        sc[0] = c_a * (mu * g + vTh);
     }
     __syncthreads();
-    const double phi = sc[2];
+    const double phi = sc[0];
     double* o = out + (long)a * (D + nI);
     if (t < nI) {
         const int r = t / D, c = t - r * D;
         double acc2 = 0.0;
-        for (int k = 0; k < D; ++k) acc2 = fma(TH[r * D + k], G[k * nc + D + c], acc2);
-        o[D + t] = -0.5 * phi * G[r * nc + D + c] + 0.5 * c_a * acc2 - 0.5 * c_a * (u[r] * Th[c] + Th[r] * u[c]);
+        for (int k = 0; k < D; ++k) acc2 = fma(TH[r * D + k], T[k * D + c], acc2);
+        o[D + t] = -0.5 * phi * T[r * D + c] + 0.5 * c_a * acc2 - 0.5 * c_a * (u[r] * Th[c] + Th[r] * u[c]);
     } else if (t < nI + D) {
         const int r = t - nI;
         double tw = 0.0;
-        for (int c = 0; c < D; ++c) tw = fma(G[r * nc + D + c], wq[c], tw);
+        for (int c = 0; c < D; ++c) tw = fma(T[r * D + c], wq[c], tw);
         o[r] = c_a * (tw - g * u[r]);
     }
 }
@@ -1249,12 +1281,12 @@ constexpr int BWD_RC = 16;  // row chunks per pair / output
 __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, const double* __restrict__ rowmom,
                                                     const double* __restrict__ cpart, int njs, int nrb,
                                                     double* __restrict__ part, int nrc,
-                                                    const double* __restrict__ bars, double* __restrict__ mpart) {
+                                                    const double* __restrict__ head, double* __restrict__ mpart) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int npad = md.npad, D = md.D, E = md.E, t = threadIdx.x;
     const int pl = blockIdx.x, rc = blockIdx.y;
     if (pl >= wk.PL) {   // the last E workgroup columns: mean part of output pl - PL
-        bwd_mean_partial(md, wk, bars, pl - wk.PL, rc, nrc, mpart, sm);
+        bwd_mean_partial(md, wk, head, pl - wk.PL, rc, nrc, mpart, sm);
         return;
     }
     int a, b;
@@ -1267,8 +1299,17 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
     double* ms = ws + 64 * LD;    // [64][LD]
     double* rs = ms + 64 * LD;    // [64]
     double* cs = rs + 64;         // [64]
+    double* ia = cs + 64;         // [D] 1 / l_a^2
+    double* ib = ia + D;          // [D] 1 / l_b^2
+    double* mm = ib + D;          // [D] input mean
     const int nI = D * D;
     const int nblk = npad / 64;
+    if (t < D) {
+        const double la = md.ls[a * D + t], lb = md.ls[b * D + t];
+        ia[t] = 1.0 / (la * la);
+        ib[t] = 1.0 / (lb * lb);
+        mm[t] = wk.in_m[t];
+    }
     double acc = 0.0;
     for (int blk = rc; blk < nblk; blk += nrc) {
         const int i0 = blk * 64;
@@ -1277,10 +1318,9 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
             const int d = e >> 6, ii = e & 63;   // consecutive threads -> consecutive points: coalesced
             const int i = i0 + ii;
             const bool valid = i < md.n;
-            const double zeta = valid ? md.Pt[(long)d * npad + i] - wk.in_m[d] : 0.0;
-            const double la = md.ls[a * D + d], lb = md.ls[b * D + d];
-            zs[ii * LD + d] = zeta / (la * la);
-            ws[ii * LD + d] = zeta / (lb * lb);
+            const double zeta = valid ? md.Pt[(long)d * npad + i] - mm[d] : 0.0;
+            zs[ii * LD + d] = zeta * ia[d];
+            ws[ii * LD + d] = zeta * ib[d];
             double mv = 0.0;
             if (valid)
                 for (int q = 0; q < njs; ++q) mv += mom0[((long)q * 16 + d) * npad + i];
@@ -1303,7 +1343,7 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
         __syncthreads();
         if (t < nI) {
             const int d = t / D, e2 = t - d * D;
-            for (int ii = 0; ii < 64; ++ii) {
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) {
                 const double zd = zs[ii * LD + d], ze = zs[ii * LD + e2];
                 acc = fma(rs[ii] * zd, ze, acc);
                 acc = fma(cs[ii] * ws[ii * LD + d], ws[ii * LD + e2], acc);
@@ -1312,9 +1352,9 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
             }
         } else if (t < nI + D) {
             const int d = t - nI;
-            for (int ii = 0; ii < 64; ++ii) acc = fma(rs[ii], zs[ii * LD + d], fma(cs[ii], ws[ii * LD + d], acc));
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc = fma(rs[ii], zs[ii * LD + d], fma(cs[ii], ws[ii * LD + d], acc));
         } else if (t == nI + D) {
-            for (int ii = 0; ii < 64; ++ii) acc += rs[ii];
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc += rs[ii];
         }
     }
     double* o = part + ((long)pl * nrc + rc) * (1 + D + nI);
@@ -1323,52 +1363,40 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
     else if (t == nI + D) o[0] = acc;
 }
 
-// Per pair: P = (I + Lambda s)^-1, kappa = Shat_ab / sqrt(det R_ab), and the pair's contribution
+// Per pair, with P = (I + Lambda s)^-1 and kappa = Shat_ab / sqrt(det R_ab) from the step's head record:
 //   mbar += kappa P A,   sbar += kappa (P I P^T / 2 - N (P Lambda + Lambda P^T) / 4)      
-// out[E + pl][D + D*D].  bars = (Mbar [E] | Sbar [E][E] | Vbar [D][E]) on the device.
+// out[E + pl][D + D*D].  bars = (Mbar [E] | Sbar [E][E] | Vbar [D][E]) on the device.  Workgroups past the pairs
+// finish the mean part of one output each.
 __global__ __launch_bounds__(256) void k_mm_bwd_fin(MMModel md, MMWork wk, const double* __restrict__ part, int nrc,
-                                                   const double* __restrict__ bars, const double* __restrict__ mpart,
-                                                   double* __restrict__ out) {
+                                                   const double* __restrict__ bars, const double* __restrict__ head,
+                                                   const double* __restrict__ mpart, double* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x;
     if (pl >= wk.PL) {
-        bwd_mean_final(md, wk, bars, pl - wk.PL, nrc, mpart, out, sm);
+        bwd_mean_final(md, bars, head, pl - wk.PL, nrc, mpart, out, sm);
         return;
     }
-    int a, b;
-    local_pair_ab(wk, E, pl, a, b);
-    const int nI = D * D, rec = 1 + D + nI, nc = 2 * D;
-    double* G0 = sm;               // [D][2D]
-    double* G1 = G0 + D * nc;      // [D][2D]
-    double* Iv = G1 + D * nc;      // [rec]  summed partials (N | A | I)
+    const int nI = D * D, rec = 1 + D + nI;
+    double* Pm = sm;               // [D][D]
+    double* lam = Pm + nI;         // [D + 2]: lambda | kappa
+    double* Iv = lam + D + 2;      // [rec]  summed partials (N | A | I)
     double* PI = Iv + rec;         // [D][D]
-    double* lam = PI + nI;         // [D]
+    const double* hd = head + (long)(E + pl) * (nI + D + 2);
+    for (int e = t; e < nI + D + 2; e += 256) (e < nI ? Pm[e] : lam[e - nI]) = hd[e];
     for (int e = t; e < rec; e += 256) {
         double acc = 0.0;
         for (int c = 0; c < nrc; ++c) acc += part[((long)pl * nrc + c) * rec + e];   // fixed order
         Iv[e] = acc;
     }
-    if (t < D) {
-        const double la = md.ls[a * D + t], lb = md.ls[b * D + t];
-        lam[t] = 1.0 / (la * la) + 1.0 / (lb * lb);
-    }
     __syncthreads();
-    for (int e = t; e < D * nc; e += 256) {
-        const int r = e / nc, c = e - r * nc;
-        G0[e] = (c < D) ? lam[r] * wk.in_s[r * D + c] + (r == c ? 1.0 : 0.0) : (c - D == r ? 1.0 : 0.0);
-    }
-    double det;
-    const double* G = gauss_jordan(G0, G1, D, nc, det);   // P = G[:, D:]
-    const double* Sbar = bars + E;
-    const double shat = (a == b) ? Sbar[a * E + a] : Sbar[a * E + b] + Sbar[b * E + a];
-    const double kappa = shat / sqrt(det);   // det(I + Lambda s) = det(s Lambda + I) = det R_ab
+    const double kappa = lam[D];
     const double Nab = Iv[0];
     const double* Av = Iv + 1;
     const double* Im = Iv + 1 + D;
     if (t < nI) {
         const int r = t / D, c = t - r * D;
         double acc = 0.0;
-        for (int k = 0; k < D; ++k) acc = fma(G[r * nc + D + k], Im[k * D + c], acc);
+        for (int k = 0; k < D; ++k) acc = fma(Pm[r * D + k], Im[k * D + c], acc);
         PI[t] = acc;
     }
     __syncthreads();
@@ -1376,13 +1404,13 @@ __global__ __launch_bounds__(256) void k_mm_bwd_fin(MMModel md, MMWork wk, const
     if (t < nI) {
         const int r = t / D, c = t - r * D;
         double acc = 0.0;
-        for (int k = 0; k < D; ++k) acc = fma(PI[r * D + k], G[c * nc + D + k], acc);   // (P I P^T)[r][c]
-        const double pl2 = G[r * nc + D + c] * lam[c] + G[c * nc + D + r] * lam[r];     // P Lambda + Lambda P^T
+        for (int k = 0; k < D; ++k) acc = fma(PI[r * D + k], Pm[c * D + k], acc);   // (P I P^T)[r][c]
+        const double pl2 = Pm[r * D + c] * lam[c] + Pm[c * D + r] * lam[r];         // P Lambda + Lambda P^T
         o[D + t] = kappa * (0.5 * acc - 0.25 * Nab * pl2);
     } else if (t < nI + D) {
         const int r = t - nI;
         double acc = 0.0;
-        for (int c = 0; c < D; ++c) acc = fma(G[r * nc + D + c], Av[c], acc);
+        for (int c = 0; c < D; ++c) acc = fma(Pm[r * D + c], Av[c], acc);
         o[r] = kappa * acc;
     }
 }
@@ -1395,13 +1423,15 @@ void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb) {
 }
 
 void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* part,
-                   const double* bars, double* out) {
+                   const double* bars, double* head, double* out) {
     const int P = wk.PL, E = md.E, D = md.D;
     int njs, nrb;
     mm_bwd_geometry(md.npad, P, &njs, &nrb);
-    dim3 grid(nrb, P, njs);
-    const size_t lds_pair = sizeof(double) * 4 * (md.npad / njs);
-#define PB(K_) hipLaunchKernelGGL((k_mm_bwd_pair<K_>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs)
+    const int nhead = E + P, per_row = nrb * njs;
+    dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);   // the rows past P hold the head workgroups
+    const int LD = D | 1, nI = D * D;
+    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * (md.npad / njs), (size_t)4 * nI + D);
+#define PB(K_) hipLaunchKernelGGL((k_mm_bwd_pair<K_>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head)
     switch (wk.KP / 4) {
         case 1: PB(1); break;
         case 2: PB(2); break;
@@ -1409,15 +1439,13 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
         default: PB(4); break;
     }
 #undef PB
-    const int LD = D | 1, nI = D * D;
     const int nrc = mm_bwd_rc(md.npad);
     double* mpart = part + (size_t)P * nrc * (1 + D + nI);
-    const size_t lds_post = sizeof(double) * std::max((size_t)3 * 64 * LD + 128, (size_t)4 * D * D + 64 * LD + 128 + D + 2);
+    const size_t lds_post = sizeof(double) * std::max((size_t)3 * 64 * LD + 128 + 3 * D, (size_t)nI + 64 * LD + 128 + D + 2);
     hipLaunchKernelGGL(k_mm_bwd_post, dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
-                       bars, mpart);
-    const size_t lds_fin = sizeof(double) * std::max((size_t)4 * D * D + 1 + D + nI + nI + D,
-                                                     (size_t)4 * D * D + D + 4 + D + nI + 2 * D + 1 + nI);
-    hipLaunchKernelGGL(k_mm_bwd_fin, dim3(P + E), dim3(256), lds_fin, st, md, wk, part, nrc, bars, mpart, out);
+                       head, mpart);
+    const size_t lds_fin = sizeof(double) * ((size_t)3 * nI + 4 * D + 8);
+    hipLaunchKernelGGL(k_mm_bwd_fin, dim3(P + E), dim3(256), lds_fin, st, md, wk, part, nrc, bars, head, mpart, out);
 }
 int mm_bwd_rc(int npad) { return std::min(BWD_RC, npad / 64); }
 
