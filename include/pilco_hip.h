@@ -147,6 +147,13 @@ int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double
 int pilco_rollout_tape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
                        const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj,
                        double* tape);
+/* Value and gradient of the rollout reward w.r.t. a squashed LinearController's parameters, dW (U,E) and db (U):
+ * training_loss + TensorFlow reverse mode in the reference (pilco/models/pilco.py:47-50,85-90).  Forward rollout
+ * with a tape, then the reverse sweep with the moment-matching adjoint of every step on the device and the O(D^3)
+ * links (propagate, joint Gaussian, controller + squash, rewards) in native host code.  Other policies: drive
+ * pilco_rollout_tape + pilco_gp_predict_vjp from the caller (pilco_amd/adjoint.py does for the RBF policy). */
+int pilco_rollout_grad(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                       const double* m0, const double* S0, int H, double* reward, double* dW, double* db);
 
 /* ------------------------------------------------------------------ timing / introspection */
 /* Time `reps` back-to-back rollouts with HIP events on the library's stream.

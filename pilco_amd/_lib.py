@@ -69,6 +69,8 @@ SIGNATURES = {
     "pilco_gp_predict_vjp": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "pilco_rollout_tape": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
                                      _dp, _dp, _dp, _dp, _dp]),
+    "pilco_rollout_grad": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
+                                     _dp, _dp, _dp]),
     "pilco_propagate": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp]),
     "pilco_policy_action": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp, _dp]),
     "pilco_reward_eval": (C.c_int, [_vp, C.POINTER(RewardTerm), C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
@@ -300,6 +302,17 @@ class Context:
         self._chk(self.lib.pilco_rollout_tape(self.h, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H),
                                               _ptr(mH), _ptr(SH), _ptr(rew), _ptr(traj), _ptr(tape)))
         return mH, SH, rew, traj, tape[:H]
+
+    def rollout_grad(self, policy, rewards, m0, S0, H):
+        """(reward, dW (U,E), db (U)) for a squashed linear policy: the native reverse sweep (pilco_rollout_grad)."""
+        E = policy["state_dim"]; U = policy["control_dim"]
+        p, k1 = self._policy(policy)
+        r, k2 = self._rewards(rewards, E)
+        m0 = _f64(m0, (E,)); S0 = _f64(S0, (E, E))
+        rew = np.zeros((1, 1)); dW = np.empty((U, E)); db = np.empty((U,))
+        self._chk(self.lib.pilco_rollout_grad(self.h, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H),
+                                              _ptr(rew), _ptr(dW), _ptr(db)))
+        return float(rew[0, 0]), dW, db
 
     def propagate(self, policy, m_x, s_x):
         E = policy["state_dim"]

@@ -555,6 +555,11 @@ def test_policy_gradient_adjoint_vs_autograd_and_fd(ctx):
     p.controller.W.assign(W0)
     r2, (Wb2, bb2) = rollout_value_and_grad(p)
     assert r2 == r and np.array_equal(Wb2, Wb) and np.array_equal(bb2, bb)
+    # the native sweep (pilco_rollout_grad) and the same sweep driven from Python agree to rounding
+    r3, (Wb3, bb3) = rollout_value_and_grad(p, native=False)
+    np.testing.assert_allclose(r3, r, rtol=1e-13)
+    np.testing.assert_allclose(Wb3, Wb, rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(bb3, bb, rtol=1e-9, atol=1e-13)
 
 
 def test_degenerate_dims_and_two_controls(ctx):
