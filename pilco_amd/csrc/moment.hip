@@ -398,6 +398,7 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk) {
     double* s_sc = s_T + DT * DT;      // [4] isdet, cfac
     double* red = s_sc + 4;            // 5 * (DT + 1)
     double* colbuf = red + 5 * (DT + 1);  // 2 * DT: pivot columns of the two Gauss-Jordan waves
+    double* zst = colbuf + 2 * DT;        // [256][DT + 1] centred points of the first 256 rows
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int grp = t >> 8, tl = t & 255;
     const int pl = blockIdx.x, ch = blockIdx.y;
@@ -428,6 +429,21 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk) {
     DBG_STAMP(wk, 1, dbg0);
     const int rpc = npad / wk.NCH;
     const int i_begin = ch * rpc, i_end = i_begin + rpc;
+    // The centred points of the chunk's first 256 rows are staged in LDS by the six waves that do not run a
+    // Gauss-Jordan, so their load latency (and the log of the signal variance) hides behind that phase.
+    const bool mean_role = diag && grp == 1;
+    const int side = diag ? 0 : grp;
+    constexpr int LDZ = DT + 1;
+    if (w != 0 && w != 4) {
+        const int idx = (w < 4 ? w - 1 : w - 2) * 64 + lane;   // 0..383
+        for (int e = idx; e < 256 * D; e += 384) {
+            const int d = e >> 8, r = e & 255;
+            const int i = i_begin + r;
+            zst[r * LDZ + d] = (i < md.n && i < i_end) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
+        }
+    }
+    const double beta0 = (mean_role && i_begin + tl < i_end) ? md.beta[(long)a * npad + i_begin + tl] : 0.0;
+    const double logvar = log(md.var[side ? b : a]);
     if (wk.abl & 2) {
         if (t == 0) { s_sc[0] = 1.0; s_sc[1] = 1.0; }
     } else if (w == 0) {
@@ -489,20 +505,14 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk) {
     double h[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) h[d] = 0.0;
-    const bool mean_role = diag && grp == 1;
-    for (int i = i_begin + tl; i < ((wk.abl & 4) ? i_begin : i_end); i += 256) {
-        const bool valid = i < md.n;
-        double zeta[DT];
-#pragma unroll
-        for (int d = 0; d < DT; ++d) zeta[d] = (d < D && valid) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
+    auto row = [&](const int i, const bool valid, const double (&zeta)[DT], const double bet) {
         if (!mean_role) {
             // y = Q x by columns of the symmetric Q: DT independent accumulators, one wide LDS row
             // read per column step (no LDS latency on the FMA chains).  side 0: x = zeta / la^2 -> row
             // operand (2 Q z | u | 1); side 1: x = zeta / lb^2 -> column operand (w | 1 | v).
-            const int side = diag ? 0 : grp;
             const double* il2 = side ? s_ib2 : s_ia2;   // padding entries are zero
             double x[DT], y[DT];
-            double kk = log(md.var[side ? b : a]);
+            double kk = logvar;
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
                 x[d] = zeta[d] * il2[d];
@@ -555,10 +565,26 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk) {
             double q = 0.0;
 #pragma unroll
             for (int r = 0; r < DT; ++r) q = fma(zeta[r], tz[r], q);
-            const double lb = exp(-0.5 * q) * md.beta[(long)a * npad + i];
+            const double lb = exp(-0.5 * q) * bet;
             g += lb;
 #pragma unroll
             for (int d = 0; d < DT; ++d) h[d] = fma(zeta[d], lb, h[d]);
+        }
+    };
+    if (!(wk.abl & 4)) {
+        if (i_begin + tl < i_end) {   // first row of this thread: centred point from the LDS stage
+            const int i = i_begin + tl;
+            double zeta[DT];
+#pragma unroll
+            for (int d = 0; d < DT; ++d) zeta[d] = (d < D) ? zst[tl * LDZ + d] : 0.0;
+            row(i, i < md.n, zeta, beta0);
+        }
+        for (int i = i_begin + tl + 256; i < i_end; i += 256) {   // chunks longer than 256 rows
+            const bool valid = i < md.n;
+            double zeta[DT];
+#pragma unroll
+            for (int d = 0; d < DT; ++d) zeta[d] = (d < D && valid) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
+            row(i, valid, zeta, mean_role ? md.beta[(long)a * npad + i] : 0.0);
         }
     }
     DBG_STAMP(wk, 3, dbg0);
@@ -596,7 +622,7 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk) {
 }
 
 size_t prep_lds_bytes(int DT) {
-    return sizeof(double) * ((size_t)4 * DT + 3 * (size_t)DT * DT + 4 + 5 * (size_t)(DT + 1) + 2 * (size_t)DT);
+    return sizeof(double) * ((size_t)4 * DT + 3 * (size_t)DT * DT + 4 + 5 * (size_t)(DT + 1) + 2 * (size_t)DT + 256 * (size_t)(DT + 1));
 }
 
 int mm_kp(int D) { return round_up(D + 2, 4); }
