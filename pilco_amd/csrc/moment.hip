@@ -916,7 +916,12 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
     for (int e = threadIdx.x; e < FEXP_TN; e += blockDim.x) tab[e] = wk.exp_tab[e];
     __syncthreads();
     const int npad = md.npad, lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (own L2 each), so workgroup b takes
+    // position (b % 8) * (blocks / 8) + b / 8 of the cost line: the waves of one XCD cover one contiguous eighth of it
+    // and its L2 holds the operands of ~1/8 of the pairs instead of all of them.
+    int bpos = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bpos = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int w = __builtin_amdgcn_readfirstlane(bpos * 4 + (threadIdx.x >> 6));
     const int NS = npad / 16;
     const int KP = wk.KP;
     DBG_STAMP(wk, 16, w == 0 && lane == 0);
