@@ -47,7 +47,7 @@ def test_gram_matches_oracle(ctx):
                                rtol=1e-12, atol=1e-15)
 
 
-@pytest.mark.parametrize("N", [100, 257])
+@pytest.mark.parametrize("N", [100, 257, 700])
 def test_factorization_matches_oracle(ctx, N):
     rs = np.random.RandomState(N)
     X = rs.randn(N, 4)
