@@ -123,6 +123,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     const int PLa = std::max(wk.PL, 1);
     // stream-K geometry (variant 0)
     wk.sk_waves = 0;
+    wk.sk_maxw = 0;
     if (ctx->variant == 0 && wk.PL > 0) {
         int tdiag, toff;
         mm_pair_sk_steps(npad, &tdiag, &toff);
@@ -147,20 +148,13 @@ int build_work(pilco_ctx* ctx, Slot& s) {
             int a = 0, b = 0;
             if (sscanf(env, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { wk.sk_ud = a; wk.sk_uo = b; }
         }
+        wk.sk_maxw = mm_sk_maxw(wk);
     }
-    const size_t n_int = (size_t)2 * std::max(wk.sk_waves, 4);
-    if (n_int > s.lists_cap) {
-        if (s.d_lists) (void)hipFree(s.d_lists);
-        s.d_lists = nullptr;
-        HIPCHK(hipMalloc(&s.d_lists, n_int * sizeof(int)));
-        s.lists_cap = n_int;
-    }
-    wk.sk_pidx = s.d_lists;
     ENSURE(s.w_in, (size_t)D + D * D + E + E * E + D * E);   // m | s | cotangents (Mbar | Sbar | Vbar) of the reverse pass
     ENSURE(s.w_At, (size_t)PLa * wk.KP * npad);
     ENSURE(s.w_Bt, (size_t)PLa * wk.KP * npad);
     ENSURE(s.w_small, (size_t)PLa + (size_t)E * wk.NCH * (1 + D));
-    ENSURE(s.w_part, std::max((size_t)PLa * wk.NT * 2, (size_t)2 * std::max(wk.sk_waves, 4)));
+    ENSURE(s.w_part, std::max((size_t)PLa * wk.NT * 2, (size_t)PLa * std::max(wk.sk_maxw, 4)));
     ENSURE(s.w_gath, (size_t)W * wk.SEG);
     ENSURE(s.w_out, (size_t)E + E * E + D * E);
     wk.in_m = s.w_in.p;
@@ -178,6 +172,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.exp_tab = ctx->exp_tab.p;
     wk.dbg = ctx->dbg;
     HIPCHK(hipMemsetAsync(s.w_gath.p, 0, sizeof(double) * W * wk.SEG, ctx->st));
+    if (wk.sk_waves > 0) HIPCHK(hipMemsetAsync(s.w_part.p, 0, sizeof(double) * PLa * wk.sk_maxw, ctx->st));   // slots no wave writes
     s.wk_valid = true;
     s.wk_variant = ctx->variant;
     return PILCO_OK;

@@ -34,9 +34,8 @@ struct MMWork {
     // (0,0),(1,1),..,(E-1,E-1),(1,0),(2,0),(2,1),(3,0).. : order index kk -> rank kk % nranks,
     // local index kk / nranks; output a belongs to the owner of (a,a).
     // stream-K decomposition of the MFMA pair kernel (variant 0)
-    double* sk_part;     // [sk_waves][2] per-wave partial of the (at most two) pairs a wave touches
-    int* sk_pidx;        // [sk_waves][2] local pair index of each partial (-1 = none)
-    int sk_waves, sk_total, sk_nd, sk_tdiag, sk_toff;
+    double* sk_part;     // [PL][sk_maxw] stream-K partials, pair-major: slot = wave - first wave of the pair (unused slots stay zero)
+    int sk_waves, sk_total, sk_nd, sk_tdiag, sk_toff, sk_maxw;
     unsigned long long* dbg;  // optional [32] phase timestamps (100 MHz wall clock) of the last prep / glue launch
     int abl;             // experiment switches (PILCO_ABL, tools only; 0 in product use)
     int sk_ud, sk_uo;    // cost units of a diagonal / off-diagonal column step (diagonal steps also stream iK)
@@ -102,6 +101,7 @@ void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int var
 int mm_pair_sk_capacity(int KP);
 void mm_pair_sk_steps(int npad, int* tdiag, int* toff);
 int mm_sk_boundary(int w, int waves, int nd_steps, int total, int ud, int uo);
+int mm_sk_maxw(const MMWork& wk);   // needs the sk_* geometry fields and PL
 void launch_glue(hipStream_t st, const GlueArgs& g, bool with_reward_block = false);
 size_t glue_lds_bytes(int E, int D);
 // tile-partial counts per pair for a variant (NT) and the number of row chunks of the prep kernel

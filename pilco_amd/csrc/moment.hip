@@ -357,7 +357,7 @@ __device__ double exp_reward_moment(const RewardDev& rw, int E, double scale, co
 __host__ __device__ inline size_t reward_lds_doubles(int E) { return (size_t)E + 4 * (size_t)E * E + (size_t)E * (E + 1) + (size_t)E + 16; }
 
 // mean (and variance) of the combined reward at (mx, sx) held in LDS (rewards.py:19-81)
-__device__ void reward_eval(int n, const RewardDev* rws, int E, const double* mx, const double* sx, double* ws,
+__device__ __forceinline__ void reward_eval(int n, const RewardDev* rws, int E, const double* mx, const double* sx, double* ws,
                             bool want_var, double& mu_out, double& var_out) {
     double mu = 0.0, var = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -906,6 +906,16 @@ __host__ __device__ inline void sk_pair_waves(int k, int waves, int nd, int tdia
 __device__ __forceinline__ int sk_boundary(const MMWork& wk, int w) {
     return sk_boundary_of(w, wk.sk_waves, wk.sk_nd * wk.sk_tdiag, wk.sk_total, wk.sk_ud, wk.sk_uo);
 }
+// row stride of the pair-major partial array: the largest number of waves touching one local pair, rounded up to 4
+int mm_sk_maxw(const MMWork& wk) {
+    int m = 4;
+    for (int k = 0; k < wk.PL; ++k) {
+        int wlo, fs, whi;
+        sk_pair_waves(k, wk.sk_waves, wk.sk_nd, wk.sk_tdiag, wk.sk_toff, wk.sk_total, wk.sk_ud, wk.sk_uo, wlo, fs, whi);
+        m = std::max(m, whi - wlo + 1);
+    }
+    return (m + 3) / 4 * 4;
+}
 int mm_sk_boundary(int w, int waves, int nd_steps, int total, int ud, int uo) {
     return sk_boundary_of(w, waves, nd_steps, total, ud, uo);
 }
@@ -989,10 +999,15 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
         out1 += __shfl_down(out1, off);
     }
     if (lane == 0) {
-        wk.sk_part[2 * w] = out0;
-        wk.sk_part[2 * w + 1] = out1;
-        wk.sk_pidx[2 * w] = p0;
-        wk.sk_pidx[2 * w + 1] = p1;
+        // pair-major layout sk_part[pair][slot], slot = wave - (first wave of the pair): the reader (k_glue, one
+        // workgroup on the step's critical path) then needs no index arithmetic at all.  A wave that enters a pair from
+        // a previous one IS that pair's first wave (slot 0); only the first touched pair needs the closed form.
+        if (p0 >= 0) {
+            const long S0 = (p0 < wk.sk_nd) ? (long)p0 * wk.sk_tdiag : (long)wk.sk_nd * wk.sk_tdiag + (long)(p0 - wk.sk_nd) * wk.sk_toff;
+            const int wlo = sk_wave_of(S0, wk.sk_waves, nd_steps, wk.sk_total, wk.sk_ud, wk.sk_uo);
+            wk.sk_part[(long)p0 * wk.sk_maxw + (w - wlo)] = out0;
+        }
+        if (p1 >= 0) wk.sk_part[(long)p1 * wk.sk_maxw] = out1;
     }
     DBG_STAMP(wk, 17, w == 0 && lane == 0);
     DBG_STAMP(wk, 18, w == wk.sk_waves - 1 && lane == 0);
@@ -1688,7 +1703,7 @@ __device__ __forceinline__ void bulk_load(double* dst, const double* __restrict_
 }
 
 // squash_sin on (mu[U], su[U][U]) in place; cdiag[u] = e_u exp(-s_uu/2) cos(m_u)   (controllers.py:13-36)
-__device__ void squash_inplace(const GlueLds& L, int U, const double* maxact, double* cdiag) {
+__device__ __forceinline__ void squash_inplace(const GlueLds& L, int U, const double* maxact, double* cdiag) {
     const int t = threadIdx.x;
     for (int e = t; e < U * U; e += blockDim.x) {
         const int u = e / U, v = e - u * U;
@@ -1713,7 +1728,7 @@ __device__ void squash_inplace(const GlueLds& L, int U, const double* maxact, do
 }
 
 // joint Gaussian of (x,u) from mx,sx,mu,su,cxu in LDS -> in_m, in_s, s1 (pilco.py:141-144)
-__device__ void write_joint(const GlueArgs& g, const GlueLds& L) {
+__device__ __forceinline__ void write_joint(const GlueArgs& g, const GlueLds& L) {
     const int E = g.E, U = g.U, D = g.D, t = threadIdx.x;
     for (int e = t; e < E * U; e += blockDim.x) {  // sc = s_x c_xu  (E,U)
         const int r = e / U, u = e - r * U;
@@ -1750,29 +1765,24 @@ __device__ void write_joint(const GlueArgs& g, const GlueLds& L) {
 struct PackPre {
     double v[16];
     double isdet;
-    int qn, q1, wlo, fs;   // next unread wave, end of this thread's range, first wave of the pair and its slot
 };
+// stream-K partials of pair k live in sk_part[k][0 .. sk_maxw) in wave order (unused slots stay zero); lane gq of the
+// pair's four lanes takes the quarter [gq * sk_maxw / 4, (gq + 1) * sk_maxw / 4): 16 contiguous doubles = one cache line
+// at the usual sizes, addresses known from the thread index alone.
 __device__ __forceinline__ void mm_pack_issue(const MMWork& wk, int base, PackPre& pp) {
     const int t = threadIdx.x;
     const int k = base + (t >> 2), gq = t & 3;
     pp.isdet = 0.0;
-    pp.qn = pp.q1 = pp.wlo = pp.fs = 0;
 #pragma unroll
     for (int u = 0; u < 16; ++u) pp.v[u] = 0.0;
     if (k >= wk.PL) return;
     pp.isdet = wk.pair_isdet[k];
-    if (wk.sk_waves > 0) {  // stream-K partials of waves wlo..whi; every wave after the first holds this pair in slot 0
-        int whi;
-        sk_pair_waves(k, wk.sk_waves, wk.sk_nd, wk.sk_tdiag, wk.sk_toff, wk.sk_total, wk.sk_ud, wk.sk_uo, pp.wlo, pp.fs, whi);
-        const int n = whi - pp.wlo + 1;
-        const int q0 = pp.wlo + ((n * gq) >> 2);
-        pp.q1 = pp.wlo + ((n * (gq + 1)) >> 2);
+    if (wk.sk_waves > 0) {
+        const int qw = wk.sk_maxw >> 2;
+        const double* src = wk.sk_part + (long)k * wk.sk_maxw + gq * qw;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int q = q0 + u;
-            if (q < pp.q1) pp.v[u] = wk.sk_part[2 * q + ((q == pp.wlo) ? pp.fs : 0)];
-        }
-        pp.qn = q0 + 16;
+        for (int u = 0; u < 16; ++u)
+            if (u < qw) pp.v[u] = src[u];
     }
 }
 __device__ __forceinline__ void mm_pack_sum(const MMWork& wk, int base, const PackPre& pp, double& s0, double& s1) {
@@ -1784,16 +1794,9 @@ __device__ __forceinline__ void mm_pack_sum(const MMWork& wk, int base, const Pa
     if (wk.sk_waves > 0) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) s0 += pp.v[u];
-        for (int qb = pp.qn; qb < pp.q1; qb += 16) {   // long ranges (few pairs): 16 independent loads at a time
-            double v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int q = qb + u;
-                v[u] = (q < pp.q1) ? wk.sk_part[2 * q] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) s0 += v[u];
-        }
+        const int qw = wk.sk_maxw >> 2;
+        const double* src = wk.sk_part + (long)k * wk.sk_maxw + gq * qw;
+        for (int u = 16; u < qw; ++u) s0 += src[u];   // few pairs spread over many waves
     } else {
         const double* part = wk.pair_part + (long)k * wk.NT * 2;
         const int q0 = (int)((long)wk.NT * gq / 4), q1 = (int)((long)wk.NT * (gq + 1) / 4);
@@ -1804,7 +1807,7 @@ __device__ __forceinline__ void mm_pack_sum(const MMWork& wk, int base, const Pa
     }
 }
 
-__device__ void mm_pack(const MMWork& wk, int D, int E, const GlueLds& L, PackPre& pp) {
+__device__ __forceinline__ void mm_pack(const MMWork& wk, int D, int E, const GlueLds& L, PackPre& pp) {
     const int t = threadIdx.x;
     double* seg = wk.gath + (long)wk.rank * wk.SEG;
     for (int base = 0; base < wk.PL; base += 64) {
@@ -1836,7 +1839,7 @@ __device__ void mm_pack(const MMWork& wk, int D, int E, const GlueLds& L, PackPr
 }
 
 // packed results -> out_M [E], out_S [E][E], out_V [D][E]; also left in LDS (oM, oS, oV)
-__device__ void mm_assemble(const MMWork& wk, const double* src, const double* var, int D, int E, double* oM,
+__device__ __forceinline__ void mm_assemble(const MMWork& wk, const double* src, const double* var, int D, int E, double* oM,
                             double* oS, double* oV) {
     const int t = threadIdx.x;
     for (int a = t; a < E; a += blockDim.x) {
