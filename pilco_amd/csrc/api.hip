@@ -795,7 +795,16 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
     size_t evi = 0;
     for (int t = 0; t < H; ++t) {
         if (s.wk.PL > 0) {
-            launch_mm_prep(ctx->st, md, s.wk);
+            PrepReward pr{};
+            if (rew) {   // reward of state t rides in a spare workgroup of this step's prep launch
+                pr.n = g.n_rewards;
+                pr.E = E;
+                for (int i = 0; i < g.n_rewards; ++i) pr.rw[i] = g.rw[i];
+                pr.m_x = plan.st[t & 1];
+                pr.s_x = plan.st[t & 1] + E;
+                pr.reward = g.reward;
+            }
+            launch_mm_prep(ctx->st, md, s.wk, rew ? &pr : nullptr);
             if (ctx->dbg && (s.wk.abl & 64)) launch_stamp(ctx->st, ctx->dbg, 30);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
             launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
@@ -816,7 +825,7 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
             if (int r = all_gather_segments(ctx, s)) return r;
             g.flags = tail;
         }
-        launch_glue(ctx->st, g, rew);
+        launch_glue(ctx->st, g, rew && s.wk.PL == 0);   // (a rank without pairs keeps the reward in the glue launch)
         if (rbf && more) {  // the policy stage reads the NEW state
             g.m_x = g.m_out;
             g.s_x = g.s_out;

@@ -52,6 +52,17 @@ struct RewardDev {
     int rank;         // >= 0: factored fast path; -1: general pivoted path
 };
 
+// Reward of the rollout's current state, evaluated by one spare workgroup of the dynamics prep launch (the state it
+// reads was written by the previous glue kernel; nothing on the step's critical path waits for it).
+struct PrepReward {
+    int n;                // number of terms; 0 = no reward workgroup
+    int E;                // state dimension
+    RewardDev rw[MAX_REWARD_TERMS];
+    const double* m_x;    // [E]
+    const double* s_x;    // [E][E]
+    double* reward;       // [1] accumulator (single writer, stream ordered)
+};
+
 enum GlueFlags {
     GF_PACK = 1,       // reduce tile partials of the local pairs/outputs into gath[rank]
     GF_ASSEMBLE = 2,   // gath -> out_M, out_S, out_V
@@ -94,7 +105,7 @@ struct GlueArgs {
     double* rew_out;  // [2] mean, variance: set only by pilco_reward_eval
 };
 
-void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk);
+void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const PrepReward* pr = nullptr);
 // variant 0 = MFMA stream-K, 1 = VALU (tiled), 2 = MFMA tiled (bits independent of the rank count)
 void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int variant);
 // stream-K geometry: resident waves of the MFMA pair kernel for this KP, and the per-pair step counts

@@ -385,8 +385,23 @@ __device__ __forceinline__ void reward_eval(int n, const RewardDev* rws, int E, 
 // 256..511 ("group 1") the column-side operand; on a diagonal pair both operands are the same
 // vectors, so group 0 writes both and group 1 does the mean / input-output covariance sums.
 template <int DT>
-__global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk) {
+__global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepReward pr) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    if ((int)blockIdx.x >= wk.PL) {
+        // spare workgroup: mean reward of the current (pre-propagation) state (rewards.py:19-81, pilco.py:133)
+        if (blockIdx.y != 0 || pr.n <= 0) return;
+        const int E = pr.E, t = threadIdx.x;
+        double* mx = sm;              // [E]
+        double* sx = mx + E;          // [E][E]
+        double* ws = sx + E * E;      // reward_lds_doubles(E)
+        if (t < E) mx[t] = pr.m_x[t];
+        for (int e = t; e < E * E; e += blockDim.x) sx[e] = pr.s_x[e];
+        __syncthreads();
+        double mu, var;
+        reward_eval(pr.n, pr.rw, E, mx, sx, ws, false, mu, var);
+        if (t == 0) pr.reward[0] += mu;
+        return;
+    }
     const int D = md.D, npad = md.npad;
     double* s_m = sm;
     double* s_ia2 = s_m + DT;
@@ -640,11 +655,14 @@ int mm_prep_nch(int npad, int PL) {
     return nch;
 }
 
-void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk) {
-    dim3 grid(wk.PL, wk.NCH);
+void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const PrepReward* pr) {
+    PrepReward none{};
+    const PrepReward& r = pr ? *pr : none;
+    dim3 grid(wk.PL + (r.n > 0 ? 1 : 0), wk.NCH);
     const int D = md.D;
+    const size_t lds_rw = r.n > 0 ? sizeof(double) * ((size_t)r.E + (size_t)r.E * r.E + reward_lds_doubles(r.E)) : 0;
 #define PREP(DT_)                                                                                          \
-    hipLaunchKernelGGL((k_mm_prep<DT_>), grid, dim3(512), prep_lds_bytes(DT_), st, md, wk)
+    hipLaunchKernelGGL((k_mm_prep<DT_>), grid, dim3(512), std::max(prep_lds_bytes(DT_), lds_rw), st, md, wk, r)
     if (D <= 4) PREP(4);
     else if (D <= 8) PREP(8);
     else if (D <= 12) PREP(12);
