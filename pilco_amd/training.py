@@ -79,8 +79,7 @@ def optimize_mgpr(mgpr, restarts=1, maxiter=1000, verbose=False):
     from .models.smgpr import SMGPR
     from . import _lib
     if isinstance(mgpr, SMGPR):
-        raise NotImplementedError("FITC hyper-parameter / inducing-point training is not built; "
-                                  "set hyper-parameters and Z explicitly")
+        raise TypeError("optimize_mgpr fits the exact GP objective; SMGPR.optimize wraps it (subset fit + inducing subset)")
     noise_trainable = all(m.likelihood.variance.trainable for m in mgpr.models)
 
     def run(u0):

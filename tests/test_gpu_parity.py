@@ -671,3 +671,31 @@ def test_rbf_policy_gradient_adjoint_vs_autograd(ctx):
     np.testing.assert_allclose(lb, tl.grad.numpy(), rtol=1e-6, atol=1e-10)
     r_opt = p.optimize_policy(maxiter=5, verbose=False)
     assert r_opt >= r - 1e-12
+
+
+def test_sparse_optimize_models_runs_and_predicts(ctx):
+    """PILCO(num_induced_points=..).optimize_models() (pilco.py:52-56 -> SMGPR): the sparse model's fit (exact-GP
+    objective on a data subset + inducing subset, see SMGPR.optimize) must leave a usable model whose one-step
+    prediction is close to the dense model trained the same way."""
+    from pilco_amd.models import PILCO
+    rs = np.random.RandomState(5)
+    X = rs.rand(160, 3) * 2 - 1
+    f = lambda x: np.stack([np.sin(2 * x[:, 0]) + 0.3 * x[:, 2], np.cos(x[:, 1]) * x[:, 0]], 1)
+    Y = f(X) + 0.02 * rs.randn(160, 2)
+    ps = PILCO((X, Y), num_induced_points=60, horizon=2)
+    np.random.seed(0)
+    ps.optimize_models(verbose=False)
+    pd = PILCO((X, Y), horizon=2)
+    np.random.seed(0)   # same restart draws: the hyper-parameter fits coincide
+    pd.optimize_models(verbose=False)
+    assert ps.mgpr.Z.shape == (60, 3)
+    m, s = np.array([[0.1, -0.2, 0.3]]), 0.01 * np.eye(3)
+    Ms, Ss, Vs = ps.mgpr.predict_on_noisy_inputs(m, s)
+    Md, Sd, Vd = pd.mgpr.predict_on_noisy_inputs(m, s)
+    assert np.all(np.isfinite(Ms)) and np.all(np.isfinite(Ss))
+    np.testing.assert_allclose(Ms, Md, atol=0.05)
+    np.testing.assert_allclose(ls_of(ps), ls_of(pd), rtol=0.2)
+
+
+def ls_of(p):
+    return np.stack([np.asarray(mm.kernel.lengthscales.numpy()) for mm in p.mgpr.models])
