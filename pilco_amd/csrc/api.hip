@@ -25,8 +25,6 @@ struct Slot {
     DevBuf Kmn, V2, Am, AmInv, AmD, iAt, G;    // FITC extras
     // moment-matching workspace
     DevBuf w_in, w_At, w_Bt, w_small, w_part, w_gath, w_out;
-    int* d_lists = nullptr;
-    size_t lists_cap = 0;
     MMWork wk{};
     bool wk_valid = false;
     int wk_variant = -1;
@@ -58,8 +56,6 @@ struct pilco_ctx {
     bool use_graph = true;
     bool graph_rccl_failed = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipStream_t st2 = nullptr;                        // side stream of the reward kernel
-    hipEvent_t ev_state = nullptr, ev_rew = nullptr;  // fork / join of the side stream
     std::vector<hipEvent_t> pair_events;
     double* pin = nullptr;   // pinned host staging buffer of the reverse pass (truly asynchronous small copies)
     size_t pin_cap = 0;
@@ -354,11 +350,8 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
     ctx->device = device;
     ctx->slot[PILCO_SLOT_POLICY].ignore_iK = true;
     if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&ctx->d_info, 64 * sizeof(int)) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
-        hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_state, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_rew, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
         return PILCO_E_HIP;
     }
@@ -390,7 +383,6 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
                           &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
                           &s.w_part, &s.w_gath, &s.w_out})
             b->release();
-        if (s.d_lists) (void)hipFree(s.d_lists);
     }
     ctx->state.release();
     ctx->params.release();
@@ -401,9 +393,6 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     for (hipEvent_t e : ctx->pair_events) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->ev_state) (void)hipEventDestroy(ctx->ev_state);
-    if (ctx->ev_rew) (void)hipEventDestroy(ctx->ev_rew);
-    if (ctx->st2) (void)hipStreamDestroy(ctx->st2);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->st) (void)hipStreamDestroy(ctx->st);
@@ -851,13 +840,13 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
         (unsigned long long)(uintptr_t)g.traj, (unsigned long long)(uintptr_t)g.tape, (unsigned long long)(uintptr_t)g.W, (unsigned long long)(uintptr_t)g.maxact,
         (unsigned long long)(uintptr_t)s.w_part.p, (unsigned long long)(uintptr_t)s.w_At.p, (unsigned long long)(uintptr_t)s.w_Bt.p,
         (unsigned long long)(uintptr_t)s.w_small.p, (unsigned long long)(uintptr_t)s.w_gath.p, (unsigned long long)(uintptr_t)s.w_out.p,
-        (unsigned long long)(uintptr_t)s.w_in.p, (unsigned long long)(uintptr_t)s.d_lists, (unsigned long long)(uintptr_t)s.beta.p,
+        (unsigned long long)(uintptr_t)s.w_in.p, (unsigned long long)(uintptr_t)s.beta.p,
         (unsigned long long)(uintptr_t)s.iK.p, (unsigned long long)s.iK_null, (unsigned long long)(uintptr_t)s.Xt.p,
         (unsigned long long)(uintptr_t)s.Zt.p, (unsigned long long)(uintptr_t)s.ls.p, (unsigned long long)s.n,
         (unsigned long long)s.wk.sk_waves, (unsigned long long)s.wk.NT, (unsigned long long)s.wk.NCH, (unsigned long long)s.wk.abl,
         (unsigned long long)(uintptr_t)ctx->slot[1].w_part.p, (unsigned long long)(uintptr_t)ctx->slot[1].w_At.p,
         (unsigned long long)(uintptr_t)ctx->slot[1].beta.p, (unsigned long long)(uintptr_t)ctx->slot[1].Xt.p,
-        (unsigned long long)(uintptr_t)ctx->slot[1].d_lists, (unsigned long long)ctx->slot[1].n,
+        (unsigned long long)ctx->slot[1].n,
         (unsigned long long)ctx->slot[1].wk.sk_waves, (unsigned long long)(uintptr_t)ctx->slot[1].w_small.p,
         (unsigned long long)(uintptr_t)ctx->slot[1].w_in.p, (unsigned long long)(uintptr_t)ctx->slot[1].ls.p};
     for (int i = 0; i < g.n_rewards; ++i) {

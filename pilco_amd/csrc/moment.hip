@@ -185,9 +185,6 @@ __device__ double* gauss_jordan(double* G0, double* G1, int n, int nc, double& d
     return cur;
 }
 
-#ifndef GJ_VIA_LDS
-#define GJ_VIA_LDS 0
-#endif
 // 1/x to fp64 accuracy: hardware reciprocal estimate + two Newton steps (short dependency chain;
 // the IEEE division sequence is ~3x longer and sits on the critical path of every pivot).
 __device__ __forceinline__ double fast_rcp(double x) {
@@ -198,32 +195,19 @@ __device__ __forceinline__ double fast_rcp(double x) {
 }
 
 // Unpivoted Gauss-Jordan with the matrix in registers: lane c of ONE wave holds column c of the
-// DT x 2DT augmented matrix [A | B].  Per pivot the owning lane publishes its column (the
-// multipliers) through a DT-double LDS buffer that every lane reads back as a broadcast; LDS
-// operations of one wave execute in order, so no barrier is needed.  On return lanes DT..2DT-1 hold
-// the columns of A^{-1} B.  For SPD / diagonally-similar-to-SPD systems (no pivoting).
+// DT x 2DT augmented matrix [A | B].  Per pivot the multipliers (column k) are broadcast from lane k
+// with v_readlane; no LDS, no barriers (an LDS-broadcast variant measured slower at DT = 12).  On return
+// lanes DT..2DT-1 hold the columns of A^{-1} B.  For SPD / diagonally-similar-to-SPD systems (no pivoting).
 template <int DT>
 __device__ __forceinline__ double gj_wave(double (&a)[DT], double* colbuf, int lane) {
     double det = 1.0;
 #pragma unroll
     for (int k = 0; k < DT; ++k) {
-#if GJ_VIA_LDS
-        if (lane == k) {
-#pragma unroll
-            for (int r = 0; r < DT; ++r) colbuf[r] = a[r];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        double f[DT];
-#pragma unroll
-        for (int r = 0; r < DT; ++r) f[r] = colbuf[r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
         double f[DT];
 #pragma unroll
         for (int r = 0; r < DT; ++r) f[r] = readlane_f64(a[r], k);
         (void)colbuf;
         (void)lane;
-#endif
         const double piv = f[k];
         det *= piv;
         const double pk = a[k] * fast_rcp(piv);

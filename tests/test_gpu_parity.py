@@ -699,3 +699,26 @@ def test_sparse_optimize_models_runs_and_predicts(ctx):
 
 def ls_of(p):
     return np.stack([np.asarray(mm.kernel.lengthscales.numpy()) for mm in p.mgpr.models])
+
+
+def test_native_rollout_grad_combined_reward_and_errors(ctx):
+    """pilco_rollout_grad with a CombinedRewards objective (exponential + linear terms, rewards.py:64-81) against the
+    same sweep driven from Python; unsupported policies are refused, not silently mishandled."""
+    from pilco_amd import _lib
+    from pilco_amd.adjoint import rollout_value_and_grad
+    from pilco_amd.rewards import CombinedRewards, ExponentialReward, LinearReward
+    c = synthetic.config_cascade()
+    cfg = {k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise")}
+    p = _pilco_from(cfg, 4)
+    p.reward = CombinedRewards(2, [ExponentialReward(2, W=np.array([[1.2, 0.1], [0.1, 0.8]]), t=np.array([[0.5, -0.2]])),
+                                   LinearReward(2, np.array([[0.3], [-0.4]]))], coefs=[0.7, 1.5])
+    p.m_init, p.S_init = c["m"], c["s"]
+    p.controller.W.assign(c["W"]); p.controller.b.assign(c["b"]); p.controller.max_action = 1.3
+    r1, (W1, b1) = rollout_value_and_grad(p, native=True)
+    r2, (W2, b2) = rollout_value_and_grad(p, native=False)
+    np.testing.assert_allclose(r1, r2, rtol=1e-13)
+    np.testing.assert_allclose(W1, W2, rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(b1, b2, rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(r1, float(p.compute_reward()[0, 0]), rtol=1e-12)
+    with pytest.raises(_lib.PilcoError):
+        p.ctx.rollout_grad(dict(kind=_lib.POLICY_NONE, state_dim=2, control_dim=0), p.reward.terms(), c["m"], c["s"], 2)
