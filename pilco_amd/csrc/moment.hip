@@ -21,6 +21,8 @@
 //                pilco.py:139-144).
 #include "moment.h"
 
+#include <type_traits>
+
 namespace pilco {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -1150,46 +1152,55 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
 #pragma unroll
     for (int rt = 0; rt < BWD_RT; ++rt) acc[rt] = d4{0.0, 0.0, 0.0, 0.0};
     double* myslice = csl + w * jw;
-    for (int j0 = jbeg; j0 < jend; j0 += 16) {
-        double cf[KC], a2[4], bcol[4];
-        const unsigned so = (unsigned)j0 * 8u;
-#pragma unroll
-        for (int c = 0; c < KC; ++c) cf[c] = buf_ld(rB, cf_off[c], so);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            bcol[r] = buf_ld(rbeta, bc_off[r], so);
-            a2[r] = buf_ld(rB, a2_off[r], so);
-        }
-        double csum[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int rt = 0; rt < BWD_RT; ++rt) {
-            d4 e = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int c = 0; c < KC; ++c)
-                e = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[c], rf[rt][c], e, 0, 0, 0);   // e[r]: i = irow, j = j0+lr+4r
-            double wl[4];
-#pragma unroll
+    // the column sweep, specialised at compile time (branches inside the loop would fence the scheduler between the
+    // eight exp evaluations of a step): MODE 0 off-diagonal pair (column sums), 1 diagonal pair with the iK stream,
+    // 2 diagonal pair without it (RBF policy GP)
+    auto sweep = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        for (int j0 = jbeg; j0 < jend; j0 += 16) {
+            double cf[KC], a2[4], bcol[4];
+            const unsigned so = (unsigned)j0 * 8u;
+    #pragma unroll
+            for (int c = 0; c < KC; ++c) cf[c] = buf_ld(rB, cf_off[c], so);
+    #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                double wgt = brow[rt] * bcol[r];
-                if (iKa) wgt -= buf_ld(rIK, ik_off[rt][r], (unsigned)(j0 - jbeg) * (unsigned)npad * 8u);   // iK symmetric: coalesced along the rows
-                wl[r] = wgt * fexp(e[r], tab);
-                csum[r] += wl[r];
+                bcol[r] = buf_ld(rbeta, bc_off[r], so);
+                a2[r] = buf_ld(rB, a2_off[r], so);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[r], wl[r], acc[rt], 0, 0, 0);
-        }
-        if (!diag) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double v = csum[r];
-                v = dpp_add<0x111, 0xf>(v);
-                v = dpp_add<0x112, 0xf>(v);
-                v = dpp_add<0x114, 0xf>(v);
-                v = dpp_add<0x118, 0xf>(v);   // lane 15 of every DPP row: sum over the 16 rows i
-                if (lc == 15) myslice[j0 - jbeg + lr + 4 * r] = v;
+            double csum[4] = {0.0, 0.0, 0.0, 0.0};
+    #pragma unroll
+            for (int rt = 0; rt < BWD_RT; ++rt) {
+                d4 e = {0.0, 0.0, 0.0, 0.0};
+    #pragma unroll
+                for (int c = 0; c < KC; ++c)
+                    e = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[c], rf[rt][c], e, 0, 0, 0);   // e[r]: i = irow, j = j0+lr+4r
+                double wl[4];
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double wgt = brow[rt] * bcol[r];
+                    if (MODE == 1) wgt -= buf_ld(rIK, ik_off[rt][r], (unsigned)(j0 - jbeg) * (unsigned)npad * 8u);   // iK symmetric: coalesced along the rows
+                    wl[r] = wgt * fexp(e[r], tab);
+                    csum[r] += wl[r];
+                }
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[r], wl[r], acc[rt], 0, 0, 0);
+            }
+            if (MODE == 0) {
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double v = csum[r];
+                    v = dpp_add<0x111, 0xf>(v);
+                    v = dpp_add<0x112, 0xf>(v);
+                    v = dpp_add<0x114, 0xf>(v);
+                    v = dpp_add<0x118, 0xf>(v);   // lane 15 of every DPP row: sum over the 16 rows i
+                    if (lc == 15) myslice[j0 - jbeg + lr + 4 * r] = v;
+                }
             }
         }
-    }
+    };
+    if (!diag) sweep(std::integral_constant<int, 0>{});
+    else if (iKa) sweep(std::integral_constant<int, 1>{});
+    else sweep(std::integral_constant<int, 2>{});
     double* out = rowmom + ((long)pl * njs + js) * 16 * npad;
 #pragma unroll
     for (int rt = 0; rt < BWD_RT; ++rt)
