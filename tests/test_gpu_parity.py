@@ -722,3 +722,20 @@ def test_native_rollout_grad_combined_reward_and_errors(ctx):
     np.testing.assert_allclose(r1, float(p.compute_reward()[0, 0]), rtol=1e-12)
     with pytest.raises(_lib.PilcoError):
         p.ctx.rollout_grad(dict(kind=_lib.POLICY_NONE, state_dim=2, control_dim=0), p.reward.terms(), c["m"], c["s"], 2)
+
+
+def test_large_n_exact_step(ctx):
+    """N = 3000 (47 diagonal blocks: deep, uneven recursive-doubling levels; 188 column steps per row tile in the pair
+    kernel), low noise: factorisation + one moment-matching step against the oracle."""
+    c = synthetic.config_c2(N=3000, D=4, E=2, noise=1e-3, seed=31, control_dim=2)
+    m = _mgpr(c)
+    rs = np.random.RandomState(2)
+    mm = 0.2 * rs.randn(1, 4)
+    A = 0.2 * rs.randn(4, 4)
+    ss = A @ A.T + 0.05 * np.eye(4)
+    M, S, V = m.predict_on_noisy_inputs(mm, ss)
+    iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+    Mo, So, Vo = tp.predict_given_factorizations_pairs(c["X"], c["lengthscales"], c["variance"], mm, ss, iK, beta)
+    np.testing.assert_allclose(M, Mo, rtol=RTOL)
+    np.testing.assert_allclose(S, So, rtol=RTOL, atol=1e-10)
+    np.testing.assert_allclose(V, Vo, rtol=RTOL, atol=1e-10)
