@@ -444,7 +444,8 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
         }
     }
     const double beta0 = (mean_role && i_begin + tl < i_end) ? md.beta[(long)a * npad + i_begin + tl] : 0.0;
-    const double logvar = log(md.var[side ? b : a]);
+    const double var_s = md.var[side ? b : a];   // (diagonal pairs: var_a, also the mean part's prefactor)
+    const double logvar = log(var_s);
     if (wk.abl & 2) {
         if (t == 0) { s_sc[0] = 1.0; s_sc[1] = 1.0; }
     } else if (w == 0) {
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
             for (int r = 0; r < DT; ++r)
                 if (r < D) s_T[r * DT + cc] = col[r] * s_ia[r] * s_ia[cc];
         }
-        if (lane == 0) s_sc[1] = md.var[a] / sqrt(detB);
+        if (lane == 0) s_sc[1] = var_s / sqrt(detB);   // diagonal pair: side 0 -> var_a, loaded before the Gauss-Jordan
     }
     __syncthreads();
     DBG_STAMP(wk, 2, dbg0);
