@@ -170,6 +170,31 @@ def main():
     except Exception:
         traffic = None
 
+    # N > 1 only: the zero-communication alternative (SURVEY.md 8(e) "Alternative DP"): every rank also runs the whole
+    # rollout on its own GPU (an unsharded second context); the aggregate is reported under "secondary", never as `value`.
+    replicas = None
+    if dist is not None:
+        import torch
+        local_ms, err = float("inf"), None
+        try:   # no collective inside the try: a rank that fails must not leave the others waiting
+            ctx2 = _lib.Context(device=local_rank)
+            ctx2.gp_set_data(0, cfg["X"], cfg["Y"])
+            ctx2.gp_set_hyp(0, cfg["lengthscales"], cfg["variance"], cfg["noise"])
+            ctx2.gp_factorize(0)
+            ctx2.rollout_timed(policy, rewards, cfg["m0"], cfg["S0"], H, max(args.warmup, 1), time_pair=False)
+            t0 = time.perf_counter()
+            ctx2.rollout_timed(policy, rewards, cfg["m0"], cfg["S0"], H, args.steps, time_pair=False)
+            local_ms = (time.perf_counter() - t0) * 1e3
+        except Exception as exc:
+            err = repr(exc)
+        tt = torch.tensor([local_ms], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if np.isfinite(float(tt.item())):
+            replicas = {"replica_rollouts_per_s": world * args.steps * 1e3 / float(tt.item()),
+                        "note": "independent unsharded rollouts, one per GPU, concurrently, no communication (not the sharded metric)"}
+        else:
+            replicas = {"error": err or "a rank failed"}
+
     if rank == 0:
         out = {
             "metric": "moment-matching rollouts/sec (N=1000,D=10,E=10,H=40)",
@@ -199,6 +224,8 @@ def main():
         }
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_metrics(ctx, cfg, policy, rewards, ms_per_rollout)
+        if replicas is not None:
+            out["secondary"] = replicas
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
