@@ -649,7 +649,16 @@ void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const P
     const int D = md.D;
     const size_t lds_rw = r.n > 0 ? sizeof(double) * ((size_t)r.E + (size_t)r.E * r.E + reward_lds_doubles(r.E)) : 0;
 #define PREP(DT_)                                                                                          \
-    hipLaunchKernelGGL((k_mm_prep<DT_>), grid, dim3(512), std::max(prep_lds_bytes(DT_), lds_rw), st, md, wk, r)
+    do {                                                                                                   \
+        const size_t lds_ = std::max(prep_lds_bytes(DT_), lds_rw);                                         \
+        static size_t configured_ = 48 * 1024;   /* beyond the default dynamic-LDS limit: opt in once */   \
+        if (lds_ > configured_) {                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mm_prep<DT_>),                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);              \
+            configured_ = lds_;                                                                            \
+        }                                                                                                  \
+        hipLaunchKernelGGL((k_mm_prep<DT_>), grid, dim3(512), lds_, st, md, wk, r);                        \
+    } while (0)
     if (D <= 4) PREP(4);
     else if (D <= 8) PREP(8);
     else if (D <= 12) PREP(12);

@@ -739,3 +739,21 @@ def test_large_n_exact_step(ctx):
     np.testing.assert_allclose(M, Mo, rtol=RTOL)
     np.testing.assert_allclose(S, So, rtol=RTOL, atol=1e-10)
     np.testing.assert_allclose(V, Vo, rtol=RTOL, atol=1e-10)
+
+
+@pytest.mark.parametrize("D,E", [(18, 3), (26, 2)])
+def test_wide_inputs_vs_oracle(ctx, D, E):
+    """GP input dimensions beyond the tuned range (register tiles DT = 24 and 32 of k_mm_prep, KC = 5 and 7 of the pair
+    kernel): one moment-matching step against the oracle."""
+    c = synthetic.config_c2(N=150, D=D, E=E, noise=1e-2, seed=D, control_dim=D - E)
+    m = _mgpr(c)
+    rs = np.random.RandomState(D)
+    mm = 0.2 * rs.randn(1, D)
+    A = 0.15 * rs.randn(D, D)
+    ss = A @ A.T + 0.02 * np.eye(D)
+    M, S, V = m.predict_on_noisy_inputs(mm, ss)
+    iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+    Mo, So, Vo = tp.predict_given_factorizations_pairs(c["X"], c["lengthscales"], c["variance"], mm, ss, iK, beta)
+    np.testing.assert_allclose(M, Mo, rtol=RTOL)
+    np.testing.assert_allclose(S, So, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(V, Vo, rtol=RTOL, atol=1e-12)
