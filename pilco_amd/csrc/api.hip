@@ -109,7 +109,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.EL = (rank < E) ? (E - rank + W - 1) / W : 0;
     wk.P = P;
     wk.KP = mm_kp(D);
-    wk.NCH = mm_prep_nch(npad, std::max(wk.PL, 1));
+    mm_prep_chunks(npad, std::max(wk.PL, 1), wk.EL, &wk.NCH, &wk.NCHM);
     wk.NT = mm_pair_nt(npad, ctx->variant, std::max(wk.PL, 1));
     wk.OUTOFF = PLcap;
     wk.SEG = PLcap + ELcap * (1 + D);
@@ -149,7 +149,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     ENSURE(s.w_in, (size_t)D + D * D + E + E * E + D * E);   // m | s | cotangents (Mbar | Sbar | Vbar) of the reverse pass
     ENSURE(s.w_At, (size_t)PLa * wk.KP * npad);
     ENSURE(s.w_Bt, (size_t)PLa * wk.KP * npad);
-    ENSURE(s.w_small, (size_t)PLa + (size_t)E * wk.NCH * (1 + D));
+    ENSURE(s.w_small, (size_t)PLa + (size_t)E * wk.NCHM * (1 + D));
     ENSURE(s.w_part, std::max((size_t)PLa * wk.NT * 2, (size_t)PLa * std::max(wk.sk_maxw, 4)));
     ENSURE(s.w_gath, (size_t)W * wk.SEG);
     ENSURE(s.w_out, (size_t)E + E * E + D * E);
@@ -843,7 +843,7 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
         (unsigned long long)(uintptr_t)s.w_in.p, (unsigned long long)(uintptr_t)s.beta.p,
         (unsigned long long)(uintptr_t)s.iK.p, (unsigned long long)s.iK_null, (unsigned long long)(uintptr_t)s.Xt.p,
         (unsigned long long)(uintptr_t)s.Zt.p, (unsigned long long)(uintptr_t)s.ls.p, (unsigned long long)s.n,
-        (unsigned long long)s.wk.sk_waves, (unsigned long long)s.wk.NT, (unsigned long long)s.wk.NCH, (unsigned long long)s.wk.abl,
+        (unsigned long long)s.wk.sk_waves, (unsigned long long)s.wk.NT, (unsigned long long)s.wk.NCH, (unsigned long long)s.wk.NCHM, (unsigned long long)s.wk.abl,
         (unsigned long long)(uintptr_t)ctx->slot[1].w_part.p, (unsigned long long)(uintptr_t)ctx->slot[1].w_At.p,
         (unsigned long long)(uintptr_t)ctx->slot[1].beta.p, (unsigned long long)(uintptr_t)ctx->slot[1].Xt.p,
         (unsigned long long)ctx->slot[1].n,

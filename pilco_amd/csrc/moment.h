@@ -24,7 +24,7 @@ struct MMWork {
     double* At;          // [PL][KP][npad]  row-side operand   (2 Q z_i | u_i | 1 | 0..)
     double* Bt;          // [PL][KP][npad]  column-side operand (w_j   | 1 | v_j | 0..)
     double* pair_isdet;  // [PL]     1/sqrt(det R_ab)
-    double* mean_part;   // [E][NCH][1+D]  per row chunk: c_a g and c_a T_a h (contributions to M_a, V_a)
+    double* mean_part;   // [EL][NCHM][1+D]  per row chunk: c_a g and c_a T_a h (contributions to M_a, V_a)
     double* pair_part;   // [PL][NT][2]
     double* gath;        // [nranks][SEG]  packed per-rank results (all-gather buffer)
     double* out_M;       // [E]
@@ -40,7 +40,7 @@ struct MMWork {
     int abl;             // experiment switches (PILCO_ABL, tools only; 0 in product use)
     int sk_ud, sk_uo;    // cost units of a diagonal / off-diagonal column step (diagonal steps also stream iK)
     const double* exp_tab;    // [n] 2^(j/n), n = mm_exp_table_size(), for the table-driven fp64 exp of the pair kernel
-    int PL, EL, P, KP, NCH, NT, SEG, OUTOFF, rank, nranks;  // OUTOFF: offset of the output records inside a segment
+    int PL, EL, P, KP, NCH, NCHM, NT, SEG, OUTOFF, rank, nranks;  // NCH / NCHM: row chunks of the pair / mean-part prep workgroups; OUTOFF: offset of the output records inside a segment
 };
 
 struct RewardDev {
@@ -117,7 +117,7 @@ void launch_glue(hipStream_t st, const GlueArgs& g, bool with_reward_block = fal
 size_t glue_lds_bytes(int E, int D);
 // tile-partial counts per pair for a variant (NT) and the number of row chunks of the prep kernel
 int mm_pair_nt(int npad, int variant, int PL);
-int mm_prep_nch(int npad, int PL);
+void mm_prep_chunks(int npad, int PL, int EL, int* nch, int* nchm);
 int mm_kp(int D);
 void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot);
 // reverse pass of one moment-matching step (single rank, D <= 14; the step's prep kernel must precede it on st):

@@ -22,14 +22,18 @@ for rep in range(3):
 b = ctx.debug_blocks(960 + 256 + 8)
 we = b[960:960+256]
 print("pair wave end stamps relative to wave 0 end (every 8th wave): min %+.1f max %+.1f us; by position: %s" % (min((x-ts[17])/100.0 for x in we if x), max((x-ts[17])/100.0 for x in we if x), " ".join("%+.0f" % ((x-ts[17])/100.0) for x in we[::16])))
-t0 = min(b[0::2])
-import collections
-print("prep per-block (start, dur) us by chunk row:")
-for ch in range(4):
-    row = [( (b[2*(ch*55+pl)]-t0)/100.0, (b[2*(ch*55+pl)+1]-b[2*(ch*55+pl)])/100.0) for pl in range(55)]
-    print(" ch%d starts: %s" % (ch, " ".join("%.1f" % r[0] for r in row[:55:6])))
-    print("     durs:   %s" % (" ".join("%.1f" % r[1] for r in row[:55:6])))
-durs = [((b[2*k+1]-b[2*k])/100.0, (b[2*k]-t0)/100.0, k % 55, k // 55) for k in range(220)]
-durs.sort(reverse=True)
-print("slowest prep blocks (dur, start, pl, ch):", [(round(d,1), round(s,1), pl, ch) for d, s, pl, ch in durs[:12]])
-print("fastest:", [(round(d,1), round(s,1), pl, ch) for d, s, pl, ch in durs[-5:]])
+NX, NY = 61, 4   # prep grid at C2: 55 pair columns + 6 spare columns, 4 row chunks
+st = {}
+for y in range(NY):
+    for x in range(NX):
+        k = y * NX + x
+        if 2 * k + 1 < 894 and b[2 * k]:
+            st[(x, y)] = (b[2 * k], b[2 * k + 1])
+t0 = min(v[0] for v in st.values())
+def rng(keys):
+    v = [((st[k][1] - st[k][0]) / 100.0, (st[k][1] - t0) / 100.0) for k in keys if k in st and st[k][1]]
+    return "n=%d dur %.1f..%.1f us, end %.1f..%.1f us" % (len(v), min(x[0] for x in v), max(x[0] for x in v), min(x[1] for x in v), max(x[1] for x in v)) if v else "none"
+print("prep pair blocks :", rng([(x, y) for x in range(55) for y in range(NY)]))
+spare = [(55 + i // NY, i % NY) for i in range(24)]
+print("prep mean blocks :", rng(spare[:20]))
+print("prep reward block:", rng(spare[20:21]))
