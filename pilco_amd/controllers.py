@@ -1,6 +1,6 @@
 """Controllers with the reference's interface (/root/reference/pilco/controllers.py):
 ``compute_action(m, s, squash=True) -> (M (1,k), S (k,k), V (d,k))`` and
-``randomize()``.  Arithmetic runs on the device (k_glue in csrc/moment.hip)."""
+``randomize()``.  Arithmetic runs on the device (k_glue in csrc/glue.hip)."""
 from __future__ import annotations
 
 import numpy as np

@@ -1,0 +1,495 @@
+// Reverse pass of one moment-matching step: k_mm_bwd_pair / _post / _fin.
+#include "mm_device.h"
+
+namespace pilco {
+
+// ------------------------------------------------------------------ adjoint of the pair sums
+// d e_ij/d m = P (z_i + w_j) and d e_ij/d s = (P y)(P y)^T / 2, so the reverse
+// pass needs, per pair, only   r_i = sum_j W_ij L_ij,   c_j = sum_i W_ij L_ij,   m_i = sum_j W_ij L_ij w_j
+// with W = beta_a beta_b^T (- iK_a on the diagonal pair).  A wave owns 16*BWD_RT rows and sweeps a range
+// of columns; the exponent tile is computed TRANSPOSED (column operand as MFMA A, row operand as B) so
+// that the weighted tile W.L lands in the B-operand layout of a second MFMA that contracts it with
+// [w_j | 1]: moments and row sums cost 4 MFMAs per 16x16 tile and no VALU reductions.  The column sums of
+// an off-diagonal pair run along the lanes of a DPP row: four row_shr adds per result register, the four
+// waves of a workgroup keep their partial columns in separate LDS slices that are summed in a fixed order
+// (diagonal pairs: c = r by symmetry).
+// rowmom[pl][js][16][npad]: d < D -> m_i[d], d = D -> r_i, per column split js;
+// cpart[pl - E][row block][npad]: column sums over the rows of one workgroup.
+#ifndef BWD_RT
+#define BWD_RT 2
+#endif
+// Per-step constants of the reverse pass, computed once by spare workgroups of the k_mm_bwd_pair launch and read by
+// k_mm_bwd_post / k_mm_bwd_fin:   head[h][D*D + D + 2]
+//   output a (h = a):      T = (s + Lambda_a^2)^-1 | u = T Vbar_a | mu = Mbar_a - sum_b (Sbar_ab + Sbar_ba) M_b | c_a
+//   pair pl (h = E + pl):  P = (I + Lambda_ab s)^-1 | lambda_ab | kappa = Shat_ab / sqrt(det R_ab) | 0
+// M_b comes from the mean partials the prep kernel of the same step left in wk.mean_part.
+__device__ void bwd_head(const MMModel& md, const MMWork& wk, const double* __restrict__ bars, int h,
+                         double* __restrict__ head, double* sm) {
+    const int D = md.D, E = md.E, t = threadIdx.x, nc = 2 * D, nI = D * D;
+    double* G0 = sm;               // [D][2D]
+    double* G1 = G0 + D * nc;      // [D][2D]
+    double* lam = G1 + D * nc;     // [D]
+    const double* Mbar = bars;
+    const double* Sbar = bars + E;
+    const double* Vbar = bars + E + E * E;
+    double* o = head + (long)h * (nI + D + 2);
+    int a = h, b = h;
+    if (h >= E) local_pair_ab(wk, E, h - E, a, b);
+    if (t < D) {
+        const double la = md.ls[a * D + t], lb = md.ls[b * D + t];
+        lam[t] = (h < E) ? la * la : 1.0 / (la * la) + 1.0 / (lb * lb);
+    }
+    __syncthreads();
+    for (int e = t; e < D * nc; e += 256) {
+        const int r = e / nc, c = e - r * nc;
+        double v;
+        if (c >= D) v = (c - D == r) ? 1.0 : 0.0;
+        else if (h < E) v = wk.in_s[r * D + c] + (r == c ? lam[r] : 0.0);        // s + Lambda_a^2
+        else v = lam[r] * wk.in_s[r * D + c] + (r == c ? 1.0 : 0.0);             // I + Lambda_ab s
+        G0[e] = v;
+    }
+    double det;
+    const double* G = gauss_jordan(G0, G1, D, nc, det);   // inverse in G[:, D:]
+    if (t < nI) o[t] = G[(t / D) * nc + D + (t % D)];
+    if (h < E) {
+        if (t < D) {
+            double acc = 0.0;
+            for (int c = 0; c < D; ++c) acc = fma(G[t * nc + D + c], Vbar[c * E + a], acc);
+            o[nI + t] = acc;
+        }
+        if (t == 64) {
+            double mu = Mbar[a];
+            for (int bb = 0; bb < E; ++bb) {
+                double Mb = 0.0;
+                for (int ch = 0; ch < wk.NCHM; ++ch) Mb += wk.mean_part[((long)bb * wk.NCHM + ch) * (1 + D)];
+                mu -= (Sbar[a * E + bb] + Sbar[bb * E + a]) * Mb;
+            }
+            double lp = 1.0;
+            for (int d = 0; d < D; ++d) lp *= md.ls[a * D + d];
+            o[nI + D] = mu;
+            o[nI + D + 1] = md.var[a] * lp / sqrt(det);
+        }
+    } else {
+        if (t < D) o[nI + t] = lam[t];
+        if (t == 64) {
+            const double shat = (a == b) ? Sbar[a * E + a] : Sbar[a * E + b] + Sbar[b * E + a];
+            o[nI + D] = shat / sqrt(det);   // det(I + Lambda s) = det(s Lambda + I) = det R_ab
+            o[nI + D + 1] = 0.0;
+        }
+    }
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ rowmom,
+                                                    double* __restrict__ cpart, int njs, const double* __restrict__ bars,
+                                                    double* __restrict__ head) {
+    __shared__ double tab[FEXP_TN];
+    extern __shared__ __attribute__((aligned(16))) double csl[];   // [4][jw]  (head workgroups: Gauss-Jordan scratch)
+    if ((int)blockIdx.y >= wk.PL) {   // spare workgroups: the step's D x D inverses, one per output / pair
+        const int h = ((int)blockIdx.y - wk.PL) * (int)(gridDim.x * gridDim.z) + (int)(blockIdx.z * gridDim.x + blockIdx.x);
+        if (h < md.E + wk.PL) bwd_head(md, wk, bars, h, head, csl);
+        return;
+    }
+    for (int e = threadIdx.x; e < FEXP_TN; e += blockDim.x) tab[e] = wk.exp_tab[e];
+    __syncthreads();
+    const int npad = md.npad, D = md.D, E = md.E;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lr = lane >> 4, lc = lane & 15;
+    const int pl = blockIdx.y, js = blockIdx.z, rb = blockIdx.x;
+    int a, b;
+    local_pair_ab(wk, E, pl, a, b);
+    const int KP = wk.KP;
+    const double* At = wk.At + (long)pl * KP * npad;
+    const double* Bt = wk.Bt + (long)pl * KP * npad;
+    const double* beta_a = md.beta + (long)a * npad;
+    const double* beta_b = md.beta + (long)b * npad;
+    const bool diag = (a == b);
+    const double* iKa = (diag && md.iK) ? md.iK + (long)a * npad * npad : nullptr;
+    const int jw = npad / njs, jbeg = js * jw, jend = jbeg + jw;
+    const int ibase = rb * 64 * BWD_RT + w * 16 * BWD_RT;
+    double rf[BWD_RT][KC], brow[BWD_RT];
+    int irow[BWD_RT];
+#pragma unroll
+    for (int rt = 0; rt < BWD_RT; ++rt) {
+        const bool ok = ibase + 16 * rt < npad;                  // wave-uniform; rows past the padding weigh zero
+        irow[rt] = ok ? ibase + 16 * rt + lc : lc;
+        brow[rt] = ok ? beta_a[irow[rt]] : 0.0;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) rf[rt][c] = At[(long)(4 * c + lr) * npad + irow[rt]];
+    }
+    // buffer loads: uniform resource + per-lane byte offset + scalar column offset (no 64-bit VALU address math)
+    const __amdgpu_buffer_rsrc_t rB = buf_rsrc(Bt), rbeta = buf_rsrc(beta_b);
+    const __amdgpu_buffer_rsrc_t rIK = buf_rsrc(iKa ? iKa + (long)jbeg * npad : Bt);
+    unsigned cf_off[KC], a2_off[4], bc_off[4], ik_off[BWD_RT][4];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) cf_off[c] = ((unsigned)(4 * c + lr) * (unsigned)npad + (unsigned)lc) * 8u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        bc_off[r] = (unsigned)(lr + 4 * r) * 8u;
+        // rows of the column operand contracted by the second product: w_j (d < D) and the ones (d = D); lanes past
+        // that repeat row D: their result rows (d > D of rowmom) are never read
+        a2_off[r] = ((unsigned)(lc <= D ? lc : D) * (unsigned)npad + (unsigned)(4 * r + lr)) * 8u;
+#pragma unroll
+        for (int rt = 0; rt < BWD_RT; ++rt) ik_off[rt][r] = ((unsigned)(lr + 4 * r) * (unsigned)npad + (unsigned)irow[rt]) * 8u;
+    }
+    d4 acc[BWD_RT];
+#pragma unroll
+    for (int rt = 0; rt < BWD_RT; ++rt) acc[rt] = d4{0.0, 0.0, 0.0, 0.0};
+    double* myslice = csl + w * jw;
+    // the column sweep, specialised at compile time (branches inside the loop would fence the scheduler between the
+    // eight exp evaluations of a step): MODE 0 off-diagonal pair (column sums), 1 diagonal pair with the iK stream,
+    // 2 diagonal pair without it (RBF policy GP)
+    auto sweep = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        for (int j0 = jbeg; j0 < jend; j0 += 16) {
+            double cf[KC], a2[4], bcol[4];
+            const unsigned so = (unsigned)j0 * 8u;
+    #pragma unroll
+            for (int c = 0; c < KC; ++c) cf[c] = buf_ld(rB, cf_off[c], so);
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bcol[r] = buf_ld(rbeta, bc_off[r], so);
+                a2[r] = buf_ld(rB, a2_off[r], so);
+            }
+            double csum[4] = {0.0, 0.0, 0.0, 0.0};
+    #pragma unroll
+            for (int rt = 0; rt < BWD_RT; ++rt) {
+                d4 e = {0.0, 0.0, 0.0, 0.0};
+    #pragma unroll
+                for (int c = 0; c < KC; ++c)
+                    e = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[c], rf[rt][c], e, 0, 0, 0);   // e[r]: i = irow, j = j0+lr+4r
+                double wl[4];
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double wgt = brow[rt] * bcol[r];
+                    if (MODE == 1) wgt -= buf_ld(rIK, ik_off[rt][r], (unsigned)(j0 - jbeg) * (unsigned)npad * 8u);   // iK symmetric: coalesced along the rows
+                    wl[r] = wgt * fexp(e[r], tab);
+                    csum[r] += wl[r];
+                }
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[r], wl[r], acc[rt], 0, 0, 0);
+            }
+            if (MODE == 0) {
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double v = csum[r];
+                    v = dpp_add<0x111, 0xf>(v);
+                    v = dpp_add<0x112, 0xf>(v);
+                    v = dpp_add<0x114, 0xf>(v);
+                    v = dpp_add<0x118, 0xf>(v);   // lane 15 of every DPP row: sum over the 16 rows i
+                    if (lc == 15) myslice[j0 - jbeg + lr + 4 * r] = v;
+                }
+            }
+        }
+    };
+    if (!diag) sweep(std::integral_constant<int, 0>{});
+    else if (iKa) sweep(std::integral_constant<int, 1>{});
+    else sweep(std::integral_constant<int, 2>{});
+    double* out = rowmom + ((long)pl * njs + js) * 16 * npad;
+#pragma unroll
+    for (int rt = 0; rt < BWD_RT; ++rt)
+        if (ibase + 16 * rt < npad) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(long)(lr + 4 * r) * npad + irow[rt]] = acc[rt][r];
+        }
+    if (!diag) {
+        __syncthreads();
+        double* cp = cpart + ((long)(pl - wk.EL) * gridDim.x + rb) * npad + jbeg;
+        for (int jj = threadIdx.x; jj < jw; jj += 256)
+            cp[jj] = (csl[jj] + csl[jw + jj]) + (csl[2 * jw + jj] + csl[3 * jw + jj]);
+    }
+}
+
+// Reverse of the mean part (mgpr.py:99-118) for output a, including the -M M^T term of S:
+// with T = (s + Lambda_a^2)^-1, l_i = beta_i exp(-zeta_i^T T zeta_i / 2), g = sum l_i, h = sum l_i zeta_i,
+// u = T Vbar_a, mu = Mbar_a - sum_b (Sbar_ab + Sbar_ba) M_b, q_i = mu + zeta_i . u:
+//   mbar_a = c (T sum l_i q_i zeta_i - g u),
+//   sbar_a = -phi T / 2 + c T (sum l_i q_i zeta_i zeta_i^T) T / 2 - c (u (T h)^T + (T h) u^T) / 2,  phi = c (mu g + Vbar_a . T h).
+// M_b is read from the mean partials the prep kernel of the same step left in wk.mean_part.
+// stage 1 (a workgroup of k_mm_bwd_post): sums over the 64-point blocks rc, rc + nrc, ..:  mpart[a][rc][D*D + 2D + 1]
+__device__ void bwd_mean_partial(const MMModel& md, const MMWork& wk, const double* __restrict__ head, int a, int rc,
+                                 int nrc, double* __restrict__ mpart, double* sm) {
+    const int D = md.D, npad = md.npad, t = threadIdx.x;
+    const int nI = D * D, LD = D | 1;
+    double* T = sm;                 // [D][D]
+    double* zs = T + nI;            // [64][LD]
+    double* lv = zs + 64 * LD;      // [64]
+    double* lq = lv + 64;           // [64]
+    double* u = lq + 64;            // [D + 2]: u | mu | c_a
+    const double* hd = head + (long)a * (nI + D + 2);
+    for (int e = t; e < nI + D + 2; e += 256) (e < nI ? T[e] : u[e - nI]) = hd[e];
+    __syncthreads();
+    const double mu = u[D];
+    double acc = 0.0;
+    for (int blk = rc; blk < npad / 64; blk += nrc) {
+        if (t < 64) {
+            const int i = blk * 64 + t;
+            double l = 0.0, q = 0.0;
+            if (i < md.n) {
+                double quad = 0.0;
+                q = mu;
+                for (int d = 0; d < D; ++d) zs[t * LD + d] = md.Pt[(long)d * npad + i] - wk.in_m[d];
+                for (int r = 0; r < D; ++r) {
+                    double tz = 0.0;
+                    for (int c = 0; c < D; ++c) tz = fma(T[r * D + c], zs[t * LD + c], tz);
+                    quad = fma(zs[t * LD + r], tz, quad);
+                    q = fma(zs[t * LD + r], u[r], q);
+                }
+                l = exp(-0.5 * quad) * md.beta[(long)a * npad + i];
+            } else {
+                for (int d = 0; d < D; ++d) zs[t * LD + d] = 0.0;
+            }
+            lv[t] = l;
+            lq[t] = l * q;
+        }
+        __syncthreads();
+        if (t < nI) {
+            const int d = t / D, e2 = t - d * D;
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc = fma(lq[ii] * zs[ii * LD + d], zs[ii * LD + e2], acc);
+        } else if (t < nI + D) {
+            const int d = t - nI;
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc = fma(lq[ii], zs[ii * LD + d], acc);
+        } else if (t < nI + 2 * D) {
+            const int d = t - nI - D;
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc = fma(lv[ii], zs[ii * LD + d], acc);
+        } else if (t == nI + 2 * D) {
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc += lv[ii];
+        }
+        __syncthreads();
+    }
+    if (t <= nI + 2 * D) mpart[((long)a * nrc + rc) * (nI + 2 * D + 1) + t] = acc;
+}
+
+// stage 2 (a workgroup of k_mm_bwd_fin): out[a][D + D*D]
+__device__ void bwd_mean_final(const MMModel& md, const double* __restrict__ bars, const double* __restrict__ head, int a,
+                               int nrc, const double* __restrict__ mpart, double* __restrict__ out, double* sm) {
+    const int D = md.D, E = md.E, t = threadIdx.x;
+    const int nI = D * D;
+    double* T = sm;                 // [D][D]
+    double* u = T + nI;             // [D + 2]: u | mu | c_a
+    double* sc = u + D + 2;         // [2]  phi
+    double* Th = sc + 2;            // [D]
+    double* red = Th + D;           // [nI + 2 D + 1]   H2q | wq | h | g
+    double* TH = red + nI + 2 * D + 1;  // [D][D]
+    const double* Vbar = bars + E + E * E;
+    const double* hd = head + (long)a * (nI + D + 2);
+    for (int e = t; e < nI + D + 2; e += 256) (e < nI ? T[e] : u[e - nI]) = hd[e];
+    if (t <= nI + 2 * D) {
+        double acc = 0.0;
+        for (int c = 0; c < nrc; ++c) acc += mpart[((long)a * nrc + c) * (nI + 2 * D + 1) + t];   // fixed order
+        red[t] = acc;
+    }
+    __syncthreads();
+    const double mu = u[D], c_a = u[D + 1];
+    const double* H2q = red;
+    const double* wq = red + nI;
+    const double* h = red + nI + D;
+    const double g = red[nI + 2 * D];
+    if (t < D) {
+        double acc2 = 0.0;
+        for (int c = 0; c < D; ++c) acc2 = fma(T[t * D + c], h[c], acc2);
+        Th[t] = acc2;
+    }
+    if (t < nI) {
+        const int r = t / D, c = t - r * D;
+        double acc2 = 0.0;
+        for (int k = 0; k < D; ++k) acc2 = fma(T[r * D + k], H2q[k * D + c], acc2);
+        TH[t] = acc2;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double vTh = 0.0;
+        for (int d = 0; d < D; ++d) vTh = fma(Vbar[d * E + a], Th[d], vTh);
+        sc[0] = c_a * (mu * g + vTh);
+    }
+    __syncthreads();
+    const double phi = sc[0];
+    double* o = out + (long)a * (D + nI);
+    if (t < nI) {
+        const int r = t / D, c = t - r * D;
+        double acc2 = 0.0;
+        for (int k = 0; k < D; ++k) acc2 = fma(TH[r * D + k], T[k * D + c], acc2);
+        o[D + t] = -0.5 * phi * T[r * D + c] + 0.5 * c_a * acc2 - 0.5 * c_a * (u[r] * Th[c] + Th[r] * u[c]);
+    } else if (t < nI + D) {
+        const int r = t - nI;
+        double tw = 0.0;
+        for (int c = 0; c < D; ++c) tw = fma(T[r * D + c], wq[c], tw);
+        o[r] = c_a * (tw - g * u[r]);
+    }
+}
+
+// Per unordered pair and row chunk: partial sums of  N_ab = sum_i r_i,  A = sum_i (r_i z_i + c_i w_i)  (D),
+// I = sum_i (r_i z_i z_i^T + c_i w_i w_i^T + z_i m_i^T + m_i z_i^T)  (D x D).   part[pl][chunk][1 + D + D*D]
+constexpr int BWD_RC = 16;  // row chunks per pair / output
+__global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, const double* __restrict__ rowmom,
+                                                    const double* __restrict__ cpart, int njs, int nrb,
+                                                    double* __restrict__ part, int nrc,
+                                                    const double* __restrict__ head, double* __restrict__ mpart) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int npad = md.npad, D = md.D, E = md.E, t = threadIdx.x;
+    const int pl = blockIdx.x, rc = blockIdx.y;
+    if (pl >= wk.PL) {   // the last E workgroup columns: mean part of output pl - PL
+        bwd_mean_partial(md, wk, head, pl - wk.PL, rc, nrc, mpart, sm);
+        return;
+    }
+    int a, b;
+    local_pair_ab(wk, E, pl, a, b);
+    const double* mom0 = rowmom + (long)pl * njs * 16 * npad;
+    const double* cp = (a != b) ? cpart + (long)(pl - wk.EL) * nrb * npad : nullptr;
+    const int LD = D | 1;         // odd row stride: the (d, e) readers of one point spread over the banks
+    double* zs = sm;              // [64][LD]
+    double* ws = zs + 64 * LD;    // [64][LD]
+    double* ms = ws + 64 * LD;    // [64][LD]
+    double* rs = ms + 64 * LD;    // [64]
+    double* cs = rs + 64;         // [64]
+    double* ia = cs + 64;         // [D] 1 / l_a^2
+    double* ib = ia + D;          // [D] 1 / l_b^2
+    double* mm = ib + D;          // [D] input mean
+    const int nI = D * D;
+    const int nblk = npad / 64;
+    if (t < D) {
+        const double la = md.ls[a * D + t], lb = md.ls[b * D + t];
+        ia[t] = 1.0 / (la * la);
+        ib[t] = 1.0 / (lb * lb);
+        mm[t] = wk.in_m[t];
+    }
+    double acc = 0.0;
+    for (int blk = rc; blk < nblk; blk += nrc) {
+        const int i0 = blk * 64;
+        __syncthreads();
+        for (int e = t; e < 64 * D; e += 256) {
+            const int d = e >> 6, ii = e & 63;   // consecutive threads -> consecutive points: coalesced
+            const int i = i0 + ii;
+            const bool valid = i < md.n;
+            const double zeta = valid ? md.Pt[(long)d * npad + i] - mm[d] : 0.0;
+            zs[ii * LD + d] = zeta * ia[d];
+            ws[ii * LD + d] = zeta * ib[d];
+            double mv = 0.0;
+            if (valid)
+                for (int q = 0; q < njs; ++q) mv += mom0[((long)q * 16 + d) * npad + i];
+            ms[ii * LD + d] = mv;
+        }
+        if (t < 64) {
+            const int i = i0 + t;
+            const bool valid = i < md.n;
+            double r = 0.0, c = 0.0;
+            if (valid) {
+                for (int q = 0; q < njs; ++q) r += mom0[((long)q * 16 + D) * npad + i];
+                if (cp)
+                    for (int q = 0; q < nrb; ++q) c += cp[(long)q * npad + i];
+                else
+                    c = r;
+            }
+            rs[t] = r;
+            cs[t] = c;
+        }
+        __syncthreads();
+        if (t < nI) {
+            const int d = t / D, e2 = t - d * D;
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) {
+                const double zd = zs[ii * LD + d], ze = zs[ii * LD + e2];
+                acc = fma(rs[ii] * zd, ze, acc);
+                acc = fma(cs[ii] * ws[ii * LD + d], ws[ii * LD + e2], acc);
+                acc = fma(zd, ms[ii * LD + e2], acc);
+                acc = fma(ms[ii * LD + d], ze, acc);
+            }
+        } else if (t < nI + D) {
+            const int d = t - nI;
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc = fma(rs[ii], zs[ii * LD + d], fma(cs[ii], ws[ii * LD + d], acc));
+        } else if (t == nI + D) {
+            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc += rs[ii];
+        }
+    }
+    double* o = part + ((long)pl * nrc + rc) * (1 + D + nI);
+    if (t < nI) o[1 + D + t] = acc;
+    else if (t < nI + D) o[1 + (t - nI)] = acc;
+    else if (t == nI + D) o[0] = acc;
+}
+
+// Per pair, with P = (I + Lambda s)^-1 and kappa = Shat_ab / sqrt(det R_ab) from the step's head record:
+//   mbar += kappa P A,   sbar += kappa (P I P^T / 2 - N (P Lambda + Lambda P^T) / 4)      
+// out[E + pl][D + D*D].  bars = (Mbar [E] | Sbar [E][E] | Vbar [D][E]) on the device.  Workgroups past the pairs
+// finish the mean part of one output each.
+__global__ __launch_bounds__(256) void k_mm_bwd_fin(MMModel md, MMWork wk, const double* __restrict__ part, int nrc,
+                                                   const double* __restrict__ bars, const double* __restrict__ head,
+                                                   const double* __restrict__ mpart, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x;
+    if (pl >= wk.PL) {
+        bwd_mean_final(md, bars, head, pl - wk.PL, nrc, mpart, out, sm);
+        return;
+    }
+    const int nI = D * D, rec = 1 + D + nI;
+    double* Pm = sm;               // [D][D]
+    double* lam = Pm + nI;         // [D + 2]: lambda | kappa
+    double* Iv = lam + D + 2;      // [rec]  summed partials (N | A | I)
+    double* PI = Iv + rec;         // [D][D]
+    const double* hd = head + (long)(E + pl) * (nI + D + 2);
+    for (int e = t; e < nI + D + 2; e += 256) (e < nI ? Pm[e] : lam[e - nI]) = hd[e];
+    for (int e = t; e < rec; e += 256) {
+        double acc = 0.0;
+        for (int c = 0; c < nrc; ++c) acc += part[((long)pl * nrc + c) * rec + e];   // fixed order
+        Iv[e] = acc;
+    }
+    __syncthreads();
+    const double kappa = lam[D];
+    const double Nab = Iv[0];
+    const double* Av = Iv + 1;
+    const double* Im = Iv + 1 + D;
+    if (t < nI) {
+        const int r = t / D, c = t - r * D;
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k) acc = fma(Pm[r * D + k], Im[k * D + c], acc);
+        PI[t] = acc;
+    }
+    __syncthreads();
+    double* o = out + (long)(E + pl) * (D + nI);
+    if (t < nI) {
+        const int r = t / D, c = t - r * D;
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k) acc = fma(PI[r * D + k], Pm[c * D + k], acc);   // (P I P^T)[r][c]
+        const double pl2 = Pm[r * D + c] * lam[c] + Pm[c * D + r] * lam[r];         // P Lambda + Lambda P^T
+        o[D + t] = kappa * (0.5 * acc - 0.25 * Nab * pl2);
+    } else if (t < nI + D) {
+        const int r = t - nI;
+        double acc = 0.0;
+        for (int c = 0; c < D; ++c) acc = fma(Pm[r * D + c], Av[c], acc);
+        o[r] = kappa * acc;
+    }
+}
+
+void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb) {
+    *nrb = (npad + 64 * BWD_RT - 1) / (64 * BWD_RT);
+    int q = 1;   // column splits: enough workgroups for a few balanced rounds of the chip
+    while (q < 4 && (npad / 16) % (2 * q) == 0 && (long)*nrb * PL * q < 1536) q *= 2;
+    *njs = q;
+}
+
+void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* part,
+                   const double* bars, double* head, double* out) {
+    const int P = wk.PL, E = md.E, D = md.D;
+    int njs, nrb;
+    mm_bwd_geometry(md.npad, P, &njs, &nrb);
+    const int nhead = E + P, per_row = nrb * njs;
+    dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);   // the rows past P hold the head workgroups
+    const int LD = D | 1, nI = D * D;
+    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * (md.npad / njs), (size_t)4 * nI + D);
+#define PB(K_) hipLaunchKernelGGL((k_mm_bwd_pair<K_>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head)
+    switch (wk.KP / 4) {
+        case 1: PB(1); break;
+        case 2: PB(2); break;
+        case 3: PB(3); break;
+        default: PB(4); break;
+    }
+#undef PB
+    const int nrc = mm_bwd_rc(md.npad);
+    double* mpart = part + (size_t)P * nrc * (1 + D + nI);
+    const size_t lds_post = sizeof(double) * std::max((size_t)3 * 64 * LD + 128 + 3 * D, (size_t)nI + 64 * LD + 128 + D + 2);
+    hipLaunchKernelGGL(k_mm_bwd_post, dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
+                       head, mpart);
+    const size_t lds_fin = sizeof(double) * ((size_t)3 * nI + 4 * D + 8);
+    hipLaunchKernelGGL(k_mm_bwd_fin, dim3(P + E), dim3(256), lds_fin, st, md, wk, part, nrc, bars, head, mpart, out);
+}
+int mm_bwd_rc(int npad) { return std::min(BWD_RC, npad / 64); }
+
+}  // namespace pilco

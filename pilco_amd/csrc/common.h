@@ -89,7 +89,7 @@ void launch_logdet(hipStream_t st, const double* L, int npad, int n, int batch, 
 void launch_nlml_grad(hipStream_t st, const double* Pt, int npad, int n, int D, const double* ls, const double* var,
                       const double* iK, const double* beta, int batch, double* partial, double* grad);
 
-// ---------------------------------------------------------------- moment.hip
+// ---------------------------------------------------------------- prep.hip / pair.hip / glue.hip / bwd.hip
 struct MMWork;  // defined in moment.h
 
 }  // namespace pilco

@@ -1,0 +1,362 @@
+// Device-side helpers shared by the moment-matching translation units (prep.hip, pair.hip, bwd.hip, glue.hip):
+// pair indexing, write-through stores, DPP reductions, the table-driven fp64 exp, register / LDS Gauss-Jordan,
+// buffer loads and the reward evaluation.  Internal; gfx950 only.
+#pragma once
+#include "moment.h"
+
+#include <type_traits>
+
+namespace pilco {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// local pair index -> outputs (a >= b); see the dealing order in moment.h
+__device__ __forceinline__ void local_pair_ab(const MMWork& wk, int E, int pl, int& a, int& b) {
+    const int kk = pl * wk.nranks + wk.rank;
+    if (kk < E) {
+        a = b = kk;
+        return;
+    }
+    const int q = kk - E;
+    a = 1;
+    while (a * (a + 1) / 2 <= q) ++a;
+    b = q - a * (a - 1) / 2;
+}
+__device__ __forceinline__ int pair_order_index(int E, int a, int b) {  // a >= b
+    return (a == b) ? a : E + a * (a - 1) / 2 + b;
+}
+
+// Write-through (sc1) store: the 10 MB of per-step operands leave the XCD's L2 as they are
+// produced instead of in the end-of-kernel write-back, which is what the next kernel waits on.
+__device__ __forceinline__ void store_wt(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define DBG_STAMP(wk_, slot_, cond_)                                           \
+    do {                                                                       \
+        if ((wk_).dbg && (cond_)) (wk_).dbg[slot_] = wall_clock64();          \
+    } while (0)
+
+// Wave-wide sum in lane 63 with DPP row shifts / broadcasts (no LDS traffic, fixed order).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row sum
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return v;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Table-driven fp64 exp for the pair kernel: with T = 2^FEXP_TB table entries, x = (T m + j) ln2/T + r,
+// exp(x) = 2^m * tab[j] * (1 + r + r^2/2 + r^3/6 + r^4/24), |r| <= ln2/(2T): for T = 256 the dropped
+// r^5/120 term is < 4e-17 (T = 64 keeps it).  n = rint(T x / ln2) comes out of the low mantissa
+// bits of x*C + 1.5*2^52 (no cvt), 2^m is an integer add into the exponent field.
+// Inputs below -700 are clamped (result ~1e-304 instead of 0); the exponents of
+// this path are bounded above by log(var_a var_b).  The reduction uses a single
+// ln2/T constant: its rounding contributes |x| * 1.1e-16 relative error, the same
+// size as the rounding of the exponent x itself.  Split into three phases so that a
+// wave keeps all its table reads in flight while it evaluates the polynomials.
+#ifndef FEXP_TB
+#define FEXP_TB 8    // log2 of the table size: 256 entries let the polynomial stop at degree 4 (|r| <= ln2/512)
+#endif
+#define FEXP_TN (1 << FEXP_TB)
+#if FEXP_TB == 6
+#define FEXP_C 92.332482616893656758       /* 64 / ln2 */
+#define FEXP_LN2_64 0.010830424696249145   /* ln2 / 64 */
+#else
+#define FEXP_C 369.3299304675746       /* 256 / ln2 */
+#define FEXP_LN2_64 0.0027076061740622863   /* ln2 / 256 */
+#endif
+#define FEXP_MAGIC 6755399441055744.0      /* 1.5 * 2^52 */
+
+#ifndef PAIR_OPT
+#define PAIR_OPT 0   // experiment bits (tools): 1 no inline asm, 2 no clamp, 4 no sched barriers
+#endif
+__device__ __forceinline__ double fexp_clamp(double x) {
+#if PAIR_OPT & 2
+    return x;
+#elif PAIR_OPT & 1
+    return fmax(x, -700.0);
+#else
+    double y;
+    const double lo = -700.0;
+    asm("v_max_f64 %0, %1, %2" : "=v"(y) : "v"(x), "s"(lo));  // one instruction: no canonicalising pre-max
+    return y;
+#endif
+}
+__device__ __forceinline__ double fexp_t(double x) { return fma(x, FEXP_C, FEXP_MAGIC); }
+__device__ __forceinline__ double fexp_poly(double x, double t) {
+    const double nf = t - FEXP_MAGIC;
+    const double r = fma(nf, -FEXP_LN2_64, x);
+#if FEXP_TB == 6
+    double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    q = fma(r, q, 1.0 / 6.0);
+#else
+    double q = fma(r, 1.0 / 24.0, 1.0 / 6.0);
+#endif
+    q = fma(r, q, 0.5);
+    q = fma(r, q, 1.0);
+    return r * q;
+}
+__device__ __forceinline__ double fexp_finish(double tv, double pm1, double t) {
+    const double res = fma(tv, pm1, tv);
+    const int lo = __double2loint(t) & ~(FEXP_TN - 1);
+    int hi;
+#if PAIR_OPT & 1
+    hi = __double2hiint(res) + (lo << (20 - FEXP_TB));
+#else
+    asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(hi) : "v"(lo), "v"(__double2hiint(res)), "n"(20 - FEXP_TB));  // exponent += n >> FEXP_TB
+#endif
+    return __hiloint2double(hi, __double2loint(res));
+}
+__device__ __forceinline__ double fexp(double x, const double* __restrict__ tab) {
+    x = fexp_clamp(x);
+    const double t = fexp_t(x);
+    const double tv = tab[__double2loint(t) & (FEXP_TN - 1)];
+    return fexp_finish(tv, fexp_poly(x, t), t);
+}
+
+// Pivoted Gauss-Jordan on an n x nc augmented matrix held in LDS (row-major,
+// ld = nc), ping-ponging between two buffers: one barrier per pivot step.
+// Called by the whole workgroup.  Returns the buffer holding [I | A^{-1} B];
+// det = det(A) (valid in every thread).  General (slow) path.
+__device__ inline double* gauss_jordan(double* G0, double* G1, int n, int nc, double& det) {
+    double* cur = G0;
+    double* nxt = G1;
+    det = 1.0;
+    for (int k = 0; k < n; ++k) {
+        __syncthreads();
+        int p = k;
+        double best = fabs(cur[k * nc + k]);
+        for (int r = k + 1; r < n; ++r) {
+            const double v = fabs(cur[r * nc + k]);
+            if (v > best) {
+                best = v;
+                p = r;
+            }
+        }
+        const double piv = cur[p * nc + k];
+        det *= (p == k) ? piv : -piv;
+        for (int e = threadIdx.x; e < n * nc; e += blockDim.x) {
+            const int r = e / nc, c = e - r * nc;
+            const double pk = cur[p * nc + c] / piv;
+            double val;
+            if (r == k) {
+                val = pk;
+            } else {
+                const int rs = (r == p) ? k : r;
+                val = fma(-cur[rs * nc + k], pk, cur[rs * nc + c]);
+            }
+            nxt[e] = val;
+        }
+        double* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+    }
+    __syncthreads();
+    return cur;
+}
+
+// 1/x to fp64 accuracy: hardware reciprocal estimate + two Newton steps (short dependency chain;
+// the IEEE division sequence is ~3x longer and sits on the critical path of every pivot).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// Unpivoted Gauss-Jordan with the matrix in registers: lane c of ONE wave holds column c of the
+// DT x 2DT augmented matrix [A | B].  Per pivot the multipliers (column k) are broadcast from lane k
+// with v_readlane; no LDS, no barriers (an LDS-broadcast variant measured slower at DT = 12).  On return
+// lanes DT..2DT-1 hold the columns of A^{-1} B.  For SPD / diagonally-similar-to-SPD systems (no pivoting).
+template <int DT>
+__device__ __forceinline__ double gj_wave(double (&a)[DT], double* colbuf, int lane) {
+    double det = 1.0;
+#pragma unroll
+    for (int k = 0; k < DT; ++k) {
+        double f[DT];
+#pragma unroll
+        for (int r = 0; r < DT; ++r) f[r] = readlane_f64(a[r], k);
+        (void)colbuf;
+        (void)lane;
+        const double piv = f[k];
+        det *= piv;
+        const double pk = a[k] * fast_rcp(piv);
+#pragma unroll
+        for (int r = 0; r < DT; ++r)
+            if (r != k) a[r] = fma(-f[r], pk, a[r]);
+        a[k] = pk;
+    }
+    return det;
+}
+
+// ------------------------------------------------------------------ rewards
+// Unpivoted Gauss-Jordan for symmetric positive definite systems on an n x nc augmented
+// matrix in LDS (ping-pong buffers, one barrier per pivot, one element per thread when
+// n*nc <= blockDim).  Returns the buffer holding [I | A^{-1} B]; det in every thread.
+__device__ inline double* gauss_jordan_spd(double* G0, double* G1, int n, int nc, double& det) {
+    double* cur = G0;
+    double* nxt = G1;
+    det = 1.0;
+    for (int k = 0; k < n; ++k) {
+        __syncthreads();
+        const double piv = cur[k * nc + k];
+        det *= piv;
+        for (int e = threadIdx.x; e < n * nc; e += blockDim.x) {
+            const int r = e / nc, c = e - r * nc;
+            const double pk = cur[k * nc + c] / piv;
+            nxt[e] = (r == k) ? pk : fma(-cur[r * nc + k], pk, cur[r * nc + c]);
+        }
+        double* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+    }
+    __syncthreads();
+    return cur;
+}
+
+// exp(-scale q / 2) / sqrt(det(I + scale S W)),  q = d^T W (I + scale S W)^{-1} d,  d = m - t
+// (rewards.py:32-48; scale 1 -> mean, scale 2 -> second moment).  ws: LDS scratch.
+__device__ inline double exp_reward_moment(const RewardDev& rw, int E, double scale, const double* mx, const double* sx,
+                                    double* ws) {
+    const int t = threadIdx.x;
+    double result;
+    if (rw.rank >= 0) {
+        // W = F F^T (symmetric PSD): q = y^T (I + scale F^T S F)^{-1} y with y = F^T d, and
+        // det(I + scale S W) = det(I_r + scale F^T S F): an SPD r x r system, no pivoting needed.
+        const int r = rw.rank;
+        double* y = ws;              // [E]
+        double* Fl = y + E;          // [E*E]  F staged in LDS
+        double* SF = Fl + E * E;     // [E*E]
+        double* A = SF + E * E;      // [E*E]
+        double* slot = A + E * E + E * (E + 1);
+        for (int e2 = t; e2 < E * r; e2 += blockDim.x) Fl[e2] = rw.F[e2];
+        if (t < E) slot[2 + t] = mx[t] - rw.t[t];
+        __syncthreads();
+        const double* d = slot + 2;
+        for (int k = t; k < r; k += blockDim.x) {
+            double acc = 0.0;
+            _Pragma("unroll 8") for (int e = 0; e < E; ++e) acc = fma(Fl[e * r + k], d[e], acc);
+            y[k] = acc;
+        }
+        for (int e2 = t; e2 < E * r; e2 += blockDim.x) {
+            const int e = e2 / r, k = e2 - e * r;
+            double acc = 0.0;
+            _Pragma("unroll 8") for (int f = 0; f < E; ++f) acc = fma(sx[e * E + f], Fl[f * r + k], acc);
+            SF[e2] = acc;
+        }
+        __syncthreads();
+        for (int e2 = t; e2 < r * r; e2 += blockDim.x) {
+            const int k = e2 / r, l = e2 - k * r;
+            double acc = 0.0;
+            _Pragma("unroll 8") for (int e = 0; e < E; ++e) acc = fma(Fl[e * r + k], SF[e * r + l], acc);
+            A[e2] = fma(scale, acc, (k == l) ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        // [A | y] -> A^{-1} y; A is SPD so no pivoting is needed
+        double* G0 = SF;             // SF is dead from here on: reuse as the augmented matrix
+        double* G1 = A + E * E;      // [E*(E+1)]
+        const int nc = r + 1;
+        for (int e2 = t; e2 < r * nc; e2 += blockDim.x) {
+            const int k = e2 / nc, l = e2 - k * nc;
+            G1[e2] = (l < r) ? A[k * r + l] : y[k];
+        }
+        __syncthreads();
+        for (int e2 = t; e2 < r * nc; e2 += blockDim.x) G0[e2] = G1[e2];
+        double det;
+        const double* res = gauss_jordan_spd(G0, G1, r, nc, det);
+        if (t == 0) {
+            double q = 0.0;
+            for (int k = 0; k < r; ++k) q = fma(y[k], res[k * nc + r], q);
+            slot[0] = exp(-0.5 * scale * q) / sqrt(det);
+        }
+        __syncthreads();
+        result = slot[0];
+        __syncthreads();
+    } else {
+        // general W: aug = [(I + scale S W)^T | W^T] -> X^T, X = W (I + scale S W)^{-1}
+        const int nc = 2 * E;
+        double* G0 = ws;
+        double* G1 = G0 + 2 * E * E;
+        double* slot = G1 + 2 * E * E;
+        for (int e = t; e < E * nc; e += blockDim.x) {
+            const int r = e / nc, c = e - r * nc;
+            double v;
+            if (c < E) {
+                double sw = 0.0;  // (S W)[c][r]
+                _Pragma("unroll 8") for (int k = 0; k < E; ++k) sw = fma(sx[c * E + k], rw.W[k * E + r], sw);
+                v = fma(scale, sw, (r == c) ? 1.0 : 0.0);
+            } else {
+                v = rw.W[(c - E) * E + r];
+            }
+            G0[e] = v;
+        }
+        double det;
+        double* res = gauss_jordan(G0, G1, E, nc, det);
+        if (t == 0) {
+            double q = 0.0;
+            for (int r = 0; r < E; ++r) {
+                double acc = 0.0;
+                _Pragma("unroll 8") for (int c = 0; c < E; ++c) acc = fma(res[c * nc + E + r], mx[c] - rw.t[c], acc);
+                q = fma(mx[r] - rw.t[r], acc, q);
+            }
+            slot[0] = exp(-0.5 * scale * q) / sqrt(det);
+        }
+        __syncthreads();
+        result = slot[0];
+        __syncthreads();
+    }
+    return result;
+}
+
+__host__ __device__ inline size_t reward_lds_doubles(int E) { return (size_t)E + 4 * (size_t)E * E + (size_t)E * (E + 1) + (size_t)E + 16; }
+
+// mean (and variance) of the combined reward at (mx, sx) held in LDS (rewards.py:19-81)
+__device__ __forceinline__ void reward_eval(int n, const RewardDev* rws, int E, const double* mx, const double* sx, double* ws,
+                            bool want_var, double& mu_out, double& var_out) {
+    double mu = 0.0, var = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const RewardDev& rw = rws[i];
+        double m_i = 0.0, v_i = 0.0;
+        if (rw.kind == PILCO_REWARD_EXPONENTIAL) {
+            m_i = exp_reward_moment(rw, E, 1.0, mx, sx, ws);
+            if (want_var) v_i = exp_reward_moment(rw, E, 2.0, mx, sx, ws) - m_i * m_i;
+        } else {  // linear: rewards.py:58-61
+            _Pragma("unroll 8") for (int k = 0; k < E; ++k) m_i = fma(mx[k], rw.W[k], m_i);
+            if (want_var)
+                for (int r = 0; r < E; ++r)
+                    _Pragma("unroll 8") for (int c = 0; c < E; ++c) v_i = fma(rw.W[r] * sx[r * E + c], rw.W[c], v_i);
+        }
+        mu = fma(rw.coef, m_i, mu);
+        var = fma(rw.coef * rw.coef, v_i, var);
+    }
+    mu_out = mu;
+    var_out = var;
+}
+
+// Buffer loads for the hot loop: wave-uniform resource (base pointer) + 32-bit per-lane byte offset + scalar byte
+// offset, i.e. no 64-bit address arithmetic in the VALU stream (the fp64 pipe is the bottleneck of this kernel).
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const double* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, 0x7fffffff, 0x00020000);   // raw, untyped
+}
+__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+
+}  // namespace pilco
