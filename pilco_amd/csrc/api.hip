@@ -1,84 +1,11 @@
-// C ABI of libpilco_hip.so (see include/pilco_hip.h): context, GP slots,
-// factorisation drivers, single moment-matching step, rollout, sharding.
-#include <rccl/rccl.h>
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdint>
-
-#include "moment.h"
-
-using namespace pilco;
-
-namespace {
-
-struct Slot {
-    int N = 0, D = 0, E = 0, M = 0;  // data size, input dim, outputs, inducing points (0 = exact)
-    int Npad = 0;                    // padded N
-    int n = 0, npad = 0;             // points the moment matching runs over (N or M) and padding
-    bool has_data = false, has_hyp = false, factor_valid = false, user_factors = false, iK_null = false;
-    bool ignore_iK = false;  // policy slot: RbfController evaluates with iK zeroed (controllers.py:116)
-    DevBuf bwd_mom, bwd_cp, bwd_part, bwd_out; // reverse-pass scratch
-    DevBuf Xt, Yt, Zt, ls, var, noise;         // Yt: [E][Npad]
-    DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
-    DevBuf Kmn, V2, Am, AmInv, AmD, iAt, G;    // FITC extras
-    // moment-matching workspace
-    DevBuf w_in, w_At, w_Bt, w_small, w_part, w_gath, w_out;
-    MMWork wk{};
-    bool wk_valid = false;
-    int wk_variant = -1;
-    std::vector<int> pair_owner;  // [P]
-};
-
-}  // namespace
-
-struct pilco_ctx {
-    int device = 0;
-    hipStream_t st = nullptr;
-    std::string err;
-    int not_pd = -1;
-    int variant = 0;
-    int rank = 0, nranks = 1;
-    ncclComm_t comm = nullptr;
-    Slot slot[2];
-    int* d_info = nullptr;
-    DevBuf state;   // m_x, s_x, s1, reward, act_out, rew_out
-    DevBuf params;  // policy + reward parameters
-    DevBuf traj;
-    DevBuf tape;
-    DevBuf selftest;
-    DevBuf exp_tab;  // 2^(j/n), j = 0..n-1, n = mm_exp_table_size()
-    unsigned long long* dbg = nullptr;
-    // cached hipGraph of one rollout (single-rank): replayed while the plan key is unchanged
-    hipGraphExec_t graph = nullptr;
-    std::vector<unsigned long long> graph_key;
-    bool use_graph = true;
-    bool graph_rccl_failed = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<hipEvent_t> pair_events;
-    double* pin = nullptr;   // pinned host staging buffer of the reverse pass (truly asynchronous small copies)
-    size_t pin_cap = 0;
-};
-
-namespace {
+// C ABI of libpilco_hip.so (see include/pilco_hip.h): context, GP slots, factorisation drivers, the single
+// moment-matching step and introspection.  Rollouts: rollout.hip; reverse mode: grad.hip; sharding: shard.hip.
+#include "ctx.h"
 
 int fail(pilco_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
     return code;
 }
-
-#define HIPCHK(call)                                                                                       \
-    do {                                                                                                   \
-        hipError_t e_ = (call);                                                                            \
-        if (e_ != hipSuccess)                                                                              \
-            return fail(ctx, PILCO_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
-    } while (0)
-
-#define ENSURE(buf, count)                                                                                 \
-    do {                                                                                                   \
-        if ((buf).ensure(count) != hipSuccess) return fail(ctx, PILCO_E_ALLOC, "hipMalloc failed: " #buf); \
-    } while (0)
 
 int check_slot(pilco_ctx* ctx, int slot) {
     if (!ctx) return PILCO_E_SHAPE;
@@ -174,100 +101,6 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     return PILCO_OK;
 }
 
-// W (E x E, symmetric PSD) = F F^T with F (E x rank) from a cyclic Jacobi eigen-decomposition.
-// Returns rank, or -1 when W is not symmetric PSD (the general pivoted device path is used then).
-int psd_factor(const double* W, int E, std::vector<double>& F) {
-    double scale = 0.0;
-    for (int i = 0; i < E * E; ++i) scale = std::max(scale, std::fabs(W[i]));
-    if (scale == 0.0) { F.clear(); return 0; }
-    for (int i = 0; i < E; ++i)
-        for (int j = 0; j < i; ++j)
-            if (std::fabs(W[i * E + j] - W[j * E + i]) > 1e-13 * scale) return -1;
-    std::vector<double> A(W, W + E * E), V(E * E, 0.0);
-    for (int i = 0; i < E; ++i) V[i * E + i] = 1.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0;
-        for (int i = 0; i < E; ++i)
-            for (int j = 0; j < i; ++j) off += A[i * E + j] * A[i * E + j];
-        if (off <= 1e-32 * scale * scale) break;
-        for (int p = 0; p < E; ++p)
-            for (int q = p + 1; q < E; ++q) {
-                const double apq = A[p * E + q];
-                if (apq == 0.0) continue;
-                const double theta = (A[q * E + q] - A[p * E + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
-                for (int k = 0; k < E; ++k) {
-                    const double akp = A[k * E + p], akq = A[k * E + q];
-                    A[k * E + p] = c * akp - sn * akq;
-                    A[k * E + q] = sn * akp + c * akq;
-                }
-                for (int k = 0; k < E; ++k) {
-                    const double apk = A[p * E + k], aqk = A[q * E + k];
-                    A[p * E + k] = c * apk - sn * aqk;
-                    A[q * E + k] = sn * apk + c * aqk;
-                }
-                for (int k = 0; k < E; ++k) {
-                    const double vkp = V[k * E + p], vkq = V[k * E + q];
-                    V[k * E + p] = c * vkp - sn * vkq;
-                    V[k * E + q] = sn * vkp + c * vkq;
-                }
-            }
-    }
-    double lmax = 0.0;
-    for (int i = 0; i < E; ++i) lmax = std::max(lmax, A[i * E + i]);
-    for (int i = 0; i < E; ++i)
-        if (A[i * E + i] < -1e-12 * std::max(lmax, scale)) return -1;
-    std::vector<int> keep;
-    for (int i = 0; i < E; ++i)
-        if (A[i * E + i] > 1e-15 * lmax) keep.push_back(i);
-    const int r = (int)keep.size();
-    F.assign((size_t)E * std::max(r, 1), 0.0);
-    for (int k = 0; k < r; ++k) {
-        const double sq = std::sqrt(A[keep[k] * E + keep[k]]);
-        for (int e = 0; e < E; ++e) F[(size_t)e * r + k] = V[e * E + keep[k]] * sq;
-    }
-    return r;
-}
-
-// marshal reward terms into a host staging vector; pointers are patched relative to dev_base
-int stage_rewards(pilco_ctx* ctx, const pilco_reward_term* rw, int n_rw, int E, std::vector<double>& hp, size_t& off,
-                  const double* dev_base, RewardDev* out) {
-    for (int i = 0; i < n_rw; ++i) {
-        out[i].kind = rw[i].kind;
-        out[i].coef = rw[i].coef;
-        out[i].F = nullptr;
-        out[i].rank = -1;
-        if (!rw[i].W) return fail(ctx, PILCO_E_SHAPE, "reward: W is required");
-        if (rw[i].kind == PILCO_REWARD_EXPONENTIAL) {
-            hp.resize(std::max(hp.size(), off + (size_t)2 * E * E + E));
-            memcpy(&hp[off], rw[i].W, sizeof(double) * E * E);
-            out[i].W = dev_base + off; off += (size_t)E * E;
-            if (rw[i].t) memcpy(&hp[off], rw[i].t, sizeof(double) * E);
-            else std::fill(hp.begin() + off, hp.begin() + off + E, 0.0);
-            out[i].t = dev_base + off; off += E;
-            std::vector<double> F;
-            const int r = psd_factor(rw[i].W, E, F);
-            out[i].rank = r;
-            if (r > 0) {
-                memcpy(&hp[off], F.data(), sizeof(double) * E * r);
-                out[i].F = dev_base + off;
-            } else if (r == 0) {
-                out[i].F = dev_base + off;
-            }
-            off += (size_t)E * E;
-        } else if (rw[i].kind == PILCO_REWARD_LINEAR) {
-            hp.resize(std::max(hp.size(), off + (size_t)E));
-            memcpy(&hp[off], rw[i].W, sizeof(double) * E);
-            out[i].W = dev_base + off; off += E;
-            out[i].t = out[i].W;
-        } else {
-            return fail(ctx, PILCO_E_SHAPE, "reward: unknown kind");
-        }
-    }
-    return PILCO_OK;
-}
-
 MMModel model_of(const Slot& s) {
     MMModel md{};
     md.Pt = s.M > 0 ? s.Zt.p : s.Xt.p;
@@ -330,10 +163,6 @@ int factorize_exact(pilco_ctx* ctx, Slot& s) {
     return PILCO_OK;
 }
 
-}  // namespace
-
-// sparse FITC factorisation lives in fitc.hip
-int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr);
 
 extern "C" {
 
@@ -673,449 +502,6 @@ int pilco_gp_predict(pilco_ctx* ctx, int slot, const double* m, const double* s_
     return PILCO_OK;
 }
 
-}  // extern "C"
-
-// ------------------------------------------------------------------ rollout
-namespace {
-
-struct RolloutPlan {
-    GlueArgs g{};
-    double* st[2] = {nullptr, nullptr};  // double-buffered state: m_x[E] | s_x[E*E]
-    int E = 0, D = 0, U = 0;
-};
-
-int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_term* rw, int n_rw, int H, bool want_traj,
-                  RolloutPlan& plan) {
-    Slot& s = ctx->slot[0];
-    if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "rollout: dynamics model has no current factorisation");
-    if (!pol) return fail(ctx, PILCO_E_SHAPE, "rollout: null policy");
-    const int E = s.E, D = s.D, U = D - E;
-    if (pol->state_dim != E || pol->control_dim != U || U < 0)
-        return fail(ctx, PILCO_E_SHAPE, "rollout: policy dims do not match the model (state_dim must be E, control_dim D-E)");
-    if (pol->kind == PILCO_POLICY_NONE && U != 0) return fail(ctx, PILCO_E_SHAPE, "rollout: policy NONE needs D == E");
-    if (pol->kind == PILCO_POLICY_LINEAR && (U == 0 || !pol->W || !pol->b)) return fail(ctx, PILCO_E_SHAPE, "rollout: linear policy needs W, b and control_dim > 0");
-    if (pol->kind == PILCO_POLICY_RBF) {
-        Slot& ps = ctx->slot[PILCO_SLOT_POLICY];
-        if (!ps.factor_valid) return fail(ctx, PILCO_E_STATE, "rollout: RBF policy slot has no current factorisation");
-        if (ps.D != E || ps.E != U || U == 0) return fail(ctx, PILCO_E_SHAPE, "rollout: RBF policy GP must map state_dim -> control_dim");
-        if (ctx->nranks != 1) return fail(ctx, PILCO_E_STATE, "rollout: the RBF policy is evaluated unsharded; use one rank");
-        if (int r = build_work(ctx, ps)) return r;
-    }
-    if (pol->kind < 0 || pol->kind > 2) return fail(ctx, PILCO_E_SHAPE, "rollout: unknown policy kind");
-    if (n_rw < 0 || n_rw > MAX_REWARD_TERMS || (n_rw > 0 && !rw)) return fail(ctx, PILCO_E_SHAPE, "rollout: 0..4 reward terms supported");
-    if (int r = build_work(ctx, s)) return r;
-    // state: 2 x (m_x[E] s_x[E*E]) | s1[E*D] | reward[1]
-    const size_t n_state = 2 * ((size_t)E + E * E) + (size_t)E * D + 1 + 8;
-    ENSURE(ctx->state, n_state);
-    // params: W[U*E] b[U] maxact[U] then per reward W[E*E] t[E] F[E*E]
-    const size_t n_par = (size_t)U * E + 2 * U + (size_t)MAX_REWARD_TERMS * (2 * E * E + E) + 8;
-    ENSURE(ctx->params, n_par);
-    if (want_traj) ENSURE(ctx->traj, (size_t)(H + 1) * (E + E * E));
-    std::vector<double> hp(n_par, 0.0);
-    size_t off = 0;
-    GlueArgs& g = plan.g;
-    g = GlueArgs{};
-    g.E = E; g.D = D; g.U = U;
-    g.wk = s.wk;
-    g.var = s.var.p;
-    plan.st[0] = ctx->state.p;
-    plan.st[1] = ctx->state.p + (E + E * E);
-    g.s1 = ctx->state.p + 2 * (E + E * E);
-    g.reward = g.s1 + (size_t)E * D;
-    g.traj = want_traj ? ctx->traj.p : nullptr;
-    g.pol_kind = pol->kind;
-    g.squash = pol->squash;
-    if (pol->kind == PILCO_POLICY_RBF) {
-        g.pwk = ctx->slot[PILCO_SLOT_POLICY].wk;
-        g.pvar = ctx->slot[PILCO_SLOT_POLICY].var.p;
-        for (int u = 0; u < U; ++u) hp[off + u] = pol->max_action ? pol->max_action[u] : 1.0;
-        g.maxact = ctx->params.p + off; off += U;
-    }
-    if (pol->kind == PILCO_POLICY_LINEAR) {
-        memcpy(&hp[off], pol->W, sizeof(double) * U * E);
-        g.W = ctx->params.p + off; off += (size_t)U * E;
-        memcpy(&hp[off], pol->b, sizeof(double) * U);
-        g.b = ctx->params.p + off; off += U;
-        for (int u = 0; u < U; ++u) hp[off + u] = pol->max_action ? pol->max_action[u] : 1.0;
-        g.maxact = ctx->params.p + off; off += U;
-    }
-    g.n_rewards = n_rw;
-    g.rew_out = nullptr;
-    if (int r = stage_rewards(ctx, rw, n_rw, E, hp, off, ctx->params.p, g.rw)) return r;
-    if (hp.size() > n_par) return fail(ctx, PILCO_E_ALLOC, "rollout: parameter staging overflow");
-    HIPCHK(hipMemcpyAsync(ctx->params.p, hp.data(), sizeof(double) * n_par, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));  // hp is a local vector
-    plan.E = E; plan.D = D; plan.U = U;
-    return PILCO_OK;
-}
-
-// enqueue one full rollout on the stream (initial state already in plan.st[0]); the final
-// state ends up in plan.st[H & 1].  The reward of state t (pilco.py:133) is evaluated by the
-// second workgroup of the glue launch that turns state t into state t+1.
-int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev) {
-    Slot& s = ctx->slot[0];
-    const MMModel md = model_of(s);
-    const int E = plan.E;
-    GlueArgs g = plan.g;
-    const bool rew = g.n_rewards > 0 && !(s.wk.abl & 8);
-    HIPCHK(hipMemsetAsync(g.reward, 0, sizeof(double), ctx->st));
-    g.step = 0;
-    g.m_x = plan.st[0];
-    g.s_x = plan.st[0] + E;
-    g.m_out = nullptr;
-    g.s_out = nullptr;
-    const bool rbf = (g.pol_kind == PILCO_POLICY_RBF);
-    Slot& ps = ctx->slot[PILCO_SLOT_POLICY];
-    const MMModel pmd = rbf ? model_of(ps) : MMModel{};
-    // RBF policy (controllers.py:108-121): the glue that produced the state hands it to the policy GP
-    // (GF_RBF_PRE), the policy's moment matching runs as its own prep/pair, a second glue squashes and
-    // builds the joint Gaussian (GF_RBF_POST | GF_POLICY).
-    auto policy_stage = [&](GlueArgs& ga) {
-        launch_mm_prep(ctx->st, pmd, ps.wk);
-        launch_mm_pair(ctx->st, pmd, ps.wk, ctx->variant);
-        const int keep = ga.flags;
-        ga.flags = GF_RBF_POST | GF_POLICY;
-        launch_glue(ctx->st, ga);
-        ga.flags = keep;
-    };
-    g.flags = GF_TRAJ | (H > 0 ? (rbf ? GF_RBF_PRE : GF_POLICY) : 0);
-    launch_glue(ctx->st, g);
-    if (rbf && H > 0) policy_stage(g);
-    size_t evi = 0;
-    for (int t = 0; t < H; ++t) {
-        if (s.wk.PL > 0) {
-            PrepReward pr{};
-            if (rew) {   // reward of state t rides in a spare workgroup of this step's prep launch
-                pr.n = g.n_rewards;
-                pr.E = E;
-                for (int i = 0; i < g.n_rewards; ++i) pr.rw[i] = g.rw[i];
-                pr.m_x = plan.st[t & 1];
-                pr.s_x = plan.st[t & 1] + E;
-                pr.reward = g.reward;
-            }
-            launch_mm_prep(ctx->st, md, s.wk, rew ? &pr : nullptr);
-            if (ctx->dbg && (s.wk.abl & 64)) launch_stamp(ctx->st, ctx->dbg, 30);
-            if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
-            launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
-            if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
-        }
-        g.step = t + 1;
-        g.m_x = plan.st[t & 1];
-        g.s_x = plan.st[t & 1] + E;
-        g.m_out = plan.st[(t + 1) & 1];
-        g.s_out = plan.st[(t + 1) & 1] + E;
-        const bool more = t + 1 < H;
-        const int tail = GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ | (more ? (rbf ? GF_RBF_PRE : GF_POLICY) : 0);
-        if (ctx->nranks == 1 && !ctx->comm) {
-            g.flags = GF_PACK | tail;
-        } else {
-            g.flags = GF_PACK;
-            launch_glue(ctx->st, g);
-            if (int r = all_gather_segments(ctx, s)) return r;
-            g.flags = tail;
-        }
-        launch_glue(ctx->st, g, rew && s.wk.PL == 0);   // (a rank without pairs keeps the reward in the glue launch)
-        if (rbf && more) {  // the policy stage reads the NEW state
-            g.m_x = g.m_out;
-            g.s_x = g.s_out;
-            policy_stage(g);
-        }
-    }
-    return PILCO_OK;
-}
-
-// Run one rollout: replay the cached hipGraph when the launch sequence is unchanged
-// (same buffers, sizes, horizon, policy / reward structure), otherwise (re)capture it.
-int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
-    Slot& s = ctx->slot[0];
-    // With a communicator the captured graph contains the ncclAllGather nodes (RCCL supports stream
-    // capture); if capture or instantiation fails the rollout falls back to eager launches for good.
-    const bool sharded = (ctx->nranks != 1 || ctx->comm);
-    if (!ctx->use_graph || (sharded && (!ctx->comm || ctx->graph_rccl_failed)) || (ctx->dbg && !getenv("PILCO_DBG_GRAPH")))
-        return enqueue_rollout(ctx, plan, H, nullptr);
-    const GlueArgs& g = plan.g;
-    std::vector<unsigned long long> key = {
-        (unsigned long long)H, (unsigned long long)g.pol_kind, (unsigned long long)g.n_rewards, (unsigned long long)g.squash,
-        (unsigned long long)ctx->variant, (unsigned long long)(uintptr_t)plan.st[0], (unsigned long long)(uintptr_t)g.s1,
-        (unsigned long long)(uintptr_t)g.traj, (unsigned long long)(uintptr_t)g.tape, (unsigned long long)(uintptr_t)g.W, (unsigned long long)(uintptr_t)g.maxact,
-        (unsigned long long)(uintptr_t)s.w_part.p, (unsigned long long)(uintptr_t)s.w_At.p, (unsigned long long)(uintptr_t)s.w_Bt.p,
-        (unsigned long long)(uintptr_t)s.w_small.p, (unsigned long long)(uintptr_t)s.w_gath.p, (unsigned long long)(uintptr_t)s.w_out.p,
-        (unsigned long long)(uintptr_t)s.w_in.p, (unsigned long long)(uintptr_t)s.beta.p,
-        (unsigned long long)(uintptr_t)s.iK.p, (unsigned long long)s.iK_null, (unsigned long long)(uintptr_t)s.Xt.p,
-        (unsigned long long)(uintptr_t)s.Zt.p, (unsigned long long)(uintptr_t)s.ls.p, (unsigned long long)s.n,
-        (unsigned long long)s.wk.sk_waves, (unsigned long long)s.wk.NT, (unsigned long long)s.wk.NCH, (unsigned long long)s.wk.NCHM, (unsigned long long)s.wk.abl,
-        (unsigned long long)(uintptr_t)ctx->slot[1].w_part.p, (unsigned long long)(uintptr_t)ctx->slot[1].w_At.p,
-        (unsigned long long)(uintptr_t)ctx->slot[1].beta.p, (unsigned long long)(uintptr_t)ctx->slot[1].Xt.p,
-        (unsigned long long)ctx->slot[1].n,
-        (unsigned long long)ctx->slot[1].wk.sk_waves, (unsigned long long)(uintptr_t)ctx->slot[1].w_small.p,
-        (unsigned long long)(uintptr_t)ctx->slot[1].w_in.p, (unsigned long long)(uintptr_t)ctx->slot[1].ls.p};
-    for (int i = 0; i < g.n_rewards; ++i) {
-        key.push_back((unsigned long long)g.rw[i].kind);
-        key.push_back((unsigned long long)(long long)g.rw[i].rank);
-        key.push_back((unsigned long long)(uintptr_t)g.rw[i].W);
-        unsigned long long cbits;
-        memcpy(&cbits, &g.rw[i].coef, sizeof(cbits));
-        key.push_back(cbits);
-    }
-    if (!ctx->graph || key != ctx->graph_key) {
-        if (ctx->graph) {
-            (void)hipGraphExecDestroy(ctx->graph);
-            ctx->graph = nullptr;
-        }
-        // warm the per-kernel one-time host configuration outside the capture
-        if (int r = enqueue_rollout(ctx, plan, H > 0 ? 1 : 0, nullptr)) return r;
-        HIPCHK(hipStreamSynchronize(ctx->st));
-        hipGraph_t graph = nullptr;
-        HIPCHK(hipStreamBeginCapture(ctx->st, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue_rollout(ctx, plan, H, nullptr);
-        hipError_t e = hipStreamEndCapture(ctx->st, &graph);
-        if (rc != PILCO_OK) {
-            if (graph) (void)hipGraphDestroy(graph);
-            if (sharded) {
-                ctx->graph_rccl_failed = true;
-                (void)hipGetLastError();
-                return -1;
-            }
-            return rc;
-        }
-        if (e != hipSuccess) {
-            if (sharded) {  // not fatal: run this and all later sharded rollouts eagerly
-                ctx->graph_rccl_failed = true;
-                (void)hipGetLastError();
-                return -1;
-            }
-            return fail(ctx, PILCO_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-        }
-        e = hipGraphInstantiate(&ctx->graph, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) {
-            ctx->graph = nullptr;
-            if (sharded) {
-                ctx->graph_rccl_failed = true;
-                (void)hipGetLastError();
-                return -1;
-            }
-            return fail(ctx, PILCO_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-        }
-        ctx->graph_key = key;
-        // the warm-up rollout above overwrote the initial state: the caller re-uploads it (see callers)
-        return -1;
-    }
-    HIPCHK(hipGraphLaunch(ctx->graph, ctx->st));
-    return PILCO_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-int pilco_rollout(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
-                  const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj) {
-    if (!ctx) return PILCO_E_SHAPE;
-    if (!m0 || !S0 || !mH || !SH || !reward || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout: bad arguments");
-    HIPCHK(hipSetDevice(ctx->device));
-    RolloutPlan plan;
-    if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, traj != nullptr, plan)) return r;
-    const int E = plan.E;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        HIPCHK(hipMemcpyAsync(plan.st[0], m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
-        HIPCHK(hipMemcpyAsync(plan.st[0] + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
-        const int r = run_rollout(ctx, plan, H);
-        if (r == -1) continue;  // graph was just (re)captured: upload the state again and replay it
-        if (r != PILCO_OK) return r;
-        break;
-    }
-    HIPCHK(hipMemcpyAsync(mH, plan.st[H & 1], sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(SH, plan.st[H & 1] + E, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(reward, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
-    if (traj)
-        HIPCHK(hipMemcpyAsync(traj, ctx->traj.p, sizeof(double) * (size_t)(H + 1) * (E + E * E), hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
-    HIPCHK(hipGetLastError());
-    return PILCO_OK;
-}
-
-int pilco_propagate(pilco_ctx* ctx, const pilco_policy* policy, const double* m_x, const double* s_x, double* M_x, double* S_x) {
-    double r = 0.0;
-    return pilco_rollout(ctx, policy, nullptr, 0, m_x, s_x, 1, M_x, S_x, &r, nullptr);
-}
-
-int pilco_policy_action(pilco_ctx* ctx, const pilco_policy* policy, const double* m, const double* s_in, double* M, double* S, double* V) {
-    if (!ctx) return PILCO_E_SHAPE;
-    if (!policy || !m || !s_in || !M || !S || !V) return fail(ctx, PILCO_E_SHAPE, "policy_action: null pointer");
-    if (policy->kind != PILCO_POLICY_LINEAR && policy->kind != PILCO_POLICY_RBF) return fail(ctx, PILCO_E_SHAPE, "policy_action: policy kind must be LINEAR or RBF");
-    HIPCHK(hipSetDevice(ctx->device));
-    const int E = policy->state_dim, U = policy->control_dim;
-    if (E <= 0 || U <= 0 || E > MAX_D || U > MAX_D) return fail(ctx, PILCO_E_SHAPE, "policy_action: bad dims");
-    if (policy->kind == PILCO_POLICY_RBF) {
-        Slot& ps = ctx->slot[PILCO_SLOT_POLICY];
-        if (!ps.factor_valid) return fail(ctx, PILCO_E_STATE, "policy_action: RBF policy slot has no current factorisation");
-        if (ps.D != E || ps.E != U) return fail(ctx, PILCO_E_SHAPE, "policy_action: RBF policy GP must map state_dim -> control_dim");
-        if (int r = build_work(ctx, ps)) return r;
-        const size_t n_st = (size_t)E + E * E + U + (U + U * U + (size_t)E * U);
-        ENSURE(ctx->state, n_st + 8);
-        std::vector<double> h(n_st, 0.0);
-        memcpy(&h[0], m, sizeof(double) * E);
-        memcpy(&h[E], s_in, sizeof(double) * E * E);
-        size_t off = (size_t)E + E * E;
-        GlueArgs g{};
-        g.E = E; g.D = E + U; g.U = U;
-        g.m_x = ctx->state.p;
-        g.s_x = ctx->state.p + E;
-        for (int u = 0; u < U; ++u) h[off + u] = policy->max_action ? policy->max_action[u] : 1.0;
-        g.maxact = ctx->state.p + off; off += U;
-        g.act_out = ctx->state.p + off;
-        g.pol_kind = PILCO_POLICY_RBF;
-        g.squash = policy->squash;
-        g.pwk = ps.wk;
-        g.pvar = ps.var.p;
-        HIPCHK(hipMemcpyAsync(ctx->state.p, h.data(), sizeof(double) * n_st, hipMemcpyHostToDevice, ctx->st));
-        HIPCHK(hipMemcpyAsync(ps.wk.in_m, m, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
-        HIPCHK(hipMemcpyAsync(ps.wk.in_s, s_in, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
-        const MMModel pmd = model_of(ps);
-        launch_mm_prep(ctx->st, pmd, ps.wk);
-        launch_mm_pair(ctx->st, pmd, ps.wk, ctx->variant);
-        g.flags = GF_RBF_POST | GF_POLICY;
-        launch_glue(ctx->st, g);
-        std::vector<double> o((size_t)U + U * U + (size_t)E * U);
-        HIPCHK(hipMemcpyAsync(o.data(), g.act_out, sizeof(double) * o.size(), hipMemcpyDeviceToHost, ctx->st));
-        HIPCHK(hipStreamSynchronize(ctx->st));
-        HIPCHK(hipGetLastError());
-        memcpy(M, &o[0], sizeof(double) * U);
-        memcpy(S, &o[U], sizeof(double) * U * U);
-        memcpy(V, &o[(size_t)U + U * U], sizeof(double) * E * U);
-        return PILCO_OK;
-    }
-    if (!policy->W || !policy->b) return fail(ctx, PILCO_E_SHAPE, "policy_action: linear policy needs W and b");
-    const size_t n_state = (size_t)E + E * E + (size_t)U * E + 2 * U + (U + U * U + (size_t)E * U);
-    ENSURE(ctx->state, n_state + 8);
-    std::vector<double> h(n_state, 0.0);
-    memcpy(&h[0], m, sizeof(double) * E);
-    memcpy(&h[E], s_in, sizeof(double) * E * E);
-    size_t off = (size_t)E + E * E;
-    GlueArgs g{};
-    g.E = E; g.D = E + U; g.U = U;
-    g.m_x = ctx->state.p;
-    g.s_x = g.m_x + E;
-    memcpy(&h[off], policy->W, sizeof(double) * U * E);
-    g.W = ctx->state.p + off; off += (size_t)U * E;
-    memcpy(&h[off], policy->b, sizeof(double) * U);
-    g.b = ctx->state.p + off; off += U;
-    for (int u = 0; u < U; ++u) h[off + u] = policy->max_action ? policy->max_action[u] : 1.0;
-    g.maxact = ctx->state.p + off; off += U;
-    g.act_out = ctx->state.p + off;
-    g.pol_kind = PILCO_POLICY_LINEAR;
-    g.squash = policy->squash;
-    g.flags = GF_POLICY;
-    HIPCHK(hipMemcpyAsync(ctx->state.p, h.data(), sizeof(double) * n_state, hipMemcpyHostToDevice, ctx->st));
-    launch_glue(ctx->st, g);
-    std::vector<double> o((size_t)U + U * U + (size_t)E * U);
-    HIPCHK(hipMemcpyAsync(o.data(), g.act_out, sizeof(double) * o.size(), hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
-    HIPCHK(hipGetLastError());
-    memcpy(M, &o[0], sizeof(double) * U);
-    memcpy(S, &o[U], sizeof(double) * U * U);
-    memcpy(V, &o[(size_t)U + U * U], sizeof(double) * E * U);
-    return PILCO_OK;
-}
-
-int pilco_reward_eval(pilco_ctx* ctx, const pilco_reward_term* rewards, int n_rewards, int state_dim, const double* m,
-                      const double* s_in, double* muR, double* sR) {
-    if (!ctx) return PILCO_E_SHAPE;
-    if (!rewards || n_rewards <= 0 || n_rewards > MAX_REWARD_TERMS || !m || !s_in || !muR || !sR || state_dim <= 0 || state_dim > MAX_D)
-        return fail(ctx, PILCO_E_SHAPE, "reward_eval: bad arguments");
-    HIPCHK(hipSetDevice(ctx->device));
-    const int E = state_dim;
-    const size_t n = (size_t)E + E * E + (size_t)n_rewards * (2 * E * E + E) + 2;
-    ENSURE(ctx->state, n + 8);
-    std::vector<double> h(n, 0.0);
-    memcpy(&h[0], m, sizeof(double) * E);
-    memcpy(&h[E], s_in, sizeof(double) * E * E);
-    size_t off = (size_t)E + E * E;
-    GlueArgs g{};
-    g.E = E; g.D = E; g.U = 0;
-    g.m_x = ctx->state.p;
-    g.s_x = ctx->state.p + E;
-    g.n_rewards = n_rewards;
-    if (int r = stage_rewards(ctx, rewards, n_rewards, E, h, off, ctx->state.p, g.rw)) return r;
-    if (h.size() < off + 2) h.resize(off + 2, 0.0);
-    if (h.size() + 8 > ctx->state.cap) return fail(ctx, PILCO_E_ALLOC, "reward_eval: staging overflow");
-    g.rew_out = ctx->state.p + off;
-    g.flags = 0;  // workgroup 0 idles; workgroup 1 evaluates mean and variance
-    HIPCHK(hipMemcpyAsync(ctx->state.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->st));
-    launch_glue(ctx->st, g, true);
-    double o[2];
-    HIPCHK(hipMemcpyAsync(o, g.rew_out, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
-    HIPCHK(hipGetLastError());
-    *muR = o[0];
-    *sR = o[1];
-    return PILCO_OK;
-}
-
-int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
-                        const double* m0, const double* S0, int H, int reps, double* mH, double* SH, double* reward,
-                        float* ms_total, float* ms_pair, int* n_pair_launches) {
-    if (!ctx) return PILCO_E_SHAPE;
-    if (!m0 || !S0 || !mH || !SH || !reward || H < 0 || reps <= 0 || !ms_total) return fail(ctx, PILCO_E_SHAPE, "rollout_timed: bad arguments");
-    HIPCHK(hipSetDevice(ctx->device));
-    RolloutPlan plan;
-    if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, false, plan)) return r;
-    const int E = plan.E;
-    ENSURE(ctx->selftest, (size_t)E + E * E + 256);
-    double* init = ctx->selftest.p + 256;  // device copy of (m0, S0) so that the timed region has no host traffic
-    HIPCHK(hipMemcpyAsync(init, m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipMemcpyAsync(init + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
-    {   // make sure the graph exists before the timed region
-        HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
-        const int r = run_rollout(ctx, plan, H);
-        if (r != PILCO_OK && r != -1) return r;
-        HIPCHK(hipStreamSynchronize(ctx->st));
-    }
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->st));
-    for (int rep = 0; rep < reps; ++rep) {
-        HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
-        int r = run_rollout(ctx, plan, H);
-        if (r == -1) {  // only possible when the sharded capture fell back to eager mode: redo this rollout
-            HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
-            r = run_rollout(ctx, plan, H);
-        }
-        if (r != PILCO_OK) return r;
-    }
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->st));
-    HIPCHK(hipEventSynchronize(ctx->ev1));
-    HIPCHK(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
-    if (ms_pair) {
-        // second pass with an event pair around every pair-kernel launch (perturbs the total, so timed separately)
-        const size_t need = (size_t)2 * H;
-        while (ctx->pair_events.size() < need) {
-            hipEvent_t e;
-            HIPCHK(hipEventCreate(&e));
-            ctx->pair_events.push_back(e);
-        }
-        HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
-        if (int r = enqueue_rollout(ctx, plan, H, &ctx->pair_events)) return r;
-        HIPCHK(hipStreamSynchronize(ctx->st));
-        float tot = 0.f;
-        int cnt = 0;
-        if (ctx->slot[0].wk.PL > 0)
-            for (int t = 0; t < H; ++t) {
-                float ms = 0.f;
-                HIPCHK(hipEventElapsedTime(&ms, ctx->pair_events[2 * t], ctx->pair_events[2 * t + 1]));
-                tot += ms;
-                ++cnt;
-            }
-        *ms_pair = tot;
-        if (n_pair_launches) *n_pair_launches = cnt;
-    }
-    HIPCHK(hipMemcpyAsync(mH, plan.st[H & 1], sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(SH, plan.st[H & 1] + E, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(reward, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
-    HIPCHK(hipGetLastError());
-    return PILCO_OK;
-}
 
 int pilco_factorize_timed(pilco_ctx* ctx, int slot, int reps, float* ms_each) {
     if (int r = check_slot(ctx, slot)) return r;
@@ -1134,46 +520,6 @@ int pilco_factorize_timed(pilco_ctx* ctx, int slot, int reps, float* ms_each) {
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *ms_each = ms / reps;
     return PILCO_OK;
-}
-
-// ------------------------------------------------------------------ multi-GPU
-int pilco_comm_unique_id(void* id128) {
-    if (!id128) return PILCO_E_SHAPE;
-    static_assert(sizeof(ncclUniqueId) <= PILCO_COMM_ID_BYTES, "ncclUniqueId larger than the ABI slot");
-    ncclUniqueId id;
-    if (ncclGetUniqueId(&id) != ncclSuccess) return PILCO_E_RCCL;
-    memset(id128, 0, PILCO_COMM_ID_BYTES);
-    memcpy(id128, &id, sizeof(id));
-    return PILCO_OK;
-}
-
-int pilco_shard_set(pilco_ctx* ctx, int rank, int nranks) {
-    if (!ctx || nranks <= 0 || rank < 0 || rank >= nranks) return fail(ctx, PILCO_E_SHAPE, "shard_set: bad rank / nranks");
-    ctx->rank = rank;
-    ctx->nranks = nranks;
-    for (Slot& s : ctx->slot) s.wk_valid = false;
-    return PILCO_OK;
-}
-
-int pilco_comm_init(pilco_ctx* ctx, const void* id128, int rank, int nranks) {
-    if (!ctx || !id128) return PILCO_E_SHAPE;
-    if (int r = pilco_shard_set(ctx, rank, nranks)) return r;
-    HIPCHK(hipSetDevice(ctx->device));
-    ncclUniqueId id;
-    memcpy(&id, id128, sizeof(id));
-    ncclResult_t r = ncclCommInitRank(&ctx->comm, nranks, id, rank);
-    if (r != ncclSuccess) {
-        ctx->comm = nullptr;
-        return fail(ctx, PILCO_E_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
-    }
-    return PILCO_OK;
-}
-
-int pilco_shard_owner_of_pair(const pilco_ctx* ctx, int pair_index) {
-    if (!ctx) return -1;
-    const Slot& s = ctx->slot[0];
-    if (pair_index < 0 || pair_index >= (int)s.pair_owner.size()) return -1;
-    return s.pair_owner[pair_index];
 }
 
 int pilco_debug_blocks(pilco_ctx* ctx, unsigned long long* out, int n) {
@@ -1200,465 +546,6 @@ int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32) {  // 64 s
         HIPCHK(hipMemset(ctx->dbg + 5, 0xff, sizeof(unsigned long long)));
         HIPCHK(hipMemset(ctx->dbg + 22, 0xff, sizeof(unsigned long long)));
     }
-    return PILCO_OK;
-}
-
-// ---- pure host functions of the ownership / gather-buffer layout (no GPU needed)
-int pilco_shard_plan(int E, int D, int nranks, int rank, int* out5) {
-    if (E <= 0 || D <= 0 || nranks <= 0 || rank < 0 || rank >= nranks || !out5) return PILCO_E_SHAPE;
-    const int P = E * (E + 1) / 2;
-    const int PLcap = (P + nranks - 1) / nranks, ELcap = (E + nranks - 1) / nranks;
-    out5[0] = (rank < P) ? (P - rank + nranks - 1) / nranks : 0;  // local pairs
-    out5[1] = (rank < E) ? (E - rank + nranks - 1) / nranks : 0;  // owned outputs
-    out5[2] = PLcap + ELcap * (1 + D);                            // SEG: doubles per rank in the gather buffer
-    out5[3] = PLcap;                                              // OUTOFF: offset of the output records
-    out5[4] = P;
-    return PILCO_OK;
-}
-// index into the gathered buffer [nranks][SEG] of the value of pair (a,b), a >= b
-int pilco_shard_pair_slot(int E, int D, int nranks, int a, int b) {
-    if (a < b) { const int t = a; a = b; b = t; }
-    if (b < 0 || a >= E) return -1;
-    int plan[5];
-    if (pilco_shard_plan(E, D, nranks, 0, plan) != PILCO_OK) return -1;
-    const int kk = (a == b) ? a : E + a * (a - 1) / 2 + b;
-    return (kk % nranks) * plan[2] + kk / nranks;
-}
-// index of M_a in the gathered buffer (V_a[0..D) follows)
-int pilco_shard_output_slot(int E, int D, int nranks, int a) {
-    if (a < 0 || a >= E) return -1;
-    int plan[5];
-    if (pilco_shard_plan(E, D, nranks, 0, plan) != PILCO_OK) return -1;
-    return (a % nranks) * plan[2] + plan[3] + (a / nranks) * (1 + D);
-}
-
-// ---- host-mediated exchange: the caller moves the segments between the ranks
-int pilco_gp_shard_pack(pilco_ctx* ctx, int slot, const double* m, const double* s_in, double* segment) {
-    if (int r = check_slot(ctx, slot)) return r;
-    Slot& s = ctx->slot[slot];
-    if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "shard_pack: no current factorisation");
-    if (!m || !s_in || !segment) return fail(ctx, PILCO_E_SHAPE, "shard_pack: null pointer");
-    HIPCHK(hipSetDevice(ctx->device));
-    if (int r = build_work(ctx, s)) return r;
-    const int D = s.D, E = s.E;
-    HIPCHK(hipMemcpyAsync(s.wk.in_m, m, sizeof(double) * D, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipMemcpyAsync(s.wk.in_s, s_in, sizeof(double) * D * D, hipMemcpyHostToDevice, ctx->st));
-    const MMModel md = model_of(s);
-    if (s.wk.PL > 0) {
-        launch_mm_prep(ctx->st, md, s.wk);
-        launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
-    }
-    GlueArgs g{};
-    g.E = E; g.D = D; g.U = 0;
-    g.wk = s.wk;
-    g.var = s.var.p;
-    g.flags = GF_PACK;
-    launch_glue(ctx->st, g);
-    HIPCHK(hipMemcpyAsync(segment, s.wk.gath + (size_t)ctx->rank * s.wk.SEG, sizeof(double) * s.wk.SEG, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
-    HIPCHK(hipGetLastError());
-    return PILCO_OK;
-}
-
-int pilco_gp_shard_finish(pilco_ctx* ctx, int slot, const double* gathered, double* M, double* S, double* V) {
-    if (int r = check_slot(ctx, slot)) return r;
-    Slot& s = ctx->slot[slot];
-    if (!s.wk_valid) return fail(ctx, PILCO_E_STATE, "shard_finish before shard_pack");
-    if (!gathered || !M || !S || !V) return fail(ctx, PILCO_E_SHAPE, "shard_finish: null pointer");
-    HIPCHK(hipSetDevice(ctx->device));
-    const int D = s.D, E = s.E;
-    HIPCHK(hipMemcpyAsync(s.wk.gath, gathered, sizeof(double) * (size_t)ctx->nranks * s.wk.SEG, hipMemcpyHostToDevice, ctx->st));
-    GlueArgs g{};
-    g.E = E; g.D = D; g.U = 0;
-    g.wk = s.wk;
-    g.var = s.var.p;
-    g.flags = GF_ASSEMBLE;
-    launch_glue(ctx->st, g);
-    HIPCHK(hipMemcpyAsync(M, s.wk.out_M, sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(S, s.wk.out_S, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(V, s.wk.out_V, sizeof(double) * D * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
-    HIPCHK(hipGetLastError());
-    return PILCO_OK;
-}
-
-int pilco_comm_rank(const pilco_ctx* ctx) { return ctx ? ctx->rank : -1; }
-int pilco_comm_size(const pilco_ctx* ctx) { return ctx ? ctx->nranks : -1; }
-
-// Vector-Jacobian product of one moment-matching step (the reverse of pilco_gp_predict):
-// given cotangents Mbar (1,E), Sbar (E,E), Vbar (D,E) returns mbar (1,D) and the symmetric sbar (D,D).
-// Entirely on the device (k_mm_bwd_pair / _post / _fin; the mean part rides in extra workgroups of _post / _fin); the
-// host only sums the E + P contribution records.  Single rank, exact or sparse model, D <= 14.
-int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double* s_in, const double* Mbar,
-                         const double* Sbar, const double* Vbar, double* mbar, double* sbar) {
-    if (int r = check_slot(ctx, slot)) return r;
-    Slot& s = ctx->slot[slot];
-    if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "predict_vjp: no current factorisation");
-    if (!m || !s_in || !Mbar || !Sbar || !Vbar || !mbar || !sbar) return fail(ctx, PILCO_E_SHAPE, "predict_vjp: null pointer");
-    if (ctx->nranks != 1) return fail(ctx, PILCO_E_STATE, "predict_vjp: single rank only");
-    const int D = s.D, E = s.E, npad = s.npad;
-    if (D + 2 > 16) return fail(ctx, PILCO_E_SHAPE, "predict_vjp: D <= 14 in this build");
-    HIPCHK(hipSetDevice(ctx->device));
-    if (int r = build_work(ctx, s)) return r;
-    const int P = s.wk.PL;
-    // ---- device: operands (prep), reverse pair sweep, mean part, per-pair / per-output contributions
-    const int rec = D + D * D, nb = E + E * E + D * E;
-    int njs, nrb;
-    mm_bwd_geometry(npad, P, &njs, &nrb);
-    ENSURE(s.bwd_mom, (size_t)P * njs * 16 * npad);
-    ENSURE(s.bwd_cp, (size_t)std::max(1, P - E) * nrb * npad);
-    ENSURE(s.bwd_part, (size_t)(P + E) * mm_bwd_rc(npad) * (1 + rec + D));   // pair partials, then mean partials
-    ENSURE(s.bwd_out, (size_t)(E + P) * rec + (size_t)(E + P) * (D * D + D + 2));   // contributions | head records
-    const size_t n_in = (size_t)D + D * D + nb, n_out = (size_t)(E + P) * rec;
-    if (ctx->pin_cap < n_in + n_out) {
-        if (ctx->pin) (void)hipHostFree(ctx->pin);
-        ctx->pin = nullptr;
-        ctx->pin_cap = 0;
-        HIPCHK(hipHostMalloc((void**)&ctx->pin, sizeof(double) * (n_in + n_out), hipHostMallocDefault));
-        ctx->pin_cap = n_in + n_out;
-    }
-    double* hin = ctx->pin;
-    const double* po = ctx->pin + n_in;
-    memcpy(hin, m, sizeof(double) * D);
-    memcpy(hin + D, s_in, sizeof(double) * D * D);
-    memcpy(hin + D + D * D, Mbar, sizeof(double) * E);
-    memcpy(hin + D + D * D + E, Sbar, sizeof(double) * E * E);
-    memcpy(hin + D + D * D + E + E * E, Vbar, sizeof(double) * D * E);
-    HIPCHK(hipMemcpyAsync(s.wk.in_m, hin, sizeof(double) * n_in, hipMemcpyHostToDevice, ctx->st));   // in_m | in_s | bars are contiguous
-    const double* bars = s.wk.in_s + D * D;
-    const MMModel md = model_of(s);
-    launch_mm_prep(ctx->st, md, s.wk);
-    launch_mm_bwd(ctx->st, md, s.wk, s.bwd_mom.p, s.bwd_cp.p, s.bwd_part.p, bars, s.bwd_out.p + (size_t)(E + P) * rec, s.bwd_out.p);
-    HIPCHK(hipMemcpyAsync(ctx->pin + n_in, s.bwd_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
-    HIPCHK(hipGetLastError());
-    // ---- host: sum the E + P records in a fixed order, symmetrise
-    std::vector<double> acc(rec, 0.0);
-    for (int k = 0; k < E + P; ++k)
-        for (int e = 0; e < rec; ++e) acc[e] += po[(size_t)k * rec + e];
-    for (int e = 0; e < rec; ++e)
-        if (!std::isfinite(acc[e])) return fail(ctx, PILCO_E_NOT_PD, "predict_vjp: singular s + Lambda^2 or I + Lambda s");
-    for (int d = 0; d < D; ++d) mbar[d] = acc[d];
-    for (int r = 0; r < D; ++r)
-        for (int c = 0; c < D; ++c) sbar[(size_t)r * D + c] = 0.5 * (acc[D + (size_t)r * D + c] + acc[D + (size_t)c * D + r]);
-    return PILCO_OK;
-}
-
-// pilco_rollout that also records, for every step t < H, the joint Gaussian (m, s, s1) handed to
-// the dynamics GP and its outputs (M, S, V): tape [H][D + D*D + E*D + E + E*E + D*E].  The reverse
-// sweep of the policy gradient replays these records (pilco_amd/adjoint.py).
-int pilco_rollout_tape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
-                       const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj,
-                       double* tape) {
-    if (!ctx) return PILCO_E_SHAPE;
-    if (!m0 || !S0 || !mH || !SH || !reward || !tape || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout_tape: bad arguments");
-    HIPCHK(hipSetDevice(ctx->device));
-    RolloutPlan plan;
-    if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, traj != nullptr, plan)) return r;
-    const int E = plan.E, D = plan.D;
-    const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
-    ENSURE(ctx->tape, std::max<size_t>(1, (size_t)H * TS));
-    plan.g.tape = ctx->tape.p;
-    HIPCHK(hipMemcpyAsync(plan.st[0], m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipMemcpyAsync(plan.st[0] + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
-    if (int r = enqueue_rollout(ctx, plan, H, nullptr)) return r;
-    HIPCHK(hipMemcpyAsync(mH, plan.st[H & 1], sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(SH, plan.st[H & 1] + E, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(reward, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
-    if (traj) HIPCHK(hipMemcpyAsync(traj, ctx->traj.p, sizeof(double) * (size_t)(H + 1) * (E + E * E), hipMemcpyDeviceToHost, ctx->st));
-    if (H > 0) HIPCHK(hipMemcpyAsync(tape, ctx->tape.p, sizeof(double) * (size_t)H * TS, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
-    HIPCHK(hipGetLastError());
-    return PILCO_OK;
-}
-
-// ------------------------------------------------------------------ native reverse sweep (policy gradient)
-}  // extern "C"
-
-namespace {
-
-typedef std::vector<double> vec;
-
-// inverse and determinant of a small dense matrix (partial pivoting); false if singular
-bool inv_small(const double* A, int n, vec& inv, double& det) {
-    vec a(A, A + (size_t)n * n);
-    inv.assign((size_t)n * n, 0.0);
-    for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
-    det = 1.0;
-    for (int k = 0; k < n; ++k) {
-        int p = k;
-        for (int r = k + 1; r < n; ++r)
-            if (std::fabs(a[(size_t)r * n + k]) > std::fabs(a[(size_t)p * n + k])) p = r;
-        const double piv = a[(size_t)p * n + k];
-        if (piv == 0.0 || !std::isfinite(piv)) return false;
-        if (p != k) {
-            for (int c = 0; c < n; ++c) {
-                std::swap(a[(size_t)p * n + c], a[(size_t)k * n + c]);
-                std::swap(inv[(size_t)p * n + c], inv[(size_t)k * n + c]);
-            }
-            det = -det;
-        }
-        det *= piv;
-        const double ip = 1.0 / piv;
-        for (int c = 0; c < n; ++c) {
-            a[(size_t)k * n + c] *= ip;
-            inv[(size_t)k * n + c] *= ip;
-        }
-        for (int r = 0; r < n; ++r) {
-            if (r == k) continue;
-            const double f = a[(size_t)r * n + k];
-            if (f == 0.0) continue;
-            for (int c = 0; c < n; ++c) {
-                a[(size_t)r * n + c] -= f * a[(size_t)k * n + c];
-                inv[(size_t)r * n + c] -= f * inv[(size_t)k * n + c];
-            }
-        }
-    }
-    return true;
-}
-
-// squash_sin (controllers.py:13-36) forward quantities and its vector-Jacobian product (derivatives as in gSin.m:50-74)
-struct Squash {
-    int U;
-    vec M, Cd, S, q, Ep, Em, dm, sm, ee;
-    void fwd(const vec& mu0, const vec& su0, const vec& e) {
-        U = (int)mu0.size();
-        M.resize(U); Cd.resize(U);
-        S.resize((size_t)U * U); q = Ep = Em = dm = sm = ee = S;
-        for (int u = 0; u < U; ++u) {
-            const double ex = std::exp(-su0[(size_t)u * U + u] / 2.0);
-            M[u] = e[u] * ex * std::sin(mu0[u]);
-            Cd[u] = e[u] * ex * std::cos(mu0[u]);
-        }
-        for (int u = 0; u < U; ++u)
-            for (int v = 0; v < U; ++v) {
-                const size_t k = (size_t)u * U + v;
-                const double lq = -(su0[(size_t)u * U + u] + su0[(size_t)v * U + v]) / 2.0;
-                q[k] = std::exp(lq);
-                Ep[k] = std::exp(lq + su0[k]);
-                Em[k] = std::exp(lq - su0[k]);
-                dm[k] = mu0[u] - mu0[v];
-                sm[k] = mu0[u] + mu0[v];
-                ee[k] = e[u] * e[v];
-                S[k] = ee[k] / 2.0 * ((Ep[k] - q[k]) * std::cos(dm[k]) - (Em[k] - q[k]) * std::cos(sm[k]));
-            }
-    }
-    void vjp(const double* Mbar, const double* Sbar, const double* Cdbar, vec& mubar, vec& subar) const {
-        mubar.assign(U, 0.0);
-        subar.assign((size_t)U * U, 0.0);
-        for (int u = 0; u < U; ++u) {
-            double acc = Mbar[u] * Cd[u] - Cdbar[u] * M[u];
-            double dd = -0.5 * Mbar[u] * M[u] - 0.5 * Cdbar[u] * Cd[u];
-            for (int v = 0; v < U; ++v) {
-                const size_t uv = (size_t)u * U + v, vu = (size_t)v * U + u;
-                const double D1 = ee[uv] / 2.0 * (-(Ep[uv] - q[uv]) * std::sin(dm[uv]) + (Em[uv] - q[uv]) * std::sin(sm[uv]));
-                const double D2 = ee[vu] / 2.0 * ((Ep[vu] - q[vu]) * std::sin(dm[vu]) + (Em[vu] - q[vu]) * std::sin(sm[vu]));
-                acc += Sbar[uv] * D1 + Sbar[vu] * D2;
-                dd -= 0.5 * (Sbar[uv] * S[uv] + Sbar[vu] * S[vu]);
-                subar[uv] = Sbar[uv] * (ee[uv] / 2.0 * (Ep[uv] * std::cos(dm[uv]) + Em[uv] * std::cos(sm[uv])));
-            }
-            mubar[u] = acc;
-            subar[(size_t)u * U + u] += dd;
-        }
-    }
-};
-
-// d muR / d m, d muR / d S of the reward terms (rewards.py:19-81; formulas of reward.m:47-50), accumulated into dm, dS
-bool reward_grad(const pilco_reward_term* rw, int n_rw, int E, const double* m, const double* S, vec& dm, vec& dS) {
-    vec A((size_t)E * E), Ai, iSpW((size_t)E * E), d(E), v(E);
-    for (int k = 0; k < n_rw; ++k) {
-        const double c = rw[k].coef;
-        if (rw[k].kind == PILCO_REWARD_LINEAR) {
-            for (int i = 0; i < E; ++i) dm[i] += c * rw[k].W[i];
-            continue;
-        }
-        const double* W = rw[k].W;
-        auto Wv = [&](int i, int j) { return W ? W[(size_t)i * E + j] : (i == j ? 1.0 : 0.0); };
-        for (int i = 0; i < E; ++i) {
-            d[i] = m[i] - (rw[k].t ? rw[k].t[i] : 0.0);
-            for (int j = 0; j < E; ++j) {
-                double acc = (i == j) ? 1.0 : 0.0;
-                for (int l = 0; l < E; ++l) acc += S[(size_t)i * E + l] * Wv(l, j);
-                A[(size_t)i * E + j] = acc;   // I + S W
-            }
-        }
-        double det;
-        if (!inv_small(A.data(), E, Ai, det)) return false;
-        for (int i = 0; i < E; ++i)
-            for (int j = 0; j < E; ++j) {
-                double acc = 0.0;
-                for (int l = 0; l < E; ++l) acc += Wv(i, l) * Ai[(size_t)l * E + j];
-                iSpW[(size_t)i * E + j] = acc;   // W (I + S W)^-1
-            }
-        double quad = 0.0;
-        for (int i = 0; i < E; ++i) {
-            double acc = 0.0;
-            for (int j = 0; j < E; ++j) acc += iSpW[(size_t)i * E + j] * d[j];
-            v[i] = acc;          // iSpW d
-            quad += d[i] * acc;
-        }
-        const double muR = std::exp(-0.5 * quad) / std::sqrt(det);
-        vec dTi(E, 0.0);   // d^T iSpW
-        for (int j = 0; j < E; ++j)
-            for (int i = 0; i < E; ++i) dTi[j] += d[i] * iSpW[(size_t)i * E + j];
-        for (int j = 0; j < E; ++j) dm[j] -= c * muR * dTi[j];
-        // dS = muR (iSpW d d^T - I) iSpW / 2, symmetrised
-        vec T((size_t)E * E);
-        for (int i = 0; i < E; ++i)
-            for (int j = 0; j < E; ++j) T[(size_t)i * E + j] = 0.5 * muR * (v[i] * dTi[j] - iSpW[(size_t)i * E + j]);
-        for (int i = 0; i < E; ++i)
-            for (int j = 0; j < E; ++j) dS[(size_t)i * E + j] += c * 0.5 * (T[(size_t)i * E + j] + T[(size_t)j * E + i]);
-    }
-    return true;
-}
-
-}  // namespace
-
-extern "C" {
-
-// Value and gradient of the rollout reward w.r.t. a LinearController's (W, b): what TensorFlow's reverse mode through
-// the tf.while_loop gives the reference (pilco/models/pilco.py:85-90,126-135).  Forward rollout with a tape on the
-// device, then the reverse sweep: the O(N^2) adjoint of every moment-matching step on the device
-// (pilco_gp_predict_vjp), the O(D^3) links (propagate pilco.py:147-149, joint Gaussian :141-144, controller + squash
-// controllers.py:13-58, rewards rewards.py:19-81) here on the host in C++.  dW (U,E), db (U).
-int pilco_rollout_grad(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
-                       const double* m0, const double* S0, int H, double* reward, double* dW, double* db) {
-    if (!ctx) return PILCO_E_SHAPE;
-    if (!policy || !m0 || !S0 || !reward || !dW || !db || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout_grad: bad arguments");
-    if (policy->kind != PILCO_POLICY_LINEAR || !policy->squash || policy->control_dim <= 0)
-        return fail(ctx, PILCO_E_SHAPE, "rollout_grad: squashed LinearController only (other policies: pilco_rollout_tape + pilco_gp_predict_vjp)");
-    for (int k = 0; k < n_rewards; ++k)
-        if (rewards[k].kind != PILCO_REWARD_EXPONENTIAL && rewards[k].kind != PILCO_REWARD_LINEAR)
-            return fail(ctx, PILCO_E_SHAPE, "rollout_grad: unknown reward term");
-    const int E = policy->state_dim, U = policy->control_dim, D = E + U;
-    const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
-    vec mH(E), SH((size_t)E * E), traj((size_t)(H + 1) * (E + E * E)), tape(std::max<size_t>(1, (size_t)H * TS));
-    if (int r = pilco_rollout_tape(ctx, policy, rewards, n_rewards, m0, S0, H, mH.data(), SH.data(), reward, traj.data(), tape.data()))
-        return r;
-    const double* W = policy->W;
-    const double* b = policy->b;
-    vec e(U);
-    for (int u = 0; u < U; ++u) e[u] = policy->max_action[u];
-    vec mbar(E, 0.0), sbar((size_t)E * E, 0.0), Wbar((size_t)U * E, 0.0), bbar(U, 0.0);
-    vec G((size_t)E * E), Vb((size_t)D * E), s1bar((size_t)E * D), mjb(D), sjb((size_t)D * D), mxb(E), sxb((size_t)E * E);
-    vec Bb((size_t)E * U), sub((size_t)U * U), mu0(U), su0((size_t)U * U), WS((size_t)U * E), cb((size_t)E * U), Cdbar(U);
-    vec mu0b, su0b, rm(E), rS((size_t)E * E), T1((size_t)U * E), T2((size_t)U * E);
-    Squash sq;
-    for (int t = H - 1; t >= 0; --t) {
-        const double* m_x = &traj[(size_t)t * (E + E * E)];
-        const double* s_x = m_x + E;
-        const double* rec = &tape[(size_t)t * TS];
-        const double* m_j = rec;
-        const double* s_j = rec + D;
-        const double* s1 = rec + D + D * D;                           // (E, D)
-        const double* V = rec + D + D * D + (size_t)E * D + E + (size_t)E * E;   // (D, E)
-        // propagate (pilco.py:147-149): M_x = M + m_x, S_x = S + s_x + s1 V + (s1 V)^T
-        for (int i = 0; i < E; ++i)
-            for (int j = 0; j < E; ++j) G[(size_t)i * E + j] = sbar[(size_t)i * E + j] + sbar[(size_t)j * E + i];
-        for (int d = 0; d < D; ++d)
-            for (int j = 0; j < E; ++j) {
-                double acc = 0.0;
-                for (int i = 0; i < E; ++i) acc += s1[(size_t)i * D + d] * G[(size_t)i * E + j];
-                Vb[(size_t)d * E + j] = acc;                                 // s1^T G
-            }
-        for (int i = 0; i < E; ++i)
-            for (int d = 0; d < D; ++d) {
-                double acc = 0.0;
-                for (int j = 0; j < E; ++j) acc += G[(size_t)i * E + j] * V[(size_t)d * E + j];
-                s1bar[(size_t)i * D + d] = acc;                              // G V^T
-            }
-        mxb = mbar;
-        sxb = sbar;
-        if (int r = pilco_gp_predict_vjp(ctx, PILCO_SLOT_DYNAMICS, m_j, s_j, mbar.data(), sbar.data(), Vb.data(), mjb.data(), sjb.data()))
-            return r;
-        // joint Gaussian (pilco.py:141-144)
-        for (int i = 0; i < E; ++i) mxb[i] += mjb[i];
-        for (int i = 0; i < E; ++i)
-            for (int j = 0; j < E; ++j) sxb[(size_t)i * E + j] += sjb[(size_t)i * D + j] + s1bar[(size_t)i * D + j];
-        for (int i = 0; i < E; ++i)
-            for (int u = 0; u < U; ++u)
-                Bb[(size_t)i * U + u] = sjb[(size_t)i * D + E + u] + sjb[(size_t)(E + u) * D + i] + s1bar[(size_t)i * D + E + u];
-        for (int u = 0; u < U; ++u)
-            for (int v = 0; v < U; ++v) sub[(size_t)u * U + v] = sjb[(size_t)(E + u) * D + E + v];
-        // controller (controllers.py:46-58): mu0 = W m + b, su0 = W s W^T, c = W^T diag(Cd)
-        for (int u = 0; u < U; ++u) {
-            double acc = b[u];
-            for (int i = 0; i < E; ++i) acc += W[(size_t)u * E + i] * m_x[i];
-            mu0[u] = acc;
-            for (int j = 0; j < E; ++j) {
-                double a2 = 0.0;
-                for (int i = 0; i < E; ++i) a2 += W[(size_t)u * E + i] * s_x[(size_t)i * E + j];
-                WS[(size_t)u * E + j] = a2;                                  // W s
-            }
-        }
-        for (int u = 0; u < U; ++u)
-            for (int v = 0; v < U; ++v) {
-                double acc = 0.0;
-                for (int j = 0; j < E; ++j) acc += WS[(size_t)u * E + j] * W[(size_t)v * E + j];
-                su0[(size_t)u * U + v] = acc;
-            }
-        sq.fwd(mu0, su0, e);
-        for (int i = 0; i < E; ++i)
-            for (int j = 0; j < E; ++j) {
-                double acc = 0.0;
-                for (int u = 0; u < U; ++u) acc += Bb[(size_t)i * U + u] * W[(size_t)u * E + j] * sq.Cd[u];   // Bb c^T, c = W^T diag(Cd)
-                sxb[(size_t)i * E + j] += acc;
-            }
-        for (int i = 0; i < E; ++i)
-            for (int u = 0; u < U; ++u) {
-                double acc = 0.0;
-                for (int l = 0; l < E; ++l) acc += s_x[(size_t)l * E + i] * Bb[(size_t)l * U + u];
-                cb[(size_t)i * U + u] = acc;                                 // s_x^T Bb
-            }
-        for (int u = 0; u < U; ++u) {
-            double acc = 0.0;
-            for (int i = 0; i < E; ++i) acc += W[(size_t)u * E + i] * cb[(size_t)i * U + u];
-            Cdbar[u] = acc;
-        }
-        sq.vjp(&mjb[E], sub.data(), Cdbar.data(), mu0b, su0b);
-        // Wbar += diag(Cd) cb^T + mu0b m_x^T + su0b W s_x^T + su0b^T W s_x
-        for (int u = 0; u < U; ++u)
-            for (int j = 0; j < E; ++j) {
-                double a1 = 0.0, a2 = 0.0;
-                for (int i = 0; i < E; ++i) {
-                    a1 += W[(size_t)u * E + i] * s_x[(size_t)j * E + i];     // (W s_x^T)[u][j]
-                    a2 += W[(size_t)u * E + i] * s_x[(size_t)i * E + j];     // (W s_x)[u][j]
-                }
-                T1[(size_t)u * E + j] = a1;
-                T2[(size_t)u * E + j] = a2;
-            }
-        for (int u = 0; u < U; ++u) {
-            bbar[u] += mu0b[u];
-            for (int j = 0; j < E; ++j) {
-                double acc = sq.Cd[u] * cb[(size_t)j * U + u] + mu0b[u] * m_x[j];
-                for (int v = 0; v < U; ++v)
-                    acc += su0b[(size_t)u * U + v] * T1[(size_t)v * E + j] + su0b[(size_t)v * U + u] * T2[(size_t)v * E + j];
-                Wbar[(size_t)u * E + j] += acc;
-            }
-        }
-        for (int i = 0; i < E; ++i) {
-            double acc = 0.0;
-            for (int u = 0; u < U; ++u) acc += W[(size_t)u * E + i] * mu0b[u];
-            mxb[i] += acc;                                                   // W^T mu0b
-            for (int j = 0; j < E; ++j) {
-                double a2 = 0.0;
-                for (int u = 0; u < U; ++u)
-                    for (int v = 0; v < U; ++v) a2 += W[(size_t)u * E + i] * su0b[(size_t)u * U + v] * W[(size_t)v * E + j];
-                sxb[(size_t)i * E + j] += a2;                                // W^T su0b W
-            }
-        }
-        // reward of the pre-propagation state (pilco.py:133)
-        std::fill(rm.begin(), rm.end(), 0.0);
-        std::fill(rS.begin(), rS.end(), 0.0);
-        if (!reward_grad(rewards, n_rewards, E, m_x, s_x, rm, rS)) return fail(ctx, PILCO_E_NOT_PD, "rollout_grad: singular I + S W in the reward");
-        for (int i = 0; i < E; ++i) mxb[i] += rm[i];
-        for (int i = 0; i < E * E; ++i) sxb[i] += rS[i];
-        mbar = mxb;
-        for (int i = 0; i < E; ++i)
-            for (int j = 0; j < E; ++j) sbar[(size_t)i * E + j] = 0.5 * (sxb[(size_t)i * E + j] + sxb[(size_t)j * E + i]);
-    }
-    memcpy(dW, Wbar.data(), sizeof(double) * U * E);
-    memcpy(db, bbar.data(), sizeof(double) * U);
     return PILCO_OK;
 }
 
@@ -1752,3 +639,4 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     s.iK_null = false;
     return PILCO_OK;
 }
+

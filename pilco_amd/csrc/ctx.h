@@ -1,0 +1,92 @@
+// Internal state of libpilco_hip.so shared by its host-side translation units (api.hip, rollout.hip, shard.hip,
+// grad.hip): the context and GP-slot structs, the error / allocation macros and the cross-file helpers.
+#pragma once
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+
+#include "moment.h"
+
+using namespace pilco;
+
+struct Slot {
+    int N = 0, D = 0, E = 0, M = 0;  // data size, input dim, outputs, inducing points (0 = exact)
+    int Npad = 0;                    // padded N
+    int n = 0, npad = 0;             // points the moment matching runs over (N or M) and padding
+    bool has_data = false, has_hyp = false, factor_valid = false, user_factors = false, iK_null = false;
+    bool ignore_iK = false;  // policy slot: RbfController evaluates with iK zeroed (controllers.py:116)
+    DevBuf bwd_mom, bwd_cp, bwd_part, bwd_out; // reverse-pass scratch
+    DevBuf Xt, Yt, Zt, ls, var, noise;         // Yt: [E][Npad]
+    DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
+    DevBuf Kmn, V2, Am, AmInv, AmD, iAt, G;    // FITC extras
+    // moment-matching workspace
+    DevBuf w_in, w_At, w_Bt, w_small, w_part, w_gath, w_out;
+    MMWork wk{};
+    bool wk_valid = false;
+    int wk_variant = -1;
+    std::vector<int> pair_owner;  // [P]
+};
+
+
+struct pilco_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::string err;
+    int not_pd = -1;
+    int variant = 0;
+    int rank = 0, nranks = 1;
+    ncclComm_t comm = nullptr;
+    Slot slot[2];
+    int* d_info = nullptr;
+    DevBuf state;   // m_x, s_x, s1, reward, act_out, rew_out
+    DevBuf params;  // policy + reward parameters
+    DevBuf traj;
+    DevBuf tape;
+    DevBuf selftest;
+    DevBuf exp_tab;  // 2^(j/n), j = 0..n-1, n = mm_exp_table_size()
+    unsigned long long* dbg = nullptr;
+    // cached hipGraph of one rollout (single-rank): replayed while the plan key is unchanged
+    hipGraphExec_t graph = nullptr;
+    std::vector<unsigned long long> graph_key;
+    bool use_graph = true;
+    bool graph_rccl_failed = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> pair_events;
+    double* pin = nullptr;   // pinned host staging buffer of the reverse pass (truly asynchronous small copies)
+    size_t pin_cap = 0;
+};
+
+int fail(pilco_ctx* c, int code, const std::string& msg);
+
+#define HIPCHK(call)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(ctx, PILCO_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+#define ENSURE(buf, count)                                                                                 \
+    do {                                                                                                   \
+        if ((buf).ensure(count) != hipSuccess) return fail(ctx, PILCO_E_ALLOC, "hipMalloc failed: " #buf); \
+    } while (0)
+
+// api.hip
+int check_slot(pilco_ctx* ctx, int slot);
+int build_work(pilco_ctx* ctx, Slot& s);          // (re)builds the per-slot step workspace and its geometry
+MMModel model_of(const Slot& s);
+int all_gather_segments(pilco_ctx* ctx, Slot& s);
+int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr);
+
+// rollout.hip
+struct RolloutPlan {
+    GlueArgs g{};
+    double* st[2] = {nullptr, nullptr};  // double-buffered state: m_x[E] | s_x[E*E]
+    int E = 0, D = 0, U = 0;
+};
+int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_term* rw, int n_rw, int H, bool want_traj,
+                  RolloutPlan& plan);
+int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev);
+int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H);

@@ -1,0 +1,356 @@
+// Reverse mode: the VJP of one moment-matching step (device) and the native reverse sweep of a rollout
+// (DESIGN.md section 9).
+#include "ctx.h"
+
+extern "C" {
+
+// Vector-Jacobian product of one moment-matching step (the reverse of pilco_gp_predict):
+// given cotangents Mbar (1,E), Sbar (E,E), Vbar (D,E) returns mbar (1,D) and the symmetric sbar (D,D).
+// Entirely on the device (k_mm_bwd_pair / _post / _fin; the mean part rides in extra workgroups of _post / _fin); the
+// host only sums the E + P contribution records.  Single rank, exact or sparse model, D <= 14.
+int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double* s_in, const double* Mbar,
+                         const double* Sbar, const double* Vbar, double* mbar, double* sbar) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "predict_vjp: no current factorisation");
+    if (!m || !s_in || !Mbar || !Sbar || !Vbar || !mbar || !sbar) return fail(ctx, PILCO_E_SHAPE, "predict_vjp: null pointer");
+    if (ctx->nranks != 1) return fail(ctx, PILCO_E_STATE, "predict_vjp: single rank only");
+    const int D = s.D, E = s.E, npad = s.npad;
+    if (D + 2 > 16) return fail(ctx, PILCO_E_SHAPE, "predict_vjp: D <= 14 in this build");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (int r = build_work(ctx, s)) return r;
+    const int P = s.wk.PL;
+    // ---- device: operands (prep), reverse pair sweep, mean part, per-pair / per-output contributions
+    const int rec = D + D * D, nb = E + E * E + D * E;
+    int njs, nrb;
+    mm_bwd_geometry(npad, P, &njs, &nrb);
+    ENSURE(s.bwd_mom, (size_t)P * njs * 16 * npad);
+    ENSURE(s.bwd_cp, (size_t)std::max(1, P - E) * nrb * npad);
+    ENSURE(s.bwd_part, (size_t)(P + E) * mm_bwd_rc(npad) * (1 + rec + D));   // pair partials, then mean partials
+    ENSURE(s.bwd_out, (size_t)(E + P) * rec + (size_t)(E + P) * (D * D + D + 2));   // contributions | head records
+    const size_t n_in = (size_t)D + D * D + nb, n_out = (size_t)(E + P) * rec;
+    if (ctx->pin_cap < n_in + n_out) {
+        if (ctx->pin) (void)hipHostFree(ctx->pin);
+        ctx->pin = nullptr;
+        ctx->pin_cap = 0;
+        HIPCHK(hipHostMalloc((void**)&ctx->pin, sizeof(double) * (n_in + n_out), hipHostMallocDefault));
+        ctx->pin_cap = n_in + n_out;
+    }
+    double* hin = ctx->pin;
+    const double* po = ctx->pin + n_in;
+    memcpy(hin, m, sizeof(double) * D);
+    memcpy(hin + D, s_in, sizeof(double) * D * D);
+    memcpy(hin + D + D * D, Mbar, sizeof(double) * E);
+    memcpy(hin + D + D * D + E, Sbar, sizeof(double) * E * E);
+    memcpy(hin + D + D * D + E + E * E, Vbar, sizeof(double) * D * E);
+    HIPCHK(hipMemcpyAsync(s.wk.in_m, hin, sizeof(double) * n_in, hipMemcpyHostToDevice, ctx->st));   // in_m | in_s | bars are contiguous
+    const double* bars = s.wk.in_s + D * D;
+    const MMModel md = model_of(s);
+    launch_mm_prep(ctx->st, md, s.wk);
+    launch_mm_bwd(ctx->st, md, s.wk, s.bwd_mom.p, s.bwd_cp.p, s.bwd_part.p, bars, s.bwd_out.p + (size_t)(E + P) * rec, s.bwd_out.p);
+    HIPCHK(hipMemcpyAsync(ctx->pin + n_in, s.bwd_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    // ---- host: sum the E + P records in a fixed order, symmetrise
+    std::vector<double> acc(rec, 0.0);
+    for (int k = 0; k < E + P; ++k)
+        for (int e = 0; e < rec; ++e) acc[e] += po[(size_t)k * rec + e];
+    for (int e = 0; e < rec; ++e)
+        if (!std::isfinite(acc[e])) return fail(ctx, PILCO_E_NOT_PD, "predict_vjp: singular s + Lambda^2 or I + Lambda s");
+    for (int d = 0; d < D; ++d) mbar[d] = acc[d];
+    for (int r = 0; r < D; ++r)
+        for (int c = 0; c < D; ++c) sbar[(size_t)r * D + c] = 0.5 * (acc[D + (size_t)r * D + c] + acc[D + (size_t)c * D + r]);
+    return PILCO_OK;
+}
+
+// ------------------------------------------------------------------ native reverse sweep (policy gradient)
+}  // extern "C"
+
+namespace {
+
+typedef std::vector<double> vec;
+
+// inverse and determinant of a small dense matrix (partial pivoting); false if singular
+bool inv_small(const double* A, int n, vec& inv, double& det) {
+    vec a(A, A + (size_t)n * n);
+    inv.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
+    det = 1.0;
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        for (int r = k + 1; r < n; ++r)
+            if (std::fabs(a[(size_t)r * n + k]) > std::fabs(a[(size_t)p * n + k])) p = r;
+        const double piv = a[(size_t)p * n + k];
+        if (piv == 0.0 || !std::isfinite(piv)) return false;
+        if (p != k) {
+            for (int c = 0; c < n; ++c) {
+                std::swap(a[(size_t)p * n + c], a[(size_t)k * n + c]);
+                std::swap(inv[(size_t)p * n + c], inv[(size_t)k * n + c]);
+            }
+            det = -det;
+        }
+        det *= piv;
+        const double ip = 1.0 / piv;
+        for (int c = 0; c < n; ++c) {
+            a[(size_t)k * n + c] *= ip;
+            inv[(size_t)k * n + c] *= ip;
+        }
+        for (int r = 0; r < n; ++r) {
+            if (r == k) continue;
+            const double f = a[(size_t)r * n + k];
+            if (f == 0.0) continue;
+            for (int c = 0; c < n; ++c) {
+                a[(size_t)r * n + c] -= f * a[(size_t)k * n + c];
+                inv[(size_t)r * n + c] -= f * inv[(size_t)k * n + c];
+            }
+        }
+    }
+    return true;
+}
+
+// squash_sin (controllers.py:13-36) forward quantities and its vector-Jacobian product (derivatives as in gSin.m:50-74)
+struct Squash {
+    int U;
+    vec M, Cd, S, q, Ep, Em, dm, sm, ee;
+    void fwd(const vec& mu0, const vec& su0, const vec& e) {
+        U = (int)mu0.size();
+        M.resize(U); Cd.resize(U);
+        S.resize((size_t)U * U); q = Ep = Em = dm = sm = ee = S;
+        for (int u = 0; u < U; ++u) {
+            const double ex = std::exp(-su0[(size_t)u * U + u] / 2.0);
+            M[u] = e[u] * ex * std::sin(mu0[u]);
+            Cd[u] = e[u] * ex * std::cos(mu0[u]);
+        }
+        for (int u = 0; u < U; ++u)
+            for (int v = 0; v < U; ++v) {
+                const size_t k = (size_t)u * U + v;
+                const double lq = -(su0[(size_t)u * U + u] + su0[(size_t)v * U + v]) / 2.0;
+                q[k] = std::exp(lq);
+                Ep[k] = std::exp(lq + su0[k]);
+                Em[k] = std::exp(lq - su0[k]);
+                dm[k] = mu0[u] - mu0[v];
+                sm[k] = mu0[u] + mu0[v];
+                ee[k] = e[u] * e[v];
+                S[k] = ee[k] / 2.0 * ((Ep[k] - q[k]) * std::cos(dm[k]) - (Em[k] - q[k]) * std::cos(sm[k]));
+            }
+    }
+    void vjp(const double* Mbar, const double* Sbar, const double* Cdbar, vec& mubar, vec& subar) const {
+        mubar.assign(U, 0.0);
+        subar.assign((size_t)U * U, 0.0);
+        for (int u = 0; u < U; ++u) {
+            double acc = Mbar[u] * Cd[u] - Cdbar[u] * M[u];
+            double dd = -0.5 * Mbar[u] * M[u] - 0.5 * Cdbar[u] * Cd[u];
+            for (int v = 0; v < U; ++v) {
+                const size_t uv = (size_t)u * U + v, vu = (size_t)v * U + u;
+                const double D1 = ee[uv] / 2.0 * (-(Ep[uv] - q[uv]) * std::sin(dm[uv]) + (Em[uv] - q[uv]) * std::sin(sm[uv]));
+                const double D2 = ee[vu] / 2.0 * ((Ep[vu] - q[vu]) * std::sin(dm[vu]) + (Em[vu] - q[vu]) * std::sin(sm[vu]));
+                acc += Sbar[uv] * D1 + Sbar[vu] * D2;
+                dd -= 0.5 * (Sbar[uv] * S[uv] + Sbar[vu] * S[vu]);
+                subar[uv] = Sbar[uv] * (ee[uv] / 2.0 * (Ep[uv] * std::cos(dm[uv]) + Em[uv] * std::cos(sm[uv])));
+            }
+            mubar[u] = acc;
+            subar[(size_t)u * U + u] += dd;
+        }
+    }
+};
+
+// d muR / d m, d muR / d S of the reward terms (rewards.py:19-81; formulas of reward.m:47-50), accumulated into dm, dS
+bool reward_grad(const pilco_reward_term* rw, int n_rw, int E, const double* m, const double* S, vec& dm, vec& dS) {
+    vec A((size_t)E * E), Ai, iSpW((size_t)E * E), d(E), v(E);
+    for (int k = 0; k < n_rw; ++k) {
+        const double c = rw[k].coef;
+        if (rw[k].kind == PILCO_REWARD_LINEAR) {
+            for (int i = 0; i < E; ++i) dm[i] += c * rw[k].W[i];
+            continue;
+        }
+        const double* W = rw[k].W;
+        auto Wv = [&](int i, int j) { return W ? W[(size_t)i * E + j] : (i == j ? 1.0 : 0.0); };
+        for (int i = 0; i < E; ++i) {
+            d[i] = m[i] - (rw[k].t ? rw[k].t[i] : 0.0);
+            for (int j = 0; j < E; ++j) {
+                double acc = (i == j) ? 1.0 : 0.0;
+                for (int l = 0; l < E; ++l) acc += S[(size_t)i * E + l] * Wv(l, j);
+                A[(size_t)i * E + j] = acc;   // I + S W
+            }
+        }
+        double det;
+        if (!inv_small(A.data(), E, Ai, det)) return false;
+        for (int i = 0; i < E; ++i)
+            for (int j = 0; j < E; ++j) {
+                double acc = 0.0;
+                for (int l = 0; l < E; ++l) acc += Wv(i, l) * Ai[(size_t)l * E + j];
+                iSpW[(size_t)i * E + j] = acc;   // W (I + S W)^-1
+            }
+        double quad = 0.0;
+        for (int i = 0; i < E; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < E; ++j) acc += iSpW[(size_t)i * E + j] * d[j];
+            v[i] = acc;          // iSpW d
+            quad += d[i] * acc;
+        }
+        const double muR = std::exp(-0.5 * quad) / std::sqrt(det);
+        vec dTi(E, 0.0);   // d^T iSpW
+        for (int j = 0; j < E; ++j)
+            for (int i = 0; i < E; ++i) dTi[j] += d[i] * iSpW[(size_t)i * E + j];
+        for (int j = 0; j < E; ++j) dm[j] -= c * muR * dTi[j];
+        // dS = muR (iSpW d d^T - I) iSpW / 2, symmetrised
+        vec T((size_t)E * E);
+        for (int i = 0; i < E; ++i)
+            for (int j = 0; j < E; ++j) T[(size_t)i * E + j] = 0.5 * muR * (v[i] * dTi[j] - iSpW[(size_t)i * E + j]);
+        for (int i = 0; i < E; ++i)
+            for (int j = 0; j < E; ++j) dS[(size_t)i * E + j] += c * 0.5 * (T[(size_t)i * E + j] + T[(size_t)j * E + i]);
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Value and gradient of the rollout reward w.r.t. a LinearController's (W, b): what TensorFlow's reverse mode through
+// the tf.while_loop gives the reference (pilco/models/pilco.py:85-90,126-135).  Forward rollout with a tape on the
+// device, then the reverse sweep: the O(N^2) adjoint of every moment-matching step on the device
+// (pilco_gp_predict_vjp), the O(D^3) links (propagate pilco.py:147-149, joint Gaussian :141-144, controller + squash
+// controllers.py:13-58, rewards rewards.py:19-81) here on the host in C++.  dW (U,E), db (U).
+int pilco_rollout_grad(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                       const double* m0, const double* S0, int H, double* reward, double* dW, double* db) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!policy || !m0 || !S0 || !reward || !dW || !db || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout_grad: bad arguments");
+    if (policy->kind != PILCO_POLICY_LINEAR || !policy->squash || policy->control_dim <= 0)
+        return fail(ctx, PILCO_E_SHAPE, "rollout_grad: squashed LinearController only (other policies: pilco_rollout_tape + pilco_gp_predict_vjp)");
+    for (int k = 0; k < n_rewards; ++k)
+        if (rewards[k].kind != PILCO_REWARD_EXPONENTIAL && rewards[k].kind != PILCO_REWARD_LINEAR)
+            return fail(ctx, PILCO_E_SHAPE, "rollout_grad: unknown reward term");
+    const int E = policy->state_dim, U = policy->control_dim, D = E + U;
+    const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
+    vec mH(E), SH((size_t)E * E), traj((size_t)(H + 1) * (E + E * E)), tape(std::max<size_t>(1, (size_t)H * TS));
+    if (int r = pilco_rollout_tape(ctx, policy, rewards, n_rewards, m0, S0, H, mH.data(), SH.data(), reward, traj.data(), tape.data()))
+        return r;
+    const double* W = policy->W;
+    const double* b = policy->b;
+    vec e(U);
+    for (int u = 0; u < U; ++u) e[u] = policy->max_action[u];
+    vec mbar(E, 0.0), sbar((size_t)E * E, 0.0), Wbar((size_t)U * E, 0.0), bbar(U, 0.0);
+    vec G((size_t)E * E), Vb((size_t)D * E), s1bar((size_t)E * D), mjb(D), sjb((size_t)D * D), mxb(E), sxb((size_t)E * E);
+    vec Bb((size_t)E * U), sub((size_t)U * U), mu0(U), su0((size_t)U * U), WS((size_t)U * E), cb((size_t)E * U), Cdbar(U);
+    vec mu0b, su0b, rm(E), rS((size_t)E * E), T1((size_t)U * E), T2((size_t)U * E);
+    Squash sq;
+    for (int t = H - 1; t >= 0; --t) {
+        const double* m_x = &traj[(size_t)t * (E + E * E)];
+        const double* s_x = m_x + E;
+        const double* rec = &tape[(size_t)t * TS];
+        const double* m_j = rec;
+        const double* s_j = rec + D;
+        const double* s1 = rec + D + D * D;                           // (E, D)
+        const double* V = rec + D + D * D + (size_t)E * D + E + (size_t)E * E;   // (D, E)
+        // propagate (pilco.py:147-149): M_x = M + m_x, S_x = S + s_x + s1 V + (s1 V)^T
+        for (int i = 0; i < E; ++i)
+            for (int j = 0; j < E; ++j) G[(size_t)i * E + j] = sbar[(size_t)i * E + j] + sbar[(size_t)j * E + i];
+        for (int d = 0; d < D; ++d)
+            for (int j = 0; j < E; ++j) {
+                double acc = 0.0;
+                for (int i = 0; i < E; ++i) acc += s1[(size_t)i * D + d] * G[(size_t)i * E + j];
+                Vb[(size_t)d * E + j] = acc;                                 // s1^T G
+            }
+        for (int i = 0; i < E; ++i)
+            for (int d = 0; d < D; ++d) {
+                double acc = 0.0;
+                for (int j = 0; j < E; ++j) acc += G[(size_t)i * E + j] * V[(size_t)d * E + j];
+                s1bar[(size_t)i * D + d] = acc;                              // G V^T
+            }
+        mxb = mbar;
+        sxb = sbar;
+        if (int r = pilco_gp_predict_vjp(ctx, PILCO_SLOT_DYNAMICS, m_j, s_j, mbar.data(), sbar.data(), Vb.data(), mjb.data(), sjb.data()))
+            return r;
+        // joint Gaussian (pilco.py:141-144)
+        for (int i = 0; i < E; ++i) mxb[i] += mjb[i];
+        for (int i = 0; i < E; ++i)
+            for (int j = 0; j < E; ++j) sxb[(size_t)i * E + j] += sjb[(size_t)i * D + j] + s1bar[(size_t)i * D + j];
+        for (int i = 0; i < E; ++i)
+            for (int u = 0; u < U; ++u)
+                Bb[(size_t)i * U + u] = sjb[(size_t)i * D + E + u] + sjb[(size_t)(E + u) * D + i] + s1bar[(size_t)i * D + E + u];
+        for (int u = 0; u < U; ++u)
+            for (int v = 0; v < U; ++v) sub[(size_t)u * U + v] = sjb[(size_t)(E + u) * D + E + v];
+        // controller (controllers.py:46-58): mu0 = W m + b, su0 = W s W^T, c = W^T diag(Cd)
+        for (int u = 0; u < U; ++u) {
+            double acc = b[u];
+            for (int i = 0; i < E; ++i) acc += W[(size_t)u * E + i] * m_x[i];
+            mu0[u] = acc;
+            for (int j = 0; j < E; ++j) {
+                double a2 = 0.0;
+                for (int i = 0; i < E; ++i) a2 += W[(size_t)u * E + i] * s_x[(size_t)i * E + j];
+                WS[(size_t)u * E + j] = a2;                                  // W s
+            }
+        }
+        for (int u = 0; u < U; ++u)
+            for (int v = 0; v < U; ++v) {
+                double acc = 0.0;
+                for (int j = 0; j < E; ++j) acc += WS[(size_t)u * E + j] * W[(size_t)v * E + j];
+                su0[(size_t)u * U + v] = acc;
+            }
+        sq.fwd(mu0, su0, e);
+        for (int i = 0; i < E; ++i)
+            for (int j = 0; j < E; ++j) {
+                double acc = 0.0;
+                for (int u = 0; u < U; ++u) acc += Bb[(size_t)i * U + u] * W[(size_t)u * E + j] * sq.Cd[u];   // Bb c^T, c = W^T diag(Cd)
+                sxb[(size_t)i * E + j] += acc;
+            }
+        for (int i = 0; i < E; ++i)
+            for (int u = 0; u < U; ++u) {
+                double acc = 0.0;
+                for (int l = 0; l < E; ++l) acc += s_x[(size_t)l * E + i] * Bb[(size_t)l * U + u];
+                cb[(size_t)i * U + u] = acc;                                 // s_x^T Bb
+            }
+        for (int u = 0; u < U; ++u) {
+            double acc = 0.0;
+            for (int i = 0; i < E; ++i) acc += W[(size_t)u * E + i] * cb[(size_t)i * U + u];
+            Cdbar[u] = acc;
+        }
+        sq.vjp(&mjb[E], sub.data(), Cdbar.data(), mu0b, su0b);
+        // Wbar += diag(Cd) cb^T + mu0b m_x^T + su0b W s_x^T + su0b^T W s_x
+        for (int u = 0; u < U; ++u)
+            for (int j = 0; j < E; ++j) {
+                double a1 = 0.0, a2 = 0.0;
+                for (int i = 0; i < E; ++i) {
+                    a1 += W[(size_t)u * E + i] * s_x[(size_t)j * E + i];     // (W s_x^T)[u][j]
+                    a2 += W[(size_t)u * E + i] * s_x[(size_t)i * E + j];     // (W s_x)[u][j]
+                }
+                T1[(size_t)u * E + j] = a1;
+                T2[(size_t)u * E + j] = a2;
+            }
+        for (int u = 0; u < U; ++u) {
+            bbar[u] += mu0b[u];
+            for (int j = 0; j < E; ++j) {
+                double acc = sq.Cd[u] * cb[(size_t)j * U + u] + mu0b[u] * m_x[j];
+                for (int v = 0; v < U; ++v)
+                    acc += su0b[(size_t)u * U + v] * T1[(size_t)v * E + j] + su0b[(size_t)v * U + u] * T2[(size_t)v * E + j];
+                Wbar[(size_t)u * E + j] += acc;
+            }
+        }
+        for (int i = 0; i < E; ++i) {
+            double acc = 0.0;
+            for (int u = 0; u < U; ++u) acc += W[(size_t)u * E + i] * mu0b[u];
+            mxb[i] += acc;                                                   // W^T mu0b
+            for (int j = 0; j < E; ++j) {
+                double a2 = 0.0;
+                for (int u = 0; u < U; ++u)
+                    for (int v = 0; v < U; ++v) a2 += W[(size_t)u * E + i] * su0b[(size_t)u * U + v] * W[(size_t)v * E + j];
+                sxb[(size_t)i * E + j] += a2;                                // W^T su0b W
+            }
+        }
+        // reward of the pre-propagation state (pilco.py:133)
+        std::fill(rm.begin(), rm.end(), 0.0);
+        std::fill(rS.begin(), rS.end(), 0.0);
+        if (!reward_grad(rewards, n_rewards, E, m_x, s_x, rm, rS)) return fail(ctx, PILCO_E_NOT_PD, "rollout_grad: singular I + S W in the reward");
+        for (int i = 0; i < E; ++i) mxb[i] += rm[i];
+        for (int i = 0; i < E * E; ++i) sxb[i] += rS[i];
+        mbar = mxb;
+        for (int i = 0; i < E; ++i)
+            for (int j = 0; j < E; ++j) sbar[(size_t)i * E + j] = 0.5 * (sxb[(size_t)i * E + j] + sxb[(size_t)j * E + i]);
+    }
+    memcpy(dW, Wbar.data(), sizeof(double) * U * E);
+    memcpy(db, bbar.data(), sizeof(double) * U);
+    return PILCO_OK;
+}
+
+}  // extern "C"

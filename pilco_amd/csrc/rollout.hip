@@ -1,0 +1,563 @@
+// Rollouts (PILCO.predict / propagate, pilco/models/pilco.py:118-153): plan, launch sequence, hipGraph capture
+// and replay, and the policy / reward evaluation entry points.
+#include "ctx.h"
+
+namespace {
+
+// W (E x E, symmetric PSD) = F F^T with F (E x rank) from a cyclic Jacobi eigen-decomposition.
+// Returns rank, or -1 when W is not symmetric PSD (the general pivoted device path is used then).
+int psd_factor(const double* W, int E, std::vector<double>& F) {
+    double scale = 0.0;
+    for (int i = 0; i < E * E; ++i) scale = std::max(scale, std::fabs(W[i]));
+    if (scale == 0.0) { F.clear(); return 0; }
+    for (int i = 0; i < E; ++i)
+        for (int j = 0; j < i; ++j)
+            if (std::fabs(W[i * E + j] - W[j * E + i]) > 1e-13 * scale) return -1;
+    std::vector<double> A(W, W + E * E), V(E * E, 0.0);
+    for (int i = 0; i < E; ++i) V[i * E + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int i = 0; i < E; ++i)
+            for (int j = 0; j < i; ++j) off += A[i * E + j] * A[i * E + j];
+        if (off <= 1e-32 * scale * scale) break;
+        for (int p = 0; p < E; ++p)
+            for (int q = p + 1; q < E; ++q) {
+                const double apq = A[p * E + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * E + q] - A[p * E + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < E; ++k) {
+                    const double akp = A[k * E + p], akq = A[k * E + q];
+                    A[k * E + p] = c * akp - sn * akq;
+                    A[k * E + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < E; ++k) {
+                    const double apk = A[p * E + k], aqk = A[q * E + k];
+                    A[p * E + k] = c * apk - sn * aqk;
+                    A[q * E + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < E; ++k) {
+                    const double vkp = V[k * E + p], vkq = V[k * E + q];
+                    V[k * E + p] = c * vkp - sn * vkq;
+                    V[k * E + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    double lmax = 0.0;
+    for (int i = 0; i < E; ++i) lmax = std::max(lmax, A[i * E + i]);
+    for (int i = 0; i < E; ++i)
+        if (A[i * E + i] < -1e-12 * std::max(lmax, scale)) return -1;
+    std::vector<int> keep;
+    for (int i = 0; i < E; ++i)
+        if (A[i * E + i] > 1e-15 * lmax) keep.push_back(i);
+    const int r = (int)keep.size();
+    F.assign((size_t)E * std::max(r, 1), 0.0);
+    for (int k = 0; k < r; ++k) {
+        const double sq = std::sqrt(A[keep[k] * E + keep[k]]);
+        for (int e = 0; e < E; ++e) F[(size_t)e * r + k] = V[e * E + keep[k]] * sq;
+    }
+    return r;
+}
+
+// marshal reward terms into a host staging vector; pointers are patched relative to dev_base
+int stage_rewards(pilco_ctx* ctx, const pilco_reward_term* rw, int n_rw, int E, std::vector<double>& hp, size_t& off,
+                  const double* dev_base, RewardDev* out) {
+    for (int i = 0; i < n_rw; ++i) {
+        out[i].kind = rw[i].kind;
+        out[i].coef = rw[i].coef;
+        out[i].F = nullptr;
+        out[i].rank = -1;
+        if (!rw[i].W) return fail(ctx, PILCO_E_SHAPE, "reward: W is required");
+        if (rw[i].kind == PILCO_REWARD_EXPONENTIAL) {
+            hp.resize(std::max(hp.size(), off + (size_t)2 * E * E + E));
+            memcpy(&hp[off], rw[i].W, sizeof(double) * E * E);
+            out[i].W = dev_base + off; off += (size_t)E * E;
+            if (rw[i].t) memcpy(&hp[off], rw[i].t, sizeof(double) * E);
+            else std::fill(hp.begin() + off, hp.begin() + off + E, 0.0);
+            out[i].t = dev_base + off; off += E;
+            std::vector<double> F;
+            const int r = psd_factor(rw[i].W, E, F);
+            out[i].rank = r;
+            if (r > 0) {
+                memcpy(&hp[off], F.data(), sizeof(double) * E * r);
+                out[i].F = dev_base + off;
+            } else if (r == 0) {
+                out[i].F = dev_base + off;
+            }
+            off += (size_t)E * E;
+        } else if (rw[i].kind == PILCO_REWARD_LINEAR) {
+            hp.resize(std::max(hp.size(), off + (size_t)E));
+            memcpy(&hp[off], rw[i].W, sizeof(double) * E);
+            out[i].W = dev_base + off; off += E;
+            out[i].t = out[i].W;
+        } else {
+            return fail(ctx, PILCO_E_SHAPE, "reward: unknown kind");
+        }
+    }
+    return PILCO_OK;
+}
+
+}  // namespace
+
+int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_term* rw, int n_rw, int H, bool want_traj,
+                  RolloutPlan& plan) {
+    Slot& s = ctx->slot[0];
+    if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "rollout: dynamics model has no current factorisation");
+    if (!pol) return fail(ctx, PILCO_E_SHAPE, "rollout: null policy");
+    const int E = s.E, D = s.D, U = D - E;
+    if (pol->state_dim != E || pol->control_dim != U || U < 0)
+        return fail(ctx, PILCO_E_SHAPE, "rollout: policy dims do not match the model (state_dim must be E, control_dim D-E)");
+    if (pol->kind == PILCO_POLICY_NONE && U != 0) return fail(ctx, PILCO_E_SHAPE, "rollout: policy NONE needs D == E");
+    if (pol->kind == PILCO_POLICY_LINEAR && (U == 0 || !pol->W || !pol->b)) return fail(ctx, PILCO_E_SHAPE, "rollout: linear policy needs W, b and control_dim > 0");
+    if (pol->kind == PILCO_POLICY_RBF) {
+        Slot& ps = ctx->slot[PILCO_SLOT_POLICY];
+        if (!ps.factor_valid) return fail(ctx, PILCO_E_STATE, "rollout: RBF policy slot has no current factorisation");
+        if (ps.D != E || ps.E != U || U == 0) return fail(ctx, PILCO_E_SHAPE, "rollout: RBF policy GP must map state_dim -> control_dim");
+        if (ctx->nranks != 1) return fail(ctx, PILCO_E_STATE, "rollout: the RBF policy is evaluated unsharded; use one rank");
+        if (int r = build_work(ctx, ps)) return r;
+    }
+    if (pol->kind < 0 || pol->kind > 2) return fail(ctx, PILCO_E_SHAPE, "rollout: unknown policy kind");
+    if (n_rw < 0 || n_rw > MAX_REWARD_TERMS || (n_rw > 0 && !rw)) return fail(ctx, PILCO_E_SHAPE, "rollout: 0..4 reward terms supported");
+    if (int r = build_work(ctx, s)) return r;
+    // state: 2 x (m_x[E] s_x[E*E]) | s1[E*D] | reward[1]
+    const size_t n_state = 2 * ((size_t)E + E * E) + (size_t)E * D + 1 + 8;
+    ENSURE(ctx->state, n_state);
+    // params: W[U*E] b[U] maxact[U] then per reward W[E*E] t[E] F[E*E]
+    const size_t n_par = (size_t)U * E + 2 * U + (size_t)MAX_REWARD_TERMS * (2 * E * E + E) + 8;
+    ENSURE(ctx->params, n_par);
+    if (want_traj) ENSURE(ctx->traj, (size_t)(H + 1) * (E + E * E));
+    std::vector<double> hp(n_par, 0.0);
+    size_t off = 0;
+    GlueArgs& g = plan.g;
+    g = GlueArgs{};
+    g.E = E; g.D = D; g.U = U;
+    g.wk = s.wk;
+    g.var = s.var.p;
+    plan.st[0] = ctx->state.p;
+    plan.st[1] = ctx->state.p + (E + E * E);
+    g.s1 = ctx->state.p + 2 * (E + E * E);
+    g.reward = g.s1 + (size_t)E * D;
+    g.traj = want_traj ? ctx->traj.p : nullptr;
+    g.pol_kind = pol->kind;
+    g.squash = pol->squash;
+    if (pol->kind == PILCO_POLICY_RBF) {
+        g.pwk = ctx->slot[PILCO_SLOT_POLICY].wk;
+        g.pvar = ctx->slot[PILCO_SLOT_POLICY].var.p;
+        for (int u = 0; u < U; ++u) hp[off + u] = pol->max_action ? pol->max_action[u] : 1.0;
+        g.maxact = ctx->params.p + off; off += U;
+    }
+    if (pol->kind == PILCO_POLICY_LINEAR) {
+        memcpy(&hp[off], pol->W, sizeof(double) * U * E);
+        g.W = ctx->params.p + off; off += (size_t)U * E;
+        memcpy(&hp[off], pol->b, sizeof(double) * U);
+        g.b = ctx->params.p + off; off += U;
+        for (int u = 0; u < U; ++u) hp[off + u] = pol->max_action ? pol->max_action[u] : 1.0;
+        g.maxact = ctx->params.p + off; off += U;
+    }
+    g.n_rewards = n_rw;
+    g.rew_out = nullptr;
+    if (int r = stage_rewards(ctx, rw, n_rw, E, hp, off, ctx->params.p, g.rw)) return r;
+    if (hp.size() > n_par) return fail(ctx, PILCO_E_ALLOC, "rollout: parameter staging overflow");
+    HIPCHK(hipMemcpyAsync(ctx->params.p, hp.data(), sizeof(double) * n_par, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));  // hp is a local vector
+    plan.E = E; plan.D = D; plan.U = U;
+    return PILCO_OK;
+}
+
+// enqueue one full rollout on the stream (initial state already in plan.st[0]); the final
+// state ends up in plan.st[H & 1].  The reward of state t (pilco.py:133) is evaluated by the
+// second workgroup of the glue launch that turns state t into state t+1.
+int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev) {
+    Slot& s = ctx->slot[0];
+    const MMModel md = model_of(s);
+    const int E = plan.E;
+    GlueArgs g = plan.g;
+    const bool rew = g.n_rewards > 0 && !(s.wk.abl & 8);
+    HIPCHK(hipMemsetAsync(g.reward, 0, sizeof(double), ctx->st));
+    g.step = 0;
+    g.m_x = plan.st[0];
+    g.s_x = plan.st[0] + E;
+    g.m_out = nullptr;
+    g.s_out = nullptr;
+    const bool rbf = (g.pol_kind == PILCO_POLICY_RBF);
+    Slot& ps = ctx->slot[PILCO_SLOT_POLICY];
+    const MMModel pmd = rbf ? model_of(ps) : MMModel{};
+    // RBF policy (controllers.py:108-121): the glue that produced the state hands it to the policy GP
+    // (GF_RBF_PRE), the policy's moment matching runs as its own prep/pair, a second glue squashes and
+    // builds the joint Gaussian (GF_RBF_POST | GF_POLICY).
+    auto policy_stage = [&](GlueArgs& ga) {
+        launch_mm_prep(ctx->st, pmd, ps.wk);
+        launch_mm_pair(ctx->st, pmd, ps.wk, ctx->variant);
+        const int keep = ga.flags;
+        ga.flags = GF_RBF_POST | GF_POLICY;
+        launch_glue(ctx->st, ga);
+        ga.flags = keep;
+    };
+    g.flags = GF_TRAJ | (H > 0 ? (rbf ? GF_RBF_PRE : GF_POLICY) : 0);
+    launch_glue(ctx->st, g);
+    if (rbf && H > 0) policy_stage(g);
+    size_t evi = 0;
+    for (int t = 0; t < H; ++t) {
+        if (s.wk.PL > 0) {
+            PrepReward pr{};
+            if (rew) {   // reward of state t rides in a spare workgroup of this step's prep launch
+                pr.n = g.n_rewards;
+                pr.E = E;
+                for (int i = 0; i < g.n_rewards; ++i) pr.rw[i] = g.rw[i];
+                pr.m_x = plan.st[t & 1];
+                pr.s_x = plan.st[t & 1] + E;
+                pr.reward = g.reward;
+            }
+            launch_mm_prep(ctx->st, md, s.wk, rew ? &pr : nullptr);
+            if (ctx->dbg && (s.wk.abl & 64)) launch_stamp(ctx->st, ctx->dbg, 30);
+            if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
+            launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
+            if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
+        }
+        g.step = t + 1;
+        g.m_x = plan.st[t & 1];
+        g.s_x = plan.st[t & 1] + E;
+        g.m_out = plan.st[(t + 1) & 1];
+        g.s_out = plan.st[(t + 1) & 1] + E;
+        const bool more = t + 1 < H;
+        const int tail = GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ | (more ? (rbf ? GF_RBF_PRE : GF_POLICY) : 0);
+        if (ctx->nranks == 1 && !ctx->comm) {
+            g.flags = GF_PACK | tail;
+        } else {
+            g.flags = GF_PACK;
+            launch_glue(ctx->st, g);
+            if (int r = all_gather_segments(ctx, s)) return r;
+            g.flags = tail;
+        }
+        launch_glue(ctx->st, g, rew && s.wk.PL == 0);   // (a rank without pairs keeps the reward in the glue launch)
+        if (rbf && more) {  // the policy stage reads the NEW state
+            g.m_x = g.m_out;
+            g.s_x = g.s_out;
+            policy_stage(g);
+        }
+    }
+    return PILCO_OK;
+}
+
+// Run one rollout: replay the cached hipGraph when the launch sequence is unchanged
+// (same buffers, sizes, horizon, policy / reward structure), otherwise (re)capture it.
+int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
+    Slot& s = ctx->slot[0];
+    // With a communicator the captured graph contains the ncclAllGather nodes (RCCL supports stream
+    // capture); if capture or instantiation fails the rollout falls back to eager launches for good.
+    const bool sharded = (ctx->nranks != 1 || ctx->comm);
+    if (!ctx->use_graph || (sharded && (!ctx->comm || ctx->graph_rccl_failed)) || (ctx->dbg && !getenv("PILCO_DBG_GRAPH")))
+        return enqueue_rollout(ctx, plan, H, nullptr);
+    const GlueArgs& g = plan.g;
+    std::vector<unsigned long long> key = {
+        (unsigned long long)H, (unsigned long long)g.pol_kind, (unsigned long long)g.n_rewards, (unsigned long long)g.squash,
+        (unsigned long long)ctx->variant, (unsigned long long)(uintptr_t)plan.st[0], (unsigned long long)(uintptr_t)g.s1,
+        (unsigned long long)(uintptr_t)g.traj, (unsigned long long)(uintptr_t)g.tape, (unsigned long long)(uintptr_t)g.W, (unsigned long long)(uintptr_t)g.maxact,
+        (unsigned long long)(uintptr_t)s.w_part.p, (unsigned long long)(uintptr_t)s.w_At.p, (unsigned long long)(uintptr_t)s.w_Bt.p,
+        (unsigned long long)(uintptr_t)s.w_small.p, (unsigned long long)(uintptr_t)s.w_gath.p, (unsigned long long)(uintptr_t)s.w_out.p,
+        (unsigned long long)(uintptr_t)s.w_in.p, (unsigned long long)(uintptr_t)s.beta.p,
+        (unsigned long long)(uintptr_t)s.iK.p, (unsigned long long)s.iK_null, (unsigned long long)(uintptr_t)s.Xt.p,
+        (unsigned long long)(uintptr_t)s.Zt.p, (unsigned long long)(uintptr_t)s.ls.p, (unsigned long long)s.n,
+        (unsigned long long)s.wk.sk_waves, (unsigned long long)s.wk.NT, (unsigned long long)s.wk.NCH, (unsigned long long)s.wk.NCHM, (unsigned long long)s.wk.abl,
+        (unsigned long long)(uintptr_t)ctx->slot[1].w_part.p, (unsigned long long)(uintptr_t)ctx->slot[1].w_At.p,
+        (unsigned long long)(uintptr_t)ctx->slot[1].beta.p, (unsigned long long)(uintptr_t)ctx->slot[1].Xt.p,
+        (unsigned long long)ctx->slot[1].n,
+        (unsigned long long)ctx->slot[1].wk.sk_waves, (unsigned long long)(uintptr_t)ctx->slot[1].w_small.p,
+        (unsigned long long)(uintptr_t)ctx->slot[1].w_in.p, (unsigned long long)(uintptr_t)ctx->slot[1].ls.p};
+    for (int i = 0; i < g.n_rewards; ++i) {
+        key.push_back((unsigned long long)g.rw[i].kind);
+        key.push_back((unsigned long long)(long long)g.rw[i].rank);
+        key.push_back((unsigned long long)(uintptr_t)g.rw[i].W);
+        unsigned long long cbits;
+        memcpy(&cbits, &g.rw[i].coef, sizeof(cbits));
+        key.push_back(cbits);
+    }
+    if (!ctx->graph || key != ctx->graph_key) {
+        if (ctx->graph) {
+            (void)hipGraphExecDestroy(ctx->graph);
+            ctx->graph = nullptr;
+        }
+        // warm the per-kernel one-time host configuration outside the capture
+        if (int r = enqueue_rollout(ctx, plan, H > 0 ? 1 : 0, nullptr)) return r;
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(ctx->st, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_rollout(ctx, plan, H, nullptr);
+        hipError_t e = hipStreamEndCapture(ctx->st, &graph);
+        if (rc != PILCO_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            if (sharded) {
+                ctx->graph_rccl_failed = true;
+                (void)hipGetLastError();
+                return -1;
+            }
+            return rc;
+        }
+        if (e != hipSuccess) {
+            if (sharded) {  // not fatal: run this and all later sharded rollouts eagerly
+                ctx->graph_rccl_failed = true;
+                (void)hipGetLastError();
+                return -1;
+            }
+            return fail(ctx, PILCO_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        }
+        e = hipGraphInstantiate(&ctx->graph, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+            ctx->graph = nullptr;
+            if (sharded) {
+                ctx->graph_rccl_failed = true;
+                (void)hipGetLastError();
+                return -1;
+            }
+            return fail(ctx, PILCO_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        }
+        ctx->graph_key = key;
+        // the warm-up rollout above overwrote the initial state: the caller re-uploads it (see callers)
+        return -1;
+    }
+    HIPCHK(hipGraphLaunch(ctx->graph, ctx->st));
+    return PILCO_OK;
+}
+
+
+extern "C" {
+
+int pilco_rollout(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                  const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!m0 || !S0 || !mH || !SH || !reward || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    RolloutPlan plan;
+    if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, traj != nullptr, plan)) return r;
+    const int E = plan.E;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIPCHK(hipMemcpyAsync(plan.st[0], m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
+        HIPCHK(hipMemcpyAsync(plan.st[0] + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
+        const int r = run_rollout(ctx, plan, H);
+        if (r == -1) continue;  // graph was just (re)captured: upload the state again and replay it
+        if (r != PILCO_OK) return r;
+        break;
+    }
+    HIPCHK(hipMemcpyAsync(mH, plan.st[H & 1], sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(SH, plan.st[H & 1] + E, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(reward, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
+    if (traj)
+        HIPCHK(hipMemcpyAsync(traj, ctx->traj.p, sizeof(double) * (size_t)(H + 1) * (E + E * E), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    return PILCO_OK;
+}
+
+int pilco_propagate(pilco_ctx* ctx, const pilco_policy* policy, const double* m_x, const double* s_x, double* M_x, double* S_x) {
+    double r = 0.0;
+    return pilco_rollout(ctx, policy, nullptr, 0, m_x, s_x, 1, M_x, S_x, &r, nullptr);
+}
+
+int pilco_policy_action(pilco_ctx* ctx, const pilco_policy* policy, const double* m, const double* s_in, double* M, double* S, double* V) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!policy || !m || !s_in || !M || !S || !V) return fail(ctx, PILCO_E_SHAPE, "policy_action: null pointer");
+    if (policy->kind != PILCO_POLICY_LINEAR && policy->kind != PILCO_POLICY_RBF) return fail(ctx, PILCO_E_SHAPE, "policy_action: policy kind must be LINEAR or RBF");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int E = policy->state_dim, U = policy->control_dim;
+    if (E <= 0 || U <= 0 || E > MAX_D || U > MAX_D) return fail(ctx, PILCO_E_SHAPE, "policy_action: bad dims");
+    if (policy->kind == PILCO_POLICY_RBF) {
+        Slot& ps = ctx->slot[PILCO_SLOT_POLICY];
+        if (!ps.factor_valid) return fail(ctx, PILCO_E_STATE, "policy_action: RBF policy slot has no current factorisation");
+        if (ps.D != E || ps.E != U) return fail(ctx, PILCO_E_SHAPE, "policy_action: RBF policy GP must map state_dim -> control_dim");
+        if (int r = build_work(ctx, ps)) return r;
+        const size_t n_st = (size_t)E + E * E + U + (U + U * U + (size_t)E * U);
+        ENSURE(ctx->state, n_st + 8);
+        std::vector<double> h(n_st, 0.0);
+        memcpy(&h[0], m, sizeof(double) * E);
+        memcpy(&h[E], s_in, sizeof(double) * E * E);
+        size_t off = (size_t)E + E * E;
+        GlueArgs g{};
+        g.E = E; g.D = E + U; g.U = U;
+        g.m_x = ctx->state.p;
+        g.s_x = ctx->state.p + E;
+        for (int u = 0; u < U; ++u) h[off + u] = policy->max_action ? policy->max_action[u] : 1.0;
+        g.maxact = ctx->state.p + off; off += U;
+        g.act_out = ctx->state.p + off;
+        g.pol_kind = PILCO_POLICY_RBF;
+        g.squash = policy->squash;
+        g.pwk = ps.wk;
+        g.pvar = ps.var.p;
+        HIPCHK(hipMemcpyAsync(ctx->state.p, h.data(), sizeof(double) * n_st, hipMemcpyHostToDevice, ctx->st));
+        HIPCHK(hipMemcpyAsync(ps.wk.in_m, m, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
+        HIPCHK(hipMemcpyAsync(ps.wk.in_s, s_in, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
+        const MMModel pmd = model_of(ps);
+        launch_mm_prep(ctx->st, pmd, ps.wk);
+        launch_mm_pair(ctx->st, pmd, ps.wk, ctx->variant);
+        g.flags = GF_RBF_POST | GF_POLICY;
+        launch_glue(ctx->st, g);
+        std::vector<double> o((size_t)U + U * U + (size_t)E * U);
+        HIPCHK(hipMemcpyAsync(o.data(), g.act_out, sizeof(double) * o.size(), hipMemcpyDeviceToHost, ctx->st));
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        HIPCHK(hipGetLastError());
+        memcpy(M, &o[0], sizeof(double) * U);
+        memcpy(S, &o[U], sizeof(double) * U * U);
+        memcpy(V, &o[(size_t)U + U * U], sizeof(double) * E * U);
+        return PILCO_OK;
+    }
+    if (!policy->W || !policy->b) return fail(ctx, PILCO_E_SHAPE, "policy_action: linear policy needs W and b");
+    const size_t n_state = (size_t)E + E * E + (size_t)U * E + 2 * U + (U + U * U + (size_t)E * U);
+    ENSURE(ctx->state, n_state + 8);
+    std::vector<double> h(n_state, 0.0);
+    memcpy(&h[0], m, sizeof(double) * E);
+    memcpy(&h[E], s_in, sizeof(double) * E * E);
+    size_t off = (size_t)E + E * E;
+    GlueArgs g{};
+    g.E = E; g.D = E + U; g.U = U;
+    g.m_x = ctx->state.p;
+    g.s_x = g.m_x + E;
+    memcpy(&h[off], policy->W, sizeof(double) * U * E);
+    g.W = ctx->state.p + off; off += (size_t)U * E;
+    memcpy(&h[off], policy->b, sizeof(double) * U);
+    g.b = ctx->state.p + off; off += U;
+    for (int u = 0; u < U; ++u) h[off + u] = policy->max_action ? policy->max_action[u] : 1.0;
+    g.maxact = ctx->state.p + off; off += U;
+    g.act_out = ctx->state.p + off;
+    g.pol_kind = PILCO_POLICY_LINEAR;
+    g.squash = policy->squash;
+    g.flags = GF_POLICY;
+    HIPCHK(hipMemcpyAsync(ctx->state.p, h.data(), sizeof(double) * n_state, hipMemcpyHostToDevice, ctx->st));
+    launch_glue(ctx->st, g);
+    std::vector<double> o((size_t)U + U * U + (size_t)E * U);
+    HIPCHK(hipMemcpyAsync(o.data(), g.act_out, sizeof(double) * o.size(), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    memcpy(M, &o[0], sizeof(double) * U);
+    memcpy(S, &o[U], sizeof(double) * U * U);
+    memcpy(V, &o[(size_t)U + U * U], sizeof(double) * E * U);
+    return PILCO_OK;
+}
+
+int pilco_reward_eval(pilco_ctx* ctx, const pilco_reward_term* rewards, int n_rewards, int state_dim, const double* m,
+                      const double* s_in, double* muR, double* sR) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!rewards || n_rewards <= 0 || n_rewards > MAX_REWARD_TERMS || !m || !s_in || !muR || !sR || state_dim <= 0 || state_dim > MAX_D)
+        return fail(ctx, PILCO_E_SHAPE, "reward_eval: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int E = state_dim;
+    const size_t n = (size_t)E + E * E + (size_t)n_rewards * (2 * E * E + E) + 2;
+    ENSURE(ctx->state, n + 8);
+    std::vector<double> h(n, 0.0);
+    memcpy(&h[0], m, sizeof(double) * E);
+    memcpy(&h[E], s_in, sizeof(double) * E * E);
+    size_t off = (size_t)E + E * E;
+    GlueArgs g{};
+    g.E = E; g.D = E; g.U = 0;
+    g.m_x = ctx->state.p;
+    g.s_x = ctx->state.p + E;
+    g.n_rewards = n_rewards;
+    if (int r = stage_rewards(ctx, rewards, n_rewards, E, h, off, ctx->state.p, g.rw)) return r;
+    if (h.size() < off + 2) h.resize(off + 2, 0.0);
+    if (h.size() + 8 > ctx->state.cap) return fail(ctx, PILCO_E_ALLOC, "reward_eval: staging overflow");
+    g.rew_out = ctx->state.p + off;
+    g.flags = 0;  // workgroup 0 idles; workgroup 1 evaluates mean and variance
+    HIPCHK(hipMemcpyAsync(ctx->state.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->st));
+    launch_glue(ctx->st, g, true);
+    double o[2];
+    HIPCHK(hipMemcpyAsync(o, g.rew_out, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    *muR = o[0];
+    *sR = o[1];
+    return PILCO_OK;
+}
+
+int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                        const double* m0, const double* S0, int H, int reps, double* mH, double* SH, double* reward,
+                        float* ms_total, float* ms_pair, int* n_pair_launches) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!m0 || !S0 || !mH || !SH || !reward || H < 0 || reps <= 0 || !ms_total) return fail(ctx, PILCO_E_SHAPE, "rollout_timed: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    RolloutPlan plan;
+    if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, false, plan)) return r;
+    const int E = plan.E;
+    ENSURE(ctx->selftest, (size_t)E + E * E + 256);
+    double* init = ctx->selftest.p + 256;  // device copy of (m0, S0) so that the timed region has no host traffic
+    HIPCHK(hipMemcpyAsync(init, m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(init + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    {   // make sure the graph exists before the timed region
+        HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
+        const int r = run_rollout(ctx, plan, H);
+        if (r != PILCO_OK && r != -1) return r;
+        HIPCHK(hipStreamSynchronize(ctx->st));
+    }
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->st));
+    for (int rep = 0; rep < reps; ++rep) {
+        HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
+        int r = run_rollout(ctx, plan, H);
+        if (r == -1) {  // only possible when the sharded capture fell back to eager mode: redo this rollout
+            HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
+            r = run_rollout(ctx, plan, H);
+        }
+        if (r != PILCO_OK) return r;
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->st));
+    HIPCHK(hipEventSynchronize(ctx->ev1));
+    HIPCHK(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    if (ms_pair) {
+        // second pass with an event pair around every pair-kernel launch (perturbs the total, so timed separately)
+        const size_t need = (size_t)2 * H;
+        while (ctx->pair_events.size() < need) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            ctx->pair_events.push_back(e);
+        }
+        HIPCHK(hipMemcpyAsync(plan.st[0], init, sizeof(double) * (E + E * E), hipMemcpyDeviceToDevice, ctx->st));
+        if (int r = enqueue_rollout(ctx, plan, H, &ctx->pair_events)) return r;
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        float tot = 0.f;
+        int cnt = 0;
+        if (ctx->slot[0].wk.PL > 0)
+            for (int t = 0; t < H; ++t) {
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, ctx->pair_events[2 * t], ctx->pair_events[2 * t + 1]));
+                tot += ms;
+                ++cnt;
+            }
+        *ms_pair = tot;
+        if (n_pair_launches) *n_pair_launches = cnt;
+    }
+    HIPCHK(hipMemcpyAsync(mH, plan.st[H & 1], sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(SH, plan.st[H & 1] + E, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(reward, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    return PILCO_OK;
+}
+
+// pilco_rollout that also records, for every step t < H, the joint Gaussian (m, s, s1) handed to
+// the dynamics GP and its outputs (M, S, V): tape [H][D + D*D + E*D + E + E*E + D*E].  The reverse
+// sweep of the policy gradient replays these records (pilco_amd/adjoint.py).
+int pilco_rollout_tape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                       const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj,
+                       double* tape) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!m0 || !S0 || !mH || !SH || !reward || !tape || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout_tape: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    RolloutPlan plan;
+    if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, traj != nullptr, plan)) return r;
+    const int E = plan.E, D = plan.D;
+    const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
+    ENSURE(ctx->tape, std::max<size_t>(1, (size_t)H * TS));
+    plan.g.tape = ctx->tape.p;
+    HIPCHK(hipMemcpyAsync(plan.st[0], m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(plan.st[0] + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
+    if (int r = enqueue_rollout(ctx, plan, H, nullptr)) return r;
+    HIPCHK(hipMemcpyAsync(mH, plan.st[H & 1], sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(SH, plan.st[H & 1] + E, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(reward, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
+    if (traj) HIPCHK(hipMemcpyAsync(traj, ctx->traj.p, sizeof(double) * (size_t)(H + 1) * (E + E * E), hipMemcpyDeviceToHost, ctx->st));
+    if (H > 0) HIPCHK(hipMemcpyAsync(tape, ctx->tape.p, sizeof(double) * (size_t)H * TS, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    return PILCO_OK;
+}
+
+}  // extern "C"

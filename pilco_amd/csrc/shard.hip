@@ -1,0 +1,128 @@
+// Multi-GPU: RCCL communicator, pair ownership / gather-buffer layout, host-mediated exchange (BASELINE config 3).
+#include "ctx.h"
+
+extern "C" {
+
+// ------------------------------------------------------------------ multi-GPU
+int pilco_comm_unique_id(void* id128) {
+    if (!id128) return PILCO_E_SHAPE;
+    static_assert(sizeof(ncclUniqueId) <= PILCO_COMM_ID_BYTES, "ncclUniqueId larger than the ABI slot");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return PILCO_E_RCCL;
+    memset(id128, 0, PILCO_COMM_ID_BYTES);
+    memcpy(id128, &id, sizeof(id));
+    return PILCO_OK;
+}
+
+int pilco_shard_set(pilco_ctx* ctx, int rank, int nranks) {
+    if (!ctx || nranks <= 0 || rank < 0 || rank >= nranks) return fail(ctx, PILCO_E_SHAPE, "shard_set: bad rank / nranks");
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    for (Slot& s : ctx->slot) s.wk_valid = false;
+    return PILCO_OK;
+}
+
+int pilco_comm_init(pilco_ctx* ctx, const void* id128, int rank, int nranks) {
+    if (!ctx || !id128) return PILCO_E_SHAPE;
+    if (int r = pilco_shard_set(ctx, rank, nranks)) return r;
+    HIPCHK(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&ctx->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        ctx->comm = nullptr;
+        return fail(ctx, PILCO_E_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    }
+    return PILCO_OK;
+}
+
+int pilco_shard_owner_of_pair(const pilco_ctx* ctx, int pair_index) {
+    if (!ctx) return -1;
+    const Slot& s = ctx->slot[0];
+    if (pair_index < 0 || pair_index >= (int)s.pair_owner.size()) return -1;
+    return s.pair_owner[pair_index];
+}
+
+// ---- pure host functions of the ownership / gather-buffer layout (no GPU needed)
+int pilco_shard_plan(int E, int D, int nranks, int rank, int* out5) {
+    if (E <= 0 || D <= 0 || nranks <= 0 || rank < 0 || rank >= nranks || !out5) return PILCO_E_SHAPE;
+    const int P = E * (E + 1) / 2;
+    const int PLcap = (P + nranks - 1) / nranks, ELcap = (E + nranks - 1) / nranks;
+    out5[0] = (rank < P) ? (P - rank + nranks - 1) / nranks : 0;  // local pairs
+    out5[1] = (rank < E) ? (E - rank + nranks - 1) / nranks : 0;  // owned outputs
+    out5[2] = PLcap + ELcap * (1 + D);                            // SEG: doubles per rank in the gather buffer
+    out5[3] = PLcap;                                              // OUTOFF: offset of the output records
+    out5[4] = P;
+    return PILCO_OK;
+}
+// index into the gathered buffer [nranks][SEG] of the value of pair (a,b), a >= b
+int pilco_shard_pair_slot(int E, int D, int nranks, int a, int b) {
+    if (a < b) { const int t = a; a = b; b = t; }
+    if (b < 0 || a >= E) return -1;
+    int plan[5];
+    if (pilco_shard_plan(E, D, nranks, 0, plan) != PILCO_OK) return -1;
+    const int kk = (a == b) ? a : E + a * (a - 1) / 2 + b;
+    return (kk % nranks) * plan[2] + kk / nranks;
+}
+// index of M_a in the gathered buffer (V_a[0..D) follows)
+int pilco_shard_output_slot(int E, int D, int nranks, int a) {
+    if (a < 0 || a >= E) return -1;
+    int plan[5];
+    if (pilco_shard_plan(E, D, nranks, 0, plan) != PILCO_OK) return -1;
+    return (a % nranks) * plan[2] + plan[3] + (a / nranks) * (1 + D);
+}
+
+// ---- host-mediated exchange: the caller moves the segments between the ranks
+int pilco_gp_shard_pack(pilco_ctx* ctx, int slot, const double* m, const double* s_in, double* segment) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "shard_pack: no current factorisation");
+    if (!m || !s_in || !segment) return fail(ctx, PILCO_E_SHAPE, "shard_pack: null pointer");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (int r = build_work(ctx, s)) return r;
+    const int D = s.D, E = s.E;
+    HIPCHK(hipMemcpyAsync(s.wk.in_m, m, sizeof(double) * D, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(s.wk.in_s, s_in, sizeof(double) * D * D, hipMemcpyHostToDevice, ctx->st));
+    const MMModel md = model_of(s);
+    if (s.wk.PL > 0) {
+        launch_mm_prep(ctx->st, md, s.wk);
+        launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
+    }
+    GlueArgs g{};
+    g.E = E; g.D = D; g.U = 0;
+    g.wk = s.wk;
+    g.var = s.var.p;
+    g.flags = GF_PACK;
+    launch_glue(ctx->st, g);
+    HIPCHK(hipMemcpyAsync(segment, s.wk.gath + (size_t)ctx->rank * s.wk.SEG, sizeof(double) * s.wk.SEG, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    return PILCO_OK;
+}
+
+int pilco_gp_shard_finish(pilco_ctx* ctx, int slot, const double* gathered, double* M, double* S, double* V) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.wk_valid) return fail(ctx, PILCO_E_STATE, "shard_finish before shard_pack");
+    if (!gathered || !M || !S || !V) return fail(ctx, PILCO_E_SHAPE, "shard_finish: null pointer");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int D = s.D, E = s.E;
+    HIPCHK(hipMemcpyAsync(s.wk.gath, gathered, sizeof(double) * (size_t)ctx->nranks * s.wk.SEG, hipMemcpyHostToDevice, ctx->st));
+    GlueArgs g{};
+    g.E = E; g.D = D; g.U = 0;
+    g.wk = s.wk;
+    g.var = s.var.p;
+    g.flags = GF_ASSEMBLE;
+    launch_glue(ctx->st, g);
+    HIPCHK(hipMemcpyAsync(M, s.wk.out_M, sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(S, s.wk.out_S, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(V, s.wk.out_V, sizeof(double) * D * E, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    return PILCO_OK;
+}
+
+int pilco_comm_rank(const pilco_ctx* ctx) { return ctx ? ctx->rank : -1; }
+int pilco_comm_size(const pilco_ctx* ctx) { return ctx ? ctx->nranks : -1; }
+
+}  // extern "C"
