@@ -30,6 +30,12 @@ if pair:
     p = kern[pair]
     out["pair_kernel"] = pair
     out["pair_kernel_hbm_bytes_per_launch"] = (2.0 * p.get("FETCH_SIZE", 0.0) + p.get("WRITE_SIZE", 0.0)) * 1024.0
+    if p.get("GRBM_GUI_ACTIVE"):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES and SQ_ACTIVE_INST_VALU (x4 cycles per
+        # wave64 instruction) are summed over the 1024 SIMDs
+        simd_cycles = p["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+        out["pair_kernel_mfma_busy_frac"] = p.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles
+        out["pair_kernel_valu_busy_frac"] = 4.0 * p.get("SQ_ACTIVE_INST_VALU", 0.0) / simd_cycles
     if "SQ_BUSY_CYCLES" in p and p.get("SQ_WAVE_CYCLES"):
         out["pair_kernel_valu_active_over_wave_cycles"] = p.get("SQ_ACTIVE_INST_VALU", 0.0) / p["SQ_WAVE_CYCLES"]
         out["pair_kernel_wait_inst_over_wave_cycles"] = p.get("SQ_WAIT_INST_ANY", 0.0) / p["SQ_WAVE_CYCLES"]
