@@ -185,11 +185,11 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
         return PILCO_E_HIP;
     }
     {
-        double tab[256];
         const int tn = mm_exp_table_size();
+        std::vector<double> tab(tn);
         for (int j = 0; j < tn; ++j) tab[j] = std::exp2((double)j / (double)tn);
-        if (ctx->exp_tab.ensure(256) != hipSuccess ||
-            hipMemcpy(ctx->exp_tab.p, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) {
+        if (ctx->exp_tab.ensure(tn) != hipSuccess ||
+            hipMemcpy(ctx->exp_tab.p, tab.data(), sizeof(double) * tn, hipMemcpyHostToDevice) != hipSuccess) {
             delete ctx;
             return PILCO_E_HIP;
         }

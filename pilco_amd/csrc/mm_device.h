@@ -73,13 +73,9 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 #define FEXP_TB 8    // log2 of the table size: 256 entries let the polynomial stop at degree 4 (|r| <= ln2/512)
 #endif
 #define FEXP_TN (1 << FEXP_TB)
-#if FEXP_TB == 6
-#define FEXP_C 92.332482616893656758       /* 64 / ln2 */
-#define FEXP_LN2_64 0.010830424696249145   /* ln2 / 64 */
-#else
-#define FEXP_C 369.3299304675746       /* 256 / ln2 */
-#define FEXP_LN2_64 0.0027076061740622863   /* ln2 / 256 */
-#endif
+#define FEXP_C ((double)FEXP_TN * 1.4426950408889634074)    /* T / ln2 (exact scaling of the rounded 1/ln2) */
+#define FEXP_LN2_64 (0.69314718055994530942 / (double)FEXP_TN)   /* ln2 / T */
+#define FEXP_DEG (FEXP_TB <= 6 ? 5 : FEXP_TB <= 10 ? 4 : 3)        /* polynomial degree: r^(deg+1)/(deg+1)! < 2^-54 */
 #define FEXP_MAGIC 6755399441055744.0      /* 1.5 * 2^52 */
 
 #ifndef PAIR_OPT
@@ -101,13 +97,17 @@ __device__ __forceinline__ double fexp_t(double x) { return fma(x, FEXP_C, FEXP_
 __device__ __forceinline__ double fexp_poly(double x, double t) {
     const double nf = t - FEXP_MAGIC;
     const double r = fma(nf, -FEXP_LN2_64, x);
-#if FEXP_TB == 6
-    double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
-    q = fma(r, q, 1.0 / 6.0);
-#else
-    double q = fma(r, 1.0 / 24.0, 1.0 / 6.0);
-#endif
-    q = fma(r, q, 0.5);
+    double q;
+    if (FEXP_DEG == 5) {
+        q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+        q = fma(r, q, 1.0 / 6.0);
+        q = fma(r, q, 0.5);
+    } else if (FEXP_DEG == 4) {
+        q = fma(r, 1.0 / 24.0, 1.0 / 6.0);
+        q = fma(r, q, 0.5);
+    } else {
+        q = fma(r, 1.0 / 6.0, 0.5);
+    }
     q = fma(r, q, 1.0);
     return r * q;
 }

@@ -139,17 +139,22 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
         double rr[NE];
 #pragma unroll
         for (int i = 0; i < NE; ++i) rr[i] = fma(tt[i] - FEXP_MAGIC, -FEXP_LN2_64, x[i]);
-#if FEXP_TB == 6
+        if (FEXP_DEG == 5) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], 1.0 / 120.0, 1.0 / 24.0);
+            for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], 1.0 / 120.0, 1.0 / 24.0);
 #pragma unroll
-        for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], pm[i], 1.0 / 6.0);
-#else
+            for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], pm[i], 1.0 / 6.0);
 #pragma unroll
-        for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], 1.0 / 24.0, 1.0 / 6.0);
-#endif
+            for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], pm[i], 0.5);
+        } else if (FEXP_DEG == 4) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], pm[i], 0.5);
+            for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], 1.0 / 24.0, 1.0 / 6.0);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], pm[i], 0.5);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], 1.0 / 6.0, 0.5);
+        }
 #pragma unroll
         for (int i = 0; i < NE; ++i) pm[i] = fma(rr[i], pm[i], 1.0);
 #pragma unroll
