@@ -18,6 +18,21 @@ namespace pilco {
 #ifndef BWD_RT
 #define BWD_RT 2
 #endif
+// sum_{q < n} base[q * stride] with the loads of a batch of B issued together (a plain loop serialises one global
+// latency per term: these kernels are latency-bound); fixed summation order
+template <int B>
+__device__ __forceinline__ double sum_strided(const double* __restrict__ base, long stride, int n) {
+    double acc = 0.0;
+    for (int q0 = 0; q0 < n; q0 += B) {
+        double v[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) v[u] = (q0 + u < n) ? base[(long)(q0 + u) * stride] : 0.0;
+#pragma unroll
+        for (int u = 0; u < B; ++u) acc += v[u];
+    }
+    return acc;
+}
+
 // Per-step constants of the reverse pass, computed once by spare workgroups of the k_mm_bwd_pair launch and read by
 // k_mm_bwd_post / k_mm_bwd_fin:   head[h][D*D + D + 2]
 //   output a (h = a):      T = (s + Lambda_a^2)^-1 | u = T Vbar_a | mu = Mbar_a - sum_b (Sbar_ab + Sbar_ba) M_b | c_a
@@ -228,7 +243,14 @@ __device__ void bwd_mean_partial(const MMModel& md, const MMWork& wk, const doub
             if (i < md.n) {
                 double quad = 0.0;
                 q = mu;
-                for (int d = 0; d < D; ++d) zs[t * LD + d] = md.Pt[(long)d * npad + i] - wk.in_m[d];
+                {
+                    double pv[16];   // D <= 14: all coordinates of the point in flight together
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) pv[d] = (d < D) ? md.Pt[(long)d * npad + i] : 0.0;
+#pragma unroll
+                    for (int d = 0; d < 16; ++d)
+                        if (d < D) zs[t * LD + d] = pv[d] - wk.in_m[d];
+                }
                 for (int r = 0; r < D; ++r) {
                     double tz = 0.0;
                     for (int c = 0; c < D; ++c) tz = fma(T[r * D + c], zs[t * LD + c], tz);
@@ -276,7 +298,7 @@ __device__ void bwd_mean_final(const MMModel& md, const double* __restrict__ bar
     for (int e = t; e < nI + D + 2; e += 256) (e < nI ? T[e] : u[e - nI]) = hd[e];
     if (t <= nI + 2 * D) {
         double acc = 0.0;
-        for (int c = 0; c < nrc; ++c) acc += mpart[((long)a * nrc + c) * (nI + 2 * D + 1) + t];   // fixed order
+        acc = sum_strided<16>(mpart + (long)a * nrc * (nI + 2 * D + 1) + t, nI + 2 * D + 1, nrc);   // fixed order
         red[t] = acc;
     }
     __syncthreads();
@@ -366,7 +388,7 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
             ws[ii * LD + d] = zeta * ib[d];
             double mv = 0.0;
             if (valid)
-                for (int q = 0; q < njs; ++q) mv += mom0[((long)q * 16 + d) * npad + i];
+                mv = sum_strided<4>(mom0 + (long)d * npad + i, (long)16 * npad, njs);
             ms[ii * LD + d] = mv;
         }
         if (t < 64) {
@@ -374,9 +396,9 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
             const bool valid = i < md.n;
             double r = 0.0, c = 0.0;
             if (valid) {
-                for (int q = 0; q < njs; ++q) r += mom0[((long)q * 16 + D) * npad + i];
+                r = sum_strided<4>(mom0 + (long)D * npad + i, (long)16 * npad, njs);
                 if (cp)
-                    for (int q = 0; q < nrb; ++q) c += cp[(long)q * npad + i];
+                    c = sum_strided<8>(cp + i, npad, nrb);
                 else
                     c = r;
             }
@@ -428,7 +450,7 @@ __global__ __launch_bounds__(256) void k_mm_bwd_fin(MMModel md, MMWork wk, const
     for (int e = t; e < nI + D + 2; e += 256) (e < nI ? Pm[e] : lam[e - nI]) = hd[e];
     for (int e = t; e < rec; e += 256) {
         double acc = 0.0;
-        for (int c = 0; c < nrc; ++c) acc += part[((long)pl * nrc + c) * rec + e];   // fixed order
+        acc = sum_strided<16>(part + (long)pl * nrc * rec + e, rec, nrc);   // fixed order
         Iv[e] = acc;
     }
     __syncthreads();
