@@ -35,6 +35,8 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
     for (int e = t; e < D * D; e += 512) s_s[e] = wk.in_s[e];
     for (int e = t; e < DT * DT; e += 512) s_T[e] = 0.0;
     __syncthreads();
+    const bool dbgm = (t == 0 && al == 0 && chm == 0);
+    DBG_STAMP(wk, 40, dbgm);
     const int rpc = npad / wk.NCHM;
     const int i_begin = chm * rpc, i_end = i_begin + rpc;
     if (w == 0) {
@@ -72,6 +74,7 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
         for (int r = idx; r < 512; r += 448) bst[r] = (i_begin + r < i_end) ? md.beta[(long)a * npad + i_begin + r] : 0.0;
     }
     __syncthreads();
+    DBG_STAMP(wk, 41, dbgm);
     double g = 0.0;
     double h[DT];
 #pragma unroll
@@ -102,6 +105,7 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
 #pragma unroll
         for (int d = 0; d < DT; ++d) h[d] = fma(zeta[d], lb, h[d]);
     }
+    DBG_STAMP(wk, 42, dbgm);
     g = wave_sum_lane63(g);
     if (lane == 63) red[w * (DT + 1)] = g;
 #pragma unroll
@@ -112,6 +116,7 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
     __syncthreads();
     // block sums of g and h (fixed order), then the M and V contributions of this row chunk:
     // c g (mgpr.py:117) and c T h (mgpr.py:118, V = c tiL^T lb = c T sum_i zeta_i lb_i)
+    DBG_STAMP(wk, 43, dbgm);
     double* hs = red + 8 * (DT + 1);  // [DT + 1]
     if (t < 1 + D) {
         double acc = 0.0;
@@ -131,6 +136,7 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
         }
         wk.mean_part[((long)al * wk.NCHM + chm) * (1 + D) + t] = v;   // indexed by the LOCAL output number
     }
+    DBG_STAMP(wk, 44, dbgm);
 }
 
 template <int DT>

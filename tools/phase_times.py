@@ -37,3 +37,6 @@ print("prep pair blocks :", rng([(x, y) for x in range(55) for y in range(NY)]))
 spare = [(55 + i // NY, i % NY) for i in range(24)]
 print("prep mean blocks :", rng(spare[:20]))
 print("prep reward block:", rng(spare[20:21]))
+if ts[40]:
+    print("mean block (output 0, chunk 0) rel. to prep block0 start: init-sync %.2f | gj+staging %.2f | rows %.2f | wave sums %.2f | final %.2f  (end %.2f us)" % (
+        us(0, 40), us(40, 41), us(41, 42), us(42, 43), us(43, 44), us(0, 44)))
