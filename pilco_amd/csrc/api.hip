@@ -36,6 +36,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.EL = (rank < E) ? (E - rank + W - 1) / W : 0;
     wk.P = P;
     wk.KP = mm_kp(D);
+    wk.vsep = mm_vsep(D) ? 1 : 0;
     mm_prep_chunks(npad, std::max(wk.PL, 1), wk.EL, &wk.NCH, &wk.NCHM);
     wk.NT = mm_pair_nt(npad, ctx->variant, std::max(wk.PL, 1));
     wk.OUTOFF = PLcap;
@@ -58,7 +59,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
                 if (pl * W + rank < E) ++nd;
         if (no_iK) tdiag = toff;
         const long T = (long)nd * tdiag + (long)(wk.PL - nd) * toff;
-        int waves = mm_pair_sk_capacity(wk.KP);
+        int waves = mm_pair_sk_capacity(wk.KP, wk.vsep != 0);
         if ((long)waves > T) waves = (int)std::max<long>(4, (T + 3) / 4 * 4);
         wk.sk_waves = waves;
         wk.sk_total = (int)T;
@@ -75,7 +76,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     }
     ENSURE(s.w_in, (size_t)D + D * D + E + E * E + D * E);   // m | s | cotangents (Mbar | Sbar | Vbar) of the reverse pass
     ENSURE(s.w_At, (size_t)PLa * wk.KP * npad);
-    ENSURE(s.w_Bt, (size_t)PLa * wk.KP * npad);
+    ENSURE(s.w_Bt, (size_t)PLa * wk.KP * npad + (size_t)PLa * npad);   // column operands, then v_j on its own (vsep)
     ENSURE(s.w_small, (size_t)PLa + (size_t)E * wk.NCHM * (1 + D));
     ENSURE(s.w_part, std::max((size_t)PLa * wk.NT * 2, (size_t)PLa * std::max(wk.sk_maxw, 4)));
     ENSURE(s.w_gath, (size_t)W * wk.SEG);
@@ -84,6 +85,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.in_s = s.w_in.p + D;
     wk.At = s.w_At.p;
     wk.Bt = s.w_Bt.p;
+    wk.vcol = s.w_Bt.p + (size_t)PLa * wk.KP * npad;
     wk.pair_isdet = s.w_small.p;
     wk.mean_part = wk.pair_isdet + PLa;
     wk.pair_part = s.w_part.p;

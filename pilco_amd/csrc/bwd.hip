@@ -94,7 +94,7 @@ __device__ void bwd_head(const MMModel& md, const MMWork& wk, const double* __re
     }
 }
 
-template <int KC>
+template <int KC, bool VSEP>
 __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ rowmom,
                                                     double* __restrict__ cpart, int njs, const double* __restrict__ bars,
                                                     double* __restrict__ head) {
@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
     }
     // buffer loads: uniform resource + per-lane byte offset + scalar column offset (no 64-bit VALU address math)
     const __amdgpu_buffer_rsrc_t rB = buf_rsrc(Bt), rbeta = buf_rsrc(beta_b);
+    const __amdgpu_buffer_rsrc_t rV = buf_rsrc(VSEP ? wk.vcol + (long)pl * npad : Bt);
     const __amdgpu_buffer_rsrc_t rIK = buf_rsrc(iKa ? iKa + (long)jbeg * npad : Bt);
     unsigned cf_off[KC], a2_off[4], bc_off[4], ik_off[BWD_RT][4];
 #pragma unroll
@@ -157,13 +158,14 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
     auto sweep = [&](auto mode_c) {
         constexpr int MODE = decltype(mode_c)::value;
         for (int j0 = jbeg; j0 < jend; j0 += 16) {
-            double cf[KC], a2[4], bcol[4];
+            double cf[KC], a2[4], bcol[4], vj[4];
             const unsigned so = (unsigned)j0 * 8u;
     #pragma unroll
             for (int c = 0; c < KC; ++c) cf[c] = buf_ld(rB, cf_off[c], so);
     #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 bcol[r] = buf_ld(rbeta, bc_off[r], so);
+                vj[r] = VSEP ? buf_ld(rV, bc_off[r], so) : 0.0;   // transposed tile: v_j runs along the result registers
                 a2[r] = buf_ld(rB, a2_off[r], so);
             }
             double csum[4] = {0.0, 0.0, 0.0, 0.0};
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
                 for (int r = 0; r < 4; ++r) {
                     double wgt = brow[rt] * bcol[r];
                     if (MODE == 1) wgt -= buf_ld(rIK, ik_off[rt][r], (unsigned)(j0 - jbeg) * (unsigned)npad * 8u);   // iK symmetric: coalesced along the rows
-                    wl[r] = wgt * fexp(e[r], tab);
+                    wl[r] = wgt * fexp(VSEP ? e[r] + vj[r] : e[r], tab);
                     csum[r] += wl[r];
                 }
     #pragma unroll
@@ -496,7 +498,13 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
     dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);   // the rows past P hold the head workgroups
     const int LD = D | 1, nI = D * D;
     const size_t lds_pair = sizeof(double) * std::max((size_t)4 * (md.npad / njs), (size_t)4 * nI + D);
-#define PB(K_) hipLaunchKernelGGL((k_mm_bwd_pair<K_>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head)
+#define PB(K_)                                                                                                       \
+    do {                                                                                                             \
+        if (wk.vsep)                                                                                                 \
+            hipLaunchKernelGGL((k_mm_bwd_pair<K_, true>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head);  \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_mm_bwd_pair<K_, false>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head); \
+    } while (0)
     switch (wk.KP / 4) {
         case 1: PB(1); break;
         case 2: PB(2); break;

@@ -23,6 +23,8 @@ struct MMWork {
     double* in_s;        // [D][D]   input covariance
     double* At;          // [PL][KP][npad]  row-side operand   (2 Q z_i | u_i | 1 | 0..)
     double* Bt;          // [PL][KP][npad]  column-side operand (w_j   | 1 | v_j | 0..)
+    double* vcol;        // [PL][npad]  v_j on its own when vsep (D + 2 = 1 mod 4: K = D + 1 contraction, v_j added on the VALU)
+    int vsep;
     double* pair_isdet;  // [PL]     1/sqrt(det R_ab)
     double* mean_part;   // [EL][NCHM][1+D]  per row chunk: c_a g and c_a T_a h (contributions to M_a, V_a)
     double* pair_part;   // [PL][NT][2]
@@ -109,7 +111,7 @@ void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const P
 // variant 0 = MFMA stream-K, 1 = VALU (tiled), 2 = MFMA tiled (bits independent of the rank count)
 void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int variant);
 // stream-K geometry: resident waves of the MFMA pair kernel for this KP, and the per-pair step counts
-int mm_pair_sk_capacity(int KP);
+int mm_pair_sk_capacity(int KP, bool vsep);
 void mm_pair_sk_steps(int npad, int* tdiag, int* toff);
 int mm_sk_boundary(int w, int waves, int nd_steps, int total, int ud, int uo);
 int mm_sk_maxw(const MMWork& wk);   // needs the sk_* geometry fields and PL
@@ -119,6 +121,7 @@ size_t glue_lds_bytes(int E, int D);
 int mm_pair_nt(int npad, int variant, int PL);
 void mm_prep_chunks(int npad, int PL, int EL, int* nch, int* nchm);
 int mm_kp(int D);
+bool mm_vsep(int D);   // the contraction stops at K = D + 1 and v_j is added after it (saves a whole MFMA k-step)
 void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot);
 // reverse pass of one moment-matching step (single rank, D <= 14; the step's prep kernel must precede it on st):
 // scratch: rowmom [P][njs][16][npad], cpart [P - E][nrb][npad] (njs, nrb from mm_bwd_geometry) and

@@ -55,8 +55,9 @@ namespace pilco {
 #ifndef PAIR_MINW
 #define PAIR_MINW 1    // __launch_bounds__ min waves per SIMD for the pair kernel
 #endif
-template <int KC, bool DIAG>
+template <int KC, bool DIAG, bool VSEP>
 __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const double* __restrict__ Bt,
+                                            const double* __restrict__ vcol,
                                             const double* __restrict__ beta_a, const double* __restrict__ beta_b,
                                             const double* __restrict__ iKa, const double* __restrict__ tab, int npad, int i0,
                                             int jbeg, int jend, int lane) {
@@ -83,28 +84,31 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
     for (int c = 0; c < KC; ++c) b_off[c] = ((unsigned)(4 * c + lr) * (unsigned)npad + (unsigned)lc) * 8u;
     const unsigned bb_off = (unsigned)lc * 8u;
     const __amdgpu_buffer_rsrc_t rB = buf_rsrc(Bt), rbeta = buf_rsrc(beta_b);
+    const __amdgpu_buffer_rsrc_t rV = buf_rsrc(VSEP ? vcol : Bt);
     const __amdgpu_buffer_rsrc_t rIK = buf_rsrc(DIAG ? iKa + (long)i0 * npad : Bt);
     if (DIAG && jbeg < i0) jbeg = i0;  // columns left of the diagonal block are mirrored by the transposed tile
     double total = 0.0;
     // software pipeline: the operands of the column step two ahead are requested while this one is
     // evaluated (a first touch of Bt / beta misses the XCD's L2: ~2 us, more than one step)
-    double ring[2][KC + 1];
+    double ring[2][KC + 2];   // column operand fragments, beta_b,j and (VSEP) v_j
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
-        for (int c = 0; c <= KC; ++c) ring[p][c] = 0.0;
+        for (int c = 0; c <= KC + 1; ++c) ring[p][c] = 0.0;
         if (jbeg + 16 * p < jend) {
 #pragma unroll
             for (int c = 0; c < KC; ++c) ring[p][c] = buf_ld(rB, b_off[c], (unsigned)(jbeg + 16 * p) * 8u);
             ring[p][KC] = buf_ld(rbeta, bb_off, (unsigned)(jbeg + 16 * p) * 8u);
+            if (VSEP) ring[p][KC + 1] = buf_ld(rV, bb_off, (unsigned)(jbeg + 16 * p) * 8u);
         }
     }
     // one 16-column step on ring slot rg; the slot is refilled with the operands of column step j0 + 32
-    auto step = [&](double (&rg)[KC + 1], const int j0) {
+    auto step = [&](double (&rg)[KC + 2], const int j0) {
         double bf[KC];
 #pragma unroll
         for (int c = 0; c < KC; ++c) bf[c] = rg[c];
         const double bb = rg[KC];
+        const double vv = rg[KC + 1];
         double ik[NE];
         if (DIAG) {
 #pragma unroll
@@ -118,12 +122,13 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
 #pragma unroll
             for (int c = 0; c < KC; ++c) e = PAIR_ABL_MFMA(af[rt][c], bf[c], e);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[4 * rt + r] = e[r];
+            for (int r = 0; r < 4; ++r) x[4 * rt + r] = VSEP ? e[r] + vv : e[r];   // C/D column = lane & 15: one v_j per lane
         }
         if (PAIR_ABL != 4 && j0 + 32 < jend) {
 #pragma unroll
             for (int c = 0; c < KC; ++c) rg[c] = buf_ld(rB, b_off[c], (unsigned)(j0 + 32) * 8u);
             rg[KC] = buf_ld(rbeta, bb_off, (unsigned)(j0 + 32) * 8u);
+            if (VSEP) rg[KC + 1] = buf_ld(rV, bb_off, (unsigned)(j0 + 32) * 8u);
         }
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
@@ -190,7 +195,7 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
     return total;
 }
 
-template <int KC>
+template <int KC, bool VSEP>
 __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_tiled(MMModel md, MMWork wk, int NJB) {
     __shared__ double red[4];
     __shared__ double tab[FEXP_TN];
@@ -212,9 +217,9 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_tiled(MMModel md, MM
     const int jbeg = jb * JB + w * JW;
     double t1;
     if (diag)
-        t1 = pair_wave<KC, true>(At, Bt, beta_a, beta_b, md.iK + (long)a * npad * npad, tab, npad, i0, jbeg, jbeg + JW, lane);
+        t1 = pair_wave<KC, true, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, md.iK + (long)a * npad * npad, tab, npad, i0, jbeg, jbeg + JW, lane);
     else
-        t1 = pair_wave<KC, false>(At, Bt, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jbeg + JW, lane);
+        t1 = pair_wave<KC, false, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jbeg + JW, lane);
     for (int off = 32; off > 0; off >>= 1) t1 += __shfl_down(t1, off);
     if (lane == 0) red[w] = t1;
     __syncthreads();
@@ -283,7 +288,7 @@ int mm_sk_boundary(int w, int waves, int nd_steps, int total, int ud, int uo) {
     return sk_boundary_of(w, waves, nd_steps, total, ud, uo);
 }
 
-template <int KC>
+template <int KC, bool VSEP>
 __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWork wk) {
     __shared__ double tab[FEXP_TN];
     for (int e = threadIdx.x; e < FEXP_TN; e += blockDim.x) tab[e] = wk.exp_tab[e];
@@ -343,9 +348,9 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
         const double* beta_b = md.beta + (long)b * npad;
         const int i0 = ti * 16 * PAIR_RT, jbeg = sidx * 16, jend = jbeg + seg * 16;
         if (dg)
-            cur += pair_wave<KC, true>(At, Bt, beta_a, beta_b, md.iK + (long)a * npad * npad, tab, npad, i0, jbeg, jend, lane);
+            cur += pair_wave<KC, true, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, md.iK + (long)a * npad * npad, tab, npad, i0, jbeg, jend, lane);
         else
-            cur += pair_wave<KC, false>(At, Bt, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jend, lane);
+            cur += pair_wave<KC, false, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jend, lane);
         step += seg;
     }
     if (cur_pl >= 0) {
@@ -385,6 +390,7 @@ template <int KPT>
 __global__ __launch_bounds__(256) void k_mm_pair_valu(MMModel md, MMWork wk) {
     __shared__ double Bs[KPT][64];
     __shared__ double bbs[64];
+    __shared__ double vs[64];
     __shared__ double red[8];
     const int npad = md.npad;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -406,13 +412,16 @@ __global__ __launch_bounds__(256) void k_mm_pair_valu(MMModel md, MMWork wk) {
         const int k = e >> 6, j = e & 63;
         Bs[k][j] = (k < KP) ? Bt[(long)k * npad + j0 + j] : 0.0;
     }
-    if (t < 64) bbs[t] = md.beta[(long)b * npad + j0 + t];
+    if (t < 64) {
+        bbs[t] = md.beta[(long)b * npad + j0 + t];
+        vs[t] = wk.vsep ? wk.vcol[(long)pl * npad + j0 + t] : 0.0;
+    }
     __syncthreads();
     double s1 = 0.0, s2 = 0.0;
     if (rowok) {
         const double* iKrow = diag ? md.iK + ((long)a * npad + i) * npad + j0 : nullptr;
         for (int j = 0; j < 64; ++j) {
-            double e = 0.0;
+            double e = vs[j];
 #pragma unroll
             for (int k = 0; k < KPT; ++k) e = fma(av[k], Bs[k][j], e);
             const double L = exp(e);
@@ -466,29 +475,29 @@ void mm_pair_sk_steps(int npad, int* tdiag, int* toff) {
     *tdiag = NTI * NS - PAIR_RT * NTI * (NTI - 1) / 2;
 }
 
-template <int KC>
+template <int KC, bool VSEP>
 static int sk_capacity_of() {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mm_pair_sk<KC>, 256, 0) != hipSuccess || nb <= 0) nb = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mm_pair_sk<KC, VSEP>, 256, 0) != hipSuccess || nb <= 0) nb = 2;
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     return nb * cus * 4;
 }
 
-int mm_pair_sk_capacity(int KP) {
+int mm_pair_sk_capacity(int KP, bool vsep) {
     const char* env = getenv("PILCO_SK_WAVES");
     if (env && atoi(env) >= 4) return atoi(env) / 4 * 4;
     switch (KP / 4) {
-        case 1: return sk_capacity_of<1>();
-        case 2: return sk_capacity_of<2>();
-        case 3: return sk_capacity_of<3>();
-        case 4: return sk_capacity_of<4>();
-        case 5: return sk_capacity_of<5>();
-        case 6: return sk_capacity_of<6>();
-        case 7: return sk_capacity_of<7>();
-        case 8: return sk_capacity_of<8>();
-        default: return sk_capacity_of<9>();
+        case 1: return vsep ? sk_capacity_of<1, true>() : sk_capacity_of<1, false>();
+        case 2: return vsep ? sk_capacity_of<2, true>() : sk_capacity_of<2, false>();
+        case 3: return vsep ? sk_capacity_of<3, true>() : sk_capacity_of<3, false>();
+        case 4: return vsep ? sk_capacity_of<4, true>() : sk_capacity_of<4, false>();
+        case 5: return vsep ? sk_capacity_of<5, true>() : sk_capacity_of<5, false>();
+        case 6: return vsep ? sk_capacity_of<6, true>() : sk_capacity_of<6, false>();
+        case 7: return vsep ? sk_capacity_of<7, true>() : sk_capacity_of<7, false>();
+        case 8: return vsep ? sk_capacity_of<8, true>() : sk_capacity_of<8, false>();
+        default: return vsep ? sk_capacity_of<9, true>() : sk_capacity_of<9, false>();
     }
 }
 
@@ -509,7 +518,11 @@ void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int var
     if (variant == 2) {
         const int NJB = wk.NT / (md.npad / (16 * PAIR_RT));
         dim3 grid((md.npad / (16 * PAIR_RT)) * NJB, wk.PL);
-#define PM(K_) hipLaunchKernelGGL((k_mm_pair_tiled<K_>), grid, dim3(256), 0, st, md, wk, NJB)
+#define PM(K_)                                                                                        \
+    do {                                                                                              \
+        if (wk.vsep) hipLaunchKernelGGL((k_mm_pair_tiled<K_, true>), grid, dim3(256), 0, st, md, wk, NJB);  \
+        else hipLaunchKernelGGL((k_mm_pair_tiled<K_, false>), grid, dim3(256), 0, st, md, wk, NJB);         \
+    } while (0)
         switch (KP / 4) {
             case 1: PM(1); break;
             case 2: PM(2); break;
@@ -525,7 +538,11 @@ void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int var
         return;
     }
     dim3 grid(wk.sk_waves / 4);
-#define PS(K_) hipLaunchKernelGGL((k_mm_pair_sk<K_>), grid, dim3(256), 0, st, md, wk)
+#define PS(K_)                                                                                 \
+    do {                                                                                       \
+        if (wk.vsep) hipLaunchKernelGGL((k_mm_pair_sk<K_, true>), grid, dim3(256), 0, st, md, wk);   \
+        else hipLaunchKernelGGL((k_mm_pair_sk<K_, false>), grid, dim3(256), 0, st, md, wk);          \
+    } while (0)
     switch (KP / 4) {
         case 1: PS(1); break;
         case 2: PS(2); break;

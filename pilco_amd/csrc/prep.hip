@@ -283,14 +283,15 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
             for (int r = 0; r < DT; ++r)
                 if (r < D) store_wt(&At[(long)r * npad + i], 2.0 * y[r]);   // 2 Q z_i (0 on padded rows)
             store_wt(&At[(long)D * npad + i], uv);                           // u_i
-            store_wt(&At[(long)(D + 1) * npad + i], one);
+            if (!wk.vsep) store_wt(&At[(long)(D + 1) * npad + i], one);
             for (int k = D + 2; k < KP; ++k) store_wt(&At[(long)k * npad + i], 0.0);
         } else {
 #pragma unroll
             for (int r = 0; r < DT; ++r)
                 if (r < D) store_wt(&Bt[(long)r * npad + i], x[r]);         // w_j
             store_wt(&Bt[(long)D * npad + i], one);
-            store_wt(&Bt[(long)(D + 1) * npad + i], uv);                     // v_j
+            if (wk.vsep) store_wt(&wk.vcol[(long)pl * npad + i], uv);        // v_j, added after the K = D + 1 contraction
+            else store_wt(&Bt[(long)(D + 1) * npad + i], uv);                // v_j, riding in the contraction
             for (int k = D + 2; k < KP; ++k) store_wt(&Bt[(long)k * npad + i], 0.0);
         }
     };
@@ -321,7 +322,8 @@ size_t prep_lds_bytes(int DT) {
     return sizeof(double) * std::max(pair_blk, mean_blk);
 }
 
-int mm_kp(int D) { return round_up(D + 2, 4); }
+bool mm_vsep(int D) { return (D + 2) % 4 == 1; }
+int mm_kp(int D) { return mm_vsep(D) ? D + 1 : round_up(D + 2, 4); }
 
 static int device_cus() {
     int cus = 256;
