@@ -167,6 +167,12 @@ int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_
 int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32);
 /* per-workgroup (start, end) stamps of the last prep launch, n values (developer aid) */
 int pilco_debug_blocks(pilco_ctx* ctx, unsigned long long* out, int n);
+/* Stream-K work split of the pair kernel (pure host functions, no GPU): the column steps of nd diagonal pairs (tdiag
+ * steps each, cost ud) and n_pairs - nd off-diagonal pairs (toff steps, cost uo) lie on one line cut into `waves` equal
+ * cost ranges.  pilco_debug_sk_boundary: first step of wave w (w = waves: the total).  pilco_debug_sk_pair_waves:
+ * out3 = (first wave holding a partial of pair k, slot of the pair in that wave (0/1), last such wave). */
+int pilco_debug_sk_boundary(int w, int waves, int nd, int tdiag, int toff, int ud, int uo, int n_pairs);
+int pilco_debug_sk_pair_waves(int k, int waves, int nd, int tdiag, int toff, int ud, int uo, int n_pairs, int* out3);
 /* Time `reps` factorisations (invalidating the cache each time): ms per factorisation. */
 int pilco_factorize_timed(pilco_ctx* ctx, int slot, int reps, float* ms_each);
 

@@ -114,7 +114,8 @@ void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int var
 int mm_pair_sk_capacity(int KP, bool vsep);
 void mm_pair_sk_steps(int npad, int* tdiag, int* toff);
 int mm_sk_boundary(int w, int waves, int nd_steps, int total, int ud, int uo);
-int mm_sk_maxw(const MMWork& wk);   // needs the sk_* geometry fields and PL
+int mm_sk_maxw(const MMWork& wk);
+void mm_sk_pair_waves(int k, int waves, int nd, int tdiag, int toff, int total, int ud, int uo, int* wlo, int* fslot, int* whi);   // needs the sk_* geometry fields and PL
 void launch_glue(hipStream_t st, const GlueArgs& g, bool with_reward_block = false);
 size_t glue_lds_bytes(int E, int D);
 // tile-partial counts per pair for a variant (NT) and the number of row chunks of the prep kernel

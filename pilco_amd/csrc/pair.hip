@@ -287,6 +287,9 @@ int mm_sk_maxw(const MMWork& wk) {
 int mm_sk_boundary(int w, int waves, int nd_steps, int total, int ud, int uo) {
     return sk_boundary_of(w, waves, nd_steps, total, ud, uo);
 }
+void mm_sk_pair_waves(int k, int waves, int nd, int tdiag, int toff, int total, int ud, int uo, int* wlo, int* fslot, int* whi) {
+    sk_pair_waves(k, waves, nd, tdiag, toff, total, ud, uo, *wlo, *fslot, *whi);
+}
 
 template <int KC, bool VSEP>
 __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWork wk) {

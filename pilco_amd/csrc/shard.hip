@@ -43,6 +43,19 @@ int pilco_shard_owner_of_pair(const pilco_ctx* ctx, int pair_index) {
     return s.pair_owner[pair_index];
 }
 
+// ---- pure host functions of the stream-K work split (no GPU needed): first step of wave w, and the waves holding the
+// partials of local pair k (first wave, slot of the pair in it, last wave) -- the closed forms the pair kernel uses
+int pilco_debug_sk_boundary(int w, int waves, int nd, int tdiag, int toff, int ud, int uo, int n_pairs) {
+    if (waves <= 0 || nd < 0 || n_pairs < nd || tdiag <= 0 || toff <= 0 || ud <= 0 || uo <= 0) return -1;
+    return mm_sk_boundary(w, waves, nd * tdiag, nd * tdiag + (n_pairs - nd) * toff, ud, uo);
+}
+int pilco_debug_sk_pair_waves(int k, int waves, int nd, int tdiag, int toff, int ud, int uo, int n_pairs, int* out3) {
+    if (!out3 || waves <= 0 || nd < 0 || n_pairs < nd || k < 0 || k >= n_pairs || tdiag <= 0 || toff <= 0 || ud <= 0 || uo <= 0)
+        return PILCO_E_SHAPE;
+    mm_sk_pair_waves(k, waves, nd, tdiag, toff, nd * tdiag + (n_pairs - nd) * toff, ud, uo, &out3[0], &out3[1], &out3[2]);
+    return PILCO_OK;
+}
+
 // ---- pure host functions of the ownership / gather-buffer layout (no GPU needed)
 int pilco_shard_plan(int E, int D, int nranks, int rank, int* out5) {
     if (E <= 0 || D <= 0 || nranks <= 0 || rank < 0 || rank >= nranks || !out5) return PILCO_E_SHAPE;

@@ -143,3 +143,32 @@ def test_gloo_world_size_2_exchange():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_stream_k_closed_forms_match_enumeration():
+    """The pair kernel's stream-K split (pair.hip: sk_boundary_of / sk_wave_of / sk_pair_waves) is closed form on both the
+    writer (pair kernel) and reader (glue kernel) side; check it against a brute-force enumeration of the wave ranges."""
+    import ctypes as C
+    from pilco_amd import _lib
+    lib = _lib.load_library()
+    rs = np.random.RandomState(0)
+    for _ in range(60):
+        nd, noff = int(rs.randint(0, 7)), int(rs.randint(0, 30))
+        if nd + noff == 0:
+            continue
+        tdiag, toff = int(rs.randint(3, 300)), int(rs.randint(3, 400))
+        ud, uo = int(rs.randint(1, 6)), int(rs.randint(1, 6))
+        total = nd * tdiag + noff * toff
+        waves = int(rs.randint(1, max(2, total // 2)))
+        n_pairs = nd + noff
+        bnd = [lib.pilco_debug_sk_boundary(w, waves, nd, tdiag, toff, ud, uo, n_pairs) for w in range(waves + 1)]
+        assert bnd[0] == 0 and bnd[-1] == total and all(b1 >= b0 for b0, b1 in zip(bnd, bnd[1:]))
+        out = (C.c_int * 3)()
+        for k in range(n_pairs):
+            S0 = k * tdiag if k < nd else nd * tdiag + (k - nd) * toff
+            S1 = S0 + (tdiag if k < nd else toff)
+            touching = [w for w in range(waves) if bnd[w] < S1 and bnd[w + 1] > S0]   # non-empty ranges meeting the pair
+            assert lib.pilco_debug_sk_pair_waves(k, waves, nd, tdiag, toff, ud, uo, n_pairs, out) == 0
+            wlo, fslot, whi = out[0], out[1], out[2]
+            assert wlo == touching[0] and whi == touching[-1]
+            assert fslot == (1 if bnd[wlo] < S0 else 0)   # a wave that starts before the pair holds it in its second slot
