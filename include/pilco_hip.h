@@ -150,10 +150,15 @@ int pilco_rollout_tape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_r
 /* Value and gradient of the rollout reward w.r.t. a squashed LinearController's parameters, dW (U,E) and db (U):
  * training_loss + TensorFlow reverse mode in the reference (pilco/models/pilco.py:47-50,85-90).  Forward rollout
  * with a tape, then the reverse sweep with the moment-matching adjoint of every step on the device and the O(D^3)
- * links (propagate, joint Gaussian, controller + squash, rewards) in native host code.  Other policies: drive
- * pilco_rollout_tape + pilco_gp_predict_vjp from the caller (pilco_amd/adjoint.py does for the RBF policy). */
+ * links (propagate, joint Gaussian, controller + squash, rewards) in native host code. */
 int pilco_rollout_grad(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
                        const double* m0, const double* S0, int H, double* reward, double* dW, double* db);
+/* The same for an RbfController (policy GP in PILCO_SLOT_POLICY, pilco/controllers.py:80-129): gradients w.r.t. the
+ * centres dX (bf,E), the targets dY (bf,U) and the lengthscales dls (U,E).  Xp, Yp, lsp, noisep (U): host copies of the
+ * policy parameters that were uploaded with pilco_gp_set_data / pilco_gp_set_hyp (noise = FakeGPR likelihood variance). */
+int pilco_rollout_grad_rbf(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                           const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
+                           const double* noisep, int bf, double* reward, double* dX, double* dY, double* dls);
 
 /* ------------------------------------------------------------------ timing / introspection */
 /* Time `reps` back-to-back rollouts with HIP events on the library's stream.

@@ -71,6 +71,8 @@ SIGNATURES = {
                                      _dp, _dp, _dp, _dp, _dp]),
     "pilco_rollout_grad": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
                                      _dp, _dp, _dp]),
+    "pilco_rollout_grad_rbf": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
+                                         _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]),
     "pilco_propagate": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp]),
     "pilco_policy_action": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp, _dp]),
     "pilco_reward_eval": (C.c_int, [_vp, C.POINTER(RewardTerm), C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
@@ -315,6 +317,20 @@ class Context:
         self._chk(self.lib.pilco_rollout_grad(self.h, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H),
                                               _ptr(rew), _ptr(dW), _ptr(db)))
         return float(rew[0, 0]), dW, db
+
+    def rollout_grad_rbf(self, policy, rewards, m0, S0, H, Xp, Yp, lsp, noisep):
+        """(reward, dX (bf,E), dY (bf,U), dls (U,E)) for an RBF policy: the native reverse sweep (pilco_rollout_grad_rbf)."""
+        E = policy["state_dim"]; U = policy["control_dim"]
+        p, k1 = self._policy(policy)
+        r, k2 = self._rewards(rewards, E)
+        m0 = _f64(m0, (E,)); S0 = _f64(S0, (E, E))
+        Xp = _f64(Xp); bf = Xp.shape[0]
+        Xp = _f64(Xp, (bf, E)); Yp = _f64(Yp, (bf, U)); lsp = _f64(lsp, (U, E)); noisep = _f64(noisep, (U,))
+        rew = np.zeros((1, 1)); dX = np.empty((bf, E)); dY = np.empty((bf, U)); dls = np.empty((U, E))
+        self._chk(self.lib.pilco_rollout_grad_rbf(self.h, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H),
+                                                  _ptr(Xp), _ptr(Yp), _ptr(lsp), _ptr(noisep), bf,
+                                                  _ptr(rew), _ptr(dX), _ptr(dY), _ptr(dls)))
+        return float(rew[0, 0]), dX, dY, dls
 
     def propagate(self, policy, m_x, s_x):
         E = policy["state_dim"]

@@ -202,18 +202,22 @@ def reward_grad(terms, m, S):
 
 def rollout_value_and_grad(pilco, native=True):
     """(reward, grads): grads = (dW, db) for a LinearController, (dX, dY, dlengthscales) for an RbfController.
-    The linear controller goes through the library's native sweep (pilco_rollout_grad); ``native=False`` runs the same
-    sweep from here (the RBF policy always does: its O(bf^2) policy adjoint lives in this module)."""
+    Both go through the library's native sweeps (pilco_rollout_grad / pilco_rollout_grad_rbf); ``native=False`` runs the
+    same sweep from here in NumPy (the derivation prototype, checked against autograd on the CPU)."""
     from .controllers import LinearController, RbfController
     ctl, rew = pilco.controller, pilco.reward
     linear = isinstance(ctl, LinearController)
     if not linear and not isinstance(ctl, RbfController):
         raise TypeError("analytic policy gradient: LinearController or RbfController")
-    if linear and native:
+    if native:
         pilco.mgpr._user_factors = None
         pilco.mgpr._ensure_factorized()
-        r, dW, db = pilco.ctx.rollout_grad(pilco._policy_spec(), rew.terms(), pilco.m_init, pilco.S_init, pilco.horizon)
-        return r, (dW.reshape(ctl.W.shape), db.reshape(ctl.b.shape))
+        if linear:
+            r, dW, db = pilco.ctx.rollout_grad(pilco._policy_spec(), rew.terms(), pilco.m_init, pilco.S_init, pilco.horizon)
+            return r, (dW.reshape(ctl.W.shape), db.reshape(ctl.b.shape))
+        r, dX, dY, dl = pilco.ctx.rollout_grad_rbf(pilco._policy_spec(), rew.terms(), pilco.m_init, pilco.S_init, pilco.horizon,
+                                                   ctl.X, ctl.Y, ctl.lengthscales, ctl.noise)
+        return r, (dX, dY, dl)
     E, U, H = pilco.state_dim, pilco.control_dim, pilco.horizon
     D = E + U
     e = np.broadcast_to(np.asarray(ctl.max_action, np.float64).reshape(-1), (U,)).copy()

@@ -203,37 +203,404 @@ bool reward_grad(const pilco_reward_term* rw, int n_rw, int E, const double* m, 
     return true;
 }
 
-}  // namespace
+// ---- small dense matrices for the host side of the reverse sweep
+struct Mat {
+    int r = 0, c = 0;
+    vec d;
+    Mat() {}
+    Mat(int r_, int c_) : r(r_), c(c_), d((size_t)r_ * c_, 0.0) {}
+    double& operator()(int i, int j) { return d[(size_t)i * c + j]; }
+    double operator()(int i, int j) const { return d[(size_t)i * c + j]; }
+};
+Mat mm(const Mat& A, const Mat& B) {        // A B
+    Mat C(A.r, B.c);
+    for (int i = 0; i < A.r; ++i)
+        for (int k = 0; k < A.c; ++k) {
+            const double a = A(i, k);
+            for (int j = 0; j < B.c; ++j) C(i, j) += a * B(k, j);
+        }
+    return C;
+}
+Mat mmT(const Mat& A, const Mat& B) {       // A B^T
+    Mat C(A.r, B.r);
+    for (int i = 0; i < A.r; ++i)
+        for (int j = 0; j < B.r; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < A.c; ++k) acc += A(i, k) * B(j, k);
+            C(i, j) = acc;
+        }
+    return C;
+}
+Mat Tmm(const Mat& A, const Mat& B) {       // A^T B
+    Mat C(A.c, B.c);
+    for (int k = 0; k < A.r; ++k)
+        for (int i = 0; i < A.c; ++i) {
+            const double a = A(k, i);
+            for (int j = 0; j < B.c; ++j) C(i, j) += a * B(k, j);
+        }
+    return C;
+}
 
-extern "C" {
+// Adjoint of a policy inside the sweep: fwd gives the pre-squash action moments (mu0 (U), su0 (U,U), V0 (E,U)) at
+// (m_x, s_x); vjp takes their cotangents, accumulates the parameter gradients and returns the cotangents of (m_x, s_x).
+struct PolicyAdj {
+    virtual ~PolicyAdj() {}
+    virtual bool fwd(const double* m_x, const double* s_x, vec& mu0, vec& su0, vec& V0) = 0;
+    virtual void vjp(const double* m_x, const double* s_x, const vec& mu0b, const vec& su0b, const vec& V0b, vec& mxb, vec& sxb) = 0;
+};
 
-// Value and gradient of the rollout reward w.r.t. a LinearController's (W, b): what TensorFlow's reverse mode through
-// the tf.while_loop gives the reference (pilco/models/pilco.py:85-90,126-135).  Forward rollout with a tape on the
-// device, then the reverse sweep: the O(N^2) adjoint of every moment-matching step on the device
-// (pilco_gp_predict_vjp), the O(D^3) links (propagate pilco.py:147-149, joint Gaussian :141-144, controller + squash
-// controllers.py:13-58, rewards rewards.py:19-81) here on the host in C++.  dW (U,E), db (U).
-int pilco_rollout_grad(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
-                       const double* m0, const double* S0, int H, double* reward, double* dW, double* db) {
-    if (!ctx) return PILCO_E_SHAPE;
-    if (!policy || !m0 || !S0 || !reward || !dW || !db || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout_grad: bad arguments");
-    if (policy->kind != PILCO_POLICY_LINEAR || !policy->squash || policy->control_dim <= 0)
-        return fail(ctx, PILCO_E_SHAPE, "rollout_grad: squashed LinearController only (other policies: pilco_rollout_tape + pilco_gp_predict_vjp)");
-    for (int k = 0; k < n_rewards; ++k)
-        if (rewards[k].kind != PILCO_REWARD_EXPONENTIAL && rewards[k].kind != PILCO_REWARD_LINEAR)
-            return fail(ctx, PILCO_E_SHAPE, "rollout_grad: unknown reward term");
+// LinearController (controllers.py:46-58): mu0 = W m + b, su0 = W s W^T, V0 = W^T
+struct LinearAdj : PolicyAdj {
+    int E, U;
+    const double* W;
+    const double* b;
+    vec Wbar, bbar;
+    LinearAdj(int E_, int U_, const double* W_, const double* b_) : E(E_), U(U_), W(W_), b(b_), Wbar((size_t)U_ * E_, 0.0), bbar(U_, 0.0) {}
+    bool fwd(const double* m_x, const double* s_x, vec& mu0, vec& su0, vec& V0) override {
+        vec WS((size_t)U * E);
+        for (int u = 0; u < U; ++u) {
+            double acc = b[u];
+            for (int i = 0; i < E; ++i) acc += W[(size_t)u * E + i] * m_x[i];
+            mu0[u] = acc;
+            for (int j = 0; j < E; ++j) {
+                double a2 = 0.0;
+                for (int i = 0; i < E; ++i) a2 += W[(size_t)u * E + i] * s_x[(size_t)i * E + j];
+                WS[(size_t)u * E + j] = a2;
+            }
+        }
+        for (int u = 0; u < U; ++u)
+            for (int v = 0; v < U; ++v) {
+                double acc = 0.0;
+                for (int j = 0; j < E; ++j) acc += WS[(size_t)u * E + j] * W[(size_t)v * E + j];
+                su0[(size_t)u * U + v] = acc;
+            }
+        for (int i = 0; i < E; ++i)
+            for (int u = 0; u < U; ++u) V0[(size_t)i * U + u] = W[(size_t)u * E + i];
+        return true;
+    }
+    void vjp(const double* m_x, const double* s_x, const vec& mu0b, const vec& su0b, const vec& V0b, vec& mxb, vec& sxb) override {
+        // Wbar += V0b^T + mu0b m_x^T + su0b W s_x^T + su0b^T W s_x
+        vec T1((size_t)U * E), T2((size_t)U * E);
+        for (int u = 0; u < U; ++u)
+            for (int j = 0; j < E; ++j) {
+                double a1 = 0.0, a2 = 0.0;
+                for (int i = 0; i < E; ++i) {
+                    a1 += W[(size_t)u * E + i] * s_x[(size_t)j * E + i];     // (W s_x^T)[u][j]
+                    a2 += W[(size_t)u * E + i] * s_x[(size_t)i * E + j];     // (W s_x)[u][j]
+                }
+                T1[(size_t)u * E + j] = a1;
+                T2[(size_t)u * E + j] = a2;
+            }
+        for (int u = 0; u < U; ++u) {
+            bbar[u] += mu0b[u];
+            for (int j = 0; j < E; ++j) {
+                double acc = V0b[(size_t)j * U + u] + mu0b[u] * m_x[j];
+                for (int v = 0; v < U; ++v)
+                    acc += su0b[(size_t)u * U + v] * T1[(size_t)v * E + j] + su0b[(size_t)v * U + u] * T2[(size_t)v * E + j];
+                Wbar[(size_t)u * E + j] += acc;
+            }
+        }
+        for (int i = 0; i < E; ++i) {
+            double acc = 0.0;
+            for (int u = 0; u < U; ++u) acc += W[(size_t)u * E + i] * mu0b[u];
+            mxb[i] += acc;                                                   // W^T mu0b
+            for (int j = 0; j < E; ++j) {
+                double a2 = 0.0;
+                for (int u = 0; u < U; ++u)
+                    for (int v = 0; v < U; ++v) a2 += W[(size_t)u * E + i] * su0b[(size_t)u * U + v] * W[(size_t)v * E + j];
+                sxb[(size_t)i * E + j] += a2;                                // W^T su0b W
+            }
+        }
+    }
+};
+
+// RbfController = deterministic GP (controllers.py:80-121 calling mgpr.py:91-149 with iK = 0, unit signal variance,
+// S -= diag(var - 1e-6)): the same line-by-line reverse as pilco_amd/adjoint.py (rbf_policy_fwd / rbf_policy_vjp), which
+// is checked against autograd on the CPU (tests/test_oracle.py); beta = (K + noise I)^-1 Y and the Gram matrices do not
+// change along the sweep, so their cotangent is accumulated and pushed through the solve once at the end.
+struct RbfAdj : PolicyAdj {
+    int n, d, U;
+    Mat X, Y, ls;
+    vec noise;
+    std::vector<Mat> K, Ainv;
+    Mat beta;                         // (U, n)
+    Mat Xbar, lsbar, bbsum;           // accumulated cotangents of X (direct part), ls (direct part) and beta
+    // per-step cache
+    Mat zeta;
+    vec Mv;
+    struct MeanC { Mat T, G; vec ex, q; };
+    struct PairC { Mat z, w, Ri, Q, zQ, wQ, L; double r, val; };
+    std::vector<MeanC> mean;
+    std::vector<PairC> pair;
+    vec s_cur;
+    bool init(int n_, int d_, int U_, const double* Xp, const double* Yp, const double* lsp, const double* nz) {
+        n = n_; d = d_; U = U_;
+        X = Mat(n, d); Y = Mat(n, U); ls = Mat(U, d);
+        X.d.assign(Xp, Xp + (size_t)n * d);
+        Y.d.assign(Yp, Yp + (size_t)n * U);
+        ls.d.assign(lsp, lsp + (size_t)U * d);
+        noise.assign(nz, nz + U);
+        beta = Mat(U, n); Xbar = Mat(n, d); lsbar = Mat(U, d); bbsum = Mat(U, n);
+        K.resize(U); Ainv.resize(U);
+        for (int a = 0; a < U; ++a) {
+            K[a] = Mat(n, n);
+            Mat A(n, n);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double q = 0.0;
+                    for (int k = 0; k < d; ++k) {
+                        const double t = (X(i, k) - X(j, k)) / ls(a, k);
+                        q += t * t;
+                    }
+                    K[a](i, j) = std::exp(-0.5 * q);
+                    A(i, j) = K[a](i, j) + (i == j ? noise[a] : 0.0);   // FakeGPR likelihood variance, controllers.py:67-77
+                }
+            double det;
+            Ainv[a] = Mat(n, n);
+            if (!inv_small(A.d.data(), n, Ainv[a].d, det)) return false;
+            for (int i = 0; i < n; ++i) {
+                double acc = 0.0;
+                for (int j = 0; j < n; ++j) acc += Ainv[a](i, j) * Y(j, a);
+                beta(a, i) = acc;
+            }
+        }
+        mean.resize(U);
+        pair.resize((size_t)U * U);
+        return true;
+    }
+    bool fwd(const double* m_x, const double* s_x, vec& mu0, vec& su0, vec& V0) override {
+        s_cur.assign(s_x, s_x + (size_t)d * d);
+        zeta = Mat(n, d);
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < d; ++k) zeta(i, k) = X(i, k) - m_x[k];
+        Mv.assign(U, 0.0);
+        for (int a = 0; a < U; ++a) {
+            MeanC& mc = mean[a];
+            Mat A(d, d);
+            double sumlog = 0.0;
+            for (int i = 0; i < d; ++i) {
+                for (int j = 0; j < d; ++j) A(i, j) = s_x[(size_t)i * d + j] + (i == j ? ls(a, i) * ls(a, i) : 0.0);
+                sumlog += std::log(ls(a, i));
+            }
+            double det;
+            mc.T = Mat(d, d);
+            if (!inv_small(A.d.data(), d, mc.T.d, det) || !(det > 0.0)) return false;
+            mc.G = mm(zeta, mc.T);
+            const double logc = -0.5 * (std::log(det) - 2.0 * sumlog);
+            mc.ex.assign(n, 0.0);
+            mc.q.assign(n, 0.0);
+            double Msum = 0.0;
+            for (int i = 0; i < n; ++i) {
+                double h = 0.0;
+                for (int k = 0; k < d; ++k) h += zeta(i, k) * mc.G(i, k);
+                mc.ex[i] = std::exp(-0.5 * h + logc);
+                mc.q[i] = beta(a, i) * mc.ex[i];
+                Msum += mc.q[i];
+            }
+            Mv[a] = Msum;
+            mu0[a] = Msum;
+            for (int k = 0; k < d; ++k) {
+                double acc = 0.0;
+                for (int i = 0; i < n; ++i) acc += mc.G(i, k) * mc.q[i];
+                V0[(size_t)k * U + a] = acc;
+            }
+        }
+        for (int a = 0; a < U; ++a)
+            for (int b = 0; b < U; ++b) {
+                PairC& pc = pair[(size_t)a * U + b];
+                pc.z = Mat(n, d); pc.w = Mat(n, d);
+                vec ka(n, 0.0), kb(n, 0.0);
+                Mat R(d, d);
+                for (int i = 0; i < n; ++i)
+                    for (int k = 0; k < d; ++k) {
+                        pc.z(i, k) = zeta(i, k) / (ls(a, k) * ls(a, k));
+                        pc.w(i, k) = zeta(i, k) / (ls(b, k) * ls(b, k));
+                        ka[i] -= 0.5 * zeta(i, k) * pc.z(i, k);
+                        kb[i] -= 0.5 * zeta(i, k) * pc.w(i, k);
+                    }
+                for (int i = 0; i < d; ++i)
+                    for (int j = 0; j < d; ++j)
+                        R(i, j) = s_x[(size_t)i * d + j] * (1.0 / (ls(a, j) * ls(a, j)) + 1.0 / (ls(b, j) * ls(b, j))) + (i == j ? 1.0 : 0.0);
+                double det;
+                pc.Ri = Mat(d, d);
+                if (!inv_small(R.d.data(), d, pc.Ri.d, det) || !(det > 0.0)) return false;
+                Mat sM(d, d);
+                sM.d.assign(s_x, s_x + (size_t)d * d);
+                pc.Q = mm(pc.Ri, sM);
+                for (double& v : pc.Q.d) v *= 0.5;
+                pc.zQ = mm(pc.z, pc.Q);
+                pc.wQ = mm(pc.w, pc.Q);
+                vec uu(n), vv(n);
+                for (int i = 0; i < n; ++i) {
+                    double a1 = ka[i], a2 = kb[i];
+                    for (int k = 0; k < d; ++k) {
+                        a1 += pc.zQ(i, k) * pc.z(i, k);
+                        a2 += pc.wQ(i, k) * pc.w(i, k);
+                    }
+                    uu[i] = a1;
+                    vv[i] = a2;
+                }
+                pc.L = mmT(pc.zQ, pc.w);
+                double val = 0.0;
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j) {
+                        const double l = std::exp(uu[i] + vv[j] + 2.0 * pc.L(i, j));
+                        pc.L(i, j) = l;
+                        val += beta(a, i) * l * beta(b, j);
+                    }
+                pc.r = 1.0 / std::sqrt(det);
+                pc.val = val;
+                su0[(size_t)a * U + b] = val * pc.r - Mv[a] * Mv[b] + (a == b ? 1e-6 : 0.0);   // + var - (var - 1e-6), controllers.py:117
+            }
+        return true;
+    }
+    void vjp(const double*, const double*, const vec& mu0b, const vec& su0b, const vec& V0b, vec& mxb, vec& sxb) override {
+        vec Mbar(mu0b);
+        Mat zb(n, d), sb(d, d), ibar(U, d), bb(U, n);
+        Mat sM(d, d);
+        sM.d = s_cur;
+        for (int a = 0; a < U; ++a)
+            for (int b = 0; b < U; ++b) {
+                const double g = su0b[(size_t)a * U + b];
+                if (g == 0.0) continue;
+                const PairC& pc = pair[(size_t)a * U + b];
+                Mbar[a] -= g * Mv[b];
+                Mbar[b] -= g * Mv[a];
+                const double valb = g * pc.r, ldb = -0.5 * g * pc.val * pc.r;   // ldb: cotangent of log det R
+                Mat Eb(n, n);
+                vec ub(n, 0.0), vb(n, 0.0);
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j) {
+                        const double l = pc.L(i, j);
+                        bb(a, i) += valb * l * beta(b, j);
+                        bb(b, j) += valb * l * beta(a, i);
+                        const double e = valb * beta(a, i) * beta(b, j) * l;
+                        Eb(i, j) = e;
+                        ub[i] += e;
+                        vb[j] += e;
+                    }
+                Mat zQb = mm(Eb, pc.w);          // 2 Eb w + ub z
+                Mat wb = Tmm(Eb, pc.zQ);         // 2 Eb^T zQ + vb wQ
+                Mat zb_(n, d), wQb(n, d);
+                for (int i = 0; i < n; ++i)
+                    for (int k = 0; k < d; ++k) {
+                        zQb(i, k) = 2.0 * zQb(i, k) + ub[i] * pc.z(i, k);
+                        wb(i, k) = 2.0 * wb(i, k) + vb[i] * pc.wQ(i, k);
+                        zb_(i, k) = ub[i] * pc.zQ(i, k);
+                        wQb(i, k) = vb[i] * pc.w(i, k);
+                    }
+                const Mat t1 = mmT(zQb, pc.Q), t2 = mmT(wQb, pc.Q);
+                Mat Qb = Tmm(pc.z, zQb);
+                const Mat Qb2 = Tmm(pc.w, wQb);
+                for (size_t e = 0; e < Qb.d.size(); ++e) Qb.d[e] += Qb2.d[e];
+                for (int i = 0; i < n; ++i)
+                    for (int k = 0; k < d; ++k) {
+                        const double zbk = zb_(i, k) + t1(i, k) - 0.5 * ub[i] * zeta(i, k);
+                        const double wbk = wb(i, k) + t2(i, k) - 0.5 * vb[i] * zeta(i, k);
+                        const double ia = 1.0 / (ls(a, k) * ls(a, k)), ib = 1.0 / (ls(b, k) * ls(b, k));
+                        zb(i, k) += -0.5 * ub[i] * pc.z(i, k) - 0.5 * vb[i] * pc.w(i, k) + zbk * ia + wbk * ib;
+                        ibar(a, k) += zbk * zeta(i, k);
+                        ibar(b, k) += wbk * zeta(i, k);
+                    }
+                // Rb = -Ri^T Qb Q^T + ldb Ri^T;  sb += Ri^T Qb / 2 + Rb diag(ia + ib);  lam = colsum(s o Rb)
+                const Mat RiTQb = Tmm(pc.Ri, Qb);
+                Mat Rb = mmT(RiTQb, pc.Q);
+                for (int i = 0; i < d; ++i)
+                    for (int j = 0; j < d; ++j) Rb(i, j) = -Rb(i, j) + ldb * pc.Ri(j, i);
+                for (int i = 0; i < d; ++i)
+                    for (int j = 0; j < d; ++j) {
+                        const double lamj = 1.0 / (ls(a, j) * ls(a, j)) + 1.0 / (ls(b, j) * ls(b, j));
+                        sb(i, j) += 0.5 * RiTQb(i, j) + Rb(i, j) * lamj;
+                    }
+                for (int j = 0; j < d; ++j) {
+                    double lam = 0.0;
+                    for (int i = 0; i < d; ++i) lam += sM(i, j) * Rb(i, j);
+                    ibar(a, j) += lam;
+                    ibar(b, j) += lam;
+                }
+            }
+        for (int a = 0; a < U; ++a) {
+            const MeanC& mc = mean[a];
+            vec qb(n), hb(n);
+            double logcb = 0.0;
+            Mat Gb(n, d);
+            for (int i = 0; i < n; ++i) {
+                double acc = Mbar[a];
+                for (int k = 0; k < d; ++k) acc += mc.G(i, k) * V0b[(size_t)k * U + a];
+                qb[i] = acc;
+                hb[i] = acc * mc.q[i];
+                logcb += hb[i];
+                bb(a, i) += acc * mc.ex[i];
+                for (int k = 0; k < d; ++k) {
+                    Gb(i, k) = mc.q[i] * V0b[(size_t)k * U + a] - 0.5 * hb[i] * zeta(i, k);
+                    zb(i, k) -= 0.5 * hb[i] * mc.G(i, k);
+                }
+            }
+            const Mat zadd = mmT(Gb, mc.T);          // Gb T^T
+            for (size_t e = 0; e < zb.d.size(); ++e) zb.d[e] += zadd.d[e];
+            const Mat Tb = Tmm(zeta, Gb);
+            const Mat TtTb = Tmm(mc.T, Tb);
+            const Mat Ab2 = mmT(TtTb, mc.T);         // T^T Tb T^T
+            for (int i = 0; i < d; ++i)
+                for (int j = 0; j < d; ++j) {
+                    const double ab = -0.5 * logcb * mc.T(i, j) - Ab2(i, j);
+                    sb(i, j) += ab;
+                    if (i == j) lsbar(a, i) += logcb / ls(a, i) + 2.0 * ls(a, i) * ab;
+                }
+        }
+        for (int a = 0; a < U; ++a)
+            for (int k = 0; k < d; ++k) lsbar(a, k) += ibar(a, k) * (-2.0 / (ls(a, k) * ls(a, k) * ls(a, k)));
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < d; ++k) {
+                Xbar(i, k) += zb(i, k);
+                mxb[k] -= zb(i, k);
+            }
+        for (size_t e = 0; e < sxb.size(); ++e) sxb[e] += sb.d[e];
+        for (size_t e = 0; e < bbsum.d.size(); ++e) bbsum.d[e] += bb.d[e];
+    }
+    // push the accumulated cotangent of beta through beta = (K + noise I)^-1 Y (once, after the sweep)
+    void finish(double* dX, double* dY, double* dls) {
+        Mat Xb = Xbar, lb = lsbar, Yb(n, U);
+        for (int a = 0; a < U; ++a) {
+            vec g(n, 0.0);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) g[i] += Ainv[a](i, j) * bbsum(a, j);      // Ainv symmetric
+            Mat Wk(n, n);
+            for (int i = 0; i < n; ++i) {
+                Yb(i, a) = g[i];
+                for (int j = 0; j < n; ++j) Wk(i, j) = -g[i] * beta(a, j) * K[a](i, j);
+            }
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    const double wsym = Wk(i, j) + Wk(j, i);
+                    for (int k = 0; k < d; ++k) {
+                        const double df = X(i, k) - X(j, k);
+                        Xb(i, k) -= wsym * df / (ls(a, k) * ls(a, k));
+                        lb(a, k) += 0.5 * wsym * df * df / (ls(a, k) * ls(a, k) * ls(a, k));
+                    }
+                }
+        }
+        memcpy(dX, Xb.d.data(), sizeof(double) * n * d);
+        memcpy(dY, Yb.d.data(), sizeof(double) * n * U);
+        memcpy(dls, lb.d.data(), sizeof(double) * U * d);
+    }
+};
+
+// The reverse sweep common to both policies: propagate (pilco.py:147-149), joint Gaussian (:141-144), squash
+// (controllers.py:13-36), rewards (rewards.py:19-81); the moment-matching adjoint of every step on the device.
+int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                      const double* m0, const double* S0, int H, double* reward, PolicyAdj& pol) {
     const int E = policy->state_dim, U = policy->control_dim, D = E + U;
     const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
     vec mH(E), SH((size_t)E * E), traj((size_t)(H + 1) * (E + E * E)), tape(std::max<size_t>(1, (size_t)H * TS));
     if (int r = pilco_rollout_tape(ctx, policy, rewards, n_rewards, m0, S0, H, mH.data(), SH.data(), reward, traj.data(), tape.data()))
         return r;
-    const double* W = policy->W;
-    const double* b = policy->b;
     vec e(U);
     for (int u = 0; u < U; ++u) e[u] = policy->max_action[u];
-    vec mbar(E, 0.0), sbar((size_t)E * E, 0.0), Wbar((size_t)U * E, 0.0), bbar(U, 0.0);
+    vec mbar(E, 0.0), sbar((size_t)E * E, 0.0);
     vec G((size_t)E * E), Vb((size_t)D * E), s1bar((size_t)E * D), mjb(D), sjb((size_t)D * D), mxb(E), sxb((size_t)E * E);
-    vec Bb((size_t)E * U), sub((size_t)U * U), mu0(U), su0((size_t)U * U), WS((size_t)U * E), cb((size_t)E * U), Cdbar(U);
-    vec mu0b, su0b, rm(E), rS((size_t)E * E), T1((size_t)U * E), T2((size_t)U * E);
+    vec Bb((size_t)E * U), sub((size_t)U * U), mu0(U), su0((size_t)U * U), V0((size_t)E * U), V0b((size_t)E * U), cb((size_t)E * U), Cdbar(U);
+    vec mu0b, su0b, rm(E), rS((size_t)E * E);
     Squash sq;
     for (int t = H - 1; t >= 0; --t) {
         const double* m_x = &traj[(size_t)t * (E + E * E)];
@@ -241,7 +608,7 @@ int pilco_rollout_grad(pilco_ctx* ctx, const pilco_policy* policy, const pilco_r
         const double* rec = &tape[(size_t)t * TS];
         const double* m_j = rec;
         const double* s_j = rec + D;
-        const double* s1 = rec + D + D * D;                           // (E, D)
+        const double* s1 = rec + D + D * D;                                      // (E, D)
         const double* V = rec + D + D * D + (size_t)E * D + E + (size_t)E * E;   // (D, E)
         // propagate (pilco.py:147-149): M_x = M + m_x, S_x = S + s_x + s1 V + (s1 V)^T
         for (int i = 0; i < E; ++i)
@@ -271,28 +638,13 @@ int pilco_rollout_grad(pilco_ctx* ctx, const pilco_policy* policy, const pilco_r
                 Bb[(size_t)i * U + u] = sjb[(size_t)i * D + E + u] + sjb[(size_t)(E + u) * D + i] + s1bar[(size_t)i * D + E + u];
         for (int u = 0; u < U; ++u)
             for (int v = 0; v < U; ++v) sub[(size_t)u * U + v] = sjb[(size_t)(E + u) * D + E + v];
-        // controller (controllers.py:46-58): mu0 = W m + b, su0 = W s W^T, c = W^T diag(Cd)
-        for (int u = 0; u < U; ++u) {
-            double acc = b[u];
-            for (int i = 0; i < E; ++i) acc += W[(size_t)u * E + i] * m_x[i];
-            mu0[u] = acc;
-            for (int j = 0; j < E; ++j) {
-                double a2 = 0.0;
-                for (int i = 0; i < E; ++i) a2 += W[(size_t)u * E + i] * s_x[(size_t)i * E + j];
-                WS[(size_t)u * E + j] = a2;                                  // W s
-            }
-        }
-        for (int u = 0; u < U; ++u)
-            for (int v = 0; v < U; ++v) {
-                double acc = 0.0;
-                for (int j = 0; j < E; ++j) acc += WS[(size_t)u * E + j] * W[(size_t)v * E + j];
-                su0[(size_t)u * U + v] = acc;
-            }
+        // controller: (mu0, su0, V0) -> squash_sin -> (m_u, s_u, c = V0 diag(Cd))   (controllers.py:46-58,108-121)
+        if (!pol.fwd(m_x, s_x, mu0, su0, V0)) return fail(ctx, PILCO_E_NOT_PD, "rollout_grad: singular matrix in the policy");
         sq.fwd(mu0, su0, e);
         for (int i = 0; i < E; ++i)
             for (int j = 0; j < E; ++j) {
                 double acc = 0.0;
-                for (int u = 0; u < U; ++u) acc += Bb[(size_t)i * U + u] * W[(size_t)u * E + j] * sq.Cd[u];   // Bb c^T, c = W^T diag(Cd)
+                for (int u = 0; u < U; ++u) acc += Bb[(size_t)i * U + u] * V0[(size_t)j * U + u] * sq.Cd[u];   // Bb c^T
                 sxb[(size_t)i * E + j] += acc;
             }
         for (int i = 0; i < E; ++i)
@@ -303,41 +655,14 @@ int pilco_rollout_grad(pilco_ctx* ctx, const pilco_policy* policy, const pilco_r
             }
         for (int u = 0; u < U; ++u) {
             double acc = 0.0;
-            for (int i = 0; i < E; ++i) acc += W[(size_t)u * E + i] * cb[(size_t)i * U + u];
+            for (int i = 0; i < E; ++i) {
+                acc += V0[(size_t)i * U + u] * cb[(size_t)i * U + u];
+                V0b[(size_t)i * U + u] = cb[(size_t)i * U + u] * sq.Cd[u];
+            }
             Cdbar[u] = acc;
         }
         sq.vjp(&mjb[E], sub.data(), Cdbar.data(), mu0b, su0b);
-        // Wbar += diag(Cd) cb^T + mu0b m_x^T + su0b W s_x^T + su0b^T W s_x
-        for (int u = 0; u < U; ++u)
-            for (int j = 0; j < E; ++j) {
-                double a1 = 0.0, a2 = 0.0;
-                for (int i = 0; i < E; ++i) {
-                    a1 += W[(size_t)u * E + i] * s_x[(size_t)j * E + i];     // (W s_x^T)[u][j]
-                    a2 += W[(size_t)u * E + i] * s_x[(size_t)i * E + j];     // (W s_x)[u][j]
-                }
-                T1[(size_t)u * E + j] = a1;
-                T2[(size_t)u * E + j] = a2;
-            }
-        for (int u = 0; u < U; ++u) {
-            bbar[u] += mu0b[u];
-            for (int j = 0; j < E; ++j) {
-                double acc = sq.Cd[u] * cb[(size_t)j * U + u] + mu0b[u] * m_x[j];
-                for (int v = 0; v < U; ++v)
-                    acc += su0b[(size_t)u * U + v] * T1[(size_t)v * E + j] + su0b[(size_t)v * U + u] * T2[(size_t)v * E + j];
-                Wbar[(size_t)u * E + j] += acc;
-            }
-        }
-        for (int i = 0; i < E; ++i) {
-            double acc = 0.0;
-            for (int u = 0; u < U; ++u) acc += W[(size_t)u * E + i] * mu0b[u];
-            mxb[i] += acc;                                                   // W^T mu0b
-            for (int j = 0; j < E; ++j) {
-                double a2 = 0.0;
-                for (int u = 0; u < U; ++u)
-                    for (int v = 0; v < U; ++v) a2 += W[(size_t)u * E + i] * su0b[(size_t)u * U + v] * W[(size_t)v * E + j];
-                sxb[(size_t)i * E + j] += a2;                                // W^T su0b W
-            }
-        }
+        pol.vjp(m_x, s_x, mu0b, su0b, V0b, mxb, sxb);
         // reward of the pre-propagation state (pilco.py:133)
         std::fill(rm.begin(), rm.end(), 0.0);
         std::fill(rS.begin(), rS.end(), 0.0);
@@ -348,8 +673,53 @@ int pilco_rollout_grad(pilco_ctx* ctx, const pilco_policy* policy, const pilco_r
         for (int i = 0; i < E; ++i)
             for (int j = 0; j < E; ++j) sbar[(size_t)i * E + j] = 0.5 * (sxb[(size_t)i * E + j] + sxb[(size_t)j * E + i]);
     }
-    memcpy(dW, Wbar.data(), sizeof(double) * U * E);
-    memcpy(db, bbar.data(), sizeof(double) * U);
+    return PILCO_OK;
+}
+
+int check_grad_args(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, int kind) {
+    if (policy->kind != kind || !policy->squash || policy->control_dim <= 0)
+        return fail(ctx, PILCO_E_SHAPE, "rollout_grad: squashed LinearController (pilco_rollout_grad) or RbfController (pilco_rollout_grad_rbf) only");
+    for (int k = 0; k < n_rewards; ++k)
+        if (rewards[k].kind != PILCO_REWARD_EXPONENTIAL && rewards[k].kind != PILCO_REWARD_LINEAR)
+            return fail(ctx, PILCO_E_SHAPE, "rollout_grad: unknown reward term");
+    return PILCO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Value and gradient of the rollout reward w.r.t. a LinearController's (W, b): what TensorFlow's reverse mode through
+// the tf.while_loop gives the reference (pilco/models/pilco.py:85-90,126-135).  Forward rollout with a tape on the
+// device, then the reverse sweep: the O(N^2) adjoint of every moment-matching step on the device
+// (pilco_gp_predict_vjp), the O(D^3) links here on the host in C++.  dW (U,E), db (U).
+int pilco_rollout_grad(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                       const double* m0, const double* S0, int H, double* reward, double* dW, double* db) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!policy || !m0 || !S0 || !reward || !dW || !db || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout_grad: bad arguments");
+    if (int r = check_grad_args(ctx, policy, rewards, n_rewards, PILCO_POLICY_LINEAR)) return r;
+    LinearAdj pol(policy->state_dim, policy->control_dim, policy->W, policy->b);
+    if (int r = rollout_grad_impl(ctx, policy, rewards, n_rewards, m0, S0, H, reward, pol)) return r;
+    memcpy(dW, pol.Wbar.data(), sizeof(double) * pol.Wbar.size());
+    memcpy(db, pol.bbar.data(), sizeof(double) * pol.bbar.size());
+    return PILCO_OK;
+}
+
+// The same for an RbfController whose GP lives in PILCO_SLOT_POLICY: gradients w.r.t. the centres Xp (bf,E), the
+// targets Yp (bf,U) and the lengthscales lsp (U,E) (controllers.py:80-129); the caller passes the host copies of the
+// policy parameters it uploaded with pilco_gp_set_data / _set_hyp (noisep (U): the FakeGPR likelihood variance).
+int pilco_rollout_grad_rbf(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                           const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
+                           const double* noisep, int bf, double* reward, double* dX, double* dY, double* dls) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!policy || !m0 || !S0 || !reward || !Xp || !Yp || !lsp || !noisep || !dX || !dY || !dls || H < 0 || bf <= 0)
+        return fail(ctx, PILCO_E_SHAPE, "rollout_grad_rbf: bad arguments");
+    if (int r = check_grad_args(ctx, policy, rewards, n_rewards, PILCO_POLICY_RBF)) return r;
+    RbfAdj pol;
+    if (!pol.init(bf, policy->state_dim, policy->control_dim, Xp, Yp, lsp, noisep))
+        return fail(ctx, PILCO_E_NOT_PD, "rollout_grad_rbf: K + noise I of the policy is singular");
+    if (int r = rollout_grad_impl(ctx, policy, rewards, n_rewards, m0, S0, H, reward, pol)) return r;
+    pol.finish(dX, dY, dls);
     return PILCO_OK;
 }
 

@@ -669,6 +669,12 @@ def test_rbf_policy_gradient_adjoint_vs_autograd(ctx):
     np.testing.assert_allclose(Xb, tX.grad.numpy(), rtol=1e-6, atol=1e-10)
     np.testing.assert_allclose(Yb, tY.grad.numpy(), rtol=1e-6, atol=1e-10)
     np.testing.assert_allclose(lb, tl.grad.numpy(), rtol=1e-6, atol=1e-10)
+    # the Python-driven sweep (NumPy policy adjoint) agrees with the native one to rounding
+    r2, (Xb2, Yb2, lb2) = rollout_value_and_grad(p, native=False)
+    np.testing.assert_allclose(r2, r, rtol=1e-13)
+    np.testing.assert_allclose(Xb2, Xb, rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(Yb2, Yb, rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(lb2, lb, rtol=1e-8, atol=1e-13)
     r_opt = p.optimize_policy(maxiter=5, verbose=False)
     assert r_opt >= r - 1e-12
 
