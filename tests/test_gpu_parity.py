@@ -763,3 +763,35 @@ def test_wide_inputs_vs_oracle(ctx, D, E):
     np.testing.assert_allclose(M, Mo, rtol=RTOL)
     np.testing.assert_allclose(S, So, rtol=RTOL, atol=1e-12)
     np.testing.assert_allclose(V, Vo, rtol=RTOL, atol=1e-12)
+
+
+def test_full_size_c2_properties(ctx):
+    """Size-independent properties at BASELINE config 2 (N=1000, D=10, E=10), no oracle run needed:
+    (1) the prediction does not depend on the order of the training points (another padding / tile assignment of
+        every point, another summation order);
+    (2) with zero input covariance the moment matching collapses to the ordinary GP posterior at m:
+        M_a = k_a(m, X) beta_a,  S_aa = var_a - k_a^T iK_a k_a,  S_ab = 0  (mgpr.py:99-147 with s = 0);
+    (3) S is symmetric and, for a proper input covariance, positive definite."""
+    c = synthetic.config_c2()
+    m = _mgpr(c)
+    M, S, V = m.predict_on_noisy_inputs(c["m0"], c["S0"])
+    np.testing.assert_allclose(S, S.T, rtol=1e-12, atol=1e-15)
+    assert np.linalg.eigvalsh(0.5 * (S + S.T)).min() > 0.0
+    # (2) zero covariance vs the plain GP posterior built from the downloaded factors
+    iK, beta = m.calculate_factorizations()
+    M0, S0, V0 = m.predict_on_noisy_inputs(c["m0"], np.zeros((10, 10)))
+    for a in range(10):
+        k = c["variance"][a] * np.exp(-0.5 * (((c["X"] - c["m0"]) / c["lengthscales"][a]) ** 2).sum(1))
+        np.testing.assert_allclose(M0[0, a], k @ beta[a], rtol=1e-9)
+        np.testing.assert_allclose(S0[a, a], c["variance"][a] - k @ iK[a] @ k, rtol=1e-6, atol=1e-10)
+    off = S0 - np.diag(np.diag(S0))
+    assert np.abs(off).max() < 1e-9
+    # (1) permutation of the training set
+    perm = np.random.RandomState(7).permutation(c["X"].shape[0])
+    cp = dict(c)
+    cp["X"], cp["Y"] = c["X"][perm], c["Y"][perm]
+    mp = _mgpr(cp)
+    Mp, Sp, Vp = mp.predict_on_noisy_inputs(c["m0"], c["S0"])
+    np.testing.assert_allclose(Mp, M, rtol=1e-8)
+    np.testing.assert_allclose(Sp, S, rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(Vp, V, rtol=1e-7, atol=1e-12)
