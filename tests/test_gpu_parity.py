@@ -795,3 +795,26 @@ def test_full_size_c2_properties(ctx):
     np.testing.assert_allclose(Mp, M, rtol=1e-8)
     np.testing.assert_allclose(Sp, S, rtol=1e-7, atol=1e-12)
     np.testing.assert_allclose(Vp, V, rtol=1e-7, atol=1e-12)
+
+
+def test_full_size_c2u_gradient_directional_fd(ctx):
+    """C2u (N=1000, state 10 + 1 control, H=40): the native value-and-gradient against a central difference of device
+    rollouts along a random direction in (W, b) -- a full-size check that needs no oracle run."""
+    from pilco_amd.adjoint import rollout_value_and_grad
+    c = synthetic.config_c2(N=1000, D=11, E=10)
+    p = _pilco_from(c, 40)
+    p.controller.W.assign(c["W"]); p.controller.b.assign(c["b"]); p.controller.max_action = 1.0
+    p.m_init, p.S_init = c["m0"], c["S0"]
+    r, (Wb, bb) = rollout_value_and_grad(p)
+    np.testing.assert_allclose(r, float(p.compute_reward()[0, 0]), rtol=1e-12)
+    rs = np.random.RandomState(3)
+    dW, db = rs.randn(*Wb.shape), rs.randn(*bb.shape)
+    h = 1e-5
+    vals = []
+    for sgn in (+1.0, -1.0):
+        p.controller.W.assign(c["W"] + sgn * h * dW)
+        p.controller.b.assign(c["b"] + sgn * h * db)
+        vals.append(float(p.compute_reward()[0, 0]))
+    fd = (vals[0] - vals[1]) / (2 * h)
+    an = float((Wb * dW).sum() + (bb * db).sum())
+    np.testing.assert_allclose(an, fd, rtol=1e-5, atol=1e-9)
