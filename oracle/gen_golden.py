@@ -1,14 +1,27 @@
-"""Generate tests/golden/*.npz from the MATLAB-path transliteration.
+"""Generate tests/golden/*.npz by EXECUTING THE REFERENCE'S OWN SOURCE.
 
-TEST INFRASTRUCTURE ONLY.  Run from the repo root:  python -m oracle.gen_golden
+TEST INFRASTRUCTURE ONLY.  Run in the build container from the repo root:
 
-Each fixture stores the inputs of one of the reference's test procedures
+    python -m oracle.gen_golden
+
+Every fixture stores the inputs of one of the reference's five test procedures
 (tests/test_predictions.py, test_sparse_predictions.py, test_cascade.py,
-test_controllers.py, test_rewards.py) together with the answer of the
-corresponding MATLAB routine as restated in oracle/matlab_path.py (Octave is
-not installed, so the live oracle of the reference cannot be executed here; the
-fixtures pin the restatement against drift, and tests/test_oracle.py checks
-the independent TF-path restatement and the quadrature against them).
+test_controllers.py, test_rewards.py under /root/reference) together with the
+outputs of the reference's *unmodified* Python modules (pilco/models/mgpr.py,
+smgpr.py, pilco.py, pilco/controllers.py, pilco/rewards.py), imported from
+/root/reference by ``oracle/ref_exec.py`` on top of the tensorflow / gpflow
+stand-ins of ``oracle/refshim.py`` (torch-CPU-float64).  Each file carries a
+``provenance`` string saying so.  Beside the reference's outputs the answer of
+the MATLAB routine the reference's test compares with is stored
+(``*_matlab``, from the transliteration in oracle/matlab_path.py, Octave being
+absent), so tests/test_reference_exec.py can repeat the reference's own
+assertion at the reference's own tolerance.
+
+The ``*_trained`` fixtures follow the reference procedures literally (GPflow-
+style hyper-parameter optimisation by the reference's MGPR.optimize /
+PILCO.optimize_models / optimize_policy with the seeds the tests use); the
+others put fixed hyper-parameters into the reference's models so that the
+answers do not depend on an optimiser trajectory.
 """
 from __future__ import annotations
 
@@ -18,88 +31,266 @@ import numpy as np
 
 from pilco_amd import synthetic
 from . import matlab_path as mp
-from . import tf_path as tp
+from . import mp_truth
+from . import ref_exec
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+PROV = ("reference source executed: /root/reference/pilco/{models/mgpr,models/smgpr,models/pilco,controllers,rewards}.py "
+        "imported unmodified under oracle/refshim.py (torch-CPU-fp64 stand-in for tensorflow/gpflow); "
+        "*_matlab = oracle/matlab_path.py transliteration of tests/Matlab Code/*.m; *_mp = 40-digit mpmath evaluation (oracle/mp_truth.py)")
+n_ = ref_exec.to_np
 
 
-def gen_predictions():
-    for tag, noise in (("", (1e-4, 3e-4)), ("_lownoise", (1e-6, 1e-6))):
-        c = synthetic.config_c1(noise=noise)
-        hyp = mp.hyp_from(c["lengthscales"], c["variance"], c["noise"])
-        M, S, V = mp.gp0(c["X"], c["Y"], hyp, c["m"].T, c["s"])
-        np.savez(os.path.join(OUT, f"predictions{tag}.npz"), **c, hyp=hyp, M=M.T, S=S, V=V)
+def _save(name, **kw):
+    np.savez(os.path.join(OUT, name), provenance=np.array(PROV), **kw)
 
 
-def gen_sparse():
+def _hyp_of(models):
+    ls = np.stack([n_(m.kernel.lengthscales) for m in models])
+    var = np.stack([n_(m.kernel.variance) for m in models]).reshape(-1)
+    nz = np.stack([n_(m.likelihood.variance) for m in models]).reshape(-1)
+    return ls, var, nz
+
+
+def _set_hyp(models, ls, var, nz):
+    for i, m in enumerate(models):
+        m.kernel.lengthscales.assign(ls[i])
+        m.kernel.variance.assign(var[i])
+        m.likelihood.variance.assign(nz[i])
+
+
+def gen_predictions(R):
+    """tests/test_predictions.py:13-63."""
+    # (a) fixed hyper-parameters
+    c = synthetic.config_c1()
+    mgpr = R.MGPR((c["X_first"], c["Y"]))
+    _set_hyp(mgpr.models, c["lengthscales"], c["variance"], c["noise"])
+    M1, S1, V1 = mgpr.predict_on_noisy_inputs(c["m"], c["s"])
+    mgpr.set_data((c["X"], c["Y"]))                                   # the stale-cache check of :33-37
+    M, S, V = mgpr.predict_on_noisy_inputs(c["m"], c["s"])
+    iK, beta = mgpr.calculate_factorizations()
+    hyp = mp.hyp_from(c["lengthscales"], c["variance"], c["noise"])
+    Mm, Sm, Vm = mp.gp0(c["X"], c["Y"], hyp, c["m"].T, c["s"])
+    Mt, St, Vt = mp_truth.moments(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"], c["m"], c["s"])
+    _save("predictions.npz", **c, M_mp=Mt, S_mp=St, V_mp=Vt, hyp=hyp, M=n_(M), S=n_(S), V=n_(V), M_first=n_(M1), S_first=n_(S1), V_first=n_(V1),
+          beta=n_(beta), M_matlab=Mm.T, S_matlab=Sm, V_matlab=Vm)
+
+    # (b) the literal procedure: np.random.seed(0), MGPR.optimize() (noise ends at GPflow's 1e-6 floor)
+    np.random.seed(0)
+    d, k = 3, 2
+    X0 = np.random.rand(100, d)
+    A = np.random.rand(d, k)
+    Y0 = np.sin(X0).dot(A) + 1e-3 * (np.random.rand(100, k) - 0.5)
+    mgpr = R.MGPR((X0, Y0))
+    mgpr.optimize()
+    m = np.random.rand(1, d)
+    s = np.random.rand(d, d)
+    s = s.dot(s.T)
+    M1, S1, V1 = mgpr.predict_on_noisy_inputs(m, s)
+    X1 = 5 * np.random.rand(100, d)
+    mgpr.set_data((X1, Y0))
+    M, S, V = mgpr.predict_on_noisy_inputs(m, s)
+    ls, var, nz = _hyp_of(mgpr.models)
+    hyp = mp.hyp_from(ls, var, nz)
+    Mm, Sm, Vm = mp.gp0(X1, Y0, hyp, m.T, s)
+    Mt, St, Vt = mp_truth.moments(X1, Y0, ls, var, nz, m, s)     # 40-digit evaluation: what float64 should approach
+    _save("predictions_lownoise.npz", M_mp=Mt, S_mp=St, V_mp=Vt, X=X1, Y=Y0, X_first=X0, lengthscales=ls, variance=var, noise=nz, m=m, s=s, hyp=hyp,
+          M=n_(M), S=n_(S), V=n_(V), M_first=n_(M1), S_first=n_(S1), V_first=n_(V1),
+          M_matlab=Mm.T, S_matlab=Sm, V_matlab=Vm)
+
+
+def gen_sparse(R):
+    """tests/test_sparse_predictions.py:12-57 (fixed hyper-parameters; Z of model 0 serves every output)."""
     c = synthetic.config_c1()
     rs = np.random.RandomState(7)
     Z = 5 * rs.rand(30, 3)
+    np.random.seed(11)
+    sm = R.SMGPR((c["X"], c["Y"]), num_induced_points=30)
+    _set_hyp(sm.models, c["lengthscales"], c["variance"], c["noise"])
+    sm.models[0].inducing_variable.Z.assign(Z)
+    M, S, V = sm.predict_on_noisy_inputs(c["m"], c["s"])
+    iK, beta = sm.calculate_factorizations()
     hyp = mp.hyp_from(c["lengthscales"], c["variance"], c["noise"])
-    M, S, V = mp.gp1(c["X"], c["Y"], hyp, Z, c["m"].T, c["s"])
-    np.savez(os.path.join(OUT, "sparse_predictions.npz"), **c, Z=Z, hyp=hyp, M=M.T, S=S, V=V)
+    Mm, Sm, Vm = mp.gp1(c["X"], c["Y"], hyp, Z, c["m"].T, c["s"])
+    _save("sparse_predictions.npz", **c, Z=Z, hyp=hyp, M=n_(M), S=n_(S), V=n_(V), iK=n_(iK), beta=n_(beta),
+          M_matlab=Mm.T, S_matlab=Sm, V_matlab=Vm)
 
 
-def gen_cascade():
+def _trajectory(pilco, m, s, H):
+    Ms, Ss, Rs = [], [], []
+    for n in range(H + 1):
+        Mn, Sn, Rn = pilco.predict(m, s, n)
+        Ms.append(n_(Mn)[0])
+        Ss.append(n_(Sn))
+        Rs.append(float(n_(Rn).ravel()[0]))
+    return np.stack(Ms, 1), np.stack(Ss, 2), np.array(Rs)
+
+
+def gen_cascade(R):
+    """tests/test_cascade.py:17-78; trajectories hold the state after n = 0..H steps, rewards the running sum."""
     c = synthetic.config_cascade()
+    np.random.seed(5)
+    pilco = R.PILCO((c["X"], c["Y"]))
+    pilco.controller.max_action = c["max_action"]
+    _set_hyp(pilco.mgpr.models, c["lengthscales"], c["variance"], c["noise"])
+    pilco.controller.W.assign(c["W"])
+    pilco.controller.b.assign(c["b"])
+    H = int(c["horizon"])
+    Ms, Ss, Rs = _trajectory(pilco, c["m"], c["s"], H)
     hyp = mp.hyp_from(c["lengthscales"], c["variance"], c["noise"])
-    Ms, Ss = mp.pred(c["m"].T, c["s"], c["horizon"], c["X"], c["Y"], hyp,
-                     c["W"], c["b"].T, c["max_action"])
-    np.savez(os.path.join(OUT, "cascade.npz"), **c, hyp=hyp, M_traj=Ms, S_traj=Ss)
+    Mm, Sm = mp.pred(c["m"].T, c["s"], H, c["X"], c["Y"], hyp, c["W"], c["b"].T, c["max_action"])
+    _save("cascade.npz", **c, hyp=hyp, M_traj=Ms, S_traj=Ss, R_traj=Rs, M_traj_matlab=Mm, S_traj_matlab=Sm)
 
-
-def gen_controllers():
-    rs = np.random.RandomState(0)
-    d, k, bf = 3, 2, 100
-    X0 = rs.rand(bf, d)
-    A = rs.rand(d, k)
-    Y0 = np.sin(X0).dot(A) + 1e-3 * (rs.rand(bf, k) - 0.5)
-    m = rs.rand(1, d)
-    s = rs.rand(d, d)
+    # the literal procedure: trained models (restarts=5) and trained policy (restarts=5)
+    np.random.seed(0)
+    d, k, H = 2, 1, 10
+    e = np.array([[10.0]])
+    X0 = np.random.rand(100, d + k)
+    A = np.random.rand(d + k, d)
+    Y0 = np.sin(X0).dot(A) + 1e-3 * (np.random.rand(100, d) - 0.5)
+    pilco = R.PILCO((X0, Y0))
+    pilco.controller.max_action = e
+    pilco.optimize_models(restarts=5)
+    pilco.optimize_policy(restarts=5)
+    m = np.random.rand(1, d)
+    s = np.random.rand(d, d)
     s = s.dot(s.T)
-    ls = np.array([[1.0, 1.4, 0.8], [0.9, 1.1, 1.6]])
-    var = np.ones(k)
-    nz = 1e-4 * np.ones(k)
+    Ms, Ss, Rs = _trajectory(pilco, m, s, H)
+    ls, var, nz = _hyp_of(pilco.mgpr.models)
+    W, b = n_(pilco.controller.W), n_(pilco.controller.b)
     hyp = mp.hyp_from(ls, var, nz)
-    M, S, V = mp.gp2(X0, Y0, hyp, m.T, s)
-    np.savez(os.path.join(OUT, "rbf_controller.npz"), X=X0, Y=Y0, lengthscales=ls,
-             variance=var, noise=nz, m=m, s=s, M=M.T, S=S, V=V)
-    W = rs.rand(k, d)
-    b = rs.rand(1, k)
-    M, S, V = mp.conlin(W, b.T, m.T, s)
-    np.savez(os.path.join(OUT, "linear_controller.npz"), W=W, b=b, m=m, s=s, M=M.T, S=S, V=V)
+    Mm, Sm = mp.pred(m.T, s, H, X0, Y0, hyp, W, b.T, e)
+    _save("cascade_trained.npz", X=X0, Y=Y0, lengthscales=ls, variance=var, noise=nz, m=m, s=s, W=W, b=b, max_action=e,
+          horizon=H, hyp=hyp, M_traj=Ms, S_traj=Ss, R_traj=Rs, M_traj_matlab=Mm, S_traj_matlab=Sm)
+
+
+def gen_controllers(R):
+    """tests/test_controllers.py:13-113."""
+    np.random.seed(0)
+    d, k, bf = 3, 2, 100
+    X0 = np.random.rand(bf, d)
+    A = np.random.rand(d, k)
+    Y0 = np.sin(X0).dot(A) + 1e-3 * (np.random.rand(bf, k) - 0.5)
+    rbf = R.controllers.RbfController(d, k, bf)
+    rbf.set_data((X0, Y0))
+    ls = np.array([[1.0, 1.4, 0.8], [0.9, 1.1, 1.6]])
+    for i, mdl in enumerate(rbf.models):
+        mdl.kernel.lengthscales.assign(ls[i])
+    m = np.random.rand(1, d)
+    s = np.random.rand(d, d)
+    s = s.dot(s.T)
+    M, S, V = rbf.compute_action(m, s, squash=False)
+    Mq, Sq, Vq = rbf.compute_action(m, s, squash=True)
+    _, var, nz = _hyp_of(rbf.models)
+    hyp = mp.hyp_from(ls, var, nz)
+    Mm, Sm, Vm = mp.gp2(X0, Y0, hyp, m.T, s)
+    _save("rbf_controller.npz", X=X0, Y=Y0, lengthscales=ls, variance=var, noise=nz, m=m, s=s, M=n_(M), S=n_(S), V=n_(V),
+          M_squashed=n_(Mq), S_squashed=n_(Sq), V_squashed=n_(Vq), M_matlab=Mm.T, S_matlab=Sm, V_matlab=Vm)
+
+    np.random.seed(0)
+    m = np.random.rand(1, d)
+    s = np.random.rand(d, d)
+    s = s.dot(s.T)
+    W = np.random.rand(k, d)
+    b = np.random.rand(1, k)
+    lin = R.controllers.LinearController(d, k)
+    lin.W.assign(W)
+    lin.b.assign(b)
+    M, S, V = lin.compute_action(m, s, squash=False)
+    Mq, Sq, Vq = lin.compute_action(m, s, squash=True)
+    Mm, Sm, Vm = mp.conlin(W, b.T, m.T, s)
+    _save("linear_controller.npz", W=W, b=b, m=m, s=s, M=n_(M), S=n_(S), V=n_(V),
+          M_squashed=n_(Mq), S_squashed=n_(Sq), V_squashed=n_(Vq), M_matlab=Mm.T, S_matlab=Sm, V_matlab=Vm)
+
+    np.random.seed(0)
+    m = np.random.rand(1, d)
+    s = np.random.rand(d, d)
+    s = s.dot(s.T)
     e = 7.0
-    M, S, V = mp.gSin(m.T, s, e)
-    np.savez(os.path.join(OUT, "squash.npz"), m=m, s=s, e=e, M=M.T, S=S, V=V)
+    M, S, V = R.controllers.squash_sin(m, s, e)
+    Mm, Sm, Vm = mp.gSin(m.T, s, e)
+    _save("squash.npz", m=m, s=s, e=e, M=n_(M), S=n_(S), V=n_(V), M_matlab=Mm.T, S_matlab=Sm, V_matlab=Vm)
 
 
-def gen_reward():
+def gen_reward(R):
+    """tests/test_rewards.py:13-31 (+ non-default W, t; linear and combined rewards, untested in the reference)."""
     rs = np.random.RandomState(3)
     k = 2
     m = rs.rand(1, k)
     s = rs.rand(k, k)
     s = s.dot(s.T)
-    mu, sr = mp.reward(m.T, s, np.zeros((k, 1)), np.eye(k))
+    r = R.rewards.ExponentialReward(k)
+    mu, sr = r.compute_reward(m, s)
+    mum, srm = mp.reward(m.T, s, np.zeros((k, 1)), np.eye(k))
     W = np.array([[2.0, 0.3], [0.3, 0.5]])
     t = np.array([[0.4, -0.2]])
-    mu2, sr2 = mp.reward(m.T, s, t.T, W)
-    np.savez(os.path.join(OUT, "reward.npz"), m=m, s=s, muR=mu, sR=sr, W2=W, t2=t, muR2=mu2, sR2=sr2)
+    r2 = R.rewards.ExponentialReward(k, W=W, t=t)
+    mu2, sr2 = r2.compute_reward(m, s)
+    mum2, srm2 = mp.reward(m.T, s, t.T, W)
+    Wl = np.array([0.5, -1.0])
+    rl = R.rewards.LinearReward(k, Wl)
+    mul, srl = rl.compute_reward(m, s)
+    rc = R.rewards.CombinedRewards(k, [rl, r], coefs=[2.0, 0.5])
+    muc, src = rc.compute_reward(m, s)
+    f = lambda x: float(n_(x).ravel()[0])
+    _save("reward.npz", m=m, s=s, muR=f(mu), sR=f(sr), W2=W, t2=t, muR2=f(mu2), sR2=f(sr2),
+          muR_matlab=f(mum), sR_matlab=f(srm), muR2_matlab=f(mum2), sR2_matlab=f(srm2),
+          W_lin=Wl, muR_lin=f(mul), sR_lin=f(srl), coefs=np.array([2.0, 0.5]), muR_comb=f(muc), sR_comb=f(src))
+
+
+def gen_policy_gradient(R):
+    """d training_loss / d controller parameters by reverse mode THROUGH THE EXECUTED REFERENCE
+    (pilco.py:47-50,85-90: what gpflow.optimizers.Scipy differentiates), for both controller kinds."""
+    import torch
+    c = synthetic.config_cascade()
+    H = 5
+    Wr, tr = np.array([[1.5, 0.2], [0.2, 0.7]]), np.array([[1.0, 0.3]])
+    np.random.seed(3)
+    pilco = R.PILCO((c["X"], c["Y"]), horizon=H, reward=R.rewards.ExponentialReward(2, W=Wr, t=tr),
+                    m_init=c["m"], S_init=c["s"])
+    pilco.controller.max_action = 2.0
+    _set_hyp(pilco.mgpr.models, c["lengthscales"], c["variance"], c["noise"])
+    pilco.controller.W.assign(c["W"])
+    pilco.controller.b.assign(c["b"])
+    loss = pilco.training_loss()
+    gW, gb = torch.autograd.grad(loss.sum(), [pilco.controller.W.unconstrained_variable,
+                                               pilco.controller.b.unconstrained_variable])
+    out = dict(H=H, W_reward=Wr, t_reward=tr, max_action=2.0, reward=-float(loss.detach().sum()),
+               dreward_dW=-gW.numpy(), dreward_db=-gb.numpy())
+
+    # RBF controller with a combined reward (controllers.py:80-129, rewards.py:64-81)
+    rs = np.random.RandomState(11)
+    Hr, bf = 4, 6
+    Xp, Yp = rs.randn(bf, 2), 0.4 * rs.randn(bf, 1)
+    lsp = 1 + 0.2 * rs.rand(1, 2)
+    Wl = np.array([[0.3], [-0.2]])
+    ctl = R.controllers.RbfController(2, 1, bf, max_action=1.5)
+    ctl.set_data((Xp, Yp))
+    ctl.models[0].kernel.lengthscales.assign(lsp[0])
+    rew = R.rewards.CombinedRewards(2, [R.rewards.ExponentialReward(2), R.rewards.LinearReward(2, Wl)], coefs=[1.0, 0.5])
+    p2 = R.PILCO((c["X"], c["Y"]), horizon=Hr, controller=ctl, reward=rew, m_init=c["m"], S_init=c["s"])
+    _set_hyp(p2.mgpr.models, c["lengthscales"], c["variance"], c["noise"])
+    loss = p2.training_loss()
+    pl = ctl.models[0].kernel.lengthscales
+    gX, gY, gl = torch.autograd.grad(loss.sum(), [ctl.models[0].X.unconstrained_variable,
+                                                  ctl.models[0].Y.unconstrained_variable, pl.unconstrained_variable])
+    dls_du = torch.sigmoid(pl.unconstrained_variable.detach())          # softplus'(u): constrained-space gradient = g / that
+    out.update(rbf_H=Hr, rbf_X=Xp, rbf_Y=Yp, rbf_lengthscales=lsp, rbf_max_action=1.5, rbf_W_lin=Wl,
+               rbf_coefs=np.array([1.0, 0.5]), rbf_reward=-float(loss.detach().sum()),
+               rbf_dreward_dX=-gX.numpy(), rbf_dreward_dY=-gY.numpy(), rbf_dreward_dls=-(gl / dls_du).numpy()[None, :])
+    _save("policy_gradient.npz", **{k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise", "m", "s", "W", "b")}, **out)
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    gen_predictions()
-    gen_sparse()
-    gen_cascade()
-    gen_controllers()
-    gen_reward()
-    # sanity: the independent TF-path restatement must agree before fixtures are trusted
-    g = np.load(os.path.join(OUT, "predictions.npz"))
-    iK, beta = tp.calculate_factorizations(g["X"], g["Y"], g["lengthscales"], g["variance"], g["noise"])
-    M, S, V = tp.predict_given_factorizations(g["X"], g["lengthscales"], g["variance"], g["m"], g["s"], iK, beta)
-    for a, b in ((M, g["M"]), (S, g["S"]), (V, g["V"])):
-        assert np.allclose(a, b, rtol=1e-8, atol=0), "restatements disagree"
-    print("golden fixtures written to", OUT)
+    R = ref_exec.load()
+    gen_predictions(R)
+    gen_sparse(R)
+    gen_cascade(R)
+    gen_controllers(R)
+    gen_reward(R)
+    gen_policy_gradient(R)
+    print("golden fixtures written to", OUT, "from the executed reference")
 
 
 if __name__ == "__main__":

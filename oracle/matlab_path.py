@@ -216,9 +216,9 @@ def reward(m, S, z, W):
     D = m.shape[0]
     SW = S @ W
     iSpW = np.linalg.solve((np.eye(D) + SW).T, W.T).T           # W/(I+SW)
-    muR = float(np.exp(-(m - z).T @ iSpW @ (m - z) / 2.0) / np.sqrt(np.linalg.det(np.eye(D) + SW)))
+    muR = float((np.exp(-(m - z).T @ iSpW @ (m - z) / 2.0) / np.sqrt(np.linalg.det(np.eye(D) + SW))).item())
     i2SpW = np.linalg.solve((np.eye(D) + 2.0 * SW).T, W.T).T
-    r2 = float(np.exp(-(m - z).T @ i2SpW @ (m - z)) / np.sqrt(np.linalg.det(np.eye(D) + 2.0 * SW)))
+    r2 = float((np.exp(-(m - z).T @ i2SpW @ (m - z)) / np.sqrt(np.linalg.det(np.eye(D) + 2.0 * SW))).item())
     sR = r2 - muR ** 2
     if sR < 1e-12:
         sR = 0.0

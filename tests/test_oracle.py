@@ -1,10 +1,10 @@
-"""CPU tests of the oracle itself: the TF-path restatement against the golden
-fixtures produced from the MATLAB-path transliteration (the ground truth the
-reference's tests use), and both against an independent quadrature.
+"""CPU tests of the oracle itself: the TF-path restatement (oracle/tf_path.py) against the golden fixtures, which
+hold the outputs of the reference's own source executed (oracle/gen_golden.py; tests/test_reference_exec.py repeats
+the execution where /root/reference exists), the MATLAB-path transliteration, and both against an independent
+quadrature.  These run anywhere (no /root/reference needed).
 
-Mirrors tests/test_predictions.py, test_sparse_predictions.py, test_cascade.py,
-test_controllers.py, test_rewards.py of the reference (rtol 1e-4 there; the
-oracle must agree far tighter than the 1e-5 the product is held to)."""
+Mirrors tests/test_predictions.py, test_sparse_predictions.py, test_cascade.py, test_controllers.py, test_rewards.py
+of the reference (rtol 1e-4 there; the oracle must agree far tighter than the 1e-5 the product is held to)."""
 import os
 
 import numpy as np
@@ -21,23 +21,31 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
 
-@pytest.mark.parametrize("name,rtol", [("predictions.npz", 1e-8), ("predictions_lownoise.npz", 1e-6)])
-def test_predictions_vs_gp0(golden_dir, name, rtol):
+@pytest.mark.parametrize("name,key,rtol", [("predictions.npz", "", 1e-9), ("predictions.npz", "_mp", 1e-9),
+                                           ("predictions_lownoise.npz", "_mp", 1e-5)])
+def test_predictions_vs_executed_reference_and_truth(golden_dir, name, key, rtol):
+    """key "" = the executed reference, "_mp" = the 40-digit evaluation.  At GPflow's noise floor (the lownoise
+    fixture: the reference's literal, trained procedure) S is only defined to ~1e-5 in float64 -- the executed
+    reference itself is 4e-6 from the truth -- so there the restatement is held to the truth, not to another float64
+    evaluation."""
     g = _load(golden_dir, name)
     iK, beta = tp.calculate_factorizations(g["X"], g["Y"], g["lengthscales"], g["variance"], g["noise"])
     for fn in (tp.predict_given_factorizations, tp.predict_given_factorizations_pairs):
         M, S, V = fn(g["X"], g["lengthscales"], g["variance"], g["m"], g["s"], iK, beta)
         assert M.shape == g["M"].shape and S.shape == g["S"].shape and V.shape == g["V"].shape
-        np.testing.assert_allclose(M, g["M"], rtol=rtol)
-        np.testing.assert_allclose(S, g["S"], rtol=rtol)
-        np.testing.assert_allclose(V, g["V"], rtol=rtol)
+        np.testing.assert_allclose(M, g["M" + key], rtol=rtol)
+        np.testing.assert_allclose(S, g["S" + key], rtol=rtol)
+        np.testing.assert_allclose(V, g["V" + key], rtol=rtol)
 
 
-def test_golden_is_reproducible(golden_dir):
+def test_matlab_path_agrees_with_the_executed_reference(golden_dir):
+    """The reference's own assertion (tests/test_predictions.py:61-63, rtol 1e-4) holds ~1e-10 here."""
     g = _load(golden_dir, "predictions.npz")
+    assert str(g["provenance"]).startswith("reference source executed")
     M, S, V = mp.gp0(g["X"], g["Y"], g["hyp"], g["m"].T, g["s"])
-    np.testing.assert_allclose(M.T, g["M"], rtol=1e-12)
-    np.testing.assert_allclose(S, g["S"], rtol=1e-10)
+    np.testing.assert_allclose(M.T, g["M"], rtol=1e-10)
+    np.testing.assert_allclose(S, g["S"], rtol=1e-9)
+    np.testing.assert_allclose(V, g["V"], rtol=1e-9)
 
 
 def test_sparse_vs_gp1(golden_dir):
@@ -59,7 +67,7 @@ def test_cascade_vs_pred(golden_dir):
         M, S, R = tp.predict(model, ctrl, rew, g["m"], g["s"], H, cache=cache)
         np.testing.assert_allclose(M[0], g["M_traj"][:, -1], rtol=1e-8)
         np.testing.assert_allclose(S, g["S_traj"][:, :, -1], rtol=1e-7)
-    assert R.shape == (1, 1) and 0 < R[0, 0] < H
+        np.testing.assert_allclose(R[0, 0], g["R_traj"][-1], rtol=1e-8)
     # n = 0 returns the inputs and zero reward (Appendix A.10)
     M0, S0, R0 = tp.predict(model, ctrl, rew, g["m"], g["s"], 0)
     assert np.array_equal(M0, g["m"]) and np.array_equal(S0, g["s"]) and R0[0, 0] == 0

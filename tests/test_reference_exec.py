@@ -1,0 +1,291 @@
+"""The oracle pinned to the reference's OWN SOURCE, executed.
+
+One test per reference test file (tests/test_predictions.py, test_sparse_predictions.py, test_cascade.py,
+test_controllers.py, test_rewards.py under /root/reference).  Each one
+  (1) imports the reference's unmodified modules through oracle/ref_exec.py (tensorflow / gpflow stand-ins of
+      oracle/refshim.py) and runs the procedure of the reference's test,
+  (2) repeats the reference's own assertion -- against the MATLAB routine (transliteration, Octave being absent) at
+      the reference's own tolerance,
+  (3) checks that the committed fixture tests/golden/*.npz (which travels to the GPU box) holds exactly these
+      executed outputs, and
+  (4) checks the NumPy restatement oracle/tf_path.py (the thing the GPU parity tests and bench.py's CPU baseline
+      call at sizes without fixtures) against the executed reference.
+/root/reference exists only in the build container: (1)-(3) skip elsewhere; the fixture-vs-restatement checks of
+tests/test_oracle.py always run."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import matlab_path as mp
+from oracle import ref_exec
+from oracle import tf_path as tp
+
+pytestmark = pytest.mark.skipif(not ref_exec.available(), reason="/root/reference is not present on this box")
+n_ = ref_exec.to_np
+TIGHT = 1e-9          # executed reference vs committed fixture / vs the NumPy restatement (well-conditioned cases)
+
+
+@pytest.fixture(scope="module")
+def R():
+    return ref_exec.load()
+
+
+def _g(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name))
+    assert str(g["provenance"]).startswith("reference source executed")
+    return g
+
+
+def _set_hyp(models, g):
+    for i, m in enumerate(models):
+        m.kernel.lengthscales.assign(g["lengthscales"][i])
+        m.kernel.variance.assign(g["variance"][i])
+        m.likelihood.variance.assign(g["noise"][i])
+
+
+def test_reference_modules_come_from_the_reference_tree(R):
+    import inspect
+    for mod in (R.pilco.models.mgpr, R.pilco.models.smgpr, R.pilco.models.pilco, R.controllers, R.rewards):
+        assert inspect.getsourcefile(mod).startswith(ref_exec.REFERENCE_ROOT)
+    # the stand-ins do not stay importable by unrelated code
+    import sys
+    assert "tensorflow" not in sys.modules and "gpflow" not in sys.modules
+
+
+def test_predictions(R, golden_dir):
+    """tests/test_predictions.py:13-63 (fixed hyper-parameters), incl. the set_data stale-cache step."""
+    g = _g(golden_dir, "predictions.npz")
+    mgpr = R.MGPR((g["X_first"], g["Y"]))
+    _set_hyp(mgpr.models, g)
+    M1, S1, V1 = [n_(x) for x in mgpr.predict_on_noisy_inputs(g["m"], g["s"])]
+    mgpr.set_data((g["X"], g["Y"]))
+    M, S, V = [n_(x) for x in mgpr.predict_on_noisy_inputs(g["m"], g["s"])]
+    assert not np.allclose(M1, M)
+    # (2) the reference's assertion, at its tolerance (test_predictions.py:58-63)
+    M_mat, S_mat, V_mat = mp.gp0(g["X"], g["Y"], g["hyp"], g["m"].T, g["s"])
+    assert M.shape == M_mat.T.shape and S.shape == S_mat.shape and V.shape == V_mat.shape
+    for a, b in ((M, M_mat.T), (S, S_mat), (V, V_mat)):
+        np.testing.assert_allclose(a, b, rtol=1e-4)
+    # (3) fixture == executed reference
+    for a, k in ((M, "M"), (S, "S"), (V, "V"), (M1, "M_first"), (S1, "S_first"), (V1, "V_first")):
+        np.testing.assert_allclose(a, g[k], rtol=TIGHT)
+    # (4) restatement == executed reference
+    iK, beta = tp.calculate_factorizations(g["X"], g["Y"], g["lengthscales"], g["variance"], g["noise"])
+    iKr, betar = [n_(x) for x in mgpr.calculate_factorizations()]
+    np.testing.assert_allclose(beta, betar, rtol=1e-7)
+    np.testing.assert_allclose(iK, iKr, rtol=1e-6, atol=1e-6 * np.abs(iKr).max())
+    for fn in (tp.predict_given_factorizations, tp.predict_given_factorizations_pairs):
+        Mt, St, Vt = fn(g["X"], g["lengthscales"], g["variance"], g["m"], g["s"], iK, beta)
+        for a, b in ((Mt, M), (St, S), (Vt, V)):
+            np.testing.assert_allclose(a, b, rtol=TIGHT)
+    # the K the reference builds (mgpr.py:154-157 -> gpflow SquaredExponential, restated from recollection) vs tf_path
+    np.testing.assert_allclose(n_(mgpr.K(g["X"])), tp.se_ard_K(g["X"], None, g["lengthscales"], g["variance"]), rtol=1e-12)
+
+
+def test_predictions_at_the_noise_floor_conditioning(golden_dir):
+    """The literal reference procedure (MGPR.optimize() drives the noise to GPflow's 1e-6 floor): every float64
+    evaluation -- the executed reference included -- is several 1e-6 away from the 40-digit truth in S, and the
+    reference is 1.4e-5 from its own MATLAB oracle (its test allows 1e-4)."""
+    g = _g(golden_dir, "predictions_lownoise.npz")
+    rel = lambda a, b: np.max(np.abs(a - b) / np.abs(b))
+    assert np.all(g["noise"] < 1.1e-6)
+    assert rel(g["S"], g["S_mp"]) < 1e-5 and rel(g["S_matlab"], g["S_mp"]) < 2e-5
+    assert rel(g["S"], g["S_matlab"]) < 1e-4                       # the reference's own assertion
+    assert rel(g["M"], g["M_mp"]) < 1e-8 and rel(g["V"], g["V_mp"]) < 1e-8
+    iK, beta = tp.calculate_factorizations(g["X"], g["Y"], g["lengthscales"], g["variance"], g["noise"])
+    M, S, V = tp.predict_given_factorizations(g["X"], g["lengthscales"], g["variance"], g["m"], g["s"], iK, beta)
+    assert rel(S, g["S_mp"]) < 1e-5 and rel(M, g["M_mp"]) < 1e-8 and rel(V, g["V_mp"]) < 1e-8
+
+
+def test_sparse_predictions(R, golden_dir):
+    """tests/test_sparse_predictions.py:12-57."""
+    g = _g(golden_dir, "sparse_predictions.npz")
+    np.random.seed(11)
+    sm = R.SMGPR((g["X"], g["Y"]), num_induced_points=30)
+    _set_hyp(sm.models, g)
+    sm.models[0].inducing_variable.Z.assign(g["Z"])
+    M, S, V = [n_(x) for x in sm.predict_on_noisy_inputs(g["m"], g["s"])]
+    M_mat, S_mat, V_mat = mp.gp1(g["X"], g["Y"], g["hyp"], n_(sm.Z), g["m"].T, g["s"])
+    for a, b in ((M, M_mat.T), (S, S_mat), (V, V_mat)):
+        np.testing.assert_allclose(a, b, rtol=1e-4)
+    for a, k in ((M, "M"), (S, "S"), (V, "V")):
+        np.testing.assert_allclose(a, g[k], rtol=1e-8)
+    iK, beta = tp.fitc_factorizations(g["X"], g["Y"], g["Z"], g["lengthscales"], g["variance"], g["noise"])
+    np.testing.assert_allclose(beta, g["beta"], rtol=1e-6)
+    Mt, St, Vt = tp.predict_given_factorizations(g["Z"], g["lengthscales"], g["variance"], g["m"], g["s"], iK, beta)
+    for a, b in ((Mt, M), (St, S), (Vt, V)):
+        np.testing.assert_allclose(a, b, rtol=1e-7)
+
+
+def test_cascade(R, golden_dir):
+    """tests/test_cascade.py:17-78: PILCO.predict, H = 10, LinearController with max_action [[10]]; every
+    intermediate state and the running reward are pinned too (the reference compares the final state only)."""
+    g = _g(golden_dir, "cascade.npz")
+    np.random.seed(5)
+    pilco = R.PILCO((g["X"], g["Y"]))
+    pilco.controller.max_action = g["max_action"]
+    _set_hyp(pilco.mgpr.models, g)
+    pilco.controller.W.assign(g["W"])
+    pilco.controller.b.assign(g["b"])
+    H = int(g["horizon"])
+    M, S, reward = [n_(x) for x in pilco.predict(g["m"], g["s"], H)]
+    M_mat, S_mat = mp.pred(g["m"].T, g["s"], H, g["X"], g["Y"], g["hyp"], g["W"], g["b"].T, g["max_action"])
+    np.testing.assert_allclose(M[0], M_mat[:, -1].T, rtol=2e-4)       # test_cascade.py:77-78
+    np.testing.assert_allclose(S, S_mat[:, :, -1], rtol=2e-4)
+    np.testing.assert_allclose(M[0], g["M_traj"][:, -1], rtol=TIGHT)
+    np.testing.assert_allclose(S, g["S_traj"][:, :, -1], rtol=TIGHT)
+    np.testing.assert_allclose(reward.ravel()[0], g["R_traj"][-1], rtol=TIGHT)
+    # restatement: every step, reward included; cached and re-factorised
+    model = tp.Model(g["X"], g["Y"], g["lengthscales"], g["variance"], g["noise"])
+    ctrl = lambda m, s: tp.linear_controller(m, s, g["W"], g["b"], g["max_action"])
+    for n in range(H + 1):
+        Mt, St, Rt = tp.predict(model, ctrl, tp.exponential_reward, g["m"], g["s"], n, cache=True)
+        np.testing.assert_allclose(Mt[0], g["M_traj"][:, n], rtol=1e-8)
+        np.testing.assert_allclose(St, g["S_traj"][:, :, n], rtol=1e-7)
+        np.testing.assert_allclose(Rt[0, 0], g["R_traj"][n], rtol=1e-8, atol=1e-300)
+    # n = 0 returns the inputs and zero reward (examples/safe_cars_run.py:110)
+    M0, S0, R0 = pilco.predict(g["m"], g["s"], 0)
+    assert np.array_equal(n_(M0), g["m"]) and np.array_equal(n_(S0), g["s"]) and float(n_(R0).ravel()[0]) == 0.0
+    # compute_action evaluates at zero covariance (pilco.py:115-116)
+    u = n_(pilco.compute_action(g["m"]))
+    ut = tp.linear_controller(g["m"], np.zeros((2, 2)), g["W"], g["b"], g["max_action"])[0]
+    np.testing.assert_allclose(u, ut, rtol=1e-12)
+
+
+def test_cascade_trained_fixture(golden_dir):
+    """The literal procedure (optimize_models(restarts=5), optimize_policy(restarts=5), seed 0) was executed once by
+    oracle/gen_golden.py (2 min); here its stored outputs are checked against the MATLAB routine at the reference's
+    tolerance and against the restatement."""
+    g = _g(golden_dir, "cascade_trained.npz")
+    H = int(g["horizon"])
+    np.testing.assert_allclose(g["M_traj"][:, -1], g["M_traj_matlab"][:, -1], rtol=2e-4)
+    np.testing.assert_allclose(g["S_traj"][:, :, -1], g["S_traj_matlab"][:, :, -1], rtol=2e-4)
+    model = tp.Model(g["X"], g["Y"], g["lengthscales"], g["variance"], g["noise"])
+    ctrl = lambda m, s: tp.linear_controller(m, s, g["W"], g["b"], g["max_action"])
+    Mt, St, Rt = tp.predict(model, ctrl, tp.exponential_reward, g["m"], g["s"], H, cache=True)
+    np.testing.assert_allclose(Mt[0], g["M_traj"][:, -1], rtol=1e-5)
+    np.testing.assert_allclose(St, g["S_traj"][:, :, -1], rtol=1e-5)
+    np.testing.assert_allclose(Rt[0, 0], g["R_traj"][-1], rtol=1e-6)
+
+
+def test_controllers(R, golden_dir):
+    """tests/test_controllers.py:13-113: RbfController vs gp2.m, LinearController vs conlin.m, squash_sin vs gSin.m."""
+    g = _g(golden_dir, "rbf_controller.npz")
+    rbf = R.controllers.RbfController(3, 2, 100)
+    rbf.set_data((g["X"], g["Y"]))
+    for i, mdl in enumerate(rbf.models):
+        mdl.kernel.lengthscales.assign(g["lengthscales"][i])
+    M, S, V = [n_(x) for x in rbf.compute_action(g["m"], g["s"], squash=False)]
+    lengthscales = np.stack([n_(m.kernel.lengthscales) for m in rbf.models])
+    variance = np.stack([n_(m.kernel.variance) for m in rbf.models]).reshape(-1)
+    noise = np.stack([n_(m.likelihood.variance) for m in rbf.models]).reshape(-1)
+    np.testing.assert_allclose(variance, 1.0, rtol=1e-12)
+    np.testing.assert_allclose(noise, 1e-4, rtol=1e-9)
+    M_mat, S_mat, V_mat = mp.gp2(g["X"], g["Y"], mp.hyp_from(lengthscales, variance, noise), g["m"].T, g["s"])
+    for a, b in ((M, M_mat.T), (S, S_mat), (V, V_mat)):
+        np.testing.assert_allclose(a, b, rtol=1e-4)
+    for a, k in ((M, "M"), (S, "S"), (V, "V")):
+        np.testing.assert_allclose(a, g[k], rtol=1e-8)
+    Mt, St, Vt = tp.rbf_controller(g["m"], g["s"], g["X"], g["Y"], g["lengthscales"], squash=False)
+    for a, b in ((Mt, M), (St, S), (Vt, V)):
+        np.testing.assert_allclose(a, b, rtol=1e-7)
+    Mq, Sq, Vq = [n_(x) for x in rbf.compute_action(g["m"], g["s"], squash=True)]
+    Mt, St, Vt = tp.rbf_controller(g["m"], g["s"], g["X"], g["Y"], g["lengthscales"], squash=True)
+    for a, b in ((Mt, Mq), (St, Sq), (Vt, Vq)):
+        np.testing.assert_allclose(a, b, rtol=1e-7)
+
+    g = _g(golden_dir, "linear_controller.npz")
+    lin = R.controllers.LinearController(3, 2)
+    lin.W.assign(g["W"])
+    lin.b.assign(g["b"])
+    M, S, V = [n_(x) for x in lin.compute_action(g["m"], g["s"], squash=False)]
+    M_mat, S_mat, V_mat = mp.conlin(g["W"], g["b"].T, g["m"].T, g["s"])
+    np.testing.assert_allclose(S, S_mat, rtol=1e-4)
+    np.testing.assert_allclose(V, V_mat, rtol=1e-4)
+    Mt, St, Vt = tp.linear_controller(g["m"], g["s"], g["W"], g["b"], squash=False)
+    for a, b, k in ((Mt, M, "M"), (St, S, "S"), (Vt, V, "V")):
+        np.testing.assert_allclose(a, b, rtol=1e-13)
+        np.testing.assert_allclose(b, g[k], rtol=1e-13)
+
+    g = _g(golden_dir, "squash.npz")
+    M, S, V = [n_(x) for x in R.controllers.squash_sin(g["m"], g["s"], float(g["e"]))]
+    M_mat, S_mat, V_mat = mp.gSin(g["m"].T, g["s"], float(g["e"]))
+    for a, b in ((M, M_mat.T), (S, S_mat), (V, V_mat)):
+        np.testing.assert_allclose(a, b, rtol=1e-4)
+    Mt, St, Vt = tp.squash_sin(g["m"], g["s"], float(g["e"]))
+    for a, b, k in ((Mt, M, "M"), (St, S, "S"), (Vt, V, "V")):
+        np.testing.assert_allclose(a, b, rtol=1e-12)
+        np.testing.assert_allclose(b, g[k], rtol=1e-12)
+
+
+def test_rewards(R, golden_dir):
+    """tests/test_rewards.py:13-31 (default rtol 1e-7 there), plus the reward classes the reference leaves untested."""
+    g = _g(golden_dir, "reward.npz")
+    k = 2
+    r = R.rewards.ExponentialReward(k)
+    mu, sr = [float(n_(x).ravel()[0]) for x in r.compute_reward(g["m"], g["s"])]
+    mu_mat, sr_mat = mp.reward(g["m"].T, g["s"], np.zeros((k, 1)), np.eye(k))
+    np.testing.assert_allclose(mu, np.ravel(mu_mat)[0], rtol=1e-7)
+    np.testing.assert_allclose(sr, np.ravel(sr_mat)[0], rtol=1e-7)
+    np.testing.assert_allclose([mu, sr], [g["muR"], g["sR"]], rtol=1e-12)
+    mut, srt = tp.exponential_reward(g["m"], g["s"])
+    np.testing.assert_allclose([mut[0, 0], srt[0, 0]], [mu, sr], rtol=1e-10)
+    r2 = R.rewards.ExponentialReward(k, W=g["W2"], t=g["t2"])
+    mu2, sr2 = [float(n_(x).ravel()[0]) for x in r2.compute_reward(g["m"], g["s"])]
+    mut, srt = tp.exponential_reward(g["m"], g["s"], g["W2"], g["t2"])
+    np.testing.assert_allclose([mut[0, 0], srt[0, 0]], [mu2, sr2], rtol=1e-10)
+    np.testing.assert_allclose([mu2, sr2], [g["muR2"], g["sR2"]], rtol=1e-12)
+    rl = R.rewards.LinearReward(k, g["W_lin"])
+    rc = R.rewards.CombinedRewards(k, [rl, r], coefs=g["coefs"])
+    muc, src = [float(n_(x).ravel()[0]) for x in rc.compute_reward(g["m"], g["s"])]
+    mut, srt = tp.combined_rewards(g["m"], g["s"], [lambda m, s: tp.linear_reward(m, s, g["W_lin"]), tp.exponential_reward],
+                                   g["coefs"])
+    np.testing.assert_allclose([np.ravel(mut)[0], np.ravel(srt)[0]], [muc, src], rtol=1e-10)
+    np.testing.assert_allclose([muc, src], [g["muR_comb"], g["sR_comb"]], rtol=1e-12)
+
+
+def test_policy_gradient_through_the_executed_reference(R, golden_dir):
+    """Reverse mode through the reference's own training_loss (pilco.py:47-50; what its optimiser differentiates,
+    pilco.py:85-90) agrees with autograd of the torch restatement the GPU gradient tests use (oracle/torch_path.py)
+    and with the committed fixture."""
+    import torch
+    from oracle import torch_path as tq
+    g = _g(golden_dir, "policy_gradient.npz")
+    H = int(g["H"])
+    np.random.seed(3)
+    pilco = R.PILCO((g["X"], g["Y"]), horizon=H, reward=R.rewards.ExponentialReward(2, W=g["W_reward"], t=g["t_reward"]),
+                    m_init=g["m"], S_init=g["s"])
+    pilco.controller.max_action = float(g["max_action"])
+    _set_hyp(pilco.mgpr.models, g)
+    pilco.controller.W.assign(g["W"])
+    pilco.controller.b.assign(g["b"])
+    loss = pilco.training_loss()
+    gW, gb = torch.autograd.grad(loss.sum(), [pilco.controller.W.unconstrained_variable,
+                                               pilco.controller.b.unconstrained_variable])
+    np.testing.assert_allclose(-gW.numpy(), g["dreward_dW"], rtol=1e-9)
+    np.testing.assert_allclose(-gb.numpy(), g["dreward_db"], rtol=1e-9)
+    iK, beta = tp.calculate_factorizations(g["X"], g["Y"], g["lengthscales"], g["variance"], g["noise"])
+    Wt = torch.tensor(g["W"], dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(g["b"], dtype=torch.float64, requires_grad=True)
+    gp = lambda m, s: tq.predict_given_factorizations(g["X"], g["lengthscales"], g["variance"], m, s, iK, beta)
+    ctl = lambda m, s: tq.linear_controller(m, s, Wt, bt, float(g["max_action"]))
+    rw = lambda m, s: tq.exponential_reward(m, s, g["W_reward"], g["t_reward"])
+    _, _, Rr = tq.predict(gp, ctl, rw, tq.t(g["m"]), tq.t(g["s"]), H)
+    Rr.sum().backward()
+    np.testing.assert_allclose(Rr.item(), g["reward"], rtol=1e-9)
+    np.testing.assert_allclose(Wt.grad.numpy(), g["dreward_dW"], rtol=1e-7)
+    np.testing.assert_allclose(bt.grad.numpy(), g["dreward_db"], rtol=1e-7)
+
+
+def test_product_never_imports_the_oracle_or_the_shim():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(root, "pilco_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                for needle in ("import oracle", "from oracle", "refshim", "ref_exec", "import torch", "tensorflow"):
+                    if needle in src:
+                        bad.append((f, needle))
+    assert not bad, bad
