@@ -40,38 +40,61 @@ def algorithmic_work(n, d, e):
     return exps, flop, byts
 
 
-def cpu_baseline(cfg):
-    """Time the NumPy restatement of the GPflow CPU path (oracle/tf_path.py) on a
-    bounded sample: one factorisation + 3 cached moment-matching steps."""
+def cpu_baseline(cfg, steps=5):
+    """Time the NumPy restatement of the GPflow CPU path (oracle/tf_path.py) on a bounded sample of the SAME
+    workload: one factorisation, then the first `steps` horizon steps of the benchmarked rollout executed for real
+    (reward, propagate, state carried over)."""
     from oracle import tf_path as tp
+    model = tp.Model(cfg["X"], cfg["Y"], cfg["lengthscales"], cfg["variance"], cfg["noise"], pairs=True)
     t0 = time.perf_counter()
-    iK, beta = tp.calculate_factorizations(cfg["X"], cfg["Y"], cfg["lengthscales"], cfg["variance"], cfg["noise"])
+    model._cache = model.factorize()
     t_fact = time.perf_counter() - t0
     m, s = cfg["m0"], cfg["S0"]
     ts = []
-    for _ in range(3):
+    for _ in range(steps):
         t0 = time.perf_counter()
-        tp.predict_given_factorizations_pairs(cfg["X"], cfg["lengthscales"], cfg["variance"], m, s, iK, beta)
+        tp.exponential_reward(m, s)
+        m, s = tp.propagate(model, tp.no_controller, m, s, cache=True)
         ts.append(time.perf_counter() - t0)
     t_step = float(np.median(ts))
-    return dict(value=1.0 / (H * t_step), unit="rollouts/s", cores=os.cpu_count(), kind="port",
-                sample=("NumPy+OpenBLAS restatement of the GPflow path (oracle/tf_path.py, 55 symmetric pairs): "
-                        "1 factorisation (%.2f s) + 3 moment-matching steps (median %.3f s); rollouts/s = "
-                        "1/(40*t_step), factorisation cached; re-factorising every step as the reference does "
-                        "(mgpr.py:77-79) would give %.4f rollouts/s" % (t_fact, t_step, 1.0 / (H * (t_step + t_fact)))))
+    threads = None
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max((p.get("num_threads", 0) for p in threadpool_info()), default=None)
+    except Exception:
+        pass
+    return dict(value=1.0 / (H * t_step), unit="rollouts/s", cores=threads or os.cpu_count(), kind="port",
+                host_cpu_count=os.cpu_count(),
+                sample=("NumPy+OpenBLAS restatement of the GPflow path (oracle/tf_path.py, 55 symmetric pairs), fp64: "
+                        "1 factorisation (%.2f s) + the first %d horizon steps of the benchmarked rollout executed for real "
+                        "(median %.3f s per step); value = 1/(40 * t_step) with the factorisation cached; re-factorising "
+                        "every step as the reference does (mgpr.py:77-79) gives %.4f rollouts/s"
+                        % (t_fact, steps, t_step, 1.0 / (H * (t_step + t_fact)))))
 
 
-def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout):
-    """The other two variants SURVEY.md 8(d) asks for, measured after the timed region (1 GPU):
-    R-fwd+fact (factorise once, then roll out: what a fresh model pays) and R-grad (value + gradient of the
-    rollout reward w.r.t. a linear controller at C2u: state 10 + 1 control, D=11)."""
+def _median_ms(fn, reps):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+
+
+def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
+    """Everything else SURVEY.md 8(d) / BASELINE.md section 3 ask for, measured AFTER the timed region (1 GPU):
+    back-to-back graph replays (no host sync between rollouts), R-fwd+fact, R-grad at C2u, config 4 (SMGPR)."""
     from pilco_amd import synthetic
     from pilco_amd.adjoint import rollout_value_and_grad
     from pilco_amd.models import PILCO
     out = {}
+    res = ctx.rollout_timed(policy, rewards, cfg["m0"], cfg["S0"], H, steps, time_pair=False)
+    out["back_to_back_rollouts_per_s"] = steps * 1e3 / res["ms_total"]
+    out["back_to_back_note"] = "hipGraph replays queued without a host sync or result download in between (hipEvent-timed)"
     fact_ms = ctx.factorize_timed(0, 5)
     out["factorisation_ms"] = fact_ms
     out["R_fwd_fact_rollouts_per_s"] = 1e3 / (fact_ms + ms_rollout)
+    # ---- C2u: value + gradient w.r.t. a linear controller (state 10 + 1 control, D = 11)
     cu = synthetic.config_c2(N=N, D=D + 1, E=E)
     p = PILCO((cu["X"], cu["Y"]), horizon=H, ctx=ctx)
     for i, mdl in enumerate(p.mgpr.models):
@@ -83,22 +106,42 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout):
     p.controller.max_action = 1.0
     p.m_init, p.S_init = cu["m0"], cu["S0"]
     rollout_value_and_grad(p)
-    t0 = time.perf_counter()
-    for _ in range(3):
-        rollout_value_and_grad(p)
-    g_ms = (time.perf_counter() - t0) / 3 * 1e3
+    g_ms = _median_ms(lambda: rollout_value_and_grad(p), 5)
     p.compute_reward()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        p.compute_reward()
-    f_ms = (time.perf_counter() - t0) / 3 * 1e3
+    f_ms = _median_ms(p.compute_reward, 5)
     out["R_grad_C2u_ms"] = g_ms
     out["R_grad_C2u_per_s"] = 1e3 / g_ms
     out["R_fwd_C2u_ms"] = f_ms
+    # ---- config 4: SMGPR (M=200, N=5000, D=10, E=10), FITC factorisation + rollout
+    c4 = synthetic.config_c4()
+    ctx.gp_set_data(0, c4["X"], c4["Y"])
+    ctx.gp_set_hyp(0, c4["lengthscales"], c4["variance"], c4["noise"])
+    ctx.gp_set_inducing(0, c4["Z"])
+    ctx.gp_factorize(0)
+    out["config4_fitc_factorisation_ms"] = ctx.factorize_timed(0, 5)
+    ctx.rollout(policy, rewards, c4["m0"], c4["S0"], H)
+    r4 = _median_ms(lambda: ctx.rollout(policy, rewards, c4["m0"], c4["S0"], H), 10)
+    out["config4_rollout_ms"] = r4
+    out["config4_rollouts_per_s"] = 1e3 / r4
     # restore the benchmark model in slot 0
+    ctx.gp_set_inducing(0, None)
     ctx.gp_set_data(0, cfg["X"], cfg["Y"])
     ctx.gp_set_hyp(0, cfg["lengthscales"], cfg["variance"], cfg["noise"])
     return out
+
+
+def verify_against_reference(mH, SH, reward):
+    """The timed rollout's result against tests/golden/c2_rollout.npz: the reference's own source executed at this
+    exact configuration (oracle/gen_golden_c2.py).  Raises when the 1e-5 relative tolerance of north_star is missed."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "c2_rollout.npz"))
+    assert int(g["N"]) == N and int(g["D"]) == D and int(g["E"]) == E and int(g["H"]) == H
+    Mr, Sr, Rr = g["M_traj"][:, -1], g["S_traj"][:, :, -1], float(g["R_traj"][-1])
+    rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - b) / np.maximum(np.abs(b), 1e-300)))
+    errs = {"m_H": rel(mH.ravel(), Mr), "S_H": rel(SH, Sr), "reward": rel([reward], [Rr])}
+    bad = {k: v for k, v in errs.items() if not v <= 1e-5}
+    if bad:
+        raise SystemExit("bench.py: the timed rollout does not match the executed reference (rtol 1e-5): %r" % bad)
+    return dict(against="tests/golden/c2_rollout.npz (reference source executed, H=40)", rtol=1e-5, max_rel_err=errs)
 
 
 def main():
@@ -137,15 +180,23 @@ def main():
     policy = dict(kind=_lib.POLICY_NONE, state_dim=E, control_dim=0)
     rewards = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(E), t=np.zeros(E))]
 
-    # warm-up (untimed)
-    if args.warmup > 0:
-        ctx.rollout_timed(policy, rewards, cfg["m0"], cfg["S0"], H, args.warmup, time_pair=False)
+    # One step = ONE call of pilco_rollout -- the entry PILCO.predict (pilco.py:118-136) makes: host buffers in, the whole
+    # H = 40 rollout on the device, (m_H, S_H, reward) downloaded, host-synchronised.  The model (X, beta, iK, ...) is
+    # resident in HBM; per call only (m0, S0) go up and E + E*E + 1 doubles come down.
+    def one_rollout():
+        return ctx.rollout(policy, rewards, cfg["m0"], cfg["S0"], H)
 
+    for _ in range(args.warmup):
+        one_rollout()
     if dist is not None:
         dist.barrier()
-    t0 = time.perf_counter()
-    res = ctx.rollout_timed(policy, rewards, cfg["m0"], cfg["S0"], H, args.steps, time_pair=False)  # syncs inside
-    wall_ms = (time.perf_counter() - t0) * 1e3
+    per_call = []
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        mH, SH, rew = one_rollout()          # returns after hipStreamSynchronize + download
+        per_call.append((time.perf_counter() - t0) * 1e3)
+    wall_ms = (time.perf_counter() - t_begin) * 1e3
     if dist is not None:
         dist.barrier()
         import torch
@@ -153,6 +204,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall_ms = float(t.item())
     ms_per_rollout = wall_ms / args.steps
+    verified = verify_against_reference(mH, SH, float(rew[0, 0])) if rank == 0 else None
 
     # dominant kernel (pair kernel): its own HIP-event pairs on the launch stream, separate pass
     prof = ctx.rollout_timed(policy, rewards, cfg["m0"], cfg["S0"], H, 1, time_pair=True)
@@ -161,14 +213,17 @@ def main():
     flop_local = flop / world  # pairs are dealt over the ranks
     achieved = flop_local / (pair_ms * 1e-3) / 1e12 if pair_ms > 0 else 0.0
 
-    # HBM bytes per pair-kernel launch: PMC counters of the committed rocprofv3 profile of this same
-    # command (profiles/r01_pmc_summary.json: 2*FETCH_SIZE + WRITE_SIZE, see the calibration note there)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-            traffic = json.load(f)["pair_kernel_hbm_bytes_per_launch"] / world
-    except Exception:
-        traffic = None
+    # HBM bytes per pair-kernel launch: PMC counters (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes) of the committed
+    # rocprofv3 profile of this same command, newest round first; a live run cannot collect counters on itself
+    traffic, traffic_src = None, None
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic = json.load(f)["pair_kernel_hbm_bytes_per_launch"] / world
+            traffic_src = "profiles/" + name
+            break
+        except Exception:
+            continue
 
     # N > 1 only: the zero-communication alternative (SURVEY.md 8(e) "Alternative DP"): every rank also runs the whole
     # rollout on its own GPU (an unsharded second context); the aggregate is reported under "secondary", never as `value`.
@@ -181,9 +236,11 @@ def main():
             ctx2.gp_set_data(0, cfg["X"], cfg["Y"])
             ctx2.gp_set_hyp(0, cfg["lengthscales"], cfg["variance"], cfg["noise"])
             ctx2.gp_factorize(0)
-            ctx2.rollout_timed(policy, rewards, cfg["m0"], cfg["S0"], H, max(args.warmup, 1), time_pair=False)
+            for _ in range(max(args.warmup, 1)):
+                ctx2.rollout(policy, rewards, cfg["m0"], cfg["S0"], H)
             t0 = time.perf_counter()
-            ctx2.rollout_timed(policy, rewards, cfg["m0"], cfg["S0"], H, args.steps, time_pair=False)
+            for _ in range(args.steps):
+                ctx2.rollout(policy, rewards, cfg["m0"], cfg["S0"], H)
             local_ms = (time.perf_counter() - t0) * 1e3
         except Exception as exc:
             err = repr(exc)
@@ -211,10 +268,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: N=1000 D=10 E=10 H=40 full rollout + reward, "
                                    "control_dim=0 (D==E read literally), ExponentialReward(W=I,t=0), "
-                                   "factorisation cached (R-fwd)",
-                       "parallelism": "pairs%d" % world, "event_ms_per_rollout": res["ms_total"] / args.steps},
+                                   "factorisation cached (R-fwd); one step = one host-synchronised pilco_rollout call "
+                                   "(what PILCO.predict makes) with its result downloaded",
+                       "parallelism": "pairs%d" % world,
+                       "median_ms_per_call": float(np.median(per_call)), "min_ms_per_call": float(np.min(per_call)),
+                       "max_ms_per_call": float(np.max(per_call))},
+            "verified": verified,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_mm_pair_sk (f64 MFMA exponent tiles + fp64 exp; MFMA and fp64 VALU share one pipe)",
                          "avg_launch_ms": pair_ms,
                          "algorithmic_flop_per_launch": flop_local, "exp_per_launch": exps / world,
@@ -223,7 +284,7 @@ def main():
                          "hbm_GBps_algorithmic": byts / world / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0},
         }
         if world == 1 and not args.no_secondary:
-            out["secondary"] = secondary_metrics(ctx, cfg, policy, rewards, ms_per_rollout)
+            out["secondary"] = secondary_metrics(ctx, cfg, policy, rewards, ms_per_rollout, args.steps)
         if replicas is not None:
             out["secondary"] = replicas
         if world == 1 and not args.no_cpu_baseline:

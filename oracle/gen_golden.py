@@ -281,6 +281,28 @@ def gen_policy_gradient(R):
     _save("policy_gradient.npz", **{k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise", "m", "s", "W", "b")}, **out)
 
 
+def gen_safe():
+    """safe_pilco_extension/safe_pilco.py:29-50 + rewards_safe.py:27-61 executed (untested in the reference)."""
+    R = ref_exec.load(safe=True)
+    c = synthetic.config_cascade()
+    H, mu = 4, 3.0
+    np.random.seed(2)
+    risk = R.rewards_safe.SingleConstraint(0, high=1.2, inside=False)
+    p = R.safe_pilco.SafePILCO((c["X"], c["Y"]), horizon=H, reward_add=R.rewards.ExponentialReward(2), reward_mult=risk, mu=mu,
+                               m_init=c["m"], S_init=c["s"])
+    _set_hyp(p.mgpr.models, c["lengthscales"], c["variance"], c["noise"])
+    p.controller.W.assign(c["W"])
+    p.controller.b.assign(c["b"])
+    p.controller.max_action = c["max_action"]
+    M, S, Rt = p.predict(c["m"], c["s"], H)
+    import torch
+    loss = p.training_loss()
+    gW, gb = torch.autograd.grad(loss.sum(), [p.controller.W.unconstrained_variable, p.controller.b.unconstrained_variable])
+    _save("safe_pilco.npz", **{k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise", "m", "s", "W", "b", "max_action")},
+          H=H, mu=mu, high=1.2, M=n_(M), S=n_(S), reward_total=float(n_(Rt).ravel()[0]),
+          dtotal_dW=-gW.numpy(), dtotal_db=-gb.numpy())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = ref_exec.load()
@@ -290,6 +312,7 @@ def main():
     gen_controllers(R)
     gen_reward(R)
     gen_policy_gradient(R)
+    gen_safe()
     print("golden fixtures written to", OUT, "from the executed reference")
 
 

@@ -146,6 +146,9 @@ class Context:
         self.h = h
         self.device = int(device)
         self._keep = []
+        # which Python model last pushed its data / hyper-parameters into each device slot: several MGPR / SMGPR /
+        # RbfController instances may share one context, but a slot holds ONE model at a time (see MGPR._sync)
+        self._slot_owner = {}
 
     def close(self):
         if getattr(self, "h", None):
@@ -172,18 +175,21 @@ class Context:
     def set_pair_kernel(self, variant):
         self._chk(self.lib.pilco_set_pair_kernel(self.h, int(variant)))
 
-    def gp_set_data(self, slot, X, Y):
+    def gp_set_data(self, slot, X, Y, owner=None):
+        self._slot_owner[slot] = owner     # a direct caller (owner None) invalidates whatever a model believed about the slot
         X = _f64(X)
         Y = _f64(Y)
         if X.ndim != 2 or Y.ndim != 2 or X.shape[0] != Y.shape[0]:
             raise ValueError("data must be (X (N,D), Y (N,E))")
         self._chk(self.lib.pilco_gp_set_data(self.h, slot, _ptr(X), _ptr(Y), X.shape[0], X.shape[1], Y.shape[1]))
 
-    def gp_set_hyp(self, slot, lengthscales, variance, noise):
+    def gp_set_hyp(self, slot, lengthscales, variance, noise, owner=None):
+        self._slot_owner[slot] = owner
         ls, var, nz = _f64(lengthscales), _f64(variance).reshape(-1), _f64(noise).reshape(-1)
         self._chk(self.lib.pilco_gp_set_hyp(self.h, slot, _ptr(ls), _ptr(var), _ptr(nz)))
 
-    def gp_set_inducing(self, slot, Z):
+    def gp_set_inducing(self, slot, Z, owner=None):
+        self._slot_owner[slot] = owner
         if Z is None:
             self._chk(self.lib.pilco_gp_set_inducing(self.h, slot, None, 0))
         else:
@@ -217,7 +223,8 @@ class Context:
         self._chk(self.lib.pilco_gp_get_factors(self.h, slot, _ptr(iK), _ptr(beta)))
         return iK, beta
 
-    def gp_set_factors(self, slot, iK, beta):
+    def gp_set_factors(self, slot, iK, beta, owner=None):
+        self._slot_owner[slot] = owner
         iKa = None if iK is None else _f64(iK)
         beta = _f64(beta)
         self._chk(self.lib.pilco_gp_set_factors(self.h, slot, _ptr(iKa), _ptr(beta)))

@@ -56,6 +56,26 @@ class LinearController:
         return [p for p in (self.W, self.b) if p.trainable]
 
 
+class _PolicyData(Parameter):
+    """The centres X / targets Y of an RbfController as gpflow-like Parameters (controllers.py:70-73: both are
+    trainable ``Parameter``s of the reference's FakeGPR); values live in the policy GP, ``assign`` goes through set_data."""
+
+    def __init__(self, gp, which, name):
+        self._gp, self._which = gp, which
+        Parameter.__init__(self, gp._X if which == 0 else gp._Y, name=name)
+
+    @property
+    def _v(self):
+        return self._gp._X if self._which == 0 else self._gp._Y
+
+    @_v.setter
+    def _v(self, value):
+        if getattr(self, "_gp", None) is None:
+            return
+        value = np.array(value, dtype=np.float64)
+        self._gp.set_data((value, self._gp._Y) if self._which == 0 else (self._gp._X, value))
+
+
 class RbfController:
     """RBF network controller = deterministic GP (controllers.py:80-129; Deisenroth et al. 2015, sec. 5.3.2).
 
@@ -82,6 +102,8 @@ class RbfController:
             model.likelihood.variance.assign(1e-4)          # FakeGPR, controllers.py:67,76-77
             model.likelihood.variance.trainable = False
             model.kernel.lengthscales.lower = 1e-3          # positive(lower=1e-3), controllers.py:100
+        self.centres = _PolicyData(self._gp, 0, "DataX")     # shared by every output (controllers.py:104-106)
+        self.targets = _PolicyData(self._gp, 1, "DataY")
 
     # -- the MGPR surface the reference's callers use on an RbfController
     @property
@@ -142,4 +164,5 @@ class RbfController:
 
     @property
     def trainable_parameters(self):
-        return [m.kernel.lengthscales for m in self.models]
+        """Centres, targets and per-output lengthscales -- the reference's trainable set (controllers.py:70-73,100)."""
+        return [p for p in [self.centres, self.targets] + [m.kernel.lengthscales for m in self.models] if p.trainable]

@@ -43,7 +43,11 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.SEG = PLcap + ELcap * (1 + D);
     wk.rank = rank;
     wk.nranks = W;
-    wk.abl = getenv("PILCO_ABL") ? atoi(getenv("PILCO_ABL")) : 0;
+#ifdef PILCO_DEV
+    wk.abl = getenv("PILCO_ABL") ? atoi(getenv("PILCO_ABL")) : 0;   // experiment switches: developer builds (tools/) only
+#else
+    wk.abl = 0;
+#endif
     const int PLa = std::max(wk.PL, 1);
     // stream-K geometry (variant 0)
     wk.sk_waves = 0;
@@ -452,7 +456,29 @@ int pilco_gp_set_factors(pilco_ctx* ctx, int slot, const double* iK, const doubl
     HIPCHK(hipMemsetAsync(s.beta.p, 0, sizeof(double) * E * npad, ctx->st));
     HIPCHK(hipMemcpy2DAsync(s.beta.p, sizeof(double) * npad, beta, sizeof(double) * n, sizeof(double) * n, (size_t)E,
                             hipMemcpyHostToDevice, ctx->st));
+    std::vector<double> sym;   // must outlive the asynchronous copies below
     if (iK) {
+        // The pair kernel visits only the column steps at / right of the diagonal block of a diagonal pair (weight 2):
+        // that equals sum_ij iK_ij L_ij only for symmetric iK.  L_aa is symmetric, so sum iK o L = sum sym(iK) o L
+        // EXACTLY: a caller-supplied asymmetric iK (predict_given_factorizations accepts any, mgpr.py:91,143-144) is
+        // replaced by its symmetric part, which leaves the reference's result unchanged.
+        bool asym = false;
+        for (int a = 0; a < E && !asym; ++a) {
+            const double* A = iK + (size_t)a * n * n;
+            for (int i = 0; i < n && !asym; ++i)
+                for (int j = 0; j < i; ++j)
+                    if (A[(size_t)i * n + j] != A[(size_t)j * n + i]) { asym = true; break; }
+        }
+        if (asym) {
+            sym.resize((size_t)E * n * n);
+            for (int a = 0; a < E; ++a) {
+                const double* A = iK + (size_t)a * n * n;
+                double* Sm = sym.data() + (size_t)a * n * n;
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j) Sm[(size_t)i * n + j] = 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]);
+            }
+            iK = sym.data();
+        }
         ENSURE(s.iK, (size_t)E * npad * npad);
         HIPCHK(hipMemsetAsync(s.iK.p, 0, sizeof(double) * E * npad * npad, ctx->st));
         for (int a = 0; a < E; ++a)

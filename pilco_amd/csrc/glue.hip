@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
 
     DBG_STAMP(g.wk, 8 + dbo, dbg0);
     PackPre pp;   // first round of the pack: its loads are in flight together with the batch below
-    if ((g.flags & GF_PACK) && !(g.wk.abl & 16)) mm_pack_issue(g.wk, 0, pp);
+    if ((g.flags & GF_PACK) && !MM_ABL(g.wk, 16)) mm_pack_issue(g.wk, 0, pp);
     // one batch of loads for everything the serial part reads
     if (g.flags & (GF_PROPAGATE | GF_TRAJ | GF_POLICY | GF_RBF_PRE)) {
         if (t < E) L.mx[t] = g.m_x[t];
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
     __syncthreads();
 
     DBG_STAMP(g.wk, 9 + dbo, dbg0);
-    if ((g.flags & GF_PACK) && !(g.wk.abl & 16)) mm_pack(g.wk, D, E, L, pp);
+    if ((g.flags & GF_PACK) && !MM_ABL(g.wk, 16)) mm_pack(g.wk, D, E, L, pp);
     DBG_STAMP(g.wk, 10 + dbo, dbg0);
     if (g.flags & GF_ASSEMBLE) {
         // single rank: the LDS copy of the segment is the whole gather buffer
@@ -396,11 +396,14 @@ void launch_glue(hipStream_t st, const GlueArgs& g, bool with_reward_block) {
         seg_n = g.pwk.SEG;
     }
     const size_t lds = sizeof(double) * glue_lds_doubles(g.E, g.D, seg_n, mp_n);
-    static size_t configured = 0;
-    if (lds > configured) {
+    static size_t configured[64] = {};   // per DEVICE: the attribute is a property of the function on one device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& conf = configured[dev & 63];
+    if (lds > conf) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_glue), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        configured = lds;
+        conf = lds;
     }
     hipLaunchKernelGGL(k_glue, dim3(with_reward_block ? 2 : 1), dim3(256), lds, st, g);
 }

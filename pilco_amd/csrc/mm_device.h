@@ -78,6 +78,9 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 #define FEXP_DEG (FEXP_TB <= 6 ? 5 : FEXP_TB <= 10 ? 4 : 3)        /* polynomial degree: r^(deg+1)/(deg+1)! < 2^-54 */
 #define FEXP_MAGIC 6755399441055744.0      /* 1.5 * 2^52 */
 
+#if !defined(PILCO_DEV) && defined(PAIR_OPT)
+#error "PAIR_OPT is a developer experiment: build with -DPILCO_DEV (tools/ only)"
+#endif
 #ifndef PAIR_OPT
 #define PAIR_OPT 0   // experiment bits (tools): 1 no inline asm, 2 no clamp, 4 no sched barriers
 #endif

@@ -5,6 +5,13 @@
 namespace pilco {
 
 constexpr int MAX_REWARD_TERMS = 4;
+// Experiment switches (skip a stage of the step to time the rest) exist only in developer builds of tools/
+// (-DPILCO_DEV); in the product library the tests are compile-time false and the stages cannot be removed.
+#ifdef PILCO_DEV
+#define MM_ABL(wk_, bit_) (((wk_).abl & (bit_)) != 0)
+#else
+#define MM_ABL(wk_, bit_) false
+#endif
 constexpr int MAX_D = 32;  // GP input dimension supported by the register-tiled kernels
 
 // One GP as the moment-matching kernels see it (all device pointers).

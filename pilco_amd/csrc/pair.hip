@@ -36,6 +36,9 @@ namespace pilco {
 #define PAIR_RT 2      // 16-row MFMA tiles per wave (rows per work item = 16 * PAIR_RT); 2 measured best
 #endif
 // ablation switches for kernel experiments (tools/): never defined in product builds
+#if !defined(PILCO_DEV) && defined(PAIR_ABL)
+#error "PAIR_ABL is a developer experiment: build with -DPILCO_DEV (tools/ only)"
+#endif
 #ifndef PAIR_ABL
 #define PAIR_ABL 0
 #endif

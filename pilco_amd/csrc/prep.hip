@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
         }
     }
     const double logvar = log(md.var[side ? b : a]);
-    if (wk.abl & 2) {
+    if (MM_ABL(wk, 2)) {
         if (t == 0) s_sc[0] = 1.0;
     } else if (w == 0) {
         // [R | s],  R = s diag(la^-2 + lb^-2) + I        (mgpr.py:121-124,129); padded with identity
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
             for (int k = D + 2; k < KP; ++k) store_wt(&Bt[(long)k * npad + i], 0.0);
         }
     };
-    if (!(wk.abl & 4)) {
+    if (!MM_ABL(wk, 4)) {
         if (i_begin + tl < i_end) {   // first row of this thread: centred point from the LDS stage
             const int i = i_begin + tl;
             double zeta[DT];
@@ -356,11 +356,15 @@ void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const P
 #define PREP(DT_)                                                                                          \
     do {                                                                                                   \
         const size_t lds_ = std::max(prep_lds_bytes(DT_), lds_rw);                                         \
-        static size_t configured_ = 48 * 1024;   /* beyond the default dynamic-LDS limit: opt in once */   \
-        if (lds_ > configured_) {                                                                          \
+        static size_t configured_[64] = {};  /* beyond the default dynamic-LDS limit: opt in once PER DEVICE */ \
+        int dev_ = 0;                                                                                      \
+        (void)hipGetDevice(&dev_);                                                                         \
+        size_t& conf_ = configured_[dev_ & 63];                                                            \
+        if (conf_ == 0) conf_ = 48 * 1024;                                                                 \
+        if (lds_ > conf_) {                                                                                \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mm_prep<DT_>),                       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);              \
-            configured_ = lds_;                                                                            \
+            conf_ = lds_;                                                                                  \
         }                                                                                                  \
         hipLaunchKernelGGL((k_mm_prep<DT_>), grid, dim3(512), lds_, st, md, wk, r);                        \
     } while (0)

@@ -173,7 +173,7 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
     const MMModel md = model_of(s);
     const int E = plan.E;
     GlueArgs g = plan.g;
-    const bool rew = g.n_rewards > 0 && !(s.wk.abl & 8);
+    const bool rew = g.n_rewards > 0 && !MM_ABL(s.wk, 8);
     HIPCHK(hipMemsetAsync(g.reward, 0, sizeof(double), ctx->st));
     g.step = 0;
     g.m_x = plan.st[0];
@@ -210,7 +210,7 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
                 pr.reward = g.reward;
             }
             launch_mm_prep(ctx->st, md, s.wk, rew ? &pr : nullptr);
-            if (ctx->dbg && (s.wk.abl & 64)) launch_stamp(ctx->st, ctx->dbg, 30);
+            if (ctx->dbg && MM_ABL(s.wk, 64)) launch_stamp(ctx->st, ctx->dbg, 30);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
             launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));

@@ -59,14 +59,33 @@ class MGPR:
     def _points(self):
         return self._X
 
+    def _claim_slot(self):
+        """The device slot is shared by every model of this kind on the context.  If another instance used it since
+        this one last synchronised, everything this instance believes to be on the device is stale: push it all again
+        (data, hyper-parameters, inducing inputs, factorisation)."""
+        owner = self.ctx._slot_owner.get(self._slot)
+        if owner is not self:
+            self.ctx._slot_owner[self._slot] = self
+            self._data_dirty = True
+            self._hyp_dirty = True
+            self._user_factors = None
+            self._on_slot_taken()
+
+    def _on_slot_taken(self):
+        self._reset_inducing = True        # an SMGPR may have left inducing inputs in the slot
+
     def _sync(self):
+        self._claim_slot()
         if self._data_dirty:
-            self.ctx.gp_set_data(self._slot, self._X, self._Y)
+            self.ctx.gp_set_data(self._slot, self._X, self._Y, owner=self)
             self._data_dirty = False
             self._hyp_dirty = True
+            if getattr(self, "_reset_inducing", False):
+                self.ctx.gp_set_inducing(self._slot, None, owner=self)      # back to the exact GP (pilco_gp_set_data keeps M otherwise)
+                self._reset_inducing = False
             self._after_set_data()
         if self._hyp_dirty:
-            self.ctx.gp_set_hyp(self._slot, self.lengthscales, self.variance, self.noise)
+            self.ctx.gp_set_hyp(self._slot, self.lengthscales, self.variance, self.noise, owner=self)
             self._hyp_dirty = False
             self._user_factors = None
 
@@ -76,7 +95,7 @@ class MGPR:
     def _ensure_factorized(self):
         self._sync()
         if self._user_factors is None:
-            self.ctx.gp_factorize(self._slot)
+            self.ctx.gp_factorize(self._slot)                   # cached on the device: a no-op while nothing changed
 
     # -- reference: mgpr.py:47-75
     def optimize(self, restarts=1):
@@ -101,7 +120,7 @@ class MGPR:
         iK = None if iK is None else np.asarray(iK, np.float64)
         if iK is not None and not np.any(iK):
             iK = None  # 0.0 * iK of the RBF controller (controllers.py:116): skip the stream
-        self.ctx.gp_set_factors(self._slot, iK, beta)
+        self.ctx.gp_set_factors(self._slot, iK, beta, owner=self)
         self._user_factors = True
         return self.ctx.gp_predict(self._slot, m, s, self.num_dims, self.num_outputs)
 

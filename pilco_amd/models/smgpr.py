@@ -35,10 +35,14 @@ class SMGPR(MGPR):
     def _after_set_data(self):
         self._z_dirty = True
 
+    def _on_slot_taken(self):
+        self._z_dirty = True
+        self._reset_inducing = False
+
     def _sync(self):
         MGPR._sync(self)
         if self._z_dirty:
-            self.ctx.gp_set_inducing(self._slot, self.Z)
+            self.ctx.gp_set_inducing(self._slot, self.Z, owner=self)
             self._z_dirty = False
             self._user_factors = None
 

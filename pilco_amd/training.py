@@ -11,8 +11,10 @@ unpinned in the reference itself (no test inspects trained values).
 
 ``optimize_policy`` -- PILCO.optimize_policy (pilco/models/pilco.py:75-113): L-BFGS-B over the
 controller parameters with the GP frozen, restarts via controller.randomize().  The gradient of the
-rollout reward is taken by central finite differences of device rollouts (deterministic, bitwise
-repeatable); the analytic adjoint is the next step.
+rollout reward is the hand-derived adjoint (native reverse sweep, csrc/grad.hip) for the
+linear and RBF controllers with exponential / linear / combined rewards; other cases (a PILCO subclass that
+overrides predict such as SafePILCO, D beyond the reverse pass's limit) fall back to central finite differences
+of device rollouts.  Both are deterministic and bitwise repeatable.
 """
 from __future__ import annotations
 
@@ -162,7 +164,11 @@ def policy_loss_and_grad(pilco, u, put, eps=1e-6):
     from .controllers import LinearController, RbfController
     put(u)
     ctl = pilco.controller
-    analytic = (pilco.control_dim > 0 and pilco.state_dim + pilco.control_dim <= 14      # the device VJP is built for D <= 14
+    from .models.pilco import PILCO
+    # the adjoint differentiates PILCO.predict's reward (pilco.py:118-136); a subclass that overrides predict (SafePILCO's
+    # multiplicative risk term, safe_pilco.py:29-50) is differentiated by finite differences of ITS training_loss instead
+    plain = type(pilco).predict is PILCO.predict
+    analytic = (plain and pilco.control_dim > 0 and pilco.state_dim + pilco.control_dim <= 14      # the device VJP is built for D <= 14
                 and all(t["kind"] in (_lib.REWARD_EXPONENTIAL, _lib.REWARD_LINEAR) for t in pilco.reward.terms()))
     if analytic and isinstance(ctl, LinearController):
         from .adjoint import rollout_value_and_grad
