@@ -48,6 +48,11 @@ int pilco_last_not_pd_output(const pilco_ctx* ctx);
  * 1 = plain-VALU tiled reference; 2 = MFMA tiled (bits also independent of the number of ranks).
  * All three agree to rounding. */
 int pilco_set_pair_kernel(pilco_ctx* ctx, int variant);
+/* Launch structure of a rollout step.  1 (default): "fused head" -- the serial link of step t (reduce the pair sums,
+ * assemble (M,S,V), propagate, controller, joint Gaussian: mgpr.py:143-149, pilco.py:139-149) runs redundantly inside every
+ * workgroup of step t+1's operand kernel, two launches per horizon step.  0: separate link kernel, three launches per
+ * step (always used with an RBF policy or more than one rank).  Both produce bitwise identical results. */
+int pilco_set_fused_step(pilco_ctx* ctx, int on);
 /* checks the f64 MFMA fragment layout assumptions on the device; 0 = OK */
 int pilco_selftest(pilco_ctx* ctx);
 

@@ -54,6 +54,7 @@ SIGNATURES = {
     "pilco_last_not_pd_output": (C.c_int, [_vp]),
     "pilco_set_pair_kernel": (C.c_int, [_vp, C.c_int]),
     "pilco_selftest": (C.c_int, [_vp]),
+    "pilco_set_fused_step": (C.c_int, [_vp, C.c_int]),
     "pilco_gp_set_data": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int]),
     "pilco_gp_set_hyp": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "pilco_gp_set_inducing": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
@@ -171,6 +172,9 @@ class Context:
     # ---- GP model
     def selftest(self):
         self._chk(self.lib.pilco_selftest(self.h))
+
+    def set_fused_step(self, on):
+        self._chk(self.lib.pilco_set_fused_step(self.h, 1 if on else 0))
 
     def set_pair_kernel(self, variant):
         self._chk(self.lib.pilco_set_pair_kernel(self.h, int(variant)))

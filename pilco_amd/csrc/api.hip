@@ -52,6 +52,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     // stream-K geometry (variant 0)
     wk.sk_waves = 0;
     wk.sk_maxw = 0;
+    wk.sk_pls = 0;
     if (ctx->variant == 0 && wk.PL > 0) {
         int tdiag, toff;
         mm_pair_sk_steps(npad, &tdiag, &toff);
@@ -77,12 +78,14 @@ int build_work(pilco_ctx* ctx, Slot& s) {
             if (sscanf(env, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { wk.sk_ud = a; wk.sk_uo = b; }
         }
         wk.sk_maxw = mm_sk_maxw(wk);
+        wk.sk_pls = round_up(wk.PL, 16);
     }
     ENSURE(s.w_in, (size_t)D + D * D + E + E * E + D * E);   // m | s | cotangents (Mbar | Sbar | Vbar) of the reverse pass
     ENSURE(s.w_At, (size_t)PLa * wk.KP * npad);
     ENSURE(s.w_Bt, (size_t)PLa * wk.KP * npad + (size_t)PLa * npad);   // column operands, then v_j on its own (vsep)
-    ENSURE(s.w_small, (size_t)PLa + (size_t)E * wk.NCHM * (1 + D));
-    ENSURE(s.w_part, std::max((size_t)PLa * wk.NT * 2, (size_t)PLa * std::max(wk.sk_maxw, 4)));
+    const size_t n_small = (size_t)PLa + (size_t)E * wk.NCHM * (1 + D);
+    ENSURE(s.w_small, 2 * n_small);
+    ENSURE(s.w_part, std::max((size_t)PLa * wk.NT * 2, (size_t)std::max(wk.sk_pls, 16) * std::max(wk.sk_maxw, 4)));
     ENSURE(s.w_gath, (size_t)W * wk.SEG);
     ENSURE(s.w_out, (size_t)E + E * E + D * E);
     wk.in_m = s.w_in.p;
@@ -92,6 +95,8 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.vcol = s.w_Bt.p + (size_t)PLa * wk.KP * npad;
     wk.pair_isdet = s.w_small.p;
     wk.mean_part = wk.pair_isdet + PLa;
+    s.alt_isdet = s.w_small.p + n_small;
+    s.alt_mean = s.alt_isdet + PLa;
     wk.pair_part = s.w_part.p;
     wk.sk_part = s.w_part.p;
     wk.gath = s.w_gath.p;
@@ -101,7 +106,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.exp_tab = ctx->exp_tab.p;
     wk.dbg = ctx->dbg;
     HIPCHK(hipMemsetAsync(s.w_gath.p, 0, sizeof(double) * W * wk.SEG, ctx->st));
-    if (wk.sk_waves > 0) HIPCHK(hipMemsetAsync(s.w_part.p, 0, sizeof(double) * PLa * wk.sk_maxw, ctx->st));   // slots no wave writes
+    if (wk.sk_waves > 0) HIPCHK(hipMemsetAsync(s.w_part.p, 0, sizeof(double) * wk.sk_pls * wk.sk_maxw, ctx->st));   // slots no wave writes
     s.wk_valid = true;
     s.wk_variant = ctx->variant;
     return PILCO_OK;
@@ -201,6 +206,7 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
         }
     }
     if (const char* eg = getenv("PILCO_NO_GRAPH")) ctx->use_graph = (atoi(eg) == 0);
+    if (const char* ef = getenv("PILCO_FUSED")) ctx->fused = (atoi(ef) != 0);
     const char* env = getenv("PILCO_PAIR_KERNEL");
     if (env) ctx->variant = (atoi(env) >= 0 && atoi(env) <= 2) ? atoi(env) : 0;
     *out = ctx;
@@ -241,6 +247,12 @@ int pilco_last_not_pd_output(const pilco_ctx* ctx) { return ctx ? ctx->not_pd : 
 int pilco_set_pair_kernel(pilco_ctx* ctx, int variant) {
     if (!ctx || variant < 0 || variant > 2) return PILCO_E_SHAPE;
     ctx->variant = variant;
+    return PILCO_OK;
+}
+
+int pilco_set_fused_step(pilco_ctx* ctx, int on) {
+    if (!ctx) return PILCO_E_SHAPE;
+    ctx->fused = (on != 0);
     return PILCO_OK;
 }
 

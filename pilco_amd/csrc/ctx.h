@@ -25,6 +25,8 @@ struct Slot {
     // moment-matching workspace
     DevBuf w_in, w_At, w_Bt, w_small, w_part, w_gath, w_out;
     MMWork wk{};
+    double* alt_isdet = nullptr;   // second copies of pair_isdet / mean_part: the fused head reads one set (previous step)
+    double* alt_mean = nullptr;    // while its prep part writes the other
     bool wk_valid = false;
     int wk_variant = -1;
     std::vector<int> pair_owner;  // [P]
@@ -52,6 +54,7 @@ struct pilco_ctx {
     hipGraphExec_t graph = nullptr;
     std::vector<unsigned long long> graph_key;
     bool use_graph = true;
+    bool fused = true;   // fused head: the serial link of step t runs inside the prep launch of step t+1 (2 launches per step)
     bool graph_rccl_failed = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> pair_events;
@@ -84,6 +87,7 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr);
 struct RolloutPlan {
     GlueArgs g{};
     double* st[2] = {nullptr, nullptr};  // double-buffered state: m_x[E] | s_x[E*E]
+    double* s1b[2] = {nullptr, nullptr}; // double-buffered [s_x, s_x c_xu] (fused head)
     int E = 0, D = 0, U = 0;
 };
 int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_term* rw, int n_rw, int H, bool want_traj,

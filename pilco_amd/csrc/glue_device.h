@@ -1,0 +1,521 @@
+// Device code of the serial link of a horizon step (glue_body), shared by its two hosts: k_glue (glue.hip) and the
+// fused head k_mm_prep<DT, true> (prep.hip).  Internal; gfx950 only.
+#pragma once
+#include "mm_device.h"
+
+namespace pilco {
+
+// ------------------------------------------------------------------ glue
+// The serial link of a horizon step: everything it needs is pulled into LDS with ONE batch of loads (all requests in
+// flight before the first wait), then (pack ->) assemble -> propagate -> controller -> joint Gaussian.
+// Two hosts run the same code (glue_body):
+//   * k_glue: one workgroup (+ an optional second one evaluating the reward of the pre-propagation state);
+//   * k_mm_prep<DT, true> ("fused head", prep.hip): EVERY workgroup of the next step's prep launch runs the link
+//     redundantly on its own CU and goes straight on to its prep work with the new joint Gaussian in LDS -- no launch
+//     boundary and no global round trip between the two; only workgroup (0,0) (`writer`) stores the results.
+struct GlueLds {
+    double* mx;   // [nm]     current state mean
+    double* sx;   // [nm*nm]  current state covariance
+    double* mu;   // [nm]
+    double* su;   // [nm*nm]
+    double* cxu;  // [nm*nm]
+    double* t1;   // [nm*nm]
+    double* t2;   // [nm*nm]
+    double* s1;   // [nm*nm]  s1 = [s_x, s_x c_xu] of the previous joint
+    double* jm;   // [nm]     joint mean handed to the dynamics GP
+    double* js;   // [nm*nm]  joint covariance
+    double* seg;  // [SEG]    this rank's packed results
+    double* mp;   // [EL*NCH*(1+D)] mean partials
+    double* misc; // [128]
+    int nm;       // max(E, D): leading dimension of the square buffers
+    int o_sx, o_s1, o_js, o_seg, o_mp;   // offsets (doubles) of sx, s1, js, seg, mp from mx, for multi_load
+};
+
+__device__ __forceinline__ void glue_lds_carve(const GlueArgs& g, double* sm, GlueLds& L) {
+    const int E = g.E, D = g.D;
+    const int nm = E > D ? E : D;
+    int seg_n = (g.flags & (GF_PACK | GF_ASSEMBLE)) ? g.wk.SEG * ((g.flags & GF_PACK) ? 1 : g.wk.nranks) : 0;
+    if (g.flags & GF_RBF_POST) seg_n = g.pwk.SEG;
+    L.mx = sm;
+    L.sx = L.mx + nm;
+    L.mu = L.sx + nm * nm;
+    L.su = L.mu + nm;
+    L.cxu = L.su + nm * nm;
+    L.t1 = L.cxu + nm * nm;
+    L.t2 = L.t1 + nm * nm;
+    L.s1 = L.t2 + nm * nm;
+    L.jm = L.s1 + nm * nm;
+    L.js = L.jm + nm;
+    L.misc = L.js + nm * nm;
+    L.seg = L.misc + 128;
+    L.mp = L.seg + seg_n;
+    L.nm = nm;
+    L.o_sx = nm;
+    L.o_s1 = 2 * nm + 5 * nm * nm;
+    L.o_js = 3 * nm + 6 * nm * nm;
+    L.o_seg = 3 * nm + 7 * nm * nm + 128;
+    L.o_mp = L.o_seg + seg_n;
+}
+
+// Batched global -> LDS copies: up to six segments are treated as one index space; every thread requests all its
+// elements (MAXV per round) before the first one is consumed, so the whole batch costs ONE memory round trip instead
+// of one per segment (the first version copied segment after segment: ~1 us each on this serial path).
+// (Destinations are offsets from one LDS base, not pointers: an aggregate of LDS pointers makes this compiler fold the
+// LDS -> generic cast of the region's first address into an illegal instruction.)
+struct LoadSeg {
+    int dst;            // offset (doubles) from the LDS base passed to multi_load
+    const double* src;  // global
+    int n;
+};
+template <int NSEG, int MAXV>
+__device__ __forceinline__ void multi_load(double* lds, const LoadSeg (&sg)[NSEG]) {
+    int off[NSEG + 1];
+    off[0] = 0;
+#pragma unroll
+    for (int i = 0; i < NSEG; ++i) off[i + 1] = off[i] + sg[i].n;
+    const int total = off[NSEG];
+    const int nthr = (int)blockDim.x;
+    for (int base = 0; base < total; base += MAXV * nthr) {
+        double v[MAXV];
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int e = base + k * nthr + (int)threadIdx.x;
+            v[k] = 0.0;
+            if (e < total) {
+#pragma unroll
+                for (int i = 0; i < NSEG; ++i)
+                    if (e >= off[i] && e < off[i + 1]) v[k] = sg[i].src[e - off[i]];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int e = base + k * nthr + (int)threadIdx.x;
+            if (e < total) {
+#pragma unroll
+                for (int i = 0; i < NSEG; ++i)
+                    if (e >= off[i] && e < off[i + 1]) lds[sg[i].dst + (e - off[i])] = v[k];
+            }
+        }
+    }
+}
+
+// squash_sin on (mu[U], su[U][U]) in place; cdiag[u] = e_u exp(-s_uu/2) cos(m_u)   (controllers.py:13-36).
+// The 5 U^2 + 3 U transcendental evaluations of the reference's formulas (exp(lq), exp(lq +- s), cos(m_u -+ m_v) per
+// element; exp, cos, sin per control) are independent: each goes to its own thread (one library call deep instead of a
+// chain of five on this serial path), then one combining phase.  Scratch: t1 .. js (contiguous, dead at this point).
+__device__ __forceinline__ void squash_inplace(const GlueLds& L, int U, const double* maxact, double* cdiag) {
+    const int t = threadIdx.x;
+    const int nm = L.nm, nm_sq = nm * nm;
+    const int nel = 5 * U * U + 3 * U;
+    if (nel <= 4 * nm_sq + nm && nel <= (int)blockDim.x * 8) {
+        double* sc = L.t1;
+        for (int i = t; i < nel; i += blockDim.x) {
+            double val;
+            if (i < 5 * U * U) {
+                const int e = i / 5, j = i - 5 * e;
+                const int u = e / U, v = e - u * U;
+                const double lq = -(L.su[u * U + u] + L.su[v * U + v]) / 2.0;
+                const double suv = L.su[e];
+                if (j == 0) val = exp(lq);
+                else if (j == 1) val = exp(lq + suv);
+                else if (j == 2) val = exp(lq - suv);
+                else if (j == 3) val = cos(L.mu[u] - L.mu[v]);
+                else val = cos(L.mu[u] + L.mu[v]);
+            } else {
+                const int r = i - 5 * U * U;
+                const int u = r / 3, j = r - 3 * u;
+                if (j == 0) val = exp(-L.su[u * U + u] / 2.0);
+                else if (j == 1) val = cos(L.mu[u]);
+                else val = sin(L.mu[u]);
+            }
+            sc[i] = val;
+        }
+        __syncthreads();
+        double newS[8], newM = 0.0, newC = 0.0;   // U*U <= 8 * blockDim (checked above through nel)
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = t + k * (int)blockDim.x;
+            newS[k] = 0.0;
+            if (e < U * U) {
+                const int u = e / U, v = e - u * U;
+                const double q = sc[5 * e], ep = sc[5 * e + 1], em = sc[5 * e + 2], c1 = sc[5 * e + 3], c2 = sc[5 * e + 4];
+                const double val = (ep - q) * c1 - (em - q) * c2;
+                const double eu = maxact ? maxact[u] : 1.0, ev = maxact ? maxact[v] : 1.0;
+                newS[k] = eu * ev * val / 2.0;
+            }
+        }
+        (void)cnt;
+        if (t < U) {
+            const double eu = maxact ? maxact[t] : 1.0;
+            const double* r = sc + 5 * U * U + 3 * t;
+            newC = eu * r[0] * r[1];
+            newM = eu * r[0] * r[2];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = t + k * (int)blockDim.x;
+            if (e < U * U) L.su[e] = newS[k];
+        }
+        if (t < U) {
+            cdiag[t] = newC;
+            L.mu[t] = newM;
+        }
+        __syncthreads();
+        return;
+    }
+    for (int e = t; e < U * U; e += blockDim.x) {
+        const int u = e / U, v = e - u * U;
+        const double du = L.su[u * U + u], dv = L.su[v * U + v];
+        const double lq = -(du + dv) / 2.0;
+        const double q = exp(lq);
+        const double suv = L.su[e];
+        const double val = (exp(lq + suv) - q) * cos(L.mu[u] - L.mu[v]) - (exp(lq - suv) - q) * cos(L.mu[u] + L.mu[v]);
+        const double eu = maxact ? maxact[u] : 1.0, ev = maxact ? maxact[v] : 1.0;
+        L.t2[e] = eu * ev * val / 2.0;
+    }
+    if (t < U) {
+        const double eu = maxact ? maxact[t] : 1.0;
+        const double ex = exp(-L.su[t * U + t] / 2.0);
+        cdiag[t] = eu * ex * cos(L.mu[t]);
+        L.misc[64 + t] = eu * ex * sin(L.mu[t]);
+    }
+    __syncthreads();
+    for (int e = t; e < U * U; e += blockDim.x) L.su[e] = L.t2[e];
+    if (t < U) L.mu[t] = L.misc[64 + t];
+    __syncthreads();
+}
+
+// joint Gaussian of (x,u) from mx,sx,mu,su,cxu in LDS -> jm, js in LDS (pilco.py:141-144); the writer workgroup also
+// stores in_m, in_s, s1 (the next propagate's [s_x, s_x c_xu]) and the tape record
+__device__ __forceinline__ void write_joint(const GlueArgs& g, const GlueLds& L, bool writer) {
+    const int E = g.E, U = g.U, D = g.D, t = threadIdx.x;
+    for (int e = t; e < E * U; e += blockDim.x) {  // sc = s_x c_xu  (E,U)
+        const int r = e / U, u = e - r * U;
+        double acc = 0.0;
+        _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.sx[r * E + k], L.cxu[k * U + u], acc);
+        L.t1[e] = acc;
+    }
+    if (U > 0) __syncthreads();
+    double* s1_dst = g.s1_out ? g.s1_out : g.s1;
+    if (t < D) {
+        const double v = (t < E) ? L.mx[t] : L.mu[t - E];
+        L.jm[t] = v;
+        if (writer) g.wk.in_m[t] = v;
+    }
+    for (int e = t; e < D * D; e += blockDim.x) {
+        const int r = e / D, c = e - r * D;
+        double v;
+        if (r < E && c < E) v = L.sx[r * E + c];
+        else if (r < E) v = L.t1[r * U + (c - E)];
+        else if (c < E) v = L.t1[c * U + (r - E)];
+        else v = L.su[(r - E) * U + (c - E)];
+        L.js[e] = v;
+        if (writer) {
+            g.wk.in_s[e] = v;
+            if (r < E) s1_dst[r * D + c] = v;
+            if (g.tape) {
+                double* rec = g.tape + (long)g.step * (D + D * D + E * D + E + E * E + D * E);
+                rec[D + e] = v;
+                if (r < E) rec[D + D * D + r * D + c] = v;
+            }
+        }
+    }
+    if (writer && g.tape && t < D) g.tape[(long)g.step * (D + D * D + E * D + E + E * E + D * E) + t] = (t < E) ? L.mx[t] : L.mu[t - E];
+    __syncthreads();
+}
+
+// Reduce the tile / stream-K partials of the local pairs and the row-chunk partials of the
+// owned outputs into this rank's segment (LDS copy + global gather buffer).  Four lanes per
+// pair sum fixed quarters of the partial list and are combined in a fixed tree.
+// Round `base` of mm_pack (4 threads per pair), split in two so that the loads of the first round are ISSUED at the very
+// start of the glue kernel, together with its other loads, and consumed after them (vmcnt is in order: one round trip).
+// Only kernel arguments go into the addresses (closed-form wave ranges).  Threads 0..255 do the pack whatever the
+// workgroup size, so the summation order -- and with it every bit of the result -- is the same in both hosts.
+struct PackPre {
+    double v[16];
+    double isdet;
+};
+// stream-K partials are slot-major: sk_part[slot][pair] (row stride sk_pls), slot = wave - first wave of the pair
+// (unused slots stay zero).  Lane gq of a pair's four lanes sums the slots [gq * sk_maxw / 4, (gq + 1) * sk_maxw / 4) in
+// order; for one slot the lanes of a wave read consecutive pairs, i.e. every load instruction touches a few whole
+// cache lines (the pair-major layout of the first version cost 64 lines per instruction), and the addresses still come
+// from the thread index alone.
+__device__ __forceinline__ void mm_pack_issue(const MMWork& wk, int base, PackPre& pp) {
+    const int t = threadIdx.x;
+    const int k = base + (t >> 2), gq = t & 3;
+    pp.isdet = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) pp.v[u] = 0.0;
+    if (t >= 256 || k >= wk.PL) return;
+    pp.isdet = wk.pair_isdet[k];
+    if (wk.sk_waves > 0) {
+        const int qw = wk.sk_maxw >> 2;
+        const double* src = wk.sk_part + (long)(gq * qw) * wk.sk_pls + k;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (u < qw) pp.v[u] = src[(long)u * wk.sk_pls];
+    }
+}
+__device__ __forceinline__ void mm_pack_sum(const MMWork& wk, int base, const PackPre& pp, double& s0, double& s1) {
+    const int t = threadIdx.x;
+    const int k = base + (t >> 2), gq = t & 3;
+    s0 = 0.0;
+    s1 = 0.0;
+    if (t >= 256 || k >= wk.PL) return;
+    if (wk.sk_waves > 0) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s0 += pp.v[u];
+        const int qw = wk.sk_maxw >> 2;
+        const double* src = wk.sk_part + (long)(gq * qw) * wk.sk_pls + k;
+        for (int u = 16; u < qw; ++u) s0 += src[(long)u * wk.sk_pls];   // few pairs spread over many waves
+    } else {
+        const double* part = wk.pair_part + (long)k * wk.NT * 2;
+        const int q0 = (int)((long)wk.NT * gq / 4), q1 = (int)((long)wk.NT * (gq + 1) / 4);
+        for (int q = q0; q < q1; ++q) {
+            s0 += part[2 * q];
+            s1 += part[2 * q + 1];
+        }
+    }
+}
+
+__device__ __forceinline__ void mm_pack(const MMWork& wk, int D, int E, const GlueLds& L, PackPre& pp, bool writer) {
+    const int t = threadIdx.x;
+    double* seg = wk.gath + (long)wk.rank * wk.SEG;
+    for (int base = 0; base < wk.PL; base += 64) {
+        const int k = base + (t >> 2), gq = t & 3;
+        if (base > 0) mm_pack_issue(wk, base, pp);
+        double s0, s1;
+        mm_pack_sum(wk, base, pp, s0, s1);
+        s0 += __shfl_xor(s0, 1);
+        s1 += __shfl_xor(s1, 1);
+        s0 += __shfl_xor(s0, 2);
+        s1 += __shfl_xor(s1, 2);
+        if (t < 256 && k < wk.PL && gq == 0) {
+            const bool diag = k * wk.nranks + wk.rank < E;     // diagonal pairs come first in the dealing order
+            const double v = (diag ? (s0 - s1) : s0) * pp.isdet;   // mgpr.py:144-145
+            if (writer) seg[k] = v;
+            L.seg[k] = v;
+        }
+    }
+    const int W1 = 1 + D;
+    for (int e = t; e < wk.EL * W1; e += blockDim.x) {   // M_a and V_a: sums of the chunk contributions
+        const int o = e / W1, idx = e - o * W1;
+        double sum = 0.0;
+        _Pragma("unroll 8") for (int ch = 0; ch < wk.NCHM; ++ch) sum += L.mp[(o * wk.NCHM + ch) * W1 + idx];
+        if (writer) seg[wk.OUTOFF + e] = sum;
+        L.seg[wk.OUTOFF + e] = sum;
+    }
+    __syncthreads();
+}
+
+// packed results -> out_M [E], out_S [E][E], out_V [D][E] (writer); always left in LDS (oM, oS, oV)
+__device__ __forceinline__ void mm_assemble(const MMWork& wk, const double* src, const double* var, int D, int E, double* oM,
+                            double* oS, double* oV, bool writer) {
+    const int t = threadIdx.x;
+    for (int a = t; a < E; a += blockDim.x) {
+        const double v = src[(a % wk.nranks) * wk.SEG + wk.OUTOFF + (a / wk.nranks) * (1 + D)];
+        oM[a] = v;
+        if (writer) wk.out_M[a] = v;
+    }
+    for (int e = t; e < D * E; e += blockDim.x) {
+        const int d = e / E, a = e - d * E;
+        const double v = src[(a % wk.nranks) * wk.SEG + wk.OUTOFF + (a / wk.nranks) * (1 + D) + 1 + d];
+        oV[e] = v;
+        if (writer) wk.out_V[e] = v;
+    }
+    __syncthreads();
+    for (int e = t; e < E * E; e += blockDim.x) {
+        const int a = e / E, b = e - a * E;
+        const int hi = a > b ? a : b, lo = a > b ? b : a;
+        const int kk = pair_order_index(E, hi, lo);
+        double v = src[(kk % wk.nranks) * wk.SEG + kk / wk.nranks];
+        if (a == b) v += var[a];                                   // mgpr.py:146
+        v = fma(-oM[a], oM[b], v);                                 // mgpr.py:147
+        oS[e] = v;
+        if (writer) wk.out_S[e] = v;
+    }
+    __syncthreads();
+}
+
+// The serial link.  On return (GF_POLICY) the joint Gaussian is in L.jm / L.js and the (propagated) state in L.mx / L.sx.
+// All threads of the workgroup must call it; `writer` selects the one workgroup that stores results to global memory.
+__device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, bool writer) {
+    const int E = g.E, D = g.D, U = g.U, t = threadIdx.x;
+    int mp_n = (g.flags & GF_PACK) ? g.wk.EL * g.wk.NCHM * (1 + D) : 0;
+    int seg_n = (g.flags & (GF_PACK | GF_ASSEMBLE)) ? g.wk.SEG * ((g.flags & GF_PACK) ? 1 : g.wk.nranks) : 0;
+    if (g.flags & GF_RBF_POST) {  // this launch reduces the POLICY GP (inputs = state, outputs = controls)
+        mp_n = g.pwk.EL * g.pwk.NCHM * (1 + E);
+        seg_n = g.pwk.SEG;
+    }
+    const bool dbg0 = (t == 0) && writer;
+    const int dbo = g.dbg_off ? g.dbg_off : ((g.step == 0) ? 16 : 0);  // the initial glue of a rollout stamps slots 24..29
+    DBG_STAMP(g.wk, 8 + dbo, dbg0);
+    PackPre pp;   // first round of the pack: its loads are in flight together with the batch below
+    if ((g.flags & GF_PACK) && !MM_ABL(g.wk, 16)) mm_pack_issue(g.wk, 0, pp);
+    {   // one batch of loads for everything the serial part reads
+        const bool need_state = (g.flags & (GF_PROPAGATE | GF_TRAJ | GF_POLICY | GF_RBF_PRE)) != 0;
+        const bool lin = (g.flags & GF_POLICY) && g.pol_kind == PILCO_POLICY_LINEAR;
+        const LoadSeg sg[6] = {
+            {0, g.m_x, need_state ? E : 0},
+            {L.o_sx, g.s_x, need_state ? E * E : 0},
+            {L.o_s1, g.s1, (g.flags & GF_PROPAGATE) ? E * D : 0},
+            {L.o_mp, (g.flags & GF_RBF_POST) ? g.pwk.mean_part : g.wk.mean_part, mp_n},
+            {L.o_seg, g.wk.gath, ((g.flags & GF_ASSEMBLE) && !(g.flags & GF_PACK)) ? seg_n : 0},
+            {L.o_js, g.W, lin ? U * E : 0},   // W parks in the joint-covariance buffer until write_joint overwrites it
+        };
+        multi_load<6, 4>(L.mx, sg);
+    }
+    __syncthreads();
+
+    DBG_STAMP(g.wk, 9 + dbo, dbg0);
+    if ((g.flags & GF_PACK) && !MM_ABL(g.wk, 16)) mm_pack(g.wk, D, E, L, pp, writer);
+    DBG_STAMP(g.wk, 10 + dbo, dbg0);
+    const bool fast = (g.flags & (GF_PACK | GF_ASSEMBLE | GF_PROPAGATE)) == (GF_PACK | GF_ASSEMBLE | GF_PROPAGATE) && g.wk.nranks == 1;
+    if (fast) {
+        // The rollout's common case in two phases instead of five (every phase boundary is a workgroup barrier plus an LDS
+        // round trip on this serial path).  Same operations in the same order as mm_assemble + GF_PROPAGATE below: the
+        // results are bitwise identical.  S_rc (mgpr.py:143-147) and t1 = s1 V (pilco.py:149) straight from the segment:
+        const double* seg = L.seg;
+        const int W1 = 1 + D, OO = g.wk.OUTOFF;
+        for (int e = t; e < E * E; e += blockDim.x) {
+            const int r = e / E, c = e - r * E;
+            const int hi = r > c ? r : c, lo = r > c ? c : r;
+            double v = seg[pair_order_index(E, hi, lo)];
+            if (r == c) v += g.var[r];
+            v = fma(-seg[OO + r * W1], seg[OO + c * W1], v);
+            L.su[e] = v;
+            double acc = 0.0;
+            _Pragma("unroll 8") for (int k = 0; k < D; ++k) acc = fma(L.s1[r * D + k], seg[OO + c * W1 + 1 + k], acc);
+            L.t1[e] = acc;
+        }
+        if (t < E) L.mu[t] = seg[OO + t * W1];
+        if (writer && g.tape) {   // the tape wants the GP outputs (M, S, V) of the step: V in [D][E] order
+            for (int e = t; e < D * E; e += blockDim.x) L.cxu[e] = seg[OO + (e % E) * W1 + 1 + e / E];
+        }
+        __syncthreads();
+        if (writer && g.tape && g.step >= 1) {
+            double* rec = g.tape + (long)(g.step - 1) * (D + D * D + E * D + E + E * E + D * E) + D + D * D + E * D;
+            if (t < E) rec[t] = L.mu[t];
+            for (int e = t; e < E * E; e += blockDim.x) rec[E + e] = L.su[e];
+            for (int e = t; e < D * E; e += blockDim.x) rec[E + E * E + e] = L.cxu[e];
+        }
+        for (int e = t; e < E * E; e += blockDim.x) {   // in place: a thread reads sx only at the element it writes
+            const int r = e / E, c = e - r * E;
+            const double v = ((L.su[e] + L.sx[e]) + L.t1[e]) + L.t1[c * E + r];
+            L.sx[e] = v;
+            if (writer) g.s_out[e] = v;
+        }
+        if (t < E) {
+            const double v = L.mu[t] + L.mx[t];
+            L.mx[t] = v;
+            if (writer) g.m_out[t] = v;
+        }
+        __syncthreads();
+    }
+    if (!fast && (g.flags & GF_ASSEMBLE)) {
+        // single rank: the LDS copy of the segment is the whole gather buffer
+        mm_assemble(g.wk, L.seg, g.var, D, E, L.mu, L.su, L.cxu, writer);  // oM -> mu, oS -> su, oV -> cxu
+        if (writer && g.tape && g.step >= 1) {
+            double* rec = g.tape + (long)(g.step - 1) * (D + D * D + E * D + E + E * E + D * E) + D + D * D + E * D;
+            if (t < E) rec[t] = L.mu[t];
+            for (int e = t; e < E * E; e += blockDim.x) rec[E + e] = L.su[e];
+            for (int e = t; e < D * E; e += blockDim.x) rec[E + E * E + e] = L.cxu[e];
+        }
+    }
+    DBG_STAMP(g.wk, 11 + dbo, dbg0);
+    if (!fast && (g.flags & GF_PROPAGATE)) {
+        // t1 = s1 V (E,E); state += increment                      (pilco.py:147-149)
+        for (int e = t; e < E * E; e += blockDim.x) {
+            const int r = e / E, c = e - r * E;
+            double acc = 0.0;
+            _Pragma("unroll 8") for (int k = 0; k < D; ++k) acc = fma(L.s1[r * D + k], L.cxu[k * E + c], acc);
+            L.t1[e] = acc;
+        }
+        __syncthreads();
+        for (int e = t; e < E * E; e += blockDim.x) {
+            const int r = e / E, c = e - r * E;
+            const double v = ((L.su[e] + L.sx[e]) + L.t1[e]) + L.t1[c * E + r];
+            L.t2[e] = v;
+            if (writer) g.s_out[e] = v;
+        }
+        if (t < E) {
+            const double v = L.mu[t] + L.mx[t];
+            L.misc[96 + t] = v;
+            if (writer) g.m_out[t] = v;
+        }
+        __syncthreads();
+        for (int e = t; e < E * E; e += blockDim.x) L.sx[e] = L.t2[e];
+        if (t < E) L.mx[t] = L.misc[96 + t];
+        __syncthreads();
+    }
+    DBG_STAMP(g.wk, 12 + dbo, dbg0);
+    if (writer && (g.flags & GF_TRAJ) && g.traj) {
+        double* dst = g.traj + (long)g.step * (E + E * E);
+        if (t < E) dst[t] = L.mx[t];
+        for (int e = t; e < E * E; e += blockDim.x) dst[E + e] = L.sx[e];
+    }
+    if (writer && (g.flags & GF_RBF_PRE)) {  // RbfController: the state is the input of the policy GP (controllers.py:115-116)
+        if (t < E) g.pwk.in_m[t] = L.mx[t];
+        for (int e = t; e < E * E; e += blockDim.x) g.pwk.in_s[e] = L.sx[e];
+    }
+    if (g.flags & GF_POLICY) {
+        if (g.pol_kind == PILCO_POLICY_RBF) {
+            // mean-function-only GP: iK = 0, then S -= diag(var - 1e-6)      (controllers.py:116-117)
+            PackPre pq;
+            mm_pack_issue(g.pwk, 0, pq);
+            mm_pack(g.pwk, E, U, L, pq, writer);
+            mm_assemble(g.pwk, L.seg, g.pvar, E, U, L.mu, L.su, L.cxu, writer);   // M (U), S (U,U), V (E,U)
+            if (t < U) L.su[t * U + t] -= g.pvar[t] - 1e-6;
+            __syncthreads();
+            if (g.squash) {
+                double* cdiag = L.misc + 1;
+                squash_inplace(L, U, g.maxact, cdiag);
+                for (int e = t; e < E * U; e += blockDim.x) L.cxu[e] *= cdiag[e % U];
+                __syncthreads();
+            }
+        }
+        if (g.pol_kind == PILCO_POLICY_LINEAR) {
+            // M = m W^T + b, S = W s W^T, V = W^T                  (controllers.py:52-54); W is in L.js (batched load)
+            if (t < U) {
+                double acc = g.b[t];
+                _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.js[t * E + k], L.mx[k], acc);
+                L.mu[t] = acc;
+            }
+            for (int e = t; e < U * E; e += blockDim.x) {
+                const int u = e / E, c = e - u * E;
+                double acc = 0.0;
+                _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.js[u * E + k], L.sx[k * E + c], acc);
+                L.t1[e] = acc;  // W s
+                L.cxu[c * U + u] = L.js[e];
+            }
+            __syncthreads();
+            for (int e = t; e < U * U; e += blockDim.x) {
+                const int u = e / U, v = e - u * U;
+                double acc = 0.0;
+                _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.t1[u * E + k], L.js[v * E + k], acc);
+                L.su[e] = acc;
+            }
+            __syncthreads();
+            if (g.squash) {
+                double* cdiag = L.misc + 1;  // [U]
+                squash_inplace(L, U, g.maxact, cdiag);
+                for (int e = t; e < E * U; e += blockDim.x) L.cxu[e] *= cdiag[e % U];   // V @ C, C diagonal
+                __syncthreads();
+            }
+        }
+        if (g.act_out) {
+            if (writer) {
+                if (t < U) g.act_out[t] = L.mu[t];
+                for (int e = t; e < U * U; e += blockDim.x) g.act_out[U + e] = L.su[e];
+                for (int e = t; e < E * U; e += blockDim.x) g.act_out[U + U * U + e] = L.cxu[e];
+            }
+        } else {
+            write_joint(g, L, writer);
+        }
+    }
+    DBG_STAMP(g.wk, 13 + dbo, dbg0);
+}
+
+}  // namespace pilco

@@ -43,8 +43,9 @@ struct MMWork {
     // (0,0),(1,1),..,(E-1,E-1),(1,0),(2,0),(2,1),(3,0).. : order index kk -> rank kk % nranks,
     // local index kk / nranks; output a belongs to the owner of (a,a).
     // stream-K decomposition of the MFMA pair kernel (variant 0)
-    double* sk_part;     // [PL][sk_maxw] stream-K partials, pair-major: slot = wave - first wave of the pair (unused slots stay zero)
+    double* sk_part;     // [sk_maxw][sk_pls] stream-K partials, slot-major: slot = wave - first wave of the pair (unused slots stay zero)
     int sk_waves, sk_total, sk_nd, sk_tdiag, sk_toff, sk_maxw;
+    int sk_pls;          // row stride of the slot-major partial array (local pairs rounded up to 16)
     unsigned long long* dbg;  // optional [32] phase timestamps (100 MHz wall clock) of the last prep / glue launch
     int abl;             // experiment switches (PILCO_ABL, tools only; 0 in product use)
     int sk_ud, sk_uo;    // cost units of a diagonal / off-diagonal column step (diagonal steps also stream iK)
@@ -96,11 +97,14 @@ struct GlueArgs {
     const double* s_x;  // [E][E]
     double* m_out;      // [E]     next state (written by GF_PROPAGATE; the other half of the double buffer)
     double* s_out;      // [E][E]
-    double* s1;      // [E][D]  = [s_x, s_x c_xu], kept for propagate
+    double* s1;      // [E][D]  = [s_x, s_x c_xu], kept for propagate (read by GF_PROPAGATE)
+    double* s1_out;  // where the new joint's [s_x, s_x c_xu] goes; nullptr = s1 (the fused head double-buffers it: every
+                     // workgroup reads s1 while the writer workgroup stores the next one)
     double* reward;  // [1]
     double* traj;    // [(H+1)][E + E*E] or nullptr
     double* tape;    // [H][D + D*D + E*D + E + E*E + D*E] joint (m, s, s1) and GP outputs (M, S, V) of every step, or nullptr
     int step;
+    int dbg_off;     // developer aid: slot offset of this launch's phase stamps (0 = default)
     // policy
     int pol_kind;
     const double* W;       // [U][E]
@@ -114,7 +118,12 @@ struct GlueArgs {
     double* rew_out;  // [2] mean, variance: set only by pilco_reward_eval
 };
 
-void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const PrepReward* pr = nullptr);
+// fused != nullptr: the "fused head" -- every workgroup first runs the serial link of the PREVIOUS step (glue_body with
+// *fused: pack / assemble / propagate / controller / joint) redundantly and takes the joint Gaussian from its own LDS;
+// fused->wk carries the buffers that link READS (previous step's partials), wk the ones this launch WRITES.
+void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const PrepReward* pr = nullptr,
+                    const GlueArgs* fused = nullptr);
+size_t glue_lds_doubles_for(const GlueArgs& g);
 // variant 0 = MFMA stream-K, 1 = VALU (tiled), 2 = MFMA tiled (bits independent of the rank count)
 void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int variant);
 // stream-K geometry: resident waves of the MFMA pair kernel for this KP, and the per-pair step counts

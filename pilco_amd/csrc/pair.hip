@@ -373,15 +373,15 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
         out1 += __shfl_down(out1, off);
     }
     if (lane == 0) {
-        // pair-major layout sk_part[pair][slot], slot = wave - (first wave of the pair): the reader (k_glue, one
-        // workgroup on the step's critical path) then needs no index arithmetic at all.  A wave that enters a pair from
-        // a previous one IS that pair's first wave (slot 0); only the first touched pair needs the closed form.
+        // slot-major layout sk_part[slot][pair], slot = wave - (first wave of the pair): the reader (the serial link)
+        // gets coalesced loads with addresses from its thread index alone.  A wave that enters a pair from a previous one
+        // IS that pair's first wave (slot 0); only the first touched pair needs the closed form.
         if (p0 >= 0) {
             const long S0 = (p0 < wk.sk_nd) ? (long)p0 * wk.sk_tdiag : (long)wk.sk_nd * wk.sk_tdiag + (long)(p0 - wk.sk_nd) * wk.sk_toff;
             const int wlo = sk_wave_of(S0, wk.sk_waves, nd_steps, wk.sk_total, wk.sk_ud, wk.sk_uo);
-            wk.sk_part[(long)p0 * wk.sk_maxw + (w - wlo)] = out0;
+            wk.sk_part[(long)(w - wlo) * wk.sk_pls + p0] = out0;
         }
-        if (p1 >= 0) wk.sk_part[(long)p1 * wk.sk_maxw] = out1;
+        if (p1 >= 0) wk.sk_part[p1] = out1;
     }
     DBG_STAMP(wk, 17, w == 0 && lane == 0);
     DBG_STAMP(wk, 18, w == wk.sk_waves - 1 && lane == 0);

@@ -1,5 +1,5 @@
 // k_mm_prep: per-step operands of the pair kernel, mean-part and reward workgroups.
-#include "mm_device.h"
+#include "glue_device.h"
 
 namespace pilco {
 
@@ -12,8 +12,10 @@ namespace pilco {
 // of the prep launch: T = Lambda^-1 B^-1 Lambda^-1 = (s + Lambda^2)^-1 by a register Gauss-Jordan in wave 0 while the
 // other threads already have their point in flight; lb_i = exp(-zeta_i^T T zeta_i / 2) beta_i; partial c g and c T h
 // into mean_part[al][chm][1 + D].
-template <int DT>
-__device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork& wk, int al, int chm, double* sm) {
+template <int DT, bool FUSED>
+__device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork& wk, int al, int chm, double* sm,
+                                                const double* jm, const double* js,   // joint Gaussian in LDS (FUSED head only)
+                                                const double la_t, const double var_a) {  // l_a[t] (t < D) and var_a, loaded by the caller
     const int D = md.D, npad = md.npad;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: the role branches below are scalar branches
@@ -27,12 +29,12 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
     double* colbuf = red + 9 * (DT + 1);   // [2 DT]
     double* zst = colbuf + 2 * DT;         // [512][DT + 1] centred points of the chunk's first 512 rows
     double* bst = zst + 512 * (DT + 1);    // [512] their beta_a
-    constexpr int LDZ = DT + 1;
+    constexpr int LDZ = DT | 1;   // odd row stride: conflict-free LDS rows
     if (t < DT) {
-        s_m[t] = (t < D) ? wk.in_m[t] : 0.0;
-        s_ia[t] = (t < D) ? 1.0 / md.ls[a * D + t] : 0.0;
+        s_m[t] = (t < D) ? (FUSED ? jm[t] : wk.in_m[t]) : 0.0;
+        s_ia[t] = (t < D) ? 1.0 / la_t : 0.0;
     }
-    for (int e = t; e < D * D; e += 512) s_s[e] = wk.in_s[e];
+    for (int e = t; e < D * D; e += 512) s_s[e] = FUSED ? js[e] : wk.in_s[e];
     for (int e = t; e < DT * DT; e += 512) s_T[e] = 0.0;
     __syncthreads();
     const bool dbgm = (t == 0 && al == 0 && chm == 0);
@@ -41,7 +43,6 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
     const int i_begin = chm * rpc, i_end = i_begin + rpc;
     if (w == 0) {
         // [B | I],  B = Lambda^-1 s Lambda^-1 + I; T = Lambda^-1 B^-1 Lambda^-1   (mgpr.py:103-111)
-        const double var_a = md.var[a];
         double col[DT];
         const int c = lane;
 #pragma unroll
@@ -79,31 +80,43 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
     double h[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) h[d] = 0.0;
-    for (int i = i_begin + t; i < i_end; i += 512) {   // lb_i = exp(-zeta^T T zeta / 2) beta_i   (mgpr.py:113)
-        const bool staged = (i - i_begin) < 512;
-        double zeta[DT];
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-            zeta[d] = (d < D) ? (staged ? zst[(i - i_begin) * LDZ + d] : (i < md.n ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0)) : 0.0;
-        double tz[DT];
-#pragma unroll
-        for (int r = 0; r < DT; ++r) tz[r] = 0.0;
-#pragma unroll
-        for (int c = 0; c < DT; ++c) {
-            double trow[DT];
-#pragma unroll
-            for (int r = 0; r < DT; ++r) trow[r] = s_T[c * DT + r];
-#pragma unroll
-            for (int r = 0; r < DT; ++r) tz[r] = fma(trow[r], zeta[c], tz[r]);
-            if ((c & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    // lb_i = exp(-zeta^T T zeta / 2) beta_i   (mgpr.py:113).  Rows are taken from the LDS stage only; a chunk longer
+    // than 512 rows is staged in rounds (no pointer ever selects between LDS and global memory).
+    for (int r0 = 0; r0 < rpc; r0 += 512) {
+        if (r0 > 0) {
+            __syncthreads();
+            for (int e = t; e < 512 * D; e += 512) {
+                const int d = e >> 9, r = e & 511;
+                const int i = i_begin + r0 + r;
+                zst[r * LDZ + d] = (i < md.n && i < i_end) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
+            }
+            bst[t] = (i_begin + r0 + t < i_end) ? md.beta[(long)a * npad + i_begin + r0 + t] : 0.0;
+            __syncthreads();
         }
-        double q = 0.0;
+        if (i_begin + r0 + t < i_end) {
+            double zeta[DT];
 #pragma unroll
-        for (int r = 0; r < DT; ++r) q = fma(zeta[r], tz[r], q);
-        const double lb = exp(-0.5 * q) * (staged ? bst[i - i_begin] : md.beta[(long)a * npad + i]);
-        g += lb;
+            for (int d = 0; d < DT; ++d) zeta[d] = (d < D) ? zst[t * LDZ + d] : 0.0;
+            double tz[DT];
 #pragma unroll
-        for (int d = 0; d < DT; ++d) h[d] = fma(zeta[d], lb, h[d]);
+            for (int r = 0; r < DT; ++r) tz[r] = 0.0;
+#pragma unroll
+            for (int c = 0; c < DT; ++c) {
+                double trow[DT];
+#pragma unroll
+                for (int r = 0; r < DT; ++r) trow[r] = s_T[c * DT + r];
+#pragma unroll
+                for (int r = 0; r < DT; ++r) tz[r] = fma(trow[r], zeta[c], tz[r]);
+                if ((c & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            double q = 0.0;
+#pragma unroll
+            for (int r = 0; r < DT; ++r) q = fma(zeta[r], tz[r], q);
+            const double lb = exp(-0.5 * q) * bst[t];
+            g += lb;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) h[d] = fma(zeta[d], lb, h[d]);
+        }
     }
     DBG_STAMP(wk, 42, dbgm);
     g = wave_sum_lane63(g);
@@ -139,9 +152,34 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
     DBG_STAMP(wk, 44, dbgm);
 }
 
-template <int DT>
-__global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepReward pr) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+template <int DT, bool FUSED>
+__global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepReward pr, GlueArgs g, int glue_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double sm_all[];
+    // FUSED: the serial link of the previous step runs first, redundantly in every workgroup (see glue_device.h); it
+    // leaves the joint Gaussian of THIS step (L.jm, L.js) and the current state (L.mx, L.sx) in the first glue_doubles
+    // doubles of LDS.  (All LDS pointers below are derived from sm_all unconditionally: no shared/global pointer merges.)
+    GlueLds L;
+    glue_lds_carve(g, sm_all, L);
+    // The model constants this workgroup needs (its lengthscales and signal variances) are requested BEFORE the serial
+    // link, so that their memory round trip overlaps with it instead of following it.
+    const bool spare_wg = (int)blockIdx.x >= wk.PL;
+    const int spare_idx = ((int)blockIdx.x - wk.PL) * (int)gridDim.y + (int)blockIdx.y;
+    const bool mean_wg = spare_wg && spare_idx < wk.EL * wk.NCHM;
+    int a = 0, b = 0;
+    if (!spare_wg) local_pair_ab(wk, md.E, (int)blockIdx.x, a, b);
+    else if (mean_wg) a = b = (spare_idx / wk.NCHM) * wk.nranks + wk.rank;   // the owner of (a,a) owns output a
+    double pre_la = 1.0, pre_lb = 1.0, pre_var = 1.0;
+    if (!spare_wg || mean_wg) {
+        if ((int)threadIdx.x < md.D) {
+            pre_la = md.ls[a * md.D + (int)threadIdx.x];
+            pre_lb = md.ls[b * md.D + (int)threadIdx.x];
+        }
+        pre_var = md.var[(threadIdx.x >> 8) ? b : a];
+    }
+    if (FUSED) glue_body(g, L, blockIdx.x == 0 && blockIdx.y == 0);
+    double* sm = sm_all + (FUSED ? glue_doubles : 0);
+    const double* jm = L.jm;
+    const double* js = L.js;
     if ((int)blockIdx.x >= wk.PL) {
         // spare workgroups of the launch: first the mean parts (local output, row chunk), then the reward
         const int idx = ((int)blockIdx.x - wk.PL) * (int)gridDim.y + (int)blockIdx.y;
@@ -149,7 +187,7 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
         const int slot = 64 + 2 * (blockIdx.y * gridDim.x + blockIdx.x);
         if (wk.dbg && threadIdx.x == 0 && slot < 958) wk.dbg[slot] = wall_clock64();
         if (idx < nmean) {
-            prep_mean_block<DT>(md, wk, idx / wk.NCHM, idx % wk.NCHM, sm);
+            prep_mean_block<DT, FUSED>(md, wk, idx / wk.NCHM, idx % wk.NCHM, sm, jm, js, pre_la, pre_var);
             if (wk.dbg && threadIdx.x == 0 && slot < 958) wk.dbg[slot + 1] = wall_clock64();
             return;
         }
@@ -159,8 +197,13 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
         double* mx = sm;              // [E]
         double* sx = mx + E;          // [E][E]
         double* ws = sx + E * E;      // reward_lds_doubles(E)
-        if (t < E) mx[t] = pr.m_x[t];
-        for (int e = t; e < E * E; e += blockDim.x) sx[e] = pr.s_x[e];
+        if (FUSED) {
+            if (t < E) mx[t] = L.mx[t];
+            for (int e = t; e < E * E; e += blockDim.x) sx[e] = L.sx[e];
+        } else {
+            if (t < E) mx[t] = pr.m_x[t];
+            for (int e = t; e < E * E; e += blockDim.x) sx[e] = pr.s_x[e];
+        }
         __syncthreads();
         double mu, var;
         reward_eval(pr.n, pr.rw, E, mx, sx, ws, false, mu, var);
@@ -184,20 +227,18 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
     const bool dbg0 = (t == 0 && pl == 0 && ch == 0);
     DBG_STAMP(wk, 0, dbg0);
     if (wk.dbg && t == 0) wk.dbg[64 + 2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
-    int a, b;
-    local_pair_ab(wk, md.E, pl, a, b);
     if (t < DT) {
         double la = 1.0, lb = 1.0, mm = 0.0;
         if (t < D) {
-            mm = wk.in_m[t];
-            la = md.ls[a * D + t];
-            lb = md.ls[b * D + t];
+            mm = FUSED ? jm[t] : wk.in_m[t];
+            la = pre_la;
+            lb = pre_lb;
         }
         s_m[t] = mm;
         s_ia2[t] = (t < D) ? 1.0 / (la * la) : 0.0;
         s_ib2[t] = (t < D) ? 1.0 / (lb * lb) : 0.0;
     }
-    for (int e = t; e < D * D; e += 512) s_s[e] = wk.in_s[e];
+    for (int e = t; e < D * D; e += 512) s_s[e] = FUSED ? js[e] : wk.in_s[e];
     for (int e = t; e < DT * DT; e += 512) s_Q[e] = 0.0;   // padded rows / columns of Q stay zero
     __syncthreads();
     DBG_STAMP(wk, 1, dbg0);
@@ -208,7 +249,7 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
     // side 0 (threads 0..255): x = zeta / la^2 -> row operand (2 Q z | u | 1); side 1: x = zeta / lb^2 -> column
     // operand (w | 1 | v).  A diagonal pair (a == b) is not special here: its mean part runs in prep_mean_block.
     const int side = grp;
-    constexpr int LDZ = DT + 1;
+    constexpr int LDZ = DT | 1;   // odd row stride: conflict-free LDS rows
     if (w != 0) {
         const int idx = (w - 1) * 64 + lane;   // 0..447
         for (int e = idx; e < 256 * D; e += 448) {
@@ -217,7 +258,7 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
             zst[r * LDZ + d] = (i < md.n && i < i_end) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
         }
     }
-    const double logvar = log(md.var[side ? b : a]);
+    const double logvar = log(pre_var);
     if (MM_ABL(wk, 2)) {
         if (t == 0) s_sc[0] = 1.0;
     } else if (w == 0) {
@@ -346,35 +387,51 @@ void mm_prep_chunks(int npad, int PL, int EL, int* nch_out, int* nchm_out) {
     *nchm_out = nchm;
 }
 
-void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const PrepReward* pr) {
+void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const PrepReward* pr, const GlueArgs* fused) {
     PrepReward none{};
     const PrepReward& r = pr ? *pr : none;
     const int spare = wk.EL * wk.NCHM + (r.n > 0 ? 1 : 0);   // mean-part workgroups, then the reward workgroup
     dim3 grid(wk.PL + (spare + wk.NCH - 1) / wk.NCH, wk.NCH);
     const int D = md.D;
     const size_t lds_rw = r.n > 0 ? sizeof(double) * ((size_t)r.E + (size_t)r.E * r.E + reward_lds_doubles(r.E)) : 0;
-#define PREP(DT_)                                                                                          \
+    GlueArgs gnone{};
+    const GlueArgs& ga = fused ? *fused : gnone;
+    const int gd = fused ? (int)((glue_lds_doubles_for(ga) + 1) & ~(size_t)1) : 0;   // glue region of the fused head (even: 16-byte alignment)
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+#define PREP1(DT_, F_)                                                                                     \
     do {                                                                                                   \
-        const size_t lds_ = std::max(prep_lds_bytes(DT_), lds_rw);                                         \
+        const size_t lds_ = std::max(prep_lds_bytes(DT_), lds_rw) + sizeof(double) * (size_t)gd;           \
         static size_t configured_[64] = {};  /* beyond the default dynamic-LDS limit: opt in once PER DEVICE */ \
-        int dev_ = 0;                                                                                      \
-        (void)hipGetDevice(&dev_);                                                                         \
         size_t& conf_ = configured_[dev_ & 63];                                                            \
         if (conf_ == 0) conf_ = 48 * 1024;                                                                 \
         if (lds_ > conf_) {                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mm_prep<DT_>),                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mm_prep<DT_, F_>),                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);              \
             conf_ = lds_;                                                                                  \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_mm_prep<DT_>), grid, dim3(512), lds_, st, md, wk, r);                        \
+        hipLaunchKernelGGL((k_mm_prep<DT_, F_>), grid, dim3(512), lds_, st, md, wk, r, ga, gd);            \
     } while (0)
+#define PREP(DT_)                  \
+    do {                           \
+        if (fused) PREP1(DT_, true); \
+        else PREP1(DT_, false);    \
+    } while (0)
+    // DT = D where it matters: the Gauss-Jordan costs 2 DT readlanes per pivot and DT pivots, a row DT^2 FMAs -- at
+    // D = 10 the exact instantiation does 30 % less work on this latency-bound path than the padded DT = 12
     if (D <= 4) PREP(4);
+    else if (D <= 6) PREP(6);
     else if (D <= 8) PREP(8);
+    else if (D <= 10) PREP(10);
+    else if (D == 11) PREP(11);
     else if (D <= 12) PREP(12);
+    else if (D <= 14) PREP(14);
     else if (D <= 16) PREP(16);
+    else if (D <= 20) PREP(20);
     else if (D <= 24) PREP(24);
     else PREP(32);
 #undef PREP
+#undef PREP1
 }
 
 }  // namespace pilco

@@ -121,7 +121,7 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
     if (n_rw < 0 || n_rw > MAX_REWARD_TERMS || (n_rw > 0 && !rw)) return fail(ctx, PILCO_E_SHAPE, "rollout: 0..4 reward terms supported");
     if (int r = build_work(ctx, s)) return r;
     // state: 2 x (m_x[E] s_x[E*E]) | s1[E*D] | reward[1]
-    const size_t n_state = 2 * ((size_t)E + E * E) + (size_t)E * D + 1 + 8;
+    const size_t n_state = 2 * ((size_t)E + E * E) + 2 * (size_t)E * D + 1 + 8;
     ENSURE(ctx->state, n_state);
     // params: W[U*E] b[U] maxact[U] then per reward W[E*E] t[E] F[E*E]
     const size_t n_par = (size_t)U * E + 2 * U + (size_t)MAX_REWARD_TERMS * (2 * E * E + E) + 8;
@@ -137,7 +137,9 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
     plan.st[0] = ctx->state.p;
     plan.st[1] = ctx->state.p + (E + E * E);
     g.s1 = ctx->state.p + 2 * (E + E * E);
-    g.reward = g.s1 + (size_t)E * D;
+    plan.s1b[0] = g.s1;
+    plan.s1b[1] = g.s1 + (size_t)E * D;
+    g.reward = g.s1 + 2 * (size_t)E * D;
     g.traj = want_traj ? ctx->traj.p : nullptr;
     g.pol_kind = pol->kind;
     g.squash = pol->squash;
@@ -181,6 +183,52 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
     g.m_out = nullptr;
     g.s_out = nullptr;
     const bool rbf = (g.pol_kind == PILCO_POLICY_RBF);
+    if (ctx->fused && !rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && H > 0) {
+        // Fused head: launch h = 0..H-1 is [serial link producing state h and its joint Gaussian | operands of step h],
+        // followed by the pair kernel of step h; one plain glue launch closes the rollout.  What the link reads
+        // (previous step's pair_isdet / mean_part / s1 / state) and what the same launch writes alternate between two
+        // buffer sets, because the workgroups of one launch are not ordered.
+        MMWork wkb[2] = {s.wk, s.wk};
+        wkb[1].pair_isdet = s.alt_isdet;
+        wkb[1].mean_part = s.alt_mean;
+        size_t evi = 0;
+        for (int h = 0; h < H; ++h) {
+            GlueArgs gh = g;
+            gh.step = h;
+            gh.dbg_off = h > 0 ? 48 : 0;              // fused heads stamp slots 56..61 (the closing k_glue keeps 8..13)
+            gh.wk = wkb[(h + 1) & 1];                 // read side: written by launch h - 1
+            gh.flags = GF_TRAJ | GF_POLICY | (h > 0 ? (GF_PACK | GF_ASSEMBLE | GF_PROPAGATE) : 0);
+            gh.m_x = plan.st[h > 0 ? (h - 1) & 1 : 0];
+            gh.s_x = gh.m_x + E;
+            gh.m_out = h > 0 ? plan.st[h & 1] : nullptr;
+            gh.s_out = h > 0 ? plan.st[h & 1] + E : nullptr;
+            gh.s1 = plan.s1b[(h + 1) & 1];
+            gh.s1_out = plan.s1b[h & 1];
+            PrepReward pr{};
+            if (rew) {   // reward of state h (pilco.py:133), from the link's LDS copy of the state
+                pr.n = g.n_rewards;
+                pr.E = E;
+                for (int i = 0; i < g.n_rewards; ++i) pr.rw[i] = g.rw[i];
+                pr.reward = g.reward;
+            }
+            launch_mm_prep(ctx->st, md, wkb[h & 1], rew ? &pr : nullptr, &gh);
+            if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
+            launch_mm_pair(ctx->st, md, wkb[h & 1], ctx->variant);
+            if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
+        }
+        GlueArgs gf = g;
+        gf.step = H;
+        gf.wk = wkb[(H - 1) & 1];
+        gf.flags = GF_PACK | GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ;
+        gf.m_x = plan.st[(H - 1) & 1];
+        gf.s_x = gf.m_x + E;
+        gf.m_out = plan.st[H & 1];
+        gf.s_out = gf.m_out + E;
+        gf.s1 = plan.s1b[(H - 1) & 1];
+        gf.s1_out = nullptr;
+        launch_glue(ctx->st, gf);
+        return PILCO_OK;
+    }
     Slot& ps = ctx->slot[PILCO_SLOT_POLICY];
     const MMModel pmd = rbf ? model_of(ps) : MMModel{};
     // RBF policy (controllers.py:108-121): the glue that produced the state hands it to the policy GP
@@ -252,7 +300,7 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
     const GlueArgs& g = plan.g;
     std::vector<unsigned long long> key = {
         (unsigned long long)H, (unsigned long long)g.pol_kind, (unsigned long long)g.n_rewards, (unsigned long long)g.squash,
-        (unsigned long long)ctx->variant, (unsigned long long)(uintptr_t)plan.st[0], (unsigned long long)(uintptr_t)g.s1,
+        (unsigned long long)ctx->variant, (unsigned long long)ctx->fused, (unsigned long long)(uintptr_t)plan.st[0], (unsigned long long)(uintptr_t)g.s1,
         (unsigned long long)(uintptr_t)g.traj, (unsigned long long)(uintptr_t)g.tape, (unsigned long long)(uintptr_t)g.W, (unsigned long long)(uintptr_t)g.maxact,
         (unsigned long long)(uintptr_t)s.w_part.p, (unsigned long long)(uintptr_t)s.w_At.p, (unsigned long long)(uintptr_t)s.w_Bt.p,
         (unsigned long long)(uintptr_t)s.w_small.p, (unsigned long long)(uintptr_t)s.w_gath.p, (unsigned long long)(uintptr_t)s.w_out.p,

@@ -345,7 +345,7 @@ def test_headline_rollout_h40_vs_executed_reference(ctx, golden_dir, tag, D, noi
         Mt, St = traj[t, :E], traj[t, E:].reshape(E, E)
         np.testing.assert_allclose(Mt, g["M_traj"][:, t], rtol=RTOL, err_msg="mean, step %d" % t)
         np.testing.assert_allclose(St, g["S_traj"][:, :, t], rtol=RTOL, err_msg="covariance, step %d" % t)
-        worst = max(worst, np.max(np.abs(St - g["S_traj"][:, :, t]) / np.abs(g["S_traj"][:, :, t])))
+        worst = max(worst, np.max(np.abs(St - g["S_traj"][:, :, t]) / np.maximum(np.abs(g["S_traj"][:, :, t]), 1e-300)))
     np.testing.assert_allclose(M[0], g["M_traj"][:, -1], rtol=RTOL)
     np.testing.assert_allclose(S, g["S_traj"][:, :, -1], rtol=RTOL)
     np.testing.assert_allclose(R[0, 0], g["R_traj"][-1], rtol=RTOL)
@@ -357,6 +357,31 @@ def test_headline_rollout_h40_vs_executed_reference(ctx, golden_dir, tag, D, noi
     M3, S3, R3 = p.predict(c["m0"], c["S0"], H)
     assert np.array_equal(M2, M3) and np.array_equal(S2, S3) and np.array_equal(R2, R3)
     np.testing.assert_allclose(S2, S, rtol=1e-13)
+
+
+@pytest.mark.parametrize("D", [10, 11])
+def test_fused_head_is_bitwise_identical_to_the_three_kernel_step(ctx, D):
+    """The fused head (serial link inside the next step's operand kernel, 2 launches per step) and the separate link
+    kernel (3 launches per step) run the same code in the same order: every state of the trajectory and the reward agree
+    to the last bit, with and without a controller, at the benchmarked size and at a small one."""
+    for N, E, H in ((1000, 10, 6), (130, 10, 4)):
+        c = synthetic.config_c2(N=N, D=D, E=E)
+        p = _pilco_from(c, H)
+        if D > E:
+            p.controller.W.assign(c["W"]); p.controller.b.assign(c["b"]); p.controller.max_action = 1.0
+        out = []
+        for fused in (1, 0, 1):
+            ctx.set_fused_step(fused)
+            try:
+                out.append(p.predict_trajectory(c["m0"], c["S0"], H))
+            finally:
+                ctx.set_fused_step(1)
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a, b)
+        for a, b in zip(out[0], out[2]):
+            assert np.array_equal(a, b)
+        m1, s1 = p.propagate(c["m0"], c["S0"])
+        assert np.array_equal(m1[0], out[0][3][1, :E]) and np.array_equal(s1.ravel(), out[0][3][1, E:])
 
 
 def test_full_size_c2u_gradient_vs_reverse_mode_through_the_reference(ctx, golden_dir):
