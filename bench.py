@@ -130,6 +130,44 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
     return out
 
 
+def config5_metrics(ctx, with_cpu):
+    """BASELINE config 5: the loop of the reference's examples/inverted_pendulum.py:13-39 (InvertedPendulum-v2-shaped
+    built-in plant, 5 x 40 random steps, RbfController(bf=10), horizon 40, 3 x [optimize_models, optimize_policy
+    (maxiter=50), 100-step rollout]) on the HIP path, and ONE iteration of the same loop on the CPU stand-in
+    (oracle/cpu_loop.py; bounded sample) timed beside it."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import inverted_pendulum as ip
+    from pilco_amd import _lib
+    prev = _lib._default_ctx
+    _lib.set_context(ctx)
+    try:
+        hip = ip.run_hip(verbose=False)
+    finally:
+        _lib.set_context(prev)
+    out = {"hip_total_s": hip["total_s"], "hip_iterations": hip["iterations"]}
+    if with_cpu:
+        # in a child process with a hard time limit: a CPU stand-in must never stall the benchmark
+        import subprocess
+        code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r); import inverted_pendulum as ip; "
+                "print('CPU5 ' + json.dumps(ip.run_cpu(iters=1, verbose=False)))" % (ROOT, os.path.join(ROOT, "examples")))
+        try:
+            pr = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+            line = [l for l in pr.stdout.splitlines() if l.startswith("CPU5 ")]
+            cpu = json.loads(line[-1][5:]) if line else None
+        except subprocess.TimeoutExpired:
+            cpu = None
+        if cpu is None:
+            out["cpu_stand_in_first_iteration"] = "did not finish within 240 s"
+            return out
+        c0, h0 = cpu["iterations"][0], hip["iterations"][0]
+        out["cpu_stand_in_first_iteration"] = c0
+        out["cpu_stand_in_note"] = ("oracle/cpu_loop.py (NumPy/SciPy GP fit + torch-CPU reverse mode through the restated "
+                                    "rollout, L-BFGS-B maxiter=50), 8 torch threads of %d host threads; same data, same objective; iteration 0 only" % os.cpu_count())
+        out["speedup_first_iteration"] = ((c0["optimize_models_s"] + c0["optimize_policy_s"]) /
+                                          max(h0["optimize_models_s"] + h0["optimize_policy_s"], 1e-9))
+    return out
+
+
 def verify_against_reference(mH, SH, reward):
     """The timed rollout's result against tests/golden/c2_rollout.npz: the reference's own source executed at this
     exact configuration (oracle/gen_golden_c2.py).  Raises when the 1e-5 relative tolerance of north_star is missed."""
@@ -285,6 +323,12 @@ def main():
         }
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_metrics(ctx, cfg, policy, rewards, ms_per_rollout, args.steps)
+            try:
+                out["secondary"]["config5_inverted_pendulum"] = config5_metrics(ctx, not args.no_cpu_baseline)
+            except Exception as exc:   # never lose the headline line to a secondary measurement
+                out["secondary"]["config5_inverted_pendulum"] = {"error": repr(exc)}
+            ctx.gp_set_data(0, cfg["X"], cfg["Y"])
+            ctx.gp_set_hyp(0, cfg["lengthscales"], cfg["variance"], cfg["noise"])
         if replicas is not None:
             out["secondary"] = replicas
         if world == 1 and not args.no_cpu_baseline:

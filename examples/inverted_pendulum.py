@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
-"""BASELINE config 5: the PILCO loop of the reference's examples/inverted_pendulum.py:15-39
-(random rollouts -> PILCO(RbfController(bf=10), horizon) -> 3 x [optimize_models, optimize_policy,
-rollout, set_data]) on the MI355X path.  gym is not installed, so the pendulum swing-up plant is
-simulated here (same equations as gym's Pendulum-v0: state (cos th, sin th, th_dot), torque in [-2, 2],
-dt = 0.05).  Prints the wall-clock of every stage; `--quick` is a short smoke variant.
+"""BASELINE config 5: the PILCO loop of the reference's examples/inverted_pendulum.py:13-39, as it is written there:
 
-    python examples/inverted_pendulum.py [--quick]
+    env = InvertedPendulum-v2;  5 random rollouts x 40 steps;  RbfController(bf=10);  PILCO(..., horizon=40)
+    3 x [ optimize_models();  optimize_policy()  (maxiter=50, pilco.py:75);  rollout(100 steps);  set_data ]
+
+on the MI355X path (pilco_amd) and, with --cpu, on the CPU stand-in (oracle/cpu_loop.py) beside it.  gym / MuJoCo are
+not installed, so a cart-pole with InvertedPendulum-v2's interface is simulated here: observation (x, theta, x_dot,
+theta_dot) with theta = 0 upright, one action in [-3, 3] (gear 100 N), 0.04 s per step (2 x 0.02 s), reset to
+uniform(-0.01, 0.01), an episode ends when |theta| > 0.2 (examples/utils.py:7-29 breaks the rollout on `done`).
+
+    python examples/inverted_pendulum.py [--quick] [--cpu] [--cpu-iters K]
 """
 import argparse
 import os
@@ -15,79 +19,140 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pilco_amd.controllers import RbfController  # noqa: E402
-from pilco_amd.models import PILCO  # noqa: E402
-from pilco_amd.rewards import ExponentialReward  # noqa: E402
 
 
-class Pendulum:
-    """Pendulum-v0 dynamics (g = 10, m = l = 1, dt = 0.05, max torque 2, max speed 8)."""
-    max_torque, max_speed, dt = 2.0, 8.0, 0.05
+class InvertedPendulumLike:
+    """Cart-pole with the observation / action / termination conventions of gym's InvertedPendulum-v2."""
+    mc, mp, l, g, gear, dt, substeps = 10.5, 5.0, 0.3, 9.81, 100.0, 0.02, 2
 
     def __init__(self, rs):
         self.rs = rs
-        self.th, self.thdot = np.pi, 0.0
+        self.q = np.zeros(4)
+        self.action_low, self.action_high = -3.0, 3.0
 
     def reset(self):
-        self.th = np.pi + 0.1 * self.rs.randn()
-        self.thdot = 0.1 * self.rs.randn()
-        return self.obs()
+        self.q = self.rs.uniform(-0.01, 0.01, size=4)
+        return self.q.copy()
 
-    def obs(self):
-        return np.array([np.cos(self.th), np.sin(self.th), self.thdot])
+    def sample_action(self):
+        return self.rs.uniform(self.action_low, self.action_high, size=1)
+
+    def _deriv(self, q, f):
+        x, th, xd, thd = q
+        s, c = np.sin(th), np.cos(th)
+        tot = self.mc + self.mp
+        tmp = (f + self.mp * self.l * thd * thd * s) / tot
+        thdd = (self.g * s - c * tmp) / (self.l * (4.0 / 3.0 - self.mp * c * c / tot))
+        xdd = tmp - self.mp * self.l * thdd * c / tot
+        return np.array([xd, thd, xdd, thdd])
 
     def step(self, u):
-        u = float(np.clip(u, -self.max_torque, self.max_torque))
-        self.thdot = np.clip(self.thdot + (-3 * 10.0 / 2 * np.sin(self.th + np.pi) + 3.0 * u) * self.dt,
-                             -self.max_speed, self.max_speed)
-        self.th = self.th + self.thdot * self.dt
-        return self.obs()
+        f = self.gear * float(np.clip(np.ravel(u)[0], self.action_low, self.action_high))
+        for _ in range(self.substeps):   # RK4
+            k1 = self._deriv(self.q, f)
+            k2 = self._deriv(self.q + 0.5 * self.dt * k1, f)
+            k3 = self._deriv(self.q + 0.5 * self.dt * k2, f)
+            k4 = self._deriv(self.q + self.dt * k3, f)
+            self.q = self.q + self.dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+        done = (not np.all(np.isfinite(self.q))) or abs(self.q[1]) > 0.2
+        return self.q.copy(), 1.0, done
 
 
-def rollout(env, pilco, timesteps, random=False, rs=None):
-    """examples/utils.py:7-29: collect (x, u) -> delta-x pairs."""
+def rollout(env, action_fn, timesteps):
+    """examples/utils.py:7-29: (x, u) -> delta-x pairs; stops when the episode is done."""
     X, Y = [], []
     x = env.reset()
+    ret = 0.0
     for _ in range(timesteps):
-        u = rs.uniform(-env.max_torque, env.max_torque, size=1) if random else np.asarray(pilco.compute_action(x[None, :])).ravel()
-        x_new = env.step(u[0])
+        u = np.asarray(action_fn(x), np.float64).ravel()
+        x_new, r, done = env.step(u)
+        ret += r
         X.append(np.hstack((x, u)))
         Y.append(x_new - x)
         x = x_new
-    return np.stack(X), np.stack(Y)
+        if done:
+            break
+    return np.stack(X), np.stack(Y), ret
+
+
+def initial_data(seed, J, T):
+    rs = np.random.RandomState(seed)
+    env = InvertedPendulumLike(rs)
+    X, Y, _ = rollout(env, lambda x: env.sample_action(), T)
+    for _ in range(1, J):
+        X_, Y_, _ = rollout(env, lambda x: env.sample_action(), T)
+        X, Y = np.vstack((X, X_)), np.vstack((Y, Y_))
+    return env, X, Y
+
+
+def run_hip(J=5, T=40, iters=3, maxiter=50, rollout_steps=100, seed=0, verbose=True):
+    """The loop on the HIP path.  -> dict of stage timings."""
+    from pilco_amd.controllers import RbfController
+    from pilco_amd.models import PILCO
+    np.random.seed(seed)
+    env, X, Y = initial_data(seed, J, T)
+    state_dim, control_dim = Y.shape[1], X.shape[1] - Y.shape[1]
+    controller = RbfController(state_dim=state_dim, control_dim=control_dim, num_basis_functions=10, max_action=3.0)
+    pilco = PILCO((X, Y), controller=controller, horizon=40)     # examples/inverted_pendulum.py:24-27: defaults otherwise
+    stages = []
+    t_all = time.perf_counter()
+    for it in range(iters):
+        t0 = time.perf_counter()
+        pilco.optimize_models(verbose=False)
+        t1 = time.perf_counter()
+        r = pilco.optimize_policy(maxiter=maxiter, restarts=1, verbose=False)
+        t2 = time.perf_counter()
+        X_new, Y_new, ret = rollout(env, lambda x: pilco.compute_action(x[None, :]), rollout_steps)
+        X, Y = np.vstack((X, X_new)), np.vstack((Y, Y_new))
+        pilco.mgpr.set_data((X, Y))
+        stages.append(dict(N=int(X.shape[0] - X_new.shape[0]), optimize_models_s=t1 - t0, optimize_policy_s=t2 - t1,
+                           predicted_reward=float(r), steps_balanced=int(X_new.shape[0])))
+        if verbose:
+            print("[hip] iteration %d: N=%d  optimize_models %.2f s  optimize_policy(maxiter=%d) %.2f s  predicted reward %.3f  "
+                  "pole kept up for %d/%d steps" % (it, stages[-1]["N"], t1 - t0, maxiter, t2 - t1, r, X_new.shape[0], rollout_steps))
+    return dict(total_s=time.perf_counter() - t_all, iterations=stages)
+
+
+def run_cpu(J=5, T=40, iters=3, maxiter=50, rollout_steps=100, seed=0, verbose=True):
+    """The same loop on the CPU stand-in (oracle/cpu_loop.py: NumPy / SciPy / torch-CPU autograd)."""
+    from oracle import cpu_loop
+    np.random.seed(seed)
+    env, X, Y = initial_data(seed, J, T)
+    E, U = Y.shape[1], X.shape[1] - Y.shape[1]
+    D = E + U
+    ls, var, nz = np.ones((E, D)), np.ones(E), np.ones(E)
+    Xp, Yp, lsp = np.random.randn(10, E), 0.1 * np.random.randn(10, U), np.ones((U, E))   # controllers.py:87-90
+    m_init, S_init = X[0:1, :E], 0.1 * np.eye(E)                                          # pilco.py:37-41
+    stages = []
+    t_all = time.perf_counter()
+    for it in range(iters):
+        ls, var, nz, tm = cpu_loop.optimize_models(X, Y, ls, var, nz, restarts=1)
+        Xp, Yp, lsp, r, tpol = cpu_loop.optimize_policy(X, Y, ls, var, nz, Xp, Yp, lsp, m_init, S_init, 40, 3.0, maxiter=maxiter)
+        X_new, Y_new, ret = rollout(env, lambda x: cpu_loop.compute_action(x, Xp, Yp, lsp, 3.0), rollout_steps)
+        stages.append(dict(N=int(X.shape[0]), optimize_models_s=tm, optimize_policy_s=tpol, predicted_reward=float(r),
+                           steps_balanced=int(X_new.shape[0])))
+        X, Y = np.vstack((X, X_new)), np.vstack((Y, Y_new))
+        if verbose:
+            print("[cpu] iteration %d: N=%d  optimize_models %.2f s  optimize_policy(maxiter=%d) %.2f s  predicted reward %.3f  "
+                  "pole kept up for %d/%d steps" % (it, stages[-1]["N"], tm, maxiter, tpol, r, X_new.shape[0], rollout_steps))
+    return dict(total_s=time.perf_counter() - t_all, iterations=stages)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="short smoke variant (2 x 20 random steps, 1 iteration, maxiter 3)")
+    ap.add_argument("--cpu", action="store_true", help="also run the CPU stand-in (oracle/cpu_loop.py)")
+    ap.add_argument("--cpu-iters", type=int, default=None)
     args = ap.parse_args()
-    rs = np.random.RandomState(0)
-    np.random.seed(0)
-    env = Pendulum(rs)
-    T, J, iters, maxiter = (20, 2, 1, 3) if args.quick else (40, 5, 3, 20)
-    t_all = time.time()
-    X, Y = rollout(env, None, T, random=True, rs=rs)
-    for _ in range(1, J):
-        X_, Y_ = rollout(env, None, T, random=True, rs=rs)
-        X, Y = np.vstack((X, X_)), np.vstack((Y, Y_))
-    state_dim, control_dim = Y.shape[1], X.shape[1] - Y.shape[1]
-    controller = RbfController(state_dim=state_dim, control_dim=control_dim, num_basis_functions=10, max_action=2.0)
-    reward = ExponentialReward(state_dim, W=np.diag([2.0, 0.0, 0.3]) + 1e-9 * np.eye(3), t=np.array([1.0, 0.0, 0.0]))
-    m_init = np.array([[-1.0, 0.0, 0.0]])
-    S_init = np.diag([0.01, 0.05, 0.01])
-    pilco = PILCO((X, Y), controller=controller, horizon=T, reward=reward, m_init=m_init, S_init=S_init)
-    for it in range(iters):
-        t0 = time.time()
-        pilco.optimize_models(verbose=False)
-        t1 = time.time()
-        r = pilco.optimize_policy(maxiter=maxiter, restarts=1, verbose=False)
-        t2 = time.time()
-        X_new, Y_new = rollout(env, pilco, T)
-        X, Y = np.vstack((X, X_new)), np.vstack((Y, Y_new))
-        pilco.mgpr.set_data((X, Y))
-        print("iteration %d: N=%d  optimize_models %.2f s  optimize_policy(maxiter=%d) %.2f s  predicted reward %.3f  "
-              "realised cos(theta) at end %.2f" % (it, X.shape[0] - T, t1 - t0, maxiter, t2 - t1, r, X_new[-1, 0]))
-    print("total wall-clock %.1f s" % (time.time() - t_all))
+    kw = dict(J=2, T=20, iters=1, maxiter=3, rollout_steps=20) if args.quick else {}
+    res = run_hip(**kw)
+    print("HIP path: total wall-clock %.2f s" % res["total_s"])
+    if args.cpu:
+        kc = dict(kw)
+        if args.cpu_iters is not None:
+            kc["iters"] = args.cpu_iters
+        rc = run_cpu(**kc)
+        print("CPU stand-in (NumPy/SciPy + torch-CPU autograd, %d host threads): total wall-clock %.2f s" % (os.cpu_count(), rc["total_s"]))
 
 
 if __name__ == "__main__":
