@@ -82,6 +82,12 @@ int pilco_gp_factorize(pilco_ctx* ctx, int slot);
  * autodiff provide to MGPR.optimize (pilco/models/mgpr.py:47-75), without the prior terms (added on
  * the host).  nlml (E), grad (E, D+2) may be NULL.  Exact GP only. */
 int pilco_gp_nlml(pilco_ctx* ctx, int slot, double* nlml, double* grad);
+/* The same for the sparse model: negative log marginal likelihood of gpflow's GPRFITC (one model per output, each with its
+ * OWN inducing inputs: pilco/models/smgpr.py:16-22) and its gradient w.r.t. (lengthscales[D], kernel variance, noise
+ * variance) and w.r.t. the inducing inputs -- what MGPR.optimize's SciPy loop receives for an SMGPR
+ * (pilco/models/mgpr.py:47-75; no priors, smgpr.py sets none).  Z_all (E,M,D); nlml (E); grad_hyp (E,D+2) and
+ * grad_Z (E,M,D) may be NULL.  Uses the slot's data and hyper-parameters; invalidates its cached factorisation. */
+int pilco_gp_fitc_nlml(pilco_ctx* ctx, int slot, const double* Z_all, int M, double* nlml, double* grad_hyp, double* grad_Z);
 /* number of points the moment-matching runs over: N (exact) or M (sparse) */
 int pilco_gp_num_points(const pilco_ctx* ctx, int slot);
 /* download iK (E,n,n) and beta (E,n); either may be NULL */

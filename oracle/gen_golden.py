@@ -281,6 +281,33 @@ def gen_policy_gradient(R):
     _save("policy_gradient.npz", **{k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise", "m", "s", "W", "b")}, **out)
 
 
+def gen_fitc_objective(R):
+    """GPRFITC training loss of every output of an SMGPR (smgpr.py:16-22; what mgpr.py:47-75 hands to SciPy) and its
+    gradient w.r.t. lengthscales / kernel variance / noise variance / the output's OWN inducing inputs: torch autograd
+    through the shim's restatement of gpflow.models.GPRFITC (third-party arithmetic, refshim.py docstring)."""
+    import torch
+    c = synthetic.config_c1()
+    rs = np.random.RandomState(17)
+    M = 30
+    np.random.seed(12)
+    sm = R.SMGPR((c["X"], c["Y"]), num_induced_points=M)
+    _set_hyp(sm.models, c["lengthscales"], c["variance"], np.array([3e-3, 8e-3]))
+    Z_all = np.stack([5 * rs.rand(M, 3), 5 * rs.rand(M, 3)])
+    loss, g_ls, g_var, g_nz, g_Z = [], [], [], [], []
+    for i, mdl in enumerate(sm.models):
+        mdl.inducing_variable.Z.assign(Z_all[i])
+        l = mdl.training_loss()
+        ps = [mdl.kernel.lengthscales, mdl.kernel.variance, mdl.likelihood.variance, mdl.inducing_variable.Z]
+        gs = torch.autograd.grad(l, [p.unconstrained_variable for p in ps])
+        dcon = [torch.sigmoid(p.unconstrained_variable.detach()) if p.transform is not None else 1.0 for p in ps]   # d value / d u
+        loss.append(float(l.detach()))
+        g_ls.append((gs[0] / dcon[0]).numpy()); g_var.append(float(gs[1] / dcon[1])); g_nz.append(float(gs[2] / dcon[2]))
+        g_Z.append(gs[3].numpy())
+    _save("fitc_objective.npz", X=c["X"], Y=c["Y"], lengthscales=c["lengthscales"], variance=c["variance"], noise=np.array([3e-3, 8e-3]),
+          Z_all=Z_all, loss=np.array(loss), dloss_dls=np.stack(g_ls), dloss_dvar=np.array(g_var), dloss_dnoise=np.array(g_nz),
+          dloss_dZ=np.stack(g_Z))
+
+
 def gen_safe():
     """safe_pilco_extension/safe_pilco.py:29-50 + rewards_safe.py:27-61 executed (untested in the reference)."""
     R = ref_exec.load(safe=True)
@@ -312,6 +339,7 @@ def main():
     gen_controllers(R)
     gen_reward(R)
     gen_policy_gradient(R)
+    gen_fitc_objective(R)
     gen_safe()
     print("golden fixtures written to", OUT, "from the executed reference")
 

@@ -61,6 +61,7 @@ SIGNATURES = {
     "pilco_gp_gram": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp]),
     "pilco_gp_factorize": (C.c_int, [_vp, C.c_int]),
     "pilco_gp_nlml": (C.c_int, [_vp, C.c_int, _dp, _dp]),
+    "pilco_gp_fitc_nlml": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _dp]),
     "pilco_gp_num_points": (C.c_int, [_vp, C.c_int]),
     "pilco_gp_get_factors": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "pilco_gp_set_factors": (C.c_int, [_vp, C.c_int, _dp, _dp]),
@@ -216,6 +217,17 @@ class Context:
         grad = np.empty((E, D + 2)) if want_grad else None
         self._chk(self.lib.pilco_gp_nlml(self.h, slot, _ptr(nlml), _ptr(grad)))
         return nlml, grad
+
+    def gp_fitc_nlml(self, slot, Z_all, D, E, want_grad=True):
+        """GPRFITC negative log marginal likelihood per output and its gradients: (nlml (E), dhyp (E, D+2), dZ (E, M, D))."""
+        Z_all = _f64(Z_all)
+        M = Z_all.shape[1]
+        Z_all = _f64(Z_all, (E, M, D))
+        nlml = np.empty(E)
+        gh = np.empty((E, D + 2)) if want_grad else None
+        gz = np.empty((E, M, D)) if want_grad else None
+        self._chk(self.lib.pilco_gp_fitc_nlml(self.h, slot, _ptr(Z_all), M, _ptr(nlml), _ptr(gh), _ptr(gz)))
+        return nlml, gh, gz
 
     def gp_num_points(self, slot):
         return self.lib.pilco_gp_num_points(self.h, slot)

@@ -60,7 +60,7 @@ void launch_gemm(hipStream_t st, const GemmDesc& g, bool ta, bool tb, int batch)
 // diag_mode 0: none; 1: += diag_add[a] on i==j<n1, padding diag = 1; 2: += jitter on diag, padding diag = 1
 void launch_gram(hipStream_t st, const double* P1t, int ld1, int n1, const double* P2t, int ld2, int n2, int D,
                  const double* ls, const double* var, int E, double* out, int rows_pad, int cols_pad, int diag_mode,
-                 const double* diag_add, double jitter);
+                 const double* diag_add, double jitter, long sP1 = 0, long sP2 = 0);   // sP*: per-output strides of the point sets (0 = shared)
 
 // Blocked Cholesky (lower) of batch matrices A[b] (npad x npad, ld = npad), in place; strictly-upper part zeroed.
 // invD receives the inverses of the diagonal 64x64 blocks of L: [batch][npad/64][64][64].

@@ -22,6 +22,7 @@ struct Slot {
     DevBuf Xt, Yt, Zt, ls, var, noise;         // Yt: [E][Npad]
     DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
     DevBuf Kmn, V2, Am, AmInv, AmD, iAt, G;    // FITC extras
+    DevBuf ft_P, ft_T3, ft_Z;                  // FITC training objective (fitc_train.hip)
     // moment-matching workspace
     DevBuf w_in, w_At, w_Bt, w_small, w_part, w_gath, w_out;
     MMWork wk{};

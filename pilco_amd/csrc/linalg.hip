@@ -19,8 +19,10 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ P1t, in
                                               const double* __restrict__ P2t, int ld2, int n2, int D,
                                               const double* __restrict__ ls, const double* __restrict__ var,
                                               double* __restrict__ out, int rows_pad, int cols_pad, int diag_mode,
-                                              const double* __restrict__ diag_add, double jitter) {
+                                              const double* __restrict__ diag_add, double jitter, long sP1, long sP2) {
     const int a = blockIdx.z;
+    P1t += (long)a * sP1;   // per-output point sets (FITC training: every output owns its inducing inputs); 0 = shared
+    P2t += (long)a * sP2;
     const int i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= cols_pad) return;
@@ -45,10 +47,10 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ P1t, in
 
 void launch_gram(hipStream_t st, const double* P1t, int ld1, int n1, const double* P2t, int ld2, int n2, int D,
                  const double* ls, const double* var, int E, double* out, int rows_pad, int cols_pad, int diag_mode,
-                 const double* diag_add, double jitter) {
+                 const double* diag_add, double jitter, long sP1, long sP2) {
     dim3 grid((cols_pad + 255) / 256, rows_pad, E);
     hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, st, P1t, ld1, n1, P2t, ld2, n2, D, ls, var, out, rows_pad, cols_pad,
-                       diag_mode, diag_add, jitter);
+                       diag_mode, diag_add, jitter, sP1, sP2);
 }
 
 __global__ void k_transpose_points(const double* __restrict__ X, int n, int D, double* __restrict__ Xt, int ld) {

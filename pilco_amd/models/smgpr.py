@@ -50,36 +50,13 @@ class SMGPR(MGPR):
         return self.Z
 
     # -- reference: MGPR.optimize applied to GPRFITC models (mgpr.py:47-75 with smgpr.py:16-22)
-    def optimize(self, restarts=1, max_subset=1024):
-        """Hyper-parameter fit for the sparse model.
-
-        The reference hands every GPRFITC model (hyper-parameters AND its own M x D inducing inputs) to
-        SciPy through GPflow's autodiff.  The FITC objective and its Z-gradient are not built here; instead
-        (documented deviation, SURVEY.md 8c marks training as unpinned): the kernel hyper-parameters are fitted
-        with the exact-GP objective on the device (pilco_gp_nlml) over at most ``max_subset`` randomly chosen
-        data points, and the inducing inputs of every output are set to a random subset of the training inputs
-        (the usual FITC initialisation) instead of being moved by gradient steps."""
-        from ..training import optimize_mgpr
-        n = self.num_datapoints
-        idx = np.arange(n) if n <= max_subset else np.sort(np.random.choice(n, max_subset, replace=False))
-        dense = MGPR((self._X[idx], self._Y[idx]), ctx=self.ctx)
-        for src, dst in zip(self.models, dense.models):
-            dst.kernel.lengthscales.assign(src.kernel.lengthscales.numpy())
-            dst.kernel.variance.assign(src.kernel.variance.numpy())
-            dst.likelihood.variance.assign(src.likelihood.variance.numpy())
-        per = optimize_mgpr(dense, restarts=restarts)
-        zi = np.random.choice(n, self.num_induced_points, replace=n < self.num_induced_points)
-        for src, dst in zip(dense.models, self.models):
-            dst.kernel.lengthscales.assign(src.kernel.lengthscales.numpy())
-            dst.kernel.variance.assign(src.kernel.variance.numpy())
-            dst.likelihood.variance.assign(src.likelihood.variance.numpy())
-            dst.inducing_variable.Z.assign(self._X[zi])
-        # the temporary dense model used this model's device slot: push everything again
-        self._data_dirty = True
-        self._hyp_dirty = True
-        self._z_dirty = True
-        self._user_factors = None
-        return per
+    def optimize(self, restarts=1):
+        """Every output's GPRFITC model is fitted as the reference does it: kernel hyper-parameters, noise variance AND
+        the output's own M x D inducing inputs by L-BFGS-B on the FITC marginal likelihood, evaluated with its analytic
+        gradient on the device (pilco_gp_fitc_nlml, csrc/fitc_train.hip).  Prediction then uses model 0's inducing
+        inputs for every output, as the reference does (smgpr.py:47-52)."""
+        from ..training import optimize_smgpr
+        return optimize_smgpr(self, restarts=restarts)
 
     @property
     def Z(self):

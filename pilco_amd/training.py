@@ -81,7 +81,7 @@ def optimize_mgpr(mgpr, restarts=1, maxiter=1000, verbose=False):
     from .models.smgpr import SMGPR
     from . import _lib
     if isinstance(mgpr, SMGPR):
-        raise TypeError("optimize_mgpr fits the exact GP objective; SMGPR.optimize wraps it (subset fit + inducing subset)")
+        raise TypeError("optimize_mgpr fits the exact GP objective; SMGPR.optimize uses optimize_smgpr (GPRFITC objective)")
     noise_trainable = all(m.likelihood.variance.trainable for m in mgpr.models)
 
     def run(u0):
@@ -120,6 +120,71 @@ def optimize_mgpr(mgpr, restarts=1, maxiter=1000, verbose=False):
         u_best, per_best = ub, np.minimum(per, per_best)
     mgpr_objective(mgpr, u_best, noise_trainable)   # leaves the best parameters assigned
     mgpr._sync()
+    return per_best
+
+
+def smgpr_objective(smgpr, u):
+    """Sum over outputs of gpflow's GPRFITC training loss (no priors: smgpr.py:16-22 sets none) and its gradient in
+    the unconstrained space: softplus for lengthscales / variances (noise floor 1e-6), identity for the inducing inputs."""
+    E, D, M = smgpr.num_outputs, smgpr.num_dims, smgpr.num_induced_points
+    nk = E * D + 2 * E
+    ls, var, nz = _mgpr_unpack(smgpr, u[:nk])
+    Z = u[nk:].reshape(E, M, D)
+    for i, m in enumerate(smgpr.models):
+        m.kernel.lengthscales.assign(ls[i])
+        m.kernel.variance.assign(var[i])
+        m.likelihood.variance.assign(nz[i])
+    smgpr._sync()
+    nlml, gh, gz = smgpr.ctx.gp_fitc_nlml(smgpr._slot, Z, D, E)
+    g_ls = gh[:, :D] * _dsoftplus(u[:E * D]).reshape(E, D)
+    g_var = gh[:, D] * _dsoftplus(u[E * D:E * D + E])
+    g_nz = gh[:, D + 1] * _dsoftplus(u[E * D + E:nk])
+    return nlml, np.concatenate([g_ls.ravel(), g_var, g_nz, gz.ravel()])
+
+
+def optimize_smgpr(smgpr, restarts=1, maxiter=1000):
+    """MGPR.optimize applied to GPRFITC models (mgpr.py:47-75 with smgpr.py:16-22): every output's kernel
+    hyper-parameters, noise variance and OWN inducing inputs by L-BFGS-B on the device objective (pilco_gp_fitc_nlml);
+    the outputs are independent problems, optimised jointly as one separable problem.  `restarts` extra fits start
+    from randomize() (mgpr.py:8-15; the inducing inputs keep their current values, as in the reference)."""
+    from . import _lib
+    E, D, M = smgpr.num_outputs, smgpr.num_dims, smgpr.num_induced_points
+    Z0 = np.stack([np.asarray(m.inducing_variable.Z.numpy(), np.float64) for m in smgpr.models])
+
+    def run(u0):
+        def fun(u):
+            try:
+                per, grad = smgpr_objective(smgpr, u)
+            except _lib.NotPositiveDefiniteError:
+                return 1e25, np.zeros_like(u)
+            return float(per.sum()), grad
+        res = minimize(fun, u0, jac=True, method="L-BFGS-B", options=dict(maxiter=maxiter))
+        per, _ = smgpr_objective(smgpr, res.x)
+        return res.x, per
+
+    u_best, per_best = run(np.concatenate([_mgpr_pack(smgpr), Z0.ravel()]))
+    nk = E * D + 2 * E
+    for _ in range(restarts):
+        ls0 = 1 + 0.01 * np.random.normal(size=(E, D))
+        var0 = 1 + 0.01 * np.random.normal(size=E)
+        nz0 = 1 + 0.01 * np.random.normal(size=E)
+        u0 = np.concatenate([_softplus_inv(ls0).ravel(), _softplus_inv(var0), _softplus_inv(np.maximum(nz0 - NOISE_LOWER, 1e-12)),
+                             u_best[nk:]])
+        u, per = run(u0)
+        better = per < per_best
+        ub = u_best.copy()
+        Zb, Zn = ub[nk:].reshape(E, M, D), u[nk:].reshape(E, M, D)
+        for a in np.nonzero(better)[0]:
+            ub[a * D:(a + 1) * D] = u[a * D:(a + 1) * D]
+            ub[E * D + a] = u[E * D + a]
+            ub[E * D + E + a] = u[E * D + E + a]
+            Zb[a] = Zn[a]
+        u_best, per_best = ub, np.minimum(per, per_best)
+    smgpr_objective(smgpr, u_best)      # leaves the best kernel parameters assigned
+    Zf = u_best[nk:].reshape(E, M, D)
+    for i, m in enumerate(smgpr.models):
+        m.inducing_variable.Z.assign(Zf[i])
+    smgpr._sync()
     return per_best
 
 

@@ -918,10 +918,69 @@ def test_rbf_policy_gradient_adjoint_vs_autograd(ctx):
     assert r_opt >= r - 1e-12
 
 
+def test_fitc_training_objective_and_gradients(ctx, golden_dir):
+    """GPRFITC negative log marginal likelihood per output and its gradient w.r.t. lengthscales, kernel variance, noise
+    variance and each output's own inducing inputs (the trainable set of the reference's sparse models, smgpr.py:16-22
+    via mgpr.py:47-75) against torch autograd of the restated GPflow objective (fixture fitc_objective.npz), then
+    against central differences of the device objective itself."""
+    from pilco_amd.models import SMGPR
+    g = np.load(os.path.join(golden_dir, "fitc_objective.npz"))
+    cfg = dict(X=g["X"], Y=g["Y"], lengthscales=g["lengthscales"], variance=g["variance"], noise=g["noise"])
+    m = _mgpr(cfg, cls=SMGPR, num_induced_points=g["Z_all"].shape[1])
+    m._sync()
+    nlml, gh, gz = ctx.gp_fitc_nlml(0, g["Z_all"], 3, 2)
+    np.testing.assert_allclose(nlml, g["loss"], rtol=1e-9)
+    np.testing.assert_allclose(gh[:, :3], g["dloss_dls"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(gh[:, 3], g["dloss_dvar"], rtol=1e-6)
+    np.testing.assert_allclose(gh[:, 4], g["dloss_dnoise"], rtol=1e-6)
+    np.testing.assert_allclose(gz, g["dloss_dZ"], rtol=1e-6, atol=1e-8)
+    Z = g["Z_all"].copy()
+    for idx in [(0, 3, 1), (1, 17, 2)]:
+        h = 1e-6
+        Zp, Zm = Z.copy(), Z.copy()
+        Zp[idx] += h
+        Zm[idx] -= h
+        fd = (ctx.gp_fitc_nlml(0, Zp, 3, 2, want_grad=False)[0][idx[0]] - ctx.gp_fitc_nlml(0, Zm, 3, 2, want_grad=False)[0][idx[0]]) / (2 * h)
+        np.testing.assert_allclose(gz[idx], fd, rtol=1e-5)
+    # a larger, padded case (N not a multiple of 64, M = 70): value vs the NumPy restatement, gradient vs differences
+    c = synthetic.config_c2(N=333, D=4, E=3, seed=4, control_dim=1)
+    ms = _mgpr(c, cls=SMGPR, num_induced_points=70)
+    ms._sync()
+    rs = np.random.RandomState(2)
+    Zb = rs.randn(3, 70, 4)
+    nl, gh2, gz2 = ctx.gp_fitc_nlml(0, Zb, 4, 3)
+    for e in range(3):
+        np.testing.assert_allclose(nl[e], _fitc_loss_np(c["X"], c["Y"][:, e], Zb[e], c["lengthscales"][e], c["variance"][e], c["noise"][e]), rtol=1e-9)
+    u = np.log(c["lengthscales"])
+    for (e, d) in [(0, 1), (2, 3)]:
+        lp, lm = c["lengthscales"].copy(), c["lengthscales"].copy()
+        lp[e, d] *= 1 + 1e-6
+        lm[e, d] *= 1 - 1e-6
+        fp = _fitc_loss_np(c["X"], c["Y"][:, e], Zb[e], lp[e], c["variance"][e], c["noise"][e])
+        fm = _fitc_loss_np(c["X"], c["Y"][:, e], Zb[e], lm[e], c["variance"][e], c["noise"][e])
+        np.testing.assert_allclose(gh2[e, d], (fp - fm) / (2e-6 * c["lengthscales"][e, d]), rtol=1e-4)
+
+
+def _fitc_loss_np(X, y, Z, ls, var, noise, jitter=1e-6):
+    """NumPy restatement of gpflow GPRFITC's negative log marginal likelihood (one output)."""
+    import scipy.linalg as sla
+    N, M = X.shape[0], Z.shape[0]
+    Kuf = tp.se_ard_K(Z, X, ls[None, :], np.array([var]))[0]
+    Kuu = tp.se_ard_K(Z, None, ls[None, :], np.array([var]))[0] + jitter * np.eye(M)
+    Luu = np.linalg.cholesky(Kuu)
+    V = sla.solve_triangular(Luu, Kuf, lower=True)
+    nu = var - np.sum(V * V, 0) + noise
+    B = np.eye(M) + (V / nu) @ V.T
+    L = np.linalg.cholesky(B)
+    gamma = sla.solve_triangular(L, V @ (y / nu), lower=True)
+    f = -0.5 * np.sum(y * y / nu) + 0.5 * gamma @ gamma - 0.5 * N * np.log(2 * np.pi) - 0.5 * np.sum(np.log(nu)) - np.sum(np.log(np.diag(L)))
+    return -f
+
+
 def test_sparse_optimize_models_runs_and_predicts(ctx):
-    """PILCO(num_induced_points=..).optimize_models() (pilco.py:52-56 -> SMGPR): the sparse model's fit (exact-GP
-    objective on a data subset + inducing subset, see SMGPR.optimize) must leave a usable model whose one-step
-    prediction is close to the dense model trained the same way."""
+    """PILCO(num_induced_points=..).optimize_models() (pilco.py:52-56 -> SMGPR): the sparse model's fit (GPRFITC objective
+    with trained inducing inputs) must lower its objective and leave a usable model whose one-step prediction is close
+    to the dense model's."""
     from pilco_amd.models import PILCO
     rs = np.random.RandomState(5)
     X = rs.rand(160, 3) * 2 - 1
@@ -929,7 +988,15 @@ def test_sparse_optimize_models_runs_and_predicts(ctx):
     Y = f(X) + 0.02 * rs.randn(160, 2)
     ps = PILCO((X, Y), num_induced_points=60, horizon=2)
     np.random.seed(0)
+    from pilco_amd.training import _mgpr_pack, smgpr_objective
+    Z0 = np.stack([mm.inducing_variable.Z.numpy() for mm in ps.mgpr.models])
+    before, _ = smgpr_objective(ps.mgpr, np.concatenate([_mgpr_pack(ps.mgpr), Z0.ravel()]))
     ps.optimize_models(verbose=False)
+    Z1 = np.stack([mm.inducing_variable.Z.numpy() for mm in ps.mgpr.models])
+    after, _ = smgpr_objective(ps.mgpr, np.concatenate([_mgpr_pack(ps.mgpr), Z1.ravel()]))
+    assert np.all(after < before - 1.0), (before, after)          # the FITC objective went down for every output
+    assert not np.allclose(Z0, Z1)                                 # and the inducing inputs moved (they are trained)
+    assert not np.allclose(Z1[0], Z1[1])                           # every output owns its inducing inputs (smgpr.py:20-22)
     pd = PILCO((X, Y), horizon=2)
     np.random.seed(0)   # same restart draws: the hyper-parameter fits coincide
     pd.optimize_models(verbose=False)
@@ -938,8 +1005,7 @@ def test_sparse_optimize_models_runs_and_predicts(ctx):
     Ms, Ss, Vs = ps.mgpr.predict_on_noisy_inputs(m, s)
     Md, Sd, Vd = pd.mgpr.predict_on_noisy_inputs(m, s)
     assert np.all(np.isfinite(Ms)) and np.all(np.isfinite(Ss))
-    np.testing.assert_allclose(Ms, Md, atol=0.05)
-    np.testing.assert_allclose(ls_of(ps), ls_of(pd), rtol=0.2)
+    np.testing.assert_allclose(Ms, Md, atol=0.1)
     # the standard loop (examples/inverted_pendulum.py:32-39): optimize_models again after predictions and new data
     Ms2, _, _ = ps.mgpr.predict_on_noisy_inputs(m, s)
     np.testing.assert_allclose(Ms2, Ms, rtol=1e-12)      # pd's use of the slot in between did not leak into ps
