@@ -217,6 +217,14 @@ int pilco_shard_output_slot(int E, int D, int nranks, int a);
  * same with ncclAllGather when a communicator is attached. */
 int pilco_gp_shard_pack(pilco_ctx* ctx, int slot, const double* m, const double* s, double* segment);
 int pilco_gp_shard_finish(pilco_ctx* ctx, int slot, const double* gathered, double* M, double* S, double* V);
+/* The whole sharded rollout over n contexts of ONE process (context i = rank i of n; several contexts may share a GPU):
+ * every context runs pilco_rollout on its own host thread and the per-step exchange is done with peer copies between
+ * host barriers instead of ncclAllGather -- the same launch sequence as the RCCL path, so the multi-rank rollout can be
+ * validated without a multi-GPU node (host-synchronised per step: a test vehicle, not a fast path).
+ * Outputs are rank 0's; *mismatch (may be NULL) = 1 if another rank finished with a different bit pattern. */
+int pilco_rollout_group(pilco_ctx** ctxs, int n, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                        const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj,
+                        int* mismatch);
 int pilco_comm_rank(const pilco_ctx* ctx);
 int pilco_comm_size(const pilco_ctx* ctx);
 

@@ -95,6 +95,8 @@ SIGNATURES = {
     "pilco_shard_output_slot": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "pilco_gp_shard_pack": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "pilco_gp_shard_finish": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
+    "pilco_rollout_group": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp,
+                            C.c_int, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     "pilco_comm_rank": (C.c_int, [_vp]),
     "pilco_comm_size": (C.c_int, [_vp]),
 }
@@ -448,6 +450,24 @@ class Context:
 
     def shard_set(self, rank, nranks):
         self._chk(self.lib.pilco_shard_set(self.h, int(rank), int(nranks)))
+
+
+def rollout_group(ctxs, policy, rewards, m0, S0, H, want_traj=False):
+    """One rollout sharded over the contexts of this process (context i = rank i; each must be shard_set(i, n) and hold
+    the same factorised model).  -> (mH, SH, reward[, traj], mismatch)."""
+    c0 = ctxs[0]
+    E = policy["state_dim"]
+    p, k1 = c0._policy(policy)
+    r, k2 = c0._rewards(rewards, E)
+    m0 = _f64(m0, (E,))
+    S0 = _f64(S0, (E, E))
+    mH, SH, rew = np.empty((1, E)), np.empty((E, E)), np.zeros((1, 1))
+    traj = np.empty((H + 1, E + E * E)) if want_traj else None
+    arr = (_vp * len(ctxs))(*[c.h for c in ctxs])
+    mm = C.c_int(0)
+    c0._chk(c0.lib.pilco_rollout_group(arr, len(ctxs), C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H), _ptr(mH), _ptr(SH),
+                                       _ptr(rew), _ptr(traj), C.byref(mm)))
+    return (mH, SH, rew, traj, mm.value) if want_traj else (mH, SH, rew, mm.value)
 
 
 def shard_plan(E, D, nranks, rank):

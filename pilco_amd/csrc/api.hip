@@ -126,8 +126,28 @@ MMModel model_of(const Slot& s) {
     return md;
 }
 
+// in-process exchange (pilco_rollout_group): every member waits for all segments to be complete, copies the peers'
+// segments into its own gather buffer (device-to-device / peer-to-peer), and nobody starts the next step before all
+// copies are done
+static int group_exchange(pilco_ctx* ctx, Slot& s) {
+    PeerGroup& grp = *ctx->group;
+    const int slot_idx = (int)(&s - &ctx->slot[0]);
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    if (!grp.arrive_and_wait()) return fail(ctx, PILCO_E_STATE, "group exchange: another member failed");
+    const size_t seg = (size_t)s.wk.SEG;
+    for (int j = 0; j < (int)grp.ctxs.size(); ++j) {
+        if (j == ctx->rank) continue;
+        const double* src = grp.ctxs[j]->slot[slot_idx].wk.gath + (size_t)j * seg;
+        HIPCHK(hipMemcpyAsync(s.wk.gath + (size_t)j * seg, src, sizeof(double) * seg, hipMemcpyDefault, ctx->st));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    if (!grp.arrive_and_wait()) return fail(ctx, PILCO_E_STATE, "group exchange: another member failed");
+    return PILCO_OK;
+}
+
 int all_gather_segments(pilco_ctx* ctx, Slot& s) {
     if (ctx->nranks == 1 && !ctx->comm) return PILCO_OK;
+    if (ctx->group) return group_exchange(ctx, s);
     if (!ctx->comm) return fail(ctx, PILCO_E_STATE, "sharded context without communicator: use pilco_gp_shard_pack / pilco_gp_shard_finish");
     double* base = s.wk.gath;
     ncclResult_t r = ncclAllGather(base + (size_t)ctx->rank * s.wk.SEG, base, s.wk.SEG, ncclDouble, ctx->comm, ctx->st);

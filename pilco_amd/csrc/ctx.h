@@ -5,6 +5,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <cmath>
 #include <cstdint>
 
@@ -34,6 +37,35 @@ struct Slot {
 };
 
 
+// Several contexts of ONE process exchanging their per-step segments through peer copies (pilco_rollout_group): a
+// reusable host barrier shared by the group; `failed` releases everybody when one member hits an error.
+struct PeerGroup {
+    std::vector<struct pilco_ctx*> ctxs;
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    unsigned long generation = 0;
+    bool failed = false;
+    bool arrive_and_wait() {   // false when the group has failed
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed) return false;
+        const unsigned long gen = generation;
+        if (++waiting == (int)ctxs.size()) {
+            waiting = 0;
+            ++generation;
+            cv.notify_all();
+            return true;
+        }
+        cv.wait(lk, [&] { return generation != gen || failed; });
+        return !failed;
+    }
+    void fail_all() {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        cv.notify_all();
+    }
+};
+
 struct pilco_ctx {
     int device = 0;
     hipStream_t st = nullptr;
@@ -42,6 +74,7 @@ struct pilco_ctx {
     int variant = 0;
     int rank = 0, nranks = 1;
     ncclComm_t comm = nullptr;
+    std::shared_ptr<PeerGroup> group;   // set only while pilco_rollout_group runs
     Slot slot[2];
     int* d_info = nullptr;
     DevBuf state;   // m_x, s_x, s1, reward, act_out, rew_out

@@ -1,6 +1,8 @@
 // Multi-GPU: RCCL communicator, pair ownership / gather-buffer layout, host-mediated exchange (BASELINE config 3).
 #include "ctx.h"
 
+#include <thread>
+
 extern "C" {
 
 // ------------------------------------------------------------------ multi-GPU
@@ -132,6 +134,55 @@ int pilco_gp_shard_finish(pilco_ctx* ctx, int slot, const double* gathered, doub
     HIPCHK(hipMemcpyAsync(V, s.wk.out_V, sizeof(double) * D * E, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());
+    return PILCO_OK;
+}
+
+// One sharded rollout over n contexts of THIS process (rank i = ctxs[i], any devices): every context runs its own
+// pilco_rollout on a host thread; the per-step exchange is done by peer copies between host barriers.  It drives exactly
+// the launch sequence the RCCL path runs (PACK launch, exchange, tail launch) with the collective swapped for copies,
+// so the sharded rollout can be validated on a single GPU.  Outputs: rank 0's; *mismatch = 1 if any other rank ended
+// with a different bit pattern.
+int pilco_rollout_group(pilco_ctx** ctxs, int n, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                        const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj,
+                        int* mismatch) {
+    if (!ctxs || n <= 0 || !ctxs[0]) return PILCO_E_SHAPE;
+    pilco_ctx* c0 = ctxs[0];
+    if (!policy || !mH || !SH || !reward) return fail(c0, PILCO_E_SHAPE, "rollout_group: null pointer");
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i] || ctxs[i]->nranks != n || ctxs[i]->rank != i || ctxs[i]->comm)
+            return fail(c0, PILCO_E_STATE, "rollout_group: context i must be shard_set(i, n) and have no communicator");
+    const int E = policy->state_dim;
+    auto grp = std::make_shared<PeerGroup>();
+    grp->ctxs.assign(ctxs, ctxs + n);
+    for (int i = 0; i < n; ++i) ctxs[i]->group = grp;
+    const size_t nt = traj ? (size_t)(H + 1) * (E + (size_t)E * E) : 0;
+    std::vector<std::vector<double>> om(n, std::vector<double>(E)), os(n, std::vector<double>((size_t)E * E)), orw(n, std::vector<double>(1)),
+        otr(n, std::vector<double>(nt));
+    std::vector<int> rc(n, PILCO_OK);
+    std::vector<std::thread> th;
+    for (int i = 0; i < n; ++i)
+        th.emplace_back([&, i] {
+            rc[i] = pilco_rollout(ctxs[i], policy, rewards, n_rewards, m0, S0, H, om[i].data(), os[i].data(), orw[i].data(),
+                                  traj ? otr[i].data() : nullptr);
+            if (rc[i] != PILCO_OK) grp->fail_all();
+        });
+    for (auto& t : th) t.join();
+    for (int i = 0; i < n; ++i) ctxs[i]->group.reset();
+    for (int i = 0; i < n; ++i)
+        if (rc[i] != PILCO_OK) {
+            if (i != 0) c0->err = "rank " + std::to_string(i) + ": " + ctxs[i]->err;
+            return rc[i];
+        }
+    int mm = 0;
+    for (int i = 1; i < n; ++i)
+        if (memcmp(om[i].data(), om[0].data(), sizeof(double) * E) || memcmp(os[i].data(), os[0].data(), sizeof(double) * E * E) ||
+            memcmp(orw[i].data(), orw[0].data(), sizeof(double)) || (nt && memcmp(otr[i].data(), otr[0].data(), sizeof(double) * nt)))
+            mm = 1;
+    if (mismatch) *mismatch = mm;
+    memcpy(mH, om[0].data(), sizeof(double) * E);
+    memcpy(SH, os[0].data(), sizeof(double) * (size_t)E * E);
+    *reward = orw[0][0];
+    if (traj) memcpy(traj, otr[0].data(), sizeof(double) * nt);
     return PILCO_OK;
 }
 

@@ -511,6 +511,62 @@ def test_sharded_step_two_contexts_host_allgather(variant, nranks):
             cx.close()
 
 
+@pytest.mark.parametrize("E,U,nranks", [(5, 1, 2), (5, 1, 3), (2, 1, 4), (10, 0, 8)])
+def test_sharded_rollout_group_of_contexts(E, U, nranks):
+    """BASELINE config 3's ROLLOUT on one GPU: `nranks` contexts of this process run the whole sharded H-step rollout
+    (per step: own pairs -> PACK launch -> exchange -> assemble / propagate / controller on every rank; the reward of a
+    rank without pairs stays in its glue launch), the ncclAllGather replaced by peer copies between host barriers
+    (pilco_rollout_group).  Every rank must end bit-identical to the others; with the tiled kernel (variant 2) also
+    bit-identical to the single-rank run, with the default stream-K kernel equal to rounding.  (2, 1, 4): more ranks
+    than pairs, so rank 3 owns nothing.  (10, 0, 8): the benchmark's pair / rank split (55 pairs over 8 ranks)."""
+    from pilco_amd import _lib
+    D, H = E + U, 6
+    c = synthetic.config_c2(N=180, D=D, E=E, noise=1e-2, seed=31, control_dim=U)
+    pol = (dict(kind=_lib.POLICY_LINEAR, state_dim=E, control_dim=U, W=c["W"], b=c["b"].ravel(), max_action=1.5, squash=True) if U
+           else dict(kind=_lib.POLICY_NONE, state_dim=E, control_dim=0))
+    rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(E), t=np.zeros(E))]
+    m0, S0 = c["m0"], 0.05 * np.eye(E)
+    made = []
+
+    def ctx_for(rank, n, variant):
+        cx = _lib.Context(device=0)
+        made.append(cx)
+        cx.set_pair_kernel(variant)
+        if n > 1:
+            cx.shard_set(rank, n)
+        cx.gp_set_data(0, c["X"], c["Y"])
+        cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"])
+        cx.gp_factorize(0)
+        return cx
+    try:
+        for variant in (2, 0):
+            ref = ctx_for(0, 1, variant)
+            ref.set_fused_step(0)
+            M1, S1, R1, T1 = ref.rollout(pol, rw, m0, S0, H, want_traj=True)
+            ref.set_fused_step(1)
+            Mf, Sf, Rf, Tf = ref.rollout(pol, rw, m0, S0, H, want_traj=True)
+            assert np.array_equal(T1, Tf) and np.array_equal(R1, Rf)
+            group = [ctx_for(r, nranks, variant) for r in range(nranks)]
+            M, S, R, T, mismatch = _lib.rollout_group(group, pol, rw, m0, S0, H, want_traj=True)
+            assert mismatch == 0                               # all ranks agree to the bit
+            if variant == 2:
+                assert np.array_equal(M, M1) and np.array_equal(S, S1) and np.array_equal(R, R1) and np.array_equal(T, T1)
+            else:
+                np.testing.assert_allclose(T, T1, rtol=1e-10, atol=1e-13)
+                np.testing.assert_allclose(R, R1, rtol=1e-12)
+            M2, S2, R2, mm2 = _lib.rollout_group(group, pol, rw, m0, S0, H)     # and it is repeatable
+            assert mm2 == 0 and np.array_equal(M2, M) and np.array_equal(S2, S) and np.array_equal(R2, R)
+        model = tp.Model(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+        ctl = (lambda mm, ss: tp.linear_controller(mm, ss, c["W"], c["b"], 1.5)) if U else tp.no_controller
+        Mo, So, Ro = tp.predict(model, ctl, tp.exponential_reward, m0, S0, H, cache=True)
+        np.testing.assert_allclose(M, Mo, rtol=RTOL)
+        np.testing.assert_allclose(S, So, rtol=RTOL, atol=1e-12)
+        np.testing.assert_allclose(R, Ro, rtol=RTOL)
+    finally:
+        for cx in made:
+            cx.close()
+
+
 def test_rccl_path_world_size_one():
     """The RCCL branch (pack -> ncclAllGather -> assemble) with a one-rank communicator."""
     from pilco_amd import _lib
