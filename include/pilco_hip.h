@@ -217,6 +217,11 @@ int pilco_shard_output_slot(int E, int D, int nranks, int a);
  * same with ncclAllGather when a communicator is attached. */
 int pilco_gp_shard_pack(pilco_ctx* ctx, int slot, const double* m, const double* s, double* segment);
 int pilco_gp_shard_finish(pilco_ctx* ctx, int slot, const double* gathered, double* M, double* S, double* V);
+/* Sharded factorisation: with nranks > 1 pilco_gp_factorize computes and stores K / L^-1 / iK only for the outputs this
+ * rank owns (a = rank, rank + nranks, ...; memory and work / nranks, no communication) and then needs every rank's beta
+ * rows: one ncclAllGather per MODEL when a communicator is attached, or -- contexts of one process -- this call, after
+ * all of them have factorised. */
+int pilco_group_sync_model(pilco_ctx** ctxs, int n, int slot);
 /* The whole sharded rollout over n contexts of ONE process (context i = rank i of n; several contexts may share a GPU):
  * every context runs pilco_rollout on its own host thread and the per-step exchange is done with peer copies between
  * host barriers instead of ncclAllGather -- the same launch sequence as the RCCL path, so the multi-rank rollout can be

@@ -97,6 +97,7 @@ SIGNATURES = {
     "pilco_gp_shard_finish": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
     "pilco_rollout_group": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp,
                             C.c_int, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
+    "pilco_group_sync_model": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int]),
     "pilco_comm_rank": (C.c_int, [_vp]),
     "pilco_comm_size": (C.c_int, [_vp]),
 }
@@ -450,6 +451,12 @@ class Context:
 
     def shard_set(self, rank, nranks):
         self._chk(self.lib.pilco_shard_set(self.h, int(rank), int(nranks)))
+
+
+def group_sync_model(ctxs, slot=0):
+    """Exchange the beta rows of the contexts of this process after each has factorised its own outputs."""
+    arr = (_vp * len(ctxs))(*[c.h for c in ctxs])
+    ctxs[0]._chk(ctxs[0].lib.pilco_group_sync_model(arr, len(ctxs), int(slot)))
 
 
 def rollout_group(ctxs, policy, rewards, m0, S0, H, want_traj=False):

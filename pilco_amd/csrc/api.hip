@@ -119,6 +119,8 @@ MMModel model_of(const Slot& s) {
     md.var = s.var.p;
     md.beta = s.beta.p;
     md.iK = (s.iK_null || s.ignore_iK) ? nullptr : s.iK.p;
+    md.bW = s.shW > 0 ? s.shW : 1;
+    md.bEL = s.shW > 1 ? s.shEL : s.E;
     md.n = s.n;
     md.npad = s.npad;
     md.D = s.D;
@@ -155,43 +157,99 @@ int all_gather_segments(pilco_ctx* ctx, Slot& s) {
     return PILCO_OK;
 }
 
-// ---- exact GP: Gram -> Cholesky -> L^{-1} -> iK = L^{-T} L^{-1}, beta = L^{-T} (L^{-1} y)
+// ---- which outputs this rank factorises, and their hyper-parameters / targets compacted for the batched kernels
+struct OwnView {
+    int W, rank, EL, ELcap;
+    const double *ls, *var, *noise, *Yt;   // [EL][D], [EL], [EL], [EL][Npad]
+};
+static int prepare_own(pilco_ctx* ctx, Slot& s, OwnView& o) {
+    o.W = ctx->nranks;
+    o.rank = ctx->rank;
+    const int E = s.E, D = s.D, Np = s.Npad;
+    o.ELcap = (E + o.W - 1) / o.W;
+    o.EL = (o.rank < E) ? (E - o.rank + o.W - 1) / o.W : 0;
+    if (o.W == 1) {
+        o.ls = s.ls.p; o.var = s.var.p; o.noise = s.noise.p; o.Yt = s.Yt.p;
+        return PILCO_OK;
+    }
+    const int ELa = std::max(o.EL, 1);
+    ENSURE(s.own, (size_t)ELa * (D + 2) + (size_t)ELa * Np);
+    double* pls = s.own.p;
+    double* pvar = pls + (size_t)ELa * D;
+    double* pnz = pvar + ELa;
+    double* pY = pnz + ELa;
+    if (o.EL > 0) {   // rows rank, rank + W, ... of the full arrays (strided device-to-device copies)
+        hipStream_t st = ctx->st;
+        HIPCHK(hipMemcpy2DAsync(pls, sizeof(double) * D, s.ls.p + (size_t)o.rank * D, sizeof(double) * D * o.W, sizeof(double) * D, o.EL, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpy2DAsync(pvar, sizeof(double), s.var.p + o.rank, sizeof(double) * o.W, sizeof(double), o.EL, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpy2DAsync(pnz, sizeof(double), s.noise.p + o.rank, sizeof(double) * o.W, sizeof(double), o.EL, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpy2DAsync(pY, sizeof(double) * Np, s.Yt.p + (size_t)o.rank * Np, sizeof(double) * Np * o.W, sizeof(double) * Np, o.EL, hipMemcpyDeviceToDevice, st));
+    }
+    o.ls = pls; o.var = pvar; o.noise = pnz; o.Yt = pY;
+    return PILCO_OK;
+}
+
+// beta rows of the other ranks: one ncclAllGather per MODEL (not per step).  Without a communicator the rows arrive
+// later through pilco_group_sync_model (contexts of one process) and the factorisation stays incomplete until then.
+static int gather_beta(pilco_ctx* ctx, Slot& s, const OwnView& o, int npad) {
+    s.shW = o.W; s.shEL = o.ELcap; s.shOwn = o.EL; s.shRank = o.rank;
+    s.beta_complete = true;
+    if (o.W == 1) return PILCO_OK;
+    if (ctx->comm) {
+        const size_t blk = (size_t)o.ELcap * npad;
+        ncclResult_t r = ncclAllGather(s.beta.p + (size_t)o.rank * blk, s.beta.p, blk, ncclDouble, ctx->comm, ctx->st);
+        if (r != ncclSuccess) return fail(ctx, PILCO_E_RCCL, std::string("ncclAllGather(beta): ") + ncclGetErrorString(r));
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        return PILCO_OK;
+    }
+    s.beta_complete = false;
+    return PILCO_OK;
+}
+
+// ---- exact GP: Gram -> Cholesky -> L^{-1} -> iK = L^{-T} L^{-1}, beta = L^{-T} (L^{-1} y), for the outputs this rank owns
 int factorize_exact(pilco_ctx* ctx, Slot& s) {
-    const int E = s.E, npad = s.Npad, nblk = npad / NB;
+    OwnView o{};
+    if (int r = prepare_own(ctx, s, o)) return r;
+    const int EL = o.EL, ELa = std::max(EL, 1), npad = s.Npad, nblk = npad / NB;
     const size_t mat = (size_t)npad * npad;
-    ENSURE(s.K, E * mat);
-    ENSURE(s.Linv, E * mat);
-    ENSURE(s.iK, E * mat);
-    ENSURE(s.invD, (size_t)E * nblk * NB * NB);
-    ENSURE(s.beta, (size_t)E * npad);
-    ENSURE(s.vec, (size_t)E * npad);
+    ENSURE(s.K, ELa * mat);
+    ENSURE(s.Linv, ELa * mat);
+    ENSURE(s.iK, ELa * mat);
+    ENSURE(s.invD, (size_t)ELa * nblk * NB * NB);
+    ENSURE(s.beta, (size_t)o.W * o.ELcap * npad);
+    ENSURE(s.vec, (size_t)ELa * npad);
     hipStream_t st = ctx->st;
     HIPCHK(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * 64, st));
-    launch_gram(st, s.Xt.p, npad, s.N, s.Xt.p, npad, s.N, s.D, s.ls.p, s.var.p, E, s.K.p, npad, npad, 1, s.noise.p, 0.0);
-    launch_potrf(st, s.K.p, npad, E, s.invD.p, ctx->d_info);
-    launch_trtri(st, s.K.p, npad, E, s.invD.p, s.Linv.p, s.iK.p, (long)mat);   // iK is free until the next GEMM
-    GemmDesc g{};
-    g.A = s.Linv.p; g.lda = npad; g.sA = (long)mat;
-    g.B = s.Linv.p; g.ldb = npad; g.sB = (long)mat;
-    g.C = s.iK.p; g.ldc = npad; g.sC = (long)mat;
-    g.M = npad; g.N = npad; g.K = npad; g.alpha = 1.0; g.beta = 0.0; g.tile_mode = 0; g.k_mode = 1;
-    launch_gemm(st, g, true, false, E);
-    launch_clear_padding(st, s.iK.p, npad, s.N, E);
-    launch_matvec(st, s.Linv.p, npad, E, s.Yt.p, s.vec.p, false);
-    launch_matvec(st, s.Linv.p, npad, E, s.vec.p, s.beta.p, true);
+    if (o.W > 1) HIPCHK(hipMemsetAsync(s.beta.p, 0, sizeof(double) * (size_t)o.W * o.ELcap * npad, st));
+    double* beta_own = s.beta.p + (size_t)o.rank * o.ELcap * npad;
+    if (EL > 0) {
+        launch_gram(st, s.Xt.p, npad, s.N, s.Xt.p, npad, s.N, s.D, o.ls, o.var, EL, s.K.p, npad, npad, 1, o.noise, 0.0);
+        launch_potrf(st, s.K.p, npad, EL, s.invD.p, ctx->d_info);
+        launch_trtri(st, s.K.p, npad, EL, s.invD.p, s.Linv.p, s.iK.p, (long)mat);   // iK is free until the next GEMM
+        GemmDesc g{};
+        g.A = s.Linv.p; g.lda = npad; g.sA = (long)mat;
+        g.B = s.Linv.p; g.ldb = npad; g.sB = (long)mat;
+        g.C = s.iK.p; g.ldc = npad; g.sC = (long)mat;
+        g.M = npad; g.N = npad; g.K = npad; g.alpha = 1.0; g.beta = 0.0; g.tile_mode = 0; g.k_mode = 1;
+        launch_gemm(st, g, true, false, EL);
+        launch_clear_padding(st, s.iK.p, npad, s.N, EL);
+        launch_matvec(st, s.Linv.p, npad, EL, o.Yt, s.vec.p, false);
+        launch_matvec(st, s.Linv.p, npad, EL, s.vec.p, beta_own, true);
+    }
     int info[64];
-    HIPCHK(hipMemcpyAsync(info, ctx->d_info, sizeof(int) * std::min(E, 64), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(info, ctx->d_info, sizeof(int) * std::min(ELa, 64), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    for (int a = 0; a < std::min(E, 64); ++a)
-        if (info[a] != 0) {
+    for (int al = 0; al < std::min(EL, 64); ++al)
+        if (info[al] != 0) {
+            const int a = al * o.W + o.rank;
             ctx->not_pd = a;
             return fail(ctx, PILCO_E_NOT_PD, "Cholesky failed: K + noise*I of output " + std::to_string(a) +
-                                                 " is not positive definite (pivot " + std::to_string(info[a]) + ")");
+                                                 " is not positive definite (pivot " + std::to_string(info[al]) + ")");
         }
     s.n = s.N;
     s.npad = npad;
     s.iK_null = false;
-    return PILCO_OK;
+    return gather_beta(ctx, s, o, npad);
 }
 
 
@@ -419,7 +477,8 @@ int pilco_gp_nlml(pilco_ctx* ctx, int slot, double* nlml, double* grad) {
     if (int r = check_slot(ctx, slot)) return r;
     Slot& s = ctx->slot[slot];
     if (!s.has_data || !s.has_hyp) return fail(ctx, PILCO_E_STATE, "nlml needs set_data and set_hyp first");
-    if (s.M > 0) return fail(ctx, PILCO_E_STATE, "nlml: the FITC training objective is not built; exact GP only");
+    if (s.M > 0) return fail(ctx, PILCO_E_STATE, "nlml: exact GP only (the sparse objective is pilco_gp_fitc_nlml)");
+    if (ctx->nranks != 1) return fail(ctx, PILCO_E_STATE, "nlml: hyper-parameter training runs unsharded (one rank)");
     if (!nlml) return fail(ctx, PILCO_E_SHAPE, "nlml: null pointer");
     HIPCHK(hipSetDevice(ctx->device));
     if (!s.factor_valid || s.user_factors) {
@@ -461,6 +520,16 @@ int pilco_gp_get_factors(pilco_ctx* ctx, int slot, double* iK, double* beta) {
     if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "get_factors: no current factorisation");
     HIPCHK(hipSetDevice(ctx->device));
     const int n = s.n, npad = s.npad, E = s.E;
+    if (s.shW > 1) {   // sharded: beta of every output (once complete), iK of no other rank's outputs
+        if (iK) return fail(ctx, PILCO_E_STATE, "get_factors: a sharded context holds iK of its own outputs only");
+        if (!s.beta_complete) return fail(ctx, PILCO_E_STATE, "get_factors: beta of the other ranks has not arrived yet");
+        if (beta)
+            for (int a = 0; a < E; ++a)
+                HIPCHK(hipMemcpyAsync(beta + (size_t)a * n, s.beta.p + ((size_t)(a % s.shW) * s.shEL + a / s.shW) * npad, sizeof(double) * n,
+                                      hipMemcpyDeviceToHost, ctx->st));
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        return PILCO_OK;
+    }
     if (iK) {
         if (s.iK_null) {
             memset(iK, 0, sizeof(double) * (size_t)E * n * n);
@@ -484,10 +553,13 @@ int pilco_gp_set_factors(pilco_ctx* ctx, int slot, const double* iK, const doubl
     if (!beta) return fail(ctx, PILCO_E_SHAPE, "set_factors: beta is required");
     HIPCHK(hipSetDevice(ctx->device));
     const int n = s.n, npad = s.npad, E = s.E;
-    ENSURE(s.beta, (size_t)E * npad);
-    HIPCHK(hipMemsetAsync(s.beta.p, 0, sizeof(double) * E * npad, ctx->st));
-    HIPCHK(hipMemcpy2DAsync(s.beta.p, sizeof(double) * npad, beta, sizeof(double) * n, sizeof(double) * n, (size_t)E,
-                            hipMemcpyHostToDevice, ctx->st));
+    const int W = ctx->nranks, rank = ctx->rank, ELcap = (E + W - 1) / W;
+    const int EL = (rank < E) ? (E - rank + W - 1) / W : 0;
+    ENSURE(s.beta, (size_t)W * ELcap * npad);
+    HIPCHK(hipMemsetAsync(s.beta.p, 0, sizeof(double) * (size_t)W * ELcap * npad, ctx->st));
+    for (int a = 0; a < E; ++a)      // row of output a in the [W][ELcap][npad] layout (plain [E][npad] for one rank)
+        HIPCHK(hipMemcpyAsync(s.beta.p + ((size_t)(a % W) * ELcap + a / W) * npad, beta + (size_t)a * n, sizeof(double) * n,
+                              hipMemcpyHostToDevice, ctx->st));
     std::vector<double> sym;   // must outlive the asynchronous copies below
     if (iK) {
         // The pair kernel visits only the column steps at / right of the diagonal block of a diagonal pair (weight 2):
@@ -511,13 +583,17 @@ int pilco_gp_set_factors(pilco_ctx* ctx, int slot, const double* iK, const doubl
             }
             iK = sym.data();
         }
-        ENSURE(s.iK, (size_t)E * npad * npad);
-        HIPCHK(hipMemsetAsync(s.iK.p, 0, sizeof(double) * E * npad * npad, ctx->st));
-        for (int a = 0; a < E; ++a)
-            HIPCHK(hipMemcpy2DAsync(s.iK.p + (size_t)a * npad * npad, sizeof(double) * npad, iK + (size_t)a * n * n,
+        ENSURE(s.iK, (size_t)std::max(EL, 1) * npad * npad);
+        HIPCHK(hipMemsetAsync(s.iK.p, 0, sizeof(double) * (size_t)std::max(EL, 1) * npad * npad, ctx->st));
+        for (int al = 0; al < EL; ++al) {   // this rank keeps the blocks of its own outputs a = al W + rank
+            const int a = al * W + rank;
+            HIPCHK(hipMemcpy2DAsync(s.iK.p + (size_t)al * npad * npad, sizeof(double) * npad, iK + (size_t)a * n * n,
                                     sizeof(double) * n, sizeof(double) * n, (size_t)n, hipMemcpyHostToDevice, ctx->st));
+        }
     }
     HIPCHK(hipStreamSynchronize(ctx->st));
+    s.shW = W; s.shEL = ELcap; s.shOwn = EL; s.shRank = rank;
+    s.beta_complete = true;
     s.iK_null = (iK == nullptr);
     s.factor_valid = true;
     s.user_factors = true;
@@ -529,6 +605,7 @@ int pilco_gp_predict(pilco_ctx* ctx, int slot, const double* m, const double* s_
     if (int r = check_slot(ctx, slot)) return r;
     Slot& s = ctx->slot[slot];
     if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "predict: no current factorisation (call pilco_gp_factorize)");
+    if (!s.beta_complete) return fail(ctx, PILCO_E_STATE, "predict: beta of the other ranks is missing (attach a communicator before factorising, or pilco_group_sync_model)");
     if (!m || !s_in || !M || !S || !V) return fail(ctx, PILCO_E_SHAPE, "predict: null pointer");
     HIPCHK(hipSetDevice(ctx->device));
     if (int r = build_work(ctx, s)) return r;
@@ -617,7 +694,9 @@ int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32) {  // 64 s
 // Explicit triangular inverses turn every solve into an MFMA GEMM / mat-vec.
 int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     Slot& s = *static_cast<Slot*>(slot_ptr);
-    const int E = s.E, Mp = s.npad, Np = s.Npad, nblk = Mp / NB;
+    OwnView o{};
+    if (int r = prepare_own(ctx, s, o)) return r;
+    const int E = std::max(o.EL, 1), EL = o.EL, Mp = s.npad, Np = s.Npad, nblk = Mp / NB;   // E: batch of OWNED outputs
     const size_t mm = (size_t)Mp * Mp, mn = (size_t)Mp * Np;
     ENSURE(s.K, E * mm);        // Kmm -> L
     ENSURE(s.Linv, E * mm);
@@ -629,14 +708,21 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     ENSURE(s.AmD, (size_t)E * nblk * NB * NB);
     ENSURE(s.iAt, E * mm);
     ENSURE(s.G, (size_t)E * Np);
-    ENSURE(s.beta, (size_t)E * Mp);
+    ENSURE(s.beta, (size_t)o.W * o.ELcap * Mp);
     ENSURE(s.Tscr, (size_t)E * Mp * Mp);
     ENSURE(s.vec, (size_t)E * std::max(Mp, Np) * 2);
     hipStream_t st = ctx->st;
     HIPCHK(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * 64, st));
+    if (o.W > 1) HIPCHK(hipMemsetAsync(s.beta.p, 0, sizeof(double) * (size_t)o.W * o.ELcap * Mp, st));
+    double* beta_own = s.beta.p + (size_t)o.rank * o.ELcap * Mp;
+    if (EL == 0) {
+        s.n = s.M;
+        s.iK_null = false;
+        return gather_beta(ctx, s, o, Mp);
+    }
     // smgpr.py:27-28: Kmm = K(Z) + 1e-6 I, Kmn = K(Z, X)
-    launch_gram(st, s.Zt.p, Mp, s.M, s.Zt.p, Mp, s.M, s.D, s.ls.p, s.var.p, E, s.K.p, Mp, Mp, 2, nullptr, 1e-6);
-    launch_gram(st, s.Zt.p, Mp, s.M, s.Xt.p, Np, s.N, s.D, s.ls.p, s.var.p, E, s.Kmn.p, Mp, Np, 0, nullptr, 0.0);
+    launch_gram(st, s.Zt.p, Mp, s.M, s.Zt.p, Mp, s.M, s.D, o.ls, o.var, E, s.K.p, Mp, Mp, 2, nullptr, 1e-6);
+    launch_gram(st, s.Zt.p, Mp, s.M, s.Xt.p, Np, s.N, s.D, o.ls, o.var, E, s.Kmn.p, Mp, Np, 0, nullptr, 0.0);
     launch_potrf(st, s.K.p, Mp, E, s.invD.p, ctx->d_info);                      // smgpr.py:29
     launch_trtri(st, s.K.p, Mp, E, s.invD.p, s.Linv.p, s.Tscr.p, (long)Mp * Mp);
     GemmDesc g{};
@@ -650,7 +736,7 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     g.C = Vb.p; g.ldc = Np; g.sC = (long)mn;
     g.M = Mp; g.N = Np; g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.k_mode = 3;
     launch_gemm(st, g, false, false, E);
-    launch_fitc_scale(st, Vb.p, Mp, Np, E, s.var.p, s.noise.p, s.G.p);          // smgpr.py:31-33
+    launch_fitc_scale(st, Vb.p, Mp, Np, E, o.var, o.noise, s.G.p);          // smgpr.py:31-33
     // Am = chol(V V^T + sn2 I)  (smgpr.py:34-35)
     g = GemmDesc{};
     g.A = Vb.p; g.lda = Np; g.sA = (long)mn;
@@ -658,7 +744,7 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     g.C = s.Am.p; g.ldc = Mp; g.sC = (long)mm;
     g.M = Mp; g.N = Mp; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
     launch_gemm(st, g, false, true, E);
-    launch_add_diag(st, s.Am.p, Mp, E, s.noise.p);
+    launch_add_diag(st, s.Am.p, Mp, E, o.noise);
     launch_potrf(st, s.Am.p, Mp, E, s.AmD.p, ctx->d_info + 32);
     launch_trtri(st, s.Am.p, Mp, E, s.AmD.p, s.AmInv.p, s.Tscr.p, (long)Mp * Mp);
     // iAt = (L Am)^{-1} = Am^{-1} L^{-1}  (smgpr.py:36-37)
@@ -671,10 +757,10 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     // beta = L^{-T} Am^{-T} Am^{-1} (V/G) y  (smgpr.py:38-42)
     double* r0 = s.vec.p;
     double* r1 = s.vec.p + (size_t)E * Mp;
-    launch_fitc_rhs(st, Vb.p, s.G.p, s.Yt.p, Mp, Np, E, r0);
+    launch_fitc_rhs(st, Vb.p, s.G.p, o.Yt, Mp, Np, E, r0);
     launch_matvec(st, s.AmInv.p, Mp, E, r0, r1, false);
     launch_matvec(st, s.AmInv.p, Mp, E, r1, r0, true);
-    launch_matvec(st, s.Linv.p, Mp, E, r0, s.beta.p, true);
+    launch_matvec(st, s.Linv.p, Mp, E, r0, beta_own, true);
     // iK = Kmm^{-1} - sn2 iAt^T iAt  (smgpr.py:43-44)
     g = GemmDesc{};
     g.A = s.Linv.p; g.lda = Mp; g.sA = (long)mm;
@@ -684,19 +770,20 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     launch_gemm(st, g, true, false, E);
     g.A = s.iAt.p;
     g.B = s.iAt.p;
-    g.alpha = -1.0; g.alpha_vec = s.noise.p; g.beta = 1.0; g.k_mode = 1;
+    g.alpha = -1.0; g.alpha_vec = o.noise; g.beta = 1.0; g.k_mode = 1;
     launch_gemm(st, g, true, false, E);
     launch_clear_padding(st, s.iK.p, Mp, s.M, E);
     int info[64];
     HIPCHK(hipMemcpyAsync(info, ctx->d_info, sizeof(int) * 64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    for (int a = 0; a < std::min(E, 32); ++a)
-        if (info[a] != 0 || info[32 + a] != 0) {
+    for (int al = 0; al < std::min(EL, 32); ++al)
+        if (info[al] != 0 || info[32 + al] != 0) {
+            const int a = al * o.W + o.rank;
             ctx->not_pd = a;
             return fail(ctx, PILCO_E_NOT_PD, "FITC Cholesky failed for output " + std::to_string(a));
         }
     s.n = s.M;
     s.iK_null = false;
-    return PILCO_OK;
+    return gather_beta(ctx, s, o, Mp);
 }
 

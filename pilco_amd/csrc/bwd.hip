@@ -116,10 +116,10 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
     const int KP = wk.KP;
     const double* At = wk.At + (long)pl * KP * npad;
     const double* Bt = wk.Bt + (long)pl * KP * npad;
-    const double* beta_a = md.beta + (long)a * npad;
-    const double* beta_b = md.beta + (long)b * npad;
+    const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
+    const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
     const bool diag = (a == b);
-    const double* iKa = (diag && md.iK) ? md.iK + (long)a * npad * npad : nullptr;
+    const double* iKa = (diag && md.iK) ? md.iK + mm_ik_blk(md, a) * npad * npad : nullptr;
     const int jw = npad / njs, jbeg = js * jw, jend = jbeg + jw;
     const int ibase = rb * 64 * BWD_RT + w * 16 * BWD_RT;
     double rf[BWD_RT][KC], brow[BWD_RT];
@@ -259,7 +259,7 @@ __device__ void bwd_mean_partial(const MMModel& md, const MMWork& wk, const doub
                     quad = fma(zs[t * LD + r], tz, quad);
                     q = fma(zs[t * LD + r], u[r], q);
                 }
-                l = exp(-0.5 * quad) * md.beta[(long)a * npad + i];
+                l = exp(-0.5 * quad) * md.beta[mm_beta_row(md, a) * npad + i];
             } else {
                 for (int d = 0; d < D; ++d) zs[t * LD + d] = 0.0;
             }

@@ -26,6 +26,11 @@ struct Slot {
     DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
     DevBuf Kmn, V2, Am, AmInv, AmD, iAt, G;    // FITC extras
     DevBuf ft_P, ft_T3, ft_Z;                  // FITC training objective (fitc_train.hip)
+    // sharded factorisation (8e): this rank factorises only its outputs a = rank, rank + shW, ...; `own` holds their
+    // hyper-parameters and targets compacted ([EL][D] | [EL] | [EL] | [EL][Npad]); beta is all-gathered afterwards
+    DevBuf own;
+    int shW = 1, shEL = 0, shOwn = 0, shRank = 0;   // ranks, outputs per rank (capacity), outputs owned, rank at factorisation time
+    bool beta_complete = true;                      // false until the other ranks' beta rows have arrived
     // moment-matching workspace
     DevBuf w_in, w_At, w_Bt, w_small, w_part, w_gath, w_out;
     MMWork wk{};

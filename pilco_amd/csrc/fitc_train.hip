@@ -158,6 +158,7 @@ extern "C" int pilco_gp_fitc_nlml(pilco_ctx* ctx, int slot, const double* Z_all,
     if (!s.has_data || !s.has_hyp) return fail(ctx, PILCO_E_STATE, "fitc_nlml needs set_data and set_hyp first");
     if (!Z_all || M <= 0 || !nlml) return fail(ctx, PILCO_E_SHAPE, "fitc_nlml: bad arguments");
     if (s.D > FT_MAXD) return fail(ctx, PILCO_E_SHAPE, "fitc_nlml: D > 32");
+    if (ctx->nranks != 1) return fail(ctx, PILCO_E_STATE, "fitc_nlml: hyper-parameter training runs unsharded (one rank)");
     HIPCHK(hipSetDevice(ctx->device));
     const int E = s.E, D = s.D, N = s.N, Np = s.Npad, Mp = round_up(M, NB), nblk = Mp / NB;
     const size_t mm = (size_t)Mp * Mp, mn = (size_t)Mp * Np;

@@ -10,6 +10,10 @@ namespace pilco {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// row of output a in the (gathered) beta buffer / block of output a in this rank's iK (see MMModel)
+__device__ __forceinline__ long mm_beta_row(const MMModel& md, int a) { return (long)((a % md.bW) * md.bEL + a / md.bW); }
+__device__ __forceinline__ long mm_ik_blk(const MMModel& md, int a) { return (long)(a / md.bW); }
+
 // local pair index -> outputs (a >= b); see the dealing order in moment.h
 __device__ __forceinline__ void local_pair_ab(const MMWork& wk, int E, int pl, int& a, int& b) {
     const int kk = pl * wk.nranks + wk.rank;

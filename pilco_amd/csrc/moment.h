@@ -22,6 +22,9 @@ struct MMModel {
     const double* beta;  // [E][npad]  zero padded
     const double* iK;    // [E][npad][npad] zero padded, or nullptr (== 0: RbfController, controllers.py:116)
     int n, npad, D, E;
+    // Sharded factorisation: rank r owns the outputs a = r, r + bW, ...; beta is the all-gathered [bW][bEL][npad] buffer
+    // (row of output a: (a % bW) * bEL + a / bW), iK holds only the OWNED outputs (block a / bW).  bW = 1: plain [E] layout.
+    int bW, bEL;
 };
 
 // Per-slot workspace of one step.

@@ -213,14 +213,14 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_tiled(MMModel md, MM
     const int KP = wk.KP;
     const double* At = wk.At + (long)pl * KP * npad;
     const double* Bt = wk.Bt + (long)pl * KP * npad;
-    const double* beta_a = md.beta + (long)a * npad;
-    const double* beta_b = md.beta + (long)b * npad;
+    const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
+    const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
     const int i0 = ti * 16 * PAIR_RT;
     const int JB = npad / NJB, JW = JB / 4;
     const int jbeg = jb * JB + w * JW;
     double t1;
     if (diag)
-        t1 = pair_wave<KC, true, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, md.iK + (long)a * npad * npad, tab, npad, i0, jbeg, jbeg + JW, lane);
+        t1 = pair_wave<KC, true, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab, npad, i0, jbeg, jbeg + JW, lane);
     else
         t1 = pair_wave<KC, false, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jbeg + JW, lane);
     for (int off = 32; off > 0; off >>= 1) t1 += __shfl_down(t1, off);
@@ -350,11 +350,11 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
         local_pair_ab(wk, md.E, pl, a, b);
         const double* At = wk.At + (long)pl * KP * npad;
         const double* Bt = wk.Bt + (long)pl * KP * npad;
-        const double* beta_a = md.beta + (long)a * npad;
-        const double* beta_b = md.beta + (long)b * npad;
+        const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
+        const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
         const int i0 = ti * 16 * PAIR_RT, jbeg = sidx * 16, jend = jbeg + seg * 16;
         if (dg)
-            cur += pair_wave<KC, true, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, md.iK + (long)a * npad * npad, tab, npad, i0, jbeg, jend, lane);
+            cur += pair_wave<KC, true, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab, npad, i0, jbeg, jend, lane);
         else
             cur += pair_wave<KC, false, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jend, lane);
         step += seg;
@@ -419,13 +419,13 @@ __global__ __launch_bounds__(256) void k_mm_pair_valu(MMModel md, MMWork wk) {
         Bs[k][j] = (k < KP) ? Bt[(long)k * npad + j0 + j] : 0.0;
     }
     if (t < 64) {
-        bbs[t] = md.beta[(long)b * npad + j0 + t];
+        bbs[t] = md.beta[mm_beta_row(md, b) * npad + j0 + t];
         vs[t] = wk.vsep ? wk.vcol[(long)pl * npad + j0 + t] : 0.0;
     }
     __syncthreads();
     double s1 = 0.0, s2 = 0.0;
     if (rowok) {
-        const double* iKrow = diag ? md.iK + ((long)a * npad + i) * npad + j0 : nullptr;
+        const double* iKrow = diag ? md.iK + (mm_ik_blk(md, a) * npad + i) * npad + j0 : nullptr;
         for (int j = 0; j < 64; ++j) {
             double e = vs[j];
 #pragma unroll
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_mm_pair_valu(MMModel md, MMWork wk) {
             s1 = fma(bbs[j], L, s1);
             if (diag) s2 = fma(iKrow[j], L, s2);
         }
-        s1 *= md.beta[(long)a * npad + i];
+        s1 *= md.beta[mm_beta_row(md, a) * npad + i];
     }
     for (int off = 32; off > 0; off >>= 1) {
         s1 += __shfl_down(s1, off);

@@ -72,7 +72,7 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
             const int i = i_begin + r;
             zst[r * LDZ + d] = (i < md.n && i < i_end) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
         }
-        for (int r = idx; r < 512; r += 448) bst[r] = (i_begin + r < i_end) ? md.beta[(long)a * npad + i_begin + r] : 0.0;
+        for (int r = idx; r < 512; r += 448) bst[r] = (i_begin + r < i_end) ? md.beta[mm_beta_row(md, a) * npad + i_begin + r] : 0.0;
     }
     __syncthreads();
     DBG_STAMP(wk, 41, dbgm);
@@ -90,7 +90,7 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
                 const int i = i_begin + r0 + r;
                 zst[r * LDZ + d] = (i < md.n && i < i_end) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
             }
-            bst[t] = (i_begin + r0 + t < i_end) ? md.beta[(long)a * npad + i_begin + r0 + t] : 0.0;
+            bst[t] = (i_begin + r0 + t < i_end) ? md.beta[mm_beta_row(md, a) * npad + i_begin + r0 + t] : 0.0;
             __syncthreads();
         }
         if (i_begin + r0 + t < i_end) {

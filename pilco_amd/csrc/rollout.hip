@@ -104,6 +104,8 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
                   RolloutPlan& plan) {
     Slot& s = ctx->slot[0];
     if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "rollout: dynamics model has no current factorisation");
+    if (!s.beta_complete) return fail(ctx, PILCO_E_STATE, "rollout: beta of the other ranks is missing (attach a communicator before factorising, or pilco_group_sync_model)");
+    if (s.shW != ctx->nranks || s.shRank != ctx->rank) return fail(ctx, PILCO_E_STATE, "rollout: the model was factorised under a different rank layout; factorise again");
     if (!pol) return fail(ctx, PILCO_E_SHAPE, "rollout: null policy");
     const int E = s.E, D = s.D, U = D - E;
     if (pol->state_dim != E || pol->control_dim != U || U < 0)

@@ -18,6 +18,8 @@ int pilco_comm_unique_id(void* id128) {
 
 int pilco_shard_set(pilco_ctx* ctx, int rank, int nranks) {
     if (!ctx || nranks <= 0 || rank < 0 || rank >= nranks) return fail(ctx, PILCO_E_SHAPE, "shard_set: bad rank / nranks");
+    if (ctx->rank != rank || ctx->nranks != nranks)
+        for (Slot& s : ctx->slot) s.factor_valid = false;   // each rank factorises only the outputs it owns: the layout changed
     ctx->rank = rank;
     ctx->nranks = nranks;
     for (Slot& s : ctx->slot) s.wk_valid = false;
@@ -92,6 +94,7 @@ int pilco_gp_shard_pack(pilco_ctx* ctx, int slot, const double* m, const double*
     if (int r = check_slot(ctx, slot)) return r;
     Slot& s = ctx->slot[slot];
     if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "shard_pack: no current factorisation");
+    if (!s.beta_complete) return fail(ctx, PILCO_E_STATE, "shard_pack: beta of the other ranks is missing (pilco_group_sync_model)");
     if (!m || !s_in || !segment) return fail(ctx, PILCO_E_SHAPE, "shard_pack: null pointer");
     HIPCHK(hipSetDevice(ctx->device));
     if (int r = build_work(ctx, s)) return r;
@@ -134,6 +137,35 @@ int pilco_gp_shard_finish(pilco_ctx* ctx, int slot, const double* gathered, doub
     HIPCHK(hipMemcpyAsync(V, s.wk.out_V, sizeof(double) * D * E, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());
+    return PILCO_OK;
+}
+
+// After every context of an in-process group has factorised its own outputs: copy each rank's beta rows to all the
+// others (what ncclAllGather does inside pilco_gp_factorize when a communicator is attached).
+int pilco_group_sync_model(pilco_ctx** ctxs, int n, int slot) {
+    if (!ctxs || n <= 0 || !ctxs[0]) return PILCO_E_SHAPE;
+    pilco_ctx* c0 = ctxs[0];
+    if (slot < 0 || slot > 1) return fail(c0, PILCO_E_SHAPE, "group_sync_model: bad slot");
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || ctxs[i]->nranks != n || ctxs[i]->rank != i) return fail(c0, PILCO_E_STATE, "group_sync_model: context i must be shard_set(i, n)");
+        Slot& s = ctxs[i]->slot[slot];
+        if (!s.factor_valid || s.shW != n || s.shRank != i) return fail(c0, PILCO_E_STATE, "group_sync_model: rank " + std::to_string(i) + " has not factorised under this layout");
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess || hipStreamSynchronize(ctxs[i]->st) != hipSuccess) return fail(c0, PILCO_E_HIP, "group_sync_model: sync failed");
+    }
+    for (int i = 0; i < n; ++i) {
+        pilco_ctx* ctx = ctxs[i];
+        Slot& s = ctx->slot[slot];
+        HIPCHK(hipSetDevice(ctx->device));
+        const size_t blk = (size_t)s.shEL * s.npad;
+        for (int j = 0; j < n; ++j) {
+            if (j == i) continue;
+            Slot& sj = ctxs[j]->slot[slot];
+            if (sj.npad != s.npad || sj.shEL != s.shEL) return fail(c0, PILCO_E_STATE, "group_sync_model: the ranks hold different models");
+            HIPCHK(hipMemcpyAsync(s.beta.p + (size_t)j * blk, sj.beta.p + (size_t)j * blk, sizeof(double) * blk, hipMemcpyDefault, ctx->st));
+        }
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        s.beta_complete = true;
+    }
     return PILCO_OK;
 }
 

@@ -492,6 +492,8 @@ def test_sharded_step_two_contexts_host_allgather(variant, nranks):
             cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"])
             cx.gp_factorize(0)
             ctxs.append(cx)
+        _lib.group_sync_model(ctxs)      # every rank factorised its own outputs only: exchange the beta rows
+        for r, cx in enumerate(ctxs):
             segs.append(cx.shard_pack(0, m, s, 6, 5, nranks, r))
         gathered = np.concatenate(segs)
         for cx in ctxs:
@@ -511,8 +513,8 @@ def test_sharded_step_two_contexts_host_allgather(variant, nranks):
             cx.close()
 
 
-@pytest.mark.parametrize("E,U,nranks", [(5, 1, 2), (5, 1, 3), (2, 1, 4), (10, 0, 8)])
-def test_sharded_rollout_group_of_contexts(E, U, nranks):
+@pytest.mark.parametrize("E,U,nranks,sparse", [(5, 1, 2, False), (5, 1, 3, False), (2, 1, 4, False), (10, 0, 8, False), (5, 1, 3, True)])
+def test_sharded_rollout_group_of_contexts(E, U, nranks, sparse):
     """BASELINE config 3's ROLLOUT on one GPU: `nranks` contexts of this process run the whole sharded H-step rollout
     (per step: own pairs -> PACK launch -> exchange -> assemble / propagate / controller on every rank; the reward of a
     rank without pairs stays in its glue launch), the ncclAllGather replaced by peer copies between host barriers
@@ -536,8 +538,11 @@ def test_sharded_rollout_group_of_contexts(E, U, nranks):
             cx.shard_set(rank, n)
         cx.gp_set_data(0, c["X"], c["Y"])
         cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"])
+        if sparse:
+            cx.gp_set_inducing(0, Zs)        # FITC: the sharded factorisation of smgpr.py:24-45
         cx.gp_factorize(0)
         return cx
+    Zs = np.random.RandomState(5).randn(40, D)
     try:
         for variant in (2, 0):
             ref = ctx_for(0, 1, variant)
@@ -547,6 +552,14 @@ def test_sharded_rollout_group_of_contexts(E, U, nranks):
             Mf, Sf, Rf, Tf = ref.rollout(pol, rw, m0, S0, H, want_traj=True)
             assert np.array_equal(T1, Tf) and np.array_equal(R1, Rf)
             group = [ctx_for(r, nranks, variant) for r in range(nranks)]
+            with pytest.raises(_lib.PilcoError):      # each rank holds only its own outputs' beta until the exchange
+                group[0].rollout(pol, rw, m0, S0, 1)
+            _lib.group_sync_model(group)
+            if nranks > 1:
+                with pytest.raises(_lib.PilcoError):  # ... and iK of its own outputs only, ever
+                    group[0].gp_get_factors(0, E, want_iK=True)
+                _, bsh = group[nranks - 1].gp_get_factors(0, E, want_iK=False)
+                np.testing.assert_array_equal(bsh, ref.gp_get_factors(0, E, want_iK=False)[1])
             M, S, R, T, mismatch = _lib.rollout_group(group, pol, rw, m0, S0, H, want_traj=True)
             assert mismatch == 0                               # all ranks agree to the bit
             if variant == 2:
@@ -556,7 +569,7 @@ def test_sharded_rollout_group_of_contexts(E, U, nranks):
                 np.testing.assert_allclose(R, R1, rtol=1e-12)
             M2, S2, R2, mm2 = _lib.rollout_group(group, pol, rw, m0, S0, H)     # and it is repeatable
             assert mm2 == 0 and np.array_equal(M2, M) and np.array_equal(S2, S) and np.array_equal(R2, R)
-        model = tp.Model(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+        model = tp.Model(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"], Z=Zs if sparse else None)
         ctl = (lambda mm, ss: tp.linear_controller(mm, ss, c["W"], c["b"], 1.5)) if U else tp.no_controller
         Mo, So, Ro = tp.predict(model, ctl, tp.exponential_reward, m0, S0, H, cache=True)
         np.testing.assert_allclose(M, Mo, rtol=RTOL)
