@@ -580,6 +580,38 @@ def test_sharded_rollout_group_of_contexts(E, U, nranks, sparse):
             cx.close()
 
 
+def test_integration_stub_of_the_reference_side_binding(golden_dir):
+    """INTEGRATION.md section 2 (examples/reference_binding.py): the ctypes stub a maintainer of the reference would add,
+    executed on stand-in objects that carry exactly the attributes of the reference's MGPR / PILCO instances."""
+    import importlib.util
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("reference_binding", os.path.join(root, "examples", "reference_binding.py"))
+    rb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rb)
+    g = np.load(os.path.join(golden_dir, "cascade.npz"))
+    par = lambda v: types.SimpleNamespace(numpy=lambda: np.asarray(v))
+    mgpr = types.SimpleNamespace(data=(g["X"], g["Y"]), lengthscales=g["lengthscales"], variance=g["variance"], noise=g["noise"],
+                                 num_dims=3, num_outputs=2)
+    pilco = types.SimpleNamespace(mgpr=mgpr, state_dim=2, control_dim=1,
+                                  controller=types.SimpleNamespace(W=par(g["W"]), b=par(g["b"]), max_action=g["max_action"]),
+                                  reward=types.SimpleNamespace(W=par(np.eye(2)), t=par(np.zeros((1, 2)))))
+    rb.sync_model(mgpr)
+    H = int(g["horizon"])
+    M, S, R = rb.predict(pilco, g["m"], g["s"], H)
+    np.testing.assert_allclose(M[0], g["M_traj"][:, -1], rtol=RTOL)
+    np.testing.assert_allclose(S, g["S_traj"][:, :, -1], rtol=RTOL)
+    np.testing.assert_allclose(R[0, 0], g["R_traj"][-1], rtol=RTOL)
+    gp = np.load(os.path.join(golden_dir, "predictions.npz"))
+    mg2 = types.SimpleNamespace(data=(gp["X"], gp["Y"]), lengthscales=gp["lengthscales"], variance=gp["variance"], noise=gp["noise"],
+                                num_dims=3, num_outputs=2)
+    rb.sync_model(mg2)
+    M, S, V = rb.predict_on_noisy_inputs(mg2, gp["m"], gp["s"])
+    np.testing.assert_allclose(M, gp["M"], rtol=RTOL)
+    np.testing.assert_allclose(S, gp["S"], rtol=RTOL)
+    np.testing.assert_allclose(V, gp["V"], rtol=RTOL)
+
+
 def test_rccl_path_world_size_one():
     """The RCCL branch (pack -> ncclAllGather -> assemble) with a one-rank communicator."""
     from pilco_amd import _lib

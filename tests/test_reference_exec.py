@@ -278,6 +278,33 @@ def test_policy_gradient_through_the_executed_reference(R, golden_dir):
     np.testing.assert_allclose(bt.grad.numpy(), g["dreward_db"], rtol=1e-7)
 
 
+def test_reference_side_binding_patches_the_real_reference_classes(R):
+    """examples/reference_binding.py against the REAL reference package: patch() must find
+    the classes and methods it replaces; the arithmetic itself needs a GPU (tests/test_gpu_parity.py runs it)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "pilco_amd", "libpilco_hip.so")):
+        pytest.skip("libpilco_hip.so not built")
+    spec = importlib.util.spec_from_file_location("reference_binding", os.path.join(root, "examples", "reference_binding.py"))
+    rb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rb)
+    MGPR, PILCO = R.pilco.models.MGPR, R.pilco.models.PILCO
+    keep = (MGPR.predict_on_noisy_inputs, PILCO.predict)
+    try:
+        rb.patch(R.pilco)
+        assert MGPR.predict_on_noisy_inputs is not keep[0] and PILCO.predict is not keep[1]
+        # every attribute the stub reads exists on the reference's objects
+        np.random.seed(0)
+        p = PILCO((np.random.rand(20, 3), np.random.rand(20, 2)))
+        for obj, names in ((p.mgpr, ("data", "lengthscales", "variance", "noise", "num_dims", "num_outputs")),
+                           (p, ("state_dim", "control_dim", "controller", "reward")), (p.controller, ("W", "b", "max_action")),
+                           (p.reward, ("W", "t"))):
+            for nme in names:
+                assert hasattr(obj, nme), (type(obj).__name__, nme)
+    finally:
+        MGPR.predict_on_noisy_inputs, PILCO.predict = keep
+
+
 def test_product_never_imports_the_oracle_or_the_shim():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     bad = []
