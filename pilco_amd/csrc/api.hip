@@ -314,6 +314,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);
     if (ctx->st) (void)hipStreamDestroy(ctx->st);
     delete ctx;
     return PILCO_OK;

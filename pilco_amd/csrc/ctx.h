@@ -99,6 +99,10 @@ struct pilco_ctx {
     std::vector<hipEvent_t> pair_events;
     double* pin = nullptr;   // pinned host staging buffer of the reverse pass (truly asynchronous small copies)
     size_t pin_cap = 0;
+    double* pin_io = nullptr;   // pinned staging of pilco_rollout's inputs / results (one copy each way, no pageable detours)
+    size_t pin_io_cap = 0;
+    const double* params_dev = nullptr;
+    std::vector<double> params_host;   // what ctx->params holds on the device: identical parameters are not uploaded again
 };
 
 int fail(pilco_ctx* c, int code, const std::string& msg);

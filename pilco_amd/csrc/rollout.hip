@@ -163,8 +163,15 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
     g.rew_out = nullptr;
     if (int r = stage_rewards(ctx, rw, n_rw, E, hp, off, ctx->params.p, g.rw)) return r;
     if (hp.size() > n_par) return fail(ctx, PILCO_E_ALLOC, "rollout: parameter staging overflow");
-    HIPCHK(hipMemcpyAsync(ctx->params.p, hp.data(), sizeof(double) * n_par, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));  // hp is a local vector
+    // the policy / reward parameters of consecutive rollouts are usually the same bytes (bench loop, restarts,
+    // compute_reward after an optimiser step): upload only when they changed
+    if (ctx->params_dev != ctx->params.p || ctx->params_host.size() != n_par ||
+        memcmp(ctx->params_host.data(), hp.data(), sizeof(double) * n_par) != 0) {
+        HIPCHK(hipMemcpyAsync(ctx->params.p, hp.data(), sizeof(double) * n_par, hipMemcpyHostToDevice, ctx->st));
+        HIPCHK(hipStreamSynchronize(ctx->st));  // hp is a local vector
+        ctx->params_host = hp;
+        ctx->params_dev = ctx->params.p;
+    }
     plan.E = E; plan.D = D; plan.U = U;
     return PILCO_OK;
 }
@@ -382,21 +389,36 @@ int pilco_rollout(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     RolloutPlan plan;
     if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, traj != nullptr, plan)) return r;
     const int E = plan.E;
+    // one pinned staging area: [m0 | S0] up in ONE asynchronous copy, [m_H | S_H] and the reward down in two, one host
+    // synchronisation at the end (pageable buffers would cost a blocking staging copy per call)
+    const size_t nst = (size_t)E + (size_t)E * E;
+    if (ctx->pin_io_cap < 2 * nst + 8) {
+        if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);
+        ctx->pin_io = nullptr;
+        ctx->pin_io_cap = 0;
+        HIPCHK(hipHostMalloc((void**)&ctx->pin_io, sizeof(double) * (2 * nst + 8), hipHostMallocDefault));
+        ctx->pin_io_cap = 2 * nst + 8;
+    }
+    double* pin_in = ctx->pin_io;
+    double* pin_out = ctx->pin_io + nst;
+    memcpy(pin_in, m0, sizeof(double) * E);
+    memcpy(pin_in + E, S0, sizeof(double) * E * E);
     for (int attempt = 0; attempt < 2; ++attempt) {
-        HIPCHK(hipMemcpyAsync(plan.st[0], m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
-        HIPCHK(hipMemcpyAsync(plan.st[0] + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
+        HIPCHK(hipMemcpyAsync(plan.st[0], pin_in, sizeof(double) * nst, hipMemcpyHostToDevice, ctx->st));
         const int r = run_rollout(ctx, plan, H);
         if (r == -1) continue;  // graph was just (re)captured: upload the state again and replay it
         if (r != PILCO_OK) return r;
         break;
     }
-    HIPCHK(hipMemcpyAsync(mH, plan.st[H & 1], sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(SH, plan.st[H & 1] + E, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(reward, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(pin_out, plan.st[H & 1], sizeof(double) * nst, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(pin_out + nst, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
     if (traj)
         HIPCHK(hipMemcpyAsync(traj, ctx->traj.p, sizeof(double) * (size_t)(H + 1) * (E + E * E), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());
+    memcpy(mH, pin_out, sizeof(double) * E);
+    memcpy(SH, pin_out + E, sizeof(double) * E * E);
+    *reward = pin_out[nst];
     return PILCO_OK;
 }
 
