@@ -123,6 +123,26 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
     r4 = _median_ms(lambda: ctx.rollout(policy, rewards, c4["m0"], c4["S0"], H), 10)
     out["config4_rollout_ms"] = r4
     out["config4_rollouts_per_s"] = 1e3 / r4
+    # ---- engine clock under the pair kernel's load: shader-clock ticks against the 100 MHz wall clock inside wave 0 of one
+    # pair-kernel launch (developer stamps, separate context, eager launches -- never inside the timed region)
+    try:
+        from pilco_amd import _lib
+        cd = _lib.Context(device=ctx.device)
+        cd.debug_timestamps(read=False)
+        cd.gp_set_data(0, cfg["X"], cfg["Y"])
+        cd.gp_set_hyp(0, cfg["lengthscales"], cfg["variance"], cfg["noise"])
+        cd.gp_factorize(0)
+        for _ in range(3):
+            cd.rollout(policy, rewards, cfg["m0"], cfg["S0"], 3)
+            ts = cd.debug_timestamps()
+        mhz = (ts[33] - ts[32]) / ((ts[17] - ts[16]) / 100.0)
+        out["pair_kernel_engine_clock_mhz"] = mhz
+        out["pair_kernel_issue_bound_note"] = ("per 16-column step a wave issues 6 v_mfma_f64_16x16x4 (64 cycles each) + 104 VALU ops (4 cycles "
+                                               "each) on the shared fp64 pipe = 800 cycles for 512 exps; at the measured clock that bounds a launch "
+                                               "at %.1f us" % (5.501e7 / 512 / 1024 * 800 / mhz))
+        cd.close()
+    except Exception as exc:
+        out["pair_kernel_engine_clock_mhz"] = repr(exc)
     # restore the benchmark model in slot 0
     ctx.gp_set_inducing(0, None)
     ctx.gp_set_data(0, cfg["X"], cfg["Y"])

@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
     const int NS = npad / 16;
     const int KP = wk.KP;
     DBG_STAMP(wk, 16, w == 0 && lane == 0);
+    if (wk.dbg && w == 0 && lane == 0) wk.dbg[32] = clock64();     // shader-clock counter beside the 100 MHz wall clock: tools/ derive the engine clock under this load
     const int nd_steps = wk.sk_nd * wk.sk_tdiag;
     int step = sk_boundary(wk, w);
     const int end = sk_boundary(wk, w + 1);
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
         if (p1 >= 0) wk.sk_part[p1] = out1;
     }
     DBG_STAMP(wk, 17, w == 0 && lane == 0);
+    if (wk.dbg && w == 0 && lane == 0) wk.dbg[33] = clock64();
     DBG_STAMP(wk, 18, w == wk.sk_waves - 1 && lane == 0);
     if (wk.dbg && lane == 0 && (w & 7) == 0) wk.dbg[1024 + (w >> 3)] = wall_clock64();  // end stamp of every 8th wave
 }
