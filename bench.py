@@ -123,26 +123,6 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
     r4 = _median_ms(lambda: ctx.rollout(policy, rewards, c4["m0"], c4["S0"], H), 10)
     out["config4_rollout_ms"] = r4
     out["config4_rollouts_per_s"] = 1e3 / r4
-    # ---- engine clock under the pair kernel's load: shader-clock ticks against the 100 MHz wall clock inside wave 0 of one
-    # pair-kernel launch (developer stamps, separate context, eager launches -- never inside the timed region)
-    try:
-        from pilco_amd import _lib
-        cd = _lib.Context(device=ctx.device)
-        cd.debug_timestamps(read=False)
-        cd.gp_set_data(0, cfg["X"], cfg["Y"])
-        cd.gp_set_hyp(0, cfg["lengthscales"], cfg["variance"], cfg["noise"])
-        cd.gp_factorize(0)
-        for _ in range(3):
-            cd.rollout(policy, rewards, cfg["m0"], cfg["S0"], 3)
-            ts = cd.debug_timestamps()
-        mhz = (ts[33] - ts[32]) / ((ts[17] - ts[16]) / 100.0)
-        out["pair_kernel_engine_clock_mhz"] = mhz
-        out["pair_kernel_issue_bound_note"] = ("per 16-column step a wave issues 6 v_mfma_f64_16x16x4 (64 cycles each) + 104 VALU ops (4 cycles "
-                                               "each) on the shared fp64 pipe = 800 cycles for 512 exps; at the measured clock that bounds a launch "
-                                               "at %.1f us" % (5.501e7 / 512 / 1024 * 800 / mhz))
-        cd.close()
-    except Exception as exc:
-        out["pair_kernel_engine_clock_mhz"] = repr(exc)
     # restore the benchmark model in slot 0
     ctx.gp_set_inducing(0, None)
     ctx.gp_set_data(0, cfg["X"], cfg["Y"])
@@ -186,6 +166,25 @@ def config5_metrics(ctx, with_cpu):
         out["speedup_first_iteration"] = ((c0["optimize_models_s"] + c0["optimize_policy_s"]) /
                                           max(h0["optimize_models_s"] + h0["optimize_policy_s"], 1e-9))
     return out
+
+
+def engine_clock_under_pair_load(ctx, cfg, policy, rewards):
+    """Engine clock while the pair kernel runs: shader-clock ticks against the 100 MHz wall clock inside wave 0 of one
+    pair-kernel launch (developer stamps on a SEPARATE context with eager launches -- never inside the timed region)."""
+    from pilco_amd import _lib
+    cd = _lib.Context(device=ctx.device)
+    try:
+        cd.debug_timestamps(read=False)
+        cd.gp_set_data(0, cfg["X"], cfg["Y"])
+        cd.gp_set_hyp(0, cfg["lengthscales"], cfg["variance"], cfg["noise"])
+        cd.gp_factorize(0)
+        ts = None
+        for _ in range(3):
+            cd.rollout(policy, rewards, cfg["m0"], cfg["S0"], 3)
+            ts = cd.debug_timestamps()
+        return (ts[33] - ts[32]) / ((ts[17] - ts[16]) / 100.0)
+    finally:
+        cd.close()
 
 
 def verify_against_reference(mH, SH, reward):
@@ -271,6 +270,15 @@ def main():
     flop_local = flop / world  # pairs are dealt over the ranks
     achieved = flop_local / (pair_ms * 1e-3) / 1e12 if pair_ms > 0 else 0.0
 
+    # the clock the engine actually runs at under this kernel's load, and the kernel's own instruction-issue bound there:
+    # per 16-column step a wave issues 6 v_mfma_f64_16x16x4 (64 cycles) + 104 VALU ops (4 cycles) on the shared fp64 pipe
+    clock_mhz, issue_us = None, None
+    if world == 1:
+        try:
+            clock_mhz = engine_clock_under_pair_load(ctx, cfg, policy, rewards)
+            issue_us = exps / 512.0 / 1024.0 * 800.0 / clock_mhz
+        except Exception:
+            clock_mhz = None
     # HBM bytes per pair-kernel launch: PMC counters (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes) of the committed
     # rocprofv3 profile of this same command, newest round first; a live run cannot collect counters on itself
     traffic, traffic_src = None, None
@@ -336,6 +344,10 @@ def main():
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_mm_pair_sk (f64 MFMA exponent tiles + fp64 exp; MFMA and fp64 VALU share one pipe)",
                          "avg_launch_ms": pair_ms,
+                         "engine_clock_mhz_under_load": clock_mhz, "issue_bound_us_at_that_clock": issue_us,
+                         "frac_of_issue_bound": (issue_us / (pair_ms * 1e3)) if (issue_us and pair_ms > 0) else None,
+                         "note": "frac = SURVEY 8(d) algorithmic FLOP (exp internals excluded) / spec peak at 2.4 GHz; the kernel's own "
+                                 "bound is instruction issue: 800 cycles per 512 exps (6 f64 MFMA + 104 VALU ops) at the measured clock",
                          "algorithmic_flop_per_launch": flop_local, "exp_per_launch": exps / world,
                          "gexp_per_s": exps / world / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0,
                          "algorithmic_bytes_per_launch": byts / world,

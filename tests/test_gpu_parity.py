@@ -829,6 +829,7 @@ def test_policy_gradient_adjoint_vs_autograd_and_fd(ctx):
     import torch
     from oracle import torch_path as tq
     from pilco_amd.adjoint import rollout_value_and_grad
+    from oracle.adjoint_sweep import rollout_value_and_grad_py
     from pilco_amd.rewards import ExponentialReward
     c = synthetic.config_cascade()
     cfg = {k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise")}
@@ -871,7 +872,7 @@ def test_policy_gradient_adjoint_vs_autograd_and_fd(ctx):
     r2, (Wb2, bb2) = rollout_value_and_grad(p)
     assert r2 == r and np.array_equal(Wb2, Wb) and np.array_equal(bb2, bb)
     # the native sweep (pilco_rollout_grad) and the same sweep driven from Python agree to rounding
-    r3, (Wb3, bb3) = rollout_value_and_grad(p, native=False)
+    r3, (Wb3, bb3) = rollout_value_and_grad_py(p)
     np.testing.assert_allclose(r3, r, rtol=1e-13)
     np.testing.assert_allclose(Wb3, Wb, rtol=1e-9, atol=1e-13)
     np.testing.assert_allclose(bb3, bb, rtol=1e-9, atol=1e-13)
@@ -980,6 +981,7 @@ def test_rbf_policy_gradient_adjoint_vs_autograd(ctx):
     import torch
     from oracle import torch_path as tq
     from pilco_amd.adjoint import rollout_value_and_grad
+    from oracle.adjoint_sweep import rollout_value_and_grad_py
     from pilco_amd.controllers import RbfController
     from pilco_amd.models import PILCO
     from pilco_amd.rewards import CombinedRewards, ExponentialReward, LinearReward
@@ -1010,7 +1012,7 @@ def test_rbf_policy_gradient_adjoint_vs_autograd(ctx):
     np.testing.assert_allclose(Yb, tY.grad.numpy(), rtol=1e-6, atol=1e-10)
     np.testing.assert_allclose(lb, tl.grad.numpy(), rtol=1e-6, atol=1e-10)
     # the Python-driven sweep (NumPy policy adjoint) agrees with the native one to rounding
-    r2, (Xb2, Yb2, lb2) = rollout_value_and_grad(p, native=False)
+    r2, (Xb2, Yb2, lb2) = rollout_value_and_grad_py(p)
     np.testing.assert_allclose(r2, r, rtol=1e-13)
     np.testing.assert_allclose(Xb2, Xb, rtol=1e-8, atol=1e-13)
     np.testing.assert_allclose(Yb2, Yb, rtol=1e-8, atol=1e-13)
@@ -1127,6 +1129,7 @@ def test_native_rollout_grad_combined_reward_and_errors(ctx):
     same sweep driven from Python; unsupported policies are refused, not silently mishandled."""
     from pilco_amd import _lib
     from pilco_amd.adjoint import rollout_value_and_grad
+    from oracle.adjoint_sweep import rollout_value_and_grad_py
     from pilco_amd.rewards import CombinedRewards, ExponentialReward, LinearReward
     c = synthetic.config_cascade()
     cfg = {k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise")}
@@ -1135,8 +1138,8 @@ def test_native_rollout_grad_combined_reward_and_errors(ctx):
                                    LinearReward(2, np.array([[0.3], [-0.4]]))], coefs=[0.7, 1.5])
     p.m_init, p.S_init = c["m"], c["s"]
     p.controller.W.assign(c["W"]); p.controller.b.assign(c["b"]); p.controller.max_action = 1.3
-    r1, (W1, b1) = rollout_value_and_grad(p, native=True)
-    r2, (W2, b2) = rollout_value_and_grad(p, native=False)
+    r1, (W1, b1) = rollout_value_and_grad(p)
+    r2, (W2, b2) = rollout_value_and_grad_py(p)
     np.testing.assert_allclose(r1, r2, rtol=1e-13)
     np.testing.assert_allclose(W1, W2, rtol=1e-9, atol=1e-13)
     np.testing.assert_allclose(b1, b2, rtol=1e-9, atol=1e-13)

@@ -165,11 +165,11 @@ def test_nlml_gradient_oracle_is_consistent():
 
 
 def test_rbf_policy_vjp_host_math_vs_autograd():
-    """The hand-reversed RBF policy layer of pilco_amd/adjoint.py (host NumPy, O(bf^2)) against torch autograd of the
+    """The hand-reversed RBF policy layer of oracle/adjoint_sweep.py (host NumPy, O(bf^2); the prototype of csrc/grad.hip's) against torch autograd of the
     restated controllers.py:108-121 -- values and cotangents of (m, s, centres, targets, lengthscales)."""
     import torch
     from oracle import torch_path as tq
-    from pilco_amd.adjoint import rbf_policy_fwd, rbf_policy_vjp
+    from oracle.adjoint_sweep import rbf_policy_fwd, rbf_policy_vjp
     rng = np.random.RandomState(3)
     n, d, U = 9, 3, 2
     X, Y = rng.randn(n, d), 0.3 * rng.randn(n, U)
