@@ -295,7 +295,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (!ctx) return PILCO_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->st);
-    if (ctx->graph) (void)hipGraphExecDestroy(ctx->graph);
+    for (auto& ge : ctx->graph_cache) (void)hipGraphExecDestroy(ge.second);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
         for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr,

@@ -92,6 +92,7 @@ struct pilco_ctx {
     // cached hipGraph of one rollout (single-rank): replayed while the plan key is unchanged
     hipGraphExec_t graph = nullptr;
     std::vector<unsigned long long> graph_key;
+    std::vector<std::pair<std::vector<unsigned long long>, hipGraphExec_t>> graph_cache;   // most recently used first (<= 4)
     bool use_graph = true;
     bool fused = true;   // fused head: the serial link of step t runs inside the prep launch of step t+1 (2 launches per step)
     bool graph_rccl_failed = false;

@@ -330,10 +330,20 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
         memcpy(&cbits, &g.rw[i].coef, sizeof(cbits));
         key.push_back(cbits);
     }
-    if (!ctx->graph || key != ctx->graph_key) {
-        if (ctx->graph) {
-            (void)hipGraphExecDestroy(ctx->graph);
-            ctx->graph = nullptr;
+    // a few instantiated graphs are kept (value rollouts and tape rollouts of an optimiser alternate): find this key
+    for (size_t i = 0; i < ctx->graph_cache.size(); ++i)
+        if (ctx->graph_cache[i].first == key) {
+            if (i != 0) std::swap(ctx->graph_cache[i], ctx->graph_cache[0]);   // most recently used first
+            ctx->graph = ctx->graph_cache[0].second;
+            ctx->graph_key = key;
+            HIPCHK(hipGraphLaunch(ctx->graph, ctx->st));
+            return PILCO_OK;
+        }
+    {
+        ctx->graph = nullptr;
+        if (ctx->graph_cache.size() >= 4) {   // evict the least recently used
+            (void)hipGraphExecDestroy(ctx->graph_cache.back().second);
+            ctx->graph_cache.pop_back();
         }
         // warm the per-kernel one-time host configuration outside the capture
         if (int r = enqueue_rollout(ctx, plan, H > 0 ? 1 : 0, nullptr)) return r;
@@ -371,11 +381,10 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
             return fail(ctx, PILCO_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
         }
         ctx->graph_key = key;
+        ctx->graph_cache.insert(ctx->graph_cache.begin(), std::make_pair(key, ctx->graph));
         // the warm-up rollout above overwrote the initial state: the caller re-uploads it (see callers)
         return -1;
     }
-    HIPCHK(hipGraphLaunch(ctx->graph, ctx->st));
-    return PILCO_OK;
 }
 
 
@@ -619,9 +628,14 @@ int pilco_rollout_tape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_r
     const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
     ENSURE(ctx->tape, std::max<size_t>(1, (size_t)H * TS));
     plan.g.tape = ctx->tape.p;
-    HIPCHK(hipMemcpyAsync(plan.st[0], m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipMemcpyAsync(plan.st[0] + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
-    if (int r = enqueue_rollout(ctx, plan, H, nullptr)) return r;
+    for (int attempt = 0; attempt < 2; ++attempt) {   // replayed as a hipGraph like pilco_rollout (the tape pointer is part of the graph key)
+        HIPCHK(hipMemcpyAsync(plan.st[0], m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
+        HIPCHK(hipMemcpyAsync(plan.st[0] + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
+        const int r = run_rollout(ctx, plan, H);
+        if (r == -1) continue;
+        if (r != PILCO_OK) return r;
+        break;
+    }
     HIPCHK(hipMemcpyAsync(mH, plan.st[H & 1], sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(SH, plan.st[H & 1] + E, sizeof(double) * E * E, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(reward, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
