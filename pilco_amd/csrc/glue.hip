@@ -7,7 +7,7 @@ static size_t glue_lds_doubles(int E, int D, int SEG, int mp) {
     const int nm = E > D ? E : D;
     const size_t tail = (size_t)SEG + (size_t)mp;
     const size_t rew = reward_lds_doubles(E);
-    return (size_t)3 * nm + 7 * (size_t)nm * nm + 128 + (tail > rew ? tail : rew);
+    return (size_t)3 * nm + 7 * (size_t)nm * nm + 256 + (tail > rew ? tail : rew);
 }
 size_t glue_lds_bytes(int E, int D) { return sizeof(double) * glue_lds_doubles(E, D, 0, 0); }
 size_t glue_lds_doubles_for(const GlueArgs& g) {

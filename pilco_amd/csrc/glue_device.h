@@ -26,9 +26,9 @@ struct GlueLds {
     double* js;   // [nm*nm]  joint covariance
     double* seg;  // [SEG]    this rank's packed results
     double* mp;   // [EL*NCH*(1+D)] mean partials
-    double* misc; // [128]
+    double* misc; // [256]: [1..) cdiag, [64..) / [96..) temporaries, [128..) policy bias b, [160..) max_action (batched load)
     int nm;       // max(E, D): leading dimension of the square buffers
-    int o_sx, o_s1, o_js, o_seg, o_mp;   // offsets (doubles) of sx, s1, js, seg, mp from mx, for multi_load
+    int o_sx, o_s1, o_js, o_seg, o_mp, o_misc;   // offsets (doubles) of sx, s1, js, seg, mp from mx, for multi_load
 };
 
 __device__ __forceinline__ void glue_lds_carve(const GlueArgs& g, double* sm, GlueLds& L) {
@@ -47,13 +47,14 @@ __device__ __forceinline__ void glue_lds_carve(const GlueArgs& g, double* sm, Gl
     L.jm = L.s1 + nm * nm;
     L.js = L.jm + nm;
     L.misc = L.js + nm * nm;
-    L.seg = L.misc + 128;
+    L.seg = L.misc + 256;
     L.mp = L.seg + seg_n;
     L.nm = nm;
     L.o_sx = nm;
     L.o_s1 = 2 * nm + 5 * nm * nm;
     L.o_js = 3 * nm + 6 * nm * nm;
-    L.o_seg = 3 * nm + 7 * nm * nm + 128;
+    L.o_seg = 3 * nm + 7 * nm * nm + 256;
+    L.o_misc = 3 * nm + 7 * nm * nm;
     L.o_mp = L.o_seg + seg_n;
 }
 
@@ -152,7 +153,7 @@ __device__ __forceinline__ void squash_inplace(const GlueLds& L, int U, const do
             newC = eu * r[0] * r[1];
             newM = eu * r[0] * r[2];
         }
-        __syncthreads();
+        // (no barrier: the combine phase above reads only the scratch `sc`; su / mu / cdiag are written below)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int e = t + k * (int)blockDim.x;
@@ -357,15 +358,18 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
     {   // one batch of loads for everything the serial part reads
         const bool need_state = (g.flags & (GF_PROPAGATE | GF_TRAJ | GF_POLICY | GF_RBF_PRE)) != 0;
         const bool lin = (g.flags & GF_POLICY) && g.pol_kind == PILCO_POLICY_LINEAR;
-        const LoadSeg sg[6] = {
+        const bool pol = (g.flags & GF_POLICY) && g.pol_kind != PILCO_POLICY_NONE;
+        const LoadSeg sg[8] = {
             {0, g.m_x, need_state ? E : 0},
             {L.o_sx, g.s_x, need_state ? E * E : 0},
             {L.o_s1, g.s1, (g.flags & GF_PROPAGATE) ? E * D : 0},
             {L.o_mp, (g.flags & GF_RBF_POST) ? g.pwk.mean_part : g.wk.mean_part, mp_n},
             {L.o_seg, g.wk.gath, ((g.flags & GF_ASSEMBLE) && !(g.flags & GF_PACK)) ? seg_n : 0},
             {L.o_js, g.W, lin ? U * E : 0},   // W parks in the joint-covariance buffer until write_joint overwrites it
+            {L.o_misc + 128, g.b, lin ? U : 0},                       // the policy's small vectors ride in the same batch: read
+            {L.o_misc + 160, g.maxact, (pol && g.maxact) ? U : 0},    // from global memory later each costs a DRAM round trip
         };
-        multi_load<6, 4>(L.mx, sg);
+        multi_load<8, 4>(L.mx, sg);
     }
     __syncthreads();
 
@@ -471,7 +475,7 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
             __syncthreads();
             if (g.squash) {
                 double* cdiag = L.misc + 1;
-                squash_inplace(L, U, g.maxact, cdiag);
+                squash_inplace(L, U, g.maxact ? L.misc + 160 : nullptr, cdiag);
                 for (int e = t; e < E * U; e += blockDim.x) L.cxu[e] *= cdiag[e % U];
                 __syncthreads();
             }
@@ -479,7 +483,7 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
         if (g.pol_kind == PILCO_POLICY_LINEAR) {
             // M = m W^T + b, S = W s W^T, V = W^T                  (controllers.py:52-54); W is in L.js (batched load)
             if (t < U) {
-                double acc = g.b[t];
+                double acc = L.misc[128 + t];
                 _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.js[t * E + k], L.mx[k], acc);
                 L.mu[t] = acc;
             }
@@ -500,7 +504,7 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
             __syncthreads();
             if (g.squash) {
                 double* cdiag = L.misc + 1;  // [U]
-                squash_inplace(L, U, g.maxact, cdiag);
+                squash_inplace(L, U, g.maxact ? L.misc + 160 : nullptr, cdiag);
                 for (int e = t; e < E * U; e += blockDim.x) L.cxu[e] *= cdiag[e % U];   // V @ C, C diagonal
                 __syncthreads();
             }
