@@ -13,8 +13,6 @@ for rep in range(3):
     ts = ctx.debug_timestamps()
     us = lambda a, b: (ts[b] - ts[a]) / 100.0
     if ts[30]: print("stamp kernel between prep and pair: prep block0 end -> stamp %.2f us; stamp -> pair w0 start %.2f us" % (us(4, 30), us(30, 16)))
-    print("prep row-phase end of waves 0..3 rel. to block0 start: block(0,0) %s | block(30,1): rows start %s end %s" % (
-        " ".join("%.1f" % us(0, 40 + w) for w in range(4)), " ".join("%.1f" % us(0, 48 + w) for w in range(4)), " ".join("%.1f" % us(0, 44 + w) for w in range(4))))
     print("glue0 [%.2f] -> gap %.2f -> prep [init %.2f gj %.2f rows %.2f red %.2f = %.2f] -> gap %.2f -> pair [w0 %.2f, last wave ends +%.2f] -> gap(after w0) %.2f -> glue [loads %.2f pack %.2f asm %.2f prop %.2f joint %.2f = %.2f; reward wg %.2f]  total %.2f us" % (
         us(24, 29), us(29, 0), us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(0, 4), us(4, 16), us(16, 17), us(17, 18), us(17, 8),
         us(8, 9), us(9, 10), us(10, 11), us(11, 12), us(12, 13), us(8, 13), us(20, 21), us(24, 13)))
