@@ -178,11 +178,14 @@ def engine_clock_under_pair_load(ctx, cfg, policy, rewards):
         cd.gp_set_data(0, cfg["X"], cfg["Y"])
         cd.gp_set_hyp(0, cfg["lengthscales"], cfg["variance"], cfg["noise"])
         cd.gp_factorize(0)
-        ts = None
-        for _ in range(3):
+        ts, spans = None, []
+        for _ in range(4):
             cd.rollout(policy, rewards, cfg["m0"], cfg["S0"], 3)
             ts = cd.debug_timestamps()
-        return (ts[33] - ts[32]) / ((ts[17] - ts[16]) / 100.0)
+            ends = [x for x in cd.debug_blocks(960 + 256 + 8)[960:960 + 256] if x]
+            if ends and ts[16]:
+                spans.append((max(max(ends), ts[17], ts[18]) - ts[16]) / 100.0)   # first wave in -> last wave out, us
+        return (ts[33] - ts[32]) / ((ts[17] - ts[16]) / 100.0), (float(np.median(spans[1:])) if len(spans) > 1 else None)
     finally:
         cd.close()
 
@@ -272,10 +275,10 @@ def main():
 
     # the clock the engine actually runs at under this kernel's load, and the kernel's own instruction-issue bound there:
     # per 16-column step a wave issues 6 v_mfma_f64_16x16x4 (64 cycles) + 104 VALU ops (4 cycles) on the shared fp64 pipe
-    clock_mhz, issue_us = None, None
+    clock_mhz, issue_us, span_us = None, None, None
     if world == 1:
         try:
-            clock_mhz = engine_clock_under_pair_load(ctx, cfg, policy, rewards)
+            clock_mhz, span_us = engine_clock_under_pair_load(ctx, cfg, policy, rewards)
             issue_us = exps / 512.0 / 1024.0 * 800.0 / clock_mhz
         except Exception:
             clock_mhz = None
@@ -344,9 +347,12 @@ def main():
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_mm_pair_sk (f64 MFMA exponent tiles + fp64 exp; MFMA and fp64 VALU share one pipe)",
                          "avg_launch_ms": pair_ms,
+                         "in_kernel_span_us": span_us,
                          "engine_clock_mhz_under_load": clock_mhz, "issue_bound_us_at_that_clock": issue_us,
                          "frac_of_issue_bound": (issue_us / (pair_ms * 1e3)) if (issue_us and pair_ms > 0) else None,
-                         "note": "frac = SURVEY 8(d) algorithmic FLOP (exp internals excluded) / spec peak at 2.4 GHz; the kernel's own "
+                         "note": "avg_launch_ms: hipEvent pairs around each launch of an eager replay (includes event latency: an upper bound; rocprofv3 "
+                                 "brackets the same kernel at 46.9 us, profiles/r02_kernel_stats.csv); in_kernel_span_us: first wave in to last wave out by "
+                                 "the kernel's own 100 MHz stamps. frac = SURVEY 8(d) algorithmic FLOP (exp internals excluded) / spec peak at 2.4 GHz; the kernel's own "
                                  "bound is instruction issue: 800 cycles per 512 exps (6 f64 MFMA + 104 VALU ops) at the measured clock",
                          "algorithmic_flop_per_launch": flop_local, "exp_per_launch": exps / world,
                          "gexp_per_s": exps / world / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0,
