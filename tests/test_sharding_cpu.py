@@ -172,3 +172,32 @@ def test_stream_k_closed_forms_match_enumeration():
             wlo, fslot, whi = out[0], out[1], out[2]
             assert wlo == touching[0] and whi == touching[-1]
             assert fslot == (1 if bnd[wlo] < S0 else 0)   # a wave that starts before the pair holds it in its second slot
+
+
+def test_bench_multi_rank_host_logic_under_torchrun():
+    """bench.py --gpus 2 exactly as the driver launches it (python -m torch.distributed.run, one process per rank), with
+    the device replaced by a stand-in Context (tests/helpers/bench_fake_ranks.py): rendezvous over gloo on 127.0.0.1,
+    broadcast of rank 0's RCCL id, barriers, MAX-over-ranks timing, the replica leg, verification against the fixture and
+    ONE JSON line from rank 0 with the contract's keys."""
+    import json
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "helpers", "bench_fake_ranks.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["vs_baseline"] is None
+    assert d["ms_per_step"] >= 4.0                      # the slower rank (2 x 2 ms sleep) sets the time
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-9
+    assert d["verified"]["max_rel_err"]["S_H"] == 0.0
+    assert "replica_rollouts_per_s" in d["secondary"] and "cpu_baseline" not in d
