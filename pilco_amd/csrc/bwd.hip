@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
     const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
     const bool diag = (a == b);
     const double* iKa = (diag && md.iK) ? md.iK + mm_ik_blk(md, a) * npad * npad : nullptr;
-    const int jw = npad / njs, jbeg = js * jw, jend = jbeg + jw;
+    // column range of this split: the npad / 16 column tiles dealt as evenly as they go (njs need not divide them)
+    const int ct = npad / 16, jbeg = 16 * (int)((long)js * ct / njs), jend = 16 * (int)((long)(js + 1) * ct / njs);
+    const int jw = jend - jbeg, jws = 16 * ((ct + njs - 1) / njs);   // jws: LDS slice stride (the widest split)
     const int ibase = rb * 64 * BWD_RT + w * 16 * BWD_RT;
     double rf[BWD_RT][KC], brow[BWD_RT];
     int irow[BWD_RT];
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
     d4 acc[BWD_RT];
 #pragma unroll
     for (int rt = 0; rt < BWD_RT; ++rt) acc[rt] = d4{0.0, 0.0, 0.0, 0.0};
-    double* myslice = csl + w * jw;
+    double* myslice = csl + w * jws;
     // the column sweep, specialised at compile time (branches inside the loop would fence the scheduler between the
     // eight exp evaluations of a step): MODE 0 off-diagonal pair (column sums), 1 diagonal pair with the iK stream,
     // 2 diagonal pair without it (RBF policy GP)
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
         __syncthreads();
         double* cp = cpart + ((long)(pl - wk.EL) * gridDim.x + rb) * npad + jbeg;
         for (int jj = threadIdx.x; jj < jw; jj += 256)
-            cp[jj] = (csl[jj] + csl[jw + jj]) + (csl[2 * jw + jj] + csl[3 * jw + jj]);
+            cp[jj] = (csl[jj] + csl[jws + jj]) + (csl[2 * jws + jj] + csl[3 * jws + jj]);
     }
 }
 
@@ -486,6 +488,7 @@ void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb) {
     *nrb = (npad + 64 * BWD_RT - 1) / (64 * BWD_RT);
     int q = 1;   // column splits: enough workgroups for a few balanced rounds of the chip
     while (q < 4 && (npad / 16) % (2 * q) == 0 && (long)*nrb * PL * q < 1536) q *= 2;
+    if (const char* ev = getenv("PILCO_BWD_NJS")) q = std::max(1, std::min(atoi(ev), npad / 16));
     *njs = q;
 }
 
@@ -497,7 +500,7 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
     const int nhead = E + P, per_row = nrb * njs;
     dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);   // the rows past P hold the head workgroups
     const int LD = D | 1, nI = D * D;
-    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * (md.npad / njs), (size_t)4 * nI + D);
+    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs), (size_t)4 * nI + D);
 #define PB(K_)                                                                                                       \
     do {                                                                                                             \
         if (wk.vsep)                                                                                                 \

@@ -1236,3 +1236,92 @@ def test_full_size_c2u_gradient_directional_fd(ctx):
     fd = (vals[0] - vals[1]) / (2 * h)
     an = float((Wb * dW).sum() + (bb * db).sum())
     np.testing.assert_allclose(an, fd, rtol=1e-5, atol=1e-9)
+
+
+_FUZZ_N = [1, 2, 3, 15, 16, 17, 31, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300]
+
+
+@pytest.mark.parametrize("seed", range(28))
+def test_random_shapes_rollout_and_policy_gradient_vs_oracle(ctx, seed):
+    """Seeded sweep over shapes the other tests do not pin: N around every tile / padding boundary (1 .. 300), E 1..5,
+    0..2 controls, H 0..5, linear or RBF policy (1..12 basis functions), per-control max_action, exponential (random W, t)
+    / linear / combined reward.  Forward rollout against the NumPy restatement (held to the executed reference at 1e-9),
+    and, where there is a control, the policy gradient against torch autograd of the restated rollout."""
+    import torch
+    from oracle import torch_path as tq
+    from pilco_amd.adjoint import rollout_value_and_grad
+    from pilco_amd.controllers import LinearController, RbfController
+    from pilco_amd.models import PILCO
+    from pilco_amd.rewards import CombinedRewards, ExponentialReward, LinearReward
+    rs = np.random.RandomState(7000 + seed)
+    N = _FUZZ_N[seed % len(_FUZZ_N)] if seed < len(_FUZZ_N) else int(rs.randint(1, 301))
+    E, U, H = int(rs.randint(1, 6)), int(rs.randint(0, 3)), int(rs.randint(0, 6))
+    D = E + U
+    X = rs.randn(N, D)
+    Y = 0.3 * np.sin(X @ rs.randn(D, E)) + 1e-2 * rs.randn(N, E)
+    ls, var, nz = 0.8 + rs.rand(E, D), 0.3 + rs.rand(E), 10.0 ** rs.uniform(-3, -1, E)
+    m0, S0 = 0.2 * rs.randn(1, E), (lambda A: 0.02 * np.eye(E) + 0.02 * A @ A.T)(rs.randn(E, E))
+    maxact = 0.5 + 2.0 * rs.rand(U)
+    kind = "none" if U == 0 else ("rbf" if rs.rand() < 0.5 else "linear")
+    if kind == "linear":
+        W, b = 0.5 * rs.randn(U, E), 0.3 * rs.randn(1, U)
+        ctl = LinearController(E, U, max_action=maxact)
+        ctl.W.assign(W); ctl.b.assign(b)
+        octl = lambda mm, ss: tp.linear_controller(mm, ss, W, b, maxact)
+    elif kind == "rbf":
+        bf = int(rs.randint(1, 13))
+        cX, cY, cl = rs.randn(bf, E), 0.4 * rs.randn(bf, U), 0.9 + 0.4 * rs.rand(U, E)
+        ctl = RbfController(E, U, bf, max_action=maxact)
+        ctl.set_data((cX, cY))
+        for i, mdl in enumerate(ctl.models):
+            mdl.kernel.lengthscales.assign(cl[i])
+        octl = lambda mm, ss: tp.rbf_controller(mm, ss, cX, cY, cl, max_action=maxact, squash=True)
+    else:
+        ctl, octl = None, tp.no_controller
+    rk = int(rs.randint(0, 3))
+    A = rs.randn(E, E)
+    Wr, tr, Wl = 0.3 * np.eye(E) + 0.1 * A @ A.T, 0.3 * rs.randn(1, E), 0.3 * rs.randn(E, 1)
+    if rk == 0:
+        rew = ExponentialReward(E, W=Wr, t=tr)
+        orew = lambda mm, ss: tp.exponential_reward(mm, ss, Wr, tr)
+        trew = lambda mm, ss: tq.exponential_reward(mm, ss, Wr, tr)
+    elif rk == 1:
+        rew = LinearReward(E, Wl)
+        orew = lambda mm, ss: tp.linear_reward(mm, ss, Wl)
+        trew = lambda mm, ss: mm @ tq.t(Wl)
+    else:
+        rew = CombinedRewards(E, [ExponentialReward(E, W=Wr, t=tr), LinearReward(E, Wl)], coefs=[0.7, -0.4])
+        orew = lambda mm, ss: tp.combined_rewards(mm, ss, [lambda a, c: tp.exponential_reward(a, c, Wr, tr), lambda a, c: tp.linear_reward(a, c, Wl)], [0.7, -0.4])
+        trew = lambda mm, ss: 0.7 * tq.exponential_reward(mm, ss, Wr, tr) - 0.4 * mm @ tq.t(Wl)
+    p = PILCO((X, Y), horizon=H, controller=ctl, reward=rew, m_init=m0, S_init=S0) if U else \
+        PILCO((X, Y), num_induced_points=None, horizon=H, controller=None, reward=rew, m_init=m0, S_init=S0)
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(ls[i]); mdl.kernel.variance.assign(var[i]); mdl.likelihood.variance.assign(nz[i])
+    what = "seed %d: N=%d E=%d U=%d H=%d policy=%s reward=%d" % (seed, N, E, U, H, kind, rk)
+    Mg, Sg, Rg = p.predict(m0, S0, H)
+    model = tp.Model(X, Y, ls, var, nz)
+    Mo, So, Ro = tp.predict(model, octl, orew, m0, S0, H, cache=True)
+    np.testing.assert_allclose(Mg, Mo, rtol=RTOL, atol=1e-12, err_msg=what)
+    np.testing.assert_allclose(Sg, So, rtol=RTOL, atol=1e-12, err_msg=what)
+    np.testing.assert_allclose(Rg, Ro, rtol=RTOL, atol=1e-12, err_msg=what)
+    if U == 0:
+        return
+    iK, beta = tp.calculate_factorizations(X, Y, ls, var, nz)
+    gp = lambda mm, ss: tq.predict_given_factorizations(X, ls, var, mm, ss, iK, beta)
+    r, grads = rollout_value_and_grad(p)
+    if kind == "linear":
+        prm = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (W, b)]
+        pol = lambda mm, ss: tq.linear_controller(mm, ss, prm[0], prm[1], maxact)
+    else:
+        prm = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (cX, cY, cl)]
+        pol = lambda mm, ss: tq.rbf_controller(mm, ss, prm[0], prm[1], prm[2], torch.full((U,), 1e-4, dtype=torch.float64), maxact)
+    _, _, R = tq.predict(gp, pol, trew, tq.t(m0), tq.t(S0), H)
+    np.testing.assert_allclose(r, float(R.sum().detach()), rtol=1e-7, atol=1e-12, err_msg=what)
+    if not R.requires_grad:   # H <= 1: the reward is taken before each propagation (pilco.py:133), the policy never enters
+        for g in grads:
+            assert np.all(np.asarray(g) == 0.0), what
+        return
+    R.sum().backward()
+    for g, tprm in zip(grads, prm):
+        ref = tprm.grad.numpy()
+        np.testing.assert_allclose(np.asarray(g).reshape(ref.shape), ref, rtol=1e-5, atol=1e-9 * max(1.0, np.abs(ref).max()), err_msg=what)
