@@ -18,6 +18,8 @@ namespace pilco {
 #ifndef BWD_RT
 #define BWD_RT 2
 #endif
+constexpr int BWD_CH = 64;   // columns staged per LDS chunk (one wave-wide row segment)
+constexpr int BWD_TP = 17;   // pitch of the staged column-major tile (doubles): KP <= 16 rows + 1, conflict-free
 // sum_{q < n} base[q * stride] with the loads of a batch of B issued together (a plain loop serialises one global
 // latency per term: these kernels are latency-bound); fixed summation order
 template <int B>
@@ -134,22 +136,39 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
 #pragma unroll
         for (int c = 0; c < KC; ++c) rf[rt][c] = At[(long)(4 * c + lr) * npad + irow[rt]];
     }
-    // buffer loads: uniform resource + per-lane byte offset + scalar column offset (no 64-bit VALU address math)
-    const __amdgpu_buffer_rsrc_t rB = buf_rsrc(Bt), rbeta = buf_rsrc(beta_b);
-    const __amdgpu_buffer_rsrc_t rV = buf_rsrc(VSEP ? wk.vcol + (long)pl * npad : Bt);
+    // The column operands (KP rows of Bt, beta_b, v) are the same for the four waves of the workgroup: they are staged
+    // once per BWD_CH columns through LDS (wave w fetches rows w, w + 4, .. as 512-byte row segments) into a
+    // column-major tile T[j][BWD_TP] that serves both MFMA operand layouts -- cf (K = operand row, M = column) and its
+    // transpose a2 (M = operand row, K = column) -- without bank conflicts (pitch 17 doubles); the next chunk is in
+    // flight in registers while the current one is evaluated.  Only the iK stream of a diagonal pair stays a per-wave
+    // buffer load.
+    constexpr int KPc = 4 * KC, NR = KPc + (VSEP ? 2 : 1), NST = (NR + 3) / 4, SB = BWD_CH * BWD_TP + 2 * BWD_CH;
     const __amdgpu_buffer_rsrc_t rIK = buf_rsrc(iKa ? iKa + (long)jbeg * npad : Bt);
-    unsigned cf_off[KC], a2_off[4], bc_off[4], ik_off[BWD_RT][4];
+    const double* vsrc = VSEP ? wk.vcol + (long)pl * npad : Bt;
+    unsigned ik_off[BWD_RT][4];
 #pragma unroll
-    for (int c = 0; c < KC; ++c) cf_off[c] = ((unsigned)(4 * c + lr) * (unsigned)npad + (unsigned)lc) * 8u;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        bc_off[r] = (unsigned)(lr + 4 * r) * 8u;
-        // rows of the column operand contracted by the second product: w_j (d < D) and the ones (d = D); lanes past
-        // that repeat row D: their result rows (d > D of rowmom) are never read
-        a2_off[r] = ((unsigned)(lc <= D ? lc : D) * (unsigned)npad + (unsigned)(4 * r + lr)) * 8u;
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int rt = 0; rt < BWD_RT; ++rt) ik_off[rt][r] = ((unsigned)(lr + 4 * r) * (unsigned)npad + (unsigned)irow[rt]) * 8u;
-    }
+    const int dsel = lc <= D ? lc : D;   // operand rows contracted by the second product: w_j (d < D), the ones (d = D);
+                                         // lanes past that repeat row D: their result rows (d > D of rowmom) are never read
+    double* stg = csl + 4 * jws;         // [2][SB]
+    auto stage_load = [&](int jc, double (&sg)[NST]) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int row = w + 4 * k, col = jc + lane;   // wave-uniform row
+            const double* src = row < KPc ? Bt + (long)row * npad : (row == KPc ? beta_b : vsrc);
+            sg[k] = (row < NR && col < jend) ? src[col] : 0.0;
+        }
+    };
+    auto stage_store = [&](double* buf, const double (&sg)[NST]) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int row = w + 4 * k;
+            if (row < KPc) buf[lane * BWD_TP + row] = sg[k];
+            else if (row < NR) buf[BWD_CH * BWD_TP + (row - KPc) * BWD_CH + lane] = sg[k];
+        }
+    };
     d4 acc[BWD_RT];
 #pragma unroll
     for (int rt = 0; rt < BWD_RT; ++rt) acc[rt] = d4{0.0, 0.0, 0.0, 0.0};
@@ -159,46 +178,62 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
     // 2 diagonal pair without it (RBF policy GP)
     auto sweep = [&](auto mode_c) {
         constexpr int MODE = decltype(mode_c)::value;
-        for (int j0 = jbeg; j0 < jend; j0 += 16) {
-            double cf[KC], a2[4], bcol[4], vj[4];
-            const unsigned so = (unsigned)j0 * 8u;
+        double sg[NST];
+        stage_load(jbeg, sg);
+        stage_store(stg, sg);
+        __syncthreads();
+        int cur = 0;
+        for (int jc = jbeg; jc < jend; jc += BWD_CH) {
+            const bool more = jc + BWD_CH < jend;
+            if (more) stage_load(jc + BWD_CH, sg);
+            const double* Tb = stg + cur * SB;
+            const double* bS = Tb + BWD_CH * BWD_TP;
+            const double* vS = bS + BWD_CH;
+            const int nst = min(BWD_CH, jend - jc);
+            for (int jl = 0; jl < nst; jl += 16) {
+                const int j0 = jc + jl;
+                double cf[KC], a2[4], bcol[4], vj[4];
     #pragma unroll
-            for (int c = 0; c < KC; ++c) cf[c] = buf_ld(rB, cf_off[c], so);
-    #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                bcol[r] = buf_ld(rbeta, bc_off[r], so);
-                vj[r] = VSEP ? buf_ld(rV, bc_off[r], so) : 0.0;   // transposed tile: v_j runs along the result registers
-                a2[r] = buf_ld(rB, a2_off[r], so);
-            }
-            double csum[4] = {0.0, 0.0, 0.0, 0.0};
-    #pragma unroll
-            for (int rt = 0; rt < BWD_RT; ++rt) {
-                d4 e = {0.0, 0.0, 0.0, 0.0};
-    #pragma unroll
-                for (int c = 0; c < KC; ++c)
-                    e = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[c], rf[rt][c], e, 0, 0, 0);   // e[r]: i = irow, j = j0+lr+4r
-                double wl[4];
+                for (int c = 0; c < KC; ++c) cf[c] = Tb[(jl + lc) * BWD_TP + 4 * c + lr];
     #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    double wgt = brow[rt] * bcol[r];
-                    if (MODE == 1) wgt -= buf_ld(rIK, ik_off[rt][r], (unsigned)(j0 - jbeg) * (unsigned)npad * 8u);   // iK symmetric: coalesced along the rows
-                    wl[r] = wgt * fexp(VSEP ? e[r] + vj[r] : e[r], tab);
-                    csum[r] += wl[r];
+                    bcol[r] = bS[jl + lr + 4 * r];
+                    vj[r] = VSEP ? vS[jl + lr + 4 * r] : 0.0;   // transposed tile: v_j runs along the result registers
+                    a2[r] = Tb[(jl + 4 * r + lr) * BWD_TP + dsel];
                 }
+                double csum[4] = {0.0, 0.0, 0.0, 0.0};
     #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[r], wl[r], acc[rt], 0, 0, 0);
-            }
-            if (MODE == 0) {
+                for (int rt = 0; rt < BWD_RT; ++rt) {
+                    d4 e = {0.0, 0.0, 0.0, 0.0};
     #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double v = csum[r];
-                    v = dpp_add<0x111, 0xf>(v);
-                    v = dpp_add<0x112, 0xf>(v);
-                    v = dpp_add<0x114, 0xf>(v);
-                    v = dpp_add<0x118, 0xf>(v);   // lane 15 of every DPP row: sum over the 16 rows i
-                    if (lc == 15) myslice[j0 - jbeg + lr + 4 * r] = v;
+                    for (int c = 0; c < KC; ++c)
+                        e = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[c], rf[rt][c], e, 0, 0, 0);   // e[r]: i = irow, j = j0+lr+4r
+                    double wl[4];
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double wgt = brow[rt] * bcol[r];
+                        if (MODE == 1) wgt -= buf_ld(rIK, ik_off[rt][r], (unsigned)(j0 - jbeg) * (unsigned)npad * 8u);   // iK symmetric: coalesced along the rows
+                        wl[r] = wgt * fexp(VSEP ? e[r] + vj[r] : e[r], tab);
+                        csum[r] += wl[r];
+                    }
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[r], wl[r], acc[rt], 0, 0, 0);
+                }
+                if (MODE == 0) {
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double v = csum[r];
+                        v = dpp_add<0x111, 0xf>(v);
+                        v = dpp_add<0x112, 0xf>(v);
+                        v = dpp_add<0x114, 0xf>(v);
+                        v = dpp_add<0x118, 0xf>(v);   // lane 15 of every DPP row: sum over the 16 rows i
+                        if (lc == 15) myslice[j0 - jbeg + lr + 4 * r] = v;
+                    }
                 }
             }
+            if (more) stage_store(stg + (cur ^ 1) * SB, sg);
+            __syncthreads();
+            cur ^= 1;
         }
     };
     if (!diag) sweep(std::integral_constant<int, 0>{});
@@ -436,15 +471,35 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
 //   mbar += kappa P A,   sbar += kappa (P I P^T / 2 - N (P Lambda + Lambda P^T) / 4)      
 // out[E + pl][D + D*D].  bars = (Mbar [E] | Sbar [E][E] | Vbar [D][E]) on the device.  Workgroups past the pairs
 // finish the mean part of one output each.
+// The workgroup that finishes last (a device-scope counter) adds the E + P records up in their fixed order and writes the
+// sum (mbar | sbar before symmetrisation) to `sum_out` -- pinned host memory the caller reads after the stream has
+// drained: no device-to-host copy command, no host loop over the records.
+__device__ void bwd_fin_pairs(const MMModel& md, const MMWork& wk, const double* __restrict__ part, int nrc,
+                              const double* __restrict__ head, double* __restrict__ out, double* sm);
+
 __global__ __launch_bounds__(256) void k_mm_bwd_fin(MMModel md, MMWork wk, const double* __restrict__ part, int nrc,
                                                    const double* __restrict__ bars, const double* __restrict__ head,
-                                                   const double* __restrict__ mpart, double* __restrict__ out) {
+                                                   const double* __restrict__ mpart, double* out,
+                                                   unsigned* __restrict__ done, double* __restrict__ sum_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int last;
     const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x;
-    if (pl >= wk.PL) {
-        bwd_mean_final(md, bars, head, pl - wk.PL, nrc, mpart, out, sm);
-        return;
-    }
+    if (pl >= wk.PL) bwd_mean_final(md, bars, head, pl - wk.PL, nrc, mpart, out, sm);
+    else bwd_fin_pairs(md, wk, part, nrc, head, out, sm);
+    __threadfence();
+    __syncthreads();
+    if (t == 0) last = (atomicAdd(done, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const int rec = D + D * D;
+    for (int e = t; e < rec; e += 256) sum_out[e] = sum_strided<16>(out + e, rec, E + wk.PL);
+    if (t == 0) *done = 0u;
+}
+
+__device__ void bwd_fin_pairs(const MMModel& md, const MMWork& wk, const double* __restrict__ part, int nrc,
+                              const double* __restrict__ head, double* __restrict__ out, double* sm) {
+    const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x;
     const int nI = D * D, rec = 1 + D + nI;
     double* Pm = sm;               // [D][D]
     double* lam = Pm + nI;         // [D + 2]: lambda | kappa
@@ -493,14 +548,14 @@ void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb) {
 }
 
 void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* part,
-                   const double* bars, double* head, double* out) {
+                   const double* bars, double* head, double* out, unsigned* done, double* sum_out) {
     const int P = wk.PL, E = md.E, D = md.D;
     int njs, nrb;
     mm_bwd_geometry(md.npad, P, &njs, &nrb);
     const int nhead = E + P, per_row = nrb * njs;
     dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);   // the rows past P hold the head workgroups
     const int LD = D | 1, nI = D * D;
-    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs), (size_t)4 * nI + D);
+    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * BWD_TP + 2 * BWD_CH), (size_t)4 * nI + D);
 #define PB(K_)                                                                                                       \
     do {                                                                                                             \
         if (wk.vsep)                                                                                                 \
@@ -521,7 +576,7 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
     hipLaunchKernelGGL(k_mm_bwd_post, dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
                        head, mpart);
     const size_t lds_fin = sizeof(double) * ((size_t)3 * nI + 4 * D + 8);
-    hipLaunchKernelGGL(k_mm_bwd_fin, dim3(P + E), dim3(256), lds_fin, st, md, wk, part, nrc, bars, head, mpart, out);
+    hipLaunchKernelGGL(k_mm_bwd_fin, dim3(P + E), dim3(256), lds_fin, st, md, wk, part, nrc, bars, head, mpart, out, done, sum_out);
 }
 int mm_bwd_rc(int npad) { return std::min(BWD_RC, npad / 64); }
 

@@ -21,7 +21,7 @@ struct Slot {
     int n = 0, npad = 0;             // points the moment matching runs over (N or M) and padding
     bool has_data = false, has_hyp = false, factor_valid = false, user_factors = false, iK_null = false;
     bool ignore_iK = false;  // policy slot: RbfController evaluates with iK zeroed (controllers.py:116)
-    DevBuf bwd_mom, bwd_cp, bwd_part, bwd_out; // reverse-pass scratch
+    DevBuf bwd_mom, bwd_cp, bwd_part, bwd_out, bwd_cnt; // reverse-pass scratch (bwd_cnt: the finished-workgroups counter)
     DevBuf Xt, Yt, Zt, ls, var, noise;         // Yt: [E][Npad]
     DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
     DevBuf Kmn, V2, Am, AmInv, AmD, iAt, G;    // FITC extras

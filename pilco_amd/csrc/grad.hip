@@ -6,8 +6,8 @@ extern "C" {
 
 // Vector-Jacobian product of one moment-matching step (the reverse of pilco_gp_predict):
 // given cotangents Mbar (1,E), Sbar (E,E), Vbar (D,E) returns mbar (1,D) and the symmetric sbar (D,D).
-// Entirely on the device (k_mm_bwd_pair / _post / _fin; the mean part rides in extra workgroups of _post / _fin); the
-// host only sums the E + P contribution records.  Single rank, exact or sparse model, D <= 14.
+// Entirely on the device (k_mm_bwd_pair / _post / _fin; the mean part rides in extra workgroups of _post / _fin);
+// the E + P contribution records are summed in a fixed order by the last workgroup to finish.  Single rank, exact or sparse model, D <= 14.
 int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double* s_in, const double* Mbar,
                          const double* Sbar, const double* Vbar, double* mbar, double* sbar) {
     if (int r = check_slot(ctx, slot)) return r;
@@ -28,7 +28,11 @@ int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double
     ENSURE(s.bwd_cp, (size_t)std::max(1, P - E) * nrb * npad);
     ENSURE(s.bwd_part, (size_t)(P + E) * mm_bwd_rc(npad) * (1 + rec + D));   // pair partials, then mean partials
     ENSURE(s.bwd_out, (size_t)(E + P) * rec + (size_t)(E + P) * (D * D + D + 2));   // contributions | head records
-    const size_t n_in = (size_t)D + D * D + nb, n_out = (size_t)(E + P) * rec;
+    if (!s.bwd_cnt.p) {
+        ENSURE(s.bwd_cnt, 2);
+        HIPCHK(hipMemsetAsync(s.bwd_cnt.p, 0, 2 * sizeof(double), ctx->st));
+    }
+    const size_t n_in = (size_t)D + D * D + nb, n_out = (size_t)rec;
     if (ctx->pin_cap < n_in + n_out) {
         if (ctx->pin) (void)hipHostFree(ctx->pin);
         ctx->pin = nullptr;
@@ -47,14 +51,13 @@ int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double
     const double* bars = s.wk.in_s + D * D;
     const MMModel md = model_of(s);
     launch_mm_prep(ctx->st, md, s.wk);
-    launch_mm_bwd(ctx->st, md, s.wk, s.bwd_mom.p, s.bwd_cp.p, s.bwd_part.p, bars, s.bwd_out.p + (size_t)(E + P) * rec, s.bwd_out.p);
-    HIPCHK(hipMemcpyAsync(ctx->pin + n_in, s.bwd_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->st));
+    // the last workgroup of k_mm_bwd_fin writes the summed record straight into the pinned host buffer
+    launch_mm_bwd(ctx->st, md, s.wk, s.bwd_mom.p, s.bwd_cp.p, s.bwd_part.p, bars, s.bwd_out.p + (size_t)(E + P) * rec, s.bwd_out.p,
+                  (unsigned*)s.bwd_cnt.p, ctx->pin + n_in);
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());
-    // ---- host: sum the E + P records in a fixed order, symmetrise
-    std::vector<double> acc(rec, 0.0);
-    for (int k = 0; k < E + P; ++k)
-        for (int e = 0; e < rec; ++e) acc[e] += po[(size_t)k * rec + e];
+    // ---- host: symmetrise
+    const double* acc = po;
     for (int e = 0; e < rec; ++e)
         if (!std::isfinite(acc[e])) return fail(ctx, PILCO_E_NOT_PD, "predict_vjp: singular s + Lambda^2 or I + Lambda s");
     for (int d = 0; d < D; ++d) mbar[d] = acc[d];

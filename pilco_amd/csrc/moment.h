@@ -146,10 +146,11 @@ void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot);
 // reverse pass of one moment-matching step (single rank, D <= 14; the step's prep kernel must precede it on st):
 // scratch: rowmom [P][njs][16][npad], cpart [P - E][nrb][npad] (njs, nrb from mm_bwd_geometry) and
 // part [P][mm_bwd_rc][1 + D + D*D] + [E][mm_bwd_rc][D*D + 2D + 1]; bars = (Mbar | Sbar | Vbar) on the device,
-// out [E + P][D + D*D] = per output / per pair contributions (mbar | sbar), summed by the caller
+// out [E + P][D + D*D] = per output / per pair contributions (mbar | sbar); their sum in a fixed order goes to
+// sum_out [D + D*D] (device-visible, normally pinned host memory); done: a zeroed device counter (left zeroed)
 // head [E + P][D*D + D + 2]: the step's D x D inverses (see bwd_head)
 void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* part,
-                   const double* bars, double* head, double* out);
+                   const double* bars, double* head, double* out, unsigned* done, double* sum_out);
 void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb);
 int mm_bwd_rc(int npad);
 int mm_exp_table_size();   // entries of the 2^(j/n) table the pair kernels were built for
