@@ -178,8 +178,11 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
     }
     if (FUSED) glue_body(g, L, blockIdx.x == 0 && blockIdx.y == 0);
     double* sm = sm_all + (FUSED ? glue_doubles : 0);
-    const double* jm = L.jm;
-    const double* js = L.js;
+    // the Gaussian this launch's operands are built for: the joint (x, u) the link assembled, or -- policy head of an
+    // RbfController (GF_RBF_PRE) -- the state itself, the input of the policy GP.  (Integer offsets, not a pointer select.)
+    const bool state_in = FUSED && (g.flags & GF_RBF_PRE);
+    const double* jm = sm_all + (state_in ? 0 : L.o_js - L.nm);
+    const double* js = sm_all + (state_in ? L.o_sx : L.o_js);
     if ((int)blockIdx.x >= wk.PL) {
         // spare workgroups of the launch: first the mean parts (local output, row chunk), then the reward
         const int idx = ((int)blockIdx.x - wk.PL) * (int)gridDim.y + (int)blockIdx.y;

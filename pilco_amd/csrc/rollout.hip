@@ -240,6 +240,57 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
     }
     Slot& ps = ctx->slot[PILCO_SLOT_POLICY];
     const MMModel pmd = rbf ? model_of(ps) : MMModel{};
+    if (ctx->fused && rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && ps.wk.PL > 0 && H > 0) {
+        // Fused heads with an RbfController (controllers.py:108-121): the policy is a moment-matching GP of its own, so a
+        // step is two head + pair rounds and the serial link splits in two:
+        //   policy head   [pack / assemble / propagate of step h - 1 -> state h | operands of the POLICY GP at state h]
+        //   policy pairs
+        //   dynamics head [reduce the policy GP, S -= diag(var - 1e-6), squash, joint Gaussian | operands of step h]
+        //   dynamics pairs
+        // four launches per step instead of six (two of them single-workgroup glue launches).  What a head's link reads
+        // was written by EARLIER launches and what its prep part writes belongs to the other GP: no double buffering
+        // beyond the state's.
+        size_t evi = 0;
+        for (int h = 0; h < H; ++h) {
+            GlueArgs ga = g;
+            ga.step = h;
+            ga.dbg_off = h > 0 ? 48 : 0;
+            ga.flags = GF_TRAJ | GF_RBF_PRE | (h > 0 ? (GF_PACK | GF_ASSEMBLE | GF_PROPAGATE) : 0);
+            ga.m_x = plan.st[h > 0 ? (h - 1) & 1 : 0];
+            ga.s_x = ga.m_x + E;
+            ga.m_out = h > 0 ? plan.st[h & 1] : nullptr;
+            ga.s_out = h > 0 ? plan.st[h & 1] + E : nullptr;
+            PrepReward pr{};
+            if (rew) {   // reward of state h (pilco.py:133), from the link's LDS copy of the state
+                pr.n = g.n_rewards;
+                pr.E = E;
+                for (int i = 0; i < g.n_rewards; ++i) pr.rw[i] = g.rw[i];
+                pr.reward = g.reward;
+            }
+            launch_mm_prep(ctx->st, pmd, ps.wk, rew ? &pr : nullptr, &ga);
+            launch_mm_pair(ctx->st, pmd, ps.wk, ctx->variant);
+            GlueArgs gc = g;
+            gc.step = h;
+            gc.flags = GF_RBF_POST | GF_POLICY;
+            gc.m_x = plan.st[h & 1];
+            gc.s_x = gc.m_x + E;
+            gc.m_out = nullptr;
+            gc.s_out = nullptr;
+            launch_mm_prep(ctx->st, md, s.wk, nullptr, &gc);
+            if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
+            launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
+            if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
+        }
+        GlueArgs gf = g;
+        gf.step = H;
+        gf.flags = GF_PACK | GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ;
+        gf.m_x = plan.st[(H - 1) & 1];
+        gf.s_x = gf.m_x + E;
+        gf.m_out = plan.st[H & 1];
+        gf.s_out = gf.m_out + E;
+        launch_glue(ctx->st, gf);
+        return PILCO_OK;
+    }
     // RBF policy (controllers.py:108-121): the glue that produced the state hands it to the policy GP
     // (GF_RBF_PRE), the policy's moment matching runs as its own prep/pair, a second glue squashes and
     // builds the joint Gaussian (GF_RBF_POST | GF_POLICY).

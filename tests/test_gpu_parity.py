@@ -384,6 +384,42 @@ def test_fused_head_is_bitwise_identical_to_the_three_kernel_step(ctx, D):
         assert np.array_equal(m1[0], out[0][3][1, :E]) and np.array_equal(s1.ravel(), out[0][3][1, E:])
 
 
+@pytest.mark.parametrize("N,E,U,bf", [(225, 4, 1, 10), (130, 3, 2, 25), (1000, 10, 1, 50)])
+def test_fused_heads_with_an_rbf_policy_are_bitwise_identical_to_the_six_kernel_step(ctx, N, E, U, bf):
+    """RbfController rollouts: the two fused heads per step (policy head, dynamics head; 4 launches) against the separate
+    link kernels (6 launches): trajectory, reward and the policy gradient (whose forward pass writes the tape) to the last bit."""
+    from pilco_amd.adjoint import rollout_value_and_grad
+    from pilco_amd.controllers import RbfController
+    from pilco_amd.models import PILCO
+    rs = np.random.RandomState(5)
+    D, H = E + U, 5
+    X = rs.randn(N, D)
+    Y = 0.3 * np.sin(X @ rs.randn(D, E)) + 1e-2 * rs.randn(N, E)
+    ctl = RbfController(E, U, bf, max_action=1.0 + rs.rand(U))
+    ctl.set_data((rs.randn(bf, E), 0.3 * rs.randn(bf, U)))
+    m0, S0 = 0.1 * rs.randn(1, E), 0.05 * np.eye(E)
+    p = PILCO((X, Y), horizon=H, controller=ctl, m_init=m0, S_init=S0)
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(0.8 + rs.rand(D)); mdl.kernel.variance.assign(0.5 + rs.rand()); mdl.likelihood.variance.assign(1e-2)
+    out, grads = [], []
+    for fused in (1, 0, 1):
+        ctx.set_fused_step(fused)
+        try:
+            out.append(p.predict_trajectory(m0, S0, H))
+            grads.append(rollout_value_and_grad(p) if D <= 14 else None)
+        finally:
+            ctx.set_fused_step(1)
+    for k in (1, 2):
+        for a, b in zip(out[0], out[k]):
+            assert np.array_equal(a, b)
+        if grads[0] is not None:
+            assert grads[0][0] == grads[k][0]
+            for a, b in zip(grads[0][1], grads[k][1]):
+                assert np.array_equal(a, b)
+    Mg, Sg, Rg = p.predict(m0, S0, H)
+    assert np.array_equal(Mg[0], out[0][3][H, :E])
+
+
 def test_full_size_c2u_gradient_vs_reverse_mode_through_the_reference(ctx, golden_dir):
     """d reward / d (W, b) at C2u (N=1000, D=11, E=10), H=5: the native adjoint against torch reverse mode THROUGH THE
     EXECUTED REFERENCE's training_loss (pilco.py:47-50,85-90; fixture c2u_grad.npz), not against the HIP path itself."""
