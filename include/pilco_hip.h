@@ -51,8 +51,11 @@ int pilco_set_pair_kernel(pilco_ctx* ctx, int variant);
 /* Launch structure of a rollout step.  1 (default): "fused head" -- the serial link of step t (reduce the pair sums,
  * assemble (M,S,V), propagate, controller, joint Gaussian: mgpr.py:143-149, pilco.py:139-149) runs redundantly inside every
  * workgroup of step t+1's operand kernel, two launches per horizon step.  0: separate link kernel, three launches per
- * step (always used with an RBF policy or more than one rank).  Both produce bitwise identical results. */
+ * step (always used with more than one rank unless the peer exchange is attached).  Both produce bitwise identical results. */
 int pilco_set_fused_step(pilco_ctx* ctx, int on);
+/* 1 (default; PILCO_NO_GRAPH=1 in the environment starts with 0): a rollout's launch sequence is captured once into a
+ * hipGraph and replayed while the plan is unchanged; 0: every rollout is enqueued launch by launch.  Same results. */
+int pilco_set_use_graph(pilco_ctx* ctx, int on);
 /* checks the f64 MFMA fragment layout assumptions on the device; 0 = OK */
 int pilco_selftest(pilco_ctx* ctx);
 
@@ -230,6 +233,24 @@ int pilco_group_sync_model(pilco_ctx** ctxs, int n, int slot);
 int pilco_rollout_group(pilco_ctx** ctxs, int n, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
                         const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj,
                         int* mismatch);
+/* Peer exchange: the per-step all-gather without a collective call.  Every rank owns an exchange area in its GPU's
+ * memory; after its pair kernel a rank stores its segment straight into EVERY rank's area (over xGMI between GPUs) and
+ * raises its flag there; the next step's head waits for the W flags of that exchange and reads the segments from its
+ * own memory.  No host involvement per step, no RCCL launch (~20 us) on the critical path; the whole sharded rollout is
+ * captured in one hipGraph.  Used by pilco_rollout whenever it is attached (linear / no policy; otherwise the RCCL path).
+ *   ranks in different processes: pilco_peer_export on every rank (64 opaque bytes = a hipIpcMemHandle_t), all-gather the
+ *   handles by any host transport, pilco_peer_attach(handles[nranks][64]).  share_gpu != 0 when ranks share a GPU
+ *   (oversubscribed tests): the flag wait then runs as a one-workgroup launch of its own so that waiting kernels cannot
+ *   keep the awaited ones off the machine.
+ *   contexts of one process: pilco_group_peer_attach(ctxs, n).
+ * A wait that gives up (~2 s) makes pilco_rollout return PILCO_E_STATE instead of hanging.  All ranks must make the same
+ * sequence of pilco_rollout calls.  pilco_shard_set / pilco_comm_init detach. */
+#define PILCO_PEER_HANDLE_BYTES 64
+int pilco_peer_export(pilco_ctx* ctx, void* handle64);
+int pilco_peer_attach(pilco_ctx* ctx, const void* handles, int share_gpu);
+int pilco_group_peer_attach(pilco_ctx** ctxs, int n);
+int pilco_peer_detach(pilco_ctx* ctx);
+int pilco_peer_attached(const pilco_ctx* ctx);
 int pilco_comm_rank(const pilco_ctx* ctx);
 int pilco_comm_size(const pilco_ctx* ctx);
 

@@ -21,6 +21,7 @@ SLOT_DYNAMICS, SLOT_POLICY = 0, 1
 POLICY_NONE, POLICY_LINEAR, POLICY_RBF = 0, 1, 2
 REWARD_EXPONENTIAL, REWARD_LINEAR = 1, 2
 COMM_ID_BYTES = 128
+PEER_HANDLE_BYTES = 64
 
 _dp = C.POINTER(C.c_double)
 
@@ -55,6 +56,7 @@ SIGNATURES = {
     "pilco_set_pair_kernel": (C.c_int, [_vp, C.c_int]),
     "pilco_selftest": (C.c_int, [_vp]),
     "pilco_set_fused_step": (C.c_int, [_vp, C.c_int]),
+    "pilco_set_use_graph": (C.c_int, [_vp, C.c_int]),
     "pilco_gp_set_data": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int]),
     "pilco_gp_set_hyp": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "pilco_gp_set_inducing": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
@@ -89,6 +91,11 @@ SIGNATURES = {
     "pilco_comm_unique_id": (C.c_int, [_vp]),
     "pilco_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "pilco_shard_set": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "pilco_peer_export": (C.c_int, [_vp, _vp]),
+    "pilco_peer_attach": (C.c_int, [_vp, _vp, C.c_int]),
+    "pilco_group_peer_attach": (C.c_int, [_vp, C.c_int]),
+    "pilco_peer_detach": (C.c_int, [_vp]),
+    "pilco_peer_attached": (C.c_int, [_vp]),
     "pilco_shard_owner_of_pair": (C.c_int, [_vp, C.c_int]),
     "pilco_shard_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "pilco_shard_pair_slot": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -179,6 +186,9 @@ class Context:
 
     def set_fused_step(self, on):
         self._chk(self.lib.pilco_set_fused_step(self.h, 1 if on else 0))
+
+    def use_graph(self, on):
+        self._chk(self.lib.pilco_set_use_graph(self.h, 1 if on else 0))
 
     def set_pair_kernel(self, variant):
         self._chk(self.lib.pilco_set_pair_kernel(self.h, int(variant)))
@@ -452,11 +462,36 @@ class Context:
     def shard_set(self, rank, nranks):
         self._chk(self.lib.pilco_shard_set(self.h, int(rank), int(nranks)))
 
+    # peer exchange (include/pilco_hip.h): the per-step all-gather as direct stores into the other ranks' memory
+    def peer_export(self):
+        """-> the 64 opaque bytes of this rank's exchange area (all-gather them over any host transport)."""
+        buf = C.create_string_buffer(PEER_HANDLE_BYTES)
+        self._chk(self.lib.pilco_peer_export(self.h, buf))
+        return bytes(buf.raw)
+
+    def peer_attach(self, handles, share_gpu=False):
+        """handles: the nranks exported handles in rank order.  share_gpu: ranks share a GPU (oversubscribed tests)."""
+        blob = b"".join(bytes(h) for h in handles)
+        buf = C.create_string_buffer(blob, len(blob))
+        self._chk(self.lib.pilco_peer_attach(self.h, buf, 1 if share_gpu else 0))
+
+    def peer_detach(self):
+        self._chk(self.lib.pilco_peer_detach(self.h))
+
+    def peer_attached(self):
+        return bool(self.lib.pilco_peer_attached(self.h))
+
 
 def group_sync_model(ctxs, slot=0):
     """Exchange the beta rows of the contexts of this process after each has factorised its own outputs."""
     arr = (_vp * len(ctxs))(*[c.h for c in ctxs])
     ctxs[0]._chk(ctxs[0].lib.pilco_group_sync_model(arr, len(ctxs), int(slot)))
+
+
+def group_peer_attach(ctxs):
+    """Attach the peer exchange between the contexts of this process (context i = rank i)."""
+    arr = (_vp * len(ctxs))(*[c.h for c in ctxs])
+    ctxs[0]._chk(ctxs[0].lib.pilco_group_peer_attach(arr, len(ctxs)))
 
 
 def rollout_group(ctxs, policy, rewards, m0, S0, H, want_traj=False):

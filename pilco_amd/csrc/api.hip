@@ -295,6 +295,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (!ctx) return PILCO_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->st);
+    (void)peer_detach(ctx);
     for (auto& ge : ctx->graph_cache) (void)hipGraphExecDestroy(ge.second);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
@@ -332,6 +333,12 @@ int pilco_set_pair_kernel(pilco_ctx* ctx, int variant) {
 int pilco_set_fused_step(pilco_ctx* ctx, int on) {
     if (!ctx) return PILCO_E_SHAPE;
     ctx->fused = (on != 0);
+    return PILCO_OK;
+}
+
+int pilco_set_use_graph(pilco_ctx* ctx, int on) {
+    if (!ctx) return PILCO_E_SHAPE;
+    ctx->use_graph = (on != 0);
     return PILCO_OK;
 }
 

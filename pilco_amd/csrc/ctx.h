@@ -71,6 +71,21 @@ struct PeerGroup {
     }
 };
 
+// Peer exchange of the per-step segments without a collective call (GlueArgs::xq, moment.h): this rank's exchange area
+// and every rank's area as mapped on this device (opened from hipIpc handles for ranks in other processes, plain
+// pointers for contexts of this process).
+struct PeerXch {
+    int W = 0, cap = 0;                            // ranks, doubles per segment slot
+    unsigned long long* local = nullptr;           // fine-grained device memory, xq_area_words(W, cap) words
+    std::vector<unsigned long long*> mapped;       // [W]; mapped[rank] == local
+    std::vector<char> opened;                      // mapped[j] came from hipIpcOpenMemHandle
+    unsigned long long** d_peers = nullptr;        // device copy of `mapped`
+    unsigned long long epoch = 0;                  // exchanges enqueued so far: the same number on every rank
+    unsigned long long* pin = nullptr;             // pinned: ring [128] of epoch-base uploads; [128] error-word download
+    unsigned ring = 0;
+    bool ready = false, wait_kernel = false;       // wait_kernel: ranks share a GPU -> the flag wait gets a launch of its own
+};
+
 struct pilco_ctx {
     int device = 0;
     hipStream_t st = nullptr;
@@ -80,6 +95,7 @@ struct pilco_ctx {
     int rank = 0, nranks = 1;
     ncclComm_t comm = nullptr;
     std::shared_ptr<PeerGroup> group;   // set only while pilco_rollout_group runs
+    PeerXch xq;
     Slot slot[2];
     int* d_info = nullptr;
     DevBuf state;   // m_x, s_x, s1, reward, act_out, rew_out
@@ -138,3 +154,6 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
                   RolloutPlan& plan);
 int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev);
 int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H);
+// shard.hip: peer exchange
+void launch_peer_wait(hipStream_t st, unsigned long long* area, int k, int W, int spin);
+int peer_detach(pilco_ctx* ctx);

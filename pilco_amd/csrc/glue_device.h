@@ -340,6 +340,56 @@ __device__ __forceinline__ void mm_assemble(const MMWork& wk, const double* src,
     __syncthreads();
 }
 
+// ------------------------------------------------------------------ peer exchange (see GlueArgs::xq, moment.h)
+// System-scope accesses throughout: the words are written by other GPUs (or other processes' kernels on this GPU) while
+// this kernel runs, so nothing here may be served from a non-coherent cache.
+__device__ __forceinline__ unsigned long long xq_ld(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// wait until every rank's flag in this exchange's slot has reached the epoch (thread r watches rank r); a wait that
+// runs out of patience records the epoch in the area's error word and goes on -- the host reports it, nothing hangs
+__device__ __forceinline__ void xq_wait(const GlueArgs& g) {
+    const int t = threadIdx.x, W = g.xq_W;
+    if (t < W) {
+        const unsigned long long epoch = xq_ld(g.xq) + (unsigned long long)g.xq_k + 1ULL;
+        const unsigned long long* flag = g.xq + 8 + (int)(epoch & 1ULL) * W + t;
+        int it = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            if (++it > g.xq_spin) {
+                __hip_atomic_store(g.xq + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+}
+// the W segments of this exchange, [rank][SEG] as the gather buffer holds them, into LDS
+__device__ __forceinline__ void xq_load_segments(const GlueArgs& g, double* seg_lds) {
+    const int W = g.xq_W, SEG = g.wk.SEG;
+    const unsigned long long epoch = xq_ld(g.xq) + (unsigned long long)g.xq_k + 1ULL;
+    const unsigned long long* data = g.xq + xq_data_off(W) + (size_t)(epoch & 1ULL) * W * g.xq_cap;
+    for (int e = threadIdx.x; e < W * SEG; e += blockDim.x) {
+        const int r = e / SEG, i = e - r * SEG;
+        seg_lds[e] = __longlong_as_double((long long)xq_ld(data + (size_t)r * g.xq_cap + i));
+    }
+}
+// deliver this rank's segment (in LDS after mm_pack) to every rank's area, then raise this rank's flag there
+__device__ __forceinline__ void xq_push(const GlueArgs& g, const double* seg_lds) {
+    const int t = threadIdx.x, W = g.xq_W, SEG = g.wk.SEG, me = g.wk.rank;
+    const unsigned long long epoch = xq_ld(g.xq) + (unsigned long long)g.xq_k + 1ULL;
+    const size_t off = (size_t)xq_data_off(W) + ((size_t)(epoch & 1ULL) * W + me) * g.xq_cap;
+    for (int e = t; e < W * SEG; e += blockDim.x) {
+        const int r = e / SEG, i = e - r * SEG;
+        __hip_atomic_store(g.xq_peers[r] + off + i, (unsigned long long)__double_as_longlong(seg_lds[i]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (t < W)
+        __hip_atomic_store(g.xq_peers[t] + 8 + (int)(epoch & 1ULL) * W + me, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // The serial link.  On return (GF_POLICY) the joint Gaussian is in L.jm / L.js and the (propagated) state in L.mx / L.sx.
 // All threads of the workgroup must call it; `writer` selects the one workgroup that stores results to global memory.
 __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, bool writer) {
@@ -355,6 +405,8 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
     DBG_STAMP(g.wk, 8 + dbo, dbg0);
     PackPre pp;   // first round of the pack: its loads are in flight together with the batch below
     if ((g.flags & GF_PACK) && !MM_ABL(g.wk, 16)) mm_pack_issue(g.wk, 0, pp);
+    const bool xq_in = g.xq && (g.flags & GF_ASSEMBLE) && !(g.flags & GF_PACK);
+    if (xq_in) xq_wait(g);   // (the segment loads below must not be issued before the flags have been seen)
     {   // one batch of loads for everything the serial part reads
         const bool need_state = (g.flags & (GF_PROPAGATE | GF_TRAJ | GF_POLICY | GF_RBF_PRE)) != 0;
         const bool lin = (g.flags & GF_POLICY) && g.pol_kind == PILCO_POLICY_LINEAR;
@@ -364,17 +416,19 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
             {L.o_sx, g.s_x, need_state ? E * E : 0},
             {L.o_s1, g.s1, (g.flags & GF_PROPAGATE) ? E * D : 0},
             {L.o_mp, (g.flags & GF_RBF_POST) ? g.pwk.mean_part : g.wk.mean_part, mp_n},
-            {L.o_seg, g.wk.gath, ((g.flags & GF_ASSEMBLE) && !(g.flags & GF_PACK)) ? seg_n : 0},
+            {L.o_seg, g.wk.gath, ((g.flags & GF_ASSEMBLE) && !(g.flags & GF_PACK) && !xq_in) ? seg_n : 0},
             {L.o_js, g.W, lin ? U * E : 0},   // W parks in the joint-covariance buffer until write_joint overwrites it
             {L.o_misc + 128, g.b, lin ? U : 0},                       // the policy's small vectors ride in the same batch: read
             {L.o_misc + 160, g.maxact, (pol && g.maxact) ? U : 0},    // from global memory later each costs a DRAM round trip
         };
         multi_load<8, 4>(L.mx, sg);
+        if (xq_in) xq_load_segments(g, L.seg);
     }
     __syncthreads();
 
     DBG_STAMP(g.wk, 9 + dbo, dbg0);
     if ((g.flags & GF_PACK) && !MM_ABL(g.wk, 16)) mm_pack(g.wk, D, E, L, pp, writer);
+    if ((g.flags & GF_PACK) && g.xq_peers && writer) xq_push(g, L.seg);
     DBG_STAMP(g.wk, 10 + dbo, dbg0);
     const bool fast = (g.flags & (GF_PACK | GF_ASSEMBLE | GF_PROPAGATE)) == (GF_PACK | GF_ASSEMBLE | GF_PROPAGATE) && g.wk.nranks == 1;
     if (fast) {

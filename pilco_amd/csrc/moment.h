@@ -119,7 +119,25 @@ struct GlueArgs {
     // direct outputs of pilco_policy_action / pilco_reward_eval (optional)
     double* act_out;  // [U + U*U + E*U]
     double* rew_out;  // [2] mean, variance: set only by pilco_reward_eval
+    // peer exchange (SURVEY 8e without a collective call): every rank owns an exchange area (see PeerArea) that its peers
+    // write into directly -- over xGMI when the ranks sit on different GPUs.  A GF_PACK launch with xq_peers set stores
+    // its segment into every rank's area and then raises its flag there; a GF_ASSEMBLE launch with xq set waits for the
+    // W flags of exchange xq_k of this rollout and takes the segments from its own area.
+    unsigned long long* xq;         // this rank's exchange area, or nullptr
+    unsigned long long** xq_peers;  // device array [W]: every rank's area as mapped on this device, or nullptr
+    int xq_k;                       // exchange number within the rollout: epoch = area[0] + xq_k + 1
+    int xq_W;
+    int xq_cap;                     // doubles per segment slot
+    int xq_spin;                    // bound of the flag wait (iterations of ~1 us): on expiry the area's error word is set
 };
+
+// Layout of an exchange area, in 8-byte words:  [0] epoch base of the current rollout (uploaded by the owner's host)
+// [1] error word (0 = fine; else the epoch a wait gave up on)   [8 + s * W + r] flag of rank r in slot s (s = epoch & 1):
+// the last epoch rank r has delivered there   [xq_data_off(W) + (s * W + r) * cap + i] segment of rank r in slot s.
+// Two slots suffice: a rank delivers epoch e + 2 only after it has seen every flag of epoch e + 1, which the others raise
+// after they have finished reading epoch e.
+__host__ __device__ inline int xq_data_off(int W) { return (8 + 2 * W + 7) & ~7; }
+__host__ __device__ inline size_t xq_area_words(int W, int cap) { return (size_t)xq_data_off(W) + (size_t)2 * W * cap; }
 
 // fused != nullptr: the "fused head" -- every workgroup first runs the serial link of the PREVIOUS step (glue_body with
 // *fused: pack / assemble / propagate / controller / joint) redundantly and takes the joint Gaussian from its own LDS;

@@ -176,6 +176,23 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
     return PILCO_OK;
 }
 
+// The peer exchange carries a rollout when it is attached, the model is sharded, the policy is not an RbfController
+// (its GP is not sharded) and the segments fit the exchange slots; otherwise the RCCL / group path runs.
+static bool peer_rollout_applies(pilco_ctx* ctx, const RolloutPlan& plan, int H) {
+    const Slot& s = ctx->slot[0];
+    return ctx->xq.ready && ctx->nranks > 1 && ctx->xq.W == ctx->nranks && H > 0 && plan.g.pol_kind != PILCO_POLICY_RBF &&
+           s.wk.SEG <= ctx->xq.cap && !plan.g.tape;
+}
+// Host side of a rollout's exchanges: the epoch base goes up before the rollout's launches (outside any graph: the
+// value changes per replay), `n` exchanges are accounted for afterwards.
+static int xq_begin(pilco_ctx* ctx) {
+    PeerXch& x = ctx->xq;
+    unsigned long long* slot = x.pin + (x.ring++ & 127u);   // a ring: rollouts may be queued without a host sync in between
+    *slot = x.epoch;
+    HIPCHK(hipMemcpyAsync(x.local, slot, sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->st));
+    return PILCO_OK;
+}
+
 // enqueue one full rollout on the stream (initial state already in plan.st[0]); the final
 // state ends up in plan.st[H & 1].  The reward of state t (pilco.py:133) is evaluated by the
 // second workgroup of the glue launch that turns state t into state t+1.
@@ -240,6 +257,86 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
     }
     Slot& ps = ctx->slot[PILCO_SLOT_POLICY];
     const MMModel pmd = rbf ? model_of(ps) : MMModel{};
+    if (peer_rollout_applies(ctx, plan, H)) {
+        // Sharded rollout with the peer exchange (GlueArgs::xq): per step
+        //   head  [wait for the W flags of exchange h - 1, segments from the own area -> assemble / propagate / controller
+        //          / joint, redundantly in every workgroup | operands of step h]        (ranks without pairs: a plain k_glue)
+        //   pairs of this rank
+        //   push  [pack this rank's segment, store it into every rank's area, raise the flag there]   (one workgroup)
+        // No host involvement and no collective launch per step; the state and s1 alternate between two buffers as in the
+        // single-rank fused path.  The reward of state h is taken by head h (k_glue launches: by the launch that
+        // propagates state h, from its pre-propagation copy), i.e. in the same order on every rank.
+        PeerXch& x = ctx->xq;
+        {   // executed now (not being captured into a graph): this rollout's epoch base goes up ahead of its launches
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            HIPCHK(hipStreamIsCapturing(ctx->st, &cs));
+            if (cs == hipStreamCaptureStatusNone) {
+                if (int r = xq_begin(ctx)) return r;
+                x.epoch += (unsigned long long)H;
+            }
+        }
+        const int spin = 2000000;   // ~2 s of polling before a wait gives up
+        auto with_xq = [&](GlueArgs& ga, int k) {
+            ga.xq = x.local;
+            ga.xq_k = k;
+            ga.xq_W = x.W;
+            ga.xq_cap = x.cap;
+            ga.xq_spin = x.wait_kernel ? 1000 : spin;   // behind a wait launch the flags are already up
+        };
+        PrepReward pr{};
+        if (rew) {
+            pr.n = g.n_rewards;
+            pr.E = E;
+            for (int i = 0; i < g.n_rewards; ++i) pr.rw[i] = g.rw[i];
+            pr.reward = g.reward;
+        }
+        size_t evi = 0;
+        for (int h = 0; h < H; ++h) {
+            GlueArgs gh = g;
+            gh.step = h;
+            gh.wk = s.wk;
+            gh.flags = GF_TRAJ | GF_POLICY | (h > 0 ? (GF_ASSEMBLE | GF_PROPAGATE) : 0);
+            gh.m_x = plan.st[h > 0 ? (h - 1) & 1 : 0];
+            gh.s_x = gh.m_x + E;
+            gh.m_out = h > 0 ? plan.st[h & 1] : nullptr;
+            gh.s_out = h > 0 ? plan.st[h & 1] + E : nullptr;
+            gh.s1 = plan.s1b[(h + 1) & 1];
+            gh.s1_out = plan.s1b[h & 1];
+            if (h > 0) {
+                with_xq(gh, h - 1);
+                if (x.wait_kernel) launch_peer_wait(ctx->st, x.local, h - 1, x.W, spin);
+            }
+            if (s.wk.PL > 0) {
+                launch_mm_prep(ctx->st, md, s.wk, rew ? &pr : nullptr, &gh);
+                if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
+                launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
+                if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
+            } else {
+                launch_glue(ctx->st, gh, rew && h > 0);   // its reward workgroup takes the pre-propagation state h - 1
+            }
+            GlueArgs gp = g;
+            gp.step = h + 1;
+            gp.wk = s.wk;
+            gp.flags = GF_PACK;
+            with_xq(gp, h);
+            gp.xq_peers = x.d_peers;
+            launch_glue(ctx->st, gp);
+        }
+        GlueArgs gf = g;
+        gf.step = H;
+        gf.wk = s.wk;
+        gf.flags = GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ;
+        gf.m_x = plan.st[(H - 1) & 1];
+        gf.s_x = gf.m_x + E;
+        gf.m_out = plan.st[H & 1];
+        gf.s_out = gf.m_out + E;
+        gf.s1 = plan.s1b[(H - 1) & 1];
+        gf.s1_out = nullptr;
+        with_xq(gf, H - 1);
+        if (x.wait_kernel) launch_peer_wait(ctx->st, x.local, H - 1, x.W, spin);
+        launch_glue(ctx->st, gf, rew && s.wk.PL == 0);
+        return PILCO_OK;
+    }
     if (ctx->fused && rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && ps.wk.PL > 0 && H > 0) {
         // Fused heads with an RbfController (controllers.py:108-121): the policy is a moment-matching GP of its own, so a
         // step is two head + pair rounds and the serial link splits in two:
@@ -354,7 +451,8 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
     Slot& s = ctx->slot[0];
     // With a communicator the captured graph contains the ncclAllGather nodes (RCCL supports stream
     // capture); if capture or instantiation fails the rollout falls back to eager launches for good.
-    const bool sharded = (ctx->nranks != 1 || ctx->comm);
+    const bool peer = peer_rollout_applies(ctx, plan, H);   // no collective nodes: captured like a single-rank rollout
+    const bool sharded = (ctx->nranks != 1 || ctx->comm) && !peer;
     if (!ctx->use_graph || (sharded && (!ctx->comm || ctx->graph_rccl_failed)) || (ctx->dbg && !getenv("PILCO_DBG_GRAPH")))
         return enqueue_rollout(ctx, plan, H, nullptr);
     const GlueArgs& g = plan.g;
@@ -372,7 +470,8 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
         (unsigned long long)(uintptr_t)ctx->slot[1].beta.p, (unsigned long long)(uintptr_t)ctx->slot[1].Xt.p,
         (unsigned long long)ctx->slot[1].n,
         (unsigned long long)ctx->slot[1].wk.sk_waves, (unsigned long long)(uintptr_t)ctx->slot[1].w_small.p,
-        (unsigned long long)(uintptr_t)ctx->slot[1].w_in.p, (unsigned long long)(uintptr_t)ctx->slot[1].ls.p};
+        (unsigned long long)(uintptr_t)ctx->slot[1].w_in.p, (unsigned long long)(uintptr_t)ctx->slot[1].ls.p,
+        (unsigned long long)(peer ? 1 : 0), (unsigned long long)(uintptr_t)ctx->xq.local, (unsigned long long)ctx->nranks, (unsigned long long)ctx->rank};
     for (int i = 0; i < g.n_rewards; ++i) {
         key.push_back((unsigned long long)g.rw[i].kind);
         key.push_back((unsigned long long)(long long)g.rw[i].rank);
@@ -387,6 +486,10 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
             if (i != 0) std::swap(ctx->graph_cache[i], ctx->graph_cache[0]);   // most recently used first
             ctx->graph = ctx->graph_cache[0].second;
             ctx->graph_key = key;
+            if (peer) {
+                if (int r = xq_begin(ctx)) return r;
+                ctx->xq.epoch += (unsigned long long)H;
+            }
             HIPCHK(hipGraphLaunch(ctx->graph, ctx->st));
             return PILCO_OK;
         }
@@ -396,7 +499,8 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
             (void)hipGraphExecDestroy(ctx->graph_cache.back().second);
             ctx->graph_cache.pop_back();
         }
-        // warm the per-kernel one-time host configuration outside the capture
+        // warm the per-kernel one-time host configuration outside the capture (a one-step rollout: with the peer
+        // exchange attached every rank runs it, so it is a complete exchange of its own epoch)
         if (int r = enqueue_rollout(ctx, plan, H > 0 ? 1 : 0, nullptr)) return r;
         HIPCHK(hipStreamSynchronize(ctx->st));
         hipGraph_t graph = nullptr;
@@ -474,8 +578,16 @@ int pilco_rollout(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     HIPCHK(hipMemcpyAsync(pin_out + nst, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
     if (traj)
         HIPCHK(hipMemcpyAsync(traj, ctx->traj.p, sizeof(double) * (size_t)(H + 1) * (E + E * E), hipMemcpyDeviceToHost, ctx->st));
+    const bool peer = peer_rollout_applies(ctx, plan, H);
+    if (peer) HIPCHK(hipMemcpyAsync(ctx->xq.pin + 128, ctx->xq.local + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());
+    if (peer && ctx->xq.pin[128] != 0ULL) {   // a flag wait gave up: some rank never delivered that exchange
+        const unsigned long long ep = ctx->xq.pin[128];
+        (void)hipMemsetAsync(ctx->xq.local + 1, 0, sizeof(unsigned long long), ctx->st);
+        return fail(ctx, PILCO_E_STATE, "rollout: peer exchange " + std::to_string(ep) + " timed out on rank " + std::to_string(ctx->rank) +
+                                            " (the ranks must make the same sequence of rollout calls)");
+    }
     memcpy(mH, pin_out, sizeof(double) * E);
     memcpy(SH, pin_out + E, sizeof(double) * E * E);
     *reward = pin_out[nst];

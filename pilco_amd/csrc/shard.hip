@@ -3,6 +3,72 @@
 
 #include <thread>
 
+namespace pilco {
+// The flag wait as a launch of its own (ranks sharing a GPU): one workgroup, thread r watches rank r's flag.
+__global__ void k_peer_wait(unsigned long long* area, int k, int W, int spin) {
+    const int t = threadIdx.x;
+    if (t >= W) return;
+    const unsigned long long epoch = __hip_atomic_load(area, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + (unsigned long long)k + 1ULL;
+    const unsigned long long* flag = area + 8 + (int)(epoch & 1ULL) * W + t;
+    int it = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+        if (++it > spin) {
+            __hip_atomic_store(area + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+}  // namespace pilco
+void launch_peer_wait(hipStream_t st, unsigned long long* area, int k, int W, int spin) {
+    hipLaunchKernelGGL(pilco::k_peer_wait, dim3(1), dim3(64), 0, st, area, k, W, spin);
+}
+
+// ------------------------------------------------------------------ peer exchange (include/pilco_hip.h)
+static int peer_alloc_local(pilco_ctx* ctx) {
+    PeerXch& x = ctx->xq;
+    if (x.local && x.W == ctx->nranks) return PILCO_OK;
+    if (int r = peer_detach(ctx)) return r;
+    if (ctx->nranks < 2) return fail(ctx, PILCO_E_STATE, "peer exchange: shard_set(rank, nranks >= 2) first");
+    HIPCHK(hipSetDevice(ctx->device));
+    x.W = ctx->nranks;
+    x.cap = 4096;
+    const size_t bytes = sizeof(unsigned long long) * xq_area_words(x.W, x.cap);
+    HIPCHK(hipExtMallocWithFlags((void**)&x.local, bytes, hipDeviceMallocFinegrained));
+    HIPCHK(hipMemset(x.local, 0, bytes));
+    HIPCHK(hipHostMalloc((void**)&x.pin, sizeof(unsigned long long) * 256, hipHostMallocDefault));
+    memset(x.pin, 0, sizeof(unsigned long long) * 256);
+    x.epoch = 0;
+    x.ring = 0;
+    return PILCO_OK;
+}
+static int peer_finish_attach(pilco_ctx* ctx, bool share_gpu) {
+    PeerXch& x = ctx->xq;
+    HIPCHK(hipMalloc((void**)&x.d_peers, sizeof(unsigned long long*) * x.W));
+    HIPCHK(hipMemcpy(x.d_peers, x.mapped.data(), sizeof(unsigned long long*) * x.W, hipMemcpyHostToDevice));
+    x.wait_kernel = share_gpu;
+    x.ready = true;
+    for (Slot& s : ctx->slot) s.wk_valid = false;
+    return PILCO_OK;
+}
+int peer_detach(pilco_ctx* ctx) {
+    PeerXch& x = ctx->xq;
+    if (!x.local && x.mapped.empty()) return PILCO_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->st);
+    for (size_t j = 0; j < x.mapped.size(); ++j)
+        if (j < x.opened.size() && x.opened[j] && x.mapped[j]) (void)hipIpcCloseMemHandle(x.mapped[j]);
+    if (x.d_peers) (void)hipFree(x.d_peers);
+    if (x.local) (void)hipFree(x.local);
+    if (x.pin) (void)hipHostFree(x.pin);
+    // graphs captured with the exchange baked in must not be replayed
+    for (auto& ge : ctx->graph_cache) (void)hipGraphExecDestroy(ge.second);
+    ctx->graph_cache.clear();
+    ctx->graph = nullptr;
+    x = PeerXch{};
+    return PILCO_OK;
+}
+
 extern "C" {
 
 // ------------------------------------------------------------------ multi-GPU
@@ -18,6 +84,7 @@ int pilco_comm_unique_id(void* id128) {
 
 int pilco_shard_set(pilco_ctx* ctx, int rank, int nranks) {
     if (!ctx || nranks <= 0 || rank < 0 || rank >= nranks) return fail(ctx, PILCO_E_SHAPE, "shard_set: bad rank / nranks");
+    if (ctx->rank != rank || ctx->nranks != nranks) (void)peer_detach(ctx);
     if (ctx->rank != rank || ctx->nranks != nranks)
         for (Slot& s : ctx->slot) s.factor_valid = false;   // each rank factorises only the outputs it owns: the layout changed
     ctx->rank = rank;
@@ -217,6 +284,86 @@ int pilco_rollout_group(pilco_ctx** ctxs, int n, const pilco_policy* policy, con
     if (traj) memcpy(traj, otr[0].data(), sizeof(double) * nt);
     return PILCO_OK;
 }
+
+// ------------------------------------------------------------------ peer exchange (include/pilco_hip.h)
+int pilco_peer_export(pilco_ctx* ctx, void* handle64) {
+    if (!ctx || !handle64) return PILCO_E_SHAPE;
+    static_assert(sizeof(hipIpcMemHandle_t) <= PILCO_PEER_HANDLE_BYTES, "hipIpcMemHandle_t larger than the ABI slot");
+    if (int r = peer_alloc_local(ctx)) return r;
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, ctx->xq.local));
+    memset(handle64, 0, PILCO_PEER_HANDLE_BYTES);
+    memcpy(handle64, &h, sizeof(h));
+    return PILCO_OK;
+}
+
+int pilco_peer_attach(pilco_ctx* ctx, const void* handles, int share_gpu) {
+    if (!ctx || !handles) return PILCO_E_SHAPE;
+    PeerXch& x = ctx->xq;
+    if (!x.local || x.W != ctx->nranks) return fail(ctx, PILCO_E_STATE, "peer_attach: pilco_peer_export first");
+    if (x.ready) return PILCO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    x.mapped.assign(x.W, nullptr);
+    x.opened.assign(x.W, 0);
+    for (int j = 0; j < x.W; ++j) {
+        if (j == ctx->rank) {
+            x.mapped[j] = x.local;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char*)handles + (size_t)j * PILCO_PEER_HANDLE_BYTES, sizeof(h));
+        void* q = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            const std::string msg = std::string("peer_attach: hipIpcOpenMemHandle(rank ") + std::to_string(j) + "): " + hipGetErrorString(e);
+            (void)peer_detach(ctx);
+            return fail(ctx, PILCO_E_HIP, msg);
+        }
+        x.mapped[j] = (unsigned long long*)q;
+        x.opened[j] = 1;
+    }
+    return peer_finish_attach(ctx, share_gpu != 0);
+}
+
+int pilco_group_peer_attach(pilco_ctx** ctxs, int n) {
+    if (!ctxs || n < 2 || !ctxs[0]) return PILCO_E_SHAPE;
+    pilco_ctx* c0 = ctxs[0];
+    bool share = false;
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || ctxs[i]->nranks != n || ctxs[i]->rank != i) return fail(c0, PILCO_E_STATE, "group_peer_attach: context i must be shard_set(i, n)");
+        for (int j = 0; j < i; ++j) share = share || ctxs[j]->device == ctxs[i]->device;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (int r = peer_detach(ctxs[i])) return r;
+        if (int r = peer_alloc_local(ctxs[i])) {
+            if (i) c0->err = ctxs[i]->err;
+            return r;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        pilco_ctx* ctx = ctxs[i];
+        HIPCHK(hipSetDevice(ctx->device));
+        ctx->xq.mapped.assign(n, nullptr);
+        ctx->xq.opened.assign(n, 0);
+        for (int j = 0; j < n; ++j) {
+            ctx->xq.mapped[j] = ctxs[j]->xq.local;
+            if (ctxs[j]->device != ctx->device) {
+                hipError_t e = hipDeviceEnablePeerAccess(ctxs[j]->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(c0, PILCO_E_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+        }
+        if (int r = peer_finish_attach(ctx, share)) {
+            if (i) c0->err = ctx->err;
+            return r;
+        }
+    }
+    return PILCO_OK;
+}
+
+int pilco_peer_detach(pilco_ctx* ctx) { return ctx ? peer_detach(ctx) : PILCO_E_SHAPE; }
+int pilco_peer_attached(const pilco_ctx* ctx) { return (ctx && ctx->xq.ready) ? 1 : 0; }
 
 int pilco_comm_rank(const pilco_ctx* ctx) { return ctx ? ctx->rank : -1; }
 int pilco_comm_size(const pilco_ctx* ctx) { return ctx ? ctx->nranks : -1; }

@@ -605,6 +605,27 @@ def test_sharded_rollout_group_of_contexts(E, U, nranks, sparse):
                 np.testing.assert_allclose(R, R1, rtol=1e-12)
             M2, S2, R2, mm2 = _lib.rollout_group(group, pol, rw, m0, S0, H)     # and it is repeatable
             assert mm2 == 0 and np.array_equal(M2, M) and np.array_equal(S2, S) and np.array_equal(R2, R)
+            if nranks > 1:
+                # the same rollout with the PEER EXCHANGE: every rank stores its segment straight into the other ranks'
+                # exchange areas and raises a flag, the next head waits on the flags -- no host barrier, no collective,
+                # the whole sharded rollout one hipGraph per rank.  Bit-identical to the host-mediated run; repeated
+                # (graph replay), with another horizon (epochs carry over between rollouts) and eagerly.
+                _lib.group_peer_attach(group)
+                assert all(cx.peer_attached() for cx in group)
+                for rep in range(3):
+                    Mp, Sp, Rp, Tp, mmp = _lib.rollout_group(group, pol, rw, m0, S0, H, want_traj=True)
+                    assert mmp == 0 and np.array_equal(Mp, M) and np.array_equal(Sp, S) and np.array_equal(Rp, R) and np.array_equal(Tp, T)
+                Mq, Sq, Rq, Tq, mmq = _lib.rollout_group(group, pol, rw, m0, S0, 3, want_traj=True)
+                assert mmq == 0 and np.array_equal(Tq, T[:4])
+                for cx in group:
+                    cx.use_graph(False)
+                Mp, Sp, Rp, Tp, mmp = _lib.rollout_group(group, pol, rw, m0, S0, H, want_traj=True)
+                assert mmp == 0 and np.array_equal(Tp, T) and np.array_equal(Rp, R)
+                for cx in group:
+                    cx.use_graph(True)
+                    cx.peer_detach()
+                M3, S3, R3, mm3 = _lib.rollout_group(group, pol, rw, m0, S0, H)   # detached: the host-mediated path again
+                assert mm3 == 0 and np.array_equal(M3, M) and np.array_equal(R3, R)
         model = tp.Model(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"], Z=Zs if sparse else None)
         ctl = (lambda mm, ss: tp.linear_controller(mm, ss, c["W"], c["b"], 1.5)) if U else tp.no_controller
         Mo, So, Ro = tp.predict(model, ctl, tp.exponential_reward, m0, S0, H, cache=True)
