@@ -225,6 +225,12 @@ int pilco_gp_shard_finish(pilco_ctx* ctx, int slot, const double* gathered, doub
  * rows: one ncclAllGather per MODEL when a communicator is attached, or -- contexts of one process -- this call, after
  * all of them have factorised. */
 int pilco_group_sync_model(pilco_ctx** ctxs, int n, int slot);
+/* The same beta exchange over any host transport (ranks in different processes, no communicator): pilco_gp_beta_rows
+ * gives the block shape (elcap = ceil(E / nranks) rows of npad doubles per rank), every rank exports the rows it
+ * computed, the caller all-gathers the blocks in rank order, every rank imports [nranks][elcap][npad]. */
+int pilco_gp_beta_rows(pilco_ctx* ctx, int slot, int* elcap, int* npad);
+int pilco_gp_beta_export(pilco_ctx* ctx, int slot, double* own_rows);
+int pilco_gp_beta_import(pilco_ctx* ctx, int slot, const double* all_rows);
 /* The whole sharded rollout over n contexts of ONE process (context i = rank i of n; several contexts may share a GPU):
  * every context runs pilco_rollout on its own host thread and the per-step exchange is done with peer copies between
  * host barriers instead of ncclAllGather -- the same launch sequence as the RCCL path, so the multi-rank rollout can be

@@ -105,6 +105,9 @@ SIGNATURES = {
     "pilco_rollout_group": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp,
                             C.c_int, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     "pilco_group_sync_model": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int]),
+    "pilco_gp_beta_rows": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pilco_gp_beta_export": (C.c_int, [_vp, C.c_int, _dp]),
+    "pilco_gp_beta_import": (C.c_int, [_vp, C.c_int, _dp]),
     "pilco_comm_rank": (C.c_int, [_vp]),
     "pilco_comm_size": (C.c_int, [_vp]),
 }
@@ -461,6 +464,19 @@ class Context:
 
     def shard_set(self, rank, nranks):
         self._chk(self.lib.pilco_shard_set(self.h, int(rank), int(nranks)))
+
+    # beta rows of a sharded factorisation over any host transport (ranks in different processes, no communicator)
+    def beta_export(self, slot=0):
+        el, npad = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.pilco_gp_beta_rows(self.h, slot, C.byref(el), C.byref(npad)))
+        rows = np.zeros((el.value, npad.value))
+        self._chk(self.lib.pilco_gp_beta_export(self.h, slot, _ptr(rows)))
+        return rows
+
+    def beta_import(self, all_rows, slot=0):
+        """all_rows: the exported blocks of all ranks in rank order, (nranks, elcap, npad)."""
+        all_rows = np.ascontiguousarray(all_rows, dtype=np.float64)
+        self._chk(self.lib.pilco_gp_beta_import(self.h, slot, _ptr(all_rows)))
 
     # peer exchange (include/pilco_hip.h): the per-step all-gather as direct stores into the other ranks' memory
     def peer_export(self):

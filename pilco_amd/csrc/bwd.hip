@@ -40,6 +40,7 @@ __device__ __forceinline__ double sum_strided(const double* __restrict__ base, l
 //   output a (h = a):      T = (s + Lambda_a^2)^-1 | u = T Vbar_a | mu = Mbar_a - sum_b (Sbar_ab + Sbar_ba) M_b | c_a
 //   pair pl (h = E + pl):  P = (I + Lambda_ab s)^-1 | lambda_ab | kappa = Shat_ab / sqrt(det R_ab) | 0
 // M_b comes from the mean partials the prep kernel of the same step left in wk.mean_part.
+// bars == nullptr (Jacobian tape, below): no cotangents -- u = 0, mu = 0 and kappa = 1 / sqrt(det R_ab).
 __device__ void bwd_head(const MMModel& md, const MMWork& wk, const double* __restrict__ bars, int h,
                          double* __restrict__ head, double* sm) {
     const int D = md.D, E = md.E, t = threadIdx.x, nc = 2 * D, nI = D * D;
@@ -71,12 +72,13 @@ __device__ void bwd_head(const MMModel& md, const MMWork& wk, const double* __re
     if (h < E) {
         if (t < D) {
             double acc = 0.0;
-            for (int c = 0; c < D; ++c) acc = fma(G[t * nc + D + c], Vbar[c * E + a], acc);
+            if (bars)
+                for (int c = 0; c < D; ++c) acc = fma(G[t * nc + D + c], Vbar[c * E + a], acc);
             o[nI + t] = acc;
         }
         if (t == 64) {
-            double mu = Mbar[a];
-            for (int bb = 0; bb < E; ++bb) {
+            double mu = bars ? Mbar[a] : 0.0;
+            for (int bb = 0; bars && bb < E; ++bb) {
                 double Mb = 0.0;
                 for (int ch = 0; ch < wk.NCHM; ++ch) Mb += wk.mean_part[((long)bb * wk.NCHM + ch) * (1 + D)];
                 mu -= (Sbar[a * E + bb] + Sbar[bb * E + a]) * Mb;
@@ -89,7 +91,7 @@ __device__ void bwd_head(const MMModel& md, const MMWork& wk, const double* __re
     } else {
         if (t < D) o[nI + t] = lam[t];
         if (t == 64) {
-            const double shat = (a == b) ? Sbar[a * E + a] : Sbar[a * E + b] + Sbar[b * E + a];
+            const double shat = !bars ? 1.0 : (a == b) ? Sbar[a * E + a] : Sbar[a * E + b] + Sbar[b * E + a];
             o[nI + D] = shat / sqrt(det);   // det(I + Lambda s) = det(s Lambda + I) = det R_ab
             o[nI + D + 1] = 0.0;
         }
@@ -321,6 +323,88 @@ __device__ void bwd_mean_partial(const MMModel& md, const MMWork& wk, const doub
     if (t <= nI + 2 * D) mpart[((long)a * nrc + rc) * (nI + 2 * D + 1) + t] = acc;
 }
 
+// ---- Jacobian tape (cotangent-free form of the same reverse pass)
+// Everything above that costs O(N^2) or O(N D^2) is independent of the cotangents: the pair sums (N, A, I) are, and the
+// mean part depends on (mu, u) only through q_i = mu + zeta_i . u, i.e. through the moments of l_i up to third order.  A
+// forward rollout that runs the reverse sweep INSTEAD of the forward pair kernel therefore gets the value (N_ab) and the
+// complete Jacobian of the step's outputs with respect to (m, s) from one O(N^2) pass; the reverse sweep of the policy
+// gradient is then a chain of small contractions with no device work at all (csrc/grad.hip).
+// Moments with the point extended by a one, zeta~ = (zeta | 1): H(d, e, f) = sum_i l_i zeta~_d zeta~_e zeta~_f for
+// d >= e >= f -- g = H(D,D,D), h_d = H(D,D,d), H2_de = H(D,d,e), H3_def.  mpart[a][rc][NS], NS = (D+1)(D+2)(D+3)/6.
+__host__ __device__ inline int tri3(int d, int e, int f) { return d * (d + 1) * (d + 2) / 6 + e * (e + 1) / 2 + f; }   // d >= e >= f
+__device__ __forceinline__ int tri3_any(int a, int b, int c) {
+    const int hi = max(a, max(b, c)), lo = min(a, min(b, c));
+    return tri3(hi, a + b + c - hi - lo, lo);
+}
+int mm_jac_ns(int D) { return (D + 1) * (D + 2) * (D + 3) / 6; }
+constexpr int JAC_MAXA = 4;   // moment sums per thread: NS <= 4 * 256 (D <= 16)
+__device__ void bwd_mean_moments(const MMModel& md, const MMWork& wk, const double* __restrict__ head, int a, int rc,
+                                 int nrc, double* __restrict__ mpart, double* sm) {
+    const int D = md.D, D1 = D + 1, npad = md.npad, t = threadIdx.x;
+    const int nI = D * D, LD = D1 | 1, NS = D1 * (D1 + 1) * (D1 + 2) / 6;
+    double* T = sm;                 // [D][D]
+    double* zs = T + nI;            // [64][LD]   zeta | 1
+    double* lv = zs + 64 * LD;      // [64]
+    int* tri = (int*)(lv + 64);     // [NS] packed index triples
+    const double* hd = head + (long)a * (nI + D + 2);
+    for (int e = t; e < nI; e += 256) T[e] = hd[e];
+    if (t < D1) {
+        int off = t * (t + 1) * (t + 2) / 6;
+        for (int e = 0; e <= t; ++e)
+            for (int f = 0; f <= e; ++f) tri[off++] = t | (e << 8) | (f << 16);
+    }
+    __syncthreads();
+    int pk[JAC_MAXA];
+    double acc[JAC_MAXA];
+#pragma unroll
+    for (int k = 0; k < JAC_MAXA; ++k) {
+        const int idx = t + 256 * k;
+        pk[k] = idx < NS ? tri[idx] : -1;
+        acc[k] = 0.0;
+    }
+    for (int blk = rc; blk < npad / 64; blk += nrc) {
+        if (t < 64) {
+            const int i = blk * 64 + t;
+            double l = 0.0;
+            if (i < md.n) {
+                double quad = 0.0;
+                {
+                    double pv[16];
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) pv[d] = (d < D) ? md.Pt[(long)d * npad + i] : 0.0;
+#pragma unroll
+                    for (int d = 0; d < 16; ++d)
+                        if (d < D) zs[t * LD + d] = pv[d] - wk.in_m[d];
+                }
+                for (int r = 0; r < D; ++r) {
+                    double tz = 0.0;
+                    for (int c = 0; c < D; ++c) tz = fma(T[r * D + c], zs[t * LD + c], tz);
+                    quad = fma(zs[t * LD + r], tz, quad);
+                }
+                l = exp(-0.5 * quad) * md.beta[mm_beta_row(md, a) * npad + i];
+            } else {
+                for (int d = 0; d < D; ++d) zs[t * LD + d] = 0.0;
+            }
+            zs[t * LD + D] = 1.0;
+            lv[t] = l;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < JAC_MAXA; ++k)
+            if (pk[k] >= 0) {
+                const int d = pk[k] & 255, e = (pk[k] >> 8) & 255, f = pk[k] >> 16;
+                double a2 = acc[k];
+                _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii)
+                    a2 = fma(lv[ii] * zs[ii * LD + d], zs[ii * LD + e] * zs[ii * LD + f], a2);
+                acc[k] = a2;
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < JAC_MAXA; ++k)
+        if (pk[k] >= 0) mpart[((long)a * nrc + rc) * NS + t + 256 * k] = acc[k];
+}
+
 // stage 2 (a workgroup of k_mm_bwd_fin): out[a][D + D*D]
 __device__ void bwd_mean_final(const MMModel& md, const double* __restrict__ bars, const double* __restrict__ head, int a,
                                int nrc, const double* __restrict__ mpart, double* __restrict__ out, double* sm) {
@@ -385,12 +469,13 @@ constexpr int BWD_RC = 16;  // row chunks per pair / output
 __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, const double* __restrict__ rowmom,
                                                     const double* __restrict__ cpart, int njs, int nrb,
                                                     double* __restrict__ part, int nrc,
-                                                    const double* __restrict__ head, double* __restrict__ mpart) {
+                                                    const double* __restrict__ head, double* __restrict__ mpart, int jac) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int npad = md.npad, D = md.D, E = md.E, t = threadIdx.x;
     const int pl = blockIdx.x, rc = blockIdx.y;
     if (pl >= wk.PL) {   // the last E workgroup columns: mean part of output pl - PL
-        bwd_mean_partial(md, wk, head, pl - wk.PL, rc, nrc, mpart, sm);
+        if (jac) bwd_mean_moments(md, wk, head, pl - wk.PL, rc, nrc, mpart, sm);
+        else bwd_mean_partial(md, wk, head, pl - wk.PL, rc, nrc, mpart, sm);
         return;
     }
     int a, b;
@@ -574,7 +659,7 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
     double* mpart = part + (size_t)P * nrc * (1 + D + nI);
     const size_t lds_post = sizeof(double) * std::max((size_t)3 * 64 * LD + 128 + 3 * D, (size_t)nI + 64 * LD + 128 + D + 2);
     hipLaunchKernelGGL(k_mm_bwd_post, dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
-                       head, mpart);
+                       head, mpart, 0);
     const size_t lds_fin = sizeof(double) * ((size_t)3 * nI + 4 * D + 8);
     hipLaunchKernelGGL(k_mm_bwd_fin, dim3(P + E), dim3(256), lds_fin, st, md, wk, part, nrc, bars, head, mpart, out, done, sum_out);
 }

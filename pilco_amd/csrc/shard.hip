@@ -236,6 +236,44 @@ int pilco_group_sync_model(pilco_ctx** ctxs, int n, int slot) {
     return PILCO_OK;
 }
 
+// The same exchange over any host transport (ranks in different processes without a communicator): every rank exports
+// the beta rows it computed ([ELcap][npad] doubles, ELcap = ceil(E / nranks), npad = pilco_gp_beta_rows's second result),
+// the caller all-gathers them in rank order and every rank imports the [nranks][ELcap][npad] block.
+int pilco_gp_beta_rows(pilco_ctx* ctx, int slot, int* elcap, int* npad) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "beta_rows: no current factorisation");
+    if (elcap) *elcap = s.shW > 1 ? s.shEL : s.E;
+    if (npad) *npad = s.npad;
+    return PILCO_OK;
+}
+int pilco_gp_beta_export(pilco_ctx* ctx, int slot, double* own_rows) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!own_rows) return fail(ctx, PILCO_E_SHAPE, "beta_export: null pointer");
+    if (!s.factor_valid || s.shW != ctx->nranks || s.shRank != ctx->rank) return fail(ctx, PILCO_E_STATE, "beta_export: factorise under the current shard layout first");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t blk = (size_t)(s.shW > 1 ? s.shEL : s.E) * s.npad;
+    HIPCHK(hipMemcpyAsync(own_rows, s.beta.p + (size_t)(s.shW > 1 ? s.shRank : 0) * blk, sizeof(double) * blk, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    return PILCO_OK;
+}
+int pilco_gp_beta_import(pilco_ctx* ctx, int slot, const double* all_rows) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!all_rows) return fail(ctx, PILCO_E_SHAPE, "beta_import: null pointer");
+    if (!s.factor_valid || s.shW != ctx->nranks || s.shRank != ctx->rank) return fail(ctx, PILCO_E_STATE, "beta_import: factorise under the current shard layout first");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t blk = (size_t)(s.shW > 1 ? s.shEL : s.E) * s.npad;
+    for (int j = 0; j < s.shW; ++j) {
+        if (j == s.shRank) continue;   // the own rows stay as computed
+        HIPCHK(hipMemcpyAsync(s.beta.p + (size_t)j * blk, all_rows + (size_t)j * blk, sizeof(double) * blk, hipMemcpyHostToDevice, ctx->st));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    s.beta_complete = true;
+    return PILCO_OK;
+}
+
 // One sharded rollout over n contexts of THIS process (rank i = ctxs[i], any devices): every context runs its own
 // pilco_rollout on a host thread; the per-step exchange is done by peer copies between host barriers.  It drives exactly
 // the launch sequence the RCCL path runs (PACK launch, exchange, tail launch) with the collective swapped for copies,

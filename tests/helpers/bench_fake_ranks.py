@@ -33,6 +33,26 @@ class FakeContext:
         self.rank, self.nranks = rank, nranks
         FakeContext.calls.append(("comm_init", rank, nranks))
 
+    # peer exchange: FAKE_PEER=ok attaches on every rank; FAKE_PEER=rank1_fails lets rank 1's attach fail (then every
+    # rank must detach and stay on the RCCL path); FAKE_PEER=first_rollout_fails lets rank 1's first rollout time out
+    attached = False
+
+    def peer_export(self):
+        return bytes([self.rank]) * 64
+
+    def peer_attach(self, handles, share_gpu=False):
+        assert [h[0] for h in handles] == list(range(self.nranks)), "handles must arrive in rank order"
+        if os.environ.get("FAKE_PEER") == "rank1_fails" and self.rank == 1:
+            raise _lib.PilcoError(3, "hipIpcOpenMemHandle: stand-in failure")
+        self.attached = True
+
+    def peer_detach(self):
+        self.attached = False
+        FakeContext.calls.append(("peer_detach", self.rank))
+
+    def peer_attached(self):
+        return self.attached
+
     def gp_set_data(self, slot, X, Y):
         assert X.shape == (1000, 10) and Y.shape == (1000, 10)
 
@@ -46,6 +66,8 @@ class FakeContext:
         FakeContext.calls.append(("factorize", self.rank, self.nranks))
 
     def rollout(self, policy, rewards, m0, S0, H, want_traj=False):
+        if self.attached and os.environ.get("FAKE_PEER") == "first_rollout_fails" and self.rank == 1:
+            raise _lib.PilcoError(5, "rollout: peer exchange 1 timed out on rank 1 (stand-in)")
         time.sleep(0.002 * (1 + self.rank))            # ranks differ: the reported time must be the slowest one's
         return G["M_traj"][:, -1][None, :].copy(), G["S_traj"][:, :, -1].copy(), np.array([[G["R_traj"][-1]]])
 

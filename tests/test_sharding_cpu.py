@@ -174,11 +174,13 @@ def test_stream_k_closed_forms_match_enumeration():
             assert fslot == (1 if bnd[wlo] < S0 else 0)   # a wave that starts before the pair holds it in its second slot
 
 
-def test_bench_multi_rank_host_logic_under_torchrun():
+@pytest.mark.parametrize("peer", ["ok", "rank1_fails", "first_rollout_fails"])
+def test_bench_multi_rank_host_logic_under_torchrun(peer):
     """bench.py --gpus 2 exactly as the driver launches it (python -m torch.distributed.run, one process per rank), with
     the device replaced by a stand-in Context (tests/helpers/bench_fake_ranks.py): rendezvous over gloo on 127.0.0.1,
     broadcast of rank 0's RCCL id, barriers, MAX-over-ranks timing, the replica leg, verification against the fixture and
-    ONE JSON line from rank 0 with the contract's keys."""
+    ONE JSON line from rank 0 with the contract's keys.  The per-step exchange: peer exchange when every rank attaches and
+    the first rollout over it succeeds, otherwise every rank detaches and the RCCL path is timed."""
     import json
     import subprocess
     with socket.socket() as sk:
@@ -187,7 +189,7 @@ def test_bench_multi_rank_host_logic_under_torchrun():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "helpers", "bench_fake_ranks.py"),
            "--gpus", "2", "--steps", "3", "--warmup", "1"]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", FAKE_PEER=peer)
     pr = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
     assert pr.returncode == 0, pr.stderr[-2000:]
     lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
@@ -201,3 +203,4 @@ def test_bench_multi_rank_host_logic_under_torchrun():
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-9
     assert d["verified"]["max_rel_err"]["S_H"] == 0.0
     assert "replica_rollouts_per_s" in d["secondary"] and "cpu_baseline" not in d
+    assert ("peer stores" in d["config"]["exchange"]) == (peer == "ok"), d["config"]["exchange"]
