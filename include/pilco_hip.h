@@ -53,6 +53,11 @@ int pilco_set_pair_kernel(pilco_ctx* ctx, int variant);
  * workgroup of step t+1's operand kernel, two launches per horizon step.  0: separate link kernel, three launches per
  * step (always used with more than one rank unless the peer exchange is attached).  Both produce bitwise identical results. */
 int pilco_set_fused_step(pilco_ctx* ctx, int on);
+/* How pilco_rollout_grad / pilco_rollout_grad_rbf obtain the moment-matching adjoint: 1 (default) = Jacobian tape -- the
+ * forward rollout runs the reverse sweep in place of the forward pair kernel, so that ONE O(N^2) pass per step yields the
+ * step's value and its Jacobian, and the reverse sweep is host algebra on the downloaded records; 0 = plain tape, then the
+ * O(N^2) adjoint of every step on the device again (pilco_gp_predict_vjp).  Same gradient up to rounding. */
+int pilco_set_grad_mode(pilco_ctx* ctx, int mode);
 /* 1 (default; PILCO_NO_GRAPH=1 in the environment starts with 0): a rollout's launch sequence is captured once into a
  * hipGraph and replayed while the plan is unchanged; 0: every rollout is enqueued launch by launch.  Same results. */
 int pilco_set_use_graph(pilco_ctx* ctx, int on);

@@ -56,6 +56,7 @@ SIGNATURES = {
     "pilco_set_pair_kernel": (C.c_int, [_vp, C.c_int]),
     "pilco_selftest": (C.c_int, [_vp]),
     "pilco_set_fused_step": (C.c_int, [_vp, C.c_int]),
+    "pilco_set_grad_mode": (C.c_int, [_vp, C.c_int]),
     "pilco_set_use_graph": (C.c_int, [_vp, C.c_int]),
     "pilco_gp_set_data": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int]),
     "pilco_gp_set_hyp": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
@@ -189,6 +190,10 @@ class Context:
 
     def set_fused_step(self, on):
         self._chk(self.lib.pilco_set_fused_step(self.h, 1 if on else 0))
+
+    def set_grad_mode(self, mode):
+        """1 (default): Jacobian tape; 0: plain tape + per-step device adjoint (include/pilco_hip.h)."""
+        self._chk(self.lib.pilco_set_grad_mode(self.h, int(mode)))
 
     def use_graph(self, on):
         self._chk(self.lib.pilco_set_use_graph(self.h, 1 if on else 0))

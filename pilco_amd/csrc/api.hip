@@ -300,7 +300,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
         for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr,
-                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
+                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.jac_part, &s.jac_pn, &s.own, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
                           &s.w_part, &s.w_gath, &s.w_out, &s.ft_P, &s.ft_T3, &s.ft_Z})
             b->release();
     }
@@ -308,6 +308,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     ctx->params.release();
     ctx->traj.release();
     ctx->tape.release();
+    ctx->jrec.release();
     ctx->selftest.release();
     ctx->exp_tab.release();
     for (hipEvent_t e : ctx->pair_events) (void)hipEventDestroy(e);
@@ -316,6 +317,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);
+    if (ctx->jpin) (void)hipHostFree(ctx->jpin);
     if (ctx->st) (void)hipStreamDestroy(ctx->st);
     delete ctx;
     return PILCO_OK;
@@ -333,6 +335,12 @@ int pilco_set_pair_kernel(pilco_ctx* ctx, int variant) {
 int pilco_set_fused_step(pilco_ctx* ctx, int on) {
     if (!ctx) return PILCO_E_SHAPE;
     ctx->fused = (on != 0);
+    return PILCO_OK;
+}
+
+int pilco_set_grad_mode(pilco_ctx* ctx, int mode) {
+    if (!ctx) return PILCO_E_SHAPE;
+    ctx->grad_mode = mode;
     return PILCO_OK;
 }
 

@@ -624,6 +624,168 @@ __device__ void bwd_fin_pairs(const MMModel& md, const MMWork& wk, const double*
     }
 }
 
+// ---- Jacobian tape, last stage: one record per pair and per output (layout: mm_jac_rec_size)
+//   pair pl:   N_ab | g = rdet P A (D) | G = rdet (P I P^T / 2 - N (P Lambda + Lambda P^T) / 4) (D x D),  rdet = 1 / sqrt(det R_ab)
+//              => a cotangent Shat_ab of S_ab contributes  mbar += Shat g,  sbar += Shat G   (before symmetrisation)
+//   output a:  dM/dm (D) | dM/ds (D x D) | dV_k/dm (D x D: [k][r]) | dV_k/ds (D x D x D: [k][r][c])
+//              => cotangents (mu_a, Vbar_a) contribute  mbar += mu dM/dm + sum_k Vbar_k dV_k/dm,  sbar likewise
+// and N_ab in the layout the pack stage of the serial link reads tile partials in (pair_n[pl][2], NT = 1).
+__device__ void jac_fin_output(const MMModel& md, const double* __restrict__ head, int a, int nrc,
+                               const double* __restrict__ mpart, double* __restrict__ rec, double* sm) {
+    const int D = md.D, D1 = D + 1, t = threadIdx.x;
+    const int nI = D * D, n3 = nI * D, NS = D1 * (D1 + 1) * (D1 + 2) / 6;
+    double* T = sm;            // [D][D]
+    double* Hs = T + nI;       // [NS]
+    double* Th = Hs + NS;      // [D]
+    double* TH = Th + D;       // [D][D]   T H2
+    double* THT = TH + nI;     // [D][D]   T H2 T
+    double* W3 = THT + nI;     // [D][D][D]  W3[k][d][e] = sum_f H3(d,e,f) T[f][k]
+    double* Z3 = W3 + n3;      // [D][D][D]  Z3[k][r][e] = sum_d T[r][d] W3[k][d][e]
+    const double* hd = head + (long)a * (nI + D + 2);
+    for (int e = t; e < nI; e += 256) T[e] = hd[e];
+    const double c = hd[nI + D + 1];
+    for (int e = t; e < NS; e += 256) Hs[e] = sum_strided<16>(mpart + (long)a * nrc * NS + e, NS, nrc);   // fixed order
+    __syncthreads();
+    const double g = Hs[tri3(D, D, D)];
+    if (t < D) {
+        double acc = 0.0;
+        for (int cc = 0; cc < D; ++cc) acc = fma(T[t * D + cc], Hs[tri3(D, D, cc)], acc);
+        Th[t] = acc;
+    }
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, cc = e - r * D;
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k) acc = fma(T[r * D + k], Hs[tri3(D, max(k, cc), min(k, cc))], acc);
+        TH[e] = acc;
+    }
+    for (int e = t; e < n3; e += 256) {
+        const int k = e / nI, d = (e / D) % D, e2 = e % D;
+        double acc = 0.0;
+        for (int f = 0; f < D; ++f) acc = fma(Hs[tri3_any(d, e2, f)], T[f * D + k], acc);
+        W3[e] = acc;
+    }
+    __syncthreads();
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, cc = e - r * D;
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k) acc = fma(TH[r * D + k], T[k * D + cc], acc);
+        THT[e] = acc;
+    }
+    for (int e = t; e < n3; e += 256) {
+        const int k = e / nI, r = (e / D) % D, e2 = e % D;
+        double acc = 0.0;
+        for (int d = 0; d < D; ++d) acc = fma(T[r * D + d], W3[(k * D + d) * D + e2], acc);
+        Z3[e] = acc;
+    }
+    __syncthreads();
+    double* dMdm = rec;
+    double* dMds = rec + D;
+    double* dVdm = dMds + nI;
+    double* dVds = dVdm + nI;
+    if (t < D) dMdm[t] = c * Th[t];
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, cc = e - r * D;
+        dMds[e] = -0.5 * c * g * T[e] + 0.5 * c * THT[e];
+        dVdm[e] = c * (THT[cc * D + r] - g * T[cc * D + r]);     // [k = r][row = cc]: (T H2 T)[cc][k] - g T[cc][k]
+    }
+    for (int e = t; e < n3; e += 256) {
+        const int k = e / nI, r = (e / D) % D, cc = e % D;
+        double acc = 0.0;
+        for (int e2 = 0; e2 < D; ++e2) acc = fma(Z3[(k * D + r) * D + e2], T[e2 * D + cc], acc);
+        dVds[e] = -0.5 * c * Th[k] * T[r * D + cc] + 0.5 * c * acc - 0.5 * c * (T[r * D + k] * Th[cc] + Th[r] * T[cc * D + k]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mm_jac_fin(MMModel md, MMWork wk, const double* __restrict__ part, int nrc,
+                                                   const double* __restrict__ head, const double* __restrict__ mpart,
+                                                   double* __restrict__ jrec, double* __restrict__ pair_n) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x;
+    const int nI = D * D, rec = 1 + D + nI;
+    if (pl >= wk.PL) {
+        const int a = pl - wk.PL;
+        jac_fin_output(md, head, a, nrc, mpart, jrec + (long)wk.PL * rec + (long)a * (D + 2 * nI + nI * D), sm);
+        return;
+    }
+    double* Pm = sm;               // [D][D]
+    double* lam = Pm + nI;         // [D + 2]: lambda | rdet
+    double* Iv = lam + D + 2;      // [rec]  summed partials (N | A | I)
+    double* PI = Iv + rec;         // [D][D]
+    const double* hd = head + (long)(E + pl) * (nI + D + 2);
+    for (int e = t; e < nI + D + 2; e += 256) (e < nI ? Pm[e] : lam[e - nI]) = hd[e];
+    for (int e = t; e < rec; e += 256) Iv[e] = sum_strided<16>(part + (long)pl * nrc * rec + e, rec, nrc);   // fixed order
+    __syncthreads();
+    const double rdet = lam[D];
+    const double Nab = Iv[0];
+    const double* Av = Iv + 1;
+    const double* Im = Iv + 1 + D;
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, c = e - r * D;
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k) acc = fma(Pm[r * D + k], Im[k * D + c], acc);
+        PI[e] = acc;
+    }
+    __syncthreads();
+    double* o = jrec + (long)pl * rec;
+    if (t == 0) {
+        o[0] = Nab;
+        pair_n[2 * pl] = Nab;
+        pair_n[2 * pl + 1] = 0.0;
+    }
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, c = e - r * D;
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k) acc = fma(PI[r * D + k], Pm[c * D + k], acc);   // (P I P^T)[r][c]
+        const double pl2 = Pm[r * D + c] * lam[c] + Pm[c * D + r] * lam[r];         // P Lambda + Lambda P^T
+        o[1 + D + e] = rdet * (0.5 * acc - 0.25 * Nab * pl2);
+    }
+    if (t >= 256 - D) {
+        const int r = t - (256 - D);
+        double acc = 0.0;
+        for (int c = 0; c < D; ++c) acc = fma(Pm[r * D + c], Av[c], acc);
+        o[1 + r] = rdet * acc;
+    }
+}
+
+size_t mm_jac_rec_size(int D, int E, int P) { return (size_t)P * (1 + D + D * D) + (size_t)E * (D + 2 * D * D + D * D * D); }
+size_t mm_jac_part_size(int D, int E, int P, int npad) {
+    return (size_t)P * mm_bwd_rc(npad) * (1 + D + D * D) + (size_t)E * mm_bwd_rc(npad) * mm_jac_ns(D);
+}
+
+// One moment-matching step as [reverse sweep -> partial sums and moments -> records]: value and Jacobian in one pass.
+void launch_mm_jac(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* part,
+                   double* head, double* jrec, double* pair_n) {
+    const int P = wk.PL, E = md.E, D = md.D;
+    int njs, nrb;
+    mm_bwd_geometry(md.npad, P, &njs, &nrb);
+    const int nhead = E + P, per_row = nrb * njs;
+    dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);
+    const int LD = D | 1, nI = D * D, D1 = D + 1, LD1 = D1 | 1, NS = mm_jac_ns(D);
+    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * BWD_TP + 2 * BWD_CH), (size_t)4 * nI + D);
+    const double* bars = nullptr;
+#define PB(K_)                                                                                                       \
+    do {                                                                                                             \
+        if (wk.vsep)                                                                                                 \
+            hipLaunchKernelGGL((k_mm_bwd_pair<K_, true>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head);  \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_mm_bwd_pair<K_, false>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head); \
+    } while (0)
+    switch (wk.KP / 4) {
+        case 1: PB(1); break;
+        case 2: PB(2); break;
+        case 3: PB(3); break;
+        default: PB(4); break;
+    }
+#undef PB
+    const int nrc = mm_bwd_rc(md.npad);
+    double* mpart = part + (size_t)P * nrc * (1 + D + nI);
+    const size_t lds_post = sizeof(double) * std::max((size_t)3 * 64 * LD + 128 + 3 * D, (size_t)nI + 64 * LD1 + 64 + NS / 2 + 2);
+    hipLaunchKernelGGL(k_mm_bwd_post, dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
+                       head, mpart, 1);
+    const size_t lds_fin = sizeof(double) * std::max((size_t)3 * nI + 4 * D + 8, (size_t)3 * nI + NS + D + 2 * nI * D);
+    hipLaunchKernelGGL(k_mm_jac_fin, dim3(P + E), dim3(256), lds_fin, st, md, wk, part, nrc, head, mpart, jrec, pair_n);
+}
+
 void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb) {
     *nrb = (npad + 64 * BWD_RT - 1) / (64 * BWD_RT);
     int q = 1;   // column splits: enough workgroups for a few balanced rounds of the chip

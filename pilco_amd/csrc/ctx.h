@@ -22,6 +22,7 @@ struct Slot {
     bool has_data = false, has_hyp = false, factor_valid = false, user_factors = false, iK_null = false;
     bool ignore_iK = false;  // policy slot: RbfController evaluates with iK zeroed (controllers.py:116)
     DevBuf bwd_mom, bwd_cp, bwd_part, bwd_out, bwd_cnt; // reverse-pass scratch (bwd_cnt: the finished-workgroups counter)
+    DevBuf jac_part, jac_pn;                            // Jacobian tape: partial sums / moments, N_ab as [P][2] tile partials
     DevBuf Xt, Yt, Zt, ls, var, noise;         // Yt: [E][Npad]
     DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
     DevBuf Kmn, V2, Am, AmInv, AmD, iAt, G;    // FITC extras
@@ -102,6 +103,9 @@ struct pilco_ctx {
     DevBuf params;  // policy + reward parameters
     DevBuf traj;
     DevBuf tape;
+    DevBuf jrec;             // Jacobian tape: [H][mm_jac_rec_size] records of a value-and-gradient rollout
+    double* jpin = nullptr;  // pinned host copy of (traj | tape | jrec) for the host-side reverse sweep
+    size_t jpin_cap = 0;
     DevBuf selftest;
     DevBuf exp_tab;  // 2^(j/n), j = 0..n-1, n = mm_exp_table_size()
     unsigned long long* dbg = nullptr;
@@ -112,6 +116,7 @@ struct pilco_ctx {
     bool use_graph = true;
     bool fused = true;   // fused head: the serial link of step t runs inside the prep launch of step t+1 (2 launches per step)
     bool graph_rccl_failed = false;
+    int grad_mode = 1;   // pilco_rollout_grad*: 1 = Jacobian tape (one O(N^2) sweep per step), 0 = tape + per-step device adjoint
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> pair_events;
     double* pin = nullptr;   // pinned host staging buffer of the reverse pass (truly asynchronous small copies)
@@ -149,7 +154,12 @@ struct RolloutPlan {
     double* st[2] = {nullptr, nullptr};  // double-buffered state: m_x[E] | s_x[E*E]
     double* s1b[2] = {nullptr, nullptr}; // double-buffered [s_x, s_x c_xu] (fused head)
     int E = 0, D = 0, U = 0;
+    double* jrec = nullptr;              // Jacobian tape (bwd.hip): the dynamics step runs launch_mm_jac and writes jrec[t]
+    size_t jstride = 0;
 };
+// forward rollout with the tape and the Jacobian records of every step, downloaded into pinned memory (grad.hip)
+int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
+                  const double* S0, int H, double* reward, const double** traj, const double** tape, const double** jrec, size_t* jstride);
 int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_term* rw, int n_rw, int H, bool want_traj,
                   RolloutPlan& plan);
 int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev);

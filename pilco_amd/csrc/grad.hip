@@ -591,19 +591,73 @@ struct RbfAdj : PolicyAdj {
 
 // The reverse sweep common to both policies: propagate (pilco.py:147-149), joint Gaussian (:141-144), squash
 // (controllers.py:13-36), rewards (rewards.py:19-81); the moment-matching adjoint of every step on the device.
+// Host contraction of one step's Jacobian records (bwd.hip: k_mm_jac_fin) with the cotangents of the step's outputs:
+// what pilco_gp_predict_vjp computes on the device, without touching the device.  M (E): the step's GP means (tape).
+void jac_vjp(const double* jr, int D, int E, const double* M, const double* Mbar, const double* Sbar, const double* Vbar,
+             double* mbar, double* sbar, vec& acc) {
+    const int nI = D * D, recp = 1 + D + nI, P = E * (E + 1) / 2;
+    acc.assign((size_t)D + nI, 0.0);
+    double* am = acc.data();
+    // pairs in the dealing order: (0,0) .. (E-1,E-1), (1,0), (2,0), (2,1), ...
+    int pl = 0;
+    auto add_pair = [&](int a, int b) {
+        const double shat = (a == b) ? Sbar[(size_t)a * E + a] : Sbar[(size_t)a * E + b] + Sbar[(size_t)b * E + a];
+        const double* r = jr + (size_t)pl * recp + 1;
+        if (shat != 0.0)
+            for (int e = 0; e < D + nI; ++e) am[e] += shat * r[e];
+        ++pl;
+    };
+    for (int a = 0; a < E; ++a) add_pair(a, a);
+    for (int a = 1; a < E; ++a)
+        for (int b = 0; b < a; ++b) add_pair(a, b);
+    const double* jo = jr + (size_t)P * recp;
+    const size_t reco = (size_t)D + 2 * nI + (size_t)nI * D;
+    for (int a = 0; a < E; ++a) {
+        double mu = Mbar[a];
+        for (int b = 0; b < E; ++b) mu -= (Sbar[(size_t)a * E + b] + Sbar[(size_t)b * E + a]) * M[b];
+        const double* r = jo + (size_t)a * reco;
+        for (int e = 0; e < D + nI; ++e) am[e] += mu * r[e];            // dM/dm | dM/ds are contiguous
+        const double* dVdm = r + D + nI;
+        const double* dVds = dVdm + nI;
+        for (int k = 0; k < D; ++k) {
+            const double vb = Vbar[(size_t)k * E + a];
+            if (vb == 0.0) continue;
+            for (int e = 0; e < D; ++e) am[e] += vb * dVdm[(size_t)k * D + e];
+            for (int e = 0; e < nI; ++e) am[D + e] += vb * dVds[(size_t)k * nI + e];
+        }
+    }
+    for (int d = 0; d < D; ++d) mbar[d] = am[d];
+    for (int r = 0; r < D; ++r)
+        for (int c = 0; c < D; ++c) sbar[(size_t)r * D + c] = 0.5 * (am[D + (size_t)r * D + c] + am[D + (size_t)c * D + r]);
+}
+
 int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
                       const double* m0, const double* S0, int H, double* reward, PolicyAdj& pol) {
     const int E = policy->state_dim, U = policy->control_dim, D = E + U;
     const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
-    vec mH(E), SH((size_t)E * E), traj((size_t)(H + 1) * (E + E * E)), tape(std::max<size_t>(1, (size_t)H * TS));
-    if (int r = pilco_rollout_tape(ctx, policy, rewards, n_rewards, m0, S0, H, mH.data(), SH.data(), reward, traj.data(), tape.data()))
-        return r;
+    // Forward half.  Jacobian tape (default): one O(N^2) sweep per step gives the value and the step's Jacobian records,
+    // the reverse sweep below is host algebra only.  PILCO_GRAD_MODE=0 / pilco_set_grad_mode(ctx, 0): plain tape, and
+    // the O(N^2) adjoint of every step on the device again (pilco_gp_predict_vjp) -- the two agree to rounding.
+    const bool jac = ctx->grad_mode != 0;
+    vec mH(E), SH((size_t)E * E), traj_v, tape_v;
+    const double *traj = nullptr, *tape = nullptr, *jrec = nullptr;
+    size_t JS = 0;
+    if (jac) {
+        if (int r = rollout_jtape(ctx, policy, rewards, n_rewards, m0, S0, H, reward, &traj, &tape, &jrec, &JS)) return r;
+    } else {
+        traj_v.resize((size_t)(H + 1) * (E + E * E));
+        tape_v.resize(std::max<size_t>(1, (size_t)H * TS));
+        if (int r = pilco_rollout_tape(ctx, policy, rewards, n_rewards, m0, S0, H, mH.data(), SH.data(), reward, traj_v.data(), tape_v.data()))
+            return r;
+        traj = traj_v.data();
+        tape = tape_v.data();
+    }
     vec e(U);
     for (int u = 0; u < U; ++u) e[u] = policy->max_action[u];
     vec mbar(E, 0.0), sbar((size_t)E * E, 0.0);
     vec G((size_t)E * E), Vb((size_t)D * E), s1bar((size_t)E * D), mjb(D), sjb((size_t)D * D), mxb(E), sxb((size_t)E * E);
     vec Bb((size_t)E * U), sub((size_t)U * U), mu0(U), su0((size_t)U * U), V0((size_t)E * U), V0b((size_t)E * U), cb((size_t)E * U), Cdbar(U);
-    vec mu0b, su0b, rm(E), rS((size_t)E * E);
+    vec mu0b, su0b, rm(E), rS((size_t)E * E), jacc;
     Squash sq;
     for (int t = H - 1; t >= 0; --t) {
         const double* m_x = &traj[(size_t)t * (E + E * E)];
@@ -612,6 +666,7 @@ int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_re
         const double* m_j = rec;
         const double* s_j = rec + D;
         const double* s1 = rec + D + D * D;                                      // (E, D)
+        const double* Mgp = rec + D + D * D + (size_t)E * D;                     // (E)   GP means of the step
         const double* V = rec + D + D * D + (size_t)E * D + E + (size_t)E * E;   // (D, E)
         // propagate (pilco.py:147-149): M_x = M + m_x, S_x = S + s_x + s1 V + (s1 V)^T
         for (int i = 0; i < E; ++i)
@@ -630,8 +685,13 @@ int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_re
             }
         mxb = mbar;
         sxb = sbar;
-        if (int r = pilco_gp_predict_vjp(ctx, PILCO_SLOT_DYNAMICS, m_j, s_j, mbar.data(), sbar.data(), Vb.data(), mjb.data(), sjb.data()))
+        if (jac) {
+            jac_vjp(jrec + (size_t)t * JS, D, E, Mgp, mbar.data(), sbar.data(), Vb.data(), mjb.data(), sjb.data(), jacc);
+            for (int q = 0; q < D * D; ++q)
+                if (!std::isfinite(sjb[q])) return fail(ctx, PILCO_E_NOT_PD, "rollout_grad: singular s + Lambda^2 or I + Lambda s");
+        } else if (int r = pilco_gp_predict_vjp(ctx, PILCO_SLOT_DYNAMICS, m_j, s_j, mbar.data(), sbar.data(), Vb.data(), mjb.data(), sjb.data())) {
             return r;
+        }
         // joint Gaussian (pilco.py:141-144)
         for (int i = 0; i < E; ++i) mxb[i] += mjb[i];
         for (int i = 0; i < E; ++i)

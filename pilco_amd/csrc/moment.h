@@ -170,6 +170,13 @@ void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot);
 void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* part,
                    const double* bars, double* head, double* out, unsigned* done, double* sum_out);
 void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb);
+// Jacobian tape (bwd.hip): one step as reverse sweep -> sums -> records; `part` holds mm_jac_part_size doubles, `jrec`
+// mm_jac_rec_size, `pair_n` [P][2] (N_ab in the tile-partial layout the serial link packs from, NT = 1), head as launch_mm_bwd
+void launch_mm_jac(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* part,
+                   double* head, double* jrec, double* pair_n);
+size_t mm_jac_rec_size(int D, int E, int P);
+size_t mm_jac_part_size(int D, int E, int P, int npad);
+int mm_jac_ns(int D);
 int mm_bwd_rc(int npad);
 int mm_exp_table_size();   // entries of the 2^(j/n) table the pair kernels were built for
 int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf, const double* exp_tab);

@@ -181,7 +181,7 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
 static bool peer_rollout_applies(pilco_ctx* ctx, const RolloutPlan& plan, int H) {
     const Slot& s = ctx->slot[0];
     return ctx->xq.ready && ctx->nranks > 1 && ctx->xq.W == ctx->nranks && H > 0 && plan.g.pol_kind != PILCO_POLICY_RBF &&
-           s.wk.SEG <= ctx->xq.cap && !plan.g.tape;
+           s.wk.SEG <= ctx->xq.cap && !plan.g.tape && !plan.jrec;
 }
 // Host side of a rollout's exchanges: the epoch base goes up before the rollout's launches (outside any graph: the
 // value changes per replay), `n` exchanges are accounted for afterwards.
@@ -209,7 +209,13 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
     g.m_out = nullptr;
     g.s_out = nullptr;
     const bool rbf = (g.pol_kind == PILCO_POLICY_RBF);
-    if (ctx->fused && !rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && H > 0) {
+    const bool jac = plan.jrec != nullptr;   // Jacobian tape: the three-kernel step with launch_mm_jac in place of the pair kernel
+    if (jac) {
+        g.wk.sk_waves = 0;                   // the serial link packs N_ab from the [P][2] records k_mm_jac_fin leaves
+        g.wk.NT = 1;
+        g.wk.pair_part = s.jac_pn.p;
+    }
+    if (ctx->fused && !jac && !rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && H > 0) {
         // Fused head: launch h = 0..H-1 is [serial link producing state h and its joint Gaussian | operands of step h],
         // followed by the pair kernel of step h; one plain glue launch closes the rollout.  What the link reads
         // (previous step's pair_isdet / mean_part / s1 / state) and what the same launch writes alternate between two
@@ -337,7 +343,7 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
         launch_glue(ctx->st, gf, rew && s.wk.PL == 0);
         return PILCO_OK;
     }
-    if (ctx->fused && rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && ps.wk.PL > 0 && H > 0) {
+    if (ctx->fused && !jac && rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && ps.wk.PL > 0 && H > 0) {
         // Fused heads with an RbfController (controllers.py:108-121): the policy is a moment-matching GP of its own, so a
         // step is two head + pair rounds and the serial link splits in two:
         //   policy head   [pack / assemble / propagate of step h - 1 -> state h | operands of the POLICY GP at state h]
@@ -417,7 +423,13 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
             launch_mm_prep(ctx->st, md, s.wk, rew ? &pr : nullptr);
             if (ctx->dbg && MM_ABL(s.wk, 64)) launch_stamp(ctx->st, ctx->dbg, 30);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
-            launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
+            if (jac) {
+                const int rec = s.D + s.D * s.D, EP = s.E + s.wk.PL;
+                launch_mm_jac(ctx->st, md, s.wk, s.bwd_mom.p, s.bwd_cp.p, s.jac_part.p, s.bwd_out.p + (size_t)EP * rec,
+                              plan.jrec + (size_t)t * plan.jstride, s.jac_pn.p);
+            } else {
+                launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
+            }
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
         }
         g.step = t + 1;
@@ -471,7 +483,10 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
         (unsigned long long)ctx->slot[1].n,
         (unsigned long long)ctx->slot[1].wk.sk_waves, (unsigned long long)(uintptr_t)ctx->slot[1].w_small.p,
         (unsigned long long)(uintptr_t)ctx->slot[1].w_in.p, (unsigned long long)(uintptr_t)ctx->slot[1].ls.p,
-        (unsigned long long)(peer ? 1 : 0), (unsigned long long)(uintptr_t)ctx->xq.local, (unsigned long long)ctx->nranks, (unsigned long long)ctx->rank};
+        (unsigned long long)(peer ? 1 : 0), (unsigned long long)(uintptr_t)ctx->xq.local, (unsigned long long)ctx->nranks, (unsigned long long)ctx->rank,
+        (unsigned long long)(uintptr_t)plan.jrec, (unsigned long long)plan.jstride, (unsigned long long)(uintptr_t)s.bwd_mom.p,
+        (unsigned long long)(uintptr_t)s.bwd_cp.p, (unsigned long long)(uintptr_t)s.jac_part.p, (unsigned long long)(uintptr_t)s.bwd_out.p,
+        (unsigned long long)(uintptr_t)s.jac_pn.p};
     for (int i = 0; i < g.n_rewards; ++i) {
         key.push_back((unsigned long long)g.rw[i].kind);
         key.push_back((unsigned long long)(long long)g.rw[i].rank);
@@ -810,3 +825,67 @@ int pilco_rollout_tape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_r
 }
 
 }  // extern "C"
+
+// Value-and-gradient rollout, forward half: pilco_rollout_tape with every dynamics step run as the reverse sweep
+// (launch_mm_jac), so that the step's value and its Jacobian records come out of ONE O(N^2) pass; trajectory, tape and
+// records land in pinned host memory for the host-side reverse sweep (grad.hip).  Single rank, D <= 14.
+int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
+                  const double* S0, int H, double* reward, const double** traj, const double** tape, const double** jrec, size_t* jstride) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->nranks != 1 || ctx->comm) return fail(ctx, PILCO_E_STATE, "rollout_grad: single rank only");
+    RolloutPlan plan;
+    if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, true, plan)) return r;
+    Slot& s = ctx->slot[0];
+    const int E = plan.E, D = plan.D, P = s.wk.PL, npad = s.npad;
+    if (D + 2 > 16) return fail(ctx, PILCO_E_SHAPE, "rollout_grad: D <= 14 in this build");
+    const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
+    const size_t JS = mm_jac_rec_size(D, E, P), NTJ = (size_t)(H + 1) * (E + (size_t)E * E);
+    const int rec = D + D * D;
+    int njs, nrb;
+    mm_bwd_geometry(npad, P, &njs, &nrb);
+    ENSURE(s.bwd_mom, (size_t)P * njs * 16 * npad);
+    ENSURE(s.bwd_cp, (size_t)std::max(1, P - E) * nrb * npad);
+    ENSURE(s.jac_part, mm_jac_part_size(D, E, P, npad));
+    ENSURE(s.bwd_out, (size_t)(E + P) * rec + (size_t)(E + P) * (D * D + D + 2));
+    ENSURE(s.jac_pn, (size_t)2 * std::max(P, 1));
+    ENSURE(ctx->tape, std::max<size_t>(1, (size_t)H * TS));
+    ENSURE(ctx->jrec, std::max<size_t>(1, (size_t)H * JS));
+    const size_t need = NTJ + (size_t)H * TS + (size_t)H * JS + 8;
+    if (ctx->jpin_cap < need) {
+        if (ctx->jpin) (void)hipHostFree(ctx->jpin);
+        ctx->jpin = nullptr;
+        ctx->jpin_cap = 0;
+        HIPCHK(hipHostMalloc((void**)&ctx->jpin, sizeof(double) * need, hipHostMallocDefault));
+        ctx->jpin_cap = need;
+    }
+    plan.g.tape = ctx->tape.p;
+    plan.jrec = ctx->jrec.p;
+    plan.jstride = JS;
+    double* h_traj = ctx->jpin;
+    double* h_tape = h_traj + NTJ;
+    double* h_jrec = h_tape + (size_t)H * TS;
+    double* h_misc = h_jrec + (size_t)H * JS;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIPCHK(hipMemcpyAsync(plan.st[0], m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
+        HIPCHK(hipMemcpyAsync(plan.st[0] + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
+        const int r = run_rollout(ctx, plan, H);
+        if (r == -1) continue;
+        if (r != PILCO_OK) return r;
+        break;
+    }
+    HIPCHK(hipMemcpyAsync(h_misc, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(h_traj, ctx->traj.p, sizeof(double) * NTJ, hipMemcpyDeviceToHost, ctx->st));
+    if (H > 0) {
+        HIPCHK(hipMemcpyAsync(h_tape, ctx->tape.p, sizeof(double) * (size_t)H * TS, hipMemcpyDeviceToHost, ctx->st));
+        HIPCHK(hipMemcpyAsync(h_jrec, ctx->jrec.p, sizeof(double) * (size_t)H * JS, hipMemcpyDeviceToHost, ctx->st));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    *reward = h_misc[0];
+    *traj = h_traj;
+    *tape = h_tape;
+    *jrec = h_jrec;
+    *jstride = JS;
+    return PILCO_OK;
+}
+
