@@ -300,7 +300,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
         for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr,
-                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.jac_part, &s.jac_pn, &s.own, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
+                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.jac_rowmom, &s.jac_cpart, &s.jac_head, &s.jac_part, &s.jac_np, &s.own, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
                           &s.w_part, &s.w_gath, &s.w_out, &s.ft_P, &s.ft_T3, &s.ft_Z})
             b->release();
     }

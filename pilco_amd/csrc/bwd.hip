@@ -101,8 +101,9 @@ __device__ void bwd_head(const MMModel& md, const MMWork& wk, const double* __re
 template <int KC, bool VSEP>
 __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ rowmom,
                                                     double* __restrict__ cpart, int njs, const double* __restrict__ bars,
-                                                    double* __restrict__ head) {
+                                                    double* __restrict__ head, double* __restrict__ npart) {
     __shared__ double tab[FEXP_TN];
+    __shared__ double nred[4];
     extern __shared__ __attribute__((aligned(16))) double csl[];   // [4][jw]  (head workgroups: Gauss-Jordan scratch)
     if ((int)blockIdx.y >= wk.PL) {   // spare workgroups: the step's D x D inverses, one per output / pair
         const int h = ((int)blockIdx.y - wk.PL) * (int)(gridDim.x * gridDim.z) + (int)(blockIdx.z * gridDim.x + blockIdx.x);
@@ -254,6 +255,25 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
         for (int jj = threadIdx.x; jj < jw; jj += 256)
             cp[jj] = (csl[jj] + csl[jws + jj]) + (csl[2 * jws + jj] + csl[3 * jws + jj]);
     }
+    if (npart) {
+        // Jacobian tape: this workgroup's share of N_ab = sum_i r_i, in the [pair][tile][2] layout the serial link packs
+        // tile partials from (tile = js * row blocks + rb); r_i is row D of the moment tile: lanes lr == D % 4, register D / 4
+        const int rsel = D >> 2;
+        double v = 0.0;
+#pragma unroll
+        for (int rt = 0; rt < BWD_RT; ++rt) {
+            const double x = rsel == 0 ? acc[rt][0] : rsel == 1 ? acc[rt][1] : rsel == 2 ? acc[rt][2] : acc[rt][3];
+            v += (lr == (D & 3) && ibase + 16 * rt < npad) ? x : 0.0;   // tiles past the padding carry iK garbage and are never stored
+        }
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) nred[w] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double* o = npart + ((long)pl * (njs * (int)gridDim.x) + js * (int)gridDim.x + rb) * 2;
+            o[0] = (nred[0] + nred[1]) + (nred[2] + nred[3]);
+            o[1] = 0.0;
+        }
+    }
 }
 
 // Reverse of the mean part (mgpr.py:99-118) for output a, including the -M M^T term of S:
@@ -263,7 +283,7 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
 //   sbar_a = -phi T / 2 + c T (sum l_i q_i zeta_i zeta_i^T) T / 2 - c (u (T h)^T + (T h) u^T) / 2,  phi = c (mu g + Vbar_a . T h).
 // M_b is read from the mean partials the prep kernel of the same step left in wk.mean_part.
 // stage 1 (a workgroup of k_mm_bwd_post): sums over the 64-point blocks rc, rc + nrc, ..:  mpart[a][rc][D*D + 2D + 1]
-__device__ void bwd_mean_partial(const MMModel& md, const MMWork& wk, const double* __restrict__ head, int a, int rc,
+__device__ void bwd_mean_partial(const MMModel& md, const double* __restrict__ in_m, const double* __restrict__ head, int a, int rc,
                                  int nrc, double* __restrict__ mpart, double* sm) {
     const int D = md.D, npad = md.npad, t = threadIdx.x;
     const int nI = D * D, LD = D | 1;
@@ -290,7 +310,7 @@ __device__ void bwd_mean_partial(const MMModel& md, const MMWork& wk, const doub
                     for (int d = 0; d < 16; ++d) pv[d] = (d < D) ? md.Pt[(long)d * npad + i] : 0.0;
 #pragma unroll
                     for (int d = 0; d < 16; ++d)
-                        if (d < D) zs[t * LD + d] = pv[d] - wk.in_m[d];
+                        if (d < D) zs[t * LD + d] = pv[d] - in_m[d];
                 }
                 for (int r = 0; r < D; ++r) {
                     double tz = 0.0;
@@ -338,7 +358,7 @@ __device__ __forceinline__ int tri3_any(int a, int b, int c) {
 }
 int mm_jac_ns(int D) { return (D + 1) * (D + 2) * (D + 3) / 6; }
 constexpr int JAC_MAXA = 4;   // moment sums per thread: NS <= 4 * 256 (D <= 16)
-__device__ void bwd_mean_moments(const MMModel& md, const MMWork& wk, const double* __restrict__ head, int a, int rc,
+__device__ void bwd_mean_moments(const MMModel& md, const double* __restrict__ in_m, const double* __restrict__ head, int a, int rc,
                                  int nrc, double* __restrict__ mpart, double* sm) {
     const int D = md.D, D1 = D + 1, npad = md.npad, t = threadIdx.x;
     const int nI = D * D, LD = D1 | 1, NS = D1 * (D1 + 1) * (D1 + 2) / 6;
@@ -374,7 +394,7 @@ __device__ void bwd_mean_moments(const MMModel& md, const MMWork& wk, const doub
                     for (int d = 0; d < 16; ++d) pv[d] = (d < D) ? md.Pt[(long)d * npad + i] : 0.0;
 #pragma unroll
                     for (int d = 0; d < 16; ++d)
-                        if (d < D) zs[t * LD + d] = pv[d] - wk.in_m[d];
+                        if (d < D) zs[t * LD + d] = pv[d] - in_m[d];
                 }
                 for (int r = 0; r < D; ++r) {
                     double tz = 0.0;
@@ -466,16 +486,29 @@ __device__ void bwd_mean_final(const MMModel& md, const double* __restrict__ bar
 // Per unordered pair and row chunk: partial sums of  N_ab = sum_i r_i,  A = sum_i (r_i z_i + c_i w_i)  (D),
 // I = sum_i (r_i z_i z_i^T + c_i w_i w_i^T + z_i m_i^T + m_i z_i^T)  (D x D).   part[pl][chunk][1 + D + D*D]
 constexpr int BWD_RC = 16;  // row chunks per pair / output
+// Batched form (Jacobian tape): blockIdx.z = horizon step; every per-step array advances by its stride and the input
+// mean comes from the step's tape record (wk.in_m holds the LAST step's by then).  Unbatched: strides 0, in_m = nullptr.
+struct BwdBatch {
+    long rowmom, cpart, part, head;
+    const double* in_m;
+    long in_m_stride;
+};
 __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, const double* __restrict__ rowmom,
                                                     const double* __restrict__ cpart, int njs, int nrb,
                                                     double* __restrict__ part, int nrc,
-                                                    const double* __restrict__ head, double* __restrict__ mpart, int jac) {
+                                                    const double* __restrict__ head, double* __restrict__ mpart, int jac, BwdBatch bb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int npad = md.npad, D = md.D, E = md.E, t = threadIdx.x;
-    const int pl = blockIdx.x, rc = blockIdx.y;
+    const int pl = blockIdx.x, rc = blockIdx.y, z = blockIdx.z;
+    rowmom += (long)z * bb.rowmom;
+    cpart += (long)z * bb.cpart;
+    part += (long)z * bb.part;
+    mpart += (long)z * bb.part;
+    head += (long)z * bb.head;
+    const double* in_m = bb.in_m ? bb.in_m + (long)z * bb.in_m_stride : wk.in_m;
     if (pl >= wk.PL) {   // the last E workgroup columns: mean part of output pl - PL
-        if (jac) bwd_mean_moments(md, wk, head, pl - wk.PL, rc, nrc, mpart, sm);
-        else bwd_mean_partial(md, wk, head, pl - wk.PL, rc, nrc, mpart, sm);
+        if (jac) bwd_mean_moments(md, in_m, head, pl - wk.PL, rc, nrc, mpart, sm);
+        else bwd_mean_partial(md, in_m, head, pl - wk.PL, rc, nrc, mpart, sm);
         return;
     }
     int a, b;
@@ -497,7 +530,7 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
         const double la = md.ls[a * D + t], lb = md.ls[b * D + t];
         ia[t] = 1.0 / (la * la);
         ib[t] = 1.0 / (lb * lb);
-        mm[t] = wk.in_m[t];
+        mm[t] = in_m[t];
     }
     double acc = 0.0;
     for (int blk = rc; blk < nblk; blk += nrc) {
@@ -698,10 +731,14 @@ __device__ void jac_fin_output(const MMModel& md, const double* __restrict__ hea
 
 __global__ __launch_bounds__(256) void k_mm_jac_fin(MMModel md, MMWork wk, const double* __restrict__ part, int nrc,
                                                    const double* __restrict__ head, const double* __restrict__ mpart,
-                                                   double* __restrict__ jrec, double* __restrict__ pair_n) {
+                                                   double* __restrict__ jrec, long jstride, BwdBatch bb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x;
+    const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x, z = blockIdx.y;
     const int nI = D * D, rec = 1 + D + nI;
+    part += (long)z * bb.part;
+    mpart += (long)z * bb.part;
+    head += (long)z * bb.head;
+    jrec += (long)z * jstride;
     if (pl >= wk.PL) {
         const int a = pl - wk.PL;
         jac_fin_output(md, head, a, nrc, mpart, jrec + (long)wk.PL * rec + (long)a * (D + 2 * nI + nI * D), sm);
@@ -727,11 +764,7 @@ __global__ __launch_bounds__(256) void k_mm_jac_fin(MMModel md, MMWork wk, const
     }
     __syncthreads();
     double* o = jrec + (long)pl * rec;
-    if (t == 0) {
-        o[0] = Nab;
-        pair_n[2 * pl] = Nab;
-        pair_n[2 * pl + 1] = 0.0;
-    }
+    if (t == 0) o[0] = Nab;
     for (int e = t; e < nI; e += 256) {
         const int r = e / D, c = e - r * D;
         double acc = 0.0;
@@ -752,23 +785,43 @@ size_t mm_jac_part_size(int D, int E, int P, int npad) {
     return (size_t)P * mm_bwd_rc(npad) * (1 + D + D * D) + (size_t)E * mm_bwd_rc(npad) * mm_jac_ns(D);
 }
 
-// One moment-matching step as [reverse sweep -> partial sums and moments -> records]: value and Jacobian in one pass.
-void launch_mm_jac(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* part,
-                   double* head, double* jrec, double* pair_n) {
+void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb);
+size_t mm_jac_rowmom_size(int npad, int P) {
+    int njs, nrb;
+    mm_bwd_geometry(npad, P, &njs, &nrb);
+    return (size_t)P * njs * 16 * npad;
+}
+size_t mm_jac_cpart_size(int npad, int P, int E) {
+    int njs, nrb;
+    mm_bwd_geometry(npad, P, &njs, &nrb);
+    return (size_t)std::max(1, P - E) * nrb * npad;
+}
+size_t mm_jac_head_size(int D, int E, int P) { return (size_t)(E + P) * (D * D + D + 2); }
+int mm_jac_nt(int npad, int P) {
+    int njs, nrb;
+    mm_bwd_geometry(npad, P, &njs, &nrb);
+    return njs * nrb;
+}
+
+// Jacobian tape, per step (on the rollout's critical path): the reverse sweep in place of the forward pair kernel.  It
+// leaves the step's row moments / column sums / head records in THIS step's buffers and N_ab as [P][mm_jac_nt][2] tile
+// partials for the serial link.
+void launch_mm_sweep(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* head,
+                     double* npart) {
     const int P = wk.PL, E = md.E, D = md.D;
     int njs, nrb;
     mm_bwd_geometry(md.npad, P, &njs, &nrb);
     const int nhead = E + P, per_row = nrb * njs;
     dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);
-    const int LD = D | 1, nI = D * D, D1 = D + 1, LD1 = D1 | 1, NS = mm_jac_ns(D);
+    const int nI = D * D;
     const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * BWD_TP + 2 * BWD_CH), (size_t)4 * nI + D);
     const double* bars = nullptr;
 #define PB(K_)                                                                                                       \
     do {                                                                                                             \
         if (wk.vsep)                                                                                                 \
-            hipLaunchKernelGGL((k_mm_bwd_pair<K_, true>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head);  \
+            hipLaunchKernelGGL((k_mm_bwd_pair<K_, true>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head, npart);  \
         else                                                                                                         \
-            hipLaunchKernelGGL((k_mm_bwd_pair<K_, false>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head); \
+            hipLaunchKernelGGL((k_mm_bwd_pair<K_, false>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head, npart); \
     } while (0)
     switch (wk.KP / 4) {
         case 1: PB(1); break;
@@ -777,13 +830,33 @@ void launch_mm_jac(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
         default: PB(4); break;
     }
 #undef PB
+}
+
+// Jacobian tape, once per rollout (off the critical path): sums, moments and records of ALL H steps in two launches --
+// nothing of the forward chain waits for them, so they run at throughput instead of paying their latency per step.
+// Per-step arrays: rowmom / cpart / head / part advance by the sizes above, in_m is the head of the step's tape record.
+void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, int H, const double* rowmom, const double* cpart,
+                          const double* head, double* part, const double* tape, size_t tape_stride, double* jrec) {
+    if (H <= 0) return;
+    const int P = wk.PL, E = md.E, D = md.D;
+    int njs, nrb;
+    mm_bwd_geometry(md.npad, P, &njs, &nrb);
+    const int LD = D | 1, nI = D * D, D1 = D + 1, LD1 = D1 | 1, NS = mm_jac_ns(D);
     const int nrc = mm_bwd_rc(md.npad);
+    BwdBatch bb;
+    bb.rowmom = (long)mm_jac_rowmom_size(md.npad, P);
+    bb.cpart = (long)mm_jac_cpart_size(md.npad, P, E);
+    bb.part = (long)mm_jac_part_size(D, E, P, md.npad);
+    bb.head = (long)mm_jac_head_size(D, E, P);
+    bb.in_m = tape;
+    bb.in_m_stride = (long)tape_stride;
     double* mpart = part + (size_t)P * nrc * (1 + D + nI);
     const size_t lds_post = sizeof(double) * std::max((size_t)3 * 64 * LD + 128 + 3 * D, (size_t)nI + 64 * LD1 + 64 + NS / 2 + 2);
-    hipLaunchKernelGGL(k_mm_bwd_post, dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
-                       head, mpart, 1);
+    hipLaunchKernelGGL(k_mm_bwd_post, dim3(P + E, nrc, H), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
+                       head, mpart, 1, bb);
     const size_t lds_fin = sizeof(double) * std::max((size_t)3 * nI + 4 * D + 8, (size_t)3 * nI + NS + D + 2 * nI * D);
-    hipLaunchKernelGGL(k_mm_jac_fin, dim3(P + E), dim3(256), lds_fin, st, md, wk, part, nrc, head, mpart, jrec, pair_n);
+    hipLaunchKernelGGL(k_mm_jac_fin, dim3(P + E, H), dim3(256), lds_fin, st, md, wk, part, nrc, head, mpart, jrec,
+                       (long)mm_jac_rec_size(D, E, P), bb);
 }
 
 void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb) {
@@ -803,12 +876,13 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
     dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);   // the rows past P hold the head workgroups
     const int LD = D | 1, nI = D * D;
     const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * BWD_TP + 2 * BWD_CH), (size_t)4 * nI + D);
+    double* npart = nullptr;
 #define PB(K_)                                                                                                       \
     do {                                                                                                             \
         if (wk.vsep)                                                                                                 \
-            hipLaunchKernelGGL((k_mm_bwd_pair<K_, true>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head);  \
+            hipLaunchKernelGGL((k_mm_bwd_pair<K_, true>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head, npart);  \
         else                                                                                                         \
-            hipLaunchKernelGGL((k_mm_bwd_pair<K_, false>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head); \
+            hipLaunchKernelGGL((k_mm_bwd_pair<K_, false>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head, npart); \
     } while (0)
     switch (wk.KP / 4) {
         case 1: PB(1); break;
@@ -821,7 +895,7 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
     double* mpart = part + (size_t)P * nrc * (1 + D + nI);
     const size_t lds_post = sizeof(double) * std::max((size_t)3 * 64 * LD + 128 + 3 * D, (size_t)nI + 64 * LD + 128 + D + 2);
     hipLaunchKernelGGL(k_mm_bwd_post, dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
-                       head, mpart, 0);
+                       head, mpart, 0, BwdBatch{0, 0, 0, 0, nullptr, 0});
     const size_t lds_fin = sizeof(double) * ((size_t)3 * nI + 4 * D + 8);
     hipLaunchKernelGGL(k_mm_bwd_fin, dim3(P + E), dim3(256), lds_fin, st, md, wk, part, nrc, bars, head, mpart, out, done, sum_out);
 }

@@ -22,7 +22,7 @@ struct Slot {
     bool has_data = false, has_hyp = false, factor_valid = false, user_factors = false, iK_null = false;
     bool ignore_iK = false;  // policy slot: RbfController evaluates with iK zeroed (controllers.py:116)
     DevBuf bwd_mom, bwd_cp, bwd_part, bwd_out, bwd_cnt; // reverse-pass scratch (bwd_cnt: the finished-workgroups counter)
-    DevBuf jac_part, jac_pn;                            // Jacobian tape: partial sums / moments, N_ab as [P][2] tile partials
+    DevBuf jac_rowmom, jac_cpart, jac_head, jac_part, jac_np;   // Jacobian tape: per-step sweep outputs [H][..], N_ab tile partials
     DevBuf Xt, Yt, Zt, ls, var, noise;         // Yt: [E][Npad]
     DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
     DevBuf Kmn, V2, Am, AmInv, AmD, iAt, G;    // FITC extras
@@ -157,6 +157,7 @@ struct RolloutPlan {
     double* jrec = nullptr;              // Jacobian tape (bwd.hip): the dynamics step runs launch_mm_jac and writes jrec[t]
     size_t jstride = 0;
 };
+constexpr int PILCO_JAC_TOO_LARGE = -77;   // rollout_jtape: the per-step buffers would exceed the cap (caller falls back)
 // forward rollout with the tape and the Jacobian records of every step, downloaded into pinned memory (grad.hip)
 int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
                   const double* S0, int H, double* reward, const double** traj, const double** tape, const double** jrec, size_t* jstride);

@@ -638,13 +638,16 @@ int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_re
     // Forward half.  Jacobian tape (default): one O(N^2) sweep per step gives the value and the step's Jacobian records,
     // the reverse sweep below is host algebra only.  PILCO_GRAD_MODE=0 / pilco_set_grad_mode(ctx, 0): plain tape, and
     // the O(N^2) adjoint of every step on the device again (pilco_gp_predict_vjp) -- the two agree to rounding.
-    const bool jac = ctx->grad_mode != 0;
+    bool jac = ctx->grad_mode != 0;
     vec mH(E), SH((size_t)E * E), traj_v, tape_v;
     const double *traj = nullptr, *tape = nullptr, *jrec = nullptr;
     size_t JS = 0;
     if (jac) {
-        if (int r = rollout_jtape(ctx, policy, rewards, n_rewards, m0, S0, H, reward, &traj, &tape, &jrec, &JS)) return r;
-    } else {
+        const int r = rollout_jtape(ctx, policy, rewards, n_rewards, m0, S0, H, reward, &traj, &tape, &jrec, &JS);
+        if (r == PILCO_JAC_TOO_LARGE) jac = false;
+        else if (r) return r;
+    }
+    if (!jac) {
         traj_v.resize((size_t)(H + 1) * (E + E * E));
         tape_v.resize(std::max<size_t>(1, (size_t)H * TS));
         if (int r = pilco_rollout_tape(ctx, policy, rewards, n_rewards, m0, S0, H, mH.data(), SH.data(), reward, traj_v.data(), tape_v.data()))

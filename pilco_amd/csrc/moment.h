@@ -170,12 +170,20 @@ void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot);
 void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* part,
                    const double* bars, double* head, double* out, unsigned* done, double* sum_out);
 void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb);
-// Jacobian tape (bwd.hip): one step as reverse sweep -> sums -> records; `part` holds mm_jac_part_size doubles, `jrec`
-// mm_jac_rec_size, `pair_n` [P][2] (N_ab in the tile-partial layout the serial link packs from, NT = 1), head as launch_mm_bwd
-void launch_mm_jac(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* part,
-                   double* head, double* jrec, double* pair_n);
+// Jacobian tape (bwd.hip).  Per step: launch_mm_sweep runs the reverse sweep in place of the forward pair kernel and
+// leaves rowmom / cpart / head in the step's own buffers (sizes below) and N_ab as npart [P][mm_jac_nt][2] tile partials
+// for the serial link; once per rollout launch_mm_jac_finish turns the H steps' buffers into the records
+// jrec [H][mm_jac_rec_size] (part: [H][mm_jac_part_size] scratch; tape: the rollout tape, whose records start with m_j).
+void launch_mm_sweep(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* head,
+                     double* npart);
+void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, int H, const double* rowmom, const double* cpart,
+                          const double* head, double* part, const double* tape, size_t tape_stride, double* jrec);
 size_t mm_jac_rec_size(int D, int E, int P);
 size_t mm_jac_part_size(int D, int E, int P, int npad);
+size_t mm_jac_rowmom_size(int npad, int P);
+size_t mm_jac_cpart_size(int npad, int P, int E);
+size_t mm_jac_head_size(int D, int E, int P);
+int mm_jac_nt(int npad, int P);
 int mm_jac_ns(int D);
 int mm_bwd_rc(int npad);
 int mm_exp_table_size();   // entries of the 2^(j/n) table the pair kernels were built for

@@ -196,7 +196,19 @@ static int xq_begin(pilco_ctx* ctx) {
 // enqueue one full rollout on the stream (initial state already in plan.st[0]); the final
 // state ends up in plan.st[H & 1].  The reward of state t (pilco.py:133) is evaluated by the
 // second workgroup of the glue launch that turns state t into state t+1.
+static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev);
 int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev) {
+    if (int r = enqueue_rollout_steps(ctx, plan, H, pair_ev)) return r;
+    if (plan.jrec && H > 0) {   // Jacobian tape: the H steps' sums, moments and records in two launches behind the chain
+        Slot& s = ctx->slot[0];
+        launch_mm_jac_finish(ctx->st, model_of(s), s.wk, H, s.jac_rowmom.p, s.jac_cpart.p, s.jac_head.p, s.jac_part.p,
+                             plan.g.tape, (size_t)plan.D + plan.D * plan.D + (size_t)plan.E * plan.D + plan.E + (size_t)plan.E * plan.E + (size_t)plan.D * plan.E,
+                             plan.jrec);
+    }
+    return PILCO_OK;
+}
+
+static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev) {
     Slot& s = ctx->slot[0];
     const MMModel md = model_of(s);
     const int E = plan.E;
@@ -209,18 +221,31 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
     g.m_out = nullptr;
     g.s_out = nullptr;
     const bool rbf = (g.pol_kind == PILCO_POLICY_RBF);
-    const bool jac = plan.jrec != nullptr;   // Jacobian tape: the three-kernel step with launch_mm_jac in place of the pair kernel
+    // Jacobian tape (bwd.hip): the dynamics step runs the reverse sweep in place of the forward pair kernel; the serial
+    // link packs N_ab from the per-workgroup partials the sweep leaves in the tile-partial layout
+    const bool jac = plan.jrec != nullptr;
+    MMWork wk0 = s.wk;
     if (jac) {
-        g.wk.sk_waves = 0;                   // the serial link packs N_ab from the [P][2] records k_mm_jac_fin leaves
-        g.wk.NT = 1;
-        g.wk.pair_part = s.jac_pn.p;
+        wk0.sk_waves = 0;
+        wk0.NT = mm_jac_nt(s.npad, s.wk.PL);
+        wk0.pair_part = s.jac_np.p;
+        g.wk = wk0;
     }
-    if (ctx->fused && !jac && !rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && H > 0) {
+    const size_t j_rm = jac ? mm_jac_rowmom_size(s.npad, s.wk.PL) : 0, j_cp = jac ? mm_jac_cpart_size(s.npad, s.wk.PL, s.E) : 0,
+                 j_hd = jac ? mm_jac_head_size(s.D, s.E, s.wk.PL) : 0;
+    auto dyn_pairs = [&](const MMWork& w, int t) {
+        if (jac)
+            launch_mm_sweep(ctx->st, md, w, s.jac_rowmom.p + (size_t)t * j_rm, s.jac_cpart.p + (size_t)t * j_cp,
+                            s.jac_head.p + (size_t)t * j_hd, s.jac_np.p);
+        else
+            launch_mm_pair(ctx->st, md, w, ctx->variant);
+    };
+    if (ctx->fused && !rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && H > 0) {
         // Fused head: launch h = 0..H-1 is [serial link producing state h and its joint Gaussian | operands of step h],
         // followed by the pair kernel of step h; one plain glue launch closes the rollout.  What the link reads
         // (previous step's pair_isdet / mean_part / s1 / state) and what the same launch writes alternate between two
         // buffer sets, because the workgroups of one launch are not ordered.
-        MMWork wkb[2] = {s.wk, s.wk};
+        MMWork wkb[2] = {wk0, wk0};
         wkb[1].pair_isdet = s.alt_isdet;
         wkb[1].mean_part = s.alt_mean;
         size_t evi = 0;
@@ -245,7 +270,7 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
             }
             launch_mm_prep(ctx->st, md, wkb[h & 1], rew ? &pr : nullptr, &gh);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
-            launch_mm_pair(ctx->st, md, wkb[h & 1], ctx->variant);
+            dyn_pairs(wkb[h & 1], h);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
         }
         GlueArgs gf = g;
@@ -343,7 +368,7 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
         launch_glue(ctx->st, gf, rew && s.wk.PL == 0);
         return PILCO_OK;
     }
-    if (ctx->fused && !jac && rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && ps.wk.PL > 0 && H > 0) {
+    if (ctx->fused && rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && ps.wk.PL > 0 && H > 0) {
         // Fused heads with an RbfController (controllers.py:108-121): the policy is a moment-matching GP of its own, so a
         // step is two head + pair rounds and the serial link splits in two:
         //   policy head   [pack / assemble / propagate of step h - 1 -> state h | operands of the POLICY GP at state h]
@@ -381,7 +406,7 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
             gc.s_out = nullptr;
             launch_mm_prep(ctx->st, md, s.wk, nullptr, &gc);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
-            launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
+            dyn_pairs(s.wk, h);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
         }
         GlueArgs gf = g;
@@ -423,13 +448,7 @@ int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEve
             launch_mm_prep(ctx->st, md, s.wk, rew ? &pr : nullptr);
             if (ctx->dbg && MM_ABL(s.wk, 64)) launch_stamp(ctx->st, ctx->dbg, 30);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
-            if (jac) {
-                const int rec = s.D + s.D * s.D, EP = s.E + s.wk.PL;
-                launch_mm_jac(ctx->st, md, s.wk, s.bwd_mom.p, s.bwd_cp.p, s.jac_part.p, s.bwd_out.p + (size_t)EP * rec,
-                              plan.jrec + (size_t)t * plan.jstride, s.jac_pn.p);
-            } else {
-                launch_mm_pair(ctx->st, md, s.wk, ctx->variant);
-            }
+            dyn_pairs(s.wk, t);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
         }
         g.step = t + 1;
@@ -484,9 +503,9 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
         (unsigned long long)ctx->slot[1].wk.sk_waves, (unsigned long long)(uintptr_t)ctx->slot[1].w_small.p,
         (unsigned long long)(uintptr_t)ctx->slot[1].w_in.p, (unsigned long long)(uintptr_t)ctx->slot[1].ls.p,
         (unsigned long long)(peer ? 1 : 0), (unsigned long long)(uintptr_t)ctx->xq.local, (unsigned long long)ctx->nranks, (unsigned long long)ctx->rank,
-        (unsigned long long)(uintptr_t)plan.jrec, (unsigned long long)plan.jstride, (unsigned long long)(uintptr_t)s.bwd_mom.p,
-        (unsigned long long)(uintptr_t)s.bwd_cp.p, (unsigned long long)(uintptr_t)s.jac_part.p, (unsigned long long)(uintptr_t)s.bwd_out.p,
-        (unsigned long long)(uintptr_t)s.jac_pn.p};
+        (unsigned long long)(uintptr_t)plan.jrec, (unsigned long long)plan.jstride, (unsigned long long)(uintptr_t)s.jac_rowmom.p,
+        (unsigned long long)(uintptr_t)s.jac_cpart.p, (unsigned long long)(uintptr_t)s.jac_part.p, (unsigned long long)(uintptr_t)s.jac_head.p,
+        (unsigned long long)(uintptr_t)s.jac_np.p};
     for (int i = 0; i < g.n_rewards; ++i) {
         key.push_back((unsigned long long)g.rw[i].kind);
         key.push_back((unsigned long long)(long long)g.rw[i].rank);
@@ -840,14 +859,18 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     if (D + 2 > 16) return fail(ctx, PILCO_E_SHAPE, "rollout_grad: D <= 14 in this build");
     const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
     const size_t JS = mm_jac_rec_size(D, E, P), NTJ = (size_t)(H + 1) * (E + (size_t)E * E);
-    const int rec = D + D * D;
-    int njs, nrb;
-    mm_bwd_geometry(npad, P, &njs, &nrb);
-    ENSURE(s.bwd_mom, (size_t)P * njs * 16 * npad);
-    ENSURE(s.bwd_cp, (size_t)std::max(1, P - E) * nrb * npad);
-    ENSURE(s.jac_part, mm_jac_part_size(D, E, P, npad));
-    ENSURE(s.bwd_out, (size_t)(E + P) * rec + (size_t)(E + P) * (D * D + D + 2));
-    ENSURE(s.jac_pn, (size_t)2 * std::max(P, 1));
+    // every step keeps its own sweep output until the batched finish (nothing on the chain waits for a buffer): at C2u
+    // 29 MB per step -- HBM is 288 GB; a rollout that would need more than PILCO_JAC_GB (default 32) falls back
+    const size_t Hn = (size_t)std::max(H, 1);
+    const size_t per_step = mm_jac_rowmom_size(npad, P) + mm_jac_cpart_size(npad, P, E) + mm_jac_head_size(D, E, P) + mm_jac_part_size(D, E, P, npad);
+    double cap_gb = 32.0;
+    if (const char* ev = getenv("PILCO_JAC_GB")) cap_gb = atof(ev);
+    if ((double)per_step * 8.0 * (double)Hn > cap_gb * 1e9) return PILCO_JAC_TOO_LARGE;
+    ENSURE(s.jac_rowmom, Hn * mm_jac_rowmom_size(npad, P));
+    ENSURE(s.jac_cpart, Hn * mm_jac_cpart_size(npad, P, E));
+    ENSURE(s.jac_head, Hn * mm_jac_head_size(D, E, P));
+    ENSURE(s.jac_part, Hn * mm_jac_part_size(D, E, P, npad));
+    ENSURE(s.jac_np, (size_t)2 * std::max(P, 1) * mm_jac_nt(npad, P));
     ENSURE(ctx->tape, std::max<size_t>(1, (size_t)H * TS));
     ENSURE(ctx->jrec, std::max<size_t>(1, (size_t)H * JS));
     const size_t need = NTJ + (size_t)H * TS + (size_t)H * JS + 8;

@@ -1197,7 +1197,7 @@ def test_native_rollout_grad_combined_reward_and_errors(ctx):
     p.controller.W.assign(c["W"]); p.controller.b.assign(c["b"]); p.controller.max_action = 1.3
     r1, (W1, b1) = rollout_value_and_grad(p)
     r2, (W2, b2) = rollout_value_and_grad_py(p)
-    np.testing.assert_allclose(r1, r2, rtol=1e-13)
+    np.testing.assert_allclose(r1, r2, rtol=1e-10)
     np.testing.assert_allclose(W1, W2, rtol=1e-9, atol=1e-13)
     np.testing.assert_allclose(b1, b2, rtol=1e-9, atol=1e-13)
     np.testing.assert_allclose(r1, float(p.compute_reward()[0, 0]), rtol=1e-10)   # two summation orders of the same pair sums
