@@ -99,7 +99,7 @@ __device__ void bwd_head(const MMModel& md, const MMWork& wk, const double* __re
 }
 
 template <int KC, bool VSEP>
-__global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ rowmom,
+__global__ __launch_bounds__(256, 4) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ rowmom,
                                                     double* __restrict__ cpart, int njs, const double* __restrict__ bars,
                                                     double* __restrict__ head, double* __restrict__ npart) {
     __shared__ double tab[FEXP_TN];
@@ -176,6 +176,18 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
 #pragma unroll
     for (int rt = 0; rt < BWD_RT; ++rt) acc[rt] = d4{0.0, 0.0, 0.0, 0.0};
     double* myslice = csl + w * jws;
+    // column-sum scratch of this wave: [4 result registers][64 lanes]; reader lane = (column jj = lane / 4, quarter q = lane % 4)
+    // takes the four partials of lanes lc = 4 q .. 4 q + 3 of DPP row lr = jj % 4, register jj / 4
+    double* scr = csl + 4 * jws + 2 * (BWD_CH * BWD_TP + 2 * BWD_CH) + w * 256;
+    const int rd_jj = lane >> 2, rd_q = lane & 3;
+    const double* rd_src = scr + (rd_jj >> 2) * 64 + (rd_jj & 3) * 16 + 4 * rd_q;
+    int jprev = -1;
+    auto flush_cols = [&](int jp) {
+        double p = (rd_src[0] + rd_src[1]) + (rd_src[2] + rd_src[3]);
+        p = dpp_add<0xB1, 0xf>(p);   // quad_perm [1,0,3,2]
+        p = dpp_add<0x4E, 0xf>(p);   // quad_perm [2,3,0,1]: every lane of the quad holds the sum over the 16 rows
+        if (rd_q == 0) myslice[jp - jbeg + rd_jj] = p;
+    };
     // the column sweep, specialised at compile time (branches inside the loop would fence the scheduler between the
     // eight exp evaluations of a step): MODE 0 off-diagonal pair (column sums), 1 diagonal pair with the iK stream,
     // 2 diagonal pair without it (RBF policy GP)
@@ -214,30 +226,38 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
                     double wl[4];
     #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        double wgt = brow[rt] * bcol[r];
-                        if (MODE == 1) wgt -= buf_ld(rIK, ik_off[rt][r], (unsigned)(j0 - jbeg) * (unsigned)npad * 8u);   // iK symmetric: coalesced along the rows
-                        wl[r] = wgt * fexp(VSEP ? e[r] + vj[r] : e[r], tab);
-                        csum[r] += wl[r];
+                        if (MODE == 0) {
+                            // off-diagonal pair: W = beta_a beta_b^T is separable -- the row side carries beta_b,j only and
+                            // the column side beta_a,i only (one multiply and one FMA instead of two multiplies and an
+                            // add); k_mm_bwd_post applies the missing factor per row / per column
+                            const double l = fexp(VSEP ? e[r] + vj[r] : e[r], tab);
+                            wl[r] = bcol[r] * l;
+                            csum[r] = fma(brow[rt], l, csum[r]);
+                        } else {
+                            double wgt = brow[rt] * bcol[r];
+                            if (MODE == 1) wgt -= buf_ld(rIK, ik_off[rt][r], (unsigned)(j0 - jbeg) * (unsigned)npad * 8u);   // iK symmetric: coalesced along the rows
+                            wl[r] = wgt * fexp(VSEP ? e[r] + vj[r] : e[r], tab);
+                        }
                     }
     #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[r], wl[r], acc[rt], 0, 0, 0);
                 }
                 if (MODE == 0) {
+                    // column sums over the wave's 16 lanes of a DPP row, through a per-wave LDS scratch instead of four
+                    // DPP row shifts per register (12 VALU ops each on the pipe this kernel is bound by): the partial sums
+                    // of the PREVIOUS column step are read back four at a time, added and finished with two quad
+                    // permutes (9 VALU ops per step instead of 48); LDS operations of one wave execute in order
+                    if (jprev >= 0) flush_cols(jprev);
     #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        double v = csum[r];
-                        v = dpp_add<0x111, 0xf>(v);
-                        v = dpp_add<0x112, 0xf>(v);
-                        v = dpp_add<0x114, 0xf>(v);
-                        v = dpp_add<0x118, 0xf>(v);   // lane 15 of every DPP row: sum over the 16 rows i
-                        if (lc == 15) myslice[j0 - jbeg + lr + 4 * r] = v;
-                    }
+                    for (int r = 0; r < 4; ++r) scr[r * 64 + lane] = csum[r];
+                    jprev = j0;
                 }
             }
             if (more) stage_store(stg + (cur ^ 1) * SB, sg);
             __syncthreads();
             cur ^= 1;
         }
+        if (MODE == 0 && jprev >= 0) flush_cols(jprev);
     };
     if (!diag) sweep(std::integral_constant<int, 0>{});
     else if (iKa) sweep(std::integral_constant<int, 1>{});
@@ -263,7 +283,7 @@ __global__ __launch_bounds__(256) void k_mm_bwd_pair(MMModel md, MMWork wk, doub
 #pragma unroll
         for (int rt = 0; rt < BWD_RT; ++rt) {
             const double x = rsel == 0 ? acc[rt][0] : rsel == 1 ? acc[rt][1] : rsel == 2 ? acc[rt][2] : acc[rt][3];
-            v += (lr == (D & 3) && ibase + 16 * rt < npad) ? x : 0.0;   // tiles past the padding carry iK garbage and are never stored
+            v += (lr == (D & 3) && ibase + 16 * rt < npad) ? (diag ? x : x * brow[rt]) : 0.0;   // tiles past the padding carry garbage and are never stored
         }
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
         if (lane == 0) nred[w] = v;
@@ -515,6 +535,8 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
     local_pair_ab(wk, E, pl, a, b);
     const double* mom0 = rowmom + (long)pl * njs * 16 * npad;
     const double* cp = (a != b) ? cpart + (long)(pl - wk.EL) * nrb * npad : nullptr;
+    const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
+    const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
     const int LD = D | 1;         // odd row stride: the (d, e) readers of one point spread over the banks
     double* zs = sm;              // [64][LD]
     double* ws = zs + 64 * LD;    // [64][LD]
@@ -544,8 +566,10 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
             zs[ii * LD + d] = zeta * ia[d];
             ws[ii * LD + d] = zeta * ib[d];
             double mv = 0.0;
-            if (valid)
+            if (valid) {
                 mv = sum_strided<4>(mom0 + (long)d * npad + i, (long)16 * npad, njs);
+                if (cp) mv *= beta_a[i];   // off-diagonal pair: the sweep left beta_a,i out of the row side
+            }
             ms[ii * LD + d] = mv;
         }
         if (t < 64) {
@@ -554,10 +578,12 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
             double r = 0.0, c = 0.0;
             if (valid) {
                 r = sum_strided<4>(mom0 + (long)D * npad + i, (long)16 * npad, njs);
-                if (cp)
-                    c = sum_strided<8>(cp + i, npad, nrb);
-                else
+                if (cp) {
+                    r *= beta_a[i];
+                    c = sum_strided<8>(cp + i, npad, nrb) * beta_b[i];   // ... and beta_b,j out of the column side
+                } else {
                     c = r;
+                }
             }
             rs[t] = r;
             cs[t] = c;
@@ -814,7 +840,7 @@ void launch_mm_sweep(hipStream_t st, const MMModel& md, const MMWork& wk, double
     const int nhead = E + P, per_row = nrb * njs;
     dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);
     const int nI = D * D;
-    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * BWD_TP + 2 * BWD_CH), (size_t)4 * nI + D);
+    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * BWD_TP + 2 * BWD_CH) + 4 * 256, (size_t)4 * nI + D);
     const double* bars = nullptr;
 #define PB(K_)                                                                                                       \
     do {                                                                                                             \
@@ -875,7 +901,7 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
     const int nhead = E + P, per_row = nrb * njs;
     dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);   // the rows past P hold the head workgroups
     const int LD = D | 1, nI = D * D;
-    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * BWD_TP + 2 * BWD_CH), (size_t)4 * nI + D);
+    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * BWD_TP + 2 * BWD_CH) + 4 * 256, (size_t)4 * nI + D);
     double* npart = nullptr;
 #define PB(K_)                                                                                                       \
     do {                                                                                                             \

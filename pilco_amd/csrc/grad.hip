@@ -639,6 +639,8 @@ int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_re
     // the reverse sweep below is host algebra only.  PILCO_GRAD_MODE=0 / pilco_set_grad_mode(ctx, 0): plain tape, and
     // the O(N^2) adjoint of every step on the device again (pilco_gp_predict_vjp) -- the two agree to rounding.
     bool jac = ctx->grad_mode != 0;
+    const bool timing = getenv("PILCO_GRAD_TIMING") != nullptr;   // developer aid: forward / reverse split on stderr
+    const auto tm0 = std::chrono::steady_clock::now();
     vec mH(E), SH((size_t)E * E), traj_v, tape_v;
     const double *traj = nullptr, *tape = nullptr, *jrec = nullptr;
     size_t JS = 0;
@@ -655,6 +657,7 @@ int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_re
         traj = traj_v.data();
         tape = tape_v.data();
     }
+    const auto tm1 = std::chrono::steady_clock::now();
     vec e(U);
     for (int u = 0; u < U; ++u) e[u] = policy->max_action[u];
     vec mbar(E, 0.0), sbar((size_t)E * E, 0.0);
@@ -738,6 +741,11 @@ int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_re
         mbar = mxb;
         for (int i = 0; i < E; ++i)
             for (int j = 0; j < E; ++j) sbar[(size_t)i * E + j] = 0.5 * (sxb[(size_t)i * E + j] + sxb[(size_t)j * E + i]);
+    }
+    if (timing) {
+        const auto tm2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pilco grad] forward (device + download) %.3f ms, reverse sweep %.3f ms, mode %d\n",
+                std::chrono::duration<double, std::milli>(tm1 - tm0).count(), std::chrono::duration<double, std::milli>(tm2 - tm1).count(), jac ? 1 : 0);
     }
     return PILCO_OK;
 }
