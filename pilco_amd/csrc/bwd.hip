@@ -684,10 +684,11 @@ __device__ void bwd_fin_pairs(const MMModel& md, const MMWork& wk, const double*
 }
 
 // ---- Jacobian tape, last stage: one record per pair and per output (layout: mm_jac_rec_size)
-//   pair pl:   N_ab | g = rdet P A (D) | G = rdet (P I P^T / 2 - N (P Lambda + Lambda P^T) / 4) (D x D),  rdet = 1 / sqrt(det R_ab)
-//              => a cotangent Shat_ab of S_ab contributes  mbar += Shat g,  sbar += Shat G   (before symmetrisation)
-//   output a:  dM/dm (D) | dM/ds (D x D) | dV_k/dm (D x D: [k][r]) | dV_k/ds (D x D x D: [k][r][c])
+//   pair pl:   N_ab | g = rdet P A (D) | sym G, G = rdet (P I P^T / 2 - N (P Lambda + Lambda P^T) / 4),  rdet = 1 / sqrt(det R_ab)
+//              => a cotangent Shat_ab of S_ab contributes  mbar += Shat g,  sbar += Shat sym G
+//   output a:  dM/dm (D) | sym dM/ds | dV_k/dm (D x D: [k][r]) | sym dV_k/ds (D of them: [k][..])
 //              => cotangents (mu_a, Vbar_a) contribute  mbar += mu dM/dm + sum_k Vbar_k dV_k/dm,  sbar likewise
+// every symmetric D x D matrix is stored packed: (X + X^T) / 2 at [c (c + 1) / 2 + r], r <= c  (D (D + 1) / 2 doubles)
 // and N_ab in the layout the pack stage of the serial link reads tile partials in (pair_n[pl][2], NT = 1).
 __device__ void jac_fin_output(const MMModel& md, const double* __restrict__ head, int a, int nrc,
                                const double* __restrict__ mpart, double* __restrict__ rec, double* sm) {
@@ -737,21 +738,32 @@ __device__ void jac_fin_output(const MMModel& md, const double* __restrict__ hea
         Z3[e] = acc;
     }
     __syncthreads();
-    double* dMdm = rec;
-    double* dMds = rec + D;
-    double* dVdm = dMds + nI;
-    double* dVds = dVdm + nI;
-    if (t < D) dMdm[t] = c * Th[t];
-    for (int e = t; e < nI; e += 256) {
-        const int r = e / D, cc = e - r * D;
-        dMds[e] = -0.5 * c * g * T[e] + 0.5 * c * THT[e];
-        dVdm[e] = c * (THT[cc * D + r] - g * T[cc * D + r]);     // [k = r][row = cc]: (T H2 T)[cc][k] - g T[cc][k]
-    }
+    // full dV_k/ds into W3 (dead by now), then everything symmetric goes out packed: X -> (X + X^T) / 2 at [c (c + 1) / 2 + r],
+    // r <= c (the caller symmetrises the sum anyway; half the bytes to download and to stream through the host)
     for (int e = t; e < n3; e += 256) {
         const int k = e / nI, r = (e / D) % D, cc = e % D;
         double acc = 0.0;
         for (int e2 = 0; e2 < D; ++e2) acc = fma(Z3[(k * D + r) * D + e2], T[e2 * D + cc], acc);
-        dVds[e] = -0.5 * c * Th[k] * T[r * D + cc] + 0.5 * c * acc - 0.5 * c * (T[r * D + k] * Th[cc] + Th[r] * T[cc * D + k]);
+        W3[e] = -0.5 * c * Th[k] * T[r * D + cc] + 0.5 * c * acc - 0.5 * c * (T[r * D + k] * Th[cc] + Th[r] * T[cc * D + k]);
+    }
+    __syncthreads();
+    const int NT2 = D * (D + 1) / 2;
+    double* dMdm = rec;
+    double* dMds = rec + D;
+    double* dVdm = dMds + NT2;
+    double* dVds = dVdm + nI;
+    if (t < D) dMdm[t] = c * Th[t];
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, cc = e - r * D;
+        dVdm[e] = c * (THT[cc * D + r] - g * T[cc * D + r]);     // [k = r][row = cc]: (T H2 T)[cc][k] - g T[cc][k]
+        if (r <= cc) {
+            const double x = -0.5 * c * g * T[e] + 0.5 * c * THT[e], y = -0.5 * c * g * T[cc * D + r] + 0.5 * c * THT[cc * D + r];
+            dMds[cc * (cc + 1) / 2 + r] = 0.5 * (x + y);
+        }
+    }
+    for (int e = t; e < n3; e += 256) {
+        const int k = e / nI, r = (e / D) % D, cc = e % D;
+        if (r <= cc) dVds[(long)k * NT2 + cc * (cc + 1) / 2 + r] = 0.5 * (W3[(k * D + r) * D + cc] + W3[(k * D + cc) * D + r]);
     }
 }
 
@@ -760,14 +772,14 @@ __global__ __launch_bounds__(256) void k_mm_jac_fin(MMModel md, MMWork wk, const
                                                    double* __restrict__ jrec, long jstride, BwdBatch bb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x, z = blockIdx.y;
-    const int nI = D * D, rec = 1 + D + nI;
+    const int nI = D * D, rec = 1 + D + nI, NT2 = D * (D + 1) / 2, recp = 1 + D + NT2;
     part += (long)z * bb.part;
     mpart += (long)z * bb.part;
     head += (long)z * bb.head;
     jrec += (long)z * jstride;
     if (pl >= wk.PL) {
         const int a = pl - wk.PL;
-        jac_fin_output(md, head, a, nrc, mpart, jrec + (long)wk.PL * rec + (long)a * (D + 2 * nI + nI * D), sm);
+        jac_fin_output(md, head, a, nrc, mpart, jrec + (long)wk.PL * recp + (long)a * (D + NT2 + nI + D * NT2), sm);
         return;
     }
     double* Pm = sm;               // [D][D]
@@ -789,14 +801,21 @@ __global__ __launch_bounds__(256) void k_mm_jac_fin(MMModel md, MMWork wk, const
         PI[e] = acc;
     }
     __syncthreads();
-    double* o = jrec + (long)pl * rec;
-    if (t == 0) o[0] = Nab;
+    // G = rdet (P I P^T / 2 - N (P Lambda + Lambda P^T) / 4) into Pm's neighbour PI2, then packed symmetric
+    double* Gf = PI + nI;          // [D][D]
     for (int e = t; e < nI; e += 256) {
         const int r = e / D, c = e - r * D;
         double acc = 0.0;
         for (int k = 0; k < D; ++k) acc = fma(PI[r * D + k], Pm[c * D + k], acc);   // (P I P^T)[r][c]
         const double pl2 = Pm[r * D + c] * lam[c] + Pm[c * D + r] * lam[r];         // P Lambda + Lambda P^T
-        o[1 + D + e] = rdet * (0.5 * acc - 0.25 * Nab * pl2);
+        Gf[e] = rdet * (0.5 * acc - 0.25 * Nab * pl2);
+    }
+    __syncthreads();
+    double* o = jrec + (long)pl * recp;
+    if (t == 0) o[0] = Nab;
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, c = e - r * D;
+        if (r <= c) o[1 + D + c * (c + 1) / 2 + r] = 0.5 * (Gf[e] + Gf[c * D + r]);
     }
     if (t >= 256 - D) {
         const int r = t - (256 - D);
@@ -806,7 +825,10 @@ __global__ __launch_bounds__(256) void k_mm_jac_fin(MMModel md, MMWork wk, const
     }
 }
 
-size_t mm_jac_rec_size(int D, int E, int P) { return (size_t)P * (1 + D + D * D) + (size_t)E * (D + 2 * D * D + D * D * D); }
+size_t mm_jac_rec_size(int D, int E, int P) {
+    const size_t NT2 = (size_t)D * (D + 1) / 2;
+    return (size_t)P * (1 + D + NT2) + (size_t)E * (D + NT2 + (size_t)D * D + D * NT2);
+}
 size_t mm_jac_part_size(int D, int E, int P, int npad) {
     return (size_t)P * mm_bwd_rc(npad) * (1 + D + D * D) + (size_t)E * mm_bwd_rc(npad) * mm_jac_ns(D);
 }
@@ -880,7 +902,7 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
     const size_t lds_post = sizeof(double) * std::max((size_t)3 * 64 * LD + 128 + 3 * D, (size_t)nI + 64 * LD1 + 64 + NS / 2 + 2);
     hipLaunchKernelGGL(k_mm_bwd_post, dim3(P + E, nrc, H), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
                        head, mpart, 1, bb);
-    const size_t lds_fin = sizeof(double) * std::max((size_t)3 * nI + 4 * D + 8, (size_t)3 * nI + NS + D + 2 * nI * D);
+    const size_t lds_fin = sizeof(double) * std::max((size_t)4 * nI + 4 * D + 8, (size_t)3 * nI + NS + D + 2 * nI * D);
     hipLaunchKernelGGL(k_mm_jac_fin, dim3(P + E, H), dim3(256), lds_fin, st, md, wk, part, nrc, head, mpart, jrec,
                        (long)mm_jac_rec_size(D, E, P), bb);
 }

@@ -593,42 +593,42 @@ struct RbfAdj : PolicyAdj {
 // (controllers.py:13-36), rewards (rewards.py:19-81); the moment-matching adjoint of every step on the device.
 // Host contraction of one step's Jacobian records (bwd.hip: k_mm_jac_fin) with the cotangents of the step's outputs:
 // what pilco_gp_predict_vjp computes on the device, without touching the device.  M (E): the step's GP means (tape).
-void jac_vjp(const double* jr, int D, int E, const double* M, const double* Mbar, const double* Sbar, const double* Vbar,
+void jac_vjp(const double* __restrict__ jr, int D, int E, const double* M, const double* Mbar, const double* Sbar, const double* Vbar,
              double* mbar, double* sbar, vec& acc) {
-    const int nI = D * D, recp = 1 + D + nI, P = E * (E + 1) / 2;
-    acc.assign((size_t)D + nI, 0.0);
-    double* am = acc.data();
+    const int nI = D * D, NT2 = D * (D + 1) / 2, recp = 1 + D + NT2, P = E * (E + 1) / 2;
+    acc.assign((size_t)D + NT2, 0.0);
+    double* __restrict__ am = acc.data();
     // pairs in the dealing order: (0,0) .. (E-1,E-1), (1,0), (2,0), (2,1), ...
     int pl = 0;
     auto add_pair = [&](int a, int b) {
         const double shat = (a == b) ? Sbar[(size_t)a * E + a] : Sbar[(size_t)a * E + b] + Sbar[(size_t)b * E + a];
-        const double* r = jr + (size_t)pl * recp + 1;
+        const double* __restrict__ r = jr + (size_t)pl * recp + 1;
         if (shat != 0.0)
-            for (int e = 0; e < D + nI; ++e) am[e] += shat * r[e];
+            for (int e = 0; e < D + NT2; ++e) am[e] += shat * r[e];
         ++pl;
     };
     for (int a = 0; a < E; ++a) add_pair(a, a);
     for (int a = 1; a < E; ++a)
         for (int b = 0; b < a; ++b) add_pair(a, b);
     const double* jo = jr + (size_t)P * recp;
-    const size_t reco = (size_t)D + 2 * nI + (size_t)nI * D;
+    const size_t reco = (size_t)D + NT2 + nI + (size_t)D * NT2;
     for (int a = 0; a < E; ++a) {
         double mu = Mbar[a];
         for (int b = 0; b < E; ++b) mu -= (Sbar[(size_t)a * E + b] + Sbar[(size_t)b * E + a]) * M[b];
-        const double* r = jo + (size_t)a * reco;
-        for (int e = 0; e < D + nI; ++e) am[e] += mu * r[e];            // dM/dm | dM/ds are contiguous
-        const double* dVdm = r + D + nI;
-        const double* dVds = dVdm + nI;
+        const double* __restrict__ r = jo + (size_t)a * reco;
+        for (int e = 0; e < D + NT2; ++e) am[e] += mu * r[e];            // dM/dm | sym dM/ds are contiguous
+        const double* __restrict__ dVdm = r + D + NT2;
+        const double* __restrict__ dVds = dVdm + nI;
         for (int k = 0; k < D; ++k) {
             const double vb = Vbar[(size_t)k * E + a];
             if (vb == 0.0) continue;
             for (int e = 0; e < D; ++e) am[e] += vb * dVdm[(size_t)k * D + e];
-            for (int e = 0; e < nI; ++e) am[D + e] += vb * dVds[(size_t)k * nI + e];
+            for (int e = 0; e < NT2; ++e) am[D + e] += vb * dVds[(size_t)k * NT2 + e];
         }
     }
     for (int d = 0; d < D; ++d) mbar[d] = am[d];
-    for (int r = 0; r < D; ++r)
-        for (int c = 0; c < D; ++c) sbar[(size_t)r * D + c] = 0.5 * (am[D + (size_t)r * D + c] + am[D + (size_t)c * D + r]);
+    for (int c = 0; c < D; ++c)
+        for (int r = 0; r <= c; ++r) sbar[(size_t)r * D + c] = sbar[(size_t)c * D + r] = am[D + (size_t)c * (c + 1) / 2 + r];
 }
 
 int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
