@@ -267,7 +267,8 @@ __global__ __launch_bounds__(256, 4) void k_mm_bwd_pair(MMModel md, MMWork wk, d
     for (int rt = 0; rt < BWD_RT; ++rt)
         if (ibase + 16 * rt < npad) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(long)(lr + 4 * r) * npad + irow[rt]] = acc[rt][r];
+            for (int r = 0; r < 4; ++r)
+                if (lr + 4 * r <= D) out[(long)(lr + 4 * r) * npad + irow[rt]] = acc[rt][r];   // rows past D are never read
         }
     if (!diag) {
         __syncthreads();
@@ -554,6 +555,12 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
         ib[t] = 1.0 / (lb * lb);
         mm[t] = in_m[t];
     }
+    const int NT2 = D * (D + 1) / 2, per = NT2 + D + 1;          // I (packed) | A | N
+    const int NG = per <= 85 ? 3 : per <= 128 ? 2 : 1;           // thread groups sharing the points of a block
+    const int grp = t / per, idx = t - grp * per;
+    int pd = 0;
+    while (idx < NT2 && (pd + 1) * (pd + 2) / 2 <= idx) ++pd;    // idx = pd (pd + 1) / 2 + pe, pe <= pd
+    const int pe = idx < NT2 ? idx - pd * (pd + 1) / 2 : 0;
     double acc = 0.0;
     for (int blk = rc; blk < nblk; blk += nrc) {
         const int i0 = blk * 64;
@@ -589,26 +596,43 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
             cs[t] = c;
         }
         __syncthreads();
-        if (t < nI) {
-            const int d = t / D, e2 = t - d * D;
-            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) {
-                const double zd = zs[ii * LD + d], ze = zs[ii * LD + e2];
-                acc = fma(rs[ii] * zd, ze, acc);
-                acc = fma(cs[ii] * ws[ii * LD + d], ws[ii * LD + e2], acc);
-                acc = fma(zd, ms[ii * LD + e2], acc);
-                acc = fma(ms[ii * LD + d], ze, acc);
+        // I is symmetric: only d >= e2 is accumulated (NT2 entries), and the 64 points of the block are dealt over NG
+        // thread groups whose partial sums are added in a fixed order at the end
+        if (grp < NG) {
+            const int ii0 = grp * 64 / NG, ii1 = (grp + 1) * 64 / NG;
+            if (idx < NT2) {
+                for (int ii = ii0; ii < ii1; ++ii) {
+                    const double zd = zs[ii * LD + pd], ze = zs[ii * LD + pe];
+                    acc = fma(rs[ii] * zd, ze, acc);
+                    acc = fma(cs[ii] * ws[ii * LD + pd], ws[ii * LD + pe], acc);
+                    acc = fma(zd, ms[ii * LD + pe], acc);
+                    acc = fma(ms[ii * LD + pd], ze, acc);
+                }
+            } else if (idx < NT2 + D) {
+                const int d = idx - NT2;
+                for (int ii = ii0; ii < ii1; ++ii) acc = fma(rs[ii], zs[ii * LD + d], fma(cs[ii], ws[ii * LD + d], acc));
+            } else {
+                for (int ii = ii0; ii < ii1; ++ii) acc += rs[ii];
             }
-        } else if (t < nI + D) {
-            const int d = t - nI;
-            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc = fma(rs[ii], zs[ii * LD + d], fma(cs[ii], ws[ii * LD + d], acc));
-        } else if (t == nI + D) {
-            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc += rs[ii];
         }
     }
-    double* o = part + ((long)pl * nrc + rc) * (1 + D + nI);
-    if (t < nI) o[1 + D + t] = acc;
-    else if (t < nI + D) o[1 + (t - nI)] = acc;
-    else if (t == nI + D) o[0] = acc;
+    __syncthreads();
+    double* red = zs;   // [NG][per]
+    if (grp < NG) red[grp * per + idx] = acc;
+    __syncthreads();
+    if (t < per) {
+        double v = red[t];
+        for (int g2 = 1; g2 < NG; ++g2) v += red[g2 * per + t];
+        double* o = part + ((long)pl * nrc + rc) * (1 + D + nI);
+        if (t < NT2) {
+            o[1 + D + pd * D + pe] = v;
+            o[1 + D + pe * D + pd] = v;
+        } else if (t < NT2 + D) {
+            o[1 + (t - NT2)] = v;
+        } else {
+            o[0] = v;
+        }
+    }
 }
 
 // Per pair, with P = (I + Lambda s)^-1 and kappa = Shat_ab / sqrt(det R_ab) from the step's head record:
