@@ -158,7 +158,7 @@ int pilco_reward_eval(pilco_ctx* ctx, const pilco_reward_term* rewards, int n_re
  * The reference differentiates training_loss with TensorFlow's autodiff (pilco/models/pilco.py:85-90);
  * here the adjoint of the moment-matching step is hand-derived.
  * pilco_gp_predict_vjp: cotangents Mbar (1,E), Sbar (E,E), Vbar (D,E) of pilco_gp_predict's outputs ->
- * mbar (1,D), sbar (D,D, symmetric) at the input (m, s).  Single rank, D <= 14.
+ * mbar (1,D), sbar (D,D, symmetric) at the input (m, s).  Single rank, D <= 32.
  * pilco_rollout_tape: pilco_rollout that also returns, per step, the joint Gaussian handed to the
  * dynamics GP (m (D), s (D,D), s1 (E,D)) and its outputs (M (E), S (E,E), V (D,E)). */
 int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double* s, const double* Mbar,
@@ -191,6 +191,8 @@ int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_
 int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32);
 /* per-workgroup (start, end) stamps of the last prep launch, n values (developer aid) */
 int pilco_debug_blocks(pilco_ctx* ctx, unsigned long long* out, int n);
+/* developer aid: raw copy of a work buffer (0 row operands At, 1 column operands Bt, 2 reverse-pass row moments, 3 column sums, 4 beta) */
+int pilco_debug_buffer(pilco_ctx* ctx, int slot, int which, double* out, long n);
 /* Stream-K work split of the pair kernel (pure host functions, no GPU): the column steps of nd diagonal pairs (tdiag
  * steps each, cost ud) and n_pairs - nd off-diagonal pairs (toff steps, cost uo) lie on one line cut into `waves` equal
  * cost ranges.  pilco_debug_sk_boundary: first step of wave w (w = waves: the total).  pilco_debug_sk_pair_waves:

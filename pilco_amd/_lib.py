@@ -87,6 +87,7 @@ SIGNATURES = {
     "pilco_factorize_timed": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "pilco_debug_timestamps": (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
     "pilco_debug_blocks": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.c_int]),
+    "pilco_debug_buffer": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_long]),
     "pilco_debug_sk_boundary": (C.c_int, [C.c_int] * 8),
     "pilco_debug_sk_pair_waves": (C.c_int, [C.c_int] * 8 + [C.POINTER(C.c_int)]),
     "pilco_comm_unique_id": (C.c_int, [_vp]),

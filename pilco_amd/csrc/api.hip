@@ -675,6 +675,17 @@ int pilco_factorize_timed(pilco_ctx* ctx, int slot, int reps, float* ms_each) {
     return PILCO_OK;
 }
 
+// developer aid (tools/): raw copy of a device work buffer of a slot -- 0 At, 1 Bt, 2 reverse-pass row moments, 3 column sums, 4 beta
+int pilco_debug_buffer(pilco_ctx* ctx, int slot, int which, double* out, long n) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    const double* src = which == 0 ? s.wk.At : which == 1 ? s.wk.Bt : which == 2 ? s.bwd_mom.p : which == 3 ? s.bwd_cp.p : s.beta.p;
+    if (!src || !out || n <= 0) return fail(ctx, PILCO_E_SHAPE, "debug_buffer: bad arguments");
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipMemcpy(out, src, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return PILCO_OK;
+}
+
 int pilco_debug_blocks(pilco_ctx* ctx, unsigned long long* out, int n) {
     if (!ctx || !ctx->dbg || !out || n <= 0 || n > 4032) return PILCO_E_SHAPE;
     HIPCHK(hipStreamSynchronize(ctx->st));

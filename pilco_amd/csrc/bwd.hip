@@ -19,7 +19,7 @@ namespace pilco {
 #define BWD_RT 2
 #endif
 constexpr int BWD_CH = 64;   // columns staged per LDS chunk (one wave-wide row segment)
-constexpr int BWD_TP = 17;   // pitch of the staged column-major tile (doubles): KP <= 16 rows + 1, conflict-free
+__host__ __device__ constexpr int bwd_tp(int kp) { return kp <= 16 ? 17 : kp + 1; }   // pitch of the staged column-major tile (doubles): operand rows + 1 (odd: conflict-free)
 // sum_{q < n} base[q * stride] with the loads of a batch of B issued together (a plain loop serialises one global
 // latency per term: these kernels are latency-bound); fixed summation order
 template <int B>
@@ -68,7 +68,7 @@ __device__ void bwd_head(const MMModel& md, const MMWork& wk, const double* __re
     }
     double det;
     const double* G = gauss_jordan(G0, G1, D, nc, det);   // inverse in G[:, D:]
-    if (t < nI) o[t] = G[(t / D) * nc + D + (t % D)];
+    for (int e = t; e < nI; e += 256) o[e] = G[(e / D) * nc + D + (e % D)];
     if (h < E) {
         if (t < D) {
             double acc = 0.0;
@@ -98,8 +98,13 @@ __device__ void bwd_head(const MMModel& md, const MMWork& wk, const double* __re
     }
 }
 
-template <int KC, bool VSEP>
-__global__ __launch_bounds__(256, 4) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ rowmom,
+// NMT: 16-row tiles of the moment product (rows d = 0..D: w_j and the ones), NMT = ceil((D + 1) / 16); KC <= 4 keeps four
+// waves per SIMD, wider contractions run at two
+template <int KC, bool VSEP, int NMT>
+#ifndef BWD_LBW
+#define BWD_LBW 2
+#endif
+__global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ rowmom,
                                                     double* __restrict__ cpart, int njs, const double* __restrict__ bars,
                                                     double* __restrict__ head, double* __restrict__ npart) {
     __shared__ double tab[FEXP_TN];
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256, 4) void k_mm_bwd_pair(MMModel md, MMWork wk, d
     // transpose a2 (M = operand row, K = column) -- without bank conflicts (pitch 17 doubles); the next chunk is in
     // flight in registers while the current one is evaluated.  Only the iK stream of a diagonal pair stays a per-wave
     // buffer load.
-    constexpr int KPc = 4 * KC, NR = KPc + (VSEP ? 2 : 1), NST = (NR + 3) / 4, SB = BWD_CH * BWD_TP + 2 * BWD_CH;
+    constexpr int KPc = 4 * KC, NR = KPc + (VSEP ? 2 : 1), NST = (NR + 3) / 4, BWD_TP = bwd_tp(KPc), SB = BWD_CH * BWD_TP + 2 * BWD_CH;
     const __amdgpu_buffer_rsrc_t rIK = buf_rsrc(iKa ? iKa + (long)jbeg * npad : Bt);
     const double* vsrc = VSEP ? wk.vcol + (long)pl * npad : Bt;
     unsigned ik_off[BWD_RT][4];
@@ -153,8 +158,9 @@ __global__ __launch_bounds__(256, 4) void k_mm_bwd_pair(MMModel md, MMWork wk, d
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int rt = 0; rt < BWD_RT; ++rt) ik_off[rt][r] = ((unsigned)(lr + 4 * r) * (unsigned)npad + (unsigned)irow[rt]) * 8u;
-    const int dsel = lc <= D ? lc : D;   // operand rows contracted by the second product: w_j (d < D), the ones (d = D);
-                                         // lanes past that repeat row D: their result rows (d > D of rowmom) are never read
+    int dsel[NMT];                       // operand rows contracted by the second product: w_j (d < D), the ones (d = D);
+#pragma unroll                           // lanes past that repeat row D: their result rows (d > D of rowmom) are never read
+    for (int m = 0; m < NMT; ++m) dsel[m] = 16 * m + lc <= D ? 16 * m + lc : D;
     double* stg = csl + 4 * jws;         // [2][SB]
     auto stage_load = [&](int jc, double (&sg)[NST]) {
 #pragma unroll
@@ -172,13 +178,15 @@ __global__ __launch_bounds__(256, 4) void k_mm_bwd_pair(MMModel md, MMWork wk, d
             else if (row < NR) buf[BWD_CH * BWD_TP + (row - KPc) * BWD_CH + lane] = sg[k];
         }
     };
-    d4 acc[BWD_RT];
+    d4 acc[BWD_RT][NMT];
 #pragma unroll
-    for (int rt = 0; rt < BWD_RT; ++rt) acc[rt] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int rt = 0; rt < BWD_RT; ++rt)
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) acc[rt][m] = d4{0.0, 0.0, 0.0, 0.0};
     double* myslice = csl + w * jws;
     // column-sum scratch of this wave: [4 result registers][64 lanes]; reader lane = (column jj = lane / 4, quarter q = lane % 4)
     // takes the four partials of lanes lc = 4 q .. 4 q + 3 of DPP row lr = jj % 4, register jj / 4
-    double* scr = csl + 4 * jws + 2 * (BWD_CH * BWD_TP + 2 * BWD_CH) + w * 256;
+    double* scr = csl + 4 * jws + 2 * SB + w * 256;
     const int rd_jj = lane >> 2, rd_q = lane & 3;
     const double* rd_src = scr + (rd_jj >> 2) * 64 + (rd_jj & 3) * 16 + 4 * rd_q;
     int jprev = -1;
@@ -207,14 +215,15 @@ __global__ __launch_bounds__(256, 4) void k_mm_bwd_pair(MMModel md, MMWork wk, d
             const int nst = min(BWD_CH, jend - jc);
             for (int jl = 0; jl < nst; jl += 16) {
                 const int j0 = jc + jl;
-                double cf[KC], a2[4], bcol[4], vj[4];
+                double cf[KC], a2[NMT][4], bcol[4], vj[4];
     #pragma unroll
                 for (int c = 0; c < KC; ++c) cf[c] = Tb[(jl + lc) * BWD_TP + 4 * c + lr];
     #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     bcol[r] = bS[jl + lr + 4 * r];
                     vj[r] = VSEP ? vS[jl + lr + 4 * r] : 0.0;   // transposed tile: v_j runs along the result registers
-                    a2[r] = Tb[(jl + 4 * r + lr) * BWD_TP + dsel];
+#pragma unroll
+                    for (int m = 0; m < NMT; ++m) a2[m][r] = Tb[(jl + 4 * r + lr) * BWD_TP + dsel[m]];
                 }
                 double csum[4] = {0.0, 0.0, 0.0, 0.0};
     #pragma unroll
@@ -223,6 +232,12 @@ __global__ __launch_bounds__(256, 4) void k_mm_bwd_pair(MMModel md, MMWork wk, d
     #pragma unroll
                     for (int c = 0; c < KC; ++c)
                         e = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[c], rf[rt][c], e, 0, 0, 0);   // e[r]: i = irow, j = j0+lr+4r
+                    MFMA_KEEP_ALIVE(cf[0]);      // (the first MFMA of the chain has a constant-zero accumulator)
+                    MFMA_KEEP_ALIVE(rf[rt][0]);
+                    // this hipcc leaves the instantiations below without the wait states (the K = D + 1 ones with one moment
+                    // tile get them: there the fence would only cost its 11 slots twice per step); tests/test_build_isa.py
+                    // scans the generated code of ALL instantiations for reads that come too early
+                    if (!VSEP || KC > 4 || NMT > 1) MFMA_RESULT_FENCE(e);
                     double wl[4];
     #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -240,17 +255,31 @@ __global__ __launch_bounds__(256, 4) void k_mm_bwd_pair(MMModel md, MMWork wk, d
                         }
                     }
     #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[r], wl[r], acc[rt], 0, 0, 0);
+                    for (int m = 0; m < NMT; ++m)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[rt][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[m][r], wl[r], acc[rt][m], 0, 0, 0);
                 }
                 if (MODE == 0) {
                     // column sums over the wave's 16 lanes of a DPP row, through a per-wave LDS scratch instead of four
                     // DPP row shifts per register (12 VALU ops each on the pipe this kernel is bound by): the partial sums
                     // of the PREVIOUS column step are read back four at a time, added and finished with two quad
                     // permutes (9 VALU ops per step instead of 48); LDS operations of one wave execute in order
+#ifdef BWD_DPP_COLS
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double v = csum[r];
+                        v = dpp_add<0x111, 0xf>(v);
+                        v = dpp_add<0x112, 0xf>(v);
+                        v = dpp_add<0x114, 0xf>(v);
+                        v = dpp_add<0x118, 0xf>(v);
+                        if (lc == 15) myslice[j0 - jbeg + lr + 4 * r] = v;
+                    }
+#else
                     if (jprev >= 0) flush_cols(jprev);
     #pragma unroll
                     for (int r = 0; r < 4; ++r) scr[r * 64 + lane] = csum[r];
                     jprev = j0;
+#endif
                 }
             }
             if (more) stage_store(stg + (cur ^ 1) * SB, sg);
@@ -262,13 +291,15 @@ __global__ __launch_bounds__(256, 4) void k_mm_bwd_pair(MMModel md, MMWork wk, d
     if (!diag) sweep(std::integral_constant<int, 0>{});
     else if (iKa) sweep(std::integral_constant<int, 1>{});
     else sweep(std::integral_constant<int, 2>{});
-    double* out = rowmom + ((long)pl * njs + js) * 16 * npad;
+    double* out = rowmom + ((long)pl * njs + js) * (16 * NMT) * npad;
 #pragma unroll
     for (int rt = 0; rt < BWD_RT; ++rt)
         if (ibase + 16 * rt < npad) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (lr + 4 * r <= D) out[(long)(lr + 4 * r) * npad + irow[rt]] = acc[rt][r];   // rows past D are never read
+            for (int m = 0; m < NMT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * m + lr + 4 * r <= D) out[(long)(16 * m + lr + 4 * r) * npad + irow[rt]] = acc[rt][m][r];   // rows past D are never read
         }
     if (!diag) {
         __syncthreads();
@@ -279,11 +310,14 @@ __global__ __launch_bounds__(256, 4) void k_mm_bwd_pair(MMModel md, MMWork wk, d
     if (npart) {
         // Jacobian tape: this workgroup's share of N_ab = sum_i r_i, in the [pair][tile][2] layout the serial link packs
         // tile partials from (tile = js * row blocks + rb); r_i is row D of the moment tile: lanes lr == D % 4, register D / 4
-        const int rsel = D >> 2;
+        const int rsel = (D & 15) >> 2, msel = D >> 4;
         double v = 0.0;
 #pragma unroll
         for (int rt = 0; rt < BWD_RT; ++rt) {
-            const double x = rsel == 0 ? acc[rt][0] : rsel == 1 ? acc[rt][1] : rsel == 2 ? acc[rt][2] : acc[rt][3];
+            double x = 0.0;
+#pragma unroll
+            for (int m = 0; m < NMT; ++m)
+                if (m == msel) x = rsel == 0 ? acc[rt][m][0] : rsel == 1 ? acc[rt][m][1] : rsel == 2 ? acc[rt][m][2] : acc[rt][m][3];
             v += (lr == (D & 3) && ibase + 16 * rt < npad) ? (diag ? x : x * brow[rt]) : 0.0;   // tiles past the padding carry garbage and are never stored
         }
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -304,6 +338,7 @@ __global__ __launch_bounds__(256, 4) void k_mm_bwd_pair(MMModel md, MMWork wk, d
 //   sbar_a = -phi T / 2 + c T (sum l_i q_i zeta_i zeta_i^T) T / 2 - c (u (T h)^T + (T h) u^T) / 2,  phi = c (mu g + Vbar_a . T h).
 // M_b is read from the mean partials the prep kernel of the same step left in wk.mean_part.
 // stage 1 (a workgroup of k_mm_bwd_post): sums over the 64-point blocks rc, rc + nrc, ..:  mpart[a][rc][D*D + 2D + 1]
+template <int NA>   // sums per thread: D*D + 2 D + 1 <= NA * 256  (NA = 1: D <= 14, NA = 5: D <= 32)
 __device__ void bwd_mean_partial(const MMModel& md, const double* __restrict__ in_m, const double* __restrict__ head, int a, int rc,
                                  int nrc, double* __restrict__ mpart, double* sm) {
     const int D = md.D, npad = md.npad, t = threadIdx.x;
@@ -317,7 +352,10 @@ __device__ void bwd_mean_partial(const MMModel& md, const double* __restrict__ i
     for (int e = t; e < nI + D + 2; e += 256) (e < nI ? T[e] : u[e - nI]) = hd[e];
     __syncthreads();
     const double mu = u[D];
-    double acc = 0.0;
+    const int ntot = nI + 2 * D + 1; // H2q [D][D] | wq [D] | h [D] | g
+    double acc[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) acc[k] = 0.0;
     for (int blk = rc; blk < npad / 64; blk += nrc) {
         if (t < 64) {
             const int i = blk * 64 + t;
@@ -325,13 +363,13 @@ __device__ void bwd_mean_partial(const MMModel& md, const double* __restrict__ i
             if (i < md.n) {
                 double quad = 0.0;
                 q = mu;
-                {
-                    double pv[16];   // D <= 14: all coordinates of the point in flight together
+                for (int d0 = 0; d0 < D; d0 += 16) {
+                    double pv[16];   // sixteen coordinates of the point in flight together
 #pragma unroll
-                    for (int d = 0; d < 16; ++d) pv[d] = (d < D) ? md.Pt[(long)d * npad + i] : 0.0;
+                    for (int d = 0; d < 16; ++d) pv[d] = (d0 + d < D) ? md.Pt[(long)(d0 + d) * npad + i] : 0.0;
 #pragma unroll
                     for (int d = 0; d < 16; ++d)
-                        if (d < D) zs[t * LD + d] = pv[d] - in_m[d];
+                        if (d0 + d < D) zs[t * LD + d0 + d] = pv[d] - in_m[d0 + d];
                 }
                 for (int r = 0; r < D; ++r) {
                     double tz = 0.0;
@@ -347,21 +385,30 @@ __device__ void bwd_mean_partial(const MMModel& md, const double* __restrict__ i
             lq[t] = l * q;
         }
         __syncthreads();
-        if (t < nI) {
-            const int d = t / D, e2 = t - d * D;
-            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc = fma(lq[ii] * zs[ii * LD + d], zs[ii * LD + e2], acc);
-        } else if (t < nI + D) {
-            const int d = t - nI;
-            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc = fma(lq[ii], zs[ii * LD + d], acc);
-        } else if (t < nI + 2 * D) {
-            const int d = t - nI - D;
-            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc = fma(lv[ii], zs[ii * LD + d], acc);
-        } else if (t == nI + 2 * D) {
-            _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) acc += lv[ii];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int e = t + 256 * k;
+            if (e >= ntot) break;
+            double a2 = acc[k];
+            if (e < nI) {
+                const int d = e / D, e2 = e - d * D;
+                _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) a2 = fma(lq[ii] * zs[ii * LD + d], zs[ii * LD + e2], a2);
+            } else if (e < nI + D) {
+                const int d = e - nI;
+                _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) a2 = fma(lq[ii], zs[ii * LD + d], a2);
+            } else if (e < nI + 2 * D) {
+                const int d = e - nI - D;
+                _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) a2 = fma(lv[ii], zs[ii * LD + d], a2);
+            } else {
+                _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii) a2 += lv[ii];
+            }
+            acc[k] = a2;
         }
         __syncthreads();
     }
-    if (t <= nI + 2 * D) mpart[((long)a * nrc + rc) * (nI + 2 * D + 1) + t] = acc;
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+        if (t + 256 * k < ntot) mpart[((long)a * nrc + rc) * ntot + t + 256 * k] = acc[k];
 }
 
 // ---- Jacobian tape (cotangent-free form of the same reverse pass)
@@ -460,11 +507,8 @@ __device__ void bwd_mean_final(const MMModel& md, const double* __restrict__ bar
     const double* Vbar = bars + E + E * E;
     const double* hd = head + (long)a * (nI + D + 2);
     for (int e = t; e < nI + D + 2; e += 256) (e < nI ? T[e] : u[e - nI]) = hd[e];
-    if (t <= nI + 2 * D) {
-        double acc = 0.0;
-        acc = sum_strided<16>(mpart + (long)a * nrc * (nI + 2 * D + 1) + t, nI + 2 * D + 1, nrc);   // fixed order
-        red[t] = acc;
-    }
+    for (int e = t; e <= nI + 2 * D; e += 256)
+        red[e] = sum_strided<16>(mpart + (long)a * nrc * (nI + 2 * D + 1) + e, nI + 2 * D + 1, nrc);   // fixed order
     __syncthreads();
     const double mu = u[D], c_a = u[D + 1];
     const double* H2q = red;
@@ -476,11 +520,11 @@ __device__ void bwd_mean_final(const MMModel& md, const double* __restrict__ bar
         for (int c = 0; c < D; ++c) acc2 = fma(T[t * D + c], h[c], acc2);
         Th[t] = acc2;
     }
-    if (t < nI) {
-        const int r = t / D, c = t - r * D;
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, c = e - r * D;
         double acc2 = 0.0;
         for (int k = 0; k < D; ++k) acc2 = fma(T[r * D + k], H2q[k * D + c], acc2);
-        TH[t] = acc2;
+        TH[e] = acc2;
     }
     __syncthreads();
     if (t == 0) {
@@ -491,13 +535,14 @@ __device__ void bwd_mean_final(const MMModel& md, const double* __restrict__ bar
     __syncthreads();
     const double phi = sc[0];
     double* o = out + (long)a * (D + nI);
-    if (t < nI) {
-        const int r = t / D, c = t - r * D;
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, c = e - r * D;
         double acc2 = 0.0;
         for (int k = 0; k < D; ++k) acc2 = fma(TH[r * D + k], T[k * D + c], acc2);
-        o[D + t] = -0.5 * phi * T[r * D + c] + 0.5 * c_a * acc2 - 0.5 * c_a * (u[r] * Th[c] + Th[r] * u[c]);
-    } else if (t < nI + D) {
-        const int r = t - nI;
+        o[D + e] = -0.5 * phi * T[r * D + c] + 0.5 * c_a * acc2 - 0.5 * c_a * (u[r] * Th[c] + Th[r] * u[c]);
+    }
+    if (t < D) {
+        const int r = t;
         double tw = 0.0;
         for (int c = 0; c < D; ++c) tw = fma(T[r * D + c], wq[c], tw);
         o[r] = c_a * (tw - g * u[r]);
@@ -514,6 +559,7 @@ struct BwdBatch {
     const double* in_m;
     long in_m_stride;
 };
+template <int NA>   // NA = 1: D <= 14 (one sum per thread everywhere), NA = 5: D <= 32
 __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, const double* __restrict__ rowmom,
                                                     const double* __restrict__ cpart, int njs, int nrb,
                                                     double* __restrict__ part, int nrc,
@@ -528,13 +574,14 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
     head += (long)z * bb.head;
     const double* in_m = bb.in_m ? bb.in_m + (long)z * bb.in_m_stride : wk.in_m;
     if (pl >= wk.PL) {   // the last E workgroup columns: mean part of output pl - PL
-        if (jac) bwd_mean_moments(md, in_m, head, pl - wk.PL, rc, nrc, mpart, sm);
-        else bwd_mean_partial(md, in_m, head, pl - wk.PL, rc, nrc, mpart, sm);
+        if (jac && NA == 1) bwd_mean_moments(md, in_m, head, pl - wk.PL, rc, nrc, mpart, sm);
+        else bwd_mean_partial<NA>(md, in_m, head, pl - wk.PL, rc, nrc, mpart, sm);
         return;
     }
     int a, b;
     local_pair_ab(wk, E, pl, a, b);
-    const double* mom0 = rowmom + (long)pl * njs * 16 * npad;
+    const int mrows = 16 * ((D + 16) / 16);   // rows of a moment block: 16 per moment tile of the sweep
+    const double* mom0 = rowmom + (long)pl * njs * mrows * npad;
     const double* cp = (a != b) ? cpart + (long)(pl - wk.EL) * nrb * npad : nullptr;
     const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
     const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
@@ -561,7 +608,10 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
     int pd = 0;
     while (idx < NT2 && (pd + 1) * (pd + 2) / 2 <= idx) ++pd;    // idx = pd (pd + 1) / 2 + pe, pe <= pd
     const int pe = idx < NT2 ? idx - pd * (pd + 1) / 2 : 0;
-    double acc = 0.0;
+    constexpr int NP = NA == 1 ? 1 : 3;   // pair sums per thread
+    double acc[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) acc[k] = 0.0;
     for (int blk = rc; blk < nblk; blk += nrc) {
         const int i0 = blk * 64;
         __syncthreads();
@@ -574,7 +624,7 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
             ws[ii * LD + d] = zeta * ib[d];
             double mv = 0.0;
             if (valid) {
-                mv = sum_strided<4>(mom0 + (long)d * npad + i, (long)16 * npad, njs);
+                mv = sum_strided<4>(mom0 + (long)d * npad + i, (long)mrows * npad, njs);
                 if (cp) mv *= beta_a[i];   // off-diagonal pair: the sweep left beta_a,i out of the row side
             }
             ms[ii * LD + d] = mv;
@@ -584,7 +634,7 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
             const bool valid = i < md.n;
             double r = 0.0, c = 0.0;
             if (valid) {
-                r = sum_strided<4>(mom0 + (long)D * npad + i, (long)16 * npad, njs);
+                r = sum_strided<4>(mom0 + (long)D * npad + i, (long)mrows * npad, njs);
                 if (cp) {
                     r *= beta_a[i];
                     c = sum_strided<8>(cp + i, npad, nrb) * beta_b[i];   // ... and beta_b,j out of the column side
@@ -597,41 +647,65 @@ __global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, cons
         }
         __syncthreads();
         // I is symmetric: only d >= e2 is accumulated (NT2 entries), and the 64 points of the block are dealt over NG
-        // thread groups whose partial sums are added in a fixed order at the end
-        if (grp < NG) {
-            const int ii0 = grp * 64 / NG, ii1 = (grp + 1) * 64 / NG;
-            if (idx < NT2) {
-                for (int ii = ii0; ii < ii1; ++ii) {
-                    const double zd = zs[ii * LD + pd], ze = zs[ii * LD + pe];
-                    acc = fma(rs[ii] * zd, ze, acc);
-                    acc = fma(cs[ii] * ws[ii * LD + pd], ws[ii * LD + pe], acc);
-                    acc = fma(zd, ms[ii * LD + pe], acc);
-                    acc = fma(ms[ii * LD + pd], ze, acc);
+        // thread groups whose partial sums are added in a fixed order at the end (wide inputs, per > 256: one group,
+        // up to three entries per thread)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int ek = (NG > 1) ? idx : t + 256 * k;
+            if ((NG > 1 && (k > 0 || grp >= NG)) || ek >= per) break;
+            const int ii0 = (NG > 1) ? grp * 64 / NG : 0, ii1 = (NG > 1) ? (grp + 1) * 64 / NG : 64;
+            double a2 = acc[k];
+            if (ek < NT2) {
+                int qd = pd, qe = pe;
+                if (k > 0) {
+                    qd = 0;
+                    while ((qd + 1) * (qd + 2) / 2 <= ek) ++qd;
+                    qe = ek - qd * (qd + 1) / 2;
                 }
-            } else if (idx < NT2 + D) {
-                const int d = idx - NT2;
-                for (int ii = ii0; ii < ii1; ++ii) acc = fma(rs[ii], zs[ii * LD + d], fma(cs[ii], ws[ii * LD + d], acc));
+                for (int ii = ii0; ii < ii1; ++ii) {
+                    const double zd = zs[ii * LD + qd], ze = zs[ii * LD + qe];
+                    a2 = fma(rs[ii] * zd, ze, a2);
+                    a2 = fma(cs[ii] * ws[ii * LD + qd], ws[ii * LD + qe], a2);
+                    a2 = fma(zd, ms[ii * LD + qe], a2);
+                    a2 = fma(ms[ii * LD + qd], ze, a2);
+                }
+            } else if (ek < NT2 + D) {
+                const int d = ek - NT2;
+                for (int ii = ii0; ii < ii1; ++ii) a2 = fma(rs[ii], zs[ii * LD + d], fma(cs[ii], ws[ii * LD + d], a2));
             } else {
-                for (int ii = ii0; ii < ii1; ++ii) acc += rs[ii];
+                for (int ii = ii0; ii < ii1; ++ii) a2 += rs[ii];
             }
+            acc[k] = a2;
         }
     }
     __syncthreads();
-    double* red = zs;   // [NG][per]
-    if (grp < NG) red[grp * per + idx] = acc;
-    __syncthreads();
-    if (t < per) {
-        double v = red[t];
-        for (int g2 = 1; g2 < NG; ++g2) v += red[g2 * per + t];
-        double* o = part + ((long)pl * nrc + rc) * (1 + D + nI);
-        if (t < NT2) {
-            o[1 + D + pd * D + pe] = v;
-            o[1 + D + pe * D + pd] = v;
-        } else if (t < NT2 + D) {
-            o[1 + (t - NT2)] = v;
+    double* o = part + ((long)pl * nrc + rc) * (1 + D + nI);
+    auto put = [&](int e, double v) {
+        if (e < NT2) {
+            int qd = 0;
+            while ((qd + 1) * (qd + 2) / 2 <= e) ++qd;
+            const int qe = e - qd * (qd + 1) / 2;
+            o[1 + D + qd * D + qe] = v;
+            o[1 + D + qe * D + qd] = v;
+        } else if (e < NT2 + D) {
+            o[1 + (e - NT2)] = v;
         } else {
             o[0] = v;
         }
+    };
+    if (NG > 1) {
+        double* red = zs;   // [NG][per]
+        if (grp < NG) red[grp * per + idx] = acc[0];
+        __syncthreads();
+        if (t < per) {
+            double v = red[t];
+            for (int g2 = 1; g2 < NG; ++g2) v += red[g2 * per + t];
+            put(t, v);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            if (t + 256 * k < per) put(t + 256 * k, acc[k]);
     }
 }
 
@@ -685,22 +759,23 @@ __device__ void bwd_fin_pairs(const MMModel& md, const MMWork& wk, const double*
     const double Nab = Iv[0];
     const double* Av = Iv + 1;
     const double* Im = Iv + 1 + D;
-    if (t < nI) {
-        const int r = t / D, c = t - r * D;
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, c = e - r * D;
         double acc = 0.0;
         for (int k = 0; k < D; ++k) acc = fma(Pm[r * D + k], Im[k * D + c], acc);
-        PI[t] = acc;
+        PI[e] = acc;
     }
     __syncthreads();
     double* o = out + (long)(E + pl) * (D + nI);
-    if (t < nI) {
-        const int r = t / D, c = t - r * D;
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, c = e - r * D;
         double acc = 0.0;
         for (int k = 0; k < D; ++k) acc = fma(PI[r * D + k], Pm[c * D + k], acc);   // (P I P^T)[r][c]
         const double pl2 = Pm[r * D + c] * lam[c] + Pm[c * D + r] * lam[r];         // P Lambda + Lambda P^T
-        o[D + t] = kappa * (0.5 * acc - 0.25 * Nab * pl2);
-    } else if (t < nI + D) {
-        const int r = t - nI;
+        o[D + e] = kappa * (0.5 * acc - 0.25 * Nab * pl2);
+    }
+    if (t < D) {
+        const int r = t;
         double acc = 0.0;
         for (int c = 0; c < D; ++c) acc = fma(Pm[r * D + c], Av[c], acc);
         o[r] = kappa * acc;
@@ -857,6 +932,42 @@ size_t mm_jac_part_size(int D, int E, int P, int npad) {
     return (size_t)P * mm_bwd_rc(npad) * (1 + D + D * D) + (size_t)E * mm_bwd_rc(npad) * mm_jac_ns(D);
 }
 
+// the sweep kernel for this contraction width (KC = KP / 4 MFMA k-steps) and number of moment tiles
+static void launch_bwd_pair(hipStream_t st, dim3 grid, size_t lds, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart,
+                            int njs, const double* bars, double* head, double* npart) {
+    const int kc = wk.KP / 4, nmt = (md.D + 16) / 16;
+    static bool lds_set = false;   // (the attribute is per function; set for every instantiation that may need > 64 KB)
+#define PBL(K_, M_)                                                                                                                  \
+    do {                                                                                                                             \
+        if (wk.vsep) {                                                                                                               \
+            if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_mm_bwd_pair<K_, true, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_mm_bwd_pair<K_, true, M_>), grid, dim3(256), lds, st, md, wk, rowmom, cpart, njs, bars, head, npart); \
+        } else {                                                                                                                     \
+            if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_mm_bwd_pair<K_, false, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_mm_bwd_pair<K_, false, M_>), grid, dim3(256), lds, st, md, wk, rowmom, cpart, njs, bars, head, npart); \
+        }                                                                                                                            \
+    } while (0)
+    (void)lds_set;
+    if (nmt == 1) {
+        switch (kc) {
+            case 1: PBL(1, 1); break;
+            case 2: PBL(2, 1); break;
+            case 3: PBL(3, 1); break;
+            default: PBL(4, 1); break;
+        }
+    } else if (nmt == 2) {
+        switch (kc) {
+            case 5: PBL(5, 2); break;
+            case 6: PBL(6, 2); break;
+            case 7: PBL(7, 2); break;
+            default: PBL(8, 2); break;
+        }
+    } else {
+        PBL(9, 3);
+    }
+#undef PBL
+}
+
 void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb);
 size_t mm_jac_rowmom_size(int npad, int P) {
     int njs, nrb;
@@ -886,22 +997,9 @@ void launch_mm_sweep(hipStream_t st, const MMModel& md, const MMWork& wk, double
     const int nhead = E + P, per_row = nrb * njs;
     dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);
     const int nI = D * D;
-    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * BWD_TP + 2 * BWD_CH) + 4 * 256, (size_t)4 * nI + D);
+    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * bwd_tp(wk.KP) + 2 * BWD_CH) + 4 * 256, (size_t)4 * nI + D);
     const double* bars = nullptr;
-#define PB(K_)                                                                                                       \
-    do {                                                                                                             \
-        if (wk.vsep)                                                                                                 \
-            hipLaunchKernelGGL((k_mm_bwd_pair<K_, true>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head, npart);  \
-        else                                                                                                         \
-            hipLaunchKernelGGL((k_mm_bwd_pair<K_, false>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head, npart); \
-    } while (0)
-    switch (wk.KP / 4) {
-        case 1: PB(1); break;
-        case 2: PB(2); break;
-        case 3: PB(3); break;
-        default: PB(4); break;
-    }
-#undef PB
+    launch_bwd_pair(st, grid, lds_pair, md, wk, rowmom, cpart, njs, bars, head, npart);
 }
 
 // Jacobian tape, once per rollout (off the critical path): sums, moments and records of ALL H steps in two launches --
@@ -924,8 +1022,8 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
     bb.in_m_stride = (long)tape_stride;
     double* mpart = part + (size_t)P * nrc * (1 + D + nI);
     const size_t lds_post = sizeof(double) * std::max((size_t)3 * 64 * LD + 128 + 3 * D, (size_t)nI + 64 * LD1 + 64 + NS / 2 + 2);
-    hipLaunchKernelGGL(k_mm_bwd_post, dim3(P + E, nrc, H), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
-                       head, mpart, 1, bb);
+    hipLaunchKernelGGL(k_mm_bwd_post<1>, dim3(P + E, nrc, H), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
+                       head, mpart, 1, bb);   // (the Jacobian tape serves D <= 14)
     const size_t lds_fin = sizeof(double) * std::max((size_t)4 * nI + 4 * D + 8, (size_t)3 * nI + NS + D + 2 * nI * D);
     hipLaunchKernelGGL(k_mm_jac_fin, dim3(P + E, H), dim3(256), lds_fin, st, md, wk, part, nrc, head, mpart, jrec,
                        (long)mm_jac_rec_size(D, E, P), bb);
@@ -947,27 +1045,18 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
     const int nhead = E + P, per_row = nrb * njs;
     dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);   // the rows past P hold the head workgroups
     const int LD = D | 1, nI = D * D;
-    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * BWD_TP + 2 * BWD_CH) + 4 * 256, (size_t)4 * nI + D);
+    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * bwd_tp(wk.KP) + 2 * BWD_CH) + 4 * 256, (size_t)4 * nI + D);
     double* npart = nullptr;
-#define PB(K_)                                                                                                       \
-    do {                                                                                                             \
-        if (wk.vsep)                                                                                                 \
-            hipLaunchKernelGGL((k_mm_bwd_pair<K_, true>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head, npart);  \
-        else                                                                                                         \
-            hipLaunchKernelGGL((k_mm_bwd_pair<K_, false>), grid, dim3(256), lds_pair, st, md, wk, rowmom, cpart, njs, bars, head, npart); \
-    } while (0)
-    switch (wk.KP / 4) {
-        case 1: PB(1); break;
-        case 2: PB(2); break;
-        case 3: PB(3); break;
-        default: PB(4); break;
-    }
-#undef PB
+    launch_bwd_pair(st, grid, lds_pair, md, wk, rowmom, cpart, njs, bars, head, npart);
     const int nrc = mm_bwd_rc(md.npad);
     double* mpart = part + (size_t)P * nrc * (1 + D + nI);
     const size_t lds_post = sizeof(double) * std::max((size_t)3 * 64 * LD + 128 + 3 * D, (size_t)nI + 64 * LD + 128 + D + 2);
-    hipLaunchKernelGGL(k_mm_bwd_post, dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
-                       head, mpart, 0, BwdBatch{0, 0, 0, 0, nullptr, 0});
+    if (D <= 14)
+        hipLaunchKernelGGL(k_mm_bwd_post<1>, dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
+                           head, mpart, 0, BwdBatch{0, 0, 0, 0, nullptr, 0});
+    else
+        hipLaunchKernelGGL(k_mm_bwd_post<5>, dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
+                           head, mpart, 0, BwdBatch{0, 0, 0, 0, nullptr, 0});
     const size_t lds_fin = sizeof(double) * ((size_t)3 * nI + 4 * D + 8);
     hipLaunchKernelGGL(k_mm_bwd_fin, dim3(P + E), dim3(256), lds_fin, st, md, wk, part, nrc, bars, head, mpart, out, done, sum_out);
 }

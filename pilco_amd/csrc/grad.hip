@@ -7,7 +7,7 @@ extern "C" {
 // Vector-Jacobian product of one moment-matching step (the reverse of pilco_gp_predict):
 // given cotangents Mbar (1,E), Sbar (E,E), Vbar (D,E) returns mbar (1,D) and the symmetric sbar (D,D).
 // Entirely on the device (k_mm_bwd_pair / _post / _fin; the mean part rides in extra workgroups of _post / _fin);
-// the E + P contribution records are summed in a fixed order by the last workgroup to finish.  Single rank, exact or sparse model, D <= 14.
+// the E + P contribution records are summed in a fixed order by the last workgroup to finish.  Single rank, exact or sparse model, D <= 32 (the forward path's limit).
 int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double* s_in, const double* Mbar,
                          const double* Sbar, const double* Vbar, double* mbar, double* sbar) {
     if (int r = check_slot(ctx, slot)) return r;
@@ -16,7 +16,7 @@ int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double
     if (!m || !s_in || !Mbar || !Sbar || !Vbar || !mbar || !sbar) return fail(ctx, PILCO_E_SHAPE, "predict_vjp: null pointer");
     if (ctx->nranks != 1) return fail(ctx, PILCO_E_STATE, "predict_vjp: single rank only");
     const int D = s.D, E = s.E, npad = s.npad;
-    if (D + 2 > 16) return fail(ctx, PILCO_E_SHAPE, "predict_vjp: D <= 14 in this build");
+    if (D > MAX_D) return fail(ctx, PILCO_E_SHAPE, "predict_vjp: D <= 32 in this build");
     HIPCHK(hipSetDevice(ctx->device));
     if (int r = build_work(ctx, s)) return r;
     const int P = s.wk.PL;
@@ -24,7 +24,7 @@ int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double
     const int rec = D + D * D, nb = E + E * E + D * E;
     int njs, nrb;
     mm_bwd_geometry(npad, P, &njs, &nrb);
-    ENSURE(s.bwd_mom, (size_t)P * njs * 16 * npad);
+    ENSURE(s.bwd_mom, (size_t)P * njs * (16 * ((D + 16) / 16)) * npad);   // 16 rows per moment tile of the sweep
     ENSURE(s.bwd_cp, (size_t)std::max(1, P - E) * nrb * npad);
     ENSURE(s.bwd_part, (size_t)(P + E) * mm_bwd_rc(npad) * (1 + rec + D));   // pair partials, then mean partials
     ENSURE(s.bwd_out, (size_t)(E + P) * rec + (size_t)(E + P) * (D * D + D + 2));   // contributions | head records

@@ -41,6 +41,20 @@ __device__ __forceinline__ void store_wt(double* p, double v) {
         if ((wk_).dbg && (cond_)) (wk_).dbg[slot_] = wall_clock64();          \
     } while (0)
 
+// hipcc (ROCm 7.2) lets the destination registers of v_mfma_f64_16x16x4_f64 overlap its A / B source registers when
+// the accumulator input is the inline constant 0 and a source dies at that instruction; the hardware then reads the
+// source while it is already being overwritten (found in round 2: one exponent register of a reverse-sweep
+// instantiation came out wrong).  Keeping the operands of such a first MFMA alive past it (an empty asm that "uses"
+// them) rules the overlap out at no instruction cost; tools/mfma_overlap_check.py scans the generated code
+// (tests/test_build_isa.py).
+#define MFMA_KEEP_ALIVE(x_) asm volatile("" ::"v"(x_))
+// The same compiler does not always insert the wait states between a v_mfma_f64_16x16x4_f64 and a VALU read of its result
+// (it does in the forward pair kernel: 7 + destination-pair-index slots; in the wide reverse-sweep instantiations a
+// v_max read the LAST destination pair in the very next slot and got the accumulator from before the last k-step).
+// MFMA_RESULT_FENCE(e): every reader of e comes after an s_nop that covers the longest of those distances.
+// tools/mfma_hazard_check.py scans the generated code for such reads (tests/test_build_isa.py).
+#define MFMA_RESULT_FENCE(e_) asm volatile("s_nop 10" : "+v"(e_))
+
 // Wave-wide sum in lane 63 with DPP row shifts / broadcasts (no LDS traffic, fixed order).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add(double v) {

@@ -142,6 +142,7 @@ __host__ __device__ inline size_t xq_area_words(int W, int cap) { return (size_t
 // fused != nullptr: the "fused head" -- every workgroup first runs the serial link of the PREVIOUS step (glue_body with
 // *fused: pack / assemble / propagate / controller / joint) redundantly and takes the joint Gaussian from its own LDS;
 // fused->wk carries the buffers that link READS (previous step's partials), wk the ones this launch WRITES.
+bool mm_fused_head_fits(const MMModel& md, int reward_E, const GlueArgs& ga);
 void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const PrepReward* pr = nullptr,
                     const GlueArgs* fused = nullptr);
 size_t glue_lds_doubles_for(const GlueArgs& g);

@@ -124,6 +124,8 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
             d4 e = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int c = 0; c < KC; ++c) e = PAIR_ABL_MFMA(af[rt][c], bf[c], e);
+            MFMA_KEEP_ALIVE(af[rt][0]);   // (first MFMA of the chain: constant-zero accumulator, see mm_device.h)
+            MFMA_KEEP_ALIVE(bf[0]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[4 * rt + r] = VSEP ? e[r] + vv : e[r];   // C/D column = lane & 15: one v_j per lane
         }
@@ -575,6 +577,8 @@ __global__ void k_selftest_mfma(double* out) {
     const double b = (k == 0) ? (double)((lane & 15) + 1) : 0.0;
     d4 acc = {0.0, 0.0, 0.0, 0.0};
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    MFMA_KEEP_ALIVE(a);
+    MFMA_KEEP_ALIVE(b);
     for (int r = 0; r < 4; ++r) out[lane * 4 + r] = acc[r];
 }
 

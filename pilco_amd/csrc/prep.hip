@@ -390,6 +390,20 @@ void mm_prep_chunks(int npad, int PL, int EL, int* nch_out, int* nchm_out) {
     *nchm_out = nchm;
 }
 
+static int prep_dt(int D) {   // the operand kernel's instantiation for this input dimension (see the dispatch below)
+    return D <= 4 ? 4 : D <= 6 ? 6 : D <= 8 ? 8 : D <= 10 ? 10 : D == 11 ? 11 : D <= 12 ? 12 : D <= 14 ? 14 : D <= 16 ? 16 : D <= 20 ? 20 : D <= 24 ? 24 : 32;
+}
+// Does the fused head (serial link + operands in one workgroup) fit the CU's LDS for this model / policy / reward set?
+// Wide inputs (D > 24 with many outputs) do not: the rollout then runs the three-kernel step (same results).
+bool mm_fused_head_fits(const MMModel& md, int reward_E, const GlueArgs& ga) {
+    const size_t lds_rw = reward_E > 0 ? sizeof(double) * ((size_t)reward_E + (size_t)reward_E * reward_E + reward_lds_doubles(reward_E)) : 0;
+    const size_t gd = (glue_lds_doubles_for(ga) + 1) & ~(size_t)1;
+    const size_t lds = std::max(prep_lds_bytes(prep_dt(md.D)), lds_rw) + sizeof(double) * gd;
+    int dev = 0, lim = 65536;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+    return lds <= (size_t)lim;
+}
+
 void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const PrepReward* pr, const GlueArgs* fused) {
     PrepReward none{};
     const PrepReward& r = pr ? *pr : none;

@@ -176,12 +176,26 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
     return PILCO_OK;
 }
 
+// The fused heads need the serial link's and the operand kernel's LDS side by side in one workgroup: wide models
+// (D > 24 with many outputs) exceed the CU's 160 KB and run the three-kernel step instead (same results).
+static bool fused_heads_fit(pilco_ctx* ctx, const RolloutPlan& plan) {
+    const Slot& s = ctx->slot[0];
+    if (s.wk.PL <= 0) return true;
+    const bool rbf = plan.g.pol_kind == PILCO_POLICY_RBF;
+    GlueArgs gl = plan.g;
+    gl.flags = GF_TRAJ | GF_POLICY | GF_PACK | GF_ASSEMBLE | GF_PROPAGATE | (rbf ? (GF_RBF_PRE | GF_RBF_POST) : 0);
+    const int rew_E = plan.g.n_rewards > 0 ? plan.E : 0;
+    bool fits = mm_fused_head_fits(model_of(s), rew_E, gl);
+    if (fits && rbf) fits = mm_fused_head_fits(model_of(ctx->slot[PILCO_SLOT_POLICY]), rew_E, gl);
+    return fits;
+}
+
 // The peer exchange carries a rollout when it is attached, the model is sharded, the policy is not an RbfController
 // (its GP is not sharded) and the segments fit the exchange slots; otherwise the RCCL / group path runs.
 static bool peer_rollout_applies(pilco_ctx* ctx, const RolloutPlan& plan, int H) {
     const Slot& s = ctx->slot[0];
     return ctx->xq.ready && ctx->nranks > 1 && ctx->xq.W == ctx->nranks && H > 0 && plan.g.pol_kind != PILCO_POLICY_RBF &&
-           s.wk.SEG <= ctx->xq.cap && !plan.g.tape && !plan.jrec;
+           s.wk.SEG <= ctx->xq.cap && !plan.g.tape && !plan.jrec && fused_heads_fit(ctx, plan);
 }
 // Host side of a rollout's exchanges: the epoch base goes up before the rollout's launches (outside any graph: the
 // value changes per replay), `n` exchanges are accounted for afterwards.
@@ -240,7 +254,8 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
         else
             launch_mm_pair(ctx->st, md, w, ctx->variant);
     };
-    if (ctx->fused && !rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && H > 0) {
+    const bool fits = fused_heads_fit(ctx, plan);
+    if (ctx->fused && fits && !rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && H > 0) {
         // Fused head: launch h = 0..H-1 is [serial link producing state h and its joint Gaussian | operands of step h],
         // followed by the pair kernel of step h; one plain glue launch closes the rollout.  What the link reads
         // (previous step's pair_isdet / mean_part / s1 / state) and what the same launch writes alternate between two
@@ -368,7 +383,7 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
         launch_glue(ctx->st, gf, rew && s.wk.PL == 0);
         return PILCO_OK;
     }
-    if (ctx->fused && rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && ps.wk.PL > 0 && H > 0) {
+    if (ctx->fused && fits && rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && ps.wk.PL > 0 && H > 0) {
         // Fused heads with an RbfController (controllers.py:108-121): the policy is a moment-matching GP of its own, so a
         // step is two head + pair rounds and the serial link splits in two:
         //   policy head   [pack / assemble / propagate of step h - 1 -> state h | operands of the POLICY GP at state h]
@@ -847,7 +862,8 @@ int pilco_rollout_tape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_r
 
 // Value-and-gradient rollout, forward half: pilco_rollout_tape with every dynamics step run as the reverse sweep
 // (launch_mm_jac), so that the step's value and its Jacobian records come out of ONE O(N^2) pass; trajectory, tape and
-// records land in pinned host memory for the host-side reverse sweep (grad.hip).  Single rank, D <= 14.
+// records land in pinned host memory for the host-side reverse sweep (grad.hip).  Single rank; D <= 14 (wider inputs: PILCO_JAC_TOO_LARGE, the caller
+// falls back to the plain tape + per-step device adjoint, which has the forward path's D <= 32).
 int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
                   const double* S0, int H, double* reward, const double** traj, const double** tape, const double** jrec, size_t* jstride) {
     HIPCHK(hipSetDevice(ctx->device));
@@ -856,7 +872,7 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, true, plan)) return r;
     Slot& s = ctx->slot[0];
     const int E = plan.E, D = plan.D, P = s.wk.PL, npad = s.npad;
-    if (D + 2 > 16) return fail(ctx, PILCO_E_SHAPE, "rollout_grad: D <= 14 in this build");
+    if (D > 14) return PILCO_JAC_TOO_LARGE;   // third-moment records and their LDS working set are sized for D <= 14
     const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
     const size_t JS = mm_jac_rec_size(D, E, P), NTJ = (size_t)(H + 1) * (E + (size_t)E * E);
     // every step keeps its own sweep output until the batched finish (nothing on the chain waits for a buffer): at C2u

@@ -233,7 +233,7 @@ def policy_loss_and_grad(pilco, u, put, eps=1e-6):
     # the adjoint differentiates PILCO.predict's reward (pilco.py:118-136); a subclass that overrides predict (SafePILCO's
     # multiplicative risk term, safe_pilco.py:29-50) is differentiated by finite differences of ITS training_loss instead
     plain = type(pilco).predict is PILCO.predict
-    analytic = (plain and pilco.control_dim > 0 and pilco.state_dim + pilco.control_dim <= 14      # the device VJP is built for D <= 14
+    analytic = (plain and pilco.control_dim > 0 and pilco.state_dim + pilco.control_dim <= 32      # the forward path's limit; the Jacobian tape serves D <= 14, the per-step device adjoint the rest
                 and all(t["kind"] in (_lib.REWARD_EXPONENTIAL, _lib.REWARD_LINEAR) for t in pilco.reward.terms()))
     if analytic and isinstance(ctl, LinearController):
         from .adjoint import rollout_value_and_grad

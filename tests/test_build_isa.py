@@ -1,0 +1,33 @@
+"""The generated gfx950 code of the MFMA kernels, checked on the CPU (hipcc cross-compiles without a GPU).
+
+Round 2 found two ways in which hipcc (ROCm 7.2) miscompiles chains of v_mfma_f64_16x16x4_f64:
+  * the destination registers of an MFMA with a constant-zero accumulator may overlap a dying A / B source register;
+  * the wait states between an MFMA and a VALU read of its result are missing in some instantiations (the reverse sweep
+    read the last destination pair one slot after the MFMA and got the accumulator from before the last k-step).
+csrc/mm_device.h carries the source-level counter-measures (MFMA_KEEP_ALIVE, MFMA_RESULT_FENCE); this test compiles the
+MFMA-carrying translation units to assembly and scans EVERY instantiation with tools/mfma_overlap_check.py and
+tools/mfma_hazard_check.py, so a compiler or source change that re-opens either hole fails here, not on the GPU."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("unit", ["pair", "bwd", "linalg"])
+def test_mfma_chains_have_no_register_overlap_and_no_early_result_reads(unit, tmp_path):
+    src = os.path.join(ROOT, "pilco_amd", "csrc", unit + ".hip")
+    asm = str(tmp_path / (unit + ".s"))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+           "-mllvm", "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only", "-o", asm, src]
+    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0 and os.path.exists(asm), pr.stderr[-2000:]
+    assert "v_mfma_f64_16x16x4_f64" in open(asm).read()
+    for tool in ("mfma_overlap_check.py", "mfma_hazard_check.py"):
+        chk = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), asm], capture_output=True, text=True, timeout=300)
+        assert chk.returncode == 0, "%s on %s:\n%s" % (tool, unit, chk.stdout[-3000:])

@@ -839,7 +839,8 @@ def test_optimize_policy_increases_reward(ctx):
     np.testing.assert_allclose(float(p.compute_reward()[0, 0]), r1)
 
 
-@pytest.mark.parametrize("shape", [(60, 3, 2), (300, 5, 4), (1000, 10, 10)])
+@pytest.mark.parametrize("shape", [(60, 3, 2), (300, 5, 4), (1000, 10, 10), (150, 15, 3), (130, 16, 4), (200, 18, 5), (100, 23, 2),
+                                   (90, 26, 3), (70, 31, 2), (65, 32, 2)])
 def test_moment_matching_vjp_vs_autograd(ctx, shape):
     """pilco_gp_predict_vjp (hand-derived adjoint, device pair sums) against torch autograd of the restated
     forward pass (what TensorFlow's reverse mode gives the reference, pilco.py:85-90)."""
@@ -1333,6 +1334,38 @@ def test_jacobian_tape_gradient_equals_per_step_device_adjoint(ctx, shape):
         np.testing.assert_allclose(out[1][0], float(p.compute_reward()[0, 0]), rtol=1e-10)   # two summation orders of the same pair sums
         for a, b in zip(out[1][1], out[0][1]):
             np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-12 * max(1.0, float(np.abs(b).max())))
+
+
+@pytest.mark.parametrize("dims", [(12, 3), (14, 4), (20, 6)])
+def test_policy_gradient_wide_inputs_vs_autograd(ctx, dims):
+    """Reverse mode beyond D = 14 (state + control up to the forward path's D <= 32): the Jacobian tape hands over to the
+    plain tape + per-step device adjoint; d reward / d (W, b) against torch autograd of the restated rollout
+    (the reference's TF reverse mode has no such limit, pilco.py:85-90)."""
+    import torch
+    from oracle import torch_path as tq
+    from pilco_amd.adjoint import rollout_value_and_grad
+    E, U = dims
+    D, N, H = E + U, 90, 3
+    c = synthetic.config_c2(N=N, D=D, E=E, noise=1e-2, seed=7 + D, control_dim=U)
+    p = _pilco_from(c, H)
+    rs = np.random.RandomState(11)
+    W0, b0 = 0.2 * rs.randn(U, E), 0.1 * rs.randn(1, U)
+    p.controller.W.assign(W0); p.controller.b.assign(b0); p.controller.max_action = 1.2
+    p.m_init, p.S_init = c["m0"], c["S0"]
+    r, (Wb, bb) = rollout_value_and_grad(p)
+    r2, (Wb2, bb2) = rollout_value_and_grad(p)
+    assert r2 == r and np.array_equal(Wb2, Wb) and np.array_equal(bb2, bb)
+    iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+    Wt = torch.tensor(W0, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b0, dtype=torch.float64, requires_grad=True)
+    gp = lambda m, s: tq.predict_given_factorizations(c["X"], c["lengthscales"], c["variance"], m, s, iK, beta)
+    ctl = lambda m, s: tq.linear_controller(m, s, Wt, bt, 1.2)
+    rw = lambda m, s: tq.exponential_reward(m, s)
+    _, _, R = tq.predict(gp, ctl, rw, tq.t(c["m0"]), tq.t(c["S0"]), H)
+    R.sum().backward()
+    np.testing.assert_allclose(r, R.sum().item(), rtol=1e-8)
+    np.testing.assert_allclose(Wb, Wt.grad.numpy(), rtol=1e-6, atol=1e-9 * np.abs(Wt.grad.numpy()).max())
+    np.testing.assert_allclose(bb, bt.grad.numpy(), rtol=1e-6, atol=1e-9 * np.abs(bt.grad.numpy()).max())
 
 
 _FUZZ_N = [1, 2, 3, 15, 16, 17, 31, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300]
