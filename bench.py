@@ -9,9 +9,11 @@ resident in HBM when the timed region starts.
     python bench.py --gpus N --steps K --warmup W
 
 N > 1: launched under torch.distributed.run, one rank per GPU.  torch is used only
-to rendezvous (gloo: broadcast of the RCCL unique id, barrier, max-over-ranks);
-the output pairs are sharded over the ranks inside libpilco_hip.so with one
-ncclAllGather per horizon step ("scaling": "strong": one rollout is split).
+to rendezvous (gloo: broadcast of the RCCL unique id and of the peer-exchange
+handles, barrier, max-over-ranks); the output pairs are sharded over the ranks
+inside libpilco_hip.so ("scaling": "strong": one rollout is split) with one exchange
+per horizon step: direct peer stores + flags into hipIpc-mapped exchange areas,
+or one ncclAllGather when a rank cannot attach them (config.exchange says which).
 """
 from __future__ import annotations
 
