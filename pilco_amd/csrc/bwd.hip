@@ -551,7 +551,7 @@ __device__ void bwd_mean_final(const MMModel& md, const double* __restrict__ bar
 
 // Per unordered pair and row chunk: partial sums of  N_ab = sum_i r_i,  A = sum_i (r_i z_i + c_i w_i)  (D),
 // I = sum_i (r_i z_i z_i^T + c_i w_i w_i^T + z_i m_i^T + m_i z_i^T)  (D x D).   part[pl][chunk][1 + D + D*D]
-constexpr int BWD_RC = 16;  // row chunks per pair / output
+constexpr int BWD_RC = 8;   // row chunks per pair / output (16: 12 % slower in the batched form, more workgroup prologues)
 // Batched form (Jacobian tape): blockIdx.z = horizon step; every per-step array advances by its stride and the input
 // mean comes from the step's tape record (wk.in_m holds the LAST step's by then).  Unbatched: strides 0, in_m = nullptr.
 struct BwdBatch {
