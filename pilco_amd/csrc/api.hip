@@ -503,7 +503,7 @@ int pilco_gp_nlml(pilco_ctx* ctx, int slot, double* nlml, double* grad) {
     }
     const int E = s.E, D = s.D, npad = s.Npad, N = s.N;
     // after factorize_exact: s.K holds L, s.iK the inverse, s.beta = alpha, s.Yt the targets
-    const size_t npart = (size_t)E * (npad / NB) * 34;
+    const size_t npart = (size_t)E * (npad / NB) * (npad / NB) * 34;   // [E][tiles^2][NLML_MAXD + 2] partial sums of the gradient
     ENSURE(s.vec, std::max((size_t)E * npad * 2, npart + (size_t)E * (D + 2) + 2 * (size_t)E));
     double* d_part = s.vec.p;
     double* d_grad = d_part + npart;

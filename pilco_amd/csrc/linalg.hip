@@ -372,37 +372,43 @@ void launch_logdet(hipStream_t st, const double* L, int npad, int n, int batch, 
     hipLaunchKernelGGL(k_logdet, dim3(batch), dim3(256), 0, st, L, npad, n, out);
 }
 
-// one workgroup per (output, 64-row tile): thread t handles column j = t, t+256, ... of its rows;
-// partial[b][tile][D+2]; a second launch reduces the tiles in fixed order.
+// one workgroup per (output, 64-row tile, 64-column tile): thread t handles column j0 + (t & 63) against the 16 rows
+// i0 + 16 (t >> 6) ..; all per-dimension arrays are register arrays of the compile-time width DT (the first version
+// indexed [32]-arrays with a run-time D: they lived in scratch memory and one launch took 114 us at N = 225).
+// partial[b][tile_i * ntiles + tile_j][NLML_MAXD + 2]; a second launch reduces the tiles in fixed order.
 constexpr int NLML_MAXD = 32;
+template <int DT>
 __global__ __launch_bounds__(256) void k_nlml_grad_partial(const double* __restrict__ Pt, int npad, int n, int D,
                                                            const double* __restrict__ ls, const double* __restrict__ var,
                                                            const double* __restrict__ iK, const double* __restrict__ beta,
                                                            double* __restrict__ partial) {
-    __shared__ double xi[NLML_MAXD][64];
+    __shared__ double xi[DT][64];
     __shared__ double bi[64];
-    __shared__ double red[4][NLML_MAXD + 2];
-    const int b = blockIdx.y, tile = blockIdx.x, t = threadIdx.x;
-    const int i0 = tile * 64;
-    for (int e = t; e < D * 64; e += 256) xi[e >> 6][e & 63] = Pt[(long)(e >> 6) * npad + i0 + (e & 63)];
+    __shared__ double red[4][DT + 2];
+    const int b = blockIdx.z, ti = blockIdx.y, tj = blockIdx.x, t = threadIdx.x;
+    const int i0 = ti * 64, j = tj * 64 + (t & 63), g = t >> 6;
+    for (int e = t; e < DT * 64; e += 256) xi[e >> 6][e & 63] = ((e >> 6) < D) ? Pt[(long)(e >> 6) * npad + i0 + (e & 63)] : 0.0;
     if (t < 64) bi[t] = beta[(long)b * npad + i0 + t];
     __syncthreads();
     const double v = var[b];
-    double il[NLML_MAXD];
-    double acc[NLML_MAXD + 2];
-    for (int d = 0; d < NLML_MAXD; ++d) il[d] = (d < D) ? 1.0 / ls[b * D + d] : 0.0;
-    for (int d = 0; d < NLML_MAXD + 2; ++d) acc[d] = 0.0;
+    double il[DT], xj[DT], acc[DT + 2];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        il[d] = (d < D) ? 1.0 / ls[b * D + d] : 0.0;
+        xj[d] = (d < D) ? Pt[(long)d * npad + j] : 0.0;
+        acc[d] = 0.0;
+    }
+    acc[DT] = acc[DT + 1] = 0.0;
     const double* iKb = iK + (long)b * npad * npad;
-    for (int j = t; j < n; j += 256) {
-        double xj[NLML_MAXD];
-        for (int d = 0; d < D; ++d) xj[d] = Pt[(long)d * npad + j];
-        const double bj = beta[(long)b * npad + j];
-        for (int ii = 0; ii < 64; ++ii) {
-            const int i = i0 + ii;
+    const double bj = beta[(long)b * npad + j];
+    if (j < n) {
+        for (int q = 0; q < 16; ++q) {
+            const int ii = 16 * g + q, i = i0 + ii;
             if (i >= n) break;
             double r2 = 0.0;
-            double sq[NLML_MAXD];
-            for (int d = 0; d < D; ++d) {
+            double sq[DT];
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
                 const double df = (xi[d][ii] - xj[d]) * il[d];
                 sq[d] = df * df;
                 r2 += sq[d];
@@ -410,18 +416,23 @@ __global__ __launch_bounds__(256) void k_nlml_grad_partial(const double* __restr
             const double k = v * exp(-0.5 * r2);
             const double w = iKb[(long)i * npad + j] - bi[ii] * bj;
             const double wk = w * k;
-            for (int d = 0; d < D; ++d) acc[d] = fma(wk, sq[d] * il[d], acc[d]);   // (x_i-x_j)^2 / l^3
-            acc[D] += wk;
-            if (i == j) acc[D + 1] += w;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) acc[d] = fma(wk, sq[d] * il[d], acc[d]);   // (x_i-x_j)^2 / l^3
+            acc[DT] += wk;
+            if (i == j) acc[DT + 1] += w;
         }
     }
-    for (int d = 0; d < D + 2; ++d) {
-        double s = acc[d];
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-        if ((t & 63) == 0) red[t >> 6][d] = s;
+#pragma unroll
+    for (int d = 0; d < DT + 2; ++d) {
+        double s2 = acc[d];
+        for (int off = 32; off > 0; off >>= 1) s2 += __shfl_down(s2, off);
+        if ((t & 63) == 0) red[g][d] = s2;
     }
     __syncthreads();
-    if (t < D + 2) partial[((long)b * gridDim.x + tile) * (NLML_MAXD + 2) + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if (t < D + 2) {
+        const int src = t < D ? t : DT + (t - D);
+        partial[((long)b * gridDim.y * gridDim.x + (long)ti * gridDim.x + tj) * (NLML_MAXD + 2) + t] = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+    }
 }
 __global__ void k_nlml_grad_reduce(const double* __restrict__ partial, int ntiles, int D, const double* __restrict__ var,
                                    double* __restrict__ grad) {
@@ -432,11 +443,20 @@ __global__ void k_nlml_grad_reduce(const double* __restrict__ partial, int ntile
     if (t == D) s /= var[b];
     grad[b * (D + 2) + t] = 0.5 * s;
 }
+// partial: [batch][(npad / 64)^2][NLML_MAXD + 2] doubles
 void launch_nlml_grad(hipStream_t st, const double* Pt, int npad, int n, int D, const double* ls, const double* var,
                       const double* iK, const double* beta, int batch, double* partial, double* grad) {
     const int ntiles = npad / 64;
-    hipLaunchKernelGGL(k_nlml_grad_partial, dim3(ntiles, batch), dim3(256), 0, st, Pt, npad, n, D, ls, var, iK, beta, partial);
-    hipLaunchKernelGGL(k_nlml_grad_reduce, dim3(batch), dim3(64), 0, st, partial, ntiles, D, var, grad);
+    const dim3 grid(ntiles, ntiles, batch);
+#define NG(DT_) hipLaunchKernelGGL(k_nlml_grad_partial<DT_>, grid, dim3(256), 0, st, Pt, npad, n, D, ls, var, iK, beta, partial)
+    if (D <= 4) NG(4);
+    else if (D <= 8) NG(8);
+    else if (D <= 12) NG(12);
+    else if (D <= 16) NG(16);
+    else if (D <= 24) NG(24);
+    else NG(32);
+#undef NG
+    hipLaunchKernelGGL(k_nlml_grad_reduce, dim3(batch), dim3(64), 0, st, partial, ntiles * ntiles, D, var, grad);
 }
 
 // ------------------------------------------------------------------ mat-vec, padding
