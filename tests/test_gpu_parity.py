@@ -1368,6 +1368,33 @@ def test_policy_gradient_wide_inputs_vs_autograd(ctx, dims):
     np.testing.assert_allclose(bb, bt.grad.numpy(), rtol=1e-6, atol=1e-9 * np.abs(bt.grad.numpy()).max())
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_ranks_in_separate_processes_peer_exchange_on_one_gpu(world):
+    """bench.py --gpus N exactly as the driver launches it (torch.distributed.run, one PROCESS per rank), all ranks on
+    this box's single GPU (PILCO_BENCH_SHARE_GPU=1: RCCL refuses duplicate devices, so the beta rows travel over gloo): the
+    sharded factorisation, the hipIpc-mapped exchange areas, the flag waits between processes and the graph replay of the
+    sharded rollout; bench.py itself verifies the rollout against the executed-reference fixture and reports the exchange
+    it used."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "1"]
+    env = dict(os.environ, PILCO_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert pr.returncode == 0, (pr.stdout[-1500:], pr.stderr[-3000:])
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and "peer stores" in d["config"]["exchange"], d["config"]
+    assert d["verified"]["max_rel_err"]["S_H"] < 1e-5 and d["verified"]["max_rel_err"]["reward"] < 1e-5
+
+
 _FUZZ_N = [1, 2, 3, 15, 16, 17, 31, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300]
 
 
