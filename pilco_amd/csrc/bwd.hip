@@ -560,7 +560,10 @@ struct BwdBatch {
     long in_m_stride;
 };
 template <int NA>   // NA = 1: D <= 14 (one sum per thread everywhere), NA = 5: D <= 32
-__global__ __launch_bounds__(256) void k_mm_bwd_post(MMModel md, MMWork wk, const double* __restrict__ rowmom,
+#ifndef POST_LB
+#define POST_LB 8   // waves per SIMD of the narrow post kernel: latency-bound, 8 resident workgroups per CU (64 VGPRs, a few spills) beat 4 by 30 %
+#endif
+__global__ __launch_bounds__(256, NA == 1 ? POST_LB : 1) void k_mm_bwd_post(MMModel md, MMWork wk, const double* __restrict__ rowmom,
                                                     const double* __restrict__ cpart, int njs, int nrb,
                                                     double* __restrict__ part, int nrc,
                                                     const double* __restrict__ head, double* __restrict__ mpart, int jac, BwdBatch bb) {
