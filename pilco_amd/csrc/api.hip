@@ -318,6 +318,8 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);
     if (ctx->jpin) (void)hipHostFree(ctx->jpin);
+    for (hipEvent_t e : ctx->jwait_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->st) (void)hipStreamDestroy(ctx->st);
     delete ctx;
     return PILCO_OK;

@@ -106,6 +106,8 @@ struct pilco_ctx {
     DevBuf jrec;             // Jacobian tape: [H][mm_jac_rec_size] records of a value-and-gradient rollout
     double* jpin = nullptr;  // pinned host copy of (traj | tape | jrec) for the host-side reverse sweep
     size_t jpin_cap = 0;
+    hipEvent_t jwait_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // behind the chunks of the records' download (last steps first)
+    int jwait_t0[4] = {0, 0, 0, 0}, jwait_n = 0, jwait_next = 0, jwait_from = 0;   // first step of chunk k; steps >= jwait_from are on the host
     DevBuf selftest;
     DevBuf exp_tab;  // 2^(j/n), j = 0..n-1, n = mm_exp_table_size()
     unsigned long long* dbg = nullptr;
@@ -158,6 +160,7 @@ struct RolloutPlan {
     size_t jstride = 0;
 };
 constexpr int PILCO_JAC_TOO_LARGE = -77;   // rollout_jtape: the per-step buffers would exceed the cap (caller falls back)
+int rollout_jtape_wait(pilco_ctx* ctx, int t);   // blocks until the records of step t have arrived
 // forward rollout with the tape and the Jacobian records of every step, downloaded into pinned memory (grad.hip)
 int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
                   const double* S0, int H, double* reward, const double** traj, const double** tape, const double** jrec, size_t* jstride);

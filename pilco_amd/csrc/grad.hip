@@ -692,6 +692,7 @@ int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_re
         mxb = mbar;
         sxb = sbar;
         if (jac) {
+            if (int r = rollout_jtape_wait(ctx, t)) return r;
             jac_vjp(jrec + (size_t)t * JS, D, E, Mgp, mbar.data(), sbar.data(), Vb.data(), mjb.data(), sjb.data(), jacc);
             for (int q = 0; q < D * D; ++q)
                 if (!std::isfinite(sjb[q])) return fail(ctx, PILCO_E_NOT_PD, "rollout_grad: singular s + Lambda^2 or I + Lambda s");

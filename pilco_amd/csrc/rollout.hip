@@ -914,17 +914,43 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     }
     HIPCHK(hipMemcpyAsync(h_misc, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(h_traj, ctx->traj.p, sizeof(double) * NTJ, hipMemcpyDeviceToHost, ctx->st));
+    // the records come down in chunks, LAST steps first, an event behind each: the host's reverse sweep starts on the
+    // last steps while the earlier ones are still on their way (rollout_jtape_wait)
+    ctx->jwait_from = H;
+    ctx->jwait_next = 0;
+    ctx->jwait_n = 0;
     if (H > 0) {
         HIPCHK(hipMemcpyAsync(h_tape, ctx->tape.p, sizeof(double) * (size_t)H * TS, hipMemcpyDeviceToHost, ctx->st));
-        HIPCHK(hipMemcpyAsync(h_jrec, ctx->jrec.p, sizeof(double) * (size_t)H * JS, hipMemcpyDeviceToHost, ctx->st));
+        const int nch = std::min(H, 4);
+        for (int k = 0; k < nch; ++k) {
+            const int t1 = H - (int)((long)k * H / nch), t0 = H - (int)((long)(k + 1) * H / nch);   // steps [t0, t1)
+            HIPCHK(hipMemcpyAsync(h_jrec + (size_t)t0 * JS, ctx->jrec.p + (size_t)t0 * JS, sizeof(double) * (size_t)(t1 - t0) * JS,
+                                  hipMemcpyDeviceToHost, ctx->st));
+            if (!ctx->jwait_ev[k]) HIPCHK(hipEventCreateWithFlags(&ctx->jwait_ev[k], hipEventDisableTiming));
+            HIPCHK(hipEventRecord(ctx->jwait_ev[k], ctx->st));
+            ctx->jwait_t0[k] = t0;
+        }
+        ctx->jwait_n = nch;
+        if (int r = rollout_jtape_wait(ctx, H - 1)) return r;   // reward, trajectory, tape and the last chunk are on the host
+    } else {
+        HIPCHK(hipStreamSynchronize(ctx->st));
     }
-    HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());
     *reward = h_misc[0];
     *traj = h_traj;
     *tape = h_tape;
     *jrec = h_jrec;
     *jstride = JS;
+    return PILCO_OK;
+}
+
+// Block until the records of step t (and everything enqueued before them) are on the host.
+int rollout_jtape_wait(pilco_ctx* ctx, int t) {
+    while (t < ctx->jwait_from && ctx->jwait_next < ctx->jwait_n) {
+        const int k = ctx->jwait_next++;
+        HIPCHK(hipEventSynchronize(ctx->jwait_ev[k]));
+        ctx->jwait_from = ctx->jwait_t0[k];
+    }
     return PILCO_OK;
 }
 
