@@ -31,3 +31,20 @@ def test_mfma_chains_have_no_register_overlap_and_no_early_result_reads(unit, tm
     for tool in ("mfma_overlap_check.py", "mfma_hazard_check.py"):
         chk = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), asm], capture_output=True, text=True, timeout=300)
         assert chk.returncode == 0, "%s on %s:\n%s" % (tool, unit, chk.stdout[-3000:])
+
+
+def test_the_scanners_flag_the_two_patterns_they_guard_against(tmp_path):
+    """The code hipcc actually emitted in round 2 (reverse sweep, K = 20 instantiation), reduced to the offending lines."""
+    tools = os.path.join(ROOT, "tools")
+    overlap = tmp_path / "overlap.s"
+    overlap.write_text("_Zbad:\n\tv_mfma_f64_16x16x4_f64 v[108:115], v[114:115], v[80:81], 0\n")
+    early = tmp_path / "early.s"
+    early.write_text("_Zbad:\n\tv_mfma_f64_16x16x4_f64 v[108:115], v[178:179], v[96:97], v[108:115]\n"
+                     "\tv_max_f64 v[194:195], v[114:115], s[68:69]\n")
+    fine = tmp_path / "fine.s"
+    fine.write_text("_Zok:\n\tv_mfma_f64_16x16x4_f64 v[108:115], v[178:179], v[96:97], v[108:115]\n\ts_nop 10\n"
+                    "\tv_max_f64 v[194:195], v[114:115], s[68:69]\n")
+    run = lambda tool, f: subprocess.run([sys.executable, os.path.join(tools, tool), str(f)], capture_output=True, text=True).returncode
+    assert run("mfma_overlap_check.py", overlap) == 1
+    assert run("mfma_hazard_check.py", early) == 1
+    assert run("mfma_overlap_check.py", fine) == 0 and run("mfma_hazard_check.py", fine) == 0
