@@ -1336,6 +1336,40 @@ def test_jacobian_tape_gradient_equals_per_step_device_adjoint(ctx, shape):
             np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-12 * max(1.0, float(np.abs(b).max())))
 
 
+def test_sparse_model_policy_gradient_jacobian_tape_vs_device_adjoint_and_fd(ctx):
+    """Value and gradient through an SMGPR dynamics model (FITC factors, moment matching over the M inducing points,
+    smgpr.py:24-52): Jacobian tape against the per-step device adjoint and against a central difference of rollouts."""
+    from pilco_amd.adjoint import rollout_value_and_grad
+    from pilco_amd.models import PILCO
+    c = synthetic.config_c2(N=400, D=5, E=4)
+    rs = np.random.RandomState(3)
+    p = PILCO((c["X"], c["Y"]), num_induced_points=50, horizon=6)
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(c["lengthscales"][i])
+        mdl.kernel.variance.assign(c["variance"][i])
+        mdl.likelihood.variance.assign(c["noise"][i])
+        mdl.inducing_variable.Z.assign(c["X"][rs.choice(400, 50, replace=False)])
+    W0, b0 = 0.3 * rs.randn(1, 4), 0.1 * rs.randn(1, 1)
+    p.controller.W.assign(W0); p.controller.b.assign(b0); p.controller.max_action = 1.5
+    p.m_init, p.S_init = c["m0"], c["S0"]
+    out = {}
+    try:
+        for mode in (1, 0):
+            p.ctx.set_grad_mode(mode)
+            out[mode] = rollout_value_and_grad(p)
+    finally:
+        p.ctx.set_grad_mode(1)
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-10)
+    for a, b in zip(out[1][1], out[0][1]):
+        np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-12)
+    h, dW = 1e-6, rs.randn(1, 4)
+    vals = []
+    for sgn in (+1.0, -1.0):
+        p.controller.W.assign(W0 + sgn * h * dW)
+        vals.append(float(p.compute_reward()[0, 0]))
+    np.testing.assert_allclose(float((out[1][1][0] * dW).sum()), (vals[0] - vals[1]) / (2 * h), rtol=1e-5, atol=1e-9)
+
+
 @pytest.mark.parametrize("dims", [(12, 3), (14, 4), (20, 6)])
 def test_policy_gradient_wide_inputs_vs_autograd(ctx, dims):
     """Reverse mode beyond D = 14 (state + control up to the forward path's D <= 32): the Jacobian tape hands over to the
