@@ -1362,6 +1362,13 @@ def test_sparse_model_policy_gradient_jacobian_tape_vs_device_adjoint_and_fd(ctx
     np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-10)
     for a, b in zip(out[1][1], out[0][1]):
         np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-12)
+    # a rollout whose per-step buffers would exceed the cap (PILCO_JAC_GB) hands over to the per-step device adjoint by itself
+    os.environ["PILCO_JAC_GB"] = "1e-6"
+    try:
+        r_cap, g_cap = rollout_value_and_grad(p)
+    finally:
+        del os.environ["PILCO_JAC_GB"]
+    assert r_cap == out[0][0] and all(np.array_equal(a, b) for a, b in zip(g_cap, out[0][1]))
     h, dW = 1e-6, rs.randn(1, 4)
     vals = []
     for sgn in (+1.0, -1.0):
