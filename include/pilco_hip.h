@@ -166,6 +166,21 @@ int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double
 int pilco_rollout_tape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
                        const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj,
                        double* tape);
+/* Cotangent seeds for objectives beyond the additive reward (SafePILCO's multiplicative risk term,
+ * safe_pilco_extension/safe_pilco.py:29-50; any function of the state trajectory): after the forward pass the library
+ * calls seed_fn(user, H, E, traj, seeds) with traj [H+1][E + E*E] (m_t | s_t, t = 0..H; state t < H is the
+ * pre-propagation state the reward of step t sees) and seeds [H+1][E + E*E] zero-filled; the callback writes
+ * d objective / d (m_t, s_t) and the reverse sweep adds them where the reward's own cotangents enter.  *reward is the
+ * additive reward only: the caller adds its own term.  What TensorFlow's reverse mode through training_loss gives the
+ * reference for whatever predict() returns (pilco/models/pilco.py:47-50, 85-90). */
+typedef void (*pilco_seed_fn)(void* user, int H, int E, const double* traj, double* seeds);
+int pilco_rollout_grad_seeded(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                              const double* m0, const double* S0, int H, pilco_seed_fn seed_fn, void* seed_user, double* reward,
+                              double* dW, double* db);
+int pilco_rollout_grad_rbf_seeded(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                                  const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
+                                  const double* noisep, int bf, pilco_seed_fn seed_fn, void* seed_user, double* reward, double* dX,
+                                  double* dY, double* dls);
 /* Value and gradient of the rollout reward w.r.t. a squashed LinearController's parameters, dW (U,E) and db (U):
  * training_loss + TensorFlow reverse mode in the reference (pilco/models/pilco.py:47-50,85-90).  Forward rollout
  * with a tape, then the reverse sweep with the moment-matching adjoint of every step on the device and the O(D^3)

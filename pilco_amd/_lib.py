@@ -47,6 +47,8 @@ class RewardTerm(C.Structure):
 
 # every symbol include/pilco_hip.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
+# pilco_seed_fn (include/pilco_hip.h): (user, H, E, traj [H+1][E+E*E], seeds [H+1][E+E*E]) -> None
+SEED_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
 SIGNATURES = {
     "pilco_abi_version": (C.c_int, []),
     "pilco_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
@@ -78,6 +80,10 @@ SIGNATURES = {
                                      _dp, _dp, _dp]),
     "pilco_rollout_grad_rbf": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
                                          _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]),
+    "pilco_rollout_grad_seeded": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
+                                            SEED_FN, _vp, _dp, _dp, _dp]),
+    "pilco_rollout_grad_rbf_seeded": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
+                                                _dp, _dp, _dp, _dp, C.c_int, SEED_FN, _vp, _dp, _dp, _dp, _dp]),
     "pilco_propagate": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp]),
     "pilco_policy_action": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp, _dp]),
     "pilco_reward_eval": (C.c_int, [_vp, C.POINTER(RewardTerm), C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
@@ -352,18 +358,39 @@ class Context:
                                               _ptr(mH), _ptr(SH), _ptr(rew), _ptr(traj), _ptr(tape)))
         return mH, SH, rew, traj, tape[:H]
 
-    def rollout_grad(self, policy, rewards, m0, S0, H):
-        """(reward, dW (U,E), db (U)) for a squashed linear policy: the native reverse sweep (pilco_rollout_grad)."""
+    @staticmethod
+    def _seed_callback(seed_fn, errors):
+        """Wrap seed_fn(traj (H+1, E+E*E)) -> seeds of the same shape as a pilco_seed_fn; an exception inside the callback
+        is kept in `errors` (it must not unwind through the C frames) and poisons the seeds so that the call fails."""
+        def cb(_user, H, E, traj_p, seeds_p):
+            n = (H + 1) * (E + E * E)
+            out = np.ctypeslib.as_array(seeds_p, shape=(n,))
+            try:
+                traj = np.ctypeslib.as_array(traj_p, shape=(n,)).reshape(H + 1, E + E * E).copy()
+                out[:] = np.asarray(seed_fn(traj), dtype=np.float64).reshape(n)
+            except BaseException as exc:   # noqa: BLE001 -- re-raised by the caller
+                errors.append(exc)
+                out[:] = np.nan
+        return SEED_FN(cb)
+
+    def rollout_grad(self, policy, rewards, m0, S0, H, seed_fn=None):
+        """(reward, dW (U,E), db (U)) for a squashed linear policy: the native reverse sweep (pilco_rollout_grad).
+        seed_fn(traj) -> d objective / d (m_t, s_t) for an objective beyond the additive reward (pilco_rollout_grad_seeded)."""
         E = policy["state_dim"]; U = policy["control_dim"]
         p, k1 = self._policy(policy)
         r, k2 = self._rewards(rewards, E)
         m0 = _f64(m0, (E,)); S0 = _f64(S0, (E, E))
         rew = np.zeros((1, 1)); dW = np.empty((U, E)); db = np.empty((U,))
-        self._chk(self.lib.pilco_rollout_grad(self.h, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H),
-                                              _ptr(rew), _ptr(dW), _ptr(db)))
+        errors = []
+        cb = self._seed_callback(seed_fn, errors) if seed_fn is not None else SEED_FN()
+        rc = self.lib.pilco_rollout_grad_seeded(self.h, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H), cb, None,
+                                                _ptr(rew), _ptr(dW), _ptr(db))
+        if errors:
+            raise errors[0]
+        self._chk(rc)
         return float(rew[0, 0]), dW, db
 
-    def rollout_grad_rbf(self, policy, rewards, m0, S0, H, Xp, Yp, lsp, noisep):
+    def rollout_grad_rbf(self, policy, rewards, m0, S0, H, Xp, Yp, lsp, noisep, seed_fn=None):
         """(reward, dX (bf,E), dY (bf,U), dls (U,E)) for an RBF policy: the native reverse sweep (pilco_rollout_grad_rbf)."""
         E = policy["state_dim"]; U = policy["control_dim"]
         p, k1 = self._policy(policy)
@@ -372,9 +399,14 @@ class Context:
         Xp = _f64(Xp); bf = Xp.shape[0]
         Xp = _f64(Xp, (bf, E)); Yp = _f64(Yp, (bf, U)); lsp = _f64(lsp, (U, E)); noisep = _f64(noisep, (U,))
         rew = np.zeros((1, 1)); dX = np.empty((bf, E)); dY = np.empty((bf, U)); dls = np.empty((U, E))
-        self._chk(self.lib.pilco_rollout_grad_rbf(self.h, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H),
-                                                  _ptr(Xp), _ptr(Yp), _ptr(lsp), _ptr(noisep), bf,
-                                                  _ptr(rew), _ptr(dX), _ptr(dY), _ptr(dls)))
+        errors = []
+        cb = self._seed_callback(seed_fn, errors) if seed_fn is not None else SEED_FN()
+        rc = self.lib.pilco_rollout_grad_rbf_seeded(self.h, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H),
+                                                    _ptr(Xp), _ptr(Yp), _ptr(lsp), _ptr(noisep), bf, cb, None,
+                                                    _ptr(rew), _ptr(dX), _ptr(dY), _ptr(dls))
+        if errors:
+            raise errors[0]
+        self._chk(rc)
         return float(rew[0, 0]), dX, dY, dls
 
     def propagate(self, policy, m_x, s_x):

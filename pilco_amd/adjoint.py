@@ -10,8 +10,10 @@ oracle/adjoint_sweep.py.)
 from __future__ import annotations
 
 
-def rollout_value_and_grad(pilco):
-    """(reward, grads): grads = (dW, db) for a LinearController, (dX, dY, dlengthscales) for an RbfController."""
+def rollout_value_and_grad(pilco, seed_fn=None):
+    """(reward, grads): grads = (dW, db) for a LinearController, (dX, dY, dlengthscales) for an RbfController.
+    seed_fn(traj (H+1, E+E*E)) -> cotangent seeds d objective / d (m_t, s_t) for an objective beyond the additive reward
+    (the returned reward is the additive part; the gradients are those of additive reward + seeded objective)."""
     from .controllers import LinearController, RbfController
     ctl, rew = pilco.controller, pilco.reward
     linear = isinstance(ctl, LinearController)
@@ -20,8 +22,8 @@ def rollout_value_and_grad(pilco):
     pilco.mgpr._user_factors = None
     pilco.mgpr._ensure_factorized()
     if linear:
-        r, dW, db = pilco.ctx.rollout_grad(pilco._policy_spec(), rew.terms(), pilco.m_init, pilco.S_init, pilco.horizon)
+        r, dW, db = pilco.ctx.rollout_grad(pilco._policy_spec(), rew.terms(), pilco.m_init, pilco.S_init, pilco.horizon, seed_fn=seed_fn)
         return r, (dW.reshape(ctl.W.shape), db.reshape(ctl.b.shape))
     r, dX, dY, dl = pilco.ctx.rollout_grad_rbf(pilco._policy_spec(), rew.terms(), pilco.m_init, pilco.S_init, pilco.horizon,
-                                               ctl.X, ctl.Y, ctl.lengthscales, ctl.noise)
+                                               ctl.X, ctl.Y, ctl.lengthscales, ctl.noise, seed_fn=seed_fn)
     return r, (dX, dY, dl)

@@ -632,7 +632,7 @@ void jac_vjp(const double* __restrict__ jr, int D, int E, const double* M, const
 }
 
 int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
-                      const double* m0, const double* S0, int H, double* reward, PolicyAdj& pol) {
+                      const double* m0, const double* S0, int H, double* reward, PolicyAdj& pol, pilco_seed_fn seed_fn, void* seed_user) {
     const int E = policy->state_dim, U = policy->control_dim, D = E + U;
     const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
     // Forward half.  Jacobian tape (default): one O(N^2) sweep per step gives the value and the step's Jacobian records,
@@ -661,6 +661,22 @@ int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_re
     vec e(U);
     for (int u = 0; u < U; ++u) e[u] = policy->max_action[u];
     vec mbar(E, 0.0), sbar((size_t)E * E, 0.0);
+    // An objective beyond the additive reward (Safe-PILCO's multiplicative risk term, any function of the state
+    // trajectory): the caller turns the trajectory into cotangent seeds d objective / d (m_t, s_t), t = 0..H, and the
+    // sweep adds them where the reward's own cotangents enter -- what TensorFlow's reverse mode does for whatever
+    // the reference's training_loss contains (pilco/models/pilco.py:47-50, safe_pilco_extension/safe_pilco.py:29-50).
+    const size_t SE = (size_t)E + (size_t)E * E;
+    vec seeds;
+    if (seed_fn) {
+        seeds.assign((size_t)(H + 1) * SE, 0.0);
+        seed_fn(seed_user, H, E, traj, seeds.data());
+        for (size_t q = 0; q < seeds.size(); ++q)
+            if (!std::isfinite(seeds[q])) return fail(ctx, PILCO_E_SHAPE, "rollout_grad: the seed callback returned a non-finite cotangent");
+        const double* sd = &seeds[(size_t)H * SE];
+        for (int i = 0; i < E; ++i) mbar[i] = sd[i];
+        for (int i = 0; i < E; ++i)
+            for (int j = 0; j < E; ++j) sbar[(size_t)i * E + j] = 0.5 * (sd[E + (size_t)i * E + j] + sd[E + (size_t)j * E + i]);
+    }
     vec G((size_t)E * E), Vb((size_t)D * E), s1bar((size_t)E * D), mjb(D), sjb((size_t)D * D), mxb(E), sxb((size_t)E * E);
     vec Bb((size_t)E * U), sub((size_t)U * U), mu0(U), su0((size_t)U * U), V0((size_t)E * U), V0b((size_t)E * U), cb((size_t)E * U), Cdbar(U);
     vec mu0b, su0b, rm(E), rS((size_t)E * E), jacc;
@@ -739,6 +755,11 @@ int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_re
         if (!reward_grad(rewards, n_rewards, E, m_x, s_x, rm, rS)) return fail(ctx, PILCO_E_NOT_PD, "rollout_grad: singular I + S W in the reward");
         for (int i = 0; i < E; ++i) mxb[i] += rm[i];
         for (int i = 0; i < E * E; ++i) sxb[i] += rS[i];
+        if (seed_fn) {
+            const double* sd = &seeds[(size_t)t * SE];
+            for (int i = 0; i < E; ++i) mxb[i] += sd[i];
+            for (int i = 0; i < E * E; ++i) sxb[i] += sd[E + i];
+        }
         mbar = mxb;
         for (int i = 0; i < E; ++i)
             for (int j = 0; j < E; ++j) sbar[(size_t)i * E + j] = 0.5 * (sxb[(size_t)i * E + j] + sxb[(size_t)j * E + i]);
@@ -768,24 +789,30 @@ extern "C" {
 // the tf.while_loop gives the reference (pilco/models/pilco.py:85-90,126-135).  Forward rollout with a tape on the
 // device, then the reverse sweep: the O(N^2) adjoint of every moment-matching step on the device
 // (pilco_gp_predict_vjp), the O(D^3) links here on the host in C++.  dW (U,E), db (U).
-int pilco_rollout_grad(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
-                       const double* m0, const double* S0, int H, double* reward, double* dW, double* db) {
+int pilco_rollout_grad_seeded(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                              const double* m0, const double* S0, int H, pilco_seed_fn seed_fn, void* seed_user, double* reward,
+                              double* dW, double* db) {
     if (!ctx) return PILCO_E_SHAPE;
     if (!policy || !m0 || !S0 || !reward || !dW || !db || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout_grad: bad arguments");
     if (int r = check_grad_args(ctx, policy, rewards, n_rewards, PILCO_POLICY_LINEAR)) return r;
     LinearAdj pol(policy->state_dim, policy->control_dim, policy->W, policy->b);
-    if (int r = rollout_grad_impl(ctx, policy, rewards, n_rewards, m0, S0, H, reward, pol)) return r;
+    if (int r = rollout_grad_impl(ctx, policy, rewards, n_rewards, m0, S0, H, reward, pol, seed_fn, seed_user)) return r;
     memcpy(dW, pol.Wbar.data(), sizeof(double) * pol.Wbar.size());
     memcpy(db, pol.bbar.data(), sizeof(double) * pol.bbar.size());
     return PILCO_OK;
+}
+int pilco_rollout_grad(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                       const double* m0, const double* S0, int H, double* reward, double* dW, double* db) {
+    return pilco_rollout_grad_seeded(ctx, policy, rewards, n_rewards, m0, S0, H, nullptr, nullptr, reward, dW, db);
 }
 
 // The same for an RbfController whose GP lives in PILCO_SLOT_POLICY: gradients w.r.t. the centres Xp (bf,E), the
 // targets Yp (bf,U) and the lengthscales lsp (U,E) (controllers.py:80-129); the caller passes the host copies of the
 // policy parameters it uploaded with pilco_gp_set_data / _set_hyp (noisep (U): the FakeGPR likelihood variance).
-int pilco_rollout_grad_rbf(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
-                           const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
-                           const double* noisep, int bf, double* reward, double* dX, double* dY, double* dls) {
+int pilco_rollout_grad_rbf_seeded(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                                  const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
+                                  const double* noisep, int bf, pilco_seed_fn seed_fn, void* seed_user, double* reward, double* dX,
+                                  double* dY, double* dls) {
     if (!ctx) return PILCO_E_SHAPE;
     if (!policy || !m0 || !S0 || !reward || !Xp || !Yp || !lsp || !noisep || !dX || !dY || !dls || H < 0 || bf <= 0)
         return fail(ctx, PILCO_E_SHAPE, "rollout_grad_rbf: bad arguments");
@@ -793,9 +820,15 @@ int pilco_rollout_grad_rbf(pilco_ctx* ctx, const pilco_policy* policy, const pil
     RbfAdj pol;
     if (!pol.init(bf, policy->state_dim, policy->control_dim, Xp, Yp, lsp, noisep))
         return fail(ctx, PILCO_E_NOT_PD, "rollout_grad_rbf: K + noise I of the policy is singular");
-    if (int r = rollout_grad_impl(ctx, policy, rewards, n_rewards, m0, S0, H, reward, pol)) return r;
+    if (int r = rollout_grad_impl(ctx, policy, rewards, n_rewards, m0, S0, H, reward, pol, seed_fn, seed_user)) return r;
     pol.finish(dX, dY, dls);
     return PILCO_OK;
+}
+int pilco_rollout_grad_rbf(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                           const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
+                           const double* noisep, int bf, double* reward, double* dX, double* dY, double* dls) {
+    return pilco_rollout_grad_rbf_seeded(ctx, policy, rewards, n_rewards, m0, S0, H, Xp, Yp, lsp, noisep, bf, nullptr, nullptr, reward, dX,
+                                         dY, dls);
 }
 
 }  // extern "C"

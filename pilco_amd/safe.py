@@ -13,6 +13,20 @@ from scipy.stats import norm
 from .models.pilco import PILCO
 
 
+def _cdf_interval(mu, scale, high, low):
+    """P = cdf(high) - cdf(low) of Normal(mu, scale) (a missing bound: -inf / +inf) with dP/dmu and dP/dscale."""
+    P, dmu, dsc = 0.0, 0.0, 0.0
+    if high is not None:
+        z = (high - mu) / scale
+        P += norm.cdf(z); dmu -= norm.pdf(z) / scale; dsc -= z * norm.pdf(z) / scale
+    else:
+        P += 1.0
+    if low is not None:
+        z = (low - mu) / scale
+        P -= norm.cdf(z); dmu += norm.pdf(z) / scale; dsc += z * norm.pdf(z) / scale
+    return P, dmu, dsc
+
+
 class RiskOfCollision:
     """rewards_safe.py:13-25."""
 
@@ -27,6 +41,18 @@ class RiskOfCollision:
         d2 = norm(loc=m[0, 2], scale=infl[2])
         risk = (d1.cdf(self.high[0]) - d1.cdf(self.low[0])) * (d2.cdf(self.high[1]) - d2.cdf(self.low[1]))
         return risk, 0.0001 * np.ones(1)
+
+    def compute_reward_grad(self, m, s):
+        """(risk, d risk / d m (E), d risk / d s (E, E)) of compute_reward (the reference differentiates it by TF autodiff)."""
+        E = m.shape[1]
+        fac, dmu, dsc = [], [], []
+        for k, (dim, hi, lo) in enumerate(((0, self.high[0], self.low[0]), (2, self.high[1], self.low[1]))):
+            f, a, b = _cdf_interval(m[0, dim], 2.0 * s[dim, dim], hi, lo)
+            fac.append(f); dmu.append(a); dsc.append(2.0 * b)          # scale = 2 s_dd
+        dm, ds = np.zeros(E), np.zeros((E, E))
+        dm[0], dm[2] = dmu[0] * fac[1], dmu[1] * fac[0]
+        ds[0, 0], ds[2, 2] = dsc[0] * fac[1], dsc[1] * fac[0]
+        return fac[0] * fac[1], dm, ds
 
 
 class SingleConstraint:
@@ -48,6 +74,15 @@ class SingleConstraint:
         if not self.inside:
             risk = 1 - risk
         return risk, 0.0001 * np.ones(1)
+
+    def compute_reward_grad(self, m, s):
+        """(risk, d risk / d m (E), d risk / d s (E, E)) of compute_reward."""
+        E = m.shape[1]
+        f, a, b = _cdf_interval(m[0, self.dim], s[self.dim, self.dim], self.high, self.low)   # low None: cdf(high); high None: 1 - cdf(low)
+        sign = 1.0 if self.inside else -1.0
+        dm, ds = np.zeros(E), np.zeros((E, E))
+        dm[self.dim], ds[self.dim, self.dim] = sign * a, sign * b
+        return (f if self.inside else 1.0 - f), dm, ds
 
 
 class ObjectiveFunction:
@@ -79,3 +114,24 @@ class SafePILCO(PILCO):
         for t in range(n):  # pre-propagation states, like the additive reward
             mult *= 1.0 - float(self.reward_mult.compute_reward(traj[t, :E].reshape(1, E), traj[t, E:].reshape(E, E))[0])
         return M, S, reward_add + self.mu * (1.0 - mult)
+
+    def trajectory_objective(self, traj):
+        """The part of predict()'s total reward that is not the additive reward, mu (1 - prod_t (1 - risk_t)), and its
+        cotangent seeds d / d (m_t, s_t), t = 0..H (traj: (H+1, E + E*E), state t < H pre-propagation).  optimize_policy
+        hands the seeds to the native reverse sweep (pilco_rollout_grad_seeded): the reference gets the same gradient from
+        TensorFlow's reverse mode through its predict() (safe_pilco.py:29-50, pilco.py:85-90)."""
+        if not hasattr(self.reward_mult, "compute_reward_grad"):
+            return None
+        E, H = self.state_dim, traj.shape[0] - 1
+        risks, grads = np.empty(H), []
+        for t in range(H):
+            r, dm, ds = self.reward_mult.compute_reward_grad(traj[t, :E].reshape(1, E), traj[t, E:].reshape(E, E))
+            risks[t] = r
+            grads.append((dm, ds))
+        one = 1.0 - risks
+        seeds = np.zeros_like(traj)
+        for t in range(H):
+            w = self.mu * np.prod(np.delete(one, t))          # d [mu (1 - prod)] / d risk_t
+            seeds[t, :E] = w * grads[t][0]
+            seeds[t, E:] = (w * grads[t][1]).ravel()
+        return self.mu * (1.0 - np.prod(one)), seeds

@@ -233,17 +233,32 @@ def policy_loss_and_grad(pilco, u, put, eps=1e-6):
     # the adjoint differentiates PILCO.predict's reward (pilco.py:118-136); a subclass that overrides predict (SafePILCO's
     # multiplicative risk term, safe_pilco.py:29-50) is differentiated by finite differences of ITS training_loss instead
     plain = type(pilco).predict is PILCO.predict
-    analytic = (plain and pilco.control_dim > 0 and pilco.state_dim + pilco.control_dim <= 32      # the forward path's limit; the Jacobian tape serves D <= 14, the per-step device adjoint the rest
+    # ... unless it says what predict() adds to the additive reward as a function of the state trajectory
+    # (trajectory_objective -> value, cotangent seeds): the native sweep takes the seeds (pilco_rollout_grad_seeded)
+    seeded = (not plain) and hasattr(pilco, "trajectory_objective")
+    analytic = ((plain or seeded) and pilco.control_dim > 0 and pilco.state_dim + pilco.control_dim <= 32   # the forward path's limit; the Jacobian tape serves D <= 14, the per-step device adjoint the rest
                 and all(t["kind"] in (_lib.REWARD_EXPONENTIAL, _lib.REWARD_LINEAR) for t in pilco.reward.terms()))
-    if analytic and isinstance(ctl, LinearController):
+    extra = {"v": 0.0, "ok": True}
+
+    def seed_fn(traj):
+        out = pilco.trajectory_objective(traj)
+        if out is None:
+            extra["ok"] = False
+            return np.zeros_like(traj)
+        extra["v"] = float(out[0])
+        return out[1]
+
+    if analytic and isinstance(ctl, (LinearController, RbfController)):
         from .adjoint import rollout_value_and_grad
-        r, (Wb, bb) = rollout_value_and_grad(pilco)
-        return -r, -np.concatenate([Wb.ravel(), bb.ravel()])
-    if analytic and isinstance(ctl, RbfController):
-        from .adjoint import rollout_value_and_grad
-        r, (Xb, Yb, lb) = rollout_value_and_grad(pilco)
-        nu = lb.size                                         # ls = lower + softplus(u): d ls / du = sigmoid(u)
-        return -r, -np.concatenate([Xb.ravel(), Yb.ravel(), (lb * _dsoftplus(u[-nu:]).reshape(lb.shape)).ravel()])
+        r, grads = rollout_value_and_grad(pilco, seed_fn if seeded else None)
+        if extra["ok"]:
+            r += extra["v"]
+            if isinstance(ctl, LinearController):
+                Wb, bb = grads
+                return -r, -np.concatenate([Wb.ravel(), bb.ravel()])
+            Xb, Yb, lb = grads
+            nu = lb.size                                         # ls = lower + softplus(u): d ls / du = sigmoid(u)
+            return -r, -np.concatenate([Xb.ravel(), Yb.ravel(), (lb * _dsoftplus(u[-nu:]).reshape(lb.shape)).ravel()])
     f0 = float(pilco.training_loss()[0, 0])
     g = np.empty_like(u)
     for i in range(u.size):

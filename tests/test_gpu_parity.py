@@ -1008,8 +1008,8 @@ def test_safe_pilco_accumulator(ctx):
 
 def test_safe_pilco_vs_executed_extension_and_its_policy_gradient(ctx, golden_dir):
     """SafePILCO against safe_pilco_extension/safe_pilco.py executed (fixture safe_pilco.npz); the objective
-    optimize_policy differentiates must be the TOTAL reward, risk term included (the analytic adjoint only covers the
-    additive reward, so a SafePILCO falls back to finite differences of its own training_loss)."""
+    optimize_policy differentiates must be the TOTAL reward, risk term included: the risk term's cotangent seeds go into
+    the native reverse sweep; the gradient is held to reverse mode through the executed extension."""
     from pilco_amd.rewards import ExponentialReward
     from pilco_amd.safe import SafePILCO, SingleConstraint
     from pilco_amd.training import _policy_params, policy_loss_and_grad
@@ -1027,8 +1027,18 @@ def test_safe_pilco_vs_executed_extension_and_its_policy_gradient(ctx, golden_di
     get, put = _policy_params(p.controller)
     f, grad = policy_loss_and_grad(p, get(), put)
     np.testing.assert_allclose(-f, float(g["reward_total"]), rtol=RTOL)
-    np.testing.assert_allclose(-grad[:2].reshape(1, 2), g["dtotal_dW"], rtol=1e-4)     # central differences
-    np.testing.assert_allclose(-grad[2:].reshape(1, 1), g["dtotal_db"], rtol=1e-4)
+    # analytic: SafePILCO.trajectory_objective seeds the native reverse sweep with d risk term / d (m_t, s_t)
+    # (pilco_rollout_grad_seeded); central differences of training_loss could not meet this tolerance
+    np.testing.assert_allclose(-grad[:2].reshape(1, 2), g["dtotal_dW"], rtol=1e-7)
+    np.testing.assert_allclose(-grad[2:].reshape(1, 1), g["dtotal_db"], rtol=1e-7)
+    # a multiplicative reward without compute_reward_grad still works: finite differences of the subclass's training_loss
+    class NoGrad:
+        def __init__(self, inner): self.inner = inner
+        def compute_reward(self, m, s): return self.inner.compute_reward(m, s)
+    p.reward_mult = NoGrad(p.reward_mult)
+    f2, grad2 = policy_loss_and_grad(p, get(), put)
+    np.testing.assert_allclose(f2, f, rtol=1e-12)
+    np.testing.assert_allclose(grad2, grad, rtol=1e-4)
 
 
 def test_rbf_policy_gradient_adjoint_vs_autograd(ctx):
