@@ -11,6 +11,7 @@ import numpy as np
 from scipy.stats import norm
 
 from .models.pilco import PILCO
+from .params import Parameter
 
 
 def _cdf_interval(mu, scale, high, low):
@@ -104,7 +105,7 @@ class SafePILCO(PILCO):
                          reward=reward_add, m_init=m_init, S_init=S_init, name=name, ctx=ctx)
         if reward_mult is None:
             raise Exception("have to define multiplicative reward")
-        self.mu = float(mu)
+        self.mu = Parameter(float(mu), trainable=False, name="mu")   # safe_pilco.py:25: gpflow.Parameter(mu, trainable=False): callers use .numpy() / .assign()
         self.reward_mult = reward_mult
 
     def predict(self, m_x, s_x, n):
@@ -113,7 +114,10 @@ class SafePILCO(PILCO):
         mult = 1.0
         for t in range(n):  # pre-propagation states, like the additive reward
             mult *= 1.0 - float(self.reward_mult.compute_reward(traj[t, :E].reshape(1, E), traj[t, E:].reshape(E, E))[0])
-        return M, S, reward_add + self.mu * (1.0 - mult)
+        return M, S, reward_add + self._mu() * (1.0 - mult)
+
+    def _mu(self):
+        return float(self.mu.numpy()) if isinstance(self.mu, Parameter) else float(self.mu)
 
     def trajectory_objective(self, traj):
         """The part of predict()'s total reward that is not the additive reward, mu (1 - prod_t (1 - risk_t)), and its
@@ -128,10 +132,10 @@ class SafePILCO(PILCO):
             r, dm, ds = self.reward_mult.compute_reward_grad(traj[t, :E].reshape(1, E), traj[t, E:].reshape(E, E))
             risks[t] = r
             grads.append((dm, ds))
-        one = 1.0 - risks
+        one, mu = 1.0 - risks, self._mu()
         seeds = np.zeros_like(traj)
         for t in range(H):
-            w = self.mu * np.prod(np.delete(one, t))          # d [mu (1 - prod)] / d risk_t
+            w = mu * np.prod(np.delete(one, t))               # d [mu (1 - prod)] / d risk_t
             seeds[t, :E] = w * grads[t][0]
             seeds[t, E:] = (w * grads[t][1]).ravel()
-        return self.mu * (1.0 - np.prod(one)), seeds
+        return mu * (1.0 - np.prod(one)), seeds

@@ -1346,6 +1346,22 @@ def test_jacobian_tape_gradient_equals_per_step_device_adjoint(ctx, shape):
             np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-12 * max(1.0, float(np.abs(b).max())))
 
 
+def test_safe_cars_example_two_iterations(ctx):
+    """examples/safe_cars.py (the loop of the reference's examples/safe_cars_run.py:41-140 on the HIP path): SafePILCO with
+    RbfController(bf=40), a fixed likelihood variance, the risk term's seeds in the policy gradient, mu as a Parameter.
+    The optimiser must lower the predicted risk of the first iteration's policy (0.6 with mu = -300) below the threshold."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("safe_cars", os.path.join(root, "examples", "safe_cars.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.run(iters=2, verbose=False)
+    it = out["iterations"]
+    assert len(it) == 2 and all(np.isfinite(list(i[k] for k in ("predicted_return", "predicted_risk", "mu", "plant_return"))).all() for i in it)
+    assert it[0]["mu"] == -300.0 and it[1]["mu"] == -450.0          # risk above the threshold -> mu * 1.5 (safe_cars_run.py:137)
+    assert it[1]["predicted_risk"] < 0.10 < it[0]["predicted_risk"]
+
+
 def test_sparse_model_policy_gradient_jacobian_tape_vs_device_adjoint_and_fd(ctx):
     """Value and gradient through an SMGPR dynamics model (FITC factors, moment matching over the M inducing points,
     smgpr.py:24-52): Jacobian tape against the per-step device adjoint and against a central difference of rollouts."""
