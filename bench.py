@@ -456,6 +456,22 @@ def main():
                 out["secondary"]["config5_inverted_pendulum"] = config5_metrics(ctx, not args.no_cpu_baseline)
             except Exception as exc:   # never lose the headline line to a secondary measurement
                 out["secondary"]["config5_inverted_pendulum"] = {"error": repr(exc)}
+            try:   # the reference's Safe-PILCO loop (examples/safe_cars_run.py:41-140) on the HIP path: wall-clock of the whole loop
+                import safe_cars
+                from pilco_amd import _lib as _l
+                prev = _l._default_ctx
+                _l.set_context(ctx)
+                try:
+                    sc = safe_cars.run(iters=5, verbose=False)
+                finally:
+                    _l.set_context(prev)
+                out["secondary"]["safe_cars_linear_loop"] = {
+                    "hip_total_s": sc["total_s"], "predicted_risk_per_iteration": [i["predicted_risk"] for i in sc["iterations"]],
+                    "optimize_policy_s_per_iteration": [i["optimize_policy_s"] for i in sc["iterations"]],
+                    "note": "SafePILCO, RbfController(bf=40), horizon 25, 5 x [optimize_models, optimize_policy(maxiter=20, restarts=2), risk check, rollout]; "
+                            "the risk term enters the policy gradient as cotangent seeds of the native reverse sweep"}
+            except Exception as exc:
+                out["secondary"]["safe_cars_linear_loop"] = {"error": repr(exc)}
             ctx.gp_set_data(0, cfg["X"], cfg["Y"])
             ctx.gp_set_hyp(0, cfg["lengthscales"], cfg["variance"], cfg["noise"])
         if replicas is not None:
