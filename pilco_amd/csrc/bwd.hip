@@ -9,11 +9,13 @@ namespace pilco {
 // with W = beta_a beta_b^T (- iK_a on the diagonal pair).  A wave owns 16*BWD_RT rows and sweeps a range
 // of columns; the exponent tile is computed TRANSPOSED (column operand as MFMA A, row operand as B) so
 // that the weighted tile W.L lands in the B-operand layout of a second MFMA that contracts it with
-// [w_j | 1]: moments and row sums cost 4 MFMAs per 16x16 tile and no VALU reductions.  The column sums of
-// an off-diagonal pair run along the lanes of a DPP row: four row_shr adds per result register, the four
-// waves of a workgroup keep their partial columns in separate LDS slices that are summed in a fixed order
-// (diagonal pairs: c = r by symmetry).
-// rowmom[pl][js][16][npad]: d < D -> m_i[d], d = D -> r_i, per column split js;
+// [w_j | 1]: moments and row sums cost 4 MFMAs per 16x16 tile and moment tile (NMT = ceil((D + 1) / 16) of them) and no
+// VALU reductions.  The column sums of an off-diagonal pair run along the lanes of a DPP row: the wave parks its four
+// result registers in a private LDS scratch and reads the previous step's back four at a time (two quad permutes finish
+// the sum: 9 VALU ops per step instead of four row_shr adds per register); the four waves of a workgroup keep their
+// column sums in separate LDS slices that are summed in a fixed order (diagonal pairs: c = r by symmetry).
+// Off-diagonal pairs: the row side carries beta_b only, the column side beta_a only (k_mm_bwd_post applies the rest).
+// rowmom[pl][js][16 NMT][npad]: d < D -> m_i[d], d = D -> r_i, per column split js;
 // cpart[pl - E][row block][npad]: column sums over the rows of one workgroup.
 #ifndef BWD_RT
 #define BWD_RT 2

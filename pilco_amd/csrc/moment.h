@@ -162,8 +162,8 @@ void mm_prep_chunks(int npad, int PL, int EL, int* nch, int* nchm);
 int mm_kp(int D);
 bool mm_vsep(int D);   // the contraction stops at K = D + 1 and v_j is added after it (saves a whole MFMA k-step)
 void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot);
-// reverse pass of one moment-matching step (single rank, D <= 14; the step's prep kernel must precede it on st):
-// scratch: rowmom [P][njs][16][npad], cpart [P - E][nrb][npad] (njs, nrb from mm_bwd_geometry) and
+// reverse pass of one moment-matching step (single rank, D <= 32; the step's prep kernel must precede it on st):
+// scratch: rowmom [P][njs][16 ceil((D + 1) / 16)][npad], cpart [P - E][nrb][npad] (njs, nrb from mm_bwd_geometry) and
 // part [P][mm_bwd_rc][1 + D + D*D] + [E][mm_bwd_rc][D*D + 2D + 1]; bars = (Mbar | Sbar | Vbar) on the device,
 // out [E + P][D + D*D] = per output / per pair contributions (mbar | sbar); their sum in a fixed order goes to
 // sum_out [D + D*D] (device-visible, normally pinned host memory); done: a zeroed device counter (left zeroed)
