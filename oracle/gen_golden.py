@@ -330,6 +330,39 @@ def gen_safe():
           dtotal_dW=-gW.numpy(), dtotal_db=-gb.numpy())
 
 
+def gen_safe_rbf():
+    """The same extension with an RbfController and rewards_safe.RiskOfCollision (rewards_safe.py:13-25), the pairing of
+    examples/safe_cars_run.py:72-86: total reward and its reverse-mode gradient w.r.t. the RBF centres, targets and
+    lengthscales through the executed predict() (4 states + 1 control, additive LinearReward, mu < 0)."""
+    import torch
+    R = ref_exec.load(safe=True)
+    c = synthetic.config_c2(N=60, D=5, E=4, seed=31)
+    rs = np.random.RandomState(13)
+    H, bf, mu = 5, 6, -4.0
+    Xp, Yp = 0.5 * rs.randn(bf, 4), 0.3 * rs.randn(bf, 1)
+    lsp = 1 + 0.3 * rs.rand(1, 4)
+    Wl = np.array([[0.6], [0.0], [0.0], [0.0]])
+    low, high = np.array([-0.4, -0.5]), np.array([0.5, 0.3])
+    np.random.seed(4)
+    ctl = R.controllers.RbfController(4, 1, bf, max_action=0.7)
+    ctl.set_data((Xp, Yp))
+    ctl.models[0].kernel.lengthscales.assign(lsp[0])
+    risk = R.rewards_safe.RiskOfCollision(2, low, high)
+    p = R.safe_pilco.SafePILCO((c["X"], c["Y"]), horizon=H, controller=ctl, reward_add=R.rewards.LinearReward(4, Wl), reward_mult=risk,
+                               mu=mu, m_init=c["m0"], S_init=c["S0"])
+    _set_hyp(p.mgpr.models, c["lengthscales"], c["variance"], c["noise"])
+    M, S, Rt = p.predict(c["m0"], c["S0"], H)
+    loss = p.training_loss()
+    pl = ctl.models[0].kernel.lengthscales
+    gX, gY, gl = torch.autograd.grad(loss.sum(), [ctl.models[0].X.unconstrained_variable, ctl.models[0].Y.unconstrained_variable,
+                                                  pl.unconstrained_variable])
+    dls_du = torch.sigmoid(pl.unconstrained_variable.detach())
+    _save("safe_pilco_rbf.npz", **{k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise", "m0", "S0")},
+          H=H, mu=mu, low=low, high=high, W_lin=Wl, rbf_X=Xp, rbf_Y=Yp, rbf_lengthscales=lsp, max_action=0.7,
+          M=n_(M), S=n_(S), reward_total=float(n_(Rt).ravel()[0]),
+          dtotal_dX=-gX.numpy(), dtotal_dY=-gY.numpy(), dtotal_dls=-(gl / dls_du).numpy()[None, :])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = ref_exec.load()
@@ -341,6 +374,7 @@ def main():
     gen_policy_gradient(R)
     gen_fitc_objective(R)
     gen_safe()
+    gen_safe_rbf()
     print("golden fixtures written to", OUT, "from the executed reference")
 
 

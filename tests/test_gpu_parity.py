@@ -1346,6 +1346,40 @@ def test_jacobian_tape_gradient_equals_per_step_device_adjoint(ctx, shape):
             np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-12 * max(1.0, float(np.abs(b).max())))
 
 
+def test_safe_pilco_rbf_policy_gradient_vs_executed_extension(ctx, golden_dir):
+    """SafePILCO with an RbfController and RiskOfCollision (the pairing of examples/safe_cars_run.py:72-86): total reward
+    and its gradient w.r.t. the RBF centres / targets / lengthscales against reverse mode through the EXECUTED extension
+    (fixture safe_pilco_rbf.npz): the risk term reaches the native sweep as cotangent seeds (pilco_rollout_grad_rbf_seeded)."""
+    from pilco_amd.adjoint import rollout_value_and_grad
+    from pilco_amd.controllers import RbfController
+    from pilco_amd.rewards import LinearReward
+    from pilco_amd.safe import RiskOfCollision, SafePILCO
+    g = np.load(os.path.join(golden_dir, "safe_pilco_rbf.npz"))
+    H = int(g["H"])
+    ctl = RbfController(state_dim=4, control_dim=1, num_basis_functions=g["rbf_X"].shape[0], max_action=float(g["max_action"]))
+    ctl.set_data((g["rbf_X"], g["rbf_Y"]))
+    ctl.models[0].kernel.lengthscales.assign(g["rbf_lengthscales"][0])
+    p = SafePILCO((g["X"], g["Y"]), horizon=H, controller=ctl, reward_add=LinearReward(4, g["W_lin"]),
+                  reward_mult=RiskOfCollision(2, g["low"], g["high"]), mu=float(g["mu"]), m_init=g["m0"], S_init=g["S0"])
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(g["lengthscales"][i]); mdl.kernel.variance.assign(g["variance"][i]); mdl.likelihood.variance.assign(g["noise"][i])
+    M, S, R = p.predict(g["m0"], g["S0"], H)
+    np.testing.assert_allclose(M, g["M"], rtol=RTOL)
+    np.testing.assert_allclose(S, g["S"], rtol=RTOL)
+    np.testing.assert_allclose(float(np.ravel(R)[0]), float(g["reward_total"]), rtol=RTOL)
+    extra = {}
+
+    def seed_fn(traj):
+        v, seeds = p.trajectory_objective(traj)
+        extra["v"] = v
+        return seeds
+
+    r_add, (dX, dY, dls) = rollout_value_and_grad(p, seed_fn)
+    np.testing.assert_allclose(r_add + extra["v"], float(g["reward_total"]), rtol=1e-9)
+    for got, key in ((dX, "dtotal_dX"), (dY, "dtotal_dY"), (dls, "dtotal_dls")):
+        np.testing.assert_allclose(got, g[key], rtol=1e-6, atol=1e-9 * float(np.abs(g[key]).max()))
+
+
 def test_safe_cars_example_two_iterations(ctx):
     """examples/safe_cars.py (the loop of the reference's examples/safe_cars_run.py:41-140 on the HIP path): SafePILCO with
     RbfController(bf=40), a fixed likelihood variance, the risk term's seeds in the policy gradient, mu as a Parameter.

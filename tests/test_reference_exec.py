@@ -278,6 +278,45 @@ def test_policy_gradient_through_the_executed_reference(R, golden_dir):
     np.testing.assert_allclose(bt.grad.numpy(), g["dreward_db"], rtol=1e-7)
 
 
+def test_safe_pilco_extension_executed_and_host_side_risk_terms(golden_dir):
+    """safe_pilco_extension/ executed (RbfController + RiskOfCollision, the pairing of examples/safe_cars_run.py:72-86):
+    the committed fixture equals the executed output, and the product's host-side risk terms (pilco_amd/safe.py: value
+    of mu (1 - prod (1 - risk_t)) and the analytic derivatives that seed the native policy gradient) agree with the
+    reference's own RiskOfCollision evaluated -- and differentiated by autograd -- on the same states."""
+    import torch
+    from oracle import ref_exec
+    from pilco_amd.safe import RiskOfCollision
+    Rs = ref_exec.load(safe=True)
+    g = _g(golden_dir, "safe_pilco_rbf.npz")
+    H = int(g["H"])
+    np.random.seed(4)
+    ctl = Rs.controllers.RbfController(4, 1, g["rbf_X"].shape[0], max_action=float(g["max_action"]))
+    ctl.set_data((g["rbf_X"], g["rbf_Y"]))
+    ctl.models[0].kernel.lengthscales.assign(g["rbf_lengthscales"][0])
+    risk_ref = Rs.rewards_safe.RiskOfCollision(2, g["low"], g["high"])
+    p = Rs.safe_pilco.SafePILCO((g["X"], g["Y"]), horizon=H, controller=ctl, reward_add=Rs.rewards.LinearReward(4, g["W_lin"]),
+                                reward_mult=risk_ref, mu=float(g["mu"]), m_init=g["m0"], S_init=g["S0"])
+    _set_hyp(p.mgpr.models, g)
+    M, S, Rt = p.predict(g["m0"], g["S0"], H)
+    np.testing.assert_allclose(n_(M), g["M"], rtol=1e-12)
+    np.testing.assert_allclose(float(n_(Rt).ravel()[0]), float(g["reward_total"]), rtol=1e-12)
+    # the reference's risk term and its autograd derivatives at a few states against the product's closed forms
+    risk_mine = RiskOfCollision(2, g["low"], g["high"])
+    rs = np.random.RandomState(5)
+    for _ in range(4):
+        A = 0.3 * rs.randn(4, 4)
+        m = 0.3 * rs.randn(1, 4)
+        s = A @ A.T + 0.2 * np.eye(4)
+        mt = torch.tensor(m, dtype=torch.float64, requires_grad=True)
+        st = torch.tensor(s, dtype=torch.float64, requires_grad=True)
+        r_t = torch.as_tensor(risk_ref.compute_reward(mt, st)[0])   # (the shim's tensor type is a torch.Tensor subclass)
+        gm, gs = torch.autograd.grad(r_t.sum(), [mt, st])
+        r, dm, ds = risk_mine.compute_reward_grad(m, s)
+        np.testing.assert_allclose(r, float(r_t.detach().sum()), rtol=1e-12)
+        np.testing.assert_allclose(dm, gm.numpy().ravel(), rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(ds, gs.numpy(), rtol=1e-10, atol=1e-14)
+
+
 def test_reference_side_binding_patches_the_real_reference_classes(R):
     """examples/reference_binding.py against the REAL reference package: patch() must find
     the classes and methods it replaces; the arithmetic itself needs a GPU (tests/test_gpu_parity.py runs it)."""
