@@ -330,6 +330,26 @@ def gen_safe():
           dtotal_dW=-gW.numpy(), dtotal_db=-gb.numpy())
 
 
+def gen_policy_gradient_wide(R):
+    """Reverse mode through the executed reference beyond D = 14 (state 14 + 4 controls: D = 18; the reference's autodiff
+    has no width limit, pilco.py:85-90): reward of an H = 3 rollout and d reward / d (W, b) of the LinearController."""
+    import torch
+    E, U, N, H = 14, 4, 90, 3
+    c = synthetic.config_c2(N=N, D=E + U, E=E, noise=1e-2, seed=7 + E + U, control_dim=U)
+    rs = np.random.RandomState(11)
+    W0, b0 = 0.2 * rs.randn(U, E), 0.1 * rs.randn(1, U)
+    np.random.seed(6)
+    p = R.PILCO((c["X"], c["Y"]), horizon=H, m_init=c["m0"], S_init=c["S0"])
+    p.controller.max_action = 1.2
+    _set_hyp(p.mgpr.models, c["lengthscales"], c["variance"], c["noise"])
+    p.controller.W.assign(W0)
+    p.controller.b.assign(b0)
+    loss = p.training_loss()
+    gW, gb = torch.autograd.grad(loss.sum(), [p.controller.W.unconstrained_variable, p.controller.b.unconstrained_variable])
+    _save("policy_gradient_wide.npz", **{k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise", "m0", "S0")},
+          H=H, W=W0, b=b0, max_action=1.2, reward=-float(loss.detach().sum()), dreward_dW=-gW.numpy(), dreward_db=-gb.numpy())
+
+
 def gen_safe_rbf():
     """The same extension with an RbfController and rewards_safe.RiskOfCollision (rewards_safe.py:13-25), the pairing of
     examples/safe_cars_run.py:72-86: total reward and its reverse-mode gradient w.r.t. the RBF centres, targets and
@@ -372,6 +392,7 @@ def main():
     gen_controllers(R)
     gen_reward(R)
     gen_policy_gradient(R)
+    gen_policy_gradient_wide(R)
     gen_fitc_objective(R)
     gen_safe()
     gen_safe_rbf()

@@ -1437,6 +1437,22 @@ def test_sparse_model_policy_gradient_jacobian_tape_vs_device_adjoint_and_fd(ctx
     np.testing.assert_allclose(float((out[1][1][0] * dW).sum()), (vals[0] - vals[1]) / (2 * h), rtol=1e-5, atol=1e-9)
 
 
+def test_policy_gradient_wide_inputs_vs_executed_reference(ctx, golden_dir):
+    """D = 18 (state 14 + 4 controls): reward and d reward / d (W, b) against reverse mode through the EXECUTED reference
+    (fixture policy_gradient_wide.npz) -- the width the Jacobian tape does not serve, i.e. the plain tape + per-step
+    device adjoint with the two-moment-tile sweep instantiation."""
+    from pilco_amd.adjoint import rollout_value_and_grad
+    g = np.load(os.path.join(golden_dir, "policy_gradient_wide.npz"))
+    cfg = {k: g[k] for k in ("X", "Y", "lengthscales", "variance", "noise")}
+    p = _pilco_from(cfg, int(g["H"]))
+    p.controller.W.assign(g["W"]); p.controller.b.assign(g["b"]); p.controller.max_action = float(g["max_action"])
+    p.m_init, p.S_init = g["m0"], g["S0"]
+    r, (Wb, bb) = rollout_value_and_grad(p)
+    np.testing.assert_allclose(r, float(g["reward"]), rtol=1e-9)
+    np.testing.assert_allclose(Wb, g["dreward_dW"], rtol=1e-6, atol=1e-9 * float(np.abs(g["dreward_dW"]).max()))
+    np.testing.assert_allclose(bb, g["dreward_db"], rtol=1e-6, atol=1e-9 * float(np.abs(g["dreward_db"]).max()))
+
+
 @pytest.mark.parametrize("dims", [(12, 3), (14, 4), (20, 6)])
 def test_policy_gradient_wide_inputs_vs_autograd(ctx, dims):
     """Reverse mode beyond D = 14 (state + control up to the forward path's D <= 32): the Jacobian tape hands over to the
