@@ -350,6 +350,30 @@ def gen_policy_gradient_wide(R):
           H=H, W=W0, b=b0, max_action=1.2, reward=-float(loss.detach().sum()), dreward_dW=-gW.numpy(), dreward_db=-gb.numpy())
 
 
+def gen_sparse_rollout(R):
+    """PILCO(num_induced_points=M) executed (pilco.py:27-32 -> SMGPR, smgpr.py:24-52): an H-step rollout through the FITC
+    model (every step's state, running reward) and reverse mode of its training_loss w.r.t. the LinearController -- the
+    sparse counterpart of test_cascade, which the reference does not test."""
+    import torch
+    c = synthetic.config_cascade()
+    H, M = 6, 20
+    rs = np.random.RandomState(19)
+    Z_all = np.stack([rs.rand(M, 3), rs.rand(M, 3)])
+    np.random.seed(8)
+    p = R.PILCO((c["X"], c["Y"]), num_induced_points=M, horizon=H, m_init=c["m"], S_init=c["s"])
+    _set_hyp(p.mgpr.models, c["lengthscales"], c["variance"], c["noise"])
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.inducing_variable.Z.assign(Z_all[i])
+    p.controller.W.assign(c["W"])
+    p.controller.b.assign(c["b"])
+    p.controller.max_action = c["max_action"]
+    Mt, St, Rt = _trajectory(p, c["m"], c["s"], H)
+    loss = p.training_loss()
+    gW, gb = torch.autograd.grad(loss.sum(), [p.controller.W.unconstrained_variable, p.controller.b.unconstrained_variable])
+    _save("sparse_rollout.npz", **{k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise", "m", "s", "W", "b", "max_action")},
+          H=H, Z_all=Z_all, M_traj=Mt, S_traj=St, R_traj=Rt, reward=-float(loss.detach().sum()), dreward_dW=-gW.numpy(), dreward_db=-gb.numpy())
+
+
 def gen_safe_rbf():
     """The same extension with an RbfController and rewards_safe.RiskOfCollision (rewards_safe.py:13-25), the pairing of
     examples/safe_cars_run.py:72-86: total reward and its reverse-mode gradient w.r.t. the RBF centres, targets and
@@ -393,6 +417,7 @@ def main():
     gen_reward(R)
     gen_policy_gradient(R)
     gen_policy_gradient_wide(R)
+    gen_sparse_rollout(R)
     gen_fitc_objective(R)
     gen_safe()
     gen_safe_rbf()

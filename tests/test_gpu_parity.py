@@ -1396,6 +1396,31 @@ def test_safe_cars_example_two_iterations(ctx):
     assert it[1]["predicted_risk"] < 0.10 < it[0]["predicted_risk"]
 
 
+def test_sparse_rollout_and_policy_gradient_vs_executed_reference(ctx, golden_dir):
+    """PILCO(num_induced_points=M) executed (fixture sparse_rollout.npz): every state of an H = 6 rollout through the FITC
+    model, the running reward, and d reward / d (W, b) against reverse mode through the executed reference -- the sparse
+    counterpart of test_cascade (each output trains its own Z, prediction uses model 0's, smgpr.py:50-52)."""
+    from pilco_amd.adjoint import rollout_value_and_grad
+    from pilco_amd.models import PILCO
+    g = np.load(os.path.join(golden_dir, "sparse_rollout.npz"))
+    H, Zs = int(g["H"]), g["Z_all"]
+    p = PILCO((g["X"], g["Y"]), num_induced_points=Zs.shape[1], horizon=H, m_init=g["m"], S_init=g["s"])
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(g["lengthscales"][i]); mdl.kernel.variance.assign(g["variance"][i]); mdl.likelihood.variance.assign(g["noise"][i])
+        mdl.inducing_variable.Z.assign(Zs[i])
+    p.controller.W.assign(g["W"]); p.controller.b.assign(g["b"]); p.controller.max_action = g["max_action"]
+    M, S, R, traj = p.predict_trajectory(g["m"], g["s"], H)
+    E = 2
+    for t in range(H + 1):
+        np.testing.assert_allclose(traj[t, :E], g["M_traj"][:, t], rtol=RTOL)
+        np.testing.assert_allclose(traj[t, E:].reshape(E, E), g["S_traj"][:, :, t], rtol=RTOL)
+    np.testing.assert_allclose(float(np.ravel(R)[0]), g["R_traj"][-1], rtol=RTOL)
+    r, (Wb, bb) = rollout_value_and_grad(p)
+    np.testing.assert_allclose(r, float(g["reward"]), rtol=1e-8)
+    np.testing.assert_allclose(Wb, g["dreward_dW"], rtol=1e-6)
+    np.testing.assert_allclose(bb, g["dreward_db"], rtol=1e-6)
+
+
 def test_sparse_model_policy_gradient_jacobian_tape_vs_device_adjoint_and_fd(ctx):
     """Value and gradient through an SMGPR dynamics model (FITC factors, moment matching over the M inducing points,
     smgpr.py:24-52): Jacobian tape against the per-step device adjoint and against a central difference of rollouts."""
