@@ -374,6 +374,26 @@ def gen_sparse_rollout(R):
           H=H, Z_all=Z_all, M_traj=Mt, S_traj=St, R_traj=Rt, reward=-float(loss.detach().sum()), dreward_dW=-gW.numpy(), dreward_db=-gb.numpy())
 
 
+def gen_policy_optimisation(R):
+    """PILCO.optimize_policy(maxiter=12, restarts=1) executed (pilco.py:75-113: SciPy L-BFGS-B on training_loss with TF
+    reverse mode; restarts=1 means no random restart): the controller it ends at and the reward there.  The product runs
+    the same optimiser on its own value + gradient, so the two end points pin value, gradient and parameter packing
+    together."""
+    c = synthetic.config_cascade()
+    H = 8
+    np.random.seed(9)
+    p = R.PILCO((c["X"], c["Y"]), horizon=H, m_init=c["m"], S_init=c["s"])
+    _set_hyp(p.mgpr.models, c["lengthscales"], c["variance"], c["noise"])
+    p.controller.W.assign(c["W"])
+    p.controller.b.assign(c["b"])
+    p.controller.max_action = c["max_action"]
+    r0 = float(n_(p.compute_reward()).ravel()[0])
+    p.optimize_policy(maxiter=12, restarts=1)
+    r1 = float(n_(p.compute_reward()).ravel()[0])
+    _save("policy_optimisation.npz", **{k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise", "m", "s", "W", "b", "max_action")},
+          H=H, maxiter=12, reward_start=r0, reward_end=r1, W_end=n_(p.controller.W), b_end=n_(p.controller.b))
+
+
 def gen_safe_rbf():
     """The same extension with an RbfController and rewards_safe.RiskOfCollision (rewards_safe.py:13-25), the pairing of
     examples/safe_cars_run.py:72-86: total reward and its reverse-mode gradient w.r.t. the RBF centres, targets and
@@ -418,6 +438,7 @@ def main():
     gen_policy_gradient(R)
     gen_policy_gradient_wide(R)
     gen_sparse_rollout(R)
+    gen_policy_optimisation(R)
     gen_fitc_objective(R)
     gen_safe()
     gen_safe_rbf()

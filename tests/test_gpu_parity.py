@@ -1396,6 +1396,22 @@ def test_safe_cars_example_two_iterations(ctx):
     assert it[1]["predicted_risk"] < 0.10 < it[0]["predicted_risk"]
 
 
+def test_optimize_policy_ends_where_the_executed_reference_ends(ctx, golden_dir):
+    """PILCO.optimize_policy(maxiter=12, restarts=1) (pilco.py:75-113) from the same controller: the same SciPy L-BFGS-B
+    on the product's value + analytic gradient must walk to the point the executed reference's optimiser reaches with TF
+    reverse mode (fixture policy_optimisation.npz) -- value, gradient and parameter packing pinned together."""
+    g = np.load(os.path.join(golden_dir, "policy_optimisation.npz"))
+    cfg = {k: g[k] for k in ("X", "Y", "lengthscales", "variance", "noise")}
+    p = _pilco_from(cfg, int(g["H"]))
+    p.m_init, p.S_init = g["m"], g["s"]
+    p.controller.W.assign(g["W"]); p.controller.b.assign(g["b"]); p.controller.max_action = g["max_action"]
+    np.testing.assert_allclose(float(p.compute_reward()[0, 0]), float(g["reward_start"]), rtol=1e-9)
+    r = p.optimize_policy(maxiter=int(g["maxiter"]), restarts=1, verbose=False)
+    np.testing.assert_allclose(r, float(g["reward_end"]), rtol=1e-6)
+    np.testing.assert_allclose(p.controller.W.numpy(), g["W_end"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(p.controller.b.numpy(), g["b_end"], rtol=1e-4, atol=1e-6)
+
+
 def test_sparse_rollout_and_policy_gradient_vs_executed_reference(ctx, golden_dir):
     """PILCO(num_induced_points=M) executed (fixture sparse_rollout.npz): every state of an H = 6 rollout through the FITC
     model, the running reward, and d reward / d (W, b) against reverse mode through the executed reference -- the sparse
