@@ -394,6 +394,30 @@ def gen_policy_optimisation(R):
           H=H, maxiter=12, reward_start=r0, reward_end=r1, W_end=n_(p.controller.W), b_end=n_(p.controller.b))
 
 
+def gen_policy_optimisation_rbf(R):
+    """The same with an RbfController (controllers.py:80-129: centres, targets and softplus-transformed lengthscales are
+    the trainable set) and a combined reward: optimize_policy(maxiter=10, restarts=1) executed."""
+    c = synthetic.config_cascade()
+    rs = np.random.RandomState(11)
+    H, bf = 5, 6
+    Xp, Yp = rs.randn(bf, 2), 0.4 * rs.randn(bf, 1)
+    lsp = 1 + 0.2 * rs.rand(1, 2)
+    Wl = np.array([[0.3], [-0.2]])
+    np.random.seed(10)
+    ctl = R.controllers.RbfController(2, 1, bf, max_action=1.5)
+    ctl.set_data((Xp, Yp))
+    ctl.models[0].kernel.lengthscales.assign(lsp[0])
+    rew = R.rewards.CombinedRewards(2, [R.rewards.ExponentialReward(2), R.rewards.LinearReward(2, Wl)], coefs=[1.0, 0.5])
+    p = R.PILCO((c["X"], c["Y"]), horizon=H, controller=ctl, reward=rew, m_init=c["m"], S_init=c["s"])
+    _set_hyp(p.mgpr.models, c["lengthscales"], c["variance"], c["noise"])
+    r0 = float(n_(p.compute_reward()).ravel()[0])
+    p.optimize_policy(maxiter=10, restarts=1)
+    r1 = float(n_(p.compute_reward()).ravel()[0])
+    _save("policy_optimisation_rbf.npz", **{k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise", "m", "s")},
+          H=H, maxiter=10, rbf_X=Xp, rbf_Y=Yp, rbf_lengthscales=lsp, max_action=1.5, W_lin=Wl, coefs=np.array([1.0, 0.5]),
+          reward_start=r0, reward_end=r1, X_end=n_(ctl.models[0].X), Y_end=n_(ctl.models[0].Y), ls_end=n_(ctl.models[0].kernel.lengthscales))
+
+
 def gen_safe_rbf():
     """The same extension with an RbfController and rewards_safe.RiskOfCollision (rewards_safe.py:13-25), the pairing of
     examples/safe_cars_run.py:72-86: total reward and its reverse-mode gradient w.r.t. the RBF centres, targets and
@@ -439,6 +463,7 @@ def main():
     gen_policy_gradient_wide(R)
     gen_sparse_rollout(R)
     gen_policy_optimisation(R)
+    gen_policy_optimisation_rbf(R)
     gen_fitc_objective(R)
     gen_safe()
     gen_safe_rbf()

@@ -1412,6 +1412,29 @@ def test_optimize_policy_ends_where_the_executed_reference_ends(ctx, golden_dir)
     np.testing.assert_allclose(p.controller.b.numpy(), g["b_end"], rtol=1e-4, atol=1e-6)
 
 
+def test_optimize_policy_rbf_ends_where_the_executed_reference_ends(ctx, golden_dir):
+    """The same with an RbfController and a combined reward (fixture policy_optimisation_rbf.npz): the trainable set
+    (centres, targets, softplus-transformed lengthscales with their lower bound, controllers.py:70-73,100) and its packing
+    must match the reference's for the two optimisers to end at the same policy."""
+    from pilco_amd.controllers import RbfController
+    from pilco_amd.models import PILCO
+    from pilco_amd.rewards import CombinedRewards, ExponentialReward, LinearReward
+    g = np.load(os.path.join(golden_dir, "policy_optimisation_rbf.npz"))
+    ctl = RbfController(state_dim=2, control_dim=1, num_basis_functions=g["rbf_X"].shape[0], max_action=float(g["max_action"]))
+    ctl.set_data((g["rbf_X"], g["rbf_Y"]))
+    ctl.models[0].kernel.lengthscales.assign(g["rbf_lengthscales"][0])
+    rew = CombinedRewards(2, [ExponentialReward(2), LinearReward(2, g["W_lin"])], coefs=list(g["coefs"]))
+    p = PILCO((g["X"], g["Y"]), horizon=int(g["H"]), controller=ctl, reward=rew, m_init=g["m"], S_init=g["s"])
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(g["lengthscales"][i]); mdl.kernel.variance.assign(g["variance"][i]); mdl.likelihood.variance.assign(g["noise"][i])
+    np.testing.assert_allclose(float(p.compute_reward()[0, 0]), float(g["reward_start"]), rtol=1e-9)
+    r = p.optimize_policy(maxiter=int(g["maxiter"]), restarts=1, verbose=False)
+    np.testing.assert_allclose(r, float(g["reward_end"]), rtol=1e-6)
+    np.testing.assert_allclose(ctl.X, g["X_end"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(ctl.Y, g["Y_end"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(np.ravel(ctl.lengthscales), np.ravel(g["ls_end"]), rtol=1e-3)
+
+
 def test_sparse_rollout_and_policy_gradient_vs_executed_reference(ctx, golden_dir):
     """PILCO(num_induced_points=M) executed (fixture sparse_rollout.npz): every state of an H = 6 rollout through the FITC
     model, the running reward, and d reward / d (W, b) against reverse mode through the executed reference -- the sparse
