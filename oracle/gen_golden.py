@@ -418,6 +418,23 @@ def gen_policy_optimisation_rbf(R):
           reward_start=r0, reward_end=r1, X_end=n_(ctl.models[0].X), Y_end=n_(ctl.models[0].Y), ls_end=n_(ctl.models[0].kernel.lengthscales))
 
 
+def gen_models_optimisation(R):
+    """MGPR.optimize(restarts=0) executed (mgpr.py:47-75: one SciPy L-BFGS-B run per output on GPflow's GPR training loss
+    with the Gamma priors of mgpr.py:33-34, from the given start): the hyper-parameters it ends at and the loss there.
+    The objective itself is the shim's restatement of GPflow 2.1 (third-party arithmetic, refshim.py docstring): this pins the
+    product's device NLML + analytic gradient + priors + transforms + optimiser glue to THAT, end point to end point."""
+    c = synthetic.config_c1()
+    np.random.seed(12)
+    m = R.MGPR((c["X"], c["Y"]))
+    ls0 = np.array([[1.3, 0.8, 1.1], [0.9, 1.2, 1.4]])
+    var0, nz0 = np.array([1.2, 0.8]), np.array([0.05, 0.08])
+    _set_hyp(m.models, ls0, var0, nz0)
+    m.optimize(restarts=0)
+    loss = np.array([float(n_(mdl.training_loss())) for mdl in m.models])
+    _save("models_optimisation.npz", X=c["X"], Y=c["Y"], ls_start=ls0, var_start=var0, noise_start=nz0,
+          ls_end=n_(m.lengthscales), var_end=n_(m.variance), noise_end=n_(m.noise), loss_end=loss)
+
+
 def gen_safe_rbf():
     """The same extension with an RbfController and rewards_safe.RiskOfCollision (rewards_safe.py:13-25), the pairing of
     examples/safe_cars_run.py:72-86: total reward and its reverse-mode gradient w.r.t. the RBF centres, targets and
@@ -464,6 +481,7 @@ def main():
     gen_sparse_rollout(R)
     gen_policy_optimisation(R)
     gen_policy_optimisation_rbf(R)
+    gen_models_optimisation(R)
     gen_fitc_objective(R)
     gen_safe()
     gen_safe_rbf()

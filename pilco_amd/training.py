@@ -58,6 +58,72 @@ def _mgpr_unpack(mgpr, u):
     return ls, var, nz
 
 
+def lockstep_minimize(eval_all, u0, parts, maxiter=1000, wall=(RuntimeError,)):
+    """E independent L-BFGS-B problems (problem a owns the entries parts[a] of the packed vector u) solved exactly as E
+    separate scipy.optimize.minimize runs would solve them -- what the reference does, one optimiser per output
+    (mgpr.py:47-56) -- while every round of function evaluations costs ONE call of eval_all(u) -> (values (E,), gradient):
+    each problem runs in its own thread, its objective posts the point it wants evaluated and waits; when every problem
+    that is still running has posted, the coordinator evaluates them all together (one batched device call) and hands
+    the values back.  A joint run on the sum of the losses is not the same thing: its line search and stopping rule couple
+    the outputs, and it can end in another local optimum (found against the executed reference).
+    Returns (u_end, values_end)."""
+    import threading
+    E = len(parts)
+    u = np.array(u0, dtype=np.float64)
+    cv = threading.Condition()
+    pending, results, final, errors = {}, {}, {}, []
+    active = set(range(E))
+
+    def worker(a):
+        def fun(ua):
+            with cv:
+                pending[a] = np.array(ua, dtype=np.float64)
+                cv.notify_all()
+                while a not in results:
+                    cv.wait()
+                return results.pop(a)
+        try:
+            res = minimize(fun, u[parts[a]].copy(), jac=True, method="L-BFGS-B", options=dict(maxiter=maxiter))
+            x = res.x
+        except BaseException as exc:   # noqa: BLE001 -- re-raised by the coordinator
+            errors.append(exc)
+            x = None
+        with cv:
+            if x is not None:
+                final[a] = x
+            active.discard(a)
+            cv.notify_all()
+
+    threads = [threading.Thread(target=worker, args=(a,), daemon=True) for a in range(E)]
+    for t in threads:
+        t.start()
+    while True:
+        with cv:
+            while active and not all(a in pending for a in active):
+                cv.wait()
+            for a, x in final.items():
+                u[parts[a]] = x
+            if not active:
+                break
+            req = [a for a in pending if a in active]
+            for a in req:
+                u[parts[a]] = pending.pop(a)
+        try:
+            vals, grad = eval_all(u)
+            out = {a: (float(vals[a]), np.array(grad[parts[a]], dtype=np.float64)) for a in req}
+        except wall:   # e.g. a Gram matrix that is not positive definite: a wall for the problems of this round
+            out = {a: (1e25, np.zeros(len(parts[a]))) for a in req}
+        with cv:
+            results.update(out)
+            cv.notify_all()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    vals, _ = eval_all(u)
+    return u, np.asarray(vals, dtype=np.float64)
+
+
 def mgpr_objective(mgpr, u, noise_trainable=True):
     """Sum over outputs of GPflow's training loss and its gradient in the unconstrained space."""
     E, D = mgpr.num_outputs, mgpr.num_dims
@@ -85,19 +151,9 @@ def optimize_mgpr(mgpr, restarts=1, maxiter=1000, verbose=False):
     noise_trainable = all(m.likelihood.variance.trainable for m in mgpr.models)
 
     def run(u0):
-        best = {"per": None}
-
-        def fun(u):
-            try:
-                per, grad = mgpr_objective(mgpr, u, noise_trainable)
-            except _lib.NotPositiveDefiniteError:
-                return 1e25, np.zeros_like(u)
-            best["per"] = per
-            return float(per.sum()), grad
-
-        res = minimize(fun, u0, jac=True, method="L-BFGS-B", options=dict(maxiter=maxiter))
-        per, _ = mgpr_objective(mgpr, res.x, noise_trainable)
-        return res.x, per
+        E_, D_ = mgpr.num_outputs, mgpr.num_dims
+        parts = [np.concatenate([np.arange(a * D_, (a + 1) * D_), [E_ * D_ + a], [E_ * D_ + E_ + a]]) for a in range(E_)]
+        return lockstep_minimize(lambda u: mgpr_objective(mgpr, u, noise_trainable), u0, parts, maxiter, wall=(_lib.NotPositiveDefiniteError,))
 
     E, D = mgpr.num_outputs, mgpr.num_dims
     u_best, per_best = run(_mgpr_pack(mgpr))
@@ -145,22 +201,17 @@ def smgpr_objective(smgpr, u):
 def optimize_smgpr(smgpr, restarts=1, maxiter=1000):
     """MGPR.optimize applied to GPRFITC models (mgpr.py:47-75 with smgpr.py:16-22): every output's kernel
     hyper-parameters, noise variance and OWN inducing inputs by L-BFGS-B on the device objective (pilco_gp_fitc_nlml);
-    the outputs are independent problems, optimised jointly as one separable problem.  `restarts` extra fits start
+    the outputs are independent problems: one L-BFGS-B run each as in the reference, evaluated in lockstep (lockstep_minimize).  `restarts` extra fits start
     from randomize() (mgpr.py:8-15; the inducing inputs keep their current values, as in the reference)."""
     from . import _lib
     E, D, M = smgpr.num_outputs, smgpr.num_dims, smgpr.num_induced_points
     Z0 = np.stack([np.asarray(m.inducing_variable.Z.numpy(), np.float64) for m in smgpr.models])
 
     def run(u0):
-        def fun(u):
-            try:
-                per, grad = smgpr_objective(smgpr, u)
-            except _lib.NotPositiveDefiniteError:
-                return 1e25, np.zeros_like(u)
-            return float(per.sum()), grad
-        res = minimize(fun, u0, jac=True, method="L-BFGS-B", options=dict(maxiter=maxiter))
-        per, _ = smgpr_objective(smgpr, res.x)
-        return res.x, per
+        nk_ = E * D + 2 * E
+        parts = [np.concatenate([np.arange(a * D, (a + 1) * D), [E * D + a], [E * D + E + a],
+                                 nk_ + np.arange(a * M * D, (a + 1) * M * D)]) for a in range(E)]
+        return lockstep_minimize(lambda u: smgpr_objective(smgpr, u), u0, parts, maxiter, wall=(_lib.NotPositiveDefiniteError,))
 
     u_best, per_best = run(np.concatenate([_mgpr_pack(smgpr), Z0.ravel()]))
     nk = E * D + 2 * E

@@ -1,0 +1,57 @@
+"""pilco_amd.training.lockstep_minimize on the CPU: E independent L-BFGS-B problems evaluated through ONE batched callback
+per round must end exactly where E separate scipy.optimize.minimize runs end (the reference fits one optimiser per output,
+mgpr.py:47-56) -- and a joint run on the sum of the losses need not."""
+import numpy as np
+from scipy.optimize import minimize
+
+from pilco_amd.training import lockstep_minimize
+
+
+def _problems(rs, E, n):
+    return [(rs.randn(n, n), rs.randn(n), 0.5 + rs.rand()) for _ in range(E)]
+
+
+def _f(prob, x):
+    """A smooth non-convex test function with several local minima."""
+    A, b, c = prob
+    y = A @ x - b
+    val = 0.5 * y @ y + c * np.sum(np.cos(3.0 * x))
+    return val, A.T @ y - 3.0 * c * np.sin(3.0 * x)
+
+
+def test_lockstep_runs_equal_separate_runs_bitwise():
+    rs = np.random.RandomState(0)
+    E, n = 5, 4
+    probs = _problems(rs, E, n)
+    parts = [np.arange(a * n, (a + 1) * n) for a in range(E)]
+    u0 = rs.randn(E * n)
+    calls = []
+
+    def eval_all(u):
+        calls.append(1)
+        vals, grad = np.empty(E), np.empty(E * n)
+        for a in range(E):
+            vals[a], grad[parts[a]] = _f(probs[a], u[parts[a]])
+        return vals, grad
+
+    u, vals = lockstep_minimize(eval_all, u0, parts, maxiter=200)
+    n_evals = []
+    for a in range(E):
+        cnt = []
+        res = minimize(lambda x: (cnt.append(1), _f(probs[a], x))[1], u0[parts[a]], jac=True, method="L-BFGS-B", options=dict(maxiter=200))
+        n_evals.append(len(cnt))
+        assert np.array_equal(res.x, u[parts[a]]) and res.fun == vals[a]
+    # one batched evaluation per round: as many rounds as the longest single run needs (+ the closing evaluation)
+    assert len(calls) == max(n_evals) + 1
+
+
+def test_a_failing_round_is_a_wall_not_a_crash():
+    parts = [np.arange(2), np.arange(2, 4)]
+
+    def eval_all(u):
+        if u[0] > 2.0:
+            raise RuntimeError("not positive definite (stand-in)")
+        return np.array([np.sum((u[:2] - 1.0) ** 2), np.sum((u[2:] + 0.5) ** 2)]), 2.0 * np.concatenate([u[:2] - 1.0, u[2:] + 0.5])
+
+    u, vals = lockstep_minimize(eval_all, np.array([0.0, 0.0, 3.0, 3.0]), parts, maxiter=100)
+    np.testing.assert_allclose(u, [1.0, 1.0, -0.5, -0.5], atol=1e-5)
