@@ -431,8 +431,17 @@ def gen_models_optimisation(R):
     _set_hyp(m.models, ls0, var0, nz0)
     m.optimize(restarts=0)
     loss = np.array([float(n_(mdl.training_loss())) for mdl in m.models])
+    # the same with restarts=2: the starts of the extra fits come from randomize() on NumPy's global generator (seeded
+    # here); what the reference ENDS with is the last restart's fit (its best_params hold the live Parameters, mgpr.py:59-75)
+    seed_r = 5
+    np.random.seed(seed_r)
+    m2 = R.MGPR((c["X"], c["Y"]))
+    _set_hyp(m2.models, ls0, var0, nz0)
+    m2.optimize(restarts=2)
+    loss2 = np.array([float(n_(mdl.training_loss())) for mdl in m2.models])
     _save("models_optimisation.npz", X=c["X"], Y=c["Y"], ls_start=ls0, var_start=var0, noise_start=nz0,
-          ls_end=n_(m.lengthscales), var_end=n_(m.variance), noise_end=n_(m.noise), loss_end=loss)
+          ls_end=n_(m.lengthscales), var_end=n_(m.variance), noise_end=n_(m.noise), loss_end=loss,
+          restarts=2, restart_seed=seed_r, r_ls_end=n_(m2.lengthscales), r_var_end=n_(m2.variance), r_noise_end=n_(m2.noise), r_loss_end=loss2)
 
 
 def gen_safe_rbf():

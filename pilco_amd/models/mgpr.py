@@ -16,6 +16,16 @@ from .. import _lib
 from ..params import GPModelView, parameters_of
 
 
+def randomize(model, mean=1, sigma=0.01):
+    """mgpr.py:8-15: a fresh start for one output's model -- Normal(mean, sigma) draws from NumPy's global generator for the
+    lengthscales, the kernel variance and (only if trainable) the likelihood variance, in that order."""
+    k, lik = model.kernel, model.likelihood.variance
+    k.lengthscales.assign(mean + sigma * np.random.normal(size=np.shape(k.lengthscales.numpy())))
+    k.variance.assign(mean + sigma * np.random.normal(size=np.shape(k.variance.numpy())))
+    if lik.trainable:
+        lik.assign(mean + sigma * np.random.normal())
+
+
 class MGPR:
     _slot = _lib.SLOT_DYNAMICS
 
@@ -98,9 +108,10 @@ class MGPR:
             self.ctx.gp_factorize(self._slot)                   # cached on the device: a no-op while nothing changed
 
     # -- reference: mgpr.py:47-75
-    def optimize(self, restarts=1):
+    def optimize(self, restarts=1, keep="best"):
+        """keep='last' reproduces what the reference ends with when restarts > 0 (training.optimize_mgpr)."""
         from ..training import optimize_mgpr
-        return optimize_mgpr(self, restarts=restarts)
+        return optimize_mgpr(self, restarts=restarts, keep=keep)
 
     # -- reference: mgpr.py:77-79
     def predict_on_noisy_inputs(self, m, s):

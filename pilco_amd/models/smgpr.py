@@ -50,13 +50,13 @@ class SMGPR(MGPR):
         return self.Z
 
     # -- reference: MGPR.optimize applied to GPRFITC models (mgpr.py:47-75 with smgpr.py:16-22)
-    def optimize(self, restarts=1):
+    def optimize(self, restarts=1, keep="best"):
         """Every output's GPRFITC model is fitted as the reference does it: kernel hyper-parameters, noise variance AND
         the output's own M x D inducing inputs by L-BFGS-B on the FITC marginal likelihood, evaluated with its analytic
         gradient on the device (pilco_gp_fitc_nlml, csrc/fitc_train.hip).  Prediction then uses model 0's inducing
         inputs for every output, as the reference does (smgpr.py:47-52)."""
         from ..training import optimize_smgpr
-        return optimize_smgpr(self, restarts=restarts)
+        return optimize_smgpr(self, restarts=restarts, keep=keep)
 
     @property
     def Z(self):

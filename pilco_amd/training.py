@@ -143,38 +143,57 @@ def mgpr_objective(mgpr, u, noise_trainable=True):
     return per_output, np.concatenate([g_ls.ravel(), g_var, g_nz])
 
 
-def optimize_mgpr(mgpr, restarts=1, maxiter=1000, verbose=False):
+def _restart_draws(E, D, restarts, noise_trainable):
+    """randomize() (mgpr.py:8-15) for every (model, restart) in the order the reference draws them from NumPy's global
+    generator: model by model (mgpr.py:58-66), within a model restart by restart; per draw lengthscales (D), kernel variance,
+    and the likelihood variance only if it is trainable.  The lockstep driver needs restart r of ALL outputs at once, so the
+    draws are taken up front; with the same np.random.seed the starts are the reference's."""
+    ls, var, nz = np.empty((restarts, E, D)), np.empty((restarts, E)), np.full((restarts, E), np.nan)
+    for a in range(E):
+        for r in range(restarts):
+            ls[r, a] = 1 + 0.01 * np.random.normal(size=(D,))
+            var[r, a] = 1 + 0.01 * np.random.normal(size=())
+            if noise_trainable:
+                nz[r, a] = 1 + 0.01 * np.random.normal()
+    return ls, var, nz
+
+
+def _check_keep(keep):
+    if keep not in ("best", "last"):
+        raise ValueError("keep: 'best' (per output the fit with the lowest loss) or 'last' (what the reference ends with)")
+
+
+def optimize_mgpr(mgpr, restarts=1, maxiter=1000, verbose=False, keep="best"):
+    """MGPR.optimize (mgpr.py:47-75).  keep='best': every output ends with the better of its fits -- what the reference's
+    bookkeeping sets out to do.  keep='last': what the reference actually ends with: its `best_params` hold the live
+    Parameter objects, not copies (mgpr.py:59-62,69-71), so the final assign (mgpr.py:73-75) assigns every parameter to
+    itself and the model keeps the LAST restart's fit whether or not it was better."""
     from .models.smgpr import SMGPR
     from . import _lib
+    _check_keep(keep)
     if isinstance(mgpr, SMGPR):
         raise TypeError("optimize_mgpr fits the exact GP objective; SMGPR.optimize uses optimize_smgpr (GPRFITC objective)")
     noise_trainable = all(m.likelihood.variance.trainable for m in mgpr.models)
+    E, D = mgpr.num_outputs, mgpr.num_dims
+    parts = [np.concatenate([np.arange(a * D, (a + 1) * D), [E * D + a], [E * D + E + a]]) for a in range(E)]
 
     def run(u0):
-        E_, D_ = mgpr.num_outputs, mgpr.num_dims
-        parts = [np.concatenate([np.arange(a * D_, (a + 1) * D_), [E_ * D_ + a], [E_ * D_ + E_ + a]]) for a in range(E_)]
         return lockstep_minimize(lambda u: mgpr_objective(mgpr, u, noise_trainable), u0, parts, maxiter, wall=(_lib.NotPositiveDefiniteError,))
 
-    E, D = mgpr.num_outputs, mgpr.num_dims
     u_best, per_best = run(_mgpr_pack(mgpr))
-    for _ in range(restarts):
-        # randomize(model), mgpr.py:8-15
-        ls0 = 1 + 0.01 * np.random.normal(size=(E, D))
-        var0 = 1 + 0.01 * np.random.normal(size=E)
-        nz0 = 1 + 0.01 * np.random.normal(size=E) if noise_trainable else mgpr.noise
-        u0 = np.concatenate([_softplus_inv(ls0).ravel(), _softplus_inv(var0), _softplus_inv(np.maximum(nz0 - NOISE_LOWER, 1e-12))])
+    ls_r, var_r, nz_r = _restart_draws(E, D, restarts, noise_trainable)
+    for r in range(restarts):
+        nz0 = nz_r[r] if noise_trainable else mgpr.noise
+        u0 = np.concatenate([_softplus_inv(ls_r[r]).ravel(), _softplus_inv(var_r[r]), _softplus_inv(np.maximum(nz0 - NOISE_LOWER, 1e-12))])
         u, per = run(u0)
-        better = per < per_best
+        better = per < per_best if keep == "best" else np.ones(E, bool)
         if verbose:
-            print("restart: per-output losses", per, "improved", better)
-        # keep, per output, the better of the two fits (the outputs are independent problems)
+            print("restart: per-output losses", per, "kept", better)
         ub = u_best.copy()
         for a in np.nonzero(better)[0]:
-            ub[a * D:(a + 1) * D] = u[a * D:(a + 1) * D]
-            ub[E * D + a] = u[E * D + a]
-            ub[E * D + E + a] = u[E * D + E + a]
-        u_best, per_best = ub, np.minimum(per, per_best)
-    mgpr_objective(mgpr, u_best, noise_trainable)   # leaves the best parameters assigned
+            ub[parts[a]] = u[parts[a]]
+        u_best, per_best = ub, np.where(better, per, per_best)
+    mgpr_objective(mgpr, u_best, noise_trainable)   # leaves the kept parameters assigned
     mgpr._sync()
     return per_best
 
@@ -198,40 +217,37 @@ def smgpr_objective(smgpr, u):
     return nlml, np.concatenate([g_ls.ravel(), g_var, g_nz, gz.ravel()])
 
 
-def optimize_smgpr(smgpr, restarts=1, maxiter=1000):
+def optimize_smgpr(smgpr, restarts=1, maxiter=1000, keep="best"):
     """MGPR.optimize applied to GPRFITC models (mgpr.py:47-75 with smgpr.py:16-22): every output's kernel
     hyper-parameters, noise variance and OWN inducing inputs by L-BFGS-B on the device objective (pilco_gp_fitc_nlml);
-    the outputs are independent problems: one L-BFGS-B run each as in the reference, evaluated in lockstep (lockstep_minimize).  `restarts` extra fits start
-    from randomize() (mgpr.py:8-15; the inducing inputs keep their current values, as in the reference)."""
+    the outputs are independent problems: one L-BFGS-B run each as in the reference, evaluated in lockstep
+    (lockstep_minimize).  `restarts` extra fits start from randomize() (mgpr.py:8-15), which leaves the inducing inputs
+    alone: every restart starts from the inducing inputs the previous fit of that output ended with.  keep: as in
+    optimize_mgpr."""
     from . import _lib
+    _check_keep(keep)
     E, D, M = smgpr.num_outputs, smgpr.num_dims, smgpr.num_induced_points
     Z0 = np.stack([np.asarray(m.inducing_variable.Z.numpy(), np.float64) for m in smgpr.models])
+    nk = E * D + 2 * E
+    parts = [np.concatenate([np.arange(a * D, (a + 1) * D), [E * D + a], [E * D + E + a],
+                             nk + np.arange(a * M * D, (a + 1) * M * D)]) for a in range(E)]
 
     def run(u0):
-        nk_ = E * D + 2 * E
-        parts = [np.concatenate([np.arange(a * D, (a + 1) * D), [E * D + a], [E * D + E + a],
-                                 nk_ + np.arange(a * M * D, (a + 1) * M * D)]) for a in range(E)]
         return lockstep_minimize(lambda u: smgpr_objective(smgpr, u), u0, parts, maxiter, wall=(_lib.NotPositiveDefiniteError,))
 
     u_best, per_best = run(np.concatenate([_mgpr_pack(smgpr), Z0.ravel()]))
-    nk = E * D + 2 * E
-    for _ in range(restarts):
-        ls0 = 1 + 0.01 * np.random.normal(size=(E, D))
-        var0 = 1 + 0.01 * np.random.normal(size=E)
-        nz0 = 1 + 0.01 * np.random.normal(size=E)
-        u0 = np.concatenate([_softplus_inv(ls0).ravel(), _softplus_inv(var0), _softplus_inv(np.maximum(nz0 - NOISE_LOWER, 1e-12)),
-                             u_best[nk:]])
-        u, per = run(u0)
-        better = per < per_best
+    u_prev = u_best
+    ls_r, var_r, nz_r = _restart_draws(E, D, restarts, True)
+    for r in range(restarts):
+        u0 = np.concatenate([_softplus_inv(ls_r[r]).ravel(), _softplus_inv(var_r[r]), _softplus_inv(np.maximum(nz_r[r] - NOISE_LOWER, 1e-12)),
+                             u_prev[nk:]])
+        u_prev, per = run(u0)
+        better = per < per_best if keep == "best" else np.ones(E, bool)
         ub = u_best.copy()
-        Zb, Zn = ub[nk:].reshape(E, M, D), u[nk:].reshape(E, M, D)
         for a in np.nonzero(better)[0]:
-            ub[a * D:(a + 1) * D] = u[a * D:(a + 1) * D]
-            ub[E * D + a] = u[E * D + a]
-            ub[E * D + E + a] = u[E * D + E + a]
-            Zb[a] = Zn[a]
-        u_best, per_best = ub, np.minimum(per, per_best)
-    smgpr_objective(smgpr, u_best)      # leaves the best kernel parameters assigned
+            ub[parts[a]] = u_prev[parts[a]]
+        u_best, per_best = ub, np.where(better, per, per_best)
+    smgpr_objective(smgpr, u_best)      # leaves the kept kernel parameters assigned
     Zf = u_best[nk:].reshape(E, M, D)
     for i, m in enumerate(smgpr.models):
         m.inducing_variable.Z.assign(Zf[i])

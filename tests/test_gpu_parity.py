@@ -1413,6 +1413,21 @@ def test_mgpr_optimize_ends_where_the_executed_reference_ends(ctx, golden_dir):
     np.testing.assert_allclose(m.lengthscales, g["ls_end"], rtol=2e-2)
     np.testing.assert_allclose(m.variance, g["var_end"], rtol=2e-2)
     np.testing.assert_allclose(m.noise, g["noise_end"], rtol=2e-2)
+    # restarts: randomize() starts drawn from NumPy's global generator in the reference's order (model by model), and
+    # keep="last" = what the reference's bookkeeping leaves assigned (the last restart's fit, mgpr.py:59-75)
+    for keep in ("last", "best"):
+        np.random.seed(int(g["restart_seed"]))
+        m2 = MGPR((g["X"], g["Y"]))
+        for i, mdl in enumerate(m2.models):
+            mdl.kernel.lengthscales.assign(g["ls_start"][i]); mdl.kernel.variance.assign(g["var_start"][i]); mdl.likelihood.variance.assign(g["noise_start"][i])
+        per2 = m2.optimize(restarts=int(g["restarts"]), keep=keep)
+        if keep == "last":
+            np.testing.assert_allclose(per2, g["r_loss_end"], rtol=1e-6)
+            np.testing.assert_allclose(m2.lengthscales, g["r_ls_end"], rtol=2e-2)
+            np.testing.assert_allclose(m2.variance, g["r_var_end"], rtol=2e-2)
+            np.testing.assert_allclose(m2.noise, g["r_noise_end"], rtol=2e-2)
+        else:
+            assert np.all(per2 <= np.minimum(g["loss_end"], g["r_loss_end"]) * (1 + 1e-6))
 
 
 def test_optimize_policy_ends_where_the_executed_reference_ends(ctx, golden_dir):
