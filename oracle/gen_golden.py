@@ -444,6 +444,32 @@ def gen_models_optimisation(R):
           restarts=2, restart_seed=seed_r, r_ls_end=n_(m2.lengthscales), r_var_end=n_(m2.variance), r_noise_end=n_(m2.noise), r_loss_end=loss2)
 
 
+def gen_sparse_models_optimisation(R):
+    """SMGPR.optimize(restarts=0) executed (MGPR.optimize, mgpr.py:47-56, applied to the GPRFITC models of smgpr.py:16-22:
+    one L-BFGS-B run per output over lengthscales, variances and the output's OWN inducing inputs, no priors) from a fixed
+    start: the per-output FITC loss it ends at, the kernel parameters and the inducing inputs there; then the prediction of
+    the fitted model at a Gaussian input (model 0's inducing inputs serve every output, smgpr.py:47-52)."""
+    c = synthetic.config_c1()
+    rs = np.random.RandomState(21)
+    M = 8
+    Z0 = np.stack([c["X"][rs.permutation(100)[:M]] for _ in range(2)])
+    Y = c["Y"] + 0.1 * rs.randn(*c["Y"].shape)
+    ls0, var0, nz0 = c["lengthscales"], c["variance"], np.array([0.01, 0.01])
+    np.random.seed(2)
+    m = R.SMGPR((c["X"], Y), num_induced_points=M)
+    _set_hyp(m.models, ls0, var0, nz0)
+    for i, mdl in enumerate(m.models):
+        mdl.inducing_variable.Z.assign(Z0[i])
+    loss0 = np.array([float(n_(mdl.training_loss())) for mdl in m.models])
+    m.optimize(restarts=0)
+    loss = np.array([float(n_(mdl.training_loss())) for mdl in m.models])
+    Zend = np.stack([n_(mdl.inducing_variable.Z) for mdl in m.models])
+    Mp, Sp, Vp = m.predict_on_noisy_inputs(c["m"], c["s"])
+    _save("sparse_models_optimisation.npz", X=c["X"], Y=Y, Z_start=Z0, ls_start=ls0, var_start=var0, noise_start=nz0,
+          loss_start=loss0, loss_end=loss, ls_end=n_(m.lengthscales), var_end=n_(m.variance), noise_end=n_(m.noise), Z_end=Zend,
+          m=c["m"], s=c["s"], M=n_(Mp), S=n_(Sp), V=n_(Vp))
+
+
 def gen_safe_rbf():
     """The same extension with an RbfController and rewards_safe.RiskOfCollision (rewards_safe.py:13-25), the pairing of
     examples/safe_cars_run.py:72-86: total reward and its reverse-mode gradient w.r.t. the RBF centres, targets and
@@ -491,6 +517,7 @@ def main():
     gen_policy_optimisation(R)
     gen_policy_optimisation_rbf(R)
     gen_models_optimisation(R)
+    gen_sparse_models_optimisation(R)
     gen_fitc_objective(R)
     gen_safe()
     gen_safe_rbf()

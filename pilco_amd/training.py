@@ -58,7 +58,7 @@ def _mgpr_unpack(mgpr, u):
     return ls, var, nz
 
 
-def lockstep_minimize(eval_all, u0, parts, maxiter=1000, wall=(RuntimeError,)):
+def lockstep_minimize(eval_all, u0, parts, maxiter=15000, wall=(RuntimeError,)):
     """E independent L-BFGS-B problems (problem a owns the entries parts[a] of the packed vector u) solved exactly as E
     separate scipy.optimize.minimize runs would solve them -- what the reference does, one optimiser per output
     (mgpr.py:47-56) -- while every round of function evaluations costs ONE call of eval_all(u) -> (values (E,), gradient):
@@ -163,7 +163,7 @@ def _check_keep(keep):
         raise ValueError("keep: 'best' (per output the fit with the lowest loss) or 'last' (what the reference ends with)")
 
 
-def optimize_mgpr(mgpr, restarts=1, maxiter=1000, verbose=False, keep="best"):
+def optimize_mgpr(mgpr, restarts=1, maxiter=15000, verbose=False, keep="best"):
     """MGPR.optimize (mgpr.py:47-75).  keep='best': every output ends with the better of its fits -- what the reference's
     bookkeeping sets out to do.  keep='last': what the reference actually ends with: its `best_params` hold the live
     Parameter objects, not copies (mgpr.py:59-62,69-71), so the final assign (mgpr.py:73-75) assigns every parameter to
@@ -217,7 +217,7 @@ def smgpr_objective(smgpr, u):
     return nlml, np.concatenate([g_ls.ravel(), g_var, g_nz, gz.ravel()])
 
 
-def optimize_smgpr(smgpr, restarts=1, maxiter=1000, keep="best"):
+def optimize_smgpr(smgpr, restarts=1, maxiter=15000, keep="best"):
     """MGPR.optimize applied to GPRFITC models (mgpr.py:47-75 with smgpr.py:16-22): every output's kernel
     hyper-parameters, noise variance and OWN inducing inputs by L-BFGS-B on the device objective (pilco_gp_fitc_nlml);
     the outputs are independent problems: one L-BFGS-B run each as in the reference, evaluated in lockstep

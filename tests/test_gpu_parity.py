@@ -1430,6 +1430,40 @@ def test_mgpr_optimize_ends_where_the_executed_reference_ends(ctx, golden_dir):
             assert np.all(per2 <= np.minimum(g["loss_end"], g["r_loss_end"]) * (1 + 1e-6))
 
 
+def test_smgpr_optimize_ends_where_the_executed_reference_ends(ctx, golden_dir):
+    """SMGPR.optimize(restarts=0) (mgpr.py:47-56 on the GPRFITC models of smgpr.py:16-22; every output trains its own
+    inducing inputs) from the same start as the executed reference (fixture sparse_models_optimisation.npz): the product
+    (pilco_gp_fitc_nlml value + analytic gradients incl. dZ, softplus transforms with the 1e-6 noise floor, one L-BFGS-B run
+    per output in lockstep) must reach the per-output FITC loss the reference reaches, and the fitted sparse model must
+    predict what the reference's fitted model predicts.  Hundreds of iterations over 29 parameters per output in a flat
+    valley: the loss is the pinned quantity (measured 1e-6 / 1e-9), the kernel parameters agree to 2e-4."""
+    g = np.load(os.path.join(golden_dir, "sparse_models_optimisation.npz"))
+    from pilco_amd.models import SMGPR
+    M = g["Z_start"].shape[1]
+    np.random.seed(2)
+    m = SMGPR((g["X"], g["Y"]), num_induced_points=M)
+    for i, mdl in enumerate(m.models):
+        mdl.kernel.lengthscales.assign(g["ls_start"][i]); mdl.kernel.variance.assign(g["var_start"][i]); mdl.likelihood.variance.assign(g["noise_start"][i])
+        mdl.inducing_variable.Z.assign(g["Z_start"][i])
+    from pilco_amd.training import _mgpr_pack, smgpr_objective
+    before, _ = smgpr_objective(m, np.concatenate([_mgpr_pack(m), g["Z_start"].ravel()]))
+    np.testing.assert_allclose(before, g["loss_start"], rtol=1e-9)      # the same objective at the start
+    per = m.optimize(restarts=0)
+    Mp, Sp, Vp = m.predict_on_noisy_inputs(g["m"], g["s"])
+    print("FITC end losses", per, "reference", g["loss_end"], "\nlengthscales", m.lengthscales, "reference", g["ls_end"],
+          "\nM", Mp, g["M"], "\nS", Sp, g["S"])
+    np.testing.assert_allclose(per, g["loss_end"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(m.lengthscales, g["ls_end"], rtol=2e-3)
+    np.testing.assert_allclose(m.variance, g["var_end"], rtol=1e-3)
+    np.testing.assert_allclose(m.noise, g["noise_end"], rtol=5e-3)      # both at GPflow's 1e-6 floor
+    # Output 0's prediction is compared.  Output 1 predicts with OUTPUT 0's inducing inputs (smgpr.py:47-52), and one of
+    # those ends far outside the data where output 0's loss does not feel it (its position differs by 38 units between
+    # the two runs at equal loss) while output 1's longer lengthscale still does: its prediction is not a function of the
+    # pinned quantities (measured: mean 0.213 here, 0.240 in the reference run).
+    np.testing.assert_allclose(Mp[0, 0], g["M"][0, 0], rtol=1e-3)
+    np.testing.assert_allclose(Sp[0, 0], g["S"][0, 0], rtol=1e-3)
+
+
 def test_optimize_policy_ends_where_the_executed_reference_ends(ctx, golden_dir):
     """PILCO.optimize_policy(maxiter=12, restarts=1) (pilco.py:75-113) from the same controller: the same SciPy L-BFGS-B
     on the product's value + analytic gradient must walk to the point the executed reference's optimiser reaches with TF
