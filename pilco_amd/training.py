@@ -5,9 +5,10 @@ hyper-parameters.  The objective follows GPflow's GPR.training_loss as recalled 
 Appendix C: negative log marginal likelihood minus the Gamma log-priors on the lengthscales
 (shape 1.1, rate 0.1) and the kernel variance (shape 1.5, rate 0.5), optimised in softplus space
 (noise variance >= 1e-6) with SciPy L-BFGS-B.  NLML and its gradient come from the device
-(pilco_gp_nlml); the E outputs are independent, so they are optimised jointly as one separable
-problem (one batched factorisation per evaluation).  Parity with GPflow's optimiser trajectory is
-unpinned in the reference itself (no test inspects trained values).
+(pilco_gp_nlml); the E outputs are independent problems, each solved by its own L-BFGS-B run as in the
+reference, the runs evaluated in lockstep (one batched factorisation per round, lockstep_minimize).
+The end points are pinned against the executed reference (tests/golden/models_optimisation.npz,
+sparse_models_optimisation.npz).
 
 ``optimize_policy`` -- PILCO.optimize_policy (pilco/models/pilco.py:75-113): L-BFGS-B over the
 controller parameters with the GP frozen, restarts via controller.randomize().  The gradient of the
@@ -25,6 +26,9 @@ from scipy.optimize import minimize
 from scipy.special import gammaln
 
 NOISE_LOWER = 1e-6
+# L-BFGS-B iteration cap of the model fits.  The reference passes no options to SciPy for them (mgpr.py:52,55,66; the
+# maxiter argument of PILCO.optimize_models is ignored, pilco.py:52-56), i.e. SciPy's default.
+MODEL_FIT_MAXITER = 15000
 
 
 def _softplus(u):
@@ -163,7 +167,7 @@ def _check_keep(keep):
         raise ValueError("keep: 'best' (per output the fit with the lowest loss) or 'last' (what the reference ends with)")
 
 
-def optimize_mgpr(mgpr, restarts=1, maxiter=15000, verbose=False, keep="best"):
+def optimize_mgpr(mgpr, restarts=1, maxiter=None, verbose=False, keep="best"):
     """MGPR.optimize (mgpr.py:47-75).  keep='best': every output ends with the better of its fits -- what the reference's
     bookkeeping sets out to do.  keep='last': what the reference actually ends with: its `best_params` hold the live
     Parameter objects, not copies (mgpr.py:59-62,69-71), so the final assign (mgpr.py:73-75) assigns every parameter to
@@ -171,6 +175,7 @@ def optimize_mgpr(mgpr, restarts=1, maxiter=15000, verbose=False, keep="best"):
     from .models.smgpr import SMGPR
     from . import _lib
     _check_keep(keep)
+    maxiter = MODEL_FIT_MAXITER if maxiter is None else maxiter
     if isinstance(mgpr, SMGPR):
         raise TypeError("optimize_mgpr fits the exact GP objective; SMGPR.optimize uses optimize_smgpr (GPRFITC objective)")
     noise_trainable = all(m.likelihood.variance.trainable for m in mgpr.models)
@@ -217,7 +222,7 @@ def smgpr_objective(smgpr, u):
     return nlml, np.concatenate([g_ls.ravel(), g_var, g_nz, gz.ravel()])
 
 
-def optimize_smgpr(smgpr, restarts=1, maxiter=15000, keep="best"):
+def optimize_smgpr(smgpr, restarts=1, maxiter=None, keep="best"):
     """MGPR.optimize applied to GPRFITC models (mgpr.py:47-75 with smgpr.py:16-22): every output's kernel
     hyper-parameters, noise variance and OWN inducing inputs by L-BFGS-B on the device objective (pilco_gp_fitc_nlml);
     the outputs are independent problems: one L-BFGS-B run each as in the reference, evaluated in lockstep
@@ -226,6 +231,7 @@ def optimize_smgpr(smgpr, restarts=1, maxiter=15000, keep="best"):
     optimize_mgpr."""
     from . import _lib
     _check_keep(keep)
+    maxiter = MODEL_FIT_MAXITER if maxiter is None else maxiter
     E, D, M = smgpr.num_outputs, smgpr.num_dims, smgpr.num_induced_points
     Z0 = np.stack([np.asarray(m.inducing_variable.Z.numpy(), np.float64) for m in smgpr.models])
     nk = E * D + 2 * E
