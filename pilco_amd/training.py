@@ -77,25 +77,35 @@ def lockstep_minimize(eval_all, u0, parts, maxiter=15000, wall=(RuntimeError,)):
     cv = threading.Condition()
     pending, results, final, errors = {}, {}, {}, []
     active = set(range(E))
+    state = {"abort": None}
+
+    class _Abort(Exception):
+        pass
 
     def worker(a):
         def fun(ua):
             with cv:
+                if state["abort"] is not None:
+                    raise _Abort()
                 pending[a] = np.array(ua, dtype=np.float64)
                 cv.notify_all()
-                while a not in results:
+                while a not in results and state["abort"] is None:
                     cv.wait()
+                if state["abort"] is not None:
+                    raise _Abort()
                 return results.pop(a)
+        x = None
         try:
-            res = minimize(fun, u[parts[a]].copy(), jac=True, method="L-BFGS-B", options=dict(maxiter=maxiter))
-            x = res.x
+            x = minimize(fun, u[parts[a]].copy(), jac=True, method="L-BFGS-B", options=dict(maxiter=maxiter)).x
+        except _Abort:
+            pass
         except BaseException as exc:   # noqa: BLE001 -- re-raised by the coordinator
             errors.append(exc)
-            x = None
         with cv:
             if x is not None:
                 final[a] = x
             active.discard(a)
+            pending.pop(a, None)
             cv.notify_all()
 
     threads = [threading.Thread(target=worker, args=(a,), daemon=True) for a in range(E)]
@@ -103,12 +113,18 @@ def lockstep_minimize(eval_all, u0, parts, maxiter=15000, wall=(RuntimeError,)):
         t.start()
     while True:
         with cv:
-            while active and not all(a in pending for a in active):
+            while active and not all(a in pending for a in active) and not errors:
                 cv.wait()
+            if errors and state["abort"] is None:
+                state["abort"] = errors[0]          # one run failed: the others stop at their next evaluation
+                cv.notify_all()
             for a, x in final.items():
                 u[parts[a]] = x
             if not active:
                 break
+            if state["abort"] is not None:
+                cv.wait(0.05)
+                continue
             req = [a for a in pending if a in active]
             for a in req:
                 u[parts[a]] = pending.pop(a)
@@ -117,13 +133,18 @@ def lockstep_minimize(eval_all, u0, parts, maxiter=15000, wall=(RuntimeError,)):
             out = {a: (float(vals[a]), np.array(grad[parts[a]], dtype=np.float64)) for a in req}
         except wall:   # e.g. a Gram matrix that is not positive definite: a wall for the problems of this round
             out = {a: (1e25, np.zeros(len(parts[a]))) for a in req}
+        except BaseException as exc:   # noqa: BLE001 -- a device error: release every waiting run, then re-raise here
+            with cv:
+                state["abort"] = exc
+                cv.notify_all()
+            continue
         with cv:
             results.update(out)
             cv.notify_all()
     for t in threads:
         t.join()
-    if errors:
-        raise errors[0]
+    if state["abort"] is not None:
+        raise state["abort"]
     vals, _ = eval_all(u)
     return u, np.asarray(vals, dtype=np.float64)
 

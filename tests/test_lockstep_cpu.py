@@ -55,3 +55,43 @@ def test_a_failing_round_is_a_wall_not_a_crash():
 
     u, vals = lockstep_minimize(eval_all, np.array([0.0, 0.0, 3.0, 3.0]), parts, maxiter=100)
     np.testing.assert_allclose(u, [1.0, 1.0, -0.5, -0.5], atol=1e-5)
+
+
+def test_an_error_in_the_batched_evaluation_or_in_one_run_releases_every_thread():
+    import threading
+    parts = [np.arange(2), np.arange(2, 4), np.arange(4, 6)]
+    n = [0]
+
+    def eval_all(u):
+        n[0] += 1
+        if n[0] == 3:
+            raise ValueError("device error (stand-in)")      # not a wall: must surface, with no run left waiting
+        return np.array([np.sum(u[p] ** 4) for p in parts]), 4.0 * u ** 3
+
+    before = threading.active_count()
+    try:
+        lockstep_minimize(eval_all, np.arange(1.0, 7.0), parts, maxiter=50)
+        raise AssertionError("the error was swallowed")
+    except ValueError as exc:
+        assert "stand-in" in str(exc)
+    assert threading.active_count() == before
+
+    # a run that fails inside its optimiser while the others wait for the round: surfaced, nobody left waiting
+    from pilco_amd import training
+    real = training.minimize
+
+    def flaky(fun, x0, **kw):
+        if x0[0] == 3.0:
+            fun(x0)
+            raise FloatingPointError("optimiser error (stand-in)")
+        return real(fun, x0, **kw)
+    training.minimize = flaky
+    try:
+        n[0] = 10
+        lockstep_minimize(eval_all, np.arange(1.0, 7.0), parts, maxiter=50)
+        raise AssertionError("the error was swallowed")
+    except FloatingPointError:
+        pass
+    finally:
+        training.minimize = real
+    assert threading.active_count() == before
