@@ -156,7 +156,8 @@ def mgpr_objective(mgpr, u, noise_trainable=True):
     for i, m in enumerate(mgpr.models):
         m.kernel.lengthscales.assign(ls[i])
         m.kernel.variance.assign(var[i])
-        m.likelihood.variance.assign(nz[i])
+        if noise_trainable:                      # a fixed likelihood variance is not touched (no transform round trip)
+            m.likelihood.variance.assign(nz[i])
     mgpr._sync()
     nlml, g = mgpr.ctx.gp_nlml(mgpr._slot, D, E)
     lp_l, dlp_l = _gamma_logpdf_and_grad(ls, 1.1, 0.1)          # mgpr.py:33
@@ -224,7 +225,7 @@ def optimize_mgpr(mgpr, restarts=1, maxiter=None, verbose=False, keep="best"):
     return per_best
 
 
-def smgpr_objective(smgpr, u):
+def smgpr_objective(smgpr, u, noise_trainable=True):
     """Sum over outputs of gpflow's GPRFITC training loss (no priors: smgpr.py:16-22 sets none) and its gradient in
     the unconstrained space: softplus for lengthscales / variances (noise floor 1e-6), identity for the inducing inputs."""
     E, D, M = smgpr.num_outputs, smgpr.num_dims, smgpr.num_induced_points
@@ -234,12 +235,13 @@ def smgpr_objective(smgpr, u):
     for i, m in enumerate(smgpr.models):
         m.kernel.lengthscales.assign(ls[i])
         m.kernel.variance.assign(var[i])
-        m.likelihood.variance.assign(nz[i])
+        if noise_trainable:
+            m.likelihood.variance.assign(nz[i])
     smgpr._sync()
     nlml, gh, gz = smgpr.ctx.gp_fitc_nlml(smgpr._slot, Z, D, E)
     g_ls = gh[:, :D] * _dsoftplus(u[:E * D]).reshape(E, D)
     g_var = gh[:, D] * _dsoftplus(u[E * D:E * D + E])
-    g_nz = gh[:, D + 1] * _dsoftplus(u[E * D + E:nk])
+    g_nz = gh[:, D + 1] * _dsoftplus(u[E * D + E:nk]) * (1.0 if noise_trainable else 0.0)
     return nlml, np.concatenate([g_ls.ravel(), g_var, g_nz, gz.ravel()])
 
 
@@ -260,13 +262,15 @@ def optimize_smgpr(smgpr, restarts=1, maxiter=None, keep="best"):
                              nk + np.arange(a * M * D, (a + 1) * M * D)]) for a in range(E)]
 
     def run(u0):
-        return lockstep_minimize(lambda u: smgpr_objective(smgpr, u), u0, parts, maxiter, wall=(_lib.NotPositiveDefiniteError,))
+        return lockstep_minimize(lambda u: smgpr_objective(smgpr, u, noise_trainable), u0, parts, maxiter, wall=(_lib.NotPositiveDefiniteError,))
 
+    noise_trainable = all(m.likelihood.variance.trainable for m in smgpr.models)
     u_best, per_best = run(np.concatenate([_mgpr_pack(smgpr), Z0.ravel()]))
     u_prev = u_best
-    ls_r, var_r, nz_r = _restart_draws(E, D, restarts, True)
+    ls_r, var_r, nz_r = _restart_draws(E, D, restarts, noise_trainable)
     for r in range(restarts):
-        u0 = np.concatenate([_softplus_inv(ls_r[r]).ravel(), _softplus_inv(var_r[r]), _softplus_inv(np.maximum(nz_r[r] - NOISE_LOWER, 1e-12)),
+        nz0 = nz_r[r] if noise_trainable else smgpr.noise
+        u0 = np.concatenate([_softplus_inv(ls_r[r]).ravel(), _softplus_inv(var_r[r]), _softplus_inv(np.maximum(nz0 - NOISE_LOWER, 1e-12)),
                              u_prev[nk:]])
         u_prev, per = run(u0)
         better = per < per_best if keep == "best" else np.ones(E, bool)
@@ -274,7 +278,7 @@ def optimize_smgpr(smgpr, restarts=1, maxiter=None, keep="best"):
         for a in np.nonzero(better)[0]:
             ub[parts[a]] = u_prev[parts[a]]
         u_best, per_best = ub, np.where(better, per, per_best)
-    smgpr_objective(smgpr, u_best)      # leaves the kept kernel parameters assigned
+    smgpr_objective(smgpr, u_best, noise_trainable)      # leaves the kept kernel parameters assigned
     Zf = u_best[nk:].reshape(E, M, D)
     for i, m in enumerate(smgpr.models):
         m.inducing_variable.Z.assign(Zf[i])

@@ -88,3 +88,27 @@ def test_sparse_restarts_keep_their_inducing_inputs_and_the_iteration_cap_is_the
     Zend = np.stack([mdl.inducing_variable.Z.numpy() for mdl in m.models])
     assert np.array_equal(Zend.ravel(), endb[nk:]) and np.all(np.isfinite(per))
     assert ctx.calls < 80            # 2 fits x (at most ~5 iterations of a few evaluations): every round is ONE batched call
+
+
+@pytest.mark.parametrize("cls", [MGPR, SMGPR])
+def test_a_fixed_likelihood_variance_stays_where_it_is(cls, monkeypatch):
+    """set_trainable(model.likelihood.variance, False) (examples/safe_cars_run.py:88-90): the fits leave the noise alone
+    and randomize() draws nothing for it (mgpr.py:13-15), restarts included."""
+    from pilco_amd.params import set_trainable
+    g = np.load(os.path.join(GOLDEN, "sparse_models_optimisation.npz"))
+    monkeypatch.setattr(training, "MODEL_FIT_MAXITER", 4)
+    np.random.seed(1)
+    kw = dict(num_induced_points=g["Z_start"].shape[1]) if cls is SMGPR else {}
+    m = cls((g["X"], g["Y"]), ctx=CpuObjectiveContext(), **kw)
+    _start(m, g)
+    for mdl in m.models:
+        mdl.likelihood.variance.assign(0.001)
+        set_trainable(mdl.likelihood.variance, False)
+    ls0 = m.lengthscales.copy()
+    np.random.seed(7)
+    m.optimize(restarts=1, keep="last")
+    drawn = np.random.normal()
+    np.random.seed(7)
+    np.random.normal(size=2 * (3 + 1))            # 2 models x (3 lengthscales + 1 kernel variance), nothing for the noise
+    assert np.random.normal() == drawn
+    assert np.array_equal(m.noise, [0.001, 0.001]) and not np.allclose(m.lengthscales, ls0)
