@@ -155,12 +155,18 @@ class RbfController:
         return self.ctx.policy_action(self.policy_spec(squash), m, s)
 
     def randomize(self):
-        """controllers.py:123-129."""
-        X = np.random.normal(size=self._gp.X.shape)
-        Y = self.max_action / 10 * np.random.normal(size=self._gp.Y.shape)
-        self._gp.set_data((X, Y))
-        for m in self.models:
+        """controllers.py:123-129, with its draw order from NumPy's global generator: model by model the centres (the
+        shared X Parameter is re-assigned by every model, so the last model's draw stays), that model's targets, that
+        model's lengthscales -- a seeded restart starts where the reference's starts for any control_dim."""
+        bf, U = self._gp.X.shape[0], self._gp.Y.shape[1]
+        Y = np.empty((bf, U))
+        scale = np.broadcast_to(np.asarray(self.max_action, np.float64).reshape(-1), (U,)) if np.size(self.max_action) in (1, U) else None
+        for k, m in enumerate(self.models):
+            X = np.random.normal(size=self._gp.X.shape)
+            draw = np.random.normal(size=(bf, 1))
+            Y[:, k:k + 1] = (self.max_action if scale is None else scale[k]) / 10 * draw
             m.kernel.lengthscales.assign(1 + 0.1 * np.random.normal(size=m.kernel.lengthscales.shape))
+        self._gp.set_data((X, Y))
 
     @property
     def trainable_parameters(self):

@@ -391,3 +391,44 @@ def test_product_never_imports_the_oracle_or_the_shim():
                     if needle in src:
                         bad.append((f, needle))
     assert not bad, bad
+
+
+def test_randomize_draws_what_the_executed_reference_draws(R):
+    """Seeded restarts start where the reference's start: randomize() of both controllers (controllers.py:60-63,123-129) and
+    of a GP model (mgpr.py:8-15) take the same values from NumPy's global generator in the same order as the executed
+    reference code -- for a two-output RBF policy too, where every model re-draws the shared centres."""
+    from pilco_amd.controllers import LinearController, RbfController
+    from pilco_amd.models import MGPR
+    from pilco_amd.models.mgpr import randomize
+    from pilco_amd.params import set_trainable
+    n_ = ref_exec.to_np
+    for U in (1, 2):
+        np.random.seed(3)
+        ref = R.controllers.RbfController(state_dim=3, control_dim=U, num_basis_functions=5, max_action=0.7)
+        ours = RbfController(state_dim=3, control_dim=U, num_basis_functions=5, max_action=0.7)
+        np.random.seed(11); ref.randomize()
+        np.random.seed(11); ours.randomize()
+        assert np.array_equal(n_(ref.models[0].X), ours.X)
+        assert np.array_equal(np.hstack([n_(m.Y) for m in ref.models]), ours.Y)
+        np.testing.assert_allclose(np.stack([n_(m.kernel.lengthscales) for m in ref.models]), ours.lengthscales, rtol=1e-15)
+    ref, ours = R.controllers.LinearController(3, 2, max_action=1.0), LinearController(3, 2, max_action=1.0)
+    np.random.seed(5); ref.randomize()
+    np.random.seed(5); ours.randomize()
+    assert np.array_equal(n_(ref.W), ours.W.numpy()) and np.array_equal(n_(ref.b), ours.b.numpy())
+    rs = np.random.RandomState(0)
+    X, Y = rs.randn(6, 3), rs.randn(6, 2)
+    mr, mo = R.MGPR((X, Y)), MGPR((X, Y))
+    for fixed in (False, True):
+        if fixed:
+            R.gpflow.set_trainable(mr.models[1].likelihood.variance, False)
+            set_trainable(mo.models[1].likelihood.variance, False)
+        np.random.seed(9)
+        for m in mr.models:
+            R.mgpr_module.randomize(m)
+        tail_ref = np.random.normal()
+        np.random.seed(9)
+        for m in mo.models:
+            randomize(m)
+        assert np.random.normal() == tail_ref
+        np.testing.assert_allclose(np.stack([n_(m.kernel.lengthscales) for m in mr.models]), mo.lengthscales, rtol=1e-15)
+        np.testing.assert_allclose([float(n_(m.likelihood.variance)) for m in mr.models], mo.noise, rtol=1e-12)
