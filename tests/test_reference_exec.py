@@ -432,3 +432,31 @@ def test_randomize_draws_what_the_executed_reference_draws(R):
         assert np.random.normal() == tail_ref
         np.testing.assert_allclose(np.stack([n_(m.kernel.lengthscales) for m in mr.models]), mo.lengthscales, rtol=1e-15)
         np.testing.assert_allclose([float(n_(m.likelihood.variance)) for m in mr.models], mo.noise, rtol=1e-12)
+
+
+def test_constructors_consume_the_random_draws_the_executed_reference_consumes(R):
+    """A script that seeds NumPy and builds its model starts from the reference's initial state: default controller weights
+    (controllers.py:40-41), default m_init / S_init (pilco.py:37-41), every sparse output's inducing inputs (smgpr.py:20),
+    the RBF policy's centres / targets (controllers.py:84-87) -- and the generator is left where the reference leaves it."""
+    from pilco_amd.controllers import RbfController
+    from pilco_amd.models import PILCO
+    n_ = ref_exec.to_np
+    rs = np.random.RandomState(0)
+    X, Y = rs.randn(12, 4), rs.randn(12, 3)
+    np.random.seed(1); pr = R.PILCO((X, Y)); tail = np.random.normal()
+    np.random.seed(1); po = PILCO((X, Y))
+    assert np.random.normal() == tail
+    assert np.array_equal(n_(pr.controller.W), po.controller.W.numpy()) and np.array_equal(n_(pr.controller.b), po.controller.b.numpy())
+    assert np.array_equal(n_(pr.m_init), po.m_init) and np.array_equal(n_(pr.S_init), po.S_init)
+    assert (pr.state_dim, pr.control_dim, pr.horizon) == (po.state_dim, po.control_dim, po.horizon)
+    np.random.seed(2); pr = R.PILCO((X, Y), num_induced_points=5); tail = np.random.normal()
+    np.random.seed(2); po = PILCO((X, Y), num_induced_points=5)
+    assert np.random.normal() == tail
+    for a, b in zip(pr.mgpr.models, po.mgpr.models):
+        assert np.array_equal(n_(a.inducing_variable.Z), b.inducing_variable.Z.numpy())
+    np.random.seed(3); cr = R.controllers.RbfController(3, 2, 6, max_action=0.5); tail = np.random.normal()
+    np.random.seed(3); co = RbfController(3, 2, 6, max_action=0.5)
+    assert np.random.normal() == tail
+    assert np.array_equal(n_(cr.models[0].X), co.X) and np.array_equal(np.hstack([n_(m.Y) for m in cr.models]), co.Y)
+    np.testing.assert_allclose([float(n_(m.likelihood.variance)) for m in cr.models], co.noise, rtol=1e-12)
+    np.testing.assert_allclose([float(n_(m.kernel.variance)) for m in cr.models], co.variance, rtol=1e-12)
