@@ -94,16 +94,31 @@ class RbfController:
         self.control_dim = control_dim
         self.num_basis_functions = num_basis_functions
         self.max_action = max_action
-        self._gp = _PolicyGP((np.random.randn(num_basis_functions, state_dim),
-                              0.1 * np.random.randn(num_basis_functions, control_dim)), ctx=ctx)
+        data = (np.random.randn(num_basis_functions, state_dim), 0.1 * np.random.randn(num_basis_functions, control_dim))
+        self._gp = _PolicyGP(data, ctx=ctx)
+        self.create_models(data)
+        self.centres = _PolicyData(self._gp, 0, "DataX")     # shared by every output (controllers.py:104-106)
+        self.targets = _PolicyData(self._gp, 1, "DataY")
+
+    # -- controllers.py:96-106
+    def create_models(self, data):
+        """One model per control dimension over shared centres: unit kernel variance (fixed), likelihood variance 1e-4
+        (fixed), lengthscales one with the lower bound 1e-3 of the reference's transform."""
+        self._gp.create_models(data)
         for model in self._gp.models:
             model.kernel.variance.assign(1.0)               # controllers.py:92-93
             model.kernel.variance.trainable = False
             model.likelihood.variance.assign(1e-4)          # FakeGPR, controllers.py:67,76-77
             model.likelihood.variance.trainable = False
             model.kernel.lengthscales.lower = 1e-3          # positive(lower=1e-3), controllers.py:100
-        self.centres = _PolicyData(self._gp, 0, "DataX")     # shared by every output (controllers.py:104-106)
-        self.targets = _PolicyData(self._gp, 1, "DataY")
+        self._gp._invalidate()
+
+    def __getattr__(self, name):
+        """The reference's RbfController IS an MGPR (controllers.py:80): whatever of that surface is not spelled out below
+        (num_outputs, predict_given_factorizations, centralized_input, K, data, ...) is the policy GP's."""
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._gp, name)
 
     # -- the MGPR surface the reference's callers use on an RbfController
     @property

@@ -102,5 +102,6 @@ class PILCO:
     def trainable_parameters(self):
         ps = list(self.mgpr.trainable_parameters)
         if self.controller is not None:
-            ps += [p for p in parameters_of(self.controller) if p.trainable]
+            own = getattr(type(self.controller), "trainable_parameters", None)    # an RbfController lists centres, targets, lengthscales
+            ps += list(self.controller.trainable_parameters) if own is not None else [p for p in parameters_of(self.controller) if p.trainable]
         return ps

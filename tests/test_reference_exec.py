@@ -460,3 +460,48 @@ def test_constructors_consume_the_random_draws_the_executed_reference_consumes(R
     assert np.array_equal(n_(cr.models[0].X), co.X) and np.array_equal(np.hstack([n_(m.Y) for m in cr.models]), co.Y)
     np.testing.assert_allclose([float(n_(m.likelihood.variance)) for m in cr.models], co.noise, rtol=1e-12)
     np.testing.assert_allclose([float(n_(m.kernel.variance)) for m in cr.models], co.variance, rtol=1e-12)
+
+
+def test_every_public_class_and_function_of_the_reference_packages_has_its_counterpart_at_the_same_module_path():
+    """pilco/{controllers,rewards,models/*}.py and safe_pilco_extension/*.py: every top-level class / function name is
+    importable from the same relative module path under pilco_amd, with every public method the reference class defines
+    (inherited ones count)."""
+    import ast
+    import importlib
+    pairs = {"pilco/controllers.py": "pilco_amd.controllers", "pilco/rewards.py": "pilco_amd.rewards",
+             "pilco/models/mgpr.py": "pilco_amd.models.mgpr", "pilco/models/smgpr.py": "pilco_amd.models.smgpr",
+             "pilco/models/pilco.py": "pilco_amd.models.pilco",
+             "safe_pilco_extension/safe_pilco.py": "pilco_amd.safe_pilco_extension.safe_pilco",
+             "safe_pilco_extension/rewards_safe.py": "pilco_amd.safe_pilco_extension.rewards_safe"}
+    internal = {"FakeGPR"}      # controllers.py:66-78: a container for the policy GP's data, replaced by the device slot
+    for rel, modname in pairs.items():
+        tree = ast.parse(open(os.path.join(ref_exec.REFERENCE_ROOT, rel)).read())
+        mod = importlib.import_module(modname)
+        for node in tree.body:
+            if isinstance(node, ast.FunctionDef):
+                assert callable(getattr(mod, node.name, None)), (modname, node.name)
+            elif isinstance(node, ast.ClassDef) and node.name not in internal:
+                cls = getattr(mod, node.name, None)
+                assert isinstance(cls, type), (modname, node.name)
+                for item in node.body:
+                    if isinstance(item, ast.FunctionDef) and not item.name.startswith("_"):
+                        assert hasattr(cls, item.name), (modname, node.name, item.name)
+    import pilco_amd.models as pm
+    for name in ("PILCO", "MGPR", "SMGPR"):                      # pilco/models/__init__.py:1-3
+        assert isinstance(getattr(pm, name), type)
+
+
+def test_trainable_parameter_sets_match_the_executed_reference(R):
+    """PILCO.trainable_parameters (what the reference's optimize_policy saves and restores, pilco.py:96-110): same shapes
+    for a linear policy; for an RBF policy the same set with the per-model target columns (bf, 1) x U held as one (bf, U)."""
+    from pilco_amd.controllers import RbfController
+    from pilco_amd.models import PILCO
+    rs = np.random.RandomState(0)
+    X, Y = rs.randn(12, 4), rs.randn(12, 3)
+    shapes = lambda ps, f: sorted(tuple(np.shape(f(q))) for q in ps)
+    ref, ours = R.PILCO((X, Y)), PILCO((X, Y))
+    assert shapes(ref.trainable_parameters, n_) == shapes(ours.trainable_parameters, lambda q: q.numpy())
+    ref = R.PILCO((X, Y), controller=R.controllers.RbfController(3, 2, 5))
+    ours = PILCO((X, Y), controller=RbfController(3, 2, 5))
+    a, b = shapes(ref.trainable_parameters, n_), shapes(ours.trainable_parameters, lambda q: q.numpy())
+    assert [s for s in a if s != (5, 1)] == [s for s in b if s != (5, 2)] and a.count((5, 1)) == 2 and b.count((5, 2)) == 1
