@@ -39,6 +39,14 @@ class CpuObjectiveContext:
     def gp_fitc_nlml(self, slot, Z_all, D, E, want_grad=True):
         """gpflow.models.GPRFITC: -log N(y | 0, Qff + diag(Kff - Qff) + noise I) by the inducing-point identities."""
         self.calls += 1
+        nthreads = torch.get_num_threads()
+        torch.set_num_threads(1)          # bitwise repeatable sums: the fits are hundreds of iterations in a flat valley
+        try:
+            return self._fitc(Z_all, D, E)
+        finally:
+            torch.set_num_threads(nthreads)
+
+    def _fitc(self, Z_all, D, E):
         X, N = torch.from_numpy(self.X), self.X.shape[0]
         nlml, gh, gz = np.empty(E), np.empty((E, D + 2)), np.empty((E,) + Z_all.shape[1:])
         for a in range(E):
