@@ -418,6 +418,41 @@ def gen_policy_optimisation_rbf(R):
           reward_start=r0, reward_end=r1, X_end=n_(ctl.models[0].X), Y_end=n_(ctl.models[0].Y), ls_end=n_(ctl.models[0].kernel.lengthscales))
 
 
+def gen_policy_optimisation_restarts(R):
+    """optimize_policy with random restarts executed (pilco.py:93-110): after the first run, `restarts - 1` times
+    controller.randomize() (controllers.py:60-63,123-129, NumPy's global generator, seeded here) + another run; the
+    controller with the highest reward is restored.  Both policies of policy_optimisation*.npz, restarts=3."""
+    c = synthetic.config_cascade()
+    out = {}
+    # linear
+    np.random.seed(9)
+    p = R.PILCO((c["X"], c["Y"]), horizon=8, m_init=c["m"], S_init=c["s"])
+    _set_hyp(p.mgpr.models, c["lengthscales"], c["variance"], c["noise"])
+    p.controller.W.assign(c["W"]); p.controller.b.assign(c["b"]); p.controller.max_action = c["max_action"]
+    np.random.seed(21)
+    p.optimize_policy(maxiter=12, restarts=3)
+    out.update(lin_seed=21, lin_maxiter=12, lin_H=8, lin_reward_end=float(n_(p.compute_reward()).ravel()[0]),
+               lin_W_end=n_(p.controller.W), lin_b_end=n_(p.controller.b))
+    # RBF
+    rs = np.random.RandomState(11)
+    bf = 6
+    Xp, Yp = rs.randn(bf, 2), 0.4 * rs.randn(bf, 1)
+    lsp = 1 + 0.2 * rs.rand(1, 2)
+    Wl = np.array([[0.3], [-0.2]])
+    np.random.seed(10)
+    ctl = R.controllers.RbfController(2, 1, bf, max_action=1.5)
+    ctl.set_data((Xp, Yp))
+    ctl.models[0].kernel.lengthscales.assign(lsp[0])
+    rew = R.rewards.CombinedRewards(2, [R.rewards.ExponentialReward(2), R.rewards.LinearReward(2, Wl)], coefs=[1.0, 0.5])
+    p = R.PILCO((c["X"], c["Y"]), horizon=5, controller=ctl, reward=rew, m_init=c["m"], S_init=c["s"])
+    _set_hyp(p.mgpr.models, c["lengthscales"], c["variance"], c["noise"])
+    np.random.seed(22)
+    p.optimize_policy(maxiter=10, restarts=3)
+    out.update(rbf_seed=22, rbf_maxiter=10, rbf_H=5, rbf_reward_end=float(n_(p.compute_reward()).ravel()[0]),
+               rbf_X_end=n_(ctl.models[0].X), rbf_Y_end=n_(ctl.models[0].Y), rbf_ls_end=n_(ctl.models[0].kernel.lengthscales))
+    _save("policy_optimisation_restarts.npz", restarts=3, **out)
+
+
 def gen_models_optimisation(R):
     """MGPR.optimize(restarts=0) executed (mgpr.py:47-75: one SciPy L-BFGS-B run per output on GPflow's GPR training loss
     with the Gamma priors of mgpr.py:33-34, from the given start): the hyper-parameters it ends at and the loss there.
@@ -516,6 +551,7 @@ def main():
     gen_sparse_rollout(R)
     gen_policy_optimisation(R)
     gen_policy_optimisation_rbf(R)
+    gen_policy_optimisation_restarts(R)
     gen_models_optimisation(R)
     gen_sparse_models_optimisation(R)
     gen_fitc_objective(R)

@@ -147,7 +147,9 @@ class Parameter:
         return self._u
 
     def numpy(self):
-        return self.value().numpy()
+        # a COPY, as tf.Variable.numpy() gives: the reference saves "best" parameter values with it and goes on optimising
+        # (pilco.py:96,105); an alias of the variable's storage would silently follow the optimiser
+        return np.array(self.value().numpy(), copy=True)
 
     def __array__(self, dtype=None, copy=None):
         a = self.numpy()

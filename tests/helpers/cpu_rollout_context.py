@@ -1,0 +1,106 @@
+"""A CPU stand-in for the device calls PILCO.optimize_policy makes (rollout value, value + policy gradient), so that the HOST
+side of the policy optimisation -- parameter packing, the softplus transform of the RBF lengthscales with its lower bound,
+sign conventions, L-BFGS-B options, restart bookkeeping (pilco_amd/training.py, adjoint.py, controllers.py) -- can be held to
+the executed reference's end points in the CPU suite.  TEST INFRASTRUCTURE: values and gradients come from the torch
+restatement of the rollout (oracle/torch_path.py, autograd in the role of TF's reverse mode); the product computes them on the
+device (pilco_rollout, pilco_rollout_grad*)."""
+import numpy as np
+import torch
+
+from oracle import torch_path as tq
+from pilco_amd import _lib
+
+T = tq.t
+
+
+class CpuRolloutContext:
+    def __init__(self):
+        self._slot_owner = {}
+        self.slots = {}
+        self.grad_calls = 0
+
+    # -- model upload (slot 0: dynamics, slot 1: the RBF policy's GP -- only its data matter here)
+    def gp_set_data(self, slot, X, Y, owner=None):
+        self._slot_owner[slot] = owner
+        self.slots.setdefault(slot, {}).update(X=np.array(X, np.float64), Y=np.array(Y, np.float64))
+
+    def gp_set_hyp(self, slot, lengthscales, variance, noise, owner=None):
+        self._slot_owner[slot] = owner
+        self.slots.setdefault(slot, {}).update(ls=np.array(lengthscales, np.float64), var=np.ravel(variance).astype(np.float64),
+                                               nz=np.ravel(noise).astype(np.float64))
+
+    def gp_set_inducing(self, slot, Z, owner=None):
+        self._slot_owner[slot] = owner
+
+    def gp_factorize(self, slot):
+        pass
+
+    def set_grad_mode(self, mode):
+        pass
+
+    # -- the rollout in torch
+    def _dynamics(self):
+        s = self.slots[_lib.SLOT_DYNAMICS]
+        X, ls, var = T(s["X"]), T(s["ls"]), T(s["var"])
+        N, E = s["Y"].shape
+        iK, beta = [], []
+        for a in range(E):
+            K = var[a] * torch.exp(-0.5 * torch.sum(((X[:, None, :] - X[None, :, :]) / ls[a]) ** 2, -1)) + s["nz"][a] * torch.eye(N, dtype=tq.DT)
+            Ki = torch.linalg.inv(K)
+            iK.append(Ki)
+            beta.append(Ki @ T(s["Y"][:, a]))
+        iK, beta = torch.stack(iK), torch.stack(beta)
+        return lambda m, sx: tq.predict_given_factorizations(X, ls, var, m, sx, iK, beta)
+
+    @staticmethod
+    def _reward(terms, E):
+        def f(m, s):
+            tot = torch.zeros((1, 1), dtype=tq.DT)
+            for t in terms:
+                if t["kind"] == _lib.REWARD_EXPONENTIAL:
+                    tot = tot + t["coef"] * tq.exponential_reward(m, s, t["W"], t["t"])
+                elif t["kind"] == _lib.REWARD_LINEAR:
+                    tot = tot + t["coef"] * (m @ T(t["W"]).reshape(E, 1))
+                else:
+                    raise NotImplementedError(t["kind"])
+            return tot
+        return f
+
+    def _value(self, policy, rewards, m0, S0, H, params):
+        E = policy["state_dim"]
+        e = T(np.broadcast_to(np.asarray(policy["max_action"], np.float64).reshape(-1), (policy["control_dim"],)).copy())
+        if policy["kind"] == _lib.POLICY_LINEAR:
+            W, b = params
+            ctl = lambda m, s: tq.linear_controller(m, s, W, b, e, policy.get("squash", True))
+        elif policy["kind"] == _lib.POLICY_RBF:
+            Xp, Yp, lsp, nzp = params
+            ctl = lambda m, s: tq.rbf_controller(m, s, Xp, Yp, lsp, nzp, e, policy.get("squash", True))
+        else:
+            raise NotImplementedError(policy["kind"])
+        return tq.predict(self._dynamics(), ctl, self._reward(rewards, E), T(np.reshape(m0, (1, E))), T(np.reshape(S0, (E, E))), int(H))
+
+    def rollout(self, policy, rewards, m0, S0, H, want_traj=False):
+        with torch.no_grad():
+            if policy["kind"] == _lib.POLICY_LINEAR:
+                params = (T(policy["W"]), T(policy["b"]))
+            else:
+                p = self.slots[_lib.SLOT_POLICY]
+                params = (T(p["X"]), T(p["Y"]), T(p["ls"]), T(p["nz"]))
+            M, S, R = self._value(policy, rewards, m0, S0, H, params)
+        return M.numpy(), S.numpy(), R.numpy()
+
+    def rollout_grad(self, policy, rewards, m0, S0, H, seed_fn=None):
+        assert seed_fn is None
+        self.grad_calls += 1
+        W, b = T(policy["W"]).clone().requires_grad_(True), T(policy["b"]).clone().requires_grad_(True)
+        R = self._value(policy, rewards, m0, S0, H, (W, b))[2]
+        gW, gb = torch.autograd.grad(R.sum(), [W, b])
+        return float(R.detach()), gW.numpy(), gb.numpy()
+
+    def rollout_grad_rbf(self, policy, rewards, m0, S0, H, Xp, Yp, lsp, noisep, seed_fn=None):
+        assert seed_fn is None
+        self.grad_calls += 1
+        ps = [T(np.array(v, np.float64)).clone().requires_grad_(True) for v in (Xp, Yp, lsp)]
+        R = self._value(policy, rewards, m0, S0, H, (ps[0], ps[1], ps[2], T(np.ravel(noisep))))[2]
+        g = torch.autograd.grad(R.sum(), ps)
+        return float(R.detach()), g[0].numpy(), g[1].numpy(), g[2].numpy()

@@ -1,0 +1,89 @@
+"""The host side of PILCO.optimize_policy (pilco_amd/training.py, adjoint.py, controllers.py: packing of the trainable set,
+softplus transform of the RBF lengthscales with its 1e-3 lower bound, signs, L-BFGS-B options, restart bookkeeping) against
+the end points of the EXECUTED reference's optimize_policy (tests/golden/policy_optimisation*.npz), with rollout values and
+gradients supplied by a CPU stand-in for the device calls (tests/helpers/cpu_rollout_context.py).  The same fixtures are met on
+the GPU with the native reverse sweep (tests/test_gpu_parity.py::test_optimize_policy*_ends_where_the_executed_reference_ends)."""
+import os
+
+import numpy as np
+
+from helpers.cpu_rollout_context import CpuRolloutContext
+from pilco_amd.controllers import LinearController, RbfController
+from pilco_amd.models import PILCO
+from pilco_amd.rewards import CombinedRewards, ExponentialReward, LinearReward
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _hyp(p, g):
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(g["lengthscales"][i])
+        mdl.kernel.variance.assign(g["variance"][i])
+        mdl.likelihood.variance.assign(g["noise"][i])
+
+
+def test_linear_policy_ends_where_the_executed_reference_ends():
+    g = np.load(os.path.join(GOLDEN, "policy_optimisation.npz"))
+    ctx = CpuRolloutContext()
+    E = g["Y"].shape[1]
+    ctl = LinearController(E, g["X"].shape[1] - E, max_action=g["max_action"], ctx=ctx)
+    p = PILCO((g["X"], g["Y"]), horizon=int(g["H"]), controller=ctl, reward=ExponentialReward(E), m_init=g["m"], S_init=g["s"], ctx=ctx)
+    _hyp(p, g)
+    ctl.W.assign(g["W"]); ctl.b.assign(g["b"])
+    np.testing.assert_allclose(float(p.compute_reward()[0, 0]), float(g["reward_start"]), rtol=1e-9)
+    r = p.optimize_policy(maxiter=int(g["maxiter"]), restarts=1, verbose=False)
+    np.testing.assert_allclose(r, float(g["reward_end"]), rtol=1e-6)
+    np.testing.assert_allclose(ctl.W.numpy(), g["W_end"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ctl.b.numpy(), g["b_end"], rtol=1e-4, atol=1e-6)
+    assert ctx.grad_calls > 0
+
+
+def test_rbf_policy_ends_where_the_executed_reference_ends():
+    g = np.load(os.path.join(GOLDEN, "policy_optimisation_rbf.npz"))
+    ctx = CpuRolloutContext()
+    ctl = RbfController(state_dim=2, control_dim=1, num_basis_functions=g["rbf_X"].shape[0], max_action=float(g["max_action"]), ctx=ctx)
+    ctl.set_data((g["rbf_X"], g["rbf_Y"]))
+    ctl.models[0].kernel.lengthscales.assign(g["rbf_lengthscales"][0])
+    rew = CombinedRewards(2, [ExponentialReward(2), LinearReward(2, g["W_lin"])], coefs=list(g["coefs"]))
+    p = PILCO((g["X"], g["Y"]), horizon=int(g["H"]), controller=ctl, reward=rew, m_init=g["m"], S_init=g["s"], ctx=ctx)
+    _hyp(p, g)
+    np.testing.assert_allclose(float(p.compute_reward()[0, 0]), float(g["reward_start"]), rtol=1e-9)
+    r = p.optimize_policy(maxiter=int(g["maxiter"]), restarts=1, verbose=False)
+    np.testing.assert_allclose(r, float(g["reward_end"]), rtol=1e-6)
+    np.testing.assert_allclose(ctl.X, g["X_end"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(ctl.Y, g["Y_end"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(np.ravel(ctl.lengthscales), np.ravel(g["ls_end"]), rtol=1e-3)
+
+
+def test_random_restarts_keep_the_controller_the_executed_reference_keeps():
+    """optimize_policy(restarts=3) (pilco.py:93-110): two seeded controller.randomize() restarts after the first run, the
+    best controller by reward restored -- the first run's for the linear policy, a restart's for the RBF policy."""
+    r_ = np.load(os.path.join(GOLDEN, "policy_optimisation_restarts.npz"))
+    g = np.load(os.path.join(GOLDEN, "policy_optimisation.npz"))
+    ctx = CpuRolloutContext()
+    E = g["Y"].shape[1]
+    ctl = LinearController(E, g["X"].shape[1] - E, max_action=g["max_action"], ctx=ctx)
+    p = PILCO((g["X"], g["Y"]), horizon=int(r_["lin_H"]), controller=ctl, reward=ExponentialReward(E), m_init=g["m"], S_init=g["s"], ctx=ctx)
+    _hyp(p, g)
+    ctl.W.assign(g["W"]); ctl.b.assign(g["b"])
+    np.random.seed(int(r_["lin_seed"]))
+    r = p.optimize_policy(maxiter=int(r_["lin_maxiter"]), restarts=int(r_["restarts"]), verbose=False)
+    np.testing.assert_allclose(r, float(r_["lin_reward_end"]), rtol=1e-6)
+    np.testing.assert_allclose(ctl.W.numpy(), r_["lin_W_end"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(float(p.compute_reward()[0, 0]), r, rtol=1e-12)      # the kept controller is the assigned one
+
+    g = np.load(os.path.join(GOLDEN, "policy_optimisation_rbf.npz"))
+    ctx = CpuRolloutContext()
+    ctl = RbfController(state_dim=2, control_dim=1, num_basis_functions=g["rbf_X"].shape[0], max_action=float(g["max_action"]), ctx=ctx)
+    ctl.set_data((g["rbf_X"], g["rbf_Y"]))
+    ctl.models[0].kernel.lengthscales.assign(g["rbf_lengthscales"][0])
+    rew = CombinedRewards(2, [ExponentialReward(2), LinearReward(2, g["W_lin"])], coefs=list(g["coefs"]))
+    p = PILCO((g["X"], g["Y"]), horizon=int(r_["rbf_H"]), controller=ctl, reward=rew, m_init=g["m"], S_init=g["s"], ctx=ctx)
+    _hyp(p, g)
+    np.random.seed(int(r_["rbf_seed"]))
+    r = p.optimize_policy(maxiter=int(r_["rbf_maxiter"]), restarts=int(r_["restarts"]), verbose=False)
+    np.testing.assert_allclose(r, float(r_["rbf_reward_end"]), rtol=1e-6)
+    assert r > float(g["reward_end"])                                                  # a restart won
+    np.testing.assert_allclose(ctl.X, r_["rbf_X_end"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(ctl.Y, r_["rbf_Y_end"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(np.ravel(ctl.lengthscales), np.ravel(r_["rbf_ls_end"]), rtol=1e-3)
