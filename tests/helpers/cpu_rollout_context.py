@@ -66,7 +66,8 @@ class CpuRolloutContext:
             return tot
         return f
 
-    def _value(self, policy, rewards, m0, S0, H, params):
+    def _value(self, policy, rewards, m0, S0, H, params, seeds=None, traj=None):
+        """(m_H, s_H, additive reward [+ sum_t <seeds_t, state_t> when seeds are given]); traj (list) collects the states."""
         E = policy["state_dim"]
         e = T(np.broadcast_to(np.asarray(policy["max_action"], np.float64).reshape(-1), (policy["control_dim"],)).copy())
         if policy["kind"] == _lib.POLICY_LINEAR:
@@ -77,30 +78,53 @@ class CpuRolloutContext:
             ctl = lambda m, s: tq.rbf_controller(m, s, Xp, Yp, lsp, nzp, e, policy.get("squash", True))
         else:
             raise NotImplementedError(policy["kind"])
-        return tq.predict(self._dynamics(), ctl, self._reward(rewards, E), T(np.reshape(m0, (1, E))), T(np.reshape(S0, (E, E))), int(H))
+        gp, reward = self._dynamics(), self._reward(rewards, E)
+        m, s = T(np.reshape(m0, (1, E))), T(np.reshape(S0, (E, E)))
+        total = torch.zeros((1, 1), dtype=tq.DT)
+        for t in range(int(H) + 1):
+            if traj is not None:
+                traj.append(torch.cat([m.reshape(-1), s.reshape(-1)]))
+            if seeds is not None:
+                total = total + (T(seeds[t, :E]) * m.reshape(-1)).sum() + (T(seeds[t, E:]).reshape(E, E) * s).sum()
+            if t == int(H):
+                break
+            total = total + reward(m, s)
+            m, s = tq.propagate(gp, ctl, m, s)
+        return m, s, total
+
+    def _params(self, policy):
+        if policy["kind"] == _lib.POLICY_LINEAR:
+            return [T(policy["W"]), T(policy["b"])]
+        p = self.slots[_lib.SLOT_POLICY]
+        return [T(p["X"]), T(p["Y"]), T(p["ls"]), T(p["nz"])]
 
     def rollout(self, policy, rewards, m0, S0, H, want_traj=False):
         with torch.no_grad():
-            if policy["kind"] == _lib.POLICY_LINEAR:
-                params = (T(policy["W"]), T(policy["b"]))
-            else:
-                p = self.slots[_lib.SLOT_POLICY]
-                params = (T(p["X"]), T(p["Y"]), T(p["ls"]), T(p["nz"]))
-            M, S, R = self._value(policy, rewards, m0, S0, H, params)
-        return M.numpy(), S.numpy(), R.numpy()
+            traj = [] if want_traj else None
+            M, S, R = self._value(policy, rewards, m0, S0, H, self._params(policy), traj=traj)
+        out = (M.numpy(), S.numpy(), R.numpy())
+        return out + (torch.stack(traj).numpy(),) if want_traj else out
+
+    def _grad(self, policy, rewards, m0, S0, H, params, n_diff, seed_fn):
+        """What pilco_rollout_grad*_seeded does: forward pass, seeds = seed_fn(trajectory), gradient of the additive reward
+        plus the seeded objective; the value returned is the additive reward alone."""
+        self.grad_calls += 1
+        seeds = None
+        if seed_fn is not None:
+            with torch.no_grad():
+                traj = []
+                self._value(policy, rewards, m0, S0, H, [p.detach() for p in params], traj=traj)
+            seeds = np.asarray(seed_fn(torch.stack(traj).numpy()), np.float64)
+        with torch.no_grad():
+            r_add = float(self._value(policy, rewards, m0, S0, H, [p.detach() for p in params])[2])
+        obj = self._value(policy, rewards, m0, S0, H, params, seeds=seeds)[2]
+        g = torch.autograd.grad(obj.sum(), params[:n_diff])
+        return (r_add,) + tuple(x.numpy() for x in g)
 
     def rollout_grad(self, policy, rewards, m0, S0, H, seed_fn=None):
-        assert seed_fn is None
-        self.grad_calls += 1
-        W, b = T(policy["W"]).clone().requires_grad_(True), T(policy["b"]).clone().requires_grad_(True)
-        R = self._value(policy, rewards, m0, S0, H, (W, b))[2]
-        gW, gb = torch.autograd.grad(R.sum(), [W, b])
-        return float(R.detach()), gW.numpy(), gb.numpy()
+        ps = [T(policy["W"]).clone().requires_grad_(True), T(policy["b"]).clone().requires_grad_(True)]
+        return self._grad(policy, rewards, m0, S0, H, ps, 2, seed_fn)
 
     def rollout_grad_rbf(self, policy, rewards, m0, S0, H, Xp, Yp, lsp, noisep, seed_fn=None):
-        assert seed_fn is None
-        self.grad_calls += 1
-        ps = [T(np.array(v, np.float64)).clone().requires_grad_(True) for v in (Xp, Yp, lsp)]
-        R = self._value(policy, rewards, m0, S0, H, (ps[0], ps[1], ps[2], T(np.ravel(noisep))))[2]
-        g = torch.autograd.grad(R.sum(), ps)
-        return float(R.detach()), g[0].numpy(), g[1].numpy(), g[2].numpy()
+        ps = [T(np.array(v, np.float64)).clone().requires_grad_(True) for v in (Xp, Yp, lsp)] + [T(np.ravel(noisep))]
+        return self._grad(policy, rewards, m0, S0, H, ps, 3, seed_fn)

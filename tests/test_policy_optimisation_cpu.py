@@ -87,3 +87,48 @@ def test_random_restarts_keep_the_controller_the_executed_reference_keeps():
     np.testing.assert_allclose(ctl.X, r_["rbf_X_end"], rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(ctl.Y, r_["rbf_Y_end"], rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(np.ravel(ctl.lengthscales), np.ravel(r_["rbf_ls_end"]), rtol=1e-3)
+
+
+def test_safe_pilco_objective_and_its_gradient_reach_the_optimiser_as_in_the_executed_extension():
+    """SafePILCO (safe_pilco_extension/safe_pilco.py:29-50): what optimize_policy differentiates must be the TOTAL reward,
+    mu (1 - prod (1 - risk_t)) included.  The host side -- predict()'s accumulator over the trajectory, trajectory_objective's
+    cotangent seeds, their hand-over to the reverse sweep, signs and packing in policy_loss_and_grad -- against reverse mode
+    through the EXECUTED extension (fixtures safe_pilco.npz: linear policy + SingleConstraint; safe_pilco_rbf.npz: RBF policy +
+    RiskOfCollision, the pairing of examples/safe_cars_run.py), the rollout itself supplied by the CPU stand-in."""
+    from pilco_amd.safe import RiskOfCollision, SafePILCO, SingleConstraint
+    from pilco_amd.training import _policy_params, policy_loss_and_grad
+    g = np.load(os.path.join(GOLDEN, "safe_pilco.npz"))
+    ctx, H = CpuRolloutContext(), int(g["H"])
+    ctl = LinearController(2, 1, max_action=g["max_action"], ctx=ctx)
+    p = SafePILCO((g["X"], g["Y"]), horizon=H, controller=ctl, reward_add=ExponentialReward(2),
+                  reward_mult=SingleConstraint(0, high=float(g["high"]), inside=False), mu=float(g["mu"]), m_init=g["m"], S_init=g["s"], ctx=ctx)
+    _hyp(p, g)
+    ctl.W.assign(g["W"]); ctl.b.assign(g["b"])
+    M, S, R = p.predict(g["m"], g["s"], H)
+    np.testing.assert_allclose(M, g["M"], rtol=1e-9)
+    np.testing.assert_allclose(float(np.ravel(R)[0]), float(g["reward_total"]), rtol=1e-9)
+    get, put = _policy_params(ctl)
+    f, grad = policy_loss_and_grad(p, get(), put)
+    np.testing.assert_allclose(-f, float(g["reward_total"]), rtol=1e-9)
+    np.testing.assert_allclose(-grad[:2].reshape(1, 2), g["dtotal_dW"], rtol=1e-8)
+    np.testing.assert_allclose(-grad[2:].reshape(1, 1), g["dtotal_db"], rtol=1e-8)
+
+    g = np.load(os.path.join(GOLDEN, "safe_pilco_rbf.npz"))
+    ctx, H = CpuRolloutContext(), int(g["H"])
+    ctl = RbfController(state_dim=4, control_dim=1, num_basis_functions=g["rbf_X"].shape[0], max_action=float(g["max_action"]), ctx=ctx)
+    ctl.set_data((g["rbf_X"], g["rbf_Y"]))
+    ctl.models[0].kernel.lengthscales.assign(g["rbf_lengthscales"][0])
+    p = SafePILCO((g["X"], g["Y"]), horizon=H, controller=ctl, reward_add=LinearReward(4, g["W_lin"]),
+                  reward_mult=RiskOfCollision(2, g["low"], g["high"]), mu=float(g["mu"]), m_init=g["m0"], S_init=g["S0"], ctx=ctx)
+    _hyp(p, g)
+    np.testing.assert_allclose(float(np.ravel(p.predict(g["m0"], g["S0"], H)[2])[0]), float(g["reward_total"]), rtol=1e-9)
+    get, put = _policy_params(ctl)
+    u = get()
+    f, grad = policy_loss_and_grad(p, u, put)
+    np.testing.assert_allclose(-f, float(g["reward_total"]), rtol=1e-9)
+    nX, nY = g["rbf_X"].size, g["rbf_Y"].size
+    np.testing.assert_allclose(-grad[:nX].reshape(g["rbf_X"].shape), g["dtotal_dX"], rtol=1e-7, atol=1e-10 * float(np.abs(g["dtotal_dX"]).max()))
+    np.testing.assert_allclose(-grad[nX:nX + nY].reshape(g["rbf_Y"].shape), g["dtotal_dY"], rtol=1e-7, atol=1e-10 * float(np.abs(g["dtotal_dY"]).max()))
+    # the lengthscale entries of the packed gradient are w.r.t. the unconstrained variable: d ls / du = sigmoid(u)
+    dls = -grad[nX + nY:] / (1.0 / (1.0 + np.exp(-u[nX + nY:])))
+    np.testing.assert_allclose(dls.reshape(g["dtotal_dls"].shape), g["dtotal_dls"], rtol=1e-7)
