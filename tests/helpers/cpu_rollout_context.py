@@ -31,6 +31,7 @@ class CpuRolloutContext:
 
     def gp_set_inducing(self, slot, Z, owner=None):
         self._slot_owner[slot] = owner
+        self.slots.setdefault(slot, {})["Z"] = None if Z is None else np.array(Z, np.float64)
 
     def gp_factorize(self, slot):
         pass
@@ -41,6 +42,11 @@ class CpuRolloutContext:
     # -- the rollout in torch
     def _dynamics(self):
         s = self.slots[_lib.SLOT_DYNAMICS]
+        if s.get("Z") is not None:      # sparse model: FITC factors over the inducing inputs (smgpr.py:24-52)
+            from oracle import tf_path as tp
+            iK, beta = tp.fitc_factorizations(s["X"], s["Y"], s["Z"], s["ls"], s["var"], s["nz"])
+            Z, ls, var, iK, beta = T(s["Z"]), T(s["ls"]), T(s["var"]), T(iK), T(beta)
+            return lambda m, sx: tq.predict_given_factorizations(Z, ls, var, m, sx, iK, beta)
         X, ls, var = T(s["X"]), T(s["ls"]), T(s["var"])
         N, E = s["Y"].shape
         iK, beta = [], []
