@@ -108,8 +108,9 @@ class MGPR:
             self.ctx.gp_factorize(self._slot)                   # cached on the device: a no-op while nothing changed
 
     # -- reference: mgpr.py:47-75
-    def optimize(self, restarts=1, keep="best"):
-        """keep='last' reproduces what the reference ends with when restarts > 0 (training.optimize_mgpr)."""
+    def optimize(self, restarts=1, keep="last"):
+        """keep='last': the reference's end state (the last restart's fit stays, mgpr.py:59-75); keep='best': per output the
+        better fit (extension).  See training.optimize_mgpr."""
         from ..training import optimize_mgpr
         return optimize_mgpr(self, restarts=restarts, keep=keep)
 

@@ -50,7 +50,7 @@ class SMGPR(MGPR):
         return self.Z
 
     # -- reference: MGPR.optimize applied to GPRFITC models (mgpr.py:47-75 with smgpr.py:16-22)
-    def optimize(self, restarts=1, keep="best"):
+    def optimize(self, restarts=1, keep="last"):
         """Every output's GPRFITC model is fitted as the reference does it: kernel hyper-parameters, noise variance AND
         the output's own M x D inducing inputs by L-BFGS-B on the FITC marginal likelihood, evaluated with its analytic
         gradient on the device (pilco_gp_fitc_nlml, csrc/fitc_train.hip).  Prediction then uses model 0's inducing

@@ -186,14 +186,15 @@ def _restart_draws(E, D, restarts, noise_trainable):
 
 def _check_keep(keep):
     if keep not in ("best", "last"):
-        raise ValueError("keep: 'best' (per output the fit with the lowest loss) or 'last' (what the reference ends with)")
+        raise ValueError("keep: 'last' (what the reference ends with) or 'best' (per output the fit with the lowest loss)")
 
 
-def optimize_mgpr(mgpr, restarts=1, maxiter=None, verbose=False, keep="best"):
-    """MGPR.optimize (mgpr.py:47-75).  keep='best': every output ends with the better of its fits -- what the reference's
-    bookkeeping sets out to do.  keep='last': what the reference actually ends with: its `best_params` hold the live
-    Parameter objects, not copies (mgpr.py:59-62,69-71), so the final assign (mgpr.py:73-75) assigns every parameter to
-    itself and the model keeps the LAST restart's fit whether or not it was better."""
+def optimize_mgpr(mgpr, restarts=1, maxiter=None, verbose=False, keep="last"):
+    """MGPR.optimize (mgpr.py:47-75).  keep='last' (default) is what the reference ends with: its `best_params` hold the
+    live Parameter objects, not copies (mgpr.py:59-62,69-71), so the final assign (mgpr.py:73-75) assigns every parameter
+    to itself and the model keeps the LAST restart's fit whether or not it was better -- with the same np.random.seed the
+    product's models end where the reference's end.  keep='best': every output ends with the better of its fits, what that
+    bookkeeping sets out to do (an extension; not the reference's behaviour)."""
     from .models.smgpr import SMGPR
     from . import _lib
     _check_keep(keep)
@@ -245,7 +246,7 @@ def smgpr_objective(smgpr, u, noise_trainable=True):
     return nlml, np.concatenate([g_ls.ravel(), g_var, g_nz, gz.ravel()])
 
 
-def optimize_smgpr(smgpr, restarts=1, maxiter=None, keep="best"):
+def optimize_smgpr(smgpr, restarts=1, maxiter=None, keep="last"):
     """MGPR.optimize applied to GPRFITC models (mgpr.py:47-75 with smgpr.py:16-22): every output's kernel
     hyper-parameters, noise variance and OWN inducing inputs by L-BFGS-B on the device objective (pilco_gp_fitc_nlml);
     the outputs are independent problems: one L-BFGS-B run each as in the reference, evaluated in lockstep

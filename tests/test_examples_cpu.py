@@ -85,3 +85,48 @@ def test_the_standin_itself_answers_like_the_executed_reference(standin):
     np.testing.assert_allclose(float(np.ravel(R)[0]), g["R_traj"][H], rtol=1e-8)
     M1, S1 = p.propagate(g["m"], g["s"])
     np.testing.assert_allclose(np.ravel(M1), g["M_traj"][:, 1], rtol=1e-8)
+
+
+def test_one_learning_iteration_ends_where_the_executed_reference_ends(standin):
+    """Drop-in equivalence of the optimisation loop's host side, end to end: the same seeded script -- PILCO((X, Y)),
+    optimize_models(restarts=1), optimize_policy(maxiter=8, restarts=2), new data, optimize_models again -- run once on the
+    reference's own source (executed on the shim) and once on the product's Python layer (device calls answered by the
+    stand-in) must end with the same hyper-parameters, the same controller and the same predicted reward: constructor
+    draws, restart draws and their order, which fit / controller is kept, transforms, priors, optimiser options all match."""
+    from oracle import ref_exec
+    if not ref_exec.available():
+        pytest.skip("/root/reference is not present on this box")
+    from pilco_amd.models import PILCO
+    R = ref_exec.load()
+    n_ = ref_exec.to_np
+    rs = np.random.RandomState(3)
+    X = rs.randn(40, 3)
+    f = lambda Z: np.stack([0.3 * np.sin(Z[:, 0]) + 0.2 * Z[:, 2], 0.25 * np.cos(Z[:, 1]) * Z[:, 0]], 1)
+    Y = f(X) + 0.02 * rs.randn(40, 2)
+    X2 = rs.randn(10, 3)
+    Y2 = f(X2) + 0.02 * rs.randn(10, 2)
+
+    def script(P, to_np):
+        np.random.seed(7)
+        p = P((X, Y), horizon=5)
+        p.optimize_models(restarts=1)
+        p.optimize_policy(maxiter=8, restarts=2)
+        out = dict(ls1=np.stack([to_np(m.kernel.lengthscales) for m in p.mgpr.models]),
+                   nz1=np.array([float(to_np(m.likelihood.variance)) for m in p.mgpr.models]),
+                   W=to_np(p.controller.W), b=to_np(p.controller.b), r=float(np.ravel(to_np(p.compute_reward()))[0]))
+        p.mgpr.set_data((np.vstack([X, X2]), np.vstack([Y, Y2])))
+        p.optimize_models(restarts=1)
+        out.update(ls2=np.stack([to_np(m.kernel.lengthscales) for m in p.mgpr.models]),
+                   var2=np.array([float(to_np(m.kernel.variance)) for m in p.mgpr.models]),
+                   r2=float(np.ravel(to_np(p.compute_reward()))[0]), tail=np.random.normal())
+        return out
+
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = script(R.PILCO, n_)
+        ours = script(lambda data, **kw: PILCO(data, **kw), lambda v: np.asarray(v.numpy() if hasattr(v, "numpy") else v))
+    assert ours["tail"] == ref["tail"]                      # the same number of draws consumed from NumPy's global generator
+    for k, tol in (("ls1", 1e-3), ("nz1", 1e-3), ("W", 1e-3), ("b", 1e-3), ("ls2", 1e-3), ("var2", 1e-3)):
+        np.testing.assert_allclose(ours[k], ref[k], rtol=tol, atol=1e-6, err_msg=k)
+    np.testing.assert_allclose([ours["r"], ours["r2"]], [ref["r"], ref["r2"]], rtol=1e-6)
