@@ -87,7 +87,8 @@ def test_the_standin_itself_answers_like_the_executed_reference(standin):
     np.testing.assert_allclose(np.ravel(M1), g["M_traj"][:, 1], rtol=1e-8)
 
 
-def test_one_learning_iteration_ends_where_the_executed_reference_ends(standin):
+@pytest.mark.parametrize("policy", ["linear", "rbf"])
+def test_one_learning_iteration_ends_where_the_executed_reference_ends(standin, policy):
     """Drop-in equivalence of the optimisation loop's host side, end to end: the same seeded script -- PILCO((X, Y)),
     optimize_models(restarts=1), optimize_policy(maxiter=8, restarts=2), new data, optimize_models again -- run once on the
     reference's own source (executed on the shim) and once on the product's Python layer (device calls answered by the
@@ -106,14 +107,23 @@ def test_one_learning_iteration_ends_where_the_executed_reference_ends(standin):
     X2 = rs.randn(10, 3)
     Y2 = f(X2) + 0.02 * rs.randn(10, 2)
 
-    def script(P, to_np):
+    def script(P, Rbf, to_np):
         np.random.seed(7)
-        p = P((X, Y), horizon=5)
+        if policy == "linear":
+            p = P((X, Y), horizon=5)                      # default LinearController with random weights (pilco.py:30-33)
+        else:
+            p = P((X, Y), horizon=5, controller=Rbf(2, 1, 5, max_action=1.5))
         p.optimize_models(restarts=1)
         p.optimize_policy(maxiter=8, restarts=2)
+        if policy == "linear":
+            W, b = to_np(p.controller.W), to_np(p.controller.b)
+        else:                                             # centres / targets / lengthscales of the policy GP
+            m0 = p.controller.models[0]
+            W = to_np(m0.X) if hasattr(m0, "X") else np.asarray(p.controller.X)
+            b = np.concatenate([np.ravel(to_np(m0.Y) if hasattr(m0, "Y") else p.controller.Y), np.ravel(to_np(m0.kernel.lengthscales))])
         out = dict(ls1=np.stack([to_np(m.kernel.lengthscales) for m in p.mgpr.models]),
                    nz1=np.array([float(to_np(m.likelihood.variance)) for m in p.mgpr.models]),
-                   W=to_np(p.controller.W), b=to_np(p.controller.b), r=float(np.ravel(to_np(p.compute_reward()))[0]))
+                   W=W, b=b, r=float(np.ravel(to_np(p.compute_reward()))[0]))
         p.mgpr.set_data((np.vstack([X, X2]), np.vstack([Y, Y2])))
         p.optimize_models(restarts=1)
         out.update(ls2=np.stack([to_np(m.kernel.lengthscales) for m in p.mgpr.models]),
@@ -124,9 +134,51 @@ def test_one_learning_iteration_ends_where_the_executed_reference_ends(standin):
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
-        ref = script(R.PILCO, n_)
-        ours = script(lambda data, **kw: PILCO(data, **kw), lambda v: np.asarray(v.numpy() if hasattr(v, "numpy") else v))
+        ref = script(R.PILCO, R.controllers.RbfController, n_)
+        from pilco_amd.controllers import RbfController
+        ours = script(PILCO, RbfController, lambda v: np.asarray(v.numpy() if hasattr(v, "numpy") else v))
     assert ours["tail"] == ref["tail"]                      # the same number of draws consumed from NumPy's global generator
     for k, tol in (("ls1", 1e-3), ("nz1", 1e-3), ("W", 1e-3), ("b", 1e-3), ("ls2", 1e-3), ("var2", 1e-3)):
         np.testing.assert_allclose(ours[k], ref[k], rtol=tol, atol=1e-6, err_msg=k)
     np.testing.assert_allclose([ours["r"], ours["r2"]], [ref["r"], ref["r2"]], rtol=1e-6)
+
+
+def test_one_safe_pilco_iteration_ends_where_the_executed_extension_ends(standin):
+    """The same for SafePILCO (safe_pilco_extension/safe_pilco.py): optimize_models, then optimize_policy on the TOTAL
+    objective (additive reward + mu (1 - prod (1 - risk_t))) -- TF reverse mode through predict() in the reference, cotangent
+    seeds into the reverse sweep in the product -- must end at the same controller and the same total reward."""
+    import contextlib
+    import io
+    from oracle import ref_exec
+    if not ref_exec.available():
+        pytest.skip("/root/reference is not present on this box")
+    from pilco_amd.rewards import ExponentialReward
+    from pilco_amd.safe import SafePILCO, SingleConstraint
+    Rs = ref_exec.load(safe=True)
+    n_ = ref_exec.to_np
+    rs = np.random.RandomState(4)
+    X = rs.randn(36, 3)
+    Y = np.stack([0.3 * np.sin(X[:, 0]) + 0.2 * X[:, 2], 0.25 * np.cos(X[:, 1]) * X[:, 0]], 1) + 0.02 * rs.randn(36, 2)
+    m0, S0 = np.array([[0.3, -0.1]]), 0.05 * np.eye(2)
+
+    def script(make, to_np):
+        np.random.seed(11)
+        p = make()
+        p.optimize_models(restarts=1)
+        r0 = float(np.ravel(to_np(p.compute_reward()))[0])
+        p.optimize_policy(maxiter=6, restarts=1)
+        return dict(W=to_np(p.controller.W), b=to_np(p.controller.b), r0=r0, r=float(np.ravel(to_np(p.compute_reward()))[0]),
+                    tail=np.random.normal())
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = script(lambda: Rs.safe_pilco.SafePILCO((X, Y), horizon=4, reward_add=Rs.rewards.ExponentialReward(2),
+                                                     reward_mult=Rs.rewards_safe.SingleConstraint(0, high=0.8, inside=False),
+                                                     mu=-2.0, m_init=m0, S_init=S0), n_)
+        ours = script(lambda: SafePILCO((X, Y), horizon=4, reward_add=ExponentialReward(2),
+                                        reward_mult=SingleConstraint(0, high=0.8, inside=False), mu=-2.0, m_init=m0, S_init=S0),
+                      lambda v: np.asarray(v.numpy() if hasattr(v, "numpy") else v))
+    assert ours["tail"] == ref["tail"]
+    np.testing.assert_allclose([ours["r0"], ours["r"]], [ref["r0"], ref["r"]], rtol=1e-6)
+    assert ref["r"] > ref["r0"]
+    np.testing.assert_allclose(ours["W"], ref["W"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(ours["b"], ref["b"], rtol=1e-3, atol=1e-6)
