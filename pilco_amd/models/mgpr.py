@@ -13,7 +13,7 @@ from __future__ import annotations
 import numpy as np
 
 from .. import _lib
-from ..params import GPModelView, parameters_of
+from ..params import GPModelView, parameters_of, tensor_value
 
 
 def randomize(model, mean=1, sigma=0.01):
@@ -147,23 +147,23 @@ class MGPR:
     # -- reference: mgpr.py:159-190
     @property
     def Y(self):
-        return self._Y
+        return tensor_value(self._Y)
 
     @property
     def X(self):
-        return self._X
+        return tensor_value(self._X)
 
     @property
     def lengthscales(self):
-        return np.stack([np.asarray(m.kernel.lengthscales.numpy(), np.float64).reshape(-1) for m in self.models])
+        return tensor_value(np.stack([np.asarray(m.kernel.lengthscales.numpy(), np.float64).reshape(-1) for m in self.models]))
 
     @property
     def variance(self):
-        return np.array([float(m.kernel.variance.numpy()) for m in self.models])
+        return tensor_value(np.array([float(m.kernel.variance.numpy()) for m in self.models]))
 
     @property
     def noise(self):
-        return np.array([float(m.likelihood.variance.numpy()) for m in self.models])
+        return tensor_value(np.array([float(m.likelihood.variance.numpy()) for m in self.models]))
 
     @property
     def data(self):

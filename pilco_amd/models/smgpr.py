@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from ..params import Parameter
+from ..params import Parameter, tensor_value
 from .mgpr import MGPR
 
 
@@ -60,4 +60,4 @@ class SMGPR(MGPR):
 
     @property
     def Z(self):
-        return np.asarray(self.models[0].inducing_variable.Z.numpy(), np.float64)
+        return tensor_value(self.models[0].inducing_variable.Z.numpy())

@@ -8,6 +8,18 @@ from __future__ import annotations
 import numpy as np
 
 
+class TensorValue(np.ndarray):
+    """What the reference's read-only properties return is a TensorFlow tensor (mgpr.py:159-190, smgpr.py:50-52): callers
+    use it as an array or call .numpy() on it (tests/test_sparse_predictions.py:47).  An ndarray that also answers .numpy()."""
+
+    def numpy(self):
+        return np.asarray(self)
+
+
+def tensor_value(a):
+    return np.asarray(a, np.float64).view(TensorValue)
+
+
 class Parameter:
     def __init__(self, value, trainable=True, name=None, lower=None, on_change=None):
         self._v = np.array(value, dtype=np.float64)
