@@ -32,6 +32,13 @@ class Parameter:
     def numpy(self):
         return self._v.copy() if self._v.ndim else float(self._v)
 
+    def value(self):
+        """gpflow.Parameter.value() / read_value(): the constrained value as a tensor (examples/safe_swimmer_run.py:115
+        multiplies it: `R.coefs.assign(R.coefs.value() * [...])`)."""
+        return tensor_value(self._v.copy())
+
+    read_value = value
+
     def assign(self, value):
         value = value.numpy() if isinstance(value, Parameter) else value
         v = np.asarray(value, dtype=np.float64)

@@ -57,3 +57,14 @@ def test_trajectory_objective_value_and_seeds():
         tp[t, k] += h
         tm[t, k] -= h
         assert abs((value(tp) - value(tm)) / (2 * h) - seeds[t, k]) < 1e-6
+
+
+def test_parameter_value_and_coefficient_updates_as_the_reference_examples_write_them():
+    """examples/safe_swimmer_run.py:115-127: `R.coefs.assign(R.coefs.value() * [...])` on a CombinedRewards; the new
+    coefficients must reach the reward terms handed to the device."""
+    import numpy as np
+    from pilco_amd.rewards import CombinedRewards, ExponentialReward, LinearReward
+    R = CombinedRewards(2, [ExponentialReward(2), LinearReward(2, np.array([1.0, 0.0]))], coefs=[1.0, -10.0])
+    R.coefs.assign(R.coefs.value() * [1.0, 0.75])
+    assert np.array_equal(R.coefs.numpy(), [1.0, -7.5]) and np.array_equal(R.coefs.read_value().numpy(), [1.0, -7.5])
+    assert [t["coef"] for t in R.terms()] == [1.0, -7.5]
