@@ -7,6 +7,7 @@ is no CPU fallback -- compute calls raise if the library or a GPU is missing.
 """
 from . import controllers, models, rewards  # noqa: F401
 from ._lib import Context, NotPositiveDefiniteError, PilcoError, get_context, set_context  # noqa: F401
+from .params import Parameter, set_trainable  # noqa: F401  (what the reference's scripts take from gpflow)
 
 __all__ = ["models", "controllers", "rewards", "Context", "get_context", "set_context", "PilcoError",
-           "NotPositiveDefiniteError"]
+           "NotPositiveDefiniteError", "Parameter", "set_trainable"]
