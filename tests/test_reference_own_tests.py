@@ -42,3 +42,16 @@ def test_reference_test_file_passes_on_the_product_python_layer(standin_runs, na
     out, _ = standin_runs[name].communicate(timeout=900)
     assert standin_runs[name].returncode == 0, out[-3000:]
     assert out.count("PASSED " + name) == EXPECTED.get(name, 1), out[-1500:]
+
+
+@pytest.mark.skipif(os.environ.get("PILCO_SLOW_TESTS") != "1" or not os.path.isdir(REF_TESTS),
+                    reason="opt-in (PILCO_SLOW_TESTS=1, ~3.5 min) and needs the reference tree")
+def test_reference_inverted_pendulum_example_runs_unmodified_and_balances_the_pole():
+    """/root/reference/examples/inverted_pendulum.py as it is -- random rollouts, RbfController(bf=10), PILCO(horizon=40),
+    3 x [optimize_models, optimize_policy, 100-step rollout, set_data] -- against pilco_amd (gym answered by the built-in
+    plant): the learned policy keeps the pole up for all 100 steps of the last rollout."""
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "helpers", "run_reference_example.py"), "inverted_pendulum.py", "--standin"]
+    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    res = dict(kv.split("=") for kv in [l for l in pr.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:])
+    assert float(res["last_rollout_return"]) == 100.0 and int(res["N"]) > 300
