@@ -55,3 +55,21 @@ def test_reference_inverted_pendulum_example_runs_unmodified_and_balances_the_po
     assert pr.returncode == 0, pr.stderr[-3000:]
     res = dict(kv.split("=") for kv in [l for l in pr.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:])
     assert float(res["last_rollout_return"]) == 100.0 and int(res["N"]) > 300
+
+
+@pytest.mark.skipif(os.environ.get("PILCO_SLOW_TESTS") != "1" or not os.path.isdir(REF_TESTS),
+                    reason="opt-in (PILCO_SLOW_TESTS=1, ~9 min) and needs the reference tree")
+def test_reference_safe_cars_script_runs_unmodified_and_keeps_the_predicted_risk_below_its_threshold():
+    """/root/reference/examples/safe_cars_run.py as it is (its own LinearCars plant, Normalised_Env, SafePILCO with
+    RiskOfCollision, RbfController(bf=40), fixed likelihood noise, 5 iterations with the mu adaptation of lines 128-140)
+    against pilco_amd: every iteration's predicted collision risk stays below the script's threshold 0.10 and mu is relaxed
+    (x 0.75) whenever the risk is below a quarter of it."""
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "helpers", "run_reference_example.py"), "safe_cars_run.py", "--standin"]
+    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=3000, cwd=ROOT)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    res = dict(kv.split("=") for kv in [l for l in pr.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:])
+    risks = [float(v) for v in res["risks"].split(",")]
+    mus = [float(v) for v in res["mus"].split(",")]
+    assert len(risks) == 5 and max(risks) < 0.10 and mus[0] == -300.0
+    for k in range(4):
+        assert abs(mus[k + 1] - (0.75 * mus[k] if risks[k] < 0.025 else mus[k])) <= 0.06 * abs(mus[k])   # printed with 4 digits
