@@ -22,8 +22,8 @@ def rollout_value_and_grad(pilco, seed_fn=None):
     pilco.mgpr._user_factors = None
     pilco.mgpr._ensure_factorized()
     if linear:
-        r, dW, db = pilco.ctx.rollout_grad(pilco._policy_spec(), rew.terms(), pilco.m_init, pilco.S_init, pilco.horizon, seed_fn=seed_fn)
+        r, dW, db = pilco.ctx.rollout_grad(pilco._policy_spec(), pilco._reward_terms(), pilco.m_init, pilco.S_init, pilco.horizon, seed_fn=seed_fn)
         return r, (dW.reshape(ctl.W.shape), db.reshape(ctl.b.shape))
-    r, dX, dY, dl = pilco.ctx.rollout_grad_rbf(pilco._policy_spec(), rew.terms(), pilco.m_init, pilco.S_init, pilco.horizon,
+    r, dX, dY, dl = pilco.ctx.rollout_grad_rbf(pilco._policy_spec(), pilco._reward_terms(), pilco.m_init, pilco.S_init, pilco.horizon,
                                                ctl.X, ctl.Y, ctl.lengthscales, ctl.noise, seed_fn=seed_fn)
     return r, (dX, dY, dl)

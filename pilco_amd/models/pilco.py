@@ -49,6 +49,45 @@ class PILCO:
             return dict(kind=_lib.POLICY_NONE, state_dim=self.state_dim, control_dim=0)
         return self.controller.policy_spec(True)
 
+    # -- reward terms: on the device (exponential / linear) and, for anything else, on the host along the trajectory
+    def _reward_terms(self):
+        terms = self.reward.terms() if hasattr(self.reward, "terms") else []
+        return terms or [dict(kind=_lib.REWARD_LINEAR, coef=0.0, W=np.zeros(self.state_dim))]    # the C ABI wants one term
+
+    def _host_reward_terms(self):
+        r = getattr(self, "reward", None)
+        if r is None:
+            return []
+        if hasattr(r, "terms"):
+            return r.host_terms() if hasattr(r, "host_terms") else []
+        return [(1.0, r)]                       # a reward object of the caller's own: compute_reward(m, s) only
+
+    def _host_reward_value(self, traj, n):
+        """sum over the pre-propagation states t < n of the host reward terms (pilco.py:133 accumulates the same way)."""
+        E, tot = self.state_dim, 0.0
+        for t in range(int(n)):
+            m, s = traj[t, :E].reshape(1, E), traj[t, E:].reshape(E, E)
+            for c, r in self._host_reward_terms():
+                tot += c * float(np.ravel(r.compute_reward(m, s)[0])[0])
+        return tot
+
+    def trajectory_objective(self, traj):
+        """What predict() adds to the device reward as a function of the state trajectory -- the host reward terms -- and
+        its cotangent seeds d / d (m_t, s_t) for the native reverse sweep (pilco_rollout_grad_seeded).  None if a host term
+        has no compute_reward_grad (optimize_policy then differentiates training_loss by finite differences)."""
+        host = self._host_reward_terms()
+        E, H = self.state_dim, traj.shape[0] - 1
+        seeds, value = np.zeros_like(traj), 0.0
+        for c, r in host:
+            if not hasattr(r, "compute_reward_grad"):
+                return None
+            for t in range(H):
+                v, dm, ds = r.compute_reward_grad(traj[t, :E].reshape(1, E), traj[t, E:].reshape(E, E))
+                value += c * float(v)
+                seeds[t, :E] += c * np.ravel(dm)
+                seeds[t, E:] += c * np.ravel(ds)
+        return value, seeds
+
     # pilco.py:47-50
     def training_loss(self):
         return -self.predict(self.m_init, self.S_init, self.horizon)[2]
@@ -76,13 +115,19 @@ class PILCO:
     def predict(self, m_x, s_x, n):
         self.mgpr._user_factors = None
         self.mgpr._ensure_factorized()
-        return self.ctx.rollout(self._policy_spec(), self.reward.terms(), m_x, s_x, int(n))
+        if not self._host_reward_terms():
+            return self.ctx.rollout(self._policy_spec(), self._reward_terms(), m_x, s_x, int(n))
+        M, S, R, _ = self.predict_trajectory(m_x, s_x, n)
+        return M, S, R
 
     def predict_trajectory(self, m_x, s_x, n):
         """Extension: also returns the (n+1, E + E*E) per-step states."""
         self.mgpr._user_factors = None
         self.mgpr._ensure_factorized()
-        return self.ctx.rollout(self._policy_spec(), self.reward.terms(), m_x, s_x, int(n), want_traj=True)
+        M, S, R, traj = self.ctx.rollout(self._policy_spec(), self._reward_terms(), m_x, s_x, int(n), want_traj=True)
+        if self._host_reward_terms():
+            R = R + self._host_reward_value(traj, n)
+        return M, S, R, traj
 
     # pilco.py:138-153
     def propagate(self, m_x, s_x):

@@ -20,6 +20,11 @@ class _Reward:
     def terms(self):
         raise NotImplementedError
 
+    def host_terms(self):
+        """(coefficient, reward object) pairs that are evaluated on the HOST along the trajectory (models/pilco.py): base
+        rewards that are not device reward terms.  None for the built-in rewards."""
+        return []
+
     def compute_reward(self, m, s):
         return self.ctx.reward_eval(self.terms(), self.state_dim, m, s)
 
@@ -58,10 +63,33 @@ class CombinedRewards(_Reward):
         self.coefs = Parameter(np.ones(len(rewards)) if coefs is None else coefs, trainable=False)
 
     def terms(self):
+        """The device reward terms: base rewards of this package (exponential / linear, nested combinations)."""
         out = []
         for r, c in zip(self.base_rewards, np.asarray(self.coefs.numpy()).reshape(-1)):
+            if not hasattr(r, "terms"):
+                continue
             for t in r.terms():
                 t = dict(t)
                 t["coef"] = float(c) * t.get("coef", 1.0)
                 out.append(t)
         return out
+
+    def host_terms(self):
+        """Base rewards that only offer compute_reward(m, s) -- e.g. the Safe-PILCO constraints the reference's
+        examples/safe_swimmer_run.py:59-64 puts into a CombinedRewards: evaluated on the host on the rollout's states."""
+        out = []
+        for r, c in zip(self.base_rewards, np.asarray(self.coefs.numpy()).reshape(-1)):
+            if hasattr(r, "terms"):
+                out += [(float(c) * ck, rk) for ck, rk in r.host_terms()]
+            else:
+                out.append((float(c), r))
+        return out
+
+    def compute_reward(self, m, s):
+        terms, host = self.terms(), self.host_terms()
+        mu, var = self.ctx.reward_eval(terms, self.state_dim, m, s) if terms else (np.zeros((1, 1)), np.zeros((1, 1)))
+        for c, r in host:                      # rewards.py:73-81: mean sum c_k mu_k, variance sum c_k^2 var_k
+            mk, vk = r.compute_reward(np.asarray(m, np.float64).reshape(1, -1), np.asarray(s, np.float64))
+            mu = mu + c * float(np.ravel(mk)[0])
+            var = var + c * c * float(np.ravel(vk)[0])
+        return mu, var

@@ -138,4 +138,7 @@ class SafePILCO(PILCO):
             w = mu * np.prod(np.delete(one, t))               # d [mu (1 - prod)] / d risk_t
             seeds[t, :E] = w * grads[t][0]
             seeds[t, E:] = (w * grads[t][1]).ravel()
-        return mu * (1.0 - np.prod(one)), seeds
+        base = PILCO.trajectory_objective(self, traj)         # host-evaluated terms of the additive reward, if any
+        if base is None:
+            return None
+        return base[0] + mu * (1.0 - np.prod(one)), base[1] + seeds

@@ -334,9 +334,13 @@ def policy_loss_and_grad(pilco, u, put, eps=1e-6):
     plain = type(pilco).predict is PILCO.predict
     # ... unless it says what predict() adds to the additive reward as a function of the state trajectory
     # (trajectory_objective -> value, cotangent seeds): the native sweep takes the seeds (pilco_rollout_grad_seeded)
-    seeded = (not plain) and hasattr(pilco, "trajectory_objective")
+    # ... and so does a plain PILCO whose reward has terms the device does not evaluate (host reward terms, e.g. Safe-PILCO
+    # constraints inside a CombinedRewards: examples/safe_swimmer_run.py:59-64)
+    # (a subclass that overrides predict must bring its OWN trajectory_objective to take this path)
+    own_objective = getattr(type(pilco), "trajectory_objective", None) is not PILCO.trajectory_objective
+    seeded = (plain and bool(pilco._host_reward_terms())) or ((not plain) and own_objective and hasattr(pilco, "trajectory_objective"))
     analytic = ((plain or seeded) and pilco.control_dim > 0 and pilco.state_dim + pilco.control_dim <= 32   # the forward path's limit; the Jacobian tape serves D <= 14, the per-step device adjoint the rest
-                and all(t["kind"] in (_lib.REWARD_EXPONENTIAL, _lib.REWARD_LINEAR) for t in pilco.reward.terms()))
+                and all(t["kind"] in (_lib.REWARD_EXPONENTIAL, _lib.REWARD_LINEAR) for t in pilco._reward_terms()))
     extra = {"v": 0.0, "ok": True}
 
     def seed_fn(traj):

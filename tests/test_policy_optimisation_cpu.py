@@ -132,3 +132,59 @@ def test_safe_pilco_objective_and_its_gradient_reach_the_optimiser_as_in_the_exe
     # the lengthscale entries of the packed gradient are w.r.t. the unconstrained variable: d ls / du = sigmoid(u)
     dls = -grad[nX + nY:] / (1.0 / (1.0 + np.exp(-u[nX + nY:])))
     np.testing.assert_allclose(dls.reshape(g["dtotal_dls"].shape), g["dtotal_dls"], rtol=1e-7)
+
+
+def test_constraints_inside_a_combined_reward_as_the_reference_safe_swimmer_script_uses_them():
+    """examples/safe_swimmer_run.py:59-78 gives a PLAIN PILCO the reward CombinedRewards([LinearReward, SingleConstraint, ...],
+    coefs=[1, -10, ...]): constraint terms the device does not evaluate.  The product evaluates them on the host along the
+    rollout's states and hands their derivatives to the reverse sweep as cotangent seeds; value and policy gradient against
+    the EXECUTED reference (TF reverse mode through the same reward), then one optimize_policy run ending where its ends."""
+    import contextlib
+    import io
+    import torch
+    from oracle import ref_exec
+    import pytest
+    if not ref_exec.available():
+        pytest.skip("/root/reference is not present on this box")
+    from pilco_amd.safe import SingleConstraint
+    from pilco_amd.training import _policy_params, policy_loss_and_grad
+    Rs = ref_exec.load(safe=True)
+    n_ = ref_exec.to_np
+    g = np.load(os.path.join(GOLDEN, "policy_optimisation.npz"))
+    E, H = 2, 5
+    Wl = np.array([[0.4], [-0.3]])
+    ref = Rs.PILCO((g["X"], g["Y"]), horizon=H, m_init=g["m"], S_init=g["s"],
+                   reward=Rs.rewards.CombinedRewards(E, [Rs.rewards.LinearReward(E, Wl), Rs.rewards.ExponentialReward(E),
+                                                          Rs.rewards_safe.SingleConstraint(0, low=-0.5, high=0.9, inside=False),
+                                                          Rs.rewards_safe.SingleConstraint(1, high=0.4)], coefs=[1.0, 0.5, -3.0, 0.7]))
+    for i, mdl in enumerate(ref.mgpr.models):
+        mdl.kernel.lengthscales.assign(g["lengthscales"][i]); mdl.kernel.variance.assign(g["variance"][i]); mdl.likelihood.variance.assign(g["noise"][i])
+    ref.controller.W.assign(g["W"]); ref.controller.b.assign(g["b"]); ref.controller.max_action = g["max_action"]
+    loss = ref.training_loss()
+    gW, gb = torch.autograd.grad(loss.sum(), [ref.controller.W.unconstrained_variable, ref.controller.b.unconstrained_variable])
+
+    from helpers.cpu_standin_context import CpuStandInContext
+    ctx = CpuStandInContext()
+    ctl = LinearController(E, 1, max_action=g["max_action"], ctx=ctx)
+    rew = CombinedRewards(E, [LinearReward(E, Wl), ExponentialReward(E), SingleConstraint(0, low=-0.5, high=0.9, inside=False),
+                              SingleConstraint(1, high=0.4)], coefs=[1.0, 0.5, -3.0, 0.7])
+    rew._ctx = ctx
+    p = PILCO((g["X"], g["Y"]), horizon=H, controller=ctl, reward=rew, m_init=g["m"], S_init=g["s"], ctx=ctx)
+    _hyp(p, g)
+    ctl.W.assign(g["W"]); ctl.b.assign(g["b"])
+    assert len(rew.terms()) == 2 and len(rew.host_terms()) == 2
+    np.testing.assert_allclose(float(p.compute_reward()[0, 0]), -float(n_(loss).ravel()[0]), rtol=1e-9)
+    get, put = _policy_params(ctl)
+    f, grad = policy_loss_and_grad(p, get(), put)
+    np.testing.assert_allclose(f, float(n_(loss).ravel()[0]), rtol=1e-9)
+    np.testing.assert_allclose(grad[:2].reshape(1, 2), gW.numpy(), rtol=1e-7)
+    np.testing.assert_allclose(grad[2:].reshape(1, 1), gb.numpy(), rtol=1e-7)
+    mu_r, var_r = ref.reward.compute_reward(g["m"], g["s"])            # CombinedRewards.compute_reward itself (rewards.py:73-81)
+    mu_o, var_o = rew.compute_reward(g["m"], g["s"])
+    np.testing.assert_allclose(np.ravel(mu_o), np.ravel(n_(mu_r)), rtol=1e-9)
+    np.testing.assert_allclose(np.ravel(var_o), np.ravel(n_(var_r)), rtol=1e-7)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref.optimize_policy(maxiter=6, restarts=1)
+    r = p.optimize_policy(maxiter=6, restarts=1, verbose=False)
+    np.testing.assert_allclose(r, float(n_(ref.compute_reward()).ravel()[0]), rtol=1e-6)
+    np.testing.assert_allclose(ctl.W.numpy(), n_(ref.controller.W), rtol=1e-3, atol=1e-6)
