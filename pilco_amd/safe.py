@@ -97,6 +97,15 @@ class ObjectiveFunction:
         risk, _ = self.risk_f.compute_reward(m, s)
         return reward - self.mu * risk, var
 
+    # as the reward of a PILCO: the reward part on the device where it can be, the risk part (and whatever else the device does
+    # not evaluate) on the host along the trajectory, differentiated through cotangent seeds (models/pilco.py)
+    def terms(self):
+        return self.reward_f.terms() if hasattr(self.reward_f, "terms") else []
+
+    def host_terms(self):
+        base = self.reward_f.host_terms() if hasattr(self.reward_f, "terms") else [(1.0, self.reward_f)]
+        return list(base) + [(-self.mu, self.risk_f)]
+
 
 class SafePILCO(PILCO):
     def __init__(self, data, num_induced_points=None, horizon=30, controller=None, reward_add=None,

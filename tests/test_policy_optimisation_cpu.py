@@ -188,3 +188,32 @@ def test_constraints_inside_a_combined_reward_as_the_reference_safe_swimmer_scri
     r = p.optimize_policy(maxiter=6, restarts=1, verbose=False)
     np.testing.assert_allclose(r, float(n_(ref.compute_reward()).ravel()[0]), rtol=1e-6)
     np.testing.assert_allclose(ctl.W.numpy(), n_(ref.controller.W), rtol=1e-3, atol=1e-6)
+
+
+def test_objective_function_reward_takes_the_analytic_path():
+    """rewards_safe.ObjectiveFunction(reward_f, risk_f, mu) (rewards_safe.py:63-73; the reference's version cannot be
+    constructed: it uses a Parameter it never imports) as the reward of a plain PILCO: reward part on the device, risk part as a
+    host reward term.  Its policy gradient must equal a central difference of training_loss."""
+    from helpers.cpu_standin_context import CpuStandInContext
+    from pilco_amd.safe import ObjectiveFunction, SingleConstraint
+    from pilco_amd.training import _policy_params, policy_loss_and_grad
+    g = np.load(os.path.join(GOLDEN, "policy_optimisation.npz"))
+    ctx = CpuStandInContext()
+    ctl = LinearController(2, 1, max_action=g["max_action"], ctx=ctx)
+    rew = ObjectiveFunction(ExponentialReward(2), SingleConstraint(0, high=0.6), mu=1.7)
+    p = PILCO((g["X"], g["Y"]), horizon=4, controller=ctl, reward=rew, m_init=g["m"], S_init=g["s"], ctx=ctx)
+    _hyp(p, g)
+    ctl.W.assign(g["W"]); ctl.b.assign(g["b"])
+    get, put = _policy_params(ctl)
+    u = get()
+    f, grad = policy_loss_and_grad(p, u, put)
+    assert ctx.grad_calls == 1                              # the analytic (seeded) path, not 2n+1 rollouts
+    for i in range(u.size):
+        h = 1e-4
+        up, um = u.copy(), u.copy()
+        up[i] += h; um[i] -= h
+        put(up); fp = float(p.training_loss()[0, 0])
+        put(um); fm = float(p.training_loss()[0, 0])
+        np.testing.assert_allclose(grad[i], (fp - fm) / (2 * h), rtol=3e-6, atol=1e-9)
+    put(u)
+    np.testing.assert_allclose(f, float(p.training_loss()[0, 0]), rtol=1e-12)
