@@ -418,6 +418,33 @@ def gen_policy_optimisation_rbf(R):
           reward_start=r0, reward_end=r1, X_end=n_(ctl.models[0].X), Y_end=n_(ctl.models[0].Y), ls_end=n_(ctl.models[0].kernel.lengthscales))
 
 
+def gen_host_reward_terms():
+    """A plain PILCO whose reward is CombinedRewards([LinearReward, ExponentialReward, SingleConstraint, SingleConstraint])
+    -- the construction of examples/safe_swimmer_run.py:59-78 (Safe-PILCO constraints used as reward terms): total reward
+    of an H = 5 rollout and its reverse-mode gradient w.r.t. the linear controller through the executed reference, plus
+    CombinedRewards.compute_reward (mean, variance) at the initial state."""
+    import torch
+    Rs = ref_exec.load(safe=True)
+    c = synthetic.config_cascade()
+    E, H = 2, 5
+    Wl = np.array([[0.4], [-0.3]])
+    coefs = [1.0, 0.5, -3.0, 0.7]
+    np.random.seed(3)
+    rew = Rs.rewards.CombinedRewards(E, [Rs.rewards.LinearReward(E, Wl), Rs.rewards.ExponentialReward(E),
+                                         Rs.rewards_safe.SingleConstraint(0, low=-0.5, high=0.9, inside=False),
+                                         Rs.rewards_safe.SingleConstraint(1, high=0.4)], coefs=coefs)
+    p = Rs.PILCO((c["X"], c["Y"]), horizon=H, m_init=c["m"], S_init=c["s"], reward=rew)
+    _set_hyp(p.mgpr.models, c["lengthscales"], c["variance"], c["noise"])
+    p.controller.W.assign(c["W"]); p.controller.b.assign(c["b"]); p.controller.max_action = c["max_action"]
+    loss = p.training_loss()
+    gW, gb = torch.autograd.grad(loss.sum(), [p.controller.W.unconstrained_variable, p.controller.b.unconstrained_variable])
+    mu, var = rew.compute_reward(c["m"], c["s"])
+    _save("host_reward_terms.npz", **{k: c[k] for k in ("X", "Y", "lengthscales", "variance", "noise", "m", "s", "W", "b", "max_action")},
+          H=H, W_lin=Wl, coefs=np.array(coefs), c0_low=-0.5, c0_high=0.9, c1_high=0.4,
+          reward_total=-float(n_(loss).ravel()[0]), dreward_dW=-gW.numpy(), dreward_db=-gb.numpy(),
+          muR=float(n_(mu).ravel()[0]), sR=float(n_(var).ravel()[0]))
+
+
 def gen_policy_optimisation_restarts(R):
     """optimize_policy with random restarts executed (pilco.py:93-110): after the first run, `restarts - 1` times
     controller.randomize() (controllers.py:60-63,123-129, NumPy's global generator, seeded here) + another run; the
@@ -551,6 +578,7 @@ def main():
     gen_sparse_rollout(R)
     gen_policy_optimisation(R)
     gen_policy_optimisation_rbf(R)
+    gen_host_reward_terms()
     gen_policy_optimisation_restarts(R)
     gen_models_optimisation(R)
     gen_sparse_models_optimisation(R)

@@ -1733,3 +1733,34 @@ def test_random_shapes_rollout_and_policy_gradient_vs_oracle(ctx, seed):
     for g, tprm in zip(grads, prm):
         ref = tprm.grad.numpy()
         np.testing.assert_allclose(np.asarray(g).reshape(ref.shape), ref, rtol=1e-5, atol=1e-9 * max(1.0, np.abs(ref).max()), err_msg=what)
+
+
+def test_host_reward_terms_vs_executed_reference(ctx, golden_dir):
+    """A plain PILCO with CombinedRewards([LinearReward, ExponentialReward, SingleConstraint, SingleConstraint]) -- Safe-PILCO
+    constraints used as reward terms, the construction of the reference's examples/safe_swimmer_run.py:59-78 (fixture
+    host_reward_terms.npz, executed reference + reverse mode): the two constraint terms are evaluated on the host on the device
+    rollout's states, their derivatives enter the native reverse sweep as cotangent seeds (pilco_rollout_grad_seeded)."""
+    from pilco_amd.controllers import LinearController
+    from pilco_amd.models import PILCO
+    from pilco_amd.rewards import CombinedRewards, ExponentialReward, LinearReward
+    from pilco_amd.safe import SingleConstraint
+    from pilco_amd.training import _policy_params, policy_loss_and_grad
+    g = np.load(os.path.join(golden_dir, "host_reward_terms.npz"))
+    rew = CombinedRewards(2, [LinearReward(2, g["W_lin"]), ExponentialReward(2),
+                              SingleConstraint(0, low=float(g["c0_low"]), high=float(g["c0_high"]), inside=False),
+                              SingleConstraint(1, high=float(g["c1_high"]))], coefs=list(g["coefs"]))
+    ctl = LinearController(2, 1, max_action=g["max_action"])
+    p = PILCO((g["X"], g["Y"]), horizon=int(g["H"]), controller=ctl, reward=rew, m_init=g["m"], S_init=g["s"])
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(g["lengthscales"][i]); mdl.kernel.variance.assign(g["variance"][i]); mdl.likelihood.variance.assign(g["noise"][i])
+    ctl.W.assign(g["W"]); ctl.b.assign(g["b"])
+    assert len(rew.terms()) == 2 and len(rew.host_terms()) == 2
+    np.testing.assert_allclose(float(p.compute_reward()[0, 0]), float(g["reward_total"]), rtol=RTOL)
+    mu, var = rew.compute_reward(g["m"], g["s"])
+    np.testing.assert_allclose(float(np.ravel(mu)[0]), float(g["muR"]), rtol=RTOL)
+    np.testing.assert_allclose(float(np.ravel(var)[0]), float(g["sR"]), rtol=RTOL)
+    get, put = _policy_params(ctl)
+    f, grad = policy_loss_and_grad(p, get(), put)
+    np.testing.assert_allclose(-f, float(g["reward_total"]), rtol=RTOL)
+    np.testing.assert_allclose(-grad[:2].reshape(1, 2), g["dreward_dW"], rtol=1e-6)
+    np.testing.assert_allclose(-grad[2:].reshape(1, 1), g["dreward_db"], rtol=1e-6)
