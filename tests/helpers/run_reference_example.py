@@ -61,6 +61,38 @@ def main():
         def close(self):
             pass
 
+    class _MountainCar:
+        """gym's MountainCarContinuous-v0 (classic control: a car in a valley, force in [-1, 1], goal at x >= 0.45), restated
+        from its published equations; `.env` is the unwrapped environment the reference's Normalised_Env asks for."""
+
+        def __init__(self):
+            self.rs = np.random.RandomState(0)
+            self.action_space = _Box(-1.0, 1.0, shape=(1,))
+            self.observation_space = _Box(np.array([-1.2, -0.07]), np.array([0.6, 0.07]), shape=(2,))
+            self.env = self
+            self.state = np.array([-0.5, 0.0])
+
+        def reset(self):
+            self.state = np.array([self.rs.uniform(-0.6, -0.4), 0.0])
+            return self.state.copy()
+
+        def step(self, u):
+            x, v = self.state
+            f = float(np.clip(np.ravel(u)[0], -1.0, 1.0))
+            v = float(np.clip(v + f * 0.0015 - 0.0025 * np.cos(3 * x), -0.07, 0.07))
+            x = float(np.clip(x + v, -1.2, 0.6))
+            if x == -1.2 and v < 0:
+                v = 0.0
+            done = bool(x >= 0.45)
+            self.state = np.array([x, v])
+            return self.state.copy(), (100.0 if done else 0.0) - 0.1 * f * f, done, {}
+
+        def render(self):
+            pass
+
+        def close(self):
+            pass
+
     class _Box:      # gym.spaces.Box as linear_cars_env.py:7-9 uses it
         def __init__(self, low, high, shape=None, dtype=None):
             self.low, self.high, self.shape = np.broadcast_to(low, shape).astype(float), np.broadcast_to(high, shape).astype(float), shape
@@ -72,7 +104,7 @@ def main():
         pass
 
     gym = types.ModuleType("gym")
-    gym.make = _Env
+    gym.make = lambda env_id: _MountainCar() if "MountainCar" in env_id else _Env(env_id)
     gym.spaces = types.ModuleType("gym.spaces")
     gym.spaces.Box = _Box
     gym.core = types.ModuleType("gym.core")

@@ -73,3 +73,17 @@ def test_reference_safe_cars_script_runs_unmodified_and_keeps_the_predicted_risk
     assert len(risks) == 5 and max(risks) < 0.10 and mus[0] == -300.0
     for k in range(4):
         assert abs(mus[k + 1] - (0.75 * mus[k] if risks[k] < 0.025 else mus[k])) <= 0.06 * abs(mus[k])   # printed with 4 digits
+
+
+@pytest.mark.skipif(os.environ.get("PILCO_SLOW_TESTS") != "1" or not os.path.isdir(REF_TESTS),
+                    reason="opt-in (PILCO_SLOW_TESTS=1, ~10 min) and needs the reference tree")
+def test_reference_mountain_car_script_runs_unmodified_and_reaches_the_goal():
+    """/root/reference/examples/mountain_car.py as it is (sub-sampled rollouts, utils.Normalised_Env, RbfController(bf=25),
+    a weighted ExponentialReward with a target, fixed likelihood noise, 5 x [optimize_models, optimize_policy(maxiter=100,
+    restarts=3), rollout]) against pilco_amd, gym's MountainCarContinuous-v0 restated from its equations: the last rollout
+    reaches the goal (return = +100 minus the action costs)."""
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "helpers", "run_reference_example.py"), "mountain_car.py", "--standin"]
+    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=3000, cwd=ROOT)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    res = dict(kv.split("=") for kv in [l for l in pr.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:])
+    assert float(res["last_rollout_return"]) > 80.0 and float(res["predicted_reward"]) > 5.0
