@@ -93,6 +93,41 @@ def main():
         def close(self):
             pass
 
+    class _Pendulum:
+        """gym's Pendulum-v0 (classic control: torque-limited pendulum, observation [cos th, sin th, th_dot]) restated from its
+        published equations, with the attributes the reference's myPendulum wrapper reaches into (state, last_u, _get_obs)."""
+        max_speed, max_torque, dt, g, m, l = 8.0, 2.0, 0.05, 10.0, 1.0, 1.0
+
+        def __init__(self):
+            self.action_space = _Box(-self.max_torque, self.max_torque, shape=(1,))
+            self.observation_space = _Box(np.array([-1.0, -1.0, -self.max_speed]), np.array([1.0, 1.0, self.max_speed]), shape=(3,))
+            self.env, self.state, self.last_u = self, np.zeros(2), None
+
+        def _get_obs(self):
+            th, thd = self.state
+            return np.array([np.cos(th), np.sin(th), thd])
+
+        def reset(self):
+            self.state = np.random.uniform(low=-np.array([np.pi, 1.0]), high=np.array([np.pi, 1.0]))
+            self.last_u = None
+            return self._get_obs()
+
+        def step(self, u):
+            th, thd = self.state
+            u = float(np.clip(np.ravel(u)[0], -self.max_torque, self.max_torque))
+            self.last_u = u
+            cost = (((th + np.pi) % (2 * np.pi)) - np.pi) ** 2 + 0.1 * thd ** 2 + 0.001 * u ** 2
+            thd = thd + (-3 * self.g / (2 * self.l) * np.sin(th + np.pi) + 3.0 / (self.m * self.l ** 2) * u) * self.dt
+            th = th + thd * self.dt
+            self.state = np.array([th, float(np.clip(thd, -self.max_speed, self.max_speed))])
+            return self._get_obs(), -cost, False, {}
+
+        def render(self):
+            pass
+
+        def close(self):
+            pass
+
     class _Box:      # gym.spaces.Box as linear_cars_env.py:7-9 uses it
         def __init__(self, low, high, shape=None, dtype=None):
             self.low, self.high, self.shape = np.broadcast_to(low, shape).astype(float), np.broadcast_to(high, shape).astype(float), shape
@@ -104,7 +139,7 @@ def main():
         pass
 
     gym = types.ModuleType("gym")
-    gym.make = lambda env_id: _MountainCar() if "MountainCar" in env_id else _Env(env_id)
+    gym.make = lambda env_id: (_MountainCar() if "MountainCar" in env_id else _Pendulum() if env_id.startswith("Pendulum") else _Env(env_id))
     gym.spaces = types.ModuleType("gym.spaces")
     gym.spaces.Box = _Box
     gym.core = types.ModuleType("gym.core")

@@ -87,3 +87,18 @@ def test_reference_mountain_car_script_runs_unmodified_and_reaches_the_goal():
     assert pr.returncode == 0, pr.stderr[-3000:]
     res = dict(kv.split("=") for kv in [l for l in pr.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:])
     assert float(res["last_rollout_return"]) > 80.0 and float(res["predicted_reward"]) > 5.0
+
+
+@pytest.mark.skipif(os.environ.get("PILCO_SLOW_TESTS") != "1" or not os.path.isdir(REF_TESTS),
+                    reason="opt-in (PILCO_SLOW_TESTS=1, ~22 min) and needs the reference tree")
+def test_reference_pendulum_swing_up_script_runs_unmodified_and_swings_up():
+    """/root/reference/examples/pendulum_swing_up.py as it is (its myPendulum wrapper reaching into the gym environment,
+    sub-sampling, RbfController(bf=30, max_action=2), weighted ExponentialReward with a target, given m_init / S_init, fixed
+    likelihood noise, 8 x [optimize_models(restarts=2), optimize_policy(maxiter=50, restarts=2), rollout]) against pilco_amd,
+    gym's Pendulum-v0 restated from its equations.  Hanging down costs about -10 per simulator step (-1200 per episode); the
+    learned policy's last episode returned -392 and the model predicts a reward of 16 of 40."""
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "helpers", "run_reference_example.py"), "pendulum_swing_up.py", "--standin"]
+    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=5400, cwd=ROOT)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    res = dict(kv.split("=") for kv in [l for l in pr.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:])
+    assert int(res["N"]) == 480 and float(res["last_rollout_return"]) > -600.0 and float(res["predicted_reward"]) > 10.0
