@@ -34,6 +34,48 @@ class CpuRolloutContext:
         self.slots.setdefault(slot, {})["Z"] = None if Z is None else np.array(Z, np.float64)
 
     def gp_factorize(self, slot):
+        self.slots.setdefault(slot, {}).pop("user", None)      # a factorisation of the model's own replaces caller-supplied factors
+
+    def gp_set_factors(self, slot, iK, beta, owner=None):
+        self._slot_owner[slot] = owner
+        n = np.asarray(beta).shape[1]
+        self.slots.setdefault(slot, {})["user"] = (np.zeros((np.asarray(beta).shape[0], n, n)) if iK is None else np.array(iK, np.float64),
+                                                   np.array(beta, np.float64))
+
+    def _factors(self, slot):
+        """(inputs, iK, beta) of the model in `slot` as NumPy arrays: caller-supplied, FITC or exact."""
+        from oracle import tf_path as tp
+        s = self.slots[slot]
+        pts = s["Z"] if s.get("Z") is not None else s["X"]
+        if "user" in s:
+            return pts, s["user"][0], s["user"][1]
+        if s.get("Z") is not None:
+            return (pts,) + tuple(tp.fitc_factorizations(s["X"], s["Y"], s["Z"], s["ls"], s["var"], s["nz"]))
+        return (pts,) + tuple(tp.calculate_factorizations(s["X"], s["Y"], s["ls"], s["var"], s["nz"]))
+
+    def gp_get_factors(self, slot, E, want_iK=True):
+        _, iK, beta = self._factors(slot)
+        return (iK if want_iK else None), beta
+
+    def gp_num_points(self, slot):
+        return self._factors(slot)[0].shape[0]
+
+    def gp_gram(self, slot, X1, X2, E):
+        from oracle import tf_path as tp
+        s = self.slots[slot]
+        return tp.se_ard_K(np.asarray(X1, np.float64), None if X2 is None else np.asarray(X2, np.float64), s["ls"], s["var"])
+
+    # launch-structure switches of the device path: nothing to switch here
+    def set_pair_kernel(self, variant):
+        pass
+
+    def set_fused_step(self, on):
+        pass
+
+    def use_graph(self, on):
+        pass
+
+    def selftest(self):
         pass
 
     def set_grad_mode(self, mode):
@@ -42,17 +84,20 @@ class CpuRolloutContext:
     # -- the rollout in torch
     def _dynamics(self):
         s = self.slots[_lib.SLOT_DYNAMICS]
-        if s.get("Z") is not None:      # sparse model: FITC factors over the inducing inputs (smgpr.py:24-52)
-            from oracle import tf_path as tp
-            iK, beta = tp.fitc_factorizations(s["X"], s["Y"], s["Z"], s["ls"], s["var"], s["nz"])
-            Z, ls, var, iK, beta = T(s["Z"]), T(s["ls"]), T(s["var"]), T(iK), T(beta)
-            return lambda m, sx: tq.predict_given_factorizations(Z, ls, var, m, sx, iK, beta)
+        if s.get("Z") is not None or "user" in s:      # sparse model (FITC factors over the inducing inputs, smgpr.py:24-52) / caller's factors
+            pts, iK, beta = self._factors(_lib.SLOT_DYNAMICS)
+            P, ls, var, iK, beta = T(pts), T(s["ls"]), T(s["var"]), T(iK), T(beta)
+            return lambda m, sx: tq.predict_given_factorizations(P, ls, var, m, sx, iK, beta)
         X, ls, var = T(s["X"]), T(s["ls"]), T(s["var"])
         N, E = s["Y"].shape
         iK, beta = [], []
         for a in range(E):
             K = var[a] * torch.exp(-0.5 * torch.sum(((X[:, None, :] - X[None, :, :]) / ls[a]) ** 2, -1)) + s["nz"][a] * torch.eye(N, dtype=tq.DT)
-            Ki = torch.linalg.inv(K)
+            try:
+                torch.linalg.cholesky(K)
+                Ki = torch.linalg.inv(K)
+            except torch.linalg.LinAlgError as exc:      # the device reports PILCO_E_NOT_PD
+                raise _lib.NotPositiveDefiniteError(5, str(exc))
             iK.append(Ki)
             beta.append(Ki @ T(s["Y"][:, a]))
         iK, beta = torch.stack(iK), torch.stack(beta)
@@ -75,13 +120,15 @@ class CpuRolloutContext:
     def _value(self, policy, rewards, m0, S0, H, params, seeds=None, traj=None):
         """(m_H, s_H, additive reward [+ sum_t <seeds_t, state_t> when seeds are given]); traj (list) collects the states."""
         E = policy["state_dim"]
-        e = T(np.broadcast_to(np.asarray(policy["max_action"], np.float64).reshape(-1), (policy["control_dim"],)).copy())
+        e = T(np.broadcast_to(np.asarray(policy.get("max_action", 1.0), np.float64).reshape(-1), (policy["control_dim"],)).copy())
         if policy["kind"] == _lib.POLICY_LINEAR:
             W, b = params
             ctl = lambda m, s: tq.linear_controller(m, s, W, b, e, policy.get("squash", True))
         elif policy["kind"] == _lib.POLICY_RBF:
             Xp, Yp, lsp, nzp = params
             ctl = lambda m, s: tq.rbf_controller(m, s, Xp, Yp, lsp, nzp, e, policy.get("squash", True))
+        elif policy["kind"] == _lib.POLICY_NONE:      # autonomous system: no control inputs
+            ctl = lambda m, s: (torch.zeros((1, 0), dtype=tq.DT), torch.zeros((0, 0), dtype=tq.DT), torch.zeros((E, 0), dtype=tq.DT))
         else:
             raise NotImplementedError(policy["kind"])
         gp, reward = self._dynamics(), self._reward(rewards, E)
@@ -99,6 +146,8 @@ class CpuRolloutContext:
         return m, s, total
 
     def _params(self, policy):
+        if policy["kind"] == _lib.POLICY_NONE:
+            return []
         if policy["kind"] == _lib.POLICY_LINEAR:
             return [T(policy["W"]), T(policy["b"])]
         p = self.slots[_lib.SLOT_POLICY]

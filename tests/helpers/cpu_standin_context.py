@@ -35,7 +35,10 @@ class CpuStandInContext(CpuRolloutContext):
 
     def _controller(self, policy):
         params = self._params(policy)
-        e = T(np.broadcast_to(np.asarray(policy["max_action"], np.float64).reshape(-1), (policy["control_dim"],)).copy())
+        E = policy["state_dim"]
+        if policy["kind"] == _lib.POLICY_NONE:
+            return lambda m, s: (torch.zeros((1, 0), dtype=tq.DT), torch.zeros((0, 0), dtype=tq.DT), torch.zeros((E, 0), dtype=tq.DT))
+        e = T(np.broadcast_to(np.asarray(policy.get("max_action", 1.0), np.float64).reshape(-1), (policy["control_dim"],)).copy())
         if policy["kind"] == _lib.POLICY_LINEAR:
             return lambda m, s: tq.linear_controller(m, s, params[0], params[1], e, policy.get("squash", True))
         return lambda m, s: tq.rbf_controller(m, s, params[0], params[1], params[2], params[3], e, policy.get("squash", True))
