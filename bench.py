@@ -42,10 +42,12 @@ def algorithmic_work(n, d, e):
     return exps, flop, byts
 
 
-def cpu_baseline(cfg, steps=5):
-    """Time the NumPy restatement of the GPflow CPU path (oracle/tf_path.py) on a bounded sample of the SAME
-    workload: one factorisation, then the first `steps` horizon steps of the benchmarked rollout executed for real
-    (reward, propagate, state carried over)."""
+def cpu_baseline(cfg, budget_s=150.0):
+    """Time the NumPy restatement of the GPflow CPU path (oracle/tf_path.py) on the SAME workload: one factorisation,
+    then the benchmarked H = 40 rollout executed for real (reward, propagate, state carried over) with the
+    factorisation cached -- the whole rollout unless `budget_s` runs out first (then: the steps done, extrapolated, and
+    said so).  Beside it ONE step exactly as the reference evaluates it (mgpr.py:77-79,120-147: re-factorise, all E^2
+    output pairs, the (E,E,N,N) tensors materialised), timed, as the reference-faithful variant."""
     from oracle import tf_path as tp
     model = tp.Model(cfg["X"], cfg["Y"], cfg["lengthscales"], cfg["variance"], cfg["noise"], pairs=True)
     t0 = time.perf_counter()
@@ -53,25 +55,90 @@ def cpu_baseline(cfg, steps=5):
     t_fact = time.perf_counter() - t0
     m, s = cfg["m0"], cfg["S0"]
     ts = []
-    for _ in range(steps):
+    t_begin = time.perf_counter()
+    for _ in range(H):
         t0 = time.perf_counter()
         tp.exponential_reward(m, s)
         m, s = tp.propagate(model, tp.no_controller, m, s, cache=True)
         ts.append(time.perf_counter() - t0)
-    t_step = float(np.median(ts))
+        if time.perf_counter() - t_begin > budget_s:
+            break
+    done = len(ts)
+    t_rollout = float(np.sum(ts)) if done == H else float(np.median(ts)) * H
+    faithful = None
+    try:   # the reference's own evaluation order for one step: factorisation + E^2 pairs (several GB of temporaries)
+        ref_model = tp.Model(cfg["X"], cfg["Y"], cfg["lengthscales"], cfg["variance"], cfg["noise"], pairs=False)
+        t0 = time.perf_counter()
+        tp.exponential_reward(cfg["m0"], cfg["S0"])
+        tp.propagate(ref_model, tp.no_controller, cfg["m0"], cfg["S0"], cache=False)
+        faithful = time.perf_counter() - t0
+    except Exception as exc:   # (memory): the symmetric-pair number stands on its own
+        faithful = repr(exc)
     threads = None
     try:
         from threadpoolctl import threadpool_info
         threads = max((p.get("num_threads", 0) for p in threadpool_info()), default=None)
     except Exception:
         pass
-    return dict(value=1.0 / (H * t_step), unit="rollouts/s", cores=threads or os.cpu_count(), kind="port",
-                host_cpu_count=os.cpu_count(),
-                sample=("NumPy+OpenBLAS restatement of the GPflow path (oracle/tf_path.py, 55 symmetric pairs), fp64: "
-                        "1 factorisation (%.2f s) + the first %d horizon steps of the benchmarked rollout executed for real "
-                        "(median %.3f s per step); value = 1/(40 * t_step) with the factorisation cached; re-factorising "
-                        "every step as the reference does (mgpr.py:77-79) gives %.4f rollouts/s"
-                        % (t_fact, steps, t_step, 1.0 / (H * (t_step + t_fact)))))
+    out = dict(value=1.0 / t_rollout, unit="rollouts/s", cores=threads or os.cpu_count(), kind="port",
+               host_cpu_count=os.cpu_count(), rollout_s=t_rollout, steps_executed=done, factorisation_s=t_fact,
+               sample=("NumPy+OpenBLAS restatement of the GPflow path (oracle/tf_path.py, 55 symmetric pairs), fp64: 1 factorisation "
+                       "(%.2f s, cached) + %s" % (t_fact, ("the full H = 40 benchmarked rollout executed for real: %.1f s" % t_rollout) if done == H else
+                                                  ("%d of 40 steps executed for real within the %.0f s budget (median %.3f s per step), "
+                                                   "extrapolated to 40" % (done, budget_s, float(np.median(ts)))))))
+    if isinstance(faithful, float):
+        out["reference_faithful_step_s"] = faithful
+        out["reference_faithful_rollouts_per_s"] = 1.0 / (H * faithful)
+        out["reference_faithful_note"] = ("ONE step as the reference evaluates it (mgpr.py:77-79: re-factorisation every step, all E^2 = 100 output "
+                                          "pairs, (E,E,N,N) tensors materialised), timed; rollouts/s = 1 / (40 x that step)")
+    else:
+        out["reference_faithful_step_s"] = None
+        out["reference_faithful_note"] = "not measured: %s" % faithful
+    return out
+
+
+def _sha16(path):
+    import hashlib
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def newest_profile(suffix):
+    """profiles/rNN<suffix> of the highest round that exists (committed rocprofv3 evidence)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]" + suffix)):
+        m = re.match(r"r(\d\d)", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
+def rocprof_avg_us(kernel_substr, suffix="_kernel_stats.csv"):
+    """(average launch duration in us, calls, file) of the first kernel whose name contains `kernel_substr` in the newest
+    committed rocprofv3 --kernel-trace --stats summary."""
+    import csv
+    f = newest_profile(suffix)
+    if not f:
+        return None, None, None
+    try:
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Name"]:
+                return float(r["AverageNs"]) / 1e3, int(r["Calls"]), "profiles/" + os.path.basename(f)
+    except Exception:
+        pass
+    return None, None, "profiles/" + os.path.basename(f)
+
+
+KERNEL_SOURCES = ("pair.hip", "prep.hip", "glue_device.h", "mm_device.h", "rollout.hip", "bwd.hip", "linalg.hip")
+
+
+def kernel_source_hashes():
+    return {n: _sha16(os.path.join(ROOT, "pilco_amd", "csrc", n)) for n in KERNEL_SOURCES}
 
 
 def _median_ms(fn, reps):
@@ -122,6 +189,17 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
     fact_ms = ctx.factorize_timed(0, 5)
     out["factorisation_ms"] = fact_ms
     out["R_fwd_fact_rollouts_per_s"] = 1e3 / (fact_ms + ms_rollout)
+    # FLOP_fact = E (N^2 (3D+3) + N^3/3 + 2 N^3/3 + 2 N^2) (triangular-inverse route), bound: f64 MFMA
+    flop_fact = E * (N * N * (3 * D + 3) + N ** 3 / 3.0 + 2.0 * N ** 3 / 3.0 + 2.0 * N * N)
+    _, flop_step, _ = algorithmic_work(N, D, E)
+    out["R_fwd_fact_roofline"] = {
+        "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
+        "factorisation": {"achieved": flop_fact / (fact_ms * 1e-3) / 1e12, "frac": flop_fact / (fact_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                          "algorithmic_flop": flop_fact, "ms": fact_ms,
+                          "what_bounds_it": "the blocked Cholesky's chain of dependent diagonal-block launches (latency), then the iK GEMM (f64 MFMA)"},
+        "factorise_then_rollout": {"achieved": (flop_fact + H * flop_step) / ((fact_ms + ms_rollout) * 1e-3) / 1e12,
+                                   "frac": (flop_fact + H * flop_step) / ((fact_ms + ms_rollout) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                   "algorithmic_flop": flop_fact + H * flop_step, "ms": fact_ms + ms_rollout}}
     # ---- C2u: value + gradient w.r.t. a linear controller (state 10 + 1 control, D = 11)
     cu = synthetic.config_c2(N=N, D=D + 1, E=E)
     p = PILCO((cu["X"], cu["Y"]), horizon=H, ctx=ctx)
@@ -143,6 +221,26 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
                           "forward pair kernel (one O(N^2) pass per step gives value and Jacobian), the reverse sweep is host algebra")
     out["R_grad_C2u_per_s"] = 1e3 / g_ms
     out["R_fwd_C2u_ms"] = f_ms
+    # roofline of the value-and-gradient rollout's dominant kernel (the reverse sweep k_mm_bwd_pair that stands in for the
+    # forward pair kernel): its launches bracketed by HIP events in a separate, untimed pass
+    try:
+        ctx.set_pair_timing(True)
+        rollout_value_and_grad(p)
+        sw_ms, sw_n = ctx.get_pair_timing()
+    finally:
+        ctx.set_pair_timing(False)
+    if sw_n > 0:
+        Du, Pn = D + 1, E * (E + 1) // 2
+        sw_us = sw_ms * 1e3 / sw_n
+        sw_flop = Pn * N * N * (2 * (Du + 1) + 2 * (Du + 1) + 4)   # exponent contraction + moment contraction + weights / sums
+        rp, rpc, rpf = rocprof_avg_us("k_mm_bwd_pair", "_grad_kernel_stats.csv")
+        out["R_grad_roofline"] = {
+            "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS, "kernel": "k_mm_bwd_pair (reverse sweep: exponent MFMA, fp64 exp, moment MFMA, row / column sums)",
+            "avg_launch_us": sw_us, "launches": sw_n, "achieved": sw_flop / (sw_us * 1e-6) / 1e12,
+            "frac": sw_flop / (sw_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS, "algorithmic_flop_per_launch": sw_flop, "exp_per_launch": Pn * N * N,
+            "rocprofv3_avg_launch_us": rp, "rocprofv3_calls": rpc, "rocprofv3_source": rpf,
+            "rollout_level": {"algorithmic_flop": H * sw_flop, "ms": g_ms, "achieved": H * sw_flop / (g_ms * 1e-3) / 1e12,
+                              "frac": H * sw_flop / (g_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}}
     # ---- config 4: SMGPR (M=200, N=5000, D=10, E=10), FITC factorisation + rollout
     c4 = synthetic.config_c4()
     ctx.gp_set_data(0, c4["X"], c4["Y"])
@@ -154,6 +252,26 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
     r4 = _median_ms(lambda: ctx.rollout(policy, rewards, c4["m0"], c4["S0"], H), 10)
     out["config4_rollout_ms"] = r4
     out["config4_rollouts_per_s"] = 1e3 / r4
+    M4, N4 = c4["Z"].shape[0], c4["X"].shape[0]
+    flop_fitc = 3.0 * E * M4 * M4 * N4   # ~3 E M^2 N (V = L^-1 Kmn, V V^T, the right-hand sides)
+    _, flop_step4, _ = algorithmic_work(M4, D, E)
+    try:
+        ctx.set_pair_timing(True)
+        ctx.rollout(policy, rewards, c4["m0"], c4["S0"], H)
+        p4_ms, p4_n = ctx.get_pair_timing()
+    finally:
+        ctx.set_pair_timing(False)
+    out["config4_roofline"] = {
+        "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
+        "fitc_factorisation": {"achieved": flop_fitc / (out["config4_fitc_factorisation_ms"] * 1e-3) / 1e12,
+                               "frac": flop_fitc / (out["config4_fitc_factorisation_ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                               "algorithmic_flop": flop_fitc, "ms": out["config4_fitc_factorisation_ms"],
+                               "hbm_GBps_Kmn_once": 8.0 * E * M4 * N4 / (out["config4_fitc_factorisation_ms"] * 1e-3) / 1e9},
+        "rollout": {"achieved": H * flop_step4 / (r4 * 1e-3) / 1e12, "frac": H * flop_step4 / (r4 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                    "algorithmic_flop": H * flop_step4, "ms": r4,
+                    "pair_kernel_avg_launch_us": (p4_ms * 1e3 / p4_n) if p4_n else None,
+                    "what_bounds_it": "launch / latency: at M = 200 a step has 55 x 200^2 = 2.2e6 exps (2 us of the fp64 pipe); the step is the "
+                                      "serial head's chain of latencies plus two launch boundaries"}}
     # restore the benchmark model in slot 0
     ctx.gp_set_inducing(0, None)
     ctx.gp_set_data(0, cfg["X"], cfg["Y"])
@@ -375,15 +493,27 @@ def main():
             clock_mhz = None
     # HBM bytes per pair-kernel launch: PMC counters (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes) of the committed
     # rocprofv3 profile of this same command, newest round first; a live run cannot collect counters on itself
-    traffic, traffic_src = None, None
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    traffic, traffic_src, traffic_meta = None, None, {}
+    f_pmc = newest_profile("_pmc_summary.json")
+    if f_pmc:
         try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                traffic = json.load(f)["pair_kernel_hbm_bytes_per_launch"] / world
-            traffic_src = "profiles/" + name
-            break
+            with open(f_pmc) as f:
+                pj = json.load(f)
+            traffic = pj["pair_kernel_hbm_bytes_per_launch"] / world
+            traffic_src = "profiles/" + os.path.basename(f_pmc)
+            now = kernel_source_hashes()
+            then = pj.get("kernel_source_sha16") or {}
+            changed = sorted(k for k in ("pair.hip", "mm_device.h") if then.get(k) != now.get(k))
+            traffic_meta = {"profile_head": pj.get("git_head"), "profile_date": pj.get("date"),
+                            "stale": bool(changed) or not then,
+                            "stale_because": (("kernel sources changed since the profile: " + ", ".join(changed)) if changed and then else
+                                              ("the profile predates source hashes (round <= 2)" if not then else None))}
+            if traffic_meta["stale"]:
+                print("bench.py: WARNING roofline.traffic comes from %s, which is older than the pair kernel's sources (%s): "
+                      "re-run tools/profile_round.sh" % (traffic_src, traffic_meta["stale_because"]), file=sys.stderr)
         except Exception:
-            continue
+            traffic = None
+    rp_us, rp_calls, rp_file = rocprof_avg_us("k_mm_pair_sk")
 
     # N > 1 only: the zero-communication alternative (SURVEY.md 8(e) "Alternative DP"): every rank also runs the whole
     # rollout on its own GPU (an unsharded second context); the aggregate is reported under "secondary", never as `value`.
@@ -441,8 +571,11 @@ def main():
                          "in_kernel_span_us": span_us,
                          "engine_clock_mhz_under_load": clock_mhz, "issue_bound_us_at_that_clock": issue_us,
                          "frac_of_issue_bound": (issue_us / (pair_ms * 1e3)) if (issue_us and pair_ms > 0) else None,
-                         "note": "avg_launch_ms: hipEvent pairs around each launch of an eager replay (includes event latency: an upper bound; rocprofv3 "
-                                 "brackets the same kernel at 46.9 us, profiles/r02_kernel_stats.csv); in_kernel_span_us: first wave in to last wave out by "
+                         "traffic_profile": traffic_meta,
+                         "rocprofv3_avg_launch_us": rp_us, "rocprofv3_calls": rp_calls, "rocprofv3_source": rp_file,
+                         "note": "avg_launch_ms: hipEvent pairs around each launch of an eager replay, measured live in this run (includes event "
+                                 "latency: an upper bound); rocprofv3_avg_launch_us: the same kernel in the committed --kernel-trace --stats summary "
+                                 "named beside it (read from that file, not typed in); in_kernel_span_us: first wave in to last wave out by "
                                  "the kernel's own 100 MHz stamps. frac = SURVEY 8(d) algorithmic FLOP (exp internals excluded) / spec peak at 2.4 GHz; the kernel's own "
                                  "bound is instruction issue: 800 cycles per 512 exps (6 f64 MFMA + 104 VALU ops) at the measured clock",
                          "algorithmic_flop_per_launch": flop_local, "exp_per_launch": exps / world,

@@ -201,6 +201,13 @@ int pilco_rollout_grad_rbf(pilco_ctx* ctx, const pilco_policy* policy, const pil
 int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
                         const double* m0, const double* S0, int H, int reps, double* mH, double* SH, double* reward,
                         float* ms_total, float* ms_pair, int* n_pair_launches);
+/* Measurement aid for ANY rollout entry (pilco_rollout, pilco_rollout_tape, pilco_rollout_grad*): while on, every rollout
+ * is enqueued launch by launch with a HIP-event pair around each launch of the step's O(N^2) kernel (the forward pair
+ * kernel, or the reverse sweep of a value-and-gradient rollout).  pilco_get_pair_timing synchronises the stream and returns
+ * the summed duration and the number of those launches of the LAST rollout.  Perturbs the rollout's total time: never
+ * switched on inside a timed region. */
+int pilco_set_pair_timing(pilco_ctx* ctx, int on);
+int pilco_get_pair_timing(pilco_ctx* ctx, float* ms_pair, int* n_pair_launches);
 /* Developer aid: the first call (out32 may be NULL) switches on phase timestamps inside the
  * prep / glue kernels (100 MHz wall clock); later calls copy the 32 slots of the last launch. */
 int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32);

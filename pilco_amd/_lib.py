@@ -91,6 +91,8 @@ SIGNATURES = {
                                       C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "pilco_factorize_timed": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "pilco_set_pair_timing": (C.c_int, [_vp, C.c_int]),
+    "pilco_get_pair_timing": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "pilco_debug_timestamps": (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
     "pilco_debug_blocks": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.c_int]),
     "pilco_debug_buffer": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_long]),
@@ -188,7 +190,9 @@ class Context:
         if rc != PILCO_OK:
             msg = self.lib.pilco_last_error(self.h).decode("utf-8", "replace")
             if rc == 2:
-                raise NotPositiveDefiniteError(rc, msg)
+                exc = NotPositiveDefiniteError(rc, msg)
+                exc.output = int(self.lib.pilco_last_not_pd_output(self.h))   # which output's Gram matrix failed (-1: unknown)
+                raise exc
             raise PilcoError(rc, msg)
 
     # ---- GP model
@@ -461,6 +465,16 @@ class Context:
         ms = C.c_float()
         self._chk(self.lib.pilco_factorize_timed(self.h, slot, int(reps), C.byref(ms)))
         return ms.value
+
+    def set_pair_timing(self, on=True):
+        self._chk(self.lib.pilco_set_pair_timing(self.h, 1 if on else 0))
+
+    def get_pair_timing(self):
+        """(summed ms, number of launches) of the O(N^2) kernel in the last rollout made while pair timing was on."""
+        ms = C.c_float()
+        n = C.c_int()
+        self._chk(self.lib.pilco_get_pair_timing(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def debug_timestamps(self, read=True):
         buf = (C.c_ulonglong * 64)()

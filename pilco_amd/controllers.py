@@ -61,8 +61,10 @@ class _PolicyData(Parameter):
     trainable ``Parameter``s of the reference's FakeGPR); values live in the policy GP, ``assign`` goes through set_data."""
 
     def __init__(self, gp, which, name):
-        self._gp, self._which = gp, which
+        self._gp = None                      # (the base constructor's `self._v = ...` must not re-seat the GP's data)
+        self._which = which
         Parameter.__init__(self, gp._X if which == 0 else gp._Y, name=name)
+        self._gp = gp
 
     @property
     def _v(self):
@@ -104,6 +106,10 @@ class RbfController:
     def create_models(self, data):
         """One model per control dimension over shared centres: unit kernel variance (fixed), likelihood variance 1e-4
         (fixed), lengthscales one with the lower bound 1e-3 of the reference's transform."""
+        if data is not None and (np.shape(data[0]) != np.shape(self._gp._X) or np.shape(data[1]) != np.shape(self._gp._Y)
+                                 or not (np.array_equal(data[0], self._gp._X) and np.array_equal(data[1], self._gp._Y))):
+            self._gp.set_data(data)                          # the reference builds the models FROM this data (controllers.py:96-106)
+            self.num_basis_functions = self._gp.num_datapoints
         self._gp.create_models(data)
         for model in self._gp.models:
             model.kernel.variance.assign(1.0)               # controllers.py:92-93

@@ -352,6 +352,29 @@ int pilco_set_use_graph(pilco_ctx* ctx, int on) {
     return PILCO_OK;
 }
 
+int pilco_set_pair_timing(pilco_ctx* ctx, int on) {
+    if (!ctx) return PILCO_E_SHAPE;
+    ctx->time_pairs = (on != 0);
+    ctx->timed_pairs = 0;
+    return PILCO_OK;
+}
+
+int pilco_get_pair_timing(pilco_ctx* ctx, float* ms_pair, int* n_pair_launches) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!ms_pair || !n_pair_launches) return fail(ctx, PILCO_E_SHAPE, "get_pair_timing: null pointer");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    float tot = 0.f;
+    for (int t = 0; t < ctx->timed_pairs; ++t) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->pair_events[2 * t], ctx->pair_events[2 * t + 1]));
+        tot += ms;
+    }
+    *ms_pair = tot;
+    *n_pair_launches = ctx->timed_pairs;
+    return PILCO_OK;
+}
+
 int pilco_selftest(pilco_ctx* ctx) {
     if (!ctx) return PILCO_E_SHAPE;
     HIPCHK(hipSetDevice(ctx->device));

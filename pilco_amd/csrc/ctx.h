@@ -85,6 +85,9 @@ struct PeerXch {
     unsigned long long* pin = nullptr;             // pinned: ring [128] of epoch-base uploads; [128] error-word download
     unsigned ring = 0;
     bool ready = false, wait_kernel = false;       // wait_kernel: ranks share a GPU -> the flag wait gets a launch of its own
+    // contexts of ONE process attached together (pilco_group_peer_attach) hold plain pointers into each other's areas:
+    // the shared membership list lets a member that detaches (or is destroyed) take the others off the exchange first
+    std::shared_ptr<std::vector<struct pilco_ctx*>> members;
 };
 
 struct pilco_ctx {
@@ -121,6 +124,8 @@ struct pilco_ctx {
     int grad_mode = 1;   // pilco_rollout_grad*: 1 = Jacobian tape (one O(N^2) sweep per step), 0 = tape + per-step device adjoint
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> pair_events;
+    bool time_pairs = false;   // pilco_set_pair_timing: rollouts run eagerly with an event pair around every O(N^2) launch
+    int timed_pairs = 0;       // launches bracketed by the last such rollout
     double* pin = nullptr;   // pinned host staging buffer of the reverse pass (truly asynchronous small copies)
     size_t pin_cap = 0;
     double* pin_io = nullptr;   // pinned staging of pilco_rollout's inputs / results (one copy each way, no pageable detours)

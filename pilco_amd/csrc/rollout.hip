@@ -178,11 +178,21 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
 
 // The fused heads need the serial link's and the operand kernel's LDS side by side in one workgroup: wide models
 // (D > 24 with many outputs) exceed the CU's 160 KB and run the three-kernel step instead (same results).
+// The answer must be the SAME ON EVERY RANK (it selects between the peer exchange and the collective path, and ranks
+// that disagree wait for each other forever): it is computed from the model dimensions and the rank COUNT only -- the
+// geometry of rank 0, which holds the largest share of pairs and outputs under the round-robin dealing.
 static bool fused_heads_fit(pilco_ctx* ctx, const RolloutPlan& plan) {
     const Slot& s = ctx->slot[0];
-    if (s.wk.PL <= 0) return true;
     const bool rbf = plan.g.pol_kind == PILCO_POLICY_RBF;
     GlueArgs gl = plan.g;
+    if (ctx->nranks > 1) {
+        const int W = ctx->nranks, P = s.E * (s.E + 1) / 2;
+        gl.wk.PL = (P + W - 1) / W;
+        gl.wk.EL = (s.E + W - 1) / W;
+        mm_prep_chunks(s.npad, std::max(gl.wk.PL, 1), gl.wk.EL, &gl.wk.NCH, &gl.wk.NCHM);
+    } else if (s.wk.PL <= 0) {
+        return true;
+    }
     gl.flags = GF_TRAJ | GF_POLICY | GF_PACK | GF_ASSEMBLE | GF_PROPAGATE | (rbf ? (GF_RBF_PRE | GF_RBF_POST) : 0);
     const int rew_E = plan.g.n_rewards > 0 ? plan.E : 0;
     bool fits = mm_fused_head_fits(model_of(s), rew_E, gl);
@@ -499,6 +509,17 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
     // capture); if capture or instantiation fails the rollout falls back to eager launches for good.
     const bool peer = peer_rollout_applies(ctx, plan, H);   // no collective nodes: captured like a single-rank rollout
     const bool sharded = (ctx->nranks != 1 || ctx->comm) && !peer;
+    if (ctx->time_pairs) {   // measurement mode (pilco_set_pair_timing): eager, an event pair around every O(N^2) launch
+        while (ctx->pair_events.size() < (size_t)2 * std::max(H, 1)) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            ctx->pair_events.push_back(e);
+        }
+        ctx->timed_pairs = 0;
+        if (int r = enqueue_rollout(ctx, plan, H, &ctx->pair_events)) return r;
+        ctx->timed_pairs = (s.wk.PL > 0) ? H : 0;
+        return PILCO_OK;
+    }
     if (!ctx->use_graph || (sharded && (!ctx->comm || ctx->graph_rccl_failed)) || (ctx->dbg && !getenv("PILCO_DBG_GRAPH")))
         return enqueue_rollout(ctx, plan, H, nullptr);
     const GlueArgs& g = plan.g;

@@ -56,6 +56,24 @@ int peer_detach(pilco_ctx* ctx) {
     if (!x.local && x.mapped.empty()) return PILCO_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->st);
+    if (x.members) {
+        // in-process group: the other members store segments and flags straight into this context's area.  Before it is
+        // freed they are taken off the exchange (their queued work drained, ready cleared, graphs with the exchange baked
+        // in dropped): their next rollout runs the collective / host-mediated path or reports the missing exchange -- it
+        // does not write into freed memory.  (Peers in OTHER processes hold their own hipIpc mapping of the area, which
+        // keeps it alive on their side until they detach.)
+        for (pilco_ctx*& m : *x.members) {
+            if (m == ctx) { m = nullptr; continue; }
+            if (!m) continue;
+            (void)hipSetDevice(m->device);
+            (void)hipStreamSynchronize(m->st);
+            m->xq.ready = false;
+            for (auto& ge : m->graph_cache) (void)hipGraphExecDestroy(ge.second);
+            m->graph_cache.clear();
+            m->graph = nullptr;
+        }
+        (void)hipSetDevice(ctx->device);
+    }
     for (size_t j = 0; j < x.mapped.size(); ++j)
         if (j < x.opened.size() && x.opened[j] && x.mapped[j]) (void)hipIpcCloseMemHandle(x.mapped[j]);
     if (x.d_peers) (void)hipFree(x.d_peers);
@@ -397,6 +415,8 @@ int pilco_group_peer_attach(pilco_ctx** ctxs, int n) {
             return r;
         }
     }
+    auto members = std::make_shared<std::vector<pilco_ctx*>>(ctxs, ctxs + n);
+    for (int i = 0; i < n; ++i) ctxs[i]->xq.members = members;
     return PILCO_OK;
 }
 

@@ -62,7 +62,35 @@ def _mgpr_unpack(mgpr, u):
     return ls, var, nz
 
 
-def lockstep_minimize(eval_all, u0, parts, maxiter=15000, wall=(RuntimeError,)):
+def _eval_isolating(eval_all, u, parts, last_good, safe, wall):
+    """eval_all(u) with a wall exception confined to the output that caused it.  The reference fits one optimiser per
+    output (mgpr.py:47-56): a Gram matrix that is not positive definite at output a's trial point is a failed evaluation of
+    output a's line search and of nobody else's.  The batched device call reports ONE failing output per call (exception
+    attribute `output`, from pilco_last_not_pd_output); that output is set back to the last point at which it evaluated
+    (then to `safe`, if that one fails too) and the batch is evaluated again, until it goes through.
+    Returns (values, gradient, walled): the outputs in `walled` get no value from this round."""
+    u_eval = np.array(u, dtype=np.float64)
+    walled, tried_safe = set(), set()
+    while True:
+        try:
+            vals, grad = eval_all(u_eval)
+            return vals, grad, walled
+        except wall as exc:
+            bad = getattr(exc, "output", None)
+            if bad is None or not (0 <= int(bad) < len(parts)):
+                raise                       # the failing output is unknown: the caller walls the whole round
+            bad = int(bad)
+            if bad not in walled:
+                walled.add(bad)
+                u_eval[parts[bad]] = last_good[bad]
+            elif safe is not None and bad not in tried_safe:
+                tried_safe.add(bad)         # its last evaluated point fails as well (a start that is not positive definite)
+                u_eval[parts[bad]] = np.asarray(safe, dtype=np.float64)[parts[bad]]
+            else:
+                raise
+
+
+def lockstep_minimize(eval_all, u0, parts, maxiter=15000, wall=(RuntimeError,), safe=None):
     """E independent L-BFGS-B problems (problem a owns the entries parts[a] of the packed vector u) solved exactly as E
     separate scipy.optimize.minimize runs would solve them -- what the reference does, one optimiser per output
     (mgpr.py:47-56) -- while every round of function evaluations costs ONE call of eval_all(u) -> (values (E,), gradient):
@@ -70,7 +98,11 @@ def lockstep_minimize(eval_all, u0, parts, maxiter=15000, wall=(RuntimeError,)):
     that is still running has posted, the coordinator evaluates them all together (one batched device call) and hands
     the values back.  A joint run on the sum of the losses is not the same thing: its line search and stopping rule couple
     the outputs, and it can end in another local optimum (found against the executed reference).
-    Returns (u_end, values_end)."""
+    An evaluation that raises one of `wall` (a Gram matrix that is not positive definite) is a wall (1e25, zero gradient)
+    for the output that caused it ONLY (exception attribute `output`); the others get their true values from a second
+    evaluation of the batch with that output set back (_eval_isolating; `safe`: a packed vector every output can be
+    evaluated at, the last resort).  Without the attribute the whole round is walled.
+    Returns (u_end, values_end); an output whose END point cannot be evaluated reports 1e25."""
     import threading
     E = len(parts)
     u = np.array(u0, dtype=np.float64)
@@ -78,6 +110,7 @@ def lockstep_minimize(eval_all, u0, parts, maxiter=15000, wall=(RuntimeError,)):
     pending, results, final, errors = {}, {}, {}, []
     active = set(range(E))
     state = {"abort": None}
+    last_good = [u[parts[a]].copy() for a in range(E)]
 
     class _Abort(Exception):
         pass
@@ -108,6 +141,18 @@ def lockstep_minimize(eval_all, u0, parts, maxiter=15000, wall=(RuntimeError,)):
             pending.pop(a, None)
             cv.notify_all()
 
+    def evaluate(req):
+        """{a: (value, gradient)} for the outputs of `req` at the current u."""
+        try:
+            vals, grad, walled = _eval_isolating(eval_all, u, parts, last_good, safe, wall)
+        except wall:   # cannot be pinned on one output: a wall for every problem of this round
+            return {a: (1e25, np.zeros(len(parts[a]))) for a in req}
+        for a in range(E):
+            if a not in walled:
+                last_good[a] = u[parts[a]].copy()
+        return {a: ((1e25, np.zeros(len(parts[a]))) if a in walled else (float(vals[a]), np.array(grad[parts[a]], dtype=np.float64)))
+                for a in req}
+
     threads = [threading.Thread(target=worker, args=(a,), daemon=True) for a in range(E)]
     for t in threads:
         t.start()
@@ -129,10 +174,7 @@ def lockstep_minimize(eval_all, u0, parts, maxiter=15000, wall=(RuntimeError,)):
             for a in req:
                 u[parts[a]] = pending.pop(a)
         try:
-            vals, grad = eval_all(u)
-            out = {a: (float(vals[a]), np.array(grad[parts[a]], dtype=np.float64)) for a in req}
-        except wall:   # e.g. a Gram matrix that is not positive definite: a wall for the problems of this round
-            out = {a: (1e25, np.zeros(len(parts[a]))) for a in req}
+            out = evaluate(req)
         except BaseException as exc:   # noqa: BLE001 -- a device error: release every waiting run, then re-raise here
             with cv:
                 state["abort"] = exc
@@ -145,41 +187,58 @@ def lockstep_minimize(eval_all, u0, parts, maxiter=15000, wall=(RuntimeError,)):
         t.join()
     if state["abort"] is not None:
         raise state["abort"]
-    vals, _ = eval_all(u)
-    return u, np.asarray(vals, dtype=np.float64)
+    end = evaluate(list(range(E)))     # (an end point that is not positive definite -- only a start that was not -- reports the wall value)
+    return u, np.array([end[a][0] for a in range(E)], dtype=np.float64)
 
 
-def mgpr_objective(mgpr, u, noise_trainable=True):
-    """Sum over outputs of GPflow's training loss and its gradient in the unconstrained space."""
+def _trainable_masks(models):
+    """Per output: is the lengthscale vector / kernel variance / likelihood variance in the trainable set?  The reference
+    hands model.trainable_variables to its optimiser model by model (mgpr.py:51-56,66), so every output has its own set."""
+    return (np.array([bool(m.kernel.lengthscales.trainable) for m in models]),
+            np.array([bool(m.kernel.variance.trainable) for m in models]),
+            np.array([bool(m.likelihood.variance.trainable) for m in models]))
+
+
+def _as_mask(flag, E):
+    return np.full(E, bool(flag)) if np.ndim(flag) == 0 else np.asarray(flag, bool)
+
+
+def mgpr_objective(mgpr, u, noise_trainable=True, ls_trainable=True, var_trainable=True):
+    """Per-output GPflow training loss and its gradient in the unconstrained space.  The *_trainable arguments are
+    per-output masks (or one bool for all): a parameter outside an output's trainable set keeps its value (zero gradient
+    component: L-BFGS-B never moves it, and its inner products and stopping test do not see it)."""
     E, D = mgpr.num_outputs, mgpr.num_dims
+    tn, tl, tv = _as_mask(noise_trainable, E), _as_mask(ls_trainable, E), _as_mask(var_trainable, E)
     ls, var, nz = _mgpr_unpack(mgpr, u)
     for i, m in enumerate(mgpr.models):
         m.kernel.lengthscales.assign(ls[i])
         m.kernel.variance.assign(var[i])
-        if noise_trainable:                      # a fixed likelihood variance is not touched (no transform round trip)
+        if tn[i]:                                # a fixed likelihood variance is not touched (no transform round trip)
             m.likelihood.variance.assign(nz[i])
     mgpr._sync()
     nlml, g = mgpr.ctx.gp_nlml(mgpr._slot, D, E)
     lp_l, dlp_l = _gamma_logpdf_and_grad(ls, 1.1, 0.1)          # mgpr.py:33
     lp_v, dlp_v = _gamma_logpdf_and_grad(var, 1.5, 0.5)         # mgpr.py:34
     per_output = nlml - lp_l.sum(1) - lp_v
-    g_ls = (g[:, :D] - dlp_l) * _dsoftplus(u[:E * D]).reshape(E, D)
-    g_var = (g[:, D] - dlp_v) * _dsoftplus(u[E * D:E * D + E])
-    g_nz = g[:, D + 1] * _dsoftplus(u[E * D + E:]) * (1.0 if noise_trainable else 0.0)
+    g_ls = (g[:, :D] - dlp_l) * _dsoftplus(u[:E * D]).reshape(E, D) * tl[:, None]
+    g_var = (g[:, D] - dlp_v) * _dsoftplus(u[E * D:E * D + E]) * tv
+    g_nz = g[:, D + 1] * _dsoftplus(u[E * D + E:]) * tn
     return per_output, np.concatenate([g_ls.ravel(), g_var, g_nz])
 
 
 def _restart_draws(E, D, restarts, noise_trainable):
     """randomize() (mgpr.py:8-15) for every (model, restart) in the order the reference draws them from NumPy's global
-    generator: model by model (mgpr.py:58-66), within a model restart by restart; per draw lengthscales (D), kernel variance,
-    and the likelihood variance only if it is trainable.  The lockstep driver needs restart r of ALL outputs at once, so the
-    draws are taken up front; with the same np.random.seed the starts are the reference's."""
+    generator: model by model (mgpr.py:58-66), within a model restart by restart; per draw lengthscales (D) and kernel
+    variance (always, trainable or not), and the likelihood variance only if THAT model's is trainable.  The lockstep driver
+    needs restart r of ALL outputs at once, so the draws are taken up front; with the same np.random.seed the starts are the
+    reference's."""
+    tn = _as_mask(noise_trainable, E)
     ls, var, nz = np.empty((restarts, E, D)), np.empty((restarts, E)), np.full((restarts, E), np.nan)
     for a in range(E):
         for r in range(restarts):
             ls[r, a] = 1 + 0.01 * np.random.normal(size=(D,))
             var[r, a] = 1 + 0.01 * np.random.normal(size=())
-            if noise_trainable:
+            if tn[a]:
                 nz[r, a] = 1 + 0.01 * np.random.normal()
     return ls, var, nz
 
@@ -201,17 +260,22 @@ def optimize_mgpr(mgpr, restarts=1, maxiter=None, verbose=False, keep="last"):
     maxiter = MODEL_FIT_MAXITER if maxiter is None else maxiter
     if isinstance(mgpr, SMGPR):
         raise TypeError("optimize_mgpr fits the exact GP objective; SMGPR.optimize uses optimize_smgpr (GPRFITC objective)")
-    noise_trainable = all(m.likelihood.variance.trainable for m in mgpr.models)
+    tl, tv, tn = _trainable_masks(mgpr.models)
     E, D = mgpr.num_outputs, mgpr.num_dims
     parts = [np.concatenate([np.arange(a * D, (a + 1) * D), [E * D + a], [E * D + E + a]]) for a in range(E)]
+    # a point every output can be evaluated at (unit lengthscales / variance / noise), the isolation's last resort
+    safe = np.concatenate([_softplus_inv(np.ones(E * D)), _softplus_inv(np.ones(E)), _softplus_inv(np.ones(E) - NOISE_LOWER)])
+
+    def objective(u):
+        return mgpr_objective(mgpr, u, tn, tl, tv)
 
     def run(u0):
-        return lockstep_minimize(lambda u: mgpr_objective(mgpr, u, noise_trainable), u0, parts, maxiter, wall=(_lib.NotPositiveDefiniteError,))
+        return lockstep_minimize(objective, u0, parts, maxiter, wall=(_lib.NotPositiveDefiniteError,), safe=safe)
 
     u_best, per_best = run(_mgpr_pack(mgpr))
-    ls_r, var_r, nz_r = _restart_draws(E, D, restarts, noise_trainable)
+    ls_r, var_r, nz_r = _restart_draws(E, D, restarts, tn)
     for r in range(restarts):
-        nz0 = nz_r[r] if noise_trainable else mgpr.noise
+        nz0 = np.where(tn, nz_r[r], mgpr.noise)
         u0 = np.concatenate([_softplus_inv(ls_r[r]).ravel(), _softplus_inv(var_r[r]), _softplus_inv(np.maximum(nz0 - NOISE_LOWER, 1e-12))])
         u, per = run(u0)
         better = per < per_best if keep == "best" else np.ones(E, bool)
@@ -221,28 +285,34 @@ def optimize_mgpr(mgpr, restarts=1, maxiter=None, verbose=False, keep="last"):
         for a in np.nonzero(better)[0]:
             ub[parts[a]] = u[parts[a]]
         u_best, per_best = ub, np.where(better, per, per_best)
-    mgpr_objective(mgpr, u_best, noise_trainable)   # leaves the kept parameters assigned
+    try:
+        objective(u_best)   # leaves the kept parameters assigned
+    except _lib.NotPositiveDefiniteError:
+        pass                # (assigned all the same; only a start that was not positive definite ends here, and the
+                            # reference's model would hold such parameters too)
     mgpr._sync()
     return per_best
 
 
-def smgpr_objective(smgpr, u, noise_trainable=True):
-    """Sum over outputs of gpflow's GPRFITC training loss (no priors: smgpr.py:16-22 sets none) and its gradient in
-    the unconstrained space: softplus for lengthscales / variances (noise floor 1e-6), identity for the inducing inputs."""
+def smgpr_objective(smgpr, u, noise_trainable=True, ls_trainable=True, var_trainable=True):
+    """Per-output gpflow GPRFITC training loss (no priors: smgpr.py:16-22 sets none) and its gradient in the
+    unconstrained space: softplus for lengthscales / variances (noise floor 1e-6), identity for the inducing inputs.
+    *_trainable: per-output masks as in mgpr_objective."""
     E, D, M = smgpr.num_outputs, smgpr.num_dims, smgpr.num_induced_points
+    tn, tl, tv = _as_mask(noise_trainable, E), _as_mask(ls_trainable, E), _as_mask(var_trainable, E)
     nk = E * D + 2 * E
     ls, var, nz = _mgpr_unpack(smgpr, u[:nk])
     Z = u[nk:].reshape(E, M, D)
     for i, m in enumerate(smgpr.models):
         m.kernel.lengthscales.assign(ls[i])
         m.kernel.variance.assign(var[i])
-        if noise_trainable:
+        if tn[i]:
             m.likelihood.variance.assign(nz[i])
     smgpr._sync()
     nlml, gh, gz = smgpr.ctx.gp_fitc_nlml(smgpr._slot, Z, D, E)
-    g_ls = gh[:, :D] * _dsoftplus(u[:E * D]).reshape(E, D)
-    g_var = gh[:, D] * _dsoftplus(u[E * D:E * D + E])
-    g_nz = gh[:, D + 1] * _dsoftplus(u[E * D + E:nk]) * (1.0 if noise_trainable else 0.0)
+    g_ls = gh[:, :D] * _dsoftplus(u[:E * D]).reshape(E, D) * tl[:, None]
+    g_var = gh[:, D] * _dsoftplus(u[E * D:E * D + E]) * tv
+    g_nz = gh[:, D + 1] * _dsoftplus(u[E * D + E:nk]) * tn
     return nlml, np.concatenate([g_ls.ravel(), g_var, g_nz, gz.ravel()])
 
 
@@ -261,16 +331,20 @@ def optimize_smgpr(smgpr, restarts=1, maxiter=None, keep="last"):
     nk = E * D + 2 * E
     parts = [np.concatenate([np.arange(a * D, (a + 1) * D), [E * D + a], [E * D + E + a],
                              nk + np.arange(a * M * D, (a + 1) * M * D)]) for a in range(E)]
+    tl, tv, tn = _trainable_masks(smgpr.models)
+    safe = np.concatenate([_softplus_inv(np.ones(E * D)), _softplus_inv(np.ones(E)), _softplus_inv(np.ones(E) - NOISE_LOWER), Z0.ravel()])
+
+    def objective(u):
+        return smgpr_objective(smgpr, u, tn, tl, tv)
 
     def run(u0):
-        return lockstep_minimize(lambda u: smgpr_objective(smgpr, u, noise_trainable), u0, parts, maxiter, wall=(_lib.NotPositiveDefiniteError,))
+        return lockstep_minimize(objective, u0, parts, maxiter, wall=(_lib.NotPositiveDefiniteError,), safe=safe)
 
-    noise_trainable = all(m.likelihood.variance.trainable for m in smgpr.models)
     u_best, per_best = run(np.concatenate([_mgpr_pack(smgpr), Z0.ravel()]))
     u_prev = u_best
-    ls_r, var_r, nz_r = _restart_draws(E, D, restarts, noise_trainable)
+    ls_r, var_r, nz_r = _restart_draws(E, D, restarts, tn)
     for r in range(restarts):
-        nz0 = nz_r[r] if noise_trainable else smgpr.noise
+        nz0 = np.where(tn, nz_r[r], smgpr.noise)
         u0 = np.concatenate([_softplus_inv(ls_r[r]).ravel(), _softplus_inv(var_r[r]), _softplus_inv(np.maximum(nz0 - NOISE_LOWER, 1e-12)),
                              u_prev[nk:]])
         u_prev, per = run(u0)
@@ -279,7 +353,10 @@ def optimize_smgpr(smgpr, restarts=1, maxiter=None, keep="last"):
         for a in np.nonzero(better)[0]:
             ub[parts[a]] = u_prev[parts[a]]
         u_best, per_best = ub, np.where(better, per, per_best)
-    smgpr_objective(smgpr, u_best, noise_trainable)      # leaves the kept kernel parameters assigned
+    try:
+        objective(u_best)      # leaves the kept kernel parameters assigned
+    except _lib.NotPositiveDefiniteError:
+        pass
     Zf = u_best[nk:].reshape(E, M, D)
     for i, m in enumerate(smgpr.models):
         m.inducing_variable.Z.assign(Zf[i])

@@ -499,6 +499,37 @@ def test_set_data_changes_n_and_not_pd_error(ctx):
         m.predict_on_noisy_inputs(np.zeros((1, 4)), 0.1 * np.eye(4))
 
 
+def test_not_pd_output_is_named_and_isolated_in_the_lockstep_fit(ctx):
+    """mgpr.py:47-56 fits one optimiser per output, so a failed Cholesky concerns one output.  The device names it
+    (pilco_last_not_pd_output -> exception attribute `output`) and the lockstep evaluation confines the wall to it: the
+    healthy output's value and gradient are the ones it has when evaluated with a healthy neighbour."""
+    from pilco_amd import NotPositiveDefiniteError, _lib, training
+    from pilco_amd.models import MGPR
+    c = synthetic.config_c2(N=70, D=4, E=2, seed=6, control_dim=2)
+    Xd = np.vstack([c["X"][:30], c["X"][:30]])            # duplicated inputs: singular without noise
+    Yd = np.vstack([c["Y"][:30], c["Y"][:30]])
+    m = MGPR((Xd, Yd), ctx=ctx)
+    ls = np.array([[1.3, 0.9, 1.1, 1.6], [0.8, 1.2, 1.4, 1.0]])
+    good = np.concatenate([training._softplus_inv(ls).ravel(), training._softplus_inv(np.array([0.9, 1.2])),
+                           training._softplus_inv(np.array([1e-2, 1e-2]) - training.NOISE_LOWER)])
+    per_good, g_good = training.mgpr_objective(m, good)
+    for bad_out in (1, 0):
+        bad = good.copy()
+        bad[8 + bad_out] = 1e15                            # kernel variance 1e15 over a 1e-6 noise floor: rounding beats the noise
+        bad[10 + bad_out] = -40.0                          # noise at its floor
+        with pytest.raises(NotPositiveDefiniteError) as ei:
+            training.mgpr_objective(m, bad)
+        assert ei.value.output == bad_out
+        parts = [np.array([0, 1, 2, 3, 8, 10]), np.array([4, 5, 6, 7, 9, 11])]
+        last_good = [good[parts[0]].copy(), good[parts[1]].copy()]
+        vals, grad, walled = training._eval_isolating(lambda u: training.mgpr_objective(m, u), bad, parts, last_good, None,
+                                                      (_lib.NotPositiveDefiniteError,))
+        assert walled == {bad_out}
+        ok = 1 - bad_out
+        assert vals[ok] == per_good[ok]
+        assert np.array_equal(grad[parts[ok]], g_good[parts[ok]])
+
+
 @pytest.mark.parametrize("variant", [0, 2])
 @pytest.mark.parametrize("nranks", [2, 3])
 def test_sharded_step_two_contexts_host_allgather(variant, nranks):
@@ -738,6 +769,49 @@ def test_sparse_config4_scale(ctx):
     np.testing.assert_allclose(Mg, Mo, rtol=RTOL, atol=1e-12)
     np.testing.assert_allclose(Sg, So, rtol=RTOL, atol=1e-10)
     np.testing.assert_allclose(Rg, Ro, rtol=RTOL)
+
+
+def test_sparse_config4_vs_executed_reference(ctx, golden_dir):
+    """BASELINE config 4 AT ITS SIZE (M=200, N=5000, D=10, E=10) against the reference's own SMGPR / PILCO source executed
+    there (oracle/gen_golden_c4.py, smgpr.py:24-52): the FITC factors (beta in full; iK through its diagonal, Frobenius
+    norm and 4 seeded probe products per output), one predict_on_noisy_inputs, and every state + the running reward of the
+    H = 40 rollout, 1e-5 relative."""
+    from pilco_amd.models import PILCO
+    g = np.load(os.path.join(golden_dir, "c4_sparse.npz"))
+    assert str(g["provenance"]).startswith("reference source executed")
+    H, E, M = int(g["H"]), int(g["E"]), int(g["M"])
+    c = synthetic.config_c4()
+    assert c["X"].shape == (int(g["N"]), int(g["D"])) and c["Z"].shape == (M, int(g["D"]))
+    p = PILCO((c["X"], c["Y"]), num_induced_points=M, horizon=H)
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(c["lengthscales"][i])
+        mdl.kernel.variance.assign(c["variance"][i])
+        mdl.likelihood.variance.assign(c["noise"][i])
+        mdl.inducing_variable.Z.assign(c["Z"])
+    iK, beta = p.mgpr.calculate_factorizations()
+    assert iK.shape == (E, M, M) and beta.shape == (E, M)
+    P = np.random.RandomState(int(g["probe_seed"])).randn(E, M, 4)
+    for a in range(E):
+        assert np.linalg.norm(beta[a] - g["beta"][a]) / np.linalg.norm(g["beta"][a]) < 1e-7
+        assert abs(np.linalg.norm(iK[a]) - g["iK_fro"][a]) / g["iK_fro"][a] < 1e-7
+        assert np.linalg.norm(np.diag(iK[a]) - g["iK_diag"][a]) / np.linalg.norm(g["iK_diag"][a]) < 1e-7
+        pr = iK[a] @ P[a]
+        assert np.linalg.norm(pr - g["iK_probe"][a]) / np.linalg.norm(g["iK_probe"][a]) < 1e-7
+    Mp, Sp, Vp = p.mgpr.predict_on_noisy_inputs(c["m0"], c["S0"])
+    np.testing.assert_allclose(Mp, g["pred_M"], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(Sp, g["pred_S"], rtol=RTOL, atol=1e-10)
+    np.testing.assert_allclose(Vp, g["pred_V"], rtol=RTOL, atol=1e-12)
+    Mh, Sh, R, traj = p.predict_trajectory(c["m0"], c["S0"], H)
+    worst = 0.0
+    for t in range(H + 1):
+        Mt, St = traj[t, :E], traj[t, E:].reshape(E, E)
+        np.testing.assert_allclose(Mt, g["M_traj"][:, t], rtol=RTOL, atol=1e-12, err_msg="mean, step %d" % t)
+        np.testing.assert_allclose(St, g["S_traj"][:, :, t], rtol=RTOL, atol=1e-10, err_msg="covariance, step %d" % t)
+        worst = max(worst, float(np.max(np.abs(St - g["S_traj"][:, :, t])) / np.max(np.abs(g["S_traj"][:, :, t]))))
+    np.testing.assert_allclose(R[0, 0], g["R_traj"][-1], rtol=RTOL)
+    for n in (1, 3, 11):
+        np.testing.assert_allclose(p.predict(c["m0"], c["S0"], n)[2][0, 0], g["R_traj"][n], rtol=RTOL)
+    print("\nconfig 4: worst error of S over 40 steps relative to max |S| %.2e" % worst)
 
 
 def test_rbf_controller_golden(ctx, golden_dir):

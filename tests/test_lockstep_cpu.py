@@ -95,3 +95,77 @@ def test_an_error_in_the_batched_evaluation_or_in_one_run_releases_every_thread(
     finally:
         training.minimize = real
     assert threading.active_count() == before
+
+
+def test_a_wall_is_confined_to_the_output_that_caused_it():
+    """The reference runs one optimiser per output (mgpr.py:47-56): a Gram matrix that is not positive definite at output
+    0's trial point must not feed a spurious 1e25 / zero-gradient evaluation to output 1.  The batched evaluation names
+    the failing output (attribute `output`, pilco_last_not_pd_output); with it, every output ends exactly -- to the last
+    bit, after the same number of evaluations -- where its own separate scipy run with a private wall ends."""
+    rs = np.random.RandomState(3)
+    E, n = 3, 3
+    probs = _problems(rs, E, n)
+    parts = [np.arange(a * n, (a + 1) * n) for a in range(E)]
+    u0 = rs.randn(E * n)
+    limit = [0.9, 1e9, 0.7]          # outputs 0 and 2 have a forbidden region (x[0] > limit), output 1 has none
+
+    class Wall(RuntimeError):
+        pass
+
+    seen = {a: [] for a in range(E)}
+
+    def eval_all(u):
+        for a in range(E):           # like the batched factorisation: reports the FIRST failing output
+            if u[parts[a]][0] > limit[a]:
+                exc = Wall("not positive definite (stand-in)")
+                exc.output = a
+                raise exc
+        vals, grad = np.empty(E), np.empty(E * n)
+        for a in range(E):
+            vals[a], grad[parts[a]] = _f(probs[a], u[parts[a]])
+        return vals, grad
+
+    u, vals = lockstep_minimize(eval_all, u0, parts, maxiter=200, wall=(Wall,))
+    for a in range(E):
+        def single(x, a=a):
+            seen[a].append(1)
+            if x[0] > limit[a]:
+                return 1e25, np.zeros(n)
+            return _f(probs[a], x)
+        res = minimize(single, u0[parts[a]], jac=True, method="L-BFGS-B", options=dict(maxiter=200))
+        assert np.array_equal(res.x, u[parts[a]]), a
+        assert res.fun == vals[a], a
+    # the walls were actually hit (otherwise this test shows nothing)
+    hit = [0]
+
+    def counting(u):
+        try:
+            return eval_all(u)
+        except Wall:
+            hit[0] += 1
+            raise
+    lockstep_minimize(counting, u0, parts, maxiter=200, wall=(Wall,))
+    assert hit[0] > 0
+
+
+def test_a_start_that_cannot_be_evaluated_walls_only_its_own_output():
+    parts = [np.arange(2), np.arange(2, 4)]
+
+    class Wall(RuntimeError):
+        pass
+
+    def eval_all(u):
+        if u[0] > 2.0:
+            exc = Wall("not positive definite (stand-in)")
+            exc.output = 0
+            raise exc
+        return np.array([np.sum((u[:2] - 1.0) ** 2), np.sum((u[2:] + 0.5) ** 2)]), 2.0 * np.concatenate([u[:2] - 1.0, u[2:] + 0.5])
+
+    # output 0 starts inside its forbidden region: without a safe point nothing can be pinned on it -> the round is a wall
+    # for both (old behaviour, still not a crash) ...
+    u, vals = lockstep_minimize(eval_all, np.array([3.0, 0.0, 3.0, 3.0]), parts, maxiter=100, wall=(Wall,))
+    assert vals[0] == 1e25
+    # ... with one, output 1 is fitted as if output 0 did not exist, and output 0 reports the wall value at its end point
+    u, vals = lockstep_minimize(eval_all, np.array([3.0, 0.0, 3.0, 3.0]), parts, maxiter=100, wall=(Wall,), safe=np.zeros(4))
+    np.testing.assert_allclose(u[2:], [-0.5, -0.5], atol=1e-5)
+    assert vals[0] == 1e25 and vals[1] < 1e-9

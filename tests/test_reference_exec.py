@@ -314,6 +314,41 @@ def test_sparse_rollout_and_wide_gradient_fixtures_equal_the_executed_reference(
     np.testing.assert_allclose(-hb.numpy(), w["dreward_db"], rtol=1e-9)
 
 
+def test_config4_fixture_equals_the_executed_reference_and_pins_the_restatement(R, golden_dir):
+    """c4_sparse.npz (BASELINE config 4 at its size: M=200, N=5000, D=10, E=10): the reference's SMGPR factorisation
+    (smgpr.py:24-45) and three steps of its rollout are executed again here -- the committed numbers must come out -- and
+    the NumPy restatement the GPU tests use at sizes without a fixture (oracle/tf_path.fitc_factorizations) is held to the
+    executed factors at 1e-9."""
+    import torch
+    from oracle import tf_path as tp
+    from pilco_amd import synthetic
+    g = _g(golden_dir, "c4_sparse.npz")
+    c = synthetic.config_c4()
+    E, M = int(g["E"]), int(g["M"])
+    np.random.seed(1)
+    ctl = R.controllers.LinearController(E, 0, max_action=1.0)
+    p = R.PILCO((c["X"], c["Y"]), num_induced_points=M, horizon=3, controller=ctl, m_init=c["m0"], S_init=c["S0"])
+    for i, mdl in enumerate(p.mgpr.models):
+        mdl.kernel.lengthscales.assign(c["lengthscales"][i])
+        mdl.kernel.variance.assign(c["variance"][i])
+        mdl.likelihood.variance.assign(c["noise"][i])
+        mdl.inducing_variable.Z.assign(c["Z"])
+    with torch.no_grad():
+        iK, beta = p.mgpr.calculate_factorizations()
+        Mh, Sh, Rh = p.predict(c["m0"], c["S0"], 3)
+    iK, beta = n_(iK), n_(beta)
+    np.testing.assert_allclose(beta, g["beta"], rtol=1e-9, atol=1e-9 * np.abs(g["beta"]).max())
+    P = np.random.RandomState(int(g["probe_seed"])).randn(E, M, 4)
+    np.testing.assert_allclose(np.einsum("aij,ajk->aik", iK, P), g["iK_probe"], rtol=1e-8, atol=1e-9 * np.abs(g["iK_probe"]).max())
+    np.testing.assert_allclose(n_(Mh)[0], g["M_traj"][:, 3], rtol=1e-10)
+    np.testing.assert_allclose(n_(Sh), g["S_traj"][:, :, 3], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(float(n_(Rh).ravel()[0]), g["R_traj"][3], rtol=1e-12)
+    iKo, betao = tp.fitc_factorizations(c["X"], c["Y"], c["Z"], c["lengthscales"], c["variance"], c["noise"])
+    for a in range(E):
+        assert np.linalg.norm(iKo[a] - iK[a]) / np.linalg.norm(iK[a]) < 1e-9
+        assert np.linalg.norm(betao[a] - beta[a]) / np.linalg.norm(beta[a]) < 1e-9
+
+
 def test_safe_pilco_extension_executed_and_host_side_risk_terms(golden_dir):
     """safe_pilco_extension/ executed (RbfController + RiskOfCollision, the pairing of examples/safe_cars_run.py:72-86):
     the committed fixture equals the executed output, and the product's host-side risk terms (pilco_amd/safe.py: value

@@ -68,9 +68,9 @@ def test_sparse_restarts_keep_their_inducing_inputs_and_the_iteration_cap_is_the
     starts = []
     real = training.lockstep_minimize
 
-    def spy(eval_all, u0, parts, maxiter, wall):
+    def spy(eval_all, u0, parts, maxiter, wall, **kw):
         starts.append((np.array(u0), maxiter))
-        out = real(eval_all, u0, parts, maxiter, wall)
+        out = real(eval_all, u0, parts, maxiter, wall, **kw)
         starts.append((np.array(out[0]), None))
         return out
     monkeypatch.setattr(training, "lockstep_minimize", spy)
@@ -112,3 +112,70 @@ def test_a_fixed_likelihood_variance_stays_where_it_is(cls, monkeypatch):
     np.random.normal(size=2 * (3 + 1))            # 2 models x (3 lengthscales + 1 kernel variance), nothing for the noise
     assert np.random.normal() == drawn
     assert np.array_equal(m.noise, [0.001, 0.001]) and not np.allclose(m.lengthscales, ls0)
+
+
+def test_mixed_trainability_is_per_output_and_draws_follow_the_reference_order():
+    """mgpr.py:47-66 hands model.trainable_variables to the optimiser MODEL BY MODEL and randomize() (mgpr.py:8-15) draws a
+    likelihood variance only for a model whose variance is trainable: with output 1's noise fixed, output 0's noise is
+    still fitted, output 1's stays put, a fixed lengthscale vector stays put, and the global generator ends where the
+    reference's draw sequence ends (D + 1 + [1 if trainable] normals per model and restart)."""
+    g = np.load(os.path.join(GOLDEN, "models_optimisation.npz"))
+    X, Y = g["X"], g["Y"]
+    E, D = Y.shape[1], X.shape[1]
+    m = MGPR((X, Y), ctx=CpuObjectiveContext())
+    _start(m, g)
+    m.models[1].likelihood.variance.trainable = False
+    m.models[0].kernel.lengthscales.trainable = False
+    ls0, nz1 = m.lengthscales[0].copy(), float(m.noise[1])
+    per = m.optimize(restarts=0)
+    assert np.array_equal(m.lengthscales[0], ls0) or np.allclose(m.lengthscales[0], ls0, rtol=1e-14)
+    assert float(m.noise[1]) == nz1
+    assert abs(float(m.noise[0]) - float(g["noise_start"][0])) > 1e-9          # output 0's noise WAS fitted
+    assert np.all(np.isfinite(per))
+    # draw order with restarts
+    np.random.seed(5)
+    m.optimize(restarts=2)
+    after = np.random.normal()
+    np.random.seed(5)
+    for a in range(E):
+        for r in range(2):
+            np.random.normal(size=(D,))
+            np.random.normal(size=())
+            if a != 1:
+                np.random.normal()
+    assert after == np.random.normal()
+    assert float(m.noise[1]) == nz1
+
+
+def test_not_positive_definite_output_is_isolated_in_the_model_fit():
+    """One output whose Gram matrix fails during the fit (here: forced by the stand-in for lengthscales below a threshold)
+    is a wall for that output alone: the other output ends where it ends when fitted alone."""
+    from pilco_amd import _lib
+    g = np.load(os.path.join(GOLDEN, "models_optimisation.npz"))
+
+    class Flaky(CpuObjectiveContext):
+        """output 1 'fails its Cholesky' whenever its first lengthscale exceeds a threshold the fit crosses"""
+        thr = None
+
+        def gp_nlml(self, slot, D, E, want_grad=True):
+            if self.thr is not None and self.ls[1][0] > self.thr:
+                exc = _lib.NotPositiveDefiniteError(2, "output 1 (stand-in)")
+                exc.output = 1
+                self.hits = getattr(self, "hits", 0) + 1
+                raise exc
+            return super().gp_nlml(slot, D, E, want_grad)
+
+    ref = MGPR((g["X"], g["Y"]), ctx=CpuObjectiveContext())
+    _start(ref, g)
+    per_ref = ref.optimize(restarts=0)
+    ctx = Flaky()
+    m = MGPR((g["X"], g["Y"]), ctx=ctx)
+    _start(m, g)
+    lo, hi = float(g["ls_start"][1][0]), float(ref.lengthscales[1][0])
+    ctx.thr = lo + 0.5 * (hi - lo) if hi > lo else 1e9
+    per = m.optimize(restarts=0)
+    if hi > lo:
+        assert ctx.hits > 0                                   # the wall was hit ...
+        assert m.lengthscales[1][0] <= ctx.thr                 # ... and respected by output 1
+    np.testing.assert_allclose(per[0], per_ref[0], rtol=1e-12)   # output 0 never noticed
+    np.testing.assert_allclose(m.lengthscales[0], ref.lengthscales[0], rtol=1e-12)

@@ -39,6 +39,21 @@ if pair:
     if "SQ_BUSY_CYCLES" in p and p.get("SQ_WAVE_CYCLES"):
         out["pair_kernel_valu_active_over_wave_cycles"] = p.get("SQ_ACTIVE_INST_VALU", 0.0) / p["SQ_WAVE_CYCLES"]
         out["pair_kernel_wait_inst_over_wave_cycles"] = p.get("SQ_WAIT_INST_ANY", 0.0) / p["SQ_WAVE_CYCLES"]
+# provenance: which sources the profiled binary was built from (bench.py warns when the pair kernel has changed since)
+import datetime, hashlib, subprocess
+def _sha16(path):
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+out["kernel_source_sha16"] = {n: _sha16(os.path.join("pilco_amd", "csrc", n))
+                              for n in ("pair.hip", "prep.hip", "glue_device.h", "mm_device.h", "rollout.hip", "bwd.hip", "linalg.hip")}
+out["date"] = datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ")
+try:
+    out["git_head"] = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() + \
+        ("+dirty" if subprocess.run(["git", "status", "--porcelain", "pilco_amd/csrc"], capture_output=True, text=True).stdout.strip() else "")
+except Exception:
+    out["git_head"] = None
 os.makedirs("profiles", exist_ok=True)
 json.dump(out, open("profiles/%s_pmc_summary.json" % rnd, "w"), indent=1)
 shutil.copy(os.path.join(src, "trace", "r_kernel_stats.csv"), "profiles/%s_kernel_stats.csv" % rnd)
