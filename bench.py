@@ -186,6 +186,25 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
         ctxb.close()
     except Exception as exc:
         out["two_concurrent_rollouts_per_s"] = repr(exc)
+    # the whole rollout as ONE persistent launch (pilco_set_rollout_mode(ctx, 1), csrc/persist.hip): same bits, timed beside
+    # the graph replay that `value` reports.  Opt-in because it measures slower.
+    try:
+        ref = ctx.rollout(policy, rewards, cfg["m0"], cfg["S0"], H)
+        ctx.set_rollout_mode(1)
+        got = ctx.rollout(policy, rewards, cfg["m0"], cfg["S0"], H)
+        used = ctx.last_rollout_mode()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.rollout(policy, rewards, cfg["m0"], cfg["S0"], H)
+        p_ms = (time.perf_counter() - t0) * 1e3 / steps
+        out["persistent_launch"] = {"rollouts_per_s": 1e3 / p_ms, "ms_per_rollout": p_ms, "ran_as_persistent_launch": bool(used),
+                                    "bitwise_equal_to_launch_sequence": bool(all(np.array_equal(a, b) for a, b in zip(ref, got))),
+                                    "note": "one resident launch for all 40 steps, phases ordered by flags in device memory (no cache maintenance), "
+                                            "host-synchronised with the result downloaded like `value`; graph replay: %.3f ms" % ms_rollout}
+    except Exception as exc:
+        out["persistent_launch"] = {"error": repr(exc)}
+    finally:
+        ctx.set_rollout_mode(0)
     fact_ms = ctx.factorize_timed(0, 5)
     out["factorisation_ms"] = fact_ms
     out["R_fwd_fact_rollouts_per_s"] = 1e3 / (fact_ms + ms_rollout)

@@ -61,6 +61,18 @@ int pilco_set_grad_mode(pilco_ctx* ctx, int mode);
 /* 1 (default; PILCO_NO_GRAPH=1 in the environment starts with 0): a rollout's launch sequence is captured once into a
  * hipGraph and replayed while the plan is unchanged; 0: every rollout is enqueued launch by launch.  Same results. */
 int pilco_set_use_graph(pilco_ctx* ctx, int on);
+/* How a plain rollout (pilco_rollout / pilco_propagate / pilco_rollout_timed: one rank, no policy or a LinearController,
+ * stream-K pair kernel, D <= 12) is run.  0 (default): the launch sequence (two launches per step, replayed as a hipGraph).
+ * 1 (PILCO_PERSIST=1 in the environment starts with it): ONE persistent launch for all H steps -- the reference's
+ * tf.while_loop (pilco.py:126-135) as a single kernel: every workgroup stays resident, the phases of a step are ordered by
+ * flags in device memory instead of kernel boundaries, the state lives in LDS.  Both run the same device code on the same
+ * work decomposition: results are BITWISE identical.  Measured on MI355X the persistent launch is 6-20 % SLOWER than the
+ * graph replay, which is why it is not the default.  A persistent launch that cannot make progress
+ * (its workgroups are not all resident because the GPU is shared with other work) gives up after a bounded wait
+ * (PILCO_PERSIST_TIMEOUT_MS, default 200); the rollout is then repeated on the launch sequence and the context stays on
+ * it until this is called again.  pilco_last_rollout_mode: which of the two the last rollout actually used. */
+int pilco_set_rollout_mode(pilco_ctx* ctx, int mode);
+int pilco_last_rollout_mode(const pilco_ctx* ctx);
 /* checks the f64 MFMA fragment layout assumptions on the device; 0 = OK */
 int pilco_selftest(pilco_ctx* ctx);
 
@@ -213,7 +225,8 @@ int pilco_get_pair_timing(pilco_ctx* ctx, float* ms_pair, int* n_pair_launches);
 int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32);
 /* per-workgroup (start, end) stamps of the last prep launch, n values (developer aid) */
 int pilco_debug_blocks(pilco_ctx* ctx, unsigned long long* out, int n);
-/* developer aid: raw copy of a work buffer (0 row operands At, 1 column operands Bt, 2 reverse-pass row moments, 3 column sums, 4 beta) */
+/* developer aid: raw copy of a work buffer (0 row operands At, 1 column operands Bt, 2 reverse-pass row moments, 3 column sums, 4 beta,
+ * 5 the persistent rollout kernel's 64 control words: abort word and one step's phase stamps, raw 8-byte words) */
 int pilco_debug_buffer(pilco_ctx* ctx, int slot, int which, double* out, long n);
 /* Stream-K work split of the pair kernel (pure host functions, no GPU): the column steps of nd diagonal pairs (tdiag
  * steps each, cost ud) and n_pairs - nd off-diagonal pairs (toff steps, cost uo) lie on one line cut into `waves` equal

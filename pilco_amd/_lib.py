@@ -60,6 +60,8 @@ SIGNATURES = {
     "pilco_set_fused_step": (C.c_int, [_vp, C.c_int]),
     "pilco_set_grad_mode": (C.c_int, [_vp, C.c_int]),
     "pilco_set_use_graph": (C.c_int, [_vp, C.c_int]),
+    "pilco_set_rollout_mode": (C.c_int, [_vp, C.c_int]),
+    "pilco_last_rollout_mode": (C.c_int, [_vp]),
     "pilco_gp_set_data": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int]),
     "pilco_gp_set_hyp": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "pilco_gp_set_inducing": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
@@ -208,6 +210,13 @@ class Context:
 
     def use_graph(self, on):
         self._chk(self.lib.pilco_set_use_graph(self.h, 1 if on else 0))
+
+    def set_rollout_mode(self, mode):
+        """0 (default): the launch sequence (hipGraph replay); 1: plain rollouts as ONE persistent launch (include/pilco_hip.h)."""
+        self._chk(self.lib.pilco_set_rollout_mode(self.h, int(mode)))
+
+    def last_rollout_mode(self):
+        return int(self.lib.pilco_last_rollout_mode(self.h))
 
     def set_pair_kernel(self, variant):
         self._chk(self.lib.pilco_set_pair_kernel(self.h, int(variant)))
@@ -475,6 +484,12 @@ class Context:
         n = C.c_int()
         self._chk(self.lib.pilco_get_pair_timing(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def debug_buffer(self, slot, which, n):
+        """Developer aid: raw copy of a device work buffer (include/pilco_hip.h: pilco_debug_buffer)."""
+        out = np.empty(int(n))
+        self._chk(self.lib.pilco_debug_buffer(self.h, int(slot), int(which), _ptr(out), int(n)))
+        return out
 
     def debug_timestamps(self, read=True):
         buf = (C.c_ulonglong * 64)()

@@ -1,0 +1,350 @@
+// Device code of the per-step operand work (operands of the pair kernel, mean parts, reward) shared by k_mm_prep
+// (prep.hip) and the persistent whole-rollout kernel (persist.hip).  Internal; gfx950 only.
+#pragma once
+#include "glue_device.h"
+
+namespace pilco {
+
+// 512 threads per workgroup = the whole register file of one CU.  The 256 rows of the chunk are
+// handled twice in parallel: threads 0..255 ("group 0") build the row-side operand, threads
+// 256..511 ("group 1") the column-side operand; on a diagonal pair both operands are the same
+// vectors, so group 0 writes both and group 1 does the mean / input-output covariance sums.
+// Mean / input-output-covariance sums of local output al over row chunk chm (mgpr.py:99-118), by one spare workgroup
+// of the prep launch: T = Lambda^-1 B^-1 Lambda^-1 = (s + Lambda^2)^-1 by a register Gauss-Jordan in wave 0 while the
+// other threads already have their point in flight; lb_i = exp(-zeta_i^T T zeta_i / 2) beta_i; partial c g and c T h
+// into mean_part[al][chm][1 + D].
+template <int DT, bool FUSED, int NTHR>
+__device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork& wk, int al, int chm, double* sm,
+                                                const double* jm, const double* js,   // joint Gaussian in LDS (FUSED head only)
+                                                const double la_t, const double var_a) {  // l_a[t] (t < D) and var_a, loaded by the caller
+    const int D = md.D, npad = md.npad;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: the role branches below are scalar branches
+    const bool act = (NTHR == 512) || t < 512;   // a host workgroup wider than 512 threads: the extra waves only keep the barriers
+    const int a = al * wk.nranks + wk.rank;   // global output: the owner of (a,a) owns output a
+    double* s_m = sm;                  // [DT]
+    double* s_ia = s_m + DT;           // [DT] 1 / l_a
+    double* s_s = s_ia + DT;           // [DT*DT] input covariance (D x D, ld D)
+    double* s_T = s_s + DT * DT;       // [DT*DT] ld DT
+    double* s_sc = s_T + DT * DT;      // [4]
+    double* red = s_sc + 4;            // 9 * (DT + 1)
+    double* colbuf = red + 9 * (DT + 1);   // [2 DT]
+    double* zst = colbuf + 2 * DT;         // [512][DT + 1] centred points of the chunk's first 512 rows
+    double* bst = zst + 512 * (DT + 1);    // [512] their beta_a
+    constexpr int LDZ = DT | 1;   // odd row stride: conflict-free LDS rows
+    if (t < DT) {
+        s_m[t] = (t < D) ? (FUSED ? jm[t] : wk.in_m[t]) : 0.0;
+        s_ia[t] = (t < D) ? 1.0 / la_t : 0.0;
+    }
+    for (int e = t; e < D * D; e += 512) s_s[e] = FUSED ? js[e] : wk.in_s[e];
+    for (int e = t; e < DT * DT; e += 512) s_T[e] = 0.0;
+    __syncthreads();
+    const bool dbgm = (t == 0 && al == 0 && chm == 0);
+    DBG_STAMP(wk, 40, dbgm);
+    const int rpc = npad / wk.NCHM;
+    const int i_begin = chm * rpc, i_end = i_begin + rpc;
+    if (w == 0) {
+        // [B | I],  B = Lambda^-1 s Lambda^-1 + I; T = Lambda^-1 B^-1 Lambda^-1   (mgpr.py:103-111)
+        double col[DT];
+        const int c = lane;
+#pragma unroll
+        for (int r = 0; r < DT; ++r) {
+            double v = 0.0;
+            if (c < DT) {
+                v = (r == c) ? 1.0 : 0.0;
+                if (r < D && c < D) v = fma(s_s[r * D + c], s_ia[r] * s_ia[c], v);
+            } else if (c < 2 * DT) {
+                v = (c - DT == r) ? 1.0 : 0.0;
+            }
+            col[r] = v;
+        }
+        const double detB = gj_wave<DT>(col, colbuf, lane);
+        if (c >= DT && c < DT + D) {
+            const int cc = c - DT;
+#pragma unroll
+            for (int r = 0; r < DT; ++r)
+                if (r < D) s_T[r * DT + cc] = col[r] * s_ia[r] * s_ia[cc];
+        }
+        if (lane == 0) s_sc[1] = var_a / sqrt(detB);
+    } else if (act) {
+        // the other seven waves stage the centred points of the chunk's first 512 rows meanwhile
+        const int idx = (w - 1) * 64 + lane;   // 0..447
+        for (int e = idx; e < 512 * D; e += 448) {
+            const int d = e >> 9, r = e & 511;
+            const int i = i_begin + r;
+            zst[r * LDZ + d] = (i < md.n && i < i_end) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
+        }
+        for (int r = idx; r < 512; r += 448) bst[r] = (i_begin + r < i_end) ? md.beta[mm_beta_row(md, a) * npad + i_begin + r] : 0.0;
+    }
+    __syncthreads();
+    DBG_STAMP(wk, 41, dbgm);
+    double g = 0.0;
+    double h[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) h[d] = 0.0;
+    // lb_i = exp(-zeta^T T zeta / 2) beta_i   (mgpr.py:113).  Rows are taken from the LDS stage only; a chunk longer
+    // than 512 rows is staged in rounds (no pointer ever selects between LDS and global memory).
+    for (int r0 = 0; r0 < rpc; r0 += 512) {
+        if (r0 > 0) {
+            __syncthreads();
+            for (int e = t; act && e < 512 * D; e += 512) {
+                const int d = e >> 9, r = e & 511;
+                const int i = i_begin + r0 + r;
+                zst[r * LDZ + d] = (i < md.n && i < i_end) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
+            }
+            if (act) bst[t] = (i_begin + r0 + t < i_end) ? md.beta[mm_beta_row(md, a) * npad + i_begin + r0 + t] : 0.0;
+            __syncthreads();
+        }
+        if (act && i_begin + r0 + t < i_end) {
+            double zeta[DT];
+#pragma unroll
+            for (int d = 0; d < DT; ++d) zeta[d] = (d < D) ? zst[t * LDZ + d] : 0.0;
+            double tz[DT];
+#pragma unroll
+            for (int r = 0; r < DT; ++r) tz[r] = 0.0;
+#pragma unroll
+            for (int c = 0; c < DT; ++c) {
+                double trow[DT];
+#pragma unroll
+                for (int r = 0; r < DT; ++r) trow[r] = s_T[c * DT + r];
+#pragma unroll
+                for (int r = 0; r < DT; ++r) tz[r] = fma(trow[r], zeta[c], tz[r]);
+                if ((c & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            double q = 0.0;
+#pragma unroll
+            for (int r = 0; r < DT; ++r) q = fma(zeta[r], tz[r], q);
+            const double lb = exp(-0.5 * q) * bst[t];
+            g += lb;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) h[d] = fma(zeta[d], lb, h[d]);
+        }
+    }
+    DBG_STAMP(wk, 42, dbgm);
+    g = wave_sum_lane63(g);
+    if (act && lane == 63) red[w * (DT + 1)] = g;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        const double v = wave_sum_lane63(h[d]);
+        if (act && lane == 63) red[w * (DT + 1) + 1 + d] = v;
+    }
+    __syncthreads();
+    // block sums of g and h (fixed order), then the M and V contributions of this row chunk:
+    // c g (mgpr.py:117) and c T h (mgpr.py:118, V = c tiL^T lb = c T sum_i zeta_i lb_i)
+    DBG_STAMP(wk, 43, dbgm);
+    double* hs = red + 8 * (DT + 1);  // [DT + 1]
+    if (t < 1 + D) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += red[k * (DT + 1) + t];
+        hs[t] = acc;
+    }
+    __syncthreads();
+    if (t < 1 + D) {
+        double v;
+        if (t == 0) {
+            v = s_sc[1] * hs[0];
+        } else {
+            double acc = 0.0;
+            _Pragma("unroll 8") for (int k = 0; k < D; ++k) acc = fma(s_T[(t - 1) * DT + k], hs[1 + k], acc);
+            v = s_sc[1] * acc;
+        }
+        store_wt(&wk.mean_part[((long)al * wk.NCHM + chm) * (1 + D) + t], v);   // indexed by the LOCAL output number; write-through: the
+                                                                                 // persistent kernel hands it to other workgroups without an L2 write-back
+    }
+    DBG_STAMP(wk, 44, dbgm);
+}
+
+// The per-workgroup work of the operand launch AFTER the serial link: the operands of one (local pair, row chunk), or the
+// mean part of one (local output, row chunk), or the reward -- selected by the item coordinates (bx, by) of a gx x gy item
+// grid (k_mm_prep: its own block index; the persistent rollout kernel: a fixed item per workgroup).  NTHR: threads of
+// the host workgroup; the work is laid out for 512, wider workgroups keep their extra waves idle between the barriers.
+template <int DT, bool FUSED, int NTHR>
+__device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, const PrepReward& pr, const GlueArgs& g, const GlueLds& L,
+                                          double* sm_all, int glue_doubles, int bx, int by, int gx, int gy, double pre_la, double pre_lb,
+                                          double pre_var) {
+    double* sm = sm_all + (FUSED ? glue_doubles : 0);
+    // the Gaussian this launch's operands are built for: the joint (x, u) the link assembled, or -- policy head of an
+    // RbfController (GF_RBF_PRE) -- the state itself, the input of the policy GP.  (Integer offsets, not a pointer select.)
+    const bool state_in = FUSED && (g.flags & GF_RBF_PRE);
+    const double* jm = sm_all + (state_in ? 0 : L.o_js - L.nm);
+    const double* js = sm_all + (state_in ? L.o_sx : L.o_js);
+    if (bx >= wk.PL) {
+        // spare workgroups of the launch: first the mean parts (local output, row chunk), then the reward
+        const int idx = (bx - wk.PL) * gy + by;
+        const int nmean = wk.EL * wk.NCHM;
+        const int slot = 64 + 2 * (by * gx + bx);
+        if (wk.dbg && threadIdx.x == 0 && slot < 958) wk.dbg[slot] = wall_clock64();
+        if (idx < nmean) {
+            prep_mean_block<DT, FUSED, NTHR>(md, wk, idx / wk.NCHM, idx % wk.NCHM, sm, jm, js, pre_la, pre_var);
+            if (wk.dbg && threadIdx.x == 0 && slot < 958) wk.dbg[slot + 1] = wall_clock64();
+            return;
+        }
+        // mean reward of the current (pre-propagation) state (rewards.py:19-81, pilco.py:133)
+        if (idx != nmean || pr.n <= 0) return;
+        const int E = pr.E, t = threadIdx.x;
+        double* mx = sm;              // [E]
+        double* sx = mx + E;          // [E][E]
+        double* ws = sx + E * E;      // reward_lds_doubles(E)
+        if (FUSED) {
+            if (t < E) mx[t] = L.mx[t];
+            for (int e = t; e < E * E; e += blockDim.x) sx[e] = L.sx[e];
+        } else {
+            if (t < E) mx[t] = pr.m_x[t];
+            for (int e = t; e < E * E; e += blockDim.x) sx[e] = pr.s_x[e];
+        }
+        __syncthreads();
+        double mu, var;
+        reward_eval(pr.n, pr.rw, E, mx, sx, ws, false, mu, var);
+        if (t == 0) pr.reward[0] += mu;
+        if (wk.dbg && t == 0 && slot < 958) wk.dbg[slot + 1] = wall_clock64();
+        return;
+    }
+    const int D = md.D, npad = md.npad;
+    double* s_m = sm;
+    double* s_ia2 = s_m + DT;
+    double* s_ib2 = s_ia2 + DT;
+    double* s_s = s_ib2 + DT;          // [DT*DT] input covariance (D x D, ld D)
+    double* s_Q = s_s + DT * DT;       // [DT*DT] ld DT
+    double* s_sc = s_Q + DT * DT;      // [4] isdet
+    double* colbuf = s_sc + 4;         // DT (unused by the readlane Gauss-Jordan)
+    double* zst = colbuf + DT;         // [256][DT + 1] centred points of the first 256 rows
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: the role branches below are scalar branches
+    const bool act = (NTHR == 512) || t < 512;   // a host workgroup wider than 512 threads: the extra waves only keep the barriers
+    const int grp = t >> 8, tl = t & 255;
+    const int pl = bx, ch = by;
+    const bool dbg0 = (t == 0 && pl == 0 && ch == 0);
+    DBG_STAMP(wk, 0, dbg0);
+    if (wk.dbg && t == 0) wk.dbg[64 + 2 * (by * gx + bx)] = wall_clock64();
+    if (t < DT) {
+        double la = 1.0, lb = 1.0, mm = 0.0;
+        if (t < D) {
+            mm = FUSED ? jm[t] : wk.in_m[t];
+            la = pre_la;
+            lb = pre_lb;
+        }
+        s_m[t] = mm;
+        s_ia2[t] = (t < D) ? 1.0 / (la * la) : 0.0;
+        s_ib2[t] = (t < D) ? 1.0 / (lb * lb) : 0.0;
+    }
+    for (int e = t; e < D * D; e += 512) s_s[e] = FUSED ? js[e] : wk.in_s[e];
+    for (int e = t; e < DT * DT; e += 512) s_Q[e] = 0.0;   // padded rows / columns of Q stay zero
+    __syncthreads();
+    DBG_STAMP(wk, 1, dbg0);
+    const int rpc = npad / wk.NCH;
+    const int i_begin = ch * rpc, i_end = i_begin + rpc;
+    // The centred points of the chunk's first 256 rows are staged in LDS by the seven waves that do not run the
+    // Gauss-Jordan, so their load latency (and the log of the signal variance) hides behind that phase.
+    // side 0 (threads 0..255): x = zeta / la^2 -> row operand (2 Q z | u | 1); side 1: x = zeta / lb^2 -> column
+    // operand (w | 1 | v).  A diagonal pair (a == b) is not special here: its mean part runs in prep_mean_block.
+    const int side = grp;
+    constexpr int LDZ = DT | 1;   // odd row stride: conflict-free LDS rows
+    if (w != 0 && act) {
+        const int idx = (w - 1) * 64 + lane;   // 0..447
+        for (int e = idx; e < 256 * D; e += 448) {
+            const int d = e >> 8, r = e & 255;
+            const int i = i_begin + r;
+            zst[r * LDZ + d] = (i < md.n && i < i_end) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
+        }
+    }
+    const double logvar = log(pre_var);
+    if (MM_ABL(wk, 2)) {
+        if (t == 0) s_sc[0] = 1.0;
+    } else if (w == 0) {
+        // [R | s],  R = s diag(la^-2 + lb^-2) + I        (mgpr.py:121-124,129); padded with identity
+        double col[DT];
+        const int c = lane;
+#pragma unroll
+        for (int r = 0; r < DT; ++r) {
+            double v = 0.0;
+            if (c < DT) {
+                v = (r == c) ? 1.0 : 0.0;
+                if (r < D && c < D) v = fma(s_s[r * D + c], s_ia2[c] + s_ib2[c], v);
+            } else if (c < 2 * DT) {
+                const int cc = c - DT;
+                if (r < D && cc < D) v = s_s[r * D + cc];
+            }
+            col[r] = v;
+        }
+        const double det = gj_wave<DT>(col, colbuf, lane);
+        if (c >= DT && c < DT + D) {
+#pragma unroll
+            for (int r = 0; r < DT; ++r)
+                if (r < D) s_Q[r * DT + (c - DT)] = 0.5 * col[r];
+        }
+        if (lane == 0) {
+            s_sc[0] = 1.0 / sqrt(det);
+            if (ch == 0) store_wt(&wk.pair_isdet[pl], s_sc[0]);
+        }
+    }
+    __syncthreads();
+    DBG_STAMP(wk, 2, dbg0);
+    const int KP = wk.KP;
+    double* At = wk.At + (long)pl * KP * npad;
+    double* Bt = wk.Bt + (long)pl * KP * npad;
+    auto row = [&](const int i, const bool valid, const double (&zeta)[DT]) {
+        // y = Q x by columns of the symmetric Q: DT independent accumulators, one wide LDS row
+        // read per column step (no LDS latency on the FMA chains).
+        const double* il2 = side ? s_ib2 : s_ia2;   // padding entries are zero
+        double x[DT], y[DT];
+        double kk = logvar;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            x[d] = zeta[d] * il2[d];
+            kk = fma(-0.5 * zeta[d], x[d], kk);
+            y[d] = 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < DT; ++c) {
+            double qrow[DT];
+#pragma unroll
+            for (int r = 0; r < DT; ++r) qrow[r] = s_Q[c * DT + r];
+#pragma unroll
+            for (int r = 0; r < DT; ++r) y[r] = fma(qrow[r], x[c], y[r]);
+            if ((c & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // keep at most two rows of Q in flight
+        }
+        double quad = 0.0;
+#pragma unroll
+        for (int r = 0; r < DT; ++r) quad = fma(x[r], y[r], quad);
+        const double uv = valid ? (kk + quad) : 0.0;
+        const double one = valid ? 1.0 : 0.0;
+        if (side == 0) {
+#pragma unroll
+            for (int r = 0; r < DT; ++r)
+                if (r < D) store_wt(&At[(long)r * npad + i], 2.0 * y[r]);   // 2 Q z_i (0 on padded rows)
+            store_wt(&At[(long)D * npad + i], uv);                           // u_i
+            if (!wk.vsep) store_wt(&At[(long)(D + 1) * npad + i], one);
+            for (int k = D + 2; k < KP; ++k) store_wt(&At[(long)k * npad + i], 0.0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < DT; ++r)
+                if (r < D) store_wt(&Bt[(long)r * npad + i], x[r]);         // w_j
+            store_wt(&Bt[(long)D * npad + i], one);
+            if (wk.vsep) store_wt(&wk.vcol[(long)pl * npad + i], uv);        // v_j, added after the K = D + 1 contraction
+            else store_wt(&Bt[(long)(D + 1) * npad + i], uv);                // v_j, riding in the contraction
+            for (int k = D + 2; k < KP; ++k) store_wt(&Bt[(long)k * npad + i], 0.0);
+        }
+    };
+    if (!MM_ABL(wk, 4) && act) {
+        if (i_begin + tl < i_end) {   // first row of this thread: centred point from the LDS stage
+            const int i = i_begin + tl;
+            double zeta[DT];
+#pragma unroll
+            for (int d = 0; d < DT; ++d) zeta[d] = (d < D) ? zst[tl * LDZ + d] : 0.0;
+            row(i, i < md.n, zeta);
+        }
+        for (int i = i_begin + tl + 256; i < i_end; i += 256) {   // chunks longer than 256 rows
+            const bool valid = i < md.n;
+            double zeta[DT];
+#pragma unroll
+            for (int d = 0; d < DT; ++d) zeta[d] = (d < D && valid) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
+            row(i, valid, zeta);
+        }
+    }
+    DBG_STAMP(wk, 3, dbg0);
+    DBG_STAMP(wk, 4, dbg0);
+    if (wk.dbg && t == 0) wk.dbg[65 + 2 * (by * gx + bx)] = wall_clock64();
+}
+
+}  // namespace pilco

@@ -359,6 +359,78 @@ def test_headline_rollout_h40_vs_executed_reference(ctx, golden_dir, tag, D, noi
     np.testing.assert_allclose(S2, S, rtol=1e-13)
 
 
+@pytest.mark.parametrize("N,D,E,H", [(1000, 10, 10, 12), (1000, 11, 10, 8), (130, 4, 3, 5), (300, 6, 4, 9), (200, 12, 10, 4), (257, 3, 2, 6)])
+def test_persistent_rollout_is_bitwise_identical_to_the_launch_sequence(N, D, E, H):
+    """pilco_set_rollout_mode(ctx, 1): the whole rollout as ONE resident launch (csrc/persist.hip; the reference's
+    tf.while_loop, pilco.py:126-135, as a single kernel) -- phases ordered by flags in device memory, no cache maintenance,
+    every step's operands in buffers of its own.  Same device code, same stream-K decomposition as the launch sequence:
+    every state of the trajectory, the final state and the reward agree TO THE LAST BIT (so a stale or early read of another
+    workgroup's data cannot hide), run after run, with and without a controller, at the benchmarked size and small ones."""
+    from pilco_amd import _lib
+    c = synthetic.config_c2(N=N, D=D, E=E)
+    U = D - E
+    if U > 0:
+        pol = dict(kind=_lib.POLICY_LINEAR, state_dim=E, control_dim=U, W=c["W"], b=c["b"], max_action=np.ones(U), squash=1)
+    else:
+        pol = dict(kind=_lib.POLICY_NONE, state_dim=E, control_dim=0)
+    rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(E), t=np.zeros(E))]
+    cx = _lib.Context()
+    try:
+        cx.gp_set_data(0, c["X"], c["Y"]); cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"]); cx.gp_factorize(0)
+        # DIFFERENT initial states in consecutive launches: a read that comes too early, or from a stale cache line, returns
+        # what the previous launch left in the same buffer -- with identical inputs that would be the right bits
+        rs = np.random.RandomState(N + D)
+        starts = [(c["m0"], c["S0"]), (c["m0"] + 0.3 * rs.randn(1, E), 0.05 * np.eye(E)), (c["m0"], c["S0"]),
+                  (-c["m0"], 0.2 * np.eye(E))]
+        want = []
+        cx.set_rollout_mode(0)
+        for m0, S0 in starts:
+            want.append(cx.rollout(pol, rw, m0, S0, H, want_traj=True))
+            assert cx.last_rollout_mode() == 0
+        cx.set_rollout_mode(1)
+        for rep in range(2):
+            for (m0, S0), ref in zip(starts, want):
+                out = cx.rollout(pol, rw, m0, S0, H, want_traj=True)
+                assert cx.last_rollout_mode() == 1
+                for x, y in zip(ref, out):
+                    assert np.array_equal(np.asarray(x), np.asarray(y))
+                short = cx.rollout(pol, rw, m0, S0, 1)       # another horizon in between: its own per-step buffers
+                assert np.array_equal(short[0][0], out[3][1, :E])
+        assert np.all(np.isfinite(want[0][3]))
+    finally:
+        cx.close()
+
+
+def test_persistent_rollout_gives_up_and_falls_back_when_it_cannot_make_progress(monkeypatch):
+    """Every wait of the persistent launch is bounded by the wall clock: with the bound set to zero the first flag that is
+    not up yet makes the launch give up; the call then repeats the rollout on the launch sequence (same bits), reports
+    which path ran, and the context stays on the launch sequence until the mode is set again."""
+    from pilco_amd import _lib
+    c = synthetic.config_c2(N=300, D=6, E=5)
+    pol = dict(kind=_lib.POLICY_LINEAR, state_dim=5, control_dim=1, W=c["W"], b=c["b"], max_action=np.ones(1), squash=1)
+    rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(5), t=np.zeros(5))]
+    cx = _lib.Context()
+    try:
+        cx.gp_set_data(0, c["X"], c["Y"]); cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"]); cx.gp_factorize(0)
+        ref = cx.rollout(pol, rw, c["m0"], c["S0"], 7)
+        cx.set_rollout_mode(1)
+        monkeypatch.setenv("PILCO_PERSIST_TIMEOUT_MS", "0")
+        out = cx.rollout(pol, rw, c["m0"], c["S0"], 7)
+        assert cx.last_rollout_mode() == 0                         # the persistent launch gave up; the sequence delivered
+        for x, y in zip(ref, out):
+            assert np.array_equal(x, y)
+        monkeypatch.delenv("PILCO_PERSIST_TIMEOUT_MS")
+        cx.rollout(pol, rw, c["m0"], c["S0"], 7)
+        assert cx.last_rollout_mode() == 0                         # stays off ...
+        cx.set_rollout_mode(1)                                     # ... until asked for again
+        out2 = cx.rollout(pol, rw, c["m0"], c["S0"], 7)
+        assert cx.last_rollout_mode() == 1
+        for x, y in zip(ref, out2):
+            assert np.array_equal(x, y)
+    finally:
+        cx.close()
+
+
 @pytest.mark.parametrize("D", [10, 11])
 def test_fused_head_is_bitwise_identical_to_the_three_kernel_step(ctx, D):
     """The fused head (serial link inside the next step's operand kernel, 2 launches per step) and the separate link
