@@ -205,6 +205,29 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
         out["persistent_launch"] = {"error": repr(exc)}
     finally:
         ctx.set_rollout_mode(0)
+    # pilco_rollout_batch: B independent rollouts of this model in flight together (lanes borrow the model; the serial head of
+    # one lane runs under the pair kernels of the others).  Throughput mode for multi-start policy search / several initial
+    # states; NEVER the headline (`value` is one rollout at a time, as PILCO.predict is called).
+    try:
+        rs = np.random.RandomState(7)
+        batched = {}
+        for B in (4, 8):
+            m0b = cfg["m0"] + 0.05 * rs.randn(B, E)
+            S0b = np.stack([cfg["S0"]] * B)
+            mB, SB, RB = ctx.rollout_batch([policy] * B, rewards, m0b, S0b, H)
+            solo = ctx.rollout(policy, rewards, m0b[B - 1], S0b[B - 1], H)
+            same = bool(np.array_equal(mB[B - 1], solo[0][0]) and np.array_equal(SB[B - 1], solo[1]) and RB[B - 1] == solo[2][0, 0])
+            reps = max(3, steps // 2)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ctx.rollout_batch([policy] * B, rewards, m0b, S0b, H)
+            dt = time.perf_counter() - t0
+            batched["B=%d" % B] = {"rollouts_per_s": B * reps / dt, "ms_per_batch": dt / reps * 1e3, "last_lane_bit_identical_to_its_solo_run": same}
+        batched["note"] = ("aggregate over B lanes, host-synchronised with every lane's result downloaded; bound by the pair kernel alone: "
+                           "1 / (40 x its launch duration)")
+        out["batched_rollouts"] = batched
+    except Exception as exc:
+        out["batched_rollouts"] = {"error": repr(exc)}
     fact_ms = ctx.factorize_timed(0, 5)
     out["factorisation_ms"] = fact_ms
     out["R_fwd_fact_rollouts_per_s"] = 1e3 / (fact_ms + ms_rollout)

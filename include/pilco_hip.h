@@ -158,6 +158,16 @@ typedef struct pilco_reward_term {
  * The factorisation of slot 0 (and slot 1 for an RBF policy) must be current. */
 int pilco_rollout(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
                   const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj);
+/* B independent rollouts of ONE model in flight together on one GPU: policies [B] (NONE / LINEAR; each lane may have its
+ * own parameters), m0 [B][E], S0 [B][E][E] -> mH [B][E], SH [B][E][E], reward [B].  What multi-start policy search and the
+ * evaluation of several initial states need (the reference evaluates its restarts one after the other, pilco.py:96-110).
+ * Lanes 1..B-1 are internal contexts (own stream, workspace, state, cached graph) that borrow this context's model -- no
+ * copy of X / beta / iK; all B graph replays are enqueued before the first wait, so the serial head of one lane's step
+ * runs under the pair kernels of the others.  Every lane runs exactly pilco_rollout's launch sequence: its result is
+ * BIT-IDENTICAL to its solo run.  Single rank.  More than 4 lanes overlap only if the HIP runtime has as many hardware
+ * queues (GPU_MAX_HW_QUEUES, set before the runtime starts). */
+int pilco_rollout_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
+                        const double* m0, const double* S0, int H, double* mH, double* SH, double* reward);
 /* PILCO.propagate (pilco/models/pilco.py:138-153): one step, no reward. */
 int pilco_propagate(pilco_ctx* ctx, const pilco_policy* policy, const double* m_x, const double* s_x, double* M_x, double* S_x);
 /* controller.compute_action(m, s, squash) -> M (1,U), S (U,U), V (E,U)

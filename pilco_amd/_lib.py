@@ -87,6 +87,7 @@ SIGNATURES = {
     "pilco_rollout_grad_rbf_seeded": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
                                                 _dp, _dp, _dp, _dp, C.c_int, SEED_FN, _vp, _dp, _dp, _dp, _dp]),
     "pilco_propagate": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp]),
+    "pilco_rollout_batch": (C.c_int, [_vp, C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]),
     "pilco_policy_action": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp, _dp]),
     "pilco_reward_eval": (C.c_int, [_vp, C.POINTER(RewardTerm), C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
     "pilco_rollout_timed": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp,
@@ -349,6 +350,27 @@ class Context:
                                          _ptr(mH), _ptr(SH), _ptr(rew), _ptr(traj)))
         if want_traj:
             return mH, SH, rew, traj
+        return mH, SH, rew
+
+    def rollout_batch(self, policies, rewards, m0, S0, H):
+        """B independent rollouts of the same model in flight together (pilco_rollout_batch): policies: list of B policy
+        specs (kind NONE / LINEAR), m0 (B, E), S0 (B, E, E) -> mH (B, E), SH (B, E, E), reward (B,).  Each lane is
+        bit-identical to its solo rollout."""
+        B = len(policies)
+        E = policies[0]["state_dim"]
+        arr = (PolicyStruct * B)()
+        keep = []
+        for i, spec in enumerate(policies):
+            p, k = self._policy(spec)
+            keep.append((p, k))
+            arr[i] = p
+        r, k2 = self._rewards(rewards, E)
+        m0 = _f64(m0, (B, E))
+        S0 = _f64(S0, (B, E, E))
+        mH = np.empty((B, E))
+        SH = np.empty((B, E, E))
+        rew = np.zeros(B)
+        self._chk(self.lib.pilco_rollout_batch(self.h, B, arr, r, len(rewards), _ptr(m0), _ptr(S0), int(H), _ptr(mH), _ptr(SH), _ptr(rew)))
         return mH, SH, rew
 
     def gp_predict_vjp(self, slot, m, s, Mbar, Sbar, Vbar, D, E):

@@ -294,6 +294,8 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
 
 int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (!ctx) return PILCO_OK;
+    for (pilco_ctx* lane : ctx->lanes) (void)pilco_ctx_destroy(lane);   // (their borrowed model buffers are not freed there)
+    ctx->lanes.clear();
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->st);
     (void)peer_detach(ctx);

@@ -19,19 +19,28 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 struct DevBuf {
     double* p = nullptr;
     size_t cap = 0;  // in doubles
+    bool borrowed = false;  // a view of another context's buffer (rollout lanes share their parent's model): never freed here
     hipError_t ensure(size_t count) {
         if (count <= cap && p) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        borrowed = false;
         hipError_t e = hipMalloc(&p, count * sizeof(double));
         if (e == hipSuccess) cap = count;
         return e;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        borrowed = false;
+    }
+    void borrow(const DevBuf& o) {
+        release();
+        p = o.p;
+        cap = o.cap;
+        borrowed = o.p != nullptr;
     }
 };
 

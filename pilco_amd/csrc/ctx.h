@@ -140,6 +140,10 @@ struct pilco_ctx {
     size_t pin_io_cap = 0;
     const double* params_dev = nullptr;
     std::vector<double> params_host;   // what ctx->params holds on the device: identical parameters are not uploaded again
+    // pilco_rollout_batch: lanes 1.. of a batch are contexts of their own (stream, workspace, state, graph cache) whose
+    // dynamics slot BORROWS this context's model buffers; owned and destroyed by this context
+    std::vector<pilco_ctx*> lanes;
+    bool is_lane = false;
 };
 
 int fail(pilco_ctx* c, int code, const std::string& msg);

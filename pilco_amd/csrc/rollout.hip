@@ -755,12 +755,23 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
 
 extern "C" {
 
-int pilco_rollout(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
-                  const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj) {
-    if (!ctx) return PILCO_E_SHAPE;
-    if (!m0 || !S0 || !mH || !SH || !reward || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout: bad arguments");
-    HIPCHK(hipSetDevice(ctx->device));
+}  // extern "C"
+
+// pilco_rollout in two halves, so that several rollouts (the lanes of pilco_rollout_batch) can be in flight at once:
+// rollout_begin enqueues everything -- upload of (m0, S0), the rollout, the downloads into pinned memory -- and returns;
+// rollout_end waits for the stream and hands the results out.  *retry: the persistent launch gave up (call again).
+struct RolloutCall {
     RolloutPlan plan;
+    size_t nst = 0;
+    double* pin_out = nullptr;
+    bool peer = false;
+    const unsigned long long* abortw = nullptr;
+    unsigned long long* pin_abort = nullptr;
+};
+static int rollout_begin(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
+                         const double* S0, int H, double* traj, RolloutCall& rc) {
+    HIPCHK(hipSetDevice(ctx->device));
+    RolloutPlan& plan = rc.plan;
     if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, traj != nullptr, plan)) return r;
     const int E = plan.E;
     // one pinned staging area: [m0 | S0] up in ONE asynchronous copy, [m_H | S_H] and the reward down in two, one host
@@ -788,27 +799,134 @@ int pilco_rollout(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     HIPCHK(hipMemcpyAsync(pin_out + nst, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
     if (traj)
         HIPCHK(hipMemcpyAsync(traj, ctx->traj.p, sizeof(double) * (size_t)(H + 1) * (E + E * E), hipMemcpyDeviceToHost, ctx->st));
-    const bool peer = peer_rollout_applies(ctx, plan, H);
-    if (peer) HIPCHK(hipMemcpyAsync(ctx->xq.pin + 128, ctx->xq.local + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->st));
-    const unsigned long long* abortw = persist_abort_word(ctx);
-    unsigned long long* pin_abort = reinterpret_cast<unsigned long long*>(pin_out + nst + 2);
-    if (abortw) HIPCHK(hipMemcpyAsync(pin_abort, abortw, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->st));
+    rc.peer = peer_rollout_applies(ctx, plan, H);
+    if (rc.peer) HIPCHK(hipMemcpyAsync(ctx->xq.pin + 128, ctx->xq.local + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->st));
+    rc.abortw = persist_abort_word(ctx);
+    rc.pin_abort = reinterpret_cast<unsigned long long*>(pin_out + nst + 2);
+    if (rc.abortw) HIPCHK(hipMemcpyAsync(rc.pin_abort, rc.abortw, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->st));
+    rc.nst = nst;
+    rc.pin_out = pin_out;
+    return PILCO_OK;
+}
+static int rollout_end(pilco_ctx* ctx, RolloutCall& rc, double* mH, double* SH, double* reward, bool* retry) {
+    *retry = false;
+    HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());
-    if (abortw && pin_abort[0] == ctx->persist_epoch) {   // the persistent launch could not make progress (GPU shared?):
-        ctx->persist_broken = true;                       // once more, and from now on, on the launch sequence
-        return pilco_rollout(ctx, policy, rewards, n_rewards, m0, S0, H, mH, SH, reward, traj);
+    if (rc.abortw && rc.pin_abort[0] == ctx->persist_epoch) {   // the persistent launch could not make progress (GPU shared?):
+        ctx->persist_broken = true;                             // once more, and from now on, on the launch sequence
+        *retry = true;
+        return PILCO_OK;
     }
-    if (peer && ctx->xq.pin[128] != 0ULL) {   // a flag wait gave up: some rank never delivered that exchange
+    if (rc.peer && ctx->xq.pin[128] != 0ULL) {   // a flag wait gave up: some rank never delivered that exchange
         const unsigned long long ep = ctx->xq.pin[128];
         (void)hipMemsetAsync(ctx->xq.local + 1, 0, sizeof(unsigned long long), ctx->st);
         return fail(ctx, PILCO_E_STATE, "rollout: peer exchange " + std::to_string(ep) + " timed out on rank " + std::to_string(ctx->rank) +
                                             " (the ranks must make the same sequence of rollout calls)");
     }
-    memcpy(mH, pin_out, sizeof(double) * E);
-    memcpy(SH, pin_out + E, sizeof(double) * E * E);
-    *reward = pin_out[nst];
+    const int E = rc.plan.E;
+    memcpy(mH, rc.pin_out, sizeof(double) * E);
+    memcpy(SH, rc.pin_out + E, sizeof(double) * E * E);
+    *reward = rc.pin_out[rc.nst];
     return PILCO_OK;
+}
+
+// A lane of pilco_rollout_batch: a context of its own whose dynamics slot borrows the parent's model.  (Re)pointed at the
+// parent's current buffers before every batch; a changed geometry drops the lane's workspace and graphs.
+static int lane_sync_model(pilco_ctx* parent, pilco_ctx* lane) {
+    const Slot& p = parent->slot[0];
+    Slot& l = lane->slot[0];
+    const bool same = l.N == p.N && l.D == p.D && l.E == p.E && l.M == p.M && l.Npad == p.Npad && l.n == p.n && l.npad == p.npad &&
+                      l.iK_null == p.iK_null && l.Xt.p == p.Xt.p && l.Zt.p == p.Zt.p && l.beta.p == p.beta.p && l.iK.p == p.iK.p &&
+                      l.ls.p == p.ls.p && l.var.p == p.var.p;
+    l.N = p.N; l.D = p.D; l.E = p.E; l.M = p.M; l.Npad = p.Npad; l.n = p.n; l.npad = p.npad;
+    l.has_data = p.has_data; l.has_hyp = p.has_hyp; l.factor_valid = p.factor_valid; l.user_factors = p.user_factors;
+    l.iK_null = p.iK_null; l.ignore_iK = p.ignore_iK;
+    l.shW = p.shW; l.shEL = p.shEL; l.shOwn = p.shOwn; l.shRank = p.shRank; l.beta_complete = p.beta_complete;
+    l.Xt.borrow(p.Xt); l.Yt.borrow(p.Yt); l.Zt.borrow(p.Zt); l.ls.borrow(p.ls); l.var.borrow(p.var); l.noise.borrow(p.noise);
+    l.beta.borrow(p.beta); l.iK.borrow(p.iK);
+    lane->variant = parent->variant;
+    lane->fused = parent->fused;
+    lane->use_graph = parent->use_graph;
+    lane->persist = 0;   // lanes overlap each other's serial heads; a persistent launch would claim every CU for one lane
+    if (!same) {
+        l.wk_valid = false;
+        for (auto& ge : lane->graph_cache) (void)hipGraphExecDestroy(ge.second);
+        lane->graph_cache.clear();
+        lane->graph = nullptr;
+    }
+    return PILCO_OK;
+}
+
+extern "C" {
+
+int pilco_rollout(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                  const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (!m0 || !S0 || !mH || !SH || !reward || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout: bad arguments");
+    RolloutCall rc;
+    if (int r = rollout_begin(ctx, policy, rewards, n_rewards, m0, S0, H, traj, rc)) return r;
+    bool retry = false;
+    if (int r = rollout_end(ctx, rc, mH, SH, reward, &retry)) return r;
+    if (retry) return pilco_rollout(ctx, policy, rewards, n_rewards, m0, S0, H, mH, SH, reward, traj);
+    return PILCO_OK;
+}
+
+// B independent rollouts of ONE model in flight together (multi-start policy search, several initial states; the restart
+// loop of pilco.py:96-110 evaluates its candidates one after the other).  Lane 0 is this context; lanes 1..B-1 are
+// contexts of their own -- stream, per-step workspace, state, policy parameters, cached graph -- that borrow this context's
+// model (X, hyper-parameters, beta, iK are not copied).  All B graph replays are enqueued before the first wait, so the
+// serial head of one lane's step (a chain of latencies that leaves the chip idle) runs under the pair kernels of the
+// others.  Every lane runs exactly the launch sequence of pilco_rollout: its result is bit-identical to its solo run.
+int pilco_rollout_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
+                        const double* m0, const double* S0, int H, double* mH, double* SH, double* reward) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (B <= 0 || B > 64 || !policies || !m0 || !S0 || !mH || !SH || !reward || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout_batch: bad arguments");
+    if (ctx->nranks != 1 || ctx->comm) return fail(ctx, PILCO_E_STATE, "rollout_batch: single rank only (shard OR batch)");
+    for (int i = 0; i < B; ++i)
+        if (policies[i].kind == PILCO_POLICY_RBF) return fail(ctx, PILCO_E_SHAPE, "rollout_batch: RbfController lanes are not supported (one policy GP slot per context)");
+    HIPCHK(hipSetDevice(ctx->device));
+    const Slot& s = ctx->slot[0];
+    if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "rollout_batch: dynamics model has no current factorisation");
+    while ((int)ctx->lanes.size() < B - 1) {
+        pilco_ctx* lane = nullptr;
+        if (int r = pilco_ctx_create(ctx->device, &lane)) return fail(ctx, r, "rollout_batch: could not create a lane context");
+        lane->is_lane = true;
+        ctx->lanes.push_back(lane);
+    }
+    const int E = s.E;
+    const size_t nst = (size_t)E + (size_t)E * E;
+    std::vector<RolloutCall> rc((size_t)B);
+    std::vector<pilco_ctx*> lane((size_t)B);
+    for (int i = 0; i < B; ++i) {
+        lane[i] = i == 0 ? ctx : ctx->lanes[i - 1];
+        if (i > 0) {
+            HIPCHK(hipStreamSynchronize(lane[i]->st));
+            if (int r = lane_sync_model(ctx, lane[i])) return r;
+        }
+    }
+    // the parent's model must be complete in memory before another stream reads it
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    int rc_err = PILCO_OK;
+    int begun = 0;
+    for (int i = 0; i < B; ++i, ++begun) {
+        rc_err = rollout_begin(lane[i], &policies[i], rewards, n_rewards, m0 + (size_t)i * E, S0 + (size_t)i * E * E, H, nullptr, rc[i]);
+        if (rc_err) {
+            if (i > 0) ctx->err = "lane " + std::to_string(i) + ": " + lane[i]->err;
+            break;
+        }
+    }
+    for (int i = 0; i < begun; ++i) {
+        bool retry = false;
+        const int r = rollout_end(lane[i], rc[i], mH + (size_t)i * E, SH + (size_t)i * E * E, reward + i, &retry);
+        if (r && !rc_err) {
+            rc_err = r;
+            if (i > 0) ctx->err = "lane " + std::to_string(i) + ": " + lane[i]->err;
+        }
+        (void)retry;   // lanes never run persistent launches
+    }
+    (void)nst;
+    return rc_err;
 }
 
 int pilco_propagate(pilco_ctx* ctx, const pilco_policy* policy, const double* m_x, const double* s_x, double* M_x, double* S_x) {

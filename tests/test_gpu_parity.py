@@ -401,6 +401,43 @@ def test_persistent_rollout_is_bitwise_identical_to_the_launch_sequence(N, D, E,
         cx.close()
 
 
+@pytest.mark.parametrize("N,D,E,H,B", [(1000, 11, 10, 6, 5), (200, 4, 3, 9, 8), (400, 10, 10, 5, 3)])
+def test_batched_rollouts_are_bit_identical_to_their_solo_runs(N, D, E, H, B):
+    """pilco_rollout_batch: B rollouts of one model in flight together (each lane its own policy parameters and initial
+    state; lanes borrow the model, nothing is copied).  Every lane must deliver exactly the bits of its solo pilco_rollout,
+    also after the model has been replaced (the lanes re-point at the new buffers)."""
+    from pilco_amd import _lib
+    rs = np.random.RandomState(B * 7 + D)
+    cx = _lib.Context()
+    try:
+        for trial in range(2):
+            c = synthetic.config_c2(N=N - 64 * trial, D=D, E=E, seed=1234 + trial)
+            U = D - E
+            cx.gp_set_data(0, c["X"], c["Y"]); cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"]); cx.gp_factorize(0)
+            pols, m0s, S0s = [], [], []
+            for i in range(B):
+                if U > 0:
+                    pols.append(dict(kind=_lib.POLICY_LINEAR, state_dim=E, control_dim=U, W=c["W"] + 0.05 * rs.randn(U, E),
+                                     b=0.1 * rs.randn(U), max_action=np.ones(U) * (1.0 + 0.1 * i), squash=1))
+                else:
+                    pols.append(dict(kind=_lib.POLICY_NONE, state_dim=E, control_dim=0))
+                m0s.append(c["m0"][0] + 0.1 * rs.randn(E))
+                S0s.append((0.05 + 0.02 * i) * np.eye(E))
+            rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(E), t=np.zeros(E))]
+            solo = [cx.rollout(pols[i], rw, m0s[i], S0s[i], H) for i in range(B)]
+            for rep in range(2):
+                mH, SH, R = cx.rollout_batch(pols, rw, np.stack(m0s), np.stack(S0s), H)
+                for i in range(B):
+                    assert np.array_equal(mH[i], solo[i][0][0]) and np.array_equal(SH[i], solo[i][1]) and R[i] == solo[i][2][0, 0], (trial, rep, i)
+            # a smaller batch afterwards, and a solo call in between, use the same lanes
+            mH, SH, R = cx.rollout_batch(pols[:2], rw, np.stack(m0s[:2]), np.stack(S0s[:2]), H)
+            assert np.array_equal(mH[1], solo[1][0][0]) and R[0] == solo[0][2][0, 0]
+        with pytest.raises(_lib.PilcoError):
+            cx.rollout_batch([dict(kind=_lib.POLICY_RBF, state_dim=E, control_dim=max(U, 1))], rw, np.stack(m0s[:1]), np.stack(S0s[:1]), H)
+    finally:
+        cx.close()
+
+
 def test_persistent_rollout_gives_up_and_falls_back_when_it_cannot_make_progress(monkeypatch):
     """Every wait of the persistent launch is bounded by the wall clock: with the bound set to zero the first flag that is
     not up yet makes the launch give up; the call then repeats the rollout on the launch sequence (same bits), reports
