@@ -420,6 +420,7 @@ def main():
     ctx = _lib.Context(device=0 if share_gpu else local_rank)
 
     dist = None
+    rccl_ranks = None
     exchange = "none (one rank)"
     if world > 1:
         import torch
@@ -433,6 +434,7 @@ def main():
                 id_t = torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8).clone()
             dist.broadcast(id_t, src=0)
             ctx.comm_init(bytes(id_t.numpy().tobytes()), rank, world)
+            rccl_ranks = ctx.comm_count()       # what RCCL itself says (ncclCommCount), not what we asked for
         exchange = "ncclAllGather per horizon step (RCCL)"
 
     ctx.gp_set_data(0, cfg["X"], cfg["Y"])
@@ -497,23 +499,29 @@ def main():
             if share_gpu:
                 raise SystemExit("bench.py: the peer exchange failed and ranks sharing one GPU have no RCCL path")
             exchange = "ncclAllGather per horizon step (RCCL; the peer exchange failed its first rollout)"
-    for _ in range(args.warmup):
-        one_rollout()
-    if dist is not None:
-        dist.barrier()
-    per_call = []
-    t_begin = time.perf_counter()
-    for _ in range(args.steps):
-        t0 = time.perf_counter()
-        mH, SH, rew = one_rollout()          # returns after hipStreamSynchronize + download
-        per_call.append((time.perf_counter() - t0) * 1e3)
-    wall_ms = (time.perf_counter() - t_begin) * 1e3
-    if dist is not None:
-        dist.barrier()
-        import torch
-        t = torch.tensor([wall_ms], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall_ms = float(t.item())
+    def timed_leg():
+        """args.warmup untimed + args.steps timed rollouts, barrier on both sides, MAX over ranks."""
+        for _ in range(args.warmup):
+            one_rollout()
+        if dist is not None:
+            dist.barrier()
+        calls = []
+        t_begin = time.perf_counter()
+        res = None
+        for _ in range(args.steps):
+            t0 = time.perf_counter()
+            res = one_rollout()          # returns after hipStreamSynchronize + download
+            calls.append((time.perf_counter() - t0) * 1e3)
+        wall = (time.perf_counter() - t_begin) * 1e3
+        if dist is not None:
+            dist.barrier()
+            import torch
+            t = torch.tensor([wall], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall, calls, res
+
+    wall_ms, per_call, (mH, SH, rew) = timed_leg()
     ms_per_rollout = wall_ms / args.steps
     verified = verify_against_reference(mH, SH, float(rew[0, 0])) if rank == 0 else None
 
@@ -523,6 +531,33 @@ def main():
     exps, flop, byts = algorithmic_work(N, D, E)
     flop_local = flop / world  # pairs are dealt over the ranks
     achieved = flop_local / (pair_ms * 1e-3) / 1e12 if pair_ms > 0 else 0.0
+    # (N > 1: measured under the exchange `value` was timed with, before the other one is switched in)
+
+    # N > 1: BOTH exchanges in this one invocation.  `value` is the leg above (the peer exchange when every rank attached it);
+    # the other exchange is timed the same way and reported under secondary, each verified against the executed reference.
+    other_exchange = None
+    if dist is not None:
+        import torch
+        if ctx.peer_attached() and not share_gpu:
+            ctx.peer_detach()                 # every rank: the same rollouts now take one ncclAllGather per horizon step
+            ok, err = 1, None
+            try:
+                w2, calls2, (m2, S2, r2) = timed_leg()
+                v2 = verify_against_reference(m2, S2, float(r2[0, 0]), fatal=False)
+            except Exception as exc:          # (a rank that fails still reaches the all_reduce below)
+                ok, err = 0, repr(exc)
+            t = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 1:
+                other_exchange = {"exchange": "ncclAllGather per horizon step (RCCL)", "rollouts_per_s": 1e3 / (w2 / args.steps),
+                                  "ms_per_step": w2 / args.steps, "median_ms_per_call": float(np.median(calls2)), "verified": v2}
+            else:
+                other_exchange = {"exchange": "ncclAllGather per horizon step (RCCL)", "error": err or "another rank failed"}
+        elif ctx.peer_attached():
+            other_exchange = {"exchange": "ncclAllGather per horizon step (RCCL)",
+                              "error": "not available: the ranks share one GPU (PILCO_BENCH_SHARE_GPU=1) and RCCL refuses duplicate devices"}
+        else:
+            other_exchange = {"exchange": "peer stores + flags", "error": "not attached on every rank (or disabled by PILCO_BENCH_PEER=0): `value` is the RCCL leg"}
 
     # the clock the engine actually runs at under this kernel's load, and the kernel's own instruction-issue bound there:
     # per 16-column step a wave issues 6 v_mfma_f64_16x16x4 (64 cycles) + 104 VALU ops (4 cycles) on the shared fp64 pipe
@@ -574,6 +609,10 @@ def main():
             for _ in range(args.steps):
                 ctx2.rollout(policy, rewards, cfg["m0"], cfg["S0"], H)
             local_ms = (time.perf_counter() - t0) * 1e3
+            one_gpu = None
+            if rank == 0:   # the 1-GPU phase times the Amdahl model below is built from (measured while the other ranks idle)
+                pr1 = ctx2.rollout_timed(policy, rewards, cfg["m0"], cfg["S0"], H, 1, time_pair=True)
+                one_gpu = (local_ms / args.steps, pr1["ms_pair"] * 1e3 / max(pr1["n_pair_launches"], 1))
         except Exception as exc:
             err = repr(exc)
         tt = torch.tensor([local_ms], dtype=torch.float64)
@@ -581,10 +620,32 @@ def main():
         if np.isfinite(float(tt.item())):
             replicas = {"replica_rollouts_per_s": world * args.steps * 1e3 / float(tt.item()),
                         "note": "independent unsharded rollouts, one per GPU, concurrently, no communication (not the sharded metric)"}
+            if rank == 0 and err is None and one_gpu:
+                replicas["one_gpu_ms_per_rollout"], replicas["one_gpu_pair_us_per_launch"] = one_gpu
         else:
             replicas = {"error": err or "a rank failed"}
 
+    per_rank, amdahl = None, None
+    if dist is not None:
+        # per rank: its pair kernel per launch (own share of the pairs) and what is left of a step (serial head + exchange)
+        mine = {"rank": rank, "pair_us_per_launch": pair_ms * 1e3, "pair_launches": int(prof["n_pair_launches"]),
+                "other_us_per_step": (prof["ms_total"] - prof["ms_pair"]) * 1e3 / H if prof["n_pair_launches"] else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank == 0:
+        if dist is not None and replicas and "one_gpu_ms_per_rollout" in replicas:
+            # what N ranks could reach if the exchange were free: the slowest rank's pair share + the serial head of a step
+            # (which every rank repeats: Amdahl), from THIS run's 1-GPU phase times.  The measured point is read against it.
+            t1, p1 = replicas["one_gpu_ms_per_rollout"], replicas["one_gpu_pair_us_per_launch"]
+            head1 = t1 * 1e3 / H - p1
+            slowest_pair = max(r["pair_us_per_launch"] for r in per_rank)
+            pred_step = slowest_pair + head1
+            amdahl = {"one_gpu_ms_per_rollout": t1, "one_gpu_pair_us_per_launch": p1, "one_gpu_head_us_per_step": head1,
+                      "slowest_rank_pair_us_per_launch": slowest_pair,
+                      "predicted_rollouts_per_s_with_a_free_exchange": 1e6 / (H * pred_step),
+                      "measured_rollouts_per_s": 1e3 / ms_per_rollout,
+                      "exchange_and_skew_us_per_step": ms_per_rollout * 1e3 / H - pred_step,
+                      "ideal_linear_rollouts_per_s": world * 1e3 / t1}
         out = {
             "metric": "moment-matching rollouts/sec (N=1000,D=10,E=10,H=40)",
             "value": 1e3 / ms_per_rollout,
@@ -651,6 +712,11 @@ def main():
             ctx.gp_set_hyp(0, cfg["lengthscales"], cfg["variance"], cfg["noise"])
         if replicas is not None:
             out["secondary"] = replicas
+            out["secondary"]["other_exchange"] = other_exchange
+            out["secondary"]["per_rank"] = per_rank
+            out["secondary"]["amdahl_model"] = amdahl
+            out["secondary"]["rccl_comm_count"] = rccl_ranks
+            out["secondary"]["ranks_on_distinct_gpus"] = not share_gpu
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))

@@ -311,6 +311,8 @@ int pilco_peer_detach(pilco_ctx* ctx);
 int pilco_peer_attached(const pilco_ctx* ctx);
 int pilco_comm_rank(const pilco_ctx* ctx);
 int pilco_comm_size(const pilco_ctx* ctx);
+/* the number of ranks RCCL ITSELF reports for the attached communicator (ncclCommCount); 0 = none attached, -1 = RCCL error */
+int pilco_comm_count(const pilco_ctx* ctx);
 
 #ifdef __cplusplus
 }

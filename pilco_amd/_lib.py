@@ -123,6 +123,7 @@ SIGNATURES = {
     "pilco_gp_beta_import": (C.c_int, [_vp, C.c_int, _dp]),
     "pilco_comm_rank": (C.c_int, [_vp]),
     "pilco_comm_size": (C.c_int, [_vp]),
+    "pilco_comm_count": (C.c_int, [_vp]),
 }
 
 _lib = None
@@ -579,6 +580,10 @@ class Context:
         blob = b"".join(bytes(h) for h in handles)
         buf = C.create_string_buffer(blob, len(blob))
         self._chk(self.lib.pilco_peer_attach(self.h, buf, 1 if share_gpu else 0))
+
+    def comm_count(self):
+        """Ranks RCCL itself reports for the attached communicator (0: none)."""
+        return int(self.lib.pilco_comm_count(self.h))
 
     def peer_detach(self):
         self._chk(self.lib.pilco_peer_detach(self.h))

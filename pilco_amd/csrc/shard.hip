@@ -425,5 +425,11 @@ int pilco_peer_attached(const pilco_ctx* ctx) { return (ctx && ctx->xq.ready) ? 
 
 int pilco_comm_rank(const pilco_ctx* ctx) { return ctx ? ctx->rank : -1; }
 int pilco_comm_size(const pilco_ctx* ctx) { return ctx ? ctx->nranks : -1; }
+// ranks RCCL itself reports for the attached communicator (ncclCommCount); 0: no communicator; -1: RCCL error
+int pilco_comm_count(const pilco_ctx* ctx) {
+    if (!ctx || !ctx->comm) return 0;
+    int n = 0;
+    return ncclCommCount(ctx->comm, &n) == ncclSuccess ? n : -1;
+}
 
 }  // extern "C"

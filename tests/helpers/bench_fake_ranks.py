@@ -37,6 +37,9 @@ class FakeContext:
     # rank must detach and stay on the RCCL path); FAKE_PEER=first_rollout_fails lets rank 1's first rollout time out
     attached = False
 
+    def comm_count(self):
+        return self.nranks
+
     def peer_export(self):
         return bytes([self.rank]) * 64
 

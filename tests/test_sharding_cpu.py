@@ -204,3 +204,19 @@ def test_bench_multi_rank_host_logic_under_torchrun(peer):
     assert d["verified"]["max_rel_err"]["S_H"] == 0.0
     assert "replica_rollouts_per_s" in d["secondary"] and "cpu_baseline" not in d
     assert ("peer stores" in d["config"]["exchange"]) == (peer == "ok"), d["config"]["exchange"]
+    # one invocation reports BOTH exchanges: the other one timed and verified the same way (or why it could not run) ...
+    oe = d["secondary"]["other_exchange"]
+    if peer == "ok":
+        assert "RCCL" in oe["exchange"] and oe["rollouts_per_s"] > 0 and oe["verified"]["max_rel_err"]["S_H"] == 0.0
+    else:
+        assert "peer" in oe["exchange"] and "error" in oe
+    # ... what RCCL itself says about the communicator, every rank's own phase times, and the Amdahl model from this run's
+    # 1-GPU phase times that the measured point is to be read against
+    assert d["secondary"]["rccl_comm_count"] == 2 and d["secondary"]["ranks_on_distinct_gpus"] is True
+    pr_ = d["secondary"]["per_rank"]
+    assert [r["rank"] for r in pr_] == [0, 1] and all(r["pair_us_per_launch"] > 0 and r["other_us_per_step"] is not None for r in pr_)
+    am = d["secondary"]["amdahl_model"]
+    for k in ("one_gpu_ms_per_rollout", "one_gpu_pair_us_per_launch", "one_gpu_head_us_per_step", "slowest_rank_pair_us_per_launch",
+              "predicted_rollouts_per_s_with_a_free_exchange", "measured_rollouts_per_s", "exchange_and_skew_us_per_step", "ideal_linear_rollouts_per_s"):
+        assert k in am, k
+    assert abs(am["measured_rollouts_per_s"] - d["value"]) < 1e-9
