@@ -61,6 +61,13 @@ int pilco_set_grad_mode(pilco_ctx* ctx, int mode);
 /* 1 (default; PILCO_NO_GRAPH=1 in the environment starts with 0): a rollout's launch sequence is captured once into a
  * hipGraph and replayed while the plan is unchanged; 0: every rollout is enqueued launch by launch.  Same results. */
 int pilco_set_use_graph(pilco_ctx* ctx, int on);
+/* RbfController inside a rollout.  1 (default; PILCO_INLINE_POLICY=0 starts with 0): a policy GP that is small enough
+ * (bf <= 256 basis functions, state_dim <= 16, control_dim <= 4, U(U+1)/2 bf^2 <= 16384) is evaluated INSIDE the serial
+ * link of the step -- by the workgroups that run the link anyway, from the state in LDS -- so that a step is two launches
+ * (head, pair sums) as with a LinearController; 0: the policy GP gets its own operand and pair launch (four launches per
+ * step), which is also what larger policies always get.  Same formulas (controllers.py:108-121 -> mgpr.py:99-149 with
+ * iK = 0); the summation order differs, results agree to rounding (~1e-13), each mode is bitwise repeatable. */
+int pilco_set_inline_policy(pilco_ctx* ctx, int on);
 /* How a plain rollout (pilco_rollout / pilco_propagate / pilco_rollout_timed: one rank, no policy or a LinearController,
  * stream-K pair kernel, D <= 12) is run.  0 (default): the launch sequence (two launches per step, replayed as a hipGraph).
  * 1 (PILCO_PERSIST=1 in the environment starts with it): ONE persistent launch for all H steps -- the reference's

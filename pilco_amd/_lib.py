@@ -61,6 +61,7 @@ SIGNATURES = {
     "pilco_set_grad_mode": (C.c_int, [_vp, C.c_int]),
     "pilco_set_use_graph": (C.c_int, [_vp, C.c_int]),
     "pilco_set_rollout_mode": (C.c_int, [_vp, C.c_int]),
+    "pilco_set_inline_policy": (C.c_int, [_vp, C.c_int]),
     "pilco_last_rollout_mode": (C.c_int, [_vp]),
     "pilco_gp_set_data": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int]),
     "pilco_gp_set_hyp": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
@@ -212,6 +213,10 @@ class Context:
 
     def use_graph(self, on):
         self._chk(self.lib.pilco_set_use_graph(self.h, 1 if on else 0))
+
+    def set_inline_policy(self, on):
+        """1 (default): small RbfControllers are evaluated inside the step's serial link; 0: own launches (include/pilco_hip.h)."""
+        self._chk(self.lib.pilco_set_inline_policy(self.h, 1 if on else 0))
 
     def set_rollout_mode(self, mode):
         """0 (default): the launch sequence (hipGraph replay); 1: plain rollouts as ONE persistent launch (include/pilco_hip.h)."""

@@ -285,6 +285,7 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
     }
     if (const char* eg = getenv("PILCO_NO_GRAPH")) ctx->use_graph = (atoi(eg) == 0);
     if (const char* ep = getenv("PILCO_PERSIST")) ctx->persist = (atoi(ep) != 0) ? 1 : 0;
+    if (const char* ei = getenv("PILCO_INLINE_POLICY")) ctx->inline_policy = (atoi(ei) != 0);
     if (const char* ef = getenv("PILCO_FUSED")) ctx->fused = (atoi(ef) != 0);
     const char* env = getenv("PILCO_PAIR_KERNEL");
     if (env) ctx->variant = (atoi(env) >= 0 && atoi(env) <= 2) ? atoi(env) : 0;
@@ -346,6 +347,12 @@ int pilco_set_fused_step(pilco_ctx* ctx, int on) {
 int pilco_set_grad_mode(pilco_ctx* ctx, int mode) {
     if (!ctx) return PILCO_E_SHAPE;
     ctx->grad_mode = mode;
+    return PILCO_OK;
+}
+
+int pilco_set_inline_policy(pilco_ctx* ctx, int on) {
+    if (!ctx) return PILCO_E_SHAPE;
+    ctx->inline_policy = (on != 0);
     return PILCO_OK;
 }
 

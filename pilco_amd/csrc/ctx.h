@@ -127,6 +127,7 @@ struct pilco_ctx {
     bool persist_broken = false;        // a persistent launch gave up waiting (GPU shared?): this context stays on the launch sequence
     bool last_persist = false;          // the rollout just enqueued was a persistent launch (its abort word must be checked)
     unsigned long long persist_epoch = 0;
+    bool inline_policy = true;   // an RbfController small enough is evaluated inside the link (2 launches per step instead of 4)
     bool fused = true;   // fused head: the serial link of step t runs inside the prep launch of step t+1 (2 launches per step)
     bool graph_rccl_failed = false;
     int grad_mode = 1;   // pilco_rollout_grad*: 1 = Jacobian tape (one O(N^2) sweep per step), 0 = tape + per-step device adjoint

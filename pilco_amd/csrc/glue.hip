@@ -17,7 +17,15 @@ size_t glue_lds_doubles_for(const GlueArgs& g) {
         mp_n = g.pwk.EL * g.pwk.NCHM * (1 + g.E);
         seg_n = g.pwk.SEG;
     }
-    return glue_lds_doubles(g.E, g.D, seg_n, mp_n);
+    return glue_lds_doubles(g.E, g.D, seg_n, mp_n) + (((g.flags & GF_POLICY) && g.pol_inline) ? (size_t)g.pol_lds : 0);
+}
+
+int rbf_inline_lds_doubles(int E, int U, int bf) {
+    if (E < 1 || E > 16 || U < 1 || U > 4 || bf < 1 || bf > 256) return 0;
+    const int P = U * (U + 1) / 2;
+    if ((long)P * bf * bf > 16384) return 0;   // the O(bf^2) sums run redundantly in every workgroup of the head: keep them short
+    const RbfInlineLayout lay = rbf_inline_layout(E, U, bf);
+    return lay.total <= 8192 ? lay.total : 0;
 }
 
 __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {

@@ -27,6 +27,7 @@ struct GlueLds {
     double* seg;  // [SEG]    this rank's packed results
     double* mp;   // [EL*NCH*(1+D)] mean partials
     double* misc; // [256]: [1..) cdiag, [64..) / [96..) temporaries, [128..) policy bias b, [160..) max_action (batched load)
+    double* pol;  // scratch of the inline RbfController evaluation (GlueArgs::pol_lds doubles), behind mp
     int nm;       // max(E, D): leading dimension of the square buffers
     int o_sx, o_s1, o_js, o_seg, o_mp, o_misc;   // offsets (doubles) of sx, s1, js, seg, mp from mx, for multi_load
 };
@@ -49,6 +50,12 @@ __device__ __forceinline__ void glue_lds_carve(const GlueArgs& g, double* sm, Gl
     L.misc = L.js + nm * nm;
     L.seg = L.misc + 256;
     L.mp = L.seg + seg_n;
+    {
+        const int mp_n = (g.flags & GF_RBF_POST) ? g.pwk.EL * g.pwk.NCHM * (1 + E) : ((g.flags & GF_PACK) ? g.wk.EL * g.wk.NCHM * (1 + D) : 0);
+        const int rew_n = (int)reward_lds_doubles(E);
+        const int tail = seg_n + mp_n;
+        L.pol = L.seg + (tail > rew_n ? tail : rew_n);   // (matches glue_lds_doubles: the tail region is max(seg + mp, reward scratch))
+    }
     L.nm = nm;
     L.o_sx = nm;
     L.o_s1 = 2 * nm + 5 * nm * nm;
@@ -391,6 +398,253 @@ __device__ __forceinline__ void xq_push(const GlueArgs& g, const double* seg_lds
         __hip_atomic_store(g.xq_peers[t] + 8 + (int)(epoch & 1ULL) * W + me, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ------------------------------------------------------------------ RbfController inside the link
+// controllers.py:108-121 -- M, S, V = predict_given_factorizations(m, s, 0 * iK, beta) of the policy GP (mgpr.py:99-149)
+// -- evaluated by the workgroup that runs the link, from the state in LDS, instead of by an operand launch and a pair
+// launch of the policy GP's own: an RbfController has 10-50 basis functions (examples/: bf = 10, 30, 40), its O(bf^2)
+// sums are microseconds of one workgroup's time, and the two launches it used to cost were 40 % of a step at the sizes
+// PILCO is used at (profiles/r03: policy head 11.8 us + policy pair kernel 4.8 us of a 41.7 us step).
+// Same formulas as prep_device.h / pair_device.h (their comments cite the reference lines), plain fp64 `exp`.
+// Every reduction is done by threads 0..255 in a fixed order, whatever the workgroup size: all workgroups of a head -- and
+// k_glue -- produce the same bits.
+struct RbfInlineLayout {
+    int ctr, bet, il, var, aug0, aug1, piv, T, Q, det, pt, red, total;
+};
+__host__ __device__ inline RbfInlineLayout rbf_inline_layout(int E, int U, int bf) {
+    const int P = U * (U + 1) / 2, nmat = U + P;
+    RbfInlineLayout l;
+    int o = 0;
+    l.ctr = o; o += bf * E;                 // centred centres  zeta_i = c_i - m
+    l.bet = o; o += U * bf;                 // beta of every output
+    l.il = o;  o += U * E;                  // 1 / lengthscale
+    l.var = o; o += U;
+    l.aug0 = o; o += nmat * E * 2 * E;      // augmented matrices of the batched Gauss-Jordan (ping)
+    l.aug1 = o; o += nmat * E * 2 * E;      //                                                (pong)
+    l.piv = o; o += nmat * E;               // pivots -> determinants
+    l.T = o;   o += U * E * E;              // T_u = (s + Lambda_u^2)^-1
+    l.Q = o;   o += P * E * E;              // Q_uv = R_uv^-1 s / 2
+    l.det = o; o += nmat;                   // det B_u | det R_uv
+    l.pt = o;  o += bf * (2 * E + 2);       // per point of the current pair: u_i, v_i, p_i = 2 Q z_i, w_i
+    l.red = o; o += 4 * (E + 2);            // wave partials
+    l.total = (o + 1) & ~1;
+    return l;
+}
+
+// The policy GP's constants (raw centres, transposed as stored: [E][bf]; beta [U][bf]; lengthscales [U][E]; variances [U])
+// into LDS.  Issued together with the link's first batch of loads, so that their memory round trip is the link's own.
+__device__ __forceinline__ void rbf_policy_preload(const GlueArgs& g, const GlueLds& L) {
+    const int E = g.E, U = g.U, t = threadIdx.x, nthr = blockDim.x;
+    const MMModel& pm = g.pmd;
+    const int bf = pm.n, np = pm.npad;
+    const RbfInlineLayout lay = rbf_inline_layout(E, U, bf);
+    double* W = L.pol;
+    const int n0 = bf * E, n1 = n0 + U * bf, n2 = n1 + U * E, total = n2 + U;
+    for (int base = 0; base < total; base += 8 * nthr) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = base + k * nthr + t;
+            v[k] = 0.0;
+            if (e < n0) v[k] = pm.Pt[(long)(e / bf) * np + e % bf];
+            else if (e < n1) v[k] = pm.beta[(long)((e - n0) / bf) * np + (e - n0) % bf];
+            else if (e < n2) v[k] = pm.ls[e - n1];
+            else if (e < total) v[k] = pm.var[e - n2];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = base + k * nthr + t;
+            if (e < n0) W[lay.ctr + e] = v[k];
+            else if (e < n1) W[lay.bet + (e - n0)] = v[k];
+            else if (e < n2) W[lay.il + (e - n1)] = v[k];
+            else if (e < total) W[lay.var + (e - n2)] = v[k];
+        }
+    }
+}
+
+__device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueLds& L) {
+    const int E = g.E, U = g.U, t = threadIdx.x, nthr = blockDim.x;
+    const MMModel& pm = g.pmd;
+    const int bf = pm.n, np = pm.npad;
+    const int P = U * (U + 1) / 2, nmat = U + P;
+    const RbfInlineLayout lay = rbf_inline_layout(E, U, bf);
+    double* W = L.pol;
+    double *ctr = W + lay.ctr, *bet = W + lay.bet, *il = W + lay.il, *var = W + lay.var, *piv = W + lay.piv, *Tm = W + lay.T,
+           *Qm = W + lay.Q, *det = W + lay.det, *pt = W + lay.pt, *red = W + lay.red;
+    const double* mx = L.mx;
+    const double* sx = L.sx;   // [E][E]
+    // ---- 0. the model is in LDS already (rbf_policy_preload, with the link's first loads): centre the points on the
+    //         state this link has just produced, lengthscales -> reciprocals.  ctr is [E][bf] (as the centres are stored).
+    (void)np;
+    for (int e = t; e < bf * E; e += nthr) ctr[e] -= mx[e / bf];
+    for (int e = t; e < U * E; e += nthr) il[e] = 1.0 / il[e];
+    __syncthreads();
+    // ---- 1. all D x D systems at once: [B_u | I] (mean part, mgpr.py:103-111) and [R_uv | s] (mgpr.py:121-129),
+    //         unpivoted Gauss-Jordan (B is SPD, R diagonally similar to an SPD matrix), one barrier per pivot for all
+    const int nc = 2 * E, msz = E * nc;
+    double* cur = W + lay.aug0;
+    double* nxt = W + lay.aug1;
+    for (int e = t; e < nmat * msz; e += nthr) {
+        const int q = e / msz, rc = e - q * msz, r = rc / nc, c = rc - r * nc;
+        double v;
+        if (q < U) {
+            if (c < E) v = fma(sx[r * E + c], il[q * E + r] * il[q * E + c], (r == c) ? 1.0 : 0.0);
+            else v = (c - E == r) ? 1.0 : 0.0;
+        } else {
+            int a = 0, pq = q - U;
+            while ((a + 1) * (a + 2) / 2 <= pq) ++a;          // pair index pq = a (a + 1) / 2 + b, a >= b
+            const int b = pq - a * (a + 1) / 2;
+            if (c < E) {
+                const double ia = il[a * E + c], ib = il[b * E + c];
+                v = fma(sx[r * E + c], ia * ia + ib * ib, (r == c) ? 1.0 : 0.0);
+            } else {
+                v = sx[r * E + (c - E)];
+            }
+        }
+        cur[e] = v;
+    }
+    for (int k = 0; k < E; ++k) {
+        __syncthreads();
+        for (int e = t; e < nmat * msz; e += nthr) {
+            const int q = e / msz, rc = e - q * msz, r = rc / nc, c = rc - r * nc;
+            const double* Mq = cur + q * msz;
+            const double pk = Mq[k * nc + c] * fast_rcp(Mq[k * nc + k]);   // (as the register Gauss-Jordan of the operand kernel)
+            nxt[e] = (r == k) ? pk : fma(-Mq[r * nc + k], pk, Mq[rc]);
+            if (rc == 0) piv[q * E + k] = Mq[k * nc + k];
+        }
+        double* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+    }
+    __syncthreads();
+    if (t < nmat) {
+        double d = 1.0;
+        for (int k = 0; k < E; ++k) d *= piv[t * E + k];
+        det[t] = d;
+    }
+    for (int e = t; e < U * E * E; e += nthr) {   // T_u = Lambda^-1 B^-1 Lambda^-1
+        const int u = e / (E * E), rc = e - u * E * E, r = rc / E, c = rc - r * E;
+        Tm[e] = cur[u * msz + r * nc + E + c] * il[u * E + r] * il[u * E + c];
+    }
+    for (int e = t; e < P * E * E; e += nthr) {   // Q_uv = R^-1 s / 2
+        const int pq = e / (E * E), rc = e - pq * E * E, r = rc / E, c = rc - r * E;
+        Qm[e] = 0.5 * cur[(U + pq) * msz + r * nc + E + c];
+    }
+    __syncthreads();
+    const int lane = t & 63, w = t >> 6;
+    // ---- 2. mean and input-output covariance of every output (mgpr.py:113-118)
+    for (int u = 0; u < U; ++u) {
+        double gsum = 0.0;
+        double h[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) h[d] = 0.0;
+        if (t < 256)
+            for (int i = t; i < bf; i += 256) {
+                double z[16];
+#pragma unroll
+                for (int d = 0; d < 16; ++d) z[d] = (d < E) ? ctr[d * bf + i] : 0.0;
+                double q = 0.0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (r < E) {
+                        double tz = 0.0;
+#pragma unroll
+                        for (int c = 0; c < 16; ++c)
+                            if (c < E) tz = fma(Tm[(u * E + r) * E + c], z[c], tz);
+                        q = fma(z[r], tz, q);
+                    }
+                const double lb = exp(-0.5 * q) * bet[u * bf + i];
+                gsum += lb;
+#pragma unroll
+                for (int d = 0; d < 16; ++d)
+                    if (d < E) h[d] = fma(z[d], lb, h[d]);
+            }
+        if (t < 256) {
+            const double gs = wave_sum_lane63(gsum);
+            if (lane == 63) red[w * (E + 2)] = gs;
+#pragma unroll
+            for (int d = 0; d < 16; ++d)
+                if (d < E) {
+                    const double v = wave_sum_lane63(h[d]);
+                    if (lane == 63) red[w * (E + 2) + 1 + d] = v;
+                }
+        }
+        __syncthreads();
+        if (t <= E) red[t] = ((red[t] + red[(E + 2) + t]) + red[2 * (E + 2) + t]) + red[3 * (E + 2) + t];   // (row 0 receives the totals)
+        __syncthreads();
+        const double cu = var[u] / sqrt(det[u]);
+        if (t == 0) L.mu[u] = cu * red[0];
+        if (t < E) {
+            double acc = 0.0;
+            for (int k = 0; k < E; ++k) acc = fma(Tm[(u * E + t) * E + k], red[1 + k], acc);
+            L.cxu[t * U + u] = cu * acc;   // V (E, U)
+        }
+        __syncthreads();
+    }
+    // ---- 3. covariance of every output pair (mgpr.py:120-147 with iK = 0)
+    for (int a = 0; a < U; ++a)
+        for (int b = 0; b <= a; ++b) {
+            const int pq = a * (a + 1) / 2 + b;
+            const double* Q = Qm + pq * E * E;
+            double* uv = pt;                 // [bf] u_i (row side, output a)
+            double* vv = pt + bf;            // [bf] v_j (column side, output b)
+            double* pv = pt + 2 * bf;        // [bf][E] 2 Q z_i
+            double* wv = pv + bf * E;        // [bf][E] w_j
+            const double la = log(var[a]), lb_ = log(var[b]);
+            for (int i = t; i < 2 * bf; i += nthr) {
+                const int side = i >= bf, ii = side ? i - bf : i;
+                const double* ilo = il + (side ? b : a) * E;
+                double x[16], kk = side ? lb_ : la, quad = 0.0;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const double zd = (d < E) ? ctr[d * bf + ii] : 0.0;
+                    x[d] = (d < E) ? zd * ilo[d] * ilo[d] : 0.0;
+                    if (d < E) kk = fma(-0.5 * zd, x[d], kk);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)   // (compile-time indices into x[]: no scratch array)
+                    if (r < E) {
+                        double y = 0.0;
+#pragma unroll
+                        for (int c = 0; c < 16; ++c)
+                            if (c < E) y = fma(Q[r * E + c], x[c], y);
+                        quad = fma(x[r], y, quad);
+                        if (!side) pv[ii * E + r] = 2.0 * y;
+                    }
+                if (side) {
+#pragma unroll
+                    for (int d = 0; d < 16; ++d)
+                        if (d < E) wv[ii * E + d] = x[d];
+                    vv[ii] = kk + quad;
+                } else {
+                    uv[ii] = kk + quad;
+                }
+            }
+            __syncthreads();
+            double acc = 0.0;
+            if (t < 256)
+                for (int idx = t; idx < bf * bf; idx += 256) {
+                    const int i = idx / bf, j = idx - i * bf;
+                    double e = uv[i] + vv[j];
+                    for (int d = 0; d < E; ++d) e = fma(pv[i * E + d], wv[j * E + d], e);
+                    acc = fma(bet[a * bf + i] * bet[b * bf + j], exp(e), acc);
+                }
+            if (t < 256) {
+                const double sacc = wave_sum_lane63(acc);
+                if (lane == 63) red[w] = sacc;
+            }
+            __syncthreads();
+            if (t == 0) {
+                const double N = (red[0] + red[1]) + (red[2] + red[3]);
+                double v = N / sqrt(det[U + pq]);
+                if (a == b) v += var[a];                         // mgpr.py:146
+                v = fma(-L.mu[a], L.mu[b], v);                   // mgpr.py:147
+                L.su[a * U + b] = v;
+                L.su[b * U + a] = v;
+            }
+            __syncthreads();
+        }
+}
+
 // The serial link.  On return (GF_POLICY) the joint Gaussian is in L.jm / L.js and the (propagated) state in L.mx / L.sx.
 // All threads of the workgroup must call it; `writer` selects the one workgroup that stores results to global memory.
 __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, bool writer) {
@@ -424,6 +678,7 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
             {L.o_misc + 160, g.maxact, (pol && g.maxact) ? U : 0},    // from global memory later each costs a DRAM round trip
         };
         multi_load<8, 4>(L.mx, sg);
+        if ((g.flags & GF_POLICY) && g.pol_kind == PILCO_POLICY_RBF && g.pol_inline) rbf_policy_preload(g, L);
         if (xq_in) xq_load_segments(g, L.seg);
     }
     __syncthreads();
@@ -523,10 +778,14 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
     if (g.flags & GF_POLICY) {
         if (g.pol_kind == PILCO_POLICY_RBF) {
             // mean-function-only GP: iK = 0, then S -= diag(var - 1e-6)      (controllers.py:116-117)
-            PackPre pq;
-            mm_pack_issue(g.pwk, 0, pq);
-            mm_pack(g.pwk, E, U, L, pq, writer);
-            mm_assemble(g.pwk, L.seg, g.pvar, E, U, L.mu, L.su, L.cxu, writer);   // M (U), S (U,U), V (E,U)
+            if (g.pol_inline) {
+                rbf_policy_inline(g, L);                                          // M (U), S (U,U), V (E,U) from the state in LDS
+            } else {
+                PackPre pq;
+                mm_pack_issue(g.pwk, 0, pq);
+                mm_pack(g.pwk, E, U, L, pq, writer);
+                mm_assemble(g.pwk, L.seg, g.pvar, E, U, L.mu, L.su, L.cxu, writer);   // M (U), S (U,U), V (E,U)
+            }
             if (t < U) L.su[t * U + t] -= g.pvar[t] - 1e-6;
             __syncthreads();
             if (g.squash) {

@@ -108,6 +108,11 @@ struct GlueArgs {
     double* tape;    // [H][D + D*D + E*D + E + E*E + D*E] joint (m, s, s1) and GP outputs (M, S, V) of every step, or nullptr
     int step;
     int dbg_off;     // developer aid: slot offset of this launch's phase stamps (0 = default)
+    // RbfController evaluated INSIDE the link (glue_device.h: rbf_policy_inline) instead of by an operand + pair launch of its
+    // own: the policy GP's model (centres, lengthscales, targets' beta; iK = 0, controllers.py:116) and its LDS scratch
+    MMModel pmd;
+    int pol_inline;  // 1: inline evaluation (small policy GPs: pol_lds > 0 doubles of extra LDS behind the link's region)
+    int pol_lds;
     int lds_state;   // persistent rollout kernel: 1 = keep the state, [s_x, s_x c_xu] in LDS for the next link of this workgroup;
                      // 2 = ... and they ARE already there from the previous link (do not load them from global memory)
     // policy
@@ -170,6 +175,8 @@ bool mm_fused_head_fits(const MMModel& md, int reward_E, const GlueArgs& ga);
 void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const PrepReward* pr = nullptr,
                     const GlueArgs* fused = nullptr);
 size_t glue_lds_doubles_for(const GlueArgs& g);
+// LDS doubles the inline evaluation of an RbfController with bf centres needs (0: too large for the inline path)
+int rbf_inline_lds_doubles(int state_dim, int control_dim, int bf);
 // variant 0 = MFMA stream-K, 1 = VALU (tiled), 2 = MFMA tiled (bits independent of the rank count)
 void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int variant);
 // stream-K geometry: resident waves of the MFMA pair kernel for this KP, and the per-pair step counts

@@ -148,6 +148,9 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
     if (pol->kind == PILCO_POLICY_RBF) {
         g.pwk = ctx->slot[PILCO_SLOT_POLICY].wk;
         g.pvar = ctx->slot[PILCO_SLOT_POLICY].var.p;
+        g.pmd = model_of(ctx->slot[PILCO_SLOT_POLICY]);
+        g.pol_lds = rbf_inline_lds_doubles(E, U, ctx->slot[PILCO_SLOT_POLICY].n);
+        g.pol_inline = (ctx->inline_policy && g.pol_lds > 0) ? 1 : 0;
         for (int u = 0; u < U; ++u) hp[off + u] = pol->max_action ? pol->max_action[u] : 1.0;
         g.maxact = ctx->params.p + off; off += U;
     }
@@ -193,10 +196,11 @@ static bool fused_heads_fit(pilco_ctx* ctx, const RolloutPlan& plan) {
     } else if (s.wk.PL <= 0) {
         return true;
     }
-    gl.flags = GF_TRAJ | GF_POLICY | GF_PACK | GF_ASSEMBLE | GF_PROPAGATE | (rbf ? (GF_RBF_PRE | GF_RBF_POST) : 0);
+    const bool rbf_k = rbf && !gl.pol_inline;   // the policy GP as launches of its own (an inline policy is part of the link)
+    gl.flags = GF_TRAJ | GF_POLICY | GF_PACK | GF_ASSEMBLE | GF_PROPAGATE | (rbf_k ? (GF_RBF_PRE | GF_RBF_POST) : 0);
     const int rew_E = plan.g.n_rewards > 0 ? plan.E : 0;
     bool fits = mm_fused_head_fits(model_of(s), rew_E, gl);
-    if (fits && rbf) fits = mm_fused_head_fits(model_of(ctx->slot[PILCO_SLOT_POLICY]), rew_E, gl);
+    if (fits && rbf_k) fits = mm_fused_head_fits(model_of(ctx->slot[PILCO_SLOT_POLICY]), rew_E, gl);
     return fits;
 }
 
@@ -264,8 +268,15 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
         else
             launch_mm_pair(ctx->st, md, w, ctx->variant);
     };
-    const bool fits = fused_heads_fit(ctx, plan);
-    if (ctx->fused && fits && !rbf && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && H > 0) {
+    bool fits = fused_heads_fit(ctx, plan);
+    // An RbfController evaluated inside the link (GlueArgs::pol_inline) makes the step the LinearController's: two launches.
+    const bool inl = rbf && g.pol_inline && ctx->fused && fits && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && H > 0;
+    if (rbf && !inl && g.pol_inline) {   // not this time (three-kernel step, ranks, ...): the policy GP gets its own launches
+        g.pol_inline = 0;
+        plan.g.pol_inline = 0;
+        fits = fused_heads_fit(ctx, plan);
+    }
+    if (ctx->fused && fits && (!rbf || inl) && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && H > 0) {
         // Fused head: launch h = 0..H-1 is [serial link producing state h and its joint Gaussian | operands of step h],
         // followed by the pair kernel of step h; one plain glue launch closes the rollout.  What the link reads
         // (previous step's pair_isdet / mean_part / s1 / state) and what the same launch writes alternate between two
@@ -679,6 +690,7 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
         (unsigned long long)ctx->slot[1].wk.sk_waves, (unsigned long long)(uintptr_t)ctx->slot[1].w_small.p,
         (unsigned long long)(uintptr_t)ctx->slot[1].w_in.p, (unsigned long long)(uintptr_t)ctx->slot[1].ls.p,
         (unsigned long long)(peer ? 1 : 0), (unsigned long long)(uintptr_t)ctx->xq.local, (unsigned long long)ctx->nranks, (unsigned long long)ctx->rank,
+        (unsigned long long)(g.pol_inline && ctx->inline_policy ? 1 : 0), (unsigned long long)(uintptr_t)ctx->slot[1].var.p,
         (unsigned long long)(uintptr_t)plan.jrec, (unsigned long long)plan.jstride, (unsigned long long)(uintptr_t)s.jac_rowmom.p,
         (unsigned long long)(uintptr_t)s.jac_cpart.p, (unsigned long long)(uintptr_t)s.jac_part.p, (unsigned long long)(uintptr_t)s.jac_head.p,
         (unsigned long long)(uintptr_t)s.jac_np.p};

@@ -511,22 +511,40 @@ def test_fused_heads_with_an_rbf_policy_are_bitwise_identical_to_the_six_kernel_
     for i, mdl in enumerate(p.mgpr.models):
         mdl.kernel.lengthscales.assign(0.8 + rs.rand(D)); mdl.kernel.variance.assign(0.5 + rs.rand()); mdl.likelihood.variance.assign(1e-2)
     out, grads = [], []
-    for fused in (1, 0, 1):
-        ctx.set_fused_step(fused)
-        try:
-            out.append(p.predict_trajectory(m0, S0, H))
-            grads.append(rollout_value_and_grad(p) if D <= 14 else None)
-        finally:
-            ctx.set_fused_step(1)
-    for k in (1, 2):
-        for a, b in zip(out[0], out[k]):
-            assert np.array_equal(a, b)
-        if grads[0] is not None:
-            assert grads[0][0] == grads[k][0]
-            for a, b in zip(grads[0][1], grads[k][1]):
+    ctx.set_inline_policy(0)          # this test is about the policy GP's OWN launches (fused heads vs separate link kernels)
+    try:
+        for fused in (1, 0, 1):
+            ctx.set_fused_step(fused)
+            try:
+                out.append(p.predict_trajectory(m0, S0, H))
+                grads.append(rollout_value_and_grad(p) if D <= 14 else None)
+            finally:
+                ctx.set_fused_step(1)
+        for k in (1, 2):
+            for a, b in zip(out[0], out[k]):
                 assert np.array_equal(a, b)
-    Mg, Sg, Rg = p.predict(m0, S0, H)
-    assert np.array_equal(Mg[0], out[0][3][H, :E])
+            if grads[0] is not None:
+                assert grads[0][0] == grads[k][0]
+                for a, b in zip(grads[0][1], grads[k][1]):
+                    assert np.array_equal(a, b)
+        Mg, Sg, Rg = p.predict(m0, S0, H)
+        assert np.array_equal(Mg[0], out[0][3][H, :E])
+    finally:
+        ctx.set_inline_policy(1)
+    # The default: the RbfController evaluated INSIDE the link (two launches per step).  Same formulas, another summation
+    # order: every state of the trajectory, the reward and the policy gradient agree with the launch path to rounding, and
+    # the inline path is itself bitwise repeatable.
+    inl = [p.predict_trajectory(m0, S0, H) for _ in range(2)]
+    for a, b in zip(inl[0], inl[1]):
+        assert np.array_equal(a, b)
+    for a, b in zip(inl[0], out[0]):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-13)
+    if grads[0] is not None:
+        gi = [rollout_value_and_grad(p) for _ in range(2)]
+        assert gi[0][0] == gi[1][0] and all(np.array_equal(a, b) for a, b in zip(gi[0][1], gi[1][1]))
+        np.testing.assert_allclose(gi[0][0], grads[0][0], rtol=1e-9)
+        for a, b in zip(gi[0][1], grads[0][1]):
+            np.testing.assert_allclose(a, b, rtol=1e-7, atol=1e-11)
 
 
 def test_full_size_c2u_gradient_vs_reverse_mode_through_the_reference(ctx, golden_dir):
