@@ -165,6 +165,10 @@ struct OwnView {
 static int prepare_own(pilco_ctx* ctx, Slot& s, OwnView& o) {
     o.W = ctx->nranks;
     o.rank = ctx->rank;
+    if (&s == &ctx->slot[PILCO_SLOT_POLICY]) {   // the RbfController's GP is never sharded: every rank factorises all of it
+        o.W = 1;                                 // (bf <= a few hundred points) and evaluates it inside its own link
+        o.rank = 0;
+    }
     const int E = s.E, D = s.D, Np = s.Npad;
     o.ELcap = (E + o.W - 1) / o.W;
     o.EL = (o.rank < E) ? (E - o.rank + o.W - 1) / o.W : 0;

@@ -116,7 +116,8 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
         Slot& ps = ctx->slot[PILCO_SLOT_POLICY];
         if (!ps.factor_valid) return fail(ctx, PILCO_E_STATE, "rollout: RBF policy slot has no current factorisation");
         if (ps.D != E || ps.E != U || U == 0) return fail(ctx, PILCO_E_SHAPE, "rollout: RBF policy GP must map state_dim -> control_dim");
-        if (ctx->nranks != 1) return fail(ctx, PILCO_E_STATE, "rollout: the RBF policy is evaluated unsharded; use one rank");
+        if (ctx->nranks != 1 && !(ctx->inline_policy && rbf_inline_lds_doubles(E, U, ps.n) > 0))
+            return fail(ctx, PILCO_E_STATE, "rollout: with several ranks an RbfController must be small enough for the inline evaluation (pilco_set_inline_policy)");
         if (int r = build_work(ctx, ps)) return r;
     }
     if (pol->kind < 0 || pol->kind > 2) return fail(ctx, PILCO_E_SHAPE, "rollout: unknown policy kind");
@@ -208,7 +209,9 @@ static bool fused_heads_fit(pilco_ctx* ctx, const RolloutPlan& plan) {
 // (its GP is not sharded) and the segments fit the exchange slots; otherwise the RCCL / group path runs.
 static bool peer_rollout_applies(pilco_ctx* ctx, const RolloutPlan& plan, int H) {
     const Slot& s = ctx->slot[0];
-    return ctx->xq.ready && ctx->nranks > 1 && ctx->xq.W == ctx->nranks && H > 0 && plan.g.pol_kind != PILCO_POLICY_RBF &&
+    // (an RbfController rides along when it is evaluated inside the link: every rank evaluates the whole, unsharded policy)
+    return ctx->xq.ready && ctx->nranks > 1 && ctx->xq.W == ctx->nranks && H > 0 &&
+           (plan.g.pol_kind != PILCO_POLICY_RBF || plan.g.pol_inline) &&
            s.wk.SEG <= ctx->xq.cap && !plan.g.tape && !plan.jrec && fused_heads_fit(ctx, plan);
 }
 // Host side of a rollout's exchanges: the epoch base goes up before the rollout's launches (outside any graph: the
@@ -271,7 +274,10 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
     bool fits = fused_heads_fit(ctx, plan);
     // An RbfController evaluated inside the link (GlueArgs::pol_inline) makes the step the LinearController's: two launches.
     const bool inl = rbf && g.pol_inline && ctx->fused && fits && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && H > 0;
-    if (rbf && !inl && g.pol_inline) {   // not this time (three-kernel step, ranks, ...): the policy GP gets its own launches
+    const bool inl_peer = rbf && g.pol_inline && peer_rollout_applies(ctx, plan, H);   // sharded rollout over the peer exchange
+    if (rbf && ctx->nranks != 1 && !inl_peer)
+        return fail(ctx, PILCO_E_STATE, "rollout: several ranks run an RbfController only over the peer exchange (pilco_peer_attach / pilco_group_peer_attach) with the inline policy");
+    if (rbf && !inl && !inl_peer && g.pol_inline) {   // not this time (three-kernel step, ...): the policy GP gets its own launches
         g.pol_inline = 0;
         plan.g.pol_inline = 0;
         fits = fused_heads_fit(ctx, plan);

@@ -707,6 +707,49 @@ def test_sharded_step_two_contexts_host_allgather(variant, nranks):
             cx.close()
 
 
+@pytest.mark.parametrize("E,U,nranks,bf", [(4, 1, 2, 10), (5, 2, 3, 20), (4, 1, 8, 10)])
+def test_sharded_rollout_with_an_rbf_controller_over_the_peer_exchange(E, U, nranks, bf):
+    """The reference's default controller in a sharded rollout (controllers.py:108-121 inside pilco.py:126-135): the policy GP
+    is NOT sharded -- every rank holds all of it and evaluates it inside its own serial link (inline policy), so the
+    per-step exchange carries the dynamics GP's segments only and the peer exchange serves an RbfController like a linear
+    one.  Every rank ends bit-identical to the others; with the rank-count-independent pair kernel (variant 2) also
+    bit-identical to the single-rank rollout.  Without the peer exchange such a rollout is refused, not mis-run."""
+    from pilco_amd import _lib
+    D, H = E + U, 5
+    c = synthetic.config_c2(N=150, D=D, E=E, noise=1e-2, seed=41, control_dim=U)
+    rs = np.random.RandomState(E + bf)
+    cX, cY, cl = rs.randn(bf, E), 0.3 * rs.randn(bf, U), 1.0 + 0.3 * rs.rand(U, E)
+    pol = dict(kind=_lib.POLICY_RBF, state_dim=E, control_dim=U, max_action=1.0 + 0.5 * rs.rand(U), squash=True)
+    rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(E), t=np.zeros(E))]
+    m0, S0 = c["m0"], 0.05 * np.eye(E)
+    made = []
+
+    def ctx_for(rank, n):
+        cx = _lib.Context(device=0)
+        made.append(cx)
+        cx.set_pair_kernel(2)
+        if n > 1:
+            cx.shard_set(rank, n)
+        cx.gp_set_data(0, c["X"], c["Y"]); cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"]); cx.gp_factorize(0)
+        cx.gp_set_data(1, cX, cY); cx.gp_set_hyp(1, cl, np.ones(U), 1e-4 * np.ones(U)); cx.gp_factorize(1)
+        return cx
+    try:
+        ref = ctx_for(0, 1)
+        M1, S1, R1, T1 = ref.rollout(pol, rw, m0, S0, H, want_traj=True)
+        group = [ctx_for(r, nranks) for r in range(nranks)]
+        _lib.group_sync_model(group)
+        with pytest.raises(_lib.PilcoError):          # no peer exchange: refused
+            _lib.rollout_group(group, pol, rw, m0, S0, H)
+        _lib.group_peer_attach(group)
+        for rep in range(2):
+            M, S, R, T, mismatch = _lib.rollout_group(group, pol, rw, m0, S0, H, want_traj=True)
+            assert mismatch == 0
+            assert np.array_equal(T, T1) and np.array_equal(R, R1) and np.array_equal(M, M1) and np.array_equal(S, S1)
+    finally:
+        for cx in made:
+            cx.close()
+
+
 @pytest.mark.parametrize("E,U,nranks,sparse", [(5, 1, 2, False), (5, 1, 3, False), (2, 1, 4, False), (10, 0, 8, False), (5, 1, 3, True)])
 def test_sharded_rollout_group_of_contexts(E, U, nranks, sparse):
     """BASELINE config 3's ROLLOUT on one GPU: `nranks` contexts of this process run the whole sharded H-step rollout
