@@ -107,7 +107,10 @@ int pilco_gp_factorize(pilco_ctx* ctx, int slot);
 /* Negative log marginal likelihood of every output at the current hyper-parameters and its gradient
  * w.r.t. (lengthscales[D], kernel variance, noise variance): what gpflow's GPR.training_loss and its
  * autodiff provide to MGPR.optimize (pilco/models/mgpr.py:47-75), without the prior terms (added on
- * the host).  nlml (E), grad (E, D+2) may be NULL.  Exact GP only. */
+ * the host).  nlml (E), grad (E, D+2) may be NULL.  Exact GP only.
+ * Several ranks: sharded by output like the factorisation under it -- a rank evaluates the outputs it owns; with a
+ * communicator attached one ncclAllGather of (D + 3) doubles per output completes the arrays on every rank, without one the
+ * other ranks' entries come back NaN and the caller combines them (contexts of one process: pilco_amd._lib.group_nlml). */
 int pilco_gp_nlml(pilco_ctx* ctx, int slot, double* nlml, double* grad);
 /* The same for the sparse model: negative log marginal likelihood of gpflow's GPRFITC (one model per output, each with its
  * OWN inducing inputs: pilco/models/smgpr.py:16-22) and its gradient w.r.t. (lengthscales[D], kernel variance, noise

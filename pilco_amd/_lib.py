@@ -597,6 +597,18 @@ class Context:
         return bool(self.lib.pilco_peer_attached(self.h))
 
 
+def group_nlml(ctxs, slot, D, E):
+    """pilco_gp_nlml over the contexts of one process that shard a model by output: every rank evaluates the outputs it owns
+    (the others come back NaN), this combines them -- what the ncclAllGather inside pilco_gp_nlml does between processes."""
+    nlml, grad = np.full(E, np.nan), np.full((E, D + 2), np.nan)
+    for c in ctxs:
+        n, g = c.gp_nlml(slot, D, E)
+        own = ~np.isnan(n)
+        assert not np.any(own & ~np.isnan(nlml)), "two ranks claim the same output"
+        nlml[own], grad[own] = n[own], g[own]
+    return nlml, grad
+
+
 def group_sync_model(ctxs, slot=0):
     """Exchange the beta rows of the contexts of this process after each has factorised its own outputs."""
     arr = (_vp * len(ctxs))(*[c.h for c in ctxs])

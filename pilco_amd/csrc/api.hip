@@ -542,33 +542,81 @@ int pilco_gp_nlml(pilco_ctx* ctx, int slot, double* nlml, double* grad) {
     Slot& s = ctx->slot[slot];
     if (!s.has_data || !s.has_hyp) return fail(ctx, PILCO_E_STATE, "nlml needs set_data and set_hyp first");
     if (s.M > 0) return fail(ctx, PILCO_E_STATE, "nlml: exact GP only (the sparse objective is pilco_gp_fitc_nlml)");
-    if (ctx->nranks != 1) return fail(ctx, PILCO_E_STATE, "nlml: hyper-parameter training runs unsharded (one rank)");
     if (!nlml) return fail(ctx, PILCO_E_SHAPE, "nlml: null pointer");
     HIPCHK(hipSetDevice(ctx->device));
     if (!s.factor_valid || s.user_factors) {
         s.factor_valid = false;
         if (int r = pilco_gp_factorize(ctx, slot)) return r;
     }
+    // Sharded by output like the factorisation it rests on: rank r evaluates the outputs a = r, r + W, ... it
+    // owns -- their L, iK, alpha and compacted hyper-parameters are exactly what factorize_exact left on this rank -- and
+    // writes them at their global places; one ncclAllGather of (D + 3) doubles per output completes every rank's arrays.
+    // Without a communicator the other ranks' entries are NaN and the caller combines (pilco_amd._lib.group_nlml).
     const int E = s.E, D = s.D, npad = s.Npad, N = s.N;
-    // after factorize_exact: s.K holds L, s.iK the inverse, s.beta = alpha, s.Yt the targets
-    const size_t npart = (size_t)E * (npad / NB) * (npad / NB) * 34;   // [E][tiles^2][NLML_MAXD + 2] partial sums of the gradient
-    ENSURE(s.vec, std::max((size_t)E * npad * 2, npart + (size_t)E * (D + 2) + 2 * (size_t)E));
+    const int W = s.shW > 0 ? s.shW : 1, rank = W > 1 ? s.shRank : 0;
+    const int EL = W > 1 ? s.shOwn : E, ELcap = W > 1 ? s.shEL : E, ELa = std::max(EL, 1);
+    const double* ls = s.ls.p;
+    const double* var = s.var.p;
+    const double* Yt = s.Yt.p;
+    const double* beta = s.beta.p;
+    if (W > 1) {   // the compacted copies prepare_own made for the owned outputs: [EL][D] | [EL] | [EL] | [EL][Npad]
+        ls = s.own.p;
+        var = s.own.p + (size_t)ELa * D;
+        Yt = s.own.p + (size_t)ELa * (D + 2);
+        beta = s.beta.p + (size_t)rank * ELcap * npad;
+    }
+    const int W3 = D + 3;   // per output: nlml | gradient (D + 2)
+    // after factorize_exact: s.K holds L, s.iK the inverse, beta = alpha, Yt the targets (owned outputs, compact)
+    const size_t npart = (size_t)ELa * (npad / NB) * (npad / NB) * 34;   // [EL][tiles^2][NLML_MAXD + 2] partial sums of the gradient
+    ENSURE(s.vec, std::max((size_t)ELa * npad * 2, npart + (size_t)ELa * (D + 2) + 2 * (size_t)ELa + (size_t)(W + 1) * ELcap * W3));
     double* d_part = s.vec.p;
     double* d_grad = d_part + npart;
-    double* d_logdet = d_grad + (size_t)E * (D + 2);
-    launch_logdet(ctx->st, s.K.p, npad, N, E, d_logdet);
-    if (grad) launch_nlml_grad(ctx->st, s.Xt.p, npad, N, D, s.ls.p, s.var.p, s.iK.p, s.beta.p, E, d_part, d_grad);
-    std::vector<double> hl(E), hb((size_t)E * npad), hy((size_t)E * npad);
-    HIPCHK(hipMemcpyAsync(hl.data(), d_logdet, sizeof(double) * E, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(hb.data(), s.beta.p, sizeof(double) * E * npad, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(hy.data(), s.Yt.p, sizeof(double) * E * npad, hipMemcpyDeviceToHost, ctx->st));
-    if (grad) HIPCHK(hipMemcpyAsync(grad, d_grad, sizeof(double) * E * (D + 2), hipMemcpyDeviceToHost, ctx->st));
+    double* d_logdet = d_grad + (size_t)ELa * (D + 2);
+    double* d_gath = d_logdet + 2 * (size_t)ELa;   // [W][ELcap][W3] when a communicator completes the result
+    std::vector<double> hl(ELa), hb((size_t)ELa * npad), hy((size_t)ELa * npad), hg((size_t)ELa * (D + 2));
+    if (EL > 0) {
+        launch_logdet(ctx->st, s.K.p, npad, N, EL, d_logdet);
+        if (grad) launch_nlml_grad(ctx->st, s.Xt.p, npad, N, D, ls, var, s.iK.p, beta, EL, d_part, d_grad);
+        HIPCHK(hipMemcpyAsync(hl.data(), d_logdet, sizeof(double) * EL, hipMemcpyDeviceToHost, ctx->st));
+        HIPCHK(hipMemcpyAsync(hb.data(), beta, sizeof(double) * EL * npad, hipMemcpyDeviceToHost, ctx->st));
+        HIPCHK(hipMemcpyAsync(hy.data(), Yt, sizeof(double) * EL * npad, hipMemcpyDeviceToHost, ctx->st));
+        if (grad) HIPCHK(hipMemcpyAsync(hg.data(), d_grad, sizeof(double) * EL * (D + 2), hipMemcpyDeviceToHost, ctx->st));
+    }
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());
+    const double nan = std::nan("");
     for (int a = 0; a < E; ++a) {
+        nlml[a] = nan;
+        if (grad)
+            for (int k = 0; k < D + 2; ++k) grad[(size_t)a * (D + 2) + k] = nan;
+    }
+    std::vector<double> own((size_t)ELcap * W3, 0.0);
+    for (int al = 0; al < EL; ++al) {
+        const int a = al * W + rank;
         double ya = 0.0;
-        for (int i = 0; i < N; ++i) ya += hy[(size_t)a * npad + i] * hb[(size_t)a * npad + i];
-        nlml[a] = 0.5 * ya + hl[a] + 0.5 * N * std::log(2.0 * M_PI);
+        for (int i = 0; i < N; ++i) ya += hy[(size_t)al * npad + i] * hb[(size_t)al * npad + i];
+        nlml[a] = 0.5 * ya + hl[al] + 0.5 * N * std::log(2.0 * M_PI);
+        own[(size_t)al * W3] = nlml[a];
+        if (grad)
+            for (int k = 0; k < D + 2; ++k) {
+                grad[(size_t)a * (D + 2) + k] = hg[(size_t)al * (D + 2) + k];
+                own[(size_t)al * W3 + 1 + k] = hg[(size_t)al * (D + 2) + k];
+            }
+    }
+    if (W > 1 && ctx->comm) {
+        const size_t blk = (size_t)ELcap * W3;
+        std::vector<double> all((size_t)W * blk);
+        HIPCHK(hipMemcpyAsync(d_gath + (size_t)W * blk, own.data(), sizeof(double) * blk, hipMemcpyHostToDevice, ctx->st));
+        ncclResult_t r = ncclAllGather(d_gath + (size_t)W * blk, d_gath, blk, ncclDouble, ctx->comm, ctx->st);
+        if (r != ncclSuccess) return fail(ctx, PILCO_E_RCCL, std::string("ncclAllGather(nlml): ") + ncclGetErrorString(r));
+        HIPCHK(hipMemcpyAsync(all.data(), d_gath, sizeof(double) * W * blk, hipMemcpyDeviceToHost, ctx->st));
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        for (int a = 0; a < E; ++a) {
+            const double* src = all.data() + ((size_t)(a % W) * ELcap + a / W) * W3;
+            nlml[a] = src[0];
+            if (grad)
+                for (int k = 0; k < D + 2; ++k) grad[(size_t)a * (D + 2) + k] = src[1 + k];
+        }
     }
     return PILCO_OK;
 }

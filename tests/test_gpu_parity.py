@@ -707,6 +707,48 @@ def test_sharded_step_two_contexts_host_allgather(variant, nranks):
             cx.close()
 
 
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_training_objective_sharded_by_output(nranks):
+    """pilco_gp_nlml (GPR.training_loss + gradient inside MGPR.optimize, mgpr.py:47-56) sharded like the factorisation under
+    it: rank r evaluates the outputs r, r + W, ... it owns -- from the L, iK, alpha its own factorisation left -- and the
+    combined result equals the single-rank evaluation to the last bit (the outputs are independent problems)."""
+    from pilco_amd import _lib
+    E, D, N = 5, 4, 170
+    c = synthetic.config_c2(N=N, D=D, E=E, noise=1e-2, seed=77, control_dim=0)
+    made = []
+
+    def ctx_for(rank, n):
+        cx = _lib.Context(device=0)
+        made.append(cx)
+        if n > 1:
+            cx.shard_set(rank, n)
+        cx.gp_set_data(0, c["X"], c["Y"]); cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"])
+        return cx
+    try:
+        ref = ctx_for(0, 1)
+        n1, g1 = ref.gp_nlml(0, D, E)
+        assert np.all(np.isfinite(n1)) and np.all(np.isfinite(g1))
+        group = [ctx_for(r, nranks) for r in range(nranks)]
+        owned = 0
+        for r, cx in enumerate(group):
+            n, g = cx.gp_nlml(0, D, E)
+            mine = ~np.isnan(n)
+            assert list(np.nonzero(mine)[0]) == list(range(r, E, nranks))   # exactly the outputs the rank owns
+            owned += int(mine.sum())
+        assert owned == E
+        n, g = _lib.group_nlml(group, 0, D, E)
+        assert np.array_equal(n, n1) and np.array_equal(g, g1)
+        # new hyper-parameters on every rank (an optimiser step): the sharded evaluation follows
+        for cx in [ref] + group:
+            cx.gp_set_hyp(0, 1.1 * c["lengthscales"], 0.9 * c["variance"], 2.0 * c["noise"])
+        n2, g2 = ref.gp_nlml(0, D, E)
+        n3, g3 = _lib.group_nlml(group, 0, D, E)
+        assert np.array_equal(n2, n3) and np.array_equal(g2, g3) and not np.array_equal(n2, n1)
+    finally:
+        for cx in made:
+            cx.close()
+
+
 @pytest.mark.parametrize("E,U,nranks,bf", [(4, 1, 2, 10), (5, 2, 3, 20), (4, 1, 8, 10)])
 def test_sharded_rollout_with_an_rbf_controller_over_the_peer_exchange(E, U, nranks, bf):
     """The reference's default controller in a sharded rollout (controllers.py:108-121 inside pilco.py:126-135): the policy GP
