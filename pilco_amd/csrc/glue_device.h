@@ -647,6 +647,14 @@ __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueL
 
 // The serial link.  On return (GF_POLICY) the joint Gaussian is in L.jm / L.js and the (propagated) state in L.mx / L.sx.
 // All threads of the workgroup must call it; `writer` selects the one workgroup that stores results to global memory.
+// PK selects which controller code is COMPILED INTO the host kernel: -1 all of it (k_glue: dispatch at run time), 0 no
+// controller (control_dim 0), 3 LinearController, 1 RbfController reduced from its own launches (GF_RBF_POST), 2
+// RbfController evaluated inline; SR (single rank): the peer-exchange waits / stores and the general (gathered-segments)
+// assemble + propagate are left out as well -- one rank always takes the two-phase `fast` path below.  The
+// link is a chain of latencies through straight-line code: round 3 measured +1.5 us (no policy) to +3 us (linear policy)
+// per step on the fused head when the inline-RBF code was merely PRESENT in its instruction stream (instruction fetch), so
+// every fused head is instantiated for the controller kind it serves.
+template <int PK = -1, bool SR = false>
 __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, bool writer) {
     const int E = g.E, D = g.D, U = g.U, t = threadIdx.x;
     int mp_n = (g.flags & GF_PACK) ? g.wk.EL * g.wk.NCHM * (1 + D) : 0;
@@ -660,8 +668,9 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
     DBG_STAMP(g.wk, 8 + dbo, dbg0);
     PackPre pp;   // first round of the pack: its loads are in flight together with the batch below
     if ((g.flags & GF_PACK) && !MM_ABL(g.wk, 16)) mm_pack_issue(g.wk, 0, pp);
-    const bool xq_in = g.xq && (g.flags & GF_ASSEMBLE) && !(g.flags & GF_PACK);
-    if (xq_in) xq_wait(g);   // (the segment loads below must not be issued before the flags have been seen)
+    const bool xq_in = !SR && g.xq && (g.flags & GF_ASSEMBLE) && !(g.flags & GF_PACK);
+    if constexpr (!SR)
+        if (xq_in) xq_wait(g);   // (the segment loads below must not be issued before the flags have been seen)
     {   // one batch of loads for everything the serial part reads
         const bool in_lds = g.lds_state == 2;   // persistent kernel: this workgroup's previous link left the state and s1 in LDS
         const bool need_state = !in_lds && (g.flags & (GF_PROPAGATE | GF_TRAJ | GF_POLICY | GF_RBF_PRE)) != 0;
@@ -678,14 +687,17 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
             {L.o_misc + 160, g.maxact, (pol && g.maxact) ? U : 0},    // from global memory later each costs a DRAM round trip
         };
         multi_load<8, 4>(L.mx, sg);
-        if ((g.flags & GF_POLICY) && g.pol_kind == PILCO_POLICY_RBF && g.pol_inline) rbf_policy_preload(g, L);
-        if (xq_in) xq_load_segments(g, L.seg);
+        if constexpr (PK < 0 || PK == 2)
+            if ((g.flags & GF_POLICY) && g.pol_kind == PILCO_POLICY_RBF && g.pol_inline) rbf_policy_preload(g, L);
+        if constexpr (!SR)
+            if (xq_in) xq_load_segments(g, L.seg);
     }
     __syncthreads();
 
     DBG_STAMP(g.wk, 9 + dbo, dbg0);
     if ((g.flags & GF_PACK) && !MM_ABL(g.wk, 16)) mm_pack(g.wk, D, E, L, pp, writer);
-    if ((g.flags & GF_PACK) && g.xq_peers && writer) xq_push(g, L.seg);
+    if constexpr (!SR)
+        if ((g.flags & GF_PACK) && g.xq_peers && writer) xq_push(g, L.seg);
     DBG_STAMP(g.wk, 10 + dbo, dbg0);
     const bool fast = (g.flags & (GF_PACK | GF_ASSEMBLE | GF_PROPAGATE)) == (GF_PACK | GF_ASSEMBLE | GF_PROPAGATE) && g.wk.nranks == 1;
     if (fast) {
@@ -729,7 +741,7 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
         }
         __syncthreads();
     }
-    if (!fast && (g.flags & GF_ASSEMBLE)) {
+    if (!SR && !fast && (g.flags & GF_ASSEMBLE)) {
         // single rank: the LDS copy of the segment is the whole gather buffer
         mm_assemble(g.wk, L.seg, g.var, D, E, L.mu, L.su, L.cxu, writer);  // oM -> mu, oS -> su, oV -> cxu
         if (writer && g.tape && g.step >= 1) {
@@ -740,7 +752,7 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
         }
     }
     DBG_STAMP(g.wk, 11 + dbo, dbg0);
-    if (!fast && (g.flags & GF_PROPAGATE)) {
+    if (!SR && !fast && (g.flags & GF_PROPAGATE)) {
         // t1 = s1 V (E,E); state += increment                      (pilco.py:147-149)
         for (int e = t; e < E * E; e += blockDim.x) {
             const int r = e / E, c = e - r * E;
@@ -776,15 +788,22 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
         for (int e = t; e < E * E; e += blockDim.x) g.pwk.in_s[e] = L.sx[e];
     }
     if (g.flags & GF_POLICY) {
-        if (g.pol_kind == PILCO_POLICY_RBF) {
+        if (PK != 0 && PK != 3 && g.pol_kind == PILCO_POLICY_RBF) {
             // mean-function-only GP: iK = 0, then S -= diag(var - 1e-6)      (controllers.py:116-117)
-            if (g.pol_inline) {
-                rbf_policy_inline(g, L);                                          // M (U), S (U,U), V (E,U) from the state in LDS
-            } else {
-                PackPre pq;
-                mm_pack_issue(g.pwk, 0, pq);
-                mm_pack(g.pwk, E, U, L, pq, writer);
-                mm_assemble(g.pwk, L.seg, g.pvar, E, U, L.mu, L.su, L.cxu, writer);   // M (U), S (U,U), V (E,U)
+            bool done = false;
+            if constexpr (PK < 0 || PK == 2) {
+                if (g.pol_inline) {
+                    rbf_policy_inline(g, L);                                      // M (U), S (U,U), V (E,U) from the state in LDS
+                    done = true;
+                }
+            }
+            if constexpr (PK < 0 || PK == 1) {
+                if (!done) {
+                    PackPre pq;
+                    mm_pack_issue(g.pwk, 0, pq);
+                    mm_pack(g.pwk, E, U, L, pq, writer);
+                    mm_assemble(g.pwk, L.seg, g.pvar, E, U, L.mu, L.su, L.cxu, writer);   // M (U), S (U,U), V (E,U)
+                }
             }
             if (t < U) L.su[t * U + t] -= g.pvar[t] - 1e-6;
             __syncthreads();
@@ -795,7 +814,7 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
                 __syncthreads();
             }
         }
-        if (g.pol_kind == PILCO_POLICY_LINEAR) {
+        if ((PK < 0 || PK == 3) && g.pol_kind == PILCO_POLICY_LINEAR) {
             // M = m W^T + b, S = W s W^T, V = W^T                  (controllers.py:52-54); W is in L.js (batched load)
             if (t < U) {
                 double acc = L.misc[128 + t];

@@ -193,7 +193,8 @@ __global__ __launch_bounds__(PERSIST_THREADS) void k_rollout_persist(PersistArgs
             g.lds_state = h > 0 ? 2 : 1;
             GlueLds L;
             glue_lds_carve(g, sm_all, L);
-            glue_body(g, L, blockIdx.x == 0);
+            if (g.pol_kind == PILCO_POLICY_LINEAR) glue_body<3, true>(g, L, blockIdx.x == 0);
+            else glue_body<0, true>(g, L, blockIdx.x == 0);
             PSTAMP(1);
         }
         if (closing) break;

@@ -4,7 +4,10 @@
 namespace pilco {
 
 // ------------------------------------------------------------------ prep
-template <int DT, bool FUSED>
+// PK: the controller code compiled into the fused head's link (glue_body<PK, SR>): 0 none, 3 linear, 1 RBF from its own
+// launches, 2 RBF inline; SR: single rank (no peer exchange, no gathered segments).  The plain operand kernel (FUSED = false)
+// has no link and exists for <0, true> only.
+template <int DT, bool FUSED, int PK = 0, bool SR = true>
 __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepReward pr, GlueArgs g, int glue_doubles) {
     extern __shared__ __attribute__((aligned(16))) double sm_all[];
     // FUSED: the serial link of the previous step runs first, redundantly in every workgroup (see glue_device.h); it
@@ -28,7 +31,7 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
         }
         pre_var = md.var[(threadIdx.x >> 8) ? b : a];
     }
-    if (FUSED) glue_body(g, L, blockIdx.x == 0 && blockIdx.y == 0);
+    if (FUSED) glue_body<PK, SR>(g, L, blockIdx.x == 0 && blockIdx.y == 0);
     prep_work<DT, FUSED, 512>(md, wk, pr, g, L, sm_all, glue_doubles, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, pre_la,
                               pre_lb, pre_var);
 }
@@ -89,23 +92,35 @@ void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const P
     const int gd = fused ? (int)((glue_lds_doubles_for(ga) + 1) & ~(size_t)1) : 0;   // glue region of the fused head (even: 16-byte alignment)
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
-#define PREP1(DT_, F_)                                                                                     \
+#define PREP1(DT_, F_, PK_, SR_)                                                                           \
     do {                                                                                                   \
         const size_t lds_ = std::max(prep_lds_bytes(DT_), lds_rw) + sizeof(double) * (size_t)gd;           \
         static size_t configured_[64] = {};  /* beyond the default dynamic-LDS limit: opt in once PER DEVICE */ \
         size_t& conf_ = configured_[dev_ & 63];                                                            \
         if (conf_ == 0) conf_ = 48 * 1024;                                                                 \
         if (lds_ > conf_) {                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mm_prep<DT_, F_>),                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mm_prep<DT_, F_, PK_, SR_>),         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);              \
             conf_ = lds_;                                                                                  \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_mm_prep<DT_, F_>), grid, dim3(512), lds_, st, md, wk, r, ga, gd);            \
+        hipLaunchKernelGGL((k_mm_prep<DT_, F_, PK_, SR_>), grid, dim3(512), lds_, st, md, wk, r, ga, gd);  \
     } while (0)
-#define PREP(DT_)                  \
-    do {                           \
-        if (fused) PREP1(DT_, true); \
-        else PREP1(DT_, false);    \
+    // the fused head is instantiated per controller kind and for one rank / several (see glue_body): the serial link is a
+    // chain of latencies through straight-line code, and code that is merely present in its stream costs microseconds
+    const bool multi = fused && (ga.xq != nullptr || ga.xq_peers != nullptr || ga.wk.nranks != 1 ||
+                                 (ga.flags & (GF_PACK | GF_ASSEMBLE | GF_PROPAGATE)) == (GF_ASSEMBLE | GF_PROPAGATE));
+    const int pk = !fused ? 0 : (ga.pol_kind == PILCO_POLICY_RBF ? (ga.pol_inline ? 2 : 1) : (ga.pol_kind == PILCO_POLICY_LINEAR ? 3 : 0));
+#define PREP(DT_)                                              \
+    do {                                                       \
+        if (!fused) PREP1(DT_, false, 0, true);                \
+        else if (multi) {   /* sharded rollouts: none / linear / inline RBF */ \
+            if (pk == 0) PREP1(DT_, true, 0, false);           \
+            else if (pk == 3) PREP1(DT_, true, 3, false);      \
+            else PREP1(DT_, true, 2, false);                   \
+        } else if (pk == 0) PREP1(DT_, true, 0, true);         \
+        else if (pk == 3) PREP1(DT_, true, 3, true);           \
+        else if (pk == 1) PREP1(DT_, true, 1, true);           \
+        else PREP1(DT_, true, 2, true);                        \
     } while (0)
     // DT = D where it matters: the Gauss-Jordan costs 2 DT readlanes per pivot and DT pivots, a row DT^2 FMAs -- at
     // D = 10 the exact instantiation does 30 % less work on this latency-bound path than the padded DT = 12
