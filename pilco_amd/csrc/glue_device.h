@@ -424,7 +424,7 @@ __host__ __device__ inline RbfInlineLayout rbf_inline_layout(int E, int U, int b
     l.T = o;   o += U * E * E;              // T_u = (s + Lambda_u^2)^-1
     l.Q = o;   o += P * E * E;              // Q_uv = R_uv^-1 s / 2
     l.det = o; o += nmat;                   // det B_u | det R_uv
-    l.pt = o;  o += bf * (2 * E + 2);       // per point of the current pair: u_i, v_i, p_i = 2 Q z_i, w_i
+    l.pt = o;  o += bf * (2 * E + 2) + bf * 16;   // per point of the current pair: u_i, v_i, p_i = 2 Q z_i, w_i | 16 doubles of scratch per point
     l.red = o; o += 4 * (E + 2);            // wave partials
     l.total = (o + 1) & ~1;
     return l;
@@ -531,42 +531,27 @@ __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueL
     }
     __syncthreads();
     const int lane = t & 63, w = t >> 6;
-    // ---- 2. mean and input-output covariance of every output (mgpr.py:113-118)
+    // ---- 2. mean and input-output covariance of every output (mgpr.py:113-118).  bf <= 256: thread i < bf owns point i;
+    //         plain run-time loops over LDS (no unrolled register arrays: this code sits in the serial link's instruction
+    //         stream, where its SIZE costs as much as its work)
     for (int u = 0; u < U; ++u) {
-        double gsum = 0.0;
-        double h[16];
-#pragma unroll
-        for (int d = 0; d < 16; ++d) h[d] = 0.0;
-        if (t < 256)
-            for (int i = t; i < bf; i += 256) {
-                double z[16];
-#pragma unroll
-                for (int d = 0; d < 16; ++d) z[d] = (d < E) ? ctr[d * bf + i] : 0.0;
-                double q = 0.0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (r < E) {
-                        double tz = 0.0;
-#pragma unroll
-                        for (int c = 0; c < 16; ++c)
-                            if (c < E) tz = fma(Tm[(u * E + r) * E + c], z[c], tz);
-                        q = fma(z[r], tz, q);
-                    }
-                const double lb = exp(-0.5 * q) * bet[u * bf + i];
-                gsum += lb;
-#pragma unroll
-                for (int d = 0; d < 16; ++d)
-                    if (d < E) h[d] = fma(z[d], lb, h[d]);
+        double lb = 0.0;
+        if (t < bf) {
+            double q = 0.0;
+            for (int r = 0; r < E; ++r) {
+                double tz = 0.0;
+                for (int c = 0; c < E; ++c) tz = fma(Tm[(u * E + r) * E + c], ctr[c * bf + t], tz);
+                q = fma(ctr[r * bf + t], tz, q);
             }
+            lb = exp(-0.5 * q) * bet[u * bf + t];
+        }
         if (t < 256) {
-            const double gs = wave_sum_lane63(gsum);
+            const double gs = wave_sum_lane63(lb);
             if (lane == 63) red[w * (E + 2)] = gs;
-#pragma unroll
-            for (int d = 0; d < 16; ++d)
-                if (d < E) {
-                    const double v = wave_sum_lane63(h[d]);
-                    if (lane == 63) red[w * (E + 2) + 1 + d] = v;
-                }
+            for (int d = 0; d < E; ++d) {
+                const double v = wave_sum_lane63((t < bf) ? ctr[d * bf + t] * lb : 0.0);
+                if (lane == 63) red[w * (E + 2) + 1 + d] = v;
+            }
         }
         __syncthreads();
         if (t <= E) red[t] = ((red[t] + red[(E + 2) + t]) + red[2 * (E + 2) + t]) + red[3 * (E + 2) + t];   // (row 0 receives the totals)
@@ -593,29 +578,33 @@ __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueL
             for (int i = t; i < 2 * bf; i += nthr) {
                 const int side = i >= bf, ii = side ? i - bf : i;
                 const double* ilo = il + (side ? b : a) * E;
-                double x[16], kk = side ? lb_ : la, quad = 0.0;
-#pragma unroll
-                for (int d = 0; d < 16; ++d) {
-                    const double zd = (d < E) ? ctr[d * bf + ii] : 0.0;
-                    x[d] = (d < E) ? zd * ilo[d] * ilo[d] : 0.0;
-                    if (d < E) kk = fma(-0.5 * zd, x[d], kk);
+                double* xrow = wv + ii * E;          // side 1: w_j is what stays here; side 0: scratch in the OTHER half below
+                if (!side) xrow = pv + ii * E;       // (z_i parks in the row that 2 Q z_i will overwrite: read completely first)
+                double kk = side ? lb_ : la;
+                for (int d = 0; d < E; ++d) {
+                    const double zd = ctr[d * bf + ii];
+                    const double xd = zd * ilo[d] * ilo[d];
+                    xrow[d] = xd;
+                    kk = fma(-0.5 * zd, xd, kk);
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r)   // (compile-time indices into x[]: no scratch array)
-                    if (r < E) {
-                        double y = 0.0;
-#pragma unroll
-                        for (int c = 0; c < 16; ++c)
-                            if (c < E) y = fma(Q[r * E + c], x[c], y);
-                        quad = fma(x[r], y, quad);
-                        if (!side) pv[ii * E + r] = 2.0 * y;
-                    }
+                double quad = 0.0;
                 if (side) {
-#pragma unroll
-                    for (int d = 0; d < 16; ++d)
-                        if (d < E) wv[ii * E + d] = x[d];
+                    for (int r = 0; r < E; ++r) {
+                        double y = 0.0;
+                        for (int c = 0; c < E; ++c) y = fma(Q[r * E + c], xrow[c], y);
+                        quad = fma(xrow[r], y, quad);
+                    }
                     vv[ii] = kk + quad;
                 } else {
+                    // y = Q z needs all of z while 2 y overwrites it: through the point's 16 doubles of scratch behind the vectors
+                    double* ytmp = pt + bf * (2 * E + 2) + ii * 16;
+                    for (int r = 0; r < E; ++r) {
+                        double y = 0.0;
+                        for (int c = 0; c < E; ++c) y = fma(Q[r * E + c], xrow[c], y);
+                        quad = fma(xrow[r], y, quad);
+                        ytmp[r] = 2.0 * y;
+                    }
+                    for (int r = 0; r < E; ++r) xrow[r] = ytmp[r];
                     uv[ii] = kk + quad;
                 }
             }
