@@ -71,7 +71,9 @@ __device__ __forceinline__ const PersistArgs& kargs() {
     return *(const PersistArgs*)(p + off);
 }
 
-template <int DT, int KC, bool VSEP>
+// PK: the controller code compiled into the link (glue_body<PK, true>: 0 none, 3 LinearController) -- the kernel walks
+// its whole instruction stream once per step, and the CU pair's 64 KB instruction cache is the resource to fit.
+template <int DT, int KC, bool VSEP, int PK>
 __global__ __launch_bounds__(PERSIST_THREADS) void k_rollout_persist(PersistArgs a_unused) {
     (void)a_unused;   // (declares the layout of the kernel-argument segment; read through kargs())
     extern __shared__ __attribute__((aligned(16))) double sm_all[];
@@ -193,8 +195,7 @@ __global__ __launch_bounds__(PERSIST_THREADS) void k_rollout_persist(PersistArgs
             g.lds_state = h > 0 ? 2 : 1;
             GlueLds L;
             glue_lds_carve(g, sm_all, L);
-            if (g.pol_kind == PILCO_POLICY_LINEAR) glue_body<3, true>(g, L, blockIdx.x == 0);
-            else glue_body<0, true>(g, L, blockIdx.x == 0);
+            glue_body<PK, true>(g, L, blockIdx.x == 0);
             PSTAMP(1);
         }
         if (closing) break;
@@ -290,19 +291,24 @@ size_t mm_persist_lds_bytes(const MMModel& md, const GlueArgs& g, int reward_E) 
 int launch_rollout_persist(hipStream_t st, const PersistArgs& a, int workgroups, size_t lds) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-#define PERSIST(DT_, KC_, VS_)                                                                                             \
+#define PERSIST1(DT_, KC_, VS_, PK_)                                                                                       \
     do {                                                                                                                   \
         static size_t configured_[64] = {};                                                                                \
         size_t& conf_ = configured_[dev & 63];                                                                             \
         if (conf_ == 0) conf_ = 48 * 1024;                                                                                 \
         if (lds > conf_) {                                                                                                 \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_persist<DT_, KC_, VS_>),                       \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_persist<DT_, KC_, VS_, PK_>),                  \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                   \
                 return -1;                                                                                                 \
             conf_ = lds;                                                                                                   \
         }                                                                                                                  \
-        hipLaunchKernelGGL((k_rollout_persist<DT_, KC_, VS_>), dim3(workgroups), dim3(PERSIST_THREADS), lds, st, a);       \
+        hipLaunchKernelGGL((k_rollout_persist<DT_, KC_, VS_, PK_>), dim3(workgroups), dim3(PERSIST_THREADS), lds, st, a);  \
         return 0;                                                                                                          \
+    } while (0)
+#define PERSIST(DT_, KC_, VS_)                                                  \
+    do {                                                                        \
+        if (a.g.pol_kind == PILCO_POLICY_LINEAR) PERSIST1(DT_, KC_, VS_, 3);    \
+        else PERSIST1(DT_, KC_, VS_, 0);                                        \
     } while (0)
     switch (a.md.D) {
         case 1: case 2: PERSIST(4, 1, false);
@@ -317,6 +323,7 @@ int launch_rollout_persist(hipStream_t st, const PersistArgs& a, int workgroups,
         default: return -1;
     }
 #undef PERSIST
+#undef PERSIST1
 }
 
 }  // namespace pilco
