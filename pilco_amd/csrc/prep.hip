@@ -1,40 +1,7 @@
 // k_mm_prep: per-step operands of the pair kernel, mean-part and reward workgroups.
-#include "prep_device.h"
+#include "prep_kernel.h"
 
 namespace pilco {
-
-// ------------------------------------------------------------------ prep
-// PK: the controller code compiled into the fused head's link (glue_body<PK, SR>): 0 none, 3 linear, 1 RBF from its own
-// launches, 2 RBF inline; SR: single rank (no peer exchange, no gathered segments).  The plain operand kernel (FUSED = false)
-// has no link and exists for <0, true> only.
-template <int DT, bool FUSED, int PK = 0, bool SR = true>
-__global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepReward pr, GlueArgs g, int glue_doubles) {
-    extern __shared__ __attribute__((aligned(16))) double sm_all[];
-    // FUSED: the serial link of the previous step runs first, redundantly in every workgroup (see glue_device.h); it
-    // leaves the joint Gaussian of THIS step (L.jm, L.js) and the current state (L.mx, L.sx) in the first glue_doubles
-    // doubles of LDS.  (All LDS pointers below are derived from sm_all unconditionally: no shared/global pointer merges.)
-    GlueLds L;
-    glue_lds_carve(g, sm_all, L);
-    // The model constants this workgroup needs (its lengthscales and signal variances) are requested BEFORE the serial
-    // link, so that their memory round trip overlaps with it instead of following it.
-    const bool spare_wg = (int)blockIdx.x >= wk.PL;
-    const int spare_idx = ((int)blockIdx.x - wk.PL) * (int)gridDim.y + (int)blockIdx.y;
-    const bool mean_wg = spare_wg && spare_idx < wk.EL * wk.NCHM;
-    int a = 0, b = 0;
-    if (!spare_wg) local_pair_ab(wk, md.E, (int)blockIdx.x, a, b);
-    else if (mean_wg) a = b = (spare_idx / wk.NCHM) * wk.nranks + wk.rank;   // the owner of (a,a) owns output a
-    double pre_la = 1.0, pre_lb = 1.0, pre_var = 1.0;
-    if (!spare_wg || mean_wg) {
-        if ((int)threadIdx.x < md.D) {
-            pre_la = md.ls[a * md.D + (int)threadIdx.x];
-            pre_lb = md.ls[b * md.D + (int)threadIdx.x];
-        }
-        pre_var = md.var[(threadIdx.x >> 8) ? b : a];
-    }
-    if (FUSED) glue_body<PK, SR>(g, L, blockIdx.x == 0 && blockIdx.y == 0);
-    prep_work<DT, FUSED, 512>(md, wk, pr, g, L, sm_all, glue_doubles, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, pre_la,
-                              pre_lb, pre_var);
-}
 
 size_t prep_lds_bytes(int DT) {
     const size_t pair_blk = (size_t)4 * DT + 2 * (size_t)DT * DT + 4 + 256 * (size_t)(DT + 1);
@@ -92,51 +59,25 @@ void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const P
     const int gd = fused ? (int)((glue_lds_doubles_for(ga) + 1) & ~(size_t)1) : 0;   // glue region of the fused head (even: 16-byte alignment)
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
-#define PREP1(DT_, F_, PK_, SR_)                                                                           \
-    do {                                                                                                   \
-        const size_t lds_ = std::max(prep_lds_bytes(DT_), lds_rw) + sizeof(double) * (size_t)gd;           \
-        static size_t configured_[64] = {};  /* beyond the default dynamic-LDS limit: opt in once PER DEVICE */ \
-        size_t& conf_ = configured_[dev_ & 63];                                                            \
-        if (conf_ == 0) conf_ = 48 * 1024;                                                                 \
-        if (lds_ > conf_) {                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mm_prep<DT_, F_, PK_, SR_>),         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);              \
-            conf_ = lds_;                                                                                  \
-        }                                                                                                  \
-        hipLaunchKernelGGL((k_mm_prep<DT_, F_, PK_, SR_>), grid, dim3(512), lds_, st, md, wk, r, ga, gd);  \
-    } while (0)
     // the fused head is instantiated per controller kind and for one rank / several (see glue_body): the serial link is a
     // chain of latencies through straight-line code, and code that is merely present in its stream costs microseconds
     const bool multi = fused && (ga.xq != nullptr || ga.xq_peers != nullptr || ga.wk.nranks != 1 ||
                                  (ga.flags & (GF_PACK | GF_ASSEMBLE | GF_PROPAGATE)) == (GF_ASSEMBLE | GF_PROPAGATE));
     const int pk = !fused ? 0 : (ga.pol_kind == PILCO_POLICY_RBF ? (ga.pol_inline ? 2 : 1) : (ga.pol_kind == PILCO_POLICY_LINEAR ? 3 : 0));
-#define PREP(DT_)                                              \
-    do {                                                       \
-        if (!fused) PREP1(DT_, false, 0, true);                \
-        else if (multi) {   /* sharded rollouts: none / linear / inline RBF */ \
-            if (pk == 0) PREP1(DT_, true, 0, false);           \
-            else if (pk == 3) PREP1(DT_, true, 3, false);      \
-            else PREP1(DT_, true, 2, false);                   \
-        } else if (pk == 0) PREP1(DT_, true, 0, true);         \
-        else if (pk == 3) PREP1(DT_, true, 3, true);           \
-        else if (pk == 1) PREP1(DT_, true, 1, true);           \
-        else PREP1(DT_, true, 2, true);                        \
-    } while (0)
+    const PrepLaunch a{st, grid, lds_rw, gd, dev_, fused != nullptr, multi, pk, &md, &wk, &r, &ga};
     // DT = D where it matters: the Gauss-Jordan costs 2 DT readlanes per pivot and DT pivots, a row DT^2 FMAs -- at
     // D = 10 the exact instantiation does 30 % less work on this latency-bound path than the padded DT = 12
-    if (D <= 4) PREP(4);
-    else if (D <= 6) PREP(6);
-    else if (D <= 8) PREP(8);
-    else if (D <= 10) PREP(10);
-    else if (D == 11) PREP(11);
-    else if (D <= 12) PREP(12);
-    else if (D <= 14) PREP(14);
-    else if (D <= 16) PREP(16);
-    else if (D <= 20) PREP(20);
-    else if (D <= 24) PREP(24);
-    else PREP(32);
-#undef PREP
-#undef PREP1
+    if (D <= 4) launch_prep_4(a);
+    else if (D <= 6) launch_prep_6(a);
+    else if (D <= 8) launch_prep_8(a);
+    else if (D <= 10) launch_prep_10(a);
+    else if (D == 11) launch_prep_11(a);
+    else if (D <= 12) launch_prep_12(a);
+    else if (D <= 14) launch_prep_14(a);
+    else if (D <= 16) launch_prep_16(a);
+    else if (D <= 20) launch_prep_20(a);
+    else if (D <= 24) launch_prep_24(a);
+    else launch_prep_32(a);
 }
 
 }  // namespace pilco

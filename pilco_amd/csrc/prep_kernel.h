@@ -1,0 +1,113 @@
+// k_mm_prep (the per-step operand kernel / fused head) and the per-DT launch helper.  The 8 instantiations per input
+// dimension DT (controller kind x rank layout, see glue_body) are compiled in SEPARATE translation units (prep_dt_*.hip:
+// one group of DTs each) so that the library still builds in about a minute; prep.hip holds the host-side dispatch.
+#pragma once
+#include "prep_device.h"
+
+namespace pilco {
+
+size_t prep_lds_bytes(int DT);
+
+// ------------------------------------------------------------------ prep
+// PK: the controller code compiled into the fused head's link (glue_body<PK, SR>): 0 none, 3 linear, 1 RBF from its own
+// launches, 2 RBF inline; SR: single rank (no peer exchange, no gathered segments).  The plain operand kernel (FUSED = false)
+// has no link and exists for <0, true> only.
+template <int DT, bool FUSED, int PK = 0, bool SR = true>
+__global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepReward pr, GlueArgs g, int glue_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double sm_all[];
+    // FUSED: the serial link of the previous step runs first, redundantly in every workgroup (see glue_device.h); it
+    // leaves the joint Gaussian of THIS step (L.jm, L.js) and the current state (L.mx, L.sx) in the first glue_doubles
+    // doubles of LDS.  (All LDS pointers below are derived from sm_all unconditionally: no shared/global pointer merges.)
+    GlueLds L;
+    glue_lds_carve(g, sm_all, L);
+    // The model constants this workgroup needs (its lengthscales and signal variances) are requested BEFORE the serial
+    // link, so that their memory round trip overlaps with it instead of following it.
+    const bool spare_wg = (int)blockIdx.x >= wk.PL;
+    const int spare_idx = ((int)blockIdx.x - wk.PL) * (int)gridDim.y + (int)blockIdx.y;
+    const bool mean_wg = spare_wg && spare_idx < wk.EL * wk.NCHM;
+    int a = 0, b = 0;
+    if (!spare_wg) local_pair_ab(wk, md.E, (int)blockIdx.x, a, b);
+    else if (mean_wg) a = b = (spare_idx / wk.NCHM) * wk.nranks + wk.rank;   // the owner of (a,a) owns output a
+    double pre_la = 1.0, pre_lb = 1.0, pre_var = 1.0;
+    if (!spare_wg || mean_wg) {
+        if ((int)threadIdx.x < md.D) {
+            pre_la = md.ls[a * md.D + (int)threadIdx.x];
+            pre_lb = md.ls[b * md.D + (int)threadIdx.x];
+        }
+        pre_var = md.var[(threadIdx.x >> 8) ? b : a];
+    }
+    if (FUSED) glue_body<PK, SR>(g, L, blockIdx.x == 0 && blockIdx.y == 0);
+    prep_work<DT, FUSED, 512>(md, wk, pr, g, L, sm_all, glue_doubles, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, pre_la,
+                              pre_lb, pre_var);
+}
+
+// arguments of one head launch, as launch_mm_prep has prepared them
+struct PrepLaunch {
+    hipStream_t st;
+    dim3 grid;
+    size_t lds_rw;    // LDS bytes of the reward workgroup (0: none)
+    int gd;           // doubles of the link's LDS region (0: plain operand kernel)
+    int dev;
+    bool fused, multi;
+    int pk;
+    const MMModel* md;
+    const MMWork* wk;
+    const PrepReward* r;
+    const GlueArgs* ga;
+};
+
+template <int DT>
+void launch_prep_dt(const PrepLaunch& a) {
+    const hipStream_t st = a.st;
+    const dim3 grid = a.grid;
+    const size_t lds_rw = a.lds_rw;
+    const int gd = a.gd, dev_ = a.dev, pk = a.pk;
+    const bool fused = a.fused, multi = a.multi;
+    const MMModel& md = *a.md;
+    const MMWork& wk = *a.wk;
+    const PrepReward& r = *a.r;
+    const GlueArgs& ga = *a.ga;
+#define PREP1(DT_, F_, PK_, SR_)                                                                           \
+    do {                                                                                                   \
+        const size_t lds_ = std::max(prep_lds_bytes(DT_), lds_rw) + sizeof(double) * (size_t)gd;           \
+        static size_t configured_[64] = {};  /* beyond the default dynamic-LDS limit: opt in once PER DEVICE */ \
+        size_t& conf_ = configured_[dev_ & 63];                                                            \
+        if (conf_ == 0) conf_ = 48 * 1024;                                                                 \
+        if (lds_ > conf_) {                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mm_prep<DT_, F_, PK_, SR_>),         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);              \
+            conf_ = lds_;                                                                                  \
+        }                                                                                                  \
+        hipLaunchKernelGGL((k_mm_prep<DT_, F_, PK_, SR_>), grid, dim3(512), lds_, st, md, wk, r, ga, gd);  \
+    } while (0)
+#define PREP(DT_)                                              \
+    do {                                                       \
+        if (!fused) PREP1(DT_, false, 0, true);                \
+        else if (multi) {   /* sharded rollouts: none / linear / inline RBF */ \
+            if (pk == 0) PREP1(DT_, true, 0, false);           \
+            else if (pk == 3) PREP1(DT_, true, 3, false);      \
+            else PREP1(DT_, true, 2, false);                   \
+        } else if (pk == 0) PREP1(DT_, true, 0, true);         \
+        else if (pk == 3) PREP1(DT_, true, 3, true);           \
+        else if (pk == 1) PREP1(DT_, true, 1, true);           \
+        else PREP1(DT_, true, 2, true);                        \
+    } while (0)
+    PREP(DT);
+#undef PREP
+#undef PREP1
+}
+
+// defined in prep_dt_*.hip
+void launch_prep_4(const PrepLaunch& a);
+void launch_prep_6(const PrepLaunch& a);
+void launch_prep_8(const PrepLaunch& a);
+void launch_prep_10(const PrepLaunch& a);
+void launch_prep_11(const PrepLaunch& a);
+void launch_prep_12(const PrepLaunch& a);
+void launch_prep_14(const PrepLaunch& a);
+void launch_prep_16(const PrepLaunch& a);
+void launch_prep_20(const PrepLaunch& a);
+void launch_prep_24(const PrepLaunch& a);
+void launch_prep_32(const PrepLaunch& a);
+
+}  // namespace pilco
