@@ -40,7 +40,11 @@ namespace pilco {
 #ifndef PAIR_MINW
 #define PAIR_MINW 1    // __launch_bounds__ min waves per SIMD for the pair kernel
 #endif
-template <int KC, bool DIAG, bool VSEP>
+// FENCE: an s_nop between the MFMA chain of a tile and the first VALU read of its result (MFMA_RESULT_FENCE, mm_device.h).
+// The pair kernels do not need it (the compiler keeps 7 + p slots there); inside the persistent rollout kernel, under its
+// 168-register budget, the same source is scheduled with reads of destination pairs 2 and 3 one slot early
+// (tools/mfma_hazard_check.py, tests/test_build_isa.py), so that host asks for the fence.
+template <int KC, bool DIAG, bool VSEP, bool FENCE = false>
 __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const double* __restrict__ Bt,
                                             const double* __restrict__ vcol,
                                             const double* __restrict__ beta_a, const double* __restrict__ beta_b,
@@ -108,6 +112,7 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
             for (int c = 0; c < KC; ++c) e = PAIR_ABL_MFMA(af[rt][c], bf[c], e);
             MFMA_KEEP_ALIVE(af[rt][0]);   // (first MFMA of the chain: constant-zero accumulator, see mm_device.h)
             MFMA_KEEP_ALIVE(bf[0]);
+            if (FENCE) MFMA_RESULT_FENCE(e);
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[4 * rt + r] = VSEP ? e[r] + vv : e[r];   // C/D column = lane & 15: one v_j per lane
         }
@@ -229,7 +234,7 @@ __device__ __forceinline__ int sk_boundary(const MMWork& wk, int w) {
 // One wave's share of the stream-K line (see k_mm_pair_sk): the 16-column steps [boundary(w), boundary(w + 1)) of the
 // cost line, touching at most two local pairs p0, p1 (-1: none) with the sums out0, out1 (before the wave reduction).
 // `ready(pl)` is called once before the first tile of every pair the range touches.
-template <int KC, bool VSEP, typename Ready>
+template <int KC, bool VSEP, bool FENCE = false, typename Ready>
 __device__ __forceinline__ void sk_wave_range(const MMModel& md, const MMWork& wk, const double* __restrict__ tab, int w, int lane,
                                               Ready ready, double& out0, double& out1, int& p0, int& p1) {
     const int npad = md.npad, NS = npad / 16, KP = wk.KP;
@@ -287,9 +292,9 @@ __device__ __forceinline__ void sk_wave_range(const MMModel& md, const MMWork& w
         const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
         const int i0 = ti * 16 * PAIR_RT, jbeg = sidx * 16, jend = jbeg + seg * 16;
         if (dg)
-            cur += pair_wave<KC, true, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab, npad, i0, jbeg, jend, lane);
+            cur += pair_wave<KC, true, VSEP, FENCE>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab, npad, i0, jbeg, jend, lane);
         else
-            cur += pair_wave<KC, false, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jend, lane);
+            cur += pair_wave<KC, false, VSEP, FENCE>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jend, lane);
         step += seg;
     }
     if (cur_pl >= 0) {

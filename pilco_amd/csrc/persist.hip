@@ -246,7 +246,7 @@ __global__ __launch_bounds__(PERSIST_THREADS) void k_rollout_persist(PersistArgs
                 wkh.sk_part = wk0.sk_part + (size_t)h * a.sPart;
                 double out0, out1;
                 int p0, p1;
-                sk_wave_range<KC, VSEP>(a.md, wkh, tab, w, lane, [](int) {}, out0, out1, p0, p1);
+                sk_wave_range<KC, VSEP, true>(a.md, wkh, tab, w, lane, [](int) {}, out0, out1, p0, p1);   // (fenced MFMA results: see pair_wave)
                 for (int off = 32; off > 0; off >>= 1) {
                     out0 += __shfl_down(out0, off);
                     out1 += __shfl_down(out1, off);
