@@ -114,84 +114,68 @@ __device__ __forceinline__ void multi_load(double* lds, const LoadSeg (&sg)[NSEG
 __device__ __forceinline__ void squash_inplace(const GlueLds& L, int U, const double* maxact, double* cdiag) {
     const int t = threadIdx.x;
     const int nm = L.nm, nm_sq = nm * nm;
-    const int nel = 5 * U * U + 3 * U;
-    if (nel <= 4 * nm_sq + nm && nel <= (int)blockDim.x * 8) {
-        double* sc = L.t1;
-        for (int i = t; i < nel; i += blockDim.x) {
-            double val;
-            if (i < 5 * U * U) {
-                const int e = i / 5, j = i - 5 * e;
-                const int u = e / U, v = e - u * U;
+    // ONE inlined copy of each library function (exp, cos, sin), whatever element a thread evaluates: the argument and
+    // the function are selected first.  (The first version had a copy per branch and a second, sequential code path for
+    // large U -- 14 inlined transcendental bodies, ~20 KB of a link whose instruction stream is on the step's critical
+    // path)  The 5 U^2 + 3 U evaluations of the reference's formulas (exp(lq), exp(lq +- s),
+    // cos(m_u -+ m_v) per element; exp, cos, sin per control) are independent: each goes to its own thread, in rounds when
+    // the scratch (t1 .. js: 4 nm^2 + nm values) is smaller than that; then one combining phase per round.
+    double* sc = L.t1;
+    const int cap = ((4 * nm_sq + nm) / 5) * 5;      // whole items per round: an item is 5 slots (a control uses 3 of its 5)
+    const int nitems = U * U + U;                    // items 0 .. U^2 - 1: covariance elements, then the U controls
+    // the new covariance must not overwrite su while later rounds still read it: it is collected in registers per thread
+    // (element e = t + k * blockDim of the U x U matrix; U <= 32, blockDim >= 256: k < 4) and stored after the last round
+    double newS[4] = {0.0, 0.0, 0.0, 0.0};
+    double newM = 0.0, newC = 0.0;
+    for (int i0 = 0; i0 < 5 * nitems; i0 += cap) {
+        const int n = (5 * nitems - i0) < cap ? (5 * nitems - i0) : cap;
+        for (int k = t; k < n; k += blockDim.x) {
+            const int q = (i0 + k) / 5, j = (i0 + k) - 5 * q;
+            double arg;
+            int fn;   // 0 exp, 1 cos, 2 sin, 3 unused slot
+            if (q < U * U) {
+                const int u = q / U, v = q - u * U;
                 const double lq = -(L.su[u * U + u] + L.su[v * U + v]) / 2.0;
-                const double suv = L.su[e];
-                if (j == 0) val = exp(lq);
-                else if (j == 1) val = exp(lq + suv);
-                else if (j == 2) val = exp(lq - suv);
-                else if (j == 3) val = cos(L.mu[u] - L.mu[v]);
-                else val = cos(L.mu[u] + L.mu[v]);
+                const double suv = L.su[q];
+                arg = (j == 0) ? lq : (j == 1) ? lq + suv : (j == 2) ? lq - suv : (j == 3) ? L.mu[u] - L.mu[v] : L.mu[u] + L.mu[v];
+                fn = (j < 3) ? 0 : 1;
             } else {
-                const int r = i - 5 * U * U;
-                const int u = r / 3, j = r - 3 * u;
-                if (j == 0) val = exp(-L.su[u * U + u] / 2.0);
-                else if (j == 1) val = cos(L.mu[u]);
-                else val = sin(L.mu[u]);
+                const int u = q - U * U;
+                arg = (j == 0) ? -L.su[u * U + u] / 2.0 : L.mu[u];
+                fn = (j < 3) ? j : 3;
             }
-            sc[i] = val;
+            if (fn < 3) sc[k] = (fn == 0) ? exp(arg) : (fn == 1) ? cos(arg) : sin(arg);
         }
         __syncthreads();
-        double newS[8], newM = 0.0, newC = 0.0;   // U*U <= 8 * blockDim (checked above through nel)
-        int cnt = 0;
+        const int q0 = i0 / 5, q1 = (i0 + n) / 5;    // items [q0, q1) are complete in this round
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 4; ++k) {
             const int e = t + k * (int)blockDim.x;
-            newS[k] = 0.0;
-            if (e < U * U) {
+            if (e < U * U && e >= q0 && e < q1) {
                 const int u = e / U, v = e - u * U;
-                const double q = sc[5 * e], ep = sc[5 * e + 1], em = sc[5 * e + 2], c1 = sc[5 * e + 3], c2 = sc[5 * e + 4];
-                const double val = (ep - q) * c1 - (em - q) * c2;
+                const double* r = sc + 5 * (e - q0);
+                const double val = (r[1] - r[0]) * r[3] - (r[2] - r[0]) * r[4];
                 const double eu = maxact ? maxact[u] : 1.0, ev = maxact ? maxact[v] : 1.0;
                 newS[k] = eu * ev * val / 2.0;
             }
         }
-        (void)cnt;
-        if (t < U) {
+        if (t < U && U * U + t >= q0 && U * U + t < q1) {
             const double eu = maxact ? maxact[t] : 1.0;
-            const double* r = sc + 5 * U * U + 3 * t;
+            const double* r = sc + 5 * (U * U + t - q0);
             newC = eu * r[0] * r[1];
             newM = eu * r[0] * r[2];
         }
-        // (no barrier: the combine phase above reads only the scratch `sc`; su / mu / cdiag are written below)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int e = t + k * (int)blockDim.x;
-            if (e < U * U) L.su[e] = newS[k];
-        }
-        if (t < U) {
-            cdiag[t] = newC;
-            L.mu[t] = newM;
-        }
         __syncthreads();
-        return;
     }
-    for (int e = t; e < U * U; e += blockDim.x) {
-        const int u = e / U, v = e - u * U;
-        const double du = L.su[u * U + u], dv = L.su[v * U + v];
-        const double lq = -(du + dv) / 2.0;
-        const double q = exp(lq);
-        const double suv = L.su[e];
-        const double val = (exp(lq + suv) - q) * cos(L.mu[u] - L.mu[v]) - (exp(lq - suv) - q) * cos(L.mu[u] + L.mu[v]);
-        const double eu = maxact ? maxact[u] : 1.0, ev = maxact ? maxact[v] : 1.0;
-        L.t2[e] = eu * ev * val / 2.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = t + k * (int)blockDim.x;
+        if (e < U * U) L.su[e] = newS[k];
     }
     if (t < U) {
-        const double eu = maxact ? maxact[t] : 1.0;
-        const double ex = exp(-L.su[t * U + t] / 2.0);
-        cdiag[t] = eu * ex * cos(L.mu[t]);
-        L.misc[64 + t] = eu * ex * sin(L.mu[t]);
+        cdiag[t] = newC;
+        L.mu[t] = newM;
     }
-    __syncthreads();
-    for (int e = t; e < U * U; e += blockDim.x) L.su[e] = L.t2[e];
-    if (t < U) L.mu[t] = L.misc[64 + t];
     __syncthreads();
 }
 
