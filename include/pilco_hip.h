@@ -116,7 +116,9 @@ int pilco_gp_nlml(pilco_ctx* ctx, int slot, double* nlml, double* grad);
  * OWN inducing inputs: pilco/models/smgpr.py:16-22) and its gradient w.r.t. (lengthscales[D], kernel variance, noise
  * variance) and w.r.t. the inducing inputs -- what MGPR.optimize's SciPy loop receives for an SMGPR
  * (pilco/models/mgpr.py:47-75; no priors, smgpr.py sets none).  Z_all (E,M,D); nlml (E); grad_hyp (E,D+2) and
- * grad_Z (E,M,D) may be NULL.  Uses the slot's data and hyper-parameters; invalidates its cached factorisation. */
+ * grad_Z (E,M,D) may be NULL.  Uses the slot's data and hyper-parameters; invalidates its cached factorisation. 
+ * Several ranks: sharded by output exactly like pilco_gp_nlml (own outputs evaluated, all-gather with a communicator, NaN for
+ * the other ranks' outputs without one). */
 int pilco_gp_fitc_nlml(pilco_ctx* ctx, int slot, const double* Z_all, int M, double* nlml, double* grad_hyp, double* grad_Z);
 /* number of points the moment-matching runs over: N (exact) or M (sparse) */
 int pilco_gp_num_points(const pilco_ctx* ctx, int slot);

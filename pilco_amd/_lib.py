@@ -609,6 +609,18 @@ def group_nlml(ctxs, slot, D, E):
     return nlml, grad
 
 
+def group_fitc_nlml(ctxs, slot, Z_all, D, E):
+    """pilco_gp_fitc_nlml over the contexts of one process that shard a sparse model by output (see group_nlml)."""
+    Z_all = np.asarray(Z_all, np.float64)
+    nlml, gh, gz = np.full(E, np.nan), np.full((E, D + 2), np.nan), np.full(Z_all.shape, np.nan)
+    for c in ctxs:
+        n, h, z = c.gp_fitc_nlml(slot, Z_all, D, E)
+        own = ~np.isnan(n)
+        assert not np.any(own & ~np.isnan(nlml)), "two ranks claim the same output"
+        nlml[own], gh[own], gz[own] = n[own], h[own], z[own]
+    return nlml, gh, gz
+
+
 def group_sync_model(ctxs, slot=0):
     """Exchange the beta rows of the contexts of this process after each has factorised its own outputs."""
     arr = (_vp * len(ctxs))(*[c.h for c in ctxs])

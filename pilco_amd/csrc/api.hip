@@ -158,11 +158,7 @@ int all_gather_segments(pilco_ctx* ctx, Slot& s) {
 }
 
 // ---- which outputs this rank factorises, and their hyper-parameters / targets compacted for the batched kernels
-struct OwnView {
-    int W, rank, EL, ELcap;
-    const double *ls, *var, *noise, *Yt;   // [EL][D], [EL], [EL], [EL][Npad]
-};
-static int prepare_own(pilco_ctx* ctx, Slot& s, OwnView& o) {
+int prepare_own(pilco_ctx* ctx, Slot& s, OwnView& o) {
     o.W = ctx->nranks;
     o.rank = ctx->rank;
     if (&s == &ctx->slot[PILCO_SLOT_POLICY]) {   // the RbfController's GP is never sharded: every rank factorises all of it

@@ -162,6 +162,12 @@ int fail(pilco_ctx* c, int code, const std::string& msg);
     } while (0)
 
 // api.hip
+// which outputs this rank factorises / trains, and their hyper-parameters / targets compacted for the batched kernels
+struct OwnView {
+    int W, rank, EL, ELcap;
+    const double *ls, *var, *noise, *Yt;   // [EL][D], [EL], [EL], [EL][Npad]
+};
+int prepare_own(pilco_ctx* ctx, Slot& s, OwnView& o);
 int check_slot(pilco_ctx* ctx, int slot);
 int build_work(pilco_ctx* ctx, Slot& s);          // (re)builds the per-slot step workspace and its geometry
 MMModel model_of(const Slot& s);

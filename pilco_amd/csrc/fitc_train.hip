@@ -152,15 +152,12 @@ __global__ __launch_bounds__(256) void k_fitc_sums(const double* __restrict__ y,
 
 using namespace pilco;
 
-extern "C" int pilco_gp_fitc_nlml(pilco_ctx* ctx, int slot, const double* Z_all, int M, double* nlml, double* grad_hyp, double* grad_Z) {
-    if (int r = check_slot(ctx, slot)) return r;
-    Slot& s = ctx->slot[slot];
-    if (!s.has_data || !s.has_hyp) return fail(ctx, PILCO_E_STATE, "fitc_nlml needs set_data and set_hyp first");
-    if (!Z_all || M <= 0 || !nlml) return fail(ctx, PILCO_E_SHAPE, "fitc_nlml: bad arguments");
-    if (s.D > FT_MAXD) return fail(ctx, PILCO_E_SHAPE, "fitc_nlml: D > 32");
-    if (ctx->nranks != 1) return fail(ctx, PILCO_E_STATE, "fitc_nlml: hyper-parameter training runs unsharded (one rank)");
+// The objective for a batch of E outputs given as compact arrays (all outputs of the slot on one rank; the outputs a rank
+// owns when the model is sharded): ls [E][D], var [E], noise [E], Yt [E][Npad], Z_all [E][M][D] (host).
+static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, const double* o_var, const double* o_noise, const double* o_Yt,
+                           const double* Z_all, int M, double* nlml, double* grad_hyp, double* grad_Z) {
     HIPCHK(hipSetDevice(ctx->device));
-    const int E = s.E, D = s.D, N = s.N, Np = s.Npad, Mp = round_up(M, NB), nblk = Mp / NB;
+    const int D = s.D, N = s.N, Np = s.Npad, Mp = round_up(M, NB), nblk = Mp / NB;
     const size_t mm = (size_t)Mp * Mp, mn = (size_t)Mp * Np;
     hipStream_t st = ctx->st;
     // the slot's FITC buffers are scratch here; whatever factorisation the slot held is invalidated
@@ -190,8 +187,8 @@ extern "C" int pilco_gp_fitc_nlml(pilco_ctx* ctx, int slot, const double* Z_all,
     const long sZ = (long)D * Mp;
     double* Kuu = s.K.p;
     double* V = s.V2.p;
-    launch_gram(st, Zt, Mp, M, Zt, Mp, M, D, s.ls.p, s.var.p, E, Kuu, Mp, Mp, 2, nullptr, 1e-6, sZ, sZ);
-    launch_gram(st, Zt, Mp, M, s.Xt.p, Np, N, D, s.ls.p, s.var.p, E, s.Kmn.p, Mp, Np, 0, nullptr, 0.0, sZ, 0);
+    launch_gram(st, Zt, Mp, M, Zt, Mp, M, D, o_ls, o_var, E, Kuu, Mp, Mp, 2, nullptr, 1e-6, sZ, sZ);
+    launch_gram(st, Zt, Mp, M, s.Xt.p, Np, N, D, o_ls, o_var, E, s.Kmn.p, Mp, Np, 0, nullptr, 0.0, sZ, 0);
     launch_potrf(st, Kuu, Mp, E, s.invD.p, ctx->d_info);
     launch_trtri(st, Kuu, Mp, E, s.invD.p, s.Linv.p, s.Tscr.p, (long)mm);
     GemmDesc g{};
@@ -200,14 +197,14 @@ extern "C" int pilco_gp_fitc_nlml(pilco_ctx* ctx, int slot, const double* Z_all,
     g.C = V; g.ldc = Np; g.sC = (long)mn;
     g.M = Mp; g.N = Np; g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.k_mode = 3;
     launch_gemm(st, g, false, false, E);
-    launch_fitc_scale(st, V, Mp, Np, E, s.var.p, s.noise.p, s.G.p);     // G = sqrt(nu) / sn, V <- Vb = V / G
+    launch_fitc_scale(st, V, Mp, Np, E, o_var, o_noise, s.G.p);     // G = sqrt(nu) / sn, V <- Vb = V / G
     g = GemmDesc{};                                          // Am = Vb Vb^T + sn2 I = sn2 B
     g.A = V; g.lda = Np; g.sA = (long)mn;
     g.B = V; g.ldb = Np; g.sB = (long)mn;
     g.C = s.Am.p; g.ldc = Mp; g.sC = (long)mm;
     g.M = Mp; g.N = Mp; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
     launch_gemm(st, g, false, true, E);
-    launch_add_diag(st, s.Am.p, Mp, E, s.noise.p);
+    launch_add_diag(st, s.Am.p, Mp, E, o_noise);
     launch_potrf(st, s.Am.p, Mp, E, s.AmD.p, ctx->d_info + 32);          // Am = sn L
     launch_trtri(st, s.Am.p, Mp, E, s.AmD.p, s.AmInv.p, s.Tscr.p, (long)mm);
     g = GemmDesc{};                                          // iAt = Am^-1 Luu^-1 = L^-1 Luu^-1 / sn
@@ -222,7 +219,7 @@ extern "C" int pilco_gp_fitc_nlml(pilco_ctx* ctx, int slot, const double* Z_all,
     double* gv = av + (size_t)E * Np;                        // [E][Np]
     double* cv = gv + (size_t)E * Np;                        // [E][Mp]
     double* sums = cv + (size_t)E * Mp;                      // [E][3] + logdet [E]
-    launch_fitc_rhs(st, V, s.G.p, s.Yt.p, Mp, Np, E, r0);
+    launch_fitc_rhs(st, V, s.G.p, o_Yt, Mp, Np, E, r0);
     launch_matvec(st, s.AmInv.p, Mp, E, r0, gam, false);
     launch_logdet(st, s.Am.p, Mp, M, E, sums + 3 * E);
     const bool want_grad = grad_hyp || grad_Z;
@@ -234,7 +231,7 @@ extern "C" int pilco_gp_fitc_nlml(pilco_ctx* ctx, int slot, const double* Z_all,
         g.C = s.ft_P.p; g.ldc = Np; g.sC = (long)mn;
         g.M = Mp; g.N = Np; g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.k_mode = 3;
         launch_gemm(st, g, false, false, E);
-        hipLaunchKernelGGL(k_fitc_cols, dim3((Np + 255) / 256, E), dim3(256), 0, st, s.ft_P.p, gam, s.G.p, s.Yt.p, s.noise.p, M, Mp, N, Np, av, gv);
+        hipLaunchKernelGGL(k_fitc_cols, dim3((Np + 255) / 256, E), dim3(256), 0, st, s.ft_P.p, gam, s.G.p, o_Yt, o_noise, M, Mp, N, Np, av, gv);
         g = GemmDesc{};                                      // A' = Luu^-T Vb   (A = Kuu^-1 Kuf = A' o G)
         g.A = s.Linv.p; g.lda = Mp; g.sA = (long)mm;
         g.B = V; g.ldb = Np; g.sB = (long)mn;
@@ -258,21 +255,21 @@ extern "C" int pilco_gp_fitc_nlml(pilco_ctx* ctx, int slot, const double* Z_all,
         launch_gemm(st, g, false, true, E);
         double* part_uf = s.Tscr.p;
         double* part_uu = part_uf + (size_t)E * Mp * (2 * FT_MAXD + 1);
-        hipLaunchKernelGGL(k_fitc_kgrad, dim3(M, E), dim3(256), 0, st, s.ft_T3.p, Np, Zt, Mp, s.Xt.p, Np, 0L, N, D, s.ls.p, s.var.p,
+        hipLaunchKernelGGL(k_fitc_kgrad, dim3(M, E), dim3(256), 0, st, s.ft_T3.p, Np, Zt, Mp, s.Xt.p, Np, 0L, N, D, o_ls, o_var,
                            (const double*)nullptr, 0.0, part_uf);
-        hipLaunchKernelGGL(k_fitc_kgrad, dim3(M, E), dim3(256), 0, st, s.iK.p, Mp, Zt, Mp, Zt, Mp, sZ, M, D, s.ls.p, s.var.p,
+        hipLaunchKernelGGL(k_fitc_kgrad, dim3(M, E), dim3(256), 0, st, s.iK.p, Mp, Zt, Mp, Zt, Mp, sZ, M, D, o_ls, o_var,
                            (const double*)cv, -0.5, part_uu);
         hz.resize((size_t)2 * E * Mp * (2 * FT_MAXD + 1));
         HIPCHK(hipMemcpyAsync(hz.data(), part_uf, sizeof(double) * hz.size(), hipMemcpyDeviceToHost, st));
     } else {
         HIPCHK(hipMemsetAsync(gv, 0, sizeof(double) * (size_t)E * Np, st));
     }
-    hipLaunchKernelGGL(k_fitc_sums, dim3(E), dim3(256), 0, st, s.Yt.p, s.G.p, gv, N, Np, sums);
+    hipLaunchKernelGGL(k_fitc_sums, dim3(E), dim3(256), 0, st, o_Yt, s.G.p, gv, N, Np, sums);
     std::vector<double> hs(4 * (size_t)E), hg((size_t)E * Mp), hn(E);
     int info[64];
     HIPCHK(hipMemcpyAsync(hs.data(), sums, sizeof(double) * 4 * E, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(hg.data(), gam, sizeof(double) * (size_t)E * Mp, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(hn.data(), s.noise.p, sizeof(double) * E, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hn.data(), o_noise, sizeof(double) * E, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(info, ctx->d_info, sizeof(int) * 64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
@@ -308,6 +305,69 @@ extern "C" int pilco_gp_fitc_nlml(pilco_ctx* ctx, int slot, const double* Z_all,
             for (int m = 0; m < M; ++m)
                 for (int d = 0; d < D; ++d)
                     grad_Z[((size_t)e * M + m) * D + d] = -(uf[(size_t)m * PW + d] + 2.0 * uu[(size_t)m * PW + d]);
+    }
+    return PILCO_OK;
+}
+
+extern "C" int pilco_gp_fitc_nlml(pilco_ctx* ctx, int slot, const double* Z_all, int M, double* nlml, double* grad_hyp, double* grad_Z) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    if (!s.has_data || !s.has_hyp) return fail(ctx, PILCO_E_STATE, "fitc_nlml needs set_data and set_hyp first");
+    if (!Z_all || M <= 0 || !nlml) return fail(ctx, PILCO_E_SHAPE, "fitc_nlml: bad arguments");
+    if (s.D > FT_MAXD) return fail(ctx, PILCO_E_SHAPE, "fitc_nlml: D > 32");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int E = s.E, D = s.D;
+    if (ctx->nranks == 1) return fitc_nlml_batch(ctx, s, E, s.ls.p, s.var.p, s.noise.p, s.Yt.p, Z_all, M, nlml, grad_hyp, grad_Z);
+    // Several ranks: sharded by output like the factorisation -- every output's GPRFITC model is its own problem
+    // with its own inducing inputs (smgpr.py:16-22).  This rank evaluates the outputs a = rank, rank + W, ... from compacted
+    // copies of their hyper-parameters and targets and writes them at their global places; one ncclAllGather completes every
+    // rank's arrays when a communicator is attached, otherwise the other ranks' entries are NaN and the caller combines.
+    OwnView o{};
+    if (int r = prepare_own(ctx, s, o)) return r;
+    const int EL = o.EL, W = o.W, rank = o.rank;
+    const size_t per = 1 + (size_t)(D + 2) + (size_t)M * D;   // nlml | d hyp | d Z of one output
+    const double nan = std::nan("");
+    for (int a = 0; a < E; ++a) {
+        nlml[a] = nan;
+        if (grad_hyp) for (int k = 0; k < D + 2; ++k) grad_hyp[(size_t)a * (D + 2) + k] = nan;
+        if (grad_Z) for (size_t k = 0; k < (size_t)M * D; ++k) grad_Z[(size_t)a * M * D + k] = nan;
+    }
+    std::vector<double> Zo((size_t)std::max(EL, 1) * M * D), no(std::max(EL, 1)), gho((size_t)std::max(EL, 1) * (D + 2)), gzo((size_t)std::max(EL, 1) * M * D);
+    for (int al = 0; al < EL; ++al) memcpy(&Zo[(size_t)al * M * D], Z_all + (size_t)(al * W + rank) * M * D, sizeof(double) * M * D);
+    if (EL > 0) {
+        const int r = fitc_nlml_batch(ctx, s, EL, o.ls, o.var, o.noise, o.Yt, Zo.data(), M, no.data(), grad_hyp ? gho.data() : nullptr, grad_Z ? gzo.data() : nullptr);
+        if (r == PILCO_E_NOT_PD && ctx->not_pd >= 0) ctx->not_pd = ctx->not_pd * W + rank;   // local -> global output index
+        if (r) return r;
+    }
+    std::vector<double> own((size_t)o.ELcap * per, 0.0);
+    for (int al = 0; al < EL; ++al) {
+        const int a = al * W + rank;
+        nlml[a] = no[al];
+        own[(size_t)al * per] = no[al];
+        if (grad_hyp) {
+            memcpy(grad_hyp + (size_t)a * (D + 2), &gho[(size_t)al * (D + 2)], sizeof(double) * (D + 2));
+            memcpy(&own[(size_t)al * per + 1], &gho[(size_t)al * (D + 2)], sizeof(double) * (D + 2));
+        }
+        if (grad_Z) {
+            memcpy(grad_Z + (size_t)a * M * D, &gzo[(size_t)al * M * D], sizeof(double) * M * D);
+            memcpy(&own[(size_t)al * per + 1 + D + 2], &gzo[(size_t)al * M * D], sizeof(double) * M * D);
+        }
+    }
+    if (ctx->comm) {
+        const size_t blk = (size_t)o.ELcap * per;
+        ENSURE(s.vec, (size_t)(W + 1) * blk);
+        std::vector<double> all((size_t)W * blk);
+        HIPCHK(hipMemcpyAsync(s.vec.p + (size_t)W * blk, own.data(), sizeof(double) * blk, hipMemcpyHostToDevice, ctx->st));
+        ncclResult_t r = ncclAllGather(s.vec.p + (size_t)W * blk, s.vec.p, blk, ncclDouble, ctx->comm, ctx->st);
+        if (r != ncclSuccess) return fail(ctx, PILCO_E_RCCL, std::string("ncclAllGather(fitc_nlml): ") + ncclGetErrorString(r));
+        HIPCHK(hipMemcpyAsync(all.data(), s.vec.p, sizeof(double) * W * blk, hipMemcpyDeviceToHost, ctx->st));
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        for (int a = 0; a < E; ++a) {
+            const double* src = all.data() + ((size_t)(a % W) * o.ELcap + a / W) * per;
+            nlml[a] = src[0];
+            if (grad_hyp) memcpy(grad_hyp + (size_t)a * (D + 2), src + 1, sizeof(double) * (D + 2));
+            if (grad_Z) memcpy(grad_Z + (size_t)a * M * D, src + 1 + D + 2, sizeof(double) * M * D);
+        }
     }
     return PILCO_OK;
 }

@@ -744,6 +744,12 @@ def test_training_objective_sharded_by_output(nranks):
         n2, g2 = ref.gp_nlml(0, D, E)
         n3, g3 = _lib.group_nlml(group, 0, D, E)
         assert np.array_equal(n2, n3) and np.array_equal(g2, g3) and not np.array_equal(n2, n1)
+        # the sparse objective (GPRFITC.training_loss, every output with its own inducing inputs: smgpr.py:16-22) likewise
+        M = 24
+        Z_all = np.random.RandomState(3).randn(E, M, D)
+        f1, h1, z1 = ref.gp_fitc_nlml(0, Z_all, D, E)
+        f2, h2, z2 = _lib.group_fitc_nlml(group, 0, Z_all, D, E)
+        assert np.all(np.isfinite(f1)) and np.array_equal(f1, f2) and np.array_equal(h1, h2) and np.array_equal(z1, z2)
     finally:
         for cx in made:
             cx.close()
