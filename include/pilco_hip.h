@@ -303,6 +303,13 @@ int pilco_gp_beta_import(pilco_ctx* ctx, int slot, const double* all_rows);
 int pilco_rollout_group(pilco_ctx** ctxs, int n, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
                         const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj,
                         int* mismatch);
+/* Value and gradient of ONE sharded rollout (pilco_rollout_grad, LinearController) over n contexts of this process, as
+ * pilco_rollout_group does the forward rollout: every rank sweeps its own pairs, the per-pair Jacobian records are
+ * all-gathered once after the horizon (between processes pilco_rollout_grad does that itself with ncclAllGather when a
+ * communicator is attached), every rank runs the same host reverse sweep on the same records.  reward [n], dW [n][U*E],
+ * db [n][U]: every rank's results (bit-identical to one another). */
+int pilco_rollout_grad_group(pilco_ctx** ctxs, int n, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                             const double* m0, const double* S0, int H, double* reward, double* dW, double* db);
 /* Peer exchange: the per-step all-gather without a collective call.  Every rank owns an exchange area in its GPU's
  * memory; after its pair kernel a rank stores its segment straight into EVERY rank's area (over xGMI between GPUs) and
  * raises its flag there; the next step's head waits for the W flags of that exchange and reads the segments from its

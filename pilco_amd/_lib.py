@@ -116,6 +116,7 @@ SIGNATURES = {
     "pilco_shard_output_slot": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "pilco_gp_shard_pack": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "pilco_gp_shard_finish": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
+    "pilco_rollout_grad_group": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]),
     "pilco_rollout_group": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp,
                             C.c_int, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     "pilco_group_sync_model": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int]),
@@ -595,6 +596,21 @@ class Context:
 
     def peer_attached(self):
         return bool(self.lib.pilco_peer_attached(self.h))
+
+
+def rollout_grad_group(ctxs, policy, rewards, m0, S0, H):
+    """Value and gradient of one sharded rollout over the contexts of this process (pilco_rollout_grad_group):
+    (reward (n,), dW (n, U, E), db (n, U)) -- every rank's results."""
+    c0 = ctxs[0]
+    n = len(ctxs)
+    E, U = policy["state_dim"], policy["control_dim"]
+    p, k1 = c0._policy(policy)
+    r, k2 = c0._rewards(rewards, E)
+    m0 = _f64(m0, (E,)); S0 = _f64(S0, (E, E))
+    arr = (_vp * n)(*[c.h for c in ctxs])
+    rew, dW, db = np.zeros(n), np.empty((n, U, E)), np.empty((n, U))
+    c0._chk(c0.lib.pilco_rollout_grad_group(arr, n, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H), _ptr(rew), _ptr(dW), _ptr(db)))
+    return rew, dW, db
 
 
 def group_nlml(ctxs, slot, D, E):

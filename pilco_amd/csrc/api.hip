@@ -313,6 +313,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     ctx->traj.release();
     ctx->tape.release();
     ctx->jrec.release();
+    ctx->jgath.release();
     ctx->selftest.release();
     ctx->exp_tab.release();
     for (hipEvent_t e : ctx->pair_events) (void)hipEventDestroy(e);

@@ -1020,7 +1020,7 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
     const int nrc = mm_bwd_rc(md.npad);
     BwdBatch bb;
     bb.rowmom = (long)mm_jac_rowmom_size(md.npad, P);
-    bb.cpart = (long)mm_jac_cpart_size(md.npad, P, E);
+    bb.cpart = (long)mm_jac_cpart_size(md.npad, P, wk.EL);   // (EL = E on one rank; the first EL local pairs are the diagonal ones)
     bb.part = (long)mm_jac_part_size(D, E, P, md.npad);
     bb.head = (long)mm_jac_head_size(D, E, P);
     bb.in_m = tape;

@@ -111,6 +111,7 @@ struct pilco_ctx {
     DevBuf traj;
     DevBuf tape;
     DevBuf jrec;             // Jacobian tape: [H][mm_jac_rec_size] records of a value-and-gradient rollout
+    DevBuf jgath;            // sharded value-and-gradient rollout: [W + 1][H][PLcap * recp] pair records (own block last) for the all-gather
     double* jpin = nullptr;  // pinned host copy of (traj | tape | jrec) for the host-side reverse sweep
     size_t jpin_cap = 0;
     hipEvent_t jwait_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // behind the chunks of the records' download (last steps first)

@@ -262,7 +262,7 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
         wk0.pair_part = s.jac_np.p;
         g.wk = wk0;
     }
-    const size_t j_rm = jac ? mm_jac_rowmom_size(s.npad, s.wk.PL) : 0, j_cp = jac ? mm_jac_cpart_size(s.npad, s.wk.PL, s.E) : 0,
+    const size_t j_rm = jac ? mm_jac_rowmom_size(s.npad, s.wk.PL) : 0, j_cp = jac ? mm_jac_cpart_size(s.npad, s.wk.PL, s.wk.EL) : 0,
                  j_hd = jac ? mm_jac_head_size(s.D, s.E, s.wk.PL) : 0;
     auto dyn_pairs = [&](const MMWork& w, int t) {
         if (jac)
@@ -1173,7 +1173,16 @@ int pilco_rollout_tape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_r
 int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
                   const double* S0, int H, double* reward, const double** traj, const double** tape, const double** jrec, size_t* jstride) {
     HIPCHK(hipSetDevice(ctx->device));
-    if (ctx->nranks != 1 || ctx->comm) return fail(ctx, PILCO_E_STATE, "rollout_grad: single rank only");
+    // Several ranks (round 3): every rank sweeps ITS pairs (k_mm_bwd_pair is per-pair independent; the mean-part records of
+    // all E outputs are cheap and computed everywhere), the per-step exchange of the forward chain is the sharded
+    // rollout's own (RCCL all-gather, or host-mediated inside pilco_rollout_grad_group), and after the batched finish the
+    // per-pair records are all-gathered ONCE -- records, not sums: the host sweep below adds them in the single-rank order.
+    const int W = ctx->nranks;
+    const bool sharded = (W != 1 || ctx->comm);
+    if (sharded && !ctx->comm && !ctx->group)
+        return fail(ctx, PILCO_E_STATE, "rollout_grad: a sharded context needs a communicator (pilco_comm_init) or pilco_rollout_grad_group");
+    if (sharded && policy && policy->kind == PILCO_POLICY_RBF)
+        return fail(ctx, PILCO_E_STATE, "rollout_grad: the sharded reverse pass serves the LinearController (an RbfController's sharded rollout needs the peer exchange, which carries no tape)");
     RolloutPlan plan;
     if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, true, plan)) return r;
     Slot& s = ctx->slot[0];
@@ -1184,18 +1193,28 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     // every step keeps its own sweep output until the batched finish (nothing on the chain waits for a buffer): at C2u
     // 29 MB per step -- HBM is 288 GB; a rollout that would need more than PILCO_JAC_GB (default 32) falls back
     const size_t Hn = (size_t)std::max(H, 1);
-    const size_t per_step = mm_jac_rowmom_size(npad, P) + mm_jac_cpart_size(npad, P, E) + mm_jac_head_size(D, E, P) + mm_jac_part_size(D, E, P, npad);
+    const int ELc = s.wk.EL;   // owned outputs = diagonal pairs held here (E on one rank)
+    const size_t per_step = mm_jac_rowmom_size(npad, P) + mm_jac_cpart_size(npad, P, ELc) + mm_jac_head_size(D, E, P) + mm_jac_part_size(D, E, P, npad);
     double cap_gb = 32.0;
     if (const char* ev = getenv("PILCO_JAC_GB")) cap_gb = atof(ev);
     if ((double)per_step * 8.0 * (double)Hn > cap_gb * 1e9) return PILCO_JAC_TOO_LARGE;
     ENSURE(s.jac_rowmom, Hn * mm_jac_rowmom_size(npad, P));
-    ENSURE(s.jac_cpart, Hn * mm_jac_cpart_size(npad, P, E));
+    ENSURE(s.jac_cpart, Hn * mm_jac_cpart_size(npad, P, ELc));
     ENSURE(s.jac_head, Hn * mm_jac_head_size(D, E, P));
     ENSURE(s.jac_part, Hn * mm_jac_part_size(D, E, P, npad));
     ENSURE(s.jac_np, (size_t)2 * std::max(P, 1) * mm_jac_nt(npad, P));
     ENSURE(ctx->tape, std::max<size_t>(1, (size_t)H * TS));
     ENSURE(ctx->jrec, std::max<size_t>(1, (size_t)H * JS));
-    const size_t need = NTJ + (size_t)H * TS + (size_t)H * JS + 8;
+    // sharded: the host sweep reads GLOBAL records [P_all pair records | E output records] per step, assembled on the host
+    // from every rank's pair records (all-gathered) and this rank's own output records
+    const int NT2 = D * (D + 1) / 2, recp = 1 + D + NT2, Pall = E * (E + 1) / 2, PLcap = (Pall + W - 1) / W;
+    const size_t reco = (size_t)D + NT2 + (size_t)D * D + (size_t)D * NT2;
+    const size_t JSg = sharded ? (size_t)Pall * recp + (size_t)E * reco : JS;
+    // one rank's block: per step its pair records (padded to PLcap) and the E output records (every rank WITH pairs computes
+    // them all; a rank without pairs runs no sweep at all, so the readers take them from rank 0, which always has pairs)
+    const size_t gstep = (size_t)PLcap * recp + (size_t)E * reco;
+    const size_t gblk = (size_t)std::max(H, 1) * gstep;
+    const size_t need = NTJ + (size_t)H * TS + (size_t)H * JSg + 8 + (sharded ? (size_t)W * gblk : 0);
     if (ctx->jpin_cap < need) {
         if (ctx->jpin) (void)hipHostFree(ctx->jpin);
         ctx->jpin = nullptr;
@@ -1209,7 +1228,8 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     double* h_traj = ctx->jpin;
     double* h_tape = h_traj + NTJ;
     double* h_jrec = h_tape + (size_t)H * TS;
-    double* h_misc = h_jrec + (size_t)H * JS;
+    double* h_misc = h_jrec + (size_t)H * JSg;
+    double* h_all = h_misc + 8;                          // sharded: [W][H][PLcap * recp | E * reco]
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(hipMemcpyAsync(plan.st[0], m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
         HIPCHK(hipMemcpyAsync(plan.st[0] + E, S0, sizeof(double) * E * E, hipMemcpyHostToDevice, ctx->st));
@@ -1225,7 +1245,42 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     ctx->jwait_from = H;
     ctx->jwait_next = 0;
     ctx->jwait_n = 0;
-    if (H > 0) {
+    if (H > 0 && sharded) {
+        HIPCHK(hipMemcpyAsync(h_tape, ctx->tape.p, sizeof(double) * (size_t)H * TS, hipMemcpyDeviceToHost, ctx->st));
+        ENSURE(ctx->jgath, (size_t)(W + 1) * gblk);
+        double* own = ctx->jgath.p + (size_t)W * gblk;
+        HIPCHK(hipMemsetAsync(own, 0, sizeof(double) * gblk, ctx->st));
+        if (P > 0) {   // this rank's records of every step, compacted: [H][PLcap pair records | E output records]
+            HIPCHK(hipMemcpy2DAsync(own, sizeof(double) * gstep, ctx->jrec.p, sizeof(double) * JS, sizeof(double) * P * recp, (size_t)H,
+                                    hipMemcpyDeviceToDevice, ctx->st));
+            HIPCHK(hipMemcpy2DAsync(own + (size_t)PLcap * recp, sizeof(double) * gstep, ctx->jrec.p + (size_t)P * recp, sizeof(double) * JS,
+                                    sizeof(double) * E * reco, (size_t)H, hipMemcpyDeviceToDevice, ctx->st));
+        }
+        if (ctx->comm) {
+            ncclResult_t r = ncclAllGather(own, ctx->jgath.p, gblk, ncclDouble, ctx->comm, ctx->st);
+            if (r != ncclSuccess) return fail(ctx, PILCO_E_RCCL, std::string("ncclAllGather(jacobian records): ") + ncclGetErrorString(r));
+            HIPCHK(hipMemcpyAsync(h_all, ctx->jgath.p, sizeof(double) * (size_t)W * gblk, hipMemcpyDeviceToHost, ctx->st));
+            HIPCHK(hipStreamSynchronize(ctx->st));
+        } else {   // contexts of one process (pilco_rollout_grad_group): read the peers' blocks between two host barriers
+            HIPCHK(hipStreamSynchronize(ctx->st));
+            std::shared_ptr<PeerGroup> grp = ctx->group;
+            if (!grp->arrive_and_wait()) return fail(ctx, PILCO_E_STATE, "rollout_grad: another rank of the group failed");
+            for (int j = 0; j < W; ++j) {
+                pilco_ctx* pj = grp->ctxs[j];
+                HIPCHK(hipMemcpy(h_all + (size_t)j * gblk, pj->jgath.p + (size_t)W * gblk, sizeof(double) * gblk, hipMemcpyDeviceToHost));
+            }
+            if (!grp->arrive_and_wait()) return fail(ctx, PILCO_E_STATE, "rollout_grad: another rank of the group failed");
+        }
+        HIPCHK(hipGetLastError());
+        for (int t = 0; t < H; ++t) {   // global record of step t: pair kk of the dealing order lives on rank kk % W as its pair kk / W
+            double* dst = h_jrec + (size_t)t * JSg;
+            for (int kk = 0; kk < Pall; ++kk)
+                memcpy(dst + (size_t)kk * recp, h_all + (size_t)(kk % W) * gblk + (size_t)t * gstep + (size_t)(kk / W) * recp, sizeof(double) * recp);
+            memcpy(dst + (size_t)Pall * recp, h_all + (size_t)t * gstep + (size_t)PLcap * recp, sizeof(double) * E * reco);   // rank 0's
+        }
+        ctx->jwait_n = 0;
+        ctx->jwait_from = 0;
+    } else if (H > 0) {
         HIPCHK(hipMemcpyAsync(h_tape, ctx->tape.p, sizeof(double) * (size_t)H * TS, hipMemcpyDeviceToHost, ctx->st));
         const int nch = std::min(H, 4);
         for (int k = 0; k < nch; ++k) {
@@ -1246,7 +1301,7 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     *traj = h_traj;
     *tape = h_tape;
     *jrec = h_jrec;
-    *jstride = JS;
+    *jstride = JSg;
     return PILCO_OK;
 }
 

@@ -341,6 +341,38 @@ int pilco_rollout_group(pilco_ctx** ctxs, int n, const pilco_policy* policy, con
     return PILCO_OK;
 }
 
+// Value and gradient of one sharded rollout over n contexts of THIS process (see pilco_rollout_group): every context runs
+// pilco_rollout_grad on a host thread; the per-step exchange of the forward chain and the one all-gather of the per-pair
+// Jacobian records are done by copies between host barriers.  Outputs of every rank: reward [n], dW [n][U*E], db [n][U].
+int pilco_rollout_grad_group(pilco_ctx** ctxs, int n, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                             const double* m0, const double* S0, int H, double* reward, double* dW, double* db) {
+    if (!ctxs || n <= 0 || !ctxs[0]) return PILCO_E_SHAPE;
+    pilco_ctx* c0 = ctxs[0];
+    if (!policy || !reward || !dW || !db) return fail(c0, PILCO_E_SHAPE, "rollout_grad_group: null pointer");
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i] || ctxs[i]->nranks != n || ctxs[i]->rank != i || ctxs[i]->comm)
+            return fail(c0, PILCO_E_STATE, "rollout_grad_group: context i must be shard_set(i, n) and have no communicator");
+    const int E = policy->state_dim, U = policy->control_dim;
+    auto grp = std::make_shared<PeerGroup>();
+    grp->ctxs.assign(ctxs, ctxs + n);
+    for (int i = 0; i < n; ++i) ctxs[i]->group = grp;
+    std::vector<int> rc(n, PILCO_OK);
+    std::vector<std::thread> th;
+    for (int i = 0; i < n; ++i)
+        th.emplace_back([&, i] {
+            rc[i] = pilco_rollout_grad(ctxs[i], policy, rewards, n_rewards, m0, S0, H, reward + i, dW + (size_t)i * U * E, db + (size_t)i * U);
+            if (rc[i] != PILCO_OK) grp->fail_all();
+        });
+    for (auto& t : th) t.join();
+    for (int i = 0; i < n; ++i) ctxs[i]->group.reset();
+    for (int i = 0; i < n; ++i)
+        if (rc[i] != PILCO_OK) {
+            if (i != 0) c0->err = "rank " + std::to_string(i) + ": " + ctxs[i]->err;
+            return rc[i];
+        }
+    return PILCO_OK;
+}
+
 // ------------------------------------------------------------------ peer exchange (include/pilco_hip.h)
 int pilco_peer_export(pilco_ctx* ctx, void* handle64) {
     if (!ctx || !handle64) return PILCO_E_SHAPE;

@@ -707,6 +707,47 @@ def test_sharded_step_two_contexts_host_allgather(variant, nranks):
             cx.close()
 
 
+@pytest.mark.parametrize("E,U,nranks", [(5, 1, 2), (4, 2, 3), (3, 1, 8)])
+def test_sharded_value_and_gradient_rollout(E, U, nranks):
+    """The reverse pass over several ranks (pilco.py:85-90 is what every rank of a sharded optimize_policy needs): every rank
+    sweeps its own pairs (Jacobian tape), the per-pair records are all-gathered once, every rank runs the host reverse sweep
+    on the same records.  All ranks agree to the bit; value and gradient agree with the single-rank run to rounding (the
+    tile partials of the sweep depend on the local pair count) and with a second run bitwise."""
+    from pilco_amd import _lib
+    D, H = E + U, 6
+    c = synthetic.config_c2(N=200, D=D, E=E, noise=1e-2, seed=61, control_dim=U)
+    pol = dict(kind=_lib.POLICY_LINEAR, state_dim=E, control_dim=U, W=c["W"], b=c["b"].ravel(), max_action=1.3, squash=True)
+    rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(E), t=np.zeros(E))]
+    m0, S0 = c["m0"], 0.05 * np.eye(E)
+    made = []
+
+    def ctx_for(rank, n):
+        cx = _lib.Context(device=0)
+        made.append(cx)
+        if n > 1:
+            cx.shard_set(rank, n)
+        cx.gp_set_data(0, c["X"], c["Y"]); cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"]); cx.gp_factorize(0)
+        return cx
+    try:
+        ref = ctx_for(0, 1)
+        r1, W1, b1 = ref.rollout_grad(pol, rw, m0, S0, H)
+        group = [ctx_for(r, nranks) for r in range(nranks)]
+        _lib.group_sync_model(group)
+        with pytest.raises(_lib.PilcoError):          # a sharded context on its own has nobody to exchange with
+            group[0].rollout_grad(pol, rw, m0, S0, H)
+        out = [_lib.rollout_grad_group(group, pol, rw, m0, S0, H) for _ in range(2)]
+        rew, dW, db = out[0]
+        for i in range(1, nranks):
+            assert rew[i] == rew[0] and np.array_equal(dW[i], dW[0]) and np.array_equal(db[i], db[0])
+        assert all(np.array_equal(a, b) for a, b in zip(out[0], out[1]))
+        np.testing.assert_allclose(rew[0], r1, rtol=1e-11)
+        np.testing.assert_allclose(dW[0], W1, rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(db[0], b1, rtol=1e-8, atol=1e-12)
+    finally:
+        for cx in made:
+            cx.close()
+
+
 @pytest.mark.parametrize("nranks", [2, 3, 8])
 def test_training_objective_sharded_by_output(nranks):
     """pilco_gp_nlml (GPR.training_loss + gradient inside MGPR.optimize, mgpr.py:47-56) sharded like the factorisation under
