@@ -114,8 +114,8 @@ struct pilco_ctx {
     DevBuf jgath;            // sharded value-and-gradient rollout: [W + 1][H][PLcap * recp] pair records (own block last) for the all-gather
     double* jpin = nullptr;  // pinned host copy of (traj | tape | jrec) for the host-side reverse sweep
     size_t jpin_cap = 0;
-    hipEvent_t jwait_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // behind the chunks of the records' download (last steps first)
-    int jwait_t0[4] = {0, 0, 0, 0}, jwait_n = 0, jwait_next = 0, jwait_from = 0;   // first step of chunk k; steps >= jwait_from are on the host
+    hipEvent_t jwait_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // behind the chunks of the records' download (last steps first)
+    int jwait_t0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, jwait_n = 0, jwait_next = 0, jwait_from = 0;   // first step of chunk k; steps >= jwait_from are on the host
     DevBuf selftest;
     DevBuf exp_tab;  // 2^(j/n), j = 0..n-1, n = mm_exp_table_size()
     unsigned long long* dbg = nullptr;

@@ -176,11 +176,16 @@ void launch_gemm(hipStream_t st, const GemmDesc& g, bool ta, bool tb, int batch)
 }
 
 // ------------------------------------------------------------------ Cholesky
-// Factor the kb-th 64x64 diagonal block and invert the factor, ONE wave per matrix with the block in
-// registers: lane i holds row i.  Column j: the pivot comes from lane j by v_readlane, the scaled column is
-// published through a 64-double LDS line that every lane reads back as broadcasts, and the trailing update
-// is 63-j independent FMAs per lane -- no workgroup barriers, no LDS-resident matrix on the critical path.
-// L^-1: lane j solves column j by forward substitution against broadcast rows of L (four partial sums).
+// Factor the kb-th 64x64 diagonal block and invert the factor, TWO waves per matrix, one behind the other:
+//   wave 0 (factor): the block in registers, lane i holds row i.  Column j: the scaled column l = L[:, j] is published as one
+//     contiguous LDS line (every lane reads it back as broadcasts for its 62 - j trailing FMAs); the NEXT pivot does not
+//     wait for that round trip -- column j + 1 is updated first, from v_readlane, and its reciprocal square root is in
+//     flight while the other trailing columns are updated (one basic block: the scheduler interleaves the two);
+//   wave 1 (inverse): lane j holds column j of X = L^-1 and runs the right-looking substitution one column BEHIND wave 0:
+//     step k needs column k of L and 1 / L_kk only, i.e. exactly what wave 0 has just published:
+//     x_k *= 1 / L_kk,  x_i -= L_ik x_k  (i > k).
+// Wave 1 follows a column count in LDS; wave 0 never waits for it.  Round 2 ran both parts in ONE wave, one after the other
+// (38 us per block on the factorisation's critical path, 16 blocks at N = 1000).
 // replaces tf.linalg.cholesky at pilco/models/mgpr.py:84 / smgpr.py:29,35
 __device__ __forceinline__ double rsqrt_f64(double d) {
     double y = __builtin_amdgcn_rsq(d);
@@ -188,75 +193,169 @@ __device__ __forceinline__ double rsqrt_f64(double d) {
     y = fma(y, fma(-0.5 * d * y, y, 0.5), y);
     return y;
 }
-__global__ __launch_bounds__(64) void k_potf2_inv(double* __restrict__ Aall, int npad, int kb,
-                                                  double* __restrict__ invD, int* __restrict__ info) {
-    constexpr int LD = 66;   // 16-byte aligned rows, lanes of a column spread over the banks
-    __shared__ __attribute__((aligned(16))) double Ls[64 * LD];
-    __shared__ __attribute__((aligned(16))) double col[64];
-    __shared__ double rd[64];
+__device__ __forceinline__ double lane_bcast(double v, int l) {   // v of lane l (l wave-uniform) as a scalar
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// One column of wave 0's factor loop (k_potf2_inv below), J a compile-time constant (a recursive template instead of an
+// unrolled loop: with the hand-ordered body the loop grew past the size clang unrolls BEFORE it decides whether a[] can
+// live in registers, and a[] went to scratch memory).
+struct Potf2State {
+    double l, rinv;   // column J of L (lane i >= J: L[i][J]) and 1 / sqrt(pivot J)
+    int bad;
+};
+constexpr int POTF2_LD = 66;   // 16-byte aligned lines, lanes of a column spread over the banks
+template <int J, int K, int G>
+__device__ __forceinline__ void potf2_share(double (&a)[64], const double (&t)[64], double l) {
+    // the K-th of eight shares of the trailing updates of column J: columns J + 2 + K G .. (G each), LAST column first -- its
+    // operand is the last one requested, and LDS reads return in order: one s_waitcnt per share instead of one per read
+#pragma unroll
+    for (int q = G - 1; q >= 0; --q) {
+        constexpr int c0 = J + 2 + K * G;
+        const int c = c0 + q < 64 ? c0 + q : 63;
+        if (c0 + q < 64) a[c] = fma(-l, t[c], a[c]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int J>
+__device__ __forceinline__ void potf2_columns(double (&a)[64], Potf2State& st, double* Ls, double* rinvs, double* dump_d, int* published,
+                                              int* dump_i, int lane, int kb) {
+    constexpr int LD = POTF2_LD;
+    const double l = st.l;
+    // Publish column J: line, 1 / sqrt(pivot), then the count -- three LDS stores of ONE wave, which the LDS executes in the
+    // order they were issued, so wave 1 finds the line behind the count without this wave waiting for anything (a workgroup
+    // barrier per column made wave 0 drain its stores and meet wave 1 sixty-four times).  Every line is written after this
+    // wave has read the block out of it: same ordering argument.  Branch-free: lanes past 0 store into a dump -- a
+    // conditional block per column lets the compiler sink the trailing updates towards their uses across the columns, with
+    // every loaded line kept alive (7 KB of spills).
+    Ls[J * LD + lane] = (lane >= J) ? l : 0.0;
+    *((lane == 0) ? &rinvs[J] : &dump_d[lane]) = st.rinv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (no instruction: the compiler keeps the stores in this order)
+    __hip_atomic_store((lane == 0) ? published : &dump_i[lane], J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if constexpr (J < 63) {
+        // The trailing columns' operands (this line, read back as broadcasts) are requested first and ALL AT ONCE: the
+        // compiler's own order kept three or four reads in flight and waited for each (an LDS round trip per four columns:
+        // 670 cycles per column, 20 us for the loop).  Then the pivot chain of column J + 1 -- its own update from
+        // v_readlane, the pivot, the reciprocal square root: a dozen DEPENDENT operations -- with one share of the trailing
+        // updates behind every link, order pinned by scheduling barriers.
+        // (Taking the first few operands from v_readlane instead, to have work for the line's LDS round trip, made the loop
+        // slower: 16.0 -> 18.7 us.  The wave is bound by the NUMBER of instructions it issues, about 5 cycles each.)
+        // (16-byte reads from an even entry on: for odd J the first pair starts one entry early -- the misaligned pairs
+        // cost a ds_read2_b64 with an address register of its own each: 500 more instructions and twice the LDS cycles)
+        double t[64];
+#pragma unroll
+        for (int c = (J + 2) & ~1; c < 64; c += 2) {
+            const double2 pr = *reinterpret_cast<const double2*>(&Ls[J * LD + c]);
+            t[c] = pr.x;
+            t[c + 1] = pr.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int G = (62 - J + 7) / 8;
+        a[J + 1] = fma(-l, lane_bcast(l, J + 1), a[J + 1]);
+        double dn = lane_bcast(a[J + 1], J + 1);
+        const bool ok = dn > 0.0;   // false for NaN too
+        st.bad = (!ok && st.bad == 0) ? kb * 64 + J + 2 : st.bad;
+        dn = ok ? dn : 1.0;
+        potf2_share<J, 0, G>(a, t, l);
+        double y = __builtin_amdgcn_rsq(dn);   // rsqrt_f64(dn), link by link
+        const double h = -0.5 * dn;
+        potf2_share<J, 1, G>(a, t, l);
+        double u = h * y;
+        potf2_share<J, 2, G>(a, t, l);
+        double v = fma(u, y, 0.5);
+        potf2_share<J, 3, G>(a, t, l);
+        y = fma(y, v, y);
+        potf2_share<J, 4, G>(a, t, l);
+        u = h * y;
+        potf2_share<J, 5, G>(a, t, l);
+        v = fma(u, y, 0.5);
+        potf2_share<J, 6, G>(a, t, l);
+        y = fma(y, v, y);
+        potf2_share<J, 7, G>(a, t, l);
+        st.rinv = y;
+        st.l = a[J + 1] * y;
+        potf2_columns<J + 1>(a, st, Ls, rinvs, dump_d, published, dump_i, lane, kb);
+    }
+}
+__global__ __launch_bounds__(128) void k_potf2_inv(double* __restrict__ Aall, int npad, int kb,
+                                                   double* __restrict__ invD, int* __restrict__ info) {
+    constexpr int LD = POTF2_LD;
+    __shared__ __attribute__((aligned(16))) double Ls[64 * LD];   // first the block (row-major), then line j = column j of L
+    __shared__ double rinvs[64];                                   // 1 / sqrt(pivot j)
+    __shared__ int published;                                      // columns of L wave 0 has put out
+    __shared__ double dump_d[64];
+    __shared__ int dump_i[64];
     const int b = blockIdx.x;
     const int nblk = npad / 64;
     double* A = Aall + (long)b * npad * npad + (long)kb * 64 * npad + kb * 64;
-    const int lane = threadIdx.x;
-    for (int r = 0; r < 64; ++r) Ls[r * LD + lane] = A[(long)r * npad + lane];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#ifdef POTF2_STAMPS   // developer aid (tools/ubench_potf2.hip): 100 MHz stamps of matrix 0 behind the info words
+    unsigned long long* stp = reinterpret_cast<unsigned long long*>(info + 64);
+#define POTF2_STAMP(i_) do { if (b == 0 && lane == 0) stp[i_] = wall_clock64(); } while (0)
+#else
+#define POTF2_STAMP(i_) do { } while (0)
+#endif
+    if (w == 0) POTF2_STAMP(0);
+    if (threadIdx.x == 0) published = 0;
+    {   // the block, 32 rows per wave, all loads in flight together (one by one they cost a memory round trip each: 10 us)
+        double v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = A[(long)(2 * q + w) * npad + lane];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) Ls[(2 * q + w) * LD + lane] = v[q];
+    }
     __syncthreads();
-    double a[64];
+    if (w == 0) POTF2_STAMP(1);
+    if (w == 0) {
+        double a[64];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) a[c] = Ls[lane * LD + c];
-    int bad = 0;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[j]), j),
-                                    __builtin_amdgcn_readlane(__double2loint(a[j]), j));
+        for (int c = 0; c < 64; ++c) a[c] = Ls[lane * LD + c];
+        int bad = 0;
+        double d = lane_bcast(a[0], 0);
         if (!(d > 0.0)) {  // also catches NaN
-            if (bad == 0) bad = kb * 64 + j + 1;
+            bad = kb * 64 + 1;
             d = 1.0;
         }
-        const double rinv = rsqrt_f64(d);
-        const double l = a[j] * rinv;   // lane i >= j: L[i][j]; lane j: sqrt(d)
-        a[j] = l;
-        if (j < 63) {
-            col[lane] = l;
-            __syncthreads();
+        double rinv = rsqrt_f64(d);
+        double l = a[0] * rinv;   // lane i >= j: L[i][j]; lane j: sqrt(d)
+        Potf2State st{l, rinv, bad};
+        potf2_columns<0>(a, st, Ls, rinvs, dump_d, &published, dump_i, lane, kb);
+        bad = st.bad;
+        if (bad && lane == 0) atomicCAS(&info[b], 0, bad);
+        POTF2_STAMP(2);
+    } else {
+        double x[64];
 #pragma unroll
-            for (int c = j + 1; c < 64; ++c) a[c] = fma(-l, col[c], a[c]);
+        for (int i = 0; i < 64; ++i) x[i] = (i == lane) ? 1.0 : 0.0;
+#ifndef POTF2_NO_INVERSE   // (developer switch of tools/ubench_potf2.hip: wave 0 alone)
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            // wait for column k (bounded: wave 0 depends on nothing, so the bound is never met; a bug must not hang the GPU)
+            for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(&published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k; ++spin)
+                __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double xk = x[k] * rinvs[k];
+            x[k] = xk;
+#pragma unroll
+            for (int i = k + 1; i < 64; ++i) x[i] = fma(-Ls[k * LD + i], xk, x[i]);
         }
+#endif
+        POTF2_STAMP(3);
+        double* out = invD + ((long)b * nblk + kb) * 4096;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) out[i * 64 + lane] = x[i];
+        POTF2_STAMP(4);
     }
-    if (bad && lane == 0) atomicCAS(&info[b], 0, bad);
     __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 64; ++c) Ls[lane * LD + c] = (c <= lane) ? a[c] : 0.0;
-    __syncthreads();
-    rd[lane] = 1.0 / Ls[lane * LD + lane];
-    __syncthreads();
-    for (int r = 0; r < 64; ++r) A[(long)r * npad + lane] = Ls[r * LD + lane];
-    // inverse of the lower-triangular block: lane j owns column j
-    double x[64];
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-        for (int k = 0; k + 3 < i; k += 4) {
-            s0 = fma(Ls[i * LD + k], x[k], s0);
-            s1 = fma(Ls[i * LD + k + 1], x[k + 1], s1);
-            s2 = fma(Ls[i * LD + k + 2], x[k + 2], s2);
-            s3 = fma(Ls[i * LD + k + 3], x[k + 3], s3);
-        }
-#pragma unroll
-        for (int k = i & ~3; k < i; ++k) s0 = fma(Ls[i * LD + k], x[k], s0);
-        const double rhs = (i == lane ? 1.0 : 0.0) - ((s0 + s1) + (s2 + s3));
-        x[i] = rhs * rd[i];
-    }
-    double* out = invD + ((long)b * nblk + kb) * 4096;
-#pragma unroll
-    for (int i = 0; i < 64; ++i) out[i * 64 + lane] = x[i];
+    for (int r = w; r < 64; r += 2) A[(long)r * npad + lane] = Ls[lane * LD + r];   // L[r][lane] = line `lane`, entry r (zero above the diagonal)
+    if (w == 0) POTF2_STAMP(5);
+#undef POTF2_STAMP
 }
 
 void launch_potrf(hipStream_t st, double* A, int npad, int batch, double* invD, int* info) {
     const int nblk = npad / 64;
     const long sA = (long)npad * npad;
     for (int kb = 0; kb < nblk; ++kb) {
-        hipLaunchKernelGGL(k_potf2_inv, dim3(batch), dim3(64), 0, st, A, npad, kb, invD, info);
+        hipLaunchKernelGGL(k_potf2_inv, dim3(batch), dim3(128), 0, st, A, npad, kb, invD, info);
         const int rem = nblk - kb - 1;
         if (rem <= 0) break;
         double* panel = A + (long)(kb + 1) * 64 * npad + kb * 64;

@@ -1,6 +1,7 @@
 // Rollouts (PILCO.predict / propagate, pilco/models/pilco.py:118-153): plan, launch sequence, hipGraph capture
 // and replay, and the policy / reward evaluation entry points.
 #include "ctx.h"
+#include <chrono>
 
 namespace {
 
@@ -228,15 +229,20 @@ static int xq_begin(pilco_ctx* ctx) {
 // state ends up in plan.st[H & 1].  The reward of state t (pilco.py:133) is evaluated by the
 // second workgroup of the glue launch that turns state t into state t+1.
 static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev);
+// Jacobian tape: the sums, moments and records of steps [t0, t1) in two launches behind the chain (rollout_jtape enqueues
+// them per chunk of steps, last steps first, each followed by its download: the host's reverse sweep works on one chunk
+// while the device finishes the next)
+static void jac_finish_range(pilco_ctx* ctx, const RolloutPlan& plan, int t0, int t1) {
+    Slot& s = ctx->slot[0];
+    const int D = plan.D, E = plan.E, P = s.wk.PL;
+    const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
+    const size_t o = (size_t)t0;
+    launch_mm_jac_finish(ctx->st, model_of(s), s.wk, t1 - t0, s.jac_rowmom.p + o * mm_jac_rowmom_size(s.npad, P),
+                         s.jac_cpart.p + o * mm_jac_cpart_size(s.npad, P, s.wk.EL), s.jac_head.p + o * mm_jac_head_size(D, E, P),
+                         s.jac_part.p + o * mm_jac_part_size(D, E, P, s.npad), plan.g.tape + o * TS, TS, plan.jrec + o * plan.jstride);
+}
 int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev) {
-    if (int r = enqueue_rollout_steps(ctx, plan, H, pair_ev)) return r;
-    if (plan.jrec && H > 0) {   // Jacobian tape: the H steps' sums, moments and records in two launches behind the chain
-        Slot& s = ctx->slot[0];
-        launch_mm_jac_finish(ctx->st, model_of(s), s.wk, H, s.jac_rowmom.p, s.jac_cpart.p, s.jac_head.p, s.jac_part.p,
-                             plan.g.tape, (size_t)plan.D + plan.D * plan.D + (size_t)plan.E * plan.D + plan.E + (size_t)plan.E * plan.E + (size_t)plan.D * plan.E,
-                             plan.jrec);
-    }
-    return PILCO_OK;
+    return enqueue_rollout_steps(ctx, plan, H, pair_ev);
 }
 
 static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev) {
@@ -1246,6 +1252,7 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     ctx->jwait_next = 0;
     ctx->jwait_n = 0;
     if (H > 0 && sharded) {
+        jac_finish_range(ctx, plan, 0, H);
         HIPCHK(hipMemcpyAsync(h_tape, ctx->tape.p, sizeof(double) * (size_t)H * TS, hipMemcpyDeviceToHost, ctx->st));
         ENSURE(ctx->jgath, (size_t)(W + 1) * gblk);
         double* own = ctx->jgath.p + (size_t)W * gblk;
@@ -1282,14 +1289,24 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
         ctx->jwait_from = 0;
     } else if (H > 0) {
         HIPCHK(hipMemcpyAsync(h_tape, ctx->tape.p, sizeof(double) * (size_t)H * TS, hipMemcpyDeviceToHost, ctx->st));
+        // chunks in the order the reverse sweep consumes them, SHRINKING towards step 0.  Measured at C2u (gpurun_out/r03/
+        // chunks*.log): the device finishes a step's records in ~11 us, the host sweeps one in ~9 us, and every chunk costs
+        // both sides a fixed ~40-60 us (two launches, a copy, an event wait) -- four chunks of 16/12/8/4 fortieths: 6.03 ->
+        // 5.97 ms; six chunks (8,8,8,8,4,4): 6.14 ms; finishing the early chunks on a second stream WHILE the chain runs:
+        // 6.09 ms with one fork, 7.4 ms with three (the chain's kernels lose what the finish gains)
+        static const int parts[4] = {16, 12, 8, 4};   // fortieths of H
         const int nch = std::min(H, 4);
+        int t1 = H, used = 0;
         for (int k = 0; k < nch; ++k) {
-            const int t1 = H - (int)((long)k * H / nch), t0 = H - (int)((long)(k + 1) * H / nch);   // steps [t0, t1)
+            used += parts[k];
+            const int t0 = (k == nch - 1) ? 0 : std::min(t1 - 1, std::max(0, H - (int)((long)used * H / 40)));   // steps [t0, t1), never empty
+            jac_finish_range(ctx, plan, t0, t1);
             HIPCHK(hipMemcpyAsync(h_jrec + (size_t)t0 * JS, ctx->jrec.p + (size_t)t0 * JS, sizeof(double) * (size_t)(t1 - t0) * JS,
                                   hipMemcpyDeviceToHost, ctx->st));
             if (!ctx->jwait_ev[k]) HIPCHK(hipEventCreateWithFlags(&ctx->jwait_ev[k], hipEventDisableTiming));
             HIPCHK(hipEventRecord(ctx->jwait_ev[k], ctx->st));
             ctx->jwait_t0[k] = t0;
+            t1 = t0;
         }
         ctx->jwait_n = nch;
         if (int r = rollout_jtape_wait(ctx, H - 1)) return r;   // reward, trajectory, tape and the last chunk are on the host
@@ -1309,7 +1326,12 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
 int rollout_jtape_wait(pilco_ctx* ctx, int t) {
     while (t < ctx->jwait_from && ctx->jwait_next < ctx->jwait_n) {
         const int k = ctx->jwait_next++;
+        static const bool timing = getenv("PILCO_GRAD_TIMING") != nullptr;   // developer aid: how long the host waited for chunk k
+        const auto w0 = std::chrono::steady_clock::now();
         HIPCHK(hipEventSynchronize(ctx->jwait_ev[k]));
+        if (timing)
+            fprintf(stderr, "[pilco grad] chunk %d (steps >= %d): waited %.3f ms (asked for step %d)\n", k, ctx->jwait_t0[k],
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count(), t);
         ctx->jwait_from = ctx->jwait_t0[k];
     }
     return PILCO_OK;
