@@ -15,6 +15,11 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ Gram
 // replaces gpflow SquaredExponential.K as called from pilco/models/mgpr.py:154-157
+// One workgroup: GRAM_R rows x 256 columns.  A thread owns one column: its point x_j is loaded once per dimension and serves
+// the GRAM_R rows (whose points and the reciprocal lengthscales sit in LDS); every element is summed over d = 0 .. D-1 in
+// that order, as before.  (Round 2: one row per workgroup, 1 / l_d divided out D times per element: 80 us for ten 1000^2
+// matrices; now bound by the 10^7 double-precision exp and the write.)
+constexpr int GRAM_R = 8;
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ P1t, int ld1, int n1,
                                               const double* __restrict__ P2t, int ld2, int n2, int D,
                                               const double* __restrict__ ls, const double* __restrict__ var,
@@ -23,32 +28,55 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ P1t, in
     const int a = blockIdx.z;
     P1t += (long)a * sP1;   // per-output point sets (FITC training: every output owns its inducing inputs); 0 = shared
     P2t += (long)a * sP2;
-    const int i = blockIdx.y;
+    const int i0 = blockIdx.y * GRAM_R;
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= cols_pad) return;
-    double v;
-    if (i < n1 && j < n2) {
-        double r2 = 0.0;
-        for (int d = 0; d < D; ++d) {
-            const double il = 1.0 / ls[a * D + d];
-            const double diff = (P1t[(long)d * ld1 + i] - P2t[(long)d * ld2 + j]) * il;
-            r2 = fma(diff, diff, r2);
-        }
-        v = var[a] * exp(-0.5 * r2);
-        if (i == j) {
-            if (diag_mode == 1) v += diag_add[a];
-            if (diag_mode == 2) v += jitter;
-        }
-    } else {
-        v = (diag_mode != 0 && i == j) ? 1.0 : 0.0;
+    // diag_mode != 0: a symmetric matrix on its way to launch_potrf, which reads the diagonal tiles and the tiles below
+    // them only (so do launch_trtri and the log-determinant after it): segments wholly to the right of the rows' diagonal
+    // tile are left unwritten (the GRAM_R rows of a workgroup share their 64-row tile)
+    if (diag_mode != 0 && (int)blockIdx.x * 256 > (i0 | 63)) return;
+    __shared__ double il_s[32], xi_s[GRAM_R][33];
+    for (int e = threadIdx.x; e < GRAM_R * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        xi_s[r][d] = (i0 + r < n1) ? P1t[(long)d * ld1 + i0 + r] : 0.0;
     }
-    out[((long)a * rows_pad + i) * cols_pad + j] = v;
+    if ((int)threadIdx.x < D) il_s[threadIdx.x] = 1.0 / ls[a * D + threadIdx.x];
+    __syncthreads();
+    if (j >= cols_pad) return;
+    double r2[GRAM_R];
+#pragma unroll
+    for (int r = 0; r < GRAM_R; ++r) r2[r] = 0.0;
+    if (j < n2)
+        for (int d = 0; d < D; ++d) {
+            const double xj = P2t[(long)d * ld2 + j], il = il_s[d];
+#pragma unroll
+            for (int r = 0; r < GRAM_R; ++r) {
+                const double diff = (xi_s[r][d] - xj) * il;
+                r2[r] = fma(diff, diff, r2[r]);
+            }
+        }
+    const double va = var[a];
+#pragma unroll
+    for (int r = 0; r < GRAM_R; ++r) {
+        const int i = i0 + r;
+        if (i >= rows_pad) break;
+        double v;
+        if (i < n1 && j < n2) {
+            v = va * exp(-0.5 * r2[r]);
+            if (i == j) {
+                if (diag_mode == 1) v += diag_add[a];
+                if (diag_mode == 2) v += jitter;
+            }
+        } else {
+            v = (diag_mode != 0 && i == j) ? 1.0 : 0.0;
+        }
+        out[((long)a * rows_pad + i) * cols_pad + j] = v;
+    }
 }
 
 void launch_gram(hipStream_t st, const double* P1t, int ld1, int n1, const double* P2t, int ld2, int n2, int D,
                  const double* ls, const double* var, int E, double* out, int rows_pad, int cols_pad, int diag_mode,
                  const double* diag_add, double jitter, long sP1, long sP2) {
-    dim3 grid((cols_pad + 255) / 256, rows_pad, E);
+    dim3 grid((cols_pad + 255) / 256, (rows_pad + GRAM_R - 1) / GRAM_R, E);
     hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, st, P1t, ld1, n1, P2t, ld2, n2, D, ls, var, out, rows_pad, cols_pad,
                        diag_mode, diag_add, jitter, sP1, sP2);
 }
@@ -101,42 +129,55 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
 
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        if (!TA) {  // A stored (M,K): rows contiguous along k -> transposing write
-            const int i = t >> 2, kq = (t & 3) * 4;
-            const double* src = A + (long)(i0 + i) * g.lda + k0 + kq;
-            const double2 v0 = *reinterpret_cast<const double2*>(src);
-            const double2 v1 = *reinterpret_cast<const double2*>(src + 2);
-            As[kq + 0][i] = v0.x;
-            As[kq + 1][i] = v0.y;
-            As[kq + 2][i] = v1.x;
-            As[kq + 3][i] = v1.y;
+    // The next K chunk's global loads are in flight while the current one is multiplied (round 2 loaded, stored, multiplied
+    // in turn: the memory round trip of every chunk was hidden by other workgroups only); same sums in the same order.
+    double2 pa0, pa1, pb0, pb1;
+    auto fetch = [&](int k0) {
+        if (!TA) {  // A stored (M,K): rows contiguous along k
+            const double* src = A + (long)(i0 + (t >> 2)) * g.lda + k0 + (t & 3) * 4;
+            pa0 = *reinterpret_cast<const double2*>(src);
+            pa1 = *reinterpret_cast<const double2*>(src + 2);
         } else {  // A stored (K,M): rows contiguous along i
-            const int k = t >> 4, iq = (t & 15) * 4;
-            const double* src = A + (long)(k0 + k) * g.lda + i0 + iq;
-            const double2 v0 = *reinterpret_cast<const double2*>(src);
-            const double2 v1 = *reinterpret_cast<const double2*>(src + 2);
-            *reinterpret_cast<double2*>(&As[k][iq]) = v0;
-            *reinterpret_cast<double2*>(&As[k][iq + 2]) = v1;
+            const double* src = A + (long)(k0 + (t >> 4)) * g.lda + i0 + (t & 15) * 4;
+            pa0 = *reinterpret_cast<const double2*>(src);
+            pa1 = *reinterpret_cast<const double2*>(src + 2);
         }
         if (!TB) {  // B stored (K,N)
-            const int k = t >> 4, jq = (t & 15) * 4;
-            const double* src = B + (long)(k0 + k) * g.ldb + j0 + jq;
-            const double2 v0 = *reinterpret_cast<const double2*>(src);
-            const double2 v1 = *reinterpret_cast<const double2*>(src + 2);
-            *reinterpret_cast<double2*>(&Bs[k][jq]) = v0;
-            *reinterpret_cast<double2*>(&Bs[k][jq + 2]) = v1;
+            const double* src = B + (long)(k0 + (t >> 4)) * g.ldb + j0 + (t & 15) * 4;
+            pb0 = *reinterpret_cast<const double2*>(src);
+            pb1 = *reinterpret_cast<const double2*>(src + 2);
         } else {  // B stored (N,K)
+            const double* src = B + (long)(j0 + (t >> 2)) * g.ldb + k0 + (t & 3) * 4;
+            pb0 = *reinterpret_cast<const double2*>(src);
+            pb1 = *reinterpret_cast<const double2*>(src + 2);
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        if (!TA) {  // transposing write
+            const int i = t >> 2, kq = (t & 3) * 4;
+            As[kq + 0][i] = pa0.x;
+            As[kq + 1][i] = pa0.y;
+            As[kq + 2][i] = pa1.x;
+            As[kq + 3][i] = pa1.y;
+        } else {
+            const int k = t >> 4, iq = (t & 15) * 4;
+            *reinterpret_cast<double2*>(&As[k][iq]) = pa0;
+            *reinterpret_cast<double2*>(&As[k][iq + 2]) = pa1;
+        }
+        if (!TB) {
+            const int k = t >> 4, jq = (t & 15) * 4;
+            *reinterpret_cast<double2*>(&Bs[k][jq]) = pb0;
+            *reinterpret_cast<double2*>(&Bs[k][jq + 2]) = pb1;
+        } else {
             const int j = t >> 2, kq = (t & 3) * 4;
-            const double* src = B + (long)(j0 + j) * g.ldb + k0 + kq;
-            const double2 v0 = *reinterpret_cast<const double2*>(src);
-            const double2 v1 = *reinterpret_cast<const double2*>(src + 2);
-            Bs[kq + 0][j] = v0.x;
-            Bs[kq + 1][j] = v0.y;
-            Bs[kq + 2][j] = v1.x;
-            Bs[kq + 3][j] = v1.y;
+            Bs[kq + 0][j] = pb0.x;
+            Bs[kq + 1][j] = pb0.y;
+            Bs[kq + 2][j] = pb1.x;
+            Bs[kq + 3][j] = pb1.y;
         }
         __syncthreads();
+        if (k0 + 16 < kend) fetch(k0 + 16);
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 4) {
             const double a0 = As[kk + lr][wi + lc];
@@ -559,17 +600,34 @@ void launch_nlml_grad(hipStream_t st, const double* Pt, int npad, int n, int D, 
 }
 
 // ------------------------------------------------------------------ mat-vec, padding
+// A is LOWER TRIANGULAR (every caller passes a triangular inverse from launch_trtri, zero above the diagonal): the zero
+// part is not read.  The sums keep round 2's order term by term (the skipped terms were exact zeros), so the results are
+// bitwise what they were.
 __global__ __launch_bounds__(256) void k_matvec(const double* __restrict__ A, int npad, const double* __restrict__ x,
                                                 double* __restrict__ y, int trans) {
     const int b = blockIdx.y;
     const double* Ab = A + (long)b * npad * npad;
     const double* xb = x + (long)b * npad;
-    if (trans) {  // y[j] = sum_i A[i][j] x[i]; 64 columns per workgroup, the four waves split the rows
+    if (trans) {  // y[j] = sum_{i >= j} A[i][j] x[i]; 64 columns per workgroup, the four waves split the rows
         __shared__ double red[4][64];
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         const int j = blockIdx.x * 64 + lane;
         double s0 = 0.0, s1 = 0.0;
-        int i = w;
+        int i = blockIdx.x * 64 + w;   // rows above the workgroup's first column are zero (a multiple of 8: s0 / s1 keep their rows)
+        // eight loads in flight per wave (two, as in round 2, left this latency-bound: 45 us for ten 1024 x 1024 matrices)
+        for (; i + 28 < npad; i += 32) {
+            double av[8], xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                av[q] = Ab[(long)(i + 4 * q) * npad + j];
+                xv[q] = xb[i + 4 * q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                s0 = fma(av[q], xv[q], s0);
+                s1 = fma(av[q + 1], xv[q + 1], s1);
+            }
+        }
         for (; i + 4 < npad; i += 8) {
             s0 = fma(Ab[(long)i * npad + j], xb[i], s0);
             s1 = fma(Ab[(long)(i + 4) * npad + j], xb[i + 4], s1);
@@ -578,12 +636,13 @@ __global__ __launch_bounds__(256) void k_matvec(const double* __restrict__ A, in
         red[w][lane] = s0 + s1;
         __syncthreads();
         if (w == 0) y[(long)b * npad + j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    } else {  // y[i] = sum_j A[i][j] x[j]; one wave per row
+    } else {  // y[i] = sum_{j <= i} A[i][j] x[j]; one wave per row
         const int lane = threadIdx.x & 63;
         const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
         if (i >= npad) return;
         double s = 0.0;
-        for (int j = lane; j < npad; j += 64) s = fma(Ab[(long)i * npad + j], xb[j], s);
+        const int jend = (i | 63) + 1;   // the row's last non-zero entry is column i
+        for (int j = lane; j < jend; j += 64) s = fma(Ab[(long)i * npad + j], xb[j], s);
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
         if (lane == 0) y[(long)b * npad + i] = s;
     }
@@ -594,17 +653,21 @@ void launch_matvec(hipStream_t st, const double* A, int npad, int batch, const d
     hipLaunchKernelGGL(k_matvec, grid, dim3(256), 0, st, A, npad, x, y, trans ? 1 : 0);
 }
 
-__global__ void k_clear_padding(double* __restrict__ A, int npad, int n) {
-    const int b = blockIdx.z;
-    const int i = blockIdx.y;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= npad) return;
-    if (i >= n || j >= n) A[((long)b * npad + i) * npad + j] = 0.0;
+// zero rows and columns n .. npad - 1: one 64-thread workgroup per row (the padding is at most 63 wide; round 2 launched a
+// thread per ELEMENT of the matrix for it: 19 us at N = 1000)
+__global__ __launch_bounds__(64) void k_clear_padding(double* __restrict__ A, int npad, int n) {
+    const int b = blockIdx.y, i = blockIdx.x, t = threadIdx.x;
+    double* row = A + ((long)b * npad + i) * npad;
+    if (i >= n) {
+        for (int j = t; j < npad; j += 64) row[j] = 0.0;
+    } else if (n + t < npad) {
+        row[n + t] = 0.0;
+    }
 }
 
 void launch_clear_padding(hipStream_t st, double* A, int npad, int n, int batch) {
     if (n == npad) return;
-    hipLaunchKernelGGL(k_clear_padding, dim3((npad + 255) / 256, npad, batch), dim3(256), 0, st, A, npad, n);
+    hipLaunchKernelGGL(k_clear_padding, dim3(npad, batch), dim3(64), 0, st, A, npad, n);
 }
 
 }  // namespace pilco
