@@ -230,7 +230,8 @@ int factorize_exact(pilco_ctx* ctx, Slot& s) {
         g.A = s.Linv.p; g.lda = npad; g.sA = (long)mat;
         g.B = s.Linv.p; g.ldb = npad; g.sB = (long)mat;
         g.C = s.iK.p; g.ldc = npad; g.sC = (long)mat;
-        g.M = npad; g.N = npad; g.K = npad; g.alpha = 1.0; g.beta = 0.0; g.tile_mode = 0; g.k_mode = 1;
+        g.M = npad; g.N = npad; g.K = npad; g.alpha = 1.0; g.beta = 0.0; g.k_mode = 1;
+        g.tile_mode = 2;   // iK = Linv^T Linv is symmetric: the tiles on and below the diagonal are computed, their mirror images stored (the same sums, term by term, as when both halves were computed)
         launch_gemm(st, g, true, false, EL);
         launch_clear_padding(st, s.iK.p, npad, s.N, EL);
         launch_matvec(st, s.Linv.p, npad, EL, o.Yt, s.vec.p, false);

@@ -54,7 +54,7 @@ struct GemmDesc {
     long sA, sB, sC;    // batch strides (doubles)
     double alpha, beta;
     const double* alpha_vec;  // optional per-batch multiplier of alpha (device), or nullptr
-    int tile_mode;      // 0 all tiles, 1 only tiles with row-block >= col-block
+    int tile_mode;      // 0 all tiles, 1 only tiles with row-block >= col-block, 2 the same and every tile below the diagonal also stored transposed above it (C symmetric, beta = 0)
     int k_mode;         // 0 full K; 1: k >= max(i0,j0); 2: k >= j0; 3: k < i0+64 (A lower triangular); 4: j0 <= k < i0+64
     // optional second batch level: batch index z -> matrix z / nsub, sub-problem z % nsub (nsub = 0: off)
     int nsub;

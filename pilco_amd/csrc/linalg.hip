@@ -101,16 +101,35 @@ constexpr int LDS_LD = 80;
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
-    const int bj = blockIdx.x, bi = blockIdx.y, bz = blockIdx.z;
-    if (g.tile_mode == 1 && bi < bj) return;
+    // Grid (column tiles, matrices x sub-problems, row tiles): the row tile is the SLOWEST index, so that the tile rows with
+    // the longest K range (k_mode 1 / 2: the first rows; k_mode 3 / 4: the last, taken first) start on every matrix before any
+    // short row does.  (Round 2 had the matrix slowest: the last matrix's longest tiles started when the chip was already
+    // full of short ones and ran alone at the end -- the iK GEMM took 210 us whether all tiles or half of them were computed.)
+    // ... and XCD-aware: workgroups go to the 8 XCDs (one L2 each) round-robin in launch order, so the tiles of one tile row
+    // -- which share their A operand -- would land on eight different L2s.  Launch slot -> tile: the slots one XCD receives
+    // are dealt whole tile rows (row `r` of the (matrix, tile row) list goes to XCD r % 8).
+    int bj = blockIdx.x, byz = (int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z;
+    {
+        const int gx = gridDim.x, nyz = gridDim.y * gridDim.z;
+        if ((nyz & 7) == 0) {
+            const int L = bj + gx * byz, xcd = L & 7, sq = L >> 3;   // the sq-th workgroup this XCD receives
+            byz = (sq / gx) * 8 + xcd;
+            bj = sq - (sq / gx) * gx;
+        }
+    }
+    const int bz = byz % (int)gridDim.y, bzi = byz / (int)gridDim.y;
+    const int bi = (g.k_mode == 3 || g.k_mode == 4) ? (int)gridDim.z - 1 - bzi : bzi;
+    if (g.tile_mode != 0 && bi < bj) return;
     const int i0 = bi * 64, j0 = bj * 64;
     int kbeg = 0, kend = g.K;
     if (g.k_mode == 1) kbeg = (i0 > j0 ? i0 : j0);
     if (g.k_mode == 2 || g.k_mode == 4) kbeg = j0;
     if (g.k_mode == 3 || g.k_mode == 4) kend = (i0 + 64 < g.K) ? i0 + 64 : g.K;
     kbeg &= ~15;
-    __shared__ double As[16][LDS_LD];
-    __shared__ double Bs[16][LDS_LD];
+    // operand chunks; tile_mode 2 reuses the space (and the rest of `sm`) to turn the finished tile around for its mirror image
+    __shared__ __attribute__((aligned(16))) double sm[64 * 65];
+    double (*As)[LDS_LD] = reinterpret_cast<double (*)[LDS_LD]>(sm);
+    double (*Bs)[LDS_LD] = reinterpret_cast<double (*)[LDS_LD]>(sm + 16 * LDS_LD);
     int mat = bz, sub = 0;
     if (g.nsub > 0) {
         mat = bz / g.nsub;
@@ -129,6 +148,19 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
 
+    // beta != 0: the tile's old values are requested TOGETHER and ahead of the K loop -- read where they are used, as in round
+    // 2, they cost sixteen memory round trips in a row per thread: most of a K = 64 update's 8 us
+    const double scale = g.alpha * (g.alpha_vec ? g.alpha_vec[mat] : 1.0);
+    double cold[2][2][4];
+    if (g.beta != 0.0) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cold[ti][tj][r] = C[(long)(i0 + wi + 16 * ti + lr + 4 * r) * g.ldc + j0 + wj + 16 * tj + lc];
+    }
     // The next K chunk's global loads are in flight while the current one is multiplied (round 2 loaded, stored, multiplied
     // in turn: the memory round trip of every chunk was hidden by other workgroups only); same sums in the same order.
     double2 pa0, pa1, pb0, pb1;
@@ -201,15 +233,22 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
                 const int row = i0 + wi + 16 * ti + lr + 4 * r;
                 const int col = j0 + wj + 16 * tj + lc;
                 double* c = C + (long)row * g.ldc + col;
-                double v = g.alpha * (g.alpha_vec ? g.alpha_vec[mat] : 1.0) * acc[ti][tj][r];
-                if (g.beta != 0.0) v = fma(g.beta, *c, v);
+                double v = scale * acc[ti][tj][r];
+                if (g.beta != 0.0) v = fma(g.beta, cold[ti][tj][r], v);
                 *c = v;
+                if (g.tile_mode == 2 && bi != bj) sm[(wj + 16 * tj + lc) * 65 + wi + 16 * ti + lr + 4 * r] = v;
             }
+    // symmetric result: the tile above the diagonal is this one's mirror image -- turned around in LDS and stored as full rows
+    // (stored straight from the accumulators it is 4096 scattered 8-byte writes per tile: as slow as computing it)
+    if (g.tile_mode == 2 && bi != bj) {
+        __syncthreads();
+        for (int e = t; e < 4096; e += 256) C[(long)(j0 + (e >> 6)) * g.ldc + i0 + (e & 63)] = sm[(e >> 6) * 65 + (e & 63)];
+    }
 }
 
 void launch_gemm(hipStream_t st, const GemmDesc& g, bool ta, bool tb, int batch) {
     if (g.M <= 0 || g.N <= 0) return;
-    dim3 grid(g.N / 64, g.M / 64, batch * (g.nsub > 0 ? g.nsub : 1));
+    dim3 grid(g.N / 64, batch * (g.nsub > 0 ? g.nsub : 1), g.M / 64);
     if (!ta && !tb) hipLaunchKernelGGL((k_gemm64<false, false>), grid, dim3(256), 0, st, g);
     if (!ta && tb) hipLaunchKernelGGL((k_gemm64<false, true>), grid, dim3(256), 0, st, g);
     if (ta && !tb) hipLaunchKernelGGL((k_gemm64<true, false>), grid, dim3(256), 0, st, g);
