@@ -134,7 +134,8 @@ def rocprof_avg_us(kernel_substr, suffix="_kernel_stats.csv"):
     return None, None, "profiles/" + os.path.basename(f)
 
 
-KERNEL_SOURCES = ("pair.hip", "prep.hip", "glue_device.h", "mm_device.h", "rollout.hip", "bwd.hip", "linalg.hip")
+KERNEL_SOURCES = ("pair.hip", "pair_device.h", "prep.hip", "prep_device.h", "prep_kernel.h", "glue_device.h", "mm_device.h",
+                  "rollout.hip", "bwd.hip", "linalg.hip")
 
 
 def kernel_source_hashes():
@@ -580,7 +581,7 @@ def main():
             traffic_src = "profiles/" + os.path.basename(f_pmc)
             now = kernel_source_hashes()
             then = pj.get("kernel_source_sha16") or {}
-            changed = sorted(k for k in ("pair.hip", "mm_device.h") if then.get(k) != now.get(k))
+            changed = sorted(k for k in ("pair.hip", "pair_device.h", "mm_device.h") if then.get(k) != now.get(k))
             traffic_meta = {"profile_head": pj.get("git_head"), "profile_date": pj.get("date"),
                             "stale": bool(changed) or not then,
                             "stale_because": (("kernel sources changed since the profile: " + ", ".join(changed)) if changed and then else

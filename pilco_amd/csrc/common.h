@@ -60,6 +60,11 @@ struct GemmDesc {
     int nsub;
     long ssA, ssB, ssC; // sub-problem strides (doubles)
     int sub_rows0, sub_rows_step;  // sub-problem q only has rows < sub_rows0 - q * sub_rows_step (row tiles past that are skipped)
+    // Cholesky chain (launch_potrf): the workgroup of tile (0, 0) factors and inverts that tile afterwards -- diagonal block
+    // potf2_kb of potf2_nblk; inverse to potf2_invD[matrix][potf2_kb][64][64], first bad pivot to potf2_info[matrix]
+    double* potf2_invD;
+    int* potf2_info;
+    int potf2_kb, potf2_nblk;
 };
 // C = alpha * op(A) op(B) + beta * C, batched; op selected by ta/tb (0 = as stored, 1 = transposed)
 void launch_gemm(hipStream_t st, const GemmDesc& g, bool ta, bool tb, int batch);

@@ -99,7 +99,21 @@ void launch_transpose_points(hipStream_t st, const double* X, int n, int D, doub
 // 32-lane ds_read_b64 group on disjoint bank halves.
 constexpr int LDS_LD = 80;
 
-template <bool TA, bool TB>
+// (the block factorisation of the Cholesky section below, which the GEMM's fused form calls)
+constexpr int POTF2_LD = 66;   // 16-byte aligned lines, lanes of a column spread over the banks
+struct Potf2Lds {               // LDS of one block factorisation
+    double Ls[64 * POTF2_LD];   // first the block (row-major), then line j = column j of L
+    double rinvs[64];           // 1 / sqrt(pivot j)
+    double dump_d[64];
+    int dump_i[64];
+    int published;              // columns of L wave 0 has put out
+};
+template <int NW>
+__device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A, int npad, int kb_abs, double* __restrict__ out,
+                                            int* info_word, int lane, int w, unsigned long long* stp);
+
+// POTF2: the workgroup of tile (0, 0) goes on to factor and invert that tile (the next diagonal block of the Cholesky chain)
+template <bool TA, bool TB, bool POTF2 = false>
 __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
     // Grid (column tiles, matrices x sub-problems, row tiles): the row tile is the SLOWEST index, so that the tile rows with
     // the longest K range (k_mode 1 / 2: the first rows; k_mode 3 / 4: the last, taken first) start on every matrix before any
@@ -127,7 +141,8 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
     if (g.k_mode == 3 || g.k_mode == 4) kend = (i0 + 64 < g.K) ? i0 + 64 : g.K;
     kbeg &= ~15;
     // operand chunks; tile_mode 2 reuses the space (and the rest of `sm`) to turn the finished tile around for its mirror image
-    __shared__ __attribute__((aligned(16))) double sm[64 * 65];
+    constexpr int SM_DOUBLES = POTF2 ? (int)((sizeof(Potf2Lds) + 7) / 8) : 64 * 65;
+    __shared__ __attribute__((aligned(16))) double sm[SM_DOUBLES];
     double (*As)[LDS_LD] = reinterpret_cast<double (*)[LDS_LD]>(sm);
     double (*Bs)[LDS_LD] = reinterpret_cast<double (*)[LDS_LD]>(sm + 16 * LDS_LD);
     int mat = bz, sub = 0;
@@ -235,9 +250,21 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
                 double* c = C + (long)row * g.ldc + col;
                 double v = scale * acc[ti][tj][r];
                 if (g.beta != 0.0) v = fma(g.beta, cold[ti][tj][r], v);
-                *c = v;
+                if (POTF2 && bi == 0 && bj == 0)   // stays in LDS: the factor replaces it in memory
+                    reinterpret_cast<Potf2Lds*>(sm)->Ls[(wi + 16 * ti + lr + 4 * r) * POTF2_LD + wj + 16 * tj + lc] = v;
+                else
+                    *c = v;
                 if (g.tile_mode == 2 && bi != bj) sm[(wj + 16 * tj + lc) * 65 + wi + 16 * ti + lr + 4 * r] = v;
             }
+    if (POTF2 && bi == 0 && bj == 0) {
+        // Cholesky chain: this tile is the NEXT diagonal block.  Its factorisation and inverse (20 us, two waves) run here,
+        // beside the other tiles of the trailing update, instead of in a launch of their own behind it.
+        Potf2Lds& S = *reinterpret_cast<Potf2Lds*>(sm);
+        if (t == 0) S.published = 0;
+        __syncthreads();
+        potf2_block<4>(S, C, g.ldc, g.potf2_kb, g.potf2_invD + ((long)mat * g.potf2_nblk + g.potf2_kb) * 4096, g.potf2_info + mat,
+                       lane, w, nullptr);
+    }
     // symmetric result: the tile above the diagonal is this one's mirror image -- turned around in LDS and stored as full rows
     // (stored straight from the accumulators it is 4096 scattered 8-byte writes per tile: as slow as computing it)
     if (g.tile_mode == 2 && bi != bj) {
@@ -250,7 +277,8 @@ void launch_gemm(hipStream_t st, const GemmDesc& g, bool ta, bool tb, int batch)
     if (g.M <= 0 || g.N <= 0) return;
     dim3 grid(g.N / 64, batch * (g.nsub > 0 ? g.nsub : 1), g.M / 64);
     if (!ta && !tb) hipLaunchKernelGGL((k_gemm64<false, false>), grid, dim3(256), 0, st, g);
-    if (!ta && tb) hipLaunchKernelGGL((k_gemm64<false, true>), grid, dim3(256), 0, st, g);
+    if (!ta && tb && g.potf2_invD) hipLaunchKernelGGL((k_gemm64<false, true, true>), grid, dim3(256), 0, st, g);
+    else if (!ta && tb) hipLaunchKernelGGL((k_gemm64<false, true>), grid, dim3(256), 0, st, g);
     if (ta && !tb) hipLaunchKernelGGL((k_gemm64<true, false>), grid, dim3(256), 0, st, g);
     if (ta && tb) hipLaunchKernelGGL((k_gemm64<true, true>), grid, dim3(256), 0, st, g);
 }
@@ -283,7 +311,6 @@ struct Potf2State {
     double l, rinv;   // column J of L (lane i >= J: L[i][J]) and 1 / sqrt(pivot J)
     int bad;
 };
-constexpr int POTF2_LD = 66;   // 16-byte aligned lines, lanes of a column spread over the banks
 template <int J, int K, int G>
 __device__ __forceinline__ void potf2_share(double (&a)[64], const double (&t)[64], double l) {
     // the K-th of eight shares of the trailing updates of column J: columns J + 2 + K G .. (G each), LAST column first -- its
@@ -356,53 +383,39 @@ __device__ __forceinline__ void potf2_columns(double (&a)[64], Potf2State& st, d
         potf2_columns<J + 1>(a, st, Ls, rinvs, dump_d, published, dump_i, lane, kb);
     }
 }
-__global__ __launch_bounds__(128) void k_potf2_inv(double* __restrict__ Aall, int npad, int kb,
-                                                   double* __restrict__ invD, int* __restrict__ info) {
-    constexpr int LD = POTF2_LD;
-    __shared__ __attribute__((aligned(16))) double Ls[64 * LD];   // first the block (row-major), then line j = column j of L
-    __shared__ double rinvs[64];                                   // 1 / sqrt(pivot j)
-    __shared__ int published;                                      // columns of L wave 0 has put out
-    __shared__ double dump_d[64];
-    __shared__ int dump_i[64];
-    const int b = blockIdx.x;
-    const int nblk = npad / 64;
-    double* A = Aall + (long)b * npad * npad + (long)kb * 64 * npad + kb * 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#ifdef POTF2_STAMPS   // developer aid (tools/ubench_potf2.hip): 100 MHz stamps of matrix 0 behind the info words
-    unsigned long long* stp = reinterpret_cast<unsigned long long*>(info + 64);
-#define POTF2_STAMP(i_) do { if (b == 0 && lane == 0) stp[i_] = wall_clock64(); } while (0)
+#ifdef POTF2_STAMPS   // developer aid (tools/ubench_potf2.hip): 100 MHz stamps behind the info words
+#define POTF2_STAMP(i_) do { if (stp && lane == 0) stp[i_] = wall_clock64(); } while (0)
 #else
 #define POTF2_STAMP(i_) do { } while (0)
 #endif
-    if (w == 0) POTF2_STAMP(0);
-    if (threadIdx.x == 0) published = 0;
-    {   // the block, 32 rows per wave, all loads in flight together (one by one they cost a memory round trip each: 10 us)
-        double v[32];
-#pragma unroll
-        for (int q = 0; q < 32; ++q) v[q] = A[(long)(2 * q + w) * npad + lane];
-#pragma unroll
-        for (int q = 0; q < 32; ++q) Ls[(2 * q + w) * LD + lane] = v[q];
-    }
-    __syncthreads();
-    if (w == 0) POTF2_STAMP(1);
+// The block is in S.Ls (row-major, row stride POTF2_LD), S.published is 0 and every thread of the workgroup has passed a
+// barrier since.  Waves 0 and 1 do the work; any others only keep the two barriers company (NW waves in the workgroup: the
+// fused trailing update below has four).  Leaves L (zero above the diagonal) in the global block A and L^-1 in `out`;
+// *info_word receives kb_abs * 64 + column + 1 of the first non-positive pivot.
+template <int NW>
+__device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A, int npad, int kb_abs, double* __restrict__ out,
+                                            int* info_word, int lane, int w, unsigned long long* stp) {
+    constexpr int LD = POTF2_LD;
+    (void)stp;
     if (w == 0) {
+        POTF2_STAMP(1);
         double a[64];
 #pragma unroll
-        for (int c = 0; c < 64; ++c) a[c] = Ls[lane * LD + c];
+        for (int c = 0; c < 64; ++c) a[c] = S.Ls[lane * LD + c];
         int bad = 0;
         double d = lane_bcast(a[0], 0);
         if (!(d > 0.0)) {  // also catches NaN
-            bad = kb * 64 + 1;
+            bad = kb_abs * 64 + 1;
             d = 1.0;
         }
         double rinv = rsqrt_f64(d);
         double l = a[0] * rinv;   // lane i >= j: L[i][j]; lane j: sqrt(d)
         Potf2State st{l, rinv, bad};
-        potf2_columns<0>(a, st, Ls, rinvs, dump_d, &published, dump_i, lane, kb);
+        potf2_columns<0>(a, st, S.Ls, S.rinvs, S.dump_d, &S.published, S.dump_i, lane, kb_abs);
         bad = st.bad;
-        if (bad && lane == 0) atomicCAS(&info[b], 0, bad);
+        if (bad && lane == 0) atomicCAS(info_word, 0, bad);
         POTF2_STAMP(2);
-    } else {
+    } else if (w == 1) {
         double x[64];
 #pragma unroll
         for (int i = 0; i < 64; ++i) x[i] = (i == lane) ? 1.0 : 0.0;
@@ -410,32 +423,58 @@ __global__ __launch_bounds__(128) void k_potf2_inv(double* __restrict__ Aall, in
 #pragma unroll
         for (int k = 0; k < 64; ++k) {
             // wait for column k (bounded: wave 0 depends on nothing, so the bound is never met; a bug must not hang the GPU)
-            for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(&published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k; ++spin)
+            for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(&S.published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k; ++spin)
                 __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const double xk = x[k] * rinvs[k];
+            const double xk = x[k] * S.rinvs[k];
             x[k] = xk;
 #pragma unroll
-            for (int i = k + 1; i < 64; ++i) x[i] = fma(-Ls[k * LD + i], xk, x[i]);
+            for (int i = k + 1; i < 64; ++i) x[i] = fma(-S.Ls[k * LD + i], xk, x[i]);
         }
 #endif
         POTF2_STAMP(3);
-        double* out = invD + ((long)b * nblk + kb) * 4096;
 #pragma unroll
         for (int i = 0; i < 64; ++i) out[i * 64 + lane] = x[i];
         POTF2_STAMP(4);
     }
     __syncthreads();
-    for (int r = w; r < 64; r += 2) A[(long)r * npad + lane] = Ls[lane * LD + r];   // L[r][lane] = line `lane`, entry r (zero above the diagonal)
+    for (int r = w; r < 64; r += NW) A[(long)r * npad + lane] = S.Ls[lane * LD + r];   // L[r][lane] = line `lane`, entry r (zero above the diagonal)
     if (w == 0) POTF2_STAMP(5);
-#undef POTF2_STAMP
 }
+
+// the first diagonal block (the others are factored by the workgroup that finishes their trailing update: k_gemm64<.., true>)
+__global__ __launch_bounds__(128) void k_potf2_inv(double* __restrict__ Aall, int npad, int kb,
+                                                   double* __restrict__ invD, int* __restrict__ info) {
+    constexpr int LD = POTF2_LD;
+    __shared__ __attribute__((aligned(16))) Potf2Lds S;
+    const int b = blockIdx.x;
+    const int nblk = npad / 64;
+    double* A = Aall + (long)b * npad * npad + (long)kb * 64 * npad + kb * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long* stp = nullptr;
+#ifdef POTF2_STAMPS
+    if (b == 0) stp = reinterpret_cast<unsigned long long*>(info + 64);
+#endif
+    if (w == 0) POTF2_STAMP(0);
+    if (threadIdx.x == 0) S.published = 0;
+    {   // the block, 32 rows per wave, all loads in flight together (one by one they cost a memory round trip each: 10 us)
+        double v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = A[(long)(2 * q + w) * npad + lane];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) S.Ls[(2 * q + w) * LD + lane] = v[q];
+    }
+    __syncthreads();
+    potf2_block<2>(S, A, npad, kb, invD + ((long)b * nblk + kb) * 4096, &info[b], lane, w, stp);
+}
+#undef POTF2_STAMP
 
 void launch_potrf(hipStream_t st, double* A, int npad, int batch, double* invD, int* info) {
     const int nblk = npad / 64;
     const long sA = (long)npad * npad;
+    // block 0 has a launch of its own; block kb + 1 is factored inside the trailing update of step kb (k_gemm64<.., true>)
+    hipLaunchKernelGGL(k_potf2_inv, dim3(batch), dim3(128), 0, st, A, npad, 0, invD, info);
     for (int kb = 0; kb < nblk; ++kb) {
-        hipLaunchKernelGGL(k_potf2_inv, dim3(batch), dim3(128), 0, st, A, npad, kb, invD, info);
         const int rem = nblk - kb - 1;
         if (rem <= 0) break;
         double* panel = A + (long)(kb + 1) * 64 * npad + kb * 64;
@@ -450,6 +489,7 @@ void launch_potrf(hipStream_t st, double* A, int npad, int batch, double* invD, 
         u.B = panel; u.ldb = npad; u.sB = sA;
         u.C = A + (long)(kb + 1) * 64 * npad + (kb + 1) * 64; u.ldc = npad; u.sC = sA;
         u.M = rem * 64; u.N = rem * 64; u.K = 64; u.alpha = -1.0; u.beta = 1.0; u.tile_mode = 1; u.k_mode = 0;
+        u.potf2_invD = invD; u.potf2_info = info; u.potf2_kb = kb + 1; u.potf2_nblk = nblk;
         launch_gemm(st, u, false, true, batch);
     }
 }

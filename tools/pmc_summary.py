@@ -47,7 +47,8 @@ def _sha16(path):
     except OSError:
         return None
 out["kernel_source_sha16"] = {n: _sha16(os.path.join("pilco_amd", "csrc", n))
-                              for n in ("pair.hip", "prep.hip", "glue_device.h", "mm_device.h", "rollout.hip", "bwd.hip", "linalg.hip")}
+                              for n in ("pair.hip", "pair_device.h", "prep.hip", "prep_device.h", "prep_kernel.h", "glue_device.h", "mm_device.h",
+                                        "rollout.hip", "bwd.hip", "linalg.hip")}
 out["date"] = datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ")
 try:
     out["git_head"] = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() + \
