@@ -239,7 +239,7 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
         "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
         "factorisation": {"achieved": flop_fact / (fact_ms * 1e-3) / 1e12, "frac": flop_fact / (fact_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                           "algorithmic_flop": flop_fact, "ms": fact_ms,
-                          "what_bounds_it": "the blocked Cholesky's chain of dependent diagonal-block launches (latency), then the iK GEMM (f64 MFMA)"},
+                          "what_bounds_it": "the blocked Cholesky's chain of 16 dependent steps (panel GEMM + trailing update whose first tile carries the next 64 x 64 block factorisation: latency), then the L^-1 levels and the iK GEMM (f64 MFMA, L2-bound at 64 x 64 tiles)"},
         "factorise_then_rollout": {"achieved": (flop_fact + H * flop_step) / ((fact_ms + ms_rollout) * 1e-3) / 1e12,
                                    "frac": (flop_fact + H * flop_step) / ((fact_ms + ms_rollout) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                    "algorithmic_flop": flop_fact + H * flop_step, "ms": fact_ms + ms_rollout}}
