@@ -231,6 +231,18 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
         out["batched_rollouts"] = {"error": repr(exc)}
     fact_ms = ctx.factorize_timed(0, 5)
     out["factorisation_ms"] = fact_ms
+    # one evaluation of the GP-training objective (mgpr.py:46-58 through GPflow's training_loss): exact NLML + analytic
+    # gradient of all E outputs, hyper-parameters re-uploaded first as an optimiser step does (the factorisation is redone)
+    def nlml_eval():
+        ctx.gp_set_hyp(0, cfg["lengthscales"], cfg["variance"], cfg["noise"])
+        ctx.gp_nlml(0, D, E)
+    try:
+        nlml_eval()
+        out["nlml_eval_ms"] = _median_ms(nlml_eval, 7)
+    except Exception as exc:
+        out["nlml_eval_ms"] = None
+        out["nlml_eval_error"] = repr(exc)
+    ctx.gp_factorize(0)
     out["R_fwd_fact_rollouts_per_s"] = 1e3 / (fact_ms + ms_rollout)
     # FLOP_fact = E (N^2 (3D+3) + N^3/3 + 2 N^3/3 + 2 N^2) (triangular-inverse route), bound: f64 MFMA
     flop_fact = E * (N * N * (3 * D + 3) + N ** 3 / 3.0 + 2.0 * N ** 3 / 3.0 + 2.0 * N * N)
@@ -291,6 +303,15 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
     ctx.gp_set_inducing(0, c4["Z"])
     ctx.gp_factorize(0)
     out["config4_fitc_factorisation_ms"] = ctx.factorize_timed(0, 5)
+    try:   # GPRFITC objective + gradients w.r.t. the hyper-parameters and the 10 x 200 x 10 inducing inputs (smgpr.py:24-52 under GPflow's loss)
+        Z4 = np.stack([c4["Z"]] * E)
+        ctx.gp_fitc_nlml(0, Z4, D, E)
+        out["config4_fitc_objective_eval_ms"] = _median_ms(lambda: ctx.gp_fitc_nlml(0, Z4, D, E), 7)
+        ctx.gp_set_inducing(0, c4["Z"])
+        ctx.gp_factorize(0)
+    except Exception as exc:
+        out["config4_fitc_objective_eval_ms"] = None
+        out["config4_fitc_objective_error"] = repr(exc)
     ctx.rollout(policy, rewards, c4["m0"], c4["S0"], H)
     r4 = _median_ms(lambda: ctx.rollout(policy, rewards, c4["m0"], c4["S0"], H), 10)
     out["config4_rollout_ms"] = r4
