@@ -36,7 +36,7 @@ class LinearController:
     @property
     def ctx(self):
         if self._ctx is None:
-            self._ctx = _lib.get_context()
+            self._ctx = _lib.resolve_ctx(self)
         return self._ctx
 
     def policy_spec(self, squash=True):

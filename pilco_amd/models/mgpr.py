@@ -50,7 +50,7 @@ class MGPR:
     @property
     def ctx(self):
         if self._ctx is None:
-            self._ctx = _lib.get_context()
+            self._ctx = _lib.resolve_ctx(self)
         return self._ctx
 
     def _invalidate(self):

@@ -17,7 +17,7 @@ class PILCO:
     def __init__(self, data, num_induced_points=None, horizon=30, controller=None,
                  reward=None, m_init=None, S_init=None, name=None, ctx=None):
         self.name = name
-        self._ctx = ctx
+        self._ctx = ctx   # None: decided on first use (the ctx property) -- constructing a model touches no device
         if num_induced_points is None:
             self.mgpr = MGPR(data, ctx=ctx)
         else:
@@ -31,6 +31,13 @@ class PILCO:
         else:
             self.controller = controller
         self.reward = rewards.ExponentialReward(self.state_dim) if reward is None else reward
+        import weakref
+        for comp in (self.mgpr, self.controller, getattr(self.controller, "_gp", None), self.reward):
+            if comp is not None and getattr(comp, "_ctx", None) is None:   # components without a context will ask this object for its
+                try:
+                    comp._ctx_owner = weakref.ref(self)
+                except AttributeError:
+                    pass
         if m_init is None or S_init is None:
             # pilco.py:37-41: first state of the data set, 0.1 * I
             self.m_init = np.asarray(data[0])[0:1, 0:self.state_dim]
@@ -42,7 +49,16 @@ class PILCO:
 
     @property
     def ctx(self):
-        return self.mgpr.ctx
+        if self._ctx is None:
+            # a component that already lives on a context decides; otherwise a context of this object's own: the default one
+            # for the first live PILCO object, a pooled one for every further (_lib.context_for)
+            for comp in (self.mgpr, self.controller, getattr(self.controller, "_gp", None), self.reward):
+                if comp is not None and getattr(comp, "_ctx", None) is not None:
+                    self._ctx = comp._ctx
+                    break
+            if self._ctx is None:
+                self._ctx = _lib.context_for(self)
+        return self._ctx
 
     def _policy_spec(self):
         if self.control_dim == 0 or self.controller is None:

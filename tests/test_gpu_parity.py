@@ -2101,3 +2101,28 @@ def test_host_reward_terms_vs_executed_reference(ctx, golden_dir):
     np.testing.assert_allclose(-f, float(g["reward_total"]), rtol=RTOL)
     np.testing.assert_allclose(-grad[:2].reshape(1, 2), g["dreward_dW"], rtol=1e-6)
     np.testing.assert_allclose(-grad[2:].reshape(1, 1), g["dreward_db"], rtol=1e-6)
+
+
+def test_two_live_pilco_objects_keep_their_models_on_the_device(golden_dir):
+    """Round 2 put every PILCO object on the default context, whose dynamics slot holds ONE model: alternating between two
+    objects re-uploaded and re-factorised on every switch.  Now each live object has a context of its own
+    (_lib.context_for): alternating calls return each object's own answer, bitwise the same every time, and neither object
+    finds its slot taken over (which is what made it upload and factorise again)."""
+    from pilco_amd import _lib
+    g = np.load(os.path.join(golden_dir, "policy_optimisation.npz"))
+    cfg = {k: g[k] for k in ("X", "Y", "lengthscales", "variance", "noise")}
+    cfg2 = dict(cfg, lengthscales=cfg["lengthscales"] * 1.3)
+    p1, p2 = _pilco_from(cfg, int(g["H"])), _pilco_from(cfg2, int(g["H"]))
+    for p in (p1, p2):
+        p.m_init, p.S_init = g["m"], g["s"]
+        p.controller.W.assign(g["W"]); p.controller.b.assign(g["b"]); p.controller.max_action = g["max_action"]
+    assert p1.ctx is not p2.ctx
+    r1, r2 = float(p1.compute_reward()[0, 0]), float(p2.compute_reward()[0, 0])
+    np.testing.assert_allclose(r1, float(g["reward_start"]), rtol=1e-9)
+    assert abs(r2 - r1) > 1e-6 * abs(r1)
+    for _ in range(3):
+        assert float(p1.compute_reward()[0, 0]) == r1 and float(p2.compute_reward()[0, 0]) == r2
+    # the model layer asks for the factorisation before every prediction; the device keeps it while nothing changed: what
+    # must NOT happen is a re-upload (gp_set_data / gp_set_hyp) in between
+    assert p1.mgpr._data_dirty is False and p1.mgpr._hyp_dirty is False and p2.mgpr._hyp_dirty is False
+    assert p1.ctx._slot_owner.get(_lib.SLOT_DYNAMICS) is p1.mgpr and p2.ctx._slot_owner.get(_lib.SLOT_DYNAMICS) is p2.mgpr

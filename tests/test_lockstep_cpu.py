@@ -169,3 +169,33 @@ def test_a_start_that_cannot_be_evaluated_walls_only_its_own_output():
     u, vals = lockstep_minimize(eval_all, np.array([3.0, 0.0, 3.0, 3.0]), parts, maxiter=100, wall=(Wall,), safe=np.zeros(4))
     np.testing.assert_allclose(u[2:], [-0.5, -0.5], atol=1e-5)
     assert vals[0] == 1e25 and vals[1] < 1e-9
+
+
+def test_two_live_pilco_objects_get_a_context_each_and_a_dead_ones_context_is_handed_out_again():
+    """_lib.context_for: a context holds one dynamics model on the device, so PILCO objects that are alive together must not
+    share the default context (round 2: every switch between them re-uploaded and re-factorised the model)."""
+    import gc
+
+    from helpers.cpu_rollout_context import CpuRolloutContext
+    from pilco_amd import _lib
+    from pilco_amd.controllers import LinearController
+    from pilco_amd.models import PILCO
+
+    saved = _lib._default_ctx
+    try:
+        _lib.set_context(CpuRolloutContext())
+        rng = np.random.default_rng(0)
+        data = (rng.standard_normal((12, 3)), rng.standard_normal((12, 2)))
+        p1 = PILCO(data, horizon=2)
+        p2 = PILCO(data, horizon=2)
+        assert p1.ctx is _lib.get_context() and p2.ctx is not p1.ctx
+        assert p1.controller.ctx is p1.ctx and p2.controller.ctx is p2.ctx     # their components follow
+        c2 = p2.ctx
+        del p2
+        gc.collect()
+        p3 = PILCO(data, horizon=2)
+        assert p3.ctx is c2                                                    # handed out again
+        ctl = LinearController(2, 1, ctx=p1.ctx)
+        assert PILCO(data, horizon=2, controller=ctl).ctx is p1.ctx            # a component that lives somewhere decides
+    finally:
+        _lib.set_context(saved)
