@@ -304,7 +304,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     for (auto& ge : ctx->graph_cache) (void)hipGraphExecDestroy(ge.second);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
-        for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr,
+        for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr, &s.ksplit_ws,
                           &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.jac_rowmom, &s.jac_cpart, &s.jac_head, &s.jac_part, &s.jac_np, &s.own, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
                           &s.w_part, &s.w_gath, &s.w_out, &s.ft_P, &s.ft_T3, &s.ft_Z, &s.p_At, &s.p_Bt, &s.p_small, &s.p_part, &s.p_flags})
             b->release();
@@ -869,6 +869,8 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     g.B = Vb.p; g.ldb = Np; g.sB = (long)mn;
     g.C = s.Am.p; g.ldc = Mp; g.sC = (long)mm;
     g.M = Mp; g.N = Mp; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
+    ENSURE(s.ksplit_ws, (size_t)FITC_KSPLIT * E * Mp * Mp);
+    g.ksplit = FITC_KSPLIT; g.split_ws = s.ksplit_ws.p;
     launch_gemm(st, g, false, true, E);
     launch_add_diag(st, s.Am.p, Mp, E, o.noise);
     launch_potrf(st, s.Am.p, Mp, E, s.AmD.p, ctx->d_info + 32);

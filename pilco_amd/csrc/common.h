@@ -62,10 +62,16 @@ struct GemmDesc {
     int sub_rows0, sub_rows_step;  // sub-problem q only has rows < sub_rows0 - q * sub_rows_step (row tiles past that are skipped)
     // Cholesky chain (launch_potrf): the workgroup of tile (0, 0) factors and inverts that tile afterwards -- diagonal block
     // potf2_kb of potf2_nblk; inverse to potf2_invD[matrix][potf2_kb][64][64], first bad pivot to potf2_info[matrix]
+    // split K (long-K products of the FITC path: K = N = 5000 against 16 tiles per matrix left every tile a chain of 316
+    // chunks): K is cut in ksplit slices, each (matrix, slice) computes its partial product into split_ws
+    // [ksplit][batch][M][N], and a second launch adds the slices up in their order (deterministic).  nsub must be 0.
+    int ksplit;
+    double* split_ws;
     double* potf2_invD;
     int* potf2_info;
     int potf2_kb, potf2_nblk;
 };
+constexpr int FITC_KSPLIT = 16;   // K slices of the FITC path's M x M products over the N data points
 // C = alpha * op(A) op(B) + beta * C, batched; op selected by ta/tb (0 = as stored, 1 = transposed)
 void launch_gemm(hipStream_t st, const GemmDesc& g, bool ta, bool tb, int batch);
 

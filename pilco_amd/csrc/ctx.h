@@ -25,6 +25,7 @@ struct Slot {
     DevBuf jac_rowmom, jac_cpart, jac_head, jac_part, jac_np;   // Jacobian tape: per-step sweep outputs [H][..], N_ab tile partials
     DevBuf Xt, Yt, Zt, ls, var, noise;         // Yt: [E][Npad]
     DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
+    DevBuf ksplit_ws;                          // partial products of the split-K GEMMs of the FITC path (GemmDesc::split_ws)
     DevBuf Kmn, V2, Am, AmInv, AmD, iAt, G;    // FITC extras
     DevBuf ft_P, ft_T3, ft_Z;                  // FITC training objective (fitc_train.hip)
     // sharded factorisation (8e): this rank factorises only its outputs a = rank, rank + shW, ...; `own` holds their

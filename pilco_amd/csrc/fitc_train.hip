@@ -81,7 +81,10 @@ __global__ __launch_bounds__(256) void k_fitc_combine(double* __restrict__ T3, d
 // Kernel-derivative reductions of one row m of a weight matrix DK (mpad x ldk) against K(z_m, p_n), n < N:
 //   w = (DK_mn + cc * c_m c_n) K_mn,   out[m] = ( sum_n w (p_nd - z_md) / l_d^2  [D] | sum_n w (z_md - p_nd)^2 / l_d^3  [D] | sum_n w / var )
 // Zt: [D][mpad] of this output; Pt: [D][ldp] (stride sPt per output, 0 = shared data X).  One workgroup per (row, output).
+// The per-dimension arrays have the compile-time width DT >= D (round 2 indexed [32]-arrays with the run-time D: 1.3 KB of
+// scratch memory per thread, 709 us per launch at M = 200, N = 5000 -- 45 % of a FITC objective evaluation).
 constexpr int FT_MAXD = 32;
+template <int DT>
 __global__ __launch_bounds__(256) void k_fitc_kgrad(const double* __restrict__ DK, int ldk, const double* __restrict__ Zt, int mpad,
                                                     const double* __restrict__ Pt, int ldp, long sPt, int N, int D,
                                                     const double* __restrict__ ls, const double* __restrict__ var, const double* __restrict__ c,
@@ -90,8 +93,9 @@ __global__ __launch_bounds__(256) void k_fitc_kgrad(const double* __restrict__ D
     const int b = blockIdx.y, m = blockIdx.x, t = threadIdx.x;
     const double* Zb = Zt + (long)b * D * mpad;
     const double* Pb = Pt + (long)b * sPt;
-    double z[FT_MAXD], il[FT_MAXD], accz[FT_MAXD], accl[FT_MAXD];
-    for (int d = 0; d < FT_MAXD; ++d) {
+    double z[DT], il[DT], accz[DT], accl[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
         z[d] = (d < D) ? Zb[(long)d * mpad + m] : 0.0;
         il[d] = (d < D) ? 1.0 / ls[b * D + d] : 0.0;
         accz[d] = 0.0;
@@ -102,28 +106,50 @@ __global__ __launch_bounds__(256) void k_fitc_kgrad(const double* __restrict__ D
     double accv = 0.0;
     const double* row = DK + ((long)b * mpad + m) * ldk;
     for (int n = t; n < N; n += 256) {
-        double df[FT_MAXD];
+        double df[DT];
         double r2 = 0.0;
-        for (int d = 0; d < D; ++d) {
-            df[d] = (Pb[(long)d * ldp + n] - z[d]) * il[d];
-            r2 = fma(df[d], df[d], r2);
-        }
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+            if (d < D) {
+                df[d] = (Pb[(long)d * ldp + n] - z[d]) * il[d];
+                r2 = fma(df[d], df[d], r2);
+            } else {
+                df[d] = 0.0;
+            }
         double wgt = row[n];
         if (c) wgt = fma(cc * cm, c[(long)b * mpad + n], wgt);
         const double w = wgt * v * exp(-0.5 * r2);
-        for (int d = 0; d < D; ++d) {
-            accz[d] = fma(w, df[d] * il[d], accz[d]);
-            accl[d] = fma(w, df[d] * df[d] * il[d], accl[d]);
-        }
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+            if (d < D) {
+                accz[d] = fma(w, df[d] * il[d], accz[d]);
+                accl[d] = fma(w, df[d] * df[d] * il[d], accl[d]);
+            }
         accv += w;
     }
-    for (int d = 0; d < 2 * D + 1; ++d) {
-        double s = (d < D) ? accz[d] : (d < 2 * D ? accl[d - D] : accv / v);
+#pragma unroll
+    for (int d = 0; d < 2 * DT + 1; ++d) {
+        // slot d of the output: accz | accl | accv / v  (slots D .. 2 D - 1 hold accl: the run-time D decides where a register lands)
+        double s = 0.0;
+        if (d < DT) s = accz[d];
+        else if (d < 2 * DT) s = accl[d - DT];
+        else s = accv / v;
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-        if ((t & 63) == 0) red[t >> 6][d] = s;
+        const int slot = d < DT ? d : (d < 2 * DT ? D + (d - DT) : 2 * D);
+        const bool live = d < DT ? d < D : (d < 2 * DT ? d - DT < D : true);
+        if (live && (t & 63) == 0) red[t >> 6][slot] = s;
     }
     __syncthreads();
     if (t < 2 * D + 1) out[((long)b * mpad + m) * (2 * FT_MAXD + 1) + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+template <typename... Args>
+static void launch_fitc_kgrad(int D, dim3 grid, hipStream_t st, Args... args) {
+    if (D <= 4) hipLaunchKernelGGL(k_fitc_kgrad<4>, grid, dim3(256), 0, st, args...);
+    else if (D <= 8) hipLaunchKernelGGL(k_fitc_kgrad<8>, grid, dim3(256), 0, st, args...);
+    else if (D <= 12) hipLaunchKernelGGL(k_fitc_kgrad<12>, grid, dim3(256), 0, st, args...);
+    else if (D <= 16) hipLaunchKernelGGL(k_fitc_kgrad<16>, grid, dim3(256), 0, st, args...);
+    else if (D <= 24) hipLaunchKernelGGL(k_fitc_kgrad<24>, grid, dim3(256), 0, st, args...);
+    else hipLaunchKernelGGL(k_fitc_kgrad<32>, grid, dim3(256), 0, st, args...);
 }
 
 // sums for the value: out[b] = (sum (y/G)^2, sum log G, sum g)
@@ -172,6 +198,7 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     ENSURE(s.AmInv, E * mm);
     ENSURE(s.AmD, (size_t)E * nblk * NB * NB);
     ENSURE(s.iAt, E * mm);
+    ENSURE(s.ksplit_ws, (size_t)FITC_KSPLIT * E * mm);
     ENSURE(s.iK, E * mm);       // DKuu
     ENSURE(s.G, (size_t)E * Np);
     ENSURE(s.Tscr, std::max(E * mm, (size_t)E * Mp * (2 * FT_MAXD + 1) * 2));
@@ -203,6 +230,7 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     g.B = V; g.ldb = Np; g.sB = (long)mn;
     g.C = s.Am.p; g.ldc = Mp; g.sC = (long)mm;
     g.M = Mp; g.N = Mp; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
+    g.ksplit = FITC_KSPLIT; g.split_ws = s.ksplit_ws.p;
     launch_gemm(st, g, false, true, E);
     launch_add_diag(st, s.Am.p, Mp, E, o_noise);
     launch_potrf(st, s.Am.p, Mp, E, s.AmD.p, ctx->d_info + 32);          // Am = sn L
@@ -252,13 +280,14 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
         g.B = s.Kmn.p; g.ldb = Np; g.sB = (long)mn;
         g.C = s.iK.p; g.ldc = Mp; g.sC = (long)mm;
         g.M = Mp; g.N = Mp; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
+        g.ksplit = FITC_KSPLIT; g.split_ws = s.ksplit_ws.p;
         launch_gemm(st, g, false, true, E);
         double* part_uf = s.Tscr.p;
         double* part_uu = part_uf + (size_t)E * Mp * (2 * FT_MAXD + 1);
-        hipLaunchKernelGGL(k_fitc_kgrad, dim3(M, E), dim3(256), 0, st, s.ft_T3.p, Np, Zt, Mp, s.Xt.p, Np, 0L, N, D, o_ls, o_var,
-                           (const double*)nullptr, 0.0, part_uf);
-        hipLaunchKernelGGL(k_fitc_kgrad, dim3(M, E), dim3(256), 0, st, s.iK.p, Mp, Zt, Mp, Zt, Mp, sZ, M, D, o_ls, o_var,
-                           (const double*)cv, -0.5, part_uu);
+        launch_fitc_kgrad(D, dim3(M, E), st, (const double*)s.ft_T3.p, Np, (const double*)Zt, Mp, (const double*)s.Xt.p, Np, 0L, N, D,
+                          o_ls, o_var, (const double*)nullptr, 0.0, part_uf);
+        launch_fitc_kgrad(D, dim3(M, E), st, (const double*)s.iK.p, Mp, (const double*)Zt, Mp, (const double*)Zt, Mp, sZ, M, D, o_ls,
+                          o_var, (const double*)cv, -0.5, part_uu);
         hz.resize((size_t)2 * E * Mp * (2 * FT_MAXD + 1));
         HIPCHK(hipMemcpyAsync(hz.data(), part_uf, sizeof(double) * hz.size(), hipMemcpyDeviceToHost, st));
     } else {

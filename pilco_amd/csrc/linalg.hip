@@ -151,9 +151,22 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
         sub = bz - mat * g.nsub;
         if (i0 >= g.sub_rows0 - sub * g.sub_rows_step) return;
     }
+    int ldc = g.ldc;
+    double beta = g.beta;
+    long split_off = -1;
+    if (g.ksplit > 1) {   // this workgroup's K slice and its place in the workspace
+        const int nb = (int)gridDim.y / g.ksplit, sp = bz / nb;
+        mat = bz - sp * nb;
+        const int span = (((kend - kbeg) + g.ksplit - 1) / g.ksplit + 15) & ~15;
+        kbeg += sp * span;
+        kend = kbeg + span < kend ? kbeg + span : kend;
+        split_off = ((long)sp * nb + mat) * g.M * g.N;
+        ldc = g.N;
+        beta = 0.0;
+    }
     const double* A = g.A + (long)mat * g.sA + (long)sub * g.ssA;
     const double* B = g.B + (long)mat * g.sB + (long)sub * g.ssB;
-    double* C = g.C + (long)mat * g.sC + (long)sub * g.ssC;
+    double* C = split_off >= 0 ? g.split_ws + split_off : g.C + (long)mat * g.sC + (long)sub * g.ssC;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wi = (w >> 1) * 32, wj = (w & 1) * 32;
     const int lr = lane >> 4, lc = lane & 15;
@@ -167,14 +180,14 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
     // 2, they cost sixteen memory round trips in a row per thread: most of a K = 64 update's 8 us
     const double scale = g.alpha * (g.alpha_vec ? g.alpha_vec[mat] : 1.0);
     double cold[2][2][4];
-    if (g.beta != 0.0) {
+    if (beta != 0.0) {
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    cold[ti][tj][r] = C[(long)(i0 + wi + 16 * ti + lr + 4 * r) * g.ldc + j0 + wj + 16 * tj + lc];
+                    cold[ti][tj][r] = C[(long)(i0 + wi + 16 * ti + lr + 4 * r) * ldc + j0 + wj + 16 * tj + lc];
     }
     // The next K chunk's global loads are in flight while the current one is multiplied (round 2 loaded, stored, multiplied
     // in turn: the memory round trip of every chunk was hidden by other workgroups only); same sums in the same order.
@@ -247,9 +260,9 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + wi + 16 * ti + lr + 4 * r;
                 const int col = j0 + wj + 16 * tj + lc;
-                double* c = C + (long)row * g.ldc + col;
+                double* c = C + (long)row * ldc + col;
                 double v = scale * acc[ti][tj][r];
-                if (g.beta != 0.0) v = fma(g.beta, cold[ti][tj][r], v);
+                if (beta != 0.0) v = fma(beta, cold[ti][tj][r], v);
                 if (POTF2 && bi == 0 && bj == 0)   // stays in LDS: the factor replaces it in memory
                     reinterpret_cast<Potf2Lds*>(sm)->Ls[(wi + 16 * ti + lr + 4 * r) * POTF2_LD + wj + 16 * tj + lc] = v;
                 else
@@ -262,25 +275,40 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
         Potf2Lds& S = *reinterpret_cast<Potf2Lds*>(sm);
         if (t == 0) S.published = 0;
         __syncthreads();
-        potf2_block<4>(S, C, g.ldc, g.potf2_kb, g.potf2_invD + ((long)mat * g.potf2_nblk + g.potf2_kb) * 4096, g.potf2_info + mat,
+        potf2_block<4>(S, C, ldc, g.potf2_kb, g.potf2_invD + ((long)mat * g.potf2_nblk + g.potf2_kb) * 4096, g.potf2_info + mat,
                        lane, w, nullptr);
     }
     // symmetric result: the tile above the diagonal is this one's mirror image -- turned around in LDS and stored as full rows
     // (stored straight from the accumulators it is 4096 scattered 8-byte writes per tile: as slow as computing it)
     if (g.tile_mode == 2 && bi != bj) {
         __syncthreads();
-        for (int e = t; e < 4096; e += 256) C[(long)(j0 + (e >> 6)) * g.ldc + i0 + (e & 63)] = sm[(e >> 6) * 65 + (e & 63)];
+        for (int e = t; e < 4096; e += 256) C[(long)(j0 + (e >> 6)) * ldc + i0 + (e & 63)] = sm[(e >> 6) * 65 + (e & 63)];
     }
 }
 
-void launch_gemm(hipStream_t st, const GemmDesc& g, bool ta, bool tb, int batch) {
+// adds the K slices of a split product up in their order: C = alpha' sum_s ws[s] + beta C   (alpha is already in the slices)
+__global__ __launch_bounds__(256) void k_gemm_split_reduce(GemmDesc g, int batch) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x, mn = (long)g.M * g.N;
+    const int mat = blockIdx.y;
+    if (e >= mn) return;
+    double v = 0.0;
+    for (int sp = 0; sp < g.ksplit; ++sp) v += g.split_ws[((long)sp * batch + mat) * mn + e];
+    double* c = g.C + (long)mat * g.sC + (e / g.N) * g.ldc + (e % g.N);
+    *c = g.beta != 0.0 ? fma(g.beta, *c, v) : v;
+}
+
+void launch_gemm(hipStream_t st, const GemmDesc& g_in, bool ta, bool tb, int batch) {
+    GemmDesc g = g_in;
     if (g.M <= 0 || g.N <= 0) return;
-    dim3 grid(g.N / 64, batch * (g.nsub > 0 ? g.nsub : 1), g.M / 64);
+    if (g.ksplit <= 1 || !g.split_ws || g.nsub > 0 || g.tile_mode != 0 || g.potf2_invD) g.ksplit = 0;
+    dim3 grid(g.N / 64, batch * (g.nsub > 0 ? g.nsub : 1) * (g.ksplit > 1 ? g.ksplit : 1), g.M / 64);
     if (!ta && !tb) hipLaunchKernelGGL((k_gemm64<false, false>), grid, dim3(256), 0, st, g);
     if (!ta && tb && g.potf2_invD) hipLaunchKernelGGL((k_gemm64<false, true, true>), grid, dim3(256), 0, st, g);
     else if (!ta && tb) hipLaunchKernelGGL((k_gemm64<false, true>), grid, dim3(256), 0, st, g);
     if (ta && !tb) hipLaunchKernelGGL((k_gemm64<true, false>), grid, dim3(256), 0, st, g);
     if (ta && tb) hipLaunchKernelGGL((k_gemm64<true, true>), grid, dim3(256), 0, st, g);
+    if (g.ksplit > 1)
+        hipLaunchKernelGGL(k_gemm_split_reduce, dim3((unsigned)(((long)g.M * g.N + 255) / 256), batch), dim3(256), 0, st, g, batch);
 }
 
 // ------------------------------------------------------------------ Cholesky
@@ -531,24 +559,31 @@ void launch_trtri(hipStream_t st, const double* L, int npad, int batch, const do
 }
 
 // ------------------------------------------------------------------ FITC helpers
+// 64 columns per workgroup, the rows dealt over its four waves (round 2: one thread per column walking all M rows twice,
+// 200 workgroups on the chip: 134 us at M = 200, N = 5000)
 __global__ __launch_bounds__(256) void k_fitc_scale(double* __restrict__ V, int mpad, int npad, const double* __restrict__ var,
                                                     const double* __restrict__ noise, double* __restrict__ G) {
-    const int b = blockIdx.y;
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= npad) return;
+    __shared__ double red[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
     double* Vb = V + (long)b * mpad * npad;
     double ss = 0.0;
-    for (int m = 0; m < mpad; ++m) {
-        const double v = Vb[(long)m * npad + n];
-        ss = fma(v, v, ss);
-    }
+    if (n < npad)
+        for (int m = q; m < mpad; m += 4) {
+            const double v = Vb[(long)m * npad + n];
+            ss = fma(v, v, ss);
+        }
+    red[q][lane] = ss;
+    __syncthreads();
+    if (n >= npad) return;
+    ss = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     const double g = sqrt(1.0 + (var[b] - ss) / noise[b]);   // smgpr.py:31-32
-    G[(long)b * npad + n] = g;
+    if (q == 0) G[(long)b * npad + n] = g;
     const double ig = 1.0 / g;
-    for (int m = 0; m < mpad; ++m) Vb[(long)m * npad + n] *= ig;  // smgpr.py:33
+    for (int m = q; m < mpad; m += 4) Vb[(long)m * npad + n] *= ig;  // smgpr.py:33
 }
 void launch_fitc_scale(hipStream_t st, double* V, int mpad, int npad, int batch, const double* var, const double* noise, double* G) {
-    hipLaunchKernelGGL(k_fitc_scale, dim3((npad + 255) / 256, batch), dim3(256), 0, st, V, mpad, npad, var, noise, G);
+    hipLaunchKernelGGL(k_fitc_scale, dim3((npad + 63) / 64, batch), dim3(256), 0, st, V, mpad, npad, var, noise, G);
 }
 
 __global__ void k_add_diag(double* __restrict__ A, int npad, const double* __restrict__ d) {

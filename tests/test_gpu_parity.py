@@ -1790,7 +1790,10 @@ def test_smgpr_optimize_ends_where_the_executed_reference_ends(ctx, golden_dir):
     np.testing.assert_allclose(per, g["loss_end"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(m.lengthscales, g["ls_end"], rtol=2e-3)
     np.testing.assert_allclose(m.variance, g["var_end"], rtol=1e-3)
-    np.testing.assert_allclose(m.noise, g["noise_end"], rtol=5e-3)      # both at GPflow's 1e-6 floor
+    # Both fits end with the noise ON GPflow's lower bound (1e-6 + softplus(raw)): what differs is how far above it the walk
+    # stopped (1.4e-9 in the reference run, 1e-9 .. 2e-8 here depending on the summation order of the N = 5000 products --
+    # the objective is flat there), so the comparison allows 5 % of the bound.
+    np.testing.assert_allclose(m.noise, g["noise_end"], rtol=5e-3, atol=5e-8)
     # Output 0's prediction is compared.  Output 1 predicts with OUTPUT 0's inducing inputs (smgpr.py:47-52), and one of
     # those ends far outside the data where output 0's loss does not feel it (its position differs by 38 units between
     # the two runs at equal loss) while output 1's longer lengthscale still does: its prediction is not a function of the
