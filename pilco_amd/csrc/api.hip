@@ -871,6 +871,7 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     g.M = Mp; g.N = Mp; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
     ENSURE(s.ksplit_ws, (size_t)FITC_KSPLIT * E * Mp * Mp);
     g.ksplit = FITC_KSPLIT; g.split_ws = s.ksplit_ws.p;
+    g.tile_mode = 2;   // V V^T is symmetric: lower tiles + mirror images
     launch_gemm(st, g, false, true, E);
     launch_add_diag(st, s.Am.p, Mp, E, o.noise);
     launch_potrf(st, s.Am.p, Mp, E, s.AmD.p, ctx->d_info + 32);

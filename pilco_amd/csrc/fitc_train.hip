@@ -231,6 +231,7 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     g.C = s.Am.p; g.ldc = Mp; g.sC = (long)mm;
     g.M = Mp; g.N = Mp; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
     g.ksplit = FITC_KSPLIT; g.split_ws = s.ksplit_ws.p;
+    g.tile_mode = 2;   // V V^T is symmetric: lower tiles + mirror images
     launch_gemm(st, g, false, true, E);
     launch_add_diag(st, s.Am.p, Mp, E, o_noise);
     launch_potrf(st, s.Am.p, Mp, E, s.AmD.p, ctx->d_info + 32);          // Am = sn L

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void k_gemm_split_reduce(GemmDesc g, int batch
 void launch_gemm(hipStream_t st, const GemmDesc& g_in, bool ta, bool tb, int batch) {
     GemmDesc g = g_in;
     if (g.M <= 0 || g.N <= 0) return;
-    if (g.ksplit <= 1 || !g.split_ws || g.nsub > 0 || g.tile_mode != 0 || g.potf2_invD) g.ksplit = 0;
+    if (g.ksplit <= 1 || !g.split_ws || g.nsub > 0 || g.tile_mode == 1 || g.potf2_invD) g.ksplit = 0;   // (tile_mode 2: every slice is mirrored inside the workspace)
     dim3 grid(g.N / 64, batch * (g.nsub > 0 ? g.nsub : 1) * (g.ksplit > 1 ? g.ksplit : 1), g.M / 64);
     if (!ta && !tb) hipLaunchKernelGGL((k_gemm64<false, false>), grid, dim3(256), 0, st, g);
     if (!ta && tb && g.potf2_invD) hipLaunchKernelGGL((k_gemm64<false, true, true>), grid, dim3(256), 0, st, g);
