@@ -34,6 +34,9 @@ class PILCO:
         import weakref
         for comp in (self.mgpr, self.controller, getattr(self.controller, "_gp", None), self.reward):
             if comp is not None and getattr(comp, "_ctx", None) is None:   # components without a context will ask this object for its
+                ref = getattr(comp, "_ctx_owner", None)
+                if ref is not None and ref() is not None:
+                    continue   # a component shared with another live PILCO object stays with it (and this object joins: ctx below)
                 try:
                     comp._ctx_owner = weakref.ref(self)
                 except AttributeError:
@@ -52,10 +55,18 @@ class PILCO:
         if self._ctx is None:
             # a component that already lives on a context decides; otherwise a context of this object's own: the default one
             # for the first live PILCO object, a pooled one for every further (_lib.context_for)
-            for comp in (self.mgpr, self.controller, getattr(self.controller, "_gp", None), self.reward):
-                if comp is not None and getattr(comp, "_ctx", None) is not None:
+            comps = [c for c in (self.mgpr, self.controller, getattr(self.controller, "_gp", None), self.reward) if c is not None]
+            for comp in comps:
+                if getattr(comp, "_ctx", None) is not None:
                     self._ctx = comp._ctx
                     break
+            if self._ctx is None:
+                for comp in comps:   # a component that belongs to another live PILCO object (a shared controller): one context for both
+                    ref = getattr(comp, "_ctx_owner", None)
+                    other = ref() if ref is not None else None
+                    if other is not None and other is not self:
+                        self._ctx = other.ctx
+                        break
             if self._ctx is None:
                 self._ctx = _lib.context_for(self)
         return self._ctx

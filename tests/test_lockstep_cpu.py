@@ -197,5 +197,9 @@ def test_two_live_pilco_objects_get_a_context_each_and_a_dead_ones_context_is_ha
         assert p3.ctx is c2                                                    # handed out again
         ctl = LinearController(2, 1, ctx=p1.ctx)
         assert PILCO(data, horizon=2, controller=ctl).ctx is p1.ctx            # a component that lives somewhere decides
+        shared = LinearController(2, 1)                                        # ... and so does one shared by two live objects,
+        q1 = PILCO(data, horizon=2, controller=shared)                         # whichever of them touches the device first
+        q2 = PILCO(data, horizon=2, controller=shared)
+        assert q2.ctx is q1.ctx and shared.ctx is q1.ctx
     finally:
         _lib.set_context(saved)
