@@ -431,8 +431,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Invoked plainly (`python bench.py --gpus N ...`, the way the driver types the 1-GPU line): start the N ranks
+        # ourselves -- the same launcher line the driver uses, one process per GPU, rendezvous on 127.0.0.1 -- and let
+        # rank 0 of that job print the one JSON line.  exec, not spawn: no second Python sits above the ranks.
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or call it without a launcher)"
+                         % (args.gpus, world))
 
     from pilco_amd import _lib, synthetic
     cfg = synthetic.config_c2(N=N, D=D, E=E)
