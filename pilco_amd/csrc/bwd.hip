@@ -4,19 +4,31 @@
 namespace pilco {
 
 // ------------------------------------------------------------------ adjoint of the pair sums
-// d e_ij/d m = P (z_i + w_j) and d e_ij/d s = (P y)(P y)^T / 2, so the reverse
-// pass needs, per pair, only   r_i = sum_j W_ij L_ij,   c_j = sum_i W_ij L_ij,   m_i = sum_j W_ij L_ij w_j
-// with W = beta_a beta_b^T (- iK_a on the diagonal pair).  A wave owns 16*BWD_RT rows and sweeps a range
-// of columns; the exponent tile is computed TRANSPOSED (column operand as MFMA A, row operand as B) so
-// that the weighted tile W.L lands in the B-operand layout of a second MFMA that contracts it with
-// [w_j | 1]: moments and row sums cost 4 MFMAs per 16x16 tile and moment tile (NMT = ceil((D + 1) / 16) of them) and no
-// VALU reductions.  The column sums of an off-diagonal pair run along the lanes of a DPP row: the wave parks its four
-// result registers in a private LDS scratch and reads the previous step's back four at a time (two quad permutes finish
-// the sum: 9 VALU ops per step instead of four row_shr adds per register); the four waves of a workgroup keep their
-// column sums in separate LDS slices that are summed in a fixed order (diagonal pairs: c = r by symmetry).
-// Off-diagonal pairs: the row side carries beta_b only, the column side beta_a only (k_mm_bwd_post applies the rest).
-// rowmom[pl][js][16 NMT][npad]: d < D -> m_i[d], d = D -> r_i, per column split js;
-// cpart[pl - E][row block][npad]: column sums over the rows of one workgroup.
+// d e_ij/d m = P (z_i + w_j) and d e_ij/d s = (P y)(P y)^T / 2, so the reverse pass needs, per
+// pair, only the moments of W.L (W = beta_a beta_b^T, - iK_a on a diagonal pair) up to second order in y_ij = z_i + w_j:
+//   N = sum_ij W_ij L_ij,   A = sum_ij W_ij L_ij y_ij,   I = sum_ij W_ij L_ij y_ij y_ij^T.
+// With r_i = sum_j W_ij L_ij, c_j = sum_i W_ij L_ij and the row moments m_i = sum_j W_ij L_ij w_j:
+//   A = sum_i r_i z_i + sum_j c_j w_j,   I = sum_i (r_i z_i z_i^T + z_i m_i^T + m_i z_i^T) + sum_j c_j w_j w_j^T.
+// A wave owns 16*BWD_RT rows and sweeps a range of columns; the exponent tile is computed TRANSPOSED (column operand as
+// MFMA A, row operand as B) so that the weighted tile W.L lands in the operand layout of a second MFMA that contracts it
+// with [w_j | 1]: moments and row sums cost 4 MFMAs per 16x16 tile and moment tile (NMT = ceil((D + 1) / 16)) and no VALU
+// reductions; the result M_i = [m_i | r_i] comes out with the ROWS along the result registers (tile as the A operand),
+// which is the B-operand layout of the wave's epilogue: ONE more contraction over its rows,
+//   G[d][e] = sum_i beta~_i [z_i | 1]_d [m_i + r_i z_i / 2 | r_i]_e      ((D + 1) x (D + 1), 4 BWD_RT NMT^2 MFMAs per wave),
+// holds everything the row side contributes (I's row part = G + G^T on the D x D block, A's = column D, N = G[D][D]).
+// The four waves' G are added in LDS and ONE (16 NMT)^2 block per workgroup goes to memory (gpart): 3.6 MB per sweep at
+// C2u where rounds 1-3 wrote the row moments themselves (22 MB, read back by k_mm_bwd_post: 42 MB of the sweep's 206).
+// The column sums run along the lanes of a DPP row: the wave parks its four result registers in a private LDS scratch and
+// reads the previous step's back four at a time (two quad permutes finish the sum: 9 VALU ops per step instead of four
+// row_shr adds per register); the four waves keep their column sums in separate LDS slices that are summed in a fixed
+// order (cpart; k_mm_bwd_post contracts them with [w_j | 1] once per pair, not once per workgroup).
+// Off-diagonal pairs: the row side carries beta_b only, the column side beta_a only (the epilogue / the post kernel apply
+// the other factor).  DIAGONAL pairs (a == b: z == w, W and L symmetric) sweep only the tiles at or right of the diagonal:
+// a tile strictly right of it stands for its mirror image too (weight 2), a tile on it counts once -- N, A and I are sums
+// of a symmetric function of (i, j), so the generic row / column formulas above give the full sums from the upper half:
+// half the exps and half the iK stream (84 -> 42 MB per sweep at C2u).
+// gpart[pl][js][rb][NMT * NMT][256]: entry r * 64 + lane of block (m1, m2) = G[16 m1 + lane / 16 + 4 r][16 m2 + lane % 16];
+// cpart[pl][row block][npad]: column sums over the rows of one workgroup.
 #ifndef BWD_RT
 #define BWD_RT 2
 #endif
@@ -106,11 +118,10 @@ template <int KC, bool VSEP, int NMT>
 #ifndef BWD_LBW
 #define BWD_LBW 2
 #endif
-__global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ rowmom,
+__global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm_bwd_pair(MMModel md, MMWork wk, double* __restrict__ gpart,
                                                     double* __restrict__ cpart, int njs, const double* __restrict__ bars,
                                                     double* __restrict__ head, double* __restrict__ npart) {
     __shared__ double tab[FEXP_TN];
-    __shared__ double nred[4];
     extern __shared__ __attribute__((aligned(16))) double csl[];   // [4][jw]  (head workgroups: Gauss-Jordan scratch)
     if ((int)blockIdx.y >= wk.PL) {   // spare workgroups: the step's D x D inverses, one per output / pair
         const int h = ((int)blockIdx.y - wk.PL) * (int)(gridDim.x * gridDim.z) + (int)(blockIdx.z * gridDim.x + blockIdx.x);
@@ -118,9 +129,8 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
         return;
     }
     for (int e = threadIdx.x; e < FEXP_TN; e += blockDim.x) tab[e] = wk.exp_tab[e];
-    __syncthreads();
     const int npad = md.npad, D = md.D, E = md.E;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (the wave index in scalar registers: the diagonal pairs' tile tests are scalar)
     const int lr = lane >> 4, lc = lane & 15;
     const int pl = blockIdx.y, js = blockIdx.z, rb = blockIdx.x;
     int a, b;
@@ -135,7 +145,12 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
     // column range of this split: the npad / 16 column tiles dealt as evenly as they go (njs need not divide them)
     const int ct = npad / 16, jbeg = 16 * (int)((long)js * ct / njs), jend = 16 * (int)((long)(js + 1) * ct / njs);
     const int jw = jend - jbeg, jws = 16 * ((ct + njs - 1) / njs);   // jws: LDS slice stride (the widest split)
-    const int ibase = rb * 64 * BWD_RT + w * 16 * BWD_RT;
+    const int rbase = rb * 64 * BWD_RT, ibase = rbase + w * 16 * BWD_RT;
+    // a diagonal pair starts at the staged chunk that holds the workgroup's first row (nothing left of it is swept)
+    const int jstart = diag ? min(jend, jbeg + BWD_CH * (max(0, rbase - jbeg) / BWD_CH)) : jbeg;
+    if (diag)
+        for (int e = threadIdx.x; e < 4 * jws; e += 256) csl[e] = 0.0;   // columns a wave skips keep a zero sum
+    __syncthreads();
     double rf[BWD_RT][KC], brow[BWD_RT];
     int irow[BWD_RT];
 #pragma unroll
@@ -149,11 +164,11 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
     // The column operands (KP rows of Bt, beta_b, v) are the same for the four waves of the workgroup: they are staged
     // once per BWD_CH columns through LDS (wave w fetches rows w, w + 4, .. as 512-byte row segments) into a
     // column-major tile T[j][BWD_TP] that serves both MFMA operand layouts -- cf (K = operand row, M = column) and its
-    // transpose a2 (M = operand row, K = column) -- without bank conflicts (pitch 17 doubles); the next chunk is in
+    // transpose a2 (K = column, N = operand row) -- without bank conflicts (pitch 17 doubles); the next chunk is in
     // flight in registers while the current one is evaluated.  Only the iK stream of a diagonal pair stays a per-wave
     // buffer load.
     constexpr int KPc = 4 * KC, NR = KPc + (VSEP ? 2 : 1), NST = (NR + 3) / 4, BWD_TP = bwd_tp(KPc), SB = BWD_CH * BWD_TP + 2 * BWD_CH;
-    const __amdgpu_buffer_rsrc_t rIK = buf_rsrc(iKa ? iKa + (long)jbeg * npad : Bt);
+    const __amdgpu_buffer_rsrc_t rIK = buf_rsrc_uniform(iKa ? iKa + (long)jbeg * npad : Bt);
     const double* vsrc = VSEP ? wk.vcol + (long)pl * npad : Bt;
     unsigned ik_off[BWD_RT][4];
 #pragma unroll
@@ -161,7 +176,7 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
 #pragma unroll
         for (int rt = 0; rt < BWD_RT; ++rt) ik_off[rt][r] = ((unsigned)(lr + 4 * r) * (unsigned)npad + (unsigned)irow[rt]) * 8u;
     int dsel[NMT];                       // operand rows contracted by the second product: w_j (d < D), the ones (d = D);
-#pragma unroll                           // lanes past that repeat row D: their result rows (d > D of rowmom) are never read
+#pragma unroll                           // lanes past that repeat row D: their result columns (d > D) are never read
     for (int m = 0; m < NMT; ++m) dsel[m] = 16 * m + lc <= D ? 16 * m + lc : D;
     double* stg = csl + 4 * jws;         // [2][SB]
     auto stage_load = [&](int jc, double (&sg)[NST]) {
@@ -180,6 +195,7 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
             else if (row < NR) buf[BWD_CH * BWD_TP + (row - KPc) * BWD_CH + lane] = sg[k];
         }
     };
+    // acc[rt][m][r]: row i = 16 rt + 4 r + lane / 16 of the wave, moment column d = 16 m + lane % 16
     d4 acc[BWD_RT][NMT];
 #pragma unroll
     for (int rt = 0; rt < BWD_RT; ++rt)
@@ -199,16 +215,17 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
         if (rd_q == 0) myslice[jp - jbeg + rd_jj] = p;
     };
     // the column sweep, specialised at compile time (branches inside the loop would fence the scheduler between the
-    // eight exp evaluations of a step): MODE 0 off-diagonal pair (column sums), 1 diagonal pair with the iK stream,
+    // eight exp evaluations of a step): MODE 0 off-diagonal pair, 1 diagonal pair with the iK stream,
     // 2 diagonal pair without it (RBF policy GP)
     auto sweep = [&](auto mode_c) {
         constexpr int MODE = decltype(mode_c)::value;
+        if (jstart >= jend) return;   // (workgroup-uniform) a diagonal pair's workgroup entirely left of the diagonal
         double sg[NST];
-        stage_load(jbeg, sg);
+        stage_load(jstart, sg);
         stage_store(stg, sg);
         __syncthreads();
         int cur = 0;
-        for (int jc = jbeg; jc < jend; jc += BWD_CH) {
+        for (int jc = jstart; jc < jend; jc += BWD_CH) {
             const bool more = jc + BWD_CH < jend;
             if (more) stage_load(jc + BWD_CH, sg);
             const double* Tb = stg + cur * SB;
@@ -217,6 +234,7 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
             const int nst = min(BWD_CH, jend - jc);
             for (int jl = 0; jl < nst; jl += 16) {
                 const int j0 = jc + jl;
+                if (MODE != 0 && j0 < ibase) continue;   // (wave-uniform) both row tiles lie below this column tile's mirror
                 double cf[KC], a2[NMT][4], bcol[4], vj[4];
     #pragma unroll
                 for (int c = 0; c < KC; ++c) cf[c] = Tb[(jl + lc) * BWD_TP + 4 * c + lr];
@@ -230,6 +248,9 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
                 double csum[4] = {0.0, 0.0, 0.0, 0.0};
     #pragma unroll
                 for (int rt = 0; rt < BWD_RT; ++rt) {
+                    // diagonal pair: tile weight 2 right of the diagonal tile (it stands for its mirror image too), 1 on it, 0 left of it
+                    const int i0 = ibase + 16 * rt;
+                    const double om = j0 > i0 ? 2.0 : (j0 == i0 ? 1.0 : 0.0);
                     d4 e = {0.0, 0.0, 0.0, 0.0};
     #pragma unroll
                     for (int c = 0; c < KC; ++c)
@@ -246,91 +267,127 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
                         if (MODE == 0) {
                             // off-diagonal pair: W = beta_a beta_b^T is separable -- the row side carries beta_b,j only and
                             // the column side beta_a,i only (one multiply and one FMA instead of two multiplies and an
-                            // add); k_mm_bwd_post applies the missing factor per row / per column
+                            // add); the epilogue / k_mm_bwd_post apply the missing factor per row / per column
                             const double l = fexp(VSEP ? e[r] + vj[r] : e[r], tab);
                             wl[r] = bcol[r] * l;
                             csum[r] = fma(brow[rt], l, csum[r]);
                         } else {
                             double wgt = brow[rt] * bcol[r];
                             if (MODE == 1) wgt -= buf_ld(rIK, ik_off[rt][r], (unsigned)(j0 - jbeg) * (unsigned)npad * 8u);   // iK symmetric: coalesced along the rows
-                            wl[r] = wgt * fexp(VSEP ? e[r] + vj[r] : e[r], tab);
+                            wl[r] = (wgt * om) * fexp(VSEP ? e[r] + vj[r] : e[r], tab);
+                            csum[r] += wl[r];
                         }
                     }
     #pragma unroll
                     for (int m = 0; m < NMT; ++m)
     #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[rt][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[m][r], wl[r], acc[rt][m], 0, 0, 0);
+                        for (int r = 0; r < 4; ++r) acc[rt][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[r], a2[m][r], acc[rt][m], 0, 0, 0);
                 }
-                if (MODE == 0) {
-                    // column sums over the wave's 16 lanes of a DPP row, through a per-wave LDS scratch instead of four
-                    // DPP row shifts per register (12 VALU ops each on the pipe this kernel is bound by): the partial sums
-                    // of the PREVIOUS column step are read back four at a time, added and finished with two quad
-                    // permutes (9 VALU ops per step instead of 48); LDS operations of one wave execute in order
-#ifdef BWD_DPP_COLS
+                // column sums over the wave's 16 lanes of a DPP row, through a per-wave LDS scratch instead of four
+                // DPP row shifts per register (12 VALU ops each on the pipe this kernel is bound by): the partial sums
+                // of the PREVIOUS column step are read back four at a time, added and finished with two quad
+                // permutes (9 VALU ops per step instead of 48); LDS operations of one wave execute in order
+                if (jprev >= 0) flush_cols(jprev);
     #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        double v = csum[r];
-                        v = dpp_add<0x111, 0xf>(v);
-                        v = dpp_add<0x112, 0xf>(v);
-                        v = dpp_add<0x114, 0xf>(v);
-                        v = dpp_add<0x118, 0xf>(v);
-                        if (lc == 15) myslice[j0 - jbeg + lr + 4 * r] = v;
-                    }
-#else
-                    if (jprev >= 0) flush_cols(jprev);
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r) scr[r * 64 + lane] = csum[r];
-                    jprev = j0;
-#endif
-                }
+                for (int r = 0; r < 4; ++r) scr[r * 64 + lane] = csum[r];
+                jprev = j0;
             }
             if (more) stage_store(stg + (cur ^ 1) * SB, sg);
             __syncthreads();
             cur ^= 1;
         }
-        if (MODE == 0 && jprev >= 0) flush_cols(jprev);
+        if (jprev >= 0) flush_cols(jprev);
     };
     if (!diag) sweep(std::integral_constant<int, 0>{});
     else if (iKa) sweep(std::integral_constant<int, 1>{});
     else sweep(std::integral_constant<int, 2>{});
-    double* out = rowmom + ((long)pl * njs + js) * (16 * NMT) * npad;
+    // ---- epilogue 1: the wave's rows contracted with [z_i | 1]   (header comment: G)
+    // zt[m][r]: lane (d = 16 m + lane % 16, i = 4 r + lane / 16) -- the A-operand layout, and the layout acc holds M_i in
+    double zm[NMT], zi[NMT];
 #pragma unroll
-    for (int rt = 0; rt < BWD_RT; ++rt)
-        if (ibase + 16 * rt < npad) {
+    for (int m = 0; m < NMT; ++m) {
+        const int d = 16 * m + lc;
+        const double la = d < D ? md.ls[a * D + d] : 1.0;
+        zm[m] = d < D ? wk.in_m[d] : 0.0;
+        zi[m] = 1.0 / (la * la);
+    }
+    d4 G[NMT][NMT];
+#pragma unroll
+    for (int m1 = 0; m1 < NMT; ++m1)
+#pragma unroll
+        for (int m2 = 0; m2 < NMT; ++m2) G[m1][m2] = d4{0.0, 0.0, 0.0, 0.0};
+    const int rlane = (lane & 48) | (D & 15);   // the lane of this DPP row that holds r_i (moment column D)
+#pragma unroll
+    for (int rt = 0; rt < BWD_RT; ++rt) {
+        if (ibase + 16 * rt >= npad) continue;   // (wave-uniform) tiles past the padding carry garbage
+        double zt[NMT][4], bs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ibase + 16 * rt + 4 * r + lr;
+            const bool valid = i < md.n;
+            bs[r] = !valid ? 0.0 : (diag ? 1.0 : beta_a[i]);
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) {
+                const int d = 16 * m + lc;
+                zt[m][r] = (valid && d < D) ? (md.Pt[(long)d * npad + i] - zm[m]) * zi[m] : ((valid && d == D) ? 1.0 : 0.0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double ri = 0.0;
 #pragma unroll
             for (int m = 0; m < NMT; ++m)
+                if (m == (D >> 4)) ri = __shfl(acc[rt][m][r], rlane);
+            double mp[NMT];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (16 * m + lr + 4 * r <= D) out[(long)(16 * m + lr + 4 * r) * npad + irow[rt]] = acc[rt][m][r];   // rows past D are never read
+            for (int m = 0; m < NMT; ++m) {
+                const int d = 16 * m + lc;
+                const double x = acc[rt][m][r];
+                mp[m] = bs[r] == 0.0 ? 0.0 : (d < D ? fma(0.5 * ri, zt[m][r], x) : x);   // rows past n: nothing (their sums may be anything)
+            }
+#pragma unroll
+            for (int m1 = 0; m1 < NMT; ++m1)
+#pragma unroll
+                for (int m2 = 0; m2 < NMT; ++m2) {
+                    const double za = zt[m1][r] * bs[r];
+                    G[m1][m2] = __builtin_amdgcn_mfma_f64_16x16x4f64(za, mp[m2], G[m1][m2], 0, 0, 0);
+                    MFMA_KEEP_ALIVE(za);         // (the first MFMA of each chain has a constant-zero accumulator)
+                    MFMA_KEEP_ALIVE(mp[m2]);
+                }
         }
-    if (!diag) {
-        __syncthreads();
-        double* cp = cpart + ((long)(pl - wk.EL) * gridDim.x + rb) * npad + jbeg;
+    }
+    // ---- epilogue 2: column sums of the workgroup's rows (fixed order over the four waves)
+    __syncthreads();
+    {
+        double* cp = cpart + ((long)pl * gridDim.x + rb) * npad + jbeg;
         for (int jj = threadIdx.x; jj < jw; jj += 256)
             cp[jj] = (csl[jj] + csl[jws + jj]) + (csl[2 * jws + jj] + csl[3 * jws + jj]);
     }
-    if (npart) {
-        // Jacobian tape: this workgroup's share of N_ab = sum_i r_i, in the [pair][tile][2] layout the serial link packs
-        // tile partials from (tile = js * row blocks + rb); r_i is row D of the moment tile: lanes lr == D % 4, register D / 4
-        const int rsel = (D & 15) >> 2, msel = D >> 4;
-        double v = 0.0;
+    // ---- epilogue 3: the four waves' G added in LDS (block by block: the staging area holds 4 x 256 doubles), one block
+    // per workgroup to memory; N_ab's share for the serial link of a value-and-gradient rollout is entry (D, D)
+    double* red = stg;   // [4][256]  (2 SB + 4 * 256 >= 1024 doubles)
+    double* gout = gpart + (((long)pl * njs + js) * gridDim.x + rb) * (NMT * NMT * 256);
+    const int tN = ((D & 15) >> 2) * 64 + (D & 3) * 16 + (D & 15);   // entry of (d, e) = (D, D) inside its block
 #pragma unroll
-        for (int rt = 0; rt < BWD_RT; ++rt) {
-            double x = 0.0;
+    for (int m1 = 0; m1 < NMT; ++m1)
 #pragma unroll
-            for (int m = 0; m < NMT; ++m)
-                if (m == msel) x = rsel == 0 ? acc[rt][m][0] : rsel == 1 ? acc[rt][m][1] : rsel == 2 ? acc[rt][m][2] : acc[rt][m][3];
-            v += (lr == (D & 3) && ibase + 16 * rt < npad) ? (diag ? x : x * brow[rt]) : 0.0;   // tiles past the padding carry garbage and are never stored
+        for (int m2 = 0; m2 < NMT; ++m2) {
+            __syncthreads();
+            MFMA_RESULT_FENCE(G[m1][m2]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[w * 256 + r * 64 + lane] = G[m1][m2][r];
+            __syncthreads();
+            const int t = threadIdx.x;
+            const double v = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
+            gout[(m1 * NMT + m2) * 256 + t] = v;
+            if (npart && m1 == (D >> 4) && m2 == (D >> 4) && t == tN) {
+                // Jacobian tape: this workgroup's share of N_ab, in the [pair][tile][2] layout the serial link packs tile
+                // partials from (tile = js * row blocks + rb)
+                double* o = npart + ((long)pl * (njs * (int)gridDim.x) + js * (int)gridDim.x + rb) * 2;
+                o[0] = v;
+                o[1] = 0.0;
+            }
         }
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) nred[w] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double* o = npart + ((long)pl * (njs * (int)gridDim.x) + js * (int)gridDim.x + rb) * 2;
-            o[0] = (nred[0] + nred[1]) + (nred[2] + nred[3]);
-            o[1] = 0.0;
-        }
-    }
 }
 
 // Reverse of the mean part (mgpr.py:99-118) for output a, including the -M M^T term of S:
@@ -551,28 +608,124 @@ __device__ void bwd_mean_final(const MMModel& md, const double* __restrict__ bar
     }
 }
 
-// Per unordered pair and row chunk: partial sums of  N_ab = sum_i r_i,  A = sum_i (r_i z_i + c_i w_i)  (D),
-// I = sum_i (r_i z_i z_i^T + c_i w_i w_i^T + z_i m_i^T + m_i z_i^T)  (D x D).   part[pl][chunk][1 + D + D*D]
-constexpr int BWD_RC = 8;   // row chunks per pair / output (16: 12 % slower in the batched form, more workgroup prologues)
+// Per unordered pair and column chunk rc: a share of  N_ab | A (D) | I (D x D)  (header comment of the sweep):
+// the share of the sweep's G blocks it adds up (blocks rc, rc + nrc, .. of the pair's njs * nrb, fixed order) and the
+// column side of its 64-column blocks (rc, rc + nrc, ..), contracted on the matrix cores:
+//   Gc[d][e] = sum_j c_j [w_j | 1]_d [w_j | 1]_e,   c_j = (beta_b,j) * sum over the row blocks of cpart   (K = columns).
+//   N = G[D][D],  A_d = G[d][D] + Gc[d][D],  I_de = G[d][e] + G[e][d] + (Gc[d][e] + Gc[e][d]) / 2.      part[pl][chunk][1 + D + D*D]
+constexpr int BWD_RC = 8;   // chunks per pair / output (16: 12 % slower in the batched form, more workgroup prologues)
 // Batched form (Jacobian tape): blockIdx.z = horizon step; every per-step array advances by its stride and the input
 // mean comes from the step's tape record (wk.in_m holds the LAST step's by then).  Unbatched: strides 0, in_m = nullptr.
 struct BwdBatch {
-    long rowmom, cpart, part, head;
+    long gpart, cpart, part, head;
     const double* in_m;
     long in_m_stride;
 };
-template <int NA>   // NA = 1: D <= 14 (one sum per thread everywhere), NA = 5: D <= 32
+template <int NMT>
+__device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double* __restrict__ in_m, const double* __restrict__ gpart,
+                              const double* __restrict__ cpart, int njs, int nrb, double* __restrict__ part, int nrc, int pl, int rc,
+                              double* sm) {
+    const int npad = md.npad, D = md.D, E = md.E, t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6, lr = lane >> 4, lc = lane & 15;
+    constexpr int NB2 = NMT * NMT, GW = 16 * NMT;
+    int a, b;
+    local_pair_ab(wk, E, pl, a, b);
+    const bool diag = (a == b);
+    double* Gs = sm;                 // [GW][GW]  this chunk's share of G
+    double* Gc = Gs + GW * GW;       // [GW][GW]  ... and of the column side
+    double* red = Gc + GW * GW;      // [4][256]
+    // (i) the sweep's blocks
+    const int nparts = njs * nrb;
+    const double* g0 = gpart + (long)pl * nparts * (NB2 * 256);
+#pragma unroll
+    for (int blk = 0; blk < NB2; ++blk) {
+        const double v = sum_strided<4>(g0 + (long)rc * (NB2 * 256) + blk * 256 + t, (long)nrc * (NB2 * 256), (nparts - rc + nrc - 1) / nrc);
+        const int d = 16 * (blk / NMT) + ((t >> 4) & 3) + 4 * (t >> 6), e = 16 * (blk % NMT) + (t & 15);
+        Gs[d * GW + e] = v;
+    }
+    // (ii) the column side
+    const double* cp = cpart + (long)pl * nrb * npad;
+    const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
+    double wm[NMT], wi[NMT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) {
+        const int d = 16 * m + lc;
+        const double lb = d < D ? md.ls[b * D + d] : 1.0;
+        wm[m] = d < D ? in_m[d] : 0.0;
+        wi[m] = 1.0 / (lb * lb);
+    }
+    d4 C[NMT][NMT];
+#pragma unroll
+    for (int m1 = 0; m1 < NMT; ++m1)
+#pragma unroll
+        for (int m2 = 0; m2 < NMT; ++m2) C[m1][m2] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int blk = rc; blk < npad / 64; blk += nrc) {
+        double wt[NMT][4], cj[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = blk * 64 + 16 * w + 4 * r + lr;
+            const bool valid = j < md.n;
+            cj[r] = valid ? sum_strided<8>(cp + j, npad, nrb) * (diag ? 1.0 : beta_b[j]) : 0.0;   // the sweep left beta_b,j out of the column side
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) {
+                const int d = 16 * m + lc;
+                wt[m][r] = (valid && d < D) ? (md.Pt[(long)d * npad + j] - wm[m]) * wi[m] : ((valid && d == D) ? 1.0 : 0.0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m1 = 0; m1 < NMT; ++m1)
+#pragma unroll
+                for (int m2 = 0; m2 < NMT; ++m2) {
+                    const double ca = cj[r] * wt[m1][r];
+                    C[m1][m2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca, wt[m2][r], C[m1][m2], 0, 0, 0);
+                    MFMA_KEEP_ALIVE(ca);          // (the first MFMA of each chain has a constant-zero accumulator)
+                    MFMA_KEEP_ALIVE(wt[m2][r]);
+                }
+    }
+#pragma unroll
+    for (int m1 = 0; m1 < NMT; ++m1)
+#pragma unroll
+        for (int m2 = 0; m2 < NMT; ++m2) {
+            __syncthreads();
+            MFMA_RESULT_FENCE(C[m1][m2]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[w * 256 + r * 64 + lane] = C[m1][m2][r];
+            __syncthreads();
+            const int d = 16 * m1 + ((t >> 4) & 3) + 4 * (t >> 6), e = 16 * m2 + (t & 15);
+            Gc[d * GW + e] = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
+        }
+    __syncthreads();
+    // (iii) N | A | I
+    const int nI = D * D;
+    double* o = part + ((long)pl * nrc + rc) * (1 + D + nI);
+    for (int e2 = t; e2 < 1 + D + nI; e2 += 256) {
+        double v;
+        if (e2 == 0) {
+            v = Gs[D * GW + D];
+        } else if (e2 <= D) {
+            const int d = e2 - 1;
+            v = Gs[d * GW + D] + Gc[d * GW + D];
+        } else {
+            const int d = (e2 - 1 - D) / D, e = (e2 - 1 - D) - d * D;
+            v = (Gs[d * GW + e] + Gs[e * GW + d]) + 0.5 * (Gc[d * GW + e] + Gc[e * GW + d]);
+        }
+        o[e2] = v;
+    }
+}
+
+template <int NA, int NMT>   // NA = 1: D <= 14 (one mean-part sum per thread), NA = 5: D <= 32; NMT = ceil((D + 1) / 16)
 #ifndef POST_LB
-#define POST_LB 8   // waves per SIMD of the narrow post kernel: latency-bound, 8 resident workgroups per CU (64 VGPRs, a few spills) beat 4 by 30 %
+#define POST_LB 8   // waves per SIMD of the narrow post kernel: latency-bound, 8 resident workgroups per CU
 #endif
-__global__ __launch_bounds__(256, NA == 1 ? POST_LB : 1) void k_mm_bwd_post(MMModel md, MMWork wk, const double* __restrict__ rowmom,
+__global__ __launch_bounds__(256, NA == 1 ? POST_LB : 1) void k_mm_bwd_post(MMModel md, MMWork wk, const double* __restrict__ gpart,
                                                     const double* __restrict__ cpart, int njs, int nrb,
                                                     double* __restrict__ part, int nrc,
                                                     const double* __restrict__ head, double* __restrict__ mpart, int jac, BwdBatch bb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int npad = md.npad, D = md.D, E = md.E, t = threadIdx.x;
     const int pl = blockIdx.x, rc = blockIdx.y, z = blockIdx.z;
-    rowmom += (long)z * bb.rowmom;
+    gpart += (long)z * bb.gpart;
     cpart += (long)z * bb.cpart;
     part += (long)z * bb.part;
     mpart += (long)z * bb.part;
@@ -583,135 +736,7 @@ __global__ __launch_bounds__(256, NA == 1 ? POST_LB : 1) void k_mm_bwd_post(MMMo
         else bwd_mean_partial<NA>(md, in_m, head, pl - wk.PL, rc, nrc, mpart, sm);
         return;
     }
-    int a, b;
-    local_pair_ab(wk, E, pl, a, b);
-    const int mrows = 16 * ((D + 16) / 16);   // rows of a moment block: 16 per moment tile of the sweep
-    const double* mom0 = rowmom + (long)pl * njs * mrows * npad;
-    const double* cp = (a != b) ? cpart + (long)(pl - wk.EL) * nrb * npad : nullptr;
-    const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
-    const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
-    const int LD = D | 1;         // odd row stride: the (d, e) readers of one point spread over the banks
-    double* zs = sm;              // [64][LD]
-    double* ws = zs + 64 * LD;    // [64][LD]
-    double* ms = ws + 64 * LD;    // [64][LD]
-    double* rs = ms + 64 * LD;    // [64]
-    double* cs = rs + 64;         // [64]
-    double* ia = cs + 64;         // [D] 1 / l_a^2
-    double* ib = ia + D;          // [D] 1 / l_b^2
-    double* mm = ib + D;          // [D] input mean
-    const int nI = D * D;
-    const int nblk = npad / 64;
-    if (t < D) {
-        const double la = md.ls[a * D + t], lb = md.ls[b * D + t];
-        ia[t] = 1.0 / (la * la);
-        ib[t] = 1.0 / (lb * lb);
-        mm[t] = in_m[t];
-    }
-    const int NT2 = D * (D + 1) / 2, per = NT2 + D + 1;          // I (packed) | A | N
-    const int NG = per <= 85 ? 3 : per <= 128 ? 2 : 1;           // thread groups sharing the points of a block
-    const int grp = t / per, idx = t - grp * per;
-    int pd = 0;
-    while (idx < NT2 && (pd + 1) * (pd + 2) / 2 <= idx) ++pd;    // idx = pd (pd + 1) / 2 + pe, pe <= pd
-    const int pe = idx < NT2 ? idx - pd * (pd + 1) / 2 : 0;
-    constexpr int NP = NA == 1 ? 1 : 3;   // pair sums per thread
-    double acc[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) acc[k] = 0.0;
-    for (int blk = rc; blk < nblk; blk += nrc) {
-        const int i0 = blk * 64;
-        __syncthreads();
-        for (int e = t; e < 64 * D; e += 256) {
-            const int d = e >> 6, ii = e & 63;   // consecutive threads -> consecutive points: coalesced
-            const int i = i0 + ii;
-            const bool valid = i < md.n;
-            const double zeta = valid ? md.Pt[(long)d * npad + i] - mm[d] : 0.0;
-            zs[ii * LD + d] = zeta * ia[d];
-            ws[ii * LD + d] = zeta * ib[d];
-            double mv = 0.0;
-            if (valid) {
-                mv = sum_strided<4>(mom0 + (long)d * npad + i, (long)mrows * npad, njs);
-                if (cp) mv *= beta_a[i];   // off-diagonal pair: the sweep left beta_a,i out of the row side
-            }
-            ms[ii * LD + d] = mv;
-        }
-        if (t < 64) {
-            const int i = i0 + t;
-            const bool valid = i < md.n;
-            double r = 0.0, c = 0.0;
-            if (valid) {
-                r = sum_strided<4>(mom0 + (long)D * npad + i, (long)mrows * npad, njs);
-                if (cp) {
-                    r *= beta_a[i];
-                    c = sum_strided<8>(cp + i, npad, nrb) * beta_b[i];   // ... and beta_b,j out of the column side
-                } else {
-                    c = r;
-                }
-            }
-            rs[t] = r;
-            cs[t] = c;
-        }
-        __syncthreads();
-        // I is symmetric: only d >= e2 is accumulated (NT2 entries), and the 64 points of the block are dealt over NG
-        // thread groups whose partial sums are added in a fixed order at the end (wide inputs, per > 256: one group,
-        // up to three entries per thread)
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int ek = (NG > 1) ? idx : t + 256 * k;
-            if ((NG > 1 && (k > 0 || grp >= NG)) || ek >= per) break;
-            const int ii0 = (NG > 1) ? grp * 64 / NG : 0, ii1 = (NG > 1) ? (grp + 1) * 64 / NG : 64;
-            double a2 = acc[k];
-            if (ek < NT2) {
-                int qd = pd, qe = pe;
-                if (k > 0) {
-                    qd = 0;
-                    while ((qd + 1) * (qd + 2) / 2 <= ek) ++qd;
-                    qe = ek - qd * (qd + 1) / 2;
-                }
-                for (int ii = ii0; ii < ii1; ++ii) {
-                    const double zd = zs[ii * LD + qd], ze = zs[ii * LD + qe];
-                    a2 = fma(rs[ii] * zd, ze, a2);
-                    a2 = fma(cs[ii] * ws[ii * LD + qd], ws[ii * LD + qe], a2);
-                    a2 = fma(zd, ms[ii * LD + qe], a2);
-                    a2 = fma(ms[ii * LD + qd], ze, a2);
-                }
-            } else if (ek < NT2 + D) {
-                const int d = ek - NT2;
-                for (int ii = ii0; ii < ii1; ++ii) a2 = fma(rs[ii], zs[ii * LD + d], fma(cs[ii], ws[ii * LD + d], a2));
-            } else {
-                for (int ii = ii0; ii < ii1; ++ii) a2 += rs[ii];
-            }
-            acc[k] = a2;
-        }
-    }
-    __syncthreads();
-    double* o = part + ((long)pl * nrc + rc) * (1 + D + nI);
-    auto put = [&](int e, double v) {
-        if (e < NT2) {
-            int qd = 0;
-            while ((qd + 1) * (qd + 2) / 2 <= e) ++qd;
-            const int qe = e - qd * (qd + 1) / 2;
-            o[1 + D + qd * D + qe] = v;
-            o[1 + D + qe * D + qd] = v;
-        } else if (e < NT2 + D) {
-            o[1 + (e - NT2)] = v;
-        } else {
-            o[0] = v;
-        }
-    };
-    if (NG > 1) {
-        double* red = zs;   // [NG][per]
-        if (grp < NG) red[grp * per + idx] = acc[0];
-        __syncthreads();
-        if (t < per) {
-            double v = red[t];
-            for (int g2 = 1; g2 < NG; ++g2) v += red[g2 * per + t];
-            put(t, v);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < NP; ++k)
-            if (t + 256 * k < per) put(t + 256 * k, acc[k]);
-    }
+    bwd_pair_post<NMT>(md, wk, in_m, gpart, cpart, njs, nrb, part, nrc, pl, rc, sm);
 }
 
 // Per pair, with P = (I + Lambda s)^-1 and kappa = Shat_ab / sqrt(det R_ab) from the step's head record:
@@ -974,16 +999,19 @@ static void launch_bwd_pair(hipStream_t st, dim3 grid, size_t lds, const MMModel
 }
 
 void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb);
-size_t mm_jac_rowmom_size(int npad, int P) {
+size_t mm_bwd_gpart_size(int npad, int P, int D) {   // one (16 NMT)^2 block per sweep workgroup
     int njs, nrb;
     mm_bwd_geometry(npad, P, &njs, &nrb);
-    return (size_t)P * njs * 16 * npad;
+    const int nmt = (D + 16) / 16;
+    return (size_t)std::max(1, P) * njs * nrb * nmt * nmt * 256;
 }
-size_t mm_jac_cpart_size(int npad, int P, int E) {
+size_t mm_bwd_cpart_size(int npad, int P) {
     int njs, nrb;
     mm_bwd_geometry(npad, P, &njs, &nrb);
-    return (size_t)std::max(1, P - E) * nrb * npad;
+    return (size_t)std::max(1, P) * nrb * npad;
 }
+size_t mm_jac_rowmom_size(int npad, int P) { return mm_bwd_gpart_size(npad, P, 1); }   // (the Jacobian tape serves D <= 14: one block)
+size_t mm_jac_cpart_size(int npad, int P, int) { return mm_bwd_cpart_size(npad, P); }
 size_t mm_jac_head_size(int D, int E, int P) { return (size_t)(E + P) * (D * D + D + 2); }
 int mm_jac_nt(int npad, int P) {
     int njs, nrb;
@@ -1019,15 +1047,16 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
     const int LD = D | 1, nI = D * D, D1 = D + 1, LD1 = D1 | 1, NS = mm_jac_ns(D);
     const int nrc = mm_bwd_rc(md.npad);
     BwdBatch bb;
-    bb.rowmom = (long)mm_jac_rowmom_size(md.npad, P);
+    bb.gpart = (long)mm_jac_rowmom_size(md.npad, P);
     bb.cpart = (long)mm_jac_cpart_size(md.npad, P, wk.EL);   // (EL = E on one rank; the first EL local pairs are the diagonal ones)
     bb.part = (long)mm_jac_part_size(D, E, P, md.npad);
     bb.head = (long)mm_jac_head_size(D, E, P);
     bb.in_m = tape;
     bb.in_m_stride = (long)tape_stride;
     double* mpart = part + (size_t)P * nrc * (1 + D + nI);
-    const size_t lds_post = sizeof(double) * std::max((size_t)3 * 64 * LD + 128 + 3 * D, (size_t)nI + 64 * LD1 + 64 + NS / 2 + 2);
-    hipLaunchKernelGGL(k_mm_bwd_post<1>, dim3(P + E, nrc, H), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
+    (void)LD;
+    const size_t lds_post = sizeof(double) * std::max((size_t)2 * 256 + 4 * 256, (size_t)nI + 64 * LD1 + 64 + NS / 2 + 2);
+    hipLaunchKernelGGL((k_mm_bwd_post<1, 1>), dim3(P + E, nrc, H), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
                        head, mpart, 1, bb);   // (the Jacobian tape serves D <= 14)
     const size_t lds_fin = sizeof(double) * std::max((size_t)4 * nI + 4 * D + 8, (size_t)3 * nI + NS + D + 2 * nI * D);
     hipLaunchKernelGGL(k_mm_jac_fin, dim3(P + E, H), dim3(256), lds_fin, st, md, wk, part, nrc, head, mpart, jrec,
@@ -1055,13 +1084,17 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
     launch_bwd_pair(st, grid, lds_pair, md, wk, rowmom, cpart, njs, bars, head, npart);
     const int nrc = mm_bwd_rc(md.npad);
     double* mpart = part + (size_t)P * nrc * (1 + D + nI);
-    const size_t lds_post = sizeof(double) * std::max((size_t)3 * 64 * LD + 128 + 3 * D, (size_t)nI + 64 * LD + 128 + D + 2);
-    if (D <= 14)
-        hipLaunchKernelGGL(k_mm_bwd_post<1>, dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
-                           head, mpart, 0, BwdBatch{0, 0, 0, 0, nullptr, 0});
-    else
-        hipLaunchKernelGGL(k_mm_bwd_post<5>, dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
-                           head, mpart, 0, BwdBatch{0, 0, 0, 0, nullptr, 0});
+    const int nmt = (D + 16) / 16;
+    const size_t lds_post = sizeof(double) * std::max((size_t)2 * 256 * nmt * nmt + 4 * 256, (size_t)nI + 64 * LD + 128 + D + 2);
+    const BwdBatch nob{0, 0, 0, 0, nullptr, 0};
+#define PPOST(NA_, M_)                                                                                                          \
+    hipLaunchKernelGGL((k_mm_bwd_post<NA_, M_>), dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc, \
+                       head, mpart, 0, nob)
+    if (D <= 14) PPOST(1, 1);
+    else if (nmt == 1) PPOST(5, 1);
+    else if (nmt == 2) PPOST(5, 2);
+    else PPOST(5, 3);
+#undef PPOST
     const size_t lds_fin = sizeof(double) * ((size_t)3 * nI + 4 * D + 8);
     hipLaunchKernelGGL(k_mm_bwd_fin, dim3(P + E), dim3(256), lds_fin, st, md, wk, part, nrc, bars, head, mpart, out, done, sum_out);
 }

@@ -24,8 +24,8 @@ int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double
     const int rec = D + D * D, nb = E + E * E + D * E;
     int njs, nrb;
     mm_bwd_geometry(npad, P, &njs, &nrb);
-    ENSURE(s.bwd_mom, (size_t)P * njs * (16 * ((D + 16) / 16)) * npad);   // 16 rows per moment tile of the sweep
-    ENSURE(s.bwd_cp, (size_t)std::max(1, P - E) * nrb * npad);
+    ENSURE(s.bwd_mom, mm_bwd_gpart_size(npad, P, D));   // one (16 NMT)^2 block per sweep workgroup
+    ENSURE(s.bwd_cp, mm_bwd_cpart_size(npad, P));
     ENSURE(s.bwd_part, (size_t)(P + E) * mm_bwd_rc(npad) * (1 + rec + D));   // pair partials, then mean partials
     ENSURE(s.bwd_out, (size_t)(E + P) * rec + (size_t)(E + P) * (D * D + D + 2));   // contributions | head records
     if (!s.bwd_cnt.p) {

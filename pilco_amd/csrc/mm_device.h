@@ -375,6 +375,13 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const double* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, 0x7fffffff, 0x00020000);   // raw, untyped
 }
+// ... with the base pointer pinned to scalar registers (a resource the compiler has moved to vector registers costs a
+// waterfall loop -- readfirstlane, compare, masked load -- per load)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc_uniform(const double* base) {
+    const unsigned long long p = (unsigned long long)(uintptr_t)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    return buf_rsrc((const double*)(uintptr_t)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return __hiloint2double((int)v.y, (int)v.x);

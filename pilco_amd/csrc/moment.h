@@ -213,6 +213,8 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
 size_t mm_jac_rec_size(int D, int E, int P);
 size_t mm_jac_part_size(int D, int E, int P, int npad);
 size_t mm_jac_rowmom_size(int npad, int P);
+size_t mm_bwd_gpart_size(int npad, int P, int D);
+size_t mm_bwd_cpart_size(int npad, int P);
 size_t mm_jac_cpart_size(int npad, int P, int E);
 size_t mm_jac_head_size(int D, int E, int P);
 int mm_jac_nt(int npad, int P);
