@@ -1228,12 +1228,15 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
         HIPCHK(hipHostMalloc((void**)&ctx->jpin, sizeof(double) * need, hipHostMallocDefault));
         ctx->jpin_cap = need;
     }
-    plan.g.tape = ctx->tape.p;
-    plan.jrec = ctx->jrec.p;
-    plan.jstride = JS;
     double* h_traj = ctx->jpin;
     double* h_tape = h_traj + NTJ;
     double* h_jrec = h_tape + (size_t)H * TS;
+    plan.g.tape = ctx->tape.p;
+    // one rank: k_mm_jac_fin writes the records straight into the pinned host buffer (device-visible): their 4.3 MB cross
+    // PCIe while the kernel runs instead of as four copies that hold the stream between the chunks of the finish
+    const bool jdirect = !sharded && getenv("PILCO_JAC_COPY") == nullptr;
+    plan.jrec = jdirect ? h_jrec : ctx->jrec.p;
+    plan.jstride = JS;
     double* h_misc = h_jrec + (size_t)H * JSg;
     double* h_all = h_misc + 8;                          // sharded: [W][H][PLcap * recp | E * reco]
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1301,8 +1304,9 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
             used += parts[k];
             const int t0 = (k == nch - 1) ? 0 : std::min(t1 - 1, std::max(0, H - (int)((long)used * H / 40)));   // steps [t0, t1), never empty
             jac_finish_range(ctx, plan, t0, t1);
-            HIPCHK(hipMemcpyAsync(h_jrec + (size_t)t0 * JS, ctx->jrec.p + (size_t)t0 * JS, sizeof(double) * (size_t)(t1 - t0) * JS,
-                                  hipMemcpyDeviceToHost, ctx->st));
+            if (!jdirect)
+                HIPCHK(hipMemcpyAsync(h_jrec + (size_t)t0 * JS, ctx->jrec.p + (size_t)t0 * JS, sizeof(double) * (size_t)(t1 - t0) * JS,
+                                      hipMemcpyDeviceToHost, ctx->st));
             if (!ctx->jwait_ev[k]) HIPCHK(hipEventCreateWithFlags(&ctx->jwait_ev[k], hipEventDisableTiming));
             HIPCHK(hipEventRecord(ctx->jwait_ev[k], ctx->st));
             ctx->jwait_t0[k] = t0;
