@@ -15,7 +15,17 @@
 
 using namespace pilco;
 
+// A fixed launch sequence (factorisation, training objective) kept as an instantiated hipGraph: `key` names everything the
+// enqueued launches depend on (buffer addresses, sizes); another key -> captured again.  failed: capture or instantiation
+// did not work once -- the sequence stays on eager launches.
+struct ChainGraph {
+    std::vector<unsigned long long> key;
+    hipGraphExec_t exec = nullptr;
+    bool failed = false;
+};
+
 struct Slot {
+    ChainGraph g_fact, g_fitc, g_nlml, g_fitc_nlml;   // exact / FITC factorisation, their training objectives
     int N = 0, D = 0, E = 0, M = 0;  // data size, input dim, outputs, inducing points (0 = exact)
     int Npad = 0;                    // padded N
     int n = 0, npad = 0;             // points the moment matching runs over (N or M) and padding
@@ -162,6 +172,43 @@ int fail(pilco_ctx* c, int code, const std::string& msg);
     do {                                                                                                   \
         if ((buf).ensure(count) != hipSuccess) return fail(ctx, PILCO_E_ALLOC, "hipMalloc failed: " #buf); \
     } while (0)
+
+// Run `enqueue` -- a callable that ONLY enqueues work on ctx->st and returns a status -- as the cached graph cg.  The first
+// call with a key runs the launches eagerly (its results are this call's results; one-time host configuration of the kernels
+// happens here) and then captures the same sequence for the calls that follow; a context with graphs off, or with the
+// developer stamps armed, always launches eagerly.
+inline void chain_graph_release(ChainGraph& cg) {
+    if (cg.exec) (void)hipGraphExecDestroy(cg.exec);
+    cg.exec = nullptr;
+    cg.key.clear();
+}
+template <class F>
+int run_chain_graph(pilco_ctx* ctx, ChainGraph& cg, const std::vector<unsigned long long>& key, F&& enqueue) {
+    if (!ctx->use_graph || ctx->dbg || cg.failed) return enqueue();
+    if (cg.exec && cg.key == key) {
+        HIPCHK(hipGraphLaunch(cg.exec, ctx->st));
+        return PILCO_OK;
+    }
+    chain_graph_release(cg);
+    if (int r = enqueue()) return r;   // this call's work, eagerly
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(ctx->st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        cg.failed = true;
+        return PILCO_OK;
+    }
+    const int rc = enqueue();
+    const hipError_t e = hipStreamEndCapture(ctx->st, &graph);
+    if (rc != PILCO_OK || e != hipSuccess || !graph || hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        cg.exec = nullptr;
+        cg.failed = true;   // eager from now on (the work of this call is already enqueued)
+    } else {
+        cg.key = key;
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    return PILCO_OK;
+}
 
 // api.hip
 // which outputs this rank factorises / trains, and their hyper-parameters / targets compacted for the batched kernels

@@ -209,11 +209,29 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     double* Zt = s.ft_Z.p;                       // [E][D][Mp]
     double* Zraw = Zt + (size_t)E * D * Mp;      // [E][M][D] staging
     HIPCHK(hipMemcpyAsync(Zraw, Z_all, sizeof(double) * (size_t)E * M * D, hipMemcpyHostToDevice, st));
-    for (int e = 0; e < E; ++e) launch_transpose_points(st, Zraw + (size_t)e * M * D, M, D, Zt + (size_t)e * D * Mp, Mp);
-    HIPCHK(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * 64, st));
     const long sZ = (long)D * Mp;
     double* Kuu = s.K.p;
     double* V = s.V2.p;
+    const bool want_grad = grad_hyp || grad_Z;
+    double* r0 = s.vec.p;                                    // [E][Mp]  Vb (y / G)
+    double* gam = r0 + (size_t)E * Mp;                       // [E][Mp]  AmInv r0 = gamma sn   (gamma = L^-1 U ytil)
+    double* av = gam + (size_t)E * Mp;                       // [E][Np]
+    double* gv = av + (size_t)E * Np;                        // [E][Np]
+    double* cv = gv + (size_t)E * Np;                        // [E][Mp]
+    double* sums = cv + (size_t)E * Mp;                      // [E][3] + logdet [E]
+    double* part_uf = s.Tscr.p;
+    double* part_uu = part_uf + (size_t)E * Mp * (2 * FT_MAXD + 1);
+    // everything between the upload of Z and the downloads is a fixed launch sequence (~80 launches at M = 200): one graph
+    std::vector<unsigned long long> key;
+    for (const DevBuf* b : {&s.K, &s.Linv, &s.invD, &s.Kmn, &s.V2, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.ksplit_ws, &s.iK, &s.G, &s.Tscr, &s.ft_P,
+                            &s.ft_T3, &s.ft_Z, &s.vec, &s.Xt})
+        key.push_back((unsigned long long)(uintptr_t)b->p);
+    for (const void* q : {(const void*)o_ls, (const void*)o_var, (const void*)o_noise, (const void*)o_Yt, (const void*)ctx->d_info})
+        key.push_back((unsigned long long)(uintptr_t)q);
+    for (int v : {E, M, Mp, N, Np, D, want_grad ? 1 : 0}) key.push_back((unsigned long long)v);
+    auto chain = [&]() -> int {
+    for (int e = 0; e < E; ++e) launch_transpose_points(st, Zraw + (size_t)e * M * D, M, D, Zt + (size_t)e * D * Mp, Mp);
+    HIPCHK(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * 64, st));
     launch_gram(st, Zt, Mp, M, Zt, Mp, M, D, o_ls, o_var, E, Kuu, Mp, Mp, 2, nullptr, 1e-6, sZ, sZ);
     launch_gram(st, Zt, Mp, M, s.Xt.p, Np, N, D, o_ls, o_var, E, s.Kmn.p, Mp, Np, 0, nullptr, 0.0, sZ, 0);
     launch_potrf(st, Kuu, Mp, E, s.invD.p, ctx->d_info);
@@ -242,17 +260,9 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     g.C = s.iAt.p; g.ldc = Mp; g.sC = (long)mm;
     g.M = Mp; g.N = Mp; g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.k_mode = 4;
     launch_gemm(st, g, false, false, E);
-    double* r0 = s.vec.p;                                    // [E][Mp]  Vb (y / G)
-    double* gam = r0 + (size_t)E * Mp;                       // [E][Mp]  AmInv r0 = gamma sn   (gamma = L^-1 U ytil)
-    double* av = gam + (size_t)E * Mp;                       // [E][Np]
-    double* gv = av + (size_t)E * Np;                        // [E][Np]
-    double* cv = gv + (size_t)E * Np;                        // [E][Mp]
-    double* sums = cv + (size_t)E * Mp;                      // [E][3] + logdet [E]
     launch_fitc_rhs(st, V, s.G.p, o_Yt, Mp, Np, E, r0);
     launch_matvec(st, s.AmInv.p, Mp, E, r0, gam, false);
     launch_logdet(st, s.Am.p, Mp, M, E, sums + 3 * E);
-    const bool want_grad = grad_hyp || grad_Z;
-    std::vector<double> hz;
     if (want_grad) {
         g = GemmDesc{};                                      // P = L^-1 U = AmInv Vb
         g.A = s.AmInv.p; g.lda = Mp; g.sA = (long)mm;
@@ -283,18 +293,22 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
         g.M = Mp; g.N = Mp; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
         g.ksplit = FITC_KSPLIT; g.split_ws = s.ksplit_ws.p;
         launch_gemm(st, g, false, true, E);
-        double* part_uf = s.Tscr.p;
-        double* part_uu = part_uf + (size_t)E * Mp * (2 * FT_MAXD + 1);
         launch_fitc_kgrad(D, dim3(M, E), st, (const double*)s.ft_T3.p, Np, (const double*)Zt, Mp, (const double*)s.Xt.p, Np, 0L, N, D,
                           o_ls, o_var, (const double*)nullptr, 0.0, part_uf);
         launch_fitc_kgrad(D, dim3(M, E), st, (const double*)s.iK.p, Mp, (const double*)Zt, Mp, (const double*)Zt, Mp, sZ, M, D, o_ls,
                           o_var, (const double*)cv, -0.5, part_uu);
-        hz.resize((size_t)2 * E * Mp * (2 * FT_MAXD + 1));
-        HIPCHK(hipMemcpyAsync(hz.data(), part_uf, sizeof(double) * hz.size(), hipMemcpyDeviceToHost, st));
     } else {
         HIPCHK(hipMemsetAsync(gv, 0, sizeof(double) * (size_t)E * Np, st));
     }
     hipLaunchKernelGGL(k_fitc_sums, dim3(E), dim3(256), 0, st, o_Yt, s.G.p, gv, N, Np, sums);
+    return PILCO_OK;
+    };
+    if (int r = run_chain_graph(ctx, s.g_fitc_nlml, key, chain)) return r;
+    std::vector<double> hz;
+    if (want_grad) {
+        hz.resize((size_t)2 * E * Mp * (2 * FT_MAXD + 1));
+        HIPCHK(hipMemcpyAsync(hz.data(), part_uf, sizeof(double) * hz.size(), hipMemcpyDeviceToHost, st));
+    }
     std::vector<double> hs(4 * (size_t)E), hg((size_t)E * Mp), hn(E);
     int info[64];
     HIPCHK(hipMemcpyAsync(hs.data(), sums, sizeof(double) * 4 * E, hipMemcpyDeviceToHost, st));
