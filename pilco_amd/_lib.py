@@ -180,6 +180,10 @@ class Context:
         # which Python model last pushed its data / hyper-parameters into each device slot: several MGPR / SMGPR /
         # RbfController instances may share one context, but a slot holds ONE model at a time (see MGPR._sync)
         self._slot_owner = {}
+        # runtime knobs set on this context (method name -> arguments): context_for copies them onto the pooled siblings of
+        # the default context; nranks / has_comm: a sharded context is never pooled
+        self._settings = {}
+        self.nranks, self.has_comm = 1, False
 
     def close(self):
         if getattr(self, "h", None):
@@ -207,27 +211,33 @@ class Context:
 
     def set_fused_step(self, on):
         self._chk(self.lib.pilco_set_fused_step(self.h, 1 if on else 0))
+        self._settings["set_fused_step"] = (on,)
 
     def set_grad_mode(self, mode):
         """1 (default): Jacobian tape; 0: plain tape + per-step device adjoint (include/pilco_hip.h)."""
         self._chk(self.lib.pilco_set_grad_mode(self.h, int(mode)))
+        self._settings["set_grad_mode"] = (mode,)
 
     def use_graph(self, on):
         self._chk(self.lib.pilco_set_use_graph(self.h, 1 if on else 0))
+        self._settings["use_graph"] = (on,)
 
     def set_inline_policy(self, on):
         """1 (default): small RbfControllers are evaluated inside the step's serial link; 0: own launches (include/pilco_hip.h)."""
         self._chk(self.lib.pilco_set_inline_policy(self.h, 1 if on else 0))
+        self._settings["set_inline_policy"] = (on,)
 
     def set_rollout_mode(self, mode):
         """0 (default): the launch sequence (hipGraph replay); 1: plain rollouts as ONE persistent launch (include/pilco_hip.h)."""
         self._chk(self.lib.pilco_set_rollout_mode(self.h, int(mode)))
+        self._settings["set_rollout_mode"] = (mode,)
 
     def last_rollout_mode(self):
         return int(self.lib.pilco_last_rollout_mode(self.h))
 
     def set_pair_kernel(self, variant):
         self._chk(self.lib.pilco_set_pair_kernel(self.h, int(variant)))
+        self._settings["set_pair_kernel"] = (variant,)
 
     def gp_set_data(self, slot, X, Y, owner=None):
         self._slot_owner[slot] = owner     # a direct caller (owner None) invalidates whatever a model believed about the slot
@@ -541,6 +551,7 @@ class Context:
     def comm_init(self, id_bytes, rank, nranks):
         buf = C.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
         self._chk(self.lib.pilco_comm_init(self.h, buf, int(rank), int(nranks)))
+        self.nranks, self.has_comm = int(nranks), True
 
     def shard_pack(self, slot, m, s, D, E, nranks, rank):
         plan = shard_plan(E, D, nranks, rank)
@@ -560,6 +571,7 @@ class Context:
 
     def shard_set(self, rank, nranks):
         self._chk(self.lib.pilco_shard_set(self.h, int(rank), int(nranks)))
+        self.nranks = int(nranks)
 
     # beta rows of a sharded factorisation over any host transport (ranks in different processes, no communicator)
     def beta_export(self, slot=0):
@@ -717,10 +729,23 @@ def resolve_ctx(obj):
     return owner.ctx if owner is not None else get_context()
 
 
+def context_adopted(ctx, owner):
+    """A PILCO object took `ctx` from one of its components: if it is a pooled context without a live holder, the object
+    becomes its holder (otherwise context_for would hand the same context to the next object as well)."""
+    import weakref
+    for ent in _ctx_pool:
+        if ent[0] is ctx and (ent[1] is None or ent[1]() is None):
+            ent[1] = weakref.ref(owner)
+
+
 def context_for(owner):
     import weakref
     d = get_context()
     if os.environ.get("PILCO_CTX_POOL", "1") == "0":
+        return d
+    # a sharded default context (several ranks, a communicator or a peer group) is THE context of this process: a pooled
+    # sibling would run the full unsharded model on every rank and ignore what was configured on the default one
+    if getattr(d, "nranks", 1) != 1 or getattr(d, "has_comm", False):
         return d
     if not _ctx_pool or _ctx_pool[0][0] is not d:
         _ctx_pool[:] = [[d, None]]
@@ -733,5 +758,7 @@ def context_for(owner):
         c = type(d)(device=getattr(d, "device", None))
     except TypeError:   # a stand-in installed by set_context() (tests) that takes no device
         c = type(d)()
+    for name, arg in getattr(d, "_settings", {}).items():   # what was configured on the default context applies to its siblings
+        getattr(c, name)(*arg)
     _ctx_pool.append([c, weakref.ref(owner)])
     return c

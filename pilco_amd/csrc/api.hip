@@ -206,6 +206,24 @@ static int gather_beta(pilco_ctx* ctx, Slot& s, const OwnView& o, int npad) {
     return PILCO_OK;
 }
 
+// A failed Cholesky on one rank must fail on EVERY rank of a communicator, before any of them enters the next collective
+// (the all-gather of beta / of the objective): otherwise the peers hang in it, or pair it with the failing rank's retry.
+// bad = the failing GLOBAL output index of this rank (-1: none); returns the largest index any rank reports (-1: none).
+int agree_not_pd(pilco_ctx* ctx, int W, int bad, int* agreed) {
+    *agreed = bad;
+    if (W <= 1 || !ctx->comm) return PILCO_OK;
+    int* d = ctx->d_info + 64;   // (words 0..63 belong to the factorisations' kernels)
+    const int mine = bad + 1;    // 0 = fine
+    HIPCHK(hipMemcpyAsync(d, &mine, sizeof(int), hipMemcpyHostToDevice, ctx->st));
+    ncclResult_t r = ncclAllReduce(d, d + 1, 1, ncclInt, ncclMax, ctx->comm, ctx->st);
+    if (r != ncclSuccess) return fail(ctx, PILCO_E_RCCL, std::string("ncclAllReduce(not positive definite): ") + ncclGetErrorString(r));
+    int all = 0;
+    HIPCHK(hipMemcpyAsync(&all, d + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    *agreed = all - 1;
+    return PILCO_OK;
+}
+
 // ---- exact GP: Gram -> Cholesky -> L^{-1} -> iK = L^{-T} L^{-1}, beta = L^{-T} (L^{-1} y), for the outputs this rank owns
 int factorize_exact(pilco_ctx* ctx, Slot& s) {
     OwnView o{};
@@ -252,13 +270,15 @@ int factorize_exact(pilco_ctx* ctx, Slot& s) {
     int info[64];
     HIPCHK(hipMemcpyAsync(info, ctx->d_info, sizeof(int) * std::min(ELa, 64), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    for (int al = 0; al < std::min(EL, 64); ++al)
-        if (info[al] != 0) {
-            const int a = al * o.W + o.rank;
-            ctx->not_pd = a;
-            return fail(ctx, PILCO_E_NOT_PD, "Cholesky failed: K + noise*I of output " + std::to_string(a) +
-                                                 " is not positive definite (pivot " + std::to_string(info[al]) + ")");
-        }
+    int bad = -1, pivot = 0, agreed = -1;
+    for (int al = 0; al < std::min(EL, 64) && bad < 0; ++al)
+        if (info[al] != 0) bad = al * o.W + o.rank, pivot = info[al];
+    if (int r = agree_not_pd(ctx, o.W, bad, &agreed)) return r;
+    if (agreed >= 0) {   // the same output named, the same error raised on every rank
+        ctx->not_pd = agreed;
+        return fail(ctx, PILCO_E_NOT_PD, "Cholesky failed: K + noise*I of output " + std::to_string(agreed) + " is not positive definite" +
+                                             (agreed == bad ? " (pivot " + std::to_string(pivot) + ")" : std::string(" (on another rank)")));
+    }
     s.n = s.N;
     s.npad = npad;
     s.iK_null = false;
@@ -281,7 +301,7 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
     ctx->device = device;
     ctx->slot[PILCO_SLOT_POLICY].ignore_iK = true;
     if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&ctx->d_info, 64 * sizeof(int)) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
+        hipMalloc(&ctx->d_info, 72 * sizeof(int)) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
         hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
         return PILCO_E_HIP;
@@ -859,6 +879,12 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     if (EL == 0) {
         HIPCHK(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * 64, st));
         if (o.W > 1) HIPCHK(hipMemsetAsync(s.beta.p, 0, sizeof(double) * (size_t)o.W * o.ELcap * Mp, st));
+        int agreed0 = -1;
+        if (int r = agree_not_pd(ctx, o.W, -1, &agreed0)) return r;   // (a rank without outputs still takes part in the agreement)
+        if (agreed0 >= 0) {
+            ctx->not_pd = agreed0;
+            return fail(ctx, PILCO_E_NOT_PD, "FITC Cholesky failed for output " + std::to_string(agreed0));
+        }
         s.n = s.M;
         s.iK_null = false;
         return gather_beta(ctx, s, o, Mp);
@@ -933,12 +959,14 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     int info[64];
     HIPCHK(hipMemcpyAsync(info, ctx->d_info, sizeof(int) * 64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    for (int al = 0; al < std::min(EL, 32); ++al)
-        if (info[al] != 0 || info[32 + al] != 0) {
-            const int a = al * o.W + o.rank;
-            ctx->not_pd = a;
-            return fail(ctx, PILCO_E_NOT_PD, "FITC Cholesky failed for output " + std::to_string(a));
-        }
+    int bad = -1, agreed = -1;
+    for (int al = 0; al < std::min(EL, 32) && bad < 0; ++al)
+        if (info[al] != 0 || info[32 + al] != 0) bad = al * o.W + o.rank;
+    if (int r = agree_not_pd(ctx, o.W, bad, &agreed)) return r;
+    if (agreed >= 0) {
+        ctx->not_pd = agreed;
+        return fail(ctx, PILCO_E_NOT_PD, "FITC Cholesky failed for output " + std::to_string(agreed));
+    }
     s.n = s.M;
     s.iK_null = false;
     return gather_beta(ctx, s, o, Mp);

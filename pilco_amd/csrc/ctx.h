@@ -160,6 +160,7 @@ struct pilco_ctx {
 };
 
 int fail(pilco_ctx* c, int code, const std::string& msg);
+int agree_not_pd(pilco_ctx* ctx, int W, int bad, int* agreed);   // api.hip: a not-positive-definite failure made collective
 
 #define HIPCHK(call)                                                                                       \
     do {                                                                                                   \

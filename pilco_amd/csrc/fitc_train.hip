@@ -378,10 +378,17 @@ extern "C" int pilco_gp_fitc_nlml(pilco_ctx* ctx, int slot, const double* Z_all,
     }
     std::vector<double> Zo((size_t)std::max(EL, 1) * M * D), no(std::max(EL, 1)), gho((size_t)std::max(EL, 1) * (D + 2)), gzo((size_t)std::max(EL, 1) * M * D);
     for (int al = 0; al < EL; ++al) memcpy(&Zo[(size_t)al * M * D], Z_all + (size_t)(al * W + rank) * M * D, sizeof(double) * M * D);
+    int bad = -1, agreed = -1;
     if (EL > 0) {
         const int r = fitc_nlml_batch(ctx, s, EL, o.ls, o.var, o.noise, o.Yt, Zo.data(), M, no.data(), grad_hyp ? gho.data() : nullptr, grad_Z ? gzo.data() : nullptr);
-        if (r == PILCO_E_NOT_PD && ctx->not_pd >= 0) ctx->not_pd = ctx->not_pd * W + rank;   // local -> global output index
-        if (r) return r;
+        if (r == PILCO_E_NOT_PD && ctx->not_pd >= 0) bad = ctx->not_pd = ctx->not_pd * W + rank;   // local -> global output index
+        else if (r) return r;
+    }
+    // the failure of one rank's output is every rank's failure, agreed on BEFORE the all-gather below (the peers would wait in it)
+    if (int r = agree_not_pd(ctx, W, bad, &agreed)) return r;
+    if (agreed >= 0) {
+        ctx->not_pd = agreed;
+        return fail(ctx, PILCO_E_NOT_PD, "FITC objective: Cholesky failed for output " + std::to_string(agreed));
     }
     std::vector<double> own((size_t)o.ELcap * per, 0.0);
     for (int al = 0; al < EL; ++al) {

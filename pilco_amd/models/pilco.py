@@ -55,10 +55,13 @@ class PILCO:
         if self._ctx is None:
             # a component that already lives on a context decides; otherwise a context of this object's own: the default one
             # for the first live PILCO object, a pooled one for every further (_lib.context_for)
-            comps = [c for c in (self.mgpr, self.controller, getattr(self.controller, "_gp", None), self.reward) if c is not None]
+            # (only the components that hold device slots decide -- the models, the controller and its GP; a stateless
+            # reward object reused by several PILCO objects must not pull them all onto one context)
+            comps = [c for c in (self.mgpr, self.controller, getattr(self.controller, "_gp", None)) if c is not None]
             for comp in comps:
                 if getattr(comp, "_ctx", None) is not None:
                     self._ctx = comp._ctx
+                    _lib.context_adopted(self._ctx, self)   # ... and this object is now that context's holder in the pool
                     break
             if self._ctx is None:
                 for comp in comps:   # a component that belongs to another live PILCO object (a shared controller): one context for both

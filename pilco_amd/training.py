@@ -203,6 +203,16 @@ def _as_mask(flag, E):
     return np.full(E, bool(flag)) if np.ndim(flag) == 0 else np.asarray(flag, bool)
 
 
+def _require_complete(values, what):
+    """A context sharded by output evaluates only the outputs it owns; without a communicator the others come back NaN and
+    the ranks have to be combined by the caller (pilco_amd._lib.group_nlml / group_fitc_nlml).  Feeding NaN losses and
+    gradients to L-BFGS-B instead would fail silently, so the optimiser entry points refuse."""
+    if not np.all(np.isfinite(values)):
+        raise RuntimeError("%s.optimize: the training objective came back incomplete (NaN for outputs another rank owns): this "
+                           "context is sharded by output and has no communicator -- attach one (Context.comm_init) or train on an "
+                           "unsharded context" % what)
+
+
 def mgpr_objective(mgpr, u, noise_trainable=True, ls_trainable=True, var_trainable=True):
     """Per-output GPflow training loss and its gradient in the unconstrained space.  The *_trainable arguments are
     per-output masks (or one bool for all): a parameter outside an output's trainable set keeps its value (zero gradient
@@ -217,9 +227,12 @@ def mgpr_objective(mgpr, u, noise_trainable=True, ls_trainable=True, var_trainab
             m.likelihood.variance.assign(nz[i])
     mgpr._sync()
     nlml, g = mgpr.ctx.gp_nlml(mgpr._slot, D, E)
+    _require_complete(nlml, "MGPR")
     lp_l, dlp_l = _gamma_logpdf_and_grad(ls, 1.1, 0.1)          # mgpr.py:33
     lp_v, dlp_v = _gamma_logpdf_and_grad(var, 1.5, 0.5)         # mgpr.py:34
-    per_output = nlml - lp_l.sum(1) - lp_v
+    # GPflow's training_loss adds log_prior_density of the TRAINABLE parameters only: a frozen parameter's prior is not in
+    # the loss (a constant there, but it would shift scipy's relative ftol test and the reported value)
+    per_output = nlml - (lp_l * tl[:, None]).sum(1) - lp_v * tv
     g_ls = (g[:, :D] - dlp_l) * _dsoftplus(u[:E * D]).reshape(E, D) * tl[:, None]
     g_var = (g[:, D] - dlp_v) * _dsoftplus(u[E * D:E * D + E]) * tv
     g_nz = g[:, D + 1] * _dsoftplus(u[E * D + E:]) * tn
@@ -310,6 +323,7 @@ def smgpr_objective(smgpr, u, noise_trainable=True, ls_trainable=True, var_train
             m.likelihood.variance.assign(nz[i])
     smgpr._sync()
     nlml, gh, gz = smgpr.ctx.gp_fitc_nlml(smgpr._slot, Z, D, E)
+    _require_complete(nlml, "SMGPR")
     g_ls = gh[:, :D] * _dsoftplus(u[:E * D]).reshape(E, D) * tl[:, None]
     g_var = gh[:, D] * _dsoftplus(u[E * D:E * D + E]) * tv
     g_nz = gh[:, D + 1] * _dsoftplus(u[E * D + E:nk]) * tn

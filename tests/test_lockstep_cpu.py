@@ -203,3 +203,79 @@ def test_two_live_pilco_objects_get_a_context_each_and_a_dead_ones_context_is_ha
         assert q2.ctx is q1.ctx and shared.ctx is q1.ctx
     finally:
         _lib.set_context(saved)
+
+
+def test_a_shared_reward_does_not_merge_contexts_and_a_sharded_default_context_is_never_pooled():
+    """Round-3 advice: (i) a stateless reward object reused by two live PILCO objects must not pull the second one onto the
+    first one's context; (ii) an object that adopts a pooled context through a component becomes that context's holder;
+    (iii) pooled siblings take over the runtime knobs set on the default context; (iv) a default context that is sharded
+    (several ranks / a communicator) is the one context of its process."""
+    from helpers.cpu_rollout_context import CpuRolloutContext
+    from pilco_amd import _lib
+    from pilco_amd.controllers import LinearController
+    from pilco_amd.models import PILCO
+    from pilco_amd.rewards import ExponentialReward
+
+    class Knobs(CpuRolloutContext):
+        def __init__(self, device=None):
+            super().__init__()
+            self.device, self._settings, self.got = device, {}, {}
+
+        def set_pair_kernel(self, v):
+            self._settings["set_pair_kernel"] = (v,)
+            self.got["pair"] = v
+
+    saved = _lib._default_ctx
+    try:
+        d = Knobs()
+        d.set_pair_kernel(2)
+        _lib.set_context(d)
+        rng = np.random.default_rng(1)
+        data = (rng.standard_normal((12, 3)), rng.standard_normal((12, 2)))
+        rew = ExponentialReward(2)
+        p1 = PILCO(data, horizon=2, reward=rew)
+        p2 = PILCO(data, horizon=2, reward=rew)
+        assert p1.ctx is d and p2.ctx is not d                       # (i)
+        assert p2.ctx.got.get("pair") == 2                           # (iii)
+        c2 = p2.ctx
+        ctl = LinearController(2, 1, ctx=c2)
+        del p2
+        import gc
+        gc.collect()
+        p3 = PILCO(data, horizon=2, controller=ctl)                  # adopts c2 through its controller ...
+        assert p3.ctx is c2
+        p4 = PILCO(data, horizon=2)
+        assert p4.ctx is not c2 and p4.ctx is not d                  # (ii) ... so c2 is not handed out a second time
+        d.nranks = 2                                                 # (iv)
+        assert PILCO(data, horizon=2).ctx is d
+    finally:
+        _lib.set_context(saved)
+
+
+def test_an_incomplete_training_objective_is_refused_and_frozen_parameters_carry_no_prior():
+    """Round-3 advice: a context sharded by output without a communicator returns NaN for the outputs it does not own; the
+    optimiser entry point must raise instead of feeding NaN to L-BFGS-B.  And GPflow's loss holds the log-priors of the
+    TRAINABLE parameters only."""
+    import pytest
+    from helpers.cpu_objective_context import CpuObjectiveContext
+    from pilco_amd import training
+    from pilco_amd.models import MGPR
+
+    class Sharded(CpuObjectiveContext):
+        def gp_nlml(self, slot, D, E, want_grad=True):
+            nlml, grad = super().gp_nlml(slot, D, E, want_grad)
+            nlml[1::2] = np.nan
+            grad[1::2] = np.nan
+            return nlml, grad
+
+    rng = np.random.default_rng(3)
+    X, Y = rng.standard_normal((20, 2)), rng.standard_normal((20, 2))
+    with pytest.raises(RuntimeError, match="communicator"):
+        MGPR((X, Y), ctx=Sharded()).optimize(restarts=0)
+    m = MGPR((X, Y), ctx=CpuObjectiveContext())
+    u = training._mgpr_pack(m)
+    full, _ = training.mgpr_objective(m, u)
+    no_ls, g = training.mgpr_objective(m, u, ls_trainable=[False, True])
+    lp_l, _ = training._gamma_logpdf_and_grad(np.asarray(m.lengthscales), 1.1, 0.1)
+    np.testing.assert_allclose(no_ls - full, [lp_l[0].sum(), 0.0], atol=1e-12)
+    assert np.all(g[:2] == 0.0) and np.all(g[2:4] != 0.0)
