@@ -53,6 +53,11 @@ int pilco_set_pair_kernel(pilco_ctx* ctx, int variant);
  * workgroup of step t+1's operand kernel, two launches per horizon step.  0: separate link kernel, three launches per
  * step (always used with more than one rank unless the peer exchange is attached).  Both produce bitwise identical results. */
 int pilco_set_fused_step(pilco_ctx* ctx, int on);
+/* Models of at most 256 points (every example of the reference; the inducing points of a sparse model: smgpr.py:47-52): 1
+ * (default; PILCO_SMALL_STEP=0 in the environment starts with 0) = with the fused step, the operand launch's pair workgroups
+ * also evaluate their pair sums, so a horizon step is ONE launch; 0 = the pair sums keep their own launch.  Same arithmetic
+ * per element; the two split the sums differently, so results agree to rounding and each is bitwise repeatable. */
+int pilco_set_small_step(pilco_ctx* ctx, int on);
 /* How pilco_rollout_grad / pilco_rollout_grad_rbf obtain the moment-matching adjoint: 1 (default) = Jacobian tape -- the
  * forward rollout runs the reverse sweep in place of the forward pair kernel, so that ONE O(N^2) pass per step yields the
  * step's value and its Jacobian, and the reverse sweep is host algebra on the downloaded records; 0 = plain tape, then the

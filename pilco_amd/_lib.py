@@ -59,6 +59,7 @@ SIGNATURES = {
     "pilco_selftest": (C.c_int, [_vp]),
     "pilco_set_fused_step": (C.c_int, [_vp, C.c_int]),
     "pilco_set_grad_mode": (C.c_int, [_vp, C.c_int]),
+    "pilco_set_small_step": (C.c_int, [_vp, C.c_int]),
     "pilco_set_use_graph": (C.c_int, [_vp, C.c_int]),
     "pilco_set_rollout_mode": (C.c_int, [_vp, C.c_int]),
     "pilco_set_inline_policy": (C.c_int, [_vp, C.c_int]),
@@ -212,6 +213,11 @@ class Context:
     def set_fused_step(self, on):
         self._chk(self.lib.pilco_set_fused_step(self.h, 1 if on else 0))
         self._settings["set_fused_step"] = (on,)
+
+    def set_small_step(self, on):
+        """1 (default): models of at most 256 points run a horizon step as ONE launch (include/pilco_hip.h)."""
+        self._chk(self.lib.pilco_set_small_step(self.h, 1 if on else 0))
+        self._settings["set_small_step"] = (on,)
 
     def set_grad_mode(self, mode):
         """1 (default): Jacobian tape; 0: plain tape + per-step device adjoint (include/pilco_hip.h)."""

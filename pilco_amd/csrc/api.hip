@@ -86,6 +86,8 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     const size_t n_small = (size_t)PLa + (size_t)E * wk.NCHM * (1 + D);
     ENSURE(s.w_small, 2 * n_small);
     ENSURE(s.w_part, std::max((size_t)PLa * wk.NT * 2, (size_t)std::max(wk.sk_pls, 16) * std::max(wk.sk_maxw, 4)));
+    ENSURE(s.w_fpart, (size_t)2 * PLa * wk.NCH * 2);
+    wk.fuse_pair = 0;
     ENSURE(s.w_gath, (size_t)W * wk.SEG);
     ENSURE(s.w_out, (size_t)E + E * E + D * E);
     wk.in_m = s.w_in.p;
@@ -320,6 +322,7 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
     if (const char* ep = getenv("PILCO_PERSIST")) ctx->persist = (atoi(ep) != 0) ? 1 : 0;
     if (const char* ei = getenv("PILCO_INLINE_POLICY")) ctx->inline_policy = (atoi(ei) != 0);
     if (const char* ef = getenv("PILCO_FUSED")) ctx->fused = (atoi(ef) != 0);
+    if (const char* ef = getenv("PILCO_SMALL_STEP")) ctx->fuse_small = (atoi(ef) != 0);
     const char* env = getenv("PILCO_PAIR_KERNEL");
     if (env) ctx->variant = (atoi(env) >= 0 && atoi(env) <= 2) ? atoi(env) : 0;
     *out = ctx;
@@ -339,7 +342,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
         for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr, &s.ksplit_ws,
-                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.jac_rowmom, &s.jac_cpart, &s.jac_head, &s.jac_part, &s.jac_np, &s.own, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small,
+                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.jac_rowmom, &s.jac_cpart, &s.jac_head, &s.jac_part, &s.jac_np, &s.own, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small, &s.w_fpart,
                           &s.w_part, &s.w_gath, &s.w_out, &s.ft_P, &s.ft_T3, &s.ft_Z, &s.p_At, &s.p_Bt, &s.p_small, &s.p_part, &s.p_flags})
             b->release();
     }
@@ -377,6 +380,12 @@ int pilco_set_pair_kernel(pilco_ctx* ctx, int variant) {
 int pilco_set_fused_step(pilco_ctx* ctx, int on) {
     if (!ctx) return PILCO_E_SHAPE;
     ctx->fused = (on != 0);
+    return PILCO_OK;
+}
+
+int pilco_set_small_step(pilco_ctx* ctx, int on) {
+    if (!ctx) return PILCO_E_SHAPE;
+    ctx->fuse_small = (on != 0);
     return PILCO_OK;
 }
 

@@ -45,6 +45,7 @@ struct Slot {
     bool beta_complete = true;                      // false until the other ranks' beta rows have arrived
     // moment-matching workspace
     DevBuf w_in, w_At, w_Bt, w_small, w_part, w_gath, w_out;
+    DevBuf w_fpart;   // one-launch step of small models: [2][PL][NCH][2] pair partials (the head reads one copy, writes the other)
     MMWork wk{};
     double* alt_isdet = nullptr;   // second copies of pair_isdet / mean_part: the fused head reads one set (previous step)
     double* alt_mean = nullptr;    // while its prep part writes the other
@@ -141,6 +142,7 @@ struct pilco_ctx {
     unsigned long long persist_epoch = 0;
     bool inline_policy = true;   // an RbfController small enough is evaluated inside the link (2 launches per step instead of 4)
     bool fused = true;   // fused head: the serial link of step t runs inside the prep launch of step t+1 (2 launches per step)
+    bool fuse_small = true;   // ... and, for models of at most 256 points, the pair sums too: ONE launch per step (prep_device.h)
     bool graph_rccl_failed = false;
     int grad_mode = 1;   // pilco_rollout_grad*: 1 = Jacobian tape (one O(N^2) sweep per step), 0 = tape + per-step device adjoint
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

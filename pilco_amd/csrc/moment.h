@@ -52,6 +52,7 @@ struct MMWork {
     unsigned long long* dbg;  // optional [32] phase timestamps (100 MHz wall clock) of the last prep / glue launch
     int abl;             // experiment switches (PILCO_ABL, tools only; 0 in product use)
     int sk_ud, sk_uo;    // cost units of a diagonal / off-diagonal column step (diagonal steps also stream iK)
+    int fuse_pair;       // small models: the operand launch's pair workgroups also evaluate their pair sums (pair_part [PL][NCH][2]); no pair launch
     const double* exp_tab;    // [n] 2^(j/n), n = mm_exp_table_size(), for the table-driven fp64 exp of the pair kernel
     int PL, EL, P, KP, NCH, NCHM, NT, SEG, OUTOFF, rank, nranks;  // NCH / NCHM: row chunks of the pair / mean-part prep workgroups; OUTOFF: offset of the output records inside a segment
 };
@@ -190,8 +191,9 @@ size_t glue_lds_bytes(int E, int D);
 // tile-partial counts per pair for a variant (NT) and the number of row chunks of the prep kernel
 int mm_pair_nt(int npad, int variant, int PL);
 void mm_prep_chunks(int npad, int PL, int EL, int* nch, int* nchm);
-int mm_kp(int D);
-bool mm_vsep(int D);   // the contraction stops at K = D + 1 and v_j is added after it (saves a whole MFMA k-step)
+// the contraction stops at K = D + 1 and v_j is added after it when D + 2 = 1 (mod 4) (saves a whole MFMA k-step)
+__host__ __device__ constexpr bool mm_vsep(int D) { return (D + 2) % 4 == 1; }
+__host__ __device__ constexpr int mm_kp(int D) { return mm_vsep(D) ? D + 1 : (D + 2 + 3) / 4 * 4; }
 void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot);
 // reverse pass of one moment-matching step (single rank, D <= 32; the step's prep kernel must precede it on st):
 // scratch: rowmom [P][njs][16 ceil((D + 1) / 16)][npad], cpart [P - E][nrb][npad] (njs, nrb from mm_bwd_geometry) and

@@ -9,8 +9,6 @@ size_t prep_lds_bytes(int DT) {
     return sizeof(double) * std::max(pair_blk, mean_blk);
 }
 
-bool mm_vsep(int D) { return (D + 2) % 4 == 1; }
-int mm_kp(int D) { return mm_vsep(D) ? D + 1 : round_up(D + 2, 4); }
 
 static int device_cus() {
     int cus = 256;

@@ -2,6 +2,7 @@
 // (prep.hip) and the persistent whole-rollout kernel (persist.hip).  Internal; gfx950 only.
 #pragma once
 #include "glue_device.h"
+#include "pair_device.h"
 
 namespace pilco {
 
@@ -159,7 +160,7 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
 // mean part of one (local output, row chunk), or the reward -- selected by the item coordinates (bx, by) of a gx x gy item
 // grid (k_mm_prep: its own block index; the persistent rollout kernel: a fixed item per workgroup).  NTHR: threads of
 // the host workgroup; the work is laid out for 512, wider workgroups keep their extra waves idle between the barriers.
-template <int DT, bool FUSED, int NTHR>
+template <int DT, bool FUSED, int NTHR, bool FPAIR = false>
 __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, const PrepReward& pr, const GlueArgs& g, const GlueLds& L,
                                           double* sm_all, int glue_doubles, int bx, int by, int gx, int gy, double pre_la, double pre_lb,
                                           double pre_var) {
@@ -240,12 +241,16 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
     // operand (w | 1 | v).  A diagonal pair (a == b) is not special here: its mean part runs in prep_mean_block.
     const int side = grp;
     constexpr int LDZ = DT | 1;   // odd row stride: conflict-free LDS rows
+    // (one-launch step of small models, below: the workgroup needs the column operand of ALL points -- the stage holds
+    // points 0..255 = all of them, side 1 takes one point per thread, side 0 its rows of the chunk)
+    const bool fpair = FPAIR && wk.fuse_pair;
+    const int st_begin = fpair ? 0 : i_begin, st_end = fpair ? npad : i_end;
     if (w != 0 && act) {
         const int idx = (w - 1) * 64 + lane;   // 0..447
         for (int e = idx; e < 256 * D; e += 448) {
             const int d = e >> 8, r = e & 255;
-            const int i = i_begin + r;
-            zst[r * LDZ + d] = (i < md.n && i < i_end) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
+            const int i = st_begin + r;
+            zst[r * LDZ + d] = (i < md.n && i < st_end) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
         }
     }
     const double logvar = log(pre_var);
@@ -327,11 +332,12 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
         }
     };
     if (!MM_ABL(wk, 4) && act) {
-        if (i_begin + tl < i_end) {   // first row of this thread: centred point from the LDS stage
-            const int i = i_begin + tl;
+        const int r_begin = (fpair && side) ? 0 : i_begin, r_end = (fpair && side) ? npad : i_end;   // this side's points
+        if (r_begin + tl < r_end) {   // first row of this thread: centred point from the LDS stage
+            const int i = r_begin + tl;
             double zeta[DT];
 #pragma unroll
-            for (int d = 0; d < DT; ++d) zeta[d] = (d < D) ? zst[tl * LDZ + d] : 0.0;
+            for (int d = 0; d < DT; ++d) zeta[d] = (d < D) ? zst[(i - st_begin) * LDZ + d] : 0.0;
             row(i, i < md.n, zeta);
         }
         for (int i = i_begin + tl + 256; i < i_end; i += 256) {   // chunks longer than 256 rows
@@ -343,6 +349,46 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
         }
     }
     DBG_STAMP(wk, 3, dbg0);
+    // Small models (npad <= 256: BASELINE configs 4 and 5, every reference example): the pair sums of this workgroup's rows
+    // follow right here instead of in a launch of their own -- the step is ONE launch.  At npad = 256 a pair's sums are 1 us
+    // of the chip's fp64 pipe; as a second launch they cost 9.5 us (launch boundary, stream-K bookkeeping, first-touch
+    // misses).  The workgroup holds rows [i_begin, i_end) of the row operand (side 0 wrote them) and -- side 1 has one
+    // thread per point -- ALL npad columns of the column operand (every row chunk of the pair computes them: the same
+    // values to the same addresses), so after a barrier its eight waves evaluate the (rows) x (all columns) block with
+    // pair_wave, the arithmetic of the pair kernels, and publish ONE partial in the tile-partial layout the link packs.
+    if (fpair) {   // (compiled into the single-rank fused heads only)
+        constexpr int KCP = mm_kp(DT) / 4;
+        constexpr bool VSP = mm_vsep(DT);
+        __syncthreads();   // the operands (write-through stores) are visible to the whole workgroup; zst is free
+        double* tab = zst;
+        double* wred = zst + FEXP_TN;   // [8]
+        for (int e = t; e < FEXP_TN; e += NTHR) tab[e] = wk.exp_tab[e];
+        __syncthreads();
+        int a, b;
+        local_pair_ab(wk, md.E, pl, a, b);
+        const bool diag = (a == b) && (md.iK != nullptr);
+        const int nrg = rpc / (16 * PAIR_RT), ncs = max(1, 8 / nrg);   // row groups of 32 rows x column splits = waves at work
+        double val = 0.0;
+        if (act && w < nrg * ncs) {
+            const int rg = w / ncs, cq = w - rg * ncs, ct = npad / 16;
+            const int i0 = i_begin + 16 * PAIR_RT * rg, jb = 16 * (ct * cq / ncs), je = 16 * (ct * (cq + 1) / ncs);
+            const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
+            const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
+            if (diag)
+                val = pair_wave<KCP, true, VSP, true>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab,
+                                                       npad, i0, jb, je, lane);
+            else
+                val = pair_wave<KCP, false, VSP, true>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, nullptr, tab, npad, i0, jb, je, lane);
+            for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off);
+        }
+        if (act && lane == 0) wred[w] = val;
+        __syncthreads();
+        if (t == 0) {
+            double* out = wk.pair_part + ((long)pl * wk.NT + ch) * 2;
+            store_wt(out, ((wred[0] + wred[1]) + (wred[2] + wred[3])) + ((wred[4] + wred[5]) + (wred[6] + wred[7])));
+            store_wt(out + 1, 0.0);   // the trace term is already folded into out[0]
+        }
+    }
     DBG_STAMP(wk, 4, dbg0);
     if (wk.dbg && t == 0) wk.dbg[65 + 2 * (by * gx + bx)] = wall_clock64();
 }

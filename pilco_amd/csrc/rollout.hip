@@ -296,6 +296,19 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
         MMWork wkb[2] = {wk0, wk0};
         wkb[1].pair_isdet = s.alt_isdet;
         wkb[1].mean_part = s.alt_mean;
+        // Small models: the pair sums ride in the head launch (prep_device.h) -- one launch per step.  The head instantiated for
+        // this input dimension carries the pair arithmetic of ONE contraction depth (that of D = DT); the workgroup's rows must
+        // be whole 32-row groups and one thread per point must cover the columns.
+        const int dtk = s.D <= 4 ? 4 : s.D <= 6 ? 6 : s.D <= 8 ? 8 : s.D <= 10 ? 10 : s.D == 11 ? 11 : s.D <= 12 ? 12 : s.D <= 14 ? 14 : s.D <= 16 ? 16 : s.D <= 20 ? 20 : s.D <= 24 ? 24 : 32;
+        const bool small = ctx->fuse_small && !jac && ctx->variant == 0 && s.npad <= 256 && (s.npad / wk0.NCH) % 32 == 0 &&
+                           wk0.KP == mm_kp(dtk) && (wk0.vsep != 0) == mm_vsep(dtk) && !pair_ev && !MM_ABL(s.wk, 255);
+        if (small)
+            for (int k = 0; k < 2; ++k) {
+                wkb[k].fuse_pair = 1;
+                wkb[k].sk_waves = 0;           // the link packs tile partials: one per (pair, row chunk)
+                wkb[k].NT = wk0.NCH;
+                wkb[k].pair_part = s.w_fpart.p + (size_t)k * std::max(wk0.PL, 1) * wk0.NCH * 2;
+            }
         size_t evi = 0;
         for (int h = 0; h < H; ++h) {
             GlueArgs gh = g;
@@ -317,6 +330,7 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
                 pr.reward = g.reward;
             }
             launch_mm_prep(ctx->st, md, wkb[h & 1], rew ? &pr : nullptr, &gh);
+            if (small) continue;
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
             dyn_pairs(wkb[h & 1], h);
             if (pair_ev) HIPCHK(hipEventRecord((*pair_ev)[evi++], ctx->st));
@@ -688,7 +702,7 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
     const GlueArgs& g = plan.g;
     std::vector<unsigned long long> key = {
         (unsigned long long)H, (unsigned long long)g.pol_kind, (unsigned long long)g.n_rewards, (unsigned long long)g.squash,
-        (unsigned long long)ctx->variant, (unsigned long long)ctx->fused, (unsigned long long)(uintptr_t)plan.st[0], (unsigned long long)(uintptr_t)g.s1,
+        (unsigned long long)ctx->variant, (unsigned long long)ctx->fused + 2ull * (unsigned long long)ctx->fuse_small, (unsigned long long)(uintptr_t)plan.st[0], (unsigned long long)(uintptr_t)g.s1,
         (unsigned long long)(uintptr_t)g.traj, (unsigned long long)(uintptr_t)g.tape, (unsigned long long)(uintptr_t)g.W, (unsigned long long)(uintptr_t)g.maxact,
         (unsigned long long)(uintptr_t)s.w_part.p, (unsigned long long)(uintptr_t)s.w_At.p, (unsigned long long)(uintptr_t)s.w_Bt.p,
         (unsigned long long)(uintptr_t)s.w_small.p, (unsigned long long)(uintptr_t)s.w_gath.p, (unsigned long long)(uintptr_t)s.w_out.p,

@@ -376,6 +376,7 @@ def test_persistent_rollout_is_bitwise_identical_to_the_launch_sequence(N, D, E,
     rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(E), t=np.zeros(E))]
     cx = _lib.Context()
     try:
+        cx.set_small_step(0)   # (the one-launch step of small models splits the pair sums its own way: compared separately below)
         cx.gp_set_data(0, c["X"], c["Y"]); cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"]); cx.gp_factorize(0)
         # DIFFERENT initial states in consecutive launches: a read that comes too early, or from a stale cache line, returns
         # what the previous launch left in the same buffer -- with identical inputs that would be the right bits
@@ -479,17 +480,21 @@ def test_fused_head_is_bitwise_identical_to_the_three_kernel_step(ctx, D):
         if D > E:
             p.controller.W.assign(c["W"]); p.controller.b.assign(c["b"]); p.controller.max_action = 1.0
         out = []
-        for fused in (1, 0, 1):
-            ctx.set_fused_step(fused)
-            try:
-                out.append(p.predict_trajectory(c["m0"], c["S0"], H))
-            finally:
-                ctx.set_fused_step(1)
+        ctx.set_small_step(0)   # (the one-launch step of small models has its own test)
+        try:
+            for fused in (1, 0, 1):
+                ctx.set_fused_step(fused)
+                try:
+                    out.append(p.predict_trajectory(c["m0"], c["S0"], H))
+                finally:
+                    ctx.set_fused_step(1)
+            m1, s1 = p.propagate(c["m0"], c["S0"])
+        finally:
+            ctx.set_small_step(1)
         for a, b in zip(out[0], out[1]):
             assert np.array_equal(a, b)
         for a, b in zip(out[0], out[2]):
             assert np.array_equal(a, b)
-        m1, s1 = p.propagate(c["m0"], c["S0"])
         assert np.array_equal(m1[0], out[0][3][1, :E]) and np.array_equal(s1.ravel(), out[0][3][1, E:])
 
 
@@ -860,6 +865,7 @@ def test_sharded_rollout_group_of_contexts(E, U, nranks, sparse):
         cx = _lib.Context(device=0)
         made.append(cx)
         cx.set_pair_kernel(variant)
+        cx.set_small_step(0)   # (bit comparisons between launch structures below; the one-launch small step has its own test)
         if n > 1:
             cx.shard_set(rank, n)
         cx.gp_set_data(0, c["X"], c["Y"])
@@ -2129,3 +2135,46 @@ def test_two_live_pilco_objects_keep_their_models_on_the_device(golden_dir):
     # must NOT happen is a re-upload (gp_set_data / gp_set_hyp) in between
     assert p1.mgpr._data_dirty is False and p1.mgpr._hyp_dirty is False and p2.mgpr._hyp_dirty is False
     assert p1.ctx._slot_owner.get(_lib.SLOT_DYNAMICS) is p1.mgpr and p2.ctx._slot_owner.get(_lib.SLOT_DYNAMICS) is p2.mgpr
+
+
+@pytest.mark.parametrize("N,D,E,M", [(200, 10, 10, 0), (130, 5, 4, 0), (64, 3, 2, 0), (225, 11, 10, 0), (256, 12, 3, 0), (900, 10, 10, 200)])
+def test_one_launch_step_of_small_models_agrees_with_the_two_launch_step(N, D, E, M):
+    """Models of at most 256 points (or inducing points: smgpr.py:47-52) run a horizon step as ONE launch: the operand
+    launch's pair workgroups evaluate their pair sums themselves (pilco_set_small_step, default on).  Same arithmetic per
+    element as the pair kernel, another partition of the sums: every state of the trajectory and the reward agree with the
+    two-launch step to rounding, each path is bitwise repeatable, and the policy gradient (whose forward half is the
+    Jacobian tape's own sweep) does not depend on the switch."""
+    from pilco_amd import _lib
+    c = synthetic.config_c2(N=N, D=D, E=E)
+    U, H = D - E, 7
+    pol = (dict(kind=_lib.POLICY_LINEAR, state_dim=E, control_dim=U, W=c["W"], b=c["b"].ravel(), max_action=1.0, squash=True) if U > 0
+           else dict(kind=_lib.POLICY_NONE, state_dim=E, control_dim=0))
+    rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(E), t=np.zeros(E))]
+    cx = _lib.Context()
+    try:
+        cx.gp_set_data(0, c["X"], c["Y"]); cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"])
+        if M:
+            cx.gp_set_inducing(0, np.random.RandomState(3).randn(M, D))
+        cx.gp_factorize(0)
+        runs = {}
+        for on in (1, 0, 1):
+            cx.set_small_step(on)
+            a = cx.rollout(pol, rw, c["m0"], c["S0"], H, want_traj=True)
+            b = cx.rollout(pol, rw, c["m0"], c["S0"], H, want_traj=True)
+            for x, y in zip(a, b):
+                assert np.array_equal(np.asarray(x), np.asarray(y))          # bitwise repeatable
+            runs.setdefault(on, []).append(a)
+        for x, y in zip(runs[1][0], runs[1][1]):
+            assert np.array_equal(np.asarray(x), np.asarray(y))              # ... also after the other path ran in between
+        for x, y in zip(runs[1][0], runs[0][0]):
+            np.testing.assert_allclose(np.asarray(x), np.asarray(y), rtol=1e-10, atol=1e-13)
+        assert np.all(np.isfinite(runs[1][0][3]))
+        if U > 0 and D <= 14:
+            g1 = cx.rollout_grad(pol, rw, c["m0"], c["S0"], H)
+            cx.set_small_step(0)
+            g0 = cx.rollout_grad(pol, rw, c["m0"], c["S0"], H)
+            for x, y in zip(g1, g0):
+                assert np.array_equal(np.asarray(x), np.asarray(y))
+            np.testing.assert_allclose(g1[0], runs[1][0][2], rtol=1e-9)     # the tape's value is the rollout's reward
+    finally:
+        cx.close()

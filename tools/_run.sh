@@ -1,2 +1,2 @@
-python tools/fact_ab.py
+python tools/small_step_ab.py
 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -8
