@@ -4,9 +4,7 @@
 namespace pilco {
 
 size_t prep_lds_bytes(int DT) {
-    const size_t pair_blk = (size_t)4 * DT + 2 * (size_t)DT * DT + 4 + 256 * (size_t)(DT + 1);
-    const size_t mean_blk = (size_t)2 * DT + 2 * (size_t)DT * DT + 4 + 9 * (size_t)(DT + 1) + 2 * (size_t)DT + 512 * (size_t)(DT + 2);
-    return sizeof(double) * std::max(pair_blk, mean_blk);
+    return sizeof(double) * (prep_region_doubles(DT) + PREP_TAB_DOUBLES);   // + the exp table and the wave sums of the one-launch small step
 }
 
 

@@ -6,6 +6,13 @@
 
 namespace pilco {
 
+constexpr int PREP_TAB_DOUBLES = FEXP_TN + 8;   // LDS tail of the operand kernel: exp table + wave sums of the one-launch small step
+__host__ __device__ constexpr size_t prep_region_doubles(int DT) {   // the operand work's own LDS region (pair / mean workgroups), before that tail
+    const size_t pair_blk = (size_t)4 * DT + 2 * (size_t)DT * DT + 4 + 256 * (size_t)(DT + 1);
+    const size_t mean_blk = (size_t)2 * DT + 2 * (size_t)DT * DT + 4 + 9 * (size_t)(DT + 1) + 2 * (size_t)DT + 512 * (size_t)(DT + 2);
+    return pair_blk > mean_blk ? pair_blk : mean_blk;
+}
+
 // 512 threads per workgroup = the whole register file of one CU.  The 256 rows of the chunk are
 // handled twice in parallel: threads 0..255 ("group 0") build the row-side operand, threads
 // 256..511 ("group 1") the column-side operand; on a diagonal pair both operands are the same
@@ -359,11 +366,9 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
     if (fpair) {   // (compiled into the single-rank fused heads only)
         constexpr int KCP = mm_kp(DT) / 4;
         constexpr bool VSP = mm_vsep(DT);
-        __syncthreads();   // the operands (write-through stores) are visible to the whole workgroup; zst is free
-        double* tab = zst;
-        double* wred = zst + FEXP_TN;   // [8]
-        for (int e = t; e < FEXP_TN; e += NTHR) tab[e] = wk.exp_tab[e];
-        __syncthreads();
+        const double* tab = sm + prep_region_doubles(DT);   // loaded at the head of the kernel (k_mm_prep), long ago
+        double* wred = sm + prep_region_doubles(DT) + FEXP_TN;   // [8]
+        __syncthreads();   // the operands (write-through stores) are visible to the whole workgroup
         int a, b;
         local_pair_ab(wk, md.E, pl, a, b);
         const bool diag = (a == b) && (md.iK != nullptr);

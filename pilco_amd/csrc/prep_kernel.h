@@ -36,6 +36,10 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
         }
         pre_var = md.var[(threadIdx.x >> 8) ? b : a];
     }
+    if (FUSED && SR && PK != 1 && wk.fuse_pair && !spare_wg) {   // one-launch small step: the pair phase's exp table, on its way during the link
+        double* tabL = sm_all + glue_doubles + prep_region_doubles(DT);
+        for (int e = threadIdx.x; e < FEXP_TN; e += 512) tabL[e] = wk.exp_tab[e];
+    }
     if (FUSED) glue_body<PK, SR>(g, L, blockIdx.x == 0 && blockIdx.y == 0);
     prep_work<DT, FUSED, 512, FUSED && SR && PK != 1>(md, wk, pr, g, L, sm_all, glue_doubles, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, pre_la,
                               pre_lb, pre_var);
