@@ -44,12 +44,14 @@ namespace pilco {
 // The pair kernels do not need it (the compiler keeps 7 + p slots there); inside the persistent rollout kernel, under its
 // 168-register budget, the same source is scheduled with reads of destination pairs 2 and 3 one slot early
 // (tools/mfma_hazard_check.py, tests/test_build_isa.py), so that host asks for the fence.
-template <int KC, bool DIAG, bool VSEP, bool FENCE = false>
+// LDSOP (the one-launch step of small models, prep_device.h): the operands never went to memory -- At / Bt / vcol point into
+// the workgroup's LDS, At as [k][lda] over the workgroup's own rows (row i0 is its row i0l), Bt as [k][ldb] over all columns.
+template <int KC, bool DIAG, bool VSEP, bool FENCE = false, bool LDSOP = false>
 __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const double* __restrict__ Bt,
                                             const double* __restrict__ vcol,
                                             const double* __restrict__ beta_a, const double* __restrict__ beta_b,
                                             const double* __restrict__ iKa, const double* __restrict__ tab, int npad, int i0,
-                                            int jbeg, int jend, int lane) {
+                                            int jbeg, int jend, int lane, int lda = 0, int ldb = 0, int i0l = 0) {
     constexpr int NE = 4 * PAIR_RT;  // exponent values per lane per 16-column step
     static_assert(PAIR_PF == 2, "the column loop is unrolled over a two-slot operand ring");
     const int lr = lane >> 4, lc = lane & 15;
@@ -57,7 +59,10 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
 #pragma unroll
     for (int rt = 0; rt < PAIR_RT; ++rt)
 #pragma unroll
-        for (int c = 0; c < KC; ++c) af[rt][c] = At[(long)(4 * c + lr) * npad + i0 + 16 * rt + lc];
+        for (int c = 0; c < KC; ++c) {
+            if (LDSOP) af[rt][c] = At[(4 * c + lr) * lda + i0l + 16 * rt + lc];
+            else af[rt][c] = At[(long)(4 * c + lr) * npad + i0 + 16 * rt + lc];
+        }
     double acc[NE];
     double bi[NE];
     unsigned ik_off[NE];
@@ -72,8 +77,8 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
 #pragma unroll
     for (int c = 0; c < KC; ++c) b_off[c] = ((unsigned)(4 * c + lr) * (unsigned)npad + (unsigned)lc) * 8u;
     const unsigned bb_off = (unsigned)lc * 8u;
-    const __amdgpu_buffer_rsrc_t rB = buf_rsrc(Bt), rbeta = buf_rsrc(beta_b);
-    const __amdgpu_buffer_rsrc_t rV = buf_rsrc(VSEP ? vcol : Bt);
+    const __amdgpu_buffer_rsrc_t rB = buf_rsrc(LDSOP ? beta_b : Bt), rbeta = buf_rsrc(beta_b);   // (LDSOP: rB / rV are never used)
+    const __amdgpu_buffer_rsrc_t rV = buf_rsrc((VSEP && !LDSOP) ? vcol : beta_b);
     const __amdgpu_buffer_rsrc_t rIK = buf_rsrc(DIAG ? iKa + (long)i0 * npad : Bt);
     if (DIAG && jbeg < i0) jbeg = i0;  // columns left of the diagonal block are mirrored by the transposed tile
     double total = 0.0;
@@ -86,9 +91,15 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
         for (int c = 0; c <= KC + 1; ++c) ring[p][c] = 0.0;
         if (jbeg + 16 * p < jend) {
 #pragma unroll
-            for (int c = 0; c < KC; ++c) ring[p][c] = buf_ld(rB, b_off[c], (unsigned)(jbeg + 16 * p) * 8u);
+            for (int c = 0; c < KC; ++c) {
+                if (LDSOP) ring[p][c] = Bt[(4 * c + lr) * ldb + jbeg + 16 * p + lc];
+                else ring[p][c] = buf_ld(rB, b_off[c], (unsigned)(jbeg + 16 * p) * 8u);
+            }
             ring[p][KC] = buf_ld(rbeta, bb_off, (unsigned)(jbeg + 16 * p) * 8u);
-            if (VSEP) ring[p][KC + 1] = buf_ld(rV, bb_off, (unsigned)(jbeg + 16 * p) * 8u);
+            if (VSEP) {
+                if (LDSOP) ring[p][KC + 1] = vcol[jbeg + 16 * p + lc];
+                else ring[p][KC + 1] = buf_ld(rV, bb_off, (unsigned)(jbeg + 16 * p) * 8u);
+            }
         }
     }
     // one 16-column step on ring slot rg; the slot is refilled with the operands of column step j0 + 32
@@ -118,9 +129,15 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
         }
         if (PAIR_ABL != 4 && j0 + 32 < jend) {
 #pragma unroll
-            for (int c = 0; c < KC; ++c) rg[c] = buf_ld(rB, b_off[c], (unsigned)(j0 + 32) * 8u);
+            for (int c = 0; c < KC; ++c) {
+                if (LDSOP) rg[c] = Bt[(4 * c + lr) * ldb + j0 + 32 + lc];
+                else rg[c] = buf_ld(rB, b_off[c], (unsigned)(j0 + 32) * 8u);
+            }
             rg[KC] = buf_ld(rbeta, bb_off, (unsigned)(j0 + 32) * 8u);
-            if (VSEP) rg[KC + 1] = buf_ld(rV, bb_off, (unsigned)(j0 + 32) * 8u);
+            if (VSEP) {
+                if (LDSOP) rg[KC + 1] = vcol[j0 + 32 + lc];
+                else rg[KC + 1] = buf_ld(rV, bb_off, (unsigned)(j0 + 32) * 8u);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NE; ++i) {

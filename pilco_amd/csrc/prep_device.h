@@ -8,7 +8,10 @@ namespace pilco {
 
 constexpr int PREP_TAB_DOUBLES = FEXP_TN + 8;   // LDS tail of the operand kernel: exp table + wave sums of the one-launch small step
 __host__ __device__ constexpr size_t prep_region_doubles(int DT) {   // the operand work's own LDS region (pair / mean workgroups), before that tail
-    const size_t pair_blk = (size_t)4 * DT + 2 * (size_t)DT * DT + 4 + 256 * (size_t)(DT + 1);
+    // (the point stage of a pair workgroup, 256 (DT + 1), or -- one-launch small step with its operands in LDS, KP <= 16 --
+    // the operands of 64 rows and 256 columns and v: KP (64 + 256) + 256)
+    const size_t stage = 256 * (size_t)(DT + 1), ops = mm_kp(DT) <= 16 ? (size_t)mm_kp(DT) * (64 + 256) + 256 : 0;
+    const size_t pair_blk = (size_t)4 * DT + 2 * (size_t)DT * DT + 4 + (stage > ops ? stage : ops);
     const size_t mean_blk = (size_t)2 * DT + 2 * (size_t)DT * DT + 4 + 9 * (size_t)(DT + 1) + 2 * (size_t)DT + 512 * (size_t)(DT + 2);
     return pair_blk > mean_blk ? pair_blk : mean_blk;
 }
@@ -251,6 +254,12 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
     // (one-launch step of small models, below: the workgroup needs the column operand of ALL points -- the stage holds
     // points 0..255 = all of them, side 1 takes one point per thread, side 0 its rows of the chunk)
     const bool fpair = FPAIR && wk.fuse_pair;
+    // ... and with 64 rows per workgroup and a contraction of at most 16 rows the operands stay in LDS (the stage's place,
+    // once every thread has taken its point from it): Al [KP][64] | Bl [KP][npad] | vl [npad]
+    const bool fplds = fpair && mm_kp(DT) <= 16 && npad / wk.NCH == 64;
+    double* Al = zst;
+    double* Bl = Al + mm_kp(DT) * 64;
+    double* vl = Bl + mm_kp(DT) * 256;
     const int st_begin = fpair ? 0 : i_begin, st_end = fpair ? npad : i_end;
     if (w != 0 && act) {
         const int idx = (w - 1) * 64 + lane;   // 0..447
@@ -321,7 +330,25 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
         for (int r = 0; r < DT; ++r) quad = fma(x[r], y[r], quad);
         const double uv = valid ? (kk + quad) : 0.0;
         const double one = valid ? 1.0 : 0.0;
-        if (side == 0) {
+        if (fplds) {   // (workgroup-uniform) the same operands into LDS: nobody else reads them
+            if (side == 0) {
+                const int il = i - i_begin;
+#pragma unroll
+                for (int r = 0; r < DT; ++r)
+                    if (r < D) Al[r * 64 + il] = 2.0 * y[r];
+                Al[D * 64 + il] = uv;
+                if (!wk.vsep) Al[(D + 1) * 64 + il] = one;
+                for (int k = D + 2; k < KP; ++k) Al[k * 64 + il] = 0.0;
+            } else {
+#pragma unroll
+                for (int r = 0; r < DT; ++r)
+                    if (r < D) Bl[r * 256 + i] = x[r];
+                Bl[D * 256 + i] = one;
+                if (wk.vsep) vl[i] = uv;
+                else Bl[(D + 1) * 256 + i] = uv;
+                for (int k = D + 2; k < KP; ++k) Bl[k * 256 + i] = 0.0;
+            }
+        } else if (side == 0) {
 #pragma unroll
             for (int r = 0; r < DT; ++r)
                 if (r < D) store_wt(&At[(long)r * npad + i], 2.0 * y[r]);   // 2 Q z_i (0 on padded rows)
@@ -338,7 +365,16 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
             for (int k = D + 2; k < KP; ++k) store_wt(&Bt[(long)k * npad + i], 0.0);
         }
     };
-    if (!MM_ABL(wk, 4) && act) {
+    if (fplds) {   // (workgroup-uniform) every thread takes its point from the stage, THEN the operands overwrite it
+        const int r_begin = side ? 0 : i_begin, r_end = side ? npad : i_end;
+        const bool has = act && r_begin + tl < r_end;
+        const int i = r_begin + tl;
+        double zeta[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) zeta[d] = (has && d < D) ? zst[(i - st_begin) * LDZ + d] : 0.0;
+        __syncthreads();
+        if (has) row(i, i < md.n, zeta);
+    } else if (!MM_ABL(wk, 4) && act) {
         const int r_begin = (fpair && side) ? 0 : i_begin, r_end = (fpair && side) ? npad : i_end;   // this side's points
         if (r_begin + tl < r_end) {   // first row of this thread: centred point from the LDS stage
             const int i = r_begin + tl;
@@ -379,11 +415,15 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
             const int i0 = i_begin + 16 * PAIR_RT * rg, jb = 16 * (ct * cq / ncs), je = 16 * (ct * (cq + 1) / ncs);
             const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
             const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
-            if (diag)
-                val = pair_wave<KCP, true, VSP, true>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab,
-                                                       npad, i0, jb, je, lane);
-            else
+            const double* iKa = diag ? md.iK + mm_ik_blk(md, a) * npad * npad : nullptr;
+            if (fplds && mm_kp(DT) <= 16) {
+                if (diag) val = pair_wave<KCP, true, VSP, true, true>(Al, Bl, vl, beta_a, beta_b, iKa, tab, npad, i0, jb, je, lane, 64, 256, i0 - i_begin);
+                else val = pair_wave<KCP, false, VSP, true, true>(Al, Bl, vl, beta_a, beta_b, nullptr, tab, npad, i0, jb, je, lane, 64, 256, i0 - i_begin);
+            } else if (diag) {
+                val = pair_wave<KCP, true, VSP, true>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, iKa, tab, npad, i0, jb, je, lane);
+            } else {
                 val = pair_wave<KCP, false, VSP, true>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, nullptr, tab, npad, i0, jb, je, lane);
+            }
             for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off);
         }
         if (act && lane == 0) wred[w] = val;
