@@ -85,6 +85,8 @@ int pilco_set_inline_policy(pilco_ctx* ctx, int on);
  * it until this is called again.  pilco_last_rollout_mode: which of the two the last rollout actually used. */
 int pilco_set_rollout_mode(pilco_ctx* ctx, int mode);
 int pilco_last_rollout_mode(const pilco_ctx* ctx);
+/* 1 if this build of the library contains the persistent rollout kernel (csrc/Makefile: PERSIST=1; the product build: 0). */
+int pilco_has_persistent_kernel(void);
 /* checks the f64 MFMA fragment layout assumptions on the device; 0 = OK */
 int pilco_selftest(pilco_ctx* ctx);
 
@@ -315,6 +317,13 @@ int pilco_rollout_group(pilco_ctx** ctxs, int n, const pilco_policy* policy, con
  * db [n][U]: every rank's results (bit-identical to one another). */
 int pilco_rollout_grad_group(pilco_ctx** ctxs, int n, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
                              const double* m0, const double* S0, int H, double* reward, double* dW, double* db);
+/* The same for an RbfController (pilco_rollout_grad_rbf on every context; pilco/controllers.py:80-129).  The policy GP is not
+ * sharded -- every rank holds all of it in PILCO_SLOT_POLICY and evaluates it inside its link kernel (inline policy: at most
+ * 256 basis functions).  reward [n], dX [n][bf*E], dY [n][bf*U], dls [n][U*E]: every rank's results, bit-identical to one
+ * another and to the single-rank pilco_rollout_grad_rbf (the split of every pair's sums does not depend on the rank count). */
+int pilco_rollout_grad_rbf_group(pilco_ctx** ctxs, int n, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                                 const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
+                                 const double* noisep, int bf, double* reward, double* dX, double* dY, double* dls);
 /* Peer exchange: the per-step all-gather without a collective call.  Every rank owns an exchange area in its GPU's
  * memory; after its pair kernel a rank stores its segment straight into EVERY rank's area (over xGMI between GPUs) and
  * raises its flag there; the next step's head waits for the W flags of that exchange and reads the segments from its

@@ -60,6 +60,7 @@ SIGNATURES = {
     "pilco_set_fused_step": (C.c_int, [_vp, C.c_int]),
     "pilco_set_grad_mode": (C.c_int, [_vp, C.c_int]),
     "pilco_set_small_step": (C.c_int, [_vp, C.c_int]),
+    "pilco_has_persistent_kernel": (C.c_int, []),
     "pilco_set_use_graph": (C.c_int, [_vp, C.c_int]),
     "pilco_set_rollout_mode": (C.c_int, [_vp, C.c_int]),
     "pilco_set_inline_policy": (C.c_int, [_vp, C.c_int]),
@@ -118,6 +119,8 @@ SIGNATURES = {
     "pilco_gp_shard_pack": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "pilco_gp_shard_finish": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
     "pilco_rollout_grad_group": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]),
+    "pilco_rollout_grad_rbf_group": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
+                                               _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]),
     "pilco_rollout_group": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp,
                             C.c_int, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     "pilco_group_sync_model": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int]),
@@ -237,6 +240,9 @@ class Context:
         """0 (default): the launch sequence (hipGraph replay); 1: plain rollouts as ONE persistent launch (include/pilco_hip.h)."""
         self._chk(self.lib.pilco_set_rollout_mode(self.h, int(mode)))
         self._settings["set_rollout_mode"] = (mode,)
+
+    def has_persistent_kernel(self):
+        return bool(self.lib.pilco_has_persistent_kernel())
 
     def last_rollout_mode(self):
         return int(self.lib.pilco_last_rollout_mode(self.h))
@@ -629,6 +635,24 @@ def rollout_grad_group(ctxs, policy, rewards, m0, S0, H):
     rew, dW, db = np.zeros(n), np.empty((n, U, E)), np.empty((n, U))
     c0._chk(c0.lib.pilco_rollout_grad_group(arr, n, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H), _ptr(rew), _ptr(dW), _ptr(db)))
     return rew, dW, db
+
+
+def rollout_grad_rbf_group(ctxs, policy, rewards, m0, S0, H, Xp, Yp, lsp, noisep):
+    """Value and gradient of one sharded rollout with an RbfController over the contexts of this process
+    (pilco_rollout_grad_rbf_group): (reward (n,), dX (n, bf, E), dY (n, bf, U), dls (n, U, E)) -- every rank's results."""
+    c0 = ctxs[0]
+    n = len(ctxs)
+    E, U = policy["state_dim"], policy["control_dim"]
+    p, k1 = c0._policy(policy)
+    r, k2 = c0._rewards(rewards, E)
+    m0 = _f64(m0, (E,)); S0 = _f64(S0, (E, E))
+    Xp = _f64(Xp); bf = Xp.shape[0]
+    Xp = _f64(Xp, (bf, E)); Yp = _f64(Yp, (bf, U)); lsp = _f64(lsp, (U, E)); noisep = _f64(noisep, (U,))
+    arr = (_vp * n)(*[c.h for c in ctxs])
+    rew, dX, dY, dls = np.zeros(n), np.empty((n, bf, E)), np.empty((n, bf, U)), np.empty((n, U, E))
+    c0._chk(c0.lib.pilco_rollout_grad_rbf_group(arr, n, C.byref(p), r, len(rewards), _ptr(m0), _ptr(S0), int(H), _ptr(Xp), _ptr(Yp), _ptr(lsp),
+                                                _ptr(noisep), bf, _ptr(rew), _ptr(dX), _ptr(dY), _ptr(dls)))
+    return rew, dX, dY, dls
 
 
 def group_nlml(ctxs, slot, D, E):

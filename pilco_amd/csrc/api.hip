@@ -38,6 +38,11 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.KP = mm_kp(D);
     wk.vsep = mm_vsep(D) ? 1 : 0;
     mm_prep_chunks(npad, std::max(wk.PL, 1), wk.EL, &wk.NCH, &wk.NCHM);
+    if (W > 1) {   // the chunks of an output's mean sums decide how they are added up: taken from the WHOLE model's counts, so
+        int nch_g;  // that M and V come out with the same bits on any rank count (the operand chunks NCH carry no sums)
+        mm_prep_chunks(npad, P, E, &nch_g, &wk.NCHM);
+        wk.NCHM = std::min(wk.NCHM, wk.NCH);
+    }
     wk.NT = mm_pair_nt(npad, ctx->variant, std::max(wk.PL, 1));
     wk.OUTOFF = PLcap;
     wk.SEG = PLcap + ELcap * (1 + D);
@@ -374,6 +379,7 @@ int pilco_last_not_pd_output(const pilco_ctx* ctx) { return ctx ? ctx->not_pd : 
 int pilco_set_pair_kernel(pilco_ctx* ctx, int variant) {
     if (!ctx || variant < 0 || variant > 2) return PILCO_E_SHAPE;
     ctx->variant = variant;
+    ctx->variant_user = true;
     return PILCO_OK;
 }
 
@@ -409,6 +415,14 @@ int pilco_set_rollout_mode(pilco_ctx* ctx, int mode) {
 }
 
 int pilco_last_rollout_mode(const pilco_ctx* ctx) { return (ctx && ctx->last_persist) ? 1 : 0; }
+
+int pilco_has_persistent_kernel(void) {
+#ifdef PILCO_WITH_PERSIST
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int pilco_set_use_graph(pilco_ctx* ctx, int on) {
     if (!ctx) return PILCO_E_SHAPE;

@@ -998,24 +998,24 @@ static void launch_bwd_pair(hipStream_t st, dim3 grid, size_t lds, const MMModel
 #undef PBL
 }
 
-void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb);
-size_t mm_bwd_gpart_size(int npad, int P, int D) {   // one (16 NMT)^2 block per sweep workgroup
+void mm_bwd_geometry(int npad, int Pg, int* njs, int* nrb);
+size_t mm_bwd_gpart_size(int npad, int P, int D) {   // one (16 NMT)^2 block per sweep workgroup (sized for the most column splits: 4)
     int njs, nrb;
-    mm_bwd_geometry(npad, P, &njs, &nrb);
+    mm_bwd_geometry(npad, 1, &njs, &nrb);
     const int nmt = (D + 16) / 16;
-    return (size_t)std::max(1, P) * njs * nrb * nmt * nmt * 256;
+    return (size_t)std::max(1, P) * 4 * nrb * nmt * nmt * 256;
 }
 size_t mm_bwd_cpart_size(int npad, int P) {
     int njs, nrb;
-    mm_bwd_geometry(npad, P, &njs, &nrb);
+    mm_bwd_geometry(npad, 1, &njs, &nrb);
     return (size_t)std::max(1, P) * nrb * npad;
 }
 size_t mm_jac_rowmom_size(int npad, int P) { return mm_bwd_gpart_size(npad, P, 1); }   // (the Jacobian tape serves D <= 14: one block)
 size_t mm_jac_cpart_size(int npad, int P, int) { return mm_bwd_cpart_size(npad, P); }
 size_t mm_jac_head_size(int D, int E, int P) { return (size_t)(E + P) * (D * D + D + 2); }
-int mm_jac_nt(int npad, int P) {
+int mm_jac_nt(int npad, int Pg) {   // Pg: pairs of the WHOLE model
     int njs, nrb;
-    mm_bwd_geometry(npad, P, &njs, &nrb);
+    mm_bwd_geometry(npad, Pg, &njs, &nrb);
     return njs * nrb;
 }
 
@@ -1026,7 +1026,7 @@ void launch_mm_sweep(hipStream_t st, const MMModel& md, const MMWork& wk, double
                      double* npart) {
     const int P = wk.PL, E = md.E, D = md.D;
     int njs, nrb;
-    mm_bwd_geometry(md.npad, P, &njs, &nrb);
+    mm_bwd_geometry(md.npad, md.E * (md.E + 1) / 2, &njs, &nrb);   // (the model's pairs, not this rank's: the split of a pair's sums is the same on every rank count)
     const int nhead = E + P, per_row = nrb * njs;
     dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);
     const int nI = D * D;
@@ -1043,7 +1043,7 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
     if (H <= 0) return;
     const int P = wk.PL, E = md.E, D = md.D;
     int njs, nrb;
-    mm_bwd_geometry(md.npad, P, &njs, &nrb);
+    mm_bwd_geometry(md.npad, md.E * (md.E + 1) / 2, &njs, &nrb);   // (the model's pairs, not this rank's: the split of a pair's sums is the same on every rank count)
     const int LD = D | 1, nI = D * D, D1 = D + 1, LD1 = D1 | 1, NS = mm_jac_ns(D);
     const int nrc = mm_bwd_rc(md.npad);
     BwdBatch bb;
@@ -1063,10 +1063,12 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
                        (long)mm_jac_rec_size(D, E, P), bb);
 }
 
-void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb) {
+// Pg: the pairs of the WHOLE model, E (E + 1) / 2 -- never the local count of a rank: the column split decides how a pair's
+// sums are cut and added, and a sharded value-and-gradient rollout is bit-identical to the single-rank one because of that.
+void mm_bwd_geometry(int npad, int Pg, int* njs, int* nrb) {
     *nrb = (npad + 64 * BWD_RT - 1) / (64 * BWD_RT);
     int q = 1;   // column splits: enough workgroups for a few balanced rounds of the chip
-    while (q < 4 && (npad / 16) % (2 * q) == 0 && (long)*nrb * PL * q < 1536) q *= 2;
+    while (q < 4 && (npad / 16) % (2 * q) == 0 && (long)*nrb * Pg * q < 1536) q *= 2;
     if (const char* ev = getenv("PILCO_BWD_NJS")) q = std::max(1, std::min(atoi(ev), npad / 16));
     *njs = q;
 }
@@ -1075,7 +1077,7 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
                    const double* bars, double* head, double* out, unsigned* done, double* sum_out) {
     const int P = wk.PL, E = md.E, D = md.D;
     int njs, nrb;
-    mm_bwd_geometry(md.npad, P, &njs, &nrb);
+    mm_bwd_geometry(md.npad, md.E * (md.E + 1) / 2, &njs, &nrb);   // (the model's pairs, not this rank's: the split of a pair's sums is the same on every rank count)
     const int nhead = E + P, per_row = nrb * njs;
     dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);   // the rows past P hold the head workgroups
     const int LD = D | 1, nI = D * D;

@@ -112,6 +112,7 @@ struct pilco_ctx {
     std::string err;
     int not_pd = -1;
     int variant = 0;
+    bool variant_user = false;   // pilco_set_pair_kernel was called: the caller's choice stands (otherwise: stream-K on one rank, the tiled kernel -- whose sums do not depend on the rank count -- on several)
     int rank = 0, nranks = 1;
     ncclComm_t comm = nullptr;
     std::shared_ptr<PeerGroup> group;   // set only while pilco_rollout_group runs

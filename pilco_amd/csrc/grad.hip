@@ -23,7 +23,7 @@ int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double
     // ---- device: operands (prep), reverse pair sweep, mean part, per-pair / per-output contributions
     const int rec = D + D * D, nb = E + E * E + D * E;
     int njs, nrb;
-    mm_bwd_geometry(npad, P, &njs, &nrb);
+    mm_bwd_geometry(npad, E * (E + 1) / 2, &njs, &nrb);
     ENSURE(s.bwd_mom, mm_bwd_gpart_size(npad, P, D));   // one (16 NMT)^2 block per sweep workgroup
     ENSURE(s.bwd_cp, mm_bwd_cpart_size(npad, P));
     ENSURE(s.bwd_part, (size_t)(P + E) * mm_bwd_rc(npad) * (1 + rec + D));   // pair partials, then mean partials

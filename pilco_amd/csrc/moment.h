@@ -203,7 +203,7 @@ void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot);
 // head [E + P][D*D + D + 2]: the step's D x D inverses (see bwd_head)
 void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* part,
                    const double* bars, double* head, double* out, unsigned* done, double* sum_out);
-void mm_bwd_geometry(int npad, int PL, int* njs, int* nrb);
+void mm_bwd_geometry(int npad, int Pg, int* njs, int* nrb);   // Pg: pairs of the whole model (rank-count independent split)
 // Jacobian tape (bwd.hip).  Per step: launch_mm_sweep runs the reverse sweep in place of the forward pair kernel and
 // leaves rowmom / cpart / head in the step's own buffers (sizes below) and N_ab as npart [P][mm_jac_nt][2] tile partials
 // for the serial link; once per rollout launch_mm_jac_finish turns the H steps' buffers into the records
@@ -219,7 +219,7 @@ size_t mm_bwd_gpart_size(int npad, int P, int D);
 size_t mm_bwd_cpart_size(int npad, int P);
 size_t mm_jac_cpart_size(int npad, int P, int E);
 size_t mm_jac_head_size(int D, int E, int P);
-int mm_jac_nt(int npad, int P);
+int mm_jac_nt(int npad, int Pg);
 int mm_jac_ns(int D);
 int mm_bwd_rc(int npad);
 // persistent whole-rollout kernel: does an instantiation exist for this input dimension / contraction depth, and the launch

@@ -30,7 +30,7 @@ void mm_prep_chunks(int npad, int PL, int EL, int* nch_out, int* nchm_out) {
 }
 
 static int prep_dt(int D) {   // the operand kernel's instantiation for this input dimension (see the dispatch below)
-    return D <= 4 ? 4 : D <= 6 ? 6 : D <= 8 ? 8 : D <= 10 ? 10 : D == 11 ? 11 : D <= 12 ? 12 : D <= 14 ? 14 : D <= 16 ? 16 : D <= 20 ? 20 : D <= 24 ? 24 : 32;
+    return D <= 4 ? 4 : D <= 6 ? 6 : D <= 8 ? 8 : D <= 10 ? 10 : D == 11 ? 11 : D <= 12 ? 12 : D <= 14 ? 14 : D <= 16 ? 16 : 32;
 }
 // Does the fused head (serial link + operands in one workgroup) fit the CU's LDS for this model / policy / reward set?
 // Wide inputs (D > 24 with many outputs) do not: the rollout then runs the three-kernel step (same results).
@@ -71,9 +71,7 @@ void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const P
     else if (D <= 12) launch_prep_12(a);
     else if (D <= 14) launch_prep_14(a);
     else if (D <= 16) launch_prep_16(a);
-    else if (D <= 20) launch_prep_20(a);
-    else if (D <= 24) launch_prep_24(a);
-    else launch_prep_32(a);
+    else launch_prep_32(a);   // (17 <= D <= 32: one instantiation; rounds 1-3 also carried DT = 20 and 24, 2 MB of code for inputs no example has)
 }
 
 }  // namespace pilco

@@ -110,8 +110,6 @@ void launch_prep_11(const PrepLaunch& a);
 void launch_prep_12(const PrepLaunch& a);
 void launch_prep_14(const PrepLaunch& a);
 void launch_prep_16(const PrepLaunch& a);
-void launch_prep_20(const PrepLaunch& a);
-void launch_prep_24(const PrepLaunch& a);
 void launch_prep_32(const PrepLaunch& a);
 
 }  // namespace pilco

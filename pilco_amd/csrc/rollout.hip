@@ -264,7 +264,7 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
     MMWork wk0 = s.wk;
     if (jac) {
         wk0.sk_waves = 0;
-        wk0.NT = mm_jac_nt(s.npad, s.wk.PL);
+        wk0.NT = mm_jac_nt(s.npad, s.wk.P);
         wk0.pair_part = s.jac_np.p;
         g.wk = wk0;
     }
@@ -281,9 +281,13 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
     // An RbfController evaluated inside the link (GlueArgs::pol_inline) makes the step the LinearController's: two launches.
     const bool inl = rbf && g.pol_inline && ctx->fused && fits && ctx->nranks == 1 && !ctx->comm && s.wk.PL > 0 && H > 0;
     const bool inl_peer = rbf && g.pol_inline && peer_rollout_applies(ctx, plan, H);   // sharded rollout over the peer exchange
-    if (rbf && ctx->nranks != 1 && !inl_peer)
-        return fail(ctx, PILCO_E_STATE, "rollout: several ranks run an RbfController only over the peer exchange (pilco_peer_attach / pilco_group_peer_attach) with the inline policy");
-    if (rbf && !inl && !inl_peer && g.pol_inline) {   // not this time (three-kernel step, ...): the policy GP gets its own launches
+    // Several ranks: the policy GP is never sharded (every rank holds all of it) and its own launches would deal its pairs over
+    // the ranks, so it is evaluated INSIDE the link -- by the fused head over the peer exchange, or (value-and-gradient
+    // rollouts: the Jacobian tape runs the three-kernel step with the all-gather) by the link kernel itself.
+    const bool inl_link = rbf && g.pol_inline && !inl && !inl_peer && (ctx->nranks != 1 || ctx->comm);
+    if (rbf && (ctx->nranks != 1 || ctx->comm) && !inl_peer && !inl_link)
+        return fail(ctx, PILCO_E_STATE, "rollout: several ranks run an RbfController only with the inline policy (at most 256 basis functions, see pilco_set_inline_policy)");
+    if (rbf && !inl && !inl_peer && !inl_link && g.pol_inline) {   // not this time (three-kernel step, ...): the policy GP gets its own launches
         g.pol_inline = 0;
         plan.g.pol_inline = 0;
         fits = fused_heads_fit(ctx, plan);
@@ -299,7 +303,7 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
         // Small models: the pair sums ride in the head launch (prep_device.h) -- one launch per step.  The head instantiated for
         // this input dimension carries the pair arithmetic of ONE contraction depth (that of D = DT); the workgroup's rows must
         // be whole 32-row groups and one thread per point must cover the columns.
-        const int dtk = s.D <= 4 ? 4 : s.D <= 6 ? 6 : s.D <= 8 ? 8 : s.D <= 10 ? 10 : s.D == 11 ? 11 : s.D <= 12 ? 12 : s.D <= 14 ? 14 : s.D <= 16 ? 16 : s.D <= 20 ? 20 : s.D <= 24 ? 24 : 32;
+        const int dtk = s.D <= 4 ? 4 : s.D <= 6 ? 6 : s.D <= 8 ? 8 : s.D <= 10 ? 10 : s.D == 11 ? 11 : s.D <= 12 ? 12 : s.D <= 14 ? 14 : s.D <= 16 ? 16 : 32;
         const bool small = ctx->fuse_small && !jac && ctx->variant == 0 && s.npad <= 256 && (s.npad / wk0.NCH) % 32 == 0 &&
                            wk0.KP == mm_kp(dtk) && (wk0.vsep != 0) == mm_vsep(dtk) && !pair_ev && !MM_ABL(s.wk, 255);
         if (small)
@@ -492,9 +496,10 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
         launch_glue(ctx->st, ga);
         ga.flags = keep;
     };
-    g.flags = GF_TRAJ | (H > 0 ? (rbf ? GF_RBF_PRE : GF_POLICY) : 0);
+    const bool rbf_l = rbf && !inl_link;   // the policy GP as launches of its own (an inline policy is part of the link kernel)
+    g.flags = GF_TRAJ | (H > 0 ? (rbf_l ? GF_RBF_PRE : GF_POLICY) : 0);
     launch_glue(ctx->st, g);
-    if (rbf && H > 0) policy_stage(g);
+    if (rbf_l && H > 0) policy_stage(g);
     size_t evi = 0;
     for (int t = 0; t < H; ++t) {
         if (s.wk.PL > 0) {
@@ -519,7 +524,7 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
         g.m_out = plan.st[(t + 1) & 1];
         g.s_out = plan.st[(t + 1) & 1] + E;
         const bool more = t + 1 < H;
-        const int tail = GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ | (more ? (rbf ? GF_RBF_PRE : GF_POLICY) : 0);
+        const int tail = GF_ASSEMBLE | GF_PROPAGATE | GF_TRAJ | (more ? (rbf_l ? GF_RBF_PRE : GF_POLICY) : 0);
         if (ctx->nranks == 1 && !ctx->comm) {
             g.flags = GF_PACK | tail;
         } else {
@@ -529,7 +534,7 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
             g.flags = tail;
         }
         launch_glue(ctx->st, g, rew && s.wk.PL == 0);   // (a rank without pairs keeps the reward in the glue launch)
-        if (rbf && more) {  // the policy stage reads the NEW state
+        if (rbf_l && more) {  // the policy stage reads the NEW state
             g.m_x = g.m_out;
             g.s_x = g.s_out;
             policy_stage(g);
@@ -538,6 +543,15 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
     return PILCO_OK;
 }
 
+#ifndef PILCO_WITH_PERSIST
+// The product build leaves persist.hip out (Makefile: PERSIST=1 compiles it in): no instantiation exists, so a context asked
+// for rollout mode 1 keeps running the launch sequence (pilco_last_rollout_mode reports 0; pilco_has_persistent_kernel: 0).
+namespace pilco {
+bool mm_persist_supported(int, int, bool) { return false; }
+size_t mm_persist_lds_bytes(const MMModel&, const GlueArgs&, int) { return 0; }
+int launch_rollout_persist(hipStream_t, const PersistArgs&, int, size_t) { return -1; }
+}  // namespace pilco
+#endif
 // ---------------------------------------------------------------- persistent whole-rollout launch (persist.hip)
 static int device_cus_of(int device) {
     static int cached[64] = {};
@@ -1201,8 +1215,6 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     const bool sharded = (W != 1 || ctx->comm);
     if (sharded && !ctx->comm && !ctx->group)
         return fail(ctx, PILCO_E_STATE, "rollout_grad: a sharded context needs a communicator (pilco_comm_init) or pilco_rollout_grad_group");
-    if (sharded && policy && policy->kind == PILCO_POLICY_RBF)
-        return fail(ctx, PILCO_E_STATE, "rollout_grad: the sharded reverse pass serves the LinearController (an RbfController's sharded rollout needs the peer exchange, which carries no tape)");
     RolloutPlan plan;
     if (int r = setup_rollout(ctx, policy, rewards, n_rewards, H, true, plan)) return r;
     Slot& s = ctx->slot[0];
@@ -1222,7 +1234,7 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     ENSURE(s.jac_cpart, Hn * mm_jac_cpart_size(npad, P, ELc));
     ENSURE(s.jac_head, Hn * mm_jac_head_size(D, E, P));
     ENSURE(s.jac_part, Hn * mm_jac_part_size(D, E, P, npad));
-    ENSURE(s.jac_np, (size_t)2 * std::max(P, 1) * mm_jac_nt(npad, P));
+    ENSURE(s.jac_np, (size_t)2 * std::max(P, 1) * mm_jac_nt(npad, s.wk.P));
     ENSURE(ctx->tape, std::max<size_t>(1, (size_t)H * TS));
     ENSURE(ctx->jrec, std::max<size_t>(1, (size_t)H * JS));
     // sharded: the host sweep reads GLOBAL records [P_all pair records | E output records] per step, assembled on the host

@@ -107,6 +107,10 @@ int pilco_shard_set(pilco_ctx* ctx, int rank, int nranks) {
         for (Slot& s : ctx->slot) s.factor_valid = false;   // each rank factorises only the outputs it owns: the layout changed
     ctx->rank = rank;
     ctx->nranks = nranks;
+    // several ranks: the pair kernel whose summation order does not depend on how many pairs a rank holds (variant 2), so that
+    // a sharded rollout is bit-identical across rank counts -- and to the single-rank run under the same kernel -- without the
+    // caller asking for it; pilco_set_pair_kernel keeps the last word (stream-K: faster per rank, bits depend on the split)
+    if (!ctx->variant_user) ctx->variant = nranks > 1 ? 2 : 0;
     for (Slot& s : ctx->slot) s.wk_valid = false;
     return PILCO_OK;
 }
@@ -361,6 +365,39 @@ int pilco_rollout_grad_group(pilco_ctx** ctxs, int n, const pilco_policy* policy
     for (int i = 0; i < n; ++i)
         th.emplace_back([&, i] {
             rc[i] = pilco_rollout_grad(ctxs[i], policy, rewards, n_rewards, m0, S0, H, reward + i, dW + (size_t)i * U * E, db + (size_t)i * U);
+            if (rc[i] != PILCO_OK) grp->fail_all();
+        });
+    for (auto& t : th) t.join();
+    for (int i = 0; i < n; ++i) ctxs[i]->group.reset();
+    for (int i = 0; i < n; ++i)
+        if (rc[i] != PILCO_OK) {
+            if (i != 0) c0->err = "rank " + std::to_string(i) + ": " + ctxs[i]->err;
+            return rc[i];
+        }
+    return PILCO_OK;
+}
+
+// ... and for an RbfController (pilco_rollout_grad_rbf on every context; the policy GP is not sharded: every rank evaluates
+// all of it inside its link kernel).  Outputs of every rank: reward [n], dX [n][bf*E], dY [n][bf*U], dls [n][U*E].
+int pilco_rollout_grad_rbf_group(pilco_ctx** ctxs, int n, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                                 const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
+                                 const double* noisep, int bf, double* reward, double* dX, double* dY, double* dls) {
+    if (!ctxs || n <= 0 || !ctxs[0]) return PILCO_E_SHAPE;
+    pilco_ctx* c0 = ctxs[0];
+    if (!policy || !reward || !dX || !dY || !dls) return fail(c0, PILCO_E_SHAPE, "rollout_grad_rbf_group: null pointer");
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i] || ctxs[i]->nranks != n || ctxs[i]->rank != i || ctxs[i]->comm)
+            return fail(c0, PILCO_E_STATE, "rollout_grad_rbf_group: context i must be shard_set(i, n) and have no communicator");
+    const int E = policy->state_dim, U = policy->control_dim;
+    auto grp = std::make_shared<PeerGroup>();
+    grp->ctxs.assign(ctxs, ctxs + n);
+    for (int i = 0; i < n; ++i) ctxs[i]->group = grp;
+    std::vector<int> rc(n, PILCO_OK);
+    std::vector<std::thread> th;
+    for (int i = 0; i < n; ++i)
+        th.emplace_back([&, i] {
+            rc[i] = pilco_rollout_grad_rbf(ctxs[i], policy, rewards, n_rewards, m0, S0, H, Xp, Yp, lsp, noisep, bf, reward + i,
+                                           dX + (size_t)i * bf * E, dY + (size_t)i * bf * U, dls + (size_t)i * U * E);
             if (rc[i] != PILCO_OK) grp->fail_all();
         });
     for (auto& t : th) t.join();

@@ -359,8 +359,18 @@ def test_headline_rollout_h40_vs_executed_reference(ctx, golden_dir, tag, D, noi
     np.testing.assert_allclose(S2, S, rtol=1e-13)
 
 
+
+def _needs_persistent_kernel():
+    """The whole-rollout persistent kernel (csrc/persist.hip) is not part of the product build (`make PERSIST=1` compiles it
+    in): its tests run against such a build only."""
+    from pilco_amd import _lib
+    if not _lib.load_library().pilco_has_persistent_kernel():
+        pytest.skip("library built without the persistent rollout kernel (make -C pilco_amd/csrc PERSIST=1)")
+
+
 @pytest.mark.parametrize("N,D,E,H", [(1000, 10, 10, 12), (1000, 11, 10, 8), (130, 4, 3, 5), (300, 6, 4, 9), (200, 12, 10, 4), (257, 3, 2, 6)])
 def test_persistent_rollout_is_bitwise_identical_to_the_launch_sequence(N, D, E, H):
+    _needs_persistent_kernel()
     """pilco_set_rollout_mode(ctx, 1): the whole rollout as ONE resident launch (csrc/persist.hip; the reference's
     tf.while_loop, pilco.py:126-135, as a single kernel) -- phases ordered by flags in device memory, no cache maintenance,
     every step's operands in buffers of its own.  Same device code, same stream-K decomposition as the launch sequence:
@@ -440,6 +450,7 @@ def test_batched_rollouts_are_bit_identical_to_their_solo_runs(N, D, E, H, B):
 
 
 def test_persistent_rollout_gives_up_and_falls_back_when_it_cannot_make_progress(monkeypatch):
+    _needs_persistent_kernel()
     """Every wait of the persistent launch is bounded by the wall clock: with the bound set to zero the first flag that is
     not up yet makes the launch give up; the call then repeats the rollout on the launch sequence (same bits), reports
     which path ran, and the context stays on the launch sequence until the mode is set again."""
@@ -745,9 +756,56 @@ def test_sharded_value_and_gradient_rollout(E, U, nranks):
         for i in range(1, nranks):
             assert rew[i] == rew[0] and np.array_equal(dW[i], dW[0]) and np.array_equal(db[i], db[0])
         assert all(np.array_equal(a, b) for a, b in zip(out[0], out[1]))
-        np.testing.assert_allclose(rew[0], r1, rtol=1e-11)
-        np.testing.assert_allclose(dW[0], W1, rtol=1e-8, atol=1e-12)
-        np.testing.assert_allclose(db[0], b1, rtol=1e-8, atol=1e-12)
+        # the split of every pair's sums and of every output's mean sums is taken from the WHOLE model's counts, not from what a
+        # rank holds: value and gradient are the single-rank run's, to the last bit (round 3: "to rounding")
+        assert rew[0] == r1 and np.array_equal(dW[0], W1) and np.array_equal(db[0], b1)
+    finally:
+        for cx in made:
+            cx.close()
+
+
+@pytest.mark.parametrize("E,U,nranks,bf", [(4, 1, 2, 10), (3, 2, 3, 25)])
+def test_sharded_value_and_gradient_rollout_with_an_rbf_controller(E, U, nranks, bf):
+    """An RbfController's gradient over several ranks (controllers.py:108-121 inside pilco.py:85-90): the policy GP is not
+    sharded -- every rank holds all of it and evaluates it inside its link kernel --, the dynamics pairs are; records are
+    all-gathered once.  Every rank ends with the single-rank value and gradient, to the last bit, run after run."""
+    from pilco_amd import _lib
+    from pilco_amd.controllers import RbfController
+    D, H = E + U, 5
+    c = synthetic.config_c2(N=200, D=D, E=E, noise=1e-2, seed=67, control_dim=U)
+    rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(E), t=np.zeros(E))]
+    m0, S0 = c["m0"], 0.05 * np.eye(E)
+    rs = np.random.RandomState(9)
+    Xp, Yp, lsp = rs.randn(bf, E), 0.3 * rs.randn(bf, U), 0.8 + rs.rand(U, E)
+    made, ctls = [], []
+
+    def ctx_for(rank, n):
+        cx = _lib.Context(device=0)
+        made.append(cx)
+        if n > 1:
+            cx.shard_set(rank, n)
+        cx.gp_set_data(0, c["X"], c["Y"]); cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"]); cx.gp_factorize(0)
+        ctl = RbfController(E, U, bf, max_action=1.2, ctx=cx)
+        ctl.set_data((Xp, Yp))
+        for k, mdl in enumerate(ctl.models):
+            mdl.kernel.lengthscales.assign(lsp[k])
+        ctls.append(ctl)
+        return cx, ctl
+    try:
+        ref, rctl = ctx_for(0, 1)
+        noisep = np.asarray(rctl.noise, np.float64).reshape(-1)
+        one = ref.rollout_grad_rbf(rctl.policy_spec(), rw, m0, S0, H, Xp, Yp, lsp, noisep)
+        group = [ctx_for(r, nranks) for r in range(nranks)]
+        _lib.group_sync_model([g[0] for g in group])
+        for _, ctl in group:
+            ctl.sync()
+        spec = group[0][1].policy_spec()
+        out = [_lib.rollout_grad_rbf_group([g[0] for g in group], spec, rw, m0, S0, H, Xp, Yp, lsp, noisep) for _ in range(2)]
+        rew, dX, dY, dls = out[0]
+        for i in range(nranks):
+            assert rew[i] == one[0] and np.array_equal(dX[i], one[1]) and np.array_equal(dY[i], one[2]) and np.array_equal(dls[i], one[3])
+        assert all(np.array_equal(a, b) for a, b in zip(out[0], out[1]))
+        assert np.all(np.isfinite(dX)) and np.any(dX != 0.0)
     finally:
         for cx in made:
             cx.close()
@@ -832,8 +890,10 @@ def test_sharded_rollout_with_an_rbf_controller_over_the_peer_exchange(E, U, nra
         M1, S1, R1, T1 = ref.rollout(pol, rw, m0, S0, H, want_traj=True)
         group = [ctx_for(r, nranks) for r in range(nranks)]
         _lib.group_sync_model(group)
-        with pytest.raises(_lib.PilcoError):          # no peer exchange: refused
-            _lib.rollout_group(group, pol, rw, m0, S0, H)
+        # without the peer exchange (round 4): the exchange between host barriers, the policy inside every rank's link kernel
+        M, S, R, T, mismatch = _lib.rollout_group(group, pol, rw, m0, S0, H, want_traj=True)
+        assert mismatch == 0
+        assert np.array_equal(T, T1) and np.array_equal(R, R1) and np.array_equal(M, M1) and np.array_equal(S, S1)
         _lib.group_peer_attach(group)
         for rep in range(2):
             M, S, R, T, mismatch = _lib.rollout_group(group, pol, rw, m0, S0, H, want_traj=True)
