@@ -6,6 +6,9 @@
 
 namespace pilco {
 
+#ifndef PREP_SPARE_FIRST
+#define PREP_SPARE_FIRST 1
+#endif
 size_t prep_lds_bytes(int DT);
 
 // ------------------------------------------------------------------ prep
@@ -22,11 +25,14 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
     glue_lds_carve(g, sm_all, L);
     // The model constants this workgroup needs (its lengthscales and signal variances) are requested BEFORE the serial
     // link, so that their memory round trip overlaps with it instead of following it.
-    const bool spare_wg = (int)blockIdx.x >= wk.PL;
-    const int spare_idx = ((int)blockIdx.x - wk.PL) * (int)gridDim.y + (int)blockIdx.y;
+    // Item column of this workgroup: the spare columns (mean parts, reward) are dispatched FIRST -- their workgroups run
+    // 1.5-2 us longer than the pair workgroups of the same launch, and the launch ends with its last workgroup
+    const int bxi = PREP_SPARE_FIRST ? (int)((blockIdx.x + (unsigned)wk.PL) % gridDim.x) : (int)blockIdx.x;
+    const bool spare_wg = bxi >= wk.PL;
+    const int spare_idx = (bxi - wk.PL) * (int)gridDim.y + (int)blockIdx.y;
     const bool mean_wg = spare_wg && spare_idx < wk.EL * wk.NCHM;
     int a = 0, b = 0;
-    if (!spare_wg) local_pair_ab(wk, md.E, (int)blockIdx.x, a, b);
+    if (!spare_wg) local_pair_ab(wk, md.E, bxi, a, b);
     else if (mean_wg) a = b = (spare_idx / wk.NCHM) * wk.nranks + wk.rank;   // the owner of (a,a) owns output a
     double pre_la = 1.0, pre_lb = 1.0, pre_var = 1.0;
     if (!spare_wg || mean_wg) {
@@ -40,8 +46,8 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
         double* tabL = sm_all + glue_doubles + prep_region_doubles(DT);
         for (int e = threadIdx.x; e < FEXP_TN; e += 512) tabL[e] = wk.exp_tab[e];
     }
-    if (FUSED) glue_body<PK, SR>(g, L, blockIdx.x == 0 && blockIdx.y == 0);
-    prep_work<DT, FUSED, 512, FUSED && SR && PK != 1>(md, wk, pr, g, L, sm_all, glue_doubles, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, pre_la,
+    if (FUSED) glue_body<PK, SR>(g, L, bxi == 0 && blockIdx.y == 0);
+    prep_work<DT, FUSED, 512, FUSED && SR && PK != 1>(md, wk, pr, g, L, sm_all, glue_doubles, bxi, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, pre_la,
                               pre_lb, pre_var);
 }
 
