@@ -188,10 +188,10 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
     except Exception as exc:
         out["two_concurrent_rollouts_per_s"] = repr(exc)
     # the whole rollout as ONE persistent launch (pilco_set_rollout_mode(ctx, 1), csrc/persist.hip): same bits, timed beside
-    # the graph replay that `value` reports.  Opt-in because it measures slower.
+    # the graph replay that `value` reports.  Opt-in because it measures slower (docs/dead_ends.md).
     try:
         if not ctx.has_persistent_kernel():
-            raise RuntimeError("not in this build (csrc/Makefile: PERSIST=1; round 3 measured it 3.5-18 % slower than the graph replay, DESIGN.md section 12)")
+            raise RuntimeError("not in this build (csrc/Makefile: PERSIST=1; round 3 measured it 3.5-18 % slower than the graph replay, docs/dead_ends.md)")
         ref = ctx.rollout(policy, rewards, cfg["m0"], cfg["S0"], H)
         ctx.set_rollout_mode(1)
         got = ctx.rollout(policy, rewards, cfg["m0"], cfg["S0"], H)

@@ -79,7 +79,7 @@ int pilco_set_inline_policy(pilco_ctx* ctx, int on);
  * tf.while_loop (pilco.py:126-135) as a single kernel: every workgroup stays resident, the phases of a step are ordered by
  * flags in device memory instead of kernel boundaries, the state lives in LDS.  Both run the same device code on the same
  * work decomposition: results are BITWISE identical.  Measured on MI355X the persistent launch is 6-20 % SLOWER than the
- * graph replay, which is why it is not the default.  A persistent launch that cannot make progress
+ * graph replay (docs/dead_ends.md), which is why it is not the default.  A persistent launch that cannot make progress
  * (its workgroups are not all resident because the GPU is shared with other work) gives up after a bounded wait
  * (PILCO_PERSIST_TIMEOUT_MS, default 200); the rollout is then repeated on the launch sequence and the context stays on
  * it until this is called again.  pilco_last_rollout_mode: which of the two the last rollout actually used. */
