@@ -593,8 +593,16 @@ struct RbfAdj : PolicyAdj {
 // (controllers.py:13-36), rewards (rewards.py:19-81); the moment-matching adjoint of every step on the device.
 // Host contraction of one step's Jacobian records (bwd.hip: k_mm_jac_fin) with the cotangents of the step's outputs:
 // what pilco_gp_predict_vjp computes on the device, without touching the device.  M (E): the step's GP means (tape).
+// The step streams its records (108 kB at C2u) once, cache-cold (the device wrote them): one core reads them at ~11 GB/s --
+// 10 us per step, three quarters of the host sweep.  pf: distance (doubles) to the records the NEXT call will stream (the
+// step before this one; 0: none): every line is requested one whole record ahead of its use.
 void jac_vjp(const double* __restrict__ jr, int D, int E, const double* M, const double* Mbar, const double* Sbar, const double* Vbar,
-             double* mbar, double* sbar, vec& acc) {
+             double* mbar, double* sbar, vec& acc, long pf) {
+    auto axpy = [pf](double* __restrict__ y, const double c, const double* __restrict__ x, const int n) {
+        if (pf != 0)
+            for (int e = 0; e < n; e += 8) __builtin_prefetch(x + e + pf, 0, 1);
+        for (int e = 0; e < n; ++e) y[e] += c * x[e];
+    };
     const int nI = D * D, NT2 = D * (D + 1) / 2, recp = 1 + D + NT2, P = E * (E + 1) / 2;
     acc.assign((size_t)D + NT2, 0.0);
     double* __restrict__ am = acc.data();
@@ -603,8 +611,7 @@ void jac_vjp(const double* __restrict__ jr, int D, int E, const double* M, const
     auto add_pair = [&](int a, int b) {
         const double shat = (a == b) ? Sbar[(size_t)a * E + a] : Sbar[(size_t)a * E + b] + Sbar[(size_t)b * E + a];
         const double* __restrict__ r = jr + (size_t)pl * recp + 1;
-        if (shat != 0.0)
-            for (int e = 0; e < D + NT2; ++e) am[e] += shat * r[e];
+        axpy(am, shat, r, D + NT2);   // (a zero cotangent adds zeros: same bits as skipping it, and the prefetch still runs)
         ++pl;
     };
     for (int a = 0; a < E; ++a) add_pair(a, a);
@@ -616,14 +623,13 @@ void jac_vjp(const double* __restrict__ jr, int D, int E, const double* M, const
         double mu = Mbar[a];
         for (int b = 0; b < E; ++b) mu -= (Sbar[(size_t)a * E + b] + Sbar[(size_t)b * E + a]) * M[b];
         const double* __restrict__ r = jo + (size_t)a * reco;
-        for (int e = 0; e < D + NT2; ++e) am[e] += mu * r[e];            // dM/dm | sym dM/ds are contiguous
+        axpy(am, mu, r, D + NT2);            // dM/dm | sym dM/ds are contiguous
         const double* __restrict__ dVdm = r + D + NT2;
         const double* __restrict__ dVds = dVdm + nI;
         for (int k = 0; k < D; ++k) {
             const double vb = Vbar[(size_t)k * E + a];
-            if (vb == 0.0) continue;
-            for (int e = 0; e < D; ++e) am[e] += vb * dVdm[(size_t)k * D + e];
-            for (int e = 0; e < NT2; ++e) am[D + e] += vb * dVds[(size_t)k * NT2 + e];
+            axpy(am, vb, dVdm + (size_t)k * D, D);
+            axpy(am + D, vb, dVds + (size_t)k * NT2, NT2);
         }
     }
     for (int d = 0; d < D; ++d) mbar[d] = am[d];
@@ -709,7 +715,8 @@ int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_re
         sxb = sbar;
         if (jac) {
             if (int r = rollout_jtape_wait(ctx, t)) return r;
-            jac_vjp(jrec + (size_t)t * JS, D, E, Mgp, mbar.data(), sbar.data(), Vb.data(), mjb.data(), sjb.data(), jacc);
+            jac_vjp(jrec + (size_t)t * JS, D, E, Mgp, mbar.data(), sbar.data(), Vb.data(), mjb.data(), sjb.data(), jacc,
+                    (t > 0 && t - 1 >= ctx->jwait_from) ? -(long)JS : 0);   // (only records that have arrived)
             for (int q = 0; q < D * D; ++q)
                 if (!std::isfinite(sjb[q])) return fail(ctx, PILCO_E_NOT_PD, "rollout_grad: singular s + Lambda^2 or I + Lambda s");
         } else if (int r = pilco_gp_predict_vjp(ctx, PILCO_SLOT_DYNAMICS, m_j, s_j, mbar.data(), sbar.data(), Vb.data(), mjb.data(), sjb.data())) {
