@@ -91,8 +91,9 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     const size_t n_small = (size_t)PLa + (size_t)E * wk.NCHM * (1 + D);
     ENSURE(s.w_small, 2 * n_small);
     ENSURE(s.w_part, std::max((size_t)PLa * wk.NT * 2, (size_t)std::max(wk.sk_pls, 16) * std::max(wk.sk_maxw, 4)));
-    ENSURE(s.w_fpart, (size_t)2 * PLa * wk.NCH * 2);
+    ENSURE(s.w_fpart, (size_t)2 * PLa * wk.NCH * 4 * 2);   // (up to four column splits per row chunk)
     wk.fuse_pair = 0;
+    wk.NCS = 1;
     ENSURE(s.w_gath, (size_t)W * wk.SEG);
     ENSURE(s.w_out, (size_t)E + E * E + D * E);
     wk.in_m = s.w_in.p;

@@ -56,7 +56,8 @@ __device__ __forceinline__ double sum_strided(const double* __restrict__ base, l
 // M_b comes from the mean partials the prep kernel of the same step left in wk.mean_part.
 // bars == nullptr (Jacobian tape, below): no cotangents -- u = 0, mu = 0 and kappa = 1 / sqrt(det R_ab).
 __device__ void bwd_head(const MMModel& md, const MMWork& wk, const double* __restrict__ bars, int h,
-                         double* __restrict__ head, double* sm) {
+                         double* __restrict__ head, double* sm, const double* __restrict__ in_s = nullptr) {
+    if (!in_s) in_s = wk.in_s;
     const int D = md.D, E = md.E, t = threadIdx.x, nc = 2 * D, nI = D * D;
     double* G0 = sm;               // [D][2D]
     double* G1 = G0 + D * nc;      // [D][2D]
@@ -76,8 +77,8 @@ __device__ void bwd_head(const MMModel& md, const MMWork& wk, const double* __re
         const int r = e / nc, c = e - r * nc;
         double v;
         if (c >= D) v = (c - D == r) ? 1.0 : 0.0;
-        else if (h < E) v = wk.in_s[r * D + c] + (r == c ? lam[r] : 0.0);        // s + Lambda_a^2
-        else v = lam[r] * wk.in_s[r * D + c] + (r == c ? 1.0 : 0.0);             // I + Lambda_ab s
+        else if (h < E) v = in_s[r * D + c] + (r == c ? lam[r] : 0.0);        // s + Lambda_a^2
+        else v = lam[r] * in_s[r * D + c] + (r == c ? 1.0 : 0.0);             // I + Lambda_ab s
         G0[e] = v;
     }
     double det;
@@ -110,6 +111,14 @@ __device__ void bwd_head(const MMModel& md, const MMWork& wk, const double* __re
             o[nI + D + 1] = 0.0;
         }
     }
+}
+
+// The step's D x D inverses as a launch of their own, batched over horizon steps (blockIdx.y; the input covariance from the
+// step's tape record): the one-launch small step has no sweep launch whose spare workgroups could compute them.
+__global__ __launch_bounds__(256) void k_mm_bwd_head(MMModel md, MMWork wk, double* __restrict__ head, long head_stride,
+                                                     const double* __restrict__ in_s, long in_s_stride) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    bwd_head(md, wk, nullptr, blockIdx.x, head + (long)blockIdx.y * head_stride, sm, in_s + (long)blockIdx.y * in_s_stride);
 }
 
 // NMT: 16-row tiles of the moment product (rows d = 0..D: w_j and the ones), NMT = ceil((D + 1) / 16); KC <= 4 keeps four
@@ -634,6 +643,33 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
     double* Gs = sm;                 // [GW][GW]  this chunk's share of G
     double* Gc = Gs + GW * GW;       // [GW][GW]  ... and of the column side
     double* red = Gc + GW * GW;      // [4][256]
+    if (njs == 0) {
+        // one-launch small step (prep_device.h: small_sweep): every chunk-workgroup of the pair left TWO blocks, G and Gc (the
+        // column side is already contracted); nrb = chunks per pair.  Chunk rc of nrc adds its share, as below.
+        const double* g0s = gpart + (long)pl * nrb * 512;
+        if (t < 256) {
+            const int cnt = (nrb - rc + nrc - 1) / nrc;
+            const int d = ((t >> 4) & 3) + 4 * (t >> 6), e = t & 15;
+            Gs[d * GW + e] = rc < nrb ? sum_strided<4>(g0s + (long)rc * 512 + t, (long)nrc * 512, cnt) : 0.0;
+            Gc[d * GW + e] = rc < nrb ? sum_strided<4>(g0s + (long)rc * 512 + 256 + t, (long)nrc * 512, cnt) : 0.0;
+        }
+        __syncthreads();
+        const int nI2 = D * D;
+        double* o2 = part + ((long)pl * nrc + rc) * (1 + D + nI2);
+        for (int e2 = t; e2 < 1 + D + nI2; e2 += 256) {
+            double v;
+            if (e2 == 0) {
+                v = Gs[D * GW + D];
+            } else if (e2 <= D) {
+                v = Gs[(e2 - 1) * GW + D] + Gc[(e2 - 1) * GW + D];
+            } else {
+                const int d = (e2 - 1 - D) / D, e = (e2 - 1 - D) - d * D;
+                v = (Gs[d * GW + e] + Gs[e * GW + d]) + 0.5 * (Gc[d * GW + e] + Gc[e * GW + d]);
+            }
+            o2[e2] = v;
+        }
+        return;
+    }
     // (i) the sweep's blocks
     const int nparts = njs * nrb;
     const double* g0 = gpart + (long)pl * nparts * (NB2 * 256);
@@ -1003,7 +1039,8 @@ size_t mm_bwd_gpart_size(int npad, int P, int D) {   // one (16 NMT)^2 block per
     int njs, nrb;
     mm_bwd_geometry(npad, 1, &njs, &nrb);
     const int nmt = (D + 16) / 16;
-    return (size_t)std::max(1, P) * 4 * nrb * nmt * nmt * 256;
+    const size_t small = npad <= 256 ? (size_t)16 * 512 : 0;   // one-launch small step: up to 16 workgroups per pair, two blocks each
+    return (size_t)std::max(1, P) * std::max((size_t)4 * nrb * nmt * nmt * 256, small);
 }
 size_t mm_bwd_cpart_size(int npad, int P) {
     int njs, nrb;
@@ -1039,11 +1076,15 @@ void launch_mm_sweep(hipStream_t st, const MMModel& md, const MMWork& wk, double
 // nothing of the forward chain waits for them, so they run at throughput instead of paying their latency per step.
 // Per-step arrays: rowmom / cpart / head / part advance by the sizes above, in_m is the head of the step's tape record.
 void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, int H, const double* rowmom, const double* cpart,
-                          const double* head, double* part, const double* tape, size_t tape_stride, double* jrec) {
+                          double* head, double* part, const double* tape, size_t tape_stride, double* jrec, int small_nch) {
     if (H <= 0) return;
     const int P = wk.PL, E = md.E, D = md.D;
     int njs, nrb;
     mm_bwd_geometry(md.npad, md.E * (md.E + 1) / 2, &njs, &nrb);   // (the model's pairs, not this rank's: the split of a pair's sums is the same on every rank count)
+    if (small_nch > 0) {   // the steps ran as one launch each (small_sweep): two blocks per chunk-workgroup, and the inverses are still to be made
+        njs = 0;
+        nrb = small_nch;
+    }
     const int LD = D | 1, nI = D * D, D1 = D + 1, LD1 = D1 | 1, NS = mm_jac_ns(D);
     const int nrc = mm_bwd_rc(md.npad);
     BwdBatch bb;
@@ -1055,6 +1096,9 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
     bb.in_m_stride = (long)tape_stride;
     double* mpart = part + (size_t)P * nrc * (1 + D + nI);
     (void)LD;
+    if (small_nch > 0)
+        hipLaunchKernelGGL(k_mm_bwd_head, dim3(E + P, H), dim3(256), sizeof(double) * ((size_t)4 * nI + D), st, md, wk, head, bb.head, tape + D,
+                           (long)tape_stride);
     const size_t lds_post = sizeof(double) * std::max((size_t)2 * 256 + 4 * 256, (size_t)nI + 64 * LD1 + 64 + NS / 2 + 2);
     hipLaunchKernelGGL((k_mm_bwd_post<1, 1>), dim3(P + E, nrc, H), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
                        head, mpart, 1, bb);   // (the Jacobian tape serves D <= 14)

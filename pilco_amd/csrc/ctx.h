@@ -235,6 +235,7 @@ struct RolloutPlan {
     int E = 0, D = 0, U = 0;
     double* jrec = nullptr;              // Jacobian tape (bwd.hip): the dynamics step runs launch_mm_jac and writes jrec[t]
     size_t jstride = 0;
+    int jsmall = 0;                      // > 0: the steps of this value-and-gradient rollout run as the one-launch small step (chunks per pair)
 };
 constexpr int PILCO_JAC_TOO_LARGE = -77;   // rollout_jtape: the per-step buffers would exceed the cap (caller falls back)
 int rollout_jtape_wait(pilco_ctx* ctx, int t);   // blocks until the records of step t have arrived

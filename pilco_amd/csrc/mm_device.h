@@ -48,6 +48,10 @@ __device__ __forceinline__ void store_wt(double* p, double v) {
 // them) rules the overlap out at no instruction cost; tools/mfma_overlap_check.py scans the generated code
 // (tests/test_build_isa.py).
 #define MFMA_KEEP_ALIVE(x_) asm volatile("" ::"v"(x_))
+// ... tied to the MFMA's result, for places where the scheduler moves the plain form AHEAD of the MFMA (seen in the unrolled
+// chains of the one-launch small step): the empty asm reads and "writes" the result, so it cannot come before the MFMA,
+// and it uses both sources, so they stay alive until then.
+#define MFMA_PIN(res_, a_, b_) asm volatile("" : "+v"(res_) : "v"(a_), "v"(b_))
 // The same compiler does not always insert the wait states between a v_mfma_f64_16x16x4_f64 and a VALU read of its result
 // (it does in the forward pair kernel: 7 + destination-pair-index slots; in the wide reverse-sweep instantiations a
 // v_max read the LAST destination pair in the very next slot and got the accumulator from before the last k-step).

@@ -52,7 +52,10 @@ struct MMWork {
     unsigned long long* dbg;  // optional [32] phase timestamps (100 MHz wall clock) of the last prep / glue launch
     int abl;             // experiment switches (PILCO_ABL, tools only; 0 in product use)
     int sk_ud, sk_uo;    // cost units of a diagonal / off-diagonal column step (diagonal steps also stream iK)
-    int fuse_pair;       // small models: the operand launch's pair workgroups also evaluate their pair sums (pair_part [PL][NCH][2]); no pair launch
+    int fuse_pair;       // small models: the operand launch's pair workgroups also evaluate their pair sums (pair_part [PL][NCH][2]); no pair launch.  2: ... as the reverse sweep (value-and-gradient rollouts)
+    double* sw_gpart;    // fuse_pair == 2: this step's [PL][NT][2][256] blocks (G | Gc per workgroup)
+    int NCS;             // fuse_pair with LDS-resident operands: column splits per (pair, row chunk) -- the launch spreads a small model over
+                         // the CUs it would leave idle (grid y = NCH * NCS, NT = NCH * NCS partials per pair); 1 elsewhere
     const double* exp_tab;    // [n] 2^(j/n), n = mm_exp_table_size(), for the table-driven fp64 exp of the pair kernel
     int PL, EL, P, KP, NCH, NCHM, NT, SEG, OUTOFF, rank, nranks;  // NCH / NCHM: row chunks of the pair / mean-part prep workgroups; OUTOFF: offset of the output records inside a segment
 };
@@ -210,8 +213,10 @@ void mm_bwd_geometry(int npad, int Pg, int* njs, int* nrb);   // Pg: pairs of th
 // jrec [H][mm_jac_rec_size] (part: [H][mm_jac_part_size] scratch; tape: the rollout tape, whose records start with m_j).
 void launch_mm_sweep(hipStream_t st, const MMModel& md, const MMWork& wk, double* rowmom, double* cpart, double* head,
                      double* npart);
+// small_nch > 0: the steps ran as the one-launch small step (chunks per pair = small_nch): gpart holds two blocks per
+// chunk-workgroup, cpart is unused and the inverses (head) are made here
 void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, int H, const double* rowmom, const double* cpart,
-                          const double* head, double* part, const double* tape, size_t tape_stride, double* jrec);
+                          double* head, double* part, const double* tape, size_t tape_stride, double* jrec, int small_nch = 0);
 size_t mm_jac_rec_size(int D, int E, int P);
 size_t mm_jac_part_size(int D, int E, int P, int npad);
 size_t mm_jac_rowmom_size(int npad, int P);

@@ -47,7 +47,8 @@ void launch_mm_prep(hipStream_t st, const MMModel& md, const MMWork& wk, const P
     PrepReward none{};
     const PrepReward& r = pr ? *pr : none;
     const int spare = wk.EL * wk.NCHM + (r.n > 0 ? 1 : 0);   // mean-part workgroups, then the reward workgroup
-    dim3 grid(wk.PL + (spare + wk.NCH - 1) / wk.NCH, wk.NCH);
+    const int gy = wk.NCH * (wk.fuse_pair && wk.NCS > 1 ? wk.NCS : 1);   // (small step: column splits, see MMWork::NCS)
+    dim3 grid(wk.PL + (spare + gy - 1) / gy, gy);
     const int D = md.D;
     const size_t lds_rw = r.n > 0 ? sizeof(double) * ((size_t)r.E + (size_t)r.E * r.E + reward_lds_doubles(r.E)) : 0;
     GlueArgs gnone{};

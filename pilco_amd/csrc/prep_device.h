@@ -10,7 +10,9 @@ constexpr int PREP_TAB_DOUBLES = FEXP_TN + 8;   // LDS tail of the operand kerne
 __host__ __device__ constexpr size_t prep_region_doubles(int DT) {   // the operand work's own LDS region (pair / mean workgroups), before that tail
     // (the point stage of a pair workgroup, 256 (DT + 1), or -- one-launch small step with its operands in LDS, KP <= 16 --
     // the operands of 64 rows and 256 columns and v: KP (64 + 256) + 256)
-    const size_t stage = 256 * (size_t)(DT + 1), ops = mm_kp(DT) <= 16 ? (size_t)mm_kp(DT) * (64 + 256) + 256 : 0;
+    // (value-and-gradient form of that step, D <= 14: + z of the rows 16 x 64, beta_b 256, column-sum slices 8 x 64)
+    const size_t stage = 256 * (size_t)(DT + 1),
+                 ops = mm_kp(DT) <= 16 ? (size_t)mm_kp(DT) * (64 + 256) + 256 + (DT <= 14 ? 16 * 64 + 256 + 8 * 64 : 0) : 0;
     const size_t pair_blk = (size_t)4 * DT + 2 * (size_t)DT * DT + 4 + (stage > ops ? stage : ops);
     const size_t mean_blk = (size_t)2 * DT + 2 * (size_t)DT * DT + 4 + 9 * (size_t)(DT + 1) + 2 * (size_t)DT + 512 * (size_t)(DT + 2);
     return pair_blk > mean_blk ? pair_blk : mean_blk;
@@ -166,6 +168,197 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
     DBG_STAMP(wk, 44, dbgm);
 }
 
+// Value-and-gradient form of the one-launch small step (DESIGN.md sections 4.4, 9): the reverse sweep of bwd.hip for ONE
+// workgroup = (local pair, 64 rows) x ALL columns, operands in LDS (Al [KP][64], Bl [KP][256], vl), eight waves = two 32-row
+// groups x four column quarters.  Per 16 x 16 tile as k_mm_bwd_pair: exponent tile transposed (column operand as MFMA A),
+// W.L as the A operand of the moment product with [w_j | 1] (rows along the result registers), column sums by DPP row sums
+// into per-wave LDS slices.  Then the row side's epilogue G (header of bwd.hip) and -- the workgroup has the sums of ITS
+// rows for every column -- the column side Gc = sum_j c_j [w_j | 1] [w_j | 1]^T right here (linear in c_j: the chunks of a
+// pair add up), both on the matrix cores.  Out: two 16 x 16 blocks per workgroup (G | Gc) and N_ab's share for the link.
+// Diagonal pairs: tiles at / right of the diagonal only (weight 2 right of it).
+template <int DT>
+__device__ __forceinline__ void small_sweep(const MMModel& md, const MMWork& wk, int pl, int item, int i_begin, int c_begin, int ncols, const double* Al, const double* Bl,
+                                            const double* vl, const double* Zl, double* bbl, double* csl, double* tail, bool act) {
+    constexpr int KC = mm_kp(DT) / 4;
+    constexpr bool VSEP = mm_vsep(DT);
+    const int D = md.D, npad = md.npad, t = threadIdx.x, lane = t & 63, lr = lane >> 4, lc = lane & 15;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const double* tab = tail;          // exp table (k_mm_prep loaded it at its head)
+    int a, b;
+    local_pair_ab(wk, md.E, pl, a, b);
+    const bool diag = (a == b);
+    const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
+    const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
+    const double* iKa = (diag && md.iK) ? md.iK + mm_ik_blk(md, a) * npad * npad : nullptr;
+    if (act)
+        for (int e = t; e < 256; e += 512) bbl[e] = e < npad ? beta_b[e] : 0.0;
+    for (int e = t; e < 8 * 64; e += 512) csl[e] = 0.0;   // (a diagonal pair's waves skip the tiles left of the diagonal)
+    __syncthreads();   // operands, z, beta_b in LDS
+    const int rg = w >> 2, cq = w & 3;                       // row group (32 rows), column quarter
+    const int i0l = 32 * rg, i0 = i_begin + i0l;
+    const int cpw = ncols / 4, jb = c_begin + cpw * cq, je = jb + cpw;   // (ncols: 64, 128 or 256 -- whole 16-column tiles per wave)
+    double rf[2][KC], brow[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        brow[rt] = beta_a[i0 + 16 * rt + lc];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) rf[rt][c] = Al[(4 * c + lr) * 64 + i0l + 16 * rt + lc];
+    }
+    const __amdgpu_buffer_rsrc_t rIK = buf_rsrc_uniform(iKa ? iKa : beta_a);
+    unsigned ik_off[2][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) ik_off[rt][r] = ((unsigned)(lr + 4 * r) * (unsigned)npad + (unsigned)(i0 + 16 * rt + lc)) * 8u;
+    const int dsel = lc <= D ? lc : D;
+    d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+    double* myslice = csl + w * 64;
+    auto sweep = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;   // 0 off-diagonal, 1 diagonal with iK, 2 diagonal without (RBF policy GP)
+        // a wave has at most four column steps: ALL of its iK tiles are requested up front (one memory round trip for the
+        // workgroup instead of one per step on this latency chain; 64 of the 256 registers a wave may use here)
+        double ikv[4][2][4];
+        if (MODE == 1) {
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int j0 = jb + 16 * sidx;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ikv[sidx][rt][r] = (j0 < je && j0 >= i0) ? buf_ld(rIK, ik_off[rt][r], (unsigned)j0 * (unsigned)npad * 8u) : 0.0;
+            }
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int j0 = jb + 16 * sidx;
+            if (j0 >= je) break;
+            if (MODE != 0 && j0 < i0) continue;   // (wave-uniform) both row tiles lie below this column tile's mirror
+            double cf[KC], a2[4], bcol[4], vj[4];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) cf[c] = Bl[(4 * c + lr) * 256 + j0 + lc];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bcol[r] = bbl[j0 + lr + 4 * r];
+                vj[r] = VSEP ? vl[j0 + lr + 4 * r] : 0.0;
+                a2[r] = Bl[dsel * 256 + j0 + 4 * r + lr];
+            }
+            double csum[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int it = i0 + 16 * rt;
+                const double om = j0 > it ? 2.0 : (j0 == it ? 1.0 : 0.0);
+                d4 e = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    e = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[c], rf[rt][c], e, 0, 0, 0);   // e[r]: i = lc, j = j0 + lr + 4 r
+                    if (c == 0) MFMA_PIN(e, cf[0], rf[rt][0]);
+                }
+                MFMA_RESULT_FENCE(e);
+                double wl[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double l = fexp(VSEP ? e[r] + vj[r] : e[r], tab);
+                    if (MODE == 0) {
+                        wl[r] = bcol[r] * l;
+                        csum[r] = fma(brow[rt], l, csum[r]);
+                    } else {
+                        double wgt = brow[rt] * bcol[r];
+                        if (MODE == 1) wgt -= ikv[sidx][rt][r];
+                        wl[r] = (wgt * om) * l;
+                        csum[r] += wl[r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[r], a2[r], acc[rt], 0, 0, 0);
+                    MFMA_PIN(acc[rt], wl[r], a2[r]);   // (the step loop is unrolled: the first step's accumulator is the constant zero)
+                }
+            }
+            // column sums over the 16 lanes of a DPP row (this path is latency-bound, not issue-bound: plain row shifts)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = csum[r];
+                v = dpp_add<0x111, 0xf>(v);
+                v = dpp_add<0x112, 0xf>(v);
+                v = dpp_add<0x114, 0xf>(v);
+                v = dpp_add<0x118, 0xf>(v);
+                if (lc == 15) myslice[j0 - jb + lr + 4 * r] = v;
+            }
+        }
+    };
+    if (act) {
+        if (!diag) sweep(std::integral_constant<int, 0>{});
+        else if (iKa) sweep(std::integral_constant<int, 1>{});
+        else sweep(std::integral_constant<int, 2>{});
+    }
+    // ---- row side: G[d][e] = sum_i beta~_i [z_i | 1]_d [m_i + r_i z_i / 2 | r_i]_e over the wave's 32 rows
+    d4 G = {0.0, 0.0, 0.0, 0.0}, Gc = {0.0, 0.0, 0.0, 0.0};
+    const int rlane = (lane & 48) | (D & 15);
+    if (act) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int il = i0l + 16 * rt + 4 * r + lr, i = i_begin + il;
+                const bool valid = i < md.n;
+                const double zt = (valid && lc <= D) ? Zl[lc * 64 + il] : 0.0;   // (row D of Zl: ones)
+                const double bs = !valid ? 0.0 : (diag ? 1.0 : beta_a[i]);
+                const double ri = __shfl(acc[rt][r], rlane);
+                const double x = acc[rt][r];
+                const double mp = bs == 0.0 ? 0.0 : (lc < D ? fma(0.5 * ri, zt, x) : x);
+                const double za = zt * bs;
+                G = __builtin_amdgcn_mfma_f64_16x16x4f64(za, mp, G, 0, 0, 0);
+                MFMA_PIN(G, za, mp);
+            }
+    }
+    __syncthreads();   // every wave's column-sum slice is complete
+    // ---- column side: the workgroup's 256 columns over the eight waves (32 each); c_j = the two row groups' sums
+    if (act) {
+        const int cw8 = ncols / 8;   // columns per wave here: 8, 16 or 32
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (4 * k >= cw8) break;
+            const int jl = cw8 * w + 4 * k + lr, j = c_begin + jl;   // column of this lane in K-step k
+            const int q = jl / cpw;                                  // its column quarter (the slices are per quarter)
+            double cj = 0.0, wt = 0.0;
+            if (j < md.n) {
+                const int jj = jl - cpw * q;
+                cj = (csl[q * 64 + jj] + csl[(4 + q) * 64 + jj]) * (diag ? 1.0 : bbl[j]);
+                wt = lc <= D ? Bl[lc * 256 + j] : 0.0;          // [w_j | 1] (row D of Bl: ones)
+            }
+            const double ca = cj * wt;
+            Gc = __builtin_amdgcn_mfma_f64_16x16x4f64(ca, wt, Gc, 0, 0, 0);
+            MFMA_PIN(Gc, ca, wt);
+        }
+    }
+    __syncthreads();   // Bl is free: the eight waves' blocks are added there in wave order
+    double* red = const_cast<double*>(Bl);   // [8][256]
+    double* gout = wk.sw_gpart + ((long)pl * wk.NT + item) * 512;
+    const int tN = ((D & 15) >> 2) * 64 + (D & 3) * 16 + (D & 15);   // entry (D, D) of a block
+    for (int blk = 0; blk < 2; ++blk) {
+        if (blk) __syncthreads();
+        d4 v4 = blk ? Gc : G;
+        MFMA_RESULT_FENCE(v4);
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[w * 256 + r * 64 + lane] = v4[r];
+        }
+        __syncthreads();
+        if (t < 256) {
+            double v = red[t];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) v += red[k * 256 + t];
+            gout[blk * 256 + t] = v;
+            if (blk == 0 && t == tN) {   // N_ab's share of this chunk, in the tile-partial layout the link packs
+                double* o = wk.pair_part + ((long)pl * wk.NT + item) * 2;
+                store_wt(o, v);
+                store_wt(o + 1, 0.0);
+            }
+        }
+    }
+}
+
 // The per-workgroup work of the operand launch AFTER the serial link: the operands of one (local pair, row chunk), or the
 // mean part of one (local output, row chunk), or the reward -- selected by the item coordinates (bx, by) of a gx x gy item
 // grid (k_mm_prep: its own block index; the persistent rollout kernel: a fixed item per workgroup).  NTHR: threads of
@@ -224,7 +417,7 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: the role branches below are scalar branches
     const bool act = (NTHR == 512) || t < 512;   // a host workgroup wider than 512 threads: the extra waves only keep the barriers
     const int grp = t >> 8, tl = t & 255;
-    const int pl = bx, ch = by;
+    const int pl = bx, ch = by % wk.NCH, cs = by / wk.NCH;   // (cs: column split of the one-launch small step, 0 elsewhere)
     const bool dbg0 = (t == 0 && pl == 0 && ch == 0);
     DBG_STAMP(wk, 0, dbg0);
     if (wk.dbg && t == 0) wk.dbg[64 + 2 * (by * gx + bx)] = wall_clock64();
@@ -257,9 +450,17 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
     // ... and with 64 rows per workgroup and a contraction of at most 16 rows the operands stay in LDS (the stage's place,
     // once every thread has taken its point from it): Al [KP][64] | Bl [KP][npad] | vl [npad]
     const bool fplds = fpair && mm_kp(DT) <= 16 && npad / wk.NCH == 64;
+    // ... and over column splits (MMWork::NCS): this workgroup's share of the pair's columns
+    const int ncsg = (fplds && wk.NCS > 1) ? wk.NCS : 1, ncols = npad / ncsg, c_begin = cs * ncols, c_end = c_begin + ncols;
     double* Al = zst;
     double* Bl = Al + mm_kp(DT) * 64;
     double* vl = Bl + mm_kp(DT) * 256;
+    // value-and-gradient form (wk.fuse_pair == 2, small_sweep below): z_i of the workgroup's rows [16][64] (row D: ones),
+    // beta_b of all columns, per-wave column-sum slices
+    const bool fsweep = fplds && DT <= 14 && wk.fuse_pair == 2;
+    double* Zl = vl + 256;
+    double* bbl = Zl + 16 * 64;
+    double* csl = bbl + 256;
     const int st_begin = fpair ? 0 : i_begin, st_end = fpair ? npad : i_end;
     if (w != 0 && act) {
         const int idx = (w - 1) * 64 + lane;   // 0..447
@@ -296,7 +497,7 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
         }
         if (lane == 0) {
             s_sc[0] = 1.0 / sqrt(det);
-            if (ch == 0) store_wt(&wk.pair_isdet[pl], s_sc[0]);
+            if (by == 0) store_wt(&wk.pair_isdet[pl], s_sc[0]);
         }
     }
     __syncthreads();
@@ -339,6 +540,12 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
                 Al[D * 64 + il] = uv;
                 if (!wk.vsep) Al[(D + 1) * 64 + il] = one;
                 for (int k = D + 2; k < KP; ++k) Al[k * 64 + il] = 0.0;
+                if (fsweep) {   // z_i = zeta_i / l_a^2 (what side 0 calls x) and the ones, for the row side's epilogue
+#pragma unroll
+                    for (int r = 0; r < DT; ++r)
+                        if (r < D) Zl[r * 64 + il] = x[r];
+                    Zl[D * 64 + il] = one;
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < DT; ++r)
@@ -366,7 +573,7 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
         }
     };
     if (fplds) {   // (workgroup-uniform) every thread takes its point from the stage, THEN the operands overwrite it
-        const int r_begin = side ? 0 : i_begin, r_end = side ? npad : i_end;
+        const int r_begin = side ? c_begin : i_begin, r_end = side ? c_end : i_end;
         const bool has = act && r_begin + tl < r_end;
         const int i = r_begin + tl;
         double zeta[DT];
@@ -399,7 +606,9 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
     // thread per point -- ALL npad columns of the column operand (every row chunk of the pair computes them: the same
     // values to the same addresses), so after a barrier its eight waves evaluate the (rows) x (all columns) block with
     // pair_wave, the arithmetic of the pair kernels, and publish ONE partial in the tile-partial layout the link packs.
-    if (fpair) {   // (compiled into the single-rank fused heads only)
+    if (fsweep) {
+        small_sweep<DT>(md, wk, pl, by, i_begin, c_begin, ncols, Al, Bl, vl, Zl, bbl, csl, sm + prep_region_doubles(DT), act);
+    } else if (fpair) {   // (compiled into the single-rank fused heads only)
         constexpr int KCP = mm_kp(DT) / 4;
         constexpr bool VSP = mm_vsep(DT);
         const double* tab = sm + prep_region_doubles(DT);   // loaded at the head of the kernel (k_mm_prep), long ago
@@ -411,8 +620,8 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
         const int nrg = rpc / (16 * PAIR_RT), ncs = max(1, 8 / nrg);   // row groups of 32 rows x column splits = waves at work
         double val = 0.0;
         if (act && w < nrg * ncs) {
-            const int rg = w / ncs, cq = w - rg * ncs, ct = npad / 16;
-            const int i0 = i_begin + 16 * PAIR_RT * rg, jb = 16 * (ct * cq / ncs), je = 16 * (ct * (cq + 1) / ncs);
+            const int rg = w / ncs, cq = w - rg * ncs, ct = ncols / 16;   // (ncols = npad unless the pair's columns are split over workgroups)
+            const int i0 = i_begin + 16 * PAIR_RT * rg, jb = c_begin + 16 * (ct * cq / ncs), je = c_begin + 16 * (ct * (cq + 1) / ncs);
             const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
             const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
             const double* iKa = diag ? md.iK + mm_ik_blk(md, a) * npad * npad : nullptr;
@@ -429,7 +638,7 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
         if (act && lane == 0) wred[w] = val;
         __syncthreads();
         if (t == 0) {
-            double* out = wk.pair_part + ((long)pl * wk.NT + ch) * 2;
+            double* out = wk.pair_part + ((long)pl * wk.NT + by) * 2;
             store_wt(out, ((wred[0] + wred[1]) + (wred[2] + wred[3])) + ((wred[4] + wred[5]) + (wred[6] + wred[7])));
             store_wt(out + 1, 0.0);   // the trace term is already folded into out[0]
         }

@@ -232,6 +232,32 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
 // Jacobian tape: the sums, moments and records of steps [t0, t1) in two launches behind the chain (rollout_jtape enqueues
 // them per chunk of steps, last steps first, each followed by its download: the host's reverse sweep works on one chunk
 // while the device finishes the next)
+// Does a value-and-gradient rollout of this plan run its steps as the one-launch small step (small_sweep)?  Returns the
+// workgroups per pair (row chunks x column splits) or 0.  (The same conditions enqueue_rollout_steps applies, plus those of its fused-head branch.)
+static bool fused_heads_fit(pilco_ctx* ctx, const RolloutPlan& plan);
+static int device_cus_of(int device);
+// Column splits of the one-launch small step (MMWork::NCS): with 64-row workgroups whose operands stay in LDS, a pair's
+// columns are dealt over up to four workgroups as long as the whole launch stays ONE round of the chip (one workgroup per
+// CU) -- a small model with few outputs would otherwise leave most CUs idle while 40 of them work through the pair sums.
+static int small_col_splits(pilco_ctx* ctx, const Slot& s, bool rew) {
+    if (s.npad / s.wk.NCH != 64 || s.wk.KP > 16) return 1;
+    static const int forced = getenv("PILCO_SMALL_NCS") ? atoi(getenv("PILCO_SMALL_NCS")) : 0;   // (tools: A/B)
+    const int cus = device_cus_of(ctx->device), spare = s.wk.EL * s.wk.NCHM + (rew ? 1 : 0);
+    int ncs = 1;
+    while (ncs * 2 <= s.wk.NCH && ncs * 2 <= 4 && s.wk.PL * s.wk.NCH * ncs * 2 + spare <= cus) ncs *= 2;
+    if (forced > 0 && forced <= s.wk.NCH && (forced & (forced - 1)) == 0 && forced <= 4) ncs = forced;
+    return ncs;
+}
+static int jac_small_chunks(pilco_ctx* ctx, const RolloutPlan& plan, int H) {
+    const Slot& s = ctx->slot[0];
+    const int D = s.D, dtk = D <= 4 ? 4 : D <= 6 ? 6 : D <= 8 ? 8 : D <= 10 ? 10 : D == 11 ? 11 : D <= 12 ? 12 : D <= 14 ? 14 : D <= 16 ? 16 : 32;
+    const bool rbf = plan.g.pol_kind == PILCO_POLICY_RBF;
+    if (!ctx->fuse_small || !ctx->fused || ctx->nranks != 1 || ctx->comm || s.wk.PL <= 0 || H <= 0 || ctx->time_pairs) return 0;
+    if (D > 14 || s.npad > 256 || s.npad / s.wk.NCH != 64 || s.wk.KP != mm_kp(dtk) || (s.wk.vsep != 0) != mm_vsep(dtk) || s.wk.KP > 16) return 0;
+    if (rbf && !plan.g.pol_inline) return 0;
+    if (!fused_heads_fit(ctx, plan)) return 0;
+    return s.wk.NCH * small_col_splits(ctx, s, plan.g.n_rewards > 0 && !MM_ABL(s.wk, 8));
+}
 static void jac_finish_range(pilco_ctx* ctx, const RolloutPlan& plan, int t0, int t1) {
     Slot& s = ctx->slot[0];
     const int D = plan.D, E = plan.E, P = s.wk.PL;
@@ -239,7 +265,8 @@ static void jac_finish_range(pilco_ctx* ctx, const RolloutPlan& plan, int t0, in
     const size_t o = (size_t)t0;
     launch_mm_jac_finish(ctx->st, model_of(s), s.wk, t1 - t0, s.jac_rowmom.p + o * mm_jac_rowmom_size(s.npad, P),
                          s.jac_cpart.p + o * mm_jac_cpart_size(s.npad, P, s.wk.EL), s.jac_head.p + o * mm_jac_head_size(D, E, P),
-                         s.jac_part.p + o * mm_jac_part_size(D, E, P, s.npad), plan.g.tape + o * TS, TS, plan.jrec + o * plan.jstride);
+                         s.jac_part.p + o * mm_jac_part_size(D, E, P, s.npad), plan.g.tape + o * TS, TS, plan.jrec + o * plan.jstride,
+                         plan.jsmall);
 }
 int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev) {
     return enqueue_rollout_steps(ctx, plan, H, pair_ev);
@@ -304,14 +331,18 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
         // this input dimension carries the pair arithmetic of ONE contraction depth (that of D = DT); the workgroup's rows must
         // be whole 32-row groups and one thread per point must cover the columns.
         const int dtk = s.D <= 4 ? 4 : s.D <= 6 ? 6 : s.D <= 8 ? 8 : s.D <= 10 ? 10 : s.D == 11 ? 11 : s.D <= 12 ? 12 : s.D <= 14 ? 14 : s.D <= 16 ? 16 : 32;
-        const bool small = ctx->fuse_small && !jac && ctx->variant == 0 && s.npad <= 256 && (s.npad / wk0.NCH) % 32 == 0 &&
-                           wk0.KP == mm_kp(dtk) && (wk0.vsep != 0) == mm_vsep(dtk) && !pair_ev && !MM_ABL(s.wk, 255);
+        // Value-and-gradient rollouts (the Jacobian tape) take the same road when the workgroup's operands stay in LDS (64-row
+        // chunks, KP <= 16; the tape serves D <= 14): the pair workgroups run the reverse sweep of their block (small_sweep).
+        const bool small_ok = ctx->fuse_small && s.npad <= 256 && (s.npad / wk0.NCH) % 32 == 0 && wk0.KP == mm_kp(dtk) &&
+                              (wk0.vsep != 0) == mm_vsep(dtk) && !pair_ev && !MM_ABL(s.wk, 255);
+        const bool small = small_ok && (jac ? (plan.jsmall > 0) : ctx->variant == 0);
         if (small)
             for (int k = 0; k < 2; ++k) {
-                wkb[k].fuse_pair = 1;
+                wkb[k].fuse_pair = jac ? 2 : 1;
                 wkb[k].sk_waves = 0;           // the link packs tile partials: one per (pair, row chunk)
-                wkb[k].NT = wk0.NCH;
-                wkb[k].pair_part = s.w_fpart.p + (size_t)k * std::max(wk0.PL, 1) * wk0.NCH * 2;
+                wkb[k].NCS = small_col_splits(ctx, s, rew);
+                wkb[k].NT = wk0.NCH * wkb[k].NCS;
+                wkb[k].pair_part = s.w_fpart.p + (size_t)k * std::max(wk0.PL, 1) * wk0.NCH * 4 * 2;
             }
         size_t evi = 0;
         for (int h = 0; h < H; ++h) {
@@ -332,6 +363,12 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
                 pr.E = E;
                 for (int i = 0; i < g.n_rewards; ++i) pr.rw[i] = g.rw[i];
                 pr.reward = g.reward;
+            }
+            if (small && jac) {
+                MMWork wh = wkb[h & 1];
+                wh.sw_gpart = s.jac_rowmom.p + (size_t)h * j_rm;
+                launch_mm_prep(ctx->st, md, wh, rew ? &pr : nullptr, &gh);
+                continue;
             }
             launch_mm_prep(ctx->st, md, wkb[h & 1], rew ? &pr : nullptr, &gh);
             if (small) continue;
@@ -1263,6 +1300,7 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     const bool jdirect = !sharded && getenv("PILCO_JAC_COPY") == nullptr;
     plan.jrec = jdirect ? h_jrec : ctx->jrec.p;
     plan.jstride = JS;
+    plan.jsmall = sharded ? 0 : jac_small_chunks(ctx, plan, H);
     double* h_misc = h_jrec + (size_t)H * JSg;
     double* h_all = h_misc + 8;                          // sharded: [W][H][PLcap * recp | E * reco]
     for (int attempt = 0; attempt < 2; ++attempt) {

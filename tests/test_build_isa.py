@@ -19,7 +19,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("unit", ["pair", "bwd", "linalg", "persist", "prep_dt_b"])   # prep_dt_b: the heads for D = 10, 11, whose one-launch small step carries the pair arithmetic
+@pytest.mark.parametrize("unit", ["pair", "bwd", "linalg", "persist", "prep_dt_a", "prep_dt_b"])   # prep_dt_a, _b: the heads for D <= 11, whose one-launch small step carries the pair and sweep arithmetic
 def test_mfma_chains_have_no_register_overlap_and_no_early_result_reads(unit, tmp_path):
     src = os.path.join(ROOT, "pilco_amd", "csrc", unit + ".hip")
     asm = str(tmp_path / (unit + ".s"))
