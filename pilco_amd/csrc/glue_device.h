@@ -65,6 +65,17 @@ __device__ __forceinline__ void glue_lds_carve(const GlueArgs& g, double* sm, Gl
     L.o_mp = L.o_seg + seg_n;
 }
 
+// Quotient and remainder of a small non-negative index (e < 2^22) by a positive divisor: float reciprocal and a one-step fix-up,
+// a third of the instructions of the compiler's signed 32-bit division (~30 dependent VALU operations, 0.1 us of a lone wave
+// each) -- the link indexes its small matrices by flat thread indices in every phase, dozens of divisions on the step's serial path.
+__device__ __forceinline__ int idiv_s(int e, int d, int& rem) {
+    int q = (int)((float)e * __builtin_amdgcn_rcpf((float)d));   // (v_rcp_f32: 1 ulp, the fix-up below covers it)
+    int r = e - q * d;
+    q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+    rem = e - q * d;
+    return q;
+}
+
 // Batched global -> LDS copies: up to six segments are treated as one index space; every thread requests all its
 // elements (MAXV per round) before the first one is consumed, so the whole batch costs ONE memory round trip instead
 // of one per segment (the first version copied segment after segment: ~1 us each on this serial path).
@@ -134,7 +145,8 @@ __device__ __forceinline__ void squash_inplace(const GlueLds& L, int U, const do
             double arg;
             int fn;   // 0 exp, 1 cos, 2 sin, 3 unused slot
             if (q < U * U) {
-                const int u = q / U, v = q - u * U;
+                int v;
+                const int u = idiv_s(q, U, v);
                 const double lq = -(L.su[u * U + u] + L.su[v * U + v]) / 2.0;
                 const double suv = L.su[q];
                 arg = (j == 0) ? lq : (j == 1) ? lq + suv : (j == 2) ? lq - suv : (j == 3) ? L.mu[u] - L.mu[v] : L.mu[u] + L.mu[v];
@@ -152,7 +164,8 @@ __device__ __forceinline__ void squash_inplace(const GlueLds& L, int U, const do
         for (int k = 0; k < 4; ++k) {
             const int e = t + k * (int)blockDim.x;
             if (e < U * U && e >= q0 && e < q1) {
-                const int u = e / U, v = e - u * U;
+                int v;
+                const int u = idiv_s(e, U, v);
                 const double* r = sc + 5 * (e - q0);
                 const double val = (r[1] - r[0]) * r[3] - (r[2] - r[0]) * r[4];
                 const double eu = maxact ? maxact[u] : 1.0, ev = maxact ? maxact[v] : 1.0;
@@ -165,7 +178,7 @@ __device__ __forceinline__ void squash_inplace(const GlueLds& L, int U, const do
             newC = eu * r[0] * r[1];
             newM = eu * r[0] * r[2];
         }
-        __syncthreads();
+        if (i0 + cap < 5 * nitems) __syncthreads();   // (another round overwrites the scratch; the stores below touch su / mu / cdiag only)
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -181,12 +194,20 @@ __device__ __forceinline__ void squash_inplace(const GlueLds& L, int U, const do
 
 // joint Gaussian of (x,u) from mx,sx,mu,su,cxu in LDS -> jm, js in LDS (pilco.py:141-144); the writer workgroup also
 // stores in_m, in_s, s1 (the next propagate's [s_x, s_x c_xu]) and the tape record
-__device__ __forceinline__ void write_joint(const GlueArgs& g, const GlueLds& L, bool writer) {
+// cdiag != nullptr: c_xu is still to be scaled by the squash's diagonal C (V @ C, controllers.py:35) -- done on the fly here,
+// product first as the separate pass rounds it, instead of in a phase of its own (a barrier and an LDS round trip of the link)
+__device__ __forceinline__ void write_joint(const GlueArgs& g, const GlueLds& L, bool writer, const double* cdiag = nullptr) {
     const int E = g.E, U = g.U, D = g.D, t = threadIdx.x;
     for (int e = t; e < E * U; e += blockDim.x) {  // sc = s_x c_xu  (E,U)
-        const int r = e / U, u = e - r * U;
+        int u;
+        const int r = idiv_s(e, U, u);
         double acc = 0.0;
-        _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.sx[r * E + k], L.cxu[k * U + u], acc);
+        if (cdiag) {
+            const double cd = cdiag[u];
+            _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.sx[r * E + k], L.cxu[k * U + u] * cd, acc);
+        } else {
+            _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.sx[r * E + k], L.cxu[k * U + u], acc);
+        }
         L.t1[e] = acc;
     }
     if (U > 0) __syncthreads();
@@ -197,7 +218,8 @@ __device__ __forceinline__ void write_joint(const GlueArgs& g, const GlueLds& L,
         if (writer) g.wk.in_m[t] = v;
     }
     for (int e = t; e < D * D; e += blockDim.x) {
-        const int r = e / D, c = e - r * D;
+        int c;
+        const int r = idiv_s(e, D, c);
         double v;
         if (r < E && c < E) v = L.sx[r * E + c];
         else if (r < E) v = L.t1[r * U + (c - E)];
@@ -249,6 +271,15 @@ __device__ __forceinline__ void mm_pack_issue(const MMWork& wk, int base, PackPr
 #pragma unroll
         for (int u = 0; u < 16; ++u)
             if (u < qw) pp.v[u] = src[(long)u * wk.sk_pls];
+    } else {   // tile partials (one-launch small step, reverse sweep, tiled pair kernel): the lane's first eight (value, trace) couples
+        const double* part = wk.pair_part + (long)k * wk.NT * 2;
+        const int q0 = (int)((long)wk.NT * gq / 4), q1 = (int)((long)wk.NT * (gq + 1) / 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (q0 + u < q1) {
+                pp.v[2 * u] = part[2 * (q0 + u)];
+                pp.v[2 * u + 1] = part[2 * (q0 + u) + 1];
+            }
     }
 }
 __device__ __forceinline__ void mm_pack_sum(const MMWork& wk, int base, const PackPre& pp, double& s0, double& s1) {
@@ -266,7 +297,13 @@ __device__ __forceinline__ void mm_pack_sum(const MMWork& wk, int base, const Pa
     } else {
         const double* part = wk.pair_part + (long)k * wk.NT * 2;
         const int q0 = (int)((long)wk.NT * gq / 4), q1 = (int)((long)wk.NT * (gq + 1) / 4);
-        for (int q = q0; q < q1; ++q) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)   // (requested by mm_pack_issue; same order of additions as the plain loop)
+            if (q0 + u < q1) {
+                s0 += pp.v[2 * u];
+                s1 += pp.v[2 * u + 1];
+            }
+        for (int q = q0 + 8; q < q1; ++q) {
             s0 += part[2 * q];
             s1 += part[2 * q + 1];
         }
@@ -294,7 +331,8 @@ __device__ __forceinline__ void mm_pack(const MMWork& wk, int D, int E, const Gl
     }
     const int W1 = 1 + D;
     for (int e = t; e < wk.EL * W1; e += blockDim.x) {   // M_a and V_a: sums of the chunk contributions
-        const int o = e / W1, idx = e - o * W1;
+        int idx;
+        const int o = idiv_s(e, W1, idx);
         double sum = 0.0;
         _Pragma("unroll 8") for (int ch = 0; ch < wk.NCHM; ++ch) sum += L.mp[(o * wk.NCHM + ch) * W1 + idx];
         if (writer) seg[wk.OUTOFF + e] = sum;
@@ -313,14 +351,16 @@ __device__ __forceinline__ void mm_assemble(const MMWork& wk, const double* src,
         if (writer) wk.out_M[a] = v;
     }
     for (int e = t; e < D * E; e += blockDim.x) {
-        const int d = e / E, a = e - d * E;
+        int a;
+        const int d = idiv_s(e, E, a);
         const double v = src[(a % wk.nranks) * wk.SEG + wk.OUTOFF + (a / wk.nranks) * (1 + D) + 1 + d];
         oV[e] = v;
         if (writer) wk.out_V[e] = v;
     }
     __syncthreads();
     for (int e = t; e < E * E; e += blockDim.x) {
-        const int a = e / E, b = e - a * E;
+        int b;
+        const int a = idiv_s(e, E, b);
         const int hi = a > b ? a : b, lo = a > b ? b : a;
         const int kk = pair_order_index(E, hi, lo);
         double v = src[(kk % wk.nranks) * wk.SEG + kk / wk.nranks];
@@ -362,7 +402,8 @@ __device__ __forceinline__ void xq_load_segments(const GlueArgs& g, double* seg_
     const unsigned long long epoch = xq_ld(g.xq) + (unsigned long long)g.xq_k + 1ULL;
     const unsigned long long* data = g.xq + xq_data_off(W) + (size_t)(epoch & 1ULL) * W * g.xq_cap;
     for (int e = threadIdx.x; e < W * SEG; e += blockDim.x) {
-        const int r = e / SEG, i = e - r * SEG;
+        int i;
+        const int r = idiv_s(e, SEG, i);
         seg_lds[e] = __longlong_as_double((long long)xq_ld(data + (size_t)r * g.xq_cap + i));
     }
 }
@@ -372,7 +413,8 @@ __device__ __forceinline__ void xq_push(const GlueArgs& g, const double* seg_lds
     const unsigned long long epoch = xq_ld(g.xq) + (unsigned long long)g.xq_k + 1ULL;
     const size_t off = (size_t)xq_data_off(W) + ((size_t)(epoch & 1ULL) * W + me) * g.xq_cap;
     for (int e = t; e < W * SEG; e += blockDim.x) {
-        const int r = e / SEG, i = e - r * SEG;
+        int i;
+        const int r = idiv_s(e, SEG, i);
         __hip_atomic_store(g.xq_peers[r] + off + i, (unsigned long long)__double_as_longlong(seg_lds[i]), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -392,7 +434,7 @@ __device__ __forceinline__ void xq_push(const GlueArgs& g, const double* seg_lds
 // Every reduction is done by threads 0..255 in a fixed order, whatever the workgroup size: all workgroups of a head -- and
 // k_glue -- produce the same bits.
 struct RbfInlineLayout {
-    int ctr, bet, il, var, aug0, aug1, piv, T, Q, det, pt, red, total;
+    int ctr, bet, il, var, lvar, aug0, aug1, piv, T, Q, det, pt, red, total;
 };
 __host__ __device__ inline RbfInlineLayout rbf_inline_layout(int E, int U, int bf) {
     const int P = U * (U + 1) / 2, nmat = U + P;
@@ -402,6 +444,7 @@ __host__ __device__ inline RbfInlineLayout rbf_inline_layout(int E, int U, int b
     l.bet = o; o += U * bf;                 // beta of every output
     l.il = o;  o += U * E;                  // 1 / lengthscale
     l.var = o; o += U;
+    l.lvar = o; o += U;                     // log of the signal variances (phase 3's exponents)
     l.aug0 = o; o += nmat * E * 2 * E;      // augmented matrices of the batched Gauss-Jordan (ping)
     l.aug1 = o; o += nmat * E * 2 * E;      //                                                (pong)
     l.piv = o; o += nmat * E;               // pivots -> determinants
@@ -416,33 +459,48 @@ __host__ __device__ inline RbfInlineLayout rbf_inline_layout(int E, int U, int b
 
 // The policy GP's constants (raw centres, transposed as stored: [E][bf]; beta [U][bf]; lengthscales [U][E]; variances [U])
 // into LDS.  Issued together with the link's first batch of loads, so that their memory round trip is the link's own.
-__device__ __forceinline__ void rbf_policy_preload(const GlueArgs& g, const GlueLds& L) {
+// Two halves: the loads of the first round (8 elements per thread: every controller of the reference's examples is one round)
+// are REQUESTED before the link's own batch and stored behind it -- one memory round trip for both.
+struct RbfPre {
+    double v[8];
+};
+__device__ __forceinline__ void rbf_policy_preload_round(const GlueArgs& g, const GlueLds& L, int base, RbfPre& pre, bool issue, bool commit) {
     const int E = g.E, U = g.U, t = threadIdx.x, nthr = blockDim.x;
     const MMModel& pm = g.pmd;
     const int bf = pm.n, np = pm.npad;
     const RbfInlineLayout lay = rbf_inline_layout(E, U, bf);
     double* W = L.pol;
     const int n0 = bf * E, n1 = n0 + U * bf, n2 = n1 + U * E, total = n2 + U;
-    for (int base = 0; base < total; base += 8 * nthr) {
-        double v[8];
+    if (issue) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int e = base + k * nthr + t;
-            v[k] = 0.0;
-            if (e < n0) v[k] = pm.Pt[(long)(e / bf) * np + e % bf];
-            else if (e < n1) v[k] = pm.beta[(long)((e - n0) / bf) * np + (e - n0) % bf];
-            else if (e < n2) v[k] = pm.ls[e - n1];
-            else if (e < total) v[k] = pm.var[e - n2];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int e = base + k * nthr + t;
-            if (e < n0) W[lay.ctr + e] = v[k];
-            else if (e < n1) W[lay.bet + (e - n0)] = v[k];
-            else if (e < n2) W[lay.il + (e - n1)] = v[k];
-            else if (e < total) W[lay.var + (e - n2)] = v[k];
+            pre.v[k] = 0.0;
+            if (base + k * nthr >= total) continue;   // (workgroup-uniform: a 10-basis-function controller is one element per thread)
+            if (e < n1) {
+                int i;
+                const int row = idiv_s(e < n0 ? e : e - n0, bf, i);
+                pre.v[k] = (e < n0 ? pm.Pt : pm.beta)[(long)row * np + i];
+            } else if (e < n2) pre.v[k] = pm.ls[e - n1];
+            else if (e < total) pre.v[k] = pm.var[e - n2];
         }
     }
+    if (commit) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = base + k * nthr + t;
+            if (base + k * nthr >= total) continue;
+            if (e < n0) W[lay.ctr + e] = pre.v[k];
+            else if (e < n1) W[lay.bet + (e - n0)] = pre.v[k];
+            else if (e < n2) W[lay.il + (e - n1)] = pre.v[k];
+            else if (e < total) W[lay.var + (e - n2)] = pre.v[k];
+        }
+    }
+}
+__device__ __forceinline__ void rbf_policy_preload_rest(const GlueArgs& g, const GlueLds& L, RbfPre& pre) {
+    const int total = g.pmd.n * g.E + g.U * g.pmd.n + g.U * g.E + g.U, nthr = blockDim.x;
+    rbf_policy_preload_round(g, L, 0, pre, false, true);
+    for (int base = 8 * nthr; base < total; base += 8 * nthr) rbf_policy_preload_round(g, L, base, pre, true, true);
 }
 
 __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueLds& L) {
@@ -459,7 +517,10 @@ __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueL
     // ---- 0. the model is in LDS already (rbf_policy_preload, with the link's first loads): centre the points on the
     //         state this link has just produced, lengthscales -> reciprocals.  ctr is [E][bf] (as the centres are stored).
     (void)np;
-    for (int e = t; e < bf * E; e += nthr) ctr[e] -= mx[e / bf];
+    for (int e = t; e < bf * E; e += nthr) {
+        int i;
+        ctr[e] -= mx[idiv_s(e, bf, i)];
+    }
     for (int e = t; e < U * E; e += nthr) il[e] = 1.0 / il[e];
     __syncthreads();
     // ---- 1. all D x D systems at once: [B_u | I] (mean part, mgpr.py:103-111) and [R_uv | s] (mgpr.py:121-129),
@@ -468,7 +529,8 @@ __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueL
     double* cur = W + lay.aug0;
     double* nxt = W + lay.aug1;
     for (int e = t; e < nmat * msz; e += nthr) {
-        const int q = e / msz, rc = e - q * msz, r = rc / nc, c = rc - r * nc;
+        int rc, c;
+        const int q = idiv_s(e, msz, rc), r = idiv_s(rc, nc, c);
         double v;
         if (q < U) {
             if (c < E) v = fma(sx[r * E + c], il[q * E + r] * il[q * E + c], (r == c) ? 1.0 : 0.0);
@@ -486,10 +548,17 @@ __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueL
         }
         cur[e] = v;
     }
+    int q0_, rc0_, r0_, c0_;   // the thread's first element (all of them for U + P <= nthr / (2 E^2) systems): indices made once, not per pivot
+    q0_ = idiv_s(t, msz, rc0_);
+    r0_ = idiv_s(rc0_, nc, c0_);
     for (int k = 0; k < E; ++k) {
         __syncthreads();
         for (int e = t; e < nmat * msz; e += nthr) {
-            const int q = e / msz, rc = e - q * msz, r = rc / nc, c = rc - r * nc;
+            int q = q0_, rc = rc0_, r = r0_, c = c0_;
+            if (e != t) {
+                q = idiv_s(e, msz, rc);
+                r = idiv_s(rc, nc, c);
+            }
             const double* Mq = cur + q * msz;
             const double pk = Mq[k * nc + c] * fast_rcp(Mq[k * nc + k]);   // (as the register Gauss-Jordan of the operand kernel)
             nxt[e] = (r == k) ? pk : fma(-Mq[r * nc + k], pk, Mq[rc]);
@@ -506,11 +575,13 @@ __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueL
         det[t] = d;
     }
     for (int e = t; e < U * E * E; e += nthr) {   // T_u = Lambda^-1 B^-1 Lambda^-1
-        const int u = e / (E * E), rc = e - u * E * E, r = rc / E, c = rc - r * E;
+        int rc, c;
+        const int u = idiv_s(e, E * E, rc), r = idiv_s(rc, E, c);
         Tm[e] = cur[u * msz + r * nc + E + c] * il[u * E + r] * il[u * E + c];
     }
     for (int e = t; e < P * E * E; e += nthr) {   // Q_uv = R^-1 s / 2
-        const int pq = e / (E * E), rc = e - pq * E * E, r = rc / E, c = rc - r * E;
+        int rc, c;
+        const int pq = idiv_s(e, E * E, rc), r = idiv_s(rc, E, c);
         Qm[e] = 0.5 * cur[(U + pq) * msz + r * nc + E + c];
     }
     __syncthreads();
@@ -529,6 +600,8 @@ __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueL
             }
             lb = exp(-0.5 * q) * bet[u * bf + t];
         }
+        // (the logs phase 3 needs, by a wave that has no point: they run while the point threads are inside their exp)
+        if (u == 0 && t >= nthr - U) W[lay.lvar + (t - (nthr - U))] = log(var[t - (nthr - U)]);   // (the workgroup's last threads, whatever its size)
         if (t < 256) {
             const double gs = wave_sum_lane63(lb);
             if (lane == 63) red[w * (E + 2)] = gs;
@@ -558,7 +631,7 @@ __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueL
             double* vv = pt + bf;            // [bf] v_j (column side, output b)
             double* pv = pt + 2 * bf;        // [bf][E] 2 Q z_i
             double* wv = pv + bf * E;        // [bf][E] w_j
-            const double la = log(var[a]), lb_ = log(var[b]);
+            const double la = W[lay.lvar + a], lb_ = W[lay.lvar + b];
             for (int i = t; i < 2 * bf; i += nthr) {
                 const int side = i >= bf, ii = side ? i - bf : i;
                 const double* ilo = il + (side ? b : a) * E;
@@ -596,7 +669,8 @@ __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueL
             double acc = 0.0;
             if (t < 256)
                 for (int idx = t; idx < bf * bf; idx += 256) {
-                    const int i = idx / bf, j = idx - i * bf;
+                    int j;
+                    const int i = idiv_s(idx, bf, j);
                     double e = uv[i] + vv[j];
                     for (int d = 0; d < E; ++d) e = fma(pv[i * E + d], wv[j * E + d], e);
                     acc = fma(bet[a * bf + i] * bet[b * bf + j], exp(e), acc);
@@ -659,9 +733,13 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
             {L.o_misc + 128, g.b, lin ? U : 0},                       // the policy's small vectors ride in the same batch: read
             {L.o_misc + 160, g.maxact, (pol && g.maxact) ? U : 0},    // from global memory later each costs a DRAM round trip
         };
+        RbfPre rpre;
+        const bool rbf_in = (PK < 0 || PK == 2) && (g.flags & GF_POLICY) && g.pol_kind == PILCO_POLICY_RBF && g.pol_inline;
+        if constexpr (PK < 0 || PK == 2)
+            if (rbf_in) rbf_policy_preload_round(g, L, 0, rpre, true, false);
         multi_load<8, 4>(L.mx, sg);
         if constexpr (PK < 0 || PK == 2)
-            if ((g.flags & GF_POLICY) && g.pol_kind == PILCO_POLICY_RBF && g.pol_inline) rbf_policy_preload(g, L);
+            if (rbf_in) rbf_policy_preload_rest(g, L, rpre);
         if constexpr (!SR)
             if (xq_in) xq_load_segments(g, L.seg);
     }
@@ -680,7 +758,8 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
         const double* seg = L.seg;
         const int W1 = 1 + D, OO = g.wk.OUTOFF;
         for (int e = t; e < E * E; e += blockDim.x) {
-            const int r = e / E, c = e - r * E;
+            int c;
+            const int r = idiv_s(e, E, c);
             const int hi = r > c ? r : c, lo = r > c ? c : r;
             double v = seg[pair_order_index(E, hi, lo)];
             if (r == c) v += g.var[r];
@@ -692,7 +771,11 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
         }
         if (t < E) L.mu[t] = seg[OO + t * W1];
         if (writer && g.tape) {   // the tape wants the GP outputs (M, S, V) of the step: V in [D][E] order
-            for (int e = t; e < D * E; e += blockDim.x) L.cxu[e] = seg[OO + (e % E) * W1 + 1 + e / E];
+            for (int e = t; e < D * E; e += blockDim.x) {
+                int a_;
+                const int d_ = idiv_s(e, E, a_);
+                L.cxu[e] = seg[OO + a_ * W1 + 1 + d_];
+            }
         }
         __syncthreads();
         if (writer && g.tape && g.step >= 1) {
@@ -702,7 +785,8 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
             for (int e = t; e < D * E; e += blockDim.x) rec[E + E * E + e] = L.cxu[e];
         }
         for (int e = t; e < E * E; e += blockDim.x) {   // in place: a thread reads sx only at the element it writes
-            const int r = e / E, c = e - r * E;
+            int c;
+            const int r = idiv_s(e, E, c);
             const double v = ((L.su[e] + L.sx[e]) + L.t1[e]) + L.t1[c * E + r];
             L.sx[e] = v;
             if (writer) g.s_out[e] = v;
@@ -728,14 +812,16 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
     if (!SR && !fast && (g.flags & GF_PROPAGATE)) {
         // t1 = s1 V (E,E); state += increment                      (pilco.py:147-149)
         for (int e = t; e < E * E; e += blockDim.x) {
-            const int r = e / E, c = e - r * E;
+            int c;
+            const int r = idiv_s(e, E, c);
             double acc = 0.0;
             _Pragma("unroll 8") for (int k = 0; k < D; ++k) acc = fma(L.s1[r * D + k], L.cxu[k * E + c], acc);
             L.t1[e] = acc;
         }
         __syncthreads();
         for (int e = t; e < E * E; e += blockDim.x) {
-            const int r = e / E, c = e - r * E;
+            int c;
+            const int r = idiv_s(e, E, c);
             const double v = ((L.su[e] + L.sx[e]) + L.t1[e]) + L.t1[c * E + r];
             L.t2[e] = v;
             if (writer) g.s_out[e] = v;
@@ -761,6 +847,7 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
         for (int e = t; e < E * E; e += blockDim.x) g.pwk.in_s[e] = L.sx[e];
     }
     if (g.flags & GF_POLICY) {
+        const double* jcd = nullptr;   // the squash's diagonal, when write_joint is to apply it to c_xu
         if (PK != 0 && PK != 3 && g.pol_kind == PILCO_POLICY_RBF) {
             // mean-function-only GP: iK = 0, then S -= diag(var - 1e-6)      (controllers.py:116-117)
             bool done = false;
@@ -783,8 +870,12 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
             if (g.squash) {
                 double* cdiag = L.misc + 1;
                 squash_inplace(L, U, g.maxact ? L.misc + 160 : nullptr, cdiag);
-                for (int e = t; e < E * U; e += blockDim.x) L.cxu[e] *= cdiag[e % U];
-                __syncthreads();
+                if (g.act_out) {
+                    for (int e = t; e < E * U; e += blockDim.x) L.cxu[e] *= cdiag[e % U];
+                    __syncthreads();
+                } else {
+                    jcd = cdiag;   // (write_joint scales on the fly)
+                }
             }
         }
         if ((PK < 0 || PK == 3) && g.pol_kind == PILCO_POLICY_LINEAR) {
@@ -795,7 +886,8 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
                 L.mu[t] = acc;
             }
             for (int e = t; e < U * E; e += blockDim.x) {
-                const int u = e / E, c = e - u * E;
+                int c;
+                const int u = idiv_s(e, E, c);
                 double acc = 0.0;
                 _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.js[u * E + k], L.sx[k * E + c], acc);
                 L.t1[e] = acc;  // W s
@@ -803,7 +895,8 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
             }
             __syncthreads();
             for (int e = t; e < U * U; e += blockDim.x) {
-                const int u = e / U, v = e - u * U;
+                int v;
+                const int u = idiv_s(e, U, v);
                 double acc = 0.0;
                 _Pragma("unroll 8") for (int k = 0; k < E; ++k) acc = fma(L.t1[u * E + k], L.js[v * E + k], acc);
                 L.su[e] = acc;
@@ -812,8 +905,12 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
             if (g.squash) {
                 double* cdiag = L.misc + 1;  // [U]
                 squash_inplace(L, U, g.maxact ? L.misc + 160 : nullptr, cdiag);
-                for (int e = t; e < E * U; e += blockDim.x) L.cxu[e] *= cdiag[e % U];   // V @ C, C diagonal
-                __syncthreads();
+                if (g.act_out) {
+                    for (int e = t; e < E * U; e += blockDim.x) L.cxu[e] *= cdiag[e % U];   // V @ C, C diagonal
+                    __syncthreads();
+                } else {
+                    jcd = cdiag;
+                }
             }
         }
         if (g.act_out) {
@@ -823,7 +920,7 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
                 for (int e = t; e < E * U; e += blockDim.x) g.act_out[U + U * U + e] = L.cxu[e];
             }
         } else {
-            write_joint(g, L, writer);
+            write_joint(g, L, writer, jcd);
         }
     }
     DBG_STAMP(g.wk, 13 + dbo, dbg0);

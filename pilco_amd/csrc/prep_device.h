@@ -417,7 +417,7 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: the role branches below are scalar branches
     const bool act = (NTHR == 512) || t < 512;   // a host workgroup wider than 512 threads: the extra waves only keep the barriers
     const int grp = t >> 8, tl = t & 255;
-    const int pl = bx, ch = by % wk.NCH, cs = by / wk.NCH;   // (cs: column split of the one-launch small step, 0 elsewhere)
+    const int pl = bx, ch = by & (wk.NCH - 1), cs = by >> __builtin_ctz(wk.NCH);   // (NCH is a power of two: mm_prep_chunks)   // (cs: column split of the one-launch small step, 0 elsewhere)
     const bool dbg0 = (t == 0 && pl == 0 && ch == 0);
     DBG_STAMP(wk, 0, dbg0);
     if (wk.dbg && t == 0) wk.dbg[64 + 2 * (by * gx + bx)] = wall_clock64();

@@ -46,6 +46,8 @@ __global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepRewa
         double* tabL = sm_all + glue_doubles + prep_region_doubles(DT);
         for (int e = threadIdx.x; e < FEXP_TN; e += 512) tabL[e] = wk.exp_tab[e];
     }
+    // (the link's results are stored by the first pair workgroup; handing that to an idle slot of the spare columns -- a
+    // workgroup with nothing else to do -- measured 1-2 % SLOWER on every configuration: docs/dead_ends.md)
     if (FUSED) glue_body<PK, SR>(g, L, bxi == 0 && blockIdx.y == 0);
     prep_work<DT, FUSED, 512, FUSED && SR && PK != 1>(md, wk, pr, g, L, sm_all, glue_doubles, bxi, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, pre_la,
                               pre_lb, pre_var);

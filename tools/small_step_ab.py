@@ -2,7 +2,7 @@
 config-5 size (N=225, D=5, E=4, RbfController bf=10) and a cascade-size model.  Developer tool."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("PILCO_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (PILCO_AB_ROOT: a directory holding another build's pilco_amd/)
 from pilco_amd import _lib, synthetic
 def med(fn, n=25):
     fn(); fn(); ts = []
