@@ -234,6 +234,19 @@ int pilco_rollout_grad(pilco_ctx* ctx, const pilco_policy* policy, const pilco_r
 int pilco_rollout_grad_rbf(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
                            const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
                            const double* noisep, int bf, double* reward, double* dX, double* dY, double* dls);
+/* B value-and-gradient rollouts of ONE dynamics model in flight together -- the restarts of PILCO.optimize_policy
+ * (pilco/models/pilco.py:94-107 runs them one after the other; each restart is an L-BFGS-B walk of its own, so the evaluations
+ * of different restarts are independent).  Lanes as in pilco_rollout_batch; every lane's result is BIT-IDENTICAL to its solo
+ * pilco_rollout_grad call.  LinearController lanes: policies[i].W / .b; m0 (B,E), S0 (B,E,E); reward (B), dW (B,U,E), db (B,U). */
+int pilco_rollout_grad_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
+                             const double* m0, const double* S0, int H, double* reward, double* dW, double* db);
+/* RbfController lanes: lane i's policy GP -- centres Xp (B,bf,E), targets Yp (B,bf,U), lengthscales lsp (B,U,E), likelihood
+ * variances noisep (B,U), unit signal variance (pilco/controllers.py:92-93) -- is uploaded to and factorised in
+ * PILCO_SLOT_POLICY of lane i's context BY THIS CALL, lane 0 = this context included: the caller's policy slot holds lane 0's
+ * controller afterwards.  reward (B), dX (B,bf,E), dY (B,bf,U), dls (B,U,E); bit-identical to the solo pilco_rollout_grad_rbf. */
+int pilco_rollout_grad_rbf_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
+                                 const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
+                                 const double* noisep, int bf, double* reward, double* dX, double* dY, double* dls);
 
 /* ------------------------------------------------------------------ timing / introspection */
 /* Time `reps` back-to-back rollouts with HIP events on the library's stream.

@@ -91,6 +91,9 @@ SIGNATURES = {
                                                 _dp, _dp, _dp, _dp, C.c_int, SEED_FN, _vp, _dp, _dp, _dp, _dp]),
     "pilco_propagate": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp]),
     "pilco_rollout_batch": (C.c_int, [_vp, C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]),
+    "pilco_rollout_grad_batch": (C.c_int, [_vp, C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]),
+    "pilco_rollout_grad_rbf_batch": (C.c_int, [_vp, C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
+                                               _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]),
     "pilco_policy_action": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp, _dp]),
     "pilco_reward_eval": (C.c_int, [_vp, C.POINTER(RewardTerm), C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
     "pilco_rollout_timed": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp,
@@ -387,12 +390,7 @@ class Context:
         bit-identical to its solo rollout."""
         B = len(policies)
         E = policies[0]["state_dim"]
-        arr = (PolicyStruct * B)()
-        keep = []
-        for i, spec in enumerate(policies):
-            p, k = self._policy(spec)
-            keep.append((p, k))
-            arr[i] = p
+        arr, keep = self._policy_array(policies)
         r, k2 = self._rewards(rewards, E)
         m0 = _f64(m0, (B, E))
         S0 = _f64(S0, (B, E, E))
@@ -401,6 +399,45 @@ class Context:
         rew = np.zeros(B)
         self._chk(self.lib.pilco_rollout_batch(self.h, B, arr, r, len(rewards), _ptr(m0), _ptr(S0), int(H), _ptr(mH), _ptr(SH), _ptr(rew)))
         return mH, SH, rew
+
+    def _policy_array(self, policies):
+        arr = (PolicyStruct * len(policies))()
+        keep = []
+        for i, spec in enumerate(policies):
+            p, k = self._policy(spec)
+            keep.append((p, k))
+            arr[i] = p
+        return arr, keep
+
+    def rollout_grad_batch(self, policies, rewards, m0, S0, H):
+        """B value-and-gradient rollouts of the same model in flight together (pilco_rollout_grad_batch; the restarts of
+        optimize_policy, pilco.py:94-107): policies: B LinearController specs; m0 (B, E), S0 (B, E, E) -> reward (B,),
+        dW (B, U, E), db (B, U).  Each lane is bit-identical to its solo rollout_grad."""
+        B = len(policies)
+        E, U = policies[0]["state_dim"], policies[0]["control_dim"]
+        arr, keep = self._policy_array(policies)
+        r, k2 = self._rewards(rewards, E)
+        m0 = _f64(m0, (B, E)); S0 = _f64(S0, (B, E, E))
+        rew = np.zeros(B); dW = np.empty((B, U, E)); db = np.empty((B, U))
+        self._chk(self.lib.pilco_rollout_grad_batch(self.h, B, arr, r, len(rewards), _ptr(m0), _ptr(S0), int(H), _ptr(rew), _ptr(dW), _ptr(db)))
+        return rew, dW, db
+
+    def rollout_grad_rbf_batch(self, policies, rewards, m0, S0, H, Xp, Yp, lsp, noisep):
+        """The same for B RbfControllers: Xp (B, bf, E), Yp (B, bf, U), lsp (B, U, E), noisep (B, U) -> reward (B,), dX, dY, dls.
+        The call uploads lane i's policy GP into the policy slot of lane i's context -- this context's slot holds lane 0's
+        controller afterwards (whoever believed to own the slot must push its parameters again)."""
+        B = len(policies)
+        E, U = policies[0]["state_dim"], policies[0]["control_dim"]
+        arr, keep = self._policy_array(policies)
+        r, k2 = self._rewards(rewards, E)
+        m0 = _f64(m0, (B, E)); S0 = _f64(S0, (B, E, E))
+        Xp = _f64(Xp); bf = Xp.shape[1]
+        Xp = _f64(Xp, (B, bf, E)); Yp = _f64(Yp, (B, bf, U)); lsp = _f64(lsp, (B, U, E)); noisep = _f64(noisep, (B, U))
+        rew = np.zeros(B); dX = np.empty((B, bf, E)); dY = np.empty((B, bf, U)); dls = np.empty((B, U, E))
+        self._slot_owner[SLOT_POLICY] = None   # (the call overwrites the slot)
+        self._chk(self.lib.pilco_rollout_grad_rbf_batch(self.h, B, arr, r, len(rewards), _ptr(m0), _ptr(S0), int(H), _ptr(Xp), _ptr(Yp),
+                                                        _ptr(lsp), _ptr(noisep), bf, _ptr(rew), _ptr(dX), _ptr(dY), _ptr(dls)))
+        return rew, dX, dY, dls
 
     def gp_predict_vjp(self, slot, m, s, Mbar, Sbar, Vbar, D, E):
         m = _f64(m, (D,)); s = _f64(s, (D, D))

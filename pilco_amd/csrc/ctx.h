@@ -241,7 +241,9 @@ constexpr int PILCO_JAC_TOO_LARGE = -77;   // rollout_jtape: the per-step buffer
 int rollout_jtape_wait(pilco_ctx* ctx, int t);   // blocks until the records of step t have arrived
 // forward rollout with the tape and the Jacobian records of every step, downloaded into pinned memory (grad.hip)
 int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
-                  const double* S0, int H, double* reward, const double** traj, const double** tape, const double** jrec, size_t* jstride);
+                  const double* S0, int H, double* reward, const double** traj, const double** tape, const double** jrec, size_t* jstride,
+                  const double** reward_later = nullptr);   // reward_later: return without waiting (one rank); *reward_later is valid once rollout_jtape_wait(ctx, H - 1) has returned
+int rollout_lanes(pilco_ctx* ctx, int B, std::vector<pilco_ctx*>& lane, const char* who);   // lanes of a batch call (rollout.hip)
 int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_term* rw, int n_rw, int H, bool want_traj,
                   RolloutPlan& plan);
 int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev);

@@ -637,33 +637,59 @@ void jac_vjp(const double* __restrict__ jr, int D, int E, const double* M, const
         for (int r = 0; r <= c; ++r) sbar[(size_t)r * D + c] = sbar[(size_t)c * D + r] = am[D + (size_t)c * (c + 1) / 2 + r];
 }
 
-int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
-                      const double* m0, const double* S0, int H, double* reward, PolicyAdj& pol, pilco_seed_fn seed_fn, void* seed_user) {
+// In two halves, so that several value-and-gradient rollouts (the lanes of pilco_rollout_grad_batch) can be in flight at once:
+// rollout_grad_begin enqueues the forward half -- with `defer` it returns without waiting for anything -- and
+// rollout_grad_finish waits for the records chunk by chunk while it runs the host's reverse sweep.
+struct GradCall {
+    bool jac = false;
+    const double *traj = nullptr, *tape = nullptr, *jrec = nullptr, *reward_later = nullptr;
+    size_t JS = 0;
+    vec traj_v, tape_v;
+    std::chrono::steady_clock::time_point tm0, tm1;
+};
+int rollout_grad_begin(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
+                       const double* S0, int H, double* reward, GradCall& gc, bool defer) {
     const int E = policy->state_dim, U = policy->control_dim, D = E + U;
     const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
     // Forward half.  Jacobian tape (default): one O(N^2) sweep per step gives the value and the step's Jacobian records,
     // the reverse sweep below is host algebra only.  PILCO_GRAD_MODE=0 / pilco_set_grad_mode(ctx, 0): plain tape, and
     // the O(N^2) adjoint of every step on the device again (pilco_gp_predict_vjp) -- the two agree to rounding.
     bool jac = ctx->grad_mode != 0;
-    const bool timing = getenv("PILCO_GRAD_TIMING") != nullptr;   // developer aid: forward / reverse split on stderr
-    const auto tm0 = std::chrono::steady_clock::now();
-    vec mH(E), SH((size_t)E * E), traj_v, tape_v;
-    const double *traj = nullptr, *tape = nullptr, *jrec = nullptr;
-    size_t JS = 0;
+    gc.tm0 = std::chrono::steady_clock::now();
+    vec mH(E), SH((size_t)E * E);
     if (jac) {
-        const int r = rollout_jtape(ctx, policy, rewards, n_rewards, m0, S0, H, reward, &traj, &tape, &jrec, &JS);
+        const int r = rollout_jtape(ctx, policy, rewards, n_rewards, m0, S0, H, reward, &gc.traj, &gc.tape, &gc.jrec, &gc.JS,
+                                    defer ? &gc.reward_later : nullptr);
         if (r == PILCO_JAC_TOO_LARGE) jac = false;
         else if (r) return r;
     }
-    if (!jac) {
-        traj_v.resize((size_t)(H + 1) * (E + E * E));
-        tape_v.resize(std::max<size_t>(1, (size_t)H * TS));
-        if (int r = pilco_rollout_tape(ctx, policy, rewards, n_rewards, m0, S0, H, mH.data(), SH.data(), reward, traj_v.data(), tape_v.data()))
+    if (!jac) {   // (runs to completion here: nothing of it overlaps with other lanes)
+        gc.traj_v.resize((size_t)(H + 1) * (E + E * E));
+        gc.tape_v.resize(std::max<size_t>(1, (size_t)H * TS));
+        if (int r = pilco_rollout_tape(ctx, policy, rewards, n_rewards, m0, S0, H, mH.data(), SH.data(), reward, gc.traj_v.data(), gc.tape_v.data()))
             return r;
-        traj = traj_v.data();
-        tape = tape_v.data();
+        gc.traj = gc.traj_v.data();
+        gc.tape = gc.tape_v.data();
     }
-    const auto tm1 = std::chrono::steady_clock::now();
+    gc.jac = jac;
+    gc.tm1 = std::chrono::steady_clock::now();
+    return PILCO_OK;
+}
+int rollout_grad_finish(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, int H, double* reward,
+                        PolicyAdj& pol, pilco_seed_fn seed_fn, void* seed_user, GradCall& gc) {
+    const int E = policy->state_dim, U = policy->control_dim, D = E + U;
+    const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
+    const bool jac = gc.jac;
+    const bool timing = getenv("PILCO_GRAD_TIMING") != nullptr;   // developer aid: forward / reverse split on stderr
+    if (gc.reward_later) {   // deferred begin: the reward, the trajectory, the tape and the last chunk of records
+        if (int r = rollout_jtape_wait(ctx, H - 1)) return r;
+        if (H <= 0) HIPCHK(hipStreamSynchronize(ctx->st));
+        *reward = *gc.reward_later;
+        gc.tm1 = std::chrono::steady_clock::now();
+    }
+    const double *traj = gc.traj, *tape = gc.tape, *jrec = gc.jrec;
+    const size_t JS = gc.JS;
+    const auto tm0 = gc.tm0, tm1 = gc.tm1;
     vec e(U);
     for (int u = 0; u < U; ++u) e[u] = policy->max_action[u];
     vec mbar(E, 0.0), sbar((size_t)E * E, 0.0);
@@ -778,6 +804,12 @@ int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_re
     }
     return PILCO_OK;
 }
+int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
+                      const double* m0, const double* S0, int H, double* reward, PolicyAdj& pol, pilco_seed_fn seed_fn, void* seed_user) {
+    GradCall gc;
+    if (int r = rollout_grad_begin(ctx, policy, rewards, n_rewards, m0, S0, H, reward, gc, false)) return r;
+    return rollout_grad_finish(ctx, policy, rewards, n_rewards, H, reward, pol, seed_fn, seed_user, gc);
+}
 
 int check_grad_args(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, int kind) {
     if (policy->kind != kind || !policy->squash || policy->control_dim <= 0)
@@ -836,6 +868,96 @@ int pilco_rollout_grad_rbf(pilco_ctx* ctx, const pilco_policy* policy, const pil
                            const double* noisep, int bf, double* reward, double* dX, double* dY, double* dls) {
     return pilco_rollout_grad_rbf_seeded(ctx, policy, rewards, n_rewards, m0, S0, H, Xp, Yp, lsp, noisep, bf, nullptr, nullptr, reward, dX,
                                          dY, dls);
+}
+
+// B value-and-gradient rollouts of ONE dynamics model in flight together: the restarts of optimize_policy (pilco.py:94-107
+// runs them one after the other; every restart is an L-BFGS-B walk of its own, and their evaluations are independent).
+// Lanes as in pilco_rollout_batch (contexts of their own that borrow this context's model); every lane's forward half
+// (steps, batched finish, downloads) is enqueued on its stream before the first wait, then the host's reverse sweeps run
+// lane by lane -- lane i's sweep while lanes i+1.. are still on the device.  Every lane runs exactly the launch sequence
+// and the host arithmetic of its solo call: results are bit-identical to pilco_rollout_grad / pilco_rollout_grad_rbf.
+// LinearController lanes: policies[i].W / .b; dW (B, U, E), db (B, U), reward (B); m0 (B, E), S0 (B, E, E).
+int pilco_rollout_grad_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
+                             const double* m0, const double* S0, int H, double* reward, double* dW, double* db) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (B <= 0 || B > 64 || !policies || !m0 || !S0 || !reward || !dW || !db || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout_grad_batch: bad arguments");
+    if (ctx->nranks != 1 || ctx->comm) return fail(ctx, PILCO_E_STATE, "rollout_grad_batch: single rank only (shard OR batch)");
+    if (!ctx->slot[0].factor_valid) return fail(ctx, PILCO_E_STATE, "rollout_grad_batch: dynamics model has no current factorisation");
+    for (int i = 0; i < B; ++i)
+        if (int r = check_grad_args(ctx, &policies[i], rewards, n_rewards, PILCO_POLICY_LINEAR)) return r;
+    std::vector<pilco_ctx*> lane;
+    if (int r = rollout_lanes(ctx, B, lane, "rollout_grad_batch")) return r;
+    const int E = policies[0].state_dim, U = policies[0].control_dim;
+    std::vector<GradCall> gc((size_t)B);
+    int err = PILCO_OK, begun = 0;
+    for (int i = 0; i < B && !err; ++i, ++begun) {
+        err = rollout_grad_begin(lane[i], &policies[i], rewards, n_rewards, m0 + (size_t)i * E, S0 + (size_t)i * E * E, H, reward + i, gc[i], true);
+        if (err && i > 0) ctx->err = "lane " + std::to_string(i) + ": " + lane[i]->err;
+        if (err) break;
+    }
+    for (int i = 0; i < begun; ++i) {
+        LinearAdj pol(E, U, policies[i].W, policies[i].b);
+        const int r = rollout_grad_finish(lane[i], &policies[i], rewards, n_rewards, H, reward + i, pol, nullptr, nullptr, gc[i]);
+        if (r && !err) {
+            err = r;
+            if (i > 0) ctx->err = "lane " + std::to_string(i) + ": " + lane[i]->err;
+        }
+        if (!r) {
+            memcpy(dW + (size_t)i * U * E, pol.Wbar.data(), sizeof(double) * (size_t)U * E);
+            memcpy(db + (size_t)i * U, pol.bbar.data(), sizeof(double) * (size_t)U);
+        }
+    }
+    if (err)   // a lane that failed after others had begun: nothing may stay in flight behind the caller's back
+        for (int i = 0; i < B; ++i) (void)hipStreamSynchronize(lane[i]->st);
+    return err;
+}
+
+// RbfController lanes: lane i's policy GP (centres Xp (B, bf, E), targets Yp (B, bf, U), lengthscales lsp (B, U, E), likelihood
+// variances noisep (B, U); unit signal variance, controllers.py:92-93) is uploaded to and factorised in PILCO_SLOT_POLICY of
+// lane i's context by this call -- INCLUDING lane 0, this context: whatever the caller had in its policy slot is replaced by
+// lane 0's controller.  dX (B, bf, E), dY (B, bf, U), dls (B, U, E).
+int pilco_rollout_grad_rbf_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
+                                 const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
+                                 const double* noisep, int bf, double* reward, double* dX, double* dY, double* dls) {
+    if (!ctx) return PILCO_E_SHAPE;
+    if (B <= 0 || B > 64 || !policies || !m0 || !S0 || !reward || !Xp || !Yp || !lsp || !noisep || !dX || !dY || !dls || H < 0 || bf <= 0)
+        return fail(ctx, PILCO_E_SHAPE, "rollout_grad_rbf_batch: bad arguments");
+    if (ctx->nranks != 1 || ctx->comm) return fail(ctx, PILCO_E_STATE, "rollout_grad_rbf_batch: single rank only (shard OR batch)");
+    if (!ctx->slot[0].factor_valid) return fail(ctx, PILCO_E_STATE, "rollout_grad_rbf_batch: dynamics model has no current factorisation");
+    for (int i = 0; i < B; ++i)
+        if (int r = check_grad_args(ctx, &policies[i], rewards, n_rewards, PILCO_POLICY_RBF)) return r;
+    std::vector<pilco_ctx*> lane;
+    if (int r = rollout_lanes(ctx, B, lane, "rollout_grad_rbf_batch")) return r;
+    const int E = policies[0].state_dim, U = policies[0].control_dim;
+    const size_t nX = (size_t)bf * E, nY = (size_t)bf * U, nL = (size_t)U * E;
+    std::vector<double> ones((size_t)U, 1.0);
+    std::vector<GradCall> gc((size_t)B);
+    std::vector<RbfAdj> pol((size_t)B);
+    int err = PILCO_OK, begun = 0;
+    for (int i = 0; i < B; ++i, ++begun) {
+        pilco_ctx* l = lane[i];
+        err = pilco_gp_set_data(l, PILCO_SLOT_POLICY, Xp + i * nX, Yp + i * nY, bf, E, U);
+        if (!err) err = pilco_gp_set_hyp(l, PILCO_SLOT_POLICY, lsp + i * nL, ones.data(), noisep + (size_t)i * U);
+        if (!err) err = pilco_gp_factorize(l, PILCO_SLOT_POLICY);
+        if (!err && !pol[i].init(bf, E, U, Xp + i * nX, Yp + i * nY, lsp + i * nL, noisep + (size_t)i * U))
+            err = fail(l, PILCO_E_NOT_PD, "rollout_grad_rbf_batch: K + noise I of the policy is singular");
+        if (!err) err = rollout_grad_begin(l, &policies[i], rewards, n_rewards, m0 + (size_t)i * E, S0 + (size_t)i * E * E, H, reward + i, gc[i], true);
+        if (err) {
+            if (i > 0) ctx->err = "lane " + std::to_string(i) + ": " + l->err;
+            break;
+        }
+    }
+    for (int i = 0; i < begun; ++i) {
+        const int r = rollout_grad_finish(lane[i], &policies[i], rewards, n_rewards, H, reward + i, pol[i], nullptr, nullptr, gc[i]);
+        if (r && !err) {
+            err = r;
+            if (i > 0) ctx->err = "lane " + std::to_string(i) + ": " + lane[i]->err;
+        }
+        if (!r) pol[i].finish(dX + i * nX, dY + i * nY, dls + i * nL);
+    }
+    if (err)
+        for (int i = 0; i < B; ++i) (void)hipStreamSynchronize(lane[i]->st);
+    return err;
 }
 
 }  // extern "C"

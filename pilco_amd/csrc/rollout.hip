@@ -937,6 +937,9 @@ static int lane_sync_model(pilco_ctx* parent, pilco_ctx* lane) {
     lane->variant = parent->variant;
     lane->fused = parent->fused;
     lane->use_graph = parent->use_graph;
+    lane->fuse_small = parent->fuse_small;
+    lane->inline_policy = parent->inline_policy;
+    lane->grad_mode = parent->grad_mode;
     lane->persist = 0;   // lanes overlap each other's serial heads; a persistent launch would claim every CU for one lane
     if (!same) {
         l.wk_valid = false;
@@ -944,6 +947,27 @@ static int lane_sync_model(pilco_ctx* parent, pilco_ctx* lane) {
         lane->graph_cache.clear();
         lane->graph = nullptr;
     }
+    return PILCO_OK;
+}
+
+// The B lanes of a batch call: lane 0 is the context itself, lanes 1.. are created on first use and pointed at its model.
+int rollout_lanes(pilco_ctx* ctx, int B, std::vector<pilco_ctx*>& lane, const char* who) {
+    while ((int)ctx->lanes.size() < B - 1) {
+        pilco_ctx* l = nullptr;
+        if (int r = pilco_ctx_create(ctx->device, &l)) return fail(ctx, r, std::string(who) + ": could not create a lane context");
+        l->is_lane = true;
+        ctx->lanes.push_back(l);
+    }
+    lane.resize((size_t)B);
+    for (int i = 0; i < B; ++i) {
+        lane[i] = i == 0 ? ctx : ctx->lanes[i - 1];
+        if (i > 0) {
+            HIPCHK(hipStreamSynchronize(lane[i]->st));
+            if (int r = lane_sync_model(ctx, lane[i])) return r;
+        }
+    }
+    // the parent's model must be complete in memory before another stream reads it
+    HIPCHK(hipStreamSynchronize(ctx->st));
     return PILCO_OK;
 }
 
@@ -977,25 +1001,11 @@ int pilco_rollout_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, con
     HIPCHK(hipSetDevice(ctx->device));
     const Slot& s = ctx->slot[0];
     if (!s.factor_valid) return fail(ctx, PILCO_E_STATE, "rollout_batch: dynamics model has no current factorisation");
-    while ((int)ctx->lanes.size() < B - 1) {
-        pilco_ctx* lane = nullptr;
-        if (int r = pilco_ctx_create(ctx->device, &lane)) return fail(ctx, r, "rollout_batch: could not create a lane context");
-        lane->is_lane = true;
-        ctx->lanes.push_back(lane);
-    }
     const int E = s.E;
     const size_t nst = (size_t)E + (size_t)E * E;
     std::vector<RolloutCall> rc((size_t)B);
-    std::vector<pilco_ctx*> lane((size_t)B);
-    for (int i = 0; i < B; ++i) {
-        lane[i] = i == 0 ? ctx : ctx->lanes[i - 1];
-        if (i > 0) {
-            HIPCHK(hipStreamSynchronize(lane[i]->st));
-            if (int r = lane_sync_model(ctx, lane[i])) return r;
-        }
-    }
-    // the parent's model must be complete in memory before another stream reads it
-    HIPCHK(hipStreamSynchronize(ctx->st));
+    std::vector<pilco_ctx*> lane;
+    if (int r = rollout_lanes(ctx, B, lane, "rollout_batch")) return r;
     int rc_err = PILCO_OK;
     int begun = 0;
     for (int i = 0; i < B; ++i, ++begun) {
@@ -1242,7 +1252,8 @@ int pilco_rollout_tape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_r
 // records land in pinned host memory for the host-side reverse sweep (grad.hip).  Single rank; D <= 14 (wider inputs: PILCO_JAC_TOO_LARGE, the caller
 // falls back to the plain tape + per-step device adjoint, which has the forward path's D <= 32).
 int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
-                  const double* S0, int H, double* reward, const double** traj, const double** tape, const double** jrec, size_t* jstride) {
+                  const double* S0, int H, double* reward, const double** traj, const double** tape, const double** jrec, size_t* jstride,
+                  const double** reward_later) {
     HIPCHK(hipSetDevice(ctx->device));
     // Several ranks (round 3): every rank sweeps ITS pairs (k_mm_bwd_pair is per-pair independent; the mean-part records of
     // all E outputs are cheap and computed everywhere), the per-step exchange of the forward chain is the sharded
@@ -1377,6 +1388,14 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
             t1 = t0;
         }
         ctx->jwait_n = nch;
+        if (reward_later) {   // a lane of a batch: everything is enqueued, the caller waits when it gets to this lane
+            *reward_later = h_misc;
+            *traj = h_traj;
+            *tape = h_tape;
+            *jrec = h_jrec;
+            *jstride = JSg;
+            return PILCO_OK;
+        }
         if (int r = rollout_jtape_wait(ctx, H - 1)) return r;   // reward, trajectory, tape and the last chunk are on the host
     } else {
         HIPCHK(hipStreamSynchronize(ctx->st));

@@ -469,9 +469,98 @@ def policy_loss_and_grad(pilco, u, put, eps=1e-6):
     return f0, g
 
 
+def _restart_lanes_apply(pilco):
+    """Can the restarts of optimize_policy run as lanes of ONE batched value-and-gradient call per round?  The plain additive
+    reward through the native sweep on one rank (what policy_loss_and_grad calls `analytic` and not `seeded`)."""
+    import os
+    from . import _lib
+    from .controllers import LinearController, RbfController
+    from .models.pilco import PILCO
+    if os.environ.get("PILCO_RESTART_LANES", "1") == "0":
+        return False
+    ctx = pilco.ctx
+    if getattr(ctx, "nranks", 1) != 1 or getattr(ctx, "has_comm", False) or not hasattr(ctx, "rollout_grad_batch"):
+        return False
+    if not isinstance(pilco.controller, (LinearController, RbfController)):
+        return False
+    if type(pilco).predict is not PILCO.predict or pilco._host_reward_terms():
+        return False
+    return (pilco.control_dim > 0 and pilco.state_dim + pilco.control_dim <= 32
+            and all(t["kind"] in (_lib.REWARD_EXPONENTIAL, _lib.REWARD_LINEAR) for t in pilco._reward_terms()))
+
+
+def _optimize_policy_lanes(pilco, maxiter, restarts, verbose):
+    """pilco.py:75-113 with its restarts side by side: restart i's start is drawn exactly where the reference draws it (the
+    L-BFGS-B walks draw nothing), every walk is the scipy run of the sequential loop (lockstep_minimize: one thread per walk,
+    a round of evaluations = ONE pilco_rollout_grad[_rbf]_batch call whose lanes are bit-identical to the solo calls), and the
+    end points are compared as the reference compares them (compute_reward, first best wins)."""
+    from .controllers import LinearController
+    ctl = pilco.controller
+    get, put = _policy_params(ctl)
+    start = time.time()
+    starts = [get()]
+    for _ in range(restarts - 1):                                  # pilco.py:99
+        ctl.randomize()
+        starts.append(get())
+    B, n = len(starts), starts[0].size
+    parts = [np.arange(i * n, (i + 1) * n) for i in range(B)]
+    linear = isinstance(ctl, LinearController)
+    pilco.mgpr._user_factors = None
+    pilco.mgpr._ensure_factorized()
+    ctx, rw, H = pilco.ctx, pilco._reward_terms(), pilco.horizon
+    m0, S0 = np.asarray(pilco.m_init, np.float64).reshape(-1), np.asarray(pilco.S_init, np.float64)
+    cache = {}   # lane -> (u_i, value, gradient): a walk that has ended (or waits) is not evaluated again
+
+    def eval_all(u):
+        todo = [i for i in range(B) if i not in cache or not np.array_equal(cache[i][0], u[parts[i]])]
+        if todo:
+            us = [np.array(u[parts[i]], dtype=np.float64) for i in todo]
+            nb = len(todo)
+            mm, SS = np.tile(m0, (nb, 1)), np.tile(S0, (nb, 1, 1))
+            if linear:
+                base = ctl.policy_spec(True)
+                nW = ctl.W.numpy().size
+                specs = [dict(base, W=ui[:nW].reshape(ctl.W.shape), b=ui[nW:].reshape(-1)) for ui in us]
+                r, dW, db = ctx.rollout_grad_batch(specs, rw, mm, SS, H)
+                for k, i in enumerate(todo):
+                    cache[i] = (us[k], -float(r[k]), -np.concatenate([dW[k].ravel(), db[k].ravel()]))
+            else:
+                gp = ctl._gp
+                bf, d, U = gp.num_datapoints, gp.num_dims, gp.num_outputs
+                X = np.stack([ui[:bf * d].reshape(bf, d) for ui in us])
+                Y = np.stack([ui[bf * d:bf * d + bf * U].reshape(bf, U) for ui in us])
+                ls = np.stack([1e-3 + _softplus(ui[bf * d + bf * U:]).reshape(U, d) for ui in us])   # positive(lower=1e-3), as _policy_params
+                nz = np.tile(np.asarray(ctl.noise, np.float64).reshape(-1), (nb, 1))
+                spec = dict(kind=base_kind, state_dim=ctl.state_dim, control_dim=ctl.control_dim, max_action=ctl.max_action, squash=True)
+                r, dX, dY, dl = ctx.rollout_grad_rbf_batch([spec] * nb, rw, mm, SS, H, X, Y, ls, nz)
+                for k, i in enumerate(todo):
+                    ui = us[k]
+                    g = np.concatenate([dX[k].ravel(), dY[k].ravel(), (dl[k] * _dsoftplus(ui[-dl[k].size:]).reshape(dl[k].shape)).ravel()])
+                    cache[i] = (ui, -float(r[k]), -g)
+        vals = np.array([cache[i][1] for i in range(B)])
+        grad = np.concatenate([cache[i][2] for i in range(B)])
+        return vals, grad
+
+    from . import _lib
+    base_kind = _lib.POLICY_RBF
+    u_end, _ = lockstep_minimize(eval_all, np.concatenate(starts), parts, maxiter=maxiter, wall=())
+    best_u, best_r = None, None
+    for i in range(B):
+        put(u_end[parts[i]])
+        r = float(pilco.compute_reward()[0, 0])
+        if verbose:
+            print("Controller's optimization: done in %.1f seconds with reward=%.3f." % (time.time() - start, r))
+        if best_r is None or r > best_r:                           # pilco.py:104-106
+            best_u, best_r = u_end[parts[i]].copy(), r
+    put(best_u)
+    return best_r
+
+
 def optimize_policy(pilco, maxiter=50, restarts=1, verbose=True):
     if pilco.controller is None:
         raise ValueError("optimize_policy: the model has no controller (control_dim == 0)")
+    if restarts >= 2 and _restart_lanes_apply(pilco):
+        return _optimize_policy_lanes(pilco, maxiter, restarts, verbose)
     get, put = _policy_params(pilco.controller)
 
     def run():

@@ -2249,3 +2249,78 @@ def test_one_launch_step_of_small_models_agrees_with_the_two_launch_step(N, D, E
             np.testing.assert_allclose(g1[0], runs[1][0][2], rtol=1e-9)     # the tape's value is the rollout's reward
     finally:
         cx.close()
+
+
+@pytest.mark.parametrize("N,E,U", [(200, 4, 1), (1000, 10, 1)])
+def test_batched_value_and_gradient_lanes_are_bit_identical_to_their_solo_calls(N, E, U):
+    """pilco_rollout_grad_batch / pilco_rollout_grad_rbf_batch: B value-and-gradient rollouts of one model in flight together
+    (the restarts of optimize_policy, pilco.py:94-107).  Every lane runs the launch sequence and the host arithmetic of its
+    solo call: reward and gradients are the solo call's, to the last bit -- for a small model (one-launch steps) and at the
+    benchmark size (sweep launches), LinearController and RbfController, and again on a second batch."""
+    from pilco_amd import _lib
+    from pilco_amd.controllers import RbfController
+    D, H, B, bf = E + U, 6, 3, 7
+    c = synthetic.config_c2(N=N, D=D, E=E, noise=1e-2, seed=17, control_dim=U)
+    rs = np.random.RandomState(4)
+    rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(E), t=np.zeros(E))]
+    m0 = np.stack([c["m0"].ravel() + 0.01 * i for i in range(B)])
+    S0 = np.stack([(0.05 + 0.01 * i) * np.eye(E) for i in range(B)])
+    cx = _lib.Context()
+    try:
+        cx.gp_set_data(0, c["X"], c["Y"]); cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"]); cx.gp_factorize(0)
+        pols = [dict(kind=_lib.POLICY_LINEAR, state_dim=E, control_dim=U, W=c["W"] + 0.1 * rs.randn(U, E), b=c["b"].ravel() + 0.1 * rs.randn(U),
+                     max_action=1.3, squash=True) for _ in range(B)]
+        solo = [cx.rollout_grad(pols[i], rw, m0[i], S0[i], H) for i in range(B)]
+        for rep in range(2):
+            r, dW, db = cx.rollout_grad_batch(pols, rw, m0, S0, H)
+            for i in range(B):
+                assert r[i] == solo[i][0] and np.array_equal(dW[i], solo[i][1].reshape(U, E)) and np.array_equal(db[i], solo[i][2].reshape(U))
+        r1, dW1, db1 = cx.rollout_grad_batch(pols[:1], rw, m0[:1], S0[:1], H)           # a batch of one is the solo call
+        assert r1[0] == solo[0][0] and np.array_equal(dW1[0], solo[0][1].reshape(U, E))
+        # RbfController lanes: the call uploads every lane's policy GP itself
+        Xp = rs.randn(B, bf, E); Yp = 0.3 * rs.randn(B, bf, U); lsp = 1.0 + 0.2 * rs.rand(B, U, E); nz = np.full((B, U), 1e-4)
+        spec = dict(kind=_lib.POLICY_RBF, state_dim=E, control_dim=U, max_action=1.2, squash=True)
+        solo = []
+        for i in range(B):
+            ctl = RbfController(E, U, bf, max_action=1.2, ctx=cx)
+            ctl.set_data((Xp[i], Yp[i]))
+            for k, mdl in enumerate(ctl.models):
+                mdl.kernel.lengthscales.assign(lsp[i, k])
+            solo.append(cx.rollout_grad_rbf(ctl.policy_spec(), rw, m0[i], S0[i], H, Xp[i], Yp[i], lsp[i], nz[i]))
+        for rep in range(2):
+            r, dX, dY, dl = cx.rollout_grad_rbf_batch([spec] * B, rw, m0, S0, H, Xp, Yp, lsp, nz)
+            for i in range(B):
+                assert r[i] == solo[i][0]
+                assert np.array_equal(dX[i], solo[i][1]) and np.array_equal(dY[i], solo[i][2]) and np.array_equal(dl[i], solo[i][3])
+        # the policy slot of this context now holds lane 0's controller; a controller that believed to own it pushes again
+        again = cx.rollout_grad_rbf(ctl.policy_spec(), rw, m0[B - 1], S0[B - 1], H, Xp[B - 1], Yp[B - 1], lsp[B - 1], nz[B - 1])
+        assert again[0] == solo[B - 1][0] and np.array_equal(again[1], solo[B - 1][1])
+    finally:
+        cx.close()
+
+
+@pytest.mark.parametrize("kind", ["linear", "rbf"])
+def test_optimize_policy_runs_its_restarts_as_lanes_and_ends_where_the_sequential_loop_ends(kind, monkeypatch):
+    """PILCO.optimize_policy(restarts=3) (pilco.py:75-113): the three L-BFGS-B walks side by side, one batched value-and-gradient
+    call per round (training._optimize_policy_lanes), against the reference's loop -- one restart after the other
+    (PILCO_RESTART_LANES=0).  Same starts (drawn where the reference draws them), bit-identical evaluations: the same walks,
+    the same end point, the same reward."""
+    from pilco_amd.models import PILCO
+    from pilco_amd.controllers import LinearController, RbfController
+    rs = np.random.RandomState(2)
+    X = rs.randn(120, 4) * np.array([0.4, 0.3, 0.8, 1.5])
+    Y = 0.05 * np.stack([np.sin(X @ rs.randn(4)) for _ in range(3)], 1) + 1e-3 * rs.randn(120, 3)
+    ends = {}
+    for lanes in ("0", "1"):
+        monkeypatch.setenv("PILCO_RESTART_LANES", lanes)
+        np.random.seed(11)
+        ctl = LinearController(3, 1, max_action=2.0) if kind == "linear" else RbfController(3, 1, 6, max_action=2.0)
+        p = PILCO((X, Y), controller=ctl, horizon=8, m_init=np.array([[0.1, -0.1, 0.2]]), S_init=0.02 * np.eye(3))
+        for m in p.mgpr.models:
+            m.kernel.lengthscales.assign(np.array([0.8, 0.6, 1.5, 3.0])); m.kernel.variance.assign(0.02); m.likelihood.variance.assign(1e-5)
+        np.random.seed(5)
+        r = p.optimize_policy(maxiter=12, restarts=3, verbose=False)
+        from pilco_amd.training import _policy_params
+        ends[lanes] = (r, _policy_params(p.controller)[0]())
+    assert ends["0"][0] == ends["1"][0]
+    assert np.array_equal(ends["0"][1], ends["1"][1])

@@ -1,0 +1,55 @@
+"""optimize_policy(maxiter=50, restarts=3) at config-5 size (N=225, D=5, E=4, horizon 40): the restarts as lanes of one batched
+value-and-gradient call per round (default) against the reference's loop, one restart after the other (PILCO_RESTART_LANES=0);
+and B value-and-gradient rollouts as ONE pilco_rollout_grad[_rbf]_batch call against B solo calls.  Developer tool."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pilco_amd import _lib
+from pilco_amd.controllers import RbfController, LinearController
+from pilco_amd.models import PILCO
+rs = np.random.RandomState(0)
+X = rs.randn(225, 5) * np.array([0.3, 0.1, 0.5, 0.8, 2.0])
+Y = 0.05 * np.stack([np.sin(X @ rs.randn(5)) for _ in range(4)], 1) + 1e-3 * rs.randn(225, 4)
+def med(fn, n=15):
+    fn(); fn(); ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+for name in ("rbf", "linear"):
+    res = {}
+    for lanes in ("0", "1"):
+        os.environ["PILCO_RESTART_LANES"] = lanes
+        np.random.seed(0)
+        ctl = RbfController(state_dim=4, control_dim=1, num_basis_functions=10, max_action=3.0) if name == "rbf" else LinearController(4, 1, max_action=3.0)
+        p = PILCO((X, Y), controller=ctl, horizon=40)
+        for m in p.mgpr.models:
+            m.kernel.lengthscales.assign(np.array([0.5, 0.3, 1.0, 1.5, 3.0])); m.kernel.variance.assign(0.01); m.likelihood.variance.assign(1e-5)
+        p.compute_reward()
+        ts = []
+        for rep in range(3):
+            np.random.seed(1)
+            p.controller.randomize()
+            t0 = time.perf_counter()
+            r = p.optimize_policy(maxiter=50, restarts=3, verbose=False)
+            ts.append(time.perf_counter() - t0)
+        res[lanes] = (min(ts), r)
+    print("config-5 size, %s controller: optimize_policy(maxiter=50, restarts=3): sequential %.3f s (reward %.4f), as lanes %.3f s (reward %.4f): %.2fx" % (
+        name, res["0"][0], res["0"][1], res["1"][0], res["1"][1], res["0"][0] / res["1"][0]))
+    # raw evaluations
+    ctx = p.ctx
+    rw, H, E, U = p._reward_terms(), 40, 4, 1
+    m0, S0 = np.asarray(p.m_init).reshape(-1), np.asarray(p.S_init)
+    for B in (1, 2, 3, 4, 8):
+        mm, SS = np.tile(m0, (B, 1)), np.tile(S0, (B, 1, 1))
+        if name == "linear":
+            pols = [dict(p.controller.policy_spec(True), W=rs.randn(1, 4), b=rs.randn(1)) for _ in range(B)]
+            tb = med(lambda: ctx.rollout_grad_batch(pols, rw, mm, SS, H))
+            tsolo = med(lambda: [ctx.rollout_grad(pols[i], rw, m0, S0, H) for i in range(B)])
+        else:
+            bf = 10
+            Xp, Yp, lsp, nz = rs.randn(B, bf, E), 0.3 * rs.randn(B, bf, U), 1 + 0.1 * rs.rand(B, U, E), np.full((B, U), 1e-4)
+            spec = dict(kind=_lib.POLICY_RBF, state_dim=E, control_dim=U, max_action=3.0, squash=True)
+            tb = med(lambda: ctx.rollout_grad_rbf_batch([spec] * B, rw, mm, SS, H, Xp, Yp, lsp, nz))
+            ctx.rollout_grad_rbf_batch([spec], rw, mm[:1], SS[:1], H, Xp[:1], Yp[:1], lsp[:1], nz[:1])
+            tsolo = B * med(lambda: ctx.rollout_grad_rbf(spec, rw, m0, S0, H, Xp[0], Yp[0], lsp[0], nz[0]))
+        print("  B=%d value+gradient: one batch call %.3f ms (%.3f ms per lane), solo calls %.3f ms: %.2fx" % (B, tb, tb / B, tsolo, tsolo / tb))
