@@ -15,8 +15,13 @@ size_t prep_lds_bytes(int DT);
 // PK: the controller code compiled into the fused head's link (glue_body<PK, SR>): 0 none, 3 linear, 1 RBF from its own
 // launches, 2 RBF inline; SR: single rank (no peer exchange, no gathered segments).  The plain operand kernel (FUSED = false)
 // has no link and exists for <0, true> only.
+// Heads of small input dimensions (DT <= 6: 17-22 spilled registers, DT = 8 would spill 51) are held to 128 registers (four
+// waves per SIMD), so that TWO workgroups fit a CU: the lanes of a batch call, whose launches run side by side, then share
+// the CUs instead of queueing for them -- the serial link is latency, not issue slots.  Measured at config-5 size (one box,
+// tools/restart_lanes_bench.py): three value-and-gradient lanes 1.96 -> 1.42 ms (linear) / 3.10 -> 2.35 ms (RBF), a solo
+// call 1.043 -> 1.055 ms.
 template <int DT, bool FUSED, int PK = 0, bool SR = true>
-__global__ __launch_bounds__(512) void k_mm_prep(MMModel md, MMWork wk, PrepReward pr, GlueArgs g, int glue_doubles) {
+__global__ __launch_bounds__(512, (FUSED && DT <= 6) ? 4 : 2) void k_mm_prep(MMModel md, MMWork wk, PrepReward pr, GlueArgs g, int glue_doubles) {
     extern __shared__ __attribute__((aligned(16))) double sm_all[];
     // FUSED: the serial link of the previous step runs first, redundantly in every workgroup (see glue_device.h); it
     // leaves the joint Gaussian of THIS step (L.jm, L.js) and the current state (L.mx, L.sx) in the first glue_doubles

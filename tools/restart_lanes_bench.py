@@ -3,7 +3,7 @@ value-and-gradient call per round (default) against the reference's loop, one re
 and B value-and-gradient rollouts as ONE pilco_rollout_grad[_rbf]_batch call against B solo calls.  Developer tool."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("PILCO_AB_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (PILCO_AB_ROOT: a directory holding another build's pilco_amd/)
 from pilco_amd import _lib
 from pilco_amd.controllers import RbfController, LinearController
 from pilco_amd.models import PILCO
