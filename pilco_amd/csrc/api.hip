@@ -94,6 +94,7 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     ENSURE(s.w_fpart, (size_t)2 * PLa * wk.NCH * 4 * 2);   // (up to four column splits per row chunk)
     wk.fuse_pair = 0;
     wk.NCS = 1;
+    wk.share_cu = 0;
     ENSURE(s.w_gath, (size_t)W * wk.SEG);
     ENSURE(s.w_out, (size_t)E + E * E + D * E);
     wk.in_m = s.w_in.p;

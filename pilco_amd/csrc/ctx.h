@@ -160,6 +160,7 @@ struct pilco_ctx {
     // dynamics slot BORROWS this context's model buffers; owned and destroyed by this context
     std::vector<pilco_ctx*> lanes;
     bool is_lane = false;
+    int share_cu = 0;   // > 0 while this context runs as one of several lanes of a batch call (heads launch their two-per-CU build)
 };
 
 int fail(pilco_ctx* c, int code, const std::string& msg);
@@ -244,6 +245,11 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
                   const double* S0, int H, double* reward, const double** traj, const double** tape, const double** jrec, size_t* jstride,
                   const double** reward_later = nullptr);   // reward_later: return without waiting (one rank); *reward_later is valid once rollout_jtape_wait(ctx, H - 1) has returned
 int rollout_lanes(pilco_ctx* ctx, int B, std::vector<pilco_ctx*>& lane, const char* who);   // lanes of a batch call (rollout.hip)
+void rollout_lanes_done(pilco_ctx* ctx);   // ... and after it: the context is on its own again
+struct LanesGuard {
+    pilco_ctx* c;
+    ~LanesGuard() { rollout_lanes_done(c); }
+};
 int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_term* rw, int n_rw, int H, bool want_traj,
                   RolloutPlan& plan);
 int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev);

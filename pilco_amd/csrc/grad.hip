@@ -886,6 +886,7 @@ int pilco_rollout_grad_batch(pilco_ctx* ctx, int B, const pilco_policy* policies
     for (int i = 0; i < B; ++i)
         if (int r = check_grad_args(ctx, &policies[i], rewards, n_rewards, PILCO_POLICY_LINEAR)) return r;
     std::vector<pilco_ctx*> lane;
+    LanesGuard lanes_guard{ctx};
     if (int r = rollout_lanes(ctx, B, lane, "rollout_grad_batch")) return r;
     const int E = policies[0].state_dim, U = policies[0].control_dim;
     std::vector<GradCall> gc((size_t)B);
@@ -927,6 +928,7 @@ int pilco_rollout_grad_rbf_batch(pilco_ctx* ctx, int B, const pilco_policy* poli
     for (int i = 0; i < B; ++i)
         if (int r = check_grad_args(ctx, &policies[i], rewards, n_rewards, PILCO_POLICY_RBF)) return r;
     std::vector<pilco_ctx*> lane;
+    LanesGuard lanes_guard{ctx};
     if (int r = rollout_lanes(ctx, B, lane, "rollout_grad_rbf_batch")) return r;
     const int E = policies[0].state_dim, U = policies[0].control_dim;
     const size_t nX = (size_t)bf * E, nY = (size_t)bf * U, nL = (size_t)U * E;

@@ -54,6 +54,7 @@ struct MMWork {
     int sk_ud, sk_uo;    // cost units of a diagonal / off-diagonal column step (diagonal steps also stream iK)
     int fuse_pair;       // small models: the operand launch's pair workgroups also evaluate their pair sums (pair_part [PL][NCH][2]); no pair launch.  2: ... as the reverse sweep (value-and-gradient rollouts)
     double* sw_gpart;    // fuse_pair == 2: this step's [PL][NT][2][256] blocks (G | Gc per workgroup)
+    int share_cu;        // the head launches its 128-register build (two workgroups per CU): this context is a lane of a batch call
     int NCS;             // fuse_pair with LDS-resident operands: column splits per (pair, row chunk) -- the launch spreads a small model over
                          // the CUs it would leave idle (grid y = NCH * NCS, NT = NCH * NCS partials per pair); 1 elsewhere
     const double* exp_tab;    // [n] 2^(j/n), n = mm_exp_table_size(), for the table-driven fp64 exp of the pair kernel

@@ -15,13 +15,13 @@ size_t prep_lds_bytes(int DT);
 // PK: the controller code compiled into the fused head's link (glue_body<PK, SR>): 0 none, 3 linear, 1 RBF from its own
 // launches, 2 RBF inline; SR: single rank (no peer exchange, no gathered segments).  The plain operand kernel (FUSED = false)
 // has no link and exists for <0, true> only.
-// Heads of small input dimensions (DT <= 6: 17-22 spilled registers, DT = 8 would spill 51) are held to 128 registers (four
-// waves per SIMD), so that TWO workgroups fit a CU: the lanes of a batch call, whose launches run side by side, then share
-// the CUs instead of queueing for them -- the serial link is latency, not issue slots.  Measured at config-5 size (one box,
-// tools/restart_lanes_bench.py): three value-and-gradient lanes 1.96 -> 1.42 ms (linear) / 3.10 -> 2.35 ms (RBF), a solo
-// call 1.043 -> 1.055 ms.
-template <int DT, bool FUSED, int PK = 0, bool SR = true>
-__global__ __launch_bounds__(512, (FUSED && DT <= 6) ? 4 : 2) void k_mm_prep(MMModel md, MMWork wk, PrepReward pr, GlueArgs g, int glue_doubles) {
+// OCC2: the same kernel held to 128 registers (four waves per SIMD; it spills 17-22 registers at DT <= 6, 51 at DT = 8), so that
+// TWO workgroups fit a CU.  Launched for the lanes of a batch call (MMWork::share_cu), whose launches run side by side: they
+// then share the CUs instead of queueing for them -- the serial link is latency, not issue slots.  Same arithmetic, same bits.
+// Measured at config-5 size (tools/restart_lanes_bench.py): three value-and-gradient lanes 1.96 -> 1.42 ms (linear) /
+// 3.10 -> 2.35 ms (RBF); a SOLO call loses 3-5 % to the spills (forward pair phase 2.6 -> 3.3 us), hence two instantiations.
+template <int DT, bool FUSED, int PK = 0, bool SR = true, bool OCC2 = false>
+__global__ __launch_bounds__(512, OCC2 ? 4 : 2) void k_mm_prep(MMModel md, MMWork wk, PrepReward pr, GlueArgs g, int glue_doubles) {
     extern __shared__ __attribute__((aligned(16))) double sm_all[];
     // FUSED: the serial link of the previous step runs first, redundantly in every workgroup (see glue_device.h); it
     // leaves the joint Gaussian of THIS step (L.jm, L.js) and the current state (L.mx, L.sx) in the first glue_doubles
@@ -84,18 +84,28 @@ void launch_prep_dt(const PrepLaunch& a) {
     const MMWork& wk = *a.wk;
     const PrepReward& r = *a.r;
     const GlueArgs& ga = *a.ga;
-#define PREP1(DT_, F_, PK_, SR_)                                                                           \
+#define PREP2(DT_, F_, PK_, SR_, O_)                                                                       \
     do {                                                                                                   \
         const size_t lds_ = std::max(prep_lds_bytes(DT_), lds_rw) + sizeof(double) * (size_t)gd;           \
         static size_t configured_[64] = {};  /* beyond the default dynamic-LDS limit: opt in once PER DEVICE */ \
         size_t& conf_ = configured_[dev_ & 63];                                                            \
         if (conf_ == 0) conf_ = 48 * 1024;                                                                 \
         if (lds_ > conf_) {                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mm_prep<DT_, F_, PK_, SR_>),         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mm_prep<DT_, F_, PK_, SR_, O_>),     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);              \
             conf_ = lds_;                                                                                  \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_mm_prep<DT_, F_, PK_, SR_>), grid, dim3(512), lds_, st, md, wk, r, ga, gd);  \
+        hipLaunchKernelGGL((k_mm_prep<DT_, F_, PK_, SR_, O_>), grid, dim3(512), lds_, st, md, wk, r, ga, gd); \
+    } while (0)
+    /* the two-per-CU build exists for the single-rank heads with a controller at DT <= 8 (the lanes of a gradient batch) */
+#define PREP1(DT_, F_, PK_, SR_)                                                                           \
+    do {                                                                                                   \
+        if constexpr (F_ && SR_ && (PK_ == 2 || PK_ == 3) && DT_ <= 8) {                                   \
+            if (wk.share_cu) PREP2(DT_, F_, PK_, SR_, true);                                               \
+            else PREP2(DT_, F_, PK_, SR_, false);                                                          \
+        } else {                                                                                           \
+            PREP2(DT_, F_, PK_, SR_, false);                                                               \
+        }                                                                                                  \
     } while (0)
 #define PREP(DT_)                                              \
     do {                                                       \
@@ -112,6 +122,7 @@ void launch_prep_dt(const PrepLaunch& a) {
     PREP(DT);
 #undef PREP
 #undef PREP1
+#undef PREP2
 }
 
 // defined in prep_dt_*.hip

@@ -341,6 +341,7 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
                 wkb[k].fuse_pair = jac ? 2 : 1;
                 wkb[k].sk_waves = 0;           // the link packs tile partials: one per (pair, row chunk)
                 wkb[k].NCS = small_col_splits(ctx, s, rew);
+                wkb[k].share_cu = ctx->share_cu;
                 wkb[k].NT = wk0.NCH * wkb[k].NCS;
                 wkb[k].pair_part = s.w_fpart.p + (size_t)k * std::max(wk0.PL, 1) * wk0.NCH * 4 * 2;
             }
@@ -753,7 +754,7 @@ int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
     const GlueArgs& g = plan.g;
     std::vector<unsigned long long> key = {
         (unsigned long long)H, (unsigned long long)g.pol_kind, (unsigned long long)g.n_rewards, (unsigned long long)g.squash,
-        (unsigned long long)ctx->variant, (unsigned long long)ctx->fused + 2ull * (unsigned long long)ctx->fuse_small, (unsigned long long)(uintptr_t)plan.st[0], (unsigned long long)(uintptr_t)g.s1,
+        (unsigned long long)ctx->variant, (unsigned long long)ctx->fused + 2ull * (unsigned long long)ctx->fuse_small + 4ull * (unsigned long long)(ctx->share_cu != 0), (unsigned long long)(uintptr_t)plan.st[0], (unsigned long long)(uintptr_t)g.s1,
         (unsigned long long)(uintptr_t)g.traj, (unsigned long long)(uintptr_t)g.tape, (unsigned long long)(uintptr_t)g.W, (unsigned long long)(uintptr_t)g.maxact,
         (unsigned long long)(uintptr_t)s.w_part.p, (unsigned long long)(uintptr_t)s.w_At.p, (unsigned long long)(uintptr_t)s.w_Bt.p,
         (unsigned long long)(uintptr_t)s.w_small.p, (unsigned long long)(uintptr_t)s.w_gath.p, (unsigned long long)(uintptr_t)s.w_out.p,
@@ -961,6 +962,7 @@ int rollout_lanes(pilco_ctx* ctx, int B, std::vector<pilco_ctx*>& lane, const ch
     lane.resize((size_t)B);
     for (int i = 0; i < B; ++i) {
         lane[i] = i == 0 ? ctx : ctx->lanes[i - 1];
+        lane[i]->share_cu = B > 1 ? 1 : 0;   // (the caller resets lane 0's when the batch is over: rollout_lanes_done)
         if (i > 0) {
             HIPCHK(hipStreamSynchronize(lane[i]->st));
             if (int r = lane_sync_model(ctx, lane[i])) return r;
@@ -970,6 +972,8 @@ int rollout_lanes(pilco_ctx* ctx, int B, std::vector<pilco_ctx*>& lane, const ch
     HIPCHK(hipStreamSynchronize(ctx->st));
     return PILCO_OK;
 }
+
+void rollout_lanes_done(pilco_ctx* ctx) { ctx->share_cu = 0; }
 
 extern "C" {
 
@@ -1005,6 +1009,7 @@ int pilco_rollout_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, con
     const size_t nst = (size_t)E + (size_t)E * E;
     std::vector<RolloutCall> rc((size_t)B);
     std::vector<pilco_ctx*> lane;
+    LanesGuard lanes_guard{ctx};
     if (int r = rollout_lanes(ctx, B, lane, "rollout_batch")) return r;
     int rc_err = PILCO_OK;
     int begun = 0;

@@ -14,3 +14,7 @@ tail -1 gpurun_out/factprof/trace.log
 python tools/fact_ab.py 2>&1 | grep graph > gpurun_out/fact_ab.log; cat gpurun_out/fact_ab.log
 python tools/small_step_ab.py > gpurun_out/small_step_ab.log 2>&1; cat gpurun_out/small_step_ab.log
 python tools/grad_bench.py > gpurun_out/grad_bench.log 2>&1; cat gpurun_out/grad_bench.log
+python tools/restart_lanes_bench.py > gpurun_out/restart_lanes.log 2>&1; cat gpurun_out/restart_lanes.log
+python tools/small_phases_c5.py > gpurun_out/small_phases_c5.log 2>&1; cat gpurun_out/small_phases_c5.log
+python tools/small_phases.py 2>&1 | tail -2 > gpurun_out/small_phases_c4.log; cat gpurun_out/small_phases_c4.log
+python examples/inverted_pendulum.py 2>&1 | tail -4 > gpurun_out/c5_loop.log; cat gpurun_out/c5_loop.log

@@ -53,3 +53,15 @@ for name in ("rbf", "linear"):
             ctx.rollout_grad_rbf_batch([spec], rw, mm[:1], SS[:1], H, Xp[:1], Yp[:1], lsp[:1], nz[:1])
             tsolo = B * med(lambda: ctx.rollout_grad_rbf(spec, rw, m0, S0, H, Xp[0], Yp[0], lsp[0], nz[0]))
         print("  B=%d value+gradient: one batch call %.3f ms (%.3f ms per lane), solo calls %.3f ms: %.2fx" % (B, tb, tb / B, tsolo, tsolo / tb))
+# benchmark size (C2u: N=1000, state 10 + 1 control): the sweep launches fill the chip by themselves, lanes hide heads and finish only
+from pilco_amd import synthetic
+c = synthetic.config_c2(N=1000, D=11, E=10)
+cx = _lib.Context()
+cx.gp_set_data(0, c["X"], c["Y"]); cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"]); cx.gp_factorize(0)
+rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(10), t=np.zeros(10))]
+for B in (1, 2, 3):
+    pols = [dict(kind=_lib.POLICY_LINEAR, state_dim=10, control_dim=1, W=c["W"] + 0.05 * rs.randn(1, 10), b=c["b"].ravel(), max_action=1.0, squash=True) for _ in range(B)]
+    mm, SS = np.tile(c["m0"].ravel(), (B, 1)), np.tile(c["S0"], (B, 1, 1))
+    tb = med(lambda: cx.rollout_grad_batch(pols, rw, mm, SS, 40), 8)
+    tsolo = med(lambda: [cx.rollout_grad(pols[i], rw, c["m0"], c["S0"], 40) for i in range(B)], 8)
+    print("C2u (N=1000, D=11): B=%d value+gradient: one batch call %.3f ms (%.3f ms per lane), solo calls %.3f ms: %.2fx" % (B, tb, tb / B, tsolo, tsolo / tb))
