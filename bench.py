@@ -283,6 +283,25 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
                           "forward pair kernel (one O(N^2) pass per step gives value and Jacobian), the reverse sweep is host algebra")
     out["R_grad_C2u_per_s"] = 1e3 / g_ms
     out["R_fwd_C2u_ms"] = f_ms
+    # pilco_rollout_grad_batch: the restarts of optimize_policy (pilco.py:94-107) as lanes -- B value-and-gradient rollouts of this
+    # model in flight, one controller each; every lane bit-identical to its solo call.  Throughput mode, never the headline.
+    try:
+        rsb = np.random.RandomState(11)
+        spec = p._policy_spec()
+        lanes = {}
+        for B in (2, 3):
+            pols = [dict(spec, W=cu["W"] + 0.05 * rsb.randn(*np.shape(cu["W"])), b=np.ravel(cu["b"])) for _ in range(B)]
+            m0b, S0b = np.tile(np.ravel(cu["m0"]), (B, 1)), np.tile(cu["S0"], (B, 1, 1))
+            rB, dWB, dbB = ctx.rollout_grad_batch(pols, p._reward_terms(), m0b, S0b, H)
+            solo = ctx.rollout_grad(pols[B - 1], p._reward_terms(), m0b[B - 1], S0b[B - 1], H)
+            same = bool(rB[B - 1] == solo[0] and np.array_equal(dWB[B - 1].ravel(), np.ravel(solo[1])) and np.array_equal(dbB[B - 1].ravel(), np.ravel(solo[2])))
+            b_ms = _median_ms(lambda: ctx.rollout_grad_batch(pols, p._reward_terms(), m0b, S0b, H), 5)
+            lanes["B=%d" % B] = {"ms_per_batch": b_ms, "ms_per_lane": b_ms / B, "per_lane_over_R_fwd_C2u": b_ms / B / f_ms,
+                                 "last_lane_bit_identical_to_its_solo_call": same}
+        lanes["note"] = "the sweep launches fill the chip by themselves: lanes hide the heads and the finish only (bound: 0.77 of the solo time per lane)"
+        out["R_grad_C2u_lanes"] = lanes
+    except Exception as exc:
+        out["R_grad_C2u_lanes"] = {"error": repr(exc)}
     # roofline of the value-and-gradient rollout's dominant kernel (the reverse sweep k_mm_bwd_pair that stands in for the
     # forward pair kernel): its launches bracketed by HIP events in a separate, untimed pass
     try:
