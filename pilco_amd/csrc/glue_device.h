@@ -434,7 +434,7 @@ __device__ __forceinline__ void xq_push(const GlueArgs& g, const double* seg_lds
 // Every reduction is done by threads 0..255 in a fixed order, whatever the workgroup size: all workgroups of a head -- and
 // k_glue -- produce the same bits.
 struct RbfInlineLayout {
-    int ctr, bet, il, var, lvar, aug0, aug1, piv, T, Q, det, pt, red, total;
+    int ctr, bet, il, var, lvar, aug0, aug1, piv, T, Q, det, pt, red, red3, total;
 };
 __host__ __device__ inline RbfInlineLayout rbf_inline_layout(int E, int U, int bf) {
     const int P = U * (U + 1) / 2, nmat = U + P;
@@ -452,7 +452,8 @@ __host__ __device__ inline RbfInlineLayout rbf_inline_layout(int E, int U, int b
     l.Q = o;   o += P * E * E;              // Q_uv = R_uv^-1 s / 2
     l.det = o; o += nmat;                   // det B_u | det R_uv
     l.pt = o;  o += bf * (2 * E + 2) + bf * 16;   // per point of the current pair: u_i, v_i, p_i = 2 Q z_i, w_i | 16 doubles of scratch per point
-    l.red = o; o += 4 * (E + 2);            // wave partials
+    l.red = o; o += 4 * (E + 2);            // wave partials (mean part)
+    l.red3 = o; o += 4;                     // wave partials (covariance part: it may run beside the mean part)
     l.total = (o + 1) & ~1;
     return l;
 }
@@ -579,6 +580,8 @@ __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueL
         const int u = idiv_s(e, E * E, rc), r = idiv_s(rc, E, c);
         Tm[e] = cur[u * msz + r * nc + E + c] * il[u * E + r] * il[u * E + c];
     }
+    // (the logs the covariance part needs, by the workgroup's last threads: they run beside the T / Q products)
+    if (t >= nthr - U) W[lay.lvar + (t - (nthr - U))] = log(var[t - (nthr - U)]);
     for (int e = t; e < P * E * E; e += nthr) {   // Q_uv = R^-1 s / 2
         int rc, c;
         const int pq = idiv_s(e, E * E, rc), r = idiv_s(rc, E, c);
@@ -586,53 +589,57 @@ __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueL
     }
     __syncthreads();
     const int lane = t & 63, w = t >> 6;
-    // ---- 2. mean and input-output covariance of every output (mgpr.py:113-118).  bf <= 256: thread i < bf owns point i;
-    //         plain run-time loops over LDS (no unrolled register arrays: this code sits in the serial link's instruction
-    //         stream, where its SIZE costs as much as its work)
-    for (int u = 0; u < U; ++u) {
-        double lb = 0.0;
-        if (t < bf) {
-            double q = 0.0;
-            for (int r = 0; r < E; ++r) {
-                double tz = 0.0;
-                for (int c = 0; c < E; ++c) tz = fma(Tm[(u * E + r) * E + c], ctr[c * bf + t], tz);
-                q = fma(ctr[r * bf + t], tz, q);
+    // ---- 2. mean and input-output covariance of every output (mgpr.py:113-118) and 3. covariance of every output pair
+    //         (mgpr.py:120-147 with iK = 0).  bf <= 256: thread i < bf owns point i; plain run-time loops over LDS (no unrolled
+    //         register arrays: this code sits in the serial link's instruction stream, where its SIZE costs as much as its work).
+    //         Both parts need the batched Gauss-Jordan only, and pair k needs the means of outputs <= k: in a 512-thread host
+    //         (the fused head) round k evaluates output k on the lower half of the workgroup and pair k BESIDE it on the upper
+    //         half -- three barrier intervals per round instead of six, the pair's row operations hidden behind the mean
+    //         part's exp.  A 256-thread host (k_glue) runs the same code one part after the other: same arithmetic per
+    //         element, same bits.
+    const bool par = nthr >= 512 && 2 * bf <= 256;
+    double* red3 = W + lay.red3;
+    const int rounds = par ? (U > P ? U : P) : U + P;
+    for (int k = 0; k < rounds; ++k) {
+        const int u = k;                              // output of this round's mean part
+        const bool do2 = k < U;
+        const int pq = par ? k : k - U;               // pair of this round's covariance part
+        const bool do3 = pq >= 0 && pq < P;
+        int a = 0, b = 0;
+        if (do3) {
+            while ((a + 1) * (a + 2) / 2 <= pq) ++a;  // pair index pq = a (a + 1) / 2 + b, a >= b
+            b = pq - a * (a + 1) / 2;
+        }
+        const double* Q = Qm + (do3 ? pq : 0) * E * E;
+        double* uv = pt;                 // [bf] u_i (row side, output a)
+        double* vv = pt + bf;            // [bf] v_j (column side, output b)
+        double* pv = pt + 2 * bf;        // [bf][E] 2 Q z_i
+        double* wv = pv + bf * E;        // [bf][E] w_j
+        // -- interval A: the points' exponentials and their wave sums | the pair's row and column operands
+        if (do2) {
+            double lb = 0.0;
+            if (t < bf) {
+                double q = 0.0;
+                for (int r = 0; r < E; ++r) {
+                    double tz = 0.0;
+                    for (int c = 0; c < E; ++c) tz = fma(Tm[(u * E + r) * E + c], ctr[c * bf + t], tz);
+                    q = fma(ctr[r * bf + t], tz, q);
+                }
+                lb = exp(-0.5 * q) * bet[u * bf + t];
             }
-            lb = exp(-0.5 * q) * bet[u * bf + t];
-        }
-        // (the logs phase 3 needs, by a wave that has no point: they run while the point threads are inside their exp)
-        if (u == 0 && t >= nthr - U) W[lay.lvar + (t - (nthr - U))] = log(var[t - (nthr - U)]);   // (the workgroup's last threads, whatever its size)
-        if (t < 256) {
-            const double gs = wave_sum_lane63(lb);
-            if (lane == 63) red[w * (E + 2)] = gs;
-            for (int d = 0; d < E; ++d) {
-                const double v = wave_sum_lane63((t < bf) ? ctr[d * bf + t] * lb : 0.0);
-                if (lane == 63) red[w * (E + 2) + 1 + d] = v;
+            if (t < 256) {
+                const double gs = wave_sum_lane63(lb);
+                if (lane == 63) red[w * (E + 2)] = gs;
+                for (int d = 0; d < E; ++d) {
+                    const double v = wave_sum_lane63((t < bf) ? ctr[d * bf + t] * lb : 0.0);
+                    if (lane == 63) red[w * (E + 2) + 1 + d] = v;
+                }
             }
         }
-        __syncthreads();
-        if (t <= E) red[t] = ((red[t] + red[(E + 2) + t]) + red[2 * (E + 2) + t]) + red[3 * (E + 2) + t];   // (row 0 receives the totals)
-        __syncthreads();
-        const double cu = var[u] / sqrt(det[u]);
-        if (t == 0) L.mu[u] = cu * red[0];
-        if (t < E) {
-            double acc = 0.0;
-            for (int k = 0; k < E; ++k) acc = fma(Tm[(u * E + t) * E + k], red[1 + k], acc);
-            L.cxu[t * U + u] = cu * acc;   // V (E, U)
-        }
-        __syncthreads();
-    }
-    // ---- 3. covariance of every output pair (mgpr.py:120-147 with iK = 0)
-    for (int a = 0; a < U; ++a)
-        for (int b = 0; b <= a; ++b) {
-            const int pq = a * (a + 1) / 2 + b;
-            const double* Q = Qm + pq * E * E;
-            double* uv = pt;                 // [bf] u_i (row side, output a)
-            double* vv = pt + bf;            // [bf] v_j (column side, output b)
-            double* pv = pt + 2 * bf;        // [bf][E] 2 Q z_i
-            double* wv = pv + bf * E;        // [bf][E] w_j
+        if (do3) {
             const double la = W[lay.lvar + a], lb_ = W[lay.lvar + b];
-            for (int i = t; i < 2 * bf; i += nthr) {
+            const int t3 = par ? t - 256 : t;
+            for (int i = t3; i >= 0 && i < 2 * bf; i += nthr) {
                 const int side = i >= bf, ii = side ? i - bf : i;
                 const double* ilo = il + (side ? b : a) * E;
                 double* xrow = wv + ii * E;          // side 1: w_j is what stays here; side 0: scratch in the OTHER half below
@@ -665,31 +672,43 @@ __device__ __forceinline__ void rbf_policy_inline(const GlueArgs& g, const GlueL
                     uv[ii] = kk + quad;
                 }
             }
-            __syncthreads();
-            double acc = 0.0;
-            if (t < 256)
-                for (int idx = t; idx < bf * bf; idx += 256) {
-                    int j;
-                    const int i = idiv_s(idx, bf, j);
-                    double e = uv[i] + vv[j];
-                    for (int d = 0; d < E; ++d) e = fma(pv[i * E + d], wv[j * E + d], e);
-                    acc = fma(bet[a * bf + i] * bet[b * bf + j], exp(e), acc);
-                }
-            if (t < 256) {
-                const double sacc = wave_sum_lane63(acc);
-                if (lane == 63) red[w] = sacc;
-            }
-            __syncthreads();
-            if (t == 0) {
-                const double N = (red[0] + red[1]) + (red[2] + red[3]);
-                double v = N / sqrt(det[U + pq]);
-                if (a == b) v += var[a];                         // mgpr.py:146
-                v = fma(-L.mu[a], L.mu[b], v);                   // mgpr.py:147
-                L.su[a * U + b] = v;
-                L.su[b * U + a] = v;
-            }
-            __syncthreads();
         }
+        __syncthreads();
+        // -- interval B: the mean part's totals | the pair's bf^2 exponentials and their wave sums
+        if (do2 && t <= E) red[t] = ((red[t] + red[(E + 2) + t]) + red[2 * (E + 2) + t]) + red[3 * (E + 2) + t];   // (row 0 receives the totals)
+        if (do3 && t < 256) {
+            double acc = 0.0;
+            for (int idx = t; idx < bf * bf; idx += 256) {
+                int j;
+                const int i = idiv_s(idx, bf, j);
+                double e = uv[i] + vv[j];
+                for (int d = 0; d < E; ++d) e = fma(pv[i * E + d], wv[j * E + d], e);
+                acc = fma(bet[a * bf + i] * bet[b * bf + j], exp(e), acc);
+            }
+            const double sacc = wave_sum_lane63(acc);
+            if (lane == 63) red3[w] = sacc;
+        }
+        __syncthreads();
+        // -- interval C: M_u and V_u | S_ab (thread 0 has written the means of outputs <= k by then: a <= pq = k)
+        if (do2) {
+            const double cu = var[u] / sqrt(det[u]);
+            if (t == 0) L.mu[u] = cu * red[0];
+            if (t < E) {
+                double acc = 0.0;
+                for (int kq = 0; kq < E; ++kq) acc = fma(Tm[(u * E + t) * E + kq], red[1 + kq], acc);
+                L.cxu[t * U + u] = cu * acc;   // V (E, U)
+            }
+        }
+        if (do3 && t == 0) {
+            const double N = (red3[0] + red3[1]) + (red3[2] + red3[3]);
+            double v = N / sqrt(det[U + pq]);
+            if (a == b) v += var[a];                         // mgpr.py:146
+            v = fma(-L.mu[a], L.mu[b], v);                   // mgpr.py:147
+            L.su[a * U + b] = v;
+            L.su[b * U + a] = v;
+        }
+        __syncthreads();
+    }
 }
 
 // The serial link.  On return (GF_POLICY) the joint Gaussian is in L.jm / L.js and the (propagated) state in L.mx / L.sx.
