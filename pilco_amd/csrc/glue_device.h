@@ -140,23 +140,41 @@ __device__ __forceinline__ void squash_inplace(const GlueLds& L, int U, const do
     double newM = 0.0, newC = 0.0;
     for (int i0 = 0; i0 < 5 * nitems; i0 += cap) {
         const int n = (5 * nitems - i0) < cap ? (5 * nitems - i0) : cap;
-        for (int k = t; k < n; k += blockDim.x) {
-            const int q = (i0 + k) / 5, j = (i0 + k) - 5 * q;
-            double arg;
-            int fn;   // 0 exp, 1 cos, 2 sin, 3 unused slot
-            if (q < U * U) {
-                int v;
-                const int u = idiv_s(q, U, v);
-                const double lq = -(L.su[u * U + u] + L.su[v * U + v]) / 2.0;
-                const double suv = L.su[q];
-                arg = (j == 0) ? lq : (j == 1) ? lq + suv : (j == 2) ? lq - suv : (j == 3) ? L.mu[u] - L.mu[v] : L.mu[u] + L.mu[v];
-                fn = (j < 3) ? 0 : 1;
-            } else {
-                const int u = q - U * U;
-                arg = (j == 0) ? -L.su[u * U + u] / 2.0 : L.mu[u];
-                fn = (j < 3) ? j : 3;
+        // A wave evaluates ONE of the three functions (wave w: function w % 3; a wave whose lanes ask for different functions
+        // would run through all three bodies, 1.3 us of this serial path instead of 0.5): the round's slots of function f are
+        // dealt over the lanes of the waves that serve f.  Items [qa, qb) of this round: nc covariance elements, then nu controls.
+        {
+            const int w = t >> 6, f = w % 3, nw = (int)blockDim.x >> 6;
+            const int nwf = (nw - f + 2) / 3;                       // waves that serve function f
+            const int qa = i0 / 5, qb = (i0 + n) / 5;
+            const int nc = (U * U > qa) ? ((U * U < qb ? U * U : qb) - qa) : 0, nu = (qb - qa) - nc;
+            const int cnt = (f == 0) ? 3 * nc + nu : (f == 1) ? 2 * nc + nu : nu;
+            for (int e = (w / 3) * 64 + (t & 63); e < cnt; e += nwf * 64) {
+                int q, j;                                           // item and its slot
+                if (f == 0) {
+                    if (e < 3 * nc) { q = qa + e / 3; j = e - 3 * (e / 3); } else { q = qa + nc + (e - 3 * nc); j = 0; }
+                } else if (f == 1) {
+                    if (e < 2 * nc) { q = qa + (e >> 1); j = 3 + (e & 1); } else { q = qa + nc + (e - 2 * nc); j = 1; }
+                } else {
+                    q = qa + nc + e; j = 2;
+                }
+                double arg;
+                if (q < U * U) {
+                    int v;
+                    const int u = idiv_s(q, U, v);
+                    const double lq = -(L.su[u * U + u] + L.su[v * U + v]) / 2.0;
+                    const double suv = L.su[q];
+                    arg = (j == 0) ? lq : (j == 1) ? lq + suv : (j == 2) ? lq - suv : (j == 3) ? L.mu[u] - L.mu[v] : L.mu[u] + L.mu[v];
+                } else {
+                    const int u = q - U * U;
+                    arg = (j == 0) ? -L.su[u * U + u] / 2.0 : L.mu[u];
+                }
+                double val;
+                if (f == 0) val = exp(arg);                         // (wave-uniform: one body per wave)
+                else if (f == 1) val = cos(arg);
+                else val = sin(arg);
+                sc[5 * (q - qa) + j] = val;
             }
-            if (fn < 3) sc[k] = (fn == 0) ? exp(arg) : (fn == 1) ? cos(arg) : sin(arg);
         }
         __syncthreads();
         const int q0 = i0 / 5, q1 = (i0 + n) / 5;    // items [q0, q1) are complete in this round
