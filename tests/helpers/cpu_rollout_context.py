@@ -183,3 +183,18 @@ class CpuRolloutContext:
     def rollout_grad_rbf(self, policy, rewards, m0, S0, H, Xp, Yp, lsp, noisep, seed_fn=None):
         ps = [T(np.array(v, np.float64)).clone().requires_grad_(True) for v in (Xp, Yp, lsp)] + [T(np.ravel(noisep))]
         return self._grad(policy, rewards, m0, S0, H, ps, 3, seed_fn)
+
+    # the batched calls of the product's Context (restarts of optimize_policy as lanes): lane by lane on the stand-in -- what
+    # matters on the CPU is the HOST logic around them (training._optimize_policy_lanes)
+    nranks = 1
+    has_comm = False
+
+    def rollout_grad_batch(self, policies, rewards, m0, S0, H):
+        out = [self.rollout_grad(pol, rewards, np.asarray(m0)[i], np.asarray(S0)[i], H) for i, pol in enumerate(policies)]
+        U, E = np.shape(policies[0]["W"])
+        return (np.array([o[0] for o in out]), np.stack([np.reshape(o[1], (U, E)) for o in out]), np.stack([np.reshape(o[2], (U,)) for o in out]))
+
+    def rollout_grad_rbf_batch(self, policies, rewards, m0, S0, H, Xp, Yp, lsp, noisep):
+        out = [self.rollout_grad_rbf(pol, rewards, np.asarray(m0)[i], np.asarray(S0)[i], H, Xp[i], Yp[i], lsp[i], noisep[i])
+               for i, pol in enumerate(policies)]
+        return (np.array([o[0] for o in out]),) + tuple(np.stack([o[k] for o in out]) for k in (1, 2, 3))

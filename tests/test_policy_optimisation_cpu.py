@@ -6,6 +6,7 @@ the GPU with the native reverse sweep (tests/test_gpu_parity.py::test_optimize_p
 import os
 
 import numpy as np
+import pytest
 
 from helpers.cpu_rollout_context import CpuRolloutContext
 from pilco_amd.controllers import LinearController, RbfController
@@ -55,9 +56,13 @@ def test_rbf_policy_ends_where_the_executed_reference_ends():
     np.testing.assert_allclose(np.ravel(ctl.lengthscales), np.ravel(g["ls_end"]), rtol=1e-3)
 
 
-def test_random_restarts_keep_the_controller_the_executed_reference_keeps():
+@pytest.mark.parametrize("lanes", ["1", "0"])
+def test_random_restarts_keep_the_controller_the_executed_reference_keeps(lanes, monkeypatch):
     """optimize_policy(restarts=3) (pilco.py:93-110): two seeded controller.randomize() restarts after the first run, the
-    best controller by reward restored -- the first run's for the linear policy, a restart's for the RBF policy."""
+    best controller by reward restored -- the first run's for the linear policy, a restart's for the RBF policy.  Both ways
+    the product runs them: the three L-BFGS-B walks side by side, one batched value-and-gradient call per round
+    (training._optimize_policy_lanes, the default), and one after the other as the reference does (PILCO_RESTART_LANES=0)."""
+    monkeypatch.setenv("PILCO_RESTART_LANES", lanes)
     r_ = np.load(os.path.join(GOLDEN, "policy_optimisation_restarts.npz"))
     g = np.load(os.path.join(GOLDEN, "policy_optimisation.npz"))
     ctx = CpuRolloutContext()
