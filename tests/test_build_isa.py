@@ -18,15 +18,36 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+UNITS = ["pair", "bwd", "linalg", "persist", "prep_dt_a", "prep_dt_b"]   # prep_dt_a, _b: the heads for D <= 11 (both register builds), whose one-launch small step carries the pair and sweep arithmetic
+
+
+@pytest.fixture(scope="module")
+def assembly(tmp_path_factory):
+    """All units compiled to assembly ONCE, side by side (the scan of a unit takes seconds, its compilation a minute or two)."""
+    out = tmp_path_factory.mktemp("isa")
+    procs = {}
+    for unit in UNITS:
+        src = os.path.join(ROOT, "pilco_amd", "csrc", unit + ".hip")
+        asm = str(out / (unit + ".s"))
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+               "-mllvm", "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only", "-o", asm, src]
+        procs[unit] = (subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True), asm)
+    res = {}
+    for unit, (pr, asm) in procs.items():
+        try:
+            _, err = pr.communicate(timeout=1500)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            _, err = pr.communicate()
+        res[unit] = (pr.returncode, asm, err)
+    return res
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("unit", ["pair", "bwd", "linalg", "persist", "prep_dt_a", "prep_dt_b"])   # prep_dt_a, _b: the heads for D <= 11, whose one-launch small step carries the pair and sweep arithmetic
-def test_mfma_chains_have_no_register_overlap_and_no_early_result_reads(unit, tmp_path):
-    src = os.path.join(ROOT, "pilco_amd", "csrc", unit + ".hip")
-    asm = str(tmp_path / (unit + ".s"))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
-           "-mllvm", "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only", "-o", asm, src]
-    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    assert pr.returncode == 0 and os.path.exists(asm), pr.stderr[-2000:]
+@pytest.mark.parametrize("unit", UNITS)
+def test_mfma_chains_have_no_register_overlap_and_no_early_result_reads(unit, assembly):
+    rc, asm, err = assembly[unit]
+    assert rc == 0 and os.path.exists(asm), err[-2000:]
     assert "v_mfma_f64_16x16x4_f64" in open(asm).read()
     for tool in ("mfma_overlap_check.py", "mfma_hazard_check.py"):
         chk = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), asm], capture_output=True, text=True, timeout=300)
