@@ -247,6 +247,16 @@ int pilco_rollout_grad_batch(pilco_ctx* ctx, int B, const pilco_policy* policies
 int pilco_rollout_grad_rbf_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
                                  const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
                                  const double* noisep, int bf, double* reward, double* dX, double* dY, double* dls);
+/* ... with an objective beyond the additive reward (Safe-PILCO's risk term, host-evaluated reward terms), as
+ * pilco_rollout_grad_seeded: seed_fn is called once per lane, in lane order, with seed_users[i] (seed_users may be NULL), when
+ * lane i's trajectory has arrived and before its reverse sweep; reward[i] is lane i's additive reward alone. */
+int pilco_rollout_grad_batch_seeded(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
+                                    const double* m0, const double* S0, int H, pilco_seed_fn seed_fn, void* const* seed_users,
+                                    double* reward, double* dW, double* db);
+int pilco_rollout_grad_rbf_batch_seeded(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
+                                        const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
+                                        const double* noisep, int bf, pilco_seed_fn seed_fn, void* const* seed_users, double* reward,
+                                        double* dX, double* dY, double* dls);
 
 /* ------------------------------------------------------------------ timing / introspection */
 /* Time `reps` back-to-back rollouts with HIP events on the library's stream.

@@ -94,6 +94,10 @@ SIGNATURES = {
     "pilco_rollout_grad_batch": (C.c_int, [_vp, C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]),
     "pilco_rollout_grad_rbf_batch": (C.c_int, [_vp, C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
                                                _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]),
+    "pilco_rollout_grad_batch_seeded": (C.c_int, [_vp, C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
+                                                  SEED_FN, C.POINTER(C.c_void_p), _dp, _dp, _dp]),
+    "pilco_rollout_grad_rbf_batch_seeded": (C.c_int, [_vp, C.c_int, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp, C.c_int,
+                                                      _dp, _dp, _dp, _dp, C.c_int, SEED_FN, C.POINTER(C.c_void_p), _dp, _dp, _dp, _dp]),
     "pilco_policy_action": (C.c_int, [_vp, C.POINTER(PolicyStruct), _dp, _dp, _dp, _dp, _dp]),
     "pilco_reward_eval": (C.c_int, [_vp, C.POINTER(RewardTerm), C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
     "pilco_rollout_timed": (C.c_int, [_vp, C.POINTER(PolicyStruct), C.POINTER(RewardTerm), C.c_int, _dp, _dp,
@@ -409,7 +413,21 @@ class Context:
             arr[i] = p
         return arr, keep
 
-    def rollout_grad_batch(self, policies, rewards, m0, S0, H):
+    @staticmethod
+    def _lane_seed_callback(seed_fns, errors):
+        """One pilco_seed_fn for the B lanes of a batch: the library hands lane i's callback the user word i + 1."""
+        def cb(user, H, E, traj_p, seeds_p):
+            n = (H + 1) * (E + E * E)
+            out = np.ctypeslib.as_array(seeds_p, shape=(n,))
+            try:
+                traj = np.ctypeslib.as_array(traj_p, shape=(n,)).reshape(H + 1, E + E * E).copy()
+                out[:] = np.asarray(seed_fns[int(user) - 1](traj), dtype=np.float64).reshape(n)
+            except BaseException as exc:   # noqa: BLE001 -- re-raised by the caller
+                errors.append(exc)
+                out[:] = np.nan
+        return SEED_FN(cb)
+
+    def rollout_grad_batch(self, policies, rewards, m0, S0, H, seed_fns=None):
         """B value-and-gradient rollouts of the same model in flight together (pilco_rollout_grad_batch; the restarts of
         optimize_policy, pilco.py:94-107): policies: B LinearController specs; m0 (B, E), S0 (B, E, E) -> reward (B,),
         dW (B, U, E), db (B, U).  Each lane is bit-identical to its solo rollout_grad."""
@@ -419,10 +437,20 @@ class Context:
         r, k2 = self._rewards(rewards, E)
         m0 = _f64(m0, (B, E)); S0 = _f64(S0, (B, E, E))
         rew = np.zeros(B); dW = np.empty((B, U, E)); db = np.empty((B, U))
-        self._chk(self.lib.pilco_rollout_grad_batch(self.h, B, arr, r, len(rewards), _ptr(m0), _ptr(S0), int(H), _ptr(rew), _ptr(dW), _ptr(db)))
+        if seed_fns is None:
+            self._chk(self.lib.pilco_rollout_grad_batch(self.h, B, arr, r, len(rewards), _ptr(m0), _ptr(S0), int(H), _ptr(rew), _ptr(dW), _ptr(db)))
+            return rew, dW, db
+        errors = []
+        cb = self._lane_seed_callback(seed_fns, errors)    # (seed_fns[i](traj) -> seeds of lane i: pilco_rollout_grad_batch_seeded)
+        users = (C.c_void_p * B)(*[i + 1 for i in range(B)])
+        rc = self.lib.pilco_rollout_grad_batch_seeded(self.h, B, arr, r, len(rewards), _ptr(m0), _ptr(S0), int(H), cb, users,
+                                                      _ptr(rew), _ptr(dW), _ptr(db))
+        if errors:
+            raise errors[0]
+        self._chk(rc)
         return rew, dW, db
 
-    def rollout_grad_rbf_batch(self, policies, rewards, m0, S0, H, Xp, Yp, lsp, noisep):
+    def rollout_grad_rbf_batch(self, policies, rewards, m0, S0, H, Xp, Yp, lsp, noisep, seed_fns=None):
         """The same for B RbfControllers: Xp (B, bf, E), Yp (B, bf, U), lsp (B, U, E), noisep (B, U) -> reward (B,), dX, dY, dls.
         The call uploads lane i's policy GP into the policy slot of lane i's context -- this context's slot holds lane 0's
         controller afterwards (whoever believed to own the slot must push its parameters again)."""
@@ -435,8 +463,18 @@ class Context:
         Xp = _f64(Xp, (B, bf, E)); Yp = _f64(Yp, (B, bf, U)); lsp = _f64(lsp, (B, U, E)); noisep = _f64(noisep, (B, U))
         rew = np.zeros(B); dX = np.empty((B, bf, E)); dY = np.empty((B, bf, U)); dls = np.empty((B, U, E))
         self._slot_owner[SLOT_POLICY] = None   # (the call overwrites the slot)
-        self._chk(self.lib.pilco_rollout_grad_rbf_batch(self.h, B, arr, r, len(rewards), _ptr(m0), _ptr(S0), int(H), _ptr(Xp), _ptr(Yp),
-                                                        _ptr(lsp), _ptr(noisep), bf, _ptr(rew), _ptr(dX), _ptr(dY), _ptr(dls)))
+        if seed_fns is None:
+            self._chk(self.lib.pilco_rollout_grad_rbf_batch(self.h, B, arr, r, len(rewards), _ptr(m0), _ptr(S0), int(H), _ptr(Xp), _ptr(Yp),
+                                                            _ptr(lsp), _ptr(noisep), bf, _ptr(rew), _ptr(dX), _ptr(dY), _ptr(dls)))
+            return rew, dX, dY, dls
+        errors = []
+        cb = self._lane_seed_callback(seed_fns, errors)
+        users = (C.c_void_p * B)(*[i + 1 for i in range(B)])
+        rc = self.lib.pilco_rollout_grad_rbf_batch_seeded(self.h, B, arr, r, len(rewards), _ptr(m0), _ptr(S0), int(H), _ptr(Xp), _ptr(Yp),
+                                                          _ptr(lsp), _ptr(noisep), bf, cb, users, _ptr(rew), _ptr(dX), _ptr(dY), _ptr(dls))
+        if errors:
+            raise errors[0]
+        self._chk(rc)
         return rew, dX, dY, dls
 
     def gp_predict_vjp(self, slot, m, s, Mbar, Sbar, Vbar, D, E):

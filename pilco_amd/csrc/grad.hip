@@ -877,8 +877,11 @@ int pilco_rollout_grad_rbf(pilco_ctx* ctx, const pilco_policy* policy, const pil
 // lane by lane -- lane i's sweep while lanes i+1.. are still on the device.  Every lane runs exactly the launch sequence
 // and the host arithmetic of its solo call: results are bit-identical to pilco_rollout_grad / pilco_rollout_grad_rbf.
 // LinearController lanes: policies[i].W / .b; dW (B, U, E), db (B, U), reward (B); m0 (B, E), S0 (B, E, E).
-int pilco_rollout_grad_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
-                             const double* m0, const double* S0, int H, double* reward, double* dW, double* db) {
+// (seed_fn, seed_users [B]: an objective beyond the additive reward, as pilco_rollout_grad_seeded -- the callback runs once per lane,
+// in lane order, with seed_users[i], when lane i's trajectory has arrived and before its reverse sweep)
+int pilco_rollout_grad_batch_seeded(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
+                                    const double* m0, const double* S0, int H, pilco_seed_fn seed_fn, void* const* seed_users,
+                                    double* reward, double* dW, double* db) {
     if (!ctx) return PILCO_E_SHAPE;
     if (B <= 0 || B > 64 || !policies || !m0 || !S0 || !reward || !dW || !db || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout_grad_batch: bad arguments");
     if (ctx->nranks != 1 || ctx->comm) return fail(ctx, PILCO_E_STATE, "rollout_grad_batch: single rank only (shard OR batch)");
@@ -898,7 +901,8 @@ int pilco_rollout_grad_batch(pilco_ctx* ctx, int B, const pilco_policy* policies
     }
     for (int i = 0; i < begun; ++i) {
         LinearAdj pol(E, U, policies[i].W, policies[i].b);
-        const int r = rollout_grad_finish(lane[i], &policies[i], rewards, n_rewards, H, reward + i, pol, nullptr, nullptr, gc[i]);
+        const int r = rollout_grad_finish(lane[i], &policies[i], rewards, n_rewards, H, reward + i, pol, seed_fn,
+                                          (seed_fn && seed_users) ? seed_users[i] : nullptr, gc[i]);
         if (r && !err) {
             err = r;
             if (i > 0) ctx->err = "lane " + std::to_string(i) + ": " + lane[i]->err;
@@ -913,13 +917,19 @@ int pilco_rollout_grad_batch(pilco_ctx* ctx, int B, const pilco_policy* policies
     return err;
 }
 
+int pilco_rollout_grad_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
+                             const double* m0, const double* S0, int H, double* reward, double* dW, double* db) {
+    return pilco_rollout_grad_batch_seeded(ctx, B, policies, rewards, n_rewards, m0, S0, H, nullptr, nullptr, reward, dW, db);
+}
+
 // RbfController lanes: lane i's policy GP (centres Xp (B, bf, E), targets Yp (B, bf, U), lengthscales lsp (B, U, E), likelihood
 // variances noisep (B, U); unit signal variance, controllers.py:92-93) is uploaded to and factorised in PILCO_SLOT_POLICY of
 // lane i's context by this call -- INCLUDING lane 0, this context: whatever the caller had in its policy slot is replaced by
 // lane 0's controller.  dX (B, bf, E), dY (B, bf, U), dls (B, U, E).
-int pilco_rollout_grad_rbf_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
-                                 const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
-                                 const double* noisep, int bf, double* reward, double* dX, double* dY, double* dls) {
+int pilco_rollout_grad_rbf_batch_seeded(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
+                                        const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
+                                        const double* noisep, int bf, pilco_seed_fn seed_fn, void* const* seed_users, double* reward,
+                                        double* dX, double* dY, double* dls) {
     if (!ctx) return PILCO_E_SHAPE;
     if (B <= 0 || B > 64 || !policies || !m0 || !S0 || !reward || !Xp || !Yp || !lsp || !noisep || !dX || !dY || !dls || H < 0 || bf <= 0)
         return fail(ctx, PILCO_E_SHAPE, "rollout_grad_rbf_batch: bad arguments");
@@ -950,7 +960,8 @@ int pilco_rollout_grad_rbf_batch(pilco_ctx* ctx, int B, const pilco_policy* poli
         }
     }
     for (int i = 0; i < begun; ++i) {
-        const int r = rollout_grad_finish(lane[i], &policies[i], rewards, n_rewards, H, reward + i, pol[i], nullptr, nullptr, gc[i]);
+        const int r = rollout_grad_finish(lane[i], &policies[i], rewards, n_rewards, H, reward + i, pol[i], seed_fn,
+                                          (seed_fn && seed_users) ? seed_users[i] : nullptr, gc[i]);
         if (r && !err) {
             err = r;
             if (i > 0) ctx->err = "lane " + std::to_string(i) + ": " + lane[i]->err;
@@ -960,6 +971,12 @@ int pilco_rollout_grad_rbf_batch(pilco_ctx* ctx, int B, const pilco_policy* poli
     if (err)
         for (int i = 0; i < B; ++i) (void)hipStreamSynchronize(lane[i]->st);
     return err;
+}
+int pilco_rollout_grad_rbf_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, const pilco_reward_term* rewards, int n_rewards,
+                                 const double* m0, const double* S0, int H, const double* Xp, const double* Yp, const double* lsp,
+                                 const double* noisep, int bf, double* reward, double* dX, double* dY, double* dls) {
+    return pilco_rollout_grad_rbf_batch_seeded(ctx, B, policies, rewards, n_rewards, m0, S0, H, Xp, Yp, lsp, noisep, bf, nullptr, nullptr,
+                                               reward, dX, dY, dls);
 }
 
 }  // extern "C"

@@ -483,13 +483,27 @@ def _restart_lanes_apply(pilco):
         return False
     if not isinstance(pilco.controller, (LinearController, RbfController)):
         return False
-    if type(pilco).predict is not PILCO.predict or pilco._host_reward_terms():
+    if not (pilco.control_dim > 0 and pilco.state_dim + pilco.control_dim <= 32
+            and all(t["kind"] in (_lib.REWARD_EXPONENTIAL, _lib.REWARD_LINEAR) for t in pilco._reward_terms())):
         return False
-    return (pilco.control_dim > 0 and pilco.state_dim + pilco.control_dim <= 32
-            and all(t["kind"] in (_lib.REWARD_EXPONENTIAL, _lib.REWARD_LINEAR) for t in pilco._reward_terms()))
+    # the same decision policy_loss_and_grad makes per evaluation: the plain additive reward, or an objective that says what
+    # it adds as a function of the state trajectory (Safe-PILCO's risk term, host-evaluated reward terms: cotangent seeds)
+    plain = type(pilco).predict is PILCO.predict
+    own_objective = getattr(type(pilco), "trajectory_objective", None) is not PILCO.trajectory_objective
+    seeded = (plain and bool(pilco._host_reward_terms())) or ((not plain) and own_objective and hasattr(pilco, "trajectory_objective"))
+    if not plain and not seeded:
+        return False
+    if seeded:
+        if not hasattr(ctx, "rollout_grad_batch") or "seed_fns" not in ctx.rollout_grad_batch.__code__.co_varnames:
+            return False
+        traj = PILCO.predict_trajectory(pilco, pilco.m_init, pilco.S_init, pilco.horizon)[3]
+        if pilco.trajectory_objective(np.asarray(traj)) is None:   # (a term without compute_reward_grad: finite differences, one walk at a time)
+            return False
+        return "seeded"
+    return "plain"
 
 
-def _optimize_policy_lanes(pilco, maxiter, restarts, verbose):
+def _optimize_policy_lanes(pilco, maxiter, restarts, verbose, seeded=False):
     """pilco.py:75-113 with its restarts side by side: restart i's start is drawn exactly where the reference draws it (the
     L-BFGS-B walks draw nothing), every walk is the scipy run of the sequential loop (lockstep_minimize: one thread per walk,
     a round of evaluations = ONE pilco_rollout_grad[_rbf]_batch call whose lanes are bit-identical to the solo calls), and the
@@ -517,13 +531,25 @@ def _optimize_policy_lanes(pilco, maxiter, restarts, verbose):
             us = [np.array(u[parts[i]], dtype=np.float64) for i in todo]
             nb = len(todo)
             mm, SS = np.tile(m0, (nb, 1)), np.tile(S0, (nb, 1, 1))
+            extra = [0.0] * nb          # what the objective adds to lane k's additive reward (seeded objectives)
+            seed_kw = {}
+            if seeded:
+                def lane_seeds(k):
+                    def fn(traj):
+                        out = pilco.trajectory_objective(traj)
+                        if out is None:
+                            raise RuntimeError("optimize_policy: the trajectory objective stopped providing cotangent seeds")
+                        extra[k] = float(out[0])
+                        return out[1]
+                    return fn
+                seed_kw = dict(seed_fns=[lane_seeds(k) for k in range(nb)])
             if linear:
                 base = ctl.policy_spec(True)
                 nW = ctl.W.numpy().size
                 specs = [dict(base, W=ui[:nW].reshape(ctl.W.shape), b=ui[nW:].reshape(-1)) for ui in us]
-                r, dW, db = ctx.rollout_grad_batch(specs, rw, mm, SS, H)
+                r, dW, db = ctx.rollout_grad_batch(specs, rw, mm, SS, H, **seed_kw)
                 for k, i in enumerate(todo):
-                    cache[i] = (us[k], -float(r[k]), -np.concatenate([dW[k].ravel(), db[k].ravel()]))
+                    cache[i] = (us[k], -(float(r[k]) + extra[k]), -np.concatenate([dW[k].ravel(), db[k].ravel()]))
             else:
                 gp = ctl._gp
                 bf, d, U = gp.num_datapoints, gp.num_dims, gp.num_outputs
@@ -532,11 +558,11 @@ def _optimize_policy_lanes(pilco, maxiter, restarts, verbose):
                 ls = np.stack([1e-3 + _softplus(ui[bf * d + bf * U:]).reshape(U, d) for ui in us])   # positive(lower=1e-3), as _policy_params
                 nz = np.tile(np.asarray(ctl.noise, np.float64).reshape(-1), (nb, 1))
                 spec = dict(kind=base_kind, state_dim=ctl.state_dim, control_dim=ctl.control_dim, max_action=ctl.max_action, squash=True)
-                r, dX, dY, dl = ctx.rollout_grad_rbf_batch([spec] * nb, rw, mm, SS, H, X, Y, ls, nz)
+                r, dX, dY, dl = ctx.rollout_grad_rbf_batch([spec] * nb, rw, mm, SS, H, X, Y, ls, nz, **seed_kw)
                 for k, i in enumerate(todo):
                     ui = us[k]
                     g = np.concatenate([dX[k].ravel(), dY[k].ravel(), (dl[k] * _dsoftplus(ui[-dl[k].size:]).reshape(dl[k].shape)).ravel()])
-                    cache[i] = (ui, -float(r[k]), -g)
+                    cache[i] = (ui, -(float(r[k]) + extra[k]), -g)
         vals = np.array([cache[i][1] for i in range(B)])
         grad = np.concatenate([cache[i][2] for i in range(B)])
         return vals, grad
@@ -559,8 +585,9 @@ def _optimize_policy_lanes(pilco, maxiter, restarts, verbose):
 def optimize_policy(pilco, maxiter=50, restarts=1, verbose=True):
     if pilco.controller is None:
         raise ValueError("optimize_policy: the model has no controller (control_dim == 0)")
-    if restarts >= 2 and _restart_lanes_apply(pilco):
-        return _optimize_policy_lanes(pilco, maxiter, restarts, verbose)
+    lanes = _restart_lanes_apply(pilco) if restarts >= 2 else False
+    if lanes:
+        return _optimize_policy_lanes(pilco, maxiter, restarts, verbose, seeded=(lanes == "seeded"))
     get, put = _policy_params(pilco.controller)
 
     def run():

@@ -189,12 +189,14 @@ class CpuRolloutContext:
     nranks = 1
     has_comm = False
 
-    def rollout_grad_batch(self, policies, rewards, m0, S0, H):
-        out = [self.rollout_grad(pol, rewards, np.asarray(m0)[i], np.asarray(S0)[i], H) for i, pol in enumerate(policies)]
+    def rollout_grad_batch(self, policies, rewards, m0, S0, H, seed_fns=None):
+        out = [self.rollout_grad(pol, rewards, np.asarray(m0)[i], np.asarray(S0)[i], H, seed_fn=seed_fns[i] if seed_fns else None)
+               for i, pol in enumerate(policies)]
         U, E = np.shape(policies[0]["W"])
         return (np.array([o[0] for o in out]), np.stack([np.reshape(o[1], (U, E)) for o in out]), np.stack([np.reshape(o[2], (U,)) for o in out]))
 
-    def rollout_grad_rbf_batch(self, policies, rewards, m0, S0, H, Xp, Yp, lsp, noisep):
-        out = [self.rollout_grad_rbf(pol, rewards, np.asarray(m0)[i], np.asarray(S0)[i], H, Xp[i], Yp[i], lsp[i], noisep[i])
+    def rollout_grad_rbf_batch(self, policies, rewards, m0, S0, H, Xp, Yp, lsp, noisep, seed_fns=None):
+        out = [self.rollout_grad_rbf(pol, rewards, np.asarray(m0)[i], np.asarray(S0)[i], H, Xp[i], Yp[i], lsp[i], noisep[i],
+                                     seed_fn=seed_fns[i] if seed_fns else None)
                for i, pol in enumerate(policies)]
         return (np.array([o[0] for o in out]),) + tuple(np.stack([o[k] for o in out]) for k in (1, 2, 3))

@@ -2324,3 +2324,29 @@ def test_optimize_policy_runs_its_restarts_as_lanes_and_ends_where_the_sequentia
         ends[lanes] = (r, _policy_params(p.controller)[0]())
     assert ends["0"][0] == ends["1"][0]
     assert np.array_equal(ends["0"][1], ends["1"][1])
+
+
+def test_safe_pilco_restarts_run_as_lanes_and_end_where_the_sequential_loop_ends(golden_dir, monkeypatch):
+    """SafePILCO.optimize_policy(restarts=2) (examples/safe_cars_run.py:102, safe_swimmer_run.py:91): the objective is the TOTAL
+    reward, mu (1 - prod (1 - risk_t)) included, which enters the reverse sweep as cotangent seeds of the trajectory.  As lanes
+    (pilco_rollout_grad_batch_seeded: every lane's seeds from ITS trajectory) the two walks end where the sequential loop
+    (PILCO_RESTART_LANES=0) ends, to the bit."""
+    from pilco_amd.rewards import ExponentialReward
+    from pilco_amd.safe import SafePILCO, SingleConstraint
+    from pilco_amd.training import _policy_params, _restart_lanes_apply
+    g = np.load(os.path.join(golden_dir, "safe_pilco.npz"))
+    H = int(g["H"])
+    ends = {}
+    for lanes in ("0", "1"):
+        monkeypatch.setenv("PILCO_RESTART_LANES", lanes)
+        p = SafePILCO((g["X"], g["Y"]), horizon=H, reward_add=ExponentialReward(2),
+                      reward_mult=SingleConstraint(0, high=float(g["high"]), inside=False), mu=float(g["mu"]), m_init=g["m"], S_init=g["s"])
+        for i, mdl in enumerate(p.mgpr.models):
+            mdl.kernel.lengthscales.assign(g["lengthscales"][i]); mdl.kernel.variance.assign(g["variance"][i]); mdl.likelihood.variance.assign(g["noise"][i])
+        p.controller.W.assign(g["W"]); p.controller.b.assign(g["b"]); p.controller.max_action = g["max_action"]
+        assert _restart_lanes_apply(p) == ("seeded" if lanes == "1" else False)
+        np.random.seed(3)
+        r = p.optimize_policy(maxiter=10, restarts=2, verbose=False)
+        ends[lanes] = (r, _policy_params(p.controller)[0]())
+    assert ends["0"][0] == ends["1"][0]
+    assert np.array_equal(ends["0"][1], ends["1"][1])
