@@ -222,3 +222,28 @@ def test_objective_function_reward_takes_the_analytic_path():
         np.testing.assert_allclose(grad[i], (fp - fm) / (2 * h), rtol=3e-6, atol=1e-9)
     put(u)
     np.testing.assert_allclose(f, float(p.training_loss()[0, 0]), rtol=1e-12)
+
+
+def test_safe_pilco_restarts_as_lanes_walk_the_walks_of_the_sequential_loop(monkeypatch):
+    """SafePILCO.optimize_policy(restarts=2) (examples/safe_cars_run.py:102): with the restarts as lanes every lane's objective
+    is the TOTAL reward of ITS trajectory (per-lane cotangent seeds into the batched reverse sweep, training._optimize_policy_lanes)
+    -- the two L-BFGS-B walks, the kept controller and its reward are those of the sequential loop (PILCO_RESTART_LANES=0).
+    Host logic only: the stand-in answers the batched call lane by lane."""
+    from pilco_amd.safe import SafePILCO, SingleConstraint
+    from pilco_amd.training import _policy_params, _restart_lanes_apply
+    g = np.load(os.path.join(GOLDEN, "safe_pilco.npz"))
+    H, ends = int(g["H"]), {}
+    for lanes in ("0", "1"):
+        monkeypatch.setenv("PILCO_RESTART_LANES", lanes)
+        ctx = CpuRolloutContext()
+        ctl = LinearController(2, 1, max_action=g["max_action"], ctx=ctx)
+        p = SafePILCO((g["X"], g["Y"]), horizon=H, controller=ctl, reward_add=ExponentialReward(2),
+                      reward_mult=SingleConstraint(0, high=float(g["high"]), inside=False), mu=float(g["mu"]), m_init=g["m"], S_init=g["s"], ctx=ctx)
+        _hyp(p, g)
+        ctl.W.assign(g["W"]); ctl.b.assign(g["b"])
+        assert _restart_lanes_apply(p) == ("seeded" if lanes == "1" else False)
+        np.random.seed(4)
+        r = p.optimize_policy(maxiter=6, restarts=2, verbose=False)
+        ends[lanes] = (r, _policy_params(ctl)[0]())
+    np.testing.assert_allclose(ends["1"][0], ends["0"][0], rtol=1e-12)
+    np.testing.assert_allclose(ends["1"][1], ends["0"][1], rtol=1e-10, atol=1e-12)
