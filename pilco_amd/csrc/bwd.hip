@@ -179,11 +179,9 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
     constexpr int KPc = 4 * KC, NR = KPc + (VSEP ? 2 : 1), NST = (NR + 3) / 4, BWD_TP = bwd_tp(KPc), SB = BWD_CH * BWD_TP + 2 * BWD_CH;
     const __amdgpu_buffer_rsrc_t rIK = buf_rsrc_uniform(iKa ? iKa + (long)jbeg * npad : Bt);
     const double* vsrc = VSEP ? wk.vcol + (long)pl * npad : Bt;
-    unsigned ik_off[BWD_RT][4];
+    unsigned ik_voff[BWD_RT];   // (the 4 r part of the row index rides in the scalar offset: 2 registers instead of 8)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int rt = 0; rt < BWD_RT; ++rt) ik_off[rt][r] = ((unsigned)(lr + 4 * r) * (unsigned)npad + (unsigned)irow[rt]) * 8u;
+    for (int rt = 0; rt < BWD_RT; ++rt) ik_voff[rt] = ((unsigned)lr * (unsigned)npad + (unsigned)irow[rt]) * 8u;
     int dsel[NMT];                       // operand rows contracted by the second product: w_j (d < D), the ones (d = D);
 #pragma unroll                           // lanes past that repeat row D: their result columns (d > D) are never read
     for (int m = 0; m < NMT; ++m) dsel[m] = 16 * m + lc <= D ? 16 * m + lc : D;
@@ -229,6 +227,17 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
     auto sweep = [&](auto mode_c) {
         constexpr int MODE = decltype(mode_c)::value;
         if (jstart >= jend) return;   // (workgroup-uniform) a diagonal pair's workgroup entirely left of the diagonal
+        // the iK tiles of a diagonal pair are requested ONE column step ahead, into registers of their own (a load consumed in the
+        // step that issues it lands in registers the next MFMA chain wants: the wave then waits for the L2 round trip first)
+        double ikn[BWD_RT][4];
+        auto ik_request = [&](int j0n) {
+#pragma unroll
+            for (int rt = 0; rt < BWD_RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ikn[rt][r] = buf_ld(rIK, ik_voff[rt], ((unsigned)(j0n - jbeg) + 4u * (unsigned)r) * (unsigned)npad * 8u);
+        };
+        if (MODE == 1) ik_request(jstart < ibase ? jstart + 16 * ((ibase - jstart) / 16) : jstart);   // the wave's first swept tile
         double sg[NST];
         stage_load(jstart, sg);
         stage_store(stg, sg);
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
                             csum[r] = fma(brow[rt], l, csum[r]);
                         } else {
                             double wgt = brow[rt] * bcol[r];
-                            if (MODE == 1) wgt -= buf_ld(rIK, ik_off[rt][r], (unsigned)(j0 - jbeg) * (unsigned)npad * 8u);   // iK symmetric: coalesced along the rows
+                            if (MODE == 1) wgt -= ikn[rt][r];   // iK symmetric: coalesced along the rows (requested a step ago)
                             wl[r] = (wgt * om) * fexp(VSEP ? e[r] + vj[r] : e[r], tab);
                             csum[r] += wl[r];
                         }
@@ -292,6 +301,7 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
     #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[rt][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[r], a2[m][r], acc[rt][m], 0, 0, 0);
                 }
+                if (MODE == 1 && j0 + 16 < jend) ik_request(j0 + 16);   // (every use of this step's tile is behind us)
                 // column sums over the wave's 16 lanes of a DPP row, through a per-wave LDS scratch instead of four
                 // DPP row shifts per register (12 VALU ops each on the pipe this kernel is bound by): the partial sums
                 // of the PREVIOUS column step are read back four at a time, added and finished with two quad
