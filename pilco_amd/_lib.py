@@ -427,6 +427,8 @@ class Context:
                 out[:] = np.nan
         return SEED_FN(cb)
 
+    lane_seeds = True   # rollout_grad_batch / rollout_grad_rbf_batch take per-lane seed callbacks (pilco_rollout_grad*_batch_seeded)
+
     def rollout_grad_batch(self, policies, rewards, m0, S0, H, seed_fns=None):
         """B value-and-gradient rollouts of the same model in flight together (pilco_rollout_grad_batch; the restarts of
         optimize_policy, pilco.py:94-107): policies: B LinearController specs; m0 (B, E), S0 (B, E, E) -> reward (B,),

@@ -494,7 +494,7 @@ def _restart_lanes_apply(pilco):
     if not plain and not seeded:
         return False
     if seeded:
-        if not hasattr(ctx, "rollout_grad_batch") or "seed_fns" not in ctx.rollout_grad_batch.__code__.co_varnames:
+        if not getattr(ctx, "lane_seeds", False):   # (a context whose batched calls take per-lane seed callbacks)
             return False
         traj = PILCO.predict_trajectory(pilco, pilco.m_init, pilco.S_init, pilco.horizon)[3]
         if pilco.trajectory_objective(np.asarray(traj)) is None:   # (a term without compute_reward_grad: finite differences, one walk at a time)

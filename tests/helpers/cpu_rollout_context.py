@@ -188,6 +188,7 @@ class CpuRolloutContext:
     # matters on the CPU is the HOST logic around them (training._optimize_policy_lanes)
     nranks = 1
     has_comm = False
+    lane_seeds = True
 
     def rollout_grad_batch(self, policies, rewards, m0, S0, H, seed_fns=None):
         out = [self.rollout_grad(pol, rewards, np.asarray(m0)[i], np.asarray(S0)[i], H, seed_fn=seed_fns[i] if seed_fns else None)
