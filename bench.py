@@ -42,50 +42,76 @@ def algorithmic_work(n, d, e):
     return exps, flop, byts
 
 
-def cpu_baseline(cfg, budget_s=150.0):
+def cpu_baseline(cfg, budget_s=120.0):
     """Time the NumPy restatement of the GPflow CPU path (oracle/tf_path.py) on the SAME workload: one factorisation,
     then the benchmarked H = 40 rollout executed for real (reward, propagate, state carried over) with the
     factorisation cached -- the whole rollout unless `budget_s` runs out first (then: the steps done, extrapolated, and
-    said so).  Beside it ONE step exactly as the reference evaluates it (mgpr.py:77-79,120-147: re-factorise, all E^2
+    said so).  The host's best configuration is FOUND, not assumed: one step is timed under every thread setting of the
+    sweep below (BLAS threads for the sequential pair loop; a pool of pair workers with one BLAS thread each, which is
+    how a multi-threaded CPU runtime runs the element-wise work too) and the rollout runs at the fastest.
+    Beside it ONE step exactly as the reference evaluates it (mgpr.py:77-79,120-147: re-factorise, all E^2
     output pairs, the (E,E,N,N) tensors materialised), timed, as the reference-faithful variant."""
     from oracle import tf_path as tp
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:   # (no control over the BLAS pool: the sweep degenerates to the pair workers)
+        import contextlib
+        threadpool_limits = lambda limits=None: contextlib.nullcontext()
+    ncpu = os.cpu_count() or 1
     model = tp.Model(cfg["X"], cfg["Y"], cfg["lengthscales"], cfg["variance"], cfg["noise"], pairs=True)
     t0 = time.perf_counter()
     model._cache = model.factorize()
     t_fact = time.perf_counter() - t0
+
+    def one_step(m, s):
+        tp.exponential_reward(m, s)
+        return tp.propagate(model, tp.no_controller, m, s, cache=True)
+
+    counts = [c for c in (8, 16, 32, 64, 128) if c <= ncpu] or [ncpu]
+    settings = [("blas", c, 0) for c in counts] + [("pair_workers", 1, c) for c in counts]
+    sweep = []
+    for kind, blas, workers in settings:
+        model.workers = workers
+        with threadpool_limits(limits=blas):
+            t0 = time.perf_counter()
+            one_step(cfg["m0"], cfg["S0"])
+            sweep.append({"kind": kind, "blas_threads": blas, "pair_workers": workers, "step_s": time.perf_counter() - t0})
+    best = min(sweep, key=lambda r: r["step_s"])
+    model.workers = best["pair_workers"]
     m, s = cfg["m0"], cfg["S0"]
     ts = []
-    t_begin = time.perf_counter()
-    for _ in range(H):
-        t0 = time.perf_counter()
-        tp.exponential_reward(m, s)
-        m, s = tp.propagate(model, tp.no_controller, m, s, cache=True)
-        ts.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_begin > budget_s:
-            break
+    with threadpool_limits(limits=best["blas_threads"]):
+        t_begin = time.perf_counter()
+        for _ in range(H):
+            t0 = time.perf_counter()
+            m, s = one_step(m, s)
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_begin > budget_s:
+                break
     done = len(ts)
     t_rollout = float(np.sum(ts)) if done == H else float(np.median(ts)) * H
     faithful = None
     try:   # the reference's own evaluation order for one step: factorisation + E^2 pairs (several GB of temporaries)
         ref_model = tp.Model(cfg["X"], cfg["Y"], cfg["lengthscales"], cfg["variance"], cfg["noise"], pairs=False)
-        t0 = time.perf_counter()
-        tp.exponential_reward(cfg["m0"], cfg["S0"])
-        tp.propagate(ref_model, tp.no_controller, cfg["m0"], cfg["S0"], cache=False)
-        faithful = time.perf_counter() - t0
+        with threadpool_limits(limits=max(r["blas_threads"] for r in sweep if r["kind"] == "blas" and
+                                          r["step_s"] == min(q["step_s"] for q in sweep if q["kind"] == "blas"))):
+            t0 = time.perf_counter()
+            tp.exponential_reward(cfg["m0"], cfg["S0"])
+            tp.propagate(ref_model, tp.no_controller, cfg["m0"], cfg["S0"], cache=False)
+            faithful = time.perf_counter() - t0
     except Exception as exc:   # (memory): the symmetric-pair number stands on its own
         faithful = repr(exc)
-    threads = None
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max((p.get("num_threads", 0) for p in threadpool_info()), default=None)
-    except Exception:
-        pass
-    out = dict(value=1.0 / t_rollout, unit="rollouts/s", cores=threads or os.cpu_count(), kind="port",
-               host_cpu_count=os.cpu_count(), rollout_s=t_rollout, steps_executed=done, factorisation_s=t_fact,
-               sample=("NumPy+OpenBLAS restatement of the GPflow path (oracle/tf_path.py, 55 symmetric pairs), fp64: 1 factorisation "
-                       "(%.2f s, cached) + %s" % (t_fact, ("the full H = 40 benchmarked rollout executed for real: %.1f s" % t_rollout) if done == H else
-                                                  ("%d of 40 steps executed for real within the %.0f s budget (median %.3f s per step), "
-                                                   "extrapolated to 40" % (done, budget_s, float(np.median(ts)))))))
+    cores = best["pair_workers"] if best["pair_workers"] > 1 else best["blas_threads"]
+    how = ("%d pair workers x 1 BLAS thread" % best["pair_workers"]) if best["pair_workers"] > 1 else ("sequential pair loop, %d BLAS threads" % best["blas_threads"])
+    out = dict(value=1.0 / t_rollout, unit="rollouts/s", cores=cores, kind="port",
+               host_cpu_count=ncpu, rollout_s=t_rollout, steps_executed=done, factorisation_s=t_fact,
+               best_setting=best, thread_sweep_one_step=sweep,
+               sample=("NumPy+OpenBLAS restatement of the GPflow path (oracle/tf_path.py, 55 symmetric pairs), fp64, at the fastest of %d "
+                       "thread settings swept on one step (%s: %.3f s per step): 1 factorisation (%.2f s, cached) + %s"
+                       % (len(sweep), how, best["step_s"], t_fact,
+                          ("the full H = 40 benchmarked rollout executed for real: %.1f s" % t_rollout) if done == H else
+                          ("%d of 40 steps executed for real within the %.0f s budget (median %.3f s per step), "
+                           "extrapolated to 40" % (done, budget_s, float(np.median(ts)))))))
     if isinstance(faithful, float):
         out["reference_faithful_step_s"] = faithful
         out["reference_faithful_rollouts_per_s"] = 1.0 / (H * faithful)
@@ -187,27 +213,6 @@ def secondary_metrics(ctx, cfg, policy, rewards, ms_rollout, steps):
         ctxb.close()
     except Exception as exc:
         out["two_concurrent_rollouts_per_s"] = repr(exc)
-    # the whole rollout as ONE persistent launch (pilco_set_rollout_mode(ctx, 1), csrc/persist.hip): same bits, timed beside
-    # the graph replay that `value` reports.  Opt-in because it measures slower (docs/dead_ends.md).
-    try:
-        if not ctx.has_persistent_kernel():
-            raise RuntimeError("not in this build (csrc/Makefile: PERSIST=1; round 3 measured it 3.5-18 % slower than the graph replay, docs/dead_ends.md)")
-        ref = ctx.rollout(policy, rewards, cfg["m0"], cfg["S0"], H)
-        ctx.set_rollout_mode(1)
-        got = ctx.rollout(policy, rewards, cfg["m0"], cfg["S0"], H)
-        used = ctx.last_rollout_mode()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            ctx.rollout(policy, rewards, cfg["m0"], cfg["S0"], H)
-        p_ms = (time.perf_counter() - t0) * 1e3 / steps
-        out["persistent_launch"] = {"rollouts_per_s": 1e3 / p_ms, "ms_per_rollout": p_ms, "ran_as_persistent_launch": bool(used),
-                                    "bitwise_equal_to_launch_sequence": bool(all(np.array_equal(a, b) for a, b in zip(ref, got))),
-                                    "note": "one resident launch for all 40 steps, phases ordered by flags in device memory (no cache maintenance), "
-                                            "host-synchronised with the result downloaded like `value`; graph replay: %.3f ms" % ms_rollout}
-    except Exception as exc:
-        out["persistent_launch"] = {"error": repr(exc)}
-    finally:
-        ctx.set_rollout_mode(0)
     # pilco_rollout_batch: B independent rollouts of this model in flight together (lanes borrow the model; the serial head of
     # one lane runs under the pair kernels of the others).  Throughput mode for multi-start policy search / several initial
     # states; NEVER the headline (`value` is one rollout at a time, as PILCO.predict is called).
@@ -774,6 +779,33 @@ def main():
                 out["secondary"]["safe_cars_linear_loop"] = {"error": repr(exc)}
             ctx.gp_set_data(0, cfg["X"], cfg["Y"])
             ctx.gp_set_hyp(0, cfg["lengthscales"], cfg["variance"], cfg["noise"])
+        if world == 1 and "secondary" in out:
+            # Every BASELINE config's number as a flat dict of scalars under a key the driver's record keeps (its parser drops
+            # `secondary` and `verified`): configs 2 (R-fwd+fact), 4, 5 and R-grad on the driver's own box.
+            sec = out["secondary"]
+            c5 = sec.get("config5_inverted_pendulum") or {}
+            its = c5.get("hip_iterations") or []
+            lanes3 = ((sec.get("R_grad_C2u_lanes") or {}).get("B=3") or {})
+            rgr = sec.get("R_grad_roofline") or {}
+            num = lambda v: float(v) if isinstance(v, (int, float)) and np.isfinite(v) else None
+            out["roofline"]["other"] = {
+                "step_us": num(ms_per_rollout * 1e3 / H), "pair_us": num(pair_ms * 1e3), "non_pair_us_per_step": num(ms_per_rollout * 1e3 / H - pair_ms * 1e3),
+                "rollout_level_frac": num(H * flop / (ms_per_rollout * 1e-3) / 1e12 / FP64_PEAK_TFLOPS),
+                "back_to_back_per_s": num(sec.get("back_to_back_rollouts_per_s")),
+                "R_grad_C2u_ms": num(sec.get("R_grad_C2u_ms")), "R_fwd_C2u_ms": num(sec.get("R_fwd_C2u_ms")),
+                "R_grad_over_R_fwd": num(sec.get("R_grad_over_R_fwd_C2u")),
+                "sweep_us": num(rgr.get("avg_launch_us")), "sweep_frac": num(rgr.get("frac")),
+                "lanes_B3_ms_per_lane": num(lanes3.get("ms_per_lane")),
+                "factorisation_ms": num(sec.get("factorisation_ms")), "nlml_eval_ms": num(sec.get("nlml_eval_ms")),
+                "R_fwd_fact_per_s": num(sec.get("R_fwd_fact_rollouts_per_s")),
+                "config4_per_s": num(sec.get("config4_rollouts_per_s")), "config4_fitc_ms": num(sec.get("config4_fitc_factorisation_ms")),
+                "config4_fitc_objective_ms": num(sec.get("config4_fitc_objective_eval_ms")),
+                "config5_loop_s": num(c5.get("hip_total_s")),
+                "config5_optimize_policy_s": num(np.median([i["optimize_policy_s"] for i in its])) if its else None,
+                "config5_optimize_models_s": num(np.median([i["optimize_models_s"] for i in its])) if its else None,
+                "config5_speedup_first_iteration_vs_cpu_stand_in": num(c5.get("speedup_first_iteration")),
+                "verified_max_rel_err": num(max(verified["max_rel_err"].values())) if verified else None,
+            }
         if replicas is not None:
             out["secondary"] = replicas
             out["secondary"]["other_exchange"] = other_exchange
@@ -781,6 +813,18 @@ def main():
             out["secondary"]["amdahl_model"] = amdahl
             out["secondary"]["rccl_comm_count"] = rccl_ranks
             out["secondary"]["ranks_on_distinct_gpus"] = not share_gpu
+            num = lambda v: float(v) if isinstance(v, (int, float)) and np.isfinite(v) else None
+            out["roofline"]["other"] = {   # the multi-rank run's scalars under a key the driver's record keeps
+                "replica_rollouts_per_s": num(replicas.get("replica_rollouts_per_s")),
+                "other_exchange_rollouts_per_s": num((other_exchange or {}).get("rollouts_per_s")),
+                "one_gpu_ms_per_rollout": num((amdahl or {}).get("one_gpu_ms_per_rollout")),
+                "one_gpu_head_us_per_step": num((amdahl or {}).get("one_gpu_head_us_per_step")),
+                "slowest_rank_pair_us_per_launch": num((amdahl or {}).get("slowest_rank_pair_us_per_launch")),
+                "predicted_rollouts_per_s_with_a_free_exchange": num((amdahl or {}).get("predicted_rollouts_per_s_with_a_free_exchange")),
+                "exchange_and_skew_us_per_step": num((amdahl or {}).get("exchange_and_skew_us_per_step")),
+                "rccl_comm_count": num(rccl_ranks), "peer_exchange": 1.0 if exchange.startswith("peer") else 0.0,
+                "verified_max_rel_err": num(max(verified["max_rel_err"].values())) if verified else None,
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))

@@ -73,20 +73,6 @@ int pilco_set_use_graph(pilco_ctx* ctx, int on);
  * step), which is also what larger policies always get.  Same formulas (controllers.py:108-121 -> mgpr.py:99-149 with
  * iK = 0); the summation order differs, results agree to rounding (~1e-13), each mode is bitwise repeatable. */
 int pilco_set_inline_policy(pilco_ctx* ctx, int on);
-/* How a plain rollout (pilco_rollout / pilco_propagate / pilco_rollout_timed: one rank, no policy or a LinearController,
- * stream-K pair kernel, D <= 12) is run.  0 (default): the launch sequence (two launches per step, replayed as a hipGraph).
- * 1 (PILCO_PERSIST=1 in the environment starts with it): ONE persistent launch for all H steps -- the reference's
- * tf.while_loop (pilco.py:126-135) as a single kernel: every workgroup stays resident, the phases of a step are ordered by
- * flags in device memory instead of kernel boundaries, the state lives in LDS.  Both run the same device code on the same
- * work decomposition: results are BITWISE identical.  Measured on MI355X the persistent launch is 6-20 % SLOWER than the
- * graph replay (docs/dead_ends.md), which is why it is not the default.  A persistent launch that cannot make progress
- * (its workgroups are not all resident because the GPU is shared with other work) gives up after a bounded wait
- * (PILCO_PERSIST_TIMEOUT_MS, default 200); the rollout is then repeated on the launch sequence and the context stays on
- * it until this is called again.  pilco_last_rollout_mode: which of the two the last rollout actually used. */
-int pilco_set_rollout_mode(pilco_ctx* ctx, int mode);
-int pilco_last_rollout_mode(const pilco_ctx* ctx);
-/* 1 if this build of the library contains the persistent rollout kernel (csrc/Makefile: PERSIST=1; the product build: 0). */
-int pilco_has_persistent_kernel(void);
 /* checks the f64 MFMA fragment layout assumptions on the device; 0 = OK */
 int pilco_selftest(pilco_ctx* ctx);
 

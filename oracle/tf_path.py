@@ -118,7 +118,7 @@ def _batched_diag(v):
 
 
 def predict_given_factorizations_pairs(Xc, lengthscales, variance, m, s, iK, beta,
-                                       symmetric=True):
+                                       symmetric=True, workers=0):
     """Same arithmetic as ``predict_given_factorizations`` (mgpr.py:91-149) but
     looping over output pairs so that only one (N,N) tile is alive at a time.
 
@@ -147,23 +147,34 @@ def predict_given_factorizations_pairs(Xc, lengthscales, variance, m, s, iK, bet
         V[a] = (t @ iL).T @ lb * c
         k[a] = np.log(var[a]) - 0.5 * np.sum(iN * iN, 1)
     S = np.zeros((E, E))
-    for a in range(E):
+
+    def pair_value(a, b):
         za = zeta / np.square(ls[a])
-        for b in range(a + 1 if symmetric else E):
-            wb = -zeta / np.square(ls[b])
-            R = s @ np.diag(1.0 / np.square(ls[a]) + 1.0 / np.square(ls[b])) + np.eye(D)
-            Q = np.linalg.solve(R, s) / 2.0
-            zQ = za @ Q
-            maha = (-2.0 * zQ @ wb.T + np.sum(zQ * za, 1)[:, None]
-                    + np.sum(wb @ Q * wb, 1)[None, :])
-            L = np.exp(k[a][:, None] + k[b][None, :] + maha)
-            val = beta[a] @ L @ beta[b]
-            if a == b:
-                val -= np.sum(iK[a] * L)
-            val /= np.sqrt(np.linalg.det(R))
-            S[a, b] = val
-            if symmetric:
-                S[b, a] = val
+        wb = -zeta / np.square(ls[b])
+        R = s @ np.diag(1.0 / np.square(ls[a]) + 1.0 / np.square(ls[b])) + np.eye(D)
+        Q = np.linalg.solve(R, s) / 2.0
+        zQ = za @ Q
+        maha = (-2.0 * zQ @ wb.T + np.sum(zQ * za, 1)[:, None]
+                + np.sum(wb @ Q * wb, 1)[None, :])
+        L = np.exp(k[a][:, None] + k[b][None, :] + maha)
+        val = beta[a] @ L @ beta[b]
+        if a == b:
+            val -= np.sum(iK[a] * L)
+        return val / np.sqrt(np.linalg.det(R))
+
+    todo = [(a, b) for a in range(E) for b in range(a + 1 if symmetric else E)]
+    if workers and workers > 1:
+        # the pairs are independent: a thread pool over them (NumPy releases the GIL inside its ufuncs and BLAS calls) is
+        # what a multi-threaded CPU runtime does with this graph; every pair's arithmetic -- and so every bit -- is unchanged
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            vals = list(ex.map(lambda ab: pair_value(*ab), todo))
+    else:
+        vals = [pair_value(a, b) for a, b in todo]
+    for (a, b), val in zip(todo, vals):
+        S[a, b] = val
+        if symmetric:
+            S[b, a] = val
     S = S + np.diag(var) - np.outer(M, M)
     return M[None, :].copy(), S, V.T.copy()
 
@@ -297,6 +308,7 @@ class Model:
         self.noise = np.asarray(noise, np.float64)
         self.Z = None if Z is None else np.asarray(Z, np.float64)
         self.pairs = pairs
+        self.workers = 0      # > 1: the pair loop of the `pairs` form runs on that many threads (bench.py's CPU baseline)
         self._cache = None
 
     def factorize(self):
@@ -313,8 +325,9 @@ class Model:
         else:
             iK, beta = self.factorize()
         pts = self.X if self.Z is None else self.Z
-        fn = predict_given_factorizations_pairs if self.pairs else predict_given_factorizations
-        return fn(pts, self.ls, self.var, m, s, iK, beta)
+        if self.pairs:
+            return predict_given_factorizations_pairs(pts, self.ls, self.var, m, s, iK, beta, workers=self.workers)
+        return predict_given_factorizations(pts, self.ls, self.var, m, s, iK, beta)
 
 
 def propagate(model, controller, m_x, s_x, cache=False):

@@ -60,11 +60,8 @@ SIGNATURES = {
     "pilco_set_fused_step": (C.c_int, [_vp, C.c_int]),
     "pilco_set_grad_mode": (C.c_int, [_vp, C.c_int]),
     "pilco_set_small_step": (C.c_int, [_vp, C.c_int]),
-    "pilco_has_persistent_kernel": (C.c_int, []),
     "pilco_set_use_graph": (C.c_int, [_vp, C.c_int]),
-    "pilco_set_rollout_mode": (C.c_int, [_vp, C.c_int]),
     "pilco_set_inline_policy": (C.c_int, [_vp, C.c_int]),
-    "pilco_last_rollout_mode": (C.c_int, [_vp]),
     "pilco_gp_set_data": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int]),
     "pilco_gp_set_hyp": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "pilco_gp_set_inducing": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
@@ -242,17 +239,6 @@ class Context:
         """1 (default): small RbfControllers are evaluated inside the step's serial link; 0: own launches (include/pilco_hip.h)."""
         self._chk(self.lib.pilco_set_inline_policy(self.h, 1 if on else 0))
         self._settings["set_inline_policy"] = (on,)
-
-    def set_rollout_mode(self, mode):
-        """0 (default): the launch sequence (hipGraph replay); 1: plain rollouts as ONE persistent launch (include/pilco_hip.h)."""
-        self._chk(self.lib.pilco_set_rollout_mode(self.h, int(mode)))
-        self._settings["set_rollout_mode"] = (mode,)
-
-    def has_persistent_kernel(self):
-        return bool(self.lib.pilco_has_persistent_kernel())
-
-    def last_rollout_mode(self):
-        return int(self.lib.pilco_last_rollout_mode(self.h))
 
     def set_pair_kernel(self, variant):
         self._chk(self.lib.pilco_set_pair_kernel(self.h, int(variant)))

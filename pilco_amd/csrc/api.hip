@@ -326,7 +326,6 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
         }
     }
     if (const char* eg = getenv("PILCO_NO_GRAPH")) ctx->use_graph = (atoi(eg) == 0);
-    if (const char* ep = getenv("PILCO_PERSIST")) ctx->persist = (atoi(ep) != 0) ? 1 : 0;
     if (const char* ei = getenv("PILCO_INLINE_POLICY")) ctx->inline_policy = (atoi(ei) != 0);
     if (const char* ef = getenv("PILCO_FUSED")) ctx->fused = (atoi(ef) != 0);
     if (const char* ef = getenv("PILCO_SMALL_STEP")) ctx->fuse_small = (atoi(ef) != 0);
@@ -350,7 +349,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     for (Slot& s : ctx->slot) {
         for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr, &s.ksplit_ws,
                           &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.jac_rowmom, &s.jac_cpart, &s.jac_head, &s.jac_part, &s.jac_np, &s.own, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small, &s.w_fpart,
-                          &s.w_part, &s.w_gath, &s.w_out, &s.ft_P, &s.ft_T3, &s.ft_Z, &s.p_At, &s.p_Bt, &s.p_small, &s.p_part, &s.p_flags})
+                          &s.w_part, &s.w_gath, &s.w_out, &s.ft_P, &s.ft_T3, &s.ft_Z})
             b->release();
     }
     ctx->state.release();
@@ -407,23 +406,6 @@ int pilco_set_inline_policy(pilco_ctx* ctx, int on) {
     if (!ctx) return PILCO_E_SHAPE;
     ctx->inline_policy = (on != 0);
     return PILCO_OK;
-}
-
-int pilco_set_rollout_mode(pilco_ctx* ctx, int mode) {
-    if (!ctx || mode < 0 || mode > 1) return PILCO_E_SHAPE;
-    ctx->persist = mode;
-    if (mode == 1) ctx->persist_broken = false;   // asking for it again gives it another try
-    return PILCO_OK;
-}
-
-int pilco_last_rollout_mode(const pilco_ctx* ctx) { return (ctx && ctx->last_persist) ? 1 : 0; }
-
-int pilco_has_persistent_kernel(void) {
-#ifdef PILCO_WITH_PERSIST
-    return 1;
-#else
-    return 0;
-#endif
 }
 
 int pilco_set_use_graph(pilco_ctx* ctx, int on) {
@@ -833,11 +815,6 @@ int pilco_debug_buffer(pilco_ctx* ctx, int slot, int which, double* out, long n)
     if (int r = check_slot(ctx, slot)) return r;
     Slot& s = ctx->slot[slot];
     const double* src = which == 0 ? s.wk.At : which == 1 ? s.wk.Bt : which == 2 ? s.bwd_mom.p : which == 3 ? s.bwd_cp.p : s.beta.p;
-    if (which == 5) {   // the 64 control words behind the persistent kernel's flags (word 0: abort, 8..: one step's phase stamps), as raw 8-byte words
-        if (!s.p_flags.p || s.p_key.size() < 12) return fail(ctx, PILCO_E_STATE, "debug_buffer: no persistent rollout has run");
-        src = s.p_flags.p + (size_t)s.p_key[0] * ((size_t)s.wk.PL * s.wk.NCH + (size_t)s.p_key[11]);
-        if (n > 64) n = 64;
-    }
     if (!src || !out || n <= 0) return fail(ctx, PILCO_E_SHAPE, "debug_buffer: bad arguments");
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipMemcpy(out, src, sizeof(double) * n, hipMemcpyDeviceToHost));

@@ -51,10 +51,6 @@ struct Slot {
     double* alt_mean = nullptr;    // while its prep part writes the other
     bool wk_valid = false;
     int wk_variant = -1;
-    // persistent whole-rollout kernel (persist.hip): every step's own operands / small per-step results / partial sums,
-    // [H][stride] each, and the flag words (ready | done | control); p_key: the geometry they were sized and cleared for
-    DevBuf p_At, p_Bt, p_small, p_part, p_flags;
-    std::vector<long> p_key;
     std::vector<int> pair_owner;  // [P]
 };
 
@@ -137,10 +133,6 @@ struct pilco_ctx {
     std::vector<unsigned long long> graph_key;
     std::vector<std::pair<std::vector<unsigned long long>, hipGraphExec_t>> graph_cache;   // most recently used first (<= 4)
     bool use_graph = true;
-    int persist = 0;     // 1: single-rank plain rollouts run as ONE persistent launch (persist.hip) when the shape allows; 0 (default): launch sequence
-    bool persist_broken = false;        // a persistent launch gave up waiting (GPU shared?): this context stays on the launch sequence
-    bool last_persist = false;          // the rollout just enqueued was a persistent launch (its abort word must be checked)
-    unsigned long long persist_epoch = 0;
     bool inline_policy = true;   // an RbfController small enough is evaluated inside the link (2 launches per step instead of 4)
     bool fused = true;   // fused head: the serial link of step t runs inside the prep launch of step t+1 (2 launches per step)
     bool fuse_small = true;   // ... and, for models of at most 256 points, the pair sums too: ONE launch per step (prep_device.h)
@@ -254,8 +246,6 @@ int setup_rollout(pilco_ctx* ctx, const pilco_policy* pol, const pilco_reward_te
                   RolloutPlan& plan);
 int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev);
 int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H);
-// after the stream has been synchronised: did the persistent launch of the last rollout give up (-> repeat on the launch sequence)?
-bool persist_gave_up(pilco_ctx* ctx);
 // shard.hip: peer exchange
 void launch_peer_wait(hipStream_t st, unsigned long long* area, int k, int W, int spin);
 int peer_detach(pilco_ctx* ctx);

@@ -244,7 +244,6 @@ __device__ __forceinline__ void write_joint(const GlueArgs& g, const GlueLds& L,
         else if (c < E) v = L.t1[c * U + (r - E)];
         else v = L.su[(r - E) * U + (c - E)];
         L.js[e] = v;
-        if (g.lds_state && r < E) L.s1[r * D + c] = v;   // (dead since this link's propagate; squash may have used it as scratch)
         if (writer) {
             g.wk.in_s[e] = v;
             if (r < E) s1_dst[r * D + c] = v;
@@ -756,14 +755,13 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
     if constexpr (!SR)
         if (xq_in) xq_wait(g);   // (the segment loads below must not be issued before the flags have been seen)
     {   // one batch of loads for everything the serial part reads
-        const bool in_lds = g.lds_state == 2;   // persistent kernel: this workgroup's previous link left the state and s1 in LDS
-        const bool need_state = !in_lds && (g.flags & (GF_PROPAGATE | GF_TRAJ | GF_POLICY | GF_RBF_PRE)) != 0;
+        const bool need_state = (g.flags & (GF_PROPAGATE | GF_TRAJ | GF_POLICY | GF_RBF_PRE)) != 0;
         const bool lin = (g.flags & GF_POLICY) && g.pol_kind == PILCO_POLICY_LINEAR;
         const bool pol = (g.flags & GF_POLICY) && g.pol_kind != PILCO_POLICY_NONE;
         const LoadSeg sg[8] = {
             {0, g.m_x, need_state ? E : 0},
             {L.o_sx, g.s_x, need_state ? E * E : 0},
-            {L.o_s1, g.s1, ((g.flags & GF_PROPAGATE) && !in_lds) ? E * D : 0},
+            {L.o_s1, g.s1, (g.flags & GF_PROPAGATE) ? E * D : 0},
             {L.o_mp, (g.flags & GF_RBF_POST) ? g.pwk.mean_part : g.wk.mean_part, mp_n},
             {L.o_seg, g.wk.gath, ((g.flags & GF_ASSEMBLE) && !(g.flags & GF_PACK) && !xq_in) ? seg_n : 0},
             {L.o_js, g.W, lin ? U * E : 0},   // W parks in the joint-covariance buffer until write_joint overwrites it

@@ -118,8 +118,6 @@ struct GlueArgs {
     MMModel pmd;
     int pol_inline;  // 1: inline evaluation (small policy GPs: pol_lds > 0 doubles of extra LDS behind the link's region)
     int pol_lds;
-    int lds_state;   // persistent rollout kernel: 1 = keep the state, [s_x, s_x c_xu] in LDS for the next link of this workgroup;
-                     // 2 = ... and they ARE already there from the previous link (do not load them from global memory)
     // policy
     int pol_kind;
     const double* W;       // [U][E]
@@ -141,28 +139,6 @@ struct GlueArgs {
     int xq_W;
     int xq_cap;                     // doubles per segment slot
     int xq_spin;                    // bound of the flag wait (iterations of ~1 us): on expiry the area's error word is set
-};
-
-// Persistent whole-rollout kernel (persist.hip): ONE launch runs all H steps with every workgroup resident; the phases of
-// a step are ordered by flags in global memory instead of kernel boundaries.  Everything that crosses workgroups inside the
-// launch is written with write-through stores and read, after the flag, from addresses nobody has loaded before in this
-// launch: every step has its OWN operand / partial-sum / flag buffers (base + h * stride), so no cache holds a stale line
-// and no L2 write-back / invalidate is needed (tools/ubench_sync.hip: those fences cost ~10 us, the flags ~1.4 us).
-struct PersistArgs {
-    MMModel md;
-    GlueArgs g;              // the link's constants; g.wk = the workspace of step 0; g.m_x / g.s_x = the initial state
-    PrepReward pr;           // reward terms (n = 0: none); reward accumulator
-    int H;
-    int nitems_x;            // item grid of the operand phase: nitems_x x NCH, as k_mm_prep's launch grid
-    int glue_doubles;        // LDS doubles of the link's region (the operand phase's region follows it)
-    long sAt, sBt, sSmall, sPart;     // per-step strides (doubles) of At | Bt (+ vcol) | pair_isdet + mean_part | sk_part
-    double* st[2];           // double-buffered state (the writer workgroup stores every state; the final one is read back)
-    double* s1b[2];
-    unsigned long long* ready;   // [H][PL * NCH]   operands of (local pair, row chunk) of step h are in memory
-    unsigned long long* done;    // [H][workgroups]  workgroup finished everything of step h (dense: a poll reads a few cache lines)
-    unsigned long long* ctl;     // [0] abort word (epoch of the launch that gave up waiting), [1..] developer stamps
-    unsigned long long epoch;    // value of a raised flag: unique per launch, so flags never need clearing
-    unsigned long long timeout_ticks;   // bound of every wait in ticks of the 100 MHz wall clock
 };
 
 // Layout of an exchange area, in 8-byte words:  [0] epoch base of the current rollout (uploaded by the owner's host)
@@ -228,10 +204,6 @@ size_t mm_jac_head_size(int D, int E, int P);
 int mm_jac_nt(int npad, int Pg);
 int mm_jac_ns(int D);
 int mm_bwd_rc(int npad);
-// persistent whole-rollout kernel: does an instantiation exist for this input dimension / contraction depth, and the launch
-bool mm_persist_supported(int D, int KP, bool vsep);
-size_t mm_persist_lds_bytes(const MMModel& md, const GlueArgs& g, int reward_E);
-int launch_rollout_persist(hipStream_t st, const PersistArgs& a, int workgroups, size_t lds_bytes);
 int mm_exp_table_size();   // entries of the 2^(j/n) table the pair kernels were built for
 int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf, const double* exp_tab);
 

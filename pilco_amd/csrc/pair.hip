@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWor
     const int nd_steps = wk.sk_nd * wk.sk_tdiag;
     double out0, out1;
     int p0, p1;
-    sk_wave_range<KC, VSEP>(md, wk, tab, w, lane, [](int) {}, out0, out1, p0, p1);
+    sk_wave_range<KC, VSEP>(md, wk, tab, w, lane, out0, out1, p0, p1);
     for (int off = 32; off > 0; off >>= 1) {
         out0 += __shfl_down(out0, off);
         out1 += __shfl_down(out1, off);

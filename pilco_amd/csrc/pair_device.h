@@ -1,5 +1,5 @@
-// Device code of the O(N^2) pair sums shared by the pair kernels (pair.hip) and the persistent whole-rollout kernel
-// (persist.hip): the per-wave tile loop (pair_wave) and the closed forms of the stream-K work split.  Internal; gfx950 only.
+// Device code of the O(N^2) pair sums shared by the pair kernels (pair.hip) and the one-launch small step of the fused head
+// (prep_device.h): the per-wave tile loop (pair_wave) and the closed forms of the stream-K work split.  Internal; gfx950 only.
 #pragma once
 #include "mm_device.h"
 
@@ -41,8 +41,8 @@ namespace pilco {
 #define PAIR_MINW 1    // __launch_bounds__ min waves per SIMD for the pair kernel
 #endif
 // FENCE: an s_nop between the MFMA chain of a tile and the first VALU read of its result (MFMA_RESULT_FENCE, mm_device.h).
-// The pair kernels do not need it (the compiler keeps 7 + p slots there); inside the persistent rollout kernel, under its
-// 168-register budget, the same source is scheduled with reads of destination pairs 2 and 3 one slot early
+// The pair kernels do not need it (the compiler keeps 7 + p slots there); inside the fused head, under its register
+// budget, the same source has been seen scheduled with reads of destination pairs 2 and 3 one slot early
 // (tools/mfma_hazard_check.py, tests/test_build_isa.py), so that host asks for the fence.
 // LDSOP (the one-launch step of small models, prep_device.h): the operands never went to memory -- At / Bt / vcol point into
 // the workgroup's LDS, At as [k][lda] over the workgroup's own rows (row i0 is its row i0l), Bt as [k][ldb] over all columns.
@@ -250,13 +250,11 @@ __device__ __forceinline__ int sk_boundary(const MMWork& wk, int w) {
 }
 // One wave's share of the stream-K line (see k_mm_pair_sk): the 16-column steps [boundary(w), boundary(w + 1)) of the
 // cost line, touching at most two local pairs p0, p1 (-1: none) with the sums out0, out1 (before the wave reduction).
-// `ready(pl)` is called once before the first tile of every pair the range touches.
-template <int KC, bool VSEP, bool FENCE = false, typename Ready>
+template <int KC, bool VSEP, bool FENCE = false>
 __device__ __forceinline__ void sk_wave_range(const MMModel& md, const MMWork& wk, const double* __restrict__ tab, int w, int lane,
-                                              Ready ready, double& out0, double& out1, int& p0, int& p1) {
+                                              double& out0, double& out1, int& p0, int& p1) {
     const int npad = md.npad, NS = npad / 16, KP = wk.KP;
     const int nd_steps = wk.sk_nd * wk.sk_tdiag;
-    int last_ready = -1;
     int step = sk_boundary(wk, w);
     const int end = sk_boundary(wk, w + 1);
     out0 = 0.0;
@@ -296,10 +294,6 @@ __device__ __forceinline__ void sk_wave_range(const MMModel& md, const MMWork& w
             }
             cur_pl = pl;
             cur = 0.0;
-        }
-        if (pl != last_ready) {   // (persistent kernel: the operands of this pair must have been published)
-            ready(pl);
-            last_ready = pl;
         }
         int a, b;
         local_pair_ab(wk, md.E, pl, a, b);

@@ -1,5 +1,5 @@
 // Device code of the per-step operand work (operands of the pair kernel, mean parts, reward) shared by k_mm_prep
-// (prep.hip) and the persistent whole-rollout kernel (persist.hip).  Internal; gfx950 only.
+// (prep.hip).  Internal; gfx950 only.
 #pragma once
 #include "glue_device.h"
 #include "pair_device.h"
@@ -162,8 +162,7 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
             _Pragma("unroll 8") for (int k = 0; k < D; ++k) acc = fma(s_T[(t - 1) * DT + k], hs[1 + k], acc);
             v = s_sc[1] * acc;
         }
-        store_wt(&wk.mean_part[((long)al * wk.NCHM + chm) * (1 + D) + t], v);   // indexed by the LOCAL output number; write-through: the
-                                                                                 // persistent kernel hands it to other workgroups without an L2 write-back
+        store_wt(&wk.mean_part[((long)al * wk.NCHM + chm) * (1 + D) + t], v);   // indexed by the LOCAL output number
     }
     DBG_STAMP(wk, 44, dbgm);
 }

@@ -235,7 +235,15 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
 // Does a value-and-gradient rollout of this plan run its steps as the one-launch small step (small_sweep)?  Returns the
 // workgroups per pair (row chunks x column splits) or 0.  (The same conditions enqueue_rollout_steps applies, plus those of its fused-head branch.)
 static bool fused_heads_fit(pilco_ctx* ctx, const RolloutPlan& plan);
-static int device_cus_of(int device);
+static int device_cus_of(int device) {
+    static int cached[64] = {};
+    int& c = cached[device & 63];
+    if (c == 0) {
+        hipDeviceProp_t prop;
+        c = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    return c;
+}
 // Column splits of the one-launch small step (MMWork::NCS): with 64-row workgroups whose operands stay in LDS, a pair's
 // columns are dealt over up to four workgroups as long as the whole launch stays ONE round of the chip (one workgroup per
 // CU) -- a small model with few outputs would otherwise leave most CUs idle while 40 of them work through the pair sums.
@@ -581,161 +589,12 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
     return PILCO_OK;
 }
 
-#ifndef PILCO_WITH_PERSIST
-// The product build leaves persist.hip out (Makefile: PERSIST=1 compiles it in): no instantiation exists, so a context asked
-// for rollout mode 1 keeps running the launch sequence (pilco_last_rollout_mode reports 0; pilco_has_persistent_kernel: 0).
-namespace pilco {
-bool mm_persist_supported(int, int, bool) { return false; }
-size_t mm_persist_lds_bytes(const MMModel&, const GlueArgs&, int) { return 0; }
-int launch_rollout_persist(hipStream_t, const PersistArgs&, int, size_t) { return -1; }
-}  // namespace pilco
-#endif
-// ---------------------------------------------------------------- persistent whole-rollout launch (persist.hip)
-static int device_cus_of(int device) {
-    static int cached[64] = {};
-    int& c = cached[device & 63];
-    if (c == 0) {
-        hipDeviceProp_t prop;
-        c = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
-    return c;
-}
-static int device_lds_limit(int device) {
-    int lim = 65536;
-    (void)hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
-    return lim;
-}
-
-// Can this rollout run as one persistent launch?  One rank, no RBF policy, no tape, the stream-K pair kernel, an
-// instantiated input dimension, the item grid and the wave line within one workgroup per CU, LDS within the CU's.
-static bool persist_applies(pilco_ctx* ctx, const RolloutPlan& plan, int H) {
-    const Slot& s = ctx->slot[0];
-    if (!ctx->persist || ctx->persist_broken || ctx->time_pairs || (ctx->dbg && !getenv("PILCO_PERSIST_DBG"))) return false;
-    if (ctx->nranks != 1 || ctx->comm || H <= 0 || s.wk.PL <= 0 || s.wk.sk_waves <= 0 || ctx->variant != 0) return false;
-    if (plan.g.pol_kind == PILCO_POLICY_RBF || plan.g.tape || plan.jrec) return false;
-    if (!mm_persist_supported(s.D, s.wk.KP, s.wk.vsep != 0)) return false;
-    const int cus = device_cus_of(ctx->device);
-    const int spare = s.wk.EL * s.wk.NCHM + (plan.g.n_rewards > 0 ? 1 : 0);
-    const int gx = s.wk.PL + (spare + s.wk.NCH - 1) / s.wk.NCH;
-    if (gx * s.wk.NCH > cus || s.wk.sk_waves > cus * 12) return false;
-    GlueArgs gl = plan.g;
-    gl.flags = GF_TRAJ | GF_POLICY | GF_PACK | GF_ASSEMBLE | GF_PROPAGATE;
-    if (mm_persist_lds_bytes(model_of(s), gl, plan.g.n_rewards > 0 ? plan.E : 0) + 4096 > (size_t)device_lds_limit(ctx->device)) return false;
-    // every step owns its operand buffers (no address is reused inside a launch): [H] x ~11 MB at C2; cap by PILCO_PERSIST_GB
-    const size_t PLa = (size_t)std::max(s.wk.PL, 1);
-    const double bytes = 8.0 * (double)H * (2.0 * PLa * s.wk.KP * s.npad + PLa * s.npad + (double)s.wk.sk_pls * s.wk.sk_maxw);
-    double cap_gb = 16.0;
-    if (const char* ev = getenv("PILCO_PERSIST_GB")) cap_gb = atof(ev);
-    return bytes <= cap_gb * 1e9;
-}
-
-static int enqueue_rollout_persist(pilco_ctx* ctx, RolloutPlan& plan, int H) {
-    Slot& s = ctx->slot[0];
-    const int E = plan.E, D = plan.D, npad = s.npad;
-    const int cus = device_cus_of(ctx->device);
-    const size_t PLa = (size_t)std::max(s.wk.PL, 1);
-    PersistArgs a{};
-    a.md = model_of(s);
-    a.g = plan.g;
-    a.H = H;
-    a.sAt = (long)(PLa * s.wk.KP * npad);
-    a.sBt = (long)(PLa * s.wk.KP * npad + PLa * npad);
-    // NO TWO STEPS MAY SHARE A CACHE LINE: a step's link loads the previous step's small results with ordinary loads; a
-    // line that also held the head of the CURRENT step's (not yet written) results would then sit stale in the L1 / L2 when
-    // the next link wants them.  (Found in round 3: with an unpadded stride the first rollout at a new horizon read zeros;
-    // later ones read the previous rollout's -- identical -- values and looked right.)  128-byte lines = 16 doubles.
-    a.sSmall = (long)round_up((int)(PLa + (size_t)E * s.wk.NCHM * (1 + D)), 16);
-    a.sPart = (long)((size_t)std::max(s.wk.sk_pls, 16) * std::max(s.wk.sk_maxw, 4));
-    if ((a.sAt | a.sBt | a.sSmall | a.sPart) & 15) return fail(ctx, PILCO_E_STATE, "rollout: per-step buffers of the persistent launch are not cache-line multiples");
-    const int spare = s.wk.EL * s.wk.NCHM + (plan.g.n_rewards > 0 ? 1 : 0);
-    a.nitems_x = s.wk.PL + (spare + s.wk.NCH - 1) / s.wk.NCH;
-    const size_t nready = (size_t)s.wk.PL * s.wk.NCH, ndone = (size_t)cus;
-    const size_t nflags = (size_t)H * (nready + ndone) + 64;
-    const std::vector<long> key = {H, npad, s.wk.PL, s.wk.KP, s.wk.NCH, s.wk.NCHM, s.wk.sk_pls, s.wk.sk_maxw, s.wk.sk_waves, E, D, cus,
-                                   (long)(uintptr_t)s.p_At.p, (long)(uintptr_t)s.p_part.p, (long)(uintptr_t)s.p_flags.p};
-    if (s.p_key != key || !s.p_At.p) {
-        ENSURE(s.p_At, (size_t)H * a.sAt);
-        ENSURE(s.p_Bt, (size_t)H * a.sBt);
-        ENSURE(s.p_small, (size_t)H * a.sSmall);
-        ENSURE(s.p_part, (size_t)H * a.sPart);
-        ENSURE(s.p_flags, nflags);
-        // partial-sum slots no wave writes must read zero (the link sums whole slot rows); flags start below every epoch
-        HIPCHK(hipMemsetAsync(s.p_part.p, 0, sizeof(double) * (size_t)H * a.sPart, ctx->st));
-        HIPCHK(hipMemsetAsync(s.p_flags.p, 0, sizeof(double) * nflags, ctx->st));
-        HIPCHK(hipMemsetAsync(s.p_small.p, 0, sizeof(double) * (size_t)H * a.sSmall, ctx->st));
-        s.p_key = {H, npad, s.wk.PL, s.wk.KP, s.wk.NCH, s.wk.NCHM, s.wk.sk_pls, s.wk.sk_maxw, s.wk.sk_waves, E, D, cus,
-                   (long)(uintptr_t)s.p_At.p, (long)(uintptr_t)s.p_part.p, (long)(uintptr_t)s.p_flags.p};
-    }
-    a.g.wk = s.wk;
-    a.g.wk.At = s.p_At.p;
-    a.g.wk.Bt = s.p_Bt.p;
-    a.g.wk.vcol = s.p_Bt.p + PLa * s.wk.KP * npad;
-    a.g.wk.pair_isdet = s.p_small.p;
-    a.g.wk.mean_part = s.p_small.p + PLa;
-    a.g.wk.sk_part = s.p_part.p;
-    a.g.wk.pair_part = s.p_part.p;
-    a.g.wk.dbg = ctx->dbg;   // (phase stamps: developer runs with PILCO_PERSIST_DBG=1 only)
-    a.st[0] = plan.st[0];
-    a.st[1] = plan.st[1];
-    a.s1b[0] = plan.s1b[0];
-    a.s1b[1] = plan.s1b[1];
-    a.g.m_x = plan.st[0];
-    a.g.s_x = plan.st[0] + E;
-    if (plan.g.n_rewards > 0) {
-        a.pr.n = plan.g.n_rewards;
-        a.pr.E = E;
-        for (int i = 0; i < plan.g.n_rewards; ++i) a.pr.rw[i] = plan.g.rw[i];
-        a.pr.reward = plan.g.reward;
-    }
-    unsigned long long* fl = reinterpret_cast<unsigned long long*>(s.p_flags.p);
-    a.ready = fl;
-    a.done = fl + (size_t)H * nready;
-    a.ctl = fl + (size_t)H * (nready + ndone);
-    a.epoch = ++ctx->persist_epoch;
-    double tmo_ms = 200.0;
-    if (const char* ev = getenv("PILCO_PERSIST_TIMEOUT_MS")) tmo_ms = atof(ev);
-    a.timeout_ticks = (unsigned long long)(tmo_ms * 1e5);   // 100 MHz wall clock
-    GlueArgs gl = a.g;
-    gl.flags = GF_TRAJ | GF_POLICY | GF_PACK | GF_ASSEMBLE | GF_PROPAGATE;
-    a.glue_doubles = (int)((glue_lds_doubles_for(gl) + 1) & ~(size_t)1);
-    const size_t lds = mm_persist_lds_bytes(a.md, gl, plan.g.n_rewards > 0 ? E : 0);
-    HIPCHK(hipMemsetAsync(plan.g.reward, 0, sizeof(double), ctx->st));
-    if (launch_rollout_persist(ctx->st, a, cus, lds) != 0) return fail(ctx, PILCO_E_HIP, "rollout: persistent launch could not be configured");
-    HIPCHK(hipGetLastError());
-    ctx->last_persist = true;
-    return PILCO_OK;
-}
-
-// The abort word of the last persistent launch (device address), or nullptr when the last rollout was not one.
-static const unsigned long long* persist_abort_word(pilco_ctx* ctx) {
-    if (!ctx->last_persist) return nullptr;
-    const Slot& s = ctx->slot[0];
-    // the control words sit behind the flags of the geometry in p_key: H * (nready + ndone)
-    const size_t H = (size_t)s.p_key[0], nready = (size_t)s.wk.PL * s.wk.NCH, ndone = (size_t)s.p_key[11];
-    return reinterpret_cast<const unsigned long long*>(s.p_flags.p) + H * (nready + ndone);
-}
-// After the stream has been synchronised: did the last persistent launch give up?  (Blocking read; pilco_rollout brings
-// the word down with its results instead.)  A launch that gave up leaves this context on the launch sequence
-// (pilco_set_rollout_mode(ctx, 1) re-arms it).
-bool persist_gave_up(pilco_ctx* ctx) {
-    const unsigned long long* abortw = persist_abort_word(ctx);
-    if (!abortw) return false;
-    unsigned long long word = 0;
-    if (hipMemcpy(&word, abortw, sizeof(word), hipMemcpyDeviceToHost) != hipSuccess || word == ctx->persist_epoch) {
-        ctx->persist_broken = true;
-        return true;
-    }
-    return false;
-}
-
 // Run one rollout: replay the cached hipGraph when the launch sequence is unchanged
 // (same buffers, sizes, horizon, policy / reward structure), otherwise (re)capture it.
 int run_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H) {
     Slot& s = ctx->slot[0];
     // With a communicator the captured graph contains the ncclAllGather nodes (RCCL supports stream
     // capture); if capture or instantiation fails the rollout falls back to eager launches for good.
-    ctx->last_persist = false;
-    if (persist_applies(ctx, plan, H)) return enqueue_rollout_persist(ctx, plan, H);
     const bool peer = peer_rollout_applies(ctx, plan, H);   // no collective nodes: captured like a single-rank rollout
     const bool sharded = (ctx->nranks != 1 || ctx->comm) && !peer;
     if (ctx->time_pairs) {   // measurement mode (pilco_set_pair_timing): eager, an event pair around every O(N^2) launch
@@ -849,14 +708,12 @@ extern "C" {
 
 // pilco_rollout in two halves, so that several rollouts (the lanes of pilco_rollout_batch) can be in flight at once:
 // rollout_begin enqueues everything -- upload of (m0, S0), the rollout, the downloads into pinned memory -- and returns;
-// rollout_end waits for the stream and hands the results out.  *retry: the persistent launch gave up (call again).
+// rollout_end waits for the stream and hands the results out.
 struct RolloutCall {
     RolloutPlan plan;
     size_t nst = 0;
     double* pin_out = nullptr;
     bool peer = false;
-    const unsigned long long* abortw = nullptr;
-    unsigned long long* pin_abort = nullptr;
 };
 static int rollout_begin(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
                          const double* S0, int H, double* traj, RolloutCall& rc) {
@@ -891,23 +748,14 @@ static int rollout_begin(pilco_ctx* ctx, const pilco_policy* policy, const pilco
         HIPCHK(hipMemcpyAsync(traj, ctx->traj.p, sizeof(double) * (size_t)(H + 1) * (E + E * E), hipMemcpyDeviceToHost, ctx->st));
     rc.peer = peer_rollout_applies(ctx, plan, H);
     if (rc.peer) HIPCHK(hipMemcpyAsync(ctx->xq.pin + 128, ctx->xq.local + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->st));
-    rc.abortw = persist_abort_word(ctx);
-    rc.pin_abort = reinterpret_cast<unsigned long long*>(pin_out + nst + 2);
-    if (rc.abortw) HIPCHK(hipMemcpyAsync(rc.pin_abort, rc.abortw, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->st));
     rc.nst = nst;
     rc.pin_out = pin_out;
     return PILCO_OK;
 }
-static int rollout_end(pilco_ctx* ctx, RolloutCall& rc, double* mH, double* SH, double* reward, bool* retry) {
-    *retry = false;
+static int rollout_end(pilco_ctx* ctx, RolloutCall& rc, double* mH, double* SH, double* reward) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());
-    if (rc.abortw && rc.pin_abort[0] == ctx->persist_epoch) {   // the persistent launch could not make progress (GPU shared?):
-        ctx->persist_broken = true;                             // once more, and from now on, on the launch sequence
-        *retry = true;
-        return PILCO_OK;
-    }
     if (rc.peer && ctx->xq.pin[128] != 0ULL) {   // a flag wait gave up: some rank never delivered that exchange
         const unsigned long long ep = ctx->xq.pin[128];
         (void)hipMemsetAsync(ctx->xq.local + 1, 0, sizeof(unsigned long long), ctx->st);
@@ -941,7 +789,6 @@ static int lane_sync_model(pilco_ctx* parent, pilco_ctx* lane) {
     lane->fuse_small = parent->fuse_small;
     lane->inline_policy = parent->inline_policy;
     lane->grad_mode = parent->grad_mode;
-    lane->persist = 0;   // lanes overlap each other's serial heads; a persistent launch would claim every CU for one lane
     if (!same) {
         l.wk_valid = false;
         for (auto& ge : lane->graph_cache) (void)hipGraphExecDestroy(ge.second);
@@ -983,10 +830,7 @@ int pilco_rollout(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     if (!m0 || !S0 || !mH || !SH || !reward || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout: bad arguments");
     RolloutCall rc;
     if (int r = rollout_begin(ctx, policy, rewards, n_rewards, m0, S0, H, traj, rc)) return r;
-    bool retry = false;
-    if (int r = rollout_end(ctx, rc, mH, SH, reward, &retry)) return r;
-    if (retry) return pilco_rollout(ctx, policy, rewards, n_rewards, m0, S0, H, mH, SH, reward, traj);
-    return PILCO_OK;
+    return rollout_end(ctx, rc, mH, SH, reward);
 }
 
 // B independent rollouts of ONE model in flight together (multi-start policy search, several initial states; the restart
@@ -1021,13 +865,11 @@ int pilco_rollout_batch(pilco_ctx* ctx, int B, const pilco_policy* policies, con
         }
     }
     for (int i = 0; i < begun; ++i) {
-        bool retry = false;
-        const int r = rollout_end(lane[i], rc[i], mH + (size_t)i * E, SH + (size_t)i * E * E, reward + i, &retry);
+        const int r = rollout_end(lane[i], rc[i], mH + (size_t)i * E, SH + (size_t)i * E * E, reward + i);
         if (r && !rc_err) {
             rc_err = r;
             if (i > 0) ctx->err = "lane " + std::to_string(i) + ": " + lane[i]->err;
         }
-        (void)retry;   // lanes never run persistent launches
     }
     (void)nst;
     return rc_err;
@@ -1184,8 +1026,6 @@ int pilco_rollout_timed(pilco_ctx* ctx, const pilco_policy* policy, const pilco_
     HIPCHK(hipEventRecord(ctx->ev1, ctx->st));
     HIPCHK(hipEventSynchronize(ctx->ev1));
     HIPCHK(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
-    if (persist_gave_up(ctx))   // a persistent launch could not make progress: time the launch sequence instead
-        return pilco_rollout_timed(ctx, policy, rewards, n_rewards, m0, S0, H, reps, mH, SH, reward, ms_total, ms_pair, n_pair_launches);
     if (ms_pair) {
         // second pass with an event pair around every pair-kernel launch (perturbs the total, so timed separately)
         const size_t need = (size_t)2 * H;

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-UNITS = ["pair", "bwd", "linalg", "persist", "prep_dt_a", "prep_dt_b"]   # prep_dt_a, _b: the heads for D <= 11 (both register builds), whose one-launch small step carries the pair and sweep arithmetic
+UNITS = ["pair", "bwd", "linalg", "prep_dt_a", "prep_dt_b"]   # prep_dt_a, _b: the heads for D <= 11 (both register builds), whose one-launch small step carries the pair and sweep arithmetic
 
 
 @pytest.fixture(scope="module")
