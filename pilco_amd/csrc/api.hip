@@ -86,8 +86,12 @@ int build_work(pilco_ctx* ctx, Slot& s) {
         wk.sk_pls = round_up(wk.PL, 16);
     }
     ENSURE(s.w_in, (size_t)D + D * D + E + E * E + D * E);   // m | s | cotangents (Mbar | Sbar | Vbar) of the reverse pass
+    // operands of the exponent GEMM (layout: MMWork::At / Wt): per pair (2 Q z_i | u_i) and v_j; per column output the w rows
+    // (models of at most 256 points: a block per local pair too, for the one-launch small step with operands in memory);
+    // the ones (valid mask) and the zeros, constants of the model, are written here
+    const size_t wt_blocks = npad <= 256 ? (size_t)std::max(E, PLa) : (size_t)E;
     ENSURE(s.w_At, (size_t)PLa * wk.KP * npad);
-    ENSURE(s.w_Bt, (size_t)PLa * wk.KP * npad + (size_t)PLa * npad);   // column operands, then v_j on its own (vsep)
+    ENSURE(s.w_Wt, (wt_blocks * wk.KP + PLa) * npad);
     const size_t n_small = (size_t)PLa + (size_t)E * wk.NCHM * (1 + D);
     ENSURE(s.w_small, 2 * n_small);
     ENSURE(s.w_part, std::max((size_t)PLa * wk.NT * 2, (size_t)std::max(wk.sk_pls, 16) * std::max(wk.sk_maxw, 4)));
@@ -100,8 +104,21 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.in_m = s.w_in.p;
     wk.in_s = s.w_in.p + D;
     wk.At = s.w_At.p;
-    wk.Bt = s.w_Bt.p;
-    wk.vcol = s.w_Bt.p + (size_t)PLa * wk.KP * npad;
+    wk.Wt = s.w_Wt.p;
+    wk.vcol = wk.Wt + wt_blocks * wk.KP * npad;
+    {   // the constant rows of every block: zeros everywhere, then the ones (the valid mask) in row D + 1 of A (not vsep) and row D of B
+        HIPCHK(hipMemsetAsync(wk.At, 0, sizeof(double) * (size_t)PLa * wk.KP * npad, ctx->st));
+        HIPCHK(hipMemsetAsync(wk.Wt, 0, sizeof(double) * (wt_blocks * wk.KP + PLa) * npad, ctx->st));
+        std::vector<double> ones((size_t)npad, 0.0);
+        for (int i = 0; i < s.n && i < npad; ++i) ones[i] = 1.0;
+        ENSURE(s.w_ones, (size_t)npad);
+        HIPCHK(hipMemcpyAsync(s.w_ones.p, ones.data(), sizeof(double) * npad, hipMemcpyHostToDevice, ctx->st));
+        HIPCHK(hipStreamSynchronize(ctx->st));   // (the host vector goes out of scope)
+        for (int pl = 0; pl < PLa && !wk.vsep; ++pl)
+            HIPCHK(hipMemcpyAsync(wk.At + ((size_t)pl * wk.KP + D + 1) * npad, s.w_ones.p, sizeof(double) * npad, hipMemcpyDeviceToDevice, ctx->st));
+        for (size_t blk = 0; blk < wt_blocks; ++blk)
+            HIPCHK(hipMemcpyAsync(wk.Wt + (blk * wk.KP + D) * npad, s.w_ones.p, sizeof(double) * npad, hipMemcpyDeviceToDevice, ctx->st));
+    }
     wk.pair_isdet = s.w_small.p;
     wk.mean_part = wk.pair_isdet + PLa;
     s.alt_isdet = s.w_small.p + n_small;
@@ -348,7 +365,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
         for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr, &s.ksplit_ws,
-                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.jac_rowmom, &s.jac_cpart, &s.jac_head, &s.jac_part, &s.jac_np, &s.own, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Bt, &s.w_small, &s.w_fpart,
+                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.jac_rowmom, &s.jac_cpart, &s.jac_head, &s.jac_part, &s.jac_np, &s.own, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Wt, &s.w_ones, &s.w_small, &s.w_fpart,
                           &s.w_part, &s.w_gath, &s.w_out, &s.ft_P, &s.ft_T3, &s.ft_Z})
             b->release();
     }
@@ -814,7 +831,7 @@ int pilco_factorize_timed(pilco_ctx* ctx, int slot, int reps, float* ms_each) {
 int pilco_debug_buffer(pilco_ctx* ctx, int slot, int which, double* out, long n) {
     if (int r = check_slot(ctx, slot)) return r;
     Slot& s = ctx->slot[slot];
-    const double* src = which == 0 ? s.wk.At : which == 1 ? s.wk.Bt : which == 2 ? s.bwd_mom.p : which == 3 ? s.bwd_cp.p : s.beta.p;
+    const double* src = which == 0 ? s.wk.At : which == 1 ? s.wk.Wt : which == 2 ? s.bwd_mom.p : which == 3 ? s.bwd_cp.p : s.beta.p;
     if (!src || !out || n <= 0) return fail(ctx, PILCO_E_SHAPE, "debug_buffer: bad arguments");
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipMemcpy(out, src, sizeof(double) * n, hipMemcpyDeviceToHost));

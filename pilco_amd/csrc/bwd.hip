@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
                                                     double* __restrict__ head, double* __restrict__ npart) {
     __shared__ double tab[FEXP_TN];
     extern __shared__ __attribute__((aligned(16))) double csl[];   // [4][jw]  (head workgroups: Gauss-Jordan scratch)
+    kernarg_warm<(int)(sizeof(MMModel) + sizeof(MMWork)) + 56 + 64>();
     if ((int)blockIdx.y >= wk.PL) {   // spare workgroups: the step's D x D inverses, one per output / pair
         const int h = ((int)blockIdx.y - wk.PL) * (int)(gridDim.x * gridDim.z) + (int)(blockIdx.z * gridDim.x + blockIdx.x);
         if (h < md.E + wk.PL) bwd_head(md, wk, bars, h, head, csl);
@@ -144,9 +145,7 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
     const int pl = blockIdx.y, js = blockIdx.z, rb = blockIdx.x;
     int a, b;
     local_pair_ab(wk, E, pl, a, b);
-    const int KP = wk.KP;
-    const double* At = wk.At + (long)pl * KP * npad;
-    const double* Bt = wk.Bt + (long)pl * KP * npad;
+    const PairOps po = pair_ops(wk, D, npad, pl, b);   // operand layout: MMWork::At / Wt (moment.h)
     const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
     const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
     const bool diag = (a == b);
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
         irow[rt] = ok ? ibase + 16 * rt + lc : lc;
         brow[rt] = ok ? beta_a[irow[rt]] : 0.0;
 #pragma unroll
-        for (int c = 0; c < KC; ++c) rf[rt][c] = At[(long)(4 * c + lr) * npad + irow[rt]];
+        for (int c = 0; c < KC; ++c) rf[rt][c] = po.At[(long)(4 * c + lr) * npad + irow[rt]];
     }
     // The column operands (KP rows of Bt, beta_b, v) are the same for the four waves of the workgroup: they are staged
     // once per BWD_CH columns through LDS (wave w fetches rows w, w + 4, .. as 512-byte row segments) into a
@@ -177,8 +176,8 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
     // flight in registers while the current one is evaluated.  Only the iK stream of a diagonal pair stays a per-wave
     // buffer load.
     constexpr int KPc = 4 * KC, NR = KPc + (VSEP ? 2 : 1), NST = (NR + 3) / 4, BWD_TP = bwd_tp(KPc), SB = BWD_CH * BWD_TP + 2 * BWD_CH;
-    const __amdgpu_buffer_rsrc_t rIK = buf_rsrc_uniform(iKa ? iKa + (long)jbeg * npad : Bt);
-    const double* vsrc = VSEP ? wk.vcol + (long)pl * npad : Bt;
+    const __amdgpu_buffer_rsrc_t rIK = buf_rsrc_uniform(iKa ? iKa + (long)jbeg * npad : po.Wt);
+    const double* vsrc = (const double*)((const char*)po.Wt + po.v0);   // (staged only when VSEP: otherwise v_j is row D + 1 of the contraction)
     unsigned ik_voff[BWD_RT];   // (the 4 r part of the row index rides in the scalar offset: 2 registers instead of 8)
 #pragma unroll
     for (int rt = 0; rt < BWD_RT; ++rt) ik_voff[rt] = ((unsigned)lr * (unsigned)npad + (unsigned)irow[rt]) * 8u;
@@ -190,7 +189,7 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int row = w + 4 * k, col = jc + lane;   // wave-uniform row
-            const double* src = row < KPc ? Bt + (long)row * npad : (row == KPc ? beta_b : vsrc);
+            const double* src = row < KPc ? colop_row<VSEP>(po, npad, row) : (row == KPc ? beta_b : vsrc);
             sg[k] = (row < NR && col < jend) ? src[col] : 0.0;
         }
     };

@@ -30,6 +30,7 @@ int rbf_inline_lds_doubles(int E, int U, int bf) {
 
 __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    kernarg_warm<(int)sizeof(GlueArgs) + 64>();
     const int E = g.E, t = threadIdx.x;
     GlueLds L;
     glue_lds_carve(g, sm, L);

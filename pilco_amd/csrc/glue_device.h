@@ -28,6 +28,8 @@ struct GlueLds {
     double* mp;   // [EL*NCH*(1+D)] mean partials
     double* misc; // [256]: [1..) cdiag, [64..) / [96..) temporaries, [128..) policy bias b, [160..) max_action (batched load)
     double* pol;  // scratch of the inline RbfController evaluation (GlueArgs::pol_lds doubles), behind mp
+    double* xm;   // fused head: where the HOST workgroup's next phase wants the joint mean [D] and covariance [D][D] (its own
+    double* xs;   // LDS region): write_joint stores them there too, and that phase starts without a copy and a barrier of its own
     int nm;       // max(E, D): leading dimension of the square buffers
     int o_sx, o_s1, o_js, o_seg, o_mp, o_misc;   // offsets (doubles) of sx, s1, js, seg, mp from mx, for multi_load
 };
@@ -56,6 +58,8 @@ __device__ __forceinline__ void glue_lds_carve(const GlueArgs& g, double* sm, Gl
         const int tail = seg_n + mp_n;
         L.pol = L.seg + (tail > rew_n ? tail : rew_n);   // (matches glue_lds_doubles: the tail region is max(seg + mp, reward scratch))
     }
+    L.xm = nullptr;
+    L.xs = nullptr;
     L.nm = nm;
     L.o_sx = nm;
     L.o_s1 = 2 * nm + 5 * nm * nm;
@@ -233,6 +237,7 @@ __device__ __forceinline__ void write_joint(const GlueArgs& g, const GlueLds& L,
     if (t < D) {
         const double v = (t < E) ? L.mx[t] : L.mu[t - E];
         L.jm[t] = v;
+        if (L.xm) L.xm[t] = v;
         if (writer) g.wk.in_m[t] = v;
     }
     for (int e = t; e < D * D; e += blockDim.x) {
@@ -244,6 +249,7 @@ __device__ __forceinline__ void write_joint(const GlueArgs& g, const GlueLds& L,
         else if (c < E) v = L.t1[c * U + (r - E)];
         else v = L.su[(r - E) * U + (c - E)];
         L.js[e] = v;
+        if (L.xs) L.xs[e] = v;
         if (writer) {
             g.wk.in_s[e] = v;
             if (r < E) s1_dst[r * D + c] = v;

@@ -30,6 +30,100 @@ __device__ __forceinline__ int pair_order_index(int E, int a, int b) {  // a >= 
     return (a == b) ? a : E + a * (a - 1) / 2 + b;
 }
 
+// ---- addressing of the exponent GEMM's operands (layout: MMWork::At / Wt in moment.h)
+// Where pair (local index pl, outputs a >= b) finds them in global memory.
+struct PairOps {
+    const double* At;    // the pair's row block [KP][npad]
+    const double* Wt;    // base of the column-operand allocation (MMWork::Wt): one buffer resource for every pair
+    unsigned w0;         // BYTES from Wt to the pair's column block [KP][npad]
+    unsigned v0;         // BYTES from Wt to the pair's v_j [npad]   (v0 > w0: vcol sits behind the blocks)
+    int D;
+};
+// column block of a pair: its column output b -- or, in the fused head, the pair itself where a workgroup must read back what
+// IT wrote within one launch (one-launch small step with the operands in memory: wk.fuse_pair != 0).  Kernels that run
+// behind a head launch pass blk = b.
+__device__ __forceinline__ int pair_col_block(const MMWork& wk, int pl, int b) { return wk.fuse_pair ? pl : b; }
+__device__ __forceinline__ PairOps pair_ops(const MMWork& wk, int D, int npad, int pl, int blk) {
+    PairOps po;
+    po.At = wk.At + (long)pl * wk.KP * npad;
+    po.Wt = wk.Wt;
+    po.w0 = (unsigned)blk * (unsigned)wk.KP * (unsigned)npad * 8u;
+    po.v0 = (unsigned)((wk.vcol - wk.Wt) + (long)pl * npad) * 8u;
+    po.D = D;
+    return po;
+}
+// row k of the column-side operand B = (w_j | 1 | v_j | 0..) of a pair, as a pointer (scalar code paths)
+template <bool VSEP>
+__device__ __forceinline__ const double* colop_row(const PairOps& po, int npad, int k) {
+    return (const double*)((const char*)po.Wt + ((!VSEP && k == po.D + 1) ? po.v0 : po.w0 + (unsigned)k * (unsigned)npad * 8u));
+}
+// Does local pair pl = (a, b) write the column block of output b this step?  The FIRST local pair with that column does:
+// (b, b) when this rank owns it (diagonal pairs come first in the dealing order), else the off-diagonal (a', b) with the
+// smallest a' it owns.  (One-launch small step with operands in memory: every pair writes its own block.)
+__device__ __forceinline__ bool pair_writes_wt(const MMWork& wk, int E, int a, int b) {
+    if (wk.fuse_pair) return true;
+    if (wk.nranks == 1 || b % wk.nranks == wk.rank) return a == b;
+    for (int a2 = b + 1; a2 < a; ++a2)
+        if ((E + a2 * (a2 - 1) / 2 + b) % wk.nranks == wk.rank) return false;
+    return true;
+}
+
+// The kernel-argument segment of these kernels is 0.3-1.6 KB of by-value descriptors (MMModel, MMWork, GlueArgs, ...).  The
+// compiler fetches a field where it is first needed -- an s_load, an s_waitcnt, the arithmetic that leads to the next
+// field, the next s_load: the fused head's prologue is SIX such round trips in a row, each a miss of the scalar cache (the
+// segment of a graph node lives in device memory and was evicted from the XCD's L2 by the 60 MB the previous pair kernel
+// streamed).  kernarg_warm requests every 64-byte line of the segment at once -- one round trip -- so that the compiler's own
+// loads hit the scalar cache.  (KERNARG_WARM=0: off, for A/B runs.)
+#ifndef KERNARG_WARM
+#define KERNARG_WARM 1
+#endif
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+#if KERNARG_WARM
+    static_assert(BYTES <= 2048, "kernarg_warm covers segments of at most 2 KB");
+    // ONE asm statement -- requests and wait: nothing of the compiler's may come between a request and the wait (the
+    // destination register is dead for the compiler as soon as the statement ends, while a scalar load that is still in
+    // flight would write it later; scalar loads return out of order).  The assembler's .if keeps the lines the segment has.
+    int sink;
+    asm volatile("s_load_dword %0, %1, 0\n\t"
+                 ".if %2 > 64\n\ts_load_dword %0, %1, 64\n\t.endif\n\t"
+                 ".if %2 > 128\n\ts_load_dword %0, %1, 128\n\t.endif\n\t"
+                 ".if %2 > 192\n\ts_load_dword %0, %1, 192\n\t.endif\n\t"
+                 ".if %2 > 256\n\ts_load_dword %0, %1, 256\n\t.endif\n\t"
+                 ".if %2 > 320\n\ts_load_dword %0, %1, 320\n\t.endif\n\t"
+                 ".if %2 > 384\n\ts_load_dword %0, %1, 384\n\t.endif\n\t"
+                 ".if %2 > 448\n\ts_load_dword %0, %1, 448\n\t.endif\n\t"
+                 ".if %2 > 512\n\ts_load_dword %0, %1, 512\n\t.endif\n\t"
+                 ".if %2 > 576\n\ts_load_dword %0, %1, 576\n\t.endif\n\t"
+                 ".if %2 > 640\n\ts_load_dword %0, %1, 640\n\t.endif\n\t"
+                 ".if %2 > 704\n\ts_load_dword %0, %1, 704\n\t.endif\n\t"
+                 ".if %2 > 768\n\ts_load_dword %0, %1, 768\n\t.endif\n\t"
+                 ".if %2 > 832\n\ts_load_dword %0, %1, 832\n\t.endif\n\t"
+                 ".if %2 > 896\n\ts_load_dword %0, %1, 896\n\t.endif\n\t"
+                 ".if %2 > 960\n\ts_load_dword %0, %1, 960\n\t.endif\n\t"
+                 ".if %2 > 1024\n\ts_load_dword %0, %1, 1024\n\t.endif\n\t"
+                 ".if %2 > 1088\n\ts_load_dword %0, %1, 1088\n\t.endif\n\t"
+                 ".if %2 > 1152\n\ts_load_dword %0, %1, 1152\n\t.endif\n\t"
+                 ".if %2 > 1216\n\ts_load_dword %0, %1, 1216\n\t.endif\n\t"
+                 ".if %2 > 1280\n\ts_load_dword %0, %1, 1280\n\t.endif\n\t"
+                 ".if %2 > 1344\n\ts_load_dword %0, %1, 1344\n\t.endif\n\t"
+                 ".if %2 > 1408\n\ts_load_dword %0, %1, 1408\n\t.endif\n\t"
+                 ".if %2 > 1472\n\ts_load_dword %0, %1, 1472\n\t.endif\n\t"
+                 ".if %2 > 1536\n\ts_load_dword %0, %1, 1536\n\t.endif\n\t"
+                 ".if %2 > 1600\n\ts_load_dword %0, %1, 1600\n\t.endif\n\t"
+                 ".if %2 > 1664\n\ts_load_dword %0, %1, 1664\n\t.endif\n\t"
+                 ".if %2 > 1728\n\ts_load_dword %0, %1, 1728\n\t.endif\n\t"
+                 ".if %2 > 1792\n\ts_load_dword %0, %1, 1792\n\t.endif\n\t"
+                 ".if %2 > 1856\n\ts_load_dword %0, %1, 1856\n\t.endif\n\t"
+                 ".if %2 > 1920\n\ts_load_dword %0, %1, 1920\n\t.endif\n\t"
+                 ".if %2 > 1984\n\ts_load_dword %0, %1, 1984\n\t.endif\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(sink)
+                 : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(BYTES)
+                 : "memory");
+#endif
+}
+
 // Write-through (sc1) store: the 10 MB of per-step operands leave the XCD's L2 as they are
 // produced instead of in the end-of-kernel write-back, which is what the next kernel waits on.
 __device__ __forceinline__ void store_wt(double* p, double v) {

@@ -31,9 +31,20 @@ struct MMModel {
 struct MMWork {
     double* in_m;        // [D]      input mean  (joint state-action mean)
     double* in_s;        // [D][D]   input covariance
-    double* At;          // [PL][KP][npad]  row-side operand   (2 Q z_i | u_i | 1 | 0..)
-    double* Bt;          // [PL][KP][npad]  column-side operand (w_j   | 1 | v_j | 0..)
-    double* vcol;        // [PL][npad]  v_j on its own when vsep (D + 2 = 1 mod 4: K = D + 1 contraction, v_j added on the VALU)
+    // Operands of the exponent GEMM e_ij = sum_k A[k][i] B[k][j], K = KP rows: A = (2 Q z_i | u_i | 1 | 0..), B = (w_j | 1 | v_j | 0..).
+    // Only what depends on the step AND the pair is written per pair and step: p_i = 2 Q z_i, u_i (At) and v_j (vcol).
+    // w_j = (x_j - m) / l_b^2 depends on the pair's COLUMN output b alone: one block per output (Wt), written by the first
+    // local pair with that column -- E blocks instead of P (round 5: the head's write-through traffic 10.8 -> 6.2 MB per step
+    // at C2).  The ones (the valid mask: 1 for points < n) and the zero rows of the padded contraction are constants of the
+    // model: they sit in the rows of the blocks where the contraction expects them and are written once, when the workspace
+    // is built.  A reader addresses both operands as before (block base + k npad); only the lanes that hold row D + 1 of B
+    // are pointed at the pair's v_j instead (one select per pair_wave call, PairOps in mm_device.h).
+    double* At;          // [PL][KP][npad]  rows 0..D: (2 Q z_i | u_i) of the pair, written every step; row D + 1: ones (not vsep); beyond: zeros
+    double* Wt;          // [blocks][KP][npad]  rows 0..D-1: w_j of the column block, written every step by the block's writer; row D: ones;
+                         //   beyond: zeros (row D + 1 is never read: v_j lives in vcol).  Block = the column output b (one-launch small
+                         //   step with its operands in memory: the local pair)
+    double* vcol;        // [PL][npad]  v_j of every pair, in the SAME allocation as Wt (behind its blocks: one buffer resource reaches
+                         //   both): row D + 1 of B or -- vsep (D + 2 = 1 mod 4: K = D + 1) -- added on the VALU after the contraction
     int vsep;
     double* pair_isdet;  // [PL]     1/sqrt(det R_ab)
     double* mean_part;   // [EL][NCHM][1+D]  per row chunk: c_a g and c_a T_a h (contributions to M_a, V_a)

@@ -27,6 +27,7 @@ template <int KC, bool VSEP>
 __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_tiled(MMModel md, MMWork wk, int NJB) {
     __shared__ double red[4];
     __shared__ double tab[FEXP_TN];
+    kernarg_warm<(int)(sizeof(MMModel) + sizeof(MMWork)) + 8 + 64>();
     for (int e = threadIdx.x; e < FEXP_TN; e += blockDim.x) tab[e] = wk.exp_tab[e];
     __syncthreads();
     const int npad = md.npad;
@@ -35,9 +36,7 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_tiled(MMModel md, MM
     int a, b;
     local_pair_ab(wk, md.E, pl, a, b);
     const bool diag = (a == b) && (md.iK != nullptr);
-    const int KP = wk.KP;
-    const double* At = wk.At + (long)pl * KP * npad;
-    const double* Bt = wk.Bt + (long)pl * KP * npad;
+    const PairOps po = pair_ops(wk, md.D, npad, pl, b);
     const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
     const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
     const int i0 = ti * 16 * PAIR_RT;
@@ -45,9 +44,9 @@ __global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_tiled(MMModel md, MM
     const int jbeg = jb * JB + w * JW;
     double t1;
     if (diag)
-        t1 = pair_wave<KC, true, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab, npad, i0, jbeg, jbeg + JW, lane);
+        t1 = pair_wave<KC, true, VSEP>(po, nullptr, nullptr, nullptr, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab, npad, i0, jbeg, jbeg + JW, lane);
     else
-        t1 = pair_wave<KC, false, VSEP>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jbeg + JW, lane);
+        t1 = pair_wave<KC, false, VSEP>(po, nullptr, nullptr, nullptr, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jbeg + JW, lane);
     for (int off = 32; off > 0; off >>= 1) t1 += __shfl_down(t1, off);
     if (lane == 0) red[w] = t1;
     __syncthreads();
@@ -76,8 +75,9 @@ void mm_sk_pair_waves(int k, int waves, int nd, int tdiag, int toff, int total, 
 }
 
 template <int KC, bool VSEP>
-__global__ __launch_bounds__(256, PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWork wk) {
+__global__ __launch_bounds__(256, (KC <= 4 && PAIR_MINW < 3) ? 3 : PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWork wk) {
     __shared__ double tab[FEXP_TN];
+    kernarg_warm<(int)(sizeof(MMModel) + sizeof(MMWork)) + 64>();
     for (int e = threadIdx.x; e < FEXP_TN; e += blockDim.x) tab[e] = wk.exp_tab[e];
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -132,17 +132,16 @@ __global__ __launch_bounds__(256) void k_mm_pair_valu(MMModel md, MMWork wk) {
     local_pair_ab(wk, md.E, pl, a, b);
     const bool diag = (a == b) && (md.iK != nullptr);
     const int KP = wk.KP;
-    const double* At = wk.At + (long)pl * KP * npad;
-    const double* Bt = wk.Bt + (long)pl * KP * npad;
+    const PairOps po = pair_ops(wk, md.D, npad, pl, b);
     const int i = ti * 256 + t;
     const bool rowok = i < npad;
     double av[KPT];
 #pragma unroll
-    for (int k = 0; k < KPT; ++k) av[k] = (k < KP && rowok) ? At[(long)k * npad + i] : 0.0;
+    for (int k = 0; k < KPT; ++k) av[k] = (k < KP && rowok) ? po.At[(long)k * npad + i] : 0.0;
     const int j0 = tj * 64;
     for (int e = t; e < KPT * 64; e += 256) {
         const int k = e >> 6, j = e & 63;
-        Bs[k][j] = (k < KP) ? Bt[(long)k * npad + j0 + j] : 0.0;
+        Bs[k][j] = (k < KP) ? (wk.vsep ? colop_row<true>(po, npad, k) : colop_row<false>(po, npad, k))[j0 + j] : 0.0;   // (row D + 1: the pair's v_j)
     }
     if (t < 64) {
         bbs[t] = md.beta[mm_beta_row(md, b) * npad + j0 + t];

@@ -44,10 +44,14 @@ namespace pilco {
 // The pair kernels do not need it (the compiler keeps 7 + p slots there); inside the fused head, under its register
 // budget, the same source has been seen scheduled with reads of destination pairs 2 and 3 one slot early
 // (tools/mfma_hazard_check.py, tests/test_build_isa.py), so that host asks for the fence.
+// Operands in global memory (po: the layout of MMWork::At / Wt): every row of the column operand is reached through ONE buffer
+// resource (base po.Wt) and a per-lane row offset computed once per call -- the w rows of the pair's column block, the ones,
+// v_j, the zeros --, so the hot loop is what it was when every pair had its own copy of all KP rows.
 // LDSOP (the one-launch step of small models, prep_device.h): the operands never went to memory -- At / Bt / vcol point into
-// the workgroup's LDS, At as [k][lda] over the workgroup's own rows (row i0 is its row i0l), Bt as [k][ldb] over all columns.
+// the workgroup's LDS, At as [k][lda] over the workgroup's own rows (row i0 is its row i0l), Bt as [k][ldb] over all columns
+// (all KP rows materialised there); po is not used.
 template <int KC, bool DIAG, bool VSEP, bool FENCE = false, bool LDSOP = false>
-__device__ __forceinline__ double pair_wave(const double* __restrict__ At, const double* __restrict__ Bt,
+__device__ __forceinline__ double pair_wave(const PairOps& po, const double* __restrict__ At, const double* __restrict__ Bt,
                                             const double* __restrict__ vcol,
                                             const double* __restrict__ beta_a, const double* __restrict__ beta_b,
                                             const double* __restrict__ iKa, const double* __restrict__ tab, int npad, int i0,
@@ -61,7 +65,7 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             if (LDSOP) af[rt][c] = At[(4 * c + lr) * lda + i0l + 16 * rt + lc];
-            else af[rt][c] = At[(long)(4 * c + lr) * npad + i0 + 16 * rt + lc];
+            else af[rt][c] = po.At[(long)(4 * c + lr) * npad + i0 + 16 * rt + lc];
         }
     double acc[NE];
     double bi[NE];
@@ -75,11 +79,14 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
     }
     unsigned b_off[KC];
 #pragma unroll
-    for (int c = 0; c < KC; ++c) b_off[c] = ((unsigned)(4 * c + lr) * (unsigned)npad + (unsigned)lc) * 8u;
+    for (int c = 0; c < KC; ++c) {
+        b_off[c] = ((unsigned)(4 * c + lr) * (unsigned)npad + (unsigned)lc) * 8u;   // relative to the pair's column block (po.w0 rides in the scalar offset)
+        if (!VSEP && !LDSOP && 4 * c + lr == po.D + 1) b_off[c] = po.v0 - po.w0 + (unsigned)lc * 8u;   // the lanes of row D + 1: the pair's own v_j
+    }
     const unsigned bb_off = (unsigned)lc * 8u;
-    const __amdgpu_buffer_rsrc_t rB = buf_rsrc(LDSOP ? beta_b : Bt), rbeta = buf_rsrc(beta_b);   // (LDSOP: rB / rV are never used)
-    const __amdgpu_buffer_rsrc_t rV = buf_rsrc((VSEP && !LDSOP) ? vcol : beta_b);
-    const __amdgpu_buffer_rsrc_t rIK = buf_rsrc(DIAG ? iKa + (long)i0 * npad : Bt);
+    const unsigned sB = LDSOP ? 0u : po.w0, sV = LDSOP ? 0u : po.v0;   // scalar byte offsets of the column block / of v_j (VSEP) in the resource
+    const __amdgpu_buffer_rsrc_t rB = buf_rsrc(LDSOP ? beta_b : po.Wt), rbeta = buf_rsrc(beta_b);   // (LDSOP: rB is never used)
+    const __amdgpu_buffer_rsrc_t rIK = buf_rsrc(DIAG ? iKa + (long)i0 * npad : beta_b);
     if (DIAG && jbeg < i0) jbeg = i0;  // columns left of the diagonal block are mirrored by the transposed tile
     double total = 0.0;
     // software pipeline: the operands of the column step two ahead are requested while this one is
@@ -93,12 +100,12 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
                 if (LDSOP) ring[p][c] = Bt[(4 * c + lr) * ldb + jbeg + 16 * p + lc];
-                else ring[p][c] = buf_ld(rB, b_off[c], (unsigned)(jbeg + 16 * p) * 8u);
+                else ring[p][c] = buf_ld(rB, b_off[c], sB + (unsigned)(jbeg + 16 * p) * 8u);
             }
             ring[p][KC] = buf_ld(rbeta, bb_off, (unsigned)(jbeg + 16 * p) * 8u);
             if (VSEP) {
                 if (LDSOP) ring[p][KC + 1] = vcol[jbeg + 16 * p + lc];
-                else ring[p][KC + 1] = buf_ld(rV, bb_off, (unsigned)(jbeg + 16 * p) * 8u);
+                else ring[p][KC + 1] = buf_ld(rB, bb_off, sV + (unsigned)(jbeg + 16 * p) * 8u);
             }
         }
     }
@@ -131,12 +138,12 @@ __device__ __forceinline__ double pair_wave(const double* __restrict__ At, const
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
                 if (LDSOP) rg[c] = Bt[(4 * c + lr) * ldb + j0 + 32 + lc];
-                else rg[c] = buf_ld(rB, b_off[c], (unsigned)(j0 + 32) * 8u);
+                else rg[c] = buf_ld(rB, b_off[c], sB + (unsigned)(j0 + 32) * 8u);
             }
             rg[KC] = buf_ld(rbeta, bb_off, (unsigned)(j0 + 32) * 8u);
             if (VSEP) {
                 if (LDSOP) rg[KC + 1] = vcol[j0 + 32 + lc];
-                else rg[KC + 1] = buf_ld(rV, bb_off, (unsigned)(j0 + 32) * 8u);
+                else rg[KC + 1] = buf_ld(rB, bb_off, sV + (unsigned)(j0 + 32) * 8u);
             }
         }
 #pragma unroll
@@ -253,7 +260,7 @@ __device__ __forceinline__ int sk_boundary(const MMWork& wk, int w) {
 template <int KC, bool VSEP, bool FENCE = false>
 __device__ __forceinline__ void sk_wave_range(const MMModel& md, const MMWork& wk, const double* __restrict__ tab, int w, int lane,
                                               double& out0, double& out1, int& p0, int& p1) {
-    const int npad = md.npad, NS = npad / 16, KP = wk.KP;
+    const int npad = md.npad, NS = npad / 16;
     const int nd_steps = wk.sk_nd * wk.sk_tdiag;
     int step = sk_boundary(wk, w);
     const int end = sk_boundary(wk, w + 1);
@@ -297,15 +304,14 @@ __device__ __forceinline__ void sk_wave_range(const MMModel& md, const MMWork& w
         }
         int a, b;
         local_pair_ab(wk, md.E, pl, a, b);
-        const double* At = wk.At + (long)pl * KP * npad;
-        const double* Bt = wk.Bt + (long)pl * KP * npad;
+        const PairOps po = pair_ops(wk, md.D, npad, pl, b);
         const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
         const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
         const int i0 = ti * 16 * PAIR_RT, jbeg = sidx * 16, jend = jbeg + seg * 16;
         if (dg)
-            cur += pair_wave<KC, true, VSEP, FENCE>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab, npad, i0, jbeg, jend, lane);
+            cur += pair_wave<KC, true, VSEP, FENCE>(po, nullptr, nullptr, nullptr, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab, npad, i0, jbeg, jend, lane);
         else
-            cur += pair_wave<KC, false, VSEP, FENCE>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jend, lane);
+            cur += pair_wave<KC, false, VSEP, FENCE>(po, nullptr, nullptr, nullptr, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jend, lane);
         step += seg;
     }
     if (cur_pl >= 0) {

@@ -26,7 +26,7 @@ __host__ __device__ constexpr size_t prep_region_doubles(int DT) {   // the oper
 // of the prep launch: T = Lambda^-1 B^-1 Lambda^-1 = (s + Lambda^2)^-1 by a register Gauss-Jordan in wave 0 while the
 // other threads already have their point in flight; lb_i = exp(-zeta_i^T T zeta_i / 2) beta_i; partial c g and c T h
 // into mean_part[al][chm][1 + D].
-template <int DT, bool FUSED, int NTHR>
+template <int DT, bool FUSED, int NTHR, bool PRE = false>
 __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork& wk, int al, int chm, double* sm,
                                                 const double* jm, const double* js,   // joint Gaussian in LDS (FUSED head only)
                                                 const double la_t, const double var_a) {  // l_a[t] (t < D) and var_a, loaded by the caller
@@ -45,13 +45,15 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
     double* zst = colbuf + 2 * DT;         // [512][DT + 1] centred points of the chunk's first 512 rows
     double* bst = zst + 512 * (DT + 1);    // [512] their beta_a
     constexpr int LDZ = DT | 1;   // odd row stride: conflict-free LDS rows
-    if (t < DT) {
-        s_m[t] = (t < D) ? (FUSED ? jm[t] : wk.in_m[t]) : 0.0;
-        s_ia[t] = (t < D) ? 1.0 / la_t : 0.0;
+    if constexpr (!PRE) {   // (PRE: k_mm_prep wrote the constants before the link, the link stored the joint Gaussian here)
+        if (t < DT) {
+            s_m[t] = (t < D) ? (FUSED ? jm[t] : wk.in_m[t]) : 0.0;
+            s_ia[t] = (t < D) ? 1.0 / la_t : 0.0;
+        }
+        for (int e = t; e < D * D; e += 512) s_s[e] = FUSED ? js[e] : wk.in_s[e];
+        for (int e = t; e < DT * DT; e += 512) s_T[e] = 0.0;
+        __syncthreads();
     }
-    for (int e = t; e < D * D; e += 512) s_s[e] = FUSED ? js[e] : wk.in_s[e];
-    for (int e = t; e < DT * DT; e += 512) s_T[e] = 0.0;
-    __syncthreads();
     const bool dbgm = (t == 0 && al == 0 && chm == 0);
     DBG_STAMP(wk, 40, dbgm);
     const int rpc = npad / wk.NCHM;
@@ -362,7 +364,7 @@ __device__ __forceinline__ void small_sweep(const MMModel& md, const MMWork& wk,
 // mean part of one (local output, row chunk), or the reward -- selected by the item coordinates (bx, by) of a gx x gy item
 // grid (k_mm_prep: its own block index; the persistent rollout kernel: a fixed item per workgroup).  NTHR: threads of
 // the host workgroup; the work is laid out for 512, wider workgroups keep their extra waves idle between the barriers.
-template <int DT, bool FUSED, int NTHR, bool FPAIR = false>
+template <int DT, bool FUSED, int NTHR, bool FPAIR = false, bool PRE = false>
 __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, const PrepReward& pr, const GlueArgs& g, const GlueLds& L,
                                           double* sm_all, int glue_doubles, int bx, int by, int gx, int gy, double pre_la, double pre_lb,
                                           double pre_var) {
@@ -379,7 +381,7 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
         const int slot = 64 + 2 * (by * gx + bx);
         if (wk.dbg && threadIdx.x == 0 && slot < 958) wk.dbg[slot] = wall_clock64();
         if (idx < nmean) {
-            prep_mean_block<DT, FUSED, NTHR>(md, wk, idx / wk.NCHM, idx % wk.NCHM, sm, jm, js, pre_la, pre_var);
+            prep_mean_block<DT, FUSED, NTHR, PRE>(md, wk, idx / wk.NCHM, idx % wk.NCHM, sm, jm, js, pre_la, pre_var);
             if (wk.dbg && threadIdx.x == 0 && slot < 958) wk.dbg[slot + 1] = wall_clock64();
             return;
         }
@@ -420,20 +422,22 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
     const bool dbg0 = (t == 0 && pl == 0 && ch == 0);
     DBG_STAMP(wk, 0, dbg0);
     if (wk.dbg && t == 0) wk.dbg[64 + 2 * (by * gx + bx)] = wall_clock64();
-    if (t < DT) {
-        double la = 1.0, lb = 1.0, mm = 0.0;
-        if (t < D) {
-            mm = FUSED ? jm[t] : wk.in_m[t];
-            la = pre_la;
-            lb = pre_lb;
+    if constexpr (!PRE) {   // (PRE: k_mm_prep wrote the constants before the link, the link stored the joint Gaussian here)
+        if (t < DT) {
+            double la = 1.0, lb = 1.0, mm = 0.0;
+            if (t < D) {
+                mm = FUSED ? jm[t] : wk.in_m[t];
+                la = pre_la;
+                lb = pre_lb;
+            }
+            s_m[t] = mm;
+            s_ia2[t] = (t < D) ? 1.0 / (la * la) : 0.0;
+            s_ib2[t] = (t < D) ? 1.0 / (lb * lb) : 0.0;
         }
-        s_m[t] = mm;
-        s_ia2[t] = (t < D) ? 1.0 / (la * la) : 0.0;
-        s_ib2[t] = (t < D) ? 1.0 / (lb * lb) : 0.0;
+        for (int e = t; e < D * D; e += 512) s_s[e] = FUSED ? js[e] : wk.in_s[e];
+        for (int e = t; e < DT * DT; e += 512) s_Q[e] = 0.0;   // padded rows / columns of Q stay zero
+        __syncthreads();
     }
-    for (int e = t; e < D * D; e += 512) s_s[e] = FUSED ? js[e] : wk.in_s[e];
-    for (int e = t; e < DT * DT; e += 512) s_Q[e] = 0.0;   // padded rows / columns of Q stay zero
-    __syncthreads();
     DBG_STAMP(wk, 1, dbg0);
     const int rpc = npad / wk.NCH;
     const int i_begin = ch * rpc, i_end = i_begin + rpc;
@@ -502,8 +506,15 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
     __syncthreads();
     DBG_STAMP(wk, 2, dbg0);
     const int KP = wk.KP;
+    // what this workgroup writes to memory (layout: MMWork::At / Wt): the pair's (2 Q z_i | u_i) rows and v_j always; the
+    // w rows of the pair's column block only when this pair is the block's writer this step (every pair with the same column
+    // output computes the same w_j: P / E workgroups used to store identical values, half of the head's write-through traffic)
+    int pa_, pb_;
+    local_pair_ab(wk, md.E, pl, pa_, pb_);
     double* At = wk.At + (long)pl * KP * npad;
-    double* Bt = wk.Bt + (long)pl * KP * npad;
+    double* Wb = wk.Wt + (long)pair_col_block(wk, pl, pb_) * KP * npad;
+    double* vrow = wk.vcol + (long)pl * npad;
+    const bool wt_writer = pair_writes_wt(wk, md.E, pa_, pb_);
     auto row = [&](const int i, const bool valid, const double (&zeta)[DT]) {
         // y = Q x by columns of the symmetric Q: DT independent accumulators, one wide LDS row
         // read per column step (no LDS latency on the FMA chains).
@@ -558,17 +569,14 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
 #pragma unroll
             for (int r = 0; r < DT; ++r)
                 if (r < D) store_wt(&At[(long)r * npad + i], 2.0 * y[r]);   // 2 Q z_i (0 on padded rows)
-            store_wt(&At[(long)D * npad + i], uv);                           // u_i
-            if (!wk.vsep) store_wt(&At[(long)(D + 1) * npad + i], one);
-            for (int k = D + 2; k < KP; ++k) store_wt(&At[(long)k * npad + i], 0.0);
+            store_wt(&At[(long)D * npad + i], uv);                           // u_i   (the ones and the zero rows of A are model constants)
         } else {
+            if (wt_writer) {   // (workgroup-uniform)
 #pragma unroll
-            for (int r = 0; r < DT; ++r)
-                if (r < D) store_wt(&Bt[(long)r * npad + i], x[r]);         // w_j
-            store_wt(&Bt[(long)D * npad + i], one);
-            if (wk.vsep) store_wt(&wk.vcol[(long)pl * npad + i], uv);        // v_j, added after the K = D + 1 contraction
-            else store_wt(&Bt[(long)(D + 1) * npad + i], uv);                // v_j, riding in the contraction
-            for (int k = D + 2; k < KP; ++k) store_wt(&Bt[(long)k * npad + i], 0.0);
+                for (int r = 0; r < DT; ++r)
+                    if (r < D) store_wt(&Wb[(long)r * npad + i], x[r]);     // w_j
+            }
+            store_wt(&vrow[i], uv);   // v_j: row D + 1 of the contraction, or (vsep) added after the K = D + 1 contraction
         }
     };
     if (fplds) {   // (workgroup-uniform) every thread takes its point from the stage, THEN the operands overwrite it
@@ -624,13 +632,14 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
             const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
             const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
             const double* iKa = diag ? md.iK + mm_ik_blk(md, a) * npad * npad : nullptr;
+            const PairOps po = pair_ops(wk, D, npad, pl, pair_col_block(wk, pl, b));
             if (fplds && mm_kp(DT) <= 16) {
-                if (diag) val = pair_wave<KCP, true, VSP, true, true>(Al, Bl, vl, beta_a, beta_b, iKa, tab, npad, i0, jb, je, lane, 64, 256, i0 - i_begin);
-                else val = pair_wave<KCP, false, VSP, true, true>(Al, Bl, vl, beta_a, beta_b, nullptr, tab, npad, i0, jb, je, lane, 64, 256, i0 - i_begin);
+                if (diag) val = pair_wave<KCP, true, VSP, true, true>(po, Al, Bl, vl, beta_a, beta_b, iKa, tab, npad, i0, jb, je, lane, 64, 256, i0 - i_begin);
+                else val = pair_wave<KCP, false, VSP, true, true>(po, Al, Bl, vl, beta_a, beta_b, nullptr, tab, npad, i0, jb, je, lane, 64, 256, i0 - i_begin);
             } else if (diag) {
-                val = pair_wave<KCP, true, VSP, true>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, iKa, tab, npad, i0, jb, je, lane);
+                val = pair_wave<KCP, true, VSP, true>(po, nullptr, nullptr, nullptr, beta_a, beta_b, iKa, tab, npad, i0, jb, je, lane);
             } else {
-                val = pair_wave<KCP, false, VSP, true>(At, Bt, wk.vcol + (long)pl * npad, beta_a, beta_b, nullptr, tab, npad, i0, jb, je, lane);
+                val = pair_wave<KCP, false, VSP, true>(po, nullptr, nullptr, nullptr, beta_a, beta_b, nullptr, tab, npad, i0, jb, je, lane);
             }
             for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off);
         }

@@ -9,6 +9,9 @@ namespace pilco {
 #ifndef PREP_SPARE_FIRST
 #define PREP_SPARE_FIRST 1
 #endif
+#ifndef PREP_PRE
+#define PREP_PRE 1   // the operand work's first phase is prepared BEFORE the link (0: A/B builds)
+#endif
 size_t prep_lds_bytes(int DT);
 
 // ------------------------------------------------------------------ prep
@@ -23,6 +26,7 @@ size_t prep_lds_bytes(int DT);
 template <int DT, bool FUSED, int PK = 0, bool SR = true, bool OCC2 = false>
 __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void k_mm_prep(MMModel md, MMWork wk, PrepReward pr, GlueArgs g, int glue_doubles) {
     extern __shared__ __attribute__((aligned(16))) double sm_all[];
+    kernarg_warm<(int)(sizeof(MMModel) + sizeof(MMWork) + sizeof(PrepReward) + sizeof(GlueArgs)) + 8 + 64>();   // (+ the hidden grid / group sizes behind them)
     // FUSED: the serial link of the previous step runs first, redundantly in every workgroup (see glue_device.h); it
     // leaves the joint Gaussian of THIS step (L.jm, L.js) and the current state (L.mx, L.sx) in the first glue_doubles
     // doubles of LDS.  (All LDS pointers below are derived from sm_all unconditionally: no shared/global pointer merges.)
@@ -53,8 +57,35 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void k_mm_prep(MMModel md, MMWor
     }
     // (the link's results are stored by the first pair workgroup; handing that to an idle slot of the spare columns -- a
     // workgroup with nothing else to do -- measured 1-2 % SLOWER on every configuration: docs/dead_ends.md)
+    // The first phase of the operand work -- reciprocal lengthscales, zeroed Q / T, the joint Gaussian in the region's own
+    // layout -- does not wait for the link: its constants are written here, BEFORE the link, and the joint Gaussian is stored
+    // there by the link's last phase (GlueLds::xm / xs), under the link's own closing barrier.  One barrier interval of the
+    // step's serial path less.  (PK = 1, an RbfController's own launches: the policy head reads the state instead; it keeps the copy.)
+    constexpr bool PRE = FUSED && PK != 1 && (PREP_PRE != 0);
+    if constexpr (PRE) {
+        double* sm = sm_all + glue_doubles;
+        const int t = threadIdx.x, D = md.D;
+        if (!spare_wg) {   // prep_work's layout: s_m [DT] | s_ia2 [DT] | s_ib2 [DT] | s_s [DT*DT] | s_Q [DT*DT]
+            if (t < DT) {
+                if (t >= D) sm[t] = 0.0;
+                sm[DT + t] = (t < D) ? 1.0 / (pre_la * pre_la) : 0.0;
+                sm[2 * DT + t] = (t < D) ? 1.0 / (pre_lb * pre_lb) : 0.0;
+            }
+            for (int e = t; e < DT * DT; e += 512) sm[3 * DT + DT * DT + e] = 0.0;
+            L.xm = sm;
+            L.xs = sm + 3 * DT;
+        } else if (mean_wg) {   // prep_mean_block's layout: s_m [DT] | s_ia [DT] | s_s [DT*DT] | s_T [DT*DT]
+            if (t < DT) {
+                if (t >= D) sm[t] = 0.0;
+                sm[DT + t] = (t < D) ? 1.0 / pre_la : 0.0;
+            }
+            for (int e = t; e < DT * DT; e += 512) sm[2 * DT + DT * DT + e] = 0.0;
+            L.xm = sm;
+            L.xs = sm + 2 * DT;
+        }
+    }
     if (FUSED) glue_body<PK, SR>(g, L, bxi == 0 && blockIdx.y == 0);
-    prep_work<DT, FUSED, 512, FUSED && SR && PK != 1>(md, wk, pr, g, L, sm_all, glue_doubles, bxi, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, pre_la,
+    prep_work<DT, FUSED, 512, FUSED && SR && PK != 1, PRE>(md, wk, pr, g, L, sm_all, glue_doubles, bxi, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, pre_la,
                               pre_lb, pre_var);
 }
 
