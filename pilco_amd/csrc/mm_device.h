@@ -57,6 +57,18 @@ template <bool VSEP>
 __device__ __forceinline__ const double* colop_row(const PairOps& po, int npad, int k) {
     return (const double*)((const char*)po.Wt + ((!VSEP && k == po.D + 1) ? po.v0 : po.w0 + (unsigned)k * (unsigned)npad * 8u));
 }
+// Who writes the w rows.  The E D rows of all column blocks (row b D + d = coordinate d of output b's block: w = zeta_d /
+// l_bd^2, ONE multiplication from the centred point every operand workgroup has staged) are dealt over the local pairs,
+// wt_rows_per_pair rows each: every pair workgroup stores the same number of rows.  (First version: the block of output b
+// by the diagonal pair (b, b) -- 40 of 220 workgroups stored twice as much as the others and ended 1.7 us behind them.)
+// Not dealt -- the first local pair with column b writes the whole block, pair_writes_wt -- when a pair would get more
+// rows than the workgroup has slots for their constants (few pairs on many ranks), when a chunk is longer than the stage, and in the one-launch small step with
+// its operands in memory, where every pair owns a block.
+__device__ __forceinline__ int wt_rows_per_pair(const MMWork& wk, int E, int D) { return (E * D + (wk.PL > 1 ? wk.PL : 1) - 1) / (wk.PL > 1 ? wk.PL : 1); }
+template <int DT>
+__device__ __forceinline__ bool wt_rows_dealt(const MMWork& wk, int E, int D, int npad) {
+    return !wk.fuse_pair && wt_rows_per_pair(wk, E, D) <= DT && npad / wk.NCH <= 256;   // (... and every row of the chunk is in the workgroup's stage)
+}
 // Does local pair pl = (a, b) write the column block of output b this step?  The FIRST local pair with that column does:
 // (b, b) when this rank owns it (diagonal pairs come first in the dealing order), else the off-diagonal (a', b) with the
 // smallest a' it owns.  (One-launch small step with operands in memory: every pair writes its own block.)

@@ -18,6 +18,16 @@ __host__ __device__ constexpr size_t prep_region_doubles(int DT) {   // the oper
     return pair_blk > mean_blk ? pair_blk : mean_blk;
 }
 
+// 1 / l^2 of the w rows dealt to local pair pl (mm_device.h: wt_rows_per_pair), into the pair workgroup's `colbuf` [DT]
+template <int DT>
+__device__ __forceinline__ void prep_wt_constants(const MMModel& md, const MMWork& wk, int pl, double* sm) {
+    const int R = wt_rows_per_pair(wk, md.E, md.D), t = threadIdx.x;
+    if (wt_rows_dealt<DT>(wk, md.E, md.D, md.npad) && t < R && pl * R + t < md.E * md.D) {
+        const double l = md.ls[pl * R + t];
+        sm[3 * DT + 2 * DT * DT + 4 + t] = 1.0 / (l * l);
+    }
+}
+
 // 512 threads per workgroup = the whole register file of one CU.  The 256 rows of the chunk are
 // handled twice in parallel: threads 0..255 ("group 0") build the row-side operand, threads
 // 256..511 ("group 1") the column-side operand; on a diagonal pair both operands are the same
@@ -83,13 +93,29 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
         if (lane == 0) s_sc[1] = var_a / sqrt(detB);
     } else if (act) {
         // the other seven waves stage the centred points of the chunk's first 512 rows meanwhile
+        // (all of a thread's requests first, then the stores: element after element the loop was twelve L2 round trips in a
+        // row -- 3.3-3.7 us against the 2.6 us of the Gauss-Jordan it is meant to hide behind)
         const int idx = (w - 1) * 64 + lane;   // 0..447
-        for (int e = idx; e < 512 * D; e += 448) {
-            const int d = e >> 9, r = e & 511;
-            const int i = i_begin + r;
-            zst[r * LDZ + d] = (i < md.n && i < i_end) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
+        constexpr int NB = (512 * DT + 447) / 448;
+        double sv[NB], bv[2];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int e = idx + 448 * k, d = e >> 9, i = i_begin + (e & 511);
+            sv[k] = (e < 512 * D && i < md.n && i < i_end) ? md.Pt[(long)d * npad + i] : 0.0;
         }
-        for (int r = idx; r < 512; r += 448) bst[r] = (i_begin + r < i_end) ? md.beta[mm_beta_row(md, a) * npad + i_begin + r] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = idx + 448 * k;
+            bv[k] = (r < 512 && i_begin + r < i_end) ? md.beta[mm_beta_row(md, a) * npad + i_begin + r] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int e = idx + 448 * k, d = e >> 9, r = e & 511, i = i_begin + r;
+            if (e < 512 * D) zst[r * LDZ + d] = (i < md.n && i < i_end) ? sv[k] - s_m[d] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (idx + 448 * k < 512) bst[idx + 448 * k] = bv[k];
     }
     __syncthreads();
     DBG_STAMP(wk, 41, dbgm);
@@ -114,46 +140,45 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
             double zeta[DT];
 #pragma unroll
             for (int d = 0; d < DT; ++d) zeta[d] = (d < D) ? zst[t * LDZ + d] : 0.0;
-            double tz[DT];
-#pragma unroll
-            for (int r = 0; r < DT; ++r) tz[r] = 0.0;
+            // q / 2 = zeta^T T zeta / 2 from the upper triangle of the symmetric T: sum_c zeta_c (T_cc zeta_c / 2 + sum_{r > c} T_cr zeta_r)
+            // -- half the LDS reads (every thread reads the whole matrix by broadcast: the phase is bound by LDS return bandwidth)
+            double hq = 0.0;
 #pragma unroll
             for (int c = 0; c < DT; ++c) {
-                double trow[DT];
+                double inner = 0.5 * s_T[c * DT + c] * zeta[c];
 #pragma unroll
-                for (int r = 0; r < DT; ++r) trow[r] = s_T[c * DT + r];
-#pragma unroll
-                for (int r = 0; r < DT; ++r) tz[r] = fma(trow[r], zeta[c], tz[r]);
-                if ((c & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                for (int r = c + 1; r < DT; ++r) inner = fma(s_T[c * DT + r], zeta[r], inner);
+                hq = fma(zeta[c], inner, hq);
             }
-            double q = 0.0;
-#pragma unroll
-            for (int r = 0; r < DT; ++r) q = fma(zeta[r], tz[r], q);
-            const double lb = exp(-0.5 * q) * bst[t];
+            const double lb = exp(-hq) * bst[t];
             g += lb;
 #pragma unroll
             for (int d = 0; d < DT; ++d) h[d] = fma(zeta[d], lb, h[d]);
         }
     }
     DBG_STAMP(wk, 42, dbgm);
-    g = wave_sum_lane63(g);
-    if (act && lane == 63) red[w * (DT + 1)] = g;
+    // Block sums of g and h in a fixed order: every thread parks its 1 + D partial sums in the (now dead) stage, quantity-major
+    // [1 + D][512]; wave w then owns quantities w, w + 8, ..: each of its lanes adds the eight waves' values of its lane position
+    // (wave order), one DPP tree over the lanes finishes the sum.  (The first version ran 1 + D DPP trees in EVERY wave -- 200
+    // VALU operations per wave on a phase that is pure latency -- and added the eight wave sums in a stage of its own.)
+    double* hs = red + 8 * (DT + 1);  // [DT + 1]
+    __syncthreads();                  // every thread has taken its point from the stage
+    if (act) {
+        zst[t] = g;
 #pragma unroll
-    for (int d = 0; d < DT; ++d) {
-        const double v = wave_sum_lane63(h[d]);
-        if (act && lane == 63) red[w * (DT + 1) + 1 + d] = v;
+        for (int d = 0; d < DT; ++d)
+            if (d < D) zst[(1 + d) * 512 + t] = h[d];
     }
     __syncthreads();
-    // block sums of g and h (fixed order), then the M and V contributions of this row chunk:
-    // c g (mgpr.py:117) and c T h (mgpr.py:118, V = c tiL^T lb = c T sum_i zeta_i lb_i)
-    DBG_STAMP(wk, 43, dbgm);
-    double* hs = red + 8 * (DT + 1);  // [DT + 1]
-    if (t < 1 + D) {
-        double acc = 0.0;
+    for (int k = w; act && k < 1 + D; k += 8) {   // (wave-uniform)
+        double acc = zst[k * 512 + lane];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc += red[k * (DT + 1) + t];
-        hs[t] = acc;
+        for (int j = 1; j < 8; ++j) acc += zst[k * 512 + 64 * j + lane];
+        acc = wave_sum_lane63(acc);
+        if (lane == 63) hs[k] = acc;
     }
+    // then the M and V contributions of this row chunk: c g (mgpr.py:117) and c T h (mgpr.py:118, V = c tiL^T lb = c T sum_i zeta_i lb_i)
+    DBG_STAMP(wk, 43, dbgm);
     __syncthreads();
     if (t < 1 + D) {
         double v;
@@ -434,6 +459,7 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
             s_ia2[t] = (t < D) ? 1.0 / (la * la) : 0.0;
             s_ib2[t] = (t < D) ? 1.0 / (lb * lb) : 0.0;
         }
+        prep_wt_constants<DT>(md, wk, pl, sm);
         for (int e = t; e < D * D; e += 512) s_s[e] = FUSED ? js[e] : wk.in_s[e];
         for (int e = t; e < DT * DT; e += 512) s_Q[e] = 0.0;   // padded rows / columns of Q stay zero
         __syncthreads();
@@ -514,7 +540,9 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
     double* At = wk.At + (long)pl * KP * npad;
     double* Wb = wk.Wt + (long)pair_col_block(wk, pl, pb_) * KP * npad;
     double* vrow = wk.vcol + (long)pl * npad;
-    const bool wt_writer = pair_writes_wt(wk, md.E, pa_, pb_);
+    const bool wt_dealt = wt_rows_dealt<DT>(wk, md.E, D, npad);
+    const bool wt_writer = !wt_dealt && pair_writes_wt(wk, md.E, pa_, pb_);
+    const int wt_R = wt_rows_per_pair(wk, md.E, D);
     auto row = [&](const int i, const bool valid, const double (&zeta)[DT]) {
         // y = Q x by columns of the symmetric Q: DT independent accumulators, one wide LDS row
         // read per column step (no LDS latency on the FMA chains).
@@ -577,6 +605,14 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
                     if (r < D) store_wt(&Wb[(long)r * npad + i], x[r]);     // w_j
             }
             store_wt(&vrow[i], uv);   // v_j: row D + 1 of the contraction, or (vsep) added after the K = D + 1 contraction
+            if (wt_dealt) {           // (workgroup-uniform) this pair's share of the w rows of ALL column blocks
+                for (int q = 0; q < wt_R; ++q) {
+                    const int rr = pl * wt_R + q;
+                    if (rr >= md.E * D) break;
+                    const int bb = rr / D, dd = rr - bb * D;
+                    store_wt(&wk.Wt[((long)bb * KP + dd) * npad + i], zst[(i - st_begin) * LDZ + dd] * colbuf[q]);
+                }
+            }
         }
     };
     if (fplds) {   // (workgroup-uniform) every thread takes its point from the stage, THEN the operands overwrite it

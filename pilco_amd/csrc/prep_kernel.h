@@ -72,6 +72,7 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void k_mm_prep(MMModel md, MMWor
                 sm[2 * DT + t] = (t < D) ? 1.0 / (pre_lb * pre_lb) : 0.0;
             }
             for (int e = t; e < DT * DT; e += 512) sm[3 * DT + DT * DT + e] = 0.0;
+            prep_wt_constants<DT>(md, wk, bxi, sm);
             L.xm = sm;
             L.xs = sm + 3 * DT;
         } else if (mean_wg) {   // prep_mean_block's layout: s_m [DT] | s_ia [DT] | s_s [DT*DT] | s_T [DT*DT]
