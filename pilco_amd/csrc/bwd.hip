@@ -33,6 +33,7 @@ namespace pilco {
 #define BWD_RT 2
 #endif
 constexpr int BWD_CH = 64;   // columns staged per LDS chunk (one wave-wide row segment)
+constexpr int BWD_SCR_H = 40, BWD_SCR_R = 72, BWD_SCR_W = 4 * BWD_SCR_R;   // column-sum scratch of a wave (doubles): half / register strides, size
 __host__ __device__ constexpr int bwd_tp(int kp) { return kp <= 16 ? 17 : kp + 1; }   // pitch of the staged column-major tile (doubles): operand rows + 1 (odd: conflict-free)
 // sum_{q < n} base[q * stride] with the loads of a batch of B issued together (a plain loop serialises one global
 // latency per term: these kernels are latency-bound); fixed summation order
@@ -208,14 +209,19 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
 #pragma unroll
         for (int m = 0; m < NMT; ++m) acc[rt][m] = d4{0.0, 0.0, 0.0, 0.0};
     double* myslice = csl + w * jws;
-    // column-sum scratch of this wave: [4 result registers][64 lanes]; reader lane = (column jj = lane / 4, quarter q = lane % 4)
-    // takes the four partials of lanes lc = 4 q .. 4 q + 3 of DPP row lr = jj % 4, register jj / 4
-    double* scr = csl + 4 * jws + 2 * SB + w * 256;
+    // column-sum scratch of this wave: the partial of (result register r, DPP row lr, lane lc of the row) sits at
+    // r BWD_SCR_R + (lc / 8) BWD_SCR_H + 8 lr + lc % 8; reader lane = (column jj = lane / 4 = 4 r + lr, quarter q = lane % 4)
+    // takes the partials of lanes lc = 2 q, 2 q + 1, 8 + 2 q, 9 + 2 q as two 16-byte reads.  The strides put the four DPP
+    // rows of one 16-lane read group on the four quarters of the bank row and the two 8-lane runs of a store group on
+    // different halves of the 32 store banks: no conflicts either way (the plain [r][lr][lc] layout read back two-way: lanes
+    // l and l + 8 of a group on the same banks -- SQ_LDS_BANK_CONFLICT was twice the useful LDS cycles, profiles/r04_grad_pmc_summary.json)
+    double* scr = csl + 4 * jws + 2 * SB + w * BWD_SCR_W;
     const int rd_jj = lane >> 2, rd_q = lane & 3;
-    const double* rd_src = scr + (rd_jj >> 2) * 64 + (rd_jj & 3) * 16 + 4 * rd_q;
+    const double* rd_src = scr + (rd_jj >> 2) * BWD_SCR_R + (rd_jj & 3) * 8 + 2 * rd_q;
+    double* wr_dst = scr + (lc >> 3) * BWD_SCR_H + lr * 8 + (lc & 7);
     int jprev = -1;
     auto flush_cols = [&](int jp) {
-        double p = (rd_src[0] + rd_src[1]) + (rd_src[2] + rd_src[3]);
+        double p = (rd_src[0] + rd_src[1]) + (rd_src[BWD_SCR_H] + rd_src[BWD_SCR_H + 1]);
         p = dpp_add<0xB1, 0xf>(p);   // quad_perm [1,0,3,2]
         p = dpp_add<0x4E, 0xf>(p);   // quad_perm [2,3,0,1]: every lane of the quad holds the sum over the 16 rows
         if (rd_q == 0) myslice[jp - jbeg + rd_jj] = p;
@@ -262,22 +268,30 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
 #pragma unroll
                     for (int m = 0; m < NMT; ++m) a2[m][r] = Tb[(jl + 4 * r + lr) * BWD_TP + dsel[m]];
                 }
+                if (MODE == 0) {
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+    #pragma unroll
+                        for (int m = 0; m < NMT; ++m) a2[m][r] *= bcol[r];
+                }
                 double csum[4] = {0.0, 0.0, 0.0, 0.0};
     #pragma unroll
                 for (int rt = 0; rt < BWD_RT; ++rt) {
                     // diagonal pair: tile weight 2 right of the diagonal tile (it stands for its mirror image too), 1 on it, 0 left of it
                     const int i0 = ibase + 16 * rt;
                     const double om = j0 > i0 ? 2.0 : (j0 == i0 ? 1.0 : 0.0);
-                    d4 e = {0.0, 0.0, 0.0, 0.0};
+                    // VSEP: v_j, which runs along the result registers of the transposed tile, is the chain's initial accumulator
+                    // (the first MFMA reads it as its C operand: no add per exponent afterwards)
+                    d4 e = {VSEP ? vj[0] : 0.0, VSEP ? vj[1] : 0.0, VSEP ? vj[2] : 0.0, VSEP ? vj[3] : 0.0};
     #pragma unroll
                     for (int c = 0; c < KC; ++c)
                         e = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[c], rf[rt][c], e, 0, 0, 0);   // e[r]: i = irow, j = j0+lr+4r
-                    MFMA_KEEP_ALIVE(cf[0]);      // (the first MFMA of the chain has a constant-zero accumulator)
+                    MFMA_KEEP_ALIVE(cf[0]);      // (not VSEP: the first MFMA of the chain has a constant-zero accumulator)
                     MFMA_KEEP_ALIVE(rf[rt][0]);
-                    // this hipcc leaves the instantiations below without the wait states (the K = D + 1 ones with one moment
-                    // tile get them: there the fence would only cost its 11 slots twice per step); tests/test_build_isa.py
-                    // scans the generated code of ALL instantiations for reads that come too early
-                    if (!VSEP || KC > 4 || NMT > 1) MFMA_RESULT_FENCE(e);
+                    // this hipcc does not reliably leave the wait states between the chain and the first VALU read of its result
+                    // (since v_j became the chain's accumulator the exp's clamp reads it directly, in every instantiation);
+                    // tests/test_build_isa.py scans the generated code of ALL instantiations for reads that come too early
+                    MFMA_RESULT_FENCE(e);
                     double wl[4];
     #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -285,13 +299,14 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
                             // off-diagonal pair: W = beta_a beta_b^T is separable -- the row side carries beta_b,j only and
                             // the column side beta_a,i only (one multiply and one FMA instead of two multiplies and an
                             // add); the epilogue / k_mm_bwd_post apply the missing factor per row / per column
-                            const double l = fexp(VSEP ? e[r] + vj[r] : e[r], tab);
-                            wl[r] = bcol[r] * l;
+                            // (beta_b,j rides in the moment product's column operand a2, scaled once per column step)
+                            const double l = fexp(e[r], tab);
+                            wl[r] = l;
                             csum[r] = fma(brow[rt], l, csum[r]);
                         } else {
                             double wgt = brow[rt] * bcol[r];
                             if (MODE == 1) wgt -= ikn[rt][r];   // iK symmetric: coalesced along the rows (requested a step ago)
-                            wl[r] = (wgt * om) * fexp(VSEP ? e[r] + vj[r] : e[r], tab);
+                            wl[r] = (wgt * om) * fexp(e[r], tab);
                             csum[r] += wl[r];
                         }
                     }
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
                 // permutes (9 VALU ops per step instead of 48); LDS operations of one wave execute in order
                 if (jprev >= 0) flush_cols(jprev);
     #pragma unroll
-                for (int r = 0; r < 4; ++r) scr[r * 64 + lane] = csum[r];
+                for (int r = 0; r < 4; ++r) wr_dst[r * BWD_SCR_R] = csum[r];
                 jprev = j0;
             }
             if (more) stage_store(stg + (cur ^ 1) * SB, sg);
@@ -383,7 +398,7 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
     }
     // ---- epilogue 3: the four waves' G added in LDS (block by block: the staging area holds 4 x 256 doubles), one block
     // per workgroup to memory; N_ab's share for the serial link of a value-and-gradient rollout is entry (D, D)
-    double* red = stg;   // [4][256]  (2 SB + 4 * 256 >= 1024 doubles)
+    double* red = stg;   // [4][256]  (2 SB + 4 * BWD_SCR_W >= 1024 doubles)
     double* gout = gpart + (((long)pl * njs + js) * gridDim.x + rb) * (NMT * NMT * 256);
     const int tN = ((D & 15) >> 2) * 64 + (D & 3) * 16 + (D & 15);   // entry of (d, e) = (D, D) inside its block
 #pragma unroll
@@ -1076,7 +1091,7 @@ void launch_mm_sweep(hipStream_t st, const MMModel& md, const MMWork& wk, double
     const int nhead = E + P, per_row = nrb * njs;
     dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);
     const int nI = D * D;
-    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * bwd_tp(wk.KP) + 2 * BWD_CH) + 4 * 256, (size_t)4 * nI + D);
+    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * bwd_tp(wk.KP) + 2 * BWD_CH) + 4 * BWD_SCR_W, (size_t)4 * nI + D);
     const double* bars = nullptr;
     launch_bwd_pair(st, grid, lds_pair, md, wk, rowmom, cpart, njs, bars, head, npart);
 }
@@ -1134,7 +1149,7 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
     const int nhead = E + P, per_row = nrb * njs;
     dim3 grid(nrb, P + (nhead + per_row - 1) / per_row, njs);   // the rows past P hold the head workgroups
     const int LD = D | 1, nI = D * D;
-    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * bwd_tp(wk.KP) + 2 * BWD_CH) + 4 * 256, (size_t)4 * nI + D);
+    const size_t lds_pair = sizeof(double) * std::max((size_t)4 * 16 * ((md.npad / 16 + njs - 1) / njs) + 2 * (BWD_CH * bwd_tp(wk.KP) + 2 * BWD_CH) + 4 * BWD_SCR_W, (size_t)4 * nI + D);
     double* npart = nullptr;
     launch_bwd_pair(st, grid, lds_pair, md, wk, rowmom, cpart, njs, bars, head, npart);
     const int nrc = mm_bwd_rc(md.npad);
