@@ -1964,13 +1964,13 @@ def test_policy_gradient_wide_inputs_vs_autograd(ctx, dims):
     np.testing.assert_allclose(bb, bt.grad.numpy(), rtol=1e-6, atol=1e-9 * np.abs(bt.grad.numpy()).max())
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_ranks_in_separate_processes_peer_exchange_on_one_gpu(world):
     """bench.py --gpus N exactly as the driver launches it (torch.distributed.run, one PROCESS per rank), all ranks on
     this box's single GPU (PILCO_BENCH_SHARE_GPU=1: RCCL refuses duplicate devices, so the beta rows travel over gloo): the
     sharded factorisation, the hipIpc-mapped exchange areas, the flag waits between processes and the graph replay of the
     sharded rollout; bench.py itself verifies the rollout against the executed-reference fixture and reports the exchange
-    it used."""
+    it used.  world = 8 is BASELINE config 3's rank count: eight processes, eight exchange areas mapped into each other, one GPU."""
     import json
     import socket
     import subprocess
