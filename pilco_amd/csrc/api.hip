@@ -346,8 +346,10 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
     if (const char* ei = getenv("PILCO_INLINE_POLICY")) ctx->inline_policy = (atoi(ei) != 0);
     if (const char* ef = getenv("PILCO_FUSED")) ctx->fused = (atoi(ef) != 0);
     if (const char* ef = getenv("PILCO_SMALL_STEP")) ctx->fuse_small = (atoi(ef) != 0);
-    const char* env = getenv("PILCO_PAIR_KERNEL");
-    if (env) ctx->variant = (atoi(env) >= 0 && atoi(env) <= 2) ? atoi(env) : 0;
+    if (const char* env = getenv("PILCO_PAIR_KERNEL")) {   // a choice like pilco_set_pair_kernel's: pilco_shard_set / _comm_init leave it alone
+        ctx->variant = (atoi(env) >= 0 && atoi(env) <= 2) ? atoi(env) : 0;
+        ctx->variant_user = true;
+    }
     *out = ctx;
     return PILCO_OK;
 }
@@ -361,7 +363,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     (void)peer_detach(ctx);
     for (auto& ge : ctx->graph_cache) (void)hipGraphExecDestroy(ge.second);
     for (Slot& sl : ctx->slot)
-        for (ChainGraph* cg : {&sl.g_fact, &sl.g_fitc, &sl.g_nlml, &sl.g_fitc_nlml}) chain_graph_release(*cg);
+        for (ChainGraph* cg : {&sl.g_fact, &sl.g_fitc, &sl.g_fitc_nlml}) chain_graph_release(*cg);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
         for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr, &s.ksplit_ws,

@@ -8,7 +8,7 @@
 #include <string>
 #include <vector>
 
-#include "pilco_hip.h"
+#include "pilco_hip_dev.h"   // (includes pilco_hip.h: the boundary) + the developer / measurement entry points
 
 namespace pilco {
 
@@ -43,6 +43,62 @@ struct DevBuf {
         borrowed = o.p != nullptr;
     }
 };
+
+// The kernel-argument segment of these kernels is 0.3-1.6 KB of by-value descriptors (MMModel, MMWork, GlueArgs, ...).  The
+// compiler fetches a field where it is first needed -- an s_load, an s_waitcnt, the arithmetic that leads to the next
+// field, the next s_load: the fused head's prologue is SIX such round trips in a row, each a miss of the scalar cache (the
+// segment of a graph node lives in device memory and was evicted from the XCD's L2 by the 60 MB the previous pair kernel
+// streamed).  kernarg_warm requests every 64-byte line of the segment at once -- one round trip -- so that the compiler's own
+// loads hit the scalar cache.  (KERNARG_WARM=0: off, for A/B runs.)
+#ifndef KERNARG_WARM
+#define KERNARG_WARM 1
+#endif
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+#if KERNARG_WARM
+    static_assert(BYTES <= 2048, "kernarg_warm covers segments of at most 2 KB");
+    // ONE asm statement -- requests and wait: nothing of the compiler's may come between a request and the wait (the
+    // destination register is dead for the compiler as soon as the statement ends, while a scalar load that is still in
+    // flight would write it later; scalar loads return out of order).  The assembler's .if keeps the lines the segment has.
+    int sink;
+    asm volatile("s_load_dword %0, %1, 0\n\t"
+                 ".if %2 > 64\n\ts_load_dword %0, %1, 64\n\t.endif\n\t"
+                 ".if %2 > 128\n\ts_load_dword %0, %1, 128\n\t.endif\n\t"
+                 ".if %2 > 192\n\ts_load_dword %0, %1, 192\n\t.endif\n\t"
+                 ".if %2 > 256\n\ts_load_dword %0, %1, 256\n\t.endif\n\t"
+                 ".if %2 > 320\n\ts_load_dword %0, %1, 320\n\t.endif\n\t"
+                 ".if %2 > 384\n\ts_load_dword %0, %1, 384\n\t.endif\n\t"
+                 ".if %2 > 448\n\ts_load_dword %0, %1, 448\n\t.endif\n\t"
+                 ".if %2 > 512\n\ts_load_dword %0, %1, 512\n\t.endif\n\t"
+                 ".if %2 > 576\n\ts_load_dword %0, %1, 576\n\t.endif\n\t"
+                 ".if %2 > 640\n\ts_load_dword %0, %1, 640\n\t.endif\n\t"
+                 ".if %2 > 704\n\ts_load_dword %0, %1, 704\n\t.endif\n\t"
+                 ".if %2 > 768\n\ts_load_dword %0, %1, 768\n\t.endif\n\t"
+                 ".if %2 > 832\n\ts_load_dword %0, %1, 832\n\t.endif\n\t"
+                 ".if %2 > 896\n\ts_load_dword %0, %1, 896\n\t.endif\n\t"
+                 ".if %2 > 960\n\ts_load_dword %0, %1, 960\n\t.endif\n\t"
+                 ".if %2 > 1024\n\ts_load_dword %0, %1, 1024\n\t.endif\n\t"
+                 ".if %2 > 1088\n\ts_load_dword %0, %1, 1088\n\t.endif\n\t"
+                 ".if %2 > 1152\n\ts_load_dword %0, %1, 1152\n\t.endif\n\t"
+                 ".if %2 > 1216\n\ts_load_dword %0, %1, 1216\n\t.endif\n\t"
+                 ".if %2 > 1280\n\ts_load_dword %0, %1, 1280\n\t.endif\n\t"
+                 ".if %2 > 1344\n\ts_load_dword %0, %1, 1344\n\t.endif\n\t"
+                 ".if %2 > 1408\n\ts_load_dword %0, %1, 1408\n\t.endif\n\t"
+                 ".if %2 > 1472\n\ts_load_dword %0, %1, 1472\n\t.endif\n\t"
+                 ".if %2 > 1536\n\ts_load_dword %0, %1, 1536\n\t.endif\n\t"
+                 ".if %2 > 1600\n\ts_load_dword %0, %1, 1600\n\t.endif\n\t"
+                 ".if %2 > 1664\n\ts_load_dword %0, %1, 1664\n\t.endif\n\t"
+                 ".if %2 > 1728\n\ts_load_dword %0, %1, 1728\n\t.endif\n\t"
+                 ".if %2 > 1792\n\ts_load_dword %0, %1, 1792\n\t.endif\n\t"
+                 ".if %2 > 1856\n\ts_load_dword %0, %1, 1856\n\t.endif\n\t"
+                 ".if %2 > 1920\n\ts_load_dword %0, %1, 1920\n\t.endif\n\t"
+                 ".if %2 > 1984\n\ts_load_dword %0, %1, 1984\n\t.endif\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(sink)
+                 : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(BYTES)
+                 : "memory");
+#endif
+}
 
 // ---------------------------------------------------------------- linalg.hip
 struct GemmDesc {

@@ -25,7 +25,7 @@ struct ChainGraph {
 };
 
 struct Slot {
-    ChainGraph g_fact, g_fitc, g_nlml, g_fitc_nlml;   // exact / FITC factorisation, their training objectives
+    ChainGraph g_fact, g_fitc, g_fitc_nlml;   // exact / FITC factorisation, the FITC training objective (the exact objective = the factorisation's graph + two eager launches)
     int N = 0, D = 0, E = 0, M = 0;  // data size, input dim, outputs, inducing points (0 = exact)
     int Npad = 0;                    // padded N
     int n = 0, npad = 0;             // points the moment matching runs over (N or M) and padding
@@ -179,6 +179,12 @@ inline void chain_graph_release(ChainGraph& cg) {
     cg.exec = nullptr;
     cg.key.clear();
 }
+// a chain that falls back to eager launches says so once per process (a silent fallback is a silent slow-down)
+inline void chain_graph_note() {
+    static bool said = false;
+    if (!said) fprintf(stderr, "libpilco_hip: a launch chain could not be captured as a hipGraph; it stays on eager launches\n");
+    said = true;
+}
 template <class F>
 int run_chain_graph(pilco_ctx* ctx, ChainGraph& cg, const std::vector<unsigned long long>& key, F&& enqueue) {
     if (!ctx->use_graph || ctx->dbg || cg.failed) return enqueue();
@@ -192,6 +198,7 @@ int run_chain_graph(pilco_ctx* ctx, ChainGraph& cg, const std::vector<unsigned l
     if (hipStreamBeginCapture(ctx->st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         cg.failed = true;
+        chain_graph_note();
         return PILCO_OK;
     }
     const int rc = enqueue();
@@ -200,6 +207,7 @@ int run_chain_graph(pilco_ctx* ctx, ChainGraph& cg, const std::vector<unsigned l
         (void)hipGetLastError();
         cg.exec = nullptr;
         cg.failed = true;   // eager from now on (the work of this call is already enqueued)
+        chain_graph_note();
     } else {
         cg.key = key;
     }

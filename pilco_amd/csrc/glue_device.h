@@ -792,6 +792,9 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
         if ((g.flags & GF_PACK) && g.xq_peers && writer) xq_push(g, L.seg);
     DBG_STAMP(g.wk, 10 + dbo, dbg0);
     const bool fast = (g.flags & (GF_PACK | GF_ASSEMBLE | GF_PROPAGATE)) == (GF_PACK | GF_ASSEMBLE | GF_PROPAGATE) && g.wk.nranks == 1;
+    // A head without a controller (PK = 0: control_dim 0, D = E): the joint Gaussian IS the propagated state, so the phase that
+    // produces the state writes the joint too -- the copies write_joint would make one barrier interval later (same values).
+    const bool joint_is_state = (PK == 0) && fast && (g.flags & GF_POLICY) && !g.act_out && U == 0;
     if (fast) {
         // The rollout's common case in two phases instead of five (every phase boundary is a workgroup barrier plus an LDS
         // round trip on this serial path).  Same operations in the same order as mm_assemble + GF_PROPAGATE below: the
@@ -825,17 +828,39 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
             for (int e = t; e < E * E; e += blockDim.x) rec[E + e] = L.su[e];
             for (int e = t; e < D * E; e += blockDim.x) rec[E + E * E + e] = L.cxu[e];
         }
+        double* s1_dst = g.s1_out ? g.s1_out : g.s1;
+        double* trec = g.tape ? g.tape + (long)g.step * (D + D * D + E * D + E + E * E + D * E) : nullptr;
         for (int e = t; e < E * E; e += blockDim.x) {   // in place: a thread reads sx only at the element it writes
             int c;
             const int r = idiv_s(e, E, c);
             const double v = ((L.su[e] + L.sx[e]) + L.t1[e]) + L.t1[c * E + r];
             L.sx[e] = v;
             if (writer) g.s_out[e] = v;
+            if (joint_is_state) {   // (write_joint's stores for D = E, U = 0)
+                L.js[e] = v;
+                if (L.xs) L.xs[e] = v;
+                if (writer) {
+                    g.wk.in_s[e] = v;
+                    s1_dst[e] = v;
+                    if (trec) {
+                        trec[D + e] = v;
+                        trec[D + D * D + e] = v;
+                    }
+                }
+            }
         }
         if (t < E) {
             const double v = L.mu[t] + L.mx[t];
             L.mx[t] = v;
             if (writer) g.m_out[t] = v;
+            if (joint_is_state) {
+                L.jm[t] = v;
+                if (L.xm) L.xm[t] = v;
+                if (writer) {
+                    g.wk.in_m[t] = v;
+                    if (trec) trec[t] = v;
+                }
+            }
         }
         __syncthreads();
     }
@@ -960,7 +985,7 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
                 for (int e = t; e < U * U; e += blockDim.x) g.act_out[U + e] = L.su[e];
                 for (int e = t; e < E * U; e += blockDim.x) g.act_out[U + U * U + e] = L.cxu[e];
             }
-        } else {
+        } else if (!joint_is_state) {
             write_joint(g, L, writer, jcd);
         }
     }

@@ -115,6 +115,7 @@ __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A,
 // POTF2: the workgroup of tile (0, 0) goes on to factor and invert that tile (the next diagonal block of the Cholesky chain)
 template <bool TA, bool TB, bool POTF2 = false>
 __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
+    kernarg_warm<(int)sizeof(GemmDesc) + 64>();   // (the factorisation is a chain of ~50 dependent launches: every prologue is on its critical path)
     // Grid (column tiles, matrices x sub-problems, row tiles): the row tile is the SLOWEST index, so that the tile rows with
     // the longest K range (k_mode 1 / 2: the first rows; k_mode 3 / 4: the last, taken first) start on every matrix before any
     // short row does.  (Round 2 had the matrix slowest: the last matrix's longest tiles started when the chip was already

@@ -260,7 +260,7 @@ static int jac_small_chunks(pilco_ctx* ctx, const RolloutPlan& plan, int H) {
     const Slot& s = ctx->slot[0];
     const int D = s.D, dtk = D <= 4 ? 4 : D <= 6 ? 6 : D <= 8 ? 8 : D <= 10 ? 10 : D == 11 ? 11 : D <= 12 ? 12 : D <= 14 ? 14 : D <= 16 ? 16 : 32;
     const bool rbf = plan.g.pol_kind == PILCO_POLICY_RBF;
-    if (!ctx->fuse_small || !ctx->fused || ctx->nranks != 1 || ctx->comm || s.wk.PL <= 0 || H <= 0 || ctx->time_pairs) return 0;
+    if (!ctx->fuse_small || !ctx->fused || ctx->nranks != 1 || ctx->comm || s.wk.PL <= 0 || H <= 0 || ctx->time_pairs || MM_ABL(s.wk, 255)) return 0;
     if (D > 14 || s.npad > 256 || s.npad / s.wk.NCH != 64 || s.wk.KP != mm_kp(dtk) || (s.wk.vsep != 0) != mm_vsep(dtk) || s.wk.KP > 16) return 0;
     if (rbf && !plan.g.pol_inline) return 0;
     if (!fused_heads_fit(ctx, plan)) return 0;
@@ -343,7 +343,10 @@ static int enqueue_rollout_steps(pilco_ctx* ctx, RolloutPlan& plan, int H, std::
         // chunks, KP <= 16; the tape serves D <= 14): the pair workgroups run the reverse sweep of their block (small_sweep).
         const bool small_ok = ctx->fuse_small && s.npad <= 256 && (s.npad / wk0.NCH) % 32 == 0 && wk0.KP == mm_kp(dtk) &&
                               (wk0.vsep != 0) == mm_vsep(dtk) && !pair_ev && !MM_ABL(s.wk, 255);
-        const bool small = small_ok && (jac ? (plan.jsmall > 0) : ctx->variant == 0);
+        // value-and-gradient rollouts: the PLAN has decided (jac_small_chunks sized the tape and the finish for it); the step
+        // geometry seen here must agree, or the finish would read the tape in the wrong layout
+        if (jac && plan.jsmall > 0 && !small_ok) return fail(ctx, PILCO_E_STATE, "rollout: the planned one-launch small step does not fit the step's geometry");
+        const bool small = jac ? (plan.jsmall > 0) : (small_ok && ctx->variant == 0);
         if (small)
             for (int k = 0; k < 2; ++k) {
                 wkb[k].fuse_pair = jac ? 2 : 1;

@@ -203,11 +203,13 @@ def _as_mask(flag, E):
     return np.full(E, bool(flag)) if np.ndim(flag) == 0 else np.asarray(flag, bool)
 
 
-def _require_complete(values, what):
+def _require_complete(values, what, ctx=None):
     """A context sharded by output evaluates only the outputs it owns; without a communicator the others come back NaN and
     the ranks have to be combined by the caller (pilco_amd._lib.group_nlml / group_fitc_nlml).  Feeding NaN losses and
-    gradients to L-BFGS-B instead would fail silently, so the optimiser entry points refuse."""
-    if not np.all(np.isfinite(values)):
+    gradients to L-BFGS-B instead would fail silently, so the optimiser entry points refuse.  (Only there: a non-finite
+    objective on an unsharded context -- overflowing hyper-parameters -- is the optimiser's business, which backs off.)"""
+    sharded_alone = ctx is None or (getattr(ctx, "nranks", 1) > 1 and not getattr(ctx, "has_comm", False))
+    if sharded_alone and not np.all(np.isfinite(values)):
         raise RuntimeError("%s.optimize: the training objective came back incomplete (NaN for outputs another rank owns): this "
                            "context is sharded by output and has no communicator -- attach one (Context.comm_init) or train on an "
                            "unsharded context" % what)
@@ -227,7 +229,7 @@ def mgpr_objective(mgpr, u, noise_trainable=True, ls_trainable=True, var_trainab
             m.likelihood.variance.assign(nz[i])
     mgpr._sync()
     nlml, g = mgpr.ctx.gp_nlml(mgpr._slot, D, E)
-    _require_complete(nlml, "MGPR")
+    _require_complete(nlml, "MGPR", mgpr.ctx)
     lp_l, dlp_l = _gamma_logpdf_and_grad(ls, 1.1, 0.1)          # mgpr.py:33
     lp_v, dlp_v = _gamma_logpdf_and_grad(var, 1.5, 0.5)         # mgpr.py:34
     # GPflow's training_loss adds log_prior_density of the TRAINABLE parameters only: a frozen parameter's prior is not in
@@ -323,7 +325,7 @@ def smgpr_objective(smgpr, u, noise_trainable=True, ls_trainable=True, var_train
             m.likelihood.variance.assign(nz[i])
     smgpr._sync()
     nlml, gh, gz = smgpr.ctx.gp_fitc_nlml(smgpr._slot, Z, D, E)
-    _require_complete(nlml, "SMGPR")
+    _require_complete(nlml, "SMGPR", smgpr.ctx)
     g_ls = gh[:, :D] * _dsoftplus(u[:E * D]).reshape(E, D) * tl[:, None]
     g_var = gh[:, D] * _dsoftplus(u[E * D:E * D + E]) * tv
     g_nz = gh[:, D + 1] * _dsoftplus(u[E * D + E:nk]) * tn
@@ -469,7 +471,10 @@ def policy_loss_and_grad(pilco, u, put, eps=1e-6):
     return f0, g
 
 
-def _restart_lanes_apply(pilco):
+MAX_LANES = 64   # PILCO_MAX_LANES of include/pilco_hip.h
+
+
+def _restart_lanes_apply(pilco, restarts=2):
     """Can the restarts of optimize_policy run as lanes of ONE batched value-and-gradient call per round?  The plain additive
     reward through the native sweep on one rank (what policy_loss_and_grad calls `analytic` and not `seeded`)."""
     import os
@@ -480,6 +485,8 @@ def _restart_lanes_apply(pilco):
         return False
     ctx = pilco.ctx
     if getattr(ctx, "nranks", 1) != 1 or getattr(ctx, "has_comm", False) or not hasattr(ctx, "rollout_grad_batch"):
+        return False
+    if restarts > MAX_LANES:   # (the batch entry points take at most 64 lanes: more restarts run one after the other, as before)
         return False
     if not isinstance(pilco.controller, (LinearController, RbfController)):
         return False
@@ -532,13 +539,15 @@ def _optimize_policy_lanes(pilco, maxiter, restarts, verbose, seeded=False):
             nb = len(todo)
             mm, SS = np.tile(m0, (nb, 1)), np.tile(S0, (nb, 1, 1))
             extra = [0.0] * nb          # what the objective adds to lane k's additive reward (seeded objectives)
+            no_seeds = set()            # lanes whose objective gave no cotangent seeds at this point: evaluated like the sequential loop does
             seed_kw = {}
             if seeded:
                 def lane_seeds(k):
                     def fn(traj):
                         out = pilco.trajectory_objective(traj)
-                        if out is None:
-                            raise RuntimeError("optimize_policy: the trajectory objective stopped providing cotangent seeds")
+                        if out is None:   # (policy_loss_and_grad: this evaluation by finite differences; the lane's batch result is dropped)
+                            no_seeds.add(k)
+                            return np.zeros_like(traj)
                         extra[k] = float(out[0])
                         return out[1]
                     return fn
@@ -563,6 +572,11 @@ def _optimize_policy_lanes(pilco, maxiter, restarts, verbose, seeded=False):
                     ui = us[k]
                     g = np.concatenate([dX[k].ravel(), dY[k].ravel(), (dl[k] * _dsoftplus(ui[-dl[k].size:]).reshape(dl[k].shape)).ravel()])
                     cache[i] = (ui, -(float(r[k]) + extra[k]), -g)
+            for k in sorted(no_seeds):   # the sequential loop's own evaluation of that point (finite differences), then the controller as it was
+                keep = get()
+                f, g = policy_loss_and_grad(pilco, us[k], put)
+                put(keep)
+                cache[todo[k]] = (us[k], f, g)
         vals = np.array([cache[i][1] for i in range(B)])
         grad = np.concatenate([cache[i][2] for i in range(B)])
         return vals, grad
@@ -585,7 +599,7 @@ def _optimize_policy_lanes(pilco, maxiter, restarts, verbose, seeded=False):
 def optimize_policy(pilco, maxiter=50, restarts=1, verbose=True):
     if pilco.controller is None:
         raise ValueError("optimize_policy: the model has no controller (control_dim == 0)")
-    lanes = _restart_lanes_apply(pilco) if restarts >= 2 else False
+    lanes = _restart_lanes_apply(pilco, restarts) if restarts >= 2 else False
     if lanes:
         return _optimize_policy_lanes(pilco, maxiter, restarts, verbose, seeded=(lanes == "seeded"))
     get, put = _policy_params(pilco.controller)

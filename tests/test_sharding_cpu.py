@@ -19,11 +19,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_every_declared_symbol_is_exported():
-    """The C-ABI library loads and exports every symbol include/pilco_hip.h declares."""
+    """The C-ABI library loads and exports every symbol include/*.h declares (pilco_hip.h: the boundary; pilco_hip_dev.h: the
+    measurement / developer entry points of the same library), and the boundary header is free of developer entry points."""
+    import glob
     import re
     from pilco_amd import _lib
     lib = _lib.load_library()
-    hdr = open(os.path.join(ROOT, "include", "pilco_hip.h")).read()
+    hdr = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))))
+    boundary = open(os.path.join(ROOT, "include", "pilco_hip.h")).read()
+    assert not re.findall(r"\b(pilco_debug_[a-z0-9_]+|pilco_[a-z_]*_timed|pilco_[gs]et_pair_timing)\s*\(", boundary)
     declared = set(re.findall(r"\b(pilco_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"pilco_ctx", "pilco_status"}
     assert declared, "no declarations parsed"
