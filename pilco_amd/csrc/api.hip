@@ -143,6 +143,7 @@ MMModel model_of(const Slot& s) {
     md.Pt = s.M > 0 ? s.Zt.p : s.Xt.p;
     md.ls = s.ls.p;
     md.var = s.var.p;
+    md.lvar = s.var.p + s.E;
     md.beta = s.beta.p;
     md.iK = (s.iK_null || s.ignore_iK) ? nullptr : s.iK.p;
     md.bW = s.shW > 0 ? s.shW : 1;
@@ -509,10 +510,13 @@ int pilco_gp_set_hyp(pilco_ctx* ctx, int slot, const double* lengthscales, const
         if (!(variance[i] > 0.0) || !(noise[i] >= 0.0)) return fail(ctx, PILCO_E_SHAPE, "set_hyp: variance must be positive, noise non-negative");
     HIPCHK(hipSetDevice(ctx->device));
     ENSURE(s.ls, (size_t)s.E * s.D);
-    ENSURE(s.var, (size_t)s.E);
+    ENSURE(s.var, (size_t)2 * s.E);   // var | log var (MMModel::lvar)
     ENSURE(s.noise, (size_t)s.E);
+    std::vector<double> lv((size_t)s.E);
+    for (int i = 0; i < s.E; ++i) lv[i] = std::log(variance[i]);
     HIPCHK(hipMemcpyAsync(s.ls.p, lengthscales, sizeof(double) * s.E * s.D, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipMemcpyAsync(s.var.p, variance, sizeof(double) * s.E, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(s.var.p + s.E, lv.data(), sizeof(double) * s.E, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipMemcpyAsync(s.noise.p, noise, sizeof(double) * s.E, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
     s.has_hyp = true;

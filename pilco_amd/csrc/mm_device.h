@@ -254,6 +254,15 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r;
 }
 
+// 1/sqrt(x) to fp64 accuracy: hardware estimate + two Newton steps (x > 0); the library's sqrt and division are ~80 dependent
+// operations of a lone wave on the head's serial path
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+
 // Unpivoted Gauss-Jordan with the matrix in registers: lane c of ONE wave holds column c of the
 // DT x 2DT augmented matrix [A | B].  Per pivot the multipliers (column k) are broadcast from lane k
 // with v_readlane; no LDS, no barriers (an LDS-broadcast variant measured slower at DT = 12).  On return

@@ -19,6 +19,7 @@ struct MMModel {
     const double* Pt;    // [D][npad]  points, transposed (training inputs X, inducing Z, or RBF centres)
     const double* ls;    // [E][D]
     const double* var;   // [E]
+    const double* lvar;  // [E]  log var (the operand rows carry log var_a - ...: taken on the host when the hyper-parameters arrive, not by every workgroup of every step)
     const double* beta;  // [E][npad]  zero padded
     const double* iK;    // [E][npad][npad] zero padded, or nullptr (== 0: RbfController, controllers.py:116)
     int n, npad, D, E;

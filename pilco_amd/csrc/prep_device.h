@@ -66,22 +66,24 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
     }
     const bool dbgm = (t == 0 && al == 0 && chm == 0);
     DBG_STAMP(wk, 40, dbgm);
-    const int rpc = npad / wk.NCHM;
+    const int rpc = npad >> __builtin_ctz(wk.NCHM);
     const int i_begin = chm * rpc, i_end = i_begin + rpc;
     if (w == 0) {
         // [B | I],  B = Lambda^-1 s Lambda^-1 + I; T = Lambda^-1 B^-1 Lambda^-1   (mgpr.py:103-111)
-        double col[DT];
+        double col[DT];   // (branch-free, as the pair workgroups' build: all LDS reads in flight together)
         const int c = lane;
+        const bool in_s = c < D;
+        const double ic = in_s ? s_ia[c] : 0.0;
+        double sv[DT], ir[DT];
 #pragma unroll
         for (int r = 0; r < DT; ++r) {
-            double v = 0.0;
-            if (c < DT) {
-                v = (r == c) ? 1.0 : 0.0;
-                if (r < D && c < D) v = fma(s_s[r * D + c], s_ia[r] * s_ia[c], v);
-            } else if (c < 2 * DT) {
-                v = (c - DT == r) ? 1.0 : 0.0;
-            }
-            col[r] = v;
+            sv[r] = s_s[(in_s && r < D) ? r * D + c : 0];
+            ir[r] = s_ia[r];   // (zero for r >= D)
+        }
+#pragma unroll
+        for (int r = 0; r < DT; ++r) {
+            const double sval = (in_s && r < D) ? sv[r] : 0.0;
+            col[r] = c < DT ? fma(sval, ir[r] * ic, (r == c) ? 1.0 : 0.0) : ((c < 2 * DT && c - DT == r) ? 1.0 : 0.0);
         }
         const double detB = gj_wave<DT>(col, colbuf, lane);
         if (c >= DT && c < DT + D) {
@@ -90,7 +92,7 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
             for (int r = 0; r < DT; ++r)
                 if (r < D) s_T[r * DT + cc] = col[r] * s_ia[r] * s_ia[cc];
         }
-        if (lane == 0) s_sc[1] = var_a / sqrt(detB);
+        if (lane == 0) s_sc[1] = var_a * fast_rsqrt(detB);
     } else if (act) {
         // the other seven waves stage the centred points of the chunk's first 512 rows meanwhile
         // (all of a thread's requests first, then the stores: element after element the loop was twelve L2 round trips in a
@@ -406,7 +408,7 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
         const int slot = 64 + 2 * (by * gx + bx);
         if (wk.dbg && threadIdx.x == 0 && slot < 958) wk.dbg[slot] = wall_clock64();
         if (idx < nmean) {
-            prep_mean_block<DT, FUSED, NTHR, PRE>(md, wk, idx / wk.NCHM, idx % wk.NCHM, sm, jm, js, pre_la, pre_var);
+            prep_mean_block<DT, FUSED, NTHR, PRE>(md, wk, idx >> __builtin_ctz(wk.NCHM), idx & (wk.NCHM - 1), sm, jm, js, pre_la, pre_var);
             if (wk.dbg && threadIdx.x == 0 && slot < 958) wk.dbg[slot + 1] = wall_clock64();
             return;
         }
@@ -465,7 +467,7 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
         __syncthreads();
     }
     DBG_STAMP(wk, 1, dbg0);
-    const int rpc = npad / wk.NCH;
+    const int rpc = npad >> __builtin_ctz(wk.NCH);   // (NCH, NCHM, NCS are powers of two: mm_prep_chunks; a signed division is ~40 scalar operations on this serial path)
     const int i_begin = ch * rpc, i_end = i_begin + rpc;
     // The centred points of the chunk's first 256 rows are staged in LDS by the seven waves that do not run the
     // Gauss-Jordan, so their load latency (and the log of the signal variance) hides behind that phase.
@@ -478,9 +480,9 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
     const bool fpair = FPAIR && wk.fuse_pair;
     // ... and with 64 rows per workgroup and a contraction of at most 16 rows the operands stay in LDS (the stage's place,
     // once every thread has taken its point from it): Al [KP][64] | Bl [KP][npad] | vl [npad]
-    const bool fplds = fpair && mm_kp(DT) <= 16 && npad / wk.NCH == 64;
+    const bool fplds = fpair && mm_kp(DT) <= 16 && rpc == 64;
     // ... and over column splits (MMWork::NCS): this workgroup's share of the pair's columns
-    const int ncsg = (fplds && wk.NCS > 1) ? wk.NCS : 1, ncols = npad / ncsg, c_begin = cs * ncols, c_end = c_begin + ncols;
+    const int ncsg = (fplds && wk.NCS > 1) ? wk.NCS : 1, ncols = npad >> __builtin_ctz(ncsg), c_begin = cs * ncols, c_end = c_begin + ncols;
     double* Al = zst;
     double* Bl = Al + mm_kp(DT) * 64;
     double* vl = Bl + mm_kp(DT) * 256;
@@ -498,34 +500,39 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
             const int i = st_begin + r;
             zst[r * LDZ + d] = (i < md.n && i < st_end) ? md.Pt[(long)d * npad + i] - s_m[d] : 0.0;
         }
+        DBG_STAMP(wk, 7, t == 64 && pl == 0 && ch == 0);   // (the first staging wave is done)
     }
-    const double logvar = log(pre_var);
+    const double logvar = pre_var;   // (log var of this thread's side: MMModel::lvar, loaded by the caller)
     if (MM_ABL(wk, 2)) {
         if (t == 0) s_sc[0] = 1.0;
     } else if (w == 0) {
         // [R | s],  R = s diag(la^-2 + lb^-2) + I        (mgpr.py:121-124,129); padded with identity
+        // (branch-free: every lane reads its element of s -- or element 0 -- in ALL DT iterations and selects afterwards, so the DT
+        // LDS reads leave back to back; with the two lane populations in divergent branches each iteration was two LDS round
+        // trips of this lone wave: 1.4 us of the 2.6 us phase)
         double col[DT];
         const int c = lane;
+        const int cc = c < DT ? c : c - DT;
+        const bool in_s = cc < D && c < 2 * DT;
+        const double lam = (c < DT && c < D) ? s_ia2[c] + s_ib2[c] : 0.0;
+        double sv[DT];
+#pragma unroll
+        for (int r = 0; r < DT; ++r) sv[r] = s_s[(in_s && r < D) ? r * D + cc : 0];
 #pragma unroll
         for (int r = 0; r < DT; ++r) {
-            double v = 0.0;
-            if (c < DT) {
-                v = (r == c) ? 1.0 : 0.0;
-                if (r < D && c < D) v = fma(s_s[r * D + c], s_ia2[c] + s_ib2[c], v);
-            } else if (c < 2 * DT) {
-                const int cc = c - DT;
-                if (r < D && cc < D) v = s_s[r * D + cc];
-            }
-            col[r] = v;
+            const double sval = (in_s && r < D) ? sv[r] : 0.0;
+            col[r] = c < DT ? fma(sval, lam, (r == c) ? 1.0 : 0.0) : sval;   // lanes >= 2 DT: zeros
         }
+        DBG_STAMP(wk, 5, dbg0);
         const double det = gj_wave<DT>(col, colbuf, lane);
+        DBG_STAMP(wk, 6, dbg0);
         if (c >= DT && c < DT + D) {
 #pragma unroll
             for (int r = 0; r < DT; ++r)
                 if (r < D) s_Q[r * DT + (c - DT)] = 0.5 * col[r];
         }
         if (lane == 0) {
-            s_sc[0] = 1.0 / sqrt(det);
+            s_sc[0] = fast_rsqrt(det);
             if (by == 0) store_wt(&wk.pair_isdet[pl], s_sc[0]);
         }
     }

@@ -42,14 +42,14 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void k_mm_prep(MMModel md, MMWor
     const bool mean_wg = spare_wg && spare_idx < wk.EL * wk.NCHM;
     int a = 0, b = 0;
     if (!spare_wg) local_pair_ab(wk, md.E, bxi, a, b);
-    else if (mean_wg) a = b = (spare_idx / wk.NCHM) * wk.nranks + wk.rank;   // the owner of (a,a) owns output a
+    else if (mean_wg) a = b = (spare_idx >> __builtin_ctz(wk.NCHM)) * wk.nranks + wk.rank;   // the owner of (a,a) owns output a
     double pre_la = 1.0, pre_lb = 1.0, pre_var = 1.0;
     if (!spare_wg || mean_wg) {
         if ((int)threadIdx.x < md.D) {
             pre_la = md.ls[a * md.D + (int)threadIdx.x];
             pre_lb = md.ls[b * md.D + (int)threadIdx.x];
         }
-        pre_var = md.var[(threadIdx.x >> 8) ? b : a];
+        pre_var = mean_wg ? md.var[a] : md.lvar[(threadIdx.x >> 8) ? b : a];   // (pair workgroups want log var of their side, the mean part var_a)
     }
     if (FUSED && SR && PK != 1 && wk.fuse_pair && !spare_wg) {   // one-launch small step: the pair phase's exp table, on its way during the link
         double* tabL = sm_all + glue_doubles + prep_region_doubles(DT);

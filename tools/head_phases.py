@@ -20,5 +20,7 @@ for rep in range(4):
     print("head(2): link [loads %.2f pack %.2f asm+prop %.2f (%.2f) joint %.2f = %.2f] -> prep part [init %.2f gj %.2f rows %.2f = %.2f]  head total %.2f | -> pair w0 start +%.2f, w0 %.2f | final glue [loads %.2f pack %.2f asm+prop %.2f = %.2f]" % (
         us(56, 57), us(57, 58), us(58, 59), us(59, 60), us(60, 61), us(56, 61), us(61, 1), us(1, 2), us(2, 3), us(61, 4), us(56, 4),
         us(4, 16), us(16, 17), us(8, 9), us(9, 10), us(10, 12), us(8, 12)))
+print("inside the Gauss-Jordan phase of pair block (0,0): build %.2f | gj_wave %.2f | Q store + barrier %.2f ; first staging wave done %.2f after the phase began" % (
+    us(1, 5), us(5, 6), us(6, 2), us(1, 7)))
 print("engine clock during the pair kernel (wave 0): %.0f MHz  (shader-clock ticks %d over %.2f us of wall clock)" % (
     (ts[33] - ts[32]) / ((ts[17] - ts[16]) / 100.0), ts[33] - ts[32], (ts[17] - ts[16]) / 100.0))
