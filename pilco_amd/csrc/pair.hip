@@ -78,8 +78,8 @@ template <int KC, bool VSEP>
 __global__ __launch_bounds__(256, (KC <= 4 && PAIR_MINW < 3) ? 3 : PAIR_MINW) void k_mm_pair_sk(MMModel md, MMWork wk) {
     __shared__ double tab[FEXP_TN];
     kernarg_warm<(int)(sizeof(MMModel) + sizeof(MMWork)) + 64>();
-    for (int e = threadIdx.x; e < FEXP_TN; e += blockDim.x) tab[e] = wk.exp_tab[e];
-    __syncthreads();
+    TabArrival ta;
+    ta.request(wk.exp_tab, tab);   // requested here, stored behind the first tile's operand requests
     const int lane = threadIdx.x & 63;
     // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (own L2 each), so workgroup b takes
     // position (b % 8) * (blocks / 8) + b / 8 of the cost line: the waves of one XCD cover one contiguous eighth of it
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256, (KC <= 4 && PAIR_MINW < 3) ? 3 : PAIR_MINW) vo
     const int nd_steps = wk.sk_nd * wk.sk_tdiag;
     double out0, out1;
     int p0, p1;
-    sk_wave_range<KC, VSEP>(md, wk, tab, w, lane, out0, out1, p0, p1);
+    sk_wave_range<KC, VSEP>(md, wk, tab, w, lane, out0, out1, p0, p1, &ta);
+    ta.land();   // (a wave without a single step still owes the workgroup its barrier)
     for (int off = 32; off > 0; off >>= 1) {
         out0 += __shfl_down(out0, off);
         out1 += __shfl_down(out1, off);

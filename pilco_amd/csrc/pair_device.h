@@ -50,12 +50,38 @@ namespace pilco {
 // LDSOP (the one-launch step of small models, prep_device.h): the operands never went to memory -- At / Bt / vcol point into
 // the workgroup's LDS, At as [k][lda] over the workgroup's own rows (row i0 is its row i0l), Bt as [k][ldb] over all columns
 // (all KP rows materialised there); po is not used.
+// The exp table of a pair kernel's workgroup, on its way from memory while the first tile's operands are requested: the
+// kernel REQUESTS its entry (one per thread) at its very top and hands it to the first pair_wave call of each wave, which
+// stores it and meets the other waves at the workgroup's barrier only after its own operand requests have left (the table is
+// first read by the first exp, a whole MFMA chain later).  Loading table -> barrier -> operands in sequence was two memory
+// round trips in a row at the start of every launch.
+struct TabArrival {
+    static constexpr int NV = (FEXP_TN + 255) / 256;   // entries per thread of a 256-thread workgroup
+    double v[NV];    // this thread's table entries (requested, perhaps not yet arrived)
+    double* lds;     // the table in LDS
+    bool pending;    // not stored yet (wave-uniform)
+    __device__ __forceinline__ void request(const double* __restrict__ g, double* l) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = (FEXP_TN % 256 == 0 || threadIdx.x + 256 * k < FEXP_TN) ? g[threadIdx.x + 256 * k] : 0.0;
+        lds = l;
+        pending = true;
+    }
+    __device__ __forceinline__ void land() {
+        if (pending) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                if (FEXP_TN % 256 == 0 || threadIdx.x + 256 * k < FEXP_TN) lds[threadIdx.x + 256 * k] = v[k];
+            __syncthreads();
+            pending = false;
+        }
+    }
+};
 template <int KC, bool DIAG, bool VSEP, bool FENCE = false, bool LDSOP = false>
 __device__ __forceinline__ double pair_wave(const PairOps& po, const double* __restrict__ At, const double* __restrict__ Bt,
                                             const double* __restrict__ vcol,
                                             const double* __restrict__ beta_a, const double* __restrict__ beta_b,
                                             const double* __restrict__ iKa, const double* __restrict__ tab, int npad, int i0,
-                                            int jbeg, int jend, int lane, int lda = 0, int ldb = 0, int i0l = 0) {
+                                            int jbeg, int jend, int lane, int lda = 0, int ldb = 0, int i0l = 0, TabArrival* ta = nullptr) {
     constexpr int NE = 4 * PAIR_RT;  // exponent values per lane per 16-column step
     static_assert(PAIR_PF == 2, "the column loop is unrolled over a two-slot operand ring");
     const int lr = lane >> 4, lc = lane & 15;
@@ -109,6 +135,7 @@ __device__ __forceinline__ double pair_wave(const PairOps& po, const double* __r
             }
         }
     }
+    if (ta) ta->land();   // (the requests above are in flight; see TabArrival)
     // one 16-column step on ring slot rg; the slot is refilled with the operands of column step j0 + 32
     auto step = [&](double (&rg)[KC + 2], const int j0) {
         double bf[KC];
@@ -259,7 +286,7 @@ __device__ __forceinline__ int sk_boundary(const MMWork& wk, int w) {
 // cost line, touching at most two local pairs p0, p1 (-1: none) with the sums out0, out1 (before the wave reduction).
 template <int KC, bool VSEP, bool FENCE = false>
 __device__ __forceinline__ void sk_wave_range(const MMModel& md, const MMWork& wk, const double* __restrict__ tab, int w, int lane,
-                                              double& out0, double& out1, int& p0, int& p1) {
+                                              double& out0, double& out1, int& p0, int& p1, TabArrival* ta = nullptr) {
     const int npad = md.npad, NS = npad / 16;
     const int nd_steps = wk.sk_nd * wk.sk_tdiag;
     int step = sk_boundary(wk, w);
@@ -309,9 +336,9 @@ __device__ __forceinline__ void sk_wave_range(const MMModel& md, const MMWork& w
         const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
         const int i0 = ti * 16 * PAIR_RT, jbeg = sidx * 16, jend = jbeg + seg * 16;
         if (dg)
-            cur += pair_wave<KC, true, VSEP, FENCE>(po, nullptr, nullptr, nullptr, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab, npad, i0, jbeg, jend, lane);
+            cur += pair_wave<KC, true, VSEP, FENCE>(po, nullptr, nullptr, nullptr, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab, npad, i0, jbeg, jend, lane, 0, 0, 0, ta);
         else
-            cur += pair_wave<KC, false, VSEP, FENCE>(po, nullptr, nullptr, nullptr, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jend, lane);
+            cur += pair_wave<KC, false, VSEP, FENCE>(po, nullptr, nullptr, nullptr, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jend, lane, 0, 0, 0, ta);
         step += seg;
     }
     if (cur_pl >= 0) {
