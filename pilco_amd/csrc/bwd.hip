@@ -32,6 +32,9 @@ namespace pilco {
 #ifndef BWD_RT
 #define BWD_RT 2
 #endif
+#ifndef BWD_FAIR
+#define BWD_FAIR 1   // the sweep's workgroups lower their issue priority as they advance through their column range (1; measured:
+#endif               // sweep 98.8 -> 96.9 us, three A/B repetitions in one call; 2 = rising priority: no gain; 0 = off)
 constexpr int BWD_CH = 64;   // columns staged per LDS chunk (one wave-wide row segment)
 constexpr int BWD_SCR_H = 40, BWD_SCR_R = 72, BWD_SCR_W = 4 * BWD_SCR_R;   // column-sum scratch of a wave (doubles): half / register strides, size
 __host__ __device__ constexpr int bwd_tp(int kp) { return kp <= 16 ? 17 : kp + 1; }   // pitch of the staged column-major tile (doubles): operand rows + 1 (odd: conflict-free)
@@ -249,6 +252,17 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
         __syncthreads();
         int cur = 0;
         for (int jc = jstart; jc < jend; jc += BWD_CH) {
+#if BWD_FAIR
+            {   // issue priority by progress through the column range (see WaveProgress in pair_device.h): the workgroup's four waves
+                // step together (one barrier per chunk), so this is the workgroup's priority against the others on its SIMDs
+                const int q = (4 * (jc - jstart)) / max(jend - jstart, 1);
+                const int lv = BWD_FAIR == 1 ? 3 - q : q;
+                if (lv == 3) __builtin_amdgcn_s_setprio(3);
+                else if (lv == 2) __builtin_amdgcn_s_setprio(2);
+                else if (lv == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
             const bool more = jc + BWD_CH < jend;
             if (more) stage_load(jc + BWD_CH, sg);
             const double* Tb = stg + cur * SB;

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, (KC <= 4 && PAIR_MINW < 3) ? 3 : PAIR_MINW) vo
     const int nd_steps = wk.sk_nd * wk.sk_tdiag;
     double out0, out1;
     int p0, p1;
-    sk_wave_range<KC, VSEP>(md, wk, tab, w, lane, out0, out1, p0, p1, &ta);
+    sk_wave_range<KC, VSEP>(md, wk, tab, w, lane, out0, out1, p0, p1, &ta, PAIR_FAIR != 0);
     ta.land();   // (a wave without a single step still owes the workgroup its barrier)
     for (int off = 32; off > 0; off >>= 1) {
         out0 += __shfl_down(out0, off);

@@ -37,6 +37,9 @@ namespace pilco {
 #ifndef PAIR_PF
 #define PAIR_PF 2      // operand prefetch distance in 16-column steps
 #endif
+#ifndef PAIR_FAIR
+#define PAIR_FAIR 1    // the stream-K waves lower their issue priority as they advance (WaveProgress); 0: A/B builds
+#endif
 #ifndef PAIR_MINW
 #define PAIR_MINW 1    // __launch_bounds__ min waves per SIMD for the pair kernel
 #endif
@@ -76,12 +79,37 @@ struct TabArrival {
         }
     }
 };
+// Progress of a stream-K wave through its share of the line, turned into its issue priority.  The SIMD's arbiter serves the
+// OLDEST wave first: of the three waves a SIMD hosts the first finished after 24 us, the second after 38, the third after 50
+// (tools/pair_waves.py) -- and a lone wave cannot keep the fp64 pipe busy (dependent MFMA -> exp -> accumulate chains), so the
+// last quarter of every launch ran at two thirds of the rate.  A wave that is ahead now yields: priority 3 for the first
+// quarter of its steps down to 0 for the last, so the waves of a SIMD stay within a quarter of each other and the pipe has
+// work from all of them until the end (headline 409 -> 417 rollouts/s in one A/B call).  Finer slices -- the four
+// priorities cycled 8, 16, 32 times per share -- measured WORSE (410, 409, 399): waves in lock-step want the matrix cores
+// and the VALU at the same moments.
+#ifndef PAIR_FAIR_LEVELS
+#define PAIR_FAIR_LEVELS 4     // priority levels used (2..4): level = L - 1 - floor(L done / total)
+#endif
+struct WaveProgress {
+    int done, total, level;
+    __device__ __forceinline__ void tick(int steps) {
+        done += steps;
+        const int lv = (PAIR_FAIR_LEVELS - 1) - min(PAIR_FAIR_LEVELS - 1, (PAIR_FAIR_LEVELS * done) / max(total, 1));
+        if (lv != level) {   // (wave-uniform)
+            level = lv;
+            if (lv == 3) __builtin_amdgcn_s_setprio(3);
+            else if (lv == 2) __builtin_amdgcn_s_setprio(2);
+            else if (lv == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+    }
+};
 template <int KC, bool DIAG, bool VSEP, bool FENCE = false, bool LDSOP = false>
 __device__ __forceinline__ double pair_wave(const PairOps& po, const double* __restrict__ At, const double* __restrict__ Bt,
                                             const double* __restrict__ vcol,
                                             const double* __restrict__ beta_a, const double* __restrict__ beta_b,
                                             const double* __restrict__ iKa, const double* __restrict__ tab, int npad, int i0,
-                                            int jbeg, int jend, int lane, int lda = 0, int ldb = 0, int i0l = 0, TabArrival* ta = nullptr) {
+                                            int jbeg, int jend, int lane, int lda = 0, int ldb = 0, int i0l = 0, TabArrival* ta = nullptr, WaveProgress* wp = nullptr) {
     constexpr int NE = 4 * PAIR_RT;  // exponent values per lane per 16-column step
     static_assert(PAIR_PF == 2, "the column loop is unrolled over a two-slot operand ring");
     const int lr = lane >> 4, lc = lane & 15;
@@ -228,6 +256,7 @@ __device__ __forceinline__ double pair_wave(const PairOps& po, const double* __r
         }
     };
     for (int j0 = jbeg; j0 < jend; j0 += 32) {
+        if (wp) wp->tick(2);
         step(ring[0], j0);
         if (j0 + 16 < jend) step(ring[1], j0 + 16);
     }
@@ -286,11 +315,13 @@ __device__ __forceinline__ int sk_boundary(const MMWork& wk, int w) {
 // cost line, touching at most two local pairs p0, p1 (-1: none) with the sums out0, out1 (before the wave reduction).
 template <int KC, bool VSEP, bool FENCE = false>
 __device__ __forceinline__ void sk_wave_range(const MMModel& md, const MMWork& wk, const double* __restrict__ tab, int w, int lane,
-                                              double& out0, double& out1, int& p0, int& p1, TabArrival* ta = nullptr) {
+                                              double& out0, double& out1, int& p0, int& p1, TabArrival* ta = nullptr, bool fair = false) {
     const int npad = md.npad, NS = npad / 16;
     const int nd_steps = wk.sk_nd * wk.sk_tdiag;
     int step = sk_boundary(wk, w);
     const int end = sk_boundary(wk, w + 1);
+    WaveProgress prog{0, end - step, -1};
+    WaveProgress* wp = fair ? &prog : nullptr;
     out0 = 0.0;
     out1 = 0.0;
     p0 = -1;
@@ -336,9 +367,9 @@ __device__ __forceinline__ void sk_wave_range(const MMModel& md, const MMWork& w
         const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
         const int i0 = ti * 16 * PAIR_RT, jbeg = sidx * 16, jend = jbeg + seg * 16;
         if (dg)
-            cur += pair_wave<KC, true, VSEP, FENCE>(po, nullptr, nullptr, nullptr, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab, npad, i0, jbeg, jend, lane, 0, 0, 0, ta);
+            cur += pair_wave<KC, true, VSEP, FENCE>(po, nullptr, nullptr, nullptr, beta_a, beta_b, md.iK + mm_ik_blk(md, a) * npad * npad, tab, npad, i0, jbeg, jend, lane, 0, 0, 0, ta, wp);
         else
-            cur += pair_wave<KC, false, VSEP, FENCE>(po, nullptr, nullptr, nullptr, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jend, lane, 0, 0, 0, ta);
+            cur += pair_wave<KC, false, VSEP, FENCE>(po, nullptr, nullptr, nullptr, beta_a, beta_b, nullptr, tab, npad, i0, jbeg, jend, lane, 0, 0, 0, ta, wp);
         step += seg;
     }
     if (cur_pl >= 0) {

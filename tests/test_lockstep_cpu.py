@@ -262,6 +262,8 @@ def test_an_incomplete_training_objective_is_refused_and_frozen_parameters_carry
     from pilco_amd.models import MGPR
 
     class Sharded(CpuObjectiveContext):
+        nranks, has_comm = 2, False   # sharded by output, nobody to exchange with
+
         def gp_nlml(self, slot, D, E, want_grad=True):
             nlml, grad = super().gp_nlml(slot, D, E, want_grad)
             nlml[1::2] = np.nan
@@ -272,6 +274,10 @@ def test_an_incomplete_training_objective_is_refused_and_frozen_parameters_carry
     X, Y = rng.standard_normal((20, 2)), rng.standard_normal((20, 2))
     with pytest.raises(RuntimeError, match="communicator"):
         MGPR((X, Y), ctx=Sharded()).optimize(restarts=0)
+    # (round-4 advice) ... and ONLY there: a non-finite objective on an unsharded context is not reported as a sharding problem
+    training._require_complete(np.array([np.nan, 1.0]), "MGPR", CpuObjectiveContext())
+    with pytest.raises(RuntimeError, match="communicator"):
+        training._require_complete(np.array([np.nan, 1.0]), "MGPR", Sharded())
     m = MGPR((X, Y), ctx=CpuObjectiveContext())
     u = training._mgpr_pack(m)
     full, _ = training.mgpr_objective(m, u)
