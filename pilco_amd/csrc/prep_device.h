@@ -85,7 +85,9 @@ __device__ __forceinline__ void prep_mean_block(const MMModel& md, const MMWork&
             const double sval = (in_s && r < D) ? sv[r] : 0.0;
             col[r] = c < DT ? fma(sval, ir[r] * ic, (r == c) ? 1.0 : 0.0) : ((c < 2 * DT && c - DT == r) ? 1.0 : 0.0);
         }
+        __builtin_amdgcn_s_setprio(3);   // (the wave the other seven wait for)
         const double detB = gj_wave<DT>(col, colbuf, lane);
+        __builtin_amdgcn_s_setprio(0);
         if (c >= DT && c < DT + D) {
             const int cc = c - DT;
 #pragma unroll
@@ -524,7 +526,9 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
             col[r] = c < DT ? fma(sval, lam, (r == c) ? 1.0 : 0.0) : sval;   // lanes >= 2 DT: zeros
         }
         DBG_STAMP(wk, 5, dbg0);
+        __builtin_amdgcn_s_setprio(3);   // (the wave the other seven wait for: ahead of the staging wave that shares its SIMD)
         const double det = gj_wave<DT>(col, colbuf, lane);
+        __builtin_amdgcn_s_setprio(0);
         DBG_STAMP(wk, 6, dbg0);
         if (c >= DT && c < DT + D) {
 #pragma unroll
