@@ -33,8 +33,8 @@ namespace pilco {
 #define BWD_RT 2
 #endif
 #ifndef BWD_FAIR
-#define BWD_FAIR 1   // the sweep's workgroups lower their issue priority as they advance through their column range (1; measured:
-#endif               // sweep 98.8 -> 96.9 us, three A/B repetitions in one call; 2 = rising priority: no gain; 0 = off)
+#define BWD_FAIR 1   // the sweep's workgroups lower their issue priority as they advance through their column range (measured:
+#endif               // sweep 98.8 -> 96.9 us, three A/B repetitions in one call; rising priority: no gain; 0 = off)
 constexpr int BWD_CH = 64;   // columns staged per LDS chunk (one wave-wide row segment)
 constexpr int BWD_SCR_H = 40, BWD_SCR_R = 72, BWD_SCR_W = 4 * BWD_SCR_R;   // column-sum scratch of a wave (doubles): half / register strides, size
 __host__ __device__ constexpr int bwd_tp(int kp) { return kp <= 16 ? 17 : kp + 1; }   // pitch of the staged column-major tile (doubles): operand rows + 1 (odd: conflict-free)
@@ -245,7 +245,10 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
                 for (int r = 0; r < 4; ++r)
                     ikn[rt][r] = buf_ld(rIK, ik_voff[rt], ((unsigned)(j0n - jbeg) + 4u * (unsigned)r) * (unsigned)npad * 8u);
         };
-        if (MODE == 1) ik_request(jstart < ibase ? jstart + 16 * ((ibase - jstart) / 16) : jstart);   // the wave's first swept tile
+        // (a wave whose rows lie past the padding -- npad not a multiple of the 128-row block -- sweeps nothing, and the tile it
+        // would ask for starts below the last row of iK: the last output's block ends there.  Found in round 5 by the
+        // contraction-depth test: a memory fault at npad = 192 with seven outputs, latent since the symmetric sweep of round 4.)
+        if (MODE == 1 && ibase < npad) ik_request(jstart < ibase ? jstart + 16 * ((ibase - jstart) / 16) : jstart);   // the wave's first swept tile
         double sg[NST];
         stage_load(jstart, sg);
         stage_store(stg, sg);
@@ -254,12 +257,14 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
         for (int jc = jstart; jc < jend; jc += BWD_CH) {
 #if BWD_FAIR
             {   // issue priority by progress through the column range (see WaveProgress in pair_device.h): the workgroup's four waves
-                // step together (one barrier per chunk), so this is the workgroup's priority against the others on its SIMDs
-                const int q = (4 * (jc - jstart)) / max(jend - jstart, 1);
-                const int lv = BWD_FAIR == 1 ? 3 - q : q;
-                if (lv == 3) __builtin_amdgcn_s_setprio(3);
-                else if (lv == 2) __builtin_amdgcn_s_setprio(2);
-                else if (lv == 1) __builtin_amdgcn_s_setprio(1);
+                // step together (one barrier per chunk), so this is the workgroup's priority against the others on its SIMDs.
+                // (Quartiles by comparison with scalar thresholds: a signed division here -- the compiler's float-reciprocal
+                // sequence -- made the K = 8 instantiation compute wrong sums, found by the seeded shape sweep of the GPU tests.)
+                const int done4 = 4 * (jc - jstart), len = jend - jstart;
+                const int q = (done4 >= len ? 1 : 0) + (done4 >= 2 * len ? 1 : 0) + (done4 >= 3 * len ? 1 : 0);
+                if (q == 0) __builtin_amdgcn_s_setprio(3);
+                else if (q == 1) __builtin_amdgcn_s_setprio(2);
+                else if (q == 2) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
             }
 #endif

@@ -69,17 +69,6 @@ __device__ __forceinline__ void glue_lds_carve(const GlueArgs& g, double* sm, Gl
     L.o_mp = L.o_seg + seg_n;
 }
 
-// Quotient and remainder of a small non-negative index (e < 2^22) by a positive divisor: float reciprocal and a one-step fix-up,
-// a third of the instructions of the compiler's signed 32-bit division (~30 dependent VALU operations, 0.1 us of a lone wave
-// each) -- the link indexes its small matrices by flat thread indices in every phase, dozens of divisions on the step's serial path.
-__device__ __forceinline__ int idiv_s(int e, int d, int& rem) {
-    int q = (int)((float)e * __builtin_amdgcn_rcpf((float)d));   // (v_rcp_f32: 1 ulp, the fix-up below covers it)
-    int r = e - q * d;
-    q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
-    rem = e - q * d;
-    return q;
-}
-
 // Batched global -> LDS copies: up to six segments are treated as one index space; every thread requests all its
 // elements (MAXV per round) before the first one is consumed, so the whole batch costs ONE memory round trip instead
 // of one per segment (the first version copied segment after segment: ~1 us each on this serial path).

@@ -288,6 +288,17 @@ __device__ __forceinline__ double gj_wave(double (&a)[DT], double* colbuf, int l
     return det;
 }
 
+// Quotient and remainder of a small non-negative index (e < 2^22) by a positive divisor: float reciprocal and a one-step fix-up,
+// a third of the instructions of the compiler's signed 32-bit division (~30 dependent VALU operations, 0.1 us of a lone wave
+// each) -- the link indexes its small matrices by flat thread indices in every phase, dozens of divisions on the step's serial path.
+__device__ __forceinline__ int idiv_s(int e, int d, int& rem) {
+    int q = (int)((float)e * __builtin_amdgcn_rcpf((float)d));   // (v_rcp_f32: 1 ulp, the fix-up below covers it)
+    int r = e - q * d;
+    q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+    rem = e - q * d;
+    return q;
+}
+
 // ------------------------------------------------------------------ rewards
 // Unpivoted Gauss-Jordan for symmetric positive definite systems on an n x nc augmented
 // matrix in LDS (ping-pong buffers, one barrier per pivot, one element per thread when
@@ -296,13 +307,20 @@ __device__ inline double* gauss_jordan_spd(double* G0, double* G1, int n, int nc
     double* cur = G0;
     double* nxt = G1;
     det = 1.0;
+    // (the reward workgroup is the last of the head launch to finish: the element's row / column come from a cheap index
+    // division made once, the pivot row is scaled by a reciprocal -- estimate + two Newton steps -- instead of ~30 dependent
+    // operations of an IEEE division per element and pivot)
+    int r0, c0;
+    r0 = idiv_s((int)threadIdx.x, nc, c0);
     for (int k = 0; k < n; ++k) {
         __syncthreads();
         const double piv = cur[k * nc + k];
         det *= piv;
+        const double rp = fast_rcp(piv);
         for (int e = threadIdx.x; e < n * nc; e += blockDim.x) {
-            const int r = e / nc, c = e - r * nc;
-            const double pk = cur[k * nc + c] / piv;
+            int r = r0, c = c0;
+            if (e != (int)threadIdx.x) r = idiv_s(e, nc, c);
+            const double pk = cur[k * nc + c] * rp;
             nxt[e] = (r == k) ? pk : fma(-cur[r * nc + k], pk, cur[r * nc + c]);
         }
         double* tmp = cur;
@@ -338,31 +356,33 @@ __device__ inline double exp_reward_moment(const RewardDev& rw, int E, double sc
             y[k] = acc;
         }
         for (int e2 = t; e2 < E * r; e2 += blockDim.x) {
-            const int e = e2 / r, k = e2 - e * r;
+            int k;
+            const int e = idiv_s(e2, r, k);
             double acc = 0.0;
             _Pragma("unroll 8") for (int f = 0; f < E; ++f) acc = fma(sx[e * E + f], Fl[f * r + k], acc);
             SF[e2] = acc;
         }
         __syncthreads();
         for (int e2 = t; e2 < r * r; e2 += blockDim.x) {
-            const int k = e2 / r, l = e2 - k * r;
+            int l;
+            const int k = idiv_s(e2, r, l);
             double acc = 0.0;
             _Pragma("unroll 8") for (int e = 0; e < E; ++e) acc = fma(Fl[e * r + k], SF[e * r + l], acc);
             A[e2] = fma(scale, acc, (k == l) ? 1.0 : 0.0);
         }
         __syncthreads();
-        // [A | y] -> A^{-1} y; A is SPD so no pivoting is needed
-        double* G0 = SF;             // SF is dead from here on: reuse as the augmented matrix
+        // [A | y] -> A^{-1} y; A is SPD so no pivoting is needed.  The augmented matrix is built in G1 and the elimination
+        // ping-pongs from there into SF (dead since the barrier above): no copy and no barrier of its own for that
+        double* G0 = SF;             // [E*(E+1)] fits E*E + ... (r <= E: r (r + 1) <= E*E + E: SF and the head of A)
         double* G1 = A + E * E;      // [E*(E+1)]
         const int nc = r + 1;
         for (int e2 = t; e2 < r * nc; e2 += blockDim.x) {
-            const int k = e2 / nc, l = e2 - k * nc;
+            int l;
+            const int k = idiv_s(e2, nc, l);
             G1[e2] = (l < r) ? A[k * r + l] : y[k];
         }
-        __syncthreads();
-        for (int e2 = t; e2 < r * nc; e2 += blockDim.x) G0[e2] = G1[e2];
         double det;
-        const double* res = gauss_jordan_spd(G0, G1, r, nc, det);
+        const double* res = gauss_jordan_spd(G1, G0, r, nc, det);
         if (t == 0) {
             double q = 0.0;
             for (int k = 0; k < r; ++k) q = fma(y[k], res[k * nc + r], q);

@@ -1991,6 +1991,46 @@ def test_bench_ranks_in_separate_processes_peer_exchange_on_one_gpu(world):
     assert d["verified"]["max_rel_err"]["S_H"] < 1e-5 and d["verified"]["max_rel_err"]["reward"] < 1e-5
 
 
+@pytest.mark.parametrize("D", [3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14])
+@pytest.mark.parametrize("N", [155, 300])
+def test_value_and_gradient_rollout_is_stable_over_contraction_depths(D, N):
+    """Every instantiation of the reverse sweep the Jacobian tape can take (contraction depths K = 4 .. 16, with v_j inside the
+    contraction or as the chain's accumulator; N = 155: sweep launches of a small model with set_small_step(0), N = 300: the
+    ordinary launch sequence): the value of a value-and-gradient rollout -- taken from the SWEEP's own sums -- against the
+    forward rollout's reward, five repetitions bitwise equal, and the first gradient entry against a central difference.
+    (Round 5: an unrelated scalar division inserted into the sweep's loop made the K = 8 instantiation return wrong,
+    run-to-run different sums; only the seeded shape sweep noticed.  This test pins every depth.)"""
+    from pilco_amd import _lib
+    E = max(1, D - 2)
+    U = D - E
+    rs = np.random.RandomState(100 * D + N)
+    X = rs.randn(N, D)
+    Y = 0.3 * np.sin(X @ rs.randn(D, E)) + 1e-2 * rs.randn(N, E)
+    cx = _lib.Context(device=0)
+    try:
+        cx.set_small_step(0)
+        cx.gp_set_data(0, X, Y)
+        cx.gp_set_hyp(0, 0.8 + rs.rand(E, D), 0.3 + rs.rand(E), 1e-2 * np.ones(E))
+        cx.gp_factorize(0)
+        W, b = 0.5 * rs.randn(U, E), 0.3 * rs.randn(U)
+        pol = dict(kind=_lib.POLICY_LINEAR, state_dim=E, control_dim=U, W=W, b=b, max_action=1.2, squash=True)
+        rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(E), t=np.zeros(E))]
+        m0, S0, H = 0.2 * rs.randn(1, E), 0.05 * np.eye(E), 4
+        fwd = cx.rollout(pol, rw, m0, S0, H)[2][0, 0]
+        runs = [cx.rollout_grad(pol, rw, m0, S0, H) for _ in range(5)]
+        for r in runs[1:]:
+            assert r[0] == runs[0][0] and np.array_equal(r[1], runs[0][1]) and np.array_equal(r[2], runs[0][2])
+        np.testing.assert_allclose(runs[0][0], fwd, rtol=1e-9)
+        h = 1e-5
+        Wp, Wm = W.copy(), W.copy()
+        Wp[0, 0] += h
+        Wm[0, 0] -= h
+        fd = (cx.rollout(dict(pol, W=Wp), rw, m0, S0, H)[2][0, 0] - cx.rollout(dict(pol, W=Wm), rw, m0, S0, H)[2][0, 0]) / (2 * h)
+        np.testing.assert_allclose(np.asarray(runs[0][1])[0, 0], fd, rtol=2e-5, atol=1e-8)
+    finally:
+        cx.close()
+
+
 _FUZZ_N = [1, 2, 3, 15, 16, 17, 31, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300]
 
 
