@@ -97,6 +97,8 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     ENSURE(s.w_part, std::max((size_t)PLa * wk.NT * 2, (size_t)std::max(wk.sk_pls, 16) * std::max(wk.sk_maxw, 4)));
     ENSURE(s.w_fpart, (size_t)2 * PLa * wk.NCH * 4 * 2);   // (up to four column splits per row chunk)
     wk.fuse_pair = 0;
+    wk.wt_R = wt_rows_per_pair_of(E, D, wk.PL);
+    wk.wt_deal = (wk.wt_R <= mm_prep_dt(D) && npad / wk.NCH <= 256) ? 1 : 0;
     wk.NCS = 1;
     wk.share_cu = 0;
     ENSURE(s.w_gath, (size_t)W * wk.SEG);

@@ -11,8 +11,9 @@ namespace pilco {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // row of output a in the (gathered) beta buffer / block of output a in this rank's iK (see MMModel)
-__device__ __forceinline__ long mm_beta_row(const MMModel& md, int a) { return (long)((a % md.bW) * md.bEL + a / md.bW); }
-__device__ __forceinline__ long mm_ik_blk(const MMModel& md, int a) { return (long)(a / md.bW); }
+// (one rank: the identity -- without two signed divisions in every prologue that asks)
+__device__ __forceinline__ long mm_beta_row(const MMModel& md, int a) { return md.bW == 1 ? (long)a : (long)((a % md.bW) * md.bEL + a / md.bW); }
+__device__ __forceinline__ long mm_ik_blk(const MMModel& md, int a) { return md.bW == 1 ? (long)a : (long)(a / md.bW); }
 
 // local pair index -> outputs (a >= b); see the dealing order in moment.h
 __device__ __forceinline__ void local_pair_ab(const MMWork& wk, int E, int pl, int& a, int& b) {
@@ -64,11 +65,10 @@ __device__ __forceinline__ const double* colop_row(const PairOps& po, int npad, 
 // Not dealt -- the first local pair with column b writes the whole block, pair_writes_wt -- when a pair would get more
 // rows than the workgroup has slots for their constants (few pairs on many ranks), when a chunk is longer than the stage, and in the one-launch small step with
 // its operands in memory, where every pair owns a block.
-__device__ __forceinline__ int wt_rows_per_pair(const MMWork& wk, int E, int D) { return (E * D + (wk.PL > 1 ? wk.PL : 1) - 1) / (wk.PL > 1 ? wk.PL : 1); }
-template <int DT>
-__device__ __forceinline__ bool wt_rows_dealt(const MMWork& wk, int E, int D, int npad) {
-    return !wk.fuse_pair && wt_rows_per_pair(wk, E, D) <= DT && npad / wk.NCH <= 256;   // (... and every row of the chunk is in the workgroup's stage)
-}
+// (both decided on the host when the workspace is built -- MMWork::wt_R, wt_deal --: rows per pair = ceil(E D / PL); dealt when
+// that fits the workgroup's DT slots and every row of a chunk is in its stage, npad / NCH <= 256)
+__device__ __forceinline__ int wt_rows_per_pair(const MMWork& wk) { return wk.wt_R; }
+__device__ __forceinline__ bool wt_rows_dealt(const MMWork& wk) { return !wk.fuse_pair && wk.wt_deal; }
 // Does local pair pl = (a, b) write the column block of output b this step?  The FIRST local pair with that column does:
 // (b, b) when this rank owns it (diagonal pairs come first in the dealing order), else the off-diagonal (a', b) with the
 // smallest a' it owns.  (One-launch small step with operands in memory: every pair writes its own block.)
@@ -90,6 +90,14 @@ __device__ __forceinline__ void store_wt(double* p, double v) {
     do {                                                                       \
         if ((wk_).dbg && (cond_)) (wk_).dbg[slot_] = wall_clock64();          \
     } while (0)
+
+// stamps INSIDE the per-point operand code (tools/head_phases.py): a developer build only (-DHEAD_ROW_STAMPS) -- the test
+// for the stamp buffer in that code costs the one-launch small step 0.3 us (config 4: 1422 -> 1398 rollouts/s)
+#ifdef HEAD_ROW_STAMPS
+#define DBG_STAMP_ROW(wk_, slot_, cond_) DBG_STAMP(wk_, slot_, cond_)
+#else
+#define DBG_STAMP_ROW(wk_, slot_, cond_) do { } while (0)
+#endif
 
 // hipcc (ROCm 7.2) lets the destination registers of v_mfma_f64_16x16x4_f64 overlap its A / B source registers when
 // the accumulator input is the inline constant 0 and a source dies at that instruction; the hardware then reads the

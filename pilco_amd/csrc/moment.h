@@ -47,6 +47,8 @@ struct MMWork {
     double* vcol;        // [PL][npad]  v_j of every pair, in the SAME allocation as Wt (behind its blocks: one buffer resource reaches
                          //   both): row D + 1 of B or -- vsep (D + 2 = 1 mod 4: K = D + 1) -- added on the VALU after the contraction
     int vsep;
+    int wt_R, wt_deal;   // the w rows of all column blocks dealt over the local pairs, wt_R rows each (wt_deal: 1 when they are dealt,
+                         // mm_device.h: wt_rows_dealt) -- taken on the host: a signed division is ~40 dependent operations of the head's serial path
     double* pair_isdet;  // [PL]     1/sqrt(det R_ab)
     double* mean_part;   // [EL][NCHM][1+D]  per row chunk: c_a g and c_a T_a h (contributions to M_a, V_a)
     double* pair_part;   // [PL][NT][2]
@@ -183,6 +185,8 @@ size_t glue_lds_bytes(int E, int D);
 // tile-partial counts per pair for a variant (NT) and the number of row chunks of the prep kernel
 int mm_pair_nt(int npad, int variant, int PL);
 void mm_prep_chunks(int npad, int PL, int EL, int* nch, int* nchm);
+inline int wt_rows_per_pair_of(int E, int D, int PL) { return (E * D + (PL > 1 ? PL : 1) - 1) / (PL > 1 ? PL : 1); }
+int mm_prep_dt(int D);   // the operand kernel's instantiation (DT >= D) for this input dimension
 // the contraction stops at K = D + 1 and v_j is added after it when D + 2 = 1 (mod 4) (saves a whole MFMA k-step)
 __host__ __device__ constexpr bool mm_vsep(int D) { return (D + 2) % 4 == 1; }
 __host__ __device__ constexpr int mm_kp(int D) { return mm_vsep(D) ? D + 1 : (D + 2 + 3) / 4 * 4; }

@@ -32,6 +32,7 @@ void mm_prep_chunks(int npad, int PL, int EL, int* nch_out, int* nchm_out) {
 static int prep_dt(int D) {   // the operand kernel's instantiation for this input dimension (see the dispatch below)
     return D <= 4 ? 4 : D <= 6 ? 6 : D <= 8 ? 8 : D <= 10 ? 10 : D == 11 ? 11 : D <= 12 ? 12 : D <= 14 ? 14 : D <= 16 ? 16 : 32;
 }
+int mm_prep_dt(int D) { return prep_dt(D); }
 // Does the fused head (serial link + operands in one workgroup) fit the CU's LDS for this model / policy / reward set?
 // Wide inputs (D > 24 with many outputs) do not: the rollout then runs the three-kernel step (same results).
 bool mm_fused_head_fits(const MMModel& md, int reward_E, const GlueArgs& ga) {

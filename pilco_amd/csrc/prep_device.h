@@ -21,8 +21,8 @@ __host__ __device__ constexpr size_t prep_region_doubles(int DT) {   // the oper
 // 1 / l^2 of the w rows dealt to local pair pl (mm_device.h: wt_rows_per_pair), into the pair workgroup's `colbuf` [DT]
 template <int DT>
 __device__ __forceinline__ void prep_wt_constants(const MMModel& md, const MMWork& wk, int pl, double* sm) {
-    const int R = wt_rows_per_pair(wk, md.E, md.D), t = threadIdx.x;
-    if (wt_rows_dealt<DT>(wk, md.E, md.D, md.npad) && t < R && pl * R + t < md.E * md.D) {
+    const int R = wt_rows_per_pair(wk), t = threadIdx.x;
+    if (wt_rows_dealt(wk) && t < R && pl * R + t < md.E * md.D) {
         const double l = md.ls[pl * R + t];
         sm[3 * DT + 2 * DT * DT + 4 + t] = 1.0 / (l * l);
     }
@@ -395,7 +395,7 @@ __device__ __forceinline__ void small_sweep(const MMModel& md, const MMWork& wk,
 // the host workgroup; the work is laid out for 512, wider workgroups keep their extra waves idle between the barriers.
 template <int DT, bool FUSED, int NTHR, bool FPAIR = false, bool PRE = false>
 __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, const PrepReward& pr, const GlueArgs& g, const GlueLds& L,
-                                          double* sm_all, int glue_doubles, int bx, int by, int gx, int gy, double pre_la, double pre_lb,
+                                          double* sm_all, int glue_doubles, int bx, int by, int gx, int gy, int pair_a, int pair_b, double pre_la, double pre_lb,
                                           double pre_var) {
     double* sm = sm_all + (FUSED ? glue_doubles : 0);
     // the Gaussian this launch's operands are built for: the joint (x, u) the link assembled, or -- policy head of an
@@ -546,14 +546,13 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
     // what this workgroup writes to memory (layout: MMWork::At / Wt): the pair's (2 Q z_i | u_i) rows and v_j always; the
     // w rows of the pair's column block only when this pair is the block's writer this step (every pair with the same column
     // output computes the same w_j: P / E workgroups used to store identical values, half of the head's write-through traffic)
-    int pa_, pb_;
-    local_pair_ab(wk, md.E, pl, pa_, pb_);
+    const int pa_ = pair_a, pb_ = pair_b;   // (from the caller, found before the link)
     double* At = wk.At + (long)pl * KP * npad;
     double* Wb = wk.Wt + (long)pair_col_block(wk, pl, pb_) * KP * npad;
     double* vrow = wk.vcol + (long)pl * npad;
-    const bool wt_dealt = wt_rows_dealt<DT>(wk, md.E, D, npad);
+    const bool wt_dealt = wt_rows_dealt(wk);
     const bool wt_writer = !wt_dealt && pair_writes_wt(wk, md.E, pa_, pb_);
-    const int wt_R = wt_rows_per_pair(wk, md.E, D);
+    const int wt_R = wt_rows_per_pair(wk);
     auto row = [&](const int i, const bool valid, const double (&zeta)[DT]) {
         // y = Q x by columns of the symmetric Q: DT independent accumulators, one wide LDS row
         // read per column step (no LDS latency on the FMA chains).
@@ -566,6 +565,7 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
             kk = fma(-0.5 * zeta[d], x[d], kk);
             y[d] = 0.0;
         }
+        DBG_STAMP_ROW(wk, 34, dbg0);
 #pragma unroll
         for (int c = 0; c < DT; ++c) {
             double qrow[DT];
@@ -578,6 +578,7 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
         double quad = 0.0;
 #pragma unroll
         for (int r = 0; r < DT; ++r) quad = fma(x[r], y[r], quad);
+        DBG_STAMP_ROW(wk, 35, dbg0);
         const double uv = valid ? (kk + quad) : 0.0;
         const double one = valid ? 1.0 : 0.0;
         if (fplds) {   // (workgroup-uniform) the same operands into LDS: nobody else reads them
@@ -620,7 +621,8 @@ __device__ __forceinline__ void prep_work(const MMModel& md, const MMWork& wk, c
                 for (int q = 0; q < wt_R; ++q) {
                     const int rr = pl * wt_R + q;
                     if (rr >= md.E * D) break;
-                    const int bb = rr / D, dd = rr - bb * D;
+                    int dd;
+                    const int bb = idiv_s(rr, D, dd);
                     store_wt(&wk.Wt[((long)bb * KP + dd) * npad + i], zst[(i - st_begin) * LDZ + dd] * colbuf[q]);
                 }
             }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512, OCC2 ? 4 : 2) void k_mm_prep(MMModel md, MMWor
         }
     }
     if (FUSED) glue_body<PK, SR>(g, L, bxi == 0 && blockIdx.y == 0);
-    prep_work<DT, FUSED, 512, FUSED && SR && PK != 1, PRE>(md, wk, pr, g, L, sm_all, glue_doubles, bxi, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, pre_la,
+    prep_work<DT, FUSED, 512, FUSED && SR && PK != 1, PRE>(md, wk, pr, g, L, sm_all, glue_doubles, bxi, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, a, b, pre_la,
                               pre_lb, pre_var);
 }
 
