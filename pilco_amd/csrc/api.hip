@@ -257,12 +257,11 @@ int agree_not_pd(pilco_ctx* ctx, int W, int bad, int* agreed) {
 int factorize_exact(pilco_ctx* ctx, Slot& s) {
     OwnView o{};
     if (int r = prepare_own(ctx, s, o)) return r;
-    const int EL = o.EL, ELa = std::max(EL, 1), npad = s.Npad, nblk = npad / NB;
+    const int EL = o.EL, ELa = std::max(EL, 1), npad = s.Npad;
     const size_t mat = (size_t)npad * npad;
     ENSURE(s.K, ELa * mat);
     ENSURE(s.Linv, ELa * mat);
     ENSURE(s.iK, ELa * mat);
-    ENSURE(s.invD, (size_t)ELa * nblk * NB * NB);
     ENSURE(s.beta, (size_t)o.W * o.ELcap * npad);
     ENSURE(s.vec, (size_t)ELa * npad);
     hipStream_t st = ctx->st;
@@ -270,7 +269,7 @@ int factorize_exact(pilco_ctx* ctx, Slot& s) {
     // ~50 launches whose sequence depends only on the sizes: replayed as ONE graph launch (mgpr.py:81-89 is paid per
     // evaluation of optimize_models' objective; eager, the launches' host time was 20 % of the whole on a slower host)
     const std::vector<unsigned long long> key = {(unsigned long long)(uintptr_t)s.K.p, (unsigned long long)(uintptr_t)s.Linv.p,
-        (unsigned long long)(uintptr_t)s.iK.p, (unsigned long long)(uintptr_t)s.invD.p, (unsigned long long)(uintptr_t)s.beta.p,
+        (unsigned long long)(uintptr_t)s.iK.p, (unsigned long long)(uintptr_t)s.beta.p,
         (unsigned long long)(uintptr_t)s.vec.p, (unsigned long long)(uintptr_t)s.Xt.p, (unsigned long long)(uintptr_t)o.ls,
         (unsigned long long)(uintptr_t)o.var, (unsigned long long)(uintptr_t)o.noise, (unsigned long long)(uintptr_t)o.Yt,
         (unsigned long long)(uintptr_t)ctx->d_info, (unsigned long long)npad, (unsigned long long)s.N, (unsigned long long)s.D,
@@ -280,8 +279,8 @@ int factorize_exact(pilco_ctx* ctx, Slot& s) {
     if (o.W > 1) HIPCHK(hipMemsetAsync(s.beta.p, 0, sizeof(double) * (size_t)o.W * o.ELcap * npad, st));
     if (EL > 0) {
         launch_gram(st, s.Xt.p, npad, s.N, s.Xt.p, npad, s.N, s.D, o.ls, o.var, EL, s.K.p, npad, npad, 1, o.noise, 0.0);
-        launch_potrf(st, s.K.p, npad, EL, s.invD.p, ctx->d_info);
-        launch_trtri(st, s.K.p, npad, EL, s.invD.p, s.Linv.p, s.iK.p, (long)mat);   // iK is free until the next GEMM
+        launch_potrf(st, s.K.p, npad, EL, s.Linv.p, ctx->d_info, false);   // (nobody below reads L^-1 above its diagonal tiles: not zeroed)
+        launch_trtri(st, s.K.p, npad, EL, s.Linv.p, s.iK.p, (long)mat);    // iK is free until the next GEMM
         GemmDesc g{};
         g.A = s.Linv.p; g.lda = npad; g.sA = (long)mat;
         g.B = s.Linv.p; g.ldb = npad; g.sB = (long)mat;
@@ -369,8 +368,8 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
         for (ChainGraph* cg : {&sl.g_fact, &sl.g_fitc, &sl.g_fitc_nlml}) chain_graph_release(*cg);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
-        for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.invD, &s.beta, &s.Tscr, &s.ksplit_ws,
-                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.jac_rowmom, &s.jac_cpart, &s.jac_head, &s.jac_part, &s.jac_np, &s.own, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Wt, &s.w_ones, &s.w_small, &s.w_fpart,
+        for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.beta, &s.Tscr, &s.ksplit_ws,
+                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.jac_rowmom, &s.jac_cpart, &s.jac_head, &s.jac_part, &s.jac_np, &s.own, &s.Am, &s.AmInv, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Wt, &s.w_ones, &s.w_small, &s.w_fpart,
                           &s.w_part, &s.w_gath, &s.w_out, &s.ft_P, &s.ft_T3, &s.ft_Z})
             b->release();
     }
@@ -883,16 +882,14 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     Slot& s = *static_cast<Slot*>(slot_ptr);
     OwnView o{};
     if (int r = prepare_own(ctx, s, o)) return r;
-    const int E = std::max(o.EL, 1), EL = o.EL, Mp = s.npad, Np = s.Npad, nblk = Mp / NB;   // E: batch of OWNED outputs
+    const int E = std::max(o.EL, 1), EL = o.EL, Mp = s.npad, Np = s.Npad;   // E: batch of OWNED outputs
     const size_t mm = (size_t)Mp * Mp, mn = (size_t)Mp * Np;
     ENSURE(s.K, E * mm);        // Kmm -> L
     ENSURE(s.Linv, E * mm);
     ENSURE(s.iK, E * mm);
-    ENSURE(s.invD, (size_t)E * nblk * NB * NB);
     ENSURE(s.Kmn, E * mn);      // Kmn -> V
     ENSURE(s.Am, E * mm);
     ENSURE(s.AmInv, E * mm);
-    ENSURE(s.AmD, (size_t)E * nblk * NB * NB);
     ENSURE(s.iAt, E * mm);
     ENSURE(s.G, (size_t)E * Np);
     ENSURE(s.beta, (size_t)o.W * o.ELcap * Mp);
@@ -918,7 +915,7 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     }
     // one graph launch for the whole sequence (smgpr.py:24-45 is paid per evaluation of the sparse model's objective)
     std::vector<unsigned long long> key;
-    for (const DevBuf* b : {&s.K, &s.Linv, &s.iK, &s.invD, &s.Kmn, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.G, &s.beta, &s.Tscr, &s.vec, &s.V2,
+    for (const DevBuf* b : {&s.K, &s.Linv, &s.iK, &s.Kmn, &s.Am, &s.AmInv, &s.iAt, &s.G, &s.beta, &s.Tscr, &s.vec, &s.V2,
                             &s.ksplit_ws, &s.Zt, &s.Xt})
         key.push_back((unsigned long long)(uintptr_t)b->p);
     for (const void* q : {(const void*)o.ls, (const void*)o.var, (const void*)o.noise, (const void*)o.Yt, (const void*)ctx->d_info})
@@ -930,8 +927,8 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     // smgpr.py:27-28: Kmm = K(Z) + 1e-6 I, Kmn = K(Z, X)
     launch_gram(st, s.Zt.p, Mp, s.M, s.Zt.p, Mp, s.M, s.D, o.ls, o.var, E, s.K.p, Mp, Mp, 2, nullptr, 1e-6);
     launch_gram(st, s.Zt.p, Mp, s.M, s.Xt.p, Np, s.N, s.D, o.ls, o.var, E, s.Kmn.p, Mp, Np, 0, nullptr, 0.0);
-    launch_potrf(st, s.K.p, Mp, E, s.invD.p, ctx->d_info);                      // smgpr.py:29
-    launch_trtri(st, s.K.p, Mp, E, s.invD.p, s.Linv.p, s.Tscr.p, (long)Mp * Mp);
+    launch_potrf(st, s.K.p, Mp, E, s.Linv.p, ctx->d_info, true);                // smgpr.py:29
+    launch_trtri(st, s.K.p, Mp, E, s.Linv.p, s.Tscr.p, (long)Mp * Mp);
     GemmDesc g{};
     // V = L^{-1} Kmn  (smgpr.py:30) -- out of place into vec? Kmn is (Mp, Np): use iAt-sized scratch is too small, so
     // write V into a second Kmn-sized buffer: reuse s.Am? no (Mp x Mp).  V goes to s.Kmn2 = s.vec is too small -> allocate.
@@ -952,8 +949,8 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     g.tile_mode = 2;   // V V^T is symmetric: lower tiles + mirror images
     launch_gemm(st, g, false, true, E);
     launch_add_diag(st, s.Am.p, Mp, E, o.noise);
-    launch_potrf(st, s.Am.p, Mp, E, s.AmD.p, ctx->d_info + 32);
-    launch_trtri(st, s.Am.p, Mp, E, s.AmD.p, s.AmInv.p, s.Tscr.p, (long)Mp * Mp);
+    launch_potrf(st, s.Am.p, Mp, E, s.AmInv.p, ctx->d_info + 32, true);
+    launch_trtri(st, s.Am.p, Mp, E, s.AmInv.p, s.Tscr.p, (long)Mp * Mp);
     // iAt = (L Am)^{-1} = Am^{-1} L^{-1}  (smgpr.py:36-37)
     g = GemmDesc{};
     g.A = s.AmInv.p; g.lda = Mp; g.sA = (long)mm;

@@ -117,15 +117,17 @@ struct GemmDesc {
     long ssA, ssB, ssC; // sub-problem strides (doubles)
     int sub_rows0, sub_rows_step;  // sub-problem q only has rows < sub_rows0 - q * sub_rows_step (row tiles past that are skipped)
     // Cholesky chain (launch_potrf): the workgroup of tile (0, 0) factors and inverts that tile afterwards -- diagonal block
-    // potf2_kb of potf2_nblk; inverse to potf2_invD[matrix][potf2_kb][64][64], first bad pivot to potf2_info[matrix]
+    // potf2_kb; its inverse goes to the same diagonal block of potf2_X (the L^-1 buffer: [matrix][ldx][ldx], matrix stride
+    // potf2_sX), first bad pivot to potf2_info[matrix]
     // split K (long-K products of the FITC path: K = N = 5000 against 16 tiles per matrix left every tile a chain of 316
     // chunks): K is cut in ksplit slices, each (matrix, slice) computes its partial product into split_ws
     // [ksplit][batch][M][N], and a second launch adds the slices up in their order (deterministic).  nsub must be 0.
     int ksplit;
     double* split_ws;
-    double* potf2_invD;
+    double* potf2_X;
+    long potf2_sX;
     int* potf2_info;
-    int potf2_kb, potf2_nblk;
+    int potf2_kb;
 };
 constexpr int FITC_KSPLIT = 16;   // K slices of the FITC path's M x M products over the N data points
 // C = alpha * op(A) op(B) + beta * C, batched; op selected by ta/tb (0 = as stored, 1 = transposed)
@@ -141,10 +143,13 @@ void launch_gram(hipStream_t st, const double* P1t, int ld1, int n1, const doubl
 // Blocked Cholesky (lower) of batch matrices A[b] (npad x npad, ld = npad), in place; strictly-upper part zeroed.
 // invD receives the inverses of the diagonal 64x64 blocks of L: [batch][npad/64][64][64].
 // info[b] = 0 or 1-based index of the first non-positive pivot.
-void launch_potrf(hipStream_t st, double* A, int npad, int batch, double* invD, int* info);
-// Linv = L^{-1} (lower), using invD from launch_potrf; T is scratch, batch matrices of tstride >= npad*npad/2 doubles.
-void launch_trtri(hipStream_t st, const double* L, int npad, int batch, const double* invD, double* Linv, double* T,
-                  long tstride);
+// ... and the inverses of L's 64 x 64 diagonal blocks go straight into the diagonal blocks of Linv ([batch][npad][npad]), where
+// launch_trtri builds on them (rounds 1-4: into a buffer of their own, copied over by a launch).  zero_linv: Linv is zeroed
+// first -- needed when somebody reads Linv's tiles ABOVE the diagonal (plain GEMMs of the FITC path); the exact path's
+// consumers (launch_trtri, the k_mode 1 product iK = Linv^T Linv, launch_matvec) never do, and skip 12 us at C2.
+void launch_potrf(hipStream_t st, double* A, int npad, int batch, double* Linv, int* info, bool zero_linv);
+// Linv = L^{-1} (lower), completing the diagonal blocks launch_potrf left there; T is scratch, batch matrices of tstride >= npad*npad/2 doubles.
+void launch_trtri(hipStream_t st, const double* L, int npad, int batch, double* Linv, double* T, long tstride);
 // y = op(A) x, A [batch][npad][npad], x,y [batch][npad]
 void launch_matvec(hipStream_t st, const double* A, int npad, int batch, const double* x, double* y, bool trans);
 // zero rows/cols >= n of batch square matrices

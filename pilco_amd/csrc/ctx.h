@@ -34,9 +34,9 @@ struct Slot {
     DevBuf bwd_mom, bwd_cp, bwd_part, bwd_out, bwd_cnt; // reverse-pass scratch (bwd_cnt: the finished-workgroups counter)
     DevBuf jac_rowmom, jac_cpart, jac_head, jac_part, jac_np;   // Jacobian tape: per-step sweep outputs [H][..], N_ab tile partials
     DevBuf Xt, Yt, Zt, ls, var, noise;         // Yt: [E][Npad]
-    DevBuf K, Linv, iK, invD, beta, Tscr, vec; // factorisation
+    DevBuf K, Linv, iK, beta, Tscr, vec;       // factorisation
     DevBuf ksplit_ws;                          // partial products of the split-K GEMMs of the FITC path (GemmDesc::split_ws)
-    DevBuf Kmn, V2, Am, AmInv, AmD, iAt, G;    // FITC extras
+    DevBuf Kmn, V2, Am, AmInv, iAt, G;         // FITC extras
     DevBuf ft_P, ft_T3, ft_Z;                  // FITC training objective (fitc_train.hip)
     // sharded factorisation (8e): this rank factorises only its outputs a = rank, rank + shW, ...; `own` holds their
     // hyper-parameters and targets compacted ([EL][D] | [EL] | [EL] | [EL][Npad]); beta is all-gathered afterwards

@@ -183,7 +183,7 @@ using namespace pilco;
 static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, const double* o_var, const double* o_noise, const double* o_Yt,
                            const double* Z_all, int M, double* nlml, double* grad_hyp, double* grad_Z) {
     HIPCHK(hipSetDevice(ctx->device));
-    const int D = s.D, N = s.N, Np = s.Npad, Mp = round_up(M, NB), nblk = Mp / NB;
+    const int D = s.D, N = s.N, Np = s.Npad, Mp = round_up(M, NB);
     const size_t mm = (size_t)Mp * Mp, mn = (size_t)Mp * Np;
     hipStream_t st = ctx->st;
     // the slot's FITC buffers are scratch here; whatever factorisation the slot held is invalidated
@@ -191,12 +191,10 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     s.user_factors = false;
     ENSURE(s.K, E * mm);
     ENSURE(s.Linv, E * mm);
-    ENSURE(s.invD, (size_t)E * nblk * NB * NB);
     ENSURE(s.Kmn, E * mn);      // A' = Luu^-T Vb
     ENSURE(s.V2, E * mn);       // Kuf -> V -> Vb
     ENSURE(s.Am, E * mm);
     ENSURE(s.AmInv, E * mm);
-    ENSURE(s.AmD, (size_t)E * nblk * NB * NB);
     ENSURE(s.iAt, E * mm);
     ENSURE(s.ksplit_ws, (size_t)FITC_KSPLIT * E * mm);
     ENSURE(s.iK, E * mm);       // DKuu
@@ -223,7 +221,7 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     double* part_uu = part_uf + (size_t)E * Mp * (2 * FT_MAXD + 1);
     // everything between the upload of Z and the downloads is a fixed launch sequence (~80 launches at M = 200): one graph
     std::vector<unsigned long long> key;
-    for (const DevBuf* b : {&s.K, &s.Linv, &s.invD, &s.Kmn, &s.V2, &s.Am, &s.AmInv, &s.AmD, &s.iAt, &s.ksplit_ws, &s.iK, &s.G, &s.Tscr, &s.ft_P,
+    for (const DevBuf* b : {&s.K, &s.Linv, &s.Kmn, &s.V2, &s.Am, &s.AmInv, &s.iAt, &s.ksplit_ws, &s.iK, &s.G, &s.Tscr, &s.ft_P,
                             &s.ft_T3, &s.ft_Z, &s.vec, &s.Xt})
         key.push_back((unsigned long long)(uintptr_t)b->p);
     for (const void* q : {(const void*)o_ls, (const void*)o_var, (const void*)o_noise, (const void*)o_Yt, (const void*)ctx->d_info})
@@ -234,8 +232,8 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     HIPCHK(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * 64, st));
     launch_gram(st, Zt, Mp, M, Zt, Mp, M, D, o_ls, o_var, E, Kuu, Mp, Mp, 2, nullptr, 1e-6, sZ, sZ);
     launch_gram(st, Zt, Mp, M, s.Xt.p, Np, N, D, o_ls, o_var, E, s.Kmn.p, Mp, Np, 0, nullptr, 0.0, sZ, 0);
-    launch_potrf(st, Kuu, Mp, E, s.invD.p, ctx->d_info);
-    launch_trtri(st, Kuu, Mp, E, s.invD.p, s.Linv.p, s.Tscr.p, (long)mm);
+    launch_potrf(st, Kuu, Mp, E, s.Linv.p, ctx->d_info, true);
+    launch_trtri(st, Kuu, Mp, E, s.Linv.p, s.Tscr.p, (long)mm);
     GemmDesc g{};
     g.A = s.Linv.p; g.lda = Mp; g.sA = (long)mm;            // V = Luu^-1 Kuf
     g.B = s.Kmn.p; g.ldb = Np; g.sB = (long)mn;
@@ -252,8 +250,8 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     g.tile_mode = 2;   // V V^T is symmetric: lower tiles + mirror images
     launch_gemm(st, g, false, true, E);
     launch_add_diag(st, s.Am.p, Mp, E, o_noise);
-    launch_potrf(st, s.Am.p, Mp, E, s.AmD.p, ctx->d_info + 32);          // Am = sn L
-    launch_trtri(st, s.Am.p, Mp, E, s.AmD.p, s.AmInv.p, s.Tscr.p, (long)mm);
+    launch_potrf(st, s.Am.p, Mp, E, s.AmInv.p, ctx->d_info + 32, true);  // Am = sn L
+    launch_trtri(st, s.Am.p, Mp, E, s.AmInv.p, s.Tscr.p, (long)mm);
     g = GemmDesc{};                                          // iAt = Am^-1 Luu^-1 = L^-1 Luu^-1 / sn
     g.A = s.AmInv.p; g.lda = Mp; g.sA = (long)mm;
     g.B = s.Linv.p; g.ldb = Mp; g.sB = (long)mm;

@@ -109,7 +109,7 @@ struct Potf2Lds {               // LDS of one block factorisation
     int published;              // columns of L wave 0 has put out
 };
 template <int NW>
-__device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A, int npad, int kb_abs, double* __restrict__ out,
+__device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A, int npad, int kb_abs, double* __restrict__ out, int out_ld,
                                             int* info_word, int lane, int w, unsigned long long* stp);
 
 // POTF2: the workgroup of tile (0, 0) goes on to factor and invert that tile (the next diagonal block of the Cholesky chain)
@@ -192,8 +192,7 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
     }
     // The next K chunk's global loads are in flight while the current one is multiplied (round 2 loaded, stored, multiplied
     // in turn: the memory round trip of every chunk was hidden by other workgroups only); same sums in the same order.
-    double2 pa0, pa1, pb0, pb1;
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int k0, double2& pa0, double2& pa1, double2& pb0, double2& pb1) {
         if (!TA) {  // A stored (M,K): rows contiguous along k
             const double* src = A + (long)(i0 + (t >> 2)) * g.lda + k0 + (t & 3) * 4;
             pa0 = *reinterpret_cast<const double2*>(src);
@@ -213,8 +212,7 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
             pb1 = *reinterpret_cast<const double2*>(src + 2);
         }
     };
-    if (kbeg < kend) fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    auto stage = [&](const double2& pa0, const double2& pa1, const double2& pb0, const double2& pb1) {
         if (!TA) {  // transposing write
             const int i = t >> 2, kq = (t & 3) * 4;
             As[kq + 0][i] = pa0.x;
@@ -237,8 +235,8 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
             Bs[kq + 2][j] = pb1.x;
             Bs[kq + 3][j] = pb1.y;
         }
-        __syncthreads();
-        if (k0 + 16 < kend) fetch(k0 + 16);
+    };
+    auto multiply = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 4) {
             const double a0 = As[kk + lr][wi + lc];
@@ -250,6 +248,15 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
+    };
+    // (K = 64 launches of the Cholesky chain with ALL FOUR chunks requested at once: no faster -- 0.896 vs 0.904 ms --, dropped)
+    double2 pa0, pa1, pb0, pb1;
+    if (kbeg < kend) fetch(kbeg, pa0, pa1, pb0, pb1);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        stage(pa0, pa1, pb0, pb1);
+        __syncthreads();
+        if (k0 + 16 < kend) fetch(k0 + 16, pa0, pa1, pb0, pb1);
+        multiply();
         __syncthreads();
     }
     // f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -276,8 +283,8 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
         Potf2Lds& S = *reinterpret_cast<Potf2Lds*>(sm);
         if (t == 0) S.published = 0;
         __syncthreads();
-        potf2_block<4>(S, C, ldc, g.potf2_kb, g.potf2_invD + ((long)mat * g.potf2_nblk + g.potf2_kb) * 4096, g.potf2_info + mat,
-                       lane, w, nullptr);
+        potf2_block<4>(S, C, ldc, g.potf2_kb, g.potf2_X + (long)mat * g.potf2_sX + (long)g.potf2_kb * 64 * (ldc + 1), ldc,
+                       g.potf2_info + mat, lane, w, nullptr);
     }
     // symmetric result: the tile above the diagonal is this one's mirror image -- turned around in LDS and stored as full rows
     // (stored straight from the accumulators it is 4096 scattered 8-byte writes per tile: as slow as computing it)
@@ -301,10 +308,10 @@ __global__ __launch_bounds__(256) void k_gemm_split_reduce(GemmDesc g, int batch
 void launch_gemm(hipStream_t st, const GemmDesc& g_in, bool ta, bool tb, int batch) {
     GemmDesc g = g_in;
     if (g.M <= 0 || g.N <= 0) return;
-    if (g.ksplit <= 1 || !g.split_ws || g.nsub > 0 || g.tile_mode == 1 || g.potf2_invD) g.ksplit = 0;   // (tile_mode 2: every slice is mirrored inside the workspace)
+    if (g.ksplit <= 1 || !g.split_ws || g.nsub > 0 || g.tile_mode == 1 || g.potf2_X) g.ksplit = 0;   // (tile_mode 2: every slice is mirrored inside the workspace)
     dim3 grid(g.N / 64, batch * (g.nsub > 0 ? g.nsub : 1) * (g.ksplit > 1 ? g.ksplit : 1), g.M / 64);
     if (!ta && !tb) hipLaunchKernelGGL((k_gemm64<false, false>), grid, dim3(256), 0, st, g);
-    if (!ta && tb && g.potf2_invD) hipLaunchKernelGGL((k_gemm64<false, true, true>), grid, dim3(256), 0, st, g);
+    if (!ta && tb && g.potf2_X) hipLaunchKernelGGL((k_gemm64<false, true, true>), grid, dim3(256), 0, st, g);
     else if (!ta && tb) hipLaunchKernelGGL((k_gemm64<false, true>), grid, dim3(256), 0, st, g);
     if (ta && !tb) hipLaunchKernelGGL((k_gemm64<true, false>), grid, dim3(256), 0, st, g);
     if (ta && tb) hipLaunchKernelGGL((k_gemm64<true, true>), grid, dim3(256), 0, st, g);
@@ -417,12 +424,159 @@ __device__ __forceinline__ void potf2_columns(double (&a)[64], Potf2State& st, d
 #else
 #define POTF2_STAMP(i_) do { } while (0)
 #endif
+#ifndef POTF2_BLOCKED
+#define POTF2_BLOCKED 1
+#endif
+#if POTF2_BLOCKED
+// The block is in S.Ls (row-major, row stride POTF2_LD) and every thread of the workgroup (FOUR waves) has passed a barrier
+// since.  Leaves L (zero above the diagonal) in the global block A and L^-1 in `out`; *info_word receives
+// kb_abs * 64 + column + 1 of the first non-positive pivot.
+//
+// Blocked inside the block (round 5), panels of 16 columns:
+//   factor: wave 0 holds row i's 16 panel entries in lane i and eliminates the panel's columns in registers (pivot and
+//     multipliers by v_readlane: avg 7.5 updates per column instead of 31 over the whole block); the rank-16 update of the
+//     columns behind the panel is MFMA work of all four waves on the LDS copy (6 / 3 / 1 tiles of 16 x 16).
+//     Rounds 3-4 eliminated all 64 columns in one wave's registers: 2016 fused multiply-adds and 1008 LDS reads issued by
+//     ONE wave, 16 us of the 20 us this block takes on the chain's critical path.
+//   inverse, in place behind the stored factor: the four 16 x 16 diagonal blocks by substitution in one wave (lane
+//     16 d + j: column j of block d), then two levels of recursive doubling, X_BA = -X_BB (L_BA X_AA), on MFMA; the product
+//     in brackets is staged in the block's unused upper-right quarter.
+//     (Rounds 3-4: a second wave ran the substitution over all 64 columns one column behind the factor wave.)
+__device__ __forceinline__ d4 potf2_tile_load(const double* Ls, int r0, int c0, int lr, int lc) {
+    d4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = Ls[(r0 + lr + 4 * r) * POTF2_LD + c0 + lc];
+    return v;
+}
+__device__ __forceinline__ void potf2_tile_store(double* Ls, int r0, int c0, int lr, int lc, d4 v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ls[(r0 + lr + 4 * r) * POTF2_LD + c0 + lc] = v[r];
+}
+// acc += sign * P Q for 16 x 16 blocks of the LDS copy: P at (pr, pc) read as rows, Q at (qr, qc) -- QT: Q^T, i.e. the
+// operand is the block at (qr, qc) read as rows too (the rank-16 update L L^T)
+template <bool QT>
+__device__ __forceinline__ d4 potf2_tile_mma(const double* Ls, int pr, int pc, int qr, int qc, double sign, d4 acc, int lr, int lc) {
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 4) {
+        const double a = sign * Ls[(pr + lc) * POTF2_LD + pc + kk + lr];
+        const double b = QT ? Ls[(qr + lc) * POTF2_LD + qc + kk + lr] : Ls[(qr + kk + lr) * POTF2_LD + qc + lc];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        if (kk == 0) {   // (a first MFMA on a constant-zero accumulator: see mm_device.h, MFMA_KEEP_ALIVE)
+            asm volatile("" ::"v"(a));
+            asm volatile("" ::"v"(b));
+        }
+    }
+    return acc;
+}
+template <int NW>
+__device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A, int npad, int kb_abs, double* __restrict__ out, int out_ld,
+                                            int* info_word, int lane, int w, unsigned long long* stp) {
+    static_assert(NW == 4, "four waves");
+    constexpr int LD = POTF2_LD;
+    (void)stp;
+    const int lr = lane >> 4, lc = lane & 15;
+    double* Ls = S.Ls;
+    int bad = 0;
+    if (w == 0) POTF2_STAMP(1);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c0 = 16 * p;
+        if (w == 0) {
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; c += 2) {
+                const double2 pr = *reinterpret_cast<const double2*>(&Ls[lane * LD + c0 + c]);
+                a[c] = (lane >= c0) ? pr.x : 0.0;
+                a[c + 1] = (lane >= c0) ? pr.y : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double d = lane_bcast(a[j], c0 + j);
+                const bool ok = d > 0.0;   // false for NaN too
+                bad = (!ok && bad == 0) ? kb_abs * 64 + c0 + j + 1 : bad;
+                d = ok ? d : 1.0;
+                const double rinv = rsqrt_f64(d);
+                const double l = (lane >= c0 + j) ? a[j] * rinv : 0.0;   // lane i >= column: L[i][column]; zero above the diagonal
+                a[j] = l;
+                *((lane == 0) ? &S.rinvs[c0 + j] : &S.dump_d[lane]) = rinv;   // (branch-free: lanes past 0 store into a dump)
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c) a[c] = fma(-l, lane_bcast(l, c0 + c), a[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(&Ls[lane * LD + c0 + c]) = double2{a[c], a[c + 1]};
+        }
+        __syncthreads();
+        if (p < 3) {   // columns behind the panel: tile (I, J) -= L_I L_J^T, the next panel's column of tiles first
+            int q = 0;
+#pragma unroll
+            for (int J = p + 1; J < 4; ++J)
+#pragma unroll
+                for (int I = J; I < 4; ++I) {
+                    if ((q & 3) == w) {
+                        d4 acc = potf2_tile_load(Ls, 16 * I, 16 * J, lr, lc);
+                        acc = potf2_tile_mma<true>(Ls, 16 * I, c0, 16 * J, c0, -1.0, acc, lr, lc);
+                        potf2_tile_store(Ls, 16 * I, 16 * J, lr, lc, acc);
+                    }
+                    ++q;
+                }
+            __syncthreads();
+        }
+    }
+    if (w == 0) {
+        if (bad && lane == 0) atomicCAS(info_word, 0, bad);
+        POTF2_STAMP(2);
+    }
+    // the factor goes out (coalesced rows; what sits above the diagonal in LDS is the block's old upper half)
+    for (int r = w; r < 64; r += NW) A[(long)r * npad + lane] = (lane <= r) ? Ls[r * LD + lane] : 0.0;
+    __syncthreads();
+    if (w == 0) {   // diagonal blocks: X_dd = L_dd^-1, row by row; lane 16 d + j holds column j of block d
+        const int base = 16 * lr * LD + 16 * lr;
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double acc0 = (i == lc) ? 1.0 : 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) {
+                const double lik = Ls[base + i * LD + k];
+                if (k & 1) acc1 = fma(-lik, x[k], acc1);
+                else acc0 = fma(-lik, x[k], acc0);
+            }
+            x[i] = (acc0 + acc1) * S.rinvs[16 * lr + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Ls[base + i * LD + lc] = x[i];   // (zero above the diagonal: the recurrence leaves x[i] = 0 for i < j)
+    }
+    __syncthreads();
+    if (w < 2) {   // first doubling: X_10 = -X_11 (L_10 X_00) (wave 0), X_32 likewise (wave 1); one wave each, LDS operations of a wave keep their order
+        const int bi = 16 * (2 * w + 1), bj = 16 * (2 * w);
+        d4 t = potf2_tile_mma<false>(Ls, bi, bj, bj, bj, 1.0, d4{0.0, 0.0, 0.0, 0.0}, lr, lc);
+        potf2_tile_store(Ls, bi, bj, lr, lc, t);
+        d4 x = potf2_tile_mma<false>(Ls, bi, bi, bi, bj, -1.0, d4{0.0, 0.0, 0.0, 0.0}, lr, lc);
+        potf2_tile_store(Ls, bi, bj, lr, lc, x);
+    }
+    __syncthreads();
+    {   // second doubling, 32 x 32 blocks: T = L_BA X_AA into the unused upper-right quarter, then X_BA = -X_BB T over L_BA
+        const int I = 2 + (w >> 1), J = w & 1;   // this wave's 16 x 16 tile of the lower-left quarter
+        d4 t = d4{0.0, 0.0, 0.0, 0.0};
+        for (int K = J; K < 2; ++K) t = potf2_tile_mma<false>(Ls, 16 * I, 16 * K, 16 * K, 16 * J, 1.0, t, lr, lc);   // (X_AA is lower triangular: its block (0, 1) is not a zero in LDS)
+        potf2_tile_store(Ls, 16 * (I - 2), 32 + 16 * J, lr, lc, t);
+        __syncthreads();
+        d4 x = d4{0.0, 0.0, 0.0, 0.0};
+        for (int K = 2; K <= I; ++K) x = potf2_tile_mma<false>(Ls, 16 * I, 16 * K, 16 * (K - 2), 32 + 16 * J, -1.0, x, lr, lc);
+        potf2_tile_store(Ls, 16 * I, 16 * J, lr, lc, x);
+    }
+    __syncthreads();
+    if (w == 0) POTF2_STAMP(3);
+    for (int r = w; r < 64; r += NW) out[(long)r * out_ld + lane] = (lane <= r) ? Ls[r * LD + lane] : 0.0;
+    if (w == 0) POTF2_STAMP(5);
+}
+#else
 // The block is in S.Ls (row-major, row stride POTF2_LD), S.published is 0 and every thread of the workgroup has passed a
 // barrier since.  Waves 0 and 1 do the work; any others only keep the two barriers company (NW waves in the workgroup: the
 // fused trailing update below has four).  Leaves L (zero above the diagonal) in the global block A and L^-1 in `out`;
 // *info_word receives kb_abs * 64 + column + 1 of the first non-positive pivot.
 template <int NW>
-__device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A, int npad, int kb_abs, double* __restrict__ out,
+__device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A, int npad, int kb_abs, double* __restrict__ out, int out_ld,
                                             int* info_word, int lane, int w, unsigned long long* stp) {
     constexpr int LD = POTF2_LD;
     (void)stp;
@@ -463,7 +617,7 @@ __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A,
 #endif
         POTF2_STAMP(3);
 #pragma unroll
-        for (int i = 0; i < 64; ++i) out[i * 64 + lane] = x[i];
+        for (int i = 0; i < 64; ++i) out[(long)i * out_ld + lane] = x[i];
         POTF2_STAMP(4);
     }
     __syncthreads();
@@ -471,45 +625,47 @@ __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A,
     if (w == 0) POTF2_STAMP(5);
 }
 
+#endif
 // the first diagonal block (the others are factored by the workgroup that finishes their trailing update: k_gemm64<.., true>)
-__global__ __launch_bounds__(128) void k_potf2_inv(double* __restrict__ Aall, int npad, int kb,
-                                                   double* __restrict__ invD, int* __restrict__ info) {
+constexpr int POTF2_NW = POTF2_BLOCKED ? 4 : 2;   // waves of the first block's own launch
+__global__ __launch_bounds__(64 * POTF2_NW) void k_potf2_inv(double* __restrict__ Aall, int npad, int kb,
+                                                   double* __restrict__ Xall, int* __restrict__ info) {
     constexpr int LD = POTF2_LD;
     __shared__ __attribute__((aligned(16))) Potf2Lds S;
     const int b = blockIdx.x;
-    const int nblk = npad / 64;
     double* A = Aall + (long)b * npad * npad + (long)kb * 64 * npad + kb * 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned long long* stp = nullptr;
 #ifdef POTF2_STAMPS
-    if (b == 0) stp = reinterpret_cast<unsigned long long*>(info + 64);
+    if (b == 0) stp = reinterpret_cast<unsigned long long*>(info + 256);
 #endif
     if (w == 0) POTF2_STAMP(0);
     if (threadIdx.x == 0) S.published = 0;
     {   // the block, 32 rows per wave, all loads in flight together (one by one they cost a memory round trip each: 10 us)
-        double v[32];
+        double v[64 / POTF2_NW];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) v[q] = A[(long)(2 * q + w) * npad + lane];
+        for (int q = 0; q < 64 / POTF2_NW; ++q) v[q] = A[(long)(POTF2_NW * q + w) * npad + lane];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) S.Ls[(2 * q + w) * LD + lane] = v[q];
+        for (int q = 0; q < 64 / POTF2_NW; ++q) S.Ls[(POTF2_NW * q + w) * LD + lane] = v[q];
     }
     __syncthreads();
-    potf2_block<2>(S, A, npad, kb, invD + ((long)b * nblk + kb) * 4096, &info[b], lane, w, stp);
+    potf2_block<POTF2_NW>(S, A, npad, kb, Xall + (long)b * npad * npad + (long)kb * 64 * (npad + 1), npad, &info[b], lane, w, stp);
 }
 #undef POTF2_STAMP
 
-void launch_potrf(hipStream_t st, double* A, int npad, int batch, double* invD, int* info) {
+void launch_potrf(hipStream_t st, double* A, int npad, int batch, double* Linv, int* info, bool zero_linv) {
     const int nblk = npad / 64;
     const long sA = (long)npad * npad;
+    if (zero_linv) (void)hipMemsetAsync(Linv, 0, sizeof(double) * sA * batch, st);
     // block 0 has a launch of its own; block kb + 1 is factored inside the trailing update of step kb (k_gemm64<.., true>)
-    hipLaunchKernelGGL(k_potf2_inv, dim3(batch), dim3(128), 0, st, A, npad, 0, invD, info);
+    hipLaunchKernelGGL(k_potf2_inv, dim3(batch), dim3(64 * POTF2_NW), 0, st, A, npad, 0, Linv, info);
     for (int kb = 0; kb < nblk; ++kb) {
         const int rem = nblk - kb - 1;
         if (rem <= 0) break;
         double* panel = A + (long)(kb + 1) * 64 * npad + kb * 64;
         GemmDesc p{};  // panel <- panel * inv(L_kk)^T
         p.A = panel; p.lda = npad; p.sA = sA;
-        p.B = invD + (long)kb * 4096; p.ldb = 64; p.sB = (long)nblk * 4096;
+        p.B = Linv + (long)kb * 64 * (npad + 1); p.ldb = npad; p.sB = sA;
         p.C = panel; p.ldc = npad; p.sC = sA;
         p.M = rem * 64; p.N = 64; p.K = 64; p.alpha = 1.0; p.beta = 0.0; p.tile_mode = 0; p.k_mode = 0;
         launch_gemm(st, p, false, true, batch);
@@ -518,28 +674,18 @@ void launch_potrf(hipStream_t st, double* A, int npad, int batch, double* invD, 
         u.B = panel; u.ldb = npad; u.sB = sA;
         u.C = A + (long)(kb + 1) * 64 * npad + (kb + 1) * 64; u.ldc = npad; u.sC = sA;
         u.M = rem * 64; u.N = rem * 64; u.K = 64; u.alpha = -1.0; u.beta = 1.0; u.tile_mode = 1; u.k_mode = 0;
-        u.potf2_invD = invD; u.potf2_info = info; u.potf2_kb = kb + 1; u.potf2_nblk = nblk;
+        u.potf2_X = Linv; u.potf2_sX = sA; u.potf2_info = info; u.potf2_kb = kb + 1;
         launch_gemm(st, u, false, true, batch);
     }
 }
 
 // ------------------------------------------------------------------ triangular inverse
-// Recursive doubling: with the inverses of the 64x64 diagonal blocks in place (from k_potf2_inv), level h merges
+// Recursive doubling: with the inverses of the 64x64 diagonal blocks in place (launch_potrf wrote them there), level h merges
 // pairs of inverted h x h diagonal blocks A, B of a 2h block [[A^-1, 0], [X, B^-1]] with X = -B^-1 (C A^-1),
 // C = L[lower-left].  Two batched GEMMs per level over all (matrix, block) pairs: log2(npad/64) levels instead of
 // one GEMM pair per block row.  Trailing partial blocks (npad/64 not a power of two) are clipped per sub-problem.
-__global__ void k_copy_diag_blocks(const double* __restrict__ invD, double* __restrict__ Linv, int npad) {
-    const int I = blockIdx.x, b = blockIdx.y, nblk = npad / 64;
-    const double* s = invD + ((long)b * nblk + I) * 4096;
-    double* d = Linv + (long)b * npad * npad + (long)I * 64 * npad + I * 64;
-    for (int e = threadIdx.x; e < 4096; e += blockDim.x) d[(long)(e >> 6) * npad + (e & 63)] = s[e];
-}
-
-void launch_trtri(hipStream_t st, const double* L, int npad, int batch, const double* invD, double* Linv, double* T,
-                  long tstride) {
+void launch_trtri(hipStream_t st, const double* L, int npad, int batch, double* Linv, double* T, long tstride) {
     const long sA = (long)npad * npad;
-    (void)hipMemsetAsync(Linv, 0, sizeof(double) * sA * batch, st);
-    hipLaunchKernelGGL(k_copy_diag_blocks, dim3(npad / 64, batch), dim3(256), 0, st, invD, Linv, npad);
     for (int h = 64; h < npad; h *= 2) {
         const int nsub = (npad - h + 2 * h - 1) / (2 * h);   // 2h blocks whose lower half is not empty
         GemmDesc a{};  // T_q = C_q * A_q^-1      (A_q^-1 lower triangular: k >= j0)

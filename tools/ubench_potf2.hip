@@ -8,7 +8,7 @@
 #include <vector>
 
 int main() {
-    const int npad = 1024, batch = 10, nblk = npad / 64, reps = 200;
+    const int npad = 1024, batch = 10, reps = 200;
     std::vector<double> A((size_t)batch * npad * npad, 0.0);
     unsigned s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (double)(s >> 8) / 16777216.0 - 0.5; };
@@ -24,15 +24,15 @@ int main() {
     }
     double *dA, *dA0, *dInv;
     int* dInfo;
-    hipMalloc(&dA, A.size() * 8); hipMalloc(&dA0, A.size() * 8); hipMalloc(&dInv, (size_t)batch * nblk * 4096 * 8); hipMalloc(&dInfo, 4096);
+    hipMalloc(&dA, A.size() * 8); hipMalloc(&dA0, A.size() * 8); hipMalloc(&dInv, A.size() * 8); hipMalloc(&dInfo, 4096);
     hipMemcpy(dA0, A.data(), A.size() * 8, hipMemcpyHostToDevice);
     hipMemset(dInfo, 0, 4096);
     hipStream_t st; hipStreamCreate(&st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipMemcpy(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice);
-    hipLaunchKernelGGL(pilco::k_potf2_inv, dim3(batch), dim3(128), 0, st, dA, npad, 0, dInv, dInfo);
+    hipLaunchKernelGGL(pilco::k_potf2_inv, dim3(batch), dim3(64 * pilco::POTF2_NW), 0, st, dA, npad, 0, dInv, dInfo);
     hipStreamSynchronize(st);
-    std::vector<double> L(A.size()), X((size_t)batch * nblk * 4096);
+    std::vector<double> L(A.size()), X(A.size());
     hipMemcpy(L.data(), dA, A.size() * 8, hipMemcpyDeviceToHost);
     hipMemcpy(X.data(), dInv, X.size() * 8, hipMemcpyDeviceToHost);
     double e_llt = 0, e_xl = 0;
@@ -42,7 +42,7 @@ int main() {
                 double llt = 0, xl = 0;
                 for (int k = 0; k < 64; ++k) {
                     llt += L[(size_t)b * npad * npad + (size_t)i * npad + k] * L[(size_t)b * npad * npad + (size_t)j * npad + k];
-                    xl += X[(size_t)b * nblk * 4096 + i * 64 + k] * L[(size_t)b * npad * npad + (size_t)k * npad + j];
+                    xl += X[(size_t)b * npad * npad + (size_t)i * npad + k] * L[(size_t)b * npad * npad + (size_t)k * npad + j];
                 }
                 e_llt = std::fmax(e_llt, std::fabs(llt - A[(size_t)b * npad * npad + (size_t)i * npad + j]));
                 e_xl = std::fmax(e_xl, std::fabs(xl - (i == j ? 1.0 : 0.0)));
@@ -53,7 +53,7 @@ int main() {
         hipEventRecord(e0, st);
         for (int r = 0; r < reps; ++r) {
             hipMemcpy2DAsync(dA, npad * 8, dA0, npad * 8, 64 * 8, 64, hipMemcpyDeviceToDevice, st);
-            if (with_kernel) hipLaunchKernelGGL(pilco::k_potf2_inv, dim3(batch), dim3(128), 0, st, dA, npad, 0, dInv, dInfo);
+            if (with_kernel) hipLaunchKernelGGL(pilco::k_potf2_inv, dim3(batch), dim3(64 * pilco::POTF2_NW), 0, st, dA, npad, 0, dInv, dInfo);
         }
         hipEventRecord(e1, st);
         hipEventSynchronize(e1);
@@ -66,10 +66,15 @@ int main() {
            t_with - t_copy, reps, t_copy, e_llt, e_xl);
 #ifdef POTF2_STAMPS
     unsigned long long stp[8];
-    hipMemcpy(stp, dInfo + 64, sizeof(stp), hipMemcpyDeviceToHost);
+    hipMemcpy(stp, dInfo + 256, sizeof(stp), hipMemcpyDeviceToHost);
     auto us = [&](int a, int b) { return (double)(stp[b] - stp[a]) / 100.0; };
+#if POTF2_BLOCKED
+    printf("phases (matrix 0): load %.2f  factor (4 panels + 3 updates) %.2f  factor store + inverse %.2f  inverse store %.2f  total %.2f us\n",
+           us(0, 1), us(1, 2), us(2, 3), us(3, 5), us(0, 5));
+#else
     printf("phases (matrix 0): load %.2f  factor loop (wave 0) %.2f  inverse loop end (wave 1) +%.2f after the factor's  inverse store %.2f  factor store (to the end) %.2f  total %.2f us\n",
            us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(0, 5));
+#endif
 #endif
     return 0;
 }
