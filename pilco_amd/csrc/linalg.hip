@@ -102,11 +102,9 @@ constexpr int LDS_LD = 80;
 // (the block factorisation of the Cholesky section below, which the GEMM's fused form calls)
 constexpr int POTF2_LD = 66;   // 16-byte aligned lines, lanes of a column spread over the banks
 struct Potf2Lds {               // LDS of one block factorisation
-    double Ls[64 * POTF2_LD];   // first the block (row-major), then line j = column j of L
+    double Ls[64 * POTF2_LD];   // the block (row-major): A, then L below the diagonal, then L^-1 (potf2_block)
     double rinvs[64];           // 1 / sqrt(pivot j)
-    double dump_d[64];
-    int dump_i[64];
-    int published;              // columns of L wave 0 has put out
+    double dump_d[64];          // where lanes past 0 put what only lane 0 has to store (branch-free)
 };
 template <int NW>
 __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A, int npad, int kb_abs, double* __restrict__ out, int out_ld,
@@ -278,10 +276,9 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmDesc g) {
                 if (g.tile_mode == 2 && bi != bj) sm[(wj + 16 * tj + lc) * 65 + wi + 16 * ti + lr + 4 * r] = v;
             }
     if (POTF2 && bi == 0 && bj == 0) {
-        // Cholesky chain: this tile is the NEXT diagonal block.  Its factorisation and inverse (20 us, two waves) run here,
-        // beside the other tiles of the trailing update, instead of in a launch of their own behind it.
+        // Cholesky chain: this tile is the NEXT diagonal block.  Its factorisation and inverse (12 us, this workgroup's four
+        // waves) run here, beside the other tiles of the trailing update, instead of in a launch of their own behind it.
         Potf2Lds& S = *reinterpret_cast<Potf2Lds*>(sm);
-        if (t == 0) S.published = 0;
         __syncthreads();
         potf2_block<4>(S, C, ldc, g.potf2_kb, g.potf2_X + (long)mat * g.potf2_sX + (long)g.potf2_kb * 64 * (ldc + 1), ldc,
                        g.potf2_info + mat, lane, w, nullptr);
@@ -320,16 +317,11 @@ void launch_gemm(hipStream_t st, const GemmDesc& g_in, bool ta, bool tb, int bat
 }
 
 // ------------------------------------------------------------------ Cholesky
-// Factor the kb-th 64x64 diagonal block and invert the factor, TWO waves per matrix, one behind the other:
-//   wave 0 (factor): the block in registers, lane i holds row i.  Column j: the scaled column l = L[:, j] is published as one
-//     contiguous LDS line (every lane reads it back as broadcasts for its 62 - j trailing FMAs); the NEXT pivot does not
-//     wait for that round trip -- column j + 1 is updated first, from v_readlane, and its reciprocal square root is in
-//     flight while the other trailing columns are updated (one basic block: the scheduler interleaves the two);
-//   wave 1 (inverse): lane j holds column j of X = L^-1 and runs the right-looking substitution one column BEHIND wave 0:
-//     step k needs column k of L and 1 / L_kk only, i.e. exactly what wave 0 has just published:
-//     x_k *= 1 / L_kk,  x_i -= L_ik x_k  (i > k).
-// Wave 1 follows a column count in LDS; wave 0 never waits for it.  Round 2 ran both parts in ONE wave, one after the other
-// (38 us per block on the factorisation's critical path, 16 blocks at N = 1000).
+// Factor the kb-th 64x64 diagonal block and invert the factor: potf2_block below, four waves per matrix.
+// (History.  Round 2: one wave, factor then inverse, 38 us per block on the factorisation's critical path -- 16 blocks at
+// N = 1000.  Rounds 3-4: two waves, all 64 columns eliminated in wave 0's registers -- every column published as an LDS line
+// and read back as broadcasts --, wave 1 running the substitution for the inverse one column behind: 20 us.  Round 5:
+// blocked in panels of 16 columns with MFMA updates and a recursive-doubling inverse: 12 us.)
 // replaces tf.linalg.cholesky at pilco/models/mgpr.py:84 / smgpr.py:29,35
 __device__ __forceinline__ double rsqrt_f64(double d) {
     double y = __builtin_amdgcn_rsq(d);
@@ -340,94 +332,11 @@ __device__ __forceinline__ double rsqrt_f64(double d) {
 __device__ __forceinline__ double lane_bcast(double v, int l) {   // v of lane l (l wave-uniform) as a scalar
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-// One column of wave 0's factor loop (k_potf2_inv below), J a compile-time constant (a recursive template instead of an
-// unrolled loop: with the hand-ordered body the loop grew past the size clang unrolls BEFORE it decides whether a[] can
-// live in registers, and a[] went to scratch memory).
-struct Potf2State {
-    double l, rinv;   // column J of L (lane i >= J: L[i][J]) and 1 / sqrt(pivot J)
-    int bad;
-};
-template <int J, int K, int G>
-__device__ __forceinline__ void potf2_share(double (&a)[64], const double (&t)[64], double l) {
-    // the K-th of eight shares of the trailing updates of column J: columns J + 2 + K G .. (G each), LAST column first -- its
-    // operand is the last one requested, and LDS reads return in order: one s_waitcnt per share instead of one per read
-#pragma unroll
-    for (int q = G - 1; q >= 0; --q) {
-        constexpr int c0 = J + 2 + K * G;
-        const int c = c0 + q < 64 ? c0 + q : 63;
-        if (c0 + q < 64) a[c] = fma(-l, t[c], a[c]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int J>
-__device__ __forceinline__ void potf2_columns(double (&a)[64], Potf2State& st, double* Ls, double* rinvs, double* dump_d, int* published,
-                                              int* dump_i, int lane, int kb) {
-    constexpr int LD = POTF2_LD;
-    const double l = st.l;
-    // Publish column J: line, 1 / sqrt(pivot), then the count -- three LDS stores of ONE wave, which the LDS executes in the
-    // order they were issued, so wave 1 finds the line behind the count without this wave waiting for anything (a workgroup
-    // barrier per column made wave 0 drain its stores and meet wave 1 sixty-four times).  Every line is written after this
-    // wave has read the block out of it: same ordering argument.  Branch-free: lanes past 0 store into a dump -- a
-    // conditional block per column lets the compiler sink the trailing updates towards their uses across the columns, with
-    // every loaded line kept alive (7 KB of spills).
-    Ls[J * LD + lane] = (lane >= J) ? l : 0.0;
-    *((lane == 0) ? &rinvs[J] : &dump_d[lane]) = st.rinv;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (no instruction: the compiler keeps the stores in this order)
-    __hip_atomic_store((lane == 0) ? published : &dump_i[lane], J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if constexpr (J < 63) {
-        // The trailing columns' operands (this line, read back as broadcasts) are requested first and ALL AT ONCE: the
-        // compiler's own order kept three or four reads in flight and waited for each (an LDS round trip per four columns:
-        // 670 cycles per column, 20 us for the loop).  Then the pivot chain of column J + 1 -- its own update from
-        // v_readlane, the pivot, the reciprocal square root: a dozen DEPENDENT operations -- with one share of the trailing
-        // updates behind every link, order pinned by scheduling barriers.
-        // (Taking the first few operands from v_readlane instead, to have work for the line's LDS round trip, made the loop
-        // slower: 16.0 -> 18.7 us.  The wave is bound by the NUMBER of instructions it issues, about 5 cycles each.)
-        // (16-byte reads from an even entry on: for odd J the first pair starts one entry early -- the misaligned pairs
-        // cost a ds_read2_b64 with an address register of its own each: 500 more instructions and twice the LDS cycles)
-        double t[64];
-#pragma unroll
-        for (int c = (J + 2) & ~1; c < 64; c += 2) {
-            const double2 pr = *reinterpret_cast<const double2*>(&Ls[J * LD + c]);
-            t[c] = pr.x;
-            t[c + 1] = pr.y;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int G = (62 - J + 7) / 8;
-        a[J + 1] = fma(-l, lane_bcast(l, J + 1), a[J + 1]);
-        double dn = lane_bcast(a[J + 1], J + 1);
-        const bool ok = dn > 0.0;   // false for NaN too
-        st.bad = (!ok && st.bad == 0) ? kb * 64 + J + 2 : st.bad;
-        dn = ok ? dn : 1.0;
-        potf2_share<J, 0, G>(a, t, l);
-        double y = __builtin_amdgcn_rsq(dn);   // rsqrt_f64(dn), link by link
-        const double h = -0.5 * dn;
-        potf2_share<J, 1, G>(a, t, l);
-        double u = h * y;
-        potf2_share<J, 2, G>(a, t, l);
-        double v = fma(u, y, 0.5);
-        potf2_share<J, 3, G>(a, t, l);
-        y = fma(y, v, y);
-        potf2_share<J, 4, G>(a, t, l);
-        u = h * y;
-        potf2_share<J, 5, G>(a, t, l);
-        v = fma(u, y, 0.5);
-        potf2_share<J, 6, G>(a, t, l);
-        y = fma(y, v, y);
-        potf2_share<J, 7, G>(a, t, l);
-        st.rinv = y;
-        st.l = a[J + 1] * y;
-        potf2_columns<J + 1>(a, st, Ls, rinvs, dump_d, published, dump_i, lane, kb);
-    }
-}
 #ifdef POTF2_STAMPS   // developer aid (tools/ubench_potf2.hip): 100 MHz stamps behind the info words
 #define POTF2_STAMP(i_) do { if (stp && lane == 0) stp[i_] = wall_clock64(); } while (0)
 #else
 #define POTF2_STAMP(i_) do { } while (0)
 #endif
-#ifndef POTF2_BLOCKED
-#define POTF2_BLOCKED 1
-#endif
-#if POTF2_BLOCKED
 // The block is in S.Ls (row-major, row stride POTF2_LD) and every thread of the workgroup (FOUR waves) has passed a barrier
 // since.  Leaves L (zero above the diagonal) in the global block A and L^-1 in `out`; *info_word receives
 // kb_abs * 64 + column + 1 of the first non-positive pivot.
@@ -489,6 +398,9 @@ __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A,
                 a[c] = (lane >= c0) ? pr.x : 0.0;
                 a[c + 1] = (lane >= c0) ? pr.y : 0.0;
             }
+            // (eliminating with UNSCALED columns -- the next pivot one reciprocal and one multiply-add on scalars behind the
+            // previous, square roots beside the chain -- was no faster, 10.1 against 9.2 us for the four panels: the wave is
+            // bound by the ~43 instructions it issues per column, about 5 cycles each, not by the pivot chain)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 double d = lane_bcast(a[j], c0 + j);
@@ -570,64 +482,9 @@ __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A,
     for (int r = w; r < 64; r += NW) out[(long)r * out_ld + lane] = (lane <= r) ? Ls[r * LD + lane] : 0.0;
     if (w == 0) POTF2_STAMP(5);
 }
-#else
-// The block is in S.Ls (row-major, row stride POTF2_LD), S.published is 0 and every thread of the workgroup has passed a
-// barrier since.  Waves 0 and 1 do the work; any others only keep the two barriers company (NW waves in the workgroup: the
-// fused trailing update below has four).  Leaves L (zero above the diagonal) in the global block A and L^-1 in `out`;
-// *info_word receives kb_abs * 64 + column + 1 of the first non-positive pivot.
-template <int NW>
-__device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A, int npad, int kb_abs, double* __restrict__ out, int out_ld,
-                                            int* info_word, int lane, int w, unsigned long long* stp) {
-    constexpr int LD = POTF2_LD;
-    (void)stp;
-    if (w == 0) {
-        POTF2_STAMP(1);
-        double a[64];
-#pragma unroll
-        for (int c = 0; c < 64; ++c) a[c] = S.Ls[lane * LD + c];
-        int bad = 0;
-        double d = lane_bcast(a[0], 0);
-        if (!(d > 0.0)) {  // also catches NaN
-            bad = kb_abs * 64 + 1;
-            d = 1.0;
-        }
-        double rinv = rsqrt_f64(d);
-        double l = a[0] * rinv;   // lane i >= j: L[i][j]; lane j: sqrt(d)
-        Potf2State st{l, rinv, bad};
-        potf2_columns<0>(a, st, S.Ls, S.rinvs, S.dump_d, &S.published, S.dump_i, lane, kb_abs);
-        bad = st.bad;
-        if (bad && lane == 0) atomicCAS(info_word, 0, bad);
-        POTF2_STAMP(2);
-    } else if (w == 1) {
-        double x[64];
-#pragma unroll
-        for (int i = 0; i < 64; ++i) x[i] = (i == lane) ? 1.0 : 0.0;
-#ifndef POTF2_NO_INVERSE   // (developer switch of tools/ubench_potf2.hip: wave 0 alone)
-#pragma unroll
-        for (int k = 0; k < 64; ++k) {
-            // wait for column k (bounded: wave 0 depends on nothing, so the bound is never met; a bug must not hang the GPU)
-            for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(&S.published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k; ++spin)
-                __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const double xk = x[k] * S.rinvs[k];
-            x[k] = xk;
-#pragma unroll
-            for (int i = k + 1; i < 64; ++i) x[i] = fma(-S.Ls[k * LD + i], xk, x[i]);
-        }
-#endif
-        POTF2_STAMP(3);
-#pragma unroll
-        for (int i = 0; i < 64; ++i) out[(long)i * out_ld + lane] = x[i];
-        POTF2_STAMP(4);
-    }
-    __syncthreads();
-    for (int r = w; r < 64; r += NW) A[(long)r * npad + lane] = S.Ls[lane * LD + r];   // L[r][lane] = line `lane`, entry r (zero above the diagonal)
-    if (w == 0) POTF2_STAMP(5);
-}
 
-#endif
 // the first diagonal block (the others are factored by the workgroup that finishes their trailing update: k_gemm64<.., true>)
-constexpr int POTF2_NW = POTF2_BLOCKED ? 4 : 2;   // waves of the first block's own launch
+constexpr int POTF2_NW = 4;   // waves of a block factorisation
 __global__ __launch_bounds__(64 * POTF2_NW) void k_potf2_inv(double* __restrict__ Aall, int npad, int kb,
                                                    double* __restrict__ Xall, int* __restrict__ info) {
     constexpr int LD = POTF2_LD;
@@ -640,8 +497,7 @@ __global__ __launch_bounds__(64 * POTF2_NW) void k_potf2_inv(double* __restrict_
     if (b == 0) stp = reinterpret_cast<unsigned long long*>(info + 256);
 #endif
     if (w == 0) POTF2_STAMP(0);
-    if (threadIdx.x == 0) S.published = 0;
-    {   // the block, 32 rows per wave, all loads in flight together (one by one they cost a memory round trip each: 10 us)
+    {   // the block, 16 rows per wave, all loads in flight together (one by one they cost a memory round trip each: 10 us)
         double v[64 / POTF2_NW];
 #pragma unroll
         for (int q = 0; q < 64 / POTF2_NW; ++q) v[q] = A[(long)(POTF2_NW * q + w) * npad + lane];

@@ -68,13 +68,8 @@ int main() {
     unsigned long long stp[8];
     hipMemcpy(stp, dInfo + 256, sizeof(stp), hipMemcpyDeviceToHost);
     auto us = [&](int a, int b) { return (double)(stp[b] - stp[a]) / 100.0; };
-#if POTF2_BLOCKED
     printf("phases (matrix 0): load %.2f  factor (4 panels + 3 updates) %.2f  factor store + inverse %.2f  inverse store %.2f  total %.2f us\n",
            us(0, 1), us(1, 2), us(2, 3), us(3, 5), us(0, 5));
-#else
-    printf("phases (matrix 0): load %.2f  factor loop (wave 0) %.2f  inverse loop end (wave 1) +%.2f after the factor's  inverse store %.2f  factor store (to the end) %.2f  total %.2f us\n",
-           us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(0, 5));
-#endif
 #endif
     return 0;
 }
