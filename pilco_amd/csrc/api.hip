@@ -636,14 +636,27 @@ int pilco_gp_nlml(pilco_ctx* ctx, int slot, double* nlml, double* grad) {
     double* d_grad = d_part + npart;
     double* d_logdet = d_grad + (size_t)ELa * (D + 2);
     double* d_gath = d_logdet + 2 * (size_t)ELa;   // [W][ELcap][W3] when a communicator completes the result
-    std::vector<double> hl(ELa), hb((size_t)ELa * npad), hy((size_t)ELa * npad), hg((size_t)ELa * (D + 2));
+    // what comes back: gradient [EL][D + 2] | log-determinant sums [EL] | data-fit terms y . beta [EL], ONE copy into pinned
+    // memory (rounds 1-4: y and beta themselves came back, 2 x 82 KB into pageable vectors, and were multiplied here)
+    const size_t nback = (size_t)ELa * (D + 4);
+    if (ctx->pin_io_cap < nback) {
+        if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);
+        ctx->pin_io = nullptr;
+        ctx->pin_io_cap = 0;
+        HIPCHK(hipHostMalloc((void**)&ctx->pin_io, sizeof(double) * nback, hipHostMallocDefault));
+        ctx->pin_io_cap = nback;
+    }
+    const double* hg = ctx->pin_io;
+    const double* hl = hg + (size_t)ELa * (D + 2);
+    const double* hyb = hl + ELa;
     if (EL > 0) {
-        launch_logdet(ctx->st, s.K.p, npad, N, EL, d_logdet);
+        launch_logdet(ctx->st, s.K.p, npad, N, EL, d_logdet, Yt, beta);
         if (grad) launch_nlml_grad(ctx->st, s.Xt.p, npad, N, D, ls, var, s.iK.p, beta, EL, d_part, d_grad);
-        HIPCHK(hipMemcpyAsync(hl.data(), d_logdet, sizeof(double) * EL, hipMemcpyDeviceToHost, ctx->st));
-        HIPCHK(hipMemcpyAsync(hb.data(), beta, sizeof(double) * EL * npad, hipMemcpyDeviceToHost, ctx->st));
-        HIPCHK(hipMemcpyAsync(hy.data(), Yt, sizeof(double) * EL * npad, hipMemcpyDeviceToHost, ctx->st));
-        if (grad) HIPCHK(hipMemcpyAsync(hg.data(), d_grad, sizeof(double) * EL * (D + 2), hipMemcpyDeviceToHost, ctx->st));
+        if (grad) {
+            HIPCHK(hipMemcpyAsync(ctx->pin_io, d_grad, sizeof(double) * nback, hipMemcpyDeviceToHost, ctx->st));
+        } else {
+            HIPCHK(hipMemcpyAsync(ctx->pin_io + (size_t)ELa * (D + 2), d_logdet, sizeof(double) * 2 * ELa, hipMemcpyDeviceToHost, ctx->st));
+        }
     }
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());
@@ -656,9 +669,7 @@ int pilco_gp_nlml(pilco_ctx* ctx, int slot, double* nlml, double* grad) {
     std::vector<double> own((size_t)ELcap * W3, 0.0);
     for (int al = 0; al < EL; ++al) {
         const int a = al * W + rank;
-        double ya = 0.0;
-        for (int i = 0; i < N; ++i) ya += hy[(size_t)al * npad + i] * hb[(size_t)al * npad + i];
-        nlml[a] = 0.5 * ya + hl[al] + 0.5 * N * std::log(2.0 * M_PI);
+        nlml[a] = 0.5 * hyb[al] + hl[al] + 0.5 * N * std::log(2.0 * M_PI);
         own[(size_t)al * W3] = nlml[a];
         if (grad)
             for (int k = 0; k < D + 2; ++k) {

@@ -166,7 +166,8 @@ void launch_fitc_rhs(hipStream_t st, const double* V, const double* G, const dou
 // GP training: per output sum_i log L_ii, and the D+2 weighted sums
 //   g[d] = 1/2 sum_ij W_ij K_ij (x_id - x_jd)^2 / l_d^3,  g[D] = 1/2 sum_ij W_ij K_ij / var,  g[D+1] = 1/2 tr W,
 // with W = iK - beta beta^T and K the noise-free Gram matrix recomputed on the fly.
-void launch_logdet(hipStream_t st, const double* L, int npad, int n, int batch, double* out);
+void launch_logdet(hipStream_t st, const double* L, int npad, int n, int batch, double* out, const double* y = nullptr,
+                   const double* beta = nullptr);   // (y: out[batch + b] = y_b . beta_b as well)
 void launch_nlml_grad(hipStream_t st, const double* Pt, int npad, int n, int D, const double* ls, const double* var,
                       const double* iK, const double* beta, int batch, double* partial, double* grad);
 

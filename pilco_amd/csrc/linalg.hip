@@ -615,24 +615,41 @@ void launch_fitc_rhs(hipStream_t st, const double* V, const double* G, const dou
 }
 
 // ------------------------------------------------------------------ GP training sums
-__global__ __launch_bounds__(256) void k_logdet(const double* __restrict__ L, int npad, int n, double* __restrict__ out) {
-    __shared__ double red[4];
+// out[b] = sum_i log L_ii;  (y != nullptr) out[batch + b] = y_b . beta_b, the data-fit term of the same objective
+__global__ __launch_bounds__(256) void k_logdet(const double* __restrict__ L, int npad, int n, double* __restrict__ out,
+                                                const double* __restrict__ y, const double* __restrict__ beta) {
+    __shared__ double red[2][4];
     const int b = blockIdx.x, t = threadIdx.x;
-    double s = 0.0;
+    double s = 0.0, q = 0.0;
     for (int i = t; i < n; i += 256) s += log(L[((long)b * npad + i) * npad + i]);
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if ((t & 63) == 0) red[t >> 6] = s;
+    if (y)
+        for (int i = t; i < n; i += 256) q = fma(y[(long)b * npad + i], beta[(long)b * npad + i], q);
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off);
+        q += __shfl_down(q, off);
+    }
+    if ((t & 63) == 0) {
+        red[0][t >> 6] = s;
+        red[1][t >> 6] = q;
+    }
     __syncthreads();
-    if (t == 0) out[b] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (t == 0) {
+        out[b] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        if (y) out[gridDim.x + b] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
 }
-void launch_logdet(hipStream_t st, const double* L, int npad, int n, int batch, double* out) {
-    hipLaunchKernelGGL(k_logdet, dim3(batch), dim3(256), 0, st, L, npad, n, out);
+void launch_logdet(hipStream_t st, const double* L, int npad, int n, int batch, double* out, const double* y, const double* beta) {
+    hipLaunchKernelGGL(k_logdet, dim3(batch), dim3(256), 0, st, L, npad, n, out, y, beta);
 }
 
 // one workgroup per (output, 64-row tile, 64-column tile): thread t handles column j0 + (t & 63) against the 16 rows
 // i0 + 16 (t >> 6) ..; all per-dimension arrays are register arrays of the compile-time width DT (the first version
 // indexed [32]-arrays with a run-time D: they lived in scratch memory and one launch took 114 us at N = 225).
 // partial[b][tile_i * ntiles + tile_j][NLML_MAXD + 2]; a second launch reduces the tiles in fixed order.
+// Round 5: the summand w_ij dK_ij is symmetric in (i, j) -- only the tiles on and below the diagonal are computed, those
+// below it count twice (an exact factor) --, a thread's sixteen iK entries are requested together (one by one each cost a
+// memory round trip: sixteen in a row per workgroup), and the reduction keeps eight loads in flight (it walked its 256
+// partials one dependent load after the other).  140 -> 45 us for the two launches at C2.
 constexpr int NLML_MAXD = 32;
 template <int DT>
 __global__ __launch_bounds__(256) void k_nlml_grad_partial(const double* __restrict__ Pt, int npad, int n, int D,
@@ -643,6 +660,7 @@ __global__ __launch_bounds__(256) void k_nlml_grad_partial(const double* __restr
     __shared__ double bi[64];
     __shared__ double red[4][DT + 2];
     const int b = blockIdx.z, ti = blockIdx.y, tj = blockIdx.x, t = threadIdx.x;
+    if (tj > ti) return;   // (the mirror image of tile (tj, ti): counted there)
     const int i0 = ti * 64, j = tj * 64 + (t & 63), g = t >> 6;
     for (int e = t; e < DT * 64; e += 256) xi[e >> 6][e & 63] = ((e >> 6) < D) ? Pt[(long)(e >> 6) * npad + i0 + (e & 63)] : 0.0;
     if (t < 64) bi[t] = beta[(long)b * npad + i0 + t];
@@ -659,6 +677,10 @@ __global__ __launch_bounds__(256) void k_nlml_grad_partial(const double* __restr
     const double* iKb = iK + (long)b * npad * npad;
     const double bj = beta[(long)b * npad + j];
     if (j < n) {
+        double ikv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ikv[q] = iKb[(long)(i0 + 16 * g + q) * npad + j];   // (padding rows exist: zeros)
+#pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int ii = 16 * g + q, i = i0 + ii;
             if (i >= n) break;
@@ -671,7 +693,7 @@ __global__ __launch_bounds__(256) void k_nlml_grad_partial(const double* __restr
                 r2 += sq[d];
             }
             const double k = v * exp(-0.5 * r2);
-            const double w = iKb[(long)i * npad + j] - bi[ii] * bj;
+            const double w = ikv[q] - bi[ii] * bj;
             const double wk = w * k;
 #pragma unroll
             for (int d = 0; d < DT; ++d) acc[d] = fma(wk, sq[d] * il[d], acc[d]);   // (x_i-x_j)^2 / l^3
@@ -688,17 +710,43 @@ __global__ __launch_bounds__(256) void k_nlml_grad_partial(const double* __restr
     __syncthreads();
     if (t < D + 2) {
         const int src = t < D ? t : DT + (t - D);
-        partial[((long)b * gridDim.y * gridDim.x + (long)ti * gridDim.x + tj) * (NLML_MAXD + 2) + t] = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+        const double sum = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+        partial[((long)b * gridDim.y * gridDim.x + (long)ti * gridDim.x + tj) * (NLML_MAXD + 2) + t] = (ti != tj) ? 2.0 * sum : sum;
     }
 }
-__global__ void k_nlml_grad_reduce(const double* __restrict__ partial, int ntiles, int D, const double* __restrict__ var,
-                                   double* __restrict__ grad) {
-    const int b = blockIdx.x, t = threadIdx.x;
-    if (t >= D + 2) return;
-    double s = 0.0;
-    for (int q = 0; q < ntiles; ++q) s += partial[((long)b * ntiles + q) * (NLML_MAXD + 2) + t];
-    if (t == D) s /= var[b];
-    grad[b * (D + 2) + t] = 0.5 * s;
+// one workgroup per output, four waves: lane = gradient entry, wave w takes the tiles on and below the diagonal whose running
+// number is w mod 4 (eight loads in flight each); the four sums are added in their order
+__global__ __launch_bounds__(256) void k_nlml_grad_reduce(const double* __restrict__ partial, int nt, int D, const double* __restrict__ var,
+                                                          double* __restrict__ grad) {
+    __shared__ double red[4][64];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ntri = nt * (nt + 1) / 2;
+    double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, s9 = 0.0;
+    if (lane < D + 2) {
+        // running number q of tile (ti, tj), tj <= ti: ti (ti + 1) / 2 + tj
+        auto tile_of = [&](int q) {
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
+            return (long)ti * nt + (q - ti * (ti + 1) / 2);
+        };
+        const double* base = partial + (long)b * nt * nt * (NLML_MAXD + 2) + lane;
+        int q = w;
+        for (; q + 28 < ntri; q += 32) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[tile_of(q + 4 * u) * (NLML_MAXD + 2)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s8[u] += v[u];
+        }
+        for (; q < ntri; q += 4) s9 += base[tile_of(q) * (NLML_MAXD + 2)];
+    }
+    red[w][lane] = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) + s9;
+    __syncthreads();
+    if (w == 0 && lane < D + 2) {
+        double s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (lane == D) s /= var[b];
+        grad[b * (D + 2) + lane] = 0.5 * s;
+    }
 }
 // partial: [batch][(npad / 64)^2][NLML_MAXD + 2] doubles
 void launch_nlml_grad(hipStream_t st, const double* Pt, int npad, int n, int D, const double* ls, const double* var,
@@ -713,7 +761,7 @@ void launch_nlml_grad(hipStream_t st, const double* Pt, int npad, int n, int D, 
     else if (D <= 24) NG(24);
     else NG(32);
 #undef NG
-    hipLaunchKernelGGL(k_nlml_grad_reduce, dim3(batch), dim3(64), 0, st, partial, ntiles * ntiles, D, var, grad);
+    hipLaunchKernelGGL(k_nlml_grad_reduce, dim3(batch), dim3(256), 0, st, partial, ntiles, D, var, grad);
 }
 
 // ------------------------------------------------------------------ mat-vec, padding
