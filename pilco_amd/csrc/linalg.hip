@@ -438,12 +438,12 @@ __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A,
         if (bad && lane == 0) atomicCAS(info_word, 0, bad);
         POTF2_STAMP(2);
     }
-    // the factor goes out (coalesced rows; what sits above the diagonal in LDS is the block's old upper half)
-    for (int r = w; r < 64; r += NW) A[(long)r * npad + lane] = (lane <= r) ? Ls[r * LD + lane] : 0.0;
-    __syncthreads();
-    if (w == 0) {   // diagonal blocks: X_dd = L_dd^-1, row by row; lane 16 d + j holds column j of block d
+    // The factor goes out (coalesced rows; what sits above the diagonal in LDS is the block's old upper half) from waves 1-3,
+    // while wave 0 inverts the four 16 x 16 diagonal blocks in registers: X_dd = L_dd^-1 row by row, lane 16 d + j holds column
+    // j of block d.  They replace L_dd in LDS once the factor's rows have been read.
+    double x[16];
+    if (w == 0) {
         const int base = 16 * lr * LD + 16 * lr;
-        double x[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             double acc0 = (i == lc) ? 1.0 : 0.0, acc1 = 0.0;
@@ -455,6 +455,12 @@ __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A,
             }
             x[i] = (acc0 + acc1) * S.rinvs[16 * lr + i];
         }
+    } else {
+        for (int r = w - 1; r < 64; r += NW - 1) A[(long)r * npad + lane] = (lane <= r) ? Ls[r * LD + lane] : 0.0;
+    }
+    __syncthreads();
+    if (w == 0) {
+        const int base = 16 * lr * LD + 16 * lr;
 #pragma unroll
         for (int i = 0; i < 16; ++i) Ls[base + i * LD + lc] = x[i];   // (zero above the diagonal: the recurrence leaves x[i] = 0 for i < j)
     }
