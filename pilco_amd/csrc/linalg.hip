@@ -100,11 +100,14 @@ void launch_transpose_points(hipStream_t st, const double* X, int n, int D, doub
 constexpr int LDS_LD = 80;
 
 // (the block factorisation of the Cholesky section below, which the GEMM's fused form calls)
+#ifndef POTF2_LINE
+#define POTF2_LINE 1
+#endif
 constexpr int POTF2_LD = 66;   // 16-byte aligned lines, lanes of a column spread over the banks
 struct Potf2Lds {               // LDS of one block factorisation
     double Ls[64 * POTF2_LD];   // the block (row-major): A, then L below the diagonal, then L^-1 (potf2_block)
-    double rinvs[64];           // 1 / sqrt(pivot j)
-    double dump_d[64];          // where lanes past 0 put what only lane 0 has to store (branch-free)
+    double rinvs[64];           // 1 / L_jj
+    double line[64];            // the column being eliminated with, for broadcast reads
 };
 template <int NW>
 __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A, int npad, int kb_abs, double* __restrict__ out, int out_ld,
@@ -403,35 +406,49 @@ __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A,
             // bound by the ~43 instructions it issues per column, about 5 cycles each, not by the pivot chain)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                double d = lane_bcast(a[j], c0 + j);
-                const bool ok = d > 0.0;   // false for NaN too
-                bad = (!ok && bad == 0) ? kb_abs * 64 + c0 + j + 1 : bad;
-                d = ok ? d : 1.0;
-                const double rinv = rsqrt_f64(d);
-                const double l = (lane >= c0 + j) ? a[j] * rinv : 0.0;   // lane i >= column: L[i][column]; zero above the diagonal
+                // (few instructions per column: a failed pivot is recorded and the elimination goes on with whatever it
+                // yields -- the caller discards the factor --; rows above the diagonal carry along unread values instead of
+                // zeros; 1 / L_jj is taken by the inverse, below, for all columns at once)
+                const double d = lane_bcast(a[j], c0 + j);
+                bad = (!(d > 0.0) && bad == 0) ? kb_abs * 64 + c0 + j + 1 : bad;   // (NaN too)
+                const double l = a[j] * rsqrt_f64(d);   // lane i >= column: L[i][column]
                 a[j] = l;
-                *((lane == 0) ? &S.rinvs[c0 + j] : &S.dump_d[lane]) = rinv;   // (branch-free: lanes past 0 store into a dump)
+#if POTF2_LINE
+                // multipliers: the next column's from v_readlane (the next pivot waits for nothing else), the others read back
+                // from an LDS line as broadcasts, two per instruction (from v_readlane all of them: two instructions each,
+                // 240 of a panel's ~700)
+                S.line[lane] = l;
+                if (j < 15) a[j + 1] = fma(-l, lane_bcast(l, c0 + j + 1), a[j + 1]);
+                if (((j + 2) & 1) && j + 2 < 16) a[j + 2] = fma(-l, S.line[c0 + j + 2], a[j + 2]);
+#pragma unroll
+                for (int c = (j + 3) & ~1; c < 16; c += 2) {
+                    const double2 pr = *reinterpret_cast<const double2*>(&S.line[c0 + c]);
+                    a[c] = fma(-l, pr.x, a[c]);
+                    a[c + 1] = fma(-l, pr.y, a[c + 1]);
+                }
+#else
 #pragma unroll
                 for (int c = j + 1; c < 16; ++c) a[c] = fma(-l, lane_bcast(l, c0 + c), a[c]);
+#endif
             }
 #pragma unroll
             for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(&Ls[lane * LD + c0 + c]) = double2{a[c], a[c + 1]};
         }
         __syncthreads();
-        if (p < 3) {   // columns behind the panel: tile (I, J) -= L_I L_J^T, the next panel's column of tiles first
-            int q = 0;
-#pragma unroll
-            for (int J = p + 1; J < 4; ++J)
-#pragma unroll
-                for (int I = J; I < 4; ++I) {
-                    if ((q & 3) == w) {
-                        d4 acc = potf2_tile_load(Ls, 16 * I, 16 * J, lr, lc);
-                        acc = potf2_tile_mma<true>(Ls, 16 * I, c0, 16 * J, c0, -1.0, acc, lr, lc);
-                        potf2_tile_store(Ls, 16 * I, 16 * J, lr, lc, acc);
-                    }
-                    ++q;
-                }
+        if (p < 3) {
+            // Columns behind the panel: tile (I, J) -= L_I L_J^T.  First the next panel's column of tiles (waves 1.., one
+            // each) and one of the others (wave 0); the rest of the others run on waves 1.. BESIDE the next panel's
+            // elimination -- they touch neither its columns nor anything it reads.
+            auto update = [&](int I, int J) {
+                d4 acc = potf2_tile_load(Ls, 16 * I, 16 * J, lr, lc);
+                acc = potf2_tile_mma<true>(Ls, 16 * I, c0, 16 * J, c0, -1.0, acc, lr, lc);
+                potf2_tile_store(Ls, 16 * I, 16 * J, lr, lc, acc);
+            };
+            if (w >= 1 && p + w < 4) update(p + w, p + 1);
+            if (w == 0 && p < 2) update(p + 2, p + 2);
             __syncthreads();
+            if (p == 0 && w == 1) update(3, 2);
+            if (p == 0 && w == 2) update(3, 3);
         }
     }
     if (w == 0) {
@@ -444,6 +461,7 @@ __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A,
     double x[16];
     if (w == 0) {
         const int base = 16 * lr * LD + 16 * lr;
+        S.rinvs[lane] = 1.0 / Ls[lane * LD + lane];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             double acc0 = (i == lc) ? 1.0 : 0.0, acc1 = 0.0;
