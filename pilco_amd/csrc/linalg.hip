@@ -106,7 +106,8 @@ constexpr int LDS_LD = 80;
 constexpr int POTF2_LD = 66;   // 16-byte aligned lines, lanes of a column spread over the banks
 struct Potf2Lds {               // LDS of one block factorisation
     double Ls[64 * POTF2_LD];   // the block (row-major): A, then L below the diagonal, then L^-1 (potf2_block)
-    double rinvs[64];           // 1 / L_jj
+    double rinvs[64];           // 1 / sqrt(pivot j)
+    double dump_d[64];          // where lanes past 0 put what only lane 0 has to store (branch-free)
     double line[64];            // the column being eliminated with, for broadcast reads
 };
 template <int NW>
@@ -408,11 +409,17 @@ __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A,
             for (int j = 0; j < 16; ++j) {
                 // (few instructions per column: a failed pivot is recorded and the elimination goes on with whatever it
                 // yields -- the caller discards the factor --; rows above the diagonal carry along unread values instead of
-                // zeros; 1 / L_jj is taken by the inverse, below, for all columns at once)
+                // zeros)
                 const double d = lane_bcast(a[j], c0 + j);
                 bad = (!(d > 0.0) && bad == 0) ? kb_abs * 64 + c0 + j + 1 : bad;   // (NaN too)
-                const double l = a[j] * rsqrt_f64(d);   // lane i >= column: L[i][column]
+                const double rinv = rsqrt_f64(d);
+                const double l = a[j] * rinv;   // lane i >= column: L[i][column]
                 a[j] = l;
+                // the inverse's diagonal: 1 / sqrt(pivot) as computed here.  (Taking 1 / L_jj in the inverse instead -- one
+                // division for all columns, no store per column -- is as accurate, |X L - I| 1.7e-16 against 2.2e-16, but moved
+                // the cond(K) = 1e9 fixture of tests/test_gpu_parity.py::test_predictions_golden from inside its 1e-5 of the
+                // 40-digit truth to 1.18e-5: the arithmetic the fixtures were pinned with stays)
+                *((lane == 0) ? &S.rinvs[c0 + j] : &S.dump_d[lane]) = rinv;   // (branch-free: lanes past 0 store into a dump)
 #if POTF2_LINE
                 // multipliers: the next column's from v_readlane (the next pivot waits for nothing else), the others read back
                 // from an LDS line as broadcasts, two per instruction (from v_readlane all of them: two instructions each,
@@ -461,7 +468,6 @@ __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A,
     double x[16];
     if (w == 0) {
         const int base = 16 * lr * LD + 16 * lr;
-        S.rinvs[lane] = 1.0 / Ls[lane * LD + lane];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             double acc0 = (i == lc) ? 1.0 : 0.0, acc1 = 0.0;
