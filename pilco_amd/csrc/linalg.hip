@@ -100,9 +100,6 @@ void launch_transpose_points(hipStream_t st, const double* X, int n, int D, doub
 constexpr int LDS_LD = 80;
 
 // (the block factorisation of the Cholesky section below, which the GEMM's fused form calls)
-#ifndef POTF2_LINE
-#define POTF2_LINE 1
-#endif
 constexpr int POTF2_LD = 66;   // 16-byte aligned lines, lanes of a column spread over the banks
 struct Potf2Lds {               // LDS of one block factorisation
     double Ls[64 * POTF2_LD];   // the block (row-major): A, then L below the diagonal, then L^-1 (potf2_block)
@@ -346,9 +343,10 @@ __device__ __forceinline__ double lane_bcast(double v, int l) {   // v of lane l
 // kb_abs * 64 + column + 1 of the first non-positive pivot.
 //
 // Blocked inside the block (round 5), panels of 16 columns:
-//   factor: wave 0 holds row i's 16 panel entries in lane i and eliminates the panel's columns in registers (pivot and
-//     multipliers by v_readlane: avg 7.5 updates per column instead of 31 over the whole block); the rank-16 update of the
-//     columns behind the panel is MFMA work of all four waves on the LDS copy (6 / 3 / 1 tiles of 16 x 16).
+//   factor: wave 0 holds row i's 16 panel entries in lane i and eliminates the panel's columns in registers (avg 7.5
+//     updates per column instead of 31 over the whole block; pivot and the next column's multiplier by v_readlane, the
+//     other multipliers from an LDS line); the rank-16 update of the columns behind the panel is MFMA work on the LDS copy
+//     (6 / 3 / 1 tiles of 16 x 16): the next panel's column of tiles first, the others beside the next panel's elimination.
 //     Rounds 3-4 eliminated all 64 columns in one wave's registers: 2016 fused multiply-adds and 1008 LDS reads issued by
 //     ONE wave, 16 us of the 20 us this block takes on the chain's critical path.
 //   inverse, in place behind the stored factor: the four 16 x 16 diagonal blocks by substitution in one wave (lane
@@ -420,7 +418,6 @@ __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A,
                 // the cond(K) = 1e9 fixture of tests/test_gpu_parity.py::test_predictions_golden from inside its 1e-5 of the
                 // 40-digit truth to 1.18e-5: the arithmetic the fixtures were pinned with stays)
                 *((lane == 0) ? &S.rinvs[c0 + j] : &S.dump_d[lane]) = rinv;   // (branch-free: lanes past 0 store into a dump)
-#if POTF2_LINE
                 // multipliers: the next column's from v_readlane (the next pivot waits for nothing else), the others read back
                 // from an LDS line as broadcasts, two per instruction (from v_readlane all of them: two instructions each,
                 // 240 of a panel's ~700)
@@ -433,10 +430,6 @@ __device__ __forceinline__ void potf2_block(Potf2Lds& S, double* __restrict__ A,
                     a[c] = fma(-l, pr.x, a[c]);
                     a[c + 1] = fma(-l, pr.y, a[c + 1]);
                 }
-#else
-#pragma unroll
-                for (int c = j + 1; c < 16; ++c) a[c] = fma(-l, lane_bcast(l, c0 + c), a[c]);
-#endif
             }
 #pragma unroll
             for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(&Ls[lane * LD + c0 + c]) = double2{a[c], a[c + 1]};
