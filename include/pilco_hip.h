@@ -22,7 +22,9 @@
 extern "C" {
 #endif
 
-#define PILCO_HIP_ABI_VERSION 1
+/* 2: round 6 -- the round-4 persistent-kernel entry points are gone (since round 5) and the launch-structure knobs,
+ * the sharding-plan introspection and pilco_rollout_tape are declared in pilco_hip_dev.h (still exported). */
+#define PILCO_HIP_ABI_VERSION 2
 
 typedef struct pilco_ctx pilco_ctx;
 
@@ -44,35 +46,6 @@ int pilco_ctx_destroy(pilco_ctx* ctx);
 const char* pilco_last_error(const pilco_ctx* ctx);
 /* index of the output whose Gram matrix was not positive definite (-1 if none) */
 int pilco_last_not_pd_output(const pilco_ctx* ctx);
-/* pair-kernel variant: 0 = MFMA, stream-K work split (default, fastest; run-to-run bitwise stable);
- * 1 = plain-VALU tiled reference; 2 = MFMA tiled (bits also independent of the number of ranks).
- * All three agree to rounding. */
-int pilco_set_pair_kernel(pilco_ctx* ctx, int variant);
-/* Launch structure of a rollout step.  1 (default): "fused head" -- the serial link of step t (reduce the pair sums,
- * assemble (M,S,V), propagate, controller, joint Gaussian: mgpr.py:143-149, pilco.py:139-149) runs redundantly inside every
- * workgroup of step t+1's operand kernel, two launches per horizon step.  0: separate link kernel, three launches per
- * step (always used with more than one rank unless the peer exchange is attached).  Both produce bitwise identical results. */
-int pilco_set_fused_step(pilco_ctx* ctx, int on);
-/* Models of at most 256 points (every example of the reference; the inducing points of a sparse model: smgpr.py:47-52): 1
- * (default; PILCO_SMALL_STEP=0 in the environment starts with 0) = with the fused step, the operand launch's pair workgroups
- * also evaluate their pair sums, so a horizon step is ONE launch; 0 = the pair sums keep their own launch.  Same arithmetic
- * per element; the two split the sums differently, so results agree to rounding and each is bitwise repeatable. */
-int pilco_set_small_step(pilco_ctx* ctx, int on);
-/* How pilco_rollout_grad / pilco_rollout_grad_rbf obtain the moment-matching adjoint: 1 (default) = Jacobian tape -- the
- * forward rollout runs the reverse sweep in place of the forward pair kernel, so that ONE O(N^2) pass per step yields the
- * step's value and its Jacobian, and the reverse sweep is host algebra on the downloaded records; 0 = plain tape, then the
- * O(N^2) adjoint of every step on the device again (pilco_gp_predict_vjp).  Same gradient up to rounding. */
-int pilco_set_grad_mode(pilco_ctx* ctx, int mode);
-/* 1 (default; PILCO_NO_GRAPH=1 in the environment starts with 0): a rollout's launch sequence is captured once into a
- * hipGraph and replayed while the plan is unchanged; 0: every rollout is enqueued launch by launch.  Same results. */
-int pilco_set_use_graph(pilco_ctx* ctx, int on);
-/* RbfController inside a rollout.  1 (default; PILCO_INLINE_POLICY=0 starts with 0): a policy GP that is small enough
- * (bf <= 256 basis functions, state_dim <= 16, control_dim <= 4, U(U+1)/2 bf^2 <= 16384) is evaluated INSIDE the serial
- * link of the step -- by the workgroups that run the link anyway, from the state in LDS -- so that a step is two launches
- * (head, pair sums) as with a LinearController; 0: the policy GP gets its own operand and pair launch (four launches per
- * step), which is also what larger policies always get.  Same formulas (controllers.py:108-121 -> mgpr.py:99-149 with
- * iK = 0); the summation order differs, results agree to rounding (~1e-13), each mode is bitwise repeatable. */
-int pilco_set_inline_policy(pilco_ctx* ctx, int on);
 /* checks the f64 MFMA fragment layout assumptions on the device; 0 = OK */
 int pilco_selftest(pilco_ctx* ctx);
 
@@ -185,14 +158,9 @@ int pilco_reward_eval(pilco_ctx* ctx, const pilco_reward_term* rewards, int n_re
  * The reference differentiates training_loss with TensorFlow's autodiff (pilco/models/pilco.py:85-90);
  * here the adjoint of the moment-matching step is hand-derived.
  * pilco_gp_predict_vjp: cotangents Mbar (1,E), Sbar (E,E), Vbar (D,E) of pilco_gp_predict's outputs ->
- * mbar (1,D), sbar (D,D, symmetric) at the input (m, s).  Single rank, D <= 32.
- * pilco_rollout_tape: pilco_rollout that also returns, per step, the joint Gaussian handed to the
- * dynamics GP (m (D), s (D,D), s1 (E,D)) and its outputs (M (E), S (E,E), V (D,E)). */
+ * mbar (1,D), sbar (D,D, symmetric) at the input (m, s).  Single rank, D <= 32. */
 int pilco_gp_predict_vjp(pilco_ctx* ctx, int slot, const double* m, const double* s, const double* Mbar,
                          const double* Sbar, const double* Vbar, double* mbar, double* sbar);
-int pilco_rollout_tape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards,
-                       const double* m0, const double* S0, int H, double* mH, double* SH, double* reward, double* traj,
-                       double* tape);
 /* Cotangent seeds for objectives beyond the additive reward (SafePILCO's multiplicative risk term,
  * safe_pilco_extension/safe_pilco.py:29-50; any function of the state trajectory): after the forward pass the library
  * calls seed_fn(user, H, E, traj, seeds) with traj [H+1][E + E*E] (m_t | s_t, t = 0..H; state t < H is the
@@ -256,16 +224,9 @@ int pilco_rollout_grad_rbf_batch_seeded(pilco_ctx* ctx, int B, const pilco_polic
 int pilco_comm_unique_id(void* id128);
 int pilco_comm_init(pilco_ctx* ctx, const void* id128, int rank, int nranks);
 /* sharding without a communicator: the caller moves the bytes (host fake
- * all-gather for tests; gloo fallback).  Ownership map: pair p -> rank. */
+ * all-gather for tests; gloo fallback).  Pairs are dealt round-robin in the order (0,0),(1,1),..,(E-1,E-1),(1,0),(2,0),(2,1),..;
+ * output a belongs to the owner of (a,a)  (the plan's introspection functions: include/pilco_hip_dev.h). */
 int pilco_shard_set(pilco_ctx* ctx, int rank, int nranks);
-int pilco_shard_owner_of_pair(const pilco_ctx* ctx, int pair_index);
-/* Layout of the per-step exchange (pure host functions, usable without a GPU).
- * out5 = {local pairs, owned outputs, SEG (doubles per rank), OUTOFF, P}; pairs are dealt
- * round-robin in the order (0,0),(1,1),..,(E-1,E-1),(1,0),(2,0),(2,1),.. and output a belongs
- * to the owner of (a,a).  *_slot return indices into the gathered buffer [nranks][SEG]. */
-int pilco_shard_plan(int E, int D, int nranks, int rank, int* out5);
-int pilco_shard_pair_slot(int E, int D, int nranks, int a, int b);
-int pilco_shard_output_slot(int E, int D, int nranks, int a);
 /* One sharded moment-matching step with the exchange done by the caller: shard_pack runs this
  * rank's pairs and returns its SEG doubles; after an all-gather by any transport, shard_finish
  * assembles (M, S, V) from the [nranks][SEG] buffer.  pilco_gp_predict / pilco_rollout do the
@@ -322,11 +283,8 @@ int pilco_peer_export(pilco_ctx* ctx, void* handle64);
 int pilco_peer_attach(pilco_ctx* ctx, const void* handles, int share_gpu);
 int pilco_group_peer_attach(pilco_ctx** ctxs, int n);
 int pilco_peer_detach(pilco_ctx* ctx);
-int pilco_peer_attached(const pilco_ctx* ctx);
 int pilco_comm_rank(const pilco_ctx* ctx);
 int pilco_comm_size(const pilco_ctx* ctx);
-/* the number of ranks RCCL ITSELF reports for the attached communicator (ncclCommCount); 0 = none attached, -1 = RCCL error */
-int pilco_comm_count(const pilco_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -350,6 +350,9 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
     if (const char* ef = getenv("PILCO_SMALL_STEP")) ctx->fuse_small = (atoi(ef) != 0);
     if (const char* env = getenv("PILCO_PAIR_KERNEL")) {   // a choice like pilco_set_pair_kernel's: pilco_shard_set / _comm_init leave it alone
         ctx->variant = (atoi(env) >= 0 && atoi(env) <= 2) ? atoi(env) : 0;
+#ifndef PILCO_DEV
+        if (ctx->variant == 1) ctx->variant = 0;   // (the plain-VALU cross-check kernel is not in this build)
+#endif
         ctx->variant_user = true;
     }
     *out = ctx;
@@ -400,6 +403,9 @@ int pilco_last_not_pd_output(const pilco_ctx* ctx) { return ctx ? ctx->not_pd : 
 
 int pilco_set_pair_kernel(pilco_ctx* ctx, int variant) {
     if (!ctx || variant < 0 || variant > 2) return PILCO_E_SHAPE;
+#ifndef PILCO_DEV
+    if (variant == 1) return fail(ctx, PILCO_E_STATE, "set_pair_kernel: the plain-VALU cross-check kernel exists in -DPILCO_DEV builds only");
+#endif
     ctx->variant = variant;
     ctx->variant_user = true;
     return PILCO_OK;

@@ -116,9 +116,11 @@ __global__ __launch_bounds__(256, (KC <= 4 && PAIR_MINW < 3) ? 3 : PAIR_MINW) vo
 }
 
 
-// ------------------------------------------------------------------ pair kernel, plain VALU
+// ------------------------------------------------------------------ pair kernel, plain VALU  (-DPILCO_DEV builds only)
 // Reference implementation of the same tile sums without matrix cores: one row
-// per thread (256-row tile), 64 columns staged in LDS and read by broadcast.
+// per thread (256-row tile), 64 columns staged in LDS and read by broadcast.  A cross-check of the MFMA kernels, not a
+// product path: the shipped library does not contain it (pilco_set_pair_kernel(ctx, 1) fails there).
+#ifdef PILCO_DEV
 template <int KPT>
 __global__ __launch_bounds__(256) void k_mm_pair_valu(MMModel md, MMWork wk) {
     __shared__ double Bs[KPT][64];
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(256) void k_mm_pair_valu(MMModel md, MMWork wk) {
         out[1] = ((red[1] + red[3]) + red[5]) + red[7];
     }
 }
+#endif   // PILCO_DEV
 
 static int pair_njb(int npad, int PL) {
     const int nb = npad / 64;
@@ -235,6 +238,7 @@ int mm_pair_sk_capacity(int KP, bool vsep) {
 
 void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int variant) {
     const int KP = wk.KP;
+#ifdef PILCO_DEV
     if (variant == 1) {
         dim3 grid(((md.npad + 255) / 256) * (md.npad / 64), wk.PL);
 #define PV(K_) hipLaunchKernelGGL((k_mm_pair_valu<K_>), grid, dim3(256), 0, st, md, wk)
@@ -247,6 +251,7 @@ void launch_mm_pair(hipStream_t st, const MMModel& md, const MMWork& wk, int var
 #undef PV
         return;
     }
+#endif
     if (variant == 2) {
         const int NJB = wk.NT / (md.npad / (16 * PAIR_RT));
         dim3 grid((md.npad / (16 * PAIR_RT)) * NJB, wk.PL);

@@ -138,6 +138,26 @@ class PILCO:
         return optimize_policy(self, maxiter=maxiter, restarts=restarts, verbose=verbose)
 
     # pilco.py:115-116
+    def value_and_gradient(self, seed_fn=None):
+        """(reward, grads) of the rollout reward w.r.t. the controller parameters: grads = (dW, db) for a LinearController,
+        (dX, dY, dlengthscales) for an RbfController.  The reference obtains it from TensorFlow's reverse mode through the
+        tf.while_loop (pilco/models/pilco.py:85-90,126-135); here the whole reverse sweep is native (pilco_rollout_grad /
+        pilco_rollout_grad_rbf) and deterministic: the same inputs give bitwise the same gradient.
+        seed_fn(traj (H+1, E+E*E)) -> cotangent seeds d objective / d (m_t, s_t) for an objective beyond the additive
+        reward (the returned reward is the additive part; the gradients are those of additive reward + seeded objective)."""
+        ctl = self.controller
+        linear = isinstance(ctl, controllers.LinearController)
+        if not linear and not isinstance(ctl, controllers.RbfController):
+            raise TypeError("analytic policy gradient: LinearController or RbfController")
+        self.mgpr._user_factors = None
+        self.mgpr._ensure_factorized()
+        if linear:
+            r, dW, db = self.ctx.rollout_grad(self._policy_spec(), self._reward_terms(), self.m_init, self.S_init, self.horizon, seed_fn=seed_fn)
+            return r, (dW.reshape(ctl.W.shape), db.reshape(ctl.b.shape))
+        r, dX, dY, dl = self.ctx.rollout_grad_rbf(self._policy_spec(), self._reward_terms(), self.m_init, self.S_init, self.horizon,
+                                                  ctl.X, ctl.Y, ctl.lengthscales, ctl.noise, seed_fn=seed_fn)
+        return r, (dX, dY, dl)
+
     def compute_action(self, x_m):
         return self.controller.compute_action(x_m, np.zeros([self.state_dim, self.state_dim]))[0]
 

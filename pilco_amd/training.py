@@ -415,7 +415,7 @@ def _policy_params(controller):
 
 
 def policy_loss_and_grad(pilco, u, put, eps=1e-6):
-    """-reward and its gradient: the hand-derived adjoint (pilco_amd/adjoint.py) for linear and RBF controllers
+    """-reward and its gradient: the hand-derived adjoint (PILCO.value_and_gradient) for linear and RBF controllers
     with exponential / linear / combined rewards, central differences of device rollouts (2n+1 of them) otherwise."""
     from . import _lib
     from .controllers import LinearController, RbfController
@@ -445,8 +445,7 @@ def policy_loss_and_grad(pilco, u, put, eps=1e-6):
         return out[1]
 
     if analytic and isinstance(ctl, (LinearController, RbfController)):
-        from .adjoint import rollout_value_and_grad
-        r, grads = rollout_value_and_grad(pilco, seed_fn if seeded else None)
+        r, grads = pilco.value_and_gradient(seed_fn if seeded else None)
         if extra["ok"]:
             r += extra["v"]
             if isinstance(ctl, LinearController):

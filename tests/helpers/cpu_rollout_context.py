@@ -1,6 +1,6 @@
 """A CPU stand-in for the device calls PILCO.optimize_policy makes (rollout value, value + policy gradient), so that the HOST
 side of the policy optimisation -- parameter packing, the softplus transform of the RBF lengthscales with its lower bound,
-sign conventions, L-BFGS-B options, restart bookkeeping (pilco_amd/training.py, adjoint.py, controllers.py) -- can be held to
+sign conventions, L-BFGS-B options, restart bookkeeping (pilco_amd/training.py, models/pilco.py, controllers.py) -- can be held to
 the executed reference's end points in the CPU suite.  TEST INFRASTRUCTURE: values and gradients come from the torch
 restatement of the rollout (oracle/torch_path.py, autograd in the role of TF's reverse mode); the product computes them on the
 device (pilco_rollout, pilco_rollout_grad*)."""

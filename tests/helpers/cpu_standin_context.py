@@ -1,4 +1,4 @@
-"""Every device call the Python layer makes (pilco_amd/models, controllers, rewards, safe, training, adjoint), answered on
+"""Every device call the Python layer makes (pilco_amd/models, controllers, rewards, safe, training), answered on
 the CPU by the oracle: TEST INFRASTRUCTURE that lets the CPU suite drive the product's HOST logic end to end -- whole
 example loops included -- on a box without a GPU.  Installed with _lib.set_context() by tests only; nothing in pilco_amd/
 knows it exists, and it is no fallback: the product raises without libpilco_hip.so and a GPU

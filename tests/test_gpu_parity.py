@@ -65,12 +65,29 @@ def test_factorization_matches_oracle(ctx, N):
         assert np.linalg.norm(beta[a] - betao[a]) / np.linalg.norm(betao[a]) < 1e-9
 
 
+def _has_valu_kernel(cx):
+    """The plain-VALU cross-check pair kernel (variant 1) is compiled into -DPILCO_DEV builds only; the shipped library refuses it."""
+    from pilco_amd import _lib
+    try:
+        cx.set_pair_kernel(1)
+    except _lib.PilcoError:
+        return False
+    cx.set_pair_kernel(0)
+    return True
+
+
+def _pair_variant(cx, variant):
+    if variant == 1 and not _has_valu_kernel(cx):
+        pytest.skip("pair-kernel variant 1 (plain VALU cross-check) exists in -DPILCO_DEV builds only")
+    cx.set_pair_kernel(variant)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("name", ["predictions.npz", "predictions_lownoise.npz"])
 def test_predictions_golden(ctx, golden_dir, name, variant):
     """BASELINE config 1 = tests/test_predictions.py (set_data between two predicts included)."""
     g = np.load(os.path.join(golden_dir, name))
-    ctx.set_pair_kernel(variant)
+    _pair_variant(ctx, variant)
     try:
         cfg = dict(X=g["X_first"], Y=g["Y"], lengthscales=g["lengthscales"], variance=g["variance"], noise=g["noise"])
         m = _mgpr(cfg)
@@ -145,6 +162,8 @@ def test_asymmetric_caller_supplied_iK(ctx, golden_dir):
     iKa = iK * (1.0 + 0.3 * rs.rand(*iK.shape))        # strongly asymmetric
     assert not np.allclose(iKa, np.swapaxes(iKa, 1, 2))
     for variant in (0, 1, 2):
+        if variant == 1 and not _has_valu_kernel(ctx):
+            continue
         ctx.set_pair_kernel(variant)
         try:
             M, S, V = m.predict_given_factorizations(g["m"], g["s"], iKa, beta)
@@ -301,7 +320,7 @@ def test_controllers_and_reward_golden(ctx, golden_dir):
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_midsize_random_vs_oracle(ctx, variant):
     c = synthetic.config_c2(N=300, D=5, E=4, noise=1e-2, seed=11, control_dim=1)
-    ctx.set_pair_kernel(variant)
+    _pair_variant(ctx, variant)
     try:
         m = _mgpr(c)
         rs = np.random.RandomState(3)
@@ -445,7 +464,6 @@ def test_fused_head_is_bitwise_identical_to_the_three_kernel_step(ctx, D):
 def test_fused_heads_with_an_rbf_policy_are_bitwise_identical_to_the_six_kernel_step(ctx, N, E, U, bf):
     """RbfController rollouts: the two fused heads per step (policy head, dynamics head; 4 launches) against the separate
     link kernels (6 launches): trajectory, reward and the policy gradient (whose forward pass writes the tape) to the last bit."""
-    from pilco_amd.adjoint import rollout_value_and_grad
     from pilco_amd.controllers import RbfController
     from pilco_amd.models import PILCO
     rs = np.random.RandomState(5)
@@ -465,7 +483,7 @@ def test_fused_heads_with_an_rbf_policy_are_bitwise_identical_to_the_six_kernel_
             ctx.set_fused_step(fused)
             try:
                 out.append(p.predict_trajectory(m0, S0, H))
-                grads.append(rollout_value_and_grad(p) if D <= 14 else None)
+                grads.append(p.value_and_gradient() if D <= 14 else None)
             finally:
                 ctx.set_fused_step(1)
         for k in (1, 2):
@@ -488,7 +506,7 @@ def test_fused_heads_with_an_rbf_policy_are_bitwise_identical_to_the_six_kernel_
     for a, b in zip(inl[0], out[0]):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-13)
     if grads[0] is not None:
-        gi = [rollout_value_and_grad(p) for _ in range(2)]
+        gi = [p.value_and_gradient() for _ in range(2)]
         assert gi[0][0] == gi[1][0] and all(np.array_equal(a, b) for a, b in zip(gi[0][1], gi[1][1]))
         np.testing.assert_allclose(gi[0][0], grads[0][0], rtol=1e-9)
         for a, b in zip(gi[0][1], grads[0][1]):
@@ -498,7 +516,6 @@ def test_fused_heads_with_an_rbf_policy_are_bitwise_identical_to_the_six_kernel_
 def test_full_size_c2u_gradient_vs_reverse_mode_through_the_reference(ctx, golden_dir):
     """d reward / d (W, b) at C2u (N=1000, D=11, E=10), H=5: the native adjoint against torch reverse mode THROUGH THE
     EXECUTED REFERENCE's training_loss (pilco.py:47-50,85-90; fixture c2u_grad.npz), not against the HIP path itself."""
-    from pilco_amd.adjoint import rollout_value_and_grad
     g = np.load(os.path.join(golden_dir, "c2u_grad.npz"))
     c = synthetic.config_c2(N=1000, D=11, E=10)
     H = int(g["H"])
@@ -507,18 +524,17 @@ def test_full_size_c2u_gradient_vs_reverse_mode_through_the_reference(ctx, golde
     p.controller.b.assign(c["b"])
     p.controller.max_action = 1.0
     p.m_init, p.S_init = c["m0"], c["S0"]
-    r, (Wb, bb) = rollout_value_and_grad(p)
+    r, (Wb, bb) = p.value_and_gradient()
     np.testing.assert_allclose(r, float(g["reward"]), rtol=RTOL)
     np.testing.assert_allclose(Wb, g["dreward_dW"], rtol=RTOL, atol=1e-9)
     np.testing.assert_allclose(bb.reshape(1, -1), g["dreward_db"], rtol=RTOL, atol=1e-9)
-    r2, (Wb2, bb2) = rollout_value_and_grad(p)
+    r2, (Wb2, bb2) = p.value_and_gradient()
     assert r2 == r and np.array_equal(Wb2, Wb) and np.array_equal(bb2, bb)
 
 
 def test_policy_gradients_vs_reverse_mode_through_the_reference(ctx, golden_dir):
     """Linear and RBF controller gradients of the rollout reward against reverse mode through the executed reference
     (fixture policy_gradient.npz, oracle/gen_golden.py: gen_policy_gradient)."""
-    from pilco_amd.adjoint import rollout_value_and_grad
     from pilco_amd.controllers import RbfController
     from pilco_amd.models import PILCO
     from pilco_amd.rewards import CombinedRewards, ExponentialReward, LinearReward
@@ -530,7 +546,7 @@ def test_policy_gradients_vs_reverse_mode_through_the_reference(ctx, golden_dir)
     p.controller.W.assign(g["W"])
     p.controller.b.assign(g["b"])
     p.controller.max_action = float(g["max_action"])
-    r, (Wb, bb) = rollout_value_and_grad(p)
+    r, (Wb, bb) = p.value_and_gradient()
     np.testing.assert_allclose(r, float(g["reward"]), rtol=RTOL)
     np.testing.assert_allclose(Wb, g["dreward_dW"], rtol=RTOL, atol=1e-10)
     np.testing.assert_allclose(bb.reshape(1, -1), g["dreward_db"], rtol=RTOL, atol=1e-10)
@@ -541,7 +557,7 @@ def test_policy_gradients_vs_reverse_mode_through_the_reference(ctx, golden_dir)
     p2 = PILCO((g["X"], g["Y"]), horizon=int(g["rbf_H"]), controller=ctl, reward=rew, m_init=g["m"], S_init=g["s"])
     for i, mdl in enumerate(p2.mgpr.models):
         mdl.kernel.lengthscales.assign(g["lengthscales"][i]); mdl.kernel.variance.assign(g["variance"][i]); mdl.likelihood.variance.assign(g["noise"][i])
-    r, (Xb, Yb, lb) = rollout_value_and_grad(p2)
+    r, (Xb, Yb, lb) = p2.value_and_gradient()
     np.testing.assert_allclose(r, float(g["rbf_reward"]), rtol=RTOL)
     np.testing.assert_allclose(Xb, g["rbf_dreward_dX"], rtol=RTOL, atol=1e-10)
     np.testing.assert_allclose(Yb, g["rbf_dreward_dY"], rtol=RTOL, atol=1e-10)
@@ -1223,7 +1239,6 @@ def test_policy_gradient_adjoint_vs_autograd_and_fd(ctx):
     (the reference's TF reverse mode through the while_loop, pilco.py:85-90,126-135) and vs central differences."""
     import torch
     from oracle import torch_path as tq
-    from pilco_amd.adjoint import rollout_value_and_grad
     from oracle.adjoint_sweep import rollout_value_and_grad_py
     from pilco_amd.rewards import ExponentialReward
     c = synthetic.config_cascade()
@@ -1237,7 +1252,7 @@ def test_policy_gradient_adjoint_vs_autograd_and_fd(ctx):
     p.controller.W.assign(c["W"])
     p.controller.b.assign(c["b"])
     p.controller.max_action = 2.0
-    r, (Wb, bb) = rollout_value_and_grad(p)
+    r, (Wb, bb) = p.value_and_gradient()
     np.testing.assert_allclose(r, float(p.compute_reward()[0, 0]), rtol=1e-10)   # two summation orders of the same pair sums
     # autograd oracle
     iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
@@ -1264,7 +1279,7 @@ def test_policy_gradient_adjoint_vs_autograd_and_fd(ctx):
         fm = float(p.compute_reward()[0, 0])
         np.testing.assert_allclose(Wb[idx], (fp - fm) / (2 * h), rtol=1e-4)
     p.controller.W.assign(W0)
-    r2, (Wb2, bb2) = rollout_value_and_grad(p)
+    r2, (Wb2, bb2) = p.value_and_gradient()
     assert r2 == r and np.array_equal(Wb2, Wb) and np.array_equal(bb2, bb)
     # the native sweep (pilco_rollout_grad) and the same sweep driven from Python agree to rounding
     r3, (Wb3, bb3) = rollout_value_and_grad_py(p)
@@ -1278,7 +1293,6 @@ def test_degenerate_dims_and_two_controls(ctx):
     control dimensions, each against the oracle; plus the policy gradient with U=2 against autograd."""
     import torch
     from oracle import torch_path as tq
-    from pilco_amd.adjoint import rollout_value_and_grad
     from pilco_amd.models import PILCO
     rs = np.random.RandomState(3)
     X = rs.randn(17, 1)
@@ -1309,7 +1323,7 @@ def test_degenerate_dims_and_two_controls(ctx):
     np.testing.assert_allclose(Mg, Mo, rtol=RTOL)
     np.testing.assert_allclose(Sg, So, rtol=RTOL, atol=1e-12)
     np.testing.assert_allclose(Rg, Ro, rtol=RTOL)
-    r, (Wb, bb) = rollout_value_and_grad(p)
+    r, (Wb, bb) = p.value_and_gradient()
     iK, beta = tp.calculate_factorizations(X, Y, ls, var, nz)
     Wt = torch.tensor(W, dtype=torch.float64, requires_grad=True)
     bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
@@ -1385,7 +1399,6 @@ def test_rbf_policy_gradient_adjoint_vs_autograd(ctx):
     optimize_policy run that must not lower the reward."""
     import torch
     from oracle import torch_path as tq
-    from pilco_amd.adjoint import rollout_value_and_grad
     from oracle.adjoint_sweep import rollout_value_and_grad_py
     from pilco_amd.controllers import RbfController
     from pilco_amd.models import PILCO
@@ -1403,7 +1416,7 @@ def test_rbf_policy_gradient_adjoint_vs_autograd(ctx):
     p = PILCO((c["X"], c["Y"]), horizon=H, controller=ctl, reward=rew, m_init=c["m"], S_init=c["s"])
     for i, mdl in enumerate(p.mgpr.models):
         mdl.kernel.lengthscales.assign(c["lengthscales"][i]); mdl.kernel.variance.assign(c["variance"][i]); mdl.likelihood.variance.assign(c["noise"][i])
-    r, (Xb, Yb, lb) = rollout_value_and_grad(p)
+    r, (Xb, Yb, lb) = p.value_and_gradient()
     np.testing.assert_allclose(r, float(p.compute_reward()[0, 0]), rtol=1e-10)   # two summation orders of the same pair sums
     iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
     tX, tY, tl = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (Xp, Yp, lsp)]
@@ -1536,7 +1549,6 @@ def test_native_rollout_grad_combined_reward_and_errors(ctx):
     """pilco_rollout_grad with a CombinedRewards objective (exponential + linear terms, rewards.py:64-81) against the
     same sweep driven from Python; unsupported policies are refused, not silently mishandled."""
     from pilco_amd import _lib
-    from pilco_amd.adjoint import rollout_value_and_grad
     from oracle.adjoint_sweep import rollout_value_and_grad_py
     from pilco_amd.rewards import CombinedRewards, ExponentialReward, LinearReward
     c = synthetic.config_cascade()
@@ -1546,7 +1558,7 @@ def test_native_rollout_grad_combined_reward_and_errors(ctx):
                                    LinearReward(2, np.array([[0.3], [-0.4]]))], coefs=[0.7, 1.5])
     p.m_init, p.S_init = c["m"], c["s"]
     p.controller.W.assign(c["W"]); p.controller.b.assign(c["b"]); p.controller.max_action = 1.3
-    r1, (W1, b1) = rollout_value_and_grad(p)
+    r1, (W1, b1) = p.value_and_gradient()
     r2, (W2, b2) = rollout_value_and_grad_py(p)
     np.testing.assert_allclose(r1, r2, rtol=1e-10)
     np.testing.assert_allclose(W1, W2, rtol=1e-9, atol=1e-13)
@@ -1626,12 +1638,11 @@ def test_full_size_c2_properties(ctx):
 def test_full_size_c2u_gradient_directional_fd(ctx):
     """C2u (N=1000, state 10 + 1 control, H=40): the native value-and-gradient against a central difference of device
     rollouts along a random direction in (W, b) -- a full-size check that needs no oracle run."""
-    from pilco_amd.adjoint import rollout_value_and_grad
     c = synthetic.config_c2(N=1000, D=11, E=10)
     p = _pilco_from(c, 40)
     p.controller.W.assign(c["W"]); p.controller.b.assign(c["b"]); p.controller.max_action = 1.0
     p.m_init, p.S_init = c["m0"], c["S0"]
-    r, (Wb, bb) = rollout_value_and_grad(p)
+    r, (Wb, bb) = p.value_and_gradient()
     np.testing.assert_allclose(r, float(p.compute_reward()[0, 0]), rtol=1e-10)   # two summation orders of the same pair sums
     rs = np.random.RandomState(3)
     dW, db = rs.randn(*Wb.shape), rs.randn(*bb.shape)
@@ -1651,7 +1662,6 @@ def test_jacobian_tape_gradient_equals_per_step_device_adjoint(ctx, shape):
     """pilco_rollout_grad with the Jacobian tape (one O(N^2) sweep per step yields value + Jacobian records, reverse sweep
     on the host) against the plain tape + per-step device adjoint (pilco_gp_predict_vjp): same value, same gradient up to
     rounding, each bitwise repeatable; LinearController and RbfController."""
-    from pilco_amd.adjoint import rollout_value_and_grad
     from pilco_amd.controllers import RbfController
     from pilco_amd.models import PILCO
     N, D, E, H = shape
@@ -1674,7 +1684,7 @@ def test_jacobian_tape_gradient_equals_per_step_device_adjoint(ctx, shape):
         try:
             for mode in (1, 0, 1):
                 p.ctx.set_grad_mode(mode)
-                r, grads = rollout_value_and_grad(p)
+                r, grads = p.value_and_gradient()
                 if mode in out:   # second Jacobian-tape run (a graph replay): bitwise the same
                     assert r == out[mode][0] and all(np.array_equal(a, b) for a, b in zip(grads, out[mode][1]))
                 out[mode] = (r, [np.array(g) for g in grads])
@@ -1690,7 +1700,6 @@ def test_safe_pilco_rbf_policy_gradient_vs_executed_extension(ctx, golden_dir):
     """SafePILCO with an RbfController and RiskOfCollision (the pairing of examples/safe_cars_run.py:72-86): total reward
     and its gradient w.r.t. the RBF centres / targets / lengthscales against reverse mode through the EXECUTED extension
     (fixture safe_pilco_rbf.npz): the risk term reaches the native sweep as cotangent seeds (pilco_rollout_grad_rbf_seeded)."""
-    from pilco_amd.adjoint import rollout_value_and_grad
     from pilco_amd.controllers import RbfController
     from pilco_amd.rewards import LinearReward
     from pilco_amd.safe import RiskOfCollision, SafePILCO
@@ -1714,7 +1723,7 @@ def test_safe_pilco_rbf_policy_gradient_vs_executed_extension(ctx, golden_dir):
         extra["v"] = v
         return seeds
 
-    r_add, (dX, dY, dls) = rollout_value_and_grad(p, seed_fn)
+    r_add, (dX, dY, dls) = p.value_and_gradient(seed_fn)
     np.testing.assert_allclose(r_add + extra["v"], float(g["reward_total"]), rtol=1e-9)
     for got, key in ((dX, "dtotal_dX"), (dY, "dtotal_dY"), (dls, "dtotal_dls")):
         np.testing.assert_allclose(got, g[key], rtol=1e-6, atol=1e-9 * float(np.abs(g[key]).max()))
@@ -1854,7 +1863,6 @@ def test_sparse_rollout_and_policy_gradient_vs_executed_reference(ctx, golden_di
     """PILCO(num_induced_points=M) executed (fixture sparse_rollout.npz): every state of an H = 6 rollout through the FITC
     model, the running reward, and d reward / d (W, b) against reverse mode through the executed reference -- the sparse
     counterpart of test_cascade (each output trains its own Z, prediction uses model 0's, smgpr.py:50-52)."""
-    from pilco_amd.adjoint import rollout_value_and_grad
     from pilco_amd.models import PILCO
     g = np.load(os.path.join(golden_dir, "sparse_rollout.npz"))
     H, Zs = int(g["H"]), g["Z_all"]
@@ -1869,7 +1877,7 @@ def test_sparse_rollout_and_policy_gradient_vs_executed_reference(ctx, golden_di
         np.testing.assert_allclose(traj[t, :E], g["M_traj"][:, t], rtol=RTOL)
         np.testing.assert_allclose(traj[t, E:].reshape(E, E), g["S_traj"][:, :, t], rtol=RTOL)
     np.testing.assert_allclose(float(np.ravel(R)[0]), g["R_traj"][-1], rtol=RTOL)
-    r, (Wb, bb) = rollout_value_and_grad(p)
+    r, (Wb, bb) = p.value_and_gradient()
     np.testing.assert_allclose(r, float(g["reward"]), rtol=1e-8)
     np.testing.assert_allclose(Wb, g["dreward_dW"], rtol=1e-6)
     np.testing.assert_allclose(bb, g["dreward_db"], rtol=1e-6)
@@ -1878,7 +1886,6 @@ def test_sparse_rollout_and_policy_gradient_vs_executed_reference(ctx, golden_di
 def test_sparse_model_policy_gradient_jacobian_tape_vs_device_adjoint_and_fd(ctx):
     """Value and gradient through an SMGPR dynamics model (FITC factors, moment matching over the M inducing points,
     smgpr.py:24-52): Jacobian tape against the per-step device adjoint and against a central difference of rollouts."""
-    from pilco_amd.adjoint import rollout_value_and_grad
     from pilco_amd.models import PILCO
     c = synthetic.config_c2(N=400, D=5, E=4)
     rs = np.random.RandomState(3)
@@ -1895,7 +1902,7 @@ def test_sparse_model_policy_gradient_jacobian_tape_vs_device_adjoint_and_fd(ctx
     try:
         for mode in (1, 0):
             p.ctx.set_grad_mode(mode)
-            out[mode] = rollout_value_and_grad(p)
+            out[mode] = p.value_and_gradient()
     finally:
         p.ctx.set_grad_mode(1)
     np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-10)
@@ -1904,7 +1911,7 @@ def test_sparse_model_policy_gradient_jacobian_tape_vs_device_adjoint_and_fd(ctx
     # a rollout whose per-step buffers would exceed the cap (PILCO_JAC_GB) hands over to the per-step device adjoint by itself
     os.environ["PILCO_JAC_GB"] = "1e-6"
     try:
-        r_cap, g_cap = rollout_value_and_grad(p)
+        r_cap, g_cap = p.value_and_gradient()
     finally:
         del os.environ["PILCO_JAC_GB"]
     assert r_cap == out[0][0] and all(np.array_equal(a, b) for a, b in zip(g_cap, out[0][1]))
@@ -1920,13 +1927,12 @@ def test_policy_gradient_wide_inputs_vs_executed_reference(ctx, golden_dir):
     """D = 18 (state 14 + 4 controls): reward and d reward / d (W, b) against reverse mode through the EXECUTED reference
     (fixture policy_gradient_wide.npz) -- the width the Jacobian tape does not serve, i.e. the plain tape + per-step
     device adjoint with the two-moment-tile sweep instantiation."""
-    from pilco_amd.adjoint import rollout_value_and_grad
     g = np.load(os.path.join(golden_dir, "policy_gradient_wide.npz"))
     cfg = {k: g[k] for k in ("X", "Y", "lengthscales", "variance", "noise")}
     p = _pilco_from(cfg, int(g["H"]))
     p.controller.W.assign(g["W"]); p.controller.b.assign(g["b"]); p.controller.max_action = float(g["max_action"])
     p.m_init, p.S_init = g["m0"], g["S0"]
-    r, (Wb, bb) = rollout_value_and_grad(p)
+    r, (Wb, bb) = p.value_and_gradient()
     np.testing.assert_allclose(r, float(g["reward"]), rtol=1e-9)
     np.testing.assert_allclose(Wb, g["dreward_dW"], rtol=1e-6, atol=1e-9 * float(np.abs(g["dreward_dW"]).max()))
     np.testing.assert_allclose(bb, g["dreward_db"], rtol=1e-6, atol=1e-9 * float(np.abs(g["dreward_db"]).max()))
@@ -1939,7 +1945,6 @@ def test_policy_gradient_wide_inputs_vs_autograd(ctx, dims):
     (the reference's TF reverse mode has no such limit, pilco.py:85-90)."""
     import torch
     from oracle import torch_path as tq
-    from pilco_amd.adjoint import rollout_value_and_grad
     E, U = dims
     D, N, H = E + U, 90, 3
     c = synthetic.config_c2(N=N, D=D, E=E, noise=1e-2, seed=7 + D, control_dim=U)
@@ -1948,8 +1953,8 @@ def test_policy_gradient_wide_inputs_vs_autograd(ctx, dims):
     W0, b0 = 0.2 * rs.randn(U, E), 0.1 * rs.randn(1, U)
     p.controller.W.assign(W0); p.controller.b.assign(b0); p.controller.max_action = 1.2
     p.m_init, p.S_init = c["m0"], c["S0"]
-    r, (Wb, bb) = rollout_value_and_grad(p)
-    r2, (Wb2, bb2) = rollout_value_and_grad(p)
+    r, (Wb, bb) = p.value_and_gradient()
+    r2, (Wb2, bb2) = p.value_and_gradient()
     assert r2 == r and np.array_equal(Wb2, Wb) and np.array_equal(bb2, bb)
     iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
     Wt = torch.tensor(W0, dtype=torch.float64, requires_grad=True)
@@ -2042,7 +2047,6 @@ def test_random_shapes_rollout_and_policy_gradient_vs_oracle(ctx, seed):
     and, where there is a control, the policy gradient against torch autograd of the restated rollout."""
     import torch
     from oracle import torch_path as tq
-    from pilco_amd.adjoint import rollout_value_and_grad
     from pilco_amd.controllers import LinearController, RbfController
     from pilco_amd.models import PILCO
     from pilco_amd.rewards import CombinedRewards, ExponentialReward, LinearReward
@@ -2101,7 +2105,7 @@ def test_random_shapes_rollout_and_policy_gradient_vs_oracle(ctx, seed):
         return
     iK, beta = tp.calculate_factorizations(X, Y, ls, var, nz)
     gp = lambda mm, ss: tq.predict_given_factorizations(X, ls, var, mm, ss, iK, beta)
-    r, grads = rollout_value_and_grad(p)
+    r, grads = p.value_and_gradient()
     if kind == "linear":
         prm = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (W, b)]
         pol = lambda mm, ss: tq.linear_controller(mm, ss, prm[0], prm[1], maxact)

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported():
     assert not missing, f"symbols declared in the header but not exported: {missing}"
     unbound = [n for n in sorted(declared) if n not in _lib.SIGNATURES]
     assert not unbound, f"symbols without a ctypes signature: {unbound}"
-    assert lib.pilco_abi_version() == 1
+    assert lib.pilco_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu():
