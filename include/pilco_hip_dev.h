@@ -31,6 +31,12 @@ int pilco_set_small_step(pilco_ctx* ctx, int on);
  * step's value and its Jacobian, and the reverse sweep is host algebra on the downloaded records; 0 = plain tape, then the
  * O(N^2) adjoint of every step on the device again (pilco_gp_predict_vjp).  Same gradient up to rounding. */
 int pilco_set_grad_mode(pilco_ctx* ctx, int mode);
+/* The reverse chain of pilco_rollout_grad* for a LinearController -- H dependent steps of small contractions over the Jacobian
+ * records (propagate / joint / controller + squash / reward adjoints: pilco.py:141-149, controllers.py:13-58, rewards.py:19-81):
+ * 1 (default; PILCO_HOST_CHAIN=1 in the environment starts with 0) = on the device, one workgroup walking the records in HBM
+ * (csrc/rev.hip); 0 = the host chain of rounds 1-5 (csrc/grad.hip), which is what an RbfController always gets.  Same
+ * formulas, different summation orders: they agree to rounding, each is bitwise repeatable. */
+int pilco_set_reverse_chain(pilco_ctx* ctx, int on_device);
 /* 1 (default; PILCO_NO_GRAPH=1 in the environment starts with 0): a rollout's launch sequence is captured once into a
  * hipGraph and replayed while the plan is unchanged; 0: every rollout is enqueued launch by launch.  Same results. */
 int pilco_set_use_graph(pilco_ctx* ctx, int on);

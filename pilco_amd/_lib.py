@@ -56,6 +56,7 @@ SIGNATURES = {
     "pilco_last_error": (C.c_char_p, [_vp]),
     "pilco_last_not_pd_output": (C.c_int, [_vp]),
     "pilco_set_pair_kernel": (C.c_int, [_vp, C.c_int]),
+    "pilco_set_reverse_chain": (C.c_int, [_vp, C.c_int]),
     "pilco_selftest": (C.c_int, [_vp]),
     "pilco_set_fused_step": (C.c_int, [_vp, C.c_int]),
     "pilco_set_grad_mode": (C.c_int, [_vp, C.c_int]),
@@ -239,6 +240,11 @@ class Context:
         """1 (default): small RbfControllers are evaluated inside the step's serial link; 0: own launches (include/pilco_hip.h)."""
         self._chk(self.lib.pilco_set_inline_policy(self.h, 1 if on else 0))
         self._settings["set_inline_policy"] = (on,)
+
+    def set_reverse_chain(self, on_device):
+        """1 (default): a LinearController's reverse chain runs on the device; 0: the host chain (include/pilco_hip_dev.h)."""
+        self._chk(self.lib.pilco_set_reverse_chain(self.h, int(bool(on_device))))
+        self._settings["set_reverse_chain"] = (on_device,)
 
     def set_pair_kernel(self, variant):
         self._chk(self.lib.pilco_set_pair_kernel(self.h, int(variant)))

@@ -348,6 +348,7 @@ int pilco_ctx_create(int device, pilco_ctx** out) {
     if (const char* ei = getenv("PILCO_INLINE_POLICY")) ctx->inline_policy = (atoi(ei) != 0);
     if (const char* ef = getenv("PILCO_FUSED")) ctx->fused = (atoi(ef) != 0);
     if (const char* ef = getenv("PILCO_SMALL_STEP")) ctx->fuse_small = (atoi(ef) != 0);
+    if (const char* ef = getenv("PILCO_HOST_CHAIN")) ctx->dev_chain = (atoi(ef) == 0);
     if (const char* env = getenv("PILCO_PAIR_KERNEL")) {   // a choice like pilco_set_pair_kernel's: pilco_shard_set / _comm_init leave it alone
         ctx->variant = (atoi(env) >= 0 && atoi(env) <= 2) ? atoi(env) : 0;
 #ifndef PILCO_DEV
@@ -382,6 +383,8 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     ctx->tape.release();
     ctx->jrec.release();
     ctx->jgath.release();
+    ctx->revloc.release();
+    ctx->revseeds.release();
     ctx->selftest.release();
     ctx->exp_tab.release();
     for (hipEvent_t e : ctx->pair_events) (void)hipEventDestroy(e);
@@ -408,6 +411,12 @@ int pilco_set_pair_kernel(pilco_ctx* ctx, int variant) {
 #endif
     ctx->variant = variant;
     ctx->variant_user = true;
+    return PILCO_OK;
+}
+
+int pilco_set_reverse_chain(pilco_ctx* ctx, int on_device) {
+    if (!ctx) return PILCO_E_SHAPE;
+    ctx->dev_chain = (on_device != 0);
     return PILCO_OK;
 }
 

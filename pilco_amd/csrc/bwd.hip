@@ -673,10 +673,14 @@ struct BwdBatch {
     const double* in_m;
     long in_m_stride;
 };
+// cjl != nullptr (the fused finish: ONE workgroup per pair and step, nrc = 1): LDS for npad column coefficients.  The workgroup
+// then works for memory-level parallelism instead of per-block round trips -- every column's nrb sums and beta requested in
+// one coalesced burst (a thread per column) beside the G blocks' 32 requests, and the MFMA loop's points four blocks at a
+// time: ~8 us per workgroup where the block-by-block form needs ~50 (2 us of memory latency per 64-column block).
 template <int NMT>
 __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double* __restrict__ in_m, const double* __restrict__ gpart,
-                              const double* __restrict__ cpart, int njs, int nrb, double* __restrict__ part, int nrc, int pl, int rc,
-                              double* sm) {
+                              const double* __restrict__ cpart, int njs, int nrb, double* o /* [1 + D + D*D]: global, or LDS behind sm's 6 * 256 (NMT = 1) */,
+                              int nrc, int pl, int rc, double* sm, double* cjl = nullptr) {
     const int npad = md.npad, D = md.D, E = md.E, t = threadIdx.x;
     const int lane = t & 63, w = t >> 6, lr = lane >> 4, lc = lane & 15;
     constexpr int NB2 = NMT * NMT, GW = 16 * NMT;
@@ -698,7 +702,7 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
         }
         __syncthreads();
         const int nI2 = D * D;
-        double* o2 = part + ((long)pl * nrc + rc) * (1 + D + nI2);
+        double* o2 = o;
         for (int e2 = t; e2 < 1 + D + nI2; e2 += 256) {
             double v;
             if (e2 == 0) {
@@ -716,15 +720,29 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
     // (i) the sweep's blocks
     const int nparts = njs * nrb;
     const double* g0 = gpart + (long)pl * nparts * (NB2 * 256);
+    const double* cp = cpart + (long)pl * nrb * npad;
+    const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
+    if (cjl) {   // column coefficients c_j = (sum over the row blocks of cpart) * beta_b,j, all columns, one burst
+        for (int j0 = 0; j0 < npad; j0 += 4 * 256) {
+            double cv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + q * 256 + t;
+                cv[q] = (j < md.n) ? sum_strided<8>(cp + j, npad, nrb) * (diag ? 1.0 : beta_b[j]) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (j0 + q * 256 + t < npad) cjl[j0 + q * 256 + t] = cv[q];
+        }
+    }
 #pragma unroll
     for (int blk = 0; blk < NB2; ++blk) {
-        const double v = sum_strided<4>(g0 + (long)rc * (NB2 * 256) + blk * 256 + t, (long)nrc * (NB2 * 256), (nparts - rc + nrc - 1) / nrc);
+        const double v = cjl ? sum_strided<16>(g0 + (long)rc * (NB2 * 256) + blk * 256 + t, (long)nrc * (NB2 * 256), (nparts - rc + nrc - 1) / nrc)
+                             : sum_strided<4>(g0 + (long)rc * (NB2 * 256) + blk * 256 + t, (long)nrc * (NB2 * 256), (nparts - rc + nrc - 1) / nrc);
         const int d = 16 * (blk / NMT) + ((t >> 4) & 3) + 4 * (t >> 6), e = 16 * (blk % NMT) + (t & 15);
         Gs[d * GW + e] = v;
     }
     // (ii) the column side
-    const double* cp = cpart + (long)pl * nrb * npad;
-    const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
     double wm[NMT], wi[NMT];
 #pragma unroll
     for (int m = 0; m < NMT; ++m) {
@@ -738,6 +756,39 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
     for (int m1 = 0; m1 < NMT; ++m1)
 #pragma unroll
         for (int m2 = 0; m2 < NMT; ++m2) C[m1][m2] = d4{0.0, 0.0, 0.0, 0.0};
+    if (cjl) {
+        __syncthreads();   // (cjl complete)
+        constexpr int UB = NMT == 1 ? 4 : 1;   // 64-column blocks whose points are requested together
+        for (int blk0 = rc; blk0 < npad / 64; blk0 += nrc * UB) {
+            double wt[UB][NMT][4], cj[UB][4];
+#pragma unroll
+            for (int ub = 0; ub < UB; ++ub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int blk = blk0 + ub * nrc, j = blk * 64 + 16 * w + 4 * r + lr;
+                    const bool valid = blk < npad / 64 && j < md.n;
+                    cj[ub][r] = valid ? cjl[j] : 0.0;
+#pragma unroll
+                    for (int m = 0; m < NMT; ++m) {
+                        const int d = 16 * m + lc;
+                        wt[ub][m][r] = (valid && d < D) ? (md.Pt[(long)d * npad + j] - wm[m]) * wi[m] : ((valid && d == D) ? 1.0 : 0.0);
+                    }
+                }
+#pragma unroll
+            for (int ub = 0; ub < UB; ++ub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int m1 = 0; m1 < NMT; ++m1)
+#pragma unroll
+                        for (int m2 = 0; m2 < NMT; ++m2) {
+                            const double ca = cj[ub][r] * wt[ub][m1][r];
+                            C[m1][m2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca, wt[ub][m2][r], C[m1][m2], 0, 0, 0);
+                            MFMA_KEEP_ALIVE(ca);
+                            MFMA_KEEP_ALIVE(wt[ub][m2][r]);
+                        }
+        }
+    } else
     for (int blk = rc; blk < npad / 64; blk += nrc) {
         double wt[NMT][4], cj[4];
 #pragma unroll
@@ -778,7 +829,6 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
     __syncthreads();
     // (iii) N | A | I
     const int nI = D * D;
-    double* o = part + ((long)pl * nrc + rc) * (1 + D + nI);
     for (int e2 = t; e2 < 1 + D + nI; e2 += 256) {
         double v;
         if (e2 == 0) {
@@ -803,7 +853,7 @@ __global__ __launch_bounds__(256, NA == 1 ? POST_LB : 1) void k_mm_bwd_post(MMMo
                                                     double* __restrict__ part, int nrc,
                                                     const double* __restrict__ head, double* __restrict__ mpart, int jac, BwdBatch bb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int pl = blockIdx.x, rc = blockIdx.y, z = blockIdx.z;
+    const int pl = blockIdx.x, rc = blockIdx.y, z = blockIdx.z, D0 = md.D;
     gpart += (long)z * bb.gpart;
     cpart += (long)z * bb.cpart;
     part += (long)z * bb.part;
@@ -815,7 +865,7 @@ __global__ __launch_bounds__(256, NA == 1 ? POST_LB : 1) void k_mm_bwd_post(MMMo
         else bwd_mean_partial<NA>(md, in_m, head, pl - wk.PL, rc, nrc, mpart, sm);
         return;
     }
-    bwd_pair_post<NMT>(md, wk, in_m, gpart, cpart, njs, nrb, part, nrc, pl, rc, sm);
+    bwd_pair_post<NMT>(md, wk, in_m, gpart, cpart, njs, nrb, part + ((long)pl * nrc + rc) * (1 + D0 + D0 * D0), nrc, pl, rc, sm);
 }
 
 // Per pair, with P = (I + Lambda s)^-1 and kappa = Shat_ab / sqrt(det R_ab) from the step's head record:
@@ -975,11 +1025,49 @@ __device__ void jac_fin_output(const MMModel& md, const double* __restrict__ hea
     }
 }
 
+// The record of one pair from its sums Iv = (N | A | I) and the step's head (Pm = P = (I + Lambda s)^-1, lam = lambda | rdet),
+// all in LDS and complete (the caller has synchronised); PI: 2 D^2 doubles of scratch.  Layout: comment above.
+__device__ __forceinline__ void jac_pair_record(int D, const double* Pm, const double* lam, const double* Iv, double* PI, double* __restrict__ o) {
+    const int t = threadIdx.x, nI = D * D;
+    const double rdet = lam[D];
+    const double Nab = Iv[0];
+    const double* Av = Iv + 1;
+    const double* Im = Iv + 1 + D;
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, c = e - r * D;
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k) acc = fma(Pm[r * D + k], Im[k * D + c], acc);
+        PI[e] = acc;
+    }
+    __syncthreads();
+    // G = rdet (P I P^T / 2 - N (P Lambda + Lambda P^T) / 4), then packed symmetric
+    double* Gf = PI + nI;          // [D][D]
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, c = e - r * D;
+        double acc = 0.0;
+        for (int k = 0; k < D; ++k) acc = fma(PI[r * D + k], Pm[c * D + k], acc);   // (P I P^T)[r][c]
+        const double pl2 = Pm[r * D + c] * lam[c] + Pm[c * D + r] * lam[r];         // P Lambda + Lambda P^T
+        Gf[e] = rdet * (0.5 * acc - 0.25 * Nab * pl2);
+    }
+    __syncthreads();
+    if (t == 0) o[0] = Nab;
+    for (int e = t; e < nI; e += 256) {
+        const int r = e / D, c = e - r * D;
+        if (r <= c) o[1 + D + c * (c + 1) / 2 + r] = 0.5 * (Gf[e] + Gf[c * D + r]);
+    }
+    if (t >= 256 - D) {
+        const int r = t - (256 - D);
+        double acc = 0.0;
+        for (int c = 0; c < D; ++c) acc = fma(Pm[r * D + c], Av[c], acc);
+        o[1 + r] = rdet * acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_mm_jac_fin(MMModel md, MMWork wk, const double* __restrict__ part, int nrc,
                                                    const double* __restrict__ head, const double* __restrict__ mpart,
-                                                   double* __restrict__ jrec, long jstride, BwdBatch bb) {
+                                                   double* __restrict__ jrec, long jstride, BwdBatch bb, int pl0) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x, z = blockIdx.y;
+    const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x + pl0, z = blockIdx.y;   // pl0 = PL: the output records only (the fused finish has written the pairs')
     const int nI = D * D, rec = 1 + D + nI, NT2 = D * (D + 1) / 2, recp = 1 + D + NT2;
     part += (long)z * bb.part;
     mpart += (long)z * bb.part;
@@ -993,44 +1081,47 @@ __global__ __launch_bounds__(256) void k_mm_jac_fin(MMModel md, MMWork wk, const
     double* Pm = sm;               // [D][D]
     double* lam = Pm + nI;         // [D + 2]: lambda | rdet
     double* Iv = lam + D + 2;      // [rec]  summed partials (N | A | I)
-    double* PI = Iv + rec;         // [D][D]
+    double* PI = Iv + rec;         // [D][D] (+ [D][D] behind it)
     const double* hd = head + (long)(E + pl) * (nI + D + 2);
     for (int e = t; e < nI + D + 2; e += 256) (e < nI ? Pm[e] : lam[e - nI]) = hd[e];
     for (int e = t; e < rec; e += 256) Iv[e] = sum_strided<16>(part + (long)pl * nrc * rec + e, rec, nrc);   // fixed order
     __syncthreads();
-    const double rdet = lam[D];
-    const double Nab = Iv[0];
-    const double* Av = Iv + 1;
-    const double* Im = Iv + 1 + D;
-    for (int e = t; e < nI; e += 256) {
-        const int r = e / D, c = e - r * D;
-        double acc = 0.0;
-        for (int k = 0; k < D; ++k) acc = fma(Pm[r * D + k], Im[k * D + c], acc);
-        PI[e] = acc;
+    jac_pair_record(D, Pm, lam, Iv, PI, jrec + (long)pl * recp);
+}
+
+// Fused finish of the Jacobian tape (round 6): ONE workgroup per (pair, step) adds the sweep's G blocks, contracts the column
+// sums with [w_j | 1] on the matrix cores and writes the pair's record -- the partial sums never leave LDS -- beside the
+// E x nrc workgroups per step that take the moments of the mean part (their records: k_mm_jac_fin with pl0 = P on the
+// outputs only).  Rounds 3-5 cut a pair into nrc chunk-workgroups (k_mm_bwd_post), wrote their N | A | I to memory and ran
+// a third launch per chunk of steps (k_mm_jac_fin) over them: 20 800 + 2 600 latency-bound workgroups per rollout at C2u,
+// 0.58 ms behind the chain; one pass over the sweep's 7.2 MB per step is what the work needs.
+__global__ __launch_bounds__(256, 4) void k_mm_jac_rec(MMModel md, MMWork wk, const double* __restrict__ gpart, const double* __restrict__ cpart,
+                                                       int njs, int nrb, int nrc, const double* __restrict__ head, double* __restrict__ mpart,
+                                                       double* __restrict__ jrec, long jstride, BwdBatch bb) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int D = md.D, E = md.E, t = threadIdx.x, z = blockIdx.y;
+    const int nI = D * D, rec = 1 + D + nI, NT2 = D * (D + 1) / 2, recp = 1 + D + NT2;
+    gpart += (long)z * bb.gpart;
+    cpart += (long)z * bb.cpart;
+    mpart += (long)z * bb.part;
+    head += (long)z * bb.head;
+    jrec += (long)z * jstride;
+    const double* in_m = bb.in_m + (long)z * bb.in_m_stride;
+    if ((int)blockIdx.x >= wk.PL) {   // mean part of output a, point blocks rc, rc + nrc, ..
+        const int q = (int)blockIdx.x - wk.PL, a = q / nrc, rc = q - a * nrc;
+        bwd_mean_moments(md, in_m, head, a, rc, nrc, mpart, sm);
+        return;
     }
+    const int pl = blockIdx.x;
+    double* Iv = sm + 6 * 256;     // [rec]  behind bwd_pair_post's Gs | Gc | red
+    double* Pm = Iv + rec;         // [D][D]
+    double* lam = Pm + nI;         // [D + 2]
+    double* PI = lam + D + 2;      // [2][D][D]
+    const double* hd = head + (long)(E + pl) * (nI + D + 2);
+    for (int e = t; e < nI + D + 2; e += 256) (e < nI ? Pm[e] : lam[e - nI]) = hd[e];
+    bwd_pair_post<1>(md, wk, in_m, gpart, cpart, njs, nrb, Iv, 1, pl, 0, sm, PI + 2 * nI);
     __syncthreads();
-    // G = rdet (P I P^T / 2 - N (P Lambda + Lambda P^T) / 4) into Pm's neighbour PI2, then packed symmetric
-    double* Gf = PI + nI;          // [D][D]
-    for (int e = t; e < nI; e += 256) {
-        const int r = e / D, c = e - r * D;
-        double acc = 0.0;
-        for (int k = 0; k < D; ++k) acc = fma(PI[r * D + k], Pm[c * D + k], acc);   // (P I P^T)[r][c]
-        const double pl2 = Pm[r * D + c] * lam[c] + Pm[c * D + r] * lam[r];         // P Lambda + Lambda P^T
-        Gf[e] = rdet * (0.5 * acc - 0.25 * Nab * pl2);
-    }
-    __syncthreads();
-    double* o = jrec + (long)pl * recp;
-    if (t == 0) o[0] = Nab;
-    for (int e = t; e < nI; e += 256) {
-        const int r = e / D, c = e - r * D;
-        if (r <= c) o[1 + D + c * (c + 1) / 2 + r] = 0.5 * (Gf[e] + Gf[c * D + r]);
-    }
-    if (t >= 256 - D) {
-        const int r = t - (256 - D);
-        double acc = 0.0;
-        for (int c = 0; c < D; ++c) acc = fma(Pm[r * D + c], Av[c], acc);
-        o[1 + r] = rdet * acc;
-    }
+    jac_pair_record(D, Pm, lam, Iv, PI, jrec + (long)pl * recp);
 }
 
 size_t mm_jac_rec_size(int D, int E, int P) {
@@ -1142,12 +1233,21 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
     if (small_nch > 0)
         hipLaunchKernelGGL(k_mm_bwd_head, dim3(E + P, H), dim3(256), sizeof(double) * ((size_t)4 * nI + D), st, md, wk, head, bb.head, tape + D,
                            (long)tape_stride);
-    const size_t lds_post = sizeof(double) * std::max((size_t)2 * 256 + 4 * 256, (size_t)nI + 64 * LD1 + 64 + NS / 2 + 2);
+    const size_t lds_mean = (size_t)nI + 64 * LD1 + 64 + NS / 2 + 2;
+    const size_t lds_fin = sizeof(double) * std::max((size_t)4 * nI + 4 * D + 8, (size_t)3 * nI + NS + D + 2 * nI * D);
+    const long jstride = (long)mm_jac_rec_size(D, E, P);
+    static const bool split_finish = getenv("PILCO_JAC_SPLIT_FINISH") != nullptr;   // (A/B: the rounds 3-5 finish, chunk-workgroups + partials in memory)
+    if (!split_finish) {
+        const size_t lds_rec = sizeof(double) * std::max((size_t)6 * 256 + (1 + D + nI) + 3 * nI + D + 2 + md.npad, lds_mean);
+        hipLaunchKernelGGL(k_mm_jac_rec, dim3(P + E * nrc, H), dim3(256), lds_rec, st, md, wk, rowmom, cpart, njs, nrb, nrc, head, mpart, jrec,
+                           jstride, bb);
+        hipLaunchKernelGGL(k_mm_jac_fin, dim3(E, H), dim3(256), lds_fin, st, md, wk, part, nrc, head, mpart, jrec, jstride, bb, P);
+        return;
+    }
+    const size_t lds_post = sizeof(double) * std::max((size_t)2 * 256 + 4 * 256, lds_mean);
     hipLaunchKernelGGL((k_mm_bwd_post<1, 1>), dim3(P + E, nrc, H), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
                        head, mpart, 1, bb);   // (the Jacobian tape serves D <= 14)
-    const size_t lds_fin = sizeof(double) * std::max((size_t)4 * nI + 4 * D + 8, (size_t)3 * nI + NS + D + 2 * nI * D);
-    hipLaunchKernelGGL(k_mm_jac_fin, dim3(P + E, H), dim3(256), lds_fin, st, md, wk, part, nrc, head, mpart, jrec,
-                       (long)mm_jac_rec_size(D, E, P), bb);
+    hipLaunchKernelGGL(k_mm_jac_fin, dim3(P + E, H), dim3(256), lds_fin, st, md, wk, part, nrc, head, mpart, jrec, jstride, bb, 0);
 }
 
 // Pg: the pairs of the WHOLE model, E (E + 1) / 2 -- never the local count of a rank: the column split decides how a pair's

@@ -121,6 +121,8 @@ struct pilco_ctx {
     DevBuf tape;
     DevBuf jrec;             // Jacobian tape: [H][mm_jac_rec_size] records of a value-and-gradient rollout
     DevBuf jgath;            // sharded value-and-gradient rollout: [W + 1][H][PLcap * recp] pair records (own block last) for the all-gather
+    DevBuf revloc, revseeds; // device reverse chain (rev.hip): per-step trajectory-only quantities [H][rev_loc_doubles]; the caller's cotangent seeds [H + 1][E + E*E]
+    bool dev_chain = true;   // LinearController gradients: the reverse chain runs on the device (false: the host chain of rounds 1-5, kept for the RbfController and as a cross-check)
     double* jpin = nullptr;  // pinned host copy of (traj | tape | jrec) for the host-side reverse sweep
     size_t jpin_cap = 0;
     hipEvent_t jwait_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // behind the chunks of the records' download (last steps first)
@@ -239,11 +241,24 @@ struct RolloutPlan {
     int jsmall = 0;                      // > 0: the steps of this value-and-gradient rollout run as the one-launch small step (chunks per pair)
 };
 constexpr int PILCO_JAC_TOO_LARGE = -77;   // rollout_jtape: the per-step buffers would exceed the cap (caller falls back)
+// Device reverse chain of a LinearController's gradient: what rollout_jtape(.., dev) leaves enqueued / staged.
+struct JtapeDev {
+    bool seeds = false;                 // the caller has cotangent seeds to add: the chain kernel is launched by rollout_jtape_dev_finish, behind their upload
+    RevArgs ra{};
+    size_t n_seeds = 0, n_out = 0;
+    double* h_seeds = nullptr;          // pinned staging [H + 1][E + E*E]
+    const double* h_out = nullptr;      // pinned: dW | db | status | d / d (m_0, S_0), written by the chain kernel
+    const double* h_traj = nullptr;     // pinned trajectory (seeds only; valid once jwait_ev[0] has passed)
+    const double* h_reward = nullptr;   // pinned reward (valid with h_out)
+};
+typedef void (*jtape_seed_fn)(void* user, int H, int E, const double* traj, double* seeds);
+int rollout_jtape_dev_finish(pilco_ctx* ctx, JtapeDev& dev, int H, int E, jtape_seed_fn seed_fn, void* seed_user);
 int rollout_jtape_wait(pilco_ctx* ctx, int t);   // blocks until the records of step t have arrived
 // forward rollout with the tape and the Jacobian records of every step, downloaded into pinned memory (grad.hip)
 int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
                   const double* S0, int H, double* reward, const double** traj, const double** tape, const double** jrec, size_t* jstride,
-                  const double** reward_later = nullptr);   // reward_later: return without waiting (one rank); *reward_later is valid once rollout_jtape_wait(ctx, H - 1) has returned
+                  const double** reward_later = nullptr,    // reward_later: return without waiting (one rank); *reward_later is valid once rollout_jtape_wait(ctx, H - 1) has returned
+                  JtapeDev* dev = nullptr);                 // dev: records stay on the device, the reverse chain runs there (LinearController); returns without waiting
 int rollout_lanes(pilco_ctx* ctx, int B, std::vector<pilco_ctx*>& lane, const char* who);   // lanes of a batch call (rollout.hip)
 void rollout_lanes_done(pilco_ctx* ctx);   // ... and after it: the context is on its own again
 struct LanesGuard {

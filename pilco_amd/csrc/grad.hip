@@ -811,6 +811,32 @@ int rollout_grad_impl(pilco_ctx* ctx, const pilco_policy* policy, const pilco_re
     return rollout_grad_finish(ctx, policy, rewards, n_rewards, H, reward, pol, seed_fn, seed_user, gc);
 }
 
+// LinearController: the reverse chain on the device (rev.hip).  begin enqueues the forward half, the records' finish and --
+// unless the caller has cotangent seeds to add -- the chain itself, and returns without waiting; finish waits (with seeds:
+// trajectory -> callback -> upload -> chain -> wait).  PILCO_JAC_TOO_LARGE from begin: nothing was enqueued, the caller takes
+// the host chain.
+bool dev_chain_applies(const pilco_ctx* ctx, const pilco_policy* policy) {
+    const int E = policy->state_dim, U = policy->control_dim;
+    return ctx->dev_chain && ctx->grad_mode != 0 && E + U <= 14 && rev_chain_supported(E, U, E + U);
+}
+int rollout_grad_dev_begin(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
+                           const double* S0, int H, bool seeds, JtapeDev& dev) {
+    dev.seeds = seeds;
+    double r_unused = 0.0;
+    const double *t0 = nullptr, *t1 = nullptr, *t2 = nullptr;
+    size_t js = 0;
+    return rollout_jtape(ctx, policy, rewards, n_rewards, m0, S0, H, &r_unused, &t0, &t1, &t2, &js, nullptr, &dev);
+}
+int rollout_grad_dev_finish(pilco_ctx* ctx, JtapeDev& dev, const pilco_policy* policy, int H, pilco_seed_fn seed_fn, void* seed_user,
+                            double* reward, double* dW, double* db) {
+    const int E = policy->state_dim, U = policy->control_dim;
+    if (int r = rollout_jtape_dev_finish(ctx, dev, H, E, seed_fn, seed_user)) return r;
+    *reward = *dev.h_reward;
+    memcpy(dW, dev.h_out, sizeof(double) * (size_t)U * E);
+    memcpy(db, dev.h_out + (size_t)U * E, sizeof(double) * (size_t)U);
+    return PILCO_OK;
+}
+
 int check_grad_args(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, int kind) {
     if (policy->kind != kind || !policy->squash || policy->control_dim <= 0)
         return fail(ctx, PILCO_E_SHAPE, "rollout_grad: squashed LinearController (pilco_rollout_grad) or RbfController (pilco_rollout_grad_rbf) only");
@@ -834,6 +860,12 @@ int pilco_rollout_grad_seeded(pilco_ctx* ctx, const pilco_policy* policy, const 
     if (!ctx) return PILCO_E_SHAPE;
     if (!policy || !m0 || !S0 || !reward || !dW || !db || H < 0) return fail(ctx, PILCO_E_SHAPE, "rollout_grad: bad arguments");
     if (int r = check_grad_args(ctx, policy, rewards, n_rewards, PILCO_POLICY_LINEAR)) return r;
+    if (dev_chain_applies(ctx, policy)) {
+        JtapeDev dev;
+        const int r = rollout_grad_dev_begin(ctx, policy, rewards, n_rewards, m0, S0, H, seed_fn != nullptr, dev);
+        if (r == PILCO_OK) return rollout_grad_dev_finish(ctx, dev, policy, H, seed_fn, seed_user, reward, dW, db);
+        if (r != PILCO_JAC_TOO_LARGE) return r;
+    }
     LinearAdj pol(policy->state_dim, policy->control_dim, policy->W, policy->b);
     if (int r = rollout_grad_impl(ctx, policy, rewards, n_rewards, m0, S0, H, reward, pol, seed_fn, seed_user)) return r;
     memcpy(dW, pol.Wbar.data(), sizeof(double) * pol.Wbar.size());
@@ -894,6 +926,37 @@ int pilco_rollout_grad_batch_seeded(pilco_ctx* ctx, int B, const pilco_policy* p
     const int E = policies[0].state_dim, U = policies[0].control_dim;
     std::vector<GradCall> gc((size_t)B);
     int err = PILCO_OK, begun = 0;
+    if (dev_chain_applies(ctx, &policies[0])) {   // every lane's chain on the device: all lanes enqueued before the first wait
+        std::vector<JtapeDev> dv((size_t)B);
+        bool fallback = false;
+        for (int i = 0; i < B && !err; ++i) {
+            const int r = rollout_grad_dev_begin(lane[i], &policies[i], rewards, n_rewards, m0 + (size_t)i * E, S0 + (size_t)i * E * E, H,
+                                                 seed_fn != nullptr, dv[i]);
+            if (r == PILCO_JAC_TOO_LARGE && i == 0) {   // (the same answer for every lane: same model, same horizon)
+                fallback = true;
+                break;
+            }
+            if (r) {
+                err = r;
+                if (i > 0) ctx->err = "lane " + std::to_string(i) + ": " + lane[i]->err;
+                break;
+            }
+            ++begun;
+        }
+        if (!fallback) {
+            for (int i = 0; i < begun; ++i) {
+                const int r = rollout_grad_dev_finish(lane[i], dv[i], &policies[i], H, seed_fn, (seed_fn && seed_users) ? seed_users[i] : nullptr,
+                                                      reward + i, dW + (size_t)i * U * E, db + (size_t)i * U);
+                if (r && !err) {
+                    err = r;
+                    if (i > 0) ctx->err = "lane " + std::to_string(i) + ": " + lane[i]->err;
+                }
+            }
+            if (err)
+                for (int i = 0; i < B; ++i) (void)hipStreamSynchronize(lane[i]->st);
+            return err;
+        }
+    }
     for (int i = 0; i < B && !err; ++i, ++begun) {
         err = rollout_grad_begin(lane[i], &policies[i], rewards, n_rewards, m0 + (size_t)i * E, S0 + (size_t)i * E * E, H, reward + i, gc[i], true);
         if (err && i > 0) ctx->err = "lane " + std::to_string(i) + ": " + lane[i]->err;

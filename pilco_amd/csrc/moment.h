@@ -220,6 +220,32 @@ size_t mm_jac_head_size(int D, int E, int P);
 int mm_jac_nt(int npad, int Pg);
 int mm_jac_ns(int D);
 int mm_bwd_rc(int npad);
+// The reverse chain of the policy gradient on the device (rev.hip).
+struct RevRewards {
+    RewardDev rw[MAX_REWARD_TERMS];
+};
+struct RevArgs {
+    int E, U, D, H, P;      // P = E (E + 1) / 2: the pairs of the WHOLE model
+    // Jacobian records: step t starts at jrec + t * gstep; pair kk of the dealing order ((0,0) .. (E-1,E-1), (1,0), (2,0), (2,1), ..)
+    // lives in rank kk % W's block as its pair kk / W: + (kk % W) * gblk + (kk / W) * recp; the E output records at + out_off
+    // (rank 0's).  One rank: W = 1, gstep = mm_jac_rec_size, out_off = P * recp.
+    const double* jrec;
+    int W;
+    long gblk, gstep, out_off;
+    const double* traj;     // [H + 1][E + E*E]
+    const double* tape;     // [H][TS]: m_j | s_j | s1 (E,D) | M (E) | S (E,E) | V (D,E)
+    long TS;
+    const double* loc;      // [H][rev_loc_doubles]  (k_rev_local: reward gradients, controller / squash forward quantities)
+    const double* seeds;    // [H + 1][E + E*E] cotangent seeds of the caller's objective, or nullptr
+    const double* Wp;       // LinearController W (U,E)
+    double* out;            // [U*E + U + 1 + E + E*E]: dW | db | status (0 fine) | d / d (m_0, S_0)   (device-visible)
+    unsigned long long* dbg;   // developer aid (PILCO_REV_STAMPS): phase stamps, or nullptr
+};
+bool rev_chain_supported(int E, int U, int D);
+size_t rev_loc_doubles(int E, int U);
+void launch_rev_local(hipStream_t st, int n, const RewardDev* rw, int E, int U, int H, const double* traj, const double* Wp, const double* bp,
+                      const double* maxact, double* loc);
+void launch_rev_chain(hipStream_t st, const RevArgs& a);
 int mm_exp_table_size();   // entries of the 2^(j/n) table the pair kernels were built for
 int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf, const double* exp_tab);
 

@@ -266,12 +266,13 @@ static int jac_small_chunks(pilco_ctx* ctx, const RolloutPlan& plan, int H) {
     if (!fused_heads_fit(ctx, plan)) return 0;
     return s.wk.NCH * small_col_splits(ctx, s, plan.g.n_rewards > 0 && !MM_ABL(s.wk, 8));
 }
-static void jac_finish_range(pilco_ctx* ctx, const RolloutPlan& plan, int t0, int t1) {
+static void jac_finish_range(pilco_ctx* ctx, const RolloutPlan& plan, int t0, int t1, hipStream_t st = nullptr) {
     Slot& s = ctx->slot[0];
+    if (!st) st = ctx->st;
     const int D = plan.D, E = plan.E, P = s.wk.PL;
     const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
     const size_t o = (size_t)t0;
-    launch_mm_jac_finish(ctx->st, model_of(s), s.wk, t1 - t0, s.jac_rowmom.p + o * mm_jac_rowmom_size(s.npad, P),
+    launch_mm_jac_finish(st, model_of(s), s.wk, t1 - t0, s.jac_rowmom.p + o * mm_jac_rowmom_size(s.npad, P),
                          s.jac_cpart.p + o * mm_jac_cpart_size(s.npad, P, s.wk.EL), s.jac_head.p + o * mm_jac_head_size(D, E, P),
                          s.jac_part.p + o * mm_jac_part_size(D, E, P, s.npad), plan.g.tape + o * TS, TS, plan.jrec + o * plan.jstride,
                          plan.jsmall);
@@ -792,6 +793,7 @@ static int lane_sync_model(pilco_ctx* parent, pilco_ctx* lane) {
     lane->fuse_small = parent->fuse_small;
     lane->inline_policy = parent->inline_policy;
     lane->grad_mode = parent->grad_mode;
+    lane->dev_chain = parent->dev_chain;
     if (!same) {
         l.wk_valid = false;
         for (auto& ge : lane->graph_cache) (void)hipGraphExecDestroy(ge.second);
@@ -1101,7 +1103,7 @@ int pilco_rollout_tape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_r
 // falls back to the plain tape + per-step device adjoint, which has the forward path's D <= 32).
 int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward_term* rewards, int n_rewards, const double* m0,
                   const double* S0, int H, double* reward, const double** traj, const double** tape, const double** jrec, size_t* jstride,
-                  const double** reward_later) {
+                  const double** reward_later, JtapeDev* dev) {
     HIPCHK(hipSetDevice(ctx->device));
     // Several ranks (round 3): every rank sweeps ITS pairs (k_mm_bwd_pair is per-pair independent; the mean-part records of
     // all E outputs are cheap and computed everywhere), the per-step exchange of the forward chain is the sharded
@@ -1142,7 +1144,13 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     // them all; a rank without pairs runs no sweep at all, so the readers take them from rank 0, which always has pairs)
     const size_t gstep = (size_t)PLcap * recp + (size_t)E * reco;
     const size_t gblk = (size_t)std::max(H, 1) * gstep;
-    const size_t need = NTJ + (size_t)H * TS + (size_t)H * JSg + 8 + (sharded ? (size_t)W * gblk : 0);
+    const size_t SEd = (size_t)E + (size_t)E * E;
+    if (dev) {
+        dev->n_seeds = (size_t)(H + 1) * SEd;
+        dev->n_out = (size_t)plan.U * E + plan.U + 1 + SEd;
+    }
+    const size_t need = dev ? NTJ + 8 + dev->n_seeds + dev->n_out + 8
+                            : NTJ + (size_t)H * TS + (size_t)H * JSg + 8 + (sharded ? (size_t)W * gblk : 0);
     if (ctx->jpin_cap < need) {
         if (ctx->jpin) (void)hipHostFree(ctx->jpin);
         ctx->jpin = nullptr;
@@ -1156,11 +1164,11 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     plan.g.tape = ctx->tape.p;
     // one rank: k_mm_jac_fin writes the records straight into the pinned host buffer (device-visible): their 4.3 MB cross
     // PCIe while the kernel runs instead of as four copies that hold the stream between the chunks of the finish
-    const bool jdirect = !sharded && getenv("PILCO_JAC_COPY") == nullptr;
+    const bool jdirect = !dev && !sharded && getenv("PILCO_JAC_COPY") == nullptr;
     plan.jrec = jdirect ? h_jrec : ctx->jrec.p;
     plan.jstride = JS;
     plan.jsmall = sharded ? 0 : jac_small_chunks(ctx, plan, H);
-    double* h_misc = h_jrec + (size_t)H * JSg;
+    double* h_misc = dev ? h_traj + NTJ : h_jrec + (size_t)H * JSg;
     double* h_all = h_misc + 8;                          // sharded: [W][H][PLcap * recp | E * reco]
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(hipMemcpyAsync(plan.st[0], m0, sizeof(double) * E, hipMemcpyHostToDevice, ctx->st));
@@ -1171,6 +1179,66 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
         break;
     }
     HIPCHK(hipMemcpyAsync(h_misc, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
+    if (dev) {
+        // ---- the reverse chain on the device (rev.hip): nothing but the reward, the gradient -- and, for a caller with
+        // cotangent seeds, the trajectory -- crosses to the host
+        if (!ctx->jwait_ev[0]) HIPCHK(hipEventCreateWithFlags(&ctx->jwait_ev[0], hipEventDisableTiming));
+        if (dev->seeds) {
+            HIPCHK(hipMemcpyAsync(h_traj, ctx->traj.p, sizeof(double) * NTJ, hipMemcpyDeviceToHost, ctx->st));
+            HIPCHK(hipEventRecord(ctx->jwait_ev[0], ctx->st));   // the host turns the trajectory into seeds while the finish runs
+        }
+        RevArgs& ra = dev->ra;
+        ra = RevArgs{};
+        ra.E = E; ra.U = plan.U; ra.D = D; ra.H = H; ra.P = Pall;
+        ra.W = 1; ra.gblk = 0; ra.gstep = (long)JS; ra.out_off = (long)P * recp;
+        ra.jrec = ctx->jrec.p;
+        if (H > 0) {
+            jac_finish_range(ctx, plan, 0, H);
+            if (sharded) {   // every rank's pair records, all-gathered ONCE; the chain reads them where they land
+                ENSURE(ctx->jgath, (size_t)(W + 1) * gblk);
+                double* own = ctx->jgath.p + (size_t)W * gblk;
+                HIPCHK(hipMemsetAsync(own, 0, sizeof(double) * gblk, ctx->st));
+                if (P > 0) {
+                    HIPCHK(hipMemcpy2DAsync(own, sizeof(double) * gstep, ctx->jrec.p, sizeof(double) * JS, sizeof(double) * P * recp, (size_t)H,
+                                            hipMemcpyDeviceToDevice, ctx->st));
+                    HIPCHK(hipMemcpy2DAsync(own + (size_t)PLcap * recp, sizeof(double) * gstep, ctx->jrec.p + (size_t)P * recp, sizeof(double) * JS,
+                                            sizeof(double) * E * reco, (size_t)H, hipMemcpyDeviceToDevice, ctx->st));
+                }
+                if (ctx->comm) {
+                    ncclResult_t r = ncclAllGather(own, ctx->jgath.p, gblk, ncclDouble, ctx->comm, ctx->st);
+                    if (r != ncclSuccess) return fail(ctx, PILCO_E_RCCL, std::string("ncclAllGather(jacobian records): ") + ncclGetErrorString(r));
+                } else {   // contexts of one process (pilco_rollout_grad_group): take the peers' blocks between two host barriers
+                    HIPCHK(hipStreamSynchronize(ctx->st));
+                    std::shared_ptr<PeerGroup> grp = ctx->group;
+                    if (!grp->arrive_and_wait()) return fail(ctx, PILCO_E_STATE, "rollout_grad: another rank of the group failed");
+                    for (int j = 0; j < W; ++j) {
+                        pilco_ctx* pj = grp->ctxs[j];
+                        HIPCHK(hipMemcpy(ctx->jgath.p + (size_t)j * gblk, pj->jgath.p + (size_t)W * gblk, sizeof(double) * gblk, hipMemcpyDeviceToDevice));
+                    }
+                    if (!grp->arrive_and_wait()) return fail(ctx, PILCO_E_STATE, "rollout_grad: another rank of the group failed");
+                }
+                ra.jrec = ctx->jgath.p;
+                ra.W = W; ra.gblk = (long)gblk; ra.gstep = (long)gstep; ra.out_off = (long)PLcap * recp;
+            }
+        }
+        ENSURE(ctx->revloc, std::max<size_t>(1, (size_t)H * rev_loc_doubles(E, plan.U)));
+        launch_rev_local(ctx->st, plan.g.n_rewards, plan.g.rw, E, plan.U, H, ctx->traj.p, plan.g.W, plan.g.b, plan.g.maxact, ctx->revloc.p);
+        ra.traj = ctx->traj.p;
+        ra.tape = ctx->tape.p;
+        ra.TS = (long)TS;
+        ra.loc = ctx->revloc.p;
+        ra.seeds = nullptr;
+        ra.Wp = plan.g.W;
+        dev->h_seeds = h_misc + 8;
+        double* h_out = dev->h_seeds + dev->n_seeds;
+        ra.out = h_out;
+        dev->h_out = h_out;
+        dev->h_traj = h_traj;
+        dev->h_reward = h_misc;
+        if (!dev->seeds) launch_rev_chain(ctx->st, ra);
+        HIPCHK(hipGetLastError());
+        return PILCO_OK;
+    }
     HIPCHK(hipMemcpyAsync(h_traj, ctx->traj.p, sizeof(double) * NTJ, hipMemcpyDeviceToHost, ctx->st));
     // the records come down in chunks, LAST steps first, an event behind each: the host's reverse sweep starts on the
     // last steps while the earlier ones are still on their way (rollout_jtape_wait)
@@ -1254,6 +1322,32 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     *tape = h_tape;
     *jrec = h_jrec;
     *jstride = JSg;
+    return PILCO_OK;
+}
+
+// Device reverse chain, second half: with seeds, wait for the trajectory, let the caller turn it into cotangent seeds, upload
+// them and launch the chain; then wait for the gradient.  dev.h_out / dev.h_reward are valid on PILCO_OK.
+int rollout_jtape_dev_finish(pilco_ctx* ctx, JtapeDev& dev, int H, int E, jtape_seed_fn seed_fn, void* seed_user) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (dev.seeds) {
+        HIPCHK(hipEventSynchronize(ctx->jwait_ev[0]));
+        std::fill(dev.h_seeds, dev.h_seeds + dev.n_seeds, 0.0);
+        seed_fn(seed_user, H, E, dev.h_traj, dev.h_seeds);
+        for (size_t q = 0; q < dev.n_seeds; ++q)
+            if (!std::isfinite(dev.h_seeds[q])) {
+                (void)hipStreamSynchronize(ctx->st);
+                return fail(ctx, PILCO_E_SHAPE, "rollout_grad: the seed callback returned a non-finite cotangent");
+            }
+        ENSURE(ctx->revseeds, dev.n_seeds);
+        HIPCHK(hipMemcpyAsync(ctx->revseeds.p, dev.h_seeds, sizeof(double) * dev.n_seeds, hipMemcpyHostToDevice, ctx->st));
+        dev.ra.seeds = ctx->revseeds.p;
+        launch_rev_chain(ctx->st, dev.ra);
+    }
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    const double status = dev.h_out[(size_t)dev.ra.U * dev.ra.E + dev.ra.U];
+    if (status == 1.0) return fail(ctx, PILCO_E_NOT_PD, "rollout_grad: singular s + Lambda^2 or I + Lambda s");
+    if (status != 0.0) return fail(ctx, PILCO_E_NOT_PD, "rollout_grad: singular I + S W in the reward");
     return PILCO_OK;
 }
 
