@@ -385,6 +385,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     ctx->jgath.release();
     ctx->revloc.release();
     ctx->revseeds.release();
+    ctx->revmat.release();
     ctx->selftest.release();
     ctx->exp_tab.release();
     for (hipEvent_t e : ctx->pair_events) (void)hipEventDestroy(e);

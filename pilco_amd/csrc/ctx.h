@@ -121,7 +121,7 @@ struct pilco_ctx {
     DevBuf tape;
     DevBuf jrec;             // Jacobian tape: [H][mm_jac_rec_size] records of a value-and-gradient rollout
     DevBuf jgath;            // sharded value-and-gradient rollout: [W + 1][H][PLcap * recp] pair records (own block last) for the all-gather
-    DevBuf revloc, revseeds; // device reverse chain (rev.hip): per-step trajectory-only quantities [H][rev_loc_doubles]; the caller's cotangent seeds [H + 1][E + E*E]
+    DevBuf revloc, revseeds, revmat; // device reverse chain (rev.hip): per-step trajectory-only quantities [H][rev_loc_doubles]; the caller's cotangent seeds [H + 1][E + E*E]
     bool dev_chain = true;   // LinearController gradients: the reverse chain runs on the device (false: the host chain of rounds 1-5, kept for the RbfController and as a cross-check)
     double* jpin = nullptr;  // pinned host copy of (traj | tape | jrec) for the host-side reverse sweep
     size_t jpin_cap = 0;

@@ -238,11 +238,12 @@ struct RevArgs {
     const double* loc;      // [H][rev_loc_doubles]  (k_rev_local: reward gradients, controller / squash forward quantities)
     const double* seeds;    // [H + 1][E + E*E] cotangent seeds of the caller's objective, or nullptr
     const double* Wp;       // LinearController W (U,E)
-    double* out;            // [U*E + U + 1 + E + E*E]: dW | db | status (0 fine) | d / d (m_0, S_0)   (device-visible)
-    unsigned long long* dbg;   // developer aid (PILCO_REV_STAMPS): phase stamps, or nullptr
+    double* amat;           // [H][rev_mat_doubles]: every step's reverse map [A; B] by columns | r | flag  (k_rev_step -> k_rev_chain)
+    double* out;            // [U*E + U + 1 + E + E(E+1)/2]: dW | db | status (0 fine) | d / d (m_0, S_0 packed)   (device-visible)
 };
 bool rev_chain_supported(int E, int U, int D);
 size_t rev_loc_doubles(int E, int U);
+size_t rev_mat_doubles(int E, int U, int D);
 void launch_rev_local(hipStream_t st, int n, const RewardDev* rw, int E, int U, int H, const double* traj, const double* Wp, const double* bp,
                       const double* maxact, double* loc);
 void launch_rev_chain(hipStream_t st, const RevArgs& a);

@@ -1227,6 +1227,8 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
         ra.tape = ctx->tape.p;
         ra.TS = (long)TS;
         ra.loc = ctx->revloc.p;
+        ENSURE(ctx->revmat, std::max<size_t>(1, (size_t)H * rev_mat_doubles(E, plan.U, D)));
+        ra.amat = ctx->revmat.p;
         ra.seeds = nullptr;
         ra.Wp = plan.g.W;
         dev->h_seeds = h_misc + 8;
