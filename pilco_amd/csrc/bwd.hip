@@ -46,9 +46,9 @@ __device__ __forceinline__ double sum_strided(const double* __restrict__ base, l
     for (int q0 = 0; q0 < n; q0 += B) {
         double v[B];
 #pragma unroll
-        for (int u = 0; u < B; ++u) v[u] = (q0 + u < n) ? base[(long)(q0 + u) * stride] : 0.0;
+        for (int u = 0; u < B; ++u) v[u] = base[(long)min(q0 + u, n - 1) * stride];   // (unconditional request, clamped: n >= 1)
 #pragma unroll
-        for (int u = 0; u < B; ++u) acc += v[u];
+        for (int u = 0; u < B; ++u) acc += (q0 + u < n) ? v[u] : 0.0;
     }
     return acc;
 }
@@ -604,6 +604,117 @@ __device__ void bwd_mean_moments(const MMModel& md, const double* __restrict__ i
         if (pk[k] >= 0) mpart[((long)a * nrc + rc) * NS + t + 256 * k] = acc[k];
 }
 
+// The same moments on the matrix cores (round 6; the fused finish k_mm_jac_rec).  The VALU form above reads FOUR LDS words per
+// multiply-add -- 9.3 M wave-wide LDS reads per rollout at C2u, 60 us of the LDS pipes of the whole chip and 145 us in practice.
+// As a product:  C[(d, e)][f] = sum_i (l_i zeta~_d zeta~_e) zeta~_f,  rows = the D1 (D1 + 1) / 2 pairs d >= e (16 per tile),
+// columns f < 16, K = the points (4 per v_mfma_f64_16x16x4_f64): 4 LDS reads feed 1024 multiply-adds; entries f <= e are the
+// moments (the others are computed for nothing).  l_i itself: the quadratic form's rows dealt over the four waves (256
+// threads per 64-point block instead of 64).  Same sums in another order: agrees with the VALU form to rounding.
+constexpr int JAC_MT = 8;   // row tiles: D1 (D1 + 1) / 2 <= 128 pairs (D <= 14)
+__device__ void bwd_mean_moments_mfma(const MMModel& md, const double* __restrict__ in_m, const double* __restrict__ head, int a, int rc,
+                                      int nrc, double* __restrict__ mpart, double* sm) {
+    const int D = md.D, D1 = D + 1, npad = md.npad, t = threadIdx.x, lane = t & 63, w = t >> 6, lr = lane >> 4, lc = lane & 15;
+    const int nI = D * D, LD = D1 | 1, NS = D1 * (D1 + 1) * (D1 + 2) / 6, NPAIR = D1 * (D1 + 1) / 2, ntile = (NPAIR + 15) / 16;
+    double* T = sm;                 // [D][D]
+    double* zs = T + nI;            // [64][LD]   zeta | 1
+    double* lv = zs + 64 * LD;      // [64]
+    double* qp = lv + 64;           // [4][64]  partial quadratic forms; later [4][256] for the waves' tiles
+    const double* hd = head + (long)a * (nI + D + 2);
+    int* ptab = (int*)(qp + 4 * 256);   // [16 JAC_MT] pair row -> d | e << 8, or -1
+    for (int e = t; e < nI; e += 256) T[e] = hd[e];
+    if (t < 16 * JAC_MT) {
+        int d = 0;
+        while ((d + 1) * (d + 2) / 2 <= t) ++d;
+        ptab[t] = t < NPAIR ? (d | ((t - d * (d + 1) / 2) << 8)) : -1;
+    }
+    __syncthreads();
+    // this lane's pair row in every tile: (d, e), d >= e, or -1
+    int pd[JAC_MT], pe[JAC_MT];
+#pragma unroll
+    for (int m = 0; m < JAC_MT; ++m) {
+        const int q = ptab[16 * m + lc];
+        pd[m] = q < 0 ? -1 : (q & 255);
+        pe[m] = q < 0 ? 0 : (q >> 8);
+    }
+    d4 C[JAC_MT];
+#pragma unroll
+    for (int m = 0; m < JAC_MT; ++m) C[m] = d4{0.0, 0.0, 0.0, 0.0};
+    __syncthreads();
+    // (requests are UNCONDITIONAL, from clamped addresses -- the padding of Pt / beta is there to be read.  Requesting the NEXT
+    // block's coordinates a block ahead was tried: no faster, 32 more registers)
+    const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
+    double mloc[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) mloc[d] = in_m[min(d, D - 1)];
+    for (int blk = rc; blk < npad / 64; blk += nrc) {
+        // ---- l_i of the block's 64 points: thread (point lane, wave w) takes the rows r = w, w + 4, .. of zeta^T T zeta
+        const int i = blk * 64 + lane;
+        double pv[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) pv[d] = md.Pt[(long)min(d, D - 1) * npad + i];
+        const double bcur = beta_a[i];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) pv[d] = (d < D && i < md.n) ? pv[d] - mloc[d] : 0.0;
+        double part = 0.0;
+        for (int r = w; r < D; r += 4) {
+            double tz = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c < D) tz = fma(T[r * D + c], pv[c], tz);
+            double zr = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c == r) zr = pv[c];
+            part = fma(zr, tz, part);
+        }
+        qp[w * 64 + lane] = part;
+        if (w == 0) {
+#pragma unroll
+            for (int d = 0; d < 16; ++d)
+                if (d < D) zs[lane * LD + d] = pv[d];
+            zs[lane * LD + D] = 1.0;
+        }
+        __syncthreads();
+        if (w == 0) {
+            const double quad = (qp[lane] + qp[64 + lane]) + (qp[128 + lane] + qp[192 + lane]);
+            lv[lane] = (i < md.n) ? exp(-0.5 * quad) * bcur : 0.0;
+        }
+        __syncthreads();
+        // ---- the block's 16 k-steps of 4 points dealt over the waves
+        for (int ks = w; ks < 16; ks += 4) {
+            const int ii = 4 * ks + lr;
+            const double li = lv[ii];
+            const double bf = (lc < D1) ? zs[ii * LD + lc] : 0.0;
+#pragma unroll
+            for (int m = 0; m < JAC_MT; ++m)
+                if (m < ntile) {
+                    const double av = (pd[m] >= 0) ? li * zs[ii * LD + pd[m]] * zs[ii * LD + pe[m]] : 0.0;
+                    C[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bf, C[m], 0, 0, 0);
+                    MFMA_KEEP_ALIVE(av);          // (the first MFMA of each chain has a constant-zero accumulator)
+                    MFMA_KEEP_ALIVE(bf);
+                }
+        }
+        __syncthreads();   // (zs / lv / qp are rewritten by the next block)
+    }
+    // ---- the four waves' tiles added in a fixed order; entry (pair (d, e), f <= e) -> mpart[tri3(d, e, f)]
+    double* red = qp;   // [4][256]
+#pragma unroll
+    for (int m = 0; m < JAC_MT; ++m)
+        if (m < ntile) {
+            __syncthreads();
+            MFMA_RESULT_FENCE(C[m]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[w * 256 + r * 64 + lane] = C[m][r];
+            __syncthreads();
+            const double v = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
+            const int row = ((t >> 4) & 3) + 4 * (t >> 6), f = t & 15, q = ptab[16 * m + row];
+            if (q >= 0) {
+                const int d = q & 255, e = q >> 8;
+                if (f <= e) mpart[((long)a * nrc + rc) * NS + tri3(d, e, f)] = v;
+            }
+        }
+}
+
 // stage 2 (a workgroup of k_mm_bwd_fin): out[a][D + D*D]
 __device__ void bwd_mean_final(const MMModel& md, const double* __restrict__ bars, const double* __restrict__ head, int a,
                                int nrc, const double* __restrict__ mpart, double* __restrict__ out, double* sm) {
@@ -726,9 +837,10 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
         for (int j0 = 0; j0 < npad; j0 += 4 * 256) {
             double cv[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = j0 + q * 256 + t;
-                cv[q] = (j < md.n) ? sum_strided<8>(cp + j, npad, nrb) * (diag ? 1.0 : beta_b[j]) : 0.0;
+            for (int q = 0; q < 4; ++q) {   // (unconditional requests from clamped addresses, see bwd_mean_moments_mfma)
+                const int j = j0 + q * 256 + t, jc = min(j, npad - 1);
+                const double cs = sum_strided<8>(cp + jc, npad, nrb), bj = beta_b[jc];
+                cv[q] = (j < md.n) ? cs * (diag ? 1.0 : bj) : 0.0;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -747,8 +859,9 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
 #pragma unroll
     for (int m = 0; m < NMT; ++m) {
         const int d = 16 * m + lc;
-        const double lb = d < D ? md.ls[b * D + d] : 1.0;
-        wm[m] = d < D ? in_m[d] : 0.0;
+        const double lbr = md.ls[b * D + min(d, D - 1)], imr = in_m[min(d, D - 1)];
+        const double lb = d < D ? lbr : 1.0;
+        wm[m] = d < D ? imr : 0.0;
         wi[m] = 1.0 / (lb * lb);
     }
     d4 C[NMT][NMT];
@@ -765,13 +878,14 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
             for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int blk = blk0 + ub * nrc, j = blk * 64 + 16 * w + 4 * r + lr;
+                    const int blk = blk0 + ub * nrc, j = blk * 64 + 16 * w + 4 * r + lr, jc = min(j, npad - 1);
                     const bool valid = blk < npad / 64 && j < md.n;
-                    cj[ub][r] = valid ? cjl[j] : 0.0;
+                    cj[ub][r] = valid ? cjl[jc] : 0.0;
 #pragma unroll
                     for (int m = 0; m < NMT; ++m) {
                         const int d = 16 * m + lc;
-                        wt[ub][m][r] = (valid && d < D) ? (md.Pt[(long)d * npad + j] - wm[m]) * wi[m] : ((valid && d == D) ? 1.0 : 0.0);
+                        const double pt = md.Pt[(long)min(d, D - 1) * npad + jc];
+                        wt[ub][m][r] = (valid && d < D) ? (pt - wm[m]) * wi[m] : ((valid && d == D) ? 1.0 : 0.0);
                     }
                 }
 #pragma unroll
@@ -1095,8 +1209,8 @@ __global__ __launch_bounds__(256) void k_mm_jac_fin(MMModel md, MMWork wk, const
 // outputs only).  Rounds 3-5 cut a pair into nrc chunk-workgroups (k_mm_bwd_post), wrote their N | A | I to memory and ran
 // a third launch per chunk of steps (k_mm_jac_fin) over them: 20 800 + 2 600 latency-bound workgroups per rollout at C2u,
 // 0.58 ms behind the chain; one pass over the sweep's 7.2 MB per step is what the work needs.
-__global__ __launch_bounds__(256, 4) void k_mm_jac_rec(MMModel md, MMWork wk, const double* __restrict__ gpart, const double* __restrict__ cpart,
-                                                       int njs, int nrb, int nrc, const double* __restrict__ head, double* __restrict__ mpart,
+__global__ __launch_bounds__(256, 2) void k_mm_jac_rec(MMModel md, MMWork wk, const double* __restrict__ gpart, const double* __restrict__ cpart,
+                                                       int njs, int nrb, int nrc /* chunks of the MEAN part's points */, const double* __restrict__ head, double* __restrict__ mpart,
                                                        double* __restrict__ jrec, long jstride, BwdBatch bb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = md.D, E = md.E, t = threadIdx.x, z = blockIdx.y;
@@ -1109,7 +1223,7 @@ __global__ __launch_bounds__(256, 4) void k_mm_jac_rec(MMModel md, MMWork wk, co
     const double* in_m = bb.in_m + (long)z * bb.in_m_stride;
     if ((int)blockIdx.x >= wk.PL) {   // mean part of output a, point blocks rc, rc + nrc, ..
         const int q = (int)blockIdx.x - wk.PL, a = q / nrc, rc = q - a * nrc;
-        bwd_mean_moments(md, in_m, head, a, rc, nrc, mpart, sm);
+        bwd_mean_moments_mfma(md, in_m, head, a, rc, nrc, mpart, sm);
         return;
     }
     const int pl = blockIdx.x;
@@ -1238,10 +1352,14 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
     const long jstride = (long)mm_jac_rec_size(D, E, P);
     static const bool split_finish = getenv("PILCO_JAC_SPLIT_FINISH") != nullptr;   // (A/B: the rounds 3-5 finish, chunk-workgroups + partials in memory)
     if (!split_finish) {
-        const size_t lds_rec = sizeof(double) * std::max((size_t)6 * 256 + (1 + D + nI) + 3 * nI + D + 2 + md.npad, lds_mean);
-        hipLaunchKernelGGL(k_mm_jac_rec, dim3(P + E * nrc, H), dim3(256), lds_rec, st, md, wk, rowmom, cpart, njs, nrb, nrc, head, mpart, jrec,
+        // the mean part's points in nrcm chunks per output and step: a workgroup's set-up and its epilogue (five tiles through
+        // LDS, scattered stores) cost as much as four 64-point blocks -- 8 chunks of 2 blocks (the split finish's cut) spent
+        // 22 us per workgroup at three per CU
+        const int nrcm = std::max(1, std::min(2, md.npad / 64));
+        const size_t lds_rec = sizeof(double) * std::max((size_t)6 * 256 + (1 + D + nI) + 3 * nI + D + 2 + md.npad, (size_t)nI + 64 * LD1 + 64 + 4 * 256 + 8 * JAC_MT + 2);
+        hipLaunchKernelGGL(k_mm_jac_rec, dim3(P + E * nrcm, H), dim3(256), lds_rec, st, md, wk, rowmom, cpart, njs, nrb, nrcm, head, mpart, jrec,
                            jstride, bb);
-        hipLaunchKernelGGL(k_mm_jac_fin, dim3(E, H), dim3(256), lds_fin, st, md, wk, part, nrc, head, mpart, jrec, jstride, bb, P);
+        hipLaunchKernelGGL(k_mm_jac_fin, dim3(E, H), dim3(256), lds_fin, st, md, wk, part, nrcm, head, mpart, jrec, jstride, bb, P);
         return;
     }
     const size_t lds_post = sizeof(double) * std::max((size_t)2 * 256 + 4 * 256, lds_mean);
