@@ -2326,3 +2326,56 @@ def test_safe_pilco_restarts_run_as_lanes_and_end_where_the_sequential_loop_ends
         ends[lanes] = (r, _policy_params(p.controller)[0]())
     assert ends["0"][0] == ends["1"][0]
     assert np.array_equal(ends["0"][1], ends["1"][1])
+
+
+@pytest.mark.parametrize("N,E,U,H", [(180, 4, 1, 7), (300, 5, 2, 6), (1000, 10, 1, 12), (130, 9, 4, 5)])
+def test_device_reverse_chain_matches_the_host_chain(N, E, U, H):
+    """Round 6: for a LinearController the reverse chain of pilco_rollout_grad runs on the device (csrc/rev.hip: every step's
+    linear reverse map as a matrix, then one matrix-vector product per step) -- the reference differentiates the whole
+    tf.while_loop on the accelerator (pilco/models/pilco.py:85-90,126-135).  Held to the host chain of rounds 1-5 (csrc/grad.hip,
+    itself pinned to reverse mode through the executed reference by the fixtures above): combined exponential + linear
+    rewards (rewards.py:19-81), cotangent seeds of a trajectory objective (safe_pilco_extension/safe_pilco.py:29-50), lanes.
+    Same formulas, different summation orders: 1e-10 relative; each bitwise repeatable."""
+    from pilco_amd import _lib
+    c = synthetic.config_c2(N=N, D=E + U, E=E, noise=1e-2, seed=41 + E, control_dim=U)
+    rs = np.random.RandomState(5)
+    Wr = rs.randn(E, E)
+    rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=0.7, W=Wr @ Wr.T / E + 0.2 * np.eye(E), t=0.1 * rs.randn(E)),
+          dict(kind=_lib.REWARD_LINEAR, coef=-0.3, W=rs.randn(E), t=None)]
+    pol = dict(kind=_lib.POLICY_LINEAR, state_dim=E, control_dim=U, W=c["W"], b=0.05 * rs.randn(U), max_action=1.3 + 0.2 * rs.rand(U), squash=True)
+    m0, S0 = c["m0"], 0.05 * np.eye(E)
+    G = rs.randn(H + 1, E + E * E)
+
+    def seed_fn(traj):   # d/d traj of 0.5 * sum (G . traj)^2-like smooth objective: any finite function of the trajectory will do
+        return 0.01 * G * np.tanh(traj)
+
+    out = {}
+    for dev in (0, 1):
+        cx = _lib.Context(device=0)
+        try:
+            cx.set_reverse_chain(dev)
+            cx.gp_set_data(0, c["X"], c["Y"])
+            cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"])
+            cx.gp_factorize(0)
+            plain = [cx.rollout_grad(pol, rw, m0, S0, H) for _ in range(2)]
+            seeded = [cx.rollout_grad(pol, rw, m0, S0, H, seed_fn=seed_fn) for _ in range(2)]
+            pols = [dict(pol, W=pol["W"] * (1.0 + 0.1 * i), b=pol["b"] + 0.01 * i) for i in range(3)]
+            lanes = cx.rollout_grad_batch(pols, rw, np.tile(m0, (3, 1)), np.tile(S0, (3, 1, 1)), H)
+            solo = [cx.rollout_grad(pq, rw, m0, S0, H) for pq in pols]
+            out[dev] = (plain, seeded, lanes, solo)
+        finally:
+            cx.close()
+    for dev in (0, 1):
+        plain, seeded, lanes, solo = out[dev]
+        for pair in (plain, seeded):   # bitwise repeatable
+            assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(pair[0], pair[1]))
+        for i in range(3):             # lanes are bit-identical to their solo calls
+            assert lanes[0][i] == np.asarray(solo[i][0]).ravel()[0]
+            assert np.array_equal(lanes[1][i], solo[i][1]) and np.array_equal(lanes[2][i], solo[i][2])
+    for k in (0, 1):                   # host chain vs device chain
+        h, d = out[0][k][0], out[1][k][0]
+        assert np.asarray(h[0]).ravel()[0] == np.asarray(d[0]).ravel()[0]       # the value comes from the same forward half
+        scale = max(np.max(np.abs(h[1])), np.max(np.abs(h[2])))
+        np.testing.assert_allclose(d[1], h[1], rtol=1e-10, atol=1e-12 * scale)
+        np.testing.assert_allclose(d[2], h[2], rtol=1e-10, atol=1e-12 * scale)
+    assert not np.allclose(out[1][0][0][1], out[1][1][0][1])                    # the seeds do enter
