@@ -154,7 +154,7 @@ void launch_trtri(hipStream_t st, const double* L, int npad, int batch, double* 
 void launch_matvec(hipStream_t st, const double* A, int npad, int batch, const double* x, double* y, bool trans);
 // zero rows/cols >= n of batch square matrices
 void launch_clear_padding(hipStream_t st, double* A, int npad, int n, int batch);
-void launch_transpose_points(hipStream_t st, const double* X, int n, int D, double* Xt, int ld);
+void launch_transpose_points(hipStream_t st, const double* X, int n, int D, double* Xt, int ld, int batch = 1, long sX = 0, long sXt = 0);
 // FITC helpers (smgpr.py:30-43)
 // G[b][n] = sqrt(1 + (var[b] - sum_m V[b][m][n]^2) / noise[b]);  V[b][m][n] /= G[b][n]
 void launch_fitc_scale(hipStream_t st, double* V, int mpad, int npad, int batch, const double* var, const double* noise, double* G);

@@ -16,6 +16,7 @@
 // Everything O(M^2 N) is an f64-MFMA GEMM of csrc/linalg.hip; the kernel derivatives are weighted reductions over the
 // (m, n) grid with K recomputed on the fly.  All outputs are batched (z = output).
 #include "ctx.h"
+#include "mm_device.h"   // d4, the MFMA guards
 
 namespace pilco {
 
@@ -31,10 +32,17 @@ __global__ __launch_bounds__(256) void k_fitc_cols(const double* __restrict__ P,
     if (n < N) {
         const double* Pb = P + (long)b * mpad * npad;
         double tn = 0.0, cn = 0.0;
-        for (int m = 0; m < M; ++m) {
-            const double p = Pb[(long)m * npad + n];
-            tn = fma(p, gam[(long)b * mpad + m], tn);
-            cn = fma(p, p, cn);
+        // (8 rows requested together: a plain loop waits for one global load per row, 200 round trips per thread)
+        for (int m0 = 0; m0 < M; m0 += 8) {
+            double pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pv[u] = Pb[(long)min(m0 + u, M - 1) * npad + n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (m0 + u < M) {
+                    tn = fma(pv[u], gam[(long)b * mpad + m0 + u], tn);
+                    cn = fma(pv[u], pv[u], cn);
+                }
         }
         const double sn2 = noise[b], sn = sqrt(sn2), Gn = G[(long)b * npad + n];
         tn /= sn;                                          // gam holds gamma * sn (= Am^-1 r0)
@@ -152,6 +160,139 @@ static void launch_fitc_kgrad(int D, dim3 grid, hipStream_t st, Args... args) {
     else hipLaunchKernelGGL(k_fitc_kgrad<32>, grid, dim3(256), 0, st, args...);
 }
 
+// The same reductions on the matrix cores (round 6; D <= 14).  The VALU kernel above re-reads a point's D coordinates for every
+// row m it meets -- 880 MB of L2 traffic and a load-latency chain per thread: 350 us for the 10^7 kernel evaluations of config 4,
+// a tenth of what the arithmetic needs.  With p~ = p / l, z~ = z / l the tile of squared distances is a product,
+//     r2[n][m] = sum_k A1[n][k] B1[k][m],   A1 = (p~_n | |p~_n|^2 | 1),   B1 = (-2 z~_m | 1 | |z~_m|^2)     (K = D + 2),
+// computed TRANSPOSED (points along the result registers) so that w = DK_mn var exp(-r2 / 2) lands in the A-operand layout of
+// a second product with the points' coordinates,
+//     out[m][c] = sum_n w_mn B2[n][c],   B2 = (p_n | 1 | 0..) and (p_n^2 | 0..):   WP = sum w p,  rs = sum w,  WP2 = sum w p^2,
+// from which  sum w (p - z) / l^2 = (WP - z rs) / l^2  and  sum w (z - p)^2 / l^3 = (WP2 - 2 z WP + z^2 rs) / l^3.
+// One workgroup per (16-row tile, output, slice of the points); its four waves take the 16-point tiles of the slice in turn and
+// add their results in a fixed order.  Output: out[slice][b][mpad][2 FT_MAXD + 1], the row format of the kernel above.
+constexpr int FT_NSPLIT = 4;
+template <int KS>   // k-steps of the distance product: 4 KS >= D + 2
+__global__ __launch_bounds__(256) void k_fitc_kgrad_mfma(const double* __restrict__ DK, int ldk, const double* __restrict__ Zt, int mpad,
+                                                         const double* __restrict__ Pt, int ldp, long sPt, int N, int M, int D,
+                                                         const double* __restrict__ ls, const double* __restrict__ var,
+                                                         const double* __restrict__ c, double cc, double* __restrict__ out, int E) {
+    __shared__ double red[4][2][256];
+    const int b = blockIdx.y, m0 = blockIdx.x * 16, sp = blockIdx.z, nsp = gridDim.z;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, lr = lane >> 4, lc = lane & 15;
+    const double* Zb = Zt + (long)b * D * mpad;
+    const double* Pb = Pt + (long)b * sPt;
+    const double v = var[b];
+    // B1 fragments (constant over the points): row k = 4 q + lr, column m = m0 + lc (clamped: rows past M weigh zero below)
+    const int mc = min(m0 + lc, mpad - 1);
+    double zt2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+        const double zd = Zb[(long)d * mpad + mc] / ls[b * D + d];
+        zt2 = fma(zd, zd, zt2);
+    }
+    double b1[KS], il1[KS];
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+        const int k = 4 * q + lr, kc = min(k, D - 1);
+        const double il = 1.0 / ls[b * D + kc];
+        il1[q] = k < D ? il : 0.0;                                   // A1's scale for this lane's coordinate
+        b1[q] = k < D ? -2.0 * Zb[(long)kc * mpad + mc] * il : (k == D ? 1.0 : (k == D + 1 ? zt2 : 0.0));
+    }
+    const double cm = c ? c[(long)b * mpad + mc] : 0.0;
+    const bool mok = m0 + lc < M;
+    const int cB = min(lc, D - 1);                                     // B2's coordinate row of this lane
+    d4 C0 = d4{0.0, 0.0, 0.0, 0.0}, C1 = d4{0.0, 0.0, 0.0, 0.0};
+    // this workgroup's slice of the 16-point tiles, dealt over the waves
+    const int ntile = (N + 15) / 16, per = (ntile + nsp - 1) / nsp, t0 = sp * per, t1 = min(ntile, t0 + per);
+    const double* row = DK + ((long)b * mpad + mc) * ldk;
+    for (int tl = t0 + w; tl < t1; tl += 4) {
+        const int n0 = 16 * tl;
+        // A1: row n = n0 + lc, column k = 4 q + lr  (requests unconditional, clamped into the padding)
+        const int nA = min(n0 + lc, ldp - 1);
+        double a1[KS], sq = 0.0;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            const int kc = min(4 * q + lr, D - 1);
+            a1[q] = Pb[(long)kc * ldp + nA] * il1[q];
+            sq = fma(a1[q], a1[q], sq);
+        }
+        // weights and B2: point n = n0 + 4 r + lr
+        double wg[4], pb[4], cn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nB = min(n0 + 4 * r + lr, ldp - 1);
+            wg[r] = row[min(n0 + 4 * r + lr, ldk - 1)];
+            pb[r] = Pb[(long)cB * ldp + nB];
+            cn[r] = c ? c[(long)b * mpad + min(nB, mpad - 1)] : 0.0;
+        }
+        // |p~_n|^2: the four k-groups of a point sit in lanes lc, lc + 16, lc + 32, lc + 48
+        sq += __shfl_xor(sq, 16);
+        sq += __shfl_xor(sq, 32);
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            const int k = 4 * q + lr;
+            if (k == D) a1[q] = sq;
+            else if (k == D + 1) a1[q] = 1.0;
+        }
+        d4 ST = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            ST = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], ST, 0, 0, 0);
+            MFMA_KEEP_ALIVE(a1[q]);
+            MFMA_KEEP_ALIVE(b1[q]);
+        }
+        MFMA_RESULT_FENCE(ST);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = mok && n0 + 4 * r + lr < N;
+            double wt = wg[r];
+            if (c) wt = fma(cc * cm, cn[r], wt);
+            const double wv = ok ? wt * v * exp(-0.5 * fmax(ST[r], 0.0)) : 0.0;
+            const double b20 = lc < D ? pb[r] : (lc == D ? 1.0 : 0.0), b21 = lc < D ? pb[r] * pb[r] : 0.0;
+            C0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, b20, C0, 0, 0, 0);
+            C1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, b21, C1, 0, 0, 0);
+            MFMA_KEEP_ALIVE(wv);
+            MFMA_KEEP_ALIVE(b20);
+            MFMA_KEEP_ALIVE(b21);
+        }
+    }
+    MFMA_RESULT_FENCE(C0);
+    MFMA_RESULT_FENCE(C1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[w][0][r * 64 + lane] = C0[r];
+        red[w][1][r * 64 + lane] = C1[r];
+    }
+    __syncthreads();
+    // element t of a tile: row m = (t >> 4) & 3 + 4 (t >> 6), column t & 15
+    double* s0 = &red[0][0][0];   // (reused: sums of the four waves)
+    const double v0 = (red[0][0][t] + red[1][0][t]) + (red[2][0][t] + red[3][0][t]);
+    const double v1 = (red[0][1][t] + red[1][1][t]) + (red[2][1][t] + red[3][1][t]);
+    __syncthreads();
+    s0[t] = v0;
+    s0[256 + t] = v1;
+    __syncthreads();
+    const int mr = ((t >> 4) & 3) + 4 * (t >> 6), d = t & 15, m = m0 + mr;   // thread -> (row, coordinate)
+    const int PW = 2 * FT_MAXD + 1;
+    if (m < M) {
+        double* o = out + (((long)sp * E + b) * mpad + m) * PW;
+        const int ti = (mr & 3) * 16 + (mr >> 2) * 64;   // index of (row mr, column 0) in the tile layout
+        const double rs = s0[ti + D];
+        if (d < D) {
+            const double il = 1.0 / ls[b * D + d], z = Zb[(long)d * mpad + m], wp = s0[ti + d], wp2 = s0[256 + ti + d];
+            o[d] = il * il * (wp - z * rs);
+            o[D + d] = il * il * il * ((wp2 - 2.0 * z * wp) + z * z * rs);
+        } else if (d == D) {
+            o[2 * D] = rs / v;
+        }
+    }
+}
+template <typename... Args>
+static void launch_fitc_kgrad_mfma(int D, dim3 grid, hipStream_t st, Args... args) {
+    if (D + 2 <= 8) hipLaunchKernelGGL(k_fitc_kgrad_mfma<2>, grid, dim3(256), 0, st, args...);
+    else if (D + 2 <= 12) hipLaunchKernelGGL(k_fitc_kgrad_mfma<3>, grid, dim3(256), 0, st, args...);
+    else hipLaunchKernelGGL(k_fitc_kgrad_mfma<4>, grid, dim3(256), 0, st, args...);
+}
+
 // sums for the value: out[b] = (sum (y/G)^2, sum log G, sum g)
 __global__ __launch_bounds__(256) void k_fitc_sums(const double* __restrict__ y, const double* __restrict__ G, const double* __restrict__ g, int N,
                                                    int npad, double* __restrict__ out) {
@@ -172,6 +313,46 @@ __global__ __launch_bounds__(256) void k_fitc_sums(const double* __restrict__ y,
     if ((t & 63) == 0) { red[t >> 6][0] = s0; red[t >> 6][1] = s1; red[t >> 6][2] = s2; }
     __syncthreads();
     if (t < 3) out[b * 3 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+
+// The two reductions' per-row sums folded into what the caller gets (one workgroup per output, fixed orders):
+//   res[e] = ( d f / d lengthscale [D] | d f / d var | d f / d sn2 | gam . gam | d f / d Z [M][D] ),   sg = sums[3 e + 2] = sum_n g_n
+// -- 1.7 kB per output cross to the host instead of the (slices + 1) x M x 65 partial rows (6.6 MB at config 4, pageable).
+__global__ __launch_bounds__(256) void k_fitc_kgrad_fin(const double* __restrict__ uf, int nsp, const double* __restrict__ uu, const double* __restrict__ sums,
+                                                        const double* __restrict__ gam, int E, int M, int mpad, int D, double* __restrict__ res) {
+    __shared__ double red[4];
+    const int e = blockIdx.x, t = threadIdx.x, PW = 2 * FT_MAXD + 1;
+    const long RS = (long)D + 3 + (long)M * D;
+    double* o = res + (long)e * RS;
+    const double* u1 = uu + (long)e * mpad * PW;
+    for (int i = blockIdx.y * 256 + t; i < M * D; i += 256 * gridDim.y) {   // (blockIdx.y: slices of d f / d Z; the sums below in slice 0)
+        const int m = i / D, d = i - m * D;
+        double a = 0.0;
+        for (int q = 0; q < nsp; ++q) a += uf[(((long)q * E + e) * mpad + m) * PW + d];
+        o[D + 3 + i] = -(a + 2.0 * u1[(long)m * PW + d]);
+    }
+    if (blockIdx.y != 0) return;
+    const double sg = sums[3 * e + 2];
+    // lengthscales (slots D + d) and the variance (slot 2 D): 16 threads per slot, rows dealt over them, fixed-order tree
+    // (one thread per slot walked M (slices + 1) strided loads one after the other: 290 us for ten workgroups)
+    for (int s0 = 0; s0 <= D; s0 += 16) {
+        const int sl = s0 + (t >> 4), gi = t & 15, slot = D + min(sl, D);
+        double acc = 0.0;
+        for (int m = gi; m < M; m += 16) {
+            double a = 0.0;
+            for (int q = 0; q < nsp; ++q) a += uf[(((long)q * E + e) * mpad + m) * PW + slot];
+            acc += a + u1[(long)m * PW + slot];
+        }
+        for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 16);
+        if (gi == 0 && sl <= D) o[sl] = (sl < D) ? -acc : -(sg + acc);
+    }
+    if (t == D + 1) o[D + 1] = -sg;
+    double g2 = 0.0;
+    for (int m = t; m < M; m += 256) g2 = fma(gam[(long)e * mpad + m], gam[(long)e * mpad + m], g2);
+    for (int off = 32; off > 0; off >>= 1) g2 += __shfl_down(g2, off);
+    if ((t & 63) == 0) red[t >> 6] = g2;
+    __syncthreads();
+    if (t == 0) o[D + 2] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 }  // namespace pilco
@@ -199,14 +380,13 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     ENSURE(s.ksplit_ws, (size_t)FITC_KSPLIT * E * mm);
     ENSURE(s.iK, E * mm);       // DKuu
     ENSURE(s.G, (size_t)E * Np);
-    ENSURE(s.Tscr, std::max(E * mm, (size_t)E * Mp * (2 * FT_MAXD + 1) * 2));
+    ENSURE(s.Tscr, std::max(E * mm, (size_t)E * Mp * (2 * FT_MAXD + 1) * (FT_NSPLIT + 1)));
     ENSURE(s.ft_P, E * mn);
     ENSURE(s.ft_T3, E * mn);
     ENSURE(s.ft_Z, (size_t)E * D * Mp + (size_t)E * M * D);
-    ENSURE(s.vec, (size_t)E * (4 * (size_t)std::max(Mp, Np) + 8));
+    ENSURE(s.vec, (size_t)E * (4 * (size_t)std::max(Mp, Np) + 8) + 8 + (size_t)E * ((size_t)D + 3 + (size_t)M * D));
     double* Zt = s.ft_Z.p;                       // [E][D][Mp]
     double* Zraw = Zt + (size_t)E * D * Mp;      // [E][M][D] staging
-    HIPCHK(hipMemcpyAsync(Zraw, Z_all, sizeof(double) * (size_t)E * M * D, hipMemcpyHostToDevice, st));
     const long sZ = (long)D * Mp;
     double* Kuu = s.K.p;
     double* V = s.V2.p;
@@ -217,8 +397,13 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     double* gv = av + (size_t)E * Np;                        // [E][Np]
     double* cv = gv + (size_t)E * Np;                        // [E][Mp]
     double* sums = cv + (size_t)E * Mp;                      // [E][3] + logdet [E]
+    const size_t RS = (size_t)D + 3 + (size_t)M * D;         // per output: d ls | d var | d sn2 | gam . gam | d Z
+    double* res = sums + 4 * (size_t)E + 4;                  // [E][RS]
+    // per-row partial sums of the two kernel-derivative reductions: Kuf's in nsp slices of the points, then Kuu's
+    const bool kg_mfma = D <= 14 && getenv("PILCO_FITC_KGRAD_VALU") == nullptr;
+    const int nsp = kg_mfma ? (N >= 2048 ? FT_NSPLIT : 1) : 1;
     double* part_uf = s.Tscr.p;
-    double* part_uu = part_uf + (size_t)E * Mp * (2 * FT_MAXD + 1);
+    double* part_uu = part_uf + (size_t)nsp * E * Mp * (2 * FT_MAXD + 1);
     // everything between the upload of Z and the downloads is a fixed launch sequence (~80 launches at M = 200): one graph
     std::vector<unsigned long long> key;
     for (const DevBuf* b : {&s.K, &s.Linv, &s.Kmn, &s.V2, &s.Am, &s.AmInv, &s.iAt, &s.ksplit_ws, &s.iK, &s.G, &s.Tscr, &s.ft_P,
@@ -226,9 +411,9 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
         key.push_back((unsigned long long)(uintptr_t)b->p);
     for (const void* q : {(const void*)o_ls, (const void*)o_var, (const void*)o_noise, (const void*)o_Yt, (const void*)ctx->d_info})
         key.push_back((unsigned long long)(uintptr_t)q);
-    for (int v : {E, M, Mp, N, Np, D, want_grad ? 1 : 0}) key.push_back((unsigned long long)v);
+    for (int v : {E, M, Mp, N, Np, D, want_grad ? 1 : 0, nsp, kg_mfma ? 1 : 0}) key.push_back((unsigned long long)v);
     auto chain = [&]() -> int {
-    for (int e = 0; e < E; ++e) launch_transpose_points(st, Zraw + (size_t)e * M * D, M, D, Zt + (size_t)e * D * Mp, Mp);
+    launch_transpose_points(st, Zraw, M, D, Zt, Mp, E, (long)M * D, (long)D * Mp);
     HIPCHK(hipMemsetAsync(ctx->d_info, 0, sizeof(int) * 64, st));
     launch_gram(st, Zt, Mp, M, Zt, Mp, M, D, o_ls, o_var, E, Kuu, Mp, Mp, 2, nullptr, 1e-6, sZ, sZ);
     launch_gram(st, Zt, Mp, M, s.Xt.p, Np, N, D, o_ls, o_var, E, s.Kmn.p, Mp, Np, 0, nullptr, 0.0, sZ, 0);
@@ -291,62 +476,77 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
         g.M = Mp; g.N = Mp; g.K = Np; g.alpha = 1.0; g.beta = 0.0;
         g.ksplit = FITC_KSPLIT; g.split_ws = s.ksplit_ws.p;
         launch_gemm(st, g, false, true, E);
-        launch_fitc_kgrad(D, dim3(M, E), st, (const double*)s.ft_T3.p, Np, (const double*)Zt, Mp, (const double*)s.Xt.p, Np, 0L, N, D,
-                          o_ls, o_var, (const double*)nullptr, 0.0, part_uf);
-        launch_fitc_kgrad(D, dim3(M, E), st, (const double*)s.iK.p, Mp, (const double*)Zt, Mp, (const double*)Zt, Mp, sZ, M, D, o_ls,
-                          o_var, (const double*)cv, -0.5, part_uu);
+        if (kg_mfma) {
+            launch_fitc_kgrad_mfma(D, dim3((M + 15) / 16, E, nsp), st, (const double*)s.ft_T3.p, Np, (const double*)Zt, Mp, (const double*)s.Xt.p, Np,
+                                   0L, N, M, D, o_ls, o_var, (const double*)nullptr, 0.0, part_uf, E);
+            launch_fitc_kgrad_mfma(D, dim3((M + 15) / 16, E, 1), st, (const double*)s.iK.p, Mp, (const double*)Zt, Mp, (const double*)Zt, Mp, sZ, M, M, D,
+                                   o_ls, o_var, (const double*)cv, -0.5, part_uu, E);
+        } else {
+            launch_fitc_kgrad(D, dim3(M, E), st, (const double*)s.ft_T3.p, Np, (const double*)Zt, Mp, (const double*)s.Xt.p, Np, 0L, N, D,
+                              o_ls, o_var, (const double*)nullptr, 0.0, part_uf);
+            launch_fitc_kgrad(D, dim3(M, E), st, (const double*)s.iK.p, Mp, (const double*)Zt, Mp, (const double*)Zt, Mp, sZ, M, D, o_ls,
+                              o_var, (const double*)cv, -0.5, part_uu);
+        }
     } else {
         HIPCHK(hipMemsetAsync(gv, 0, sizeof(double) * (size_t)E * Np, st));
     }
     hipLaunchKernelGGL(k_fitc_sums, dim3(E), dim3(256), 0, st, o_Yt, s.G.p, gv, N, Np, sums);
+    if (want_grad)
+        hipLaunchKernelGGL(k_fitc_kgrad_fin, dim3(E, 8), dim3(256), 0, st, (const double*)part_uf, nsp, (const double*)part_uu, (const double*)sums,
+                           (const double*)gam, E, M, Mp, D, res);
     return PILCO_OK;
     };
-    if (int r = run_chain_graph(ctx, s.g_fitc_nlml, key, chain)) return r;
-    std::vector<double> hz;
-    if (want_grad) {
-        hz.resize((size_t)2 * E * Mp * (2 * FT_MAXD + 1));
-        HIPCHK(hipMemcpyAsync(hz.data(), part_uf, sizeof(double) * hz.size(), hipMemcpyDeviceToHost, st));
+    // everything the host needs in ONE pinned block: res [E][RS] | sums [4 E] | gam [E][Mp] (value-only calls) | noise [E] | info (64 ints)
+    const size_t n_pin = (size_t)E * RS + 4 * (size_t)E + (size_t)E * Mp + E + 32 + 8 + (size_t)E * M * D;
+    if (ctx->pin_cap < n_pin) {
+        if (ctx->pin) (void)hipHostFree(ctx->pin);
+        ctx->pin = nullptr;
+        ctx->pin_cap = 0;
+        HIPCHK(hipHostMalloc((void**)&ctx->pin, sizeof(double) * n_pin, hipHostMallocDefault));
+        ctx->pin_cap = n_pin;
     }
-    std::vector<double> hs(4 * (size_t)E), hg((size_t)E * Mp), hn(E);
-    int info[64];
-    HIPCHK(hipMemcpyAsync(hs.data(), sums, sizeof(double) * 4 * E, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(hg.data(), gam, sizeof(double) * (size_t)E * Mp, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(hn.data(), o_noise, sizeof(double) * E, hipMemcpyDeviceToHost, st));
+    {   // the inducing inputs go up from pinned memory (a pageable source is a staged, blocking copy)
+        double* h_z = ctx->pin + (n_pin - (size_t)E * M * D);
+        memcpy(h_z, Z_all, sizeof(double) * (size_t)E * M * D);
+        HIPCHK(hipMemcpyAsync(Zraw, h_z, sizeof(double) * (size_t)E * M * D, hipMemcpyHostToDevice, st));
+    }
+    if (int r = run_chain_graph(ctx, s.g_fitc_nlml, key, chain)) return r;
+    double* h_res = ctx->pin;
+    double* h_s = h_res + (size_t)E * RS;
+    double* h_g = h_s + 4 * (size_t)E;
+    double* h_n = h_g + (size_t)E * Mp;
+    int* info = (int*)(h_n + E);
+    if (want_grad) HIPCHK(hipMemcpyAsync(h_res, res, sizeof(double) * (size_t)E * RS, hipMemcpyDeviceToHost, st));
+    else HIPCHK(hipMemcpyAsync(h_g, gam, sizeof(double) * (size_t)E * Mp, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_s, sums, sizeof(double) * 4 * E, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_n, o_noise, sizeof(double) * E, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(info, ctx->d_info, sizeof(int) * 64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
+    const double* hs = h_s;
+    const double* hn = h_n;
     for (int e = 0; e < std::min(E, 32); ++e)
         if (info[e] != 0 || info[32 + e] != 0) {
             ctx->not_pd = e;
             return fail(ctx, PILCO_E_NOT_PD, "FITC objective: Cholesky failed for output " + std::to_string(e));
         }
-    const int PW = 2 * FT_MAXD + 1;
     for (int e = 0; e < E; ++e) {
         const double sn2 = hn[e];
         double g2 = 0.0;
-        for (int m = 0; m < M; ++m) g2 += hg[(size_t)e * Mp + m] * hg[(size_t)e * Mp + m];
+        if (want_grad) g2 = h_res[(size_t)e * RS + D + 2];
+        else
+            for (int m = 0; m < M; ++m) g2 += h_g[(size_t)e * Mp + m] * h_g[(size_t)e * Mp + m];
         const double f = -0.5 * hs[3 * e] / sn2 + 0.5 * g2 / sn2 - 0.5 * N * std::log(2.0 * M_PI) -
                          0.5 * (N * std::log(sn2) + 2.0 * hs[3 * e + 1]) - (hs[3 * E + e] - 0.5 * M * std::log(sn2));
         nlml[e] = -f;
         if (!want_grad) continue;
-        const double* uf = hz.data() + (size_t)e * Mp * PW;
-        const double* uu = hz.data() + (size_t)(E + e) * Mp * PW;
-        const double sg = hs[3 * e + 2];
+        const double* r = h_res + (size_t)e * RS;
         if (grad_hyp) {
-            for (int d = 0; d < D; ++d) {
-                double acc = 0.0;
-                for (int m = 0; m < M; ++m) acc += uf[(size_t)m * PW + D + d] + uu[(size_t)m * PW + D + d];
-                grad_hyp[(size_t)e * (D + 2) + d] = -acc;
-            }
-            double accv = sg;
-            for (int m = 0; m < M; ++m) accv += uf[(size_t)m * PW + 2 * D] + uu[(size_t)m * PW + 2 * D];
-            grad_hyp[(size_t)e * (D + 2) + D] = -accv;
-            grad_hyp[(size_t)e * (D + 2) + D + 1] = -sg;
+            for (int d = 0; d < D; ++d) grad_hyp[(size_t)e * (D + 2) + d] = r[d];
+            grad_hyp[(size_t)e * (D + 2) + D] = r[D];
+            grad_hyp[(size_t)e * (D + 2) + D + 1] = r[D + 1];
         }
-        if (grad_Z)
-            for (int m = 0; m < M; ++m)
-                for (int d = 0; d < D; ++d)
-                    grad_Z[((size_t)e * M + m) * D + d] = -(uf[(size_t)m * PW + d] + 2.0 * uu[(size_t)m * PW + d]);
+        if (grad_Z) memcpy(grad_Z + (size_t)e * M * D, r + D + 3, sizeof(double) * (size_t)M * D);
     }
     return PILCO_OK;
 }

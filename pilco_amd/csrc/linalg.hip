@@ -81,14 +81,17 @@ void launch_gram(hipStream_t st, const double* P1t, int ld1, int n1, const doubl
                        diag_mode, diag_add, jitter, sP1, sP2);
 }
 
-__global__ void k_transpose_points(const double* __restrict__ X, int n, int D, double* __restrict__ Xt, int ld) {
+// (blockIdx.y: one of `batch` point sets, sX / sXt doubles apart -- the E inducing-point sets of the FITC objective used to be E launches)
+__global__ void k_transpose_points(const double* __restrict__ X, int n, int D, double* __restrict__ Xt, int ld, long sX, long sXt) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= ld) return;
+    X += (long)blockIdx.y * sX;
+    Xt += (long)blockIdx.y * sXt;
     for (int d = 0; d < D; ++d) Xt[(long)d * ld + i] = (i < n) ? X[(long)i * D + d] : 0.0;
 }
 
-void launch_transpose_points(hipStream_t st, const double* X, int n, int D, double* Xt, int ld) {
-    hipLaunchKernelGGL(k_transpose_points, dim3((ld + 255) / 256), dim3(256), 0, st, X, n, D, Xt, ld);
+void launch_transpose_points(hipStream_t st, const double* X, int n, int D, double* Xt, int ld, int batch, long sX, long sXt) {
+    hipLaunchKernelGGL(k_transpose_points, dim3((ld + 255) / 256, batch), dim3(256), 0, st, X, n, D, Xt, ld, sX, sXt);
 }
 
 // ------------------------------------------------------------------ GEMM (f64 MFMA)
