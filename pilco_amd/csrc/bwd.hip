@@ -261,7 +261,11 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
                 // (Quartiles by comparison with scalar thresholds: a signed division here -- the compiler's float-reciprocal
                 // sequence -- made the K = 8 instantiation compute wrong sums, found by the seeded shape sweep of the GPU tests.)
                 const int done4 = 4 * (jc - jstart), len = jend - jstart;
+#if BWD_FAIR == 2   // (the variant of the advisor's question: the signed division that once went with wrong sums at K = 8)
+                const int q = done4 / len;
+#else
                 const int q = (done4 >= len ? 1 : 0) + (done4 >= 2 * len ? 1 : 0) + (done4 >= 3 * len ? 1 : 0);
+#endif
                 if (q == 0) __builtin_amdgcn_s_setprio(3);
                 else if (q == 1) __builtin_amdgcn_s_setprio(2);
                 else if (q == 2) __builtin_amdgcn_s_setprio(1);
@@ -333,6 +337,17 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
                     for (int m = 0; m < NMT; ++m)
     #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[rt][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[r], a2[m][r], acc[rt][m], 0, 0, 0);
+                }
+                // v_j must outlive BOTH row tiles' chains (third MFMA defect of this toolchain, round 6): it is the SrcC of each
+                // chain's first MFMA, and once dead after the last of them the compiler lets that chain accumulate IN PLACE --
+                // an f64 MFMA that writes the registers the MFMA issued one or two slots before it is still reading as its
+                // SrcC.  The hardware does not interlock that write-after-read; with nothing between the two (the quartile by
+                // a signed division happened to move two v_mul_f64 away from there) the first chain picked up the second's
+                // partial results: wrong, run-to-run different sums in the K = 8 instantiation.  Held alive here, the second
+                // chain gets a destination of its own; tools/mfma_hazard_check.py now flags the pattern.
+                if (VSEP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) MFMA_KEEP_ALIVE(vj[r]);
                 }
                 if (MODE == 1 && j0 + 16 < jend) ik_request(j0 + 16);   // (every use of this step's tile is behind us)
                 // column sums over the wave's 16 lanes of a DPP row, through a per-wave LDS scratch instead of four

@@ -1,9 +1,13 @@
 """The generated gfx950 code of the MFMA kernels, checked on the CPU (hipcc cross-compiles without a GPU).
 
-Round 2 found two ways in which hipcc (ROCm 7.2) miscompiles chains of v_mfma_f64_16x16x4_f64:
+Round 2 found two ways in which hipcc (ROCm 7.2) miscompiles chains of v_mfma_f64_16x16x4_f64, round 6 a third:
   * the destination registers of an MFMA with a constant-zero accumulator may overlap a dying A / B source register;
   * the wait states between an MFMA and a VALU read of its result are missing in some instantiations (the reverse sweep
-    read the last destination pair one slot after the MFMA and got the accumulator from before the last k-step).
+    read the last destination pair one slot after the MFMA and got the accumulator from before the last k-step);
+  * an MFMA may be given as its destination the registers the MFMA issued one or two slots earlier is still reading as
+    its SrcC (two accumulation chains that start from the same registers, the second running in place once they are
+    dead): the first chain picks up the second's partial results (the reverse sweep's K = 8 instantiation, run-to-run
+    different sums whenever nothing happened to be scheduled between the two).
 csrc/mm_device.h carries the source-level counter-measures (MFMA_KEEP_ALIVE, MFMA_RESULT_FENCE); this test compiles the
 MFMA-carrying translation units to assembly and scans EVERY instantiation with tools/mfma_overlap_check.py and
 tools/mfma_hazard_check.py, so a compiler or source change that re-opens either hole fails here, not on the GPU."""
@@ -18,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-UNITS = ["pair", "bwd", "linalg", "prep_dt_a", "prep_dt_b"]   # prep_dt_a, _b: the heads for D <= 11 (both register builds), whose one-launch small step carries the pair and sweep arithmetic
+UNITS = ["pair", "bwd", "linalg", "fitc_train", "prep_dt_a", "prep_dt_b"]   # prep_dt_a, _b: the heads for D <= 11 (both register builds), whose one-launch small step carries the pair and sweep arithmetic
 
 
 @pytest.fixture(scope="module")
@@ -65,7 +69,15 @@ def test_the_scanners_flag_the_two_patterns_they_guard_against(tmp_path):
     fine = tmp_path / "fine.s"
     fine.write_text("_Zok:\n\tv_mfma_f64_16x16x4_f64 v[108:115], v[178:179], v[96:97], v[108:115]\n\ts_nop 10\n"
                     "\tv_max_f64 v[194:195], v[114:115], s[68:69]\n")
+    # round 6: the second chain's first MFMA writes the first chain's SrcC (hipcc's code for the K = 8 sweep with nothing in between)
+    war = tmp_path / "war.s"
+    war.write_text("_Zbad:\n\tv_mfma_f64_16x16x4_f64 v[88:95], v[26:27], v[80:81], v[18:25]\n\ts_mov_b32 s76, s74\n"
+                   "\tv_mfma_f64_16x16x4_f64 v[18:25], v[26:27], v[84:85], v[18:25]\n\ts_nop 10\n\ts_nop 10\n")
+    war_ok = tmp_path / "war_ok.s"   # ... and the same chains with destinations of their own
+    war_ok.write_text("_Zok:\n\tv_mfma_f64_16x16x4_f64 v[88:95], v[26:27], v[80:81], v[18:25]\n\ts_mov_b32 s76, s74\n"
+                      "\tv_mfma_f64_16x16x4_f64 v[96:103], v[26:27], v[84:85], v[18:25]\n\ts_nop 10\n\ts_nop 10\n")
     run = lambda tool, f: subprocess.run([sys.executable, os.path.join(tools, tool), str(f)], capture_output=True, text=True).returncode
+    assert run("mfma_hazard_check.py", war) == 1 and run("mfma_hazard_check.py", war_ok) == 0
     assert run("mfma_overlap_check.py", overlap) == 1
     assert run("mfma_hazard_check.py", early) == 1
     assert run("mfma_overlap_check.py", fine) == 0 and run("mfma_hazard_check.py", fine) == 0

@@ -8,6 +8,7 @@ import re, sys
 from collections import Counter
 
 WAIT = 12
+WAR = 6   # slots an f64 MFMA's SrcC must stay untouched by a later MFMA's write (the failing build had 2, the working ones >= 6)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 if "--wait" in sys.argv:
     WAIT = int(sys.argv[sys.argv.index("--wait") + 1])
@@ -23,10 +24,11 @@ total = Counter()
 for path in args:
     func = "?"
     pend = []   # (dst lo, dst regs, states since issue)
+    srcc = []   # (SrcC regs of an f64 MFMA, states since issue, accumulated in place)
     for line in open(path):
         m = re.match(r'^(_Z\w+):', line)
         if m:
-            func, pend = m.group(1), []
+            func, pend, srcc = m.group(1), [], []
         t = line.strip()
         if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
             continue
@@ -38,6 +40,17 @@ for path in args:
         elif op.startswith("v_mfma"):
             d = regs(ops[0])
             srcs = set().union(*[regs(o) for o in ops[1:3]])   # A, B (an accumulator chain srcC == dst is fine)
+            # write-after-read on SrcC (round 6): an f64 MFMA whose destination overlaps the SrcC of an f64 MFMA issued
+            # fewer than WAR slots earlier -- unless that earlier MFMA accumulated in place (its own dst == its SrcC: then this
+            # one is the next link of the same chain, which the hardware orders)
+            if "f64" in op:
+                for sc, st2, inplace in srcc:
+                    if (d & sc) and not inplace and st2 < WAR:
+                        total[(func[:60], "srcC-war", 0, st2)] += 1
+                c_regs = regs(ops[3]) if len(ops) > 3 else set()
+                srcc = [(sc, st2 + 1, ip) for sc, st2, ip in srcc if st2 + 1 < 32]
+                if c_regs:
+                    srcc.append((c_regs, 1, c_regs == d))
             for lo, dr, st in pend:
                 if srcs & dr and st < WAIT:
                     total[(func[:60], "mfma-src", (min(srcs & dr) - lo) // 2, st)] += 1
@@ -55,11 +68,12 @@ for path in args:
                 w = regs(ops[0].split()[0])
                 pend = [(lo, dr - w, st) for lo, dr, st in pend]
         pend = [(lo, dr, st + states) for lo, dr, st in pend if dr and st + states < 64]
+        srcc = [(sc, st2 + states, ip) for sc, st2, ip in srcc if st2 + states < 32]
 for (f, kind, pair, st), n in sorted(total.items()):
     print("%-62s %-8s dst pair %d read %2d slots after issue  x%d" % (f, kind, pair, st, n))
 # violation: a read of destination pair p fewer than 7 + p slots after the MFMA (the distances this compiler keeps where it
 # does insert the wait states)
-bad = [k for k in total if k[3] < 7 + k[2]]
+bad = [k for k in total if (k[1] == "srcC-war") or (k[1] != "srcC-war" and k[3] < 7 + k[2])]
 if bad:
     print("VIOLATIONS: %d" % len(bad))
 sys.exit(1 if bad else 0)
