@@ -88,6 +88,9 @@ int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32);
 int pilco_debug_blocks(pilco_ctx* ctx, unsigned long long* out, int n);
 /* developer aid: raw copy of a work buffer (0 row operands At, 1 column operands Wt | vcol, 2 reverse-pass row moments, 3 column sums, 4 beta) */
 int pilco_debug_buffer(pilco_ctx* ctx, int slot, int which, double* out, long n);
+/* test aid: fills a factorisation buffer of the slot (0 = L^-1, 1 = iK, 2 = beta) with NaN bit patterns, so that a test can show
+ * which parts of it the next factorisation really writes before anybody reads them */
+int pilco_debug_poison(pilco_ctx* ctx, int slot, int which);
 /* Stream-K work split of the pair kernel (pure host functions, no GPU): the column steps of nd diagonal pairs (tdiag
  * steps each, cost ud) and n_pairs - nd off-diagonal pairs (toff steps, cost uo) lie on one line cut into `waves` equal
  * cost ranges.  pilco_debug_sk_boundary: first step of wave w (w = waves: the total).  pilco_debug_sk_pair_waves:

@@ -57,6 +57,7 @@ SIGNATURES = {
     "pilco_last_not_pd_output": (C.c_int, [_vp]),
     "pilco_set_pair_kernel": (C.c_int, [_vp, C.c_int]),
     "pilco_set_reverse_chain": (C.c_int, [_vp, C.c_int]),
+    "pilco_debug_poison": (C.c_int, [_vp, C.c_int, C.c_int]),
     "pilco_selftest": (C.c_int, [_vp]),
     "pilco_set_fused_step": (C.c_int, [_vp, C.c_int]),
     "pilco_set_grad_mode": (C.c_int, [_vp, C.c_int]),
@@ -240,6 +241,10 @@ class Context:
         """1 (default): small RbfControllers are evaluated inside the step's serial link; 0: own launches (include/pilco_hip.h)."""
         self._chk(self.lib.pilco_set_inline_policy(self.h, 1 if on else 0))
         self._settings["set_inline_policy"] = (on,)
+
+    def debug_poison(self, slot, which):
+        """Test aid: NaN-fill a factorisation buffer of the slot (0 = L^-1, 1 = iK, 2 = beta); include/pilco_hip_dev.h."""
+        self._chk(self.lib.pilco_debug_poison(self.h, int(slot), int(which)))
 
     def set_reverse_chain(self, on_device):
         """1 (default): a LinearController's reverse chain runs on the device; 0: the host chain (include/pilco_hip_dev.h)."""

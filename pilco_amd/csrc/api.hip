@@ -108,19 +108,13 @@ int build_work(pilco_ctx* ctx, Slot& s) {
     wk.At = s.w_At.p;
     wk.Wt = s.w_Wt.p;
     wk.vcol = wk.Wt + wt_blocks * wk.KP * npad;
-    {   // the constant rows of every block: zeros everywhere, then the ones (the valid mask) in row D + 1 of A (not vsep) and row D of B
-        HIPCHK(hipMemsetAsync(wk.At, 0, sizeof(double) * (size_t)PLa * wk.KP * npad, ctx->st));
-        HIPCHK(hipMemsetAsync(wk.Wt, 0, sizeof(double) * (wt_blocks * wk.KP + PLa) * npad, ctx->st));
-        std::vector<double> ones((size_t)npad, 0.0);
-        for (int i = 0; i < s.n && i < npad; ++i) ones[i] = 1.0;
-        ENSURE(s.w_ones, (size_t)npad);
-        HIPCHK(hipMemcpyAsync(s.w_ones.p, ones.data(), sizeof(double) * npad, hipMemcpyHostToDevice, ctx->st));
-        HIPCHK(hipStreamSynchronize(ctx->st));   // (the host vector goes out of scope)
-        for (int pl = 0; pl < PLa && !wk.vsep; ++pl)
-            HIPCHK(hipMemcpyAsync(wk.At + ((size_t)pl * wk.KP + D + 1) * npad, s.w_ones.p, sizeof(double) * npad, hipMemcpyDeviceToDevice, ctx->st));
-        for (size_t blk = 0; blk < wt_blocks; ++blk)
-            HIPCHK(hipMemcpyAsync(wk.Wt + (blk * wk.KP + D) * npad, s.w_ones.p, sizeof(double) * npad, hipMemcpyDeviceToDevice, ctx->st));
-    }
+    // the constant rows of every block: zeros everywhere, then the ones (the valid mask) in row D + 1 of A (not vsep) and row D
+    // of B -- one small launch (rounds 4-5: an upload, a stream synchronisation and PL + E device-to-device copies on every
+    // workspace rebuild, i.e. on every policy-slot update of an optimisation)
+    HIPCHK(hipMemsetAsync(wk.At, 0, sizeof(double) * (size_t)PLa * wk.KP * npad, ctx->st));
+    HIPCHK(hipMemsetAsync(wk.Wt, 0, sizeof(double) * (wt_blocks * wk.KP + PLa) * npad, ctx->st));
+    launch_const_rows(ctx->st, wk.vsep ? nullptr : wk.At + (size_t)(D + 1) * npad, PLa, wk.Wt + (size_t)D * npad, (int)wt_blocks, (long)wk.KP * npad, npad,
+                      s.n);
     wk.pair_isdet = s.w_small.p;
     wk.mean_part = wk.pair_isdet + PLa;
     s.alt_isdet = s.w_small.p + n_small;
@@ -373,7 +367,7 @@ int pilco_ctx_destroy(pilco_ctx* ctx) {
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     for (Slot& s : ctx->slot) {
         for (DevBuf* b : {&s.Xt, &s.Yt, &s.Zt, &s.ls, &s.var, &s.noise, &s.K, &s.Linv, &s.iK, &s.beta, &s.Tscr, &s.ksplit_ws,
-                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.jac_rowmom, &s.jac_cpart, &s.jac_head, &s.jac_part, &s.jac_np, &s.own, &s.Am, &s.AmInv, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Wt, &s.w_ones, &s.w_small, &s.w_fpart,
+                          &s.vec, &s.Kmn, &s.V2, &s.bwd_mom, &s.bwd_cp, &s.bwd_part, &s.bwd_out, &s.bwd_cnt, &s.jac_rowmom, &s.jac_cpart, &s.jac_head, &s.jac_part, &s.jac_np, &s.own, &s.Am, &s.AmInv, &s.iAt, &s.G, &s.w_in, &s.w_At, &s.w_Wt, &s.w_small, &s.w_fpart,
                           &s.w_part, &s.w_gath, &s.w_out, &s.ft_P, &s.ft_T3, &s.ft_Z})
             b->release();
     }
@@ -412,6 +406,16 @@ int pilco_set_pair_kernel(pilco_ctx* ctx, int variant) {
 #endif
     ctx->variant = variant;
     ctx->variant_user = true;
+    return PILCO_OK;
+}
+
+int pilco_debug_poison(pilco_ctx* ctx, int slot, int which) {
+    if (int r = check_slot(ctx, slot)) return r;
+    Slot& s = ctx->slot[slot];
+    DevBuf* b = which == 0 ? &s.Linv : which == 1 ? &s.iK : which == 2 ? &s.beta : nullptr;
+    if (!b) return fail(ctx, PILCO_E_SHAPE, "debug_poison: which = 0 (L^-1), 1 (iK), 2 (beta)");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (b->p && b->cap) HIPCHK(hipMemset(b->p, 0xff, sizeof(double) * b->cap));   // all-ones words: NaN
     return PILCO_OK;
 }
 

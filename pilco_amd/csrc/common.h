@@ -141,9 +141,12 @@ void launch_gram(hipStream_t st, const double* P1t, int ld1, int n1, const doubl
                  const double* diag_add, double jitter, long sP1 = 0, long sP2 = 0);   // sP*: per-output strides of the point sets (0 = shared)
 
 // Blocked Cholesky (lower) of batch matrices A[b] (npad x npad, ld = npad), in place; strictly-upper part zeroed.
-// invD receives the inverses of the diagonal 64x64 blocks of L: [batch][npad/64][64][64].
-// info[b] = 0 or 1-based index of the first non-positive pivot.
-// ... and the inverses of L's 64 x 64 diagonal blocks go straight into the diagonal blocks of Linv ([batch][npad][npad]), where
+// info[b] = 0 or 1-based index of the first non-positive pivot.  CONTRACT: with info[b] != 0 EVERYTHING this call and its
+// consumers produce for matrix b is garbage (a bad pivot is not replaced: NaN / Inf run through L, the inverses of its
+// diagonal blocks, every later panel and update, and from there through L^-1, iK and beta) -- the caller checks info before
+// it uses a factor and leaves the slot's factor_valid false (factorize_exact, pilco_factorize_fitc, fitc_nlml_batch do;
+// tests: test_a_failed_factorisation_leaves_no_usable_factor).
+// The inverses of L's 64 x 64 diagonal blocks go straight into the diagonal blocks of Linv ([batch][npad][npad]), where
 // launch_trtri builds on them (rounds 1-4: into a buffer of their own, copied over by a launch).  zero_linv: Linv is zeroed
 // first -- needed when somebody reads Linv's tiles ABOVE the diagonal (plain GEMMs of the FITC path); the exact path's
 // consumers (launch_trtri, the k_mode 1 product iK = Linv^T Linv, launch_matvec) never do, and skip 12 us at C2.

@@ -44,7 +44,7 @@ struct Slot {
     int shW = 1, shEL = 0, shOwn = 0, shRank = 0;   // ranks, outputs per rank (capacity), outputs owned, rank at factorisation time
     bool beta_complete = true;                      // false until the other ranks' beta rows have arrived
     // moment-matching workspace
-    DevBuf w_in, w_At, w_Wt, w_ones, w_small, w_part, w_gath, w_out;
+    DevBuf w_in, w_At, w_Wt, w_small, w_part, w_gath, w_out;
     DevBuf w_fpart;   // one-launch step of small models: [2][PL][NCH][2] pair partials (the head reads one copy, writes the other)
     MMWork wk{};
     double* alt_isdet = nullptr;   // second copies of pair_isdet / mean_part: the fused head reads one set (previous step)

@@ -28,6 +28,21 @@ int rbf_inline_lds_doubles(int E, int U, int bf) {
     return lay.total <= 8192 ? lay.total : 0;
 }
 
+// ones in the first n entries of row `a_row` of nA blocks and of row `b_row` of nB blocks (block stride `bs` doubles): the
+// valid masks of the operand blocks (api.hip: build_work)
+__global__ __launch_bounds__(256) void k_const_rows(double* a_row, int nA, double* b_row, int nB, long bs, int npad, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x, blk = blockIdx.y;
+    if (i >= npad) return;
+    const double v = i < n ? 1.0 : 0.0;
+    if (a_row && blk < nA) a_row[(long)blk * bs + i] = v;
+    if (blk < nB) b_row[(long)blk * bs + i] = v;
+}
+void launch_const_rows(hipStream_t st, double* a_row, int nA, double* b_row, int nB, long bs, int npad, int n) {
+    const int nb = nA > nB ? nA : nB;
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(k_const_rows, dim3((npad + 255) / 256, nb), dim3(256), 0, st, a_row, nA, b_row, nB, bs, npad, n);
+}
+
 __global__ __launch_bounds__(256) void k_glue(GlueArgs g) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     kernarg_warm<(int)sizeof(GlueArgs) + 64>();

@@ -191,6 +191,7 @@ int mm_prep_dt(int D);   // the operand kernel's instantiation (DT >= D) for thi
 __host__ __device__ constexpr bool mm_vsep(int D) { return (D + 2) % 4 == 1; }
 __host__ __device__ constexpr int mm_kp(int D) { return mm_vsep(D) ? D + 1 : (D + 2 + 3) / 4 * 4; }
 void launch_stamp(hipStream_t st, unsigned long long* dbg, int slot);
+void launch_const_rows(hipStream_t st, double* a_row, int nA, double* b_row, int nB, long bs, int npad, int n);   // glue.hip: valid-mask rows of the operand blocks
 // reverse pass of one moment-matching step (single rank, D <= 32; the step's prep kernel must precede it on st):
 // scratch: rowmom [P][njs][16 ceil((D + 1) / 16)][npad], cpart [P - E][nrb][npad] (njs, nrb from mm_bwd_geometry) and
 // part [P][mm_bwd_rc][1 + D + D*D] + [E][mm_bwd_rc][D*D + 2D + 1]; bars = (Mbar | Sbar | Vbar) on the device,

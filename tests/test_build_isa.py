@@ -81,3 +81,44 @@ def test_the_scanners_flag_the_two_patterns_they_guard_against(tmp_path):
     assert run("mfma_overlap_check.py", overlap) == 1
     assert run("mfma_hazard_check.py", early) == 1
     assert run("mfma_overlap_check.py", fine) == 0 and run("mfma_hazard_check.py", fine) == 0
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("unit", UNITS)
+def test_kernarg_warm_stays_inside_the_kernel_argument_segment(unit, assembly):
+    """csrc/common.h: kernarg_warm<BYTES> requests every 64-byte line of the kernel-argument segment with one s_load_dword each
+    (one scalar-cache round trip instead of one per field) -- up to a hand-written byte count.  The count must not run past
+    the segment the code object declares (.kernarg_segment_size: explicit + hidden arguments), whatever the code-object
+    version or a changed argument list make of it."""
+    import re
+    rc, asm, err = assembly[unit]
+    assert rc == 0, err[-2000:]
+    text = open(asm).read()
+    seg = {m.group(2): int(m.group(1)) for m in re.finditer(r"\.kernarg_segment_size:\s*(\d+)(?:.|\n)*?\.name:\s*(\S+)", text)}
+    if not seg:   # (metadata order: .name before .kernarg_segment_size in some versions)
+        seg = {m.group(1): int(m.group(2)) for m in re.finditer(r"\.name:\s*(\S+)(?:.|\n)*?\.kernarg_segment_size:\s*(\d+)", text)}
+    assert seg, "no kernel metadata found in " + asm
+    func, inasm, worst, checked, skip = None, False, {}, 0, False
+    for line in text.splitlines():
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            func = m.group(1)
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            inasm = True
+        elif t.startswith(";;#ASMEND"):
+            inasm = False
+        elif inasm and t.startswith(".if"):          # the assembler's own conditionals around the lines past the segment
+            c = re.match(r"\.if\s+(0x[0-9a-fA-F]+|\d+)\s*>\s*(0x[0-9a-fA-F]+|\d+)", t)
+            skip = bool(c) and not int(c.group(1), 0) > int(c.group(2), 0)
+        elif inasm and t.startswith(".endif"):
+            skip = False
+        elif inasm and func in seg and not skip:
+            m = re.match(r"s_load_dword\s+s\d+,\s*s\[\d+:\d+\],\s*(0x[0-9a-fA-F]+|\d+)", t)
+            if m:
+                worst[func] = max(worst.get(func, 0), int(m.group(1), 0) + 4)
+    for f, end in worst.items():
+        checked += 1
+        assert end <= seg[f], "%s: kernarg_warm reads up to byte %d of a %d-byte kernel-argument segment" % (f, end, seg[f])
+    if unit in ("pair", "bwd", "linalg", "prep_dt_a"):
+        assert checked > 0, "no kernarg_warm found in " + unit

@@ -2379,3 +2379,59 @@ def test_device_reverse_chain_matches_the_host_chain(N, E, U, H):
         np.testing.assert_allclose(d[1], h[1], rtol=1e-10, atol=1e-12 * scale)
         np.testing.assert_allclose(d[2], h[2], rtol=1e-10, atol=1e-12 * scale)
     assert not np.allclose(out[1][0][0][1], out[1][1][0][1])                    # the seeds do enter
+
+
+def test_a_failed_factorisation_leaves_no_usable_factor():
+    """A non-positive pivot is not patched up: NaN runs through L, L^-1, iK and beta (launch_potrf's contract, csrc/common.h).
+    What protects callers is the status: the factorisation reports PILCO_E_NOT_PD with the output's index (the reference
+    raises InvalidArgumentError from tf.linalg.cholesky, tests/test_cascade.py:22) and the slot holds NO factor afterwards --
+    a rollout on it fails with PILCO_E_STATE instead of returning NaN; a good factorisation after it is used as usual."""
+    from pilco_amd import _lib
+    c = synthetic.config_c2(N=90, D=4, E=3, noise=1e-2, seed=3, control_dim=1)
+    cx = _lib.Context(device=0)
+    try:
+        Xd = np.vstack([c["X"][:45], c["X"][:45]])          # duplicated inputs, zero noise: K singular
+        cx.gp_set_data(0, Xd, np.vstack([c["Y"][:45], c["Y"][:45]]))
+        cx.gp_set_hyp(0, c["lengthscales"], c["variance"], np.zeros(3))
+        with pytest.raises(_lib.NotPositiveDefiniteError):
+            cx.gp_factorize(0)
+        pol = dict(kind=_lib.POLICY_LINEAR, state_dim=3, control_dim=1, W=c["W"], b=c["b"].ravel(), max_action=1.0, squash=True)
+        rw = [dict(kind=_lib.REWARD_EXPONENTIAL, coef=1.0, W=np.eye(3), t=np.zeros(3))]
+        for call in (lambda: cx.rollout(pol, rw, c["m0"], 0.05 * np.eye(3), 3),
+                     lambda: cx.rollout_grad(pol, rw, c["m0"], 0.05 * np.eye(3), 3),
+                     lambda: cx.gp_predict(0, np.zeros((1, 4)), 0.1 * np.eye(4), 4, 3)):
+            with pytest.raises(_lib.PilcoError) as ei:
+                call()
+            assert not isinstance(ei.value, _lib.NotPositiveDefiniteError) and "factoris" in str(ei.value)
+        cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"])
+        cx.gp_factorize(0)
+        out = cx.rollout(pol, rw, c["m0"], 0.05 * np.eye(3), 3)
+        assert all(np.all(np.isfinite(np.asarray(o))) for o in out)
+    finally:
+        cx.close()
+
+
+def test_factorisation_never_reads_the_tiles_of_linv_it_does_not_write():
+    """The exact factorisation does not zero L^-1 (its consumers never read above the diagonal tiles: 12 us at C2).  Guarded here:
+    with every factorisation buffer filled with NaN beforehand the factors come out finite and BIT-IDENTICAL to those of a
+    fresh context (mgpr.py:81-89)."""
+    from pilco_amd import _lib
+    for N in (100, 257, 700):
+        c = synthetic.config_c2(N=N, D=5, E=3, noise=1e-2, seed=17, control_dim=1)
+        ref = _lib.Context(device=0)
+        cx = _lib.Context(device=0)
+        try:
+            for q in (ref, cx):
+                q.gp_set_data(0, c["X"], c["Y"])
+                q.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"])
+                q.gp_factorize(0)
+            iK0, b0 = ref.gp_get_factors(0, 3)
+            for which in (0, 1, 2):
+                cx.debug_poison(0, which)
+            cx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"])   # invalidates: the next call factorises again
+            cx.gp_factorize(0)
+            iK1, b1 = cx.gp_get_factors(0, 3)
+            assert np.all(np.isfinite(iK1)) and np.all(np.isfinite(b1))
+            assert np.array_equal(iK0, iK1) and np.array_equal(b0, b1)
+        finally:
+            ref.close(); cx.close()
