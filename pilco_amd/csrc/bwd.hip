@@ -1,5 +1,6 @@
 // Reverse pass of one moment-matching step: k_mm_bwd_pair / _post / _fin.
 #include "mm_device.h"
+#include "rev_local.h"
 
 namespace pilco {
 
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
                             // the column side beta_a,i only (one multiply and one FMA instead of two multiplies and an
                             // add); the epilogue / k_mm_bwd_post apply the missing factor per row / per column
                             // (beta_b,j rides in the moment product's column operand a2, scaled once per column step)
-                            const double l = fexp(e[r], tab);
+                            const double l = fexp_to_mfma(e[r], tab);   // (straight into the moment product's A operand: mm_device.h)
                             wl[r] = l;
                             csum[r] = fma(brow[rt], l, csum[r]);
                         } else {
@@ -337,17 +338,6 @@ __global__ __launch_bounds__(256, (KC <= 4 && NMT == 1) ? 4 : BWD_LBW) void k_mm
                     for (int m = 0; m < NMT; ++m)
     #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[rt][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[r], a2[m][r], acc[rt][m], 0, 0, 0);
-                }
-                // v_j must outlive BOTH row tiles' chains (third MFMA defect of this toolchain, round 6): it is the SrcC of each
-                // chain's first MFMA, and once dead after the last of them the compiler lets that chain accumulate IN PLACE --
-                // an f64 MFMA that writes the registers the MFMA issued one or two slots before it is still reading as its
-                // SrcC.  The hardware does not interlock that write-after-read; with nothing between the two (the quartile by
-                // a signed division happened to move two v_mul_f64 away from there) the first chain picked up the second's
-                // partial results: wrong, run-to-run different sums in the K = 8 instantiation.  Held alive here, the second
-                // chain gets a destination of its own; tools/mfma_hazard_check.py now flags the pattern.
-                if (VSEP) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) MFMA_KEEP_ALIVE(vj[r]);
                 }
                 if (MODE == 1 && j0 + 16 < jend) ik_request(j0 + 16);   // (every use of this step's tile is behind us)
                 // column sums over the wave's 16 lanes of a DPP row, through a per-wave LDS scratch instead of four
@@ -629,14 +619,17 @@ constexpr int JAC_MT = 8;   // row tiles: D1 (D1 + 1) / 2 <= 128 pairs (D <= 14)
 __device__ void bwd_mean_moments_mfma(const MMModel& md, const double* __restrict__ in_m, const double* __restrict__ head, int a, int rc,
                                       int nrc, double* __restrict__ mpart, double* sm) {
     const int D = md.D, D1 = D + 1, npad = md.npad, t = threadIdx.x, lane = t & 63, w = t >> 6, lr = lane >> 4, lc = lane & 15;
-    const int nI = D * D, LD = D1 | 1, NS = D1 * (D1 + 1) * (D1 + 2) / 6, NPAIR = D1 * (D1 + 1) / 2, ntile = (NPAIR + 15) / 16;
-    double* T = sm;                 // [D][D]
-    double* zs = T + nI;            // [64][LD]   zeta | 1
+    const int nI = D * D, LD = 17, NS = D1 * (D1 + 1) * (D1 + 2) / 6, NPAIR = D1 * (D1 + 1) / 2, ntile = (NPAIR + 15) / 16;
+    double* T = sm;                 // [D][16]    rows zero-padded: the quadratic form runs over 16 columns without a condition
+    double* zs = T + 16 * 16;       // [64][17]   zeta (zeros past D) | 1 at column D   (odd row length: conflict-free column reads)
     double* lv = zs + 64 * LD;      // [64]
     double* qp = lv + 64;           // [4][64]  partial quadratic forms; later [4][256] for the waves' tiles
-    const double* hd = head + (long)a * (nI + D + 2);
     int* ptab = (int*)(qp + 4 * 256);   // [16 JAC_MT] pair row -> d | e << 8, or -1
-    for (int e = t; e < nI; e += 256) T[e] = hd[e];
+    const double* hd = head + (long)a * (nI + D + 2);
+    {
+        const int r = t >> 4, c = t & 15;   // 256 threads: one entry of the padded [16][16] each
+        T[t] = (r < D && c < D) ? hd[r * D + c] : 0.0;
+    }
     if (t < 16 * JAC_MT) {
         int d = 0;
         while ((d + 1) * (d + 2) / 2 <= t) ++d;
@@ -656,7 +649,8 @@ __device__ void bwd_mean_moments_mfma(const MMModel& md, const double* __restric
     for (int m = 0; m < JAC_MT; ++m) C[m] = d4{0.0, 0.0, 0.0, 0.0};
     __syncthreads();
     // (requests are UNCONDITIONAL, from clamped addresses -- the padding of Pt / beta is there to be read.  Requesting the NEXT
-    // block's coordinates a block ahead was tried: no faster, 32 more registers)
+    // block's coordinates a block ahead was tried: no faster, 32 more registers.  No run-time index into the register copy of
+    // the point either: `pv[r]` with the wave's row r compiled into a ladder of 14 branches per row -- 8 000 cycles per block)
     const double* beta_a = md.beta + mm_beta_row(md, a) * npad;
     double mloc[16];
 #pragma unroll
@@ -670,25 +664,19 @@ __device__ void bwd_mean_moments_mfma(const MMModel& md, const double* __restric
         const double bcur = beta_a[i];
 #pragma unroll
         for (int d = 0; d < 16; ++d) pv[d] = (d < D && i < md.n) ? pv[d] - mloc[d] : 0.0;
+        if (w == 0) {
+#pragma unroll
+            for (int d = 0; d < 16; ++d) zs[lane * LD + d] = (d == D) ? 1.0 : pv[d];   // (d == D: a select, not a branch)
+        }
+        __syncthreads();
         double part = 0.0;
         for (int r = w; r < D; r += 4) {
             double tz = 0.0;
 #pragma unroll
-            for (int c = 0; c < 16; ++c)
-                if (c < D) tz = fma(T[r * D + c], pv[c], tz);
-            double zr = 0.0;
-#pragma unroll
-            for (int c = 0; c < 16; ++c)
-                if (c == r) zr = pv[c];
-            part = fma(zr, tz, part);
+            for (int c = 0; c < 16; ++c) tz = fma(T[r * 16 + c], pv[c], tz);
+            part = fma(zs[lane * LD + r], tz, part);
         }
         qp[w * 64 + lane] = part;
-        if (w == 0) {
-#pragma unroll
-            for (int d = 0; d < 16; ++d)
-                if (d < D) zs[lane * LD + d] = pv[d];
-            zs[lane * LD + D] = 1.0;
-        }
         __syncthreads();
         if (w == 0) {
             const double quad = (qp[lane] + qp[64 + lane]) + (qp[128 + lane] + qp[192 + lane]);
@@ -1194,8 +1182,12 @@ __device__ __forceinline__ void jac_pair_record(int D, const double* Pm, const d
 
 __global__ __launch_bounds__(256) void k_mm_jac_fin(MMModel md, MMWork wk, const double* __restrict__ part, int nrc,
                                                    const double* __restrict__ head, const double* __restrict__ mpart,
-                                                   double* __restrict__ jrec, long jstride, BwdBatch bb, int pl0) {
+                                                   double* __restrict__ jrec, long jstride, BwdBatch bb, int pl0, RevLocalArgs rl) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (rl.loc && (int)blockIdx.x == (int)gridDim.x - 1) {   // the extra workgroup of the step (device reverse chain, rev_local.h)
+        rev_local_step(rl.n, rl.rs, rl.E, rl.U, rl.traj, rl.Wp, rl.bp, rl.maxact, rl.loc, blockIdx.y, sm);
+        return;
+    }
     const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x + pl0, z = blockIdx.y;   // pl0 = PL: the output records only (the fused finish has written the pairs')
     const int nI = D * D, rec = 1 + D + nI, NT2 = D * (D + 1) / 2, recp = 1 + D + NT2;
     part += (long)z * bb.part;
@@ -1339,8 +1331,10 @@ void launch_mm_sweep(hipStream_t st, const MMModel& md, const MMWork& wk, double
 // nothing of the forward chain waits for them, so they run at throughput instead of paying their latency per step.
 // Per-step arrays: rowmom / cpart / head / part advance by the sizes above, in_m is the head of the step's tape record.
 void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, int H, const double* rowmom, const double* cpart,
-                          double* head, double* part, const double* tape, size_t tape_stride, double* jrec, int small_nch) {
+                          double* head, double* part, const double* tape, size_t tape_stride, double* jrec, int small_nch, const RevLocalArgs* rlp) {
     if (H <= 0) return;
+    RevLocalArgs rl{};
+    if (rlp) rl = *rlp;
     const int P = wk.PL, E = md.E, D = md.D;
     int njs, nrb;
     mm_bwd_geometry(md.npad, md.E * (md.E + 1) / 2, &njs, &nrb);   // (the model's pairs, not this rank's: the split of a pair's sums is the same on every rank count)
@@ -1363,7 +1357,8 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
         hipLaunchKernelGGL(k_mm_bwd_head, dim3(E + P, H), dim3(256), sizeof(double) * ((size_t)4 * nI + D), st, md, wk, head, bb.head, tape + D,
                            (long)tape_stride);
     const size_t lds_mean = (size_t)nI + 64 * LD1 + 64 + NS / 2 + 2;
-    const size_t lds_fin = sizeof(double) * std::max((size_t)4 * nI + 4 * D + 8, (size_t)3 * nI + NS + D + 2 * nI * D);
+    const size_t lds_fin = sizeof(double) * std::max(std::max((size_t)4 * nI + 4 * D + 8, (size_t)3 * nI + NS + D + 2 * nI * D),
+                                                     rl.loc ? rev_local_lds_doubles(rl.E, rl.U) : (size_t)0);
     const long jstride = (long)mm_jac_rec_size(D, E, P);
     static const bool split_finish = getenv("PILCO_JAC_SPLIT_FINISH") != nullptr;   // (A/B: the rounds 3-5 finish, chunk-workgroups + partials in memory)
     if (!split_finish) {
@@ -1371,16 +1366,16 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
         // LDS, scattered stores) cost as much as four 64-point blocks -- 8 chunks of 2 blocks (the split finish's cut) spent
         // 22 us per workgroup at three per CU
         const int nrcm = std::max(1, std::min(2, md.npad / 64));
-        const size_t lds_rec = sizeof(double) * std::max((size_t)6 * 256 + (1 + D + nI) + 3 * nI + D + 2 + md.npad, (size_t)nI + 64 * LD1 + 64 + 4 * 256 + 8 * JAC_MT + 2);
+        const size_t lds_rec = sizeof(double) * std::max((size_t)6 * 256 + (1 + D + nI) + 3 * nI + D + 2 + md.npad, (size_t)256 + 64 * 17 + 64 + 4 * 256 + 8 * JAC_MT + 2);
         hipLaunchKernelGGL(k_mm_jac_rec, dim3(P + E * nrcm, H), dim3(256), lds_rec, st, md, wk, rowmom, cpart, njs, nrb, nrcm, head, mpart, jrec,
                            jstride, bb);
-        hipLaunchKernelGGL(k_mm_jac_fin, dim3(E, H), dim3(256), lds_fin, st, md, wk, part, nrcm, head, mpart, jrec, jstride, bb, P);
+        hipLaunchKernelGGL(k_mm_jac_fin, dim3(E + (rl.loc ? 1 : 0), H), dim3(256), lds_fin, st, md, wk, part, nrcm, head, mpart, jrec, jstride, bb, P, rl);
         return;
     }
     const size_t lds_post = sizeof(double) * std::max((size_t)2 * 256 + 4 * 256, lds_mean);
     hipLaunchKernelGGL((k_mm_bwd_post<1, 1>), dim3(P + E, nrc, H), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
                        head, mpart, 1, bb);   // (the Jacobian tape serves D <= 14)
-    hipLaunchKernelGGL(k_mm_jac_fin, dim3(P + E, H), dim3(256), lds_fin, st, md, wk, part, nrc, head, mpart, jrec, jstride, bb, 0);
+    hipLaunchKernelGGL(k_mm_jac_fin, dim3(P + E + (rl.loc ? 1 : 0), H), dim3(256), lds_fin, st, md, wk, part, nrc, head, mpart, jrec, jstride, bb, 0, rl);
 }
 
 // Pg: the pairs of the WHOLE model, E (E + 1) / 2 -- never the local count of a rank: the column split decides how a pair's

@@ -211,6 +211,24 @@ __device__ __forceinline__ double fexp(double x, const double* __restrict__ tab)
     const double tv = tab[__double2loint(t) & (FEXP_TN - 1)];
     return fexp_finish(tv, fexp_poly(x, t), t);
 }
+// ... for a result that goes STRAIGHT into an MFMA operand.  gfx950 does not interlock "VALU writes a VGPR -> an MFMA reads
+// it as SrcA / SrcB": the MFMA must come at least three issue slots behind the write (measured: tools/ubench_srcc_war.hip --
+// next slot and one s_nop 0 read the OLD register, s_nop 1 is enough).  hipcc leaves those wait states behind its own VALU
+// instructions but NOT behind an inline-asm statement: with the exponent insertion written as asm (fexp_finish) the moment
+// product of the reverse sweep's off-diagonal pairs read a weight from before its exponent went in whenever the scheduler put
+// the MFMA within two slots -- round 5's "wrong, run-to-run different sums behind a division" (the division only moved the
+// schedule), and every instantiation's turn sooner or later.  Here the insertion is C: the same single v_lshl_add_u32, an
+// instruction the compiler's hazard recognizer sees.  tools/mfma_hazard_check.py flags the pattern.
+__device__ __forceinline__ double fexp_to_mfma(double x, const double* __restrict__ tab) {
+    x = fexp_clamp(x);
+    const double t = fexp_t(x);
+    const double tv = tab[__double2loint(t) & (FEXP_TN - 1)];
+    const double pm1 = fexp_poly(x, t);
+    const double res = fma(tv, pm1, tv);
+    const int lo = __double2loint(t) & ~(FEXP_TN - 1);
+    const int hi = __double2hiint(res) + (lo << (20 - FEXP_TB));   // exponent += n >> FEXP_TB
+    return __hiloint2double(hi, __double2loint(res));
+}
 
 // Pivoted Gauss-Jordan on an n x nc augmented matrix held in LDS (row-major,
 // ld = nc), ping-ponging between two buffers: one barrier per pivot step.

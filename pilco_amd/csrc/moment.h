@@ -210,7 +210,8 @@ void launch_mm_sweep(hipStream_t st, const MMModel& md, const MMWork& wk, double
 // small_nch > 0: the steps ran as the one-launch small step (chunks per pair = small_nch): gpart holds two blocks per
 // chunk-workgroup, cpart is unused and the inverses (head) are made here
 void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, int H, const double* rowmom, const double* cpart,
-                          double* head, double* part, const double* tape, size_t tape_stride, double* jrec, int small_nch = 0);
+                          double* head, double* part, const double* tape, size_t tape_stride, double* jrec, int small_nch = 0,
+                          const struct RevLocalArgs* rl = nullptr);   // rl: the reverse chain's per-step local quantities ride in the last launch (one more workgroup per step)
 size_t mm_jac_rec_size(int D, int E, int P);
 size_t mm_jac_part_size(int D, int E, int P, int npad);
 size_t mm_jac_rowmom_size(int npad, int P);
@@ -224,6 +225,12 @@ int mm_bwd_rc(int npad);
 // The reverse chain of the policy gradient on the device (rev.hip).
 struct RevRewards {
     RewardDev rw[MAX_REWARD_TERMS];
+};
+struct RevLocalArgs {       // k_rev_local / the extra workgroup of k_mm_jac_fin: trajectory-only quantities of every step (rev_local.h)
+    int n, E, U;
+    RevRewards rs;
+    const double *traj, *Wp, *bp, *maxact;
+    double* loc;            // [H][rev_loc_doubles]; nullptr: nothing to do
 };
 struct RevArgs {
     int E, U, D, H, P;      // P = E (E + 1) / 2: the pairs of the WHOLE model
@@ -239,14 +246,15 @@ struct RevArgs {
     const double* loc;      // [H][rev_loc_doubles]  (k_rev_local: reward gradients, controller / squash forward quantities)
     const double* seeds;    // [H + 1][E + E*E] cotangent seeds of the caller's objective, or nullptr
     const double* Wp;       // LinearController W (U,E)
+    const double* reward_dev;   // the rollout's reward on the device: handed out with the gradient (out[..]) instead of a copy of its own in front of the finish
     double* amat;           // [H][rev_mat_doubles]: every step's reverse map [A; B] by columns | r | flag  (k_rev_step -> k_rev_chain)
-    double* out;            // [U*E + U + 1 + E + E(E+1)/2]: dW | db | status (0 fine) | d / d (m_0, S_0 packed)   (device-visible)
+    double* out;            // [U*E + U + 1 + E + E(E+1)/2 + 1]: dW | db | status (0 fine) | d / d (m_0, S_0 packed) | reward   (device-visible)
 };
 bool rev_chain_supported(int E, int U, int D);
 size_t rev_loc_doubles(int E, int U);
 size_t rev_mat_doubles(int E, int U, int D);
-void launch_rev_local(hipStream_t st, int n, const RewardDev* rw, int E, int U, int H, const double* traj, const double* Wp, const double* bp,
-                      const double* maxact, double* loc);
+RevLocalArgs rev_local_args(int n, const RewardDev* rw, int E, int U, const double* traj, const double* Wp, const double* bp, const double* maxact,
+                            double* loc);
 void launch_rev_chain(hipStream_t st, const RevArgs& a);
 int mm_exp_table_size();   // entries of the 2^(j/n) table the pair kernels were built for
 int launch_selftest_mfma(hipStream_t st, double* dbuf, double* hbuf, const double* exp_tab);

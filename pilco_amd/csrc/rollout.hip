@@ -266,16 +266,16 @@ static int jac_small_chunks(pilco_ctx* ctx, const RolloutPlan& plan, int H) {
     if (!fused_heads_fit(ctx, plan)) return 0;
     return s.wk.NCH * small_col_splits(ctx, s, plan.g.n_rewards > 0 && !MM_ABL(s.wk, 8));
 }
-static void jac_finish_range(pilco_ctx* ctx, const RolloutPlan& plan, int t0, int t1, hipStream_t st = nullptr) {
+static void jac_finish_range(pilco_ctx* ctx, const RolloutPlan& plan, int t0, int t1, const RevLocalArgs* rl = nullptr) {
     Slot& s = ctx->slot[0];
-    if (!st) st = ctx->st;
+    hipStream_t st = ctx->st;
     const int D = plan.D, E = plan.E, P = s.wk.PL;
     const size_t TS = (size_t)D + D * D + (size_t)E * D + E + (size_t)E * E + (size_t)D * E;
     const size_t o = (size_t)t0;
     launch_mm_jac_finish(st, model_of(s), s.wk, t1 - t0, s.jac_rowmom.p + o * mm_jac_rowmom_size(s.npad, P),
                          s.jac_cpart.p + o * mm_jac_cpart_size(s.npad, P, s.wk.EL), s.jac_head.p + o * mm_jac_head_size(D, E, P),
                          s.jac_part.p + o * mm_jac_part_size(D, E, P, s.npad), plan.g.tape + o * TS, TS, plan.jrec + o * plan.jstride,
-                         plan.jsmall);
+                         plan.jsmall, rl);
 }
 int enqueue_rollout(pilco_ctx* ctx, RolloutPlan& plan, int H, std::vector<hipEvent_t>* pair_ev) {
     return enqueue_rollout_steps(ctx, plan, H, pair_ev);
@@ -1147,7 +1147,7 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
     const size_t SEd = (size_t)E + (size_t)E * E;
     if (dev) {
         dev->n_seeds = (size_t)(H + 1) * SEd;
-        dev->n_out = (size_t)plan.U * E + plan.U + 1 + SEd;
+        dev->n_out = (size_t)plan.U * E + plan.U + 1 + SEd + 2;
     }
     const size_t need = dev ? NTJ + 8 + dev->n_seeds + dev->n_out + 8
                             : NTJ + (size_t)H * TS + (size_t)H * JSg + 8 + (sharded ? (size_t)W * gblk : 0);
@@ -1178,7 +1178,7 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
         if (r != PILCO_OK) return r;
         break;
     }
-    HIPCHK(hipMemcpyAsync(h_misc, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
+    if (!dev) HIPCHK(hipMemcpyAsync(h_misc, plan.g.reward, sizeof(double), hipMemcpyDeviceToHost, ctx->st));
     if (dev) {
         // ---- the reverse chain on the device (rev.hip): nothing but the reward, the gradient -- and, for a caller with
         // cotangent seeds, the trajectory -- crosses to the host
@@ -1192,8 +1192,10 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
         ra.E = E; ra.U = plan.U; ra.D = D; ra.H = H; ra.P = Pall;
         ra.W = 1; ra.gblk = 0; ra.gstep = (long)JS; ra.out_off = (long)P * recp;
         ra.jrec = ctx->jrec.p;
+        ENSURE(ctx->revloc, std::max<size_t>(1, (size_t)H * rev_loc_doubles(E, plan.U)));
+        const RevLocalArgs rl = rev_local_args(plan.g.n_rewards, plan.g.rw, E, plan.U, ctx->traj.p, plan.g.W, plan.g.b, plan.g.maxact, ctx->revloc.p);
         if (H > 0) {
-            jac_finish_range(ctx, plan, 0, H);
+            jac_finish_range(ctx, plan, 0, H, &rl);   // (the trajectory-only quantities of the chain ride in its last launch)
             if (sharded) {   // every rank's pair records, all-gathered ONCE; the chain reads them where they land
                 ENSURE(ctx->jgath, (size_t)(W + 1) * gblk);
                 double* own = ctx->jgath.p + (size_t)W * gblk;
@@ -1221,8 +1223,6 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
                 ra.W = W; ra.gblk = (long)gblk; ra.gstep = (long)gstep; ra.out_off = (long)PLcap * recp;
             }
         }
-        ENSURE(ctx->revloc, std::max<size_t>(1, (size_t)H * rev_loc_doubles(E, plan.U)));
-        launch_rev_local(ctx->st, plan.g.n_rewards, plan.g.rw, E, plan.U, H, ctx->traj.p, plan.g.W, plan.g.b, plan.g.maxact, ctx->revloc.p);
         ra.traj = ctx->traj.p;
         ra.tape = ctx->tape.p;
         ra.TS = (long)TS;
@@ -1230,13 +1230,14 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
         ENSURE(ctx->revmat, std::max<size_t>(1, (size_t)H * rev_mat_doubles(E, plan.U, D)));
         ra.amat = ctx->revmat.p;
         ra.seeds = nullptr;
+        ra.reward_dev = plan.g.reward;
         ra.Wp = plan.g.W;
         dev->h_seeds = h_misc + 8;
         double* h_out = dev->h_seeds + dev->n_seeds;
         ra.out = h_out;
         dev->h_out = h_out;
         dev->h_traj = h_traj;
-        dev->h_reward = h_misc;
+        dev->h_reward = h_out + ((size_t)plan.U * E + plan.U) + 1 + (size_t)(E + Pall);   // (written by the chain kernel)
         if (!dev->seeds) launch_rev_chain(ctx->st, ra);
         HIPCHK(hipGetLastError());
         return PILCO_OK;

@@ -4,10 +4,11 @@ Round 2 found two ways in which hipcc (ROCm 7.2) miscompiles chains of v_mfma_f6
   * the destination registers of an MFMA with a constant-zero accumulator may overlap a dying A / B source register;
   * the wait states between an MFMA and a VALU read of its result are missing in some instantiations (the reverse sweep
     read the last destination pair one slot after the MFMA and got the accumulator from before the last k-step);
-  * an MFMA may be given as its destination the registers the MFMA issued one or two slots earlier is still reading as
-    its SrcC (two accumulation chains that start from the same registers, the second running in place once they are
-    dead): the first chain picks up the second's partial results (the reverse sweep's K = 8 instantiation, run-to-run
-    different sums whenever nothing happened to be scheduled between the two).
+  * gfx950 does not interlock "VALU writes a VGPR -> an MFMA reads it as a source" (three issue slots are needed, measured by
+    tools/ubench_srcc_war.hip), and hipcc pads only behind its OWN VALU instructions: behind a VALU instruction inside an
+    inline-asm statement the MFMA may come too early and read the old register (the table exp's exponent insertion in front
+    of the reverse sweep's moment product: wrong, run-to-run different sums in whichever instantiation the scheduler put
+    the two within two slots of each other -- round 5's unexplained K = 8 failure).
 csrc/mm_device.h carries the source-level counter-measures (MFMA_KEEP_ALIVE, MFMA_RESULT_FENCE); this test compiles the
 MFMA-carrying translation units to assembly and scans EVERY instantiation with tools/mfma_overlap_check.py and
 tools/mfma_hazard_check.py, so a compiler or source change that re-opens either hole fails here, not on the GPU."""
@@ -69,13 +70,13 @@ def test_the_scanners_flag_the_two_patterns_they_guard_against(tmp_path):
     fine = tmp_path / "fine.s"
     fine.write_text("_Zok:\n\tv_mfma_f64_16x16x4_f64 v[108:115], v[178:179], v[96:97], v[108:115]\n\ts_nop 10\n"
                     "\tv_max_f64 v[194:195], v[114:115], s[68:69]\n")
-    # round 6: the second chain's first MFMA writes the first chain's SrcC (hipcc's code for the K = 8 sweep with nothing in between)
-    war = tmp_path / "war.s"
-    war.write_text("_Zbad:\n\tv_mfma_f64_16x16x4_f64 v[88:95], v[26:27], v[80:81], v[18:25]\n\ts_mov_b32 s76, s74\n"
-                   "\tv_mfma_f64_16x16x4_f64 v[18:25], v[26:27], v[84:85], v[18:25]\n\ts_nop 10\n\ts_nop 10\n")
-    war_ok = tmp_path / "war_ok.s"   # ... and the same chains with destinations of their own
-    war_ok.write_text("_Zok:\n\tv_mfma_f64_16x16x4_f64 v[88:95], v[26:27], v[80:81], v[18:25]\n\ts_mov_b32 s76, s74\n"
-                      "\tv_mfma_f64_16x16x4_f64 v[96:103], v[26:27], v[84:85], v[18:25]\n\ts_nop 10\n\ts_nop 10\n")
+    # round 6: an inline-asm VALU write one instruction in front of the MFMA that reads the register (hipcc's code for the sweep)
+    war = tmp_path / "asmw.s"
+    war.write_text("_Zbad:\n\t;;#ASMSTART\n\tv_lshl_add_u32 v91, v42, 12, v91\n\t;;#ASMEND\n\tv_mov_b64_e32 v[48:49], v[40:41]\n"
+                   "\tv_mfma_f64_16x16x4_f64 v[18:25], v[90:91], v[140:141], v[18:25]\n\ts_nop 10\n\ts_nop 10\n")
+    war_ok = tmp_path / "asmw_ok.s"   # ... and with the wait states in between
+    war_ok.write_text("_Zok:\n\t;;#ASMSTART\n\tv_lshl_add_u32 v91, v42, 12, v91\n\t;;#ASMEND\n\ts_nop 1\n"
+                      "\tv_mfma_f64_16x16x4_f64 v[18:25], v[90:91], v[140:141], v[18:25]\n\ts_nop 10\n\ts_nop 10\n")
     run = lambda tool, f: subprocess.run([sys.executable, os.path.join(tools, tool), str(f)], capture_output=True, text=True).returncode
     assert run("mfma_hazard_check.py", war) == 1 and run("mfma_hazard_check.py", war_ok) == 0
     assert run("mfma_overlap_check.py", overlap) == 1

@@ -8,7 +8,7 @@ import re, sys
 from collections import Counter
 
 WAIT = 12
-WAR = 6   # slots an f64 MFMA's SrcC must stay untouched by a later MFMA's write (the failing build had 2, the working ones >= 6)
+ASMW = 3  # slots between an inline-asm VALU write and an MFMA that reads the register (s_nop 1 between them is the least that works)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 if "--wait" in sys.argv:
     WAIT = int(sys.argv[sys.argv.index("--wait") + 1])
@@ -24,12 +24,17 @@ total = Counter()
 for path in args:
     func = "?"
     pend = []   # (dst lo, dst regs, states since issue)
-    srcc = []   # (SrcC regs of an f64 MFMA, states since issue, accumulated in place)
+    asmw = []   # (registers written by a VALU instruction inside inline asm, states since)
+    inasm = False
     for line in open(path):
         m = re.match(r'^(_Z\w+):', line)
         if m:
-            func, pend, srcc = m.group(1), [], []
+            func, pend, asmw = m.group(1), [], []
         t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            inasm = True
+        elif t.startswith(";;#ASMEND"):
+            inasm = False
         if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
             continue
         op = t.split()[0]
@@ -40,23 +45,20 @@ for path in args:
         elif op.startswith("v_mfma"):
             d = regs(ops[0])
             srcs = set().union(*[regs(o) for o in ops[1:3]])   # A, B (an accumulator chain srcC == dst is fine)
-            # write-after-read on SrcC (round 6): an f64 MFMA whose destination overlaps the SrcC of an f64 MFMA issued
-            # fewer than WAR slots earlier -- unless that earlier MFMA accumulated in place (its own dst == its SrcC: then this
-            # one is the next link of the same chain, which the hardware orders)
-            if "f64" in op:
-                for sc, st2, inplace in srcc:
-                    if (d & sc) and not inplace and st2 < WAR:
-                        total[(func[:60], "srcC-war", 0, st2)] += 1
-                c_regs = regs(ops[3]) if len(ops) > 3 else set()
-                srcc = [(sc, st2 + 1, ip) for sc, st2, ip in srcc if st2 + 1 < 32]
-                if c_regs:
-                    srcc.append((c_regs, 1, c_regs == d))
+            # round 6: a VALU instruction inside an inline-asm statement wrote a source of this MFMA fewer than ASMW slots ago --
+            # gfx950 does not interlock VALU write -> MFMA SrcA / SrcB / SrcC read (tools/ubench_srcc_war.hip: the next slot and
+            # one s_nop 0 read the old value), and hipcc pads only behind its own instructions, not behind inline asm
+            allsrc = set().union(*[regs(o) for o in ops[1:4]])
+            for w_, st2 in asmw:
+                if (w_ & allsrc) and st2 < ASMW:
+                    total[(func[:60], "asm-valu", 0, st2)] += 1
             for lo, dr, st in pend:
                 if srcs & dr and st < WAIT:
                     total[(func[:60], "mfma-src", (min(srcs & dr) - lo) // 2, st)] += 1
             pend = [(lo, dr, st) for lo, dr, st in pend if not (d & dr)]
             pend.append((min(d), d, 0))
             pend = [(lo, dr, st + 1) for lo, dr, st in pend[:-1]] + [pend[-1]]
+            asmw = [(w_, st2 + 1) for w_, st2 in asmw if st2 + 1 < 8]
             continue
         elif op.startswith("v_") or op.startswith("ds_") or op.startswith("buffer_") or op.startswith("global_"):
             srcs = set().union(*[regs(o.split()[0]) for o in ops[1:]]) if len(ops) > 1 else set()
@@ -68,12 +70,14 @@ for path in args:
                 w = regs(ops[0].split()[0])
                 pend = [(lo, dr - w, st) for lo, dr, st in pend]
         pend = [(lo, dr, st + states) for lo, dr, st in pend if dr and st + states < 64]
-        srcc = [(sc, st2 + states, ip) for sc, st2, ip in srcc if st2 + states < 32]
+        if inasm and op.startswith("v_") and not op.startswith("v_mfma") and ops:
+            asmw.append((regs(ops[0].split()[0]), 0))
+        asmw = [(w_, st2 + states) for w_, st2 in asmw if st2 + states < 8]
 for (f, kind, pair, st), n in sorted(total.items()):
     print("%-62s %-8s dst pair %d read %2d slots after issue  x%d" % (f, kind, pair, st, n))
 # violation: a read of destination pair p fewer than 7 + p slots after the MFMA (the distances this compiler keeps where it
 # does insert the wait states)
-bad = [k for k in total if (k[1] == "srcC-war") or (k[1] != "srcC-war" and k[3] < 7 + k[2])]
+bad = [k for k in total if (k[1] == "asm-valu") or (k[1] != "asm-valu" and k[3] < 7 + k[2])]
 if bad:
     print("VIOLATIONS: %d" % len(bad))
 sys.exit(1 if bad else 0)
