@@ -660,8 +660,8 @@ __device__ void bwd_mean_moments_mfma(const MMModel& md, const double* __restric
         const int i = blk * 64 + lane;
         double pv[16];
 #pragma unroll
-        for (int d = 0; d < 16; ++d) pv[d] = md.Pt[(long)min(d, D - 1) * npad + i];
-        const double bcur = beta_a[i];
+        for (int d = 0; d < 16; ++d) pv[d] = md.Pt[(unsigned)(min(d, D - 1) * npad + i)];
+        const double bcur = beta_a[(unsigned)i];
 #pragma unroll
         for (int d = 0; d < 16; ++d) pv[d] = (d < D && i < md.n) ? pv[d] - mloc[d] : 0.0;
         if (w == 0) {
@@ -836,28 +836,7 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
     const double* g0 = gpart + (long)pl * nparts * (NB2 * 256);
     const double* cp = cpart + (long)pl * nrb * npad;
     const double* beta_b = md.beta + mm_beta_row(md, b) * npad;
-    if (cjl) {   // column coefficients c_j = (sum over the row blocks of cpart) * beta_b,j, all columns, one burst
-        for (int j0 = 0; j0 < npad; j0 += 4 * 256) {
-            double cv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {   // (unconditional requests from clamped addresses, see bwd_mean_moments_mfma)
-                const int j = j0 + q * 256 + t, jc = min(j, npad - 1);
-                const double cs = sum_strided<8>(cp + jc, npad, nrb), bj = beta_b[jc];
-                cv[q] = (j < md.n) ? cs * (diag ? 1.0 : bj) : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (j0 + q * 256 + t < npad) cjl[j0 + q * 256 + t] = cv[q];
-        }
-    }
-#pragma unroll
-    for (int blk = 0; blk < NB2; ++blk) {
-        const double v = cjl ? sum_strided<16>(g0 + (long)rc * (NB2 * 256) + blk * 256 + t, (long)nrc * (NB2 * 256), (nparts - rc + nrc - 1) / nrc)
-                             : sum_strided<4>(g0 + (long)rc * (NB2 * 256) + blk * 256 + t, (long)nrc * (NB2 * 256), (nparts - rc + nrc - 1) / nrc);
-        const int d = 16 * (blk / NMT) + ((t >> 4) & 3) + 4 * (t >> 6), e = 16 * (blk % NMT) + (t & 15);
-        Gs[d * GW + e] = v;
-    }
-    // (ii) the column side
+    // per-lane scale / shift of the column operand (requested first: everything below is independent of it)
     double wm[NMT], wi[NMT];
 #pragma unroll
     for (int m = 0; m < NMT; ++m) {
@@ -867,6 +846,49 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
         wm[m] = d < D ? imr : 0.0;
         wi[m] = 1.0 / (lb * lb);
     }
+    if (cjl && NMT == 1) {
+        // ONE memory round trip for the sweep's G blocks (up to 32 per thread) AND the column coefficients (nrb sums + beta for
+        // four columns per thread): a workgroup is a chain of memory latencies -- with the two bursts one behind the other,
+        // then four bursts of point coordinates, it was eight round trips of ~3 us under load (36 us per workgroup at three per CU)
+        double gq[32];
+        const int cntg = (nparts - rc + nrc - 1) / nrc;
+        const double* gb = g0 + (long)rc * 256 + t;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) gq[u] = gb[(unsigned)(min(u, cntg - 1) * nrc * 256)];   // (32-bit indices: base in SGPRs, one VALU op per address)
+        for (int j0 = 0; j0 < npad; j0 += 4 * 256) {   // column coefficients c_j = (sum over the row blocks of cpart) * beta_b,j
+            double cv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {   // (unconditional requests from clamped addresses, see bwd_mean_moments_mfma)
+                const int j = j0 + q * 256 + t, jc = min(j, npad - 1);
+                double cs = 0.0;
+                for (int k0 = 0; k0 < nrb; k0 += 8) {
+                    double cq[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) cq[u] = cp[(unsigned)(min(k0 + u, nrb - 1) * npad + jc)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) cs += (k0 + u < nrb) ? cq[u] : 0.0;
+                }
+                const double bj = beta_b[(unsigned)jc];
+                cv[q] = (j < md.n) ? cs * (diag ? 1.0 : bj) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (j0 + q * 256 + t < npad) cjl[j0 + q * 256 + t] = cv[q];
+        }
+        double v = 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v += (u < cntg) ? gq[u] : 0.0;          // fixed order
+        for (int u = 32; u < cntg; ++u) v += gb[(long)u * nrc * 256];        // (more column splits than the burst holds)
+        Gs[(((t >> 4) & 3) + 4 * (t >> 6)) * GW + (t & 15)] = v;
+    } else {
+#pragma unroll
+        for (int blk = 0; blk < NB2; ++blk) {
+            const double v = sum_strided<4>(g0 + (long)rc * (NB2 * 256) + blk * 256 + t, (long)nrc * (NB2 * 256), (nparts - rc + nrc - 1) / nrc);
+            const int d = 16 * (blk / NMT) + ((t >> 4) & 3) + 4 * (t >> 6), e = 16 * (blk % NMT) + (t & 15);
+            Gs[d * GW + e] = v;
+        }
+    }
+    // (ii) the column side
     d4 C[NMT][NMT];
 #pragma unroll
     for (int m1 = 0; m1 < NMT; ++m1)
@@ -874,7 +896,7 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
         for (int m2 = 0; m2 < NMT; ++m2) C[m1][m2] = d4{0.0, 0.0, 0.0, 0.0};
     if (cjl) {
         __syncthreads();   // (cjl complete)
-        constexpr int UB = NMT == 1 ? 4 : 1;   // 64-column blocks whose points are requested together
+        constexpr int UB = NMT == 1 ? 8 : 1;   // 64-column blocks whose points are requested together
         for (int blk0 = rc; blk0 < npad / 64; blk0 += nrc * UB) {
             double wt[UB][NMT][4], cj[UB][4];
 #pragma unroll
@@ -887,7 +909,7 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
 #pragma unroll
                     for (int m = 0; m < NMT; ++m) {
                         const int d = 16 * m + lc;
-                        const double pt = md.Pt[(long)min(d, D - 1) * npad + jc];
+                        const double pt = md.Pt[(unsigned)(min(d, D - 1) * npad + jc)];
                         wt[ub][m][r] = (valid && d < D) ? (pt - wm[m]) * wi[m] : ((valid && d == D) ? 1.0 : 0.0);
                     }
                 }
@@ -1150,8 +1172,9 @@ __device__ __forceinline__ void jac_pair_record(int D, const double* Pm, const d
     const double Nab = Iv[0];
     const double* Av = Iv + 1;
     const double* Im = Iv + 1 + D;
+    const int r0 = t / D, c0 = t - r0 * D;   // (D <= 14 on this path: D*D <= 256, one entry per thread, one division)
     for (int e = t; e < nI; e += 256) {
-        const int r = e / D, c = e - r * D;
+        const int r = r0, c = c0;
         double acc = 0.0;
         for (int k = 0; k < D; ++k) acc = fma(Pm[r * D + k], Im[k * D + c], acc);
         PI[e] = acc;
@@ -1160,7 +1183,7 @@ __device__ __forceinline__ void jac_pair_record(int D, const double* Pm, const d
     // G = rdet (P I P^T / 2 - N (P Lambda + Lambda P^T) / 4), then packed symmetric
     double* Gf = PI + nI;          // [D][D]
     for (int e = t; e < nI; e += 256) {
-        const int r = e / D, c = e - r * D;
+        const int r = r0, c = c0;
         double acc = 0.0;
         for (int k = 0; k < D; ++k) acc = fma(PI[r * D + k], Pm[c * D + k], acc);   // (P I P^T)[r][c]
         const double pl2 = Pm[r * D + c] * lam[c] + Pm[c * D + r] * lam[r];         // P Lambda + Lambda P^T
@@ -1169,7 +1192,7 @@ __device__ __forceinline__ void jac_pair_record(int D, const double* Pm, const d
     __syncthreads();
     if (t == 0) o[0] = Nab;
     for (int e = t; e < nI; e += 256) {
-        const int r = e / D, c = e - r * D;
+        const int r = r0, c = c0;
         if (r <= c) o[1 + D + c * (c + 1) / 2 + r] = 0.5 * (Gf[e] + Gf[c * D + r]);
     }
     if (t >= 256 - D) {
