@@ -541,80 +541,12 @@ __device__ __forceinline__ int tri3_any(int a, int b, int c) {
     return tri3(hi, a + b + c - hi - lo, lo);
 }
 int mm_jac_ns(int D) { return (D + 1) * (D + 2) * (D + 3) / 6; }
-constexpr int JAC_MAXA = 4;   // moment sums per thread: NS <= 4 * 256 (D <= 16)
-__device__ void bwd_mean_moments(const MMModel& md, const double* __restrict__ in_m, const double* __restrict__ head, int a, int rc,
-                                 int nrc, double* __restrict__ mpart, double* sm) {
-    const int D = md.D, D1 = D + 1, npad = md.npad, t = threadIdx.x;
-    const int nI = D * D, LD = D1 | 1, NS = D1 * (D1 + 1) * (D1 + 2) / 6;
-    double* T = sm;                 // [D][D]
-    double* zs = T + nI;            // [64][LD]   zeta | 1
-    double* lv = zs + 64 * LD;      // [64]
-    int* tri = (int*)(lv + 64);     // [NS] packed index triples
-    const double* hd = head + (long)a * (nI + D + 2);
-    for (int e = t; e < nI; e += 256) T[e] = hd[e];
-    if (t < D1) {
-        int off = t * (t + 1) * (t + 2) / 6;
-        for (int e = 0; e <= t; ++e)
-            for (int f = 0; f <= e; ++f) tri[off++] = t | (e << 8) | (f << 16);
-    }
-    __syncthreads();
-    int pk[JAC_MAXA];
-    double acc[JAC_MAXA];
-#pragma unroll
-    for (int k = 0; k < JAC_MAXA; ++k) {
-        const int idx = t + 256 * k;
-        pk[k] = idx < NS ? tri[idx] : -1;
-        acc[k] = 0.0;
-    }
-    for (int blk = rc; blk < npad / 64; blk += nrc) {
-        if (t < 64) {
-            const int i = blk * 64 + t;
-            double l = 0.0;
-            if (i < md.n) {
-                double quad = 0.0;
-                {
-                    double pv[16];
-#pragma unroll
-                    for (int d = 0; d < 16; ++d) pv[d] = (d < D) ? md.Pt[(long)d * npad + i] : 0.0;
-#pragma unroll
-                    for (int d = 0; d < 16; ++d)
-                        if (d < D) zs[t * LD + d] = pv[d] - in_m[d];
-                }
-                for (int r = 0; r < D; ++r) {
-                    double tz = 0.0;
-                    for (int c = 0; c < D; ++c) tz = fma(T[r * D + c], zs[t * LD + c], tz);
-                    quad = fma(zs[t * LD + r], tz, quad);
-                }
-                l = exp(-0.5 * quad) * md.beta[mm_beta_row(md, a) * npad + i];
-            } else {
-                for (int d = 0; d < D; ++d) zs[t * LD + d] = 0.0;
-            }
-            zs[t * LD + D] = 1.0;
-            lv[t] = l;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < JAC_MAXA; ++k)
-            if (pk[k] >= 0) {
-                const int d = pk[k] & 255, e = (pk[k] >> 8) & 255, f = pk[k] >> 16;
-                double a2 = acc[k];
-                _Pragma("unroll 4") for (int ii = 0; ii < 64; ++ii)
-                    a2 = fma(lv[ii] * zs[ii * LD + d], zs[ii * LD + e] * zs[ii * LD + f], a2);
-                acc[k] = a2;
-            }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int k = 0; k < JAC_MAXA; ++k)
-        if (pk[k] >= 0) mpart[((long)a * nrc + rc) * NS + t + 256 * k] = acc[k];
-}
-
-// The same moments on the matrix cores (round 6; the fused finish k_mm_jac_rec).  The VALU form above reads FOUR LDS words per
+// The moments on the matrix cores (round 6; the fused finish k_mm_jac_rec).  The VALU form of rounds 3-5 read FOUR LDS words per
 // multiply-add -- 9.3 M wave-wide LDS reads per rollout at C2u, 60 us of the LDS pipes of the whole chip and 145 us in practice.
 // As a product:  C[(d, e)][f] = sum_i (l_i zeta~_d zeta~_e) zeta~_f,  rows = the D1 (D1 + 1) / 2 pairs d >= e (16 per tile),
 // columns f < 16, K = the points (4 per v_mfma_f64_16x16x4_f64): 4 LDS reads feed 1024 multiply-adds; entries f <= e are the
 // moments (the others are computed for nothing).  l_i itself: the quadratic form's rows dealt over the four waves (256
-// threads per 64-point block instead of 64).  Same sums in another order: agrees with the VALU form to rounding.
+// threads per 64-point block instead of 64).
 constexpr int JAC_MT = 8;   // row tiles: D1 (D1 + 1) / 2 <= 128 pairs (D <= 14)
 __device__ void bwd_mean_moments_mfma(const MMModel& md, const double* __restrict__ in_m, const double* __restrict__ head, int a, int rc,
                                       int nrc, double* __restrict__ mpart, double* sm) {
@@ -990,7 +922,7 @@ template <int NA, int NMT>   // NA = 1: D <= 14 (one mean-part sum per thread), 
 __global__ __launch_bounds__(256, NA == 1 ? POST_LB : 1) void k_mm_bwd_post(MMModel md, MMWork wk, const double* __restrict__ gpart,
                                                     const double* __restrict__ cpart, int njs, int nrb,
                                                     double* __restrict__ part, int nrc,
-                                                    const double* __restrict__ head, double* __restrict__ mpart, int jac, BwdBatch bb) {
+                                                    const double* __restrict__ head, double* __restrict__ mpart, BwdBatch bb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int pl = blockIdx.x, rc = blockIdx.y, z = blockIdx.z, D0 = md.D;
     gpart += (long)z * bb.gpart;
@@ -1000,8 +932,7 @@ __global__ __launch_bounds__(256, NA == 1 ? POST_LB : 1) void k_mm_bwd_post(MMMo
     head += (long)z * bb.head;
     const double* in_m = bb.in_m ? bb.in_m + (long)z * bb.in_m_stride : wk.in_m;
     if (pl >= wk.PL) {   // the last E workgroup columns: mean part of output pl - PL
-        if (jac && NA == 1) bwd_mean_moments(md, in_m, head, pl - wk.PL, rc, nrc, mpart, sm);
-        else bwd_mean_partial<NA>(md, in_m, head, pl - wk.PL, rc, nrc, mpart, sm);
+        bwd_mean_partial<NA>(md, in_m, head, pl - wk.PL, rc, nrc, mpart, sm);
         return;
     }
     bwd_pair_post<NMT>(md, wk, in_m, gpart, cpart, njs, nrb, part + ((long)pl * nrc + rc) * (1 + D0 + D0 * D0), nrc, pl, rc, sm);
@@ -1211,26 +1142,14 @@ __global__ __launch_bounds__(256) void k_mm_jac_fin(MMModel md, MMWork wk, const
         rev_local_step(rl.n, rl.rs, rl.E, rl.U, rl.traj, rl.Wp, rl.bp, rl.maxact, rl.loc, blockIdx.y, sm);
         return;
     }
-    const int D = md.D, E = md.E, t = threadIdx.x, pl = blockIdx.x + pl0, z = blockIdx.y;   // pl0 = PL: the output records only (the fused finish has written the pairs')
-    const int nI = D * D, rec = 1 + D + nI, NT2 = D * (D + 1) / 2, recp = 1 + D + NT2;
+    const int D = md.D, pl = blockIdx.x + pl0, z = blockIdx.y;   // pl0 = PL: the output records only (the fused finish has written the pairs')
+    const int nI = D * D, NT2 = D * (D + 1) / 2, recp = 1 + D + NT2;
     part += (long)z * bb.part;
     mpart += (long)z * bb.part;
     head += (long)z * bb.head;
     jrec += (long)z * jstride;
-    if (pl >= wk.PL) {
-        const int a = pl - wk.PL;
-        jac_fin_output(md, head, a, nrc, mpart, jrec + (long)wk.PL * recp + (long)a * (D + NT2 + nI + D * NT2), sm);
-        return;
-    }
-    double* Pm = sm;               // [D][D]
-    double* lam = Pm + nI;         // [D + 2]: lambda | rdet
-    double* Iv = lam + D + 2;      // [rec]  summed partials (N | A | I)
-    double* PI = Iv + rec;         // [D][D] (+ [D][D] behind it)
-    const double* hd = head + (long)(E + pl) * (nI + D + 2);
-    for (int e = t; e < nI + D + 2; e += 256) (e < nI ? Pm[e] : lam[e - nI]) = hd[e];
-    for (int e = t; e < rec; e += 256) Iv[e] = sum_strided<16>(part + (long)pl * nrc * rec + e, rec, nrc);   // fixed order
-    __syncthreads();
-    jac_pair_record(D, Pm, lam, Iv, PI, jrec + (long)pl * recp);
+    const int a = pl - wk.PL;   // (launched with pl0 = PL: the output records; the pairs' come from k_mm_jac_rec)
+    jac_fin_output(md, head, a, nrc, mpart, jrec + (long)wk.PL * recp + (long)a * (D + NT2 + nI + D * NT2), sm);
 }
 
 // Fused finish of the Jacobian tape (round 6): ONE workgroup per (pair, step) adds the sweep's G blocks, contracts the column
@@ -1365,7 +1284,7 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
         njs = 0;
         nrb = small_nch;
     }
-    const int LD = D | 1, nI = D * D, D1 = D + 1, LD1 = D1 | 1, NS = mm_jac_ns(D);
+    const int nI = D * D, NS = mm_jac_ns(D);
     const int nrc = mm_bwd_rc(md.npad);
     BwdBatch bb;
     bb.gpart = (long)mm_jac_rowmom_size(md.npad, P);
@@ -1375,16 +1294,13 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
     bb.in_m = tape;
     bb.in_m_stride = (long)tape_stride;
     double* mpart = part + (size_t)P * nrc * (1 + D + nI);
-    (void)LD;
     if (small_nch > 0)
         hipLaunchKernelGGL(k_mm_bwd_head, dim3(E + P, H), dim3(256), sizeof(double) * ((size_t)4 * nI + D), st, md, wk, head, bb.head, tape + D,
                            (long)tape_stride);
-    const size_t lds_mean = (size_t)nI + 64 * LD1 + 64 + NS / 2 + 2;
     const size_t lds_fin = sizeof(double) * std::max(std::max((size_t)4 * nI + 4 * D + 8, (size_t)3 * nI + NS + D + 2 * nI * D),
                                                      rl.loc ? rev_local_lds_doubles(rl.E, rl.U) : (size_t)0);
     const long jstride = (long)mm_jac_rec_size(D, E, P);
-    static const bool split_finish = getenv("PILCO_JAC_SPLIT_FINISH") != nullptr;   // (A/B: the rounds 3-5 finish, chunk-workgroups + partials in memory)
-    if (!split_finish) {
+    {
         // the mean part's points in nrcm chunks per output and step: a workgroup's set-up and its epilogue (five tiles through
         // LDS, scattered stores) cost as much as four 64-point blocks -- 8 chunks of 2 blocks (the split finish's cut) spent
         // 22 us per workgroup at three per CU
@@ -1393,12 +1309,7 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
         hipLaunchKernelGGL(k_mm_jac_rec, dim3(P + E * nrcm, H), dim3(256), lds_rec, st, md, wk, rowmom, cpart, njs, nrb, nrcm, head, mpart, jrec,
                            jstride, bb);
         hipLaunchKernelGGL(k_mm_jac_fin, dim3(E + (rl.loc ? 1 : 0), H), dim3(256), lds_fin, st, md, wk, part, nrcm, head, mpart, jrec, jstride, bb, P, rl);
-        return;
     }
-    const size_t lds_post = sizeof(double) * std::max((size_t)2 * 256 + 4 * 256, lds_mean);
-    hipLaunchKernelGGL((k_mm_bwd_post<1, 1>), dim3(P + E, nrc, H), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc,
-                       head, mpart, 1, bb);   // (the Jacobian tape serves D <= 14)
-    hipLaunchKernelGGL(k_mm_jac_fin, dim3(P + E + (rl.loc ? 1 : 0), H), dim3(256), lds_fin, st, md, wk, part, nrc, head, mpart, jrec, jstride, bb, 0, rl);
 }
 
 // Pg: the pairs of the WHOLE model, E (E + 1) / 2 -- never the local count of a rank: the column split decides how a pair's
@@ -1429,7 +1340,7 @@ void launch_mm_bwd(hipStream_t st, const MMModel& md, const MMWork& wk, double* 
     const BwdBatch nob{0, 0, 0, 0, nullptr, 0};
 #define PPOST(NA_, M_)                                                                                                          \
     hipLaunchKernelGGL((k_mm_bwd_post<NA_, M_>), dim3(P + E, nrc), dim3(256), lds_post, st, md, wk, rowmom, cpart, njs, nrb, part, nrc, \
-                       head, mpart, 0, nob)
+                       head, mpart, nob)
     if (D <= 14) PPOST(1, 1);
     else if (nmt == 1) PPOST(5, 1);
     else if (nmt == 2) PPOST(5, 2);

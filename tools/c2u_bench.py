@@ -3,7 +3,6 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pilco_amd import synthetic
-from pilco_amd.adjoint import rollout_value_and_grad
 from pilco_amd.models import PILCO
 c = synthetic.config_c2(N=1000, D=11, E=10)
 p = PILCO((c["X"], c["Y"]), horizon=40)
@@ -16,4 +15,4 @@ def med(fn, n=15):
     for _ in range(n):
         t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
     return float(np.median(ts))
-print("C2u forward %.3f ms   value+gradient %.3f ms" % (med(p.compute_reward), med(lambda: rollout_value_and_grad(p), 7)))
+print("C2u forward %.3f ms   value+gradient %.3f ms" % (med(p.compute_reward), med(lambda: p.value_and_gradient(), 7)))

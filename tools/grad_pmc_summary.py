@@ -17,7 +17,7 @@ for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
         a = acc[k][r["Counter_Name"]]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
-kern = {k: {c: v[1] / v[0] for c, v in cs.items()} for k, cs in acc.items() if "bwd" in k or "jac" in k or "prep" in k}
+kern = {k: {c: v[1] / v[0] for c, v in cs.items()} for k, cs in acc.items() if "bwd" in k or "jac" in k or "prep" in k or "rev_" in k}
 out = {"command": "python tools/c2u_bench.py (rocprofv3 --kernel-trace --pmc <one counter group per pass>; tools/profile_grad.sh)",
        "note": "per-launch averages; GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_* over the 1024 SIMDs; FETCH_SIZE / WRITE_SIZE in KiB "
                "(corrected HBM traffic = 2*FETCH_SIZE + WRITE_SIZE, see the forward summary)",

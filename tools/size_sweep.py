@@ -5,7 +5,6 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pilco_amd import synthetic
 from pilco_amd.models import PILCO
-from pilco_amd.adjoint import rollout_value_and_grad
 
 def med(fn, n):
     fn(); ts = []
@@ -22,6 +21,6 @@ for N in [int(a) for a in sys.argv[1:]] or [250, 500, 1000, 2000, 3000]:
     p.controller.W.assign(c["W"]); p.controller.b.assign(c["b"]); p.controller.max_action = 1.0
     p.m_init, p.S_init = c["m0"], c["S0"]
     f = med(p.compute_reward, 7)
-    g = med(lambda: rollout_value_and_grad(p), 5)
+    g = med(lambda: p.value_and_gradient(), 5)
     exps = 40 * (55 * N * N + 10 * N)
     print("%6d %12.3f %12.1f %12.3f %10.2f %14.1f" % (N, f, 1e3 / f, g, g / f, exps / (f * 1e-3) / 1e9), flush=True)

@@ -4,7 +4,6 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pilco_amd.controllers import RbfController
 from pilco_amd.models import PILCO
-from pilco_amd.adjoint import rollout_value_and_grad
 N = int(os.environ.get("N", 225))
 rs = np.random.RandomState(0)
 X = rs.randn(N, 5) * np.array([0.3, 0.1, 0.5, 0.8, 2.0])
@@ -19,4 +18,4 @@ def med(fn, n=15):
     for _ in range(n):
         t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
     return float(np.median(ts))
-print("N=%d: forward rollout %.3f ms, value+gradient %.3f ms" % (N, med(lambda: p.compute_reward()), med(lambda: rollout_value_and_grad(p))))
+print("N=%d: forward rollout %.3f ms, value+gradient %.3f ms" % (N, med(lambda: p.compute_reward()), med(lambda: p.value_and_gradient())))

@@ -5,7 +5,6 @@ sys.path.insert(0, os.environ.get("PILCO_AB_ROOT") or os.path.dirname(os.path.di
 from pilco_amd import _lib
 from pilco_amd.controllers import RbfController, LinearController
 from pilco_amd.models import PILCO
-from pilco_amd.adjoint import rollout_value_and_grad
 rs = np.random.RandomState(0)
 X = rs.randn(225, 5) * np.array([0.3, 0.1, 0.5, 0.8, 2.0])
 Y = 0.05 * np.stack([np.sin(X @ rs.randn(5)) for _ in range(4)], 1) + 1e-3 * rs.randn(225, 4)
@@ -17,7 +16,7 @@ for name, ctl in (("linear", LinearController(4, 1, max_action=3.0)), ("rbf", Rb
     ctx = p.ctx
     ctx.use_graph(False)
     ctx.debug_timestamps(read=False)
-    for what, fn in (("forward", lambda: p.compute_reward()), ("value+gradient", lambda: rollout_value_and_grad(p))):
+    for what, fn in (("forward", lambda: p.compute_reward()), ("value+gradient", lambda: p.value_and_gradient())):
         for rep in range(3):
             fn()
             ts = ctx.debug_timestamps()

@@ -22,7 +22,6 @@ for on in (1, 0, 1, 0):
 ctx.gp_set_inducing(0, None)
 from pilco_amd.controllers import RbfController, LinearController
 from pilco_amd.models import PILCO
-from pilco_amd.adjoint import rollout_value_and_grad
 rs = np.random.RandomState(0)
 X = rs.randn(225, 5) * np.array([0.3, 0.1, 0.5, 0.8, 2.0])
 Y = 0.05 * np.stack([np.sin(X @ rs.randn(5)) for _ in range(4)], 1) + 1e-3 * rs.randn(225, 4)
@@ -33,5 +32,5 @@ for name, ctl in (("rbf", RbfController(state_dim=4, control_dim=1, num_basis_fu
         m.kernel.lengthscales.assign(np.array([0.5, 0.3, 1.0, 1.5, 3.0])); m.kernel.variance.assign(0.01); m.likelihood.variance.assign(1e-5)
     for on in (1, 0):
         p.ctx.set_small_step(on)
-        print("config-5 size, %s controller: small_step=%d forward %.3f ms, value+gradient %.3f ms" % (name, on, med(lambda: p.compute_reward()), med(lambda: rollout_value_and_grad(p))))
+        print("config-5 size, %s controller: small_step=%d forward %.3f ms, value+gradient %.3f ms" % (name, on, med(lambda: p.compute_reward()), med(lambda: p.value_and_gradient())))
     p.ctx.set_small_step(1)

@@ -4,7 +4,6 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pilco_amd import _lib, synthetic
 from pilco_amd.models import PILCO
-from pilco_amd.adjoint import rollout_value_and_grad
 ctx = _lib.Context()
 c = synthetic.config_c2()
 ctx.gp_set_data(0, c["X"], c["Y"]); ctx.gp_set_hyp(0, c["lengthscales"], c["variance"], c["noise"]); ctx.gp_factorize(0)
@@ -24,10 +23,10 @@ for i, mdl in enumerate(p.mgpr.models):
     mdl.kernel.lengthscales.assign(cu["lengthscales"][i]); mdl.kernel.variance.assign(cu["variance"][i]); mdl.likelihood.variance.assign(cu["noise"][i])
 p.controller.W.assign(cu["W"]); p.controller.b.assign(cu["b"]); p.controller.max_action = 1.0
 p.m_init, p.S_init = cu["m0"], cu["S0"]
-r0, (W0, b0) = rollout_value_and_grad(p)
+r0, (W0, b0) = p.value_and_gradient()
 badg = 0
 for i in range(60):
-    r, (W, b) = rollout_value_and_grad(p)
+    r, (W, b) = p.value_and_gradient()
     if r != r0 or not np.array_equal(W, W0) or not np.array_equal(b, b0):
         badg += 1
 print("C2u value+gradient: 60 repeats, %d differ from the first" % badg)
