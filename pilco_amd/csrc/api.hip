@@ -877,7 +877,7 @@ int pilco_debug_buffer(pilco_ctx* ctx, int slot, int which, double* out, long n)
 }
 
 int pilco_debug_blocks(pilco_ctx* ctx, unsigned long long* out, int n) {
-    if (!ctx || !ctx->dbg || !out || n <= 0 || n > 4032) return PILCO_E_SHAPE;
+    if (!ctx || !ctx->dbg || !out || n <= 0 || n > PILCO_DBG_WORDS - 64) return PILCO_E_SHAPE;
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipMemcpy(out, ctx->dbg + 64, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PILCO_OK;
@@ -887,7 +887,7 @@ int pilco_debug_timestamps(pilco_ctx* ctx, unsigned long long* out32) {  // 64 s
     if (!ctx) return PILCO_E_SHAPE;
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->dbg) {
-        HIPCHK(hipMalloc(&ctx->dbg, 4096 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&ctx->dbg, PILCO_DBG_WORDS * sizeof(unsigned long long)));
         HIPCHK(hipMemset(ctx->dbg, 0, 32 * sizeof(unsigned long long)));
         HIPCHK(hipMemset(ctx->dbg + 5, 0xff, sizeof(unsigned long long)));
         HIPCHK(hipMemset(ctx->dbg + 22, 0xff, sizeof(unsigned long long)));

@@ -102,6 +102,7 @@ struct PeerXch {
     std::shared_ptr<std::vector<struct pilco_ctx*>> members;
 };
 
+constexpr int PILCO_DBG_WORDS = 16384;   // 64 phase slots | block / wave stamps (tools/)
 struct pilco_ctx {
     int device = 0;
     hipStream_t st = nullptr;
@@ -129,7 +130,7 @@ struct pilco_ctx {
     int jwait_t0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, jwait_n = 0, jwait_next = 0, jwait_from = 0;   // first step of chunk k; steps >= jwait_from are on the host
     DevBuf selftest;
     DevBuf exp_tab;  // 2^(j/n), j = 0..n-1, n = mm_exp_table_size()
-    unsigned long long* dbg = nullptr;
+    unsigned long long* dbg = nullptr;   // [PILCO_DBG_WORDS] developer stamps (pilco_debug_timestamps allocates it)
     // cached hipGraph of one rollout (single-rank): replayed while the plan key is unchanged
     hipGraphExec_t graph = nullptr;
     std::vector<unsigned long long> graph_key;

@@ -87,6 +87,15 @@ __global__ __launch_bounds__(256, (KC <= 4 && PAIR_MINW < 3) ? 3 : PAIR_MINW) vo
     int bpos = blockIdx.x;
     if ((gridDim.x & 7) == 0) bpos = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int w = __builtin_amdgcn_readfirstlane(bpos * 4 + (threadIdx.x >> 6));
+#ifdef PAIR_WAVE_TRACE   // developer build (tools/pair_trace.py): start, end and hardware id of EVERY wave
+    if (wk.dbg && lane == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        wk.dbg[4096 + w] = wall_clock64();
+        wk.dbg[4096 + 2 * 3072 + w] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     DBG_STAMP(wk, 16, w == 0 && lane == 0);
     if (wk.dbg && w == 0 && lane == 0) wk.dbg[32] = clock64();     // shader-clock counter beside the 100 MHz wall clock: tools/ derive the engine clock under this load
     const int nd_steps = wk.sk_nd * wk.sk_tdiag;
@@ -113,6 +122,9 @@ __global__ __launch_bounds__(256, (KC <= 4 && PAIR_MINW < 3) ? 3 : PAIR_MINW) vo
     if (wk.dbg && w == 0 && lane == 0) wk.dbg[33] = clock64();
     DBG_STAMP(wk, 18, w == wk.sk_waves - 1 && lane == 0);
     if (wk.dbg && lane == 0 && (w & 7) == 0) wk.dbg[1024 + (w >> 3)] = wall_clock64();  // end stamp of every 8th wave
+#ifdef PAIR_WAVE_TRACE
+    if (wk.dbg && lane == 0) wk.dbg[4096 + 3072 + w] = wall_clock64();
+#endif
 }
 
 

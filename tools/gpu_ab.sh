@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: bash tools/gpu_ab.sh <tag> <what...> -- <lib> <lib> ...   (A/B in one call; default product library = the test target)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-O=gpurun_out/r05; mkdir -p $O
+O=gpurun_out/r06; mkdir -p $O
 TAG=$1; shift
 WHAT=""
 while [ "$1" != "--" ] && [ -n "$1" ]; do WHAT="$WHAT $1"; shift; done

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: bash tools/gpu_quick.sh <tag> <what...> -- <lib> <lib> ...   (A/B without the test suite, then the head's phases of the last library)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-O=gpurun_out/r05; mkdir -p $O
+O=gpurun_out/r06; mkdir -p $O
 TAG=$1; shift
 WHAT=""
 while [ "$1" != "--" ] && [ -n "$1" ]; do WHAT="$WHAT $1"; shift; done
