@@ -924,7 +924,7 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     ENSURE(s.iAt, E * mm);
     ENSURE(s.G, (size_t)E * Np);
     ENSURE(s.beta, (size_t)o.W * o.ELcap * Mp);
-    ENSURE(s.Tscr, (size_t)E * Mp * Mp);
+    ENSURE(s.Tscr, (size_t)E * Mp * std::max((size_t)Mp, (size_t)(Np + 63) / 64));   // trtri scratch | the right-hand side's per-block partials
     ENSURE(s.vec, (size_t)E * std::max(Mp, Np) * 2);
     DevBuf& Vb = s.V2;
     ENSURE(Vb, E * mn);
@@ -969,7 +969,9 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     g.C = Vb.p; g.ldc = Np; g.sC = (long)mn;
     g.M = Mp; g.N = Np; g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.k_mode = 3;
     launch_gemm(st, g, false, false, E);
-    launch_fitc_scale(st, Vb.p, Mp, Np, E, o.var, o.noise, s.G.p);          // smgpr.py:31-33
+    double* r0 = s.vec.p;
+    double* r1 = s.vec.p + (size_t)E * Mp;
+    launch_fitc_scale_rhs(st, Vb.p, Mp, Np, E, o.var, o.noise, s.G.p, o.Yt, s.Tscr.p, r0);   // smgpr.py:31-33, and r0 = Vb (y / G) (smgpr.py:40) in the same pass
     // Am = chol(V V^T + sn2 I)  (smgpr.py:34-35)
     g = GemmDesc{};
     g.A = Vb.p; g.lda = Np; g.sA = (long)mn;
@@ -990,9 +992,6 @@ int pilco_factorize_fitc(pilco_ctx* ctx, void* slot_ptr) {
     g.M = Mp; g.N = Mp; g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.k_mode = 4;
     launch_gemm(st, g, false, false, E);
     // beta = L^{-T} Am^{-T} Am^{-1} (V/G) y  (smgpr.py:38-42)
-    double* r0 = s.vec.p;
-    double* r1 = s.vec.p + (size_t)E * Mp;
-    launch_fitc_rhs(st, Vb.p, s.G.p, o.Yt, Mp, Np, E, r0);
     launch_matvec(st, s.AmInv.p, Mp, E, r0, r1, false);
     launch_matvec(st, s.AmInv.p, Mp, E, r1, r0, true);
     launch_matvec(st, s.Linv.p, Mp, E, r0, beta_own, true);

@@ -1158,7 +1158,10 @@ __global__ __launch_bounds__(256) void k_mm_jac_fin(MMModel md, MMWork wk, const
 // outputs only).  Rounds 3-5 cut a pair into nrc chunk-workgroups (k_mm_bwd_post), wrote their N | A | I to memory and ran
 // a third launch per chunk of steps (k_mm_jac_fin) over them: 20 800 + 2 600 latency-bound workgroups per rollout at C2u,
 // 0.58 ms behind the chain; one pass over the sweep's 7.2 MB per step is what the work needs.
-__global__ __launch_bounds__(256, 2) void k_mm_jac_rec(MMModel md, MMWork wk, const double* __restrict__ gpart, const double* __restrict__ cpart,
+#ifndef JAC_REC_LB
+#define JAC_REC_LB 2
+#endif
+__global__ __launch_bounds__(256, JAC_REC_LB) void k_mm_jac_rec(MMModel md, MMWork wk, const double* __restrict__ gpart, const double* __restrict__ cpart,
                                                        int njs, int nrb, int nrc /* chunks of the MEAN part's points */, const double* __restrict__ head, double* __restrict__ mpart,
                                                        double* __restrict__ jrec, long jstride, BwdBatch bb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];

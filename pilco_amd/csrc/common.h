@@ -160,11 +160,11 @@ void launch_clear_padding(hipStream_t st, double* A, int npad, int n, int batch)
 void launch_transpose_points(hipStream_t st, const double* X, int n, int D, double* Xt, int ld, int batch = 1, long sX = 0, long sXt = 0);
 // FITC helpers (smgpr.py:30-43)
 // G[b][n] = sqrt(1 + (var[b] - sum_m V[b][m][n]^2) / noise[b]);  V[b][m][n] /= G[b][n]
-void launch_fitc_scale(hipStream_t st, double* V, int mpad, int npad, int batch, const double* var, const double* noise, double* G);
+void launch_fitc_scale_rhs(hipStream_t st, double* V, int mpad, int npad, int batch, const double* var, const double* noise, double* G,
+                           const double* y, double* scratch /* [batch][ceil(npad / 64)][mpad] */, double* r /* [batch][mpad] = Vb (y / G) */);
 // A[b][i][i] += d[b]
 void launch_add_diag(hipStream_t st, double* A, int npad, int batch, const double* d);
 // r[b][m] = sum_n V[b][m][n] / G[b][n] * y[b][n]
-void launch_fitc_rhs(hipStream_t st, const double* V, const double* G, const double* y, int mpad, int npad, int batch, double* r);
 
 // GP training: per output sum_i log L_ii, and the D+2 weighted sums
 //   g[d] = 1/2 sum_ij W_ij K_ij (x_id - x_jd)^2 / l_d^3,  g[D] = 1/2 sum_ij W_ij K_ij / var,  g[D+1] = 1/2 tr W,

@@ -380,7 +380,7 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     ENSURE(s.ksplit_ws, (size_t)FITC_KSPLIT * E * mm);
     ENSURE(s.iK, E * mm);       // DKuu
     ENSURE(s.G, (size_t)E * Np);
-    ENSURE(s.Tscr, std::max(E * mm, (size_t)E * Mp * (2 * FT_MAXD + 1) * (FT_NSPLIT + 1)));
+    ENSURE(s.Tscr, std::max(std::max(E * mm, (size_t)E * Mp * ((size_t)(Np + 63) / 64)), (size_t)E * Mp * (2 * FT_MAXD + 1) * (FT_NSPLIT + 1)));
     ENSURE(s.ft_P, E * mn);
     ENSURE(s.ft_T3, E * mn);
     ENSURE(s.ft_Z, (size_t)E * D * Mp + (size_t)E * M * D);
@@ -425,7 +425,7 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     g.C = V; g.ldc = Np; g.sC = (long)mn;
     g.M = Mp; g.N = Np; g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.k_mode = 3;
     launch_gemm(st, g, false, false, E);
-    launch_fitc_scale(st, V, Mp, Np, E, o_var, o_noise, s.G.p);     // G = sqrt(nu) / sn, V <- Vb = V / G
+    launch_fitc_scale_rhs(st, V, Mp, Np, E, o_var, o_noise, s.G.p, o_Yt, s.Tscr.p, r0);   // G = sqrt(nu) / sn, V <- Vb = V / G, r0 = Vb (y / G)
     g = GemmDesc{};                                          // Am = Vb Vb^T + sn2 I = sn2 B
     g.A = V; g.lda = Np; g.sA = (long)mn;
     g.B = V; g.ldb = Np; g.sB = (long)mn;
@@ -443,7 +443,6 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     g.C = s.iAt.p; g.ldc = Mp; g.sC = (long)mm;
     g.M = Mp; g.N = Mp; g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.k_mode = 4;
     launch_gemm(st, g, false, false, E);
-    launch_fitc_rhs(st, V, s.G.p, o_Yt, Mp, Np, E, r0);
     launch_matvec(st, s.AmInv.p, Mp, E, r0, gam, false);
     launch_logdet(st, s.Am.p, Mp, M, E, sums + 3 * E);
     if (want_grad) {

@@ -590,29 +590,62 @@ void launch_trtri(hipStream_t st, const double* L, int npad, int batch, double* 
 // ------------------------------------------------------------------ FITC helpers
 // 64 columns per workgroup, the rows dealt over its four waves (round 2: one thread per column walking all M rows twice,
 // 200 workgroups on the chip: 134 us at M = 200, N = 5000)
-__global__ __launch_bounds__(256) void k_fitc_scale(double* __restrict__ V, int mpad, int npad, const double* __restrict__ var,
-                                                    const double* __restrict__ noise, double* __restrict__ G) {
+// G = sqrt(nu) / sn per column, V <- Vb = V / G (smgpr.py:31-33) and, in the same pass over V, the right-hand side
+// r = Vb (y / G) (smgpr.py:40): the scaled element is in a register, its product with y_n / G_n is summed over the block's 64
+// columns by the wave and left as a partial per (column block, row); k_fitc_rhs_sum adds the blocks in their order.  (As a
+// kernel of its own the sum was a second pass over V: 40 us of a 1.4 ms FITC objective at M = 200, N = 5000.)
+__global__ __launch_bounds__(256) void k_fitc_scale_rhs(double* __restrict__ V, int mpad, int npad, const double* __restrict__ var,
+                                                        const double* __restrict__ noise, double* __restrict__ G,
+                                                        const double* __restrict__ y, double* __restrict__ rpart) {
     __shared__ double red[4][64];
     const int b = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
+    const bool in = n < npad;
     double* Vb = V + (long)b * mpad * npad;
     double ss = 0.0;
-    if (n < npad)
+    if (in)
         for (int m = q; m < mpad; m += 4) {
             const double v = Vb[(long)m * npad + n];
             ss = fma(v, v, ss);
         }
     red[q][lane] = ss;
     __syncthreads();
-    if (n >= npad) return;
     ss = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     const double g = sqrt(1.0 + (var[b] - ss) / noise[b]);   // smgpr.py:31-32
-    if (q == 0) G[(long)b * npad + n] = g;
+    if (q == 0 && in) G[(long)b * npad + n] = g;
     const double ig = 1.0 / g;
-    for (int m = q; m < mpad; m += 4) Vb[(long)m * npad + n] *= ig;  // smgpr.py:33
+    const double yg = in ? y[(long)b * npad + n] * ig : 0.0;
+    double* rp = rpart + ((long)b * gridDim.x + blockIdx.x) * mpad;
+    for (int m = q; m < mpad; m += 4) {
+        double p = 0.0;
+        if (in) {
+            const double vb = Vb[(long)m * npad + n] * ig;   // smgpr.py:33
+            Vb[(long)m * npad + n] = vb;
+            p = vb * yg;
+        }
+        for (int off = 32; off > 0; off >>= 1) p += __shfl_down(p, off);
+        if (lane == 0) rp[m] = p;
+    }
 }
-void launch_fitc_scale(hipStream_t st, double* V, int mpad, int npad, int batch, const double* var, const double* noise, double* G) {
-    hipLaunchKernelGGL(k_fitc_scale, dim3((npad + 63) / 64, batch), dim3(256), 0, st, V, mpad, npad, var, noise, G);
+__global__ __launch_bounds__(256) void k_fitc_rhs_sum(const double* __restrict__ rpart, int nblk, int mpad, double* __restrict__ r) {
+    const int b = blockIdx.y, m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= mpad) return;
+    const double* rp = rpart + (long)b * nblk * mpad + m;
+    double s = 0.0;
+    for (int k0 = 0; k0 < nblk; k0 += 8) {   // (eight requests in flight; fixed order)
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = rp[(long)min(k0 + u, nblk - 1) * mpad];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (k0 + u < nblk) ? v[u] : 0.0;
+    }
+    r[(long)b * mpad + m] = s;
+}
+void launch_fitc_scale_rhs(hipStream_t st, double* V, int mpad, int npad, int batch, const double* var, const double* noise, double* G,
+                           const double* y, double* scratch /* [batch][ceil(npad / 64)][mpad] */, double* r) {
+    const int nblk = (npad + 63) / 64;
+    hipLaunchKernelGGL(k_fitc_scale_rhs, dim3(nblk, batch), dim3(256), 0, st, V, mpad, npad, var, noise, G, y, scratch);
+    hipLaunchKernelGGL(k_fitc_rhs_sum, dim3((mpad + 255) / 256, batch), dim3(256), 0, st, (const double*)scratch, nblk, mpad, r);
 }
 
 __global__ void k_add_diag(double* __restrict__ A, int npad, const double* __restrict__ d) {
@@ -622,22 +655,6 @@ __global__ void k_add_diag(double* __restrict__ A, int npad, const double* __res
 }
 void launch_add_diag(hipStream_t st, double* A, int npad, int batch, const double* d) {
     hipLaunchKernelGGL(k_add_diag, dim3((npad + 255) / 256, batch), dim3(256), 0, st, A, npad, d);
-}
-
-__global__ __launch_bounds__(256) void k_fitc_rhs(const double* __restrict__ V, const double* __restrict__ G,
-                                                  const double* __restrict__ y, int mpad, int npad, double* __restrict__ r) {
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= mpad) return;
-    const double* Vr = V + ((long)b * mpad + m) * npad;
-    double s = 0.0;
-    for (int n = lane; n < npad; n += 64) s = fma(Vr[n] / G[(long)b * npad + n], y[(long)b * npad + n], s);   // smgpr.py:40
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if (lane == 0) r[(long)b * mpad + m] = s;
-}
-void launch_fitc_rhs(hipStream_t st, const double* V, const double* G, const double* y, int mpad, int npad, int batch, double* r) {
-    hipLaunchKernelGGL(k_fitc_rhs, dim3((mpad + 3) / 4, batch), dim3(256), 0, st, V, G, y, mpad, npad, r);
 }
 
 // ------------------------------------------------------------------ GP training sums
