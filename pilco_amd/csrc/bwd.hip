@@ -711,6 +711,11 @@ __device__ void bwd_mean_final(const MMModel& md, const double* __restrict__ bar
 // column side of its 64-column blocks (rc, rc + nrc, ..), contracted on the matrix cores:
 //   Gc[d][e] = sum_j c_j [w_j | 1]_d [w_j | 1]_e,   c_j = (beta_b,j) * sum over the row blocks of cpart   (K = columns).
 //   N = G[D][D],  A_d = G[d][D] + Gc[d][D],  I_de = G[d][e] + G[e][d] + (Gc[d][e] + Gc[e][d]) / 2.      part[pl][chunk][1 + D + D*D]
+#ifdef JAC_STAMPS   // developer build: phase stamps of pair workgroup (0, step 0) of the fused finish (tools/jac_phases.py)
+#define JAC_STAMP(wk_, slot_, cond_) DBG_STAMP(wk_, slot_, cond_)
+#else
+#define JAC_STAMP(wk_, slot_, cond_) do { } while (0)
+#endif
 constexpr int BWD_RC = 8;   // chunks per pair / output (16: 12 % slower in the batched form, more workgroup prologues)
 // Batched form (Jacobian tape): blockIdx.z = horizon step; every per-step array advances by its stride and the input
 // mean comes from the step's tape record (wk.in_m holds the LAST step's by then).  Unbatched: strides 0, in_m = nullptr.
@@ -788,24 +793,38 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
 #pragma unroll
         for (int u = 0; u < 32; ++u) gq[u] = gb[(unsigned)(min(u, cntg - 1) * nrc * 256)];   // (32-bit indices: base in SGPRs, one VALU op per address)
         for (int j0 = 0; j0 < npad; j0 += 4 * 256) {   // column coefficients c_j = (sum over the row blocks of cpart) * beta_b,j
-            double cv[4];
+            // (unconditional requests from clamped addresses, see bwd_mean_moments_mfma; the first eight row blocks of all four
+            // columns and beta requested TOGETHER, behind the G blocks: with a wait per column the phase was five round trips,
+            // 13 of the workgroup's 31 us -- tools/jac_phases.py)
+            double cq[4][8], bj[4], cs[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {   // (unconditional requests from clamped addresses, see bwd_mean_moments_mfma)
-                const int j = j0 + q * 256 + t, jc = min(j, npad - 1);
-                double cs = 0.0;
-                for (int k0 = 0; k0 < nrb; k0 += 8) {
-                    double cq[8];
+            for (int q = 0; q < 4; ++q) {
+                const int jc = min(j0 + q * 256 + t, npad - 1);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) cq[u] = cp[(unsigned)(min(k0 + u, nrb - 1) * npad + jc)];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) cs += (k0 + u < nrb) ? cq[u] : 0.0;
-                }
-                const double bj = beta_b[(unsigned)jc];
-                cv[q] = (j < md.n) ? cs * (diag ? 1.0 : bj) : 0.0;
+                for (int u = 0; u < 8; ++u) cq[q][u] = cp[(unsigned)(min(u, nrb - 1) * npad + jc)];
+                bj[q] = beta_b[(unsigned)jc];
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (j0 + q * 256 + t < npad) cjl[j0 + q * 256 + t] = cv[q];
+            for (int q = 0; q < 4; ++q) {
+                cs[q] = 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cs[q] += (u < nrb) ? cq[q][u] : 0.0;
+            }
+            for (int k0 = 8; k0 < nrb; k0 += 8)   // (more than eight row blocks: N > 1024)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int jc = min(j0 + q * 256 + t, npad - 1);
+                    double c8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) c8[u] = cp[(unsigned)(min(k0 + u, nrb - 1) * npad + jc)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) cs[q] += (k0 + u < nrb) ? c8[u] : 0.0;
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + q * 256 + t;
+                if (j < npad) cjl[j] = (j < md.n) ? cs[q] * (diag ? 1.0 : bj[q]) : 0.0;
+            }
         }
         double v = 0.0;
 #pragma unroll
@@ -827,24 +846,45 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
 #pragma unroll
         for (int m2 = 0; m2 < NMT; ++m2) C[m1][m2] = d4{0.0, 0.0, 0.0, 0.0};
     if (cjl) {
+        JAC_STAMP(wk, 49, pl == 0 && blockIdx.y == 0 && t == 0);
         __syncthreads();   // (cjl complete)
+        JAC_STAMP(wk, 50, pl == 0 && blockIdx.y == 0 && t == 0);
         constexpr int UB = NMT == 1 ? 8 : 1;   // 64-column blocks whose points are requested together
-        for (int blk0 = rc; blk0 < npad / 64; blk0 += nrc * UB) {
+        // Lane (lr, lc) takes the FOUR CONSECUTIVE columns 16 w + 4 lr + r of a block for coordinate lc (the order of the
+        // contraction index is free): 32 contiguous bytes per lane, whole cache lines per quad of lanes.  With column
+        // 16 w + 4 r + lr -- 8 bytes per lane, sixteen lines a quarter used per request -- this loop was 15 of the workgroup's
+        // 31 us (tools/jac_phases.py).  No selects: a padded column's coefficient is 0 in cjl, a padded block's is zeroed here,
+        // and the operand row is one fma (scale 0 for lanes past D, offset 1 on lane D).
+        double wsc[NMT], wof[NMT];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+            const int d = 16 * m + lc;
+            wsc[m] = d < D ? wi[m] : 0.0;
+            wof[m] = d < D ? -wm[m] * wi[m] : (d == D ? 1.0 : 0.0);
+        }
+        const int nblk = npad / 64;
+        for (int blk0 = rc; blk0 < nblk; blk0 += nrc * UB) {
             double wt[UB][NMT][4], cj[UB][4];
 #pragma unroll
-            for (int ub = 0; ub < UB; ++ub)
+            for (int ub = 0; ub < UB; ++ub) {
+                const int blk = blk0 + ub * nrc, jb = min(blk, nblk - 1) * 64 + 16 * w + 4 * lr;
+                const double live = blk < nblk ? 1.0 : 0.0;
+                const double2 c01 = *reinterpret_cast<const double2*>(cjl + jb), c23 = *reinterpret_cast<const double2*>(cjl + jb + 2);
+                cj[ub][0] = c01.x * live;
+                cj[ub][1] = c01.y * live;
+                cj[ub][2] = c23.x * live;
+                cj[ub][3] = c23.y * live;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int blk = blk0 + ub * nrc, j = blk * 64 + 16 * w + 4 * r + lr, jc = min(j, npad - 1);
-                    const bool valid = blk < npad / 64 && j < md.n;
-                    cj[ub][r] = valid ? cjl[jc] : 0.0;
-#pragma unroll
-                    for (int m = 0; m < NMT; ++m) {
-                        const int d = 16 * m + lc;
-                        const double pt = md.Pt[(unsigned)(min(d, D - 1) * npad + jc)];
-                        wt[ub][m][r] = (valid && d < D) ? (pt - wm[m]) * wi[m] : ((valid && d == D) ? 1.0 : 0.0);
-                    }
+                for (int m = 0; m < NMT; ++m) {
+                    const int d = 16 * m + lc;
+                    const double2* pp = reinterpret_cast<const double2*>(md.Pt + (unsigned)(min(d, D - 1) * npad + jb));   // (npad and jb are multiples of 4: 16-byte aligned)
+                    const double2 p01 = pp[0], p23 = pp[1];
+                    wt[ub][m][0] = fma(p01.x, wsc[m], wof[m]);
+                    wt[ub][m][1] = fma(p01.y, wsc[m], wof[m]);
+                    wt[ub][m][2] = fma(p23.x, wsc[m], wof[m]);
+                    wt[ub][m][3] = fma(p23.y, wsc[m], wof[m]);
                 }
+            }
 #pragma unroll
             for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
@@ -885,6 +925,7 @@ __device__ void bwd_pair_post(const MMModel& md, const MMWork& wk, const double*
                     MFMA_KEEP_ALIVE(wt[m2][r]);
                 }
     }
+    JAC_STAMP(wk, 51, cjl && pl == 0 && blockIdx.y == 0 && t == 0);
 #pragma unroll
     for (int m1 = 0; m1 < NMT; ++m1)
 #pragma unroll
@@ -1159,7 +1200,7 @@ __global__ __launch_bounds__(256) void k_mm_jac_fin(MMModel md, MMWork wk, const
 // a third launch per chunk of steps (k_mm_jac_fin) over them: 20 800 + 2 600 latency-bound workgroups per rollout at C2u,
 // 0.58 ms behind the chain; one pass over the sweep's 7.2 MB per step is what the work needs.
 #ifndef JAC_REC_LB
-#define JAC_REC_LB 2
+#define JAC_REC_LB 3   // workgroups per CU: a workgroup is a chain of memory round trips (2: 4.92 ms per value + gradient at C2u, 3: 4.90, 4: 93 spilled registers)
 #endif
 __global__ __launch_bounds__(256, JAC_REC_LB) void k_mm_jac_rec(MMModel md, MMWork wk, const double* __restrict__ gpart, const double* __restrict__ cpart,
                                                        int njs, int nrb, int nrc /* chunks of the MEAN part's points */, const double* __restrict__ head, double* __restrict__ mpart,
@@ -1179,15 +1220,18 @@ __global__ __launch_bounds__(256, JAC_REC_LB) void k_mm_jac_rec(MMModel md, MMWo
         return;
     }
     const int pl = blockIdx.x;
+    JAC_STAMP(wk, 48, pl == 0 && z == 0 && t == 0);
     double* Iv = sm + 6 * 256;     // [rec]  behind bwd_pair_post's Gs | Gc | red
     double* Pm = Iv + rec;         // [D][D]
     double* lam = Pm + nI;         // [D + 2]
     double* PI = lam + D + 2;      // [2][D][D]
     const double* hd = head + (long)(E + pl) * (nI + D + 2);
     for (int e = t; e < nI + D + 2; e += 256) (e < nI ? Pm[e] : lam[e - nI]) = hd[e];
-    bwd_pair_post<1>(md, wk, in_m, gpart, cpart, njs, nrb, Iv, 1, pl, 0, sm, PI + 2 * nI);
+    bwd_pair_post<1>(md, wk, in_m, gpart, cpart, njs, nrb, Iv, 1, pl, 0, sm, sm + ((6 * 256 + rec + 3 * nI + D + 2 + 1) & ~1));   // cjl [npad] behind PI, 16-byte aligned
     __syncthreads();
+    JAC_STAMP(wk, 52, pl == 0 && z == 0 && t == 0);
     jac_pair_record(D, Pm, lam, Iv, PI, jrec + (long)pl * recp);
+    JAC_STAMP(wk, 53, pl == 0 && z == 0 && t == 0);
 }
 
 size_t mm_jac_rec_size(int D, int E, int P) {
@@ -1308,7 +1352,7 @@ void launch_mm_jac_finish(hipStream_t st, const MMModel& md, const MMWork& wk, i
         // LDS, scattered stores) cost as much as four 64-point blocks -- 8 chunks of 2 blocks (the split finish's cut) spent
         // 22 us per workgroup at three per CU
         const int nrcm = std::max(1, std::min(2, md.npad / 64));
-        const size_t lds_rec = sizeof(double) * std::max((size_t)6 * 256 + (1 + D + nI) + 3 * nI + D + 2 + md.npad, (size_t)256 + 64 * 17 + 64 + 4 * 256 + 8 * JAC_MT + 2);
+        const size_t lds_rec = sizeof(double) * std::max((size_t)6 * 256 + (1 + D + nI) + 3 * nI + D + 2 + 1 + md.npad, (size_t)256 + 64 * 17 + 64 + 4 * 256 + 8 * JAC_MT + 2);
         hipLaunchKernelGGL(k_mm_jac_rec, dim3(P + E * nrcm, H), dim3(256), lds_rec, st, md, wk, rowmom, cpart, njs, nrb, nrcm, head, mpart, jrec,
                            jstride, bb);
         hipLaunchKernelGGL(k_mm_jac_fin, dim3(E + (rl.loc ? 1 : 0), H), dim3(256), lds_fin, st, md, wk, part, nrcm, head, mpart, jrec, jstride, bb, P, rl);
