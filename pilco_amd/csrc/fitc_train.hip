@@ -25,25 +25,37 @@ namespace pilco {
 __global__ __launch_bounds__(256) void k_fitc_cols(const double* __restrict__ P, const double* __restrict__ gam, const double* __restrict__ G,
                                                    const double* __restrict__ y, const double* __restrict__ noise, int M, int mpad,
                                                    int N, int npad, double* __restrict__ a_out, double* __restrict__ g_out) {
-    const int b = blockIdx.y;
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= npad) return;
+    // 64 columns per workgroup, the rows dealt over its four waves (a thread per column walking all M rows: 80 workgroups on
+    // the chip and 25 round trips per thread at M = 200, N = 5000 -- 30 us)
+    __shared__ double red[2][4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane, nc = min(n, npad - 1);
+    const double* Pb = P + (long)b * mpad * npad;
+    const double* gb = gam + (long)b * mpad;
+    double tn = 0.0, cn = 0.0;
+    for (int m0 = q; m0 < M; m0 += 4 * 8) {   // eight rows requested together
+        double pv[8], gm[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = min(m0 + 4 * u, M - 1);
+            pv[u] = Pb[(long)m * npad + nc];
+            gm[u] = gb[m];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (m0 + 4 * u < M) {
+                tn = fma(pv[u], gm[u], tn);
+                cn = fma(pv[u], pv[u], cn);
+            }
+    }
+    red[0][q][lane] = tn;
+    red[1][q][lane] = cn;
+    __syncthreads();
+    if (q != 0 || n >= npad) return;
     double av = 0.0, gv = 0.0;
     if (n < N) {
-        const double* Pb = P + (long)b * mpad * npad;
-        double tn = 0.0, cn = 0.0;
-        // (8 rows requested together: a plain loop waits for one global load per row, 200 round trips per thread)
-        for (int m0 = 0; m0 < M; m0 += 8) {
-            double pv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) pv[u] = Pb[(long)min(m0 + u, M - 1) * npad + n];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (m0 + u < M) {
-                    tn = fma(pv[u], gam[(long)b * mpad + m0 + u], tn);
-                    cn = fma(pv[u], pv[u], cn);
-                }
-        }
+        tn = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        cn = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
         const double sn2 = noise[b], sn = sqrt(sn2), Gn = G[(long)b * npad + n];
         tn /= sn;                                          // gam holds gamma * sn (= Am^-1 r0)
         const double il = 1.0 / (sn * Gn);                 // diag(nu)^-1/2
@@ -61,8 +73,21 @@ __global__ __launch_bounds__(256) void k_fitc_c(const double* __restrict__ Ap, c
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= mpad) return;
     const double* row = Ap + ((long)b * mpad + m) * npad;
+    const double* Gb = G + (long)b * npad;
+    const double* ab = a + (long)b * npad;
     double s = 0.0;
-    for (int n = lane; n < N; n += 64) s = fma(row[n] * G[(long)b * npad + n], a[(long)b * npad + n], s);
+    for (int n0 = lane; n0 < N; n0 += 64 * 8) {   // eight requests per array in flight (one at a time: a latency chain of N / 64 round trips)
+        double rv[8], gv[8], av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int n = min(n0 + 64 * u, npad - 1);   // (clamped: the padding is there to be read; its terms are masked below)
+            rv[u] = row[n];
+            gv[u] = Gb[n];
+            av[u] = ab[n];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = fma((n0 + 64 * u < N) ? rv[u] * gv[u] : 0.0, av[u], s);
+    }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if (lane == 0) c[(long)b * mpad + m] = s;
 }
@@ -294,12 +319,13 @@ static void launch_fitc_kgrad_mfma(int D, dim3 grid, hipStream_t st, Args... arg
 }
 
 // sums for the value: out[b] = (sum (y/G)^2, sum log G, sum g)
-__global__ __launch_bounds__(256) void k_fitc_sums(const double* __restrict__ y, const double* __restrict__ G, const double* __restrict__ g, int N,
-                                                   int npad, double* __restrict__ out) {
-    __shared__ double red[4][3];
+__global__ __launch_bounds__(1024) void k_fitc_sums(const double* __restrict__ y, const double* __restrict__ G, const double* __restrict__ g, int N,
+                                                    int npad, double* __restrict__ out) {
+    // (one workgroup per output: 1024 threads -- with 256 a thread's 20 dependent iterations of a division and a log were 16 us)
+    __shared__ double red[16][3];
     const int b = blockIdx.x, t = threadIdx.x;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int n = t; n < N; n += 256) {
+    for (int n = t; n < N; n += 1024) {
         const double Gn = G[(long)b * npad + n], yy = y[(long)b * npad + n] / Gn;
         s0 = fma(yy, yy, s0);
         s1 += log(Gn);
@@ -312,7 +338,11 @@ __global__ __launch_bounds__(256) void k_fitc_sums(const double* __restrict__ y,
     }
     if ((t & 63) == 0) { red[t >> 6][0] = s0; red[t >> 6][1] = s1; red[t >> 6][2] = s2; }
     __syncthreads();
-    if (t < 3) out[b * 3 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if (t < 3) {
+        double v = 0.0;
+        for (int w = 0; w < 16; ++w) v += red[w][t];   // fixed order
+        out[b * 3 + t] = v;
+    }
 }
 
 // The two reductions' per-row sums folded into what the caller gets (one workgroup per output, fixed orders):
@@ -338,10 +368,23 @@ __global__ __launch_bounds__(256) void k_fitc_kgrad_fin(const double* __restrict
     for (int s0 = 0; s0 <= D; s0 += 16) {
         const int sl = s0 + (t >> 4), gi = t & 15, slot = D + min(sl, D);
         double acc = 0.0;
-        for (int m = gi; m < M; m += 16) {
-            double a = 0.0;
-            for (int q = 0; q < nsp; ++q) a += uf[(((long)q * E + e) * mpad + m) * PW + slot];
-            acc += a + u1[(long)m * PW + slot];
+        for (int m0 = gi; m0 < M; m0 += 16 * 4) {   // four rows' (slices + 1) requests together; the sums in the order of the plain loop
+            double v[4][FT_NSPLIT + 1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = min(m0 + 16 * k, M - 1);
+#pragma unroll
+                for (int q = 0; q < FT_NSPLIT; ++q) v[k][q] = uf[(((long)min(q, nsp - 1) * E + e) * mpad + m) * PW + slot];
+                v[k][FT_NSPLIT] = u1[(long)m * PW + slot];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (m0 + 16 * k < M) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int q = 0; q < FT_NSPLIT; ++q) a += (q < nsp) ? v[k][q] : 0.0;
+                    acc += a + v[k][FT_NSPLIT];
+                }
         }
         for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 16);
         if (gi == 0 && sl <= D) o[sl] = (sl < D) ? -acc : -(sg + acc);
@@ -452,7 +495,7 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
         g.C = s.ft_P.p; g.ldc = Np; g.sC = (long)mn;
         g.M = Mp; g.N = Np; g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.k_mode = 3;
         launch_gemm(st, g, false, false, E);
-        hipLaunchKernelGGL(k_fitc_cols, dim3((Np + 255) / 256, E), dim3(256), 0, st, s.ft_P.p, gam, s.G.p, o_Yt, o_noise, M, Mp, N, Np, av, gv);
+        hipLaunchKernelGGL(k_fitc_cols, dim3((Np + 63) / 64, E), dim3(256), 0, st, s.ft_P.p, gam, s.G.p, o_Yt, o_noise, M, Mp, N, Np, av, gv);
         g = GemmDesc{};                                      // A' = Luu^-T Vb   (A = Kuu^-1 Kuf = A' o G)
         g.A = s.Linv.p; g.lda = Mp; g.sA = (long)mm;
         g.B = V; g.ldb = Np; g.sB = (long)mn;
@@ -489,7 +532,7 @@ static int fitc_nlml_batch(pilco_ctx* ctx, Slot& s, int E, const double* o_ls, c
     } else {
         HIPCHK(hipMemsetAsync(gv, 0, sizeof(double) * (size_t)E * Np, st));
     }
-    hipLaunchKernelGGL(k_fitc_sums, dim3(E), dim3(256), 0, st, o_Yt, s.G.p, gv, N, Np, sums);
+    hipLaunchKernelGGL(k_fitc_sums, dim3(E), dim3(1024), 0, st, o_Yt, s.G.p, gv, N, Np, sums);
     if (want_grad)
         hipLaunchKernelGGL(k_fitc_kgrad_fin, dim3(E, 8), dim3(256), 0, st, (const double*)part_uf, nsp, (const double*)part_uu, (const double*)sums,
                            (const double*)gam, E, M, Mp, D, res);

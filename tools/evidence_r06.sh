@@ -26,3 +26,5 @@ AB_TAG="device chain" python tools/grad_ab.py cmp /tmp/g_host.npz >> gpurun_out/
 AB_TAG="VALU kernel-derivative reductions" PILCO_FITC_KGRAD_VALU=1 python tools/fitc_obj_bench.py save /tmp/f.npz > gpurun_out/fitc_ab.log 2>&1
 AB_TAG="MFMA kernel-derivative reductions" python tools/fitc_obj_bench.py cmp /tmp/f.npz >> gpurun_out/fitc_ab.log 2>&1; cat gpurun_out/fitc_ab.log
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-value -Wno-uninitialized tools/ubench_srcc_war.hip -o /tmp/srcc 2>/dev/null && /tmp/srcc > gpurun_out/ubench_valu_mfma.txt; cat gpurun_out/ubench_valu_mfma.txt
+python tools/pair_clock.py > gpurun_out/pair_clock.log 2>&1; cat gpurun_out/pair_clock.log
+[ -f exp/lib_jacstamps.so ] && PILCO_LIB=exp/lib_jacstamps.so python tools/jac_phases.py > gpurun_out/jac_phases.log 2>&1; cat gpurun_out/jac_phases.log   # (make -C pilco_amd/csrc BUILD=build_js OUT=exp/lib_jacstamps.so EXTRA=-DJAC_STAMPS)
