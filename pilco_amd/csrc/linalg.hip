@@ -773,15 +773,13 @@ __global__ __launch_bounds__(256) void k_nlml_grad_reduce(const double* __restri
             return (long)ti * nt + (q - ti * (ti + 1) / 2);
         };
         const double* base = partial + (long)b * nt * nt * (NLML_MAXD + 2) + lane;
-        int q = w;
-        for (; q + 28 < ntri; q += 32) {
-            double v[8];
+        for (int q = w; q < ntri; q += 32) {   // (the last, partial batch too: clamped requests, masked sums -- one at a time its
+            double v[8];                       // up to seven tiles were seven round trips, 14 of the kernel's 20 us)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = base[tile_of(q + 4 * u) * (NLML_MAXD + 2)];
+            for (int u = 0; u < 8; ++u) v[u] = base[tile_of(min(q + 4 * u, ntri - 1)) * (NLML_MAXD + 2)];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s8[u] += v[u];
+            for (int u = 0; u < 8; ++u) s8[u] += (q + 4 * u < ntri) ? v[u] : 0.0;
         }
-        for (; q < ntri; q += 4) s9 += base[tile_of(q) * (NLML_MAXD + 2)];
     }
     red[w][lane] = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) + s9;
     __syncthreads();
