@@ -957,6 +957,9 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
                 L.su[e] = acc;
             }
             __syncthreads();
+#ifdef LINK_STAMPS
+            DBG_STAMP(g.wk, 36, dbg0);
+#endif
             if (g.squash) {
                 double* cdiag = L.misc + 1;  // [U]
                 squash_inplace(L, U, g.maxact ? L.misc + 160 : nullptr, cdiag);
@@ -967,6 +970,9 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
                     jcd = cdiag;
                 }
             }
+#ifdef LINK_STAMPS
+            DBG_STAMP(g.wk, 37, dbg0);
+#endif
         }
         if (g.act_out) {
             if (writer) {

@@ -24,6 +24,8 @@ for rep in range(4):
         us(4, 16), us(16, 17), us(8, 9), us(9, 10), us(10, 12), us(8, 12)))
 print("inside the Gauss-Jordan phase of pair block (0,0): build %.2f | gj_wave %.2f | Q store + barrier %.2f ; first staging wave done %.2f after the phase began" % (
     us(1, 5), us(5, 6), us(6, 2), us(1, 7)))
+if ts[36] and ts[37]:   # (a -DLINK_STAMPS build only)
+    print("inside the joint phase (linear controller): moments M, S, V %.2f | squash %.2f | joint Gaussian + stores %.2f" % ((ts[36] - ts[60]) / 100.0, us(36, 37), (ts[61] - ts[37]) / 100.0))
 if ts[34] and ts[35]:   # (a -DHEAD_ROW_STAMPS build only)
     print("inside the rows phase of pair block (0,0), thread 0: point and x = zeta / l^2 %.2f | y = Q x and the quadratic form %.2f | stores issued %.2f" % (us(2, 34), us(34, 35), us(35, 3)))
 if ts[17] > ts[16]:
