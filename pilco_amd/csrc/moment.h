@@ -247,7 +247,7 @@ struct RevArgs {
     const double* seeds;    // [H + 1][E + E*E] cotangent seeds of the caller's objective, or nullptr
     const double* Wp;       // LinearController W (U,E)
     const double* reward_dev;   // the rollout's reward on the device: handed out with the gradient (out[..]) instead of a copy of its own in front of the finish
-    double* amat;           // [H][rev_mat_doubles]: every step's reverse map [A; B] by columns | r | flag  (k_rev_step -> k_rev_chain)
+    double* amat;           // [H][rev_mat_doubles]: every step's reverse map [A; B] by columns | r | flags  (k_rev_step -> k_rev_chain)
     double* out;            // [U*E + U + 1 + E + E(E+1)/2 + 1]: dW | db | status (0 fine) | d / d (m_0, S_0 packed) | reward   (device-visible)
 };
 bool rev_chain_supported(int E, int U, int D);

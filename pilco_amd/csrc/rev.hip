@@ -39,9 +39,10 @@ __host__ __device__ inline RevDims rev_dims(int E, int U, int D) {
     d.recp = 1 + d.NOUT; d.reco = d.NOUT + d.nI + D * d.NT2;
     return d;
 }
-size_t rev_mat_doubles(int E, int U, int D) {   // per step: [A; B] by columns | r | flag
+constexpr int REVS_SPLIT = 4;   // workgroups per step of k_rev_step (column ranges of [A; B]); a flag each
+size_t rev_mat_doubles(int E, int U, int D) {   // per step: [A; B] by columns | r | flags
     const RevDims d = rev_dims(E, U, D);
-    return (size_t)d.NX * d.NR + d.NX + 1;
+    return (size_t)d.NX * d.NR + d.NX + REVS_SPLIT;
 }
 __device__ __forceinline__ int rev_tri(int r, int c) { return r <= c ? c * (c + 1) / 2 + r : r * (r + 1) / 2 + c; }   // packed symmetric index
 // pair index of (r, c) in the dealing order (diagonal first)
@@ -62,10 +63,13 @@ __host__ __device__ inline size_t rev_step_lds_doubles(int E, int U, int D) {
 
 __global__ __launch_bounds__(REVS_NT) void k_rev_step(RevArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int tid = threadIdx.x, t = blockIdx.x;
+    const int tid = threadIdx.x, t = blockIdx.x, part = blockIdx.y;
     const RevDims dm = rev_dims(a.E, a.U, a.D);
     const int E = dm.E, U = dm.U, D = dm.D, P = dm.P, NX = dm.NX, NR = dm.NR, NOUT = dm.NOUT, NT2 = dm.NT2, nI = dm.nI;
     const int UU = U * U, UE = U * E, ED = E * D, SE = E + E * E, NLOC = rev_loc_size(E, U), GC = U + UU;
+    // this workgroup's columns of [A; B] = rows of M1 (REVS_SPLIT workgroups per step: one workgroup per step was 42 us -- 10 of
+    // set-up, 11 fold, 20 matrix entries -- on 40 of 256 CUs; every part stages the step's small data, folds into and reads its own rows only)
+    const int c0 = (int)((long)part * NX / REVS_SPLIT), c1 = (int)((long)(part + 1) * NX / REVS_SPLIT);
     double* M1 = sm;                    // [NX][NOUT]: row a < E: d (mbar_j | sbar_j) / d mbar_a, row E + p: d / d sbar_p
     double* s1 = M1 + (size_t)NX * NOUT;
     double* Mg = s1 + ED;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(REVS_NT) void k_rev_step(RevArgs a) {
         }
         pab[pp] = pa | (pb << 16);
     }
-    for (int i = tid; i < NX * NOUT; i += REVS_NT) {
+    for (int i = c0 * NOUT + tid; i < c1 * NOUT; i += REVS_NT) {
         const int row = i / NOUT, e = i - row * NOUT;
         double v;
         if (row < E) v = jr[a.out_off + (long)row * dm.reco + e];
@@ -143,11 +147,13 @@ __global__ __launch_bounds__(REVS_NT) void k_rev_step(RevArgs a) {
             if (on) {
                 const int b0 = pass ? ao + 1 : 0, b1 = pass ? E : ao + 1;
                 for (int b = b0; b < b1; ++b) {
+                    const int rr = E + rev_pair(E, ao, b);
+                    if (rr < c0 || rr >= c1) continue;   // (another part's row)
                     double acc = -Mg[b] * jo;
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
                         if (k < D) acc = fma(s1[b * D + k], jv[k], acc);
-                    M1[(size_t)(E + rev_pair(E, ao, b)) * NOUT + e] += 2.0 * acc;
+                    M1[(size_t)rr * NOUT + e] += 2.0 * acc;
                 }
             }
             __syncthreads();
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(REVS_NT) void k_rev_step(RevArgs a) {
         return v;
     };
     bool bad = false;
-    if (tid < NX) {
+    if (tid >= c0 && tid < c1) {
         const int col = tid;
         const double* am = M1 + (size_t)col * NOUT;
         for (int e = 0; e < NOUT; ++e)
@@ -195,8 +201,8 @@ __global__ __launch_bounds__(REVS_NT) void k_rev_step(RevArgs a) {
         if (!(fabs(rg[i]) <= 1.7e308)) bad = true;       // singular I + S W in a reward term
     const int anybad = __syncthreads_or(bad ? 1 : 0);
     // ---- 3: the entries of [A; B], column by column (stored by columns: the chain's lanes run along the rows)
-    double* AT = a.amat + (long)t * ((long)NX * NR + NX + 1);
-    for (int i = tid; i < NX * NR; i += REVS_NT) {
+    double* AT = a.amat + (long)t * ((long)NX * NR + NX + REVS_SPLIT);
+    for (int i = c0 * NR + tid; i < c1 * NR; i += REVS_NT) {
         const int col = i / NR, row = i - col * NR;
         const double* am = M1 + (size_t)col * NOUT;
         const double* g = gcol + (size_t)col * GC;   // mu0bar [U] | su0bar [U][U]
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(REVS_NT) void k_rev_step(RevArgs a) {
     }
     // ---- r_t: the reward's own cotangents (rewards.py:19-81), packed like x
     double* rv = AT + (long)NX * NR;
-    for (int row = tid; row < NX; row += REVS_NT) {
+    for (int row = tid; row < (part == 0 ? NX : 0); row += REVS_NT) {
         double v;
         if (row < E) v = rg[row];
         else {
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(REVS_NT) void k_rev_step(RevArgs a) {
         }
         rv[row] = v;
     }
-    if (tid == 0) rv[NX] = anybad ? 1.0 : 0.0;
+    if (tid == 0) rv[NX + part] = anybad ? 1.0 : 0.0;
 }
 
 // ------------------------------------------------------------------ the chain: x_t = A_t x_{t+1} + r_t (+ seeds), dtheta += B_t x_{t+1}
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(REV_NT) void k_rev_chain(RevArgs a) {
     const RevDims dm = rev_dims(a.E, a.U, a.D);
     const int E = dm.E, H = a.H, NX = dm.NX, NR = dm.NR, SE = E + E * E;
     const int NCH = REV_NT / NR, nper = (NX + NCH - 1) / NCH;   // thread (chunk c_, row): columns c_ * nper ..
-    const long MS = (long)NX * NR + NX + 1;
+    const long MS = (long)NX * NR + NX + REVS_SPLIT;
     double* x = sm;                 // [NX] (+ one zero behind it: the coefficient of a slot past a thread's share)
     double* part = x + NX + 1;      // [NCH][NR]
     const int c_ = tid / NR, row = tid - c_ * NR;
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(REV_NT) void k_rev_chain(RevArgs a) {
 #pragma unroll
         for (int k = 0; k < REV_RT; ++k) rv[k] = buf_ld(mres, off[k], (unsigned)(H - 1) * ms_b);
     }
-    for (int t = tid; t < H; t += REV_NT) flag += a.amat[(long)t * MS + (long)NX * NR + NX];
+    for (int t = tid; t < H * REVS_SPLIT; t += REV_NT) flag += a.amat[(long)(t / REVS_SPLIT) * MS + (long)NX * NR + NX + t % REVS_SPLIT];
     __syncthreads();
     for (int t = H - 1; t >= 0; --t) {
         if (mv) {
@@ -357,7 +363,7 @@ void launch_rev_chain(hipStream_t st, const RevArgs& a) {
             (void)hipFuncSetAttribute((const void*)k_rev_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
             lds_set = lds_s;
         }
-        hipLaunchKernelGGL(k_rev_step, dim3(a.H), dim3(REVS_NT), lds_s, st, a);
+        hipLaunchKernelGGL(k_rev_step, dim3(a.H, REVS_SPLIT), dim3(REVS_NT), lds_s, st, a);
     }
     const RevDims d = rev_dims(a.E, a.U, a.D);
     const size_t lds = sizeof(double) * ((size_t)d.NX + 1 + (size_t)(REV_NT / d.NR) * d.NR);
