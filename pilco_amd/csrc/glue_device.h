@@ -115,7 +115,9 @@ __device__ __forceinline__ void multi_load(double* lds, const LoadSeg (&sg)[NSEG
 // The 5 U^2 + 3 U transcendental evaluations of the reference's formulas (exp(lq), exp(lq +- s), cos(m_u -+ m_v) per
 // element; exp, cos, sin per control) are independent: each goes to its own thread (one library call deep instead of a
 // chain of five on this serial path), then one combining phase.  Scratch: t1 .. js (contiguous, dead at this point).
-__device__ __forceinline__ void squash_inplace(const GlueLds& L, int U, const double* maxact, double* cdiag) {
+// eval_only (sc_alt: scratch that must outlive the call; one round, 5 (U^2 + U) slots): stop behind the evaluations' barrier and
+// leave them in sc_alt -- the caller combines them where it needs them (write_joint_lin_squash below).
+__device__ __forceinline__ void squash_inplace(const GlueLds& L, int U, const double* maxact, double* cdiag, double* sc_alt = nullptr, bool eval_only = false) {
     const int t = threadIdx.x;
     const int nm = L.nm, nm_sq = nm * nm;
     // ONE inlined copy of each library function (exp, cos, sin), whatever element a thread evaluates: the argument and
@@ -124,8 +126,8 @@ __device__ __forceinline__ void squash_inplace(const GlueLds& L, int U, const do
     // path)  The 5 U^2 + 3 U evaluations of the reference's formulas (exp(lq), exp(lq +- s),
     // cos(m_u -+ m_v) per element; exp, cos, sin per control) are independent: each goes to its own thread, in rounds when
     // the scratch (t1 .. js: 4 nm^2 + nm values) is smaller than that; then one combining phase per round.
-    double* sc = L.t1;
-    const int cap = ((4 * nm_sq + nm) / 5) * 5;      // whole items per round: an item is 5 slots (a control uses 3 of its 5)
+    double* sc = sc_alt ? sc_alt : L.t1;
+    const int cap = sc_alt ? 5 * (U * U + U) : ((4 * nm_sq + nm) / 5) * 5;      // whole items per round: an item is 5 slots (a control uses 3 of its 5)
     const int nitems = U * U + U;                    // items 0 .. U^2 - 1: covariance elements, then the U controls
     // the new covariance must not overwrite su while later rounds still read it: it is collected in registers per thread
     // (element e = t + k * blockDim of the U x U matrix; U <= 32, blockDim >= 256: k < 4) and stored after the last round
@@ -170,6 +172,7 @@ __device__ __forceinline__ void squash_inplace(const GlueLds& L, int U, const do
             }
         }
         __syncthreads();
+        if (eval_only) return;   // (uniform)
         const int q0 = i0 / 5, q1 = (i0 + n) / 5;    // items [q0, q1) are complete in this round
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -250,6 +253,60 @@ __device__ __forceinline__ void write_joint(const GlueArgs& g, const GlueLds& L,
         }
     }
     if (writer && g.tape && t < D) g.tape[(long)g.step * (D + D * D + E * D + E + E * E + D * E) + t] = (t < E) ? L.mx[t] : L.mu[t - E];
+    __syncthreads();
+}
+
+// LinearController + squash_sin, U small: the joint Gaussian straight from the squash's EVALUATIONS (sq: squash_inplace's slots,
+// item (u, v): exp(lq) exp(lq + s) exp(lq - s) cos(m_u - m_v) cos(m_u + m_v); control u: exp(-s_uu / 2) cos m_u sin m_u) and the
+// controller's W s_x (L.t1): every thread combines what its own entry needs --
+//   mean E + u:  e_u exp(-s_uu/2) sin m_u;   S_uv = e_u e_v ((E+ - E0) cos(m_u - m_v) - (E- - E0) cos(m_u + m_v)) / 2;
+//   s_x c_xu C = (W s_x)^T C   (c_xu = W^T: no second E x E x U product),  C_u = e_u exp(-s_uu/2) cos m_u
+// -- instead of squash_inplace's combining phase + write_joint's product phase: two barrier intervals and two LDS round trips
+// less on the step's serial path (1 us of the link's 4 us joint phase at C2u).  Stores: as write_joint.
+__device__ __forceinline__ void write_joint_lin_squash(const GlueArgs& g, const GlueLds& L, bool writer, const double* sq, const double* maxact) {
+    const int E = g.E, U = g.U, D = g.D, t = threadIdx.x;
+    double* s1_dst = g.s1_out ? g.s1_out : g.s1;
+    auto cdiag_of = [&](int u) { const double* r = sq + 5 * (U * U + u); return (maxact ? maxact[u] : 1.0) * r[0] * r[1]; };
+    if (t < D) {
+        double v;
+        if (t < E) v = L.mx[t];
+        else {
+            const int u = t - E;
+            const double* r = sq + 5 * (U * U + u);
+            v = (maxact ? maxact[u] : 1.0) * r[0] * r[2];
+        }
+        L.jm[t] = v;
+        if (L.xm) L.xm[t] = v;
+        if (writer) {
+            g.wk.in_m[t] = v;
+            if (g.tape) g.tape[(long)g.step * (D + D * D + E * D + E + E * E + D * E) + t] = v;
+        }
+    }
+    for (int e = t; e < D * D; e += blockDim.x) {
+        int c;
+        const int r = idiv_s(e, D, c);
+        double v;
+        if (r < E && c < E) v = L.sx[r * E + c];
+        else if (r < E) v = L.t1[(c - E) * E + r] * cdiag_of(c - E);
+        else if (c < E) v = L.t1[(r - E) * E + c] * cdiag_of(r - E);
+        else {
+            const int u = r - E, v2 = c - E;
+            const double* q = sq + 5 * (u * U + v2);
+            const double val = (q[1] - q[0]) * q[3] - (q[2] - q[0]) * q[4];
+            v = (maxact ? maxact[u] * maxact[v2] : 1.0) * val / 2.0;
+        }
+        L.js[e] = v;
+        if (L.xs) L.xs[e] = v;
+        if (writer) {
+            g.wk.in_s[e] = v;
+            if (r < E) s1_dst[r * D + c] = v;
+            if (g.tape) {
+                double* rec = g.tape + (long)g.step * (D + D * D + E * D + E + E * E + D * E);
+                rec[D + e] = v;
+                if (r < E) rec[D + D * D + r * D + c] = v;
+            }
+        }
+    }
     __syncthreads();
 }
 
@@ -903,6 +960,7 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
     }
     if (g.flags & GF_POLICY) {
         const double* jcd = nullptr;   // the squash's diagonal, when write_joint is to apply it to c_xu
+        bool lin_fused = false;        // linear controller + squash: the evaluations are in L.t2, write_joint_lin_squash combines them
         if (PK != 0 && PK != 3 && g.pol_kind == PILCO_POLICY_RBF) {
             // mean-function-only GP: iK = 0, then S -= diag(var - 1e-6)      (controllers.py:116-117)
             bool done = false;
@@ -962,7 +1020,9 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
 #endif
             if (g.squash) {
                 double* cdiag = L.misc + 1;  // [U]
-                squash_inplace(L, U, g.maxact ? L.misc + 160 : nullptr, cdiag);
+                // the joint Gaussian is what follows and the evaluations fit t2: stop behind them (write_joint_lin_squash)
+                lin_fused = !g.act_out && !joint_is_state && 5 * (U * U + U) <= L.nm * L.nm;
+                squash_inplace(L, U, g.maxact ? L.misc + 160 : nullptr, cdiag, lin_fused ? L.t2 : nullptr, lin_fused);
                 if (g.act_out) {
                     for (int e = t; e < E * U; e += blockDim.x) L.cxu[e] *= cdiag[e % U];   // V @ C, C diagonal
                     __syncthreads();
@@ -981,7 +1041,8 @@ __device__ __forceinline__ void glue_body(const GlueArgs& g, const GlueLds& L, b
                 for (int e = t; e < E * U; e += blockDim.x) g.act_out[U + U * U + e] = L.cxu[e];
             }
         } else if (!joint_is_state) {
-            write_joint(g, L, writer, jcd);
+            if (lin_fused) write_joint_lin_squash(g, L, writer, L.t2, g.maxact ? L.misc + 160 : nullptr);
+            else write_joint(g, L, writer, jcd);
         }
     }
     DBG_STAMP(g.wk, 13 + dbo, dbg0);
