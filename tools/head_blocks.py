@@ -32,6 +32,8 @@ for rep in range(4):
     spare = [(55 + i // NY, i % NY) for i in range(24)]
     print("%s D=%d link(0,0) %.1f..%.1f | pair blocks %s | mean blocks %s | reward %s" % (
         os.path.basename(_lib.LIB_PATH), D, (ts[56] - t0) / 100.0, (ts[4] - t0) / 100.0, rng([(x, y) for x in range(55) for y in range(NY)]), rng(spare[:20]), rng(spare[20:21])))
+late = sorted(((v[1] - t0) / 100.0, (v[0] - t0) / 100.0, k) for k, v in st.items() if v[1])[-6:]
+print("the last workgroups to end (x, y): " + "  ".join("(%d,%d) %.1f..%.1f" % (k[0], k[1], s0, e) for e, s0, k in late))
 ts = ctx.debug_timestamps()
 us = lambda a, b: (ts[b] - ts[a]) / 100.0
 print("mean block (0,0): [gj+stage %.2f rows %.2f wave sums %.2f block sums + store %.2f] = %.2f   (stamps 40..44)" % (us(40, 41), us(41, 42), us(42, 43), us(43, 44), us(40, 44)))
