@@ -1213,10 +1213,16 @@ int rollout_jtape(pilco_ctx* ctx, const pilco_policy* policy, const pilco_reward
                     HIPCHK(hipStreamSynchronize(ctx->st));
                     std::shared_ptr<PeerGroup> grp = ctx->group;
                     if (!grp->arrive_and_wait()) return fail(ctx, PILCO_E_STATE, "rollout_grad: another rank of the group failed");
+                    // (on THIS context's stream: a device-to-device hipMemcpy is ordered on the null stream only and need not have
+                    // finished when it returns -- the chain below, on a non-blocking stream, read blocks that were still being
+                    // copied once in ten runs; the peers may reuse their blocks after the second barrier, so the copies are
+                    // waited for in front of it)
                     for (int j = 0; j < W; ++j) {
                         pilco_ctx* pj = grp->ctxs[j];
-                        HIPCHK(hipMemcpy(ctx->jgath.p + (size_t)j * gblk, pj->jgath.p + (size_t)W * gblk, sizeof(double) * gblk, hipMemcpyDeviceToDevice));
+                        HIPCHK(hipMemcpyAsync(ctx->jgath.p + (size_t)j * gblk, pj->jgath.p + (size_t)W * gblk, sizeof(double) * gblk, hipMemcpyDeviceToDevice,
+                                              ctx->st));
                     }
+                    HIPCHK(hipStreamSynchronize(ctx->st));
                     if (!grp->arrive_and_wait()) return fail(ctx, PILCO_E_STATE, "rollout_grad: another rank of the group failed");
                 }
                 ra.jrec = ctx->jgath.p;

@@ -3,7 +3,7 @@ horizon step -- operand kernel, pair kernel, pack -- with pilco_shard_set(0, W),
 exist only to factorise their outputs and hand over their beta rows; they launch nothing in the measured loop).
 
     rocprofv3 --kernel-trace --output-format csv -d <dir>/W<W>v<variant> -o r -- python tools/rank_model.py run <W> <variant>
-    python tools/rank_model.py summarise <dir-of-W1> <dir-of-W2> ... > profiles/r05_rank_model.json
+    python tools/rank_model.py summarise <dir-of-W1> <dir-of-W2> ... > profiles/r06_rank_model.json
 
 The summary is a MODEL, not a measurement of xGMI: step(W) = [fused head of the 1-rank run] - [operand kernel(1) - operand
 kernel(W)] + pair(W) + pack(W), with a free exchange."""
