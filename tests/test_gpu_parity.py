@@ -704,11 +704,14 @@ def test_sharded_value_and_gradient_rollout(E, U, nranks):
         _lib.group_sync_model(group)
         with pytest.raises(_lib.PilcoError):          # a sharded context on its own has nobody to exchange with
             group[0].rollout_grad(pol, rw, m0, S0, H)
-        out = [_lib.rollout_grad_group(group, pol, rw, m0, S0, H) for _ in range(2)]
+        # (twelve calls: the ranks' copies of the peers' record blocks once raced with the reverse chain -- one call in ten had a
+        # rank working on half-copied blocks; round 6)
+        out = [_lib.rollout_grad_group(group, pol, rw, m0, S0, H) for _ in range(12)]
         rew, dW, db = out[0]
-        for i in range(1, nranks):
-            assert rew[i] == rew[0] and np.array_equal(dW[i], dW[0]) and np.array_equal(db[i], db[0])
-        assert all(np.array_equal(a, b) for a, b in zip(out[0], out[1]))
+        for o in out:
+            for i in range(1, nranks):
+                assert o[0][i] == o[0][0] and np.array_equal(o[1][i], o[1][0]) and np.array_equal(o[2][i], o[2][0])
+        assert all(np.array_equal(a, b) for o in out[1:] for a, b in zip(out[0], o))
         # the split of every pair's sums and of every output's mean sums is taken from the WHOLE model's counts, not from what a
         # rank holds: value and gradient are the single-rank run's, to the last bit (round 3: "to rounding")
         assert rew[0] == r1 and np.array_equal(dW[0], W1) and np.array_equal(db[0], b1)
