@@ -415,7 +415,10 @@ int pilco_debug_poison(pilco_ctx* ctx, int slot, int which) {
     DevBuf* b = which == 0 ? &s.Linv : which == 1 ? &s.iK : which == 2 ? &s.beta : nullptr;
     if (!b) return fail(ctx, PILCO_E_SHAPE, "debug_poison: which = 0 (L^-1), 1 (iK), 2 (beta)");
     HIPCHK(hipSetDevice(ctx->device));
-    if (b->p && b->cap) HIPCHK(hipMemset(b->p, 0xff, sizeof(double) * b->cap));   // all-ones words: NaN
+    if (b->p && b->cap) {
+        HIPCHK(hipMemset(b->p, 0xff, sizeof(double) * b->cap));   // all-ones words: NaN
+        HIPCHK(hipStreamSynchronize(nullptr));                    // (a device memset is ordered on the null stream only; the context's stream is non-blocking)
+    }
     return PILCO_OK;
 }
 

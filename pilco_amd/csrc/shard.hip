@@ -36,6 +36,7 @@ static int peer_alloc_local(pilco_ctx* ctx) {
     const size_t bytes = sizeof(unsigned long long) * xq_area_words(x.W, x.cap);
     HIPCHK(hipExtMallocWithFlags((void**)&x.local, bytes, hipDeviceMallocFinegrained));
     HIPCHK(hipMemset(x.local, 0, bytes));
+    HIPCHK(hipStreamSynchronize(nullptr));   // (ordered on the null stream only; the kernels that poll this area run on non-blocking streams)
     HIPCHK(hipHostMalloc((void**)&x.pin, sizeof(unsigned long long) * 256, hipHostMallocDefault));
     memset(x.pin, 0, sizeof(unsigned long long) * 256);
     x.epoch = 0;
