@@ -337,6 +337,34 @@ def test_midsize_random_vs_oracle(ctx, variant):
         ctx.set_pair_kernel(0)
 
 
+def test_few_outputs_spread_over_many_stream_k_waves(ctx):
+    """Two outputs at N = 1000: three pairs on the stream-K line, each held by more than a thousand waves -- the link's pack
+    walks hundreds of partial slots per pair (its loop past the first sixteen, eight requests at a time since round 6).
+    Against the oracle, against the tiled kernel, and bitwise against itself."""
+    c = synthetic.config_c2(N=1000, D=3, E=2, noise=1e-2, seed=5, control_dim=1)
+    try:
+        m = _mgpr(c)
+        rs = np.random.RandomState(4)
+        mm = 0.3 * rs.randn(1, 3)
+        A = 0.3 * rs.randn(3, 3)
+        ss = A @ A.T + 0.05 * np.eye(3)
+        iK, beta = tp.calculate_factorizations(c["X"], c["Y"], c["lengthscales"], c["variance"], c["noise"])
+        Mo, So, Vo = tp.predict_given_factorizations(c["X"], c["lengthscales"], c["variance"], mm, ss, iK, beta)
+        out = {}
+        for variant in (0, 2, 0):
+            ctx.set_pair_kernel(variant)
+            M, S, V = m.predict_on_noisy_inputs(mm, ss)
+            np.testing.assert_allclose(M, Mo, rtol=RTOL)
+            np.testing.assert_allclose(S, So, rtol=RTOL, atol=1e-12)
+            np.testing.assert_allclose(V, Vo, rtol=RTOL)
+            if variant in out:
+                assert all(np.array_equal(a, b) for a, b in zip(out[variant], (M, S, V)))
+            out[variant] = (M, S, V)
+        np.testing.assert_allclose(out[0][1], out[2][1], rtol=1e-10, atol=1e-14)
+    finally:
+        ctx.set_pair_kernel(0)
+
+
 def test_full_size_c2_step_and_rollout(ctx):
     """BASELINE config 2 (N=1000, D=10, E=10): one step and a 3-step rollout vs the oracle."""
     c = synthetic.config_c2()
